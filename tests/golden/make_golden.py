@@ -1,0 +1,332 @@
+"""Generate golden vectors from the REAL reference (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+Imports WagnerGroup/pyqmc from /root/reference with pyscf/h5py mocked and numba
+replaced by an identity decorator (so ``pyqmc/wf/numba/gto.py`` runs as plain IEEE
+fp64 Python), feeds it the duck-typed systems of ``pyqmc_amd.systems`` and stores
+inputs + outputs as small ``.npz`` files next to this script.  Only data is stored;
+no reference source travels.  All randomness the reference draws (proposal
+Gaussians, Metropolis uniforms, ECP mask uniforms, ECP quadrature rotations) is
+routed through recorded tapes so the oracle and the HIP path can replay it.
+"""
+
+import os
+import sys
+import types
+from unittest import mock
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _identity(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+nb = types.ModuleType("numba")
+nb.njit = nb.jit = _identity
+sys.modules["numba"] = nb
+for m in ["pyscf", "pyscf.pbc", "pyscf.pbc.gto", "pyscf.pbc.gto.eval_gto", "pyscf.pbc.gto.cell", "pyscf.mcscf",
+          "pyscf.fci", "pyscf.hci", "pyscf.gto", "pyscf.lib", "pyscf.scf", "pyscf.pbc.scf", "pyscf.pbc.scf.addons", "h5py"]:
+    sys.modules[m] = mock.MagicMock(name=m)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import scipy.spatial.transform  # noqa: E402
+import pyqmc.api as pyq  # noqa: E402
+import pyqmc.wf.numba.gto as refgto  # noqa: E402
+import pyqmc.wf.func3d as func3d  # noqa: E402
+import pyqmc.observables.eval_ecp as eval_ecp  # noqa: E402
+import pyqmc.observables.energy as refenergy  # noqa: E402
+from pyqmc.method.mc import vmc_worker  # noqa: E402
+from pyqmc.configurations.coord import OpenConfigs  # noqa: E402
+from pyqmc.wf.slater import sherman_morrison_ms  # noqa: E402
+
+from pyqmc_amd import systems  # noqa: E402
+
+
+class Tapes:
+    """Route the reference's global-RNG draws through seeded generators and record them."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.log = {"normal": [], "rand": [], "random": [], "rot": []}
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        z = self.rng.standard_normal(size)
+        self.log["normal"].append(z)
+        return loc + scale * z
+
+    def rand(self, *shape):
+        u = self.rng.random(shape)
+        self.log["rand"].append(u)
+        return u
+
+    def random(self, size=None):
+        u = self.rng.random(size)
+        self.log["random"].append(u)
+        return u
+
+    def rot(self):
+        q = self.rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        self.log["rot"].append(R)
+        return types.SimpleNamespace(as_matrix=lambda R=R: R)
+
+    def __enter__(self):
+        # eval_ecp.get_rot calls ``scipy.spatial.transform.Rotation.random()`` through the module
+        # global ``scipy`` (eval_ecp.py:17,263); Rotation is an immutable type, so shadow the global.
+        self._saved = (np.random.normal, np.random.rand, np.random.random, eval_ecp.scipy)
+        np.random.normal, np.random.rand, np.random.random = self.normal, self.rand, self.random
+        ns = types.SimpleNamespace
+        eval_ecp.scipy = ns(spatial=ns(transform=ns(Rotation=ns(random=self.rot))))
+        return self
+
+    def __exit__(self, *a):
+        np.random.normal, np.random.rand, np.random.random, eval_ecp.scipy = self._saved
+
+
+def make_wf(mol, mf, determinants=None, seed=11):
+    kws = dict(evaluate_orbitals_with="numba")
+    if determinants is not None:
+        kws["determinants"] = determinants
+    wf, _ = pyq.generate_wf(mol, mf, slater_kws=kws)
+    rng = np.random.default_rng(seed)
+    jas = wf.wf_factors[1]
+    jas.parameters["acoeff"] = 0.05 * rng.standard_normal(jas.parameters["acoeff"].shape)
+    b = 0.05 * rng.standard_normal(jas.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    jas.parameters["bcoeff"] = b
+    return wf
+
+
+def walkers(mol, W, seed):
+    return OpenConfigs(systems.initial_guess(mol, W, rng=np.random.default_rng(seed)).configs.copy())
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------ G1 Sherman-Morrison
+def g_sherman_morrison():
+    rng = np.random.default_rng(1)
+    out = {}
+    for tag, (n, W, D, e) in {"small": (10, 4, 8, 2), "n32": (32, 3, 1, 17)}.items():
+        mats = rng.standard_normal((W, D, n, n)) + 2.0 * np.eye(n)
+        inv = np.linalg.inv(mats)
+        vec = rng.standard_normal((W, D, n))
+        ratio, invnew = sherman_morrison_ms(e, inv, vec)
+        out.update({f"{tag}_inv": inv, f"{tag}_vec": vec, f"{tag}_e": e, f"{tag}_ratio": ratio, f"{tag}_invnew": invnew})
+    save("g1_sherman_morrison", **out)
+
+
+# ------------------------------------------------------------------ G2 AO
+def g_ao():
+    rng = np.random.default_rng(2)
+    out = {}
+    for tag, mol in {"h2o": systems.water(), "c2": systems.carbon_dimer()}.items():
+        ev = refgto.AtomicOrbitalEvaluator(mol)
+        pts = np.concatenate([rng.standard_normal((24, 3)) * 1.5 + mol.atom_coords()[rng.integers(mol.natm, size=24)],
+                              np.linspace(0, 7, 12)[:, None] * np.ones(3)[None]])
+        out[f"{tag}_pts"] = pts
+        out[f"{tag}_val"] = ev.eval_gto("GTOval_sph", pts)
+        out[f"{tag}_deriv1"] = ev.eval_gto("GTOval_sph_deriv1", pts)
+        out[f"{tag}_deriv2"] = ev.eval_gto("GTOval_sph_deriv2", pts)
+    save("g2_ao", **out)
+
+
+# ------------------------------------------------------------------ G4 func3d
+def g_func3d():
+    r = np.concatenate([np.linspace(0.05, 2.2, 40), [1.5, 1.5 - 1e-9, 1.5 + 1e-9, 7.4999, 7.5, 9.0]])
+    rvec = np.stack([0.6 * r, 0.0 * r, 0.8 * r], axis=-1)
+    out = {"r": r, "rvec": rvec}
+    funcs = {"pade_2.0_1.5": func3d.PolyPadeFunction(2.0, 1.5), "cusp_2.0_1.5": func3d.CutoffCuspFunction(2.0, 1.5),
+             "pade_0.2_7.5": func3d.PolyPadeFunction(0.2, 7.5), "cusp_24_7.5": func3d.CutoffCuspFunction(24, 7.5)}
+    for k, f in funcs.items():
+        out[k + "_value"] = f.value(rvec, r)
+        g, v = f.gradient_value(rvec, r)
+        out[k + "_grad"], out[k + "_gv_value"] = g, v
+        g, l = f.gradient_laplacian(rvec, r)
+        out[k + "_lap"] = l
+    ev = func3d.CutoffFunc3dEvaluator([func3d.CutoffCuspFunction(24, 1.5), func3d.PolyPadeFunction(0.5, 1.5)], 1.5)
+    out["eval_value"] = ev.value(rvec, r)
+    out["eval_grad"], out["eval_gv_value"] = ev.gradient_value(rvec, r)
+    out["eval_gl_grad"], out["eval_lap"] = ev.gradient_laplacian(rvec, r)
+    save("g4_func3d", **out)
+
+
+# ------------------------------------------------------------------ G5-G8 wave-function protocol
+def protocol_dump(prefix, mol, mf, wf, W, seed, electrons, out, naip=6):
+    """The update/testvalue/recompute triangle of tests/unit/test_wf_derivatives.py applied to
+    each factor and to the product; everything needed to replay is stored."""
+    rng = np.random.default_rng(seed)
+    configs = walkers(mol, W, seed)
+    out[prefix + "configs"] = configs.configs.copy()
+    sl, ja = wf.wf_factors
+    for k in ("det_coeff", "mo_coeff_alpha", "mo_coeff_beta"):
+        out[prefix + k] = np.asarray(sl.parameters[k])
+    out[prefix + "det_occup_up"] = np.asarray(sl._det_occup[0])
+    out[prefix + "det_occup_dn"] = np.asarray(sl._det_occup[1])
+    out[prefix + "det_map"] = np.asarray(sl._det_map)
+    out[prefix + "acoeff"], out[prefix + "bcoeff"] = ja.parameters["acoeff"], ja.parameters["bcoeff"]
+    names = {"slater": sl, "jastrow": ja, "wf": wf}
+    for nm, w in names.items():
+        s, l = w.recompute(configs)
+        out[f"{prefix}{nm}_recompute_sign"], out[f"{prefix}{nm}_recompute_log"] = s, l
+    for s in (0, 1):
+        out[f"{prefix}slater_dets{s}"] = sl._dets[s].copy()
+        out[f"{prefix}slater_inverse{s}"] = sl._inverse[s].copy()
+    out[prefix + "jastrow_avalues"], out[prefix + "jastrow_bvalues"] = ja._avalues.copy(), ja._bvalues.copy()
+    out[prefix + "electrons"] = np.asarray(electrons)
+    for e in electrons:
+        newpos = configs.configs[:, e, :] + 0.3 * rng.standard_normal((W, 3))
+        aux = configs.configs[:, e, None, :] + 0.4 * rng.standard_normal((W, naip, 3))
+        mask = rng.random(W) > 0.35
+        mask[0] = True
+        accept = rng.random(W) > 0.4
+        out[f"{prefix}e{e}_newpos"], out[f"{prefix}e{e}_aux"] = newpos, aux
+        out[f"{prefix}e{e}_mask"], out[f"{prefix}e{e}_accept"] = mask, accept
+        ep = configs.make_irreducible(e, newpos)
+        ea = configs.make_irreducible(e, aux)
+        for nm, w in names.items():
+            p = f"{prefix}e{e}_{nm}_"
+            g, v, saved = w.gradient_value(e, ep)
+            out[p + "gv_grad"], out[p + "gv_val"] = g, v
+            out[p + "grad"] = w.gradient(e, ep)
+            g, l = w.gradient_laplacian(e, ep)
+            out[p + "gl_grad"], out[p + "gl_lap"] = g, l
+            g, l = w.gradient_laplacian(e, configs.electron(e))
+            out[p + "gl0_grad"], out[p + "gl0_lap"] = g, l
+            out[p + "testvalue"] = w.testvalue(e, ep)[0]
+            out[p + "testvalue_mask"] = w.testvalue(e, ep, mask)[0]
+            out[p + "testvalue_aux"] = w.testvalue(e, ea, mask)[0]
+        # masked update with the saved values of the product's gradient_value, like mc.py:124-136
+        _, _, saved = wf.gradient_value(e, ep)
+        configs.move(e, ep, accept)
+        wf.updateinternals(e, ep, configs, mask=accept, saved_values=saved)
+        for nm, w in names.items():
+            s, l = w.value()
+            out[f"{prefix}e{e}_{nm}_post_sign"], out[f"{prefix}e{e}_{nm}_post_log"] = s, l
+        spin = int(e >= mol.nelec[0])
+        out[f"{prefix}e{e}_post_inverse"] = sl._inverse[spin].copy()
+        out[f"{prefix}e{e}_post_avalues"], out[f"{prefix}e{e}_post_bvalues"] = ja._avalues.copy(), ja._bvalues.copy()
+    out[prefix + "final_configs"] = configs.configs.copy()
+    for nm, w in names.items():
+        s, l = w.recompute(configs)
+        out[f"{prefix}{nm}_final_recompute_sign"], out[f"{prefix}{nm}_final_recompute_log"] = s, l
+
+
+def g_protocol():
+    out = {}
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    protocol_dump("", mol, mf, make_wf(mol, mf), W=6, seed=5, electrons=[0, 2, 5, 7], out=out)
+    save("g5_protocol_h2o", **out)
+
+    out = {}
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = systems.random_determinants(mol, mf, 12)
+    out["det_json"] = np.asarray(repr(dets))
+    protocol_dump("", mol, mf, make_wf(mol, mf, determinants=dets), W=5, seed=8, electrons=[1, 6], out=out)
+    save("g8_protocol_h2o_multidet", **out)
+
+    out = {}
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    protocol_dump("", mol, mf, make_wf(mol, mf), W=3, seed=9, electrons=[0, 31, 32, 63], out=out)
+    save("g5_protocol_cluster", **out)
+
+
+# ------------------------------------------------------------------ G9/G10 ECP + energy
+def g_energy():
+    out = {}
+    for tag, mol, W in (("h2o", systems.water(), 8), ("cluster", systems.water_cluster(), 2)):
+        mf = systems.random_mf(mol)
+        wf = make_wf(mol, mf)
+        configs = walkers(mol, W, 21)
+        # pull a few electrons close to an oxygen so the stochastic ECP mask has both outcomes
+        rng = np.random.default_rng(3)
+        configs.configs[:, :3, :] = mol.atom_coords()[0] + 0.35 * rng.standard_normal((W, 3, 3))
+        out[tag + "_configs"] = configs.configs.copy()
+        wf.recompute(configs)
+        for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+            with Tapes(100 + len(out)) as t:
+                en = pyq.EnergyAccumulator(mol, threshold=thr)(configs, wf)
+            for k, v in en.items():
+                out[f"{tag}_{thr_tag}_{k}"] = np.asarray(v)
+            natm_ecp = sum(1 for a in mol._atom if a[0] in mol._ecp)
+            N = sum(mol.nelec)
+            out[f"{tag}_{thr_tag}_rot"] = np.asarray(t.log["rot"]).reshape(N, natm_ecp, 3, 3)
+            out[f"{tag}_{thr_tag}_unif"] = np.asarray(t.log["random"]).reshape(N, natm_ecp, W)
+        if tag == "h2o":  # one ecp_ea call in detail (eval_ecp.py:83-132)
+            with Tapes(77) as t:
+                d = eval_ecp.ecp_ea(mol, configs, wf, 1, mol._atom[0], 10.0)
+            out["ea_rot"], out["ea_unif"] = t.log["rot"][0], t.log["random"][0]
+            for k in ("total", "local", "mask", "ratio", "v_l", "P_l"):
+                out["ea_" + k] = np.asarray(d[k])
+            out["ea_epos"] = d["epos"].configs
+        ee, ei, ii = refenergy.OpenCoulomb(mol).energy(configs)
+        out[tag + "_ii"] = np.asarray(ii)
+    save("g10_energy", **out)
+
+
+# ------------------------------------------------------------------ G11 VMC trajectory
+def g_vmc():
+    out = {}
+    for tag, mol, W, nsteps, tstep in (("h2o", systems.water(), 6, 3, 0.3), ("he", systems.helium(), 10, 4, 0.5)):
+        mf = systems.random_mf(mol)
+        wf = make_wf(mol, mf)
+        N = sum(mol.nelec)
+        natm_ecp = sum(1 for a in mol._atom if a[0] in mol._ecp)
+        for attempt in range(20):
+            configs = walkers(mol, W, 31 + attempt)
+            start = configs.configs.copy()
+            accepts = []
+            orig_update = wf.updateinternals
+
+            def spy(e, epos, cfg, mask=None, saved_values=None, _o=orig_update):
+                accepts.append(np.asarray(mask).copy())
+                return _o(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+            wf.updateinternals = spy
+            with Tapes(500 + attempt) as t:
+                blk, configs = vmc_worker(wf, configs, tstep, nsteps, {"energy": pyq.EnergyAccumulator(mol)})
+            wf.updateinternals = orig_update
+            break
+        out[tag + "_start"] = start
+        out[tag + "_tstep"], out[tag + "_nsteps"] = tstep, nsteps
+        out[tag + "_gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+        out[tag + "_unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+        out[tag + "_ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm_ecp, 3, 3)
+        out[tag + "_ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm_ecp, W)
+        out[tag + "_accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+        out[tag + "_final"] = configs.configs.copy()
+        s, l = wf.value()
+        out[tag + "_final_log"] = l
+        for k, v in blk.items():
+            if "time" not in k:
+                out[f"{tag}_blk_{k}"] = np.asarray(v)
+        out[tag + "_blk_keys"] = np.asarray(sorted(blk.keys()))
+        for k in ("acoeff", "bcoeff"):
+            out[f"{tag}_{k}"] = wf.wf_factors[1].parameters[k]
+    save("g11_vmc", **out)
+
+
+if __name__ == "__main__":
+    g_sherman_morrison()
+    g_ao()
+    g_func3d()
+    g_protocol()
+    g_energy()
+    g_vmc()

@@ -1,0 +1,113 @@
+"""Shared builders for the parity tests: the same synthetic inputs the golden generator used."""
+
+import ast
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pyqmc_amd import systems  # noqa: E402
+from pyqmc_amd.configs import OpenConfigs  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def jastrow_params(mol, seed=11, na=4, nb=4):
+    """Same draws as make_golden.make_wf."""
+    rng = np.random.default_rng(seed)
+    acoeff = 0.05 * rng.standard_normal((mol.natm, na, 2))
+    bcoeff = 0.05 * rng.standard_normal((nb, 3))
+    bcoeff[0] = [-0.25, -0.5, -0.25]
+    return acoeff, bcoeff
+
+
+def oracle_wf(mol, mf, determinants=None, seed=11):
+    from oracle import jastrow_basis, wf as owf
+
+    sl = owf.Slater(mol, mf.mo_coeff, determinants)
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False)
+    ja = owf.JastrowSpin(mol, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = jastrow_params(mol, seed)
+    return owf.MultiplyWF(sl, ja)
+
+
+def gpu_wf(mol, mf, determinants=None, seed=11):
+    import pyqmc_amd as pa
+
+    wf = pa.generate_wf(mol, mf, determinants=determinants)
+    a, b = jastrow_params(mol, seed)
+    wf.parameters["wf2acoeff"] = a
+    wf.parameters["wf2bcoeff"] = b
+    return wf
+
+
+def case(name):
+    """(mol, mf, determinants, golden-dict) for the protocol fixtures."""
+    g = golden(name)
+    if name == "g5_protocol_h2o":
+        mol = systems.water()
+        return mol, systems.random_mf(mol), None, g
+    if name == "g8_protocol_h2o_multidet":
+        mol = systems.water()
+        return mol, systems.random_mf(mol, nvirt=6), ast.literal_eval(str(g["det_json"])), g
+    if name == "g5_protocol_cluster":
+        mol = systems.water_cluster()
+        return mol, systems.random_mf(mol), None, g
+    raise KeyError(name)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.max(np.abs(b)), 1e-300) if b.size else 1.0
+    return float(np.max(np.abs(a - b)) / scale) if b.size else 0.0
+
+
+def run_protocol(wf, g, names=("slater", "jastrow", "wf")):
+    """Replay ``make_golden.protocol_dump`` on ``wf`` (oracle or HIP) and return
+    {quantity: relative error vs golden}."""
+    configs = OpenConfigs(g["configs"].copy())
+    factors = {"slater": wf.wf_factors[0], "jastrow": wf.wf_factors[1], "wf": wf}
+    factors = {k: v for k, v in factors.items() if k in names}
+    err = {}
+    for nm, w in factors.items():
+        s, l = w.recompute(configs)
+        err[f"{nm}_recompute_log"] = relerr(l, g[f"{nm}_recompute_log"])
+        err[f"{nm}_recompute_sign"] = relerr(s, g[f"{nm}_recompute_sign"])
+    for e in g["electrons"]:
+        e = int(e)
+        ep = configs.make_irreducible(e, g[f"e{e}_newpos"])
+        ea = configs.make_irreducible(e, g[f"e{e}_aux"])
+        mask, accept = g[f"e{e}_mask"], g[f"e{e}_accept"]
+        for nm, w in factors.items():
+            p = f"e{e}_{nm}_"
+            gr, v, _ = w.gradient_value(e, ep)
+            err[p + "gv_grad"], err[p + "gv_val"] = relerr(gr, g[p + "gv_grad"]), relerr(v, g[p + "gv_val"])
+            err[p + "grad"] = relerr(w.gradient(e, ep), g[p + "grad"])
+            gr, l = w.gradient_laplacian(e, ep)
+            err[p + "gl_grad"], err[p + "gl_lap"] = relerr(gr, g[p + "gl_grad"]), relerr(l, g[p + "gl_lap"])
+            gr, l = w.gradient_laplacian(e, configs.electron(e))
+            err[p + "gl0_grad"], err[p + "gl0_lap"] = relerr(gr, g[p + "gl0_grad"]), relerr(l, g[p + "gl0_lap"])
+            err[p + "testvalue"] = relerr(w.testvalue(e, ep)[0], g[p + "testvalue"])
+            err[p + "testvalue_mask"] = relerr(w.testvalue(e, ep, mask)[0], g[p + "testvalue_mask"])
+            err[p + "testvalue_aux"] = relerr(w.testvalue(e, ea, mask)[0], g[p + "testvalue_aux"])
+        if "wf" in factors:
+            _, _, saved = wf.gradient_value(e, ep)
+            configs.move(e, ep, accept)
+            wf.updateinternals(e, ep, configs, mask=accept, saved_values=saved)
+        else:
+            configs.move(e, ep, accept)
+            for w in factors.values():
+                w.updateinternals(e, ep, configs, mask=accept)
+        for nm, w in factors.items():
+            s, l = w.value()
+            err[f"e{e}_{nm}_post_log"] = relerr(l, g[f"e{e}_{nm}_post_log"])
+            err[f"e{e}_{nm}_post_sign"] = relerr(s, g[f"e{e}_{nm}_post_sign"])
+    return err
