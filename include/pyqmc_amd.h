@@ -1,0 +1,170 @@
+/* pyqmc_amd — C ABI of the MI355X (gfx950) walker-batched trial-wave-function evaluator.
+ *
+ * The reference (WagnerGroup/pyqmc 0.8.0) has NO FFI: its boundary is the duck-typed
+ * Python wave-function protocol (doc/source/wavefunction.rst:5-40).  Each entry point
+ * below names the reference method it stands in for; pyqmc_amd/wf.py binds them with
+ * ctypes behind classes with the reference's names (Slater, JastrowSpin, MultiplyWF),
+ * and INTEGRATION.md shows the stub a pyqmc maintainer would add.
+ *
+ * Conventions
+ *  - return 0 = ok, <0 = error (text via pqa_last_error).
+ *  - every buffer is caller-owned, C-contiguous fp64 unless typed otherwise, and may be a
+ *    host pointer OR a device pointer (copies use hipMemcpyDefault).  No pointer is
+ *    retained after the call returns.
+ *  - one handle = one walker shard on one device, one HIP stream, not re-entrant
+ *    (same as the reference objects, which hold mutable per-walker state).
+ *  - electrons are ordered all spin-up then all spin-down (slater.py:236-239).
+ */
+#ifndef PYQMC_AMD_H
+#define PYQMC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pqa_handle pqa_handle_t;
+
+/* Flat description of a Slater-Jastrow trial wave function (all pointers: host memory). */
+typedef struct {
+  /* geometry */
+  int32_t natom;
+  int32_t nelec_up, nelec_dn;
+  const double* atom_xyz;    /* natom*3, bohr */
+  const double* atom_charge; /* natom, valence charges (energy.py:40-45) */
+  /* contracted GTO shells in AO order (numba/gto.py:435-470); coefficients already
+     normalised (gto.py:375-405) */
+  int32_t nshell, nprim, nao;
+  const int32_t* shell_atom;     /* nshell */
+  const int32_t* shell_l;        /* nshell, l <= 3 */
+  const int32_t* shell_prim_off; /* nshell+1 */
+  const int32_t* shell_ao_off;   /* nshell */
+  const double* prim_exp;        /* nprim */
+  const double* prim_coef;       /* nprim */
+  /* molecular orbitals, row-major [ao][mo] (orbitals.py:56-60), truncated to used columns */
+  int32_t nmo_up, nmo_dn;
+  const double* mo_up;
+  const double* mo_dn;
+  /* determinant expansion packed like determinant_tools.create_packed_objects (:39-71) */
+  int32_t ndet, ndet_up, ndet_dn;
+  const double* det_coeff;   /* ndet */
+  const int32_t* det_occ_up; /* ndet_up*nelec_up */
+  const int32_t* det_occ_dn; /* ndet_dn*nelec_dn */
+  const int32_t* det_map;    /* 2*ndet */
+  /* two-body Jastrow (jastrowspin.py:31-54); basis kinds: 0 = PolyPade(beta), 1 = CutoffCusp(gamma)
+     (func3d.py:52-210) */
+  int32_t na, nb; /* 0/0 = no Jastrow factor */
+  const int32_t* a_kind;
+  const double* a_param;
+  const int32_t* b_kind;
+  const double* b_param;
+  double rcut_a, rcut_b;
+  const double* acoeff; /* natom*na*2 */
+  const double* bcoeff; /* nb*3 */
+  /* semi-local ECPs (eval_ecp.py:149-200).  Channels of ECP atom k are
+     [ecp_chan_off[k], ecp_chan_off[k+1]): non-local l = 0,1,.. first, LOCAL channel last
+     (the reference's v_l column order).  Terms: sum coef * r^n * exp(-exp r^2). */
+  int32_t necp;
+  const int32_t* ecp_atom;     /* necp: atom index */
+  const int32_t* ecp_chan_off; /* necp+1 */
+  const int32_t* ecp_term_off; /* nchan_total+1 */
+  const int32_t* ecp_term_n;
+  const double* ecp_term_exp;
+  const double* ecp_term_coef;
+  int32_t has_slater; /* 0: Jastrow-only handle */
+} pqa_system_t;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+int pqa_create(const pqa_system_t* sys, int device, pqa_handle_t** out);
+void pqa_destroy(pqa_handle_t* h);
+const char* pqa_last_error(const pqa_handle_t* h); /* h may be NULL: last create error */
+int pqa_device_count(void);
+
+/* wf.parameters[...] (slater.py:193-210, jastrowspin.py:48-53): names "det_coeff",
+   "mo_coeff_alpha", "mo_coeff_beta", "acoeff", "bcoeff".  Takes effect immediately for
+   evaluations; cached walker state is refreshed by the next recompute, as in the reference. */
+int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n);
+int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int64_t n);
+
+/* ---- orbital evaluation (orbitals.py:85-96; numba/gto.py:89-254) --------------------- */
+/* out (ncomp, npts, nao); ncomp 1 = value, 4 = +gradient, 5 = +laplacian */
+int pqa_eval_ao(pqa_handle_t* h, const double* pts, int64_t npts, int ncomp, double* out);
+/* out (ncomp, npts, nmo_spin); ncomp 1 or 5.  use_mfma=1: fused AO->MO MFMA kernel (product
+   path); 0: plain VALU contraction of pqa_eval_ao output (A/B check only). */
+int pqa_eval_mo(pqa_handle_t* h, int spin, const double* pts, int64_t npts, int ncomp, int use_mfma, double* out);
+
+/* ---- Slater factor ------------------------------------------------------------------- */
+/* Slater.recompute (slater.py:227-260) -> (sign, log|psi|) each (W) */
+int pqa_slater_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs);
+/* Slater.value (slater.py:293-299) */
+int pqa_slater_value(pqa_handle_t* h, double* sign, double* logabs);
+/* _testrow/_testrowderiv (slater.py:301-380): multi-determinant ratios of replacing electron e's
+   row by the orbitals at pts.  pts (nrow, npt, 3); row r belongs to walker widx[r] (NULL: r);
+   out (ncomp, nrow*npt) with ncomp 1 (value: testvalue :429-446) or 5 (value, d/dx,d/dy,d/dz, laplacian:
+   gradient_value :403-418, gradient_laplacian :420-427).  keep_saved (npt==1, widx==NULL, ncomp==5):
+   keep the MO rows on the device for the next pqa_slater_update(use_saved=1). */
+int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                    int ncomp, int keep_saved, double* out);
+/* Slater.updateinternals (slater.py:262-291) + Sherman-Morrison (slater.py:88-94); mask (W) bytes */
+int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved);
+/* any non-finite log-determinant of spin `spin`?  (the reference's trigger for a full recompute inside
+   updateinternals, slater.py:269-275) */
+int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag);
+/* test access: _inverse[s] (W, ndet_s, n, n) in the reference's [orbital, electron] order and
+   _dets[s] (2, W, ndet_s) */
+int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, double* dets);
+
+/* ---- Jastrow factor ------------------------------------------------------------------ */
+/* JastrowSpin.recompute / value (jastrowspin.py:56-109, 251-255) -> U (W) */
+int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval);
+int pqa_jastrow_value(pqa_handle_t* h, double* logval);
+/* mode 0: testvalue (jastrowspin.py:387-419): out (nrow*npt) ratios
+   mode 1: gradient_value (:296-340): out (4, nrow): dU/dx,dU/dy,dU/dz, ratio      (npt == 1)
+   mode 2: gradient_laplacian (:342-385): out (4, nrow): grad U, lap U + |grad U|^2 (npt == 1) */
+int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                     int mode, double* out);
+/* JastrowSpin.updateinternals (jastrowspin.py:111-137): also moves the handle's copy of the walkers */
+int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask);
+/* test access: _avalues (W,natom,na,2), _bvalues (W,nb,3), _configscurrent (W,N,3); any may be NULL */
+int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs);
+
+/* ---- fused device-resident path --------------------------------------------------------- */
+/* MultiplyWF.recompute (multiplywf.py:81-88) for all factors of the handle; also fills the
+   per-electron orbital cache used by the fused sweep/energy. */
+int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs);
+int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs);
+int pqa_get_configs(pqa_handle_t* h, double* configs);
+
+/* EnergyAccumulator.__call__ (accumulators.py:60-75) on the device-resident walkers:
+   out (6, W) rows ke, ee, ei, ecp, grad2, total (kinetic energy.py:57-65, Coulomb :28-54, ECP
+   eval_ecp.py:21-146).  threshold as eval_ecp.ecp_mask (:135-146).  rot (N, necp, 3, 3) and
+   unif (N, necp, W) replay the reference's random draws; NULL -> device Philox stream `seed`. */
+int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out);
+
+/* vmc_worker move loop (mc.py:112-137) fused on the device, nsteps sweeps over all electrons,
+   optionally followed each sweep by the energy accumulator (mc.py:142-148).
+   gauss (nsteps,N,W,3) standard normals and unif (nsteps,N,W): replay tapes, or NULL -> Philox(seed).
+   ecp_rot (nsteps,N,necp,3,3) / ecp_unif (nsteps,N,necp,W): same for the ECP draws.
+   acceptance (nsteps): mean acceptance per sweep.  energy_mean (nsteps,6): walker means of
+   ke,ee,ei,ecp,grad2,total (NULL: no energy evaluation).  accept_rec (nsteps,N,W) bytes, may be NULL. */
+int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif,
+                   double threshold, const double* ecp_rot, const double* ecp_unif, uint64_t seed,
+                   double* acceptance, double* energy_mean, uint8_t* accept_rec);
+
+/* ---- measurement -------------------------------------------------------------------- */
+/* HIP-event timing on the handle's own stream (torch.cuda.Event only sees torch's stream). */
+int pqa_timer_start(pqa_handle_t* h);
+int pqa_timer_stop(pqa_handle_t* h, double* elapsed_ms); /* synchronises the stream */
+int pqa_sync(pqa_handle_t* h);
+/* per-kernel-class accounting: enable=1 brackets every launch of the orbital (AO->MO MFMA) kernel
+   with events; query returns launches, total ms, total points*ncomp processed since enable. */
+int pqa_profile_enable(pqa_handle_t* h, int enable);
+int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, double* point_comps);
+/* points evaluated by the ECP integrator in the last pqa_energy call (data dependent) */
+int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

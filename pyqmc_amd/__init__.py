@@ -1,0 +1,16 @@
+"""pyqmc_amd — MI355X-native walker-batched trial-wave-function evaluator that drops in
+behind PyQMC's wave-function protocol (see DESIGN.md / INTEGRATION.md).
+
+Importing the package does not load the HIP library; the first object that needs the GPU
+does, and raises if ``pyqmc_amd/lib/libpyqmc_amd.so`` is not built.
+"""
+
+from . import systems  # noqa: F401
+from .configs import OpenConfigs, OpenElectron  # noqa: F401
+from .energy import EnergyAccumulator  # noqa: F401
+from .func3d import CutoffCuspFunction, PolyPadeFunction, default_jastrow_basis  # noqa: F401
+from .systems import initial_guess  # noqa: F401
+from .vmc import vmc, vmc_worker  # noqa: F401
+from .wf import DeviceWF, JastrowSpin, MultiplyWF, Slater, generate_wf  # noqa: F401
+
+__version__ = "0.1.0"

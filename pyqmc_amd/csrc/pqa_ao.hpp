@@ -1,0 +1,217 @@
+// GTO atomic-orbital evaluation and the fused AO->MO contraction (fp64 MFMA).
+//
+// What is computed follows the reference's in-repo evaluator pyqmc/wf/numba/gto.py:
+//   value  mol_eval_gto      :89-136     chi = S_lm(r-R_A) * R(|r-R_A|^2)
+//   grad   mol_eval_gto_grad :139-194    d chi = dS R + S dR,  dR_i = -2 a x_i c e^{-a r^2}
+//   lap    mol_eval_gto_lap  :197-254    lap chi = S sum 2a(2a r^2-3) c e^{-a r^2} + 2 dS.dR
+// with real solid harmonics as numba/spherical_harmonics.py:40-200 (l=1 ordered x,y,z) and the
+// contraction orbitals.py:95-96 (ao.dot(C)).  How it is computed is MI355X-specific:
+// one lane per point for the transcendental work, shell tables read through the scalar
+// cache, AO tile staged in LDS (XOR-swizzled, conflict-free for ds_read_b64), contraction on
+// v_mfma_f64_16x16x4_f64.
+#pragma once
+#include "pqa_common.hpp"
+
+// p-th point lives at base + (p / group) * group_stride + (p % group) * 3
+struct PointAddr {
+  const double* base;
+  int group;
+  long group_stride;
+};
+__device__ __forceinline__ void load_point(const PointAddr& a, long p, double& x, double& y, double& z) {
+  const double* q = a.base + (p / a.group) * a.group_stride + (p % a.group) * 3;
+  x = q[0]; y = q[1]; z = q[2];
+}
+
+// normalisation constants of the orthonormal real spherical harmonics
+#define SH_S0 0.28209479177387814   // 1/(2 sqrt(pi))
+#define SH_P1 0.4886025119029199    // sqrt(3/(4 pi))
+#define SH_DXY 1.0925484305920792   // 1/2 sqrt(15/pi)
+#define SH_DZ2 0.31539156525252005  // 1/4 sqrt(5/pi)
+#define SH_DX2 0.5462742152960396   // 1/4 sqrt(15/pi)
+#define SH_F3 0.5900435899266435    // 1/4 sqrt(35/(2 pi))
+#define SH_F2 2.890611442640554     // 1/2 sqrt(105/pi)
+#define SH_F1 0.4570457994644658    // 1/4 sqrt(21/(2 pi))
+#define SH_F0 0.3731763325901154    // 1/4 sqrt(7/pi)
+#define SH_F2C 1.445305721320277    // 1/4 sqrt(105/pi)
+
+// Evaluate one contracted shell at displacement (x,y,z) from its centre and hand each of its
+// 2l+1 functions to sink(m, value, dx, dy, dz, lap).  NCOMP = 1 | 4 | 5 selects how much is computed.
+template <int NCOMP, class Sink>
+__device__ __forceinline__ void shell_eval(int l, double x, double y, double z, const double* __restrict__ pexp,
+                                           const double* __restrict__ pcoef, int np, Sink&& sink) {
+  const double r2 = x * x + y * y + z * z;
+  double R = 0.0, dRs = 0.0, lapR = 0.0;
+  for (int p = 0; p < np; ++p) {
+    const double a = pexp[p];
+    const double t = pcoef[p] * exp(-a * r2);
+    R += t;
+    if (NCOMP > 1) dRs += a * t;
+    if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
+  }
+  dRs *= -2.0;  // grad R = dRs * (x,y,z)
+  const double Rx = dRs * x, Ry = dRs * y, Rz = dRs * z;
+#define EMIT(m, S, Sx, Sy, Sz)                                                                             \
+  {                                                                                                        \
+    const double s_ = (S), sx_ = (Sx), sy_ = (Sy), sz_ = (Sz);                                             \
+    double gx_ = 0, gy_ = 0, gz_ = 0, lp_ = 0;                                                             \
+    if (NCOMP > 1) { gx_ = sx_ * R + s_ * Rx; gy_ = sy_ * R + s_ * Ry; gz_ = sz_ * R + s_ * Rz; }          \
+    if (NCOMP == 5) lp_ = s_ * lapR + 2.0 * (sx_ * Rx + sy_ * Ry + sz_ * Rz);                              \
+    sink(m, s_ * R, gx_, gy_, gz_, lp_);                                                                   \
+  }
+  switch (l) {
+    case 0:
+      EMIT(0, SH_S0, 0.0, 0.0, 0.0);
+      break;
+    case 1:
+      EMIT(0, SH_P1 * x, SH_P1, 0.0, 0.0);
+      EMIT(1, SH_P1 * y, 0.0, SH_P1, 0.0);
+      EMIT(2, SH_P1 * z, 0.0, 0.0, SH_P1);
+      break;
+    case 2:
+      EMIT(0, SH_DXY * x * y, SH_DXY * y, SH_DXY * x, 0.0);
+      EMIT(1, SH_DXY * y * z, 0.0, SH_DXY * z, SH_DXY * y);
+      EMIT(2, SH_DZ2 * (2.0 * z * z - x * x - y * y), -2.0 * SH_DZ2 * x, -2.0 * SH_DZ2 * y, 4.0 * SH_DZ2 * z);
+      EMIT(3, SH_DXY * x * z, SH_DXY * z, 0.0, SH_DXY * x);
+      EMIT(4, SH_DX2 * (x * x - y * y), 2.0 * SH_DX2 * x, -2.0 * SH_DX2 * y, 0.0);
+      break;
+    default: {  // l == 3
+      const double x2 = x * x, y2 = y * y, z2 = z * z;
+      EMIT(0, SH_F3 * y * (3.0 * x2 - y2), SH_F3 * 6.0 * x * y, SH_F3 * 3.0 * (x2 - y2), 0.0);
+      EMIT(1, SH_F2 * x * y * z, SH_F2 * y * z, SH_F2 * x * z, SH_F2 * x * y);
+      EMIT(2, SH_F1 * y * (4.0 * z2 - x2 - y2), -2.0 * SH_F1 * x * y, SH_F1 * (4.0 * z2 - x2 - 3.0 * y2),
+           8.0 * SH_F1 * y * z);
+      EMIT(3, SH_F0 * z * (2.0 * z2 - 3.0 * x2 - 3.0 * y2), -6.0 * SH_F0 * x * z, -6.0 * SH_F0 * y * z,
+           SH_F0 * (6.0 * z2 - 3.0 * x2 - 3.0 * y2));
+      EMIT(4, SH_F1 * x * (4.0 * z2 - x2 - y2), SH_F1 * (4.0 * z2 - 3.0 * x2 - y2), -2.0 * SH_F1 * x * y,
+           8.0 * SH_F1 * x * z);
+      EMIT(5, SH_F2C * z * (x2 - y2), 2.0 * SH_F2C * x * z, -2.0 * SH_F2C * y * z, SH_F2C * (x2 - y2));
+      EMIT(6, SH_F3 * x * (x2 - 3.0 * y2), SH_F3 * 3.0 * (x2 - y2), -SH_F3 * 6.0 * x * y, 0.0);
+    }
+  }
+#undef EMIT
+}
+
+// ---------------------------------------------------------------- AO only (test / A-B entry)
+// out (NCOMP, P, nao); one thread per point.
+template <int NCOMP>
+__global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  for (int sh = 0; sh < S.nshell; ++sh) {
+    const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
+    const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
+    shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0,
+                      [&](int m, double v, double gx, double gy, double gz, double lp) {
+                        double* o = out + p * S.nao + ao0 + m;
+                        const long cs = P * (long)S.nao;
+                        o[0] = v;
+                        if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
+                        if (NCOMP == 5) o[4 * cs] = lp;
+                      });
+  }
+}
+
+// plain contraction out[c][p][j] = sum_a ao[c][p][a] C[a][j]  (A/B check of the MFMA kernel only)
+__global__ void k_mo_valu(const double* __restrict__ ao, const double* __restrict__ C, long rows, int nao, int nmo,
+                          double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nmo) return;
+  const long r = idx / nmo;
+  const int j = idx % nmo;
+  double s = 0.0;
+  for (int a = 0; a < nao; ++a) s += ao[r * nao + a] * C[(long)a * nmo + j];
+  out[idx] = s;
+}
+
+// ---------------------------------------------------------------- fused AO -> MO, MFMA
+// AO index space is cut into chunks of <= KC functions made of whole shells; each chunk's shells
+// are pre-assigned to the 4 waves of a block (balanced by primitive count on the host).
+struct ChunkTab {
+  int nchunk;
+  const int* chunk_nk;    // AOs in chunk
+  const int* chunk_ao0;   // first AO
+  const int* chunk_row0;  // first row in the zero-padded coefficient matrices
+  const int* cw_off;      // [nchunk*4+1]
+  const int* cw_shell;    // shells for (chunk, wave)
+  const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
+  int ldc[2];
+};
+
+// out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), 64 points.
+template <int NCOMP, int NT, int KC>
+__global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
+                                             double* __restrict__ out) {
+  __shared__ double tile[NCOMP][KC][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long p0 = (long)blockIdx.x * 64;
+  const long pmine = (p0 + lane < P) ? p0 + lane : P - 1;
+  double px, py, pz;
+  load_point(pa, pmine, px, py, pz);
+
+  d4 acc[NT][NCOMP];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[u][c] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const double* __restrict__ C = T.cpad[spin];
+  const int ldc = T.ldc[spin];
+  const int i16 = lane & 15, kq = lane >> 4;
+
+  for (int ch = 0; ch < T.nchunk; ++ch) {
+    const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch], row0 = T.chunk_row0[ch];
+    const int nk4 = (nk + 3) & ~3;
+    // ---- phase 1: this wave's shells of the chunk, one lane per point (VALU / exp bound)
+    const int s_end = T.cw_off[ch * 4 + wv + 1];
+    for (int si = T.cw_off[ch * 4 + wv]; si < s_end; ++si) {
+      const int sh = T.cw_shell[si];
+      const int ia = S.shell_atom[sh], q0 = S.shell_prim_off[sh], kb = S.shell_ao_off[sh] - a0;
+      const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
+      shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + q0, S.prim_coef + q0, S.shell_prim_off[sh + 1] - q0,
+                        [&](int m, double v, double gx, double gy, double gz, double lp) {
+                          const int k = kb + m;
+                          const int col = lane ^ ((k & 1) << 4);
+                          tile[0][k][col] = v;
+                          if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
+                          if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+                        });
+    }
+    for (int idx = tid; idx < (nk4 - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows
+      const int rc = idx >> 6;
+      tile[rc % NCOMP][nk + rc / NCOMP][idx & 63] = 0.0;
+    }
+    __syncthreads();
+    // ---- phase 2: wave wv owns points 16wv..16wv+15; D[point][orb] += A[point][k] B[k][orb]
+    for (int k0 = 0; k0 < nk4; k0 += 4) {
+      const int k = k0 + kq;
+      const double* crow = C + (long)(row0 + k) * ldc + i16;
+      double b[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) b[u] = crow[16 * u];
+      const int col = (16 * wv + i16) ^ ((k & 1) << 4);
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const double a = tile[c][k][col];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc[u][c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: lane holds D[row = (lane>>4) + 4r][col = lane & 15]
+  const int nmo = S.nmo[spin];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int j = 16 * u + i16;
+    if (j >= nmo) continue;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long pp = p0 + 16 * wv + kq + 4 * r;
+        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+      }
+  }
+}

@@ -1,0 +1,957 @@
+// pyqmc_amd C ABI implementation (host side).  See include/pyqmc_amd.h for the contract.
+// Single translation unit: the device code lives in the headers included below.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pyqmc_amd.h"
+#include "pqa_ao.hpp"
+#include "pqa_common.hpp"
+#include "pqa_energy.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_slater.hpp"
+#include "pqa_vmc.hpp"
+
+static thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ChunkHost {
+  std::vector<int> nk, ao0, row0, cw_off, cw_shell;
+  int rows_pad = 0;
+};
+
+struct pqa_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<void*> owned;  // table allocations freed at destroy
+  // host copies needed after create
+  int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
+  int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
+  int na = 0, nb = 0, necp = 0;
+  bool has_slater = false, has_jastrow = false;
+  double ii_energy = 0.0;
+  std::vector<int> shell_l, shell_np, shell_ao;
+  SysDev S{};
+  ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
+  ChunkTab tab[2]{};
+  double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
+  double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
+  double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
+  // walker state
+  long W = 0;
+  SlaterState st{};
+  JastrowState js{};
+  DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
+  // scratch
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt;
+  DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
+  DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
+  bool saved_valid = false;
+  int saved_e = -1;
+  long last_ecp_points = 0;
+  // measurement
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  long prof_launches = 0;
+  double prof_ms = 0.0, prof_pc = 0.0;
+};
+
+#define HIPCHK(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      char buf_[512];                                                                                    \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      h->err = buf_;                                                                                     \
+      return -1;                                                                                         \
+    }                                                                                                    \
+  } while (0)
+#define FAIL(msg)      \
+  do {                 \
+    h->err = (msg);    \
+    return -2;         \
+  } while (0)
+#define TRY(x)          \
+  do {                  \
+    int rc_ = (x);      \
+    if (rc_) return rc_; \
+  } while (0)
+
+static int ensure(pqa_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return 0;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = std::max<size_t>(bytes, 256);
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return 0;
+}
+
+template <class T>
+static int upload_table(pqa_handle* h, const T* src, size_t n, T** dst) {
+  *dst = nullptr;
+  if (n == 0) n = 1;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, n * sizeof(T)));
+  h->owned.push_back(p);
+  if (src) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(p, 0, n * sizeof(T)));
+  *dst = (T*)p;
+  return 0;
+}
+
+static int copy_in(pqa_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+  return 0;
+}
+static int copy_out(pqa_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int check_launch(pqa_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + " launch failed: " + hipGetErrorString(e);
+    return -1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- chunk tables for k_orb
+static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
+  c = ChunkHost();
+  c.cw_off.push_back(0);
+  int sh = 0, rows = 0;
+  while (sh < h->nshell) {
+    const int first = sh;
+    int nk = 0;
+    while (sh < h->nshell && nk + (2 * h->shell_l[sh] + 1) <= KC) nk += 2 * h->shell_l[sh++] + 1;
+    c.nk.push_back(nk);
+    c.ao0.push_back(h->shell_ao[first]);
+    c.row0.push_back(rows);
+    rows += (nk + 3) & ~3;
+    // longest-processing-time assignment of the chunk's shells to the 4 waves of a block
+    std::vector<int> order;
+    for (int s = first; s < sh; ++s) order.push_back(s);
+    auto cost = [&](int s) { return 12 * h->shell_np[s] + 6 * (2 * h->shell_l[s] + 1); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<int> lists[4];
+    int load[4] = {0, 0, 0, 0};
+    for (int s : order) {
+      int best = 0;
+      for (int wv = 1; wv < 4; ++wv)
+        if (load[wv] < load[best]) best = wv;
+      lists[best].push_back(s);
+      load[best] += cost(s);
+    }
+    for (int wv = 0; wv < 4; ++wv) {
+      for (int s : lists[wv]) c.cw_shell.push_back(s);
+      c.cw_off.push_back((int)c.cw_shell.size());
+    }
+  }
+  c.rows_pad = rows;
+}
+
+// zero-padded coefficient matrix for one chunk table / spin
+static int upload_cpad(pqa_handle* h, int t, int s, const double* mo_host) {
+  const ChunkHost& c = h->chunks[t];
+  const int ldc = 16 * h->nt[s], nmo = h->nmo[s];
+  std::vector<double> pad((size_t)std::max(c.rows_pad, 1) * ldc, 0.0);
+  for (size_t ch = 0; ch < c.nk.size(); ++ch)
+    for (int k = 0; k < c.nk[ch]; ++k)
+      for (int j = 0; j < nmo; ++j) pad[(size_t)(c.row0[ch] + k) * ldc + j] = mo_host[(size_t)(c.ao0[ch] + k) * nmo + j];
+  HIPCHK(hipMemcpy(h->d_cpad[t][s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int set_mo(pqa_handle* h, int s, const double* mo_host) {
+  HIPCHK(hipMemcpy(h->d_mo[s], mo_host, (size_t)h->nao * std::max(h->nmo[s], 1) * sizeof(double), hipMemcpyHostToDevice));
+  for (int t = 0; t < 2; ++t) TRY(upload_cpad(h, t, s, mo_host));
+  return 0;
+}
+
+// ---------------------------------------------------------------- create / destroy
+extern "C" int pqa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char* pqa_last_error(const pqa_handle_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
+  h->nao = sys->nao; h->nshell = sys->nshell;
+  h->has_slater = sys->has_slater != 0;
+  h->has_jastrow = sys->na > 0 || sys->nb > 0;
+  h->na = sys->na; h->nb = sys->nb; h->necp = sys->necp;
+  if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS) FAIL("more than 8 Jastrow basis functions per kind");
+  if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 64 electrons per spin channel is not supported by the one-wave determinant tile");
+  SysDev& S = h->S;
+  S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;
+  double* tmp_d; int* tmp_i;
+  TRY(upload_table(h, sys->atom_xyz, (size_t)h->natom * 3, &tmp_d)); S.atom_xyz = tmp_d;
+  TRY(upload_table(h, sys->atom_charge, (size_t)h->natom, &tmp_d)); S.atom_charge = tmp_d;
+  for (int i = 0; i < h->natom; ++i)
+    for (int j = i + 1; j < h->natom; ++j) {
+      double d2 = 0;
+      for (int k = 0; k < 3; ++k) { const double d = sys->atom_xyz[3 * i + k] - sys->atom_xyz[3 * j + k]; d2 += d * d; }
+      h->ii_energy += sys->atom_charge[i] * sys->atom_charge[j] / std::sqrt(d2);
+    }
+  if (h->has_slater) {
+    S.nshell = sys->nshell; S.nprim = sys->nprim; S.nao = sys->nao;
+    for (int s = 0; s < sys->nshell; ++s) {
+      if (sys->shell_l[s] < 0 || sys->shell_l[s] > 3) FAIL("only s,p,d,f shells (l <= 3) are implemented");
+      h->shell_l.push_back(sys->shell_l[s]);
+      h->shell_np.push_back(sys->shell_prim_off[s + 1] - sys->shell_prim_off[s]);
+      h->shell_ao.push_back(sys->shell_ao_off[s]);
+    }
+    TRY(upload_table(h, sys->shell_atom, (size_t)sys->nshell, &tmp_i)); S.shell_atom = tmp_i;
+    TRY(upload_table(h, sys->shell_l, (size_t)sys->nshell, &tmp_i)); S.shell_l = tmp_i;
+    TRY(upload_table(h, sys->shell_prim_off, (size_t)sys->nshell + 1, &tmp_i)); S.shell_prim_off = tmp_i;
+    TRY(upload_table(h, sys->shell_ao_off, (size_t)sys->nshell, &tmp_i)); S.shell_ao_off = tmp_i;
+    TRY(upload_table(h, sys->prim_exp, (size_t)sys->nprim, &tmp_d)); S.prim_exp = tmp_d;
+    TRY(upload_table(h, sys->prim_coef, (size_t)sys->nprim, &tmp_d)); S.prim_coef = tmp_d;
+    h->nmo[0] = sys->nmo_up; h->nmo[1] = sys->nmo_dn;
+    h->ndet = sys->ndet; h->ndet_s[0] = sys->ndet_up; h->ndet_s[1] = sys->ndet_dn;
+    S.ndet = h->ndet;
+    const int* occ_src[2] = {sys->det_occ_up, sys->det_occ_dn};
+    const double* mo_src[2] = {sys->mo_up, sys->mo_dn};
+    const int nel[2] = {h->nup, h->ndn};
+    build_chunks(h, 16, h->chunks[0]);
+    build_chunks(h, 32, h->chunks[1]);
+    for (int s = 0; s < 2; ++s) {
+      if (h->nmo[s] > 64) FAIL("more than 64 orbitals per spin are not supported by the contraction tiles");
+      const int nt = (h->nmo[s] + 15) / 16;
+      h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+      S.nmo[s] = h->nmo[s]; S.ndet_s[s] = h->ndet_s[s];
+      TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
+      TRY(upload_table<double>(h, nullptr, (size_t)h->nao * std::max(h->nmo[s], 1), &h->d_mo[s])); S.mo[s] = h->d_mo[s];
+      for (int t = 0; t < 2; ++t)
+        TRY(upload_table<double>(h, nullptr, (size_t)std::max(h->chunks[t].rows_pad, 1) * 16 * h->nt[s], &h->d_cpad[t][s]));
+      if (h->nmo[s] > 0) TRY(set_mo(h, s, mo_src[s]));
+    }
+    TRY(upload_table(h, sys->det_coeff, (size_t)h->ndet, &h->d_detcoeff)); S.det_coeff = h->d_detcoeff;
+    TRY(upload_table(h, sys->det_map, (size_t)2 * h->ndet, &tmp_i)); S.det_map = tmp_i;
+    for (int t = 0; t < 2; ++t) {
+      const ChunkHost& c = h->chunks[t];
+      ChunkTab& T = h->tab[t];
+      T.nchunk = (int)c.nk.size();
+      TRY(upload_table(h, c.nk.data(), c.nk.size(), &tmp_i)); T.chunk_nk = tmp_i;
+      TRY(upload_table(h, c.ao0.data(), c.ao0.size(), &tmp_i)); T.chunk_ao0 = tmp_i;
+      TRY(upload_table(h, c.row0.data(), c.row0.size(), &tmp_i)); T.chunk_row0 = tmp_i;
+      TRY(upload_table(h, c.cw_off.data(), c.cw_off.size(), &tmp_i)); T.cw_off = tmp_i;
+      TRY(upload_table(h, c.cw_shell.data(), c.cw_shell.size(), &tmp_i)); T.cw_shell = tmp_i;
+      for (int s = 0; s < 2; ++s) { T.cpad[s] = h->d_cpad[t][s]; T.ldc[s] = 16 * h->nt[s]; }
+    }
+  }
+  S.na = h->na; S.nb = h->nb; S.rcut_a = sys->rcut_a; S.rcut_b = sys->rcut_b;
+  for (int k = 0; k < h->na; ++k) { S.a_kind[k] = sys->a_kind[k]; S.a_param[k] = sys->a_param[k]; }
+  for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; }
+  TRY(upload_table(h, sys->acoeff, (size_t)h->natom * h->na * 2, &h->d_acoeff)); S.acoeff = h->d_acoeff;
+  TRY(upload_table(h, sys->bcoeff, (size_t)h->nb * 3, &h->d_bcoeff)); S.bcoeff = h->d_bcoeff;
+  S.necp = h->necp;
+  if (h->necp > 0) {
+    const int nchan = sys->ecp_chan_off[h->necp];
+    const int nterm = sys->ecp_term_off[nchan];
+    for (int k = 0; k < h->necp; ++k)
+      if (sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k] > PQA_MAXCHAN) FAIL("ECP with more than 4 non-local channels");
+    TRY(upload_table(h, sys->ecp_atom, (size_t)h->necp, &tmp_i)); S.ecp_atom = tmp_i;
+    TRY(upload_table(h, sys->ecp_chan_off, (size_t)h->necp + 1, &tmp_i)); S.ecp_chan_off = tmp_i;
+    TRY(upload_table(h, sys->ecp_term_off, (size_t)nchan + 1, &tmp_i)); S.ecp_term_off = tmp_i;
+    TRY(upload_table(h, sys->ecp_term_n, (size_t)nterm, &tmp_i)); S.ecp_term_n = tmp_i;
+    TRY(upload_table(h, sys->ecp_term_exp, (size_t)nterm, &tmp_d)); S.ecp_term_exp = tmp_d;
+    TRY(upload_table(h, sys->ecp_term_coef, (size_t)nterm, &tmp_d)); S.ecp_term_coef = tmp_d;
+  }
+  // quadrature directions (eval_ecp.py:278-336): octahedral 6, icosahedral 12
+  std::vector<double> quad;
+  const double oa[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
+  for (auto& p : oa) quad.insert(quad.end(), p, p + 3);
+  {
+    const double b1 = std::atan(2.0), pi = std::acos(-1.0);
+    std::vector<double> th = {0.0, pi}, ph = {0.0, 0.0};
+    for (int k = 0; k < 10; ++k) { th.push_back(k % 2 == 0 ? b1 : pi - b1); ph.push_back(k * pi / 5.0); }
+    for (int i = 0; i < 12; ++i) {
+      quad.push_back(std::sin(th[i]) * std::cos(ph[i]));
+      quad.push_back(std::sin(th[i]) * std::sin(ph[i]));
+      quad.push_back(std::cos(th[i]));
+    }
+  }
+  TRY(upload_table(h, quad.data(), quad.size(), &h->d_quad));
+  return 0;
+}
+
+extern "C" int pqa_create(const pqa_system_t* sys, int device, pqa_handle_t** out) {
+  *out = nullptr;
+  pqa_handle* h = new pqa_handle();
+  h->device = device;
+  int rc = create_impl(h, sys);
+  if (rc) {
+    g_create_error = h->err;
+    pqa_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" void pqa_destroy(pqa_handle_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->owned) (void)hipFree(p);
+  DevBuf* bufs[] = {&h->b_x, &h->b_T[0], &h->b_T[1], &h->b_dsign[0], &h->b_dsign[1], &h->b_dlog[0], &h->b_dlog[1],
+                    &h->b_cache[0], &h->b_cache[1], &h->b_aval, &h->b_bval, &h->b_pts, &h->b_motmp, &h->b_out, &h->b_widx,
+                    &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt,
+                    &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
+                    &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp};
+  for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+// ---------------------------------------------------------------- parameters
+extern "C" int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const std::string k(name);
+  auto expect = [&](int64_t want) { return n == want; };
+  if (k == "acoeff") {
+    if (!expect((int64_t)h->natom * h->na * 2)) FAIL("acoeff size mismatch");
+    HIPCHK(hipMemcpy(h->d_acoeff, data, n * sizeof(double), hipMemcpyDefault));
+  } else if (k == "bcoeff") {
+    if (!expect((int64_t)h->nb * 3)) FAIL("bcoeff size mismatch");
+    HIPCHK(hipMemcpy(h->d_bcoeff, data, n * sizeof(double), hipMemcpyDefault));
+  } else if (k == "det_coeff") {
+    if (!h->has_slater || !expect(h->ndet)) FAIL("det_coeff size mismatch");
+    HIPCHK(hipMemcpy(h->d_detcoeff, data, n * sizeof(double), hipMemcpyDefault));
+  } else if (k == "mo_coeff_alpha" || k == "mo_coeff_beta") {
+    const int s = k == "mo_coeff_beta";
+    if (!h->has_slater || !expect((int64_t)h->nao * h->nmo[s])) FAIL("mo_coeff size mismatch");
+    std::vector<double> host((size_t)n);
+    HIPCHK(hipMemcpy(host.data(), data, n * sizeof(double), hipMemcpyDefault));
+    TRY(set_mo(h, s, host.data()));
+  } else
+    FAIL("unknown parameter name");
+  h->saved_valid = false;
+  return 0;
+}
+
+extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int64_t n) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const std::string k(name);
+  const double* src = nullptr;
+  int64_t want = 0;
+  if (k == "acoeff") { src = h->d_acoeff; want = (int64_t)h->natom * h->na * 2; }
+  else if (k == "bcoeff") { src = h->d_bcoeff; want = (int64_t)h->nb * 3; }
+  else if (k == "det_coeff") { src = h->d_detcoeff; want = h->ndet; }
+  else if (k == "mo_coeff_alpha") { src = h->d_mo[0]; want = (int64_t)h->nao * h->nmo[0]; }
+  else if (k == "mo_coeff_beta") { src = h->d_mo[1]; want = (int64_t)h->nao * h->nmo[1]; }
+  else FAIL("unknown parameter name");
+  if (n != want) FAIL("parameter size mismatch");
+  HIPCHK(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+// ---------------------------------------------------------------- orbital kernel launch
+template <int NCOMP, int KC>
+static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+  const dim3 grid((unsigned)((P + 63) / 64)), block(256);
+  switch (h->nt[spin]) {
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+  }
+}
+
+// out[p][ncomp][nmo_spin]
+static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
+  if (P <= 0 || h->nmo[spin] == 0) return 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profile) {
+    if (h->prof_used == h->prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      h->prof_events.emplace_back(a, b);
+    }
+    e0 = h->prof_events[h->prof_used].first;
+    e1 = h->prof_events[h->prof_used].second;
+    ++h->prof_used;
+    HIPCHK(hipEventRecord(e0, h->stream));
+  }
+  if (ncomp == 5) launch_orb_t<5, 16>(h, 0, spin, pa, P, out);
+  else if (ncomp == 1) launch_orb_t<1, 32>(h, 1, spin, pa, P, out);
+  else FAIL("orbital kernel supports ncomp 1 or 5");
+  TRY(check_launch(h, "k_orb"));
+  if (h->profile) {
+    HIPCHK(hipEventRecord(e1, h->stream));
+    h->prof_launches += 1;
+    h->prof_pc += (double)P * ncomp;
+  }
+  return 0;
+}
+
+static PointAddr plain_points(const double* base, long P) {
+  PointAddr pa;
+  pa.base = base;
+  pa.group = (int)std::max<long>(P, 1);
+  pa.group_stride = 0;
+  return pa;
+}
+
+extern "C" int pqa_eval_ao(pqa_handle_t* h, const double* pts, int64_t npts, int ncomp, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater) FAIL("handle has no orbital tables");
+  if (ncomp != 1 && ncomp != 4 && ncomp != 5) FAIL("ncomp must be 1, 4 or 5");
+  if (npts <= 0) return 0;
+  const size_t nout = (size_t)ncomp * npts * h->nao;
+  TRY(ensure(h, h->b_pts, (size_t)npts * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_ao, nout * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)npts * 3 * sizeof(double)));
+  const dim3 grid((unsigned)((npts + 63) / 64)), block(64);
+  if (ncomp == 1) hipLaunchKernelGGL(k_ao<1>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  else if (ncomp == 4) hipLaunchKernelGGL(k_ao<4>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  else hipLaunchKernelGGL(k_ao<5>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  TRY(check_launch(h, "k_ao"));
+  return copy_out(h, out, h->b_ao.p, nout * sizeof(double));
+}
+
+extern "C" int pqa_eval_mo(pqa_handle_t* h, int spin, const double* pts, int64_t npts, int ncomp, int use_mfma, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater) FAIL("handle has no orbital tables");
+  if (ncomp != 1 && ncomp != 5) FAIL("ncomp must be 1 or 5");
+  if (spin < 0 || spin > 1) FAIL("spin must be 0 or 1");
+  if (npts <= 0 || h->nmo[spin] == 0) return 0;
+  const int nmo = h->nmo[spin];
+  const size_t nout = (size_t)ncomp * npts * nmo;
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_pts, (size_t)npts * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_out, nout * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)npts * 3 * sizeof(double)));
+  std::vector<double> host(nout);
+  if (use_mfma) {
+    TRY(ensure(h, h->b_motmp, nout * sizeof(double)));
+    TRY(launch_orb(h, spin, plain_points((const double*)h->b_pts.p, npts), npts, ncomp, (double*)h->b_motmp.p));
+    TRY(copy_out(h, host.data(), h->b_motmp.p, nout * sizeof(double)));
+    std::vector<double> tr(nout);  // [p][c][j] -> [c][p][j]
+    for (int64_t p = 0; p < npts; ++p)
+      for (int c = 0; c < ncomp; ++c)
+        memcpy(&tr[((size_t)c * npts + p) * nmo], &host[((size_t)p * ncomp + c) * nmo], nmo * sizeof(double));
+    HIPCHK(hipMemcpy(out, tr.data(), nout * sizeof(double), hipMemcpyDefault));
+    return 0;
+  }
+  const size_t nao_out = (size_t)ncomp * npts * h->nao;
+  TRY(ensure(h, h->b_ao, nao_out * sizeof(double)));
+  const dim3 grid((unsigned)((npts + 63) / 64)), block(64);
+  if (ncomp == 1) hipLaunchKernelGGL(k_ao<1>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  else hipLaunchKernelGGL(k_ao<5>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  const long rows = (long)ncomp * npts;
+  hipLaunchKernelGGL(k_mo_valu, dim3((unsigned)((rows * nmo + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p,
+                     (const double*)h->d_mo[spin], rows, h->nao, nmo, (double*)h->b_out.p);
+  TRY(check_launch(h, "k_mo_valu"));
+  return copy_out(h, out, h->b_out.p, nout * sizeof(double));
+}
+
+// ---------------------------------------------------------------- walker state allocation
+static int ensure_walkers(pqa_handle* h, long W) {
+  if (W <= 0) FAIL("number of walkers must be positive");
+  h->W = W;
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_x, (size_t)W * h->N * 3 * sizeof(double)));
+  h->js.x = (double*)h->b_x.p;
+  if (h->has_slater) {
+    const int nel[2] = {h->nup, h->ndn};
+    for (int s = 0; s < 2; ++s) {
+      const size_t D = h->ndet_s[s], n = nel[s];
+      TRY(ensure(h, h->b_T[s], W * D * n * n * sizeof(double)));
+      TRY(ensure(h, h->b_dsign[s], W * D * sizeof(double)));
+      TRY(ensure(h, h->b_dlog[s], W * D * sizeof(double)));
+      TRY(ensure(h, h->b_cache[s], W * n * 5 * h->nmo[s] * sizeof(double)));
+      h->st.T[s] = (double*)h->b_T[s].p;
+      h->st.dsign[s] = (double*)h->b_dsign[s].p;
+      h->st.dlog[s] = (double*)h->b_dlog[s].p;
+      h->st.cache[s] = (double*)h->b_cache[s].p;
+    }
+  }
+  if (h->has_jastrow) {
+    TRY(ensure(h, h->b_aval, (size_t)W * h->natom * h->na * 2 * sizeof(double)));
+    TRY(ensure(h, h->b_bval, (size_t)W * h->nb * 3 * sizeof(double)));
+    h->js.avalues = (double*)h->b_aval.p;
+    h->js.bvalues = (double*)h->b_bval.p;
+  }
+  TRY(ensure(h, h->b_sign, W * sizeof(double)));
+  TRY(ensure(h, h->b_log, W * sizeof(double)));
+  TRY(ensure(h, h->b_ju, W * sizeof(double)));
+  TRY(ensure(h, h->b_mask, W));
+  return 0;
+}
+
+static size_t lds_sm(const pqa_handle* h) {
+  const size_t n = std::max(h->nup, h->ndn);
+  return (n * (n + 1) + 2 * n) * sizeof(double) + 64 * sizeof(int);
+}
+static size_t lds_det(const pqa_handle* h, int ncomp) {
+  return (size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double);
+}
+
+static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants from js.x
+  const int nel[2] = {h->nup, h->ndn};
+  for (int s = 0; s < 2; ++s) {
+    if (nel[s] == 0) continue;
+    PointAddr pa;
+    pa.base = h->js.x + (size_t)(s ? h->nup : 0) * 3;
+    pa.group = nel[s];
+    pa.group_stride = (long)h->N * 3;
+    TRY(launch_orb(h, s, pa, h->W * nel[s], 5, h->st.cache[s]));
+    const size_t lds = ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
+    hipLaunchKernelGGL(k_build_invert, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
+    TRY(check_launch(h, "k_build_invert"));
+  }
+  return 0;
+}
+
+static int slater_value_dev(pqa_handle* h) {
+  hipLaunchKernelGGL(k_slater_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
+  return check_launch(h, "k_slater_value");
+}
+
+extern "C" int pqa_slater_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater) FAIL("handle has no Slater factor");
+  if (!h->has_jastrow || h->W != W) {
+    TRY(ensure_walkers(h, W));
+    TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
+    TRY(slater_rebuild(h));
+  } else {
+    // the Jastrow factor owns the stored walker coordinates; evaluate from a scratch copy
+    h->saved_valid = false;
+    double* keep = h->js.x;
+    TRY(ensure(h, h->b_pts, (size_t)W * h->N * 3 * sizeof(double)));
+    TRY(copy_in(h, h->b_pts.p, configs, (size_t)W * h->N * 3 * sizeof(double)));
+    h->js.x = (double*)h->b_pts.p;
+    int rc = slater_rebuild(h);
+    h->js.x = keep;
+    if (rc) return rc;
+  }
+  return pqa_slater_value(h, sign, logabs);
+}
+
+extern "C" int pqa_slater_value(pqa_handle_t* h, double* sign, double* logabs) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  TRY(slater_value_dev(h));
+  TRY(copy_in(h, sign, h->b_sign.p, h->W * sizeof(double)));
+  return copy_out(h, logabs, h->b_log.p, h->W * sizeof(double));
+}
+
+extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                               int ncomp, int keep_saved, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  if (ncomp != 1 && ncomp != 5) FAIL("ncomp must be 1 or 5");
+  if (nrow <= 0 || npt <= 0) return 0;
+  if (!widx && nrow != h->W) FAIL("nrow must equal the number of walkers when widx is NULL");
+  const int s = e >= h->nup, nmo = h->nmo[s];
+  const long P = nrow * npt;
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_pts, (size_t)P * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_motmp, (size_t)P * ncomp * nmo * sizeof(double)));
+  TRY(ensure(h, h->b_out, (size_t)P * ncomp * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)P * 3 * sizeof(double)));
+  const int* dw = nullptr;
+  if (widx) {
+    TRY(ensure(h, h->b_widx, (size_t)nrow * sizeof(int)));
+    TRY(copy_in(h, h->b_widx.p, widx, (size_t)nrow * sizeof(int)));
+    dw = (const int*)h->b_widx.p;
+  }
+  TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, P), P, ncomp, (double*)h->b_motmp.p));
+  const dim3 grid((unsigned)nrow), block(64);
+  if (ncomp == 1)
+    hipLaunchKernelGGL(k_slater_eval<1>, grid, block, lds_det(h, 1), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                       (long)nrow, npt, dw, (double*)h->b_out.p);
+  else
+    hipLaunchKernelGGL(k_slater_eval<5>, grid, block, lds_det(h, 5), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                       (long)nrow, npt, dw, (double*)h->b_out.p);
+  TRY(check_launch(h, "k_slater_eval"));
+  TRY(copy_out(h, out, h->b_out.p, (size_t)P * ncomp * sizeof(double)));
+  if (keep_saved && npt == 1 && !widx && ncomp == 5) { h->saved_valid = true; h->saved_e = e; }
+  return 0;
+}
+
+extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  TRY(ensure(h, h->b_flag, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->b_flag.p, 0, sizeof(int), h->stream));
+  const long count = h->W * h->ndet_s[spin];
+  hipLaunchKernelGGL(k_has_zero, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->st.dlog[spin], count, (int*)h->b_flag.p);
+  TRY(check_launch(h, "k_has_zero"));
+  return copy_out(h, flag, h->b_flag.p, sizeof(int));
+}
+
+extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  const int s = e >= h->nup, nmo = h->nmo[s];
+  const long W = h->W;
+  if (!(use_saved && h->saved_valid && h->saved_e == e)) {
+    TRY(ensure(h, h->b_pts, (size_t)W * 3 * sizeof(double)));
+    TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo * sizeof(double)));
+    TRY(copy_in(h, h->b_pts.p, epos, (size_t)W * 3 * sizeof(double)));
+    TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, W), W, 5, (double*)h->b_motmp.p));
+  }
+  h->saved_valid = false;
+  const uint8_t* dm = nullptr;
+  if (mask) {
+    TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
+    dm = (const uint8_t*)h->b_mask.p;
+  }
+  hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                     5 * nmo, dm, 1);
+  TRY(check_launch(h, "k_sm_update"));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, double* dets) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  const size_t W = h->W, D = h->ndet_s[spin], n = spin ? h->ndn : h->nup;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (inverse) {
+    std::vector<double> T(W * D * n * n), inv(W * D * n * n);
+    HIPCHK(hipMemcpy(T.data(), h->st.T[spin], T.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t m = 0; m < W * D; ++m)
+      for (size_t i = 0; i < n; ++i)
+        for (size_t k = 0; k < n; ++k) inv[(m * n + k) * n + i] = T[(m * n + i) * n + k];
+    HIPCHK(hipMemcpy(inverse, inv.data(), inv.size() * sizeof(double), hipMemcpyDefault));
+  }
+  if (dets) {
+    std::vector<double> d(2 * W * D);
+    HIPCHK(hipMemcpy(d.data(), h->st.dsign[spin], W * D * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d.data() + W * D, h->st.dlog[spin], W * D * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dets, d.data(), d.size() * sizeof(double), hipMemcpyDefault));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- Jastrow
+extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_jastrow) FAIL("handle has no Jastrow factor");
+  if (h->W != W) TRY(ensure_walkers(h, W));
+  TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
+  hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
+  TRY(check_launch(h, "k_jastrow_recompute"));
+  return pqa_jastrow_value(h, logval);
+}
+
+extern "C" int pqa_jastrow_value(pqa_handle_t* h, double* logval) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
+  TRY(check_launch(h, "k_jastrow_value"));
+  return copy_out(h, logval, h->b_ju.p, h->W * sizeof(double));
+}
+
+extern "C" int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                                int mode, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  if (mode < 0 || mode > 2 || (mode > 0 && npt != 1)) FAIL("bad mode / npt combination");
+  if (nrow <= 0 || npt <= 0) return 0;
+  if (!widx && nrow != h->W) FAIL("nrow must equal the number of walkers when widx is NULL");
+  const long P = nrow * npt;
+  const size_t nout = mode == 0 ? (size_t)P : (size_t)4 * nrow;
+  TRY(ensure(h, h->b_pts, (size_t)P * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_out, nout * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)P * 3 * sizeof(double)));
+  const int* dw = nullptr;
+  if (widx) {
+    TRY(ensure(h, h->b_widx, (size_t)nrow * sizeof(int)));
+    TRY(copy_in(h, h->b_widx.p, widx, (size_t)nrow * sizeof(int)));
+    dw = (const int*)h->b_widx.p;
+  }
+  hipLaunchKernelGGL(k_jastrow_eval, dim3((unsigned)nrow), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_pts.p,
+                     (long)nrow, npt, dw, mode, (double*)h->b_out.p);
+  TRY(check_launch(h, "k_jastrow_eval"));
+  return copy_out(h, out, h->b_out.p, nout * sizeof(double));
+}
+
+extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  const long W = h->W;
+  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
+  TRY(copy_in(h, h->b_newpos.p, epos, (size_t)W * 3 * sizeof(double)));
+  const uint8_t* dm = nullptr;
+  if (mask) {
+    TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
+    dm = (const uint8_t*)h->b_mask.p;
+  }
+  hipLaunchKernelGGL(k_jastrow_update, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_newpos.p, dm);
+  TRY(check_launch(h, "k_jastrow_update"));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (avalues && h->has_jastrow) HIPCHK(hipMemcpy(avalues, h->js.avalues, (size_t)h->W * h->natom * h->na * 2 * sizeof(double), hipMemcpyDefault));
+  if (bvalues && h->has_jastrow) HIPCHK(hipMemcpy(bvalues, h->js.bvalues, (size_t)h->W * h->nb * 3 * sizeof(double), hipMemcpyDefault));
+  if (configs) HIPCHK(hipMemcpy(configs, h->js.x, (size_t)h->W * h->N * 3 * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused path
+static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
+  const long W = h->W;
+  std::vector<double> sg(W, 1.0), lg(W, 0.0), ju(W, 0.0);
+  if (h->has_slater) {
+    TRY(slater_value_dev(h));
+    TRY(copy_in(h, sg.data(), h->b_sign.p, W * sizeof(double)));
+    TRY(copy_in(h, lg.data(), h->b_log.p, W * sizeof(double)));
+  }
+  if (h->has_jastrow) {
+    hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
+    TRY(check_launch(h, "k_jastrow_value"));
+    TRY(copy_in(h, ju.data(), h->b_ju.p, W * sizeof(double)));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (long w = 0; w < W; ++w) lg[w] += ju[w];
+  if (sign) HIPCHK(hipMemcpy(sign, sg.data(), W * sizeof(double), hipMemcpyDefault));
+  if (logabs) HIPCHK(hipMemcpy(logabs, lg.data(), W * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  HIPCHK(hipSetDevice(h->device));
+  TRY(ensure_walkers(h, W));
+  TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
+  if (h->has_slater) TRY(slater_rebuild(h));
+  if (h->has_jastrow) {
+    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
+    TRY(check_launch(h, "k_jastrow_recompute"));
+  }
+  return wf_value_host(h, sign, logabs);
+}
+
+extern "C" int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  return wf_value_host(h, sign, logabs);
+}
+
+extern "C" int pqa_get_configs(pqa_handle_t* h, double* configs) { return pqa_jastrow_get_state(h, nullptr, nullptr, configs); }
+
+// energy of the resident walkers into device buffer b_en (6,W)
+static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step) {
+  const long W = h->W;
+  TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
+  TRY(ensure(h, h->b_en, (size_t)6 * W * sizeof(double)));
+  hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
+                     (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
+  TRY(check_launch(h, "k_kinetic_coulomb"));
+  const double* d_ecp = nullptr;
+  h->last_ecp_points = 0;
+  if (h->necp > 0) {
+    const size_t nrot = (size_t)h->N * h->necp;
+    TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
+    if (rot) TRY(copy_in(h, h->b_rot.p, rot, nrot * 9 * sizeof(double)));
+    else {
+      hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed, step, (double*)h->b_rot.p);
+      TRY(check_launch(h, "k_gen_rot"));
+    }
+    EcpBuf B{};
+    B.rot = (const double*)h->b_rot.p;
+    if (unif) {
+      TRY(ensure(h, h->b_eunif, nrot * W * sizeof(double)));
+      TRY(copy_in(h, h->b_eunif.p, unif, nrot * W * sizeof(double)));
+      B.unif = (const double*)h->b_eunif.p;
+    }
+    B.quad = h->d_quad; B.seed = seed; B.step = step; B.threshold = threshold;
+    TRY(ensure(h, h->b_elocal, W * sizeof(double)));
+    TRY(ensure(h, h->b_ecnt, 2 * W * sizeof(int)));
+    TRY(ensure(h, h->b_eoff, 2 * (W + 1) * sizeof(long)));
+    TRY(ensure(h, h->b_ecp, W * sizeof(double)));
+    B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
+    hipLaunchKernelGGL(k_ecp_count, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
+    TRY(check_launch(h, "k_ecp_count/k_scan2"));
+    long tot[2];
+    TRY(copy_in(h, &tot[0], B.off + W, sizeof(long)));
+    TRY(copy_out(h, &tot[1], B.off + (W + 1) + W, sizeof(long)));
+    h->last_ecp_points = tot[0] + tot[1];
+    for (int s = 0; s < 2; ++s) {
+      const size_t n = (size_t)std::max<long>(tot[s], 1);
+      TRY(ensure(h, h->b_epts[s], n * 3 * sizeof(double)));
+      TRY(ensure(h, h->b_ewgt[s], n * sizeof(double)));
+      TRY(ensure(h, h->b_epte[s], n * sizeof(int)));
+      TRY(ensure(h, h->b_emo[s], n * std::max(h->nmo[s], 1) * sizeof(double)));
+      B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
+    }
+    if (tot[0] + tot[1] > 0) {
+      hipLaunchKernelGGL(k_ecp_fill, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+      TRY(check_launch(h, "k_ecp_fill"));
+      if (h->has_slater)
+        for (int s = 0; s < 2; ++s)
+          TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
+    }
+    hipLaunchKernelGGL(k_ecp_accum, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                       (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+    TRY(check_launch(h, "k_ecp_accum"));
+    d_ecp = (const double*)h->b_ecp.p;
+  }
+  hipLaunchKernelGGL(k_energy_assemble, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
+                     h->ii_energy, W, (double*)h->b_en.p);
+  return check_launch(h, "k_energy_assemble");
+}
+
+extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
+  h->saved_valid = false;
+  TRY(energy_dev(h, threshold, rot, unif, seed, 0u));
+  return copy_out(h, out, h->b_en.p, (size_t)6 * h->W * sizeof(double));
+}
+
+extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif, double threshold,
+                              const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
+                              double* energy_mean, uint8_t* accept_rec) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
+  if (nsteps <= 0) return 0;
+  const long W = h->W;
+  const int N = h->N;
+  h->saved_valid = false;
+  const int nmo_max = std::max(h->nmo[0], h->nmo[1]);
+  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_aux, (size_t)W * 8 * sizeof(double)));
+  TRY(ensure(h, h->b_accept, (size_t)W));
+  TRY(ensure(h, h->b_acccnt, (size_t)nsteps * sizeof(int)));
+  TRY(ensure(h, h->b_motmp, (size_t)W * 5 * std::max(nmo_max, 1) * sizeof(double)));
+  TRY(ensure(h, h->b_means, (size_t)nsteps * 6 * sizeof(double)));
+  HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * sizeof(int), h->stream));
+  if (gauss) TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
+  if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
+  if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
+  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  const size_t nrot = (size_t)N * std::max(h->necp, 1);
+  for (int step = 0; step < nsteps; ++step) {
+    MoveBuf mb{};
+    mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
+    mb.acc_count = (int*)h->b_acccnt.p + step; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
+    if (gauss) {
+      TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
+      mb.gauss = (const double*)h->b_gauss.p;
+    }
+    if (unif) {
+      TRY(copy_in(h, h->b_unif.p, unif + (size_t)step * N * W, (size_t)N * W * sizeof(double)));
+      mb.unif = (const double*)h->b_unif.p;
+    }
+    if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
+    for (int e = 0; e < N; ++e) {
+      const int s = e >= h->nup;
+      hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+                         (int)h->has_slater, (int)h->has_jastrow, W);
+      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+      hipLaunchKernelGGL(k_accept, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
+                         (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+    }
+    TRY(check_launch(h, "k_propose/k_accept"));
+    if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
+    if (energy_mean) {
+      TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
+                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step));
+      hipLaunchKernelGGL(k_row_means, dim3(6), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * 6);
+      TRY(check_launch(h, "k_row_means"));
+    }
+  }
+  std::vector<int> cnt(nsteps);
+  TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));
+  if (acceptance) {
+    std::vector<double> acc(nsteps);
+    for (int i = 0; i < nsteps; ++i) acc[i] = (double)cnt[i] / ((double)W * N);
+    HIPCHK(hipMemcpy(acceptance, acc.data(), nsteps * sizeof(double), hipMemcpyDefault));
+  }
+  if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * 6 * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+// ---------------------------------------------------------------- measurement
+extern "C" int pqa_sync(pqa_handle_t* h) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int pqa_timer_start(pqa_handle_t* h) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+extern "C" int pqa_timer_stop(pqa_handle_t* h, double* elapsed_ms) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *elapsed_ms = ms;
+  return 0;
+}
+extern "C" int pqa_profile_enable(pqa_handle_t* h, int enable) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->profile = enable != 0;
+  h->prof_used = 0; h->prof_launches = 0; h->prof_ms = 0.0; h->prof_pc = 0.0;
+  return 0;
+}
+extern "C" int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, double* point_comps) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof_events[i].first, h->prof_events[i].second));
+    h->prof_ms += ms;
+  }
+  h->prof_used = 0;
+  if (launches) *launches = h->prof_launches;
+  if (total_ms) *total_ms = h->prof_ms;
+  if (point_comps) *point_comps = h->prof_pc;
+  return 0;
+}
+extern "C" int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints) {
+  *npoints = h->last_ecp_points;
+  return 0;
+}

@@ -1,0 +1,105 @@
+// pyqmc_amd device-side common definitions (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PQA_WAVE 64
+#define PQA_MAXBAS 8      // max Jastrow basis functions per kind
+#define PQA_MAXN 64       // max electrons per spin handled by one wave (LU / Sherman-Morrison tile)
+#define PQA_MAXCHAN 5     // ECP channels per atom incl. local
+#define PQA_MAXAIP 12
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Device view of the system tables (all pointers are device memory).
+struct SysDev {
+  int natom, nup, ndn, nelec;
+  const double* atom_xyz;
+  const double* atom_charge;
+  int nshell, nprim, nao;
+  const int* shell_atom;
+  const int* shell_l;
+  const int* shell_prim_off;
+  const int* shell_ao_off;
+  const double* prim_exp;
+  const double* prim_coef;
+  int nmo[2];
+  const double* mo[2];  // [ao][nmo]
+  int ndet, ndet_s[2];
+  const double* det_coeff;
+  const int* det_occ[2];  // [ndet_s][n_s]
+  const int* det_map;     // [2][ndet]
+  int na, nb;
+  int a_kind[PQA_MAXBAS];
+  double a_param[PQA_MAXBAS];
+  int b_kind[PQA_MAXBAS];
+  double b_param[PQA_MAXBAS];
+  double rcut_a, rcut_b;
+  const double* acoeff;  // [natom][na][2]
+  const double* bcoeff;  // [nb][3]
+  int necp;
+  const int* ecp_atom;
+  const int* ecp_chan_off;
+  const int* ecp_term_off;
+  const int* ecp_term_n;
+  const double* ecp_term_exp;
+  const double* ecp_term_coef;
+  int ecp_naip_max;
+};
+
+// ---------------------------------------------------------------- wave-level reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, PQA_WAVE);
+  return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, PQA_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ double wave_bcast(double v, int lane) { return __shfl(v, lane, PQA_WAVE); }
+
+// ---------------------------------------------------------------- Philox4x32-10 counter RNG
+struct Philox {
+  uint32_t c[4];
+};
+__device__ __forceinline__ Philox philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * x0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * x2;
+    uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ k0;
+    uint32_t y1 = (uint32_t)p1;
+    uint32_t y2 = (uint32_t)(p0 >> 32) ^ x3 ^ k1;
+    uint32_t y3 = (uint32_t)p0;
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox o; o.c[0] = x0; o.c[1] = x1; o.c[2] = x2; o.c[3] = x3;
+  return o;
+}
+// uniform in (0,1) with 53 random bits
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
+  uint64_t b = (((uint64_t)hi << 32) | lo) >> 11;
+  return ((double)b + 0.5) * (1.0 / 9007199254740992.0);
+}
+// two standard normals from one Philox block (Box-Muller)
+__device__ __forceinline__ void normal2(const Philox& p, double& z0, double& z1) {
+  double u1 = u01(p.c[0], p.c[1]), u2 = u01(p.c[2], p.c[3]);
+  double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  z0 = r * c; z1 = r * s;
+}
+
+// RNG stream ids (third counter word) so the draws of different kernels never collide
+#define PQA_STREAM_GAUSS_A 1u
+#define PQA_STREAM_GAUSS_B 2u
+#define PQA_STREAM_ACCEPT 3u
+#define PQA_STREAM_ECPMASK 4u
+#define PQA_STREAM_ECPROT 5u

@@ -1,0 +1,289 @@
+// Local-energy kernels on device-resident walkers: kinetic + open-boundary Coulomb in one
+// per-walker pass, and the semi-local ECP integrator as a compact-list pipeline.
+//
+// Reference semantics: pyqmc/observables/energy.py (kinetic :57-65, ee/ei :28-45),
+// pyqmc/wf/multiplywf.py:121-129 (product Laplacian), pyqmc/observables/eval_ecp.py
+// (ecp :21-40, ecp_ea :83-132, ecp_mask :135-146, rnExp :182-200, P_l :203-225, get_P_l :228-252,
+// get_rot :255-275, grids :278-336), harness pyqmc/observables/accumulators.py:60-75.
+#pragma once
+#include "pqa_common.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_slater.hpp"
+
+// ---------------------------------------------------------------- kinetic + Coulomb
+// out rows: ke, ee, ei, grad2 each (W).  LDS: max(ndet_s)*5 doubles (multi-determinant scratch).
+__global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
+                                                        int has_jastrow, long W, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double ke = 0.0, grad2 = 0.0;
+  for (int e = 0; e < S.nelec; ++e) {
+    double gs[3] = {0.0, 0.0, 0.0}, ls = 0.0;
+    if (has_slater) {
+      const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+      double r[5];
+      slater_ratios<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
+      gs[0] = r[1] / r[0]; gs[1] = r[2] / r[0]; gs[2] = r[3] / r[0];
+      ls = r[4] / r[0];
+    }
+    double gj[3] = {0.0, 0.0, 0.0}, lj = 0.0, U;
+    if (has_jastrow) {
+      jas_eval<2>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U, gj, lj);
+      lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
+    }
+    const double gx = gs[0] + gj[0], gy = gs[1] + gj[1], gz = gs[2] + gj[2];
+    const double lap = ls + lj + 2.0 * (gs[0] * gj[0] + gs[1] * gj[1] + gs[2] * gj[2]);
+    ke += -0.5 * lap;
+    grad2 += gx * gx + gy * gy + gz * gz;
+  }
+  double ee = 0.0, ei = 0.0;
+  for (int i = 0; i < S.nelec; ++i) {
+    const double ix = xw[3 * i], iy = xw[3 * i + 1], iz = xw[3 * i + 2];
+    for (int j = i + 1 + lane; j < S.nelec; j += 64) {
+      const double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
+      ee += 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    for (int I = lane; I < S.natom; I += 64) {
+      const double dx = ix - S.atom_xyz[3 * I], dy = iy - S.atom_xyz[3 * I + 1], dz = iz - S.atom_xyz[3 * I + 2];
+      ei -= S.atom_charge[I] / sqrt(dx * dx + dy * dy + dz * dz);
+    }
+  }
+  ee = wave_sum(ee);
+  ei = wave_sum(ei);
+  if (lane == 0) { out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = grad2; }
+}
+
+// ---------------------------------------------------------------- ECP
+struct EcpBuf {
+  const double* rot;     // [N][necp][3][3]
+  const double* unif;    // [N][necp][W] or NULL -> Philox
+  const double* quad;    // [6+12][3] quadrature directions: rows 0-5 octahedral, 6-17 icosahedral
+  uint64_t seed;
+  uint32_t step;
+  double threshold;
+  double* local;         // [W] sum of local channels
+  int* cnt;              // [2][W] aux points per walker per spin
+  long* off;             // [2][W+1] exclusive scan of cnt
+  double* pts[2];        // [npts_s][3]
+  double* wgt[2];        // [npts_s]  sum_l (v_l/prob)(2l+1)P_l(cos) w_i
+  int* pte[2];           // [npts_s]  electron index of the point
+};
+
+__device__ __forceinline__ double legendre_l(int l, double x) {
+  switch (l) {
+    case 0: return 1.0;
+    case 1: return x;
+    case 2: return 0.5 * (3.0 * x * x - 1.0);
+    case 3: return 0.5 * (5.0 * x * x * x - 3.0 * x);
+    default: return 0.125 * (35.0 * x * x * x * x - 30.0 * x * x + 3.0);
+  }
+}
+
+// v_l(r) for every channel of ECP atom k (local channel last) and the acceptance probability
+__device__ __forceinline__ void ecp_radial(const SysDev& S, int k, double r, double threshold, double (&v)[PQA_MAXCHAN],
+                                           int& nch, double& prob) {
+  const int c0 = S.ecp_chan_off[k];
+  nch = S.ecp_chan_off[k + 1] - c0;
+  double pr = 0.0;
+  for (int c = 0; c < nch; ++c) {
+    double sum = 0.0;
+    for (int t = S.ecp_term_off[c0 + c]; t < S.ecp_term_off[c0 + c + 1]; ++t) {
+      const int n = S.ecp_term_n[t];
+      const double rn = (n == 0) ? 1.0 : ((n == -1) ? 1.0 / r : ((n == 1) ? r : ((n == -2) ? 1.0 / (r * r) : pow(r, (double)n))));
+      sum += rn * S.ecp_term_coef[t] * exp(-S.ecp_term_exp[t] * r * r);
+    }
+    v[c] = sum;
+    if (c < nch - 1) pr += fabs(sum) * threshold * (2.0 * (2 * c + 1) + 1.0);  // eval_ecp.py:139-141
+  }
+  prob = (threshold > 0.0) ? fmin(1.0, pr) : 1.0;
+}
+
+__device__ __forceinline__ bool ecp_pass(const SysDev& S, const EcpBuf& B, long w, long W, int e, int k, double prob) {
+  double u;
+  if (B.unif) u = B.unif[((size_t)e * S.necp + k) * W + w];
+  else {
+    const Philox p = philox(B.seed, (uint32_t)w, (uint32_t)(e * S.necp + k), PQA_STREAM_ECPMASK, B.step);
+    u = u01(p.c[0], p.c[1]);
+  }
+  return prob > u;
+}
+
+// pass A: local part + number of auxiliary points per spin.  grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, EcpBuf B, long W) {
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double loc = 0.0;
+  int c_up = 0, c_dn = 0;
+  for (int q = lane; q < S.nelec * S.necp; q += 64) {
+    const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
+    const double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
+                 dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double v[PQA_MAXCHAN], prob;
+    int nch;
+    ecp_radial(S, k, r, B.threshold, v, nch, prob);
+    loc += v[nch - 1];
+    if (nch > 1 && ecp_pass(S, B, w, W, e, k, prob)) {
+      const int naip = (nch <= 2) ? 6 : 12;
+      if (e < S.nup) c_up += naip; else c_dn += naip;
+    }
+  }
+  loc = wave_sum(loc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { c_up += __shfl_xor(c_up, off, 64); c_dn += __shfl_xor(c_dn, off, 64); }
+  if (lane == 0) { B.local[w] = loc; B.cnt[w] = c_up; B.cnt[W + w] = c_dn; }
+}
+
+// exclusive scan of cnt[2][W] -> off[2][W+1]; one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, long* __restrict__ off, long W) {
+  __shared__ long part[1024];
+  for (int s = 0; s < 2; ++s) {
+    const int* c = cnt + (size_t)s * W;
+    long* o = off + (size_t)s * (W + 1);
+    const long per = (W + 1023) / 1024;
+    const long b = (long)threadIdx.x * per, e = (b + per < W) ? b + per : W;
+    long sum = 0;
+    for (long i = b; i < e; ++i) sum += c[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long run = 0;
+      for (int t = 0; t < 1024; ++t) { const long v = part[t]; part[t] = run; run += v; }
+      o[W] = run;
+    }
+    __syncthreads();
+    long run = part[threadIdx.x];
+    for (long i = b; i < e; ++i) { o[i] = run; run += c[i]; }
+    __syncthreads();
+  }
+}
+
+// pass B: emit auxiliary points, per-point weights and electron index.  grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpBuf B, long W) {
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  long run[2] = {B.off[w], B.off[(W + 1) + w]};
+  for (int q0 = 0; q0 < S.nelec * S.necp; q0 += 64) {
+    const int q = q0 + lane;
+    bool pass = false;
+    if (q < S.nelec * S.necp) {
+      const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
+      const double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
+                   dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+      double v[PQA_MAXCHAN], prob;
+      int nch;
+      ecp_radial(S, k, sqrt(dx * dx + dy * dy + dz * dz), B.threshold, v, nch, prob);
+      pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
+    }
+    unsigned long long m = __ballot(pass);
+    while (m) {  // whole wave cooperates on one (electron, atom) entry at a time, in e-major order
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int qq = q0 + src;
+      const int e = qq / S.necp, k = qq % S.necp, ia = S.ecp_atom[k], s = e >= S.nup;
+      const double ax = S.atom_xyz[3 * ia], ay = S.atom_xyz[3 * ia + 1], az = S.atom_xyz[3 * ia + 2];
+      const double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      double v[PQA_MAXCHAN], prob;
+      int nch;
+      ecp_radial(S, k, r, B.threshold, v, nch, prob);
+      const int naip = (nch <= 2) ? 6 : 12;
+      if (lane < naip) {
+        const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
+        const double* R = B.rot + ((size_t)e * S.necp + k) * 9;
+        const double vx = R[0] * qd[0] + R[1] * qd[1] + R[2] * qd[2];
+        const double vy = R[3] * qd[0] + R[4] * qd[1] + R[5] * qd[2];
+        const double vz = R[6] * qd[0] + R[7] * qd[1] + R[8] * qd[2];
+        const double rix = r * vx, riy = r * vy, riz = r * vz;  // eval_ecp.py:242
+        const double cosv = (dx * rix + dy * riy + dz * riz) / (r * sqrt(rix * rix + riy * riy + riz * riz));
+        double wsum = 0.0;
+        for (int c = 0; c < nch - 1; ++c) wsum += (v[c] / prob) * (2 * c + 1) * legendre_l(c, cosv);
+        const long slot = run[s] + lane;
+        B.pts[s][3 * slot] = (xw[3 * e] - dx) + rix;  // eval_ecp.py:110
+        B.pts[s][3 * slot + 1] = (xw[3 * e + 1] - dy) + riy;
+        B.pts[s][3 * slot + 2] = (xw[3 * e + 2] - dz) + riz;
+        B.wgt[s][slot] = wsum * (1.0 / naip);
+        B.pte[s][slot] = e;
+      }
+      run[s] += naip;
+    }
+  }
+}
+
+// pass C: ecp[w] = local + sum_points weight * Psi(aux)/Psi.  mo[s]: [npts_s][nmo_s] orbital values.
+// LDS: max(ndet_s) doubles.
+__global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
+                                                  int has_jastrow, const double* __restrict__ mo_up,
+                                                  const double* __restrict__ mo_dn, long W, double* __restrict__ ecp) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double tot = 0.0;
+  for (int s = 0; s < 2; ++s) {
+    const double* mo = s ? mo_dn : mo_up;
+    const int nmo = S.nmo[s];
+    int last_e = -1;
+    double U0 = 0.0;
+    for (long p = B.off[(size_t)s * (W + 1) + w]; p < B.off[(size_t)s * (W + 1) + w + 1]; ++p) {
+      const int e = B.pte[s][p];
+      double ratio = 1.0;
+      if (has_slater) {
+        double r1[1];
+        slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
+        ratio = r1[0];
+      }
+      if (has_jastrow) {
+        double g[3], lp, U;
+        if (e != last_e) { jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp); last_e = e; }
+        jas_eval<0>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp);
+        ratio *= exp(U - U0);
+      }
+      tot += ratio * B.wgt[s][p];
+    }
+  }
+  if (threadIdx.x == 0) ecp[w] = B.local[w] + tot;
+}
+
+// uniformly random rotations from a normalised Gaussian quaternion (one per (electron, ECP atom))
+__global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __restrict__ rot) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count) return;
+  double q0, q1, q2, q3;
+  normal2(philox(seed, (uint32_t)idx, 0u, PQA_STREAM_ECPROT, step), q0, q1);
+  normal2(philox(seed, (uint32_t)idx, 1u, PQA_STREAM_ECPROT, step), q2, q3);
+  const double inv = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  const double w = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+  double* R = rot + 9 * (size_t)idx;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// total = ke + ee + ei + ecp + ii ; rows of out: ke, ee, ei, ecp, grad2, total  (accumulators.py:68-75)
+__global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2*/, const double* __restrict__ ecp,
+                                  double ii, long W, double* __restrict__ out) {
+  const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const double ke = kc[w], ee = kc[W + w], ei = kc[2 * W + w], g2 = kc[3 * W + w], ec = ecp ? ecp[w] : 0.0;
+  out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = ec; out[4 * W + w] = g2;
+  out[5 * W + w] = ke + ee + ei + ec + ii;
+}
+
+// deterministic column means of a (nrow, W) array: one block of 256 threads per row
+__global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a, long W, double* __restrict__ out) {
+  __shared__ double part[256];
+  const double* row = a + (size_t)blockIdx.x * W;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < W; i += 256) s += row[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0] / (double)W;
+}

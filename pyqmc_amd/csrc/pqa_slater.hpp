@@ -1,0 +1,284 @@
+// Slater-determinant kernels: one walker (and one unique spin determinant) per wavefront,
+// inverse tile staged in LDS.
+//
+// Reference semantics (pyqmc/wf/slater.py): recompute :227-260 (slogdet + inv per unique
+// determinant), value via determinant_tools.compute_value :74-88, row ratios
+// _testrow/_testrowderiv :301-380, Sherman-Morrison sherman_morrison_ms :88-94 inside
+// updateinternals :262-291.
+//
+// Storage differs from the reference on purpose: the inverse is kept ELECTRON-major,
+//   T[w][d][i][k] = inverse[w][d][k][i]   (k orbital slot, i electron),
+// so the column of the inverse needed for a ratio of electron i is one contiguous 8n-byte row.
+#pragma once
+#include <float.h>
+#include "pqa_common.hpp"
+
+struct SlaterState {
+  double* T[2];      // [W][ndet_s][n_s][n_s]
+  double* dsign[2];  // [W][ndet_s]
+  double* dlog[2];   // [W][ndet_s]
+  double* cache[2];  // [W][n_s][5][nmo_s]  MO value, grad, laplacian of every electron at its current position
+};
+
+__device__ __forceinline__ double clamp_nan_to_num(double v) {
+  if (v != v) return 0.0;
+  if (v > DBL_MAX) return DBL_MAX;
+  if (v < -DBL_MAX) return -DBL_MAX;
+  return v;
+}
+
+// ---------------------------------------------------------------- build + invert (recompute)
+// grid = W * ndet_s blocks of 64 threads; dynamic LDS: n*(n+1) doubles + n ints.
+// B[j][i] = mo(electron i, orbital occ[d][j]); T = B^{-1}, det(B) = det(reference matrix).
+__global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterState st, int s, long W) {
+  extern __shared__ double lds[];
+  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s], D = S.ndet_s[s];
+  if (n == 0) return;
+  const long w = blockIdx.x / D;
+  const int d = blockIdx.x % D;
+  const int lane = threadIdx.x, ld = n + 1;
+  double* M = lds;
+  int* perm = (int*)(lds + (size_t)n * ld);
+  const int* occ = S.det_occ[s] + (size_t)d * n;
+  const double* cw = st.cache[s] + (size_t)w * n * 5 * nmo;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx % n;  // coalesced over j within an electron's row
+    M[j * ld + i] = cw[(size_t)i * 5 * nmo + occ[j]];
+  }
+  __syncthreads();
+  double sign = 1.0, logd = 0.0;
+  bool singular = false;
+  for (int k = 0; k < n; ++k) {
+    double v = (lane >= k && lane < n) ? fabs(M[lane * ld + k]) : -1.0;
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off, 64);
+      const int oi = __shfl_xor(idx, off, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int p = idx;
+    if (!(v > 0.0) || !(v <= DBL_MAX)) { singular = true; break; }
+    if (p != k && lane < n) {
+      const double t = M[k * ld + lane];
+      M[k * ld + lane] = M[p * ld + lane];
+      M[p * ld + lane] = t;
+    }
+    if (p != k) sign = -sign;
+    if (lane == 0) perm[k] = p;
+    __syncthreads();
+    const double piv = M[k * ld + k];
+    logd += log(fabs(piv));
+    if (piv < 0.0) sign = -sign;
+    __syncthreads();
+    double rk = 0.0;
+    if (lane < n) {
+      rk = (lane == k) ? 1.0 / piv : M[k * ld + lane] / piv;
+      M[k * ld + lane] = rk;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == k) continue;
+      const double f = M[r * ld + k];
+      if (lane < n) {
+        const double cur = (lane == k) ? 0.0 : M[r * ld + lane];
+        M[r * ld + lane] = cur - f * rk;
+      }
+    }
+    __syncthreads();
+  }
+  double* Tw = st.T[s] + ((size_t)w * D + d) * n * n;
+  if (singular) {  // slater.py:246-258: inverse left at zero where logdet is not finite
+    for (int idx = lane; idx < n * n; idx += 64) Tw[idx] = 0.0;
+    if (lane == 0) { st.dsign[s][w * D + d] = 0.0; st.dlog[s][w * D + d] = -INFINITY; }
+    return;
+  }
+  for (int k = n - 1; k >= 0; --k) {  // undo the row pivoting: column swaps in reverse order
+    const int p = perm[k];
+    if (p != k && lane < n) {
+      const double t = M[lane * ld + k];
+      M[lane * ld + k] = M[lane * ld + p];
+      M[lane * ld + p] = t;
+    }
+    __syncthreads();
+  }
+  for (int idx = lane; idx < n * n; idx += 64) Tw[idx] = M[(idx / n) * ld + idx % n];
+  if (lane == 0) { st.dsign[s][w * D + d] = sign; st.dlog[s][w * D + d] = logd; }
+}
+
+// ---------------------------------------------------------------- multi-determinant bookkeeping
+// weight of full determinant Dd for walker w, relative to exp(ref): c_D s_up s_dn exp(l_up + l_dn - ref)
+__device__ __forceinline__ double det_logsum(const SysDev& S, const SlaterState& st, long w, int Dd) {
+  return st.dlog[0][w * S.ndet_s[0] + S.det_map[Dd]] + st.dlog[1][w * S.ndet_s[1] + S.det_map[S.ndet + Dd]];
+}
+__device__ __forceinline__ double det_ref(const SysDev& S, const SlaterState& st, long w) {
+  double m = -INFINITY;
+  for (int Dd = threadIdx.x & 63; Dd < S.ndet; Dd += 64) m = fmax(m, det_logsum(S, st, w, Dd));
+  return wave_max(m);
+}
+__device__ __forceinline__ double det_weight(const SysDev& S, const SlaterState& st, long w, int Dd, double ref) {
+  const double su = st.dsign[0][w * S.ndet_s[0] + S.det_map[Dd]];
+  const double sd = st.dsign[1][w * S.ndet_s[1] + S.det_map[S.ndet + Dd]];
+  const double l = det_logsum(S, st, w, Dd);
+  const double ex = (l == -INFINITY) ? 0.0 : exp(l - ref);
+  return S.det_coeff[Dd] * su * sd * ex;
+}
+
+// (sign, log|Psi_S|) of one walker — determinant_tools.compute_value (:74-88)
+__device__ __forceinline__ void slater_value_wave(const SysDev& S, const SlaterState& st, long w, double& sign,
+                                                  double& logv) {
+  const double ref = det_ref(S, st, w);
+  double t = 0.0;
+  for (int Dd = threadIdx.x & 63; Dd < S.ndet; Dd += 64) t += det_weight(S, st, w, Dd, ref);
+  t = wave_sum(t);
+  sign = clamp_nan_to_num(t / fabs(t));
+  logv = clamp_nan_to_num(log(fabs(t)) + ref);
+}
+
+__global__ __launch_bounds__(64) void k_slater_value(SysDev S, SlaterState st, double* sign, double* logv) {
+  const long w = blockIdx.x;
+  double sg, lv;
+  slater_value_wave(S, st, w, sg, lv);
+  if (threadIdx.x == 0) { sign[w] = sg; logv[w] = lv; }
+}
+
+// Ratios (new row)/(current) of electron i (index within spin s) for NCOMP stacked rows
+// mo[c][nmo] — slater.py:301-380.  scratch: >= ndet_s*NCOMP doubles of LDS (multi-det only).
+template <int NCOMP>
+__device__ __forceinline__ void slater_ratios(const SysDev& S, const SlaterState& st, int s, int i, long w,
+                                              const double* __restrict__ mo, double (&out)[NCOMP], double* scratch) {
+  const int lane = threadIdx.x & 63;
+  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s], D = S.ndet_s[s];
+  if (S.ndet == 1) {
+    double part[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) part[c] = 0.0;
+    const double* Trow = st.T[s] + ((size_t)w * n + i) * n;
+    const int* occ = S.det_occ[s];
+    for (int j = lane; j < n; j += 64) {
+      const double t = Trow[j];
+      const int o = occ[j];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) part[c] += mo[c * nmo + o] * t;
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) out[c] = wave_sum(part[c]);
+    return;
+  }
+  for (int d = 0; d < D; ++d) {
+    const double* Trow = st.T[s] + (((size_t)w * D + d) * n + i) * n;
+    const int* occ = S.det_occ[s] + (size_t)d * n;
+    double part[NCOMP];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) part[c] = 0.0;
+    for (int j = lane; j < n; j += 64) {
+      const double t = Trow[j];
+      const int o = occ[j];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) part[c] += mo[c * nmo + o] * t;
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) {
+      const double r = wave_sum(part[c]);
+      if (lane == 0) scratch[d * NCOMP + c] = r;
+    }
+  }
+  __syncthreads();
+  const double ref = det_ref(S, st, w);
+  double num[NCOMP], den = 0.0;
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) num[c] = 0.0;
+  for (int Dd = lane; Dd < S.ndet; Dd += 64) {
+    const double wt = det_weight(S, st, w, Dd, ref);
+    const int ds = S.det_map[s * S.ndet + Dd];
+    den += wt;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) num[c] += wt * scratch[ds * NCOMP + c];
+  }
+  den = wave_sum(den);
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) out[c] = wave_sum(num[c]) / den;
+  __syncthreads();
+}
+
+// out (NCOMP, nrow*npt); mo rows [(r*npt+q)][NCOMP][nmo]; dynamic LDS: max(ndet_s)*NCOMP doubles
+template <int NCOMP>
+__global__ __launch_bounds__(64) void k_slater_eval(SysDev S, SlaterState st, int e, const double* __restrict__ mo,
+                                                    long nrow, int npt, const int* __restrict__ widx,
+                                                    double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long r = blockIdx.x;
+  const long w = widx ? widx[r] : r;
+  const int s = e >= S.nup, i = e - s * S.nup, nmo = S.nmo[s];
+  for (int q = 0; q < npt; ++q) {
+    double rat[NCOMP];
+    slater_ratios<NCOMP>(S, st, s, i, w, mo + ((size_t)(r * npt + q) * NCOMP) * nmo, rat, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) out[(size_t)c * nrow * npt + r * npt + q] = rat[c];
+  }
+}
+
+// ---------------------------------------------------------------- Sherman-Morrison
+// Replace the row of electron i by the orbitals `morow` (value component, [nmo]) for every unique
+// determinant of spin s of walker w.  LDS: n*(n+1) + 2n doubles.  slater.py:88-94, :286-291.
+__device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterState& st, int s, int i, long w,
+                                               const double* __restrict__ morow, double* lds) {
+  const int lane = threadIdx.x & 63;
+  const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], ld = n + 1;
+  double* L = lds;
+  double* V = lds + (size_t)n * ld;
+  double* Rr = V + n;
+  for (int d = 0; d < D; ++d) {
+    double* Tw = st.T[s] + ((size_t)w * D + d) * n * n;
+    const int* occ = S.det_occ[s] + (size_t)d * n;
+    for (int idx = lane; idx < n * n; idx += 64) L[(idx / n) * ld + idx % n] = Tw[idx];
+    for (int k = lane; k < n; k += 64) V[k] = morow[occ[k]];
+    __syncthreads();
+    // tmp[j] = sum_k vec[k] inv[k][j]  (j = electron) ; lane j
+    double tmp = 0.0;
+    if (lane < n)
+      for (int k = 0; k < n; ++k) tmp += V[k] * L[lane * ld + k];
+    const double ratio = __shfl(tmp, i, 64);
+    if (lane < n) Rr[lane] = L[i * ld + lane] / ratio;  // inv_ratio[k] = inv[k][i] / ratio
+    __syncthreads();
+    if (lane < n) {
+      if (lane == i) {
+        for (int k = 0; k < n; ++k) L[i * ld + k] = Rr[k];
+      } else {
+        for (int k = 0; k < n; ++k) L[lane * ld + k] -= Rr[k] * tmp;
+      }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < n * n; idx += 64) Tw[idx] = L[(idx / n) * ld + idx % n];
+    if (lane == 0) {
+      const size_t o = (size_t)w * D + d;
+      st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)
+      st.dlog[s][o] += log(fabs(ratio));
+    }
+    __syncthreads();
+  }
+}
+
+// grid = W; mo rows [w][NCOMP_STRIDE][nmo] (value component first); mask (W) bytes
+__global__ __launch_bounds__(64) void k_sm_update(SysDev S, SlaterState st, int e, const double* __restrict__ mo,
+                                                  int row_stride, const uint8_t* __restrict__ mask, int to_cache) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  if (mask && !mask[w]) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* row = mo + (size_t)w * row_stride;
+  sm_update_wave(S, st, s, i, w, row, lds);
+  if (to_cache) {  // keep the per-electron orbital cache current (value, grad, lap rows)
+    double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
+    for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[k] = row[k];
+  }
+}
+
+// any non-finite log-determinant? (slater.py:269-275 trigger for a full recompute)
+__global__ void k_has_zero(const double* dlog, long count, int* flag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < count) {
+    const double v = dlog[idx];
+    if (!(v >= -DBL_MAX && v <= DBL_MAX)) atomicOr(flag, 1);
+  }
+}

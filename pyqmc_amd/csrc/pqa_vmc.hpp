@@ -1,0 +1,129 @@
+// Fused single-electron-move kernels for the VMC sweep: the body of vmc_worker's electron loop
+// (pyqmc/method/mc.py:115-137) split around the one orbital evaluation a move needs.
+//
+//   k_propose : drift at the current position (Slater part from the per-electron orbital cache,
+//               Jastrow part recomputed), proposal r' = r + sqrt(tau) z + tau limdrift(grad)
+//   k_orb<5>  : orbitals (value, gradient, laplacian) of electron e at r' for all walkers
+//   k_accept  : ratio and reverse drift at r', Metropolis test, and for accepted walkers the
+//               Sherman-Morrison update, Jastrow sums, coordinate and cache commit
+//
+// The reference evaluates the orbitals twice per move (old and new position, mc.py:117,124); the
+// cached rows of the last accepted position are the same numbers, so only the new position is
+// evaluated here, and the cached Laplacian row makes the kinetic energy free of AO work.
+#pragma once
+#include "pqa_common.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_slater.hpp"
+
+struct MoveBuf {
+  double* newpos;   // [W][3]
+  double* aux;      // [W][8]: gauss*sqrt(tau) (3), limited drift (3), U_old, unused
+  const double* gauss;  // tape [N][W][3] for this step or NULL
+  const double* unif;   // tape [N][W] for this step or NULL
+  uint8_t* accept;  // [W] accept flags of this move
+  uint8_t* accept_rec;  // [N][W] record for this step or NULL
+  int* acc_count;   // accepted moves of this step
+  uint64_t seed;
+  uint32_t step;
+  double tstep;
+};
+
+__device__ __forceinline__ void limdrift3(double& gx, double& gy, double& gz) {  // mc.py:76-89, cutoff 1
+  const double tot = sqrt(gx * gx + gy * gy + gz * gz);
+  if (tot > 1.0) { gx /= tot; gy /= tot; gz /= tot; }
+}
+__device__ __forceinline__ double finite_or(double v, double alt) { return (v >= -DBL_MAX && v <= DBL_MAX) ? v : alt; }
+
+__global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
+                                                int has_slater, int has_jastrow, long W) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
+  double gx = 0.0, gy = 0.0, gz = 0.0, U0 = 0.0;
+  if (has_slater) {
+    const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+    double r[5];
+    slater_ratios<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
+    gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
+  }
+  if (has_jastrow) {
+    double g[3], lp;
+    jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp);
+    gx += g[0]; gy += g[1]; gz += g[2];
+  }
+  limdrift3(gx, gy, gz);
+  if (threadIdx.x == 0) {
+    double z0, z1, z2, z3;
+    if (mb.gauss) {
+      const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
+      z0 = zt[0]; z1 = zt[1]; z2 = zt[2];
+    } else {
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
+    }
+    const double sq = sqrt(mb.tstep);
+    z0 *= sq; z1 *= sq; z2 *= sq;
+    double* np_ = mb.newpos + 3 * w;
+    np_[0] = ex + z0 + gx * mb.tstep;  // mc.py:120
+    np_[1] = ey + z1 + gy * mb.tstep;
+    np_[2] = ez + z2 + gz * mb.tstep;
+    double* a = mb.aux + 8 * w;
+    a[0] = z0; a[1] = z1; a[2] = z2; a[3] = gx; a[4] = gy; a[5] = gz; a[6] = U0;
+  }
+}
+
+// motmp: [W][5][nmo_s] orbitals at the proposed position.  LDS: n(n+1)+2n doubles (+ multi-det scratch).
+__global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
+                                               int has_slater, int has_jastrow, const double* __restrict__ motmp, long W) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double* a = mb.aux + 8 * w;
+  const double nx = mb.newpos[3 * w], ny = mb.newpos[3 * w + 1], nz = mb.newpos[3 * w + 2];
+  double val = 1.0, gx = 0.0, gy = 0.0, gz = 0.0;
+  const double* row = motmp + (size_t)w * 5 * nmo;
+  if (has_slater) {
+    double r[5];
+    slater_ratios<5>(S, st, s, i, w, row, r, lds);
+    gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
+    val *= finite_or(r[0], 1.0);  // slater.py:414-417
+  }
+  if (has_jastrow) {
+    double g[3], lp, U;
+    jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp);
+    gx += g[0]; gy += g[1]; gz += g[2];
+    val *= exp(U - a[6]);
+  }
+  limdrift3(gx, gy, gz);
+  const double fwd = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+  const double bx = a[0] + mb.tstep * (a[3] + gx), by = a[1] + mb.tstep * (a[4] + gy), bz = a[2] + mb.tstep * (a[5] + gz);
+  const double bwd = bx * bx + by * by + bz * bz;
+  const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));  // mc.py:130
+  const double ratio = val * val * t_prob;
+  double u;
+  if (mb.unif) u = mb.unif[(size_t)e * W + w];
+  else {
+    const Philox p = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
+    u = u01(p.c[0], p.c[1]);
+  }
+  const bool acc = ratio > u;
+  if (lane == 0) {
+    mb.accept[w] = acc;
+    if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
+    if (acc) atomicAdd(mb.acc_count, 1);
+  }
+  if (!acc) return;
+  if (has_slater) {
+    sm_update_wave(S, st, s, i, w, row, lds);
+    double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
+    for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
+  }
+  if (has_jastrow) jas_commit(S, js, w, e, nx, ny, nz);
+  else if (lane == 0) {
+    double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
+    x[0] = nx; x[1] = ny; x[2] = nz;
+  }
+}

@@ -1,0 +1,527 @@
+"""Wave-function objects with the reference's protocol, computed on the MI355X.
+
+``Slater``, ``JastrowSpin`` and ``MultiplyWF`` present the methods of
+``pyqmc/wf/slater.py:97-460``, ``pyqmc/wf/jastrowspin.py:20-419`` and
+``pyqmc/wf/multiplywf.py:71-132`` (``recompute / value / gradient / gradient_value /
+gradient_laplacian / testvalue / updateinternals`` with the same argument meaning and
+return shapes) so drivers written against that protocol run unchanged.  Every number is
+produced by the HIP library behind ``include/pyqmc_amd.h``; walker state (inverse
+matrices, determinants, Jastrow sums, coordinates) stays on the device between calls and
+only per-call inputs/outputs cross the boundary.
+"""
+
+import ctypes as C
+import itertools
+
+import numpy as np
+
+from . import _ffi, func3d, tables
+from .configs import OpenConfigs
+
+_serial = itertools.count(1)
+
+
+class DeviceWF:
+    """Owner of one ``pqa_handle_t`` (one walker shard on one GPU)."""
+
+    def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1):
+        self.mol = mol
+        self.nelec = tuple(int(n) for n in mol.nelec)
+        self.N = sum(self.nelec)
+        self.natom = int(mol.natm)
+        self.has_slater = mo_coeff is not None
+        self.has_jastrow = a_basis is not None or b_basis is not None
+        keep = self._keep = {}  # host arrays referenced by the struct must outlive pqa_create
+        s = _ffi.SystemStruct()
+        s.natom, s.nelec_up, s.nelec_dn = self.natom, self.nelec[0], self.nelec[1]
+        keep["xyz"] = _ffi.f64(mol.atom_coords())
+        keep["chg"] = _ffi.f64(mol.atom_charges())
+        s.atom_xyz = keep["xyz"].ctypes.data_as(_ffi.c_double_p)
+        s.atom_charge = keep["chg"].ctypes.data_as(_ffi.c_double_p)
+
+        def setd(name, arr):
+            keep[name] = _ffi.f64(arr)
+            setattr(s, name, keep[name].ctypes.data_as(_ffi.c_double_p))
+
+        def seti(name, arr):
+            keep[name] = np.ascontiguousarray(arr, dtype=np.int32)
+            setattr(s, name, keep[name].ctypes.data_as(_ffi.c_int32_p))
+
+        self.nmo = (0, 0)
+        self.ndet, self.ndet_s = 1, (1, 1)
+        if self.has_slater:
+            bt = tables.basis_tables(mol)
+            self.nao = bt["nao"]
+            s.nshell, s.nprim, s.nao = len(bt["shell_l"]), len(bt["prim_exp"]), bt["nao"]
+            for k in ("shell_atom", "shell_l", "shell_prim_off", "shell_ao_off"):
+                seti(k, bt[k])
+            setd("prim_exp", bt["prim_exp"])
+            setd("prim_coef", bt["prim_coef"])
+            coef, occ_up, occ_dn, dmap = tables.pack_determinants(self.nelec, determinants, tol)
+            self.det_occup = [occ_up, occ_dn]
+            self.det_map = dmap
+            nmo = [int(o.max(initial=-1)) + 1 for o in (occ_up, occ_dn)]
+            self.nmo = tuple(nmo)
+            self.ndet, self.ndet_s = len(coef), (len(occ_up), len(occ_dn))
+            mo = [np.ascontiguousarray(np.asarray(mo_coeff[sp])[:, : nmo[sp]], dtype=float) for sp in (0, 1)]
+            if any(np.iscomplexobj(np.asarray(m)) for m in mo_coeff):
+                raise NotImplementedError("complex orbitals (twisted PBC) are not implemented yet")
+            self.mo_coeff = mo
+            s.nmo_up, s.nmo_dn = nmo
+            setd("mo_up", mo[0])
+            setd("mo_dn", mo[1])
+            s.ndet, s.ndet_up, s.ndet_dn = self.ndet, len(occ_up), len(occ_dn)
+            setd("det_coeff", coef)
+            seti("det_occ_up", occ_up)
+            seti("det_occ_dn", occ_dn)
+            seti("det_map", dmap)
+            self.det_coeff = coef
+        s.has_slater = int(self.has_slater)
+        self.na = self.nb = 0
+        if self.has_jastrow:
+            ak, ap, ra = tables.jastrow_basis_arrays(a_basis or [])
+            bk, bp, rb = tables.jastrow_basis_arrays(b_basis or [])
+            self.na, self.nb = len(ak), len(bk)
+            s.na, s.nb, s.rcut_a, s.rcut_b = self.na, self.nb, ra, rb
+            seti("a_kind", ak)
+            setd("a_param", ap)
+            seti("b_kind", bk)
+            setd("b_param", bp)
+            setd("acoeff", np.zeros((self.natom, self.na, 2)))
+            setd("bcoeff", np.zeros((self.nb, 3)))
+        et = tables.ecp_tables(mol)
+        self.necp = len(et["ecp_atom"])
+        s.necp = self.necp
+        for k in ("ecp_atom", "ecp_chan_off", "ecp_term_off", "ecp_term_n"):
+            seti(k, et[k])
+        setd("ecp_term_exp", et["ecp_term_exp"])
+        setd("ecp_term_coef", et["ecp_term_coef"])
+        self._struct = s
+        self._h = C.c_void_p()
+        lib = _ffi.lib()
+        rc = lib.pqa_create(C.byref(s), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = lib.pqa_last_error(None)
+            raise _ffi.PqaError(f"pqa_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.device = int(device)
+        self.W = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _ffi.lib().pqa_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------
+    def call(self, name, *args):
+        _ffi.check(self._h, getattr(_ffi.lib(), name)(self._h, *args))
+
+    def set_param(self, name, value):
+        a = _ffi.f64(value)
+        self.call("pqa_set_param", name.encode(), _ffi.ptr(a), a.size)
+
+    # fused device-resident entry points ---------------------------------
+    def recompute(self, configs):
+        x = _ffi.f64(configs)
+        W = x.shape[0]
+        sign, logv = np.empty(W), np.empty(W)
+        self.call("pqa_wf_recompute", _ffi.ptr(x), W, _ffi.ptr(sign), _ffi.ptr(logv))
+        self.W = W
+        return sign, logv
+
+    def value(self):
+        sign, logv = np.empty(self.W), np.empty(self.W)
+        self.call("pqa_wf_value", _ffi.ptr(sign), _ffi.ptr(logv))
+        return sign, logv
+
+    def configs(self):
+        out = np.empty((self.W, self.N, 3))
+        self.call("pqa_get_configs", _ffi.ptr(out))
+        return out
+
+    def energy(self, threshold=10.0, rot=None, unif=None, seed=0):
+        """(6, W): ke, ee, ei, ecp, grad2, total of the resident walkers."""
+        out = np.empty((6, self.W))
+        rot = None if rot is None else _ffi.f64(rot)
+        unif = None if unif is None else _ffi.f64(unif)
+        self.call("pqa_energy", float(threshold), _ffi.ptr(rot), _ffi.ptr(unif), int(seed), _ffi.ptr(out))
+        return out
+
+    def vmc_sweeps(self, tstep, nsteps, gauss=None, unif=None, threshold=10.0, ecp_rot=None, ecp_unif=None, seed=0,
+                   energy=True, record=False):
+        acc = np.empty(nsteps)
+        en = np.empty((nsteps, 6)) if energy else None
+        rec = np.empty((nsteps, self.N, self.W), dtype=np.uint8) if record else None
+        g = None if gauss is None else _ffi.f64(gauss)
+        u = None if unif is None else _ffi.f64(unif)
+        er = None if ecp_rot is None else _ffi.f64(ecp_rot)
+        eu = None if ecp_unif is None else _ffi.f64(ecp_unif)
+        self.call("pqa_vmc_sweeps", float(tstep), int(nsteps), _ffi.ptr(g), _ffi.ptr(u), float(threshold), _ffi.ptr(er),
+                  _ffi.ptr(eu), int(seed), _ffi.ptr(acc), _ffi.ptr(en), _ffi.ptr(rec))
+        return acc, en, (rec.astype(bool) if record else None)
+
+    # measurement ----------------------------------------------------------
+    def sync(self):
+        self.call("pqa_sync")
+
+    def timer_start(self):
+        self.call("pqa_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double()
+        self.call("pqa_timer_stop", C.byref(ms))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self.call("pqa_profile_enable", int(bool(on)))
+
+    def profile_query(self):
+        n, ms, pc = C.c_int64(), C.c_double(), C.c_double()
+        self.call("pqa_profile_query", C.byref(n), C.byref(ms), C.byref(pc))
+        return n.value, ms.value, pc.value
+
+    def last_ecp_points(self):
+        n = C.c_int64()
+        self.call("pqa_last_ecp_points", C.byref(n))
+        return n.value
+
+    def eval_ao(self, pts, ncomp):
+        p = _ffi.f64(pts).reshape(-1, 3)
+        out = np.empty((ncomp, p.shape[0], self.nao))
+        self.call("pqa_eval_ao", _ffi.ptr(p), p.shape[0], ncomp, _ffi.ptr(out))
+        return out
+
+    def eval_mo(self, spin, pts, ncomp, use_mfma=True):
+        p = _ffi.f64(pts).reshape(-1, 3)
+        out = np.empty((ncomp, p.shape[0], self.nmo[spin]))
+        self.call("pqa_eval_mo", int(spin), _ffi.ptr(p), p.shape[0], ncomp, int(use_mfma), _ffi.ptr(out))
+        return out
+
+
+class _DeviceParams(dict):
+    """``wf.parameters``: a dict of host arrays whose assignments are pushed to the device."""
+
+    def __init__(self, dev, items):
+        super().__init__(items)
+        self._dev = dev
+
+    def __setitem__(self, key, value):
+        value = np.array(value, dtype=float)
+        if key in self and value.shape != np.shape(self[key]):
+            raise ValueError(f"parameter {key} has shape {np.shape(self[key])}, got {value.shape}")
+        super().__setitem__(key, value)
+        self._dev.set_param(key, value)
+
+    def push(self):
+        for k, v in self.items():
+            self._dev.set_param(k, v)
+
+
+def _mask_args(mask, W):
+    """-> (bool mask or None, uint8 array or None)."""
+    if mask is None:
+        return None, None
+    m = np.asarray(mask, dtype=bool)
+    if m.shape != (W,):
+        raise ValueError("mask must have one entry per walker")
+    return m, np.ascontiguousarray(m, dtype=np.uint8)
+
+
+def _points(epos, mask):
+    """-> (pts (nrow,npt,3), widx int32 or None, aux?)"""
+    x = np.asarray(epos.configs, dtype=float)
+    aux = x.ndim == 3
+    widx = None
+    if mask is not None:
+        widx = np.ascontiguousarray(np.nonzero(mask)[0], dtype=np.int32)
+        x = x[mask]
+    pts = np.ascontiguousarray(x.reshape(x.shape[0], -1, 3))
+    return pts, widx, aux
+
+
+class Slater:
+    """Multi-determinant Slater factor (protocol of ``pyqmc/wf/slater.py:97-460``).
+
+    ``mol``/``mf`` are the duck-typed containers of ``pyqmc_amd.systems`` (or PySCF-like
+    objects exposing the same attributes); ``determinants`` is the list format of the
+    reference's ``determinants=`` argument (slater.py:166-180)."""
+
+    def __init__(self, mol, mf, determinants=None, tol=None, device=0, _dev=None):
+        self._mol = mol
+        self._nelec = tuple(mol.nelec)
+        if _dev is None:
+            mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
+            _dev = DeviceWF(mol, mo_coeff=mf.mo_coeff, determinants=determinants, device=device,
+                            tol=-1 if tol is None else tol)
+        self._dev = _dev
+        self.parameters = _DeviceParams(_dev, {"det_coeff": _dev.det_coeff.copy(),
+                                               "mo_coeff_alpha": _dev.mo_coeff[0].copy(),
+                                               "mo_coeff_beta": _dev.mo_coeff[1].copy()})
+        self._det_occup = [o.tolist() for o in _dev.det_occup]
+        self._det_map = _dev.det_map
+        self.dtype = float
+        self._saved = None
+
+    def _spin(self, e):
+        return int(e >= self._nelec[0])
+
+    def recompute(self, configs):
+        self.parameters.push()
+        x = _ffi.f64(configs.configs)
+        W = x.shape[0]
+        sign, logv = np.empty(W), np.empty(W)
+        self._dev.call("pqa_slater_recompute", _ffi.ptr(x), W, _ffi.ptr(sign), _ffi.ptr(logv))
+        self._dev.W = W
+        return sign, logv
+
+    def value(self):
+        W = self._dev.W
+        sign, logv = np.empty(W), np.empty(W)
+        self._dev.call("pqa_slater_value", _ffi.ptr(sign), _ffi.ptr(logv))
+        return sign, logv
+
+    def _ratios(self, e, epos, mask, ncomp, keep):
+        m, _ = _mask_args(mask, self._dev.W)
+        pts, widx, aux = _points(epos, m)
+        nrow, npt = pts.shape[0], pts.shape[1]
+        out = np.empty((ncomp, nrow * npt))
+        if nrow:
+            self._dev.call("pqa_slater_eval", int(e), _ffi.ptr(pts), nrow, npt, _ffi.ptr(widx), ncomp, int(keep), _ffi.ptr(out))
+        return out, nrow, npt, aux
+
+    def gradient_value(self, e, epos):
+        r, *_ = self._ratios(e, epos, None, 5, True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            deriv = r[1:4] / r[0]
+        deriv[~np.isfinite(deriv)] = 0.0
+        val = r[0].copy()
+        val[~np.isfinite(val)] = 1.0
+        self._saved = ("pqa-slater-saved", int(e), next(_serial))
+        return deriv, val, self._saved
+
+    def gradient(self, e, epos):
+        r, *_ = self._ratios(e, epos, None, 5, False)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return r[1:4] / r[0]
+
+    def gradient_laplacian(self, e, epos):
+        r, *_ = self._ratios(e, epos, None, 5, False)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = r / r[:1]
+        return r[1:4], r[4]
+
+    def testvalue(self, e, epos, mask=None):
+        r, nrow, npt, aux = self._ratios(e, epos, mask, 1, False)
+        r = r[0].reshape(nrow, npt) if aux else r[0]
+        return r, None
+
+    def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        s = self._spin(e)
+        flag = C.c_int()
+        self._dev.call("pqa_slater_has_zero", s, C.byref(flag))
+        if flag.value:  # slater.py:269-275
+            import warnings
+
+            warnings.warn("Found a zero in the wave function. Recomputing everything. This should not happen often.")
+            self.recompute(configs)
+            return
+        _, m8 = _mask_args(mask, self._dev.W)
+        x = _ffi.f64(epos.configs)
+        use_saved = saved_values is not None and saved_values is self._saved and saved_values[1] == int(e)
+        self._dev.call("pqa_slater_update", int(e), _ffi.ptr(x), _ffi.ptr(m8), int(use_saved))
+        self._saved = None
+
+    # test access to internals, in the reference's layout
+    def _get_state(self, s):
+        W, D, n = self._dev.W, self._dev.ndet_s[s], self._nelec[s]
+        inv, dets = np.empty((W, D, n, n)), np.empty((2, W, D))
+        self._dev.call("pqa_slater_get_state", s, _ffi.ptr(inv), _ffi.ptr(dets))
+        return inv, dets
+
+
+class JastrowSpin:
+    """One- and two-body Jastrow factor (protocol of ``pyqmc/wf/jastrowspin.py:20-419``).
+    ``a_basis``/``b_basis``: lists of ``pyqmc_amd.func3d`` descriptors."""
+
+    def __init__(self, mol, a_basis, b_basis, device=0, _dev=None):
+        self._mol = mol
+        self._nelec = int(np.sum(mol.nelec))
+        if _dev is None:
+            _dev = DeviceWF(mol, a_basis=list(a_basis), b_basis=list(b_basis), device=device)
+        self._dev = _dev
+        self.parameters = _DeviceParams(_dev, {"bcoeff": np.zeros((_dev.nb, 3)), "acoeff": np.zeros((_dev.natom, _dev.na, 2))})
+        self.dtype = float
+
+    def recompute(self, configs):
+        self.parameters.push()
+        x = _ffi.f64(configs.configs)
+        W = x.shape[0]
+        u = np.empty(W)
+        self._dev.call("pqa_jastrow_recompute", _ffi.ptr(x), W, _ffi.ptr(u))
+        self._dev.W = W
+        return np.ones(W), u
+
+    def value(self):
+        u = np.empty(self._dev.W)
+        self._dev.call("pqa_jastrow_value", _ffi.ptr(u))
+        return np.ones(len(u)), u
+
+    def _eval(self, e, epos, mask, mode):
+        m, _ = _mask_args(mask, self._dev.W)
+        pts, widx, aux = _points(epos, m)
+        nrow, npt = pts.shape[0], pts.shape[1]
+        out = np.empty(nrow * npt) if mode == 0 else np.empty((4, nrow))
+        if nrow:
+            self._dev.call("pqa_jastrow_eval", int(e), _ffi.ptr(pts), nrow, npt, _ffi.ptr(widx), mode, _ffi.ptr(out))
+        return out, nrow, npt, aux
+
+    def testvalue(self, e, epos, mask=None):
+        r, nrow, npt, aux = self._eval(e, epos, mask, 0)
+        return (r.reshape(nrow, npt) if aux else r), None
+
+    def gradient_value(self, e, epos):
+        r, *_ = self._eval(e, epos, None, 1)
+        return r[:3], r[3], None
+
+    def gradient(self, e, epos):
+        return self._eval(e, epos, None, 1)[0][:3]
+
+    def gradient_laplacian(self, e, epos):
+        r, *_ = self._eval(e, epos, None, 2)
+        return r[:3], r[3]
+
+    def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        _, m8 = _mask_args(mask, self._dev.W)
+        x = _ffi.f64(epos.configs)
+        self._dev.call("pqa_jastrow_update", int(e), _ffi.ptr(x), _ffi.ptr(m8))
+
+    def pgradient(self):
+        """jastrowspin.py:457-464: the stored sums."""
+        a, b, _ = self._get_state()
+        return {"bcoeff": b, "acoeff": a}
+
+    def _get_state(self):
+        d = self._dev
+        a, b, x = np.empty((d.W, d.natom, d.na, 2)), np.empty((d.W, d.nb, 3)), np.empty((d.W, d.N, 3))
+        d.call("pqa_jastrow_get_state", _ffi.ptr(a), _ffi.ptr(b), _ffi.ptr(x))
+        return a, b, x
+
+
+class Parameters:
+    """"wf{i}{key}" view over the factors' parameter dicts (``multiplywf.py:18-68``)."""
+
+    def __init__(self, dicts):
+        self.data = {f"wf{i + 1}": d for i, d in enumerate(dicts)}
+        self.wf_count = len(dicts)
+
+    def __setitem__(self, idx, value):
+        self.data[idx[:3]][idx[3:]] = value
+
+    def __getitem__(self, idx):
+        return self.data[idx[:3]][idx[3:]]
+
+    def __iter__(self):
+        return self.keys()
+
+    def keys(self):
+        for i in range(self.wf_count):
+            for k in self.data[f"wf{i + 1}"].keys():
+                yield f"wf{i + 1}{k}"
+
+    def items(self):
+        for k in self.keys():
+            yield k, self[k]
+
+    def values(self):
+        for k in self.keys():
+            yield self[k]
+
+    def __len__(self):
+        return sum(len(d) for d in self.data.values())
+
+
+class MultiplyWF:
+    """Product wave function (``pyqmc/wf/multiplywf.py:71-132``)."""
+
+    def __init__(self, *wf_factors):
+        self.wf_factors = list(wf_factors)
+        self.parameters = Parameters([wf.parameters for wf in wf_factors])
+        self.dtype = complex if any(wf.dtype == complex for wf in wf_factors) else float
+
+    def fused_device(self):
+        """The shared DeviceWF when every factor lives on one handle (enables the fused entry points)."""
+        devs = {id(getattr(w, "_dev", None)) for w in self.wf_factors}
+        d = getattr(self.wf_factors[0], "_dev", None)
+        return d if len(devs) == 1 and d is not None else None
+
+    def recompute(self, configs):
+        d = self.fused_device()
+        if d is not None:
+            for w in self.wf_factors:
+                w.parameters.push()
+            return d.recompute(configs.configs)
+        res = [w.recompute(configs) for w in self.wf_factors]
+        return np.prod([r[0] for r in res], axis=0), np.sum([r[1] for r in res], axis=0)
+
+    def value(self):
+        res = [w.value() for w in self.wf_factors]
+        return np.prod([r[0] for r in res], axis=0), np.sum([r[1] for r in res], axis=0)
+
+    def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        saved_values = [None] * len(self.wf_factors) if saved_values is None else saved_values
+        for w, sv in zip(self.wf_factors, saved_values):
+            w.updateinternals(e, epos, configs, mask=mask, saved_values=sv)
+
+    def gradient(self, e, epos):
+        return np.sum([w.gradient(e, epos) for w in self.wf_factors], axis=0)
+
+    def testvalue(self, e, epos, mask=None):
+        vals, saved = zip(*[w.testvalue(e, epos, mask=mask) for w in self.wf_factors])
+        return np.prod(vals, axis=0), saved
+
+    def gradient_value(self, e, epos):
+        g, v, s = zip(*[w.gradient_value(e, epos) for w in self.wf_factors])
+        return np.sum(g, axis=0), np.prod(v, axis=0), s
+
+    def gradient_laplacian(self, e, epos):
+        g, l = zip(*[w.gradient_laplacian(e, epos) for w in self.wf_factors])
+        cross = np.zeros(l[0].shape, dtype=self.dtype)
+        for i in range(len(g)):
+            for j in range(i + 1, len(g)):
+                cross += np.sum(g[i] * g[j], axis=0)
+        return np.sum(g, axis=0), np.sum(l, axis=0) + 2 * cross
+
+
+def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None):
+    """Slater x two-body-Jastrow product on ONE device handle — the counterpart of
+    ``pyqmc.wftools.generate_wf`` (wftools.py:195-241) with the default Jastrow of
+    ``generate_jastrow`` (:99-152: e-e cusp fixed at -1/4, -1/2, -1/4; ion cusp only for
+    all-electron ions)."""
+    kws = dict(jastrow_kws or {})
+    ion_cusp = kws.pop("ion_cusp", None)
+    if ion_cusp is None:
+        charges = mol.atom_charges()
+        ion_cusp = [mol.atom_symbol(i) for i in range(mol.natm) if mol.atom_symbol(i) not in mol._ecp and charges[i] > 0]
+    elif ion_cusp is True:
+        ion_cusp = [mol.atom_symbol(i) for i in range(mol.natm)]
+    elif ion_cusp is False:
+        ion_cusp = []
+    abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
+    mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
+    dev = DeviceWF(mol, mo_coeff=mf.mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
+                   tol=-1 if tol is None else tol)
+    sl = Slater(mol, mf, _dev=dev)
+    ja = JastrowSpin(mol, abasis, bbasis, _dev=dev)
+    acoeff = np.zeros((mol.natm, len(abasis), 2))
+    if ion_cusp:
+        coefs = np.array(mol.atom_charges(), dtype=float)
+        coefs[[mol.atom_symbol(i) not in ion_cusp for i in range(mol.natm)]] = 0.0
+        acoeff[:, 0, :] = coefs[:, None]
+    bcoeff = np.zeros((len(bbasis), 3))
+    bcoeff[0] = [-0.25, -0.5, -0.25]
+    ja.parameters["acoeff"] = acoeff
+    ja.parameters["bcoeff"] = bcoeff
+    return MultiplyWF(sl, ja)
