@@ -238,7 +238,8 @@ def _points(epos, mask):
     if mask is not None:
         widx = np.ascontiguousarray(np.nonzero(mask)[0], dtype=np.int32)
         x = x[mask]
-    pts = np.ascontiguousarray(x.reshape(x.shape[0], -1, 3))
+    npt = x.shape[1] if aux else 1
+    pts = np.ascontiguousarray(x.reshape(x.shape[0], npt, 3))
     return pts, widx, aux
 
 
