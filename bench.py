@@ -129,7 +129,8 @@ def main():
         return (t[:6] / t[6]).cpu().numpy()
 
     if args.warmup > 0:
-        dev.vmc_sweeps(args.tstep, args.warmup, seed=seed, energy=True)
+        _, en_w, _ = dev.vmc_sweeps(args.tstep, args.warmup, seed=seed, energy=True)
+        reduce_block(en_w)  # also warms torch's allocator / RCCL communicator outside the timed region
     if not args.no_profile:
         dev.profile_enable(True)
     fence()
