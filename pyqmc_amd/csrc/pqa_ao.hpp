@@ -127,90 +127,104 @@ __global__ void k_mo_valu(const double* __restrict__ ao, const double* __restric
 
 // ---------------------------------------------------------------- fused AO -> MO, MFMA
 // AO index space is cut into chunks of <= KC functions made of whole shells; each chunk's shells
-// are pre-assigned to the 4 waves of a block (balanced by primitive count on the host).
+// are pre-assigned to the G = 256/TP lane groups of a block (balanced by primitive count on the host).
 struct ChunkTab {
   int nchunk;
   const int* chunk_nk;    // AOs in chunk
   const int* chunk_ao0;   // first AO
   const int* chunk_row0;  // first row in the zero-padded coefficient matrices
-  const int* cw_off;      // [nchunk*4+1]
-  const int* cw_shell;    // shells for (chunk, wave)
+  const int* cw_off[2];   // [nchunk*G+1] for G = 4 (TP=64) and G = 8 (TP=32)
+  const int* cw_shell[2]; // shells for (chunk, group)
   const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
   int ldc[2];
 };
 
-// out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), 64 points.
-template <int NCOMP, int NT, int KC>
+// out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), TP = 64 or 32 points.
+//  phase 1 (VALU/exp bound): thread = (point, lane group); each group evaluates its share of the chunk's
+//          shells and writes the XOR-swizzled LDS tile [comp][k][point ^ ((k&1)<<4)]
+//  phase 2 (MFMA): TP=64: wave wv owns the 16-point tile wv and all NT orbital tiles;
+//                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
+//          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
+template <int NCOMP, int NT, int KC, int TP>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
-  __shared__ double tile[NCOMP][KC][64];
+  constexpr int G = 256 / TP;                         // lane groups in phase 1
+  constexpr int NU = (TP == 64) ? NT : (NT + 1) / 2;  // orbital tiles per wave in phase 2
+  __shared__ double tile[NCOMP][KC][TP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long p0 = (long)blockIdx.x * 64;
-  const long pmine = (p0 + lane < P) ? p0 + lane : P - 1;
+  const int pl = tid & (TP - 1), grp = tid / TP;
+  const long p0 = (long)blockIdx.x * TP;
+  const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
   double px, py, pz;
   load_point(pa, pmine, px, py, pz);
 
-  d4 acc[NT][NCOMP];
+  d4 acc[NU][NCOMP];
 #pragma unroll
-  for (int u = 0; u < NT; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) acc[u][c] = (d4){0.0, 0.0, 0.0, 0.0};
 
   const double* __restrict__ C = T.cpad[spin];
   const int ldc = T.ldc[spin];
   const int i16 = lane & 15, kq = lane >> 4;
+  const int ptile = (TP == 64) ? wv : (wv & 1);
+  const int u0 = (TP == 64) ? 0 : (wv >> 1), ustep = (TP == 64) ? 1 : 2;
+  const int* __restrict__ cw_off = T.cw_off[TP == 64 ? 0 : 1];
+  const int* __restrict__ cw_shell = T.cw_shell[TP == 64 ? 0 : 1];
 
   for (int ch = 0; ch < T.nchunk; ++ch) {
     const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch], row0 = T.chunk_row0[ch];
     const int nk4 = (nk + 3) & ~3;
-    // ---- phase 1: this wave's shells of the chunk, one lane per point (VALU / exp bound)
-    const int s_end = T.cw_off[ch * 4 + wv + 1];
-    for (int si = T.cw_off[ch * 4 + wv]; si < s_end; ++si) {
-      const int sh = T.cw_shell[si];
+    const int s_end = cw_off[ch * G + grp + 1];
+    for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
+      const int sh = cw_shell[si];
       const int ia = S.shell_atom[sh], q0 = S.shell_prim_off[sh], kb = S.shell_ao_off[sh] - a0;
       const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
       shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + q0, S.prim_coef + q0, S.shell_prim_off[sh + 1] - q0,
                         [&](int m, double v, double gx, double gy, double gz, double lp) {
                           const int k = kb + m;
-                          const int col = lane ^ ((k & 1) << 4);
+                          const int col = pl ^ ((k & 1) << 4);
                           tile[0][k][col] = v;
                           if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
                           if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
                         });
     }
-    for (int idx = tid; idx < (nk4 - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows
-      const int rc = idx >> 6;
-      tile[rc % NCOMP][nk + rc / NCOMP][idx & 63] = 0.0;
+    for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
+      const int rc = idx / TP;
+      tile[rc % NCOMP][nk + rc / NCOMP][idx & (TP - 1)] = 0.0;
     }
     __syncthreads();
-    // ---- phase 2: wave wv owns points 16wv..16wv+15; D[point][orb] += A[point][k] B[k][orb]
     for (int k0 = 0; k0 < nk4; k0 += 4) {
       const int k = k0 + kq;
       const double* crow = C + (long)(row0 + k) * ldc + i16;
-      double b[NT];
+      double b[NU];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) b[u] = crow[16 * u];
-      const int col = (16 * wv + i16) ^ ((k & 1) << 4);
+      for (int u = 0; u < NU; ++u) {
+        const int ut = u0 + u * ustep;
+        b[u] = (ut < NT) ? crow[16 * ut] : 0.0;
+      }
+      const int col = (16 * ptile + i16) ^ ((k & 1) << 4);
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) {
         const double a = tile[c][k][col];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc[u][c], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc[u][c], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  // ---- epilogue: lane holds D[row = (lane>>4) + 4r][col = lane & 15]
+  // epilogue: lane holds D[row = (lane>>4) + 4r][col = lane & 15]
   const int nmo = S.nmo[spin];
 #pragma unroll
-  for (int u = 0; u < NT; ++u) {
-    const int j = 16 * u + i16;
-    if (j >= nmo) continue;
+  for (int u = 0; u < NU; ++u) {
+    const int ut = u0 + u * ustep;
+    const int j = 16 * ut + i16;
+    if (ut >= NT || j >= nmo) continue;
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long pp = p0 + 16 * wv + kq + 4 * r;
+        const long pp = p0 + 16 * ptile + kq + 4 * r;
         if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
       }
   }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,7 +26,8 @@ struct DevBuf {
 };
 
 struct ChunkHost {
-  std::vector<int> nk, ao0, row0, cw_off, cw_shell;
+  std::vector<int> nk, ao0, row0;
+  std::vector<int> cw_off[2], cw_shell[2];  // shell lists per (chunk, lane group) for 4 and 8 groups
   int rows_pad = 0;
 };
 
@@ -56,7 +58,9 @@ struct pqa_handle {
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
+  int orb_tp = 0;  // 0 = automatic
   bool saved_valid = false;
+  bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
   int saved_e = -1;
   long last_ecp_points = 0;
   // measurement
@@ -135,7 +139,7 @@ static int check_launch(pqa_handle* h, const char* what) {
 // ---------------------------------------------------------------- chunk tables for k_orb
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
-  c.cw_off.push_back(0);
+  for (int g = 0; g < 2; ++g) c.cw_off[g].push_back(0);
   int sh = 0, rows = 0;
   while (sh < h->nshell) {
     const int first = sh;
@@ -145,23 +149,26 @@ static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
     c.ao0.push_back(h->shell_ao[first]);
     c.row0.push_back(rows);
     rows += (nk + 3) & ~3;
-    // longest-processing-time assignment of the chunk's shells to the 4 waves of a block
+    // longest-processing-time assignment of the chunk's shells to the lane groups of a block
     std::vector<int> order;
     for (int s = first; s < sh; ++s) order.push_back(s);
     auto cost = [&](int s) { return 12 * h->shell_np[s] + 6 * (2 * h->shell_l[s] + 1); };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
-    std::vector<int> lists[4];
-    int load[4] = {0, 0, 0, 0};
-    for (int s : order) {
-      int best = 0;
-      for (int wv = 1; wv < 4; ++wv)
-        if (load[wv] < load[best]) best = wv;
-      lists[best].push_back(s);
-      load[best] += cost(s);
-    }
-    for (int wv = 0; wv < 4; ++wv) {
-      for (int s : lists[wv]) c.cw_shell.push_back(s);
-      c.cw_off.push_back((int)c.cw_shell.size());
+    for (int g = 0; g < 2; ++g) {
+      const int G = g ? 8 : 4;
+      std::vector<std::vector<int>> lists(G);
+      std::vector<int> load(G, 0);
+      for (int s : order) {
+        int best = 0;
+        for (int q = 1; q < G; ++q)
+          if (load[q] < load[best]) best = q;
+        lists[best].push_back(s);
+        load[best] += cost(s);
+      }
+      for (int q = 0; q < G; ++q) {
+        for (int s : lists[q]) c.cw_shell[g].push_back(s);
+        c.cw_off[g].push_back((int)c.cw_shell[g].size());
+      }
     }
   }
   c.rows_pad = rows;
@@ -199,6 +206,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
+  if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -259,8 +267,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, c.nk.data(), c.nk.size(), &tmp_i)); T.chunk_nk = tmp_i;
       TRY(upload_table(h, c.ao0.data(), c.ao0.size(), &tmp_i)); T.chunk_ao0 = tmp_i;
       TRY(upload_table(h, c.row0.data(), c.row0.size(), &tmp_i)); T.chunk_row0 = tmp_i;
-      TRY(upload_table(h, c.cw_off.data(), c.cw_off.size(), &tmp_i)); T.cw_off = tmp_i;
-      TRY(upload_table(h, c.cw_shell.data(), c.cw_shell.size(), &tmp_i)); T.cw_shell = tmp_i;
+      for (int g = 0; g < 2; ++g) {
+        TRY(upload_table(h, c.cw_off[g].data(), c.cw_off[g].size(), &tmp_i)); T.cw_off[g] = tmp_i;
+        TRY(upload_table(h, c.cw_shell[g].data(), c.cw_shell[g].size(), &tmp_i)); T.cw_shell[g] = tmp_i;
+      }
       for (int s = 0; s < 2; ++s) { T.cpad[s] = h->d_cpad[t][s]; T.ldc[s] = 16 * h->nt[s]; }
     }
   }
@@ -379,13 +389,13 @@ extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int
 }
 
 // ---------------------------------------------------------------- orbital kernel launch
-template <int NCOMP, int KC>
+template <int NCOMP, int KC, int TP>
 static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  const dim3 grid((unsigned)((P + 63) / 64)), block(256);
+  const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
   }
 }
 
@@ -405,8 +415,12 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
     ++h->prof_used;
     HIPCHK(hipEventRecord(e0, h->stream));
   }
-  if (ncomp == 5) launch_orb_t<5, 16>(h, 0, spin, pa, P, out);
-  else if (ncomp == 1) launch_orb_t<1, 32>(h, 1, spin, pa, P, out);
+  // 64-point tiles need >= ~4 blocks per CU to overlap their exp and MFMA phases across blocks; below
+  // that, 32-point tiles double the number of resident blocks (PQA_ORB_TP overrides for A/B runs)
+  int tp = (P >= (long)64 * 1024) ? 64 : 32;
+  if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
+  if (ncomp == 5) { if (tp == 64) launch_orb_t<5, 16, 64>(h, 0, spin, pa, P, out); else launch_orb_t<5, 16, 32>(h, 0, spin, pa, P, out); }
+  else if (ncomp == 1) { if (tp == 64) launch_orb_t<1, 32, 64>(h, 1, spin, pa, P, out); else launch_orb_t<1, 32, 32>(h, 1, spin, pa, P, out); }
   else FAIL("orbital kernel supports ncomp 1 or 5");
   TRY(check_launch(h, "k_orb"));
   if (h->profile) {
@@ -512,9 +526,18 @@ static int ensure_walkers(pqa_handle* h, long W) {
   return 0;
 }
 
+static int jas_refresh(pqa_handle* h) {
+  if (h->has_jastrow && h->jas_stale && h->W > 0) {
+    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js);
+    TRY(check_launch(h, "k_jastrow_recompute"));
+  }
+  h->jas_stale = false;
+  return 0;
+}
+
 static size_t lds_sm(const pqa_handle* h) {
   const size_t n = std::max(h->nup, h->ndn);
-  return (n * (n + 1) + 2 * n) * sizeof(double) + 64 * sizeof(int);
+  return (n * (n + 1) + 2 * n + 64 + n) * sizeof(double);
 }
 static size_t lds_det(const pqa_handle* h, int ncomp) {
   return (size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double);
@@ -668,6 +691,7 @@ extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_jastrow) FAIL("handle has no Jastrow factor");
   if (h->W != W) TRY(ensure_walkers(h, W));
+  h->jas_stale = false;
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
   hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
   TRY(check_launch(h, "k_jastrow_recompute"));
@@ -677,6 +701,7 @@ extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int
 extern "C" int pqa_jastrow_value(pqa_handle_t* h, double* logval) {
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  TRY(jas_refresh(h));
   hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
   TRY(check_launch(h, "k_jastrow_value"));
   return copy_out(h, logval, h->b_ju.p, h->W * sizeof(double));
@@ -712,6 +737,7 @@ extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, co
   if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
   const long W = h->W;
+  TRY(jas_refresh(h));
   TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
   TRY(copy_in(h, h->b_newpos.p, epos, (size_t)W * 3 * sizeof(double)));
   const uint8_t* dm = nullptr;
@@ -728,6 +754,7 @@ extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, co
 extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs) {
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
+  TRY(jas_refresh(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (avalues && h->has_jastrow) HIPCHK(hipMemcpy(avalues, h->js.avalues, (size_t)h->W * h->natom * h->na * 2 * sizeof(double), hipMemcpyDefault));
   if (bvalues && h->has_jastrow) HIPCHK(hipMemcpy(bvalues, h->js.bvalues, (size_t)h->W * h->nb * 3 * sizeof(double), hipMemcpyDefault));
@@ -745,6 +772,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
     TRY(copy_in(h, lg.data(), h->b_log.p, W * sizeof(double)));
   }
   if (h->has_jastrow) {
+    TRY(jas_refresh(h));
     hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
     TRY(check_launch(h, "k_jastrow_value"));
     TRY(copy_in(h, ju.data(), h->b_ju.p, W * sizeof(double)));
@@ -759,6 +787,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
 extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
   HIPCHK(hipSetDevice(h->device));
   TRY(ensure_walkers(h, W));
+  h->jas_stale = false;
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
   if (h->has_slater) TRY(slater_rebuild(h));
   if (h->has_jastrow) {
@@ -899,6 +928,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       TRY(check_launch(h, "k_row_means"));
     }
   }
+  h->jas_stale = h->has_jastrow;
   std::vector<int> cnt(nsteps);
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));
   if (acceptance) {

@@ -220,7 +220,13 @@ __global__ __launch_bounds__(64) void k_slater_eval(SysDev S, SlaterState st, in
 
 // ---------------------------------------------------------------- Sherman-Morrison
 // Replace the row of electron i by the orbitals `morow` (value component, [nmo]) for every unique
-// determinant of spin s of walker w.  LDS: n*(n+1) + 2n doubles.  slater.py:88-94, :286-291.
+// determinant of spin s of walker w.  slater.py:88-94, :286-291.
+//   tmp[j]   = sum_k vec[k] inv[k][j]          (j = electron)       -> sum_k V[k] T[j][k]
+//   ratio    = tmp[i]
+//   T[j][k] -= (T[i][k] / ratio) tmp[j]  (j != i),   T[i][k] = T[i][k] / ratio
+// The n x n tile is staged global -> LDS with coalesced 512-B wave accesses (row stride n+1, odd, so
+// the row-per-lane accesses below are bank-conflict free); every row is split over R = 64/n lane
+// groups so all 64 lanes work for n <= 32.  LDS: n(n+1) + 2n + 64 doubles.
 __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterState& st, int s, int i, long w,
                                                const double* __restrict__ morow, double* lds) {
   const int lane = threadIdx.x & 63;
@@ -228,28 +234,56 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
   double* L = lds;
   double* V = lds + (size_t)n * ld;
   double* Rr = V + n;
+  double* Pt = Rr + n;  // [R][n] partial dot products
+  const int R = (n >= 64) ? 1 : 64 / n;          // lane groups per row
+  const int chunk = (n + R - 1) / R;             // columns per lane group
+  const int part = lane / n, row = lane - part * n;
+  const bool active = part < R;
+  const int kb = part * chunk, ke = (kb + chunk < n) ? kb + chunk : n;
+  const int di = 64 / n, dk = 64 - di * n;       // (row, col) increment of a 64-element stride
   for (int d = 0; d < D; ++d) {
     double* Tw = st.T[s] + ((size_t)w * D + d) * n * n;
     const int* occ = S.det_occ[s] + (size_t)d * n;
-    for (int idx = lane; idx < n * n; idx += 64) L[(idx / n) * ld + idx % n] = Tw[idx];
+    {
+      int r = part, c = row;  // element index lane = r*n + c
+      for (int idx = lane; idx < n * n; idx += 64) {
+        L[r * ld + c] = Tw[idx];
+        r += di; c += dk;
+        if (c >= n) { c -= n; ++r; }
+      }
+    }
     for (int k = lane; k < n; k += 64) V[k] = morow[occ[k]];
     __syncthreads();
-    // tmp[j] = sum_k vec[k] inv[k][j]  (j = electron) ; lane j
     double tmp = 0.0;
-    if (lane < n)
-      for (int k = 0; k < n; ++k) tmp += V[k] * L[lane * ld + k];
-    const double ratio = __shfl(tmp, i, 64);
-    if (lane < n) Rr[lane] = L[i * ld + lane] / ratio;  // inv_ratio[k] = inv[k][i] / ratio
+    if (active) {
+      const double* Lr = L + row * ld;
+      for (int k = kb; k < ke; ++k) tmp += V[k] * Lr[k];
+      Pt[part * n + row] = tmp;
+    }
     __syncthreads();
-    if (lane < n) {
-      if (lane == i) {
-        for (int k = 0; k < n; ++k) L[i * ld + k] = Rr[k];
+    tmp = 0.0;
+    if (active)
+      for (int q = 0; q < R; ++q) tmp += Pt[q * n + row];  // same order in every lane group: bitwise equal
+    const double ratio = __shfl(tmp, i, 64);               // lane i is (part 0, row i)
+    if (lane < n) Rr[lane] = L[i * ld + lane] / ratio;     // inv_ratio[k] = inv[k][i] / ratio
+    __syncthreads();
+    if (active) {
+      double* Lr = L + row * ld;
+      if (row == i) {
+        for (int k = kb; k < ke; ++k) Lr[k] = Rr[k];
       } else {
-        for (int k = 0; k < n; ++k) L[lane * ld + k] -= Rr[k] * tmp;
+        for (int k = kb; k < ke; ++k) Lr[k] -= Rr[k] * tmp;
       }
     }
     __syncthreads();
-    for (int idx = lane; idx < n * n; idx += 64) Tw[idx] = L[(idx / n) * ld + idx % n];
+    {
+      int r = part, c = row;
+      for (int idx = lane; idx < n * n; idx += 64) {
+        Tw[idx] = L[r * ld + c];
+        r += di; c += dk;
+        if (c >= n) { c -= n; ++r; }
+      }
+    }
     if (lane == 0) {
       const size_t o = (size_t)w * D + d;
       st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
     double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
     for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
   }
-  if (has_jastrow) jas_commit(S, js, w, e, nx, ny, nz);
-  else if (lane == 0) {
+  // The public Jastrow sums (_avalues/_bvalues) are not needed by the sweep itself (ratios come from
+  // U_e(new) - U_e(old)); the host marks them stale and rebuilds them from x on demand.
+  if (lane == 0) {
     double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
     x[0] = nx; x[1] = ny; x[2] = nz;
   }
