@@ -55,7 +55,7 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
@@ -275,8 +275,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     }
   }
   S.na = h->na; S.nb = h->nb; S.rcut_a = sys->rcut_a; S.rcut_b = sys->rcut_b;
-  for (int k = 0; k < h->na; ++k) { S.a_kind[k] = sys->a_kind[k]; S.a_param[k] = sys->a_param[k]; }
-  for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; }
+  for (int k = 0; k < h->na; ++k) { S.a_kind[k] = sys->a_kind[k]; S.a_param[k] = sys->a_param[k]; S.a_aux[k] = 1.0 / (3.0 + sys->a_param[k]); }
+  for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; S.b_aux[k] = 1.0 / (3.0 + sys->b_param[k]); }
   TRY(upload_table(h, sys->acoeff, (size_t)h->natom * h->na * 2, &h->d_acoeff)); S.acoeff = h->d_acoeff;
   TRY(upload_table(h, sys->bcoeff, (size_t)h->nb * 3, &h->d_bcoeff)); S.bcoeff = h->d_bcoeff;
   S.necp = h->necp;
@@ -331,7 +331,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (void* p : h->owned) (void)hipFree(p);
   DevBuf* bufs[] = {&h->b_x, &h->b_T[0], &h->b_T[1], &h->b_dsign[0], &h->b_dsign[1], &h->b_dlog[0], &h->b_dlog[1],
                     &h->b_cache[0], &h->b_cache[1], &h->b_aval, &h->b_bval, &h->b_pts, &h->b_motmp, &h->b_out, &h->b_widx,
-                    &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt,
+                    &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
                     &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp};
@@ -892,7 +892,9 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   TRY(ensure(h, h->b_acccnt, (size_t)nsteps * sizeof(int)));
   TRY(ensure(h, h->b_motmp, (size_t)W * 5 * std::max(nmo_max, 1) * sizeof(double)));
   TRY(ensure(h, h->b_means, (size_t)nsteps * 6 * sizeof(double)));
+  TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
   HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
   if (gauss) TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
   if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
@@ -901,7 +903,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
-    mb.acc_count = (int*)h->b_acccnt.p + step; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
+    mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
     if (gauss) {
       TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
       mb.gauss = (const double*)h->b_gauss.p;
@@ -919,6 +921,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       hipLaunchKernelGGL(k_accept, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
                          (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
     }
+    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {

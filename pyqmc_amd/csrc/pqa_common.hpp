@@ -32,8 +32,10 @@ struct SysDev {
   int na, nb;
   int a_kind[PQA_MAXBAS];
   double a_param[PQA_MAXBAS];
+  double a_aux[PQA_MAXBAS];  // 1/(3+gamma) for cusp functions
   int b_kind[PQA_MAXBAS];
   double b_param[PQA_MAXBAS];
+  double b_aux[PQA_MAXBAS];
   double rcut_a, rcut_b;
   const double* acoeff;  // [natom][na][2]
   const double* bcoeff;  // [nb][3]

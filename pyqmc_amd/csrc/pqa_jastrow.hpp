@@ -20,25 +20,73 @@ struct JastrowState {
   double* bvalues;  // [W][nb][3]
 };
 
-// value, (dU/dr)/r and laplacian of one radial basis function for r < rcut
-__device__ __forceinline__ void jas_radial(int kind, double par, double rcut, double r, double& val, double& gfac,
-                                           double& lap) {
-  if (kind == 0) {  // PolyPade(beta)  func3d.py:25-49
-    const double z1 = r / rcut - 1.0, z12 = z1 * z1;
-    const double p = (3.0 * z12 + 4.0 * z1) * z12 + 1.0;
-    const double obp = 1.0 / (1.0 + par * p);
-    val = (1.0 - p) * obp;
-    gfac = -(1.0 + par) * 12.0 / (rcut * rcut) * obp * obp * z12;
-    lap = gfac * (5.0 + 2.0 / z1 - 24.0 * par * (z1 + 1.0) * (z1 + 1.0) * z12 * obp);
-  } else {  // CutoffCusp(gamma)  func3d.py:125-182
-    const double y = r / rcut, y1 = y - 1.0, a = y1 * y1;
-    const double b = (a * y1 + 1.0) / 3.0;
-    const double ogb = 1.0 / (1.0 + par * b);
-    const double c = ogb * ogb / r;
-    val = (-b * ogb + 1.0 / (3.0 + par)) * rcut;
-    gfac = -a * c;
-    lap = -2.0 * c * ((y1 - a * a * par * ogb) * y + a);
+// ---------------------------------------------------------------- radial basis functions
+// All functions of one basis share rcut (func3d.py:289-291), so everything that depends only on r is
+// computed once per pair (RadShared) and each function costs one reciprocal:
+//   PolyPade(beta)   func3d.py:25-49    z1 = r/rcut-1, p = 3 z1^4 + 4 z1^3 + 1
+//        value = (1-p)/(1+beta p),  (dU/dr)/r = -12 (1+beta) z1^2 / (rcut^2 (1+beta p)^2),
+//        lap   = gfac (5 + 2/z1 - 24 beta (z1+1)^2 z1^2 / (1+beta p))
+//   CutoffCusp(gamma) func3d.py:125-182  y = r/rcut, a = (y-1)^2, b = (a(y-1)+1)/3
+//        value = rcut(-b/(1+gamma b) + 1/(3+gamma)),  (dU/dr)/r = -a/((1+gamma b)^2 r),
+//        lap   = -2/((1+gamma b)^2 r) ((y-1 - a^2 gamma/(1+gamma b)) y + a)
+// Reciprocals use v_rcp_f64 + two Newton steps (relative error ~1e-16) instead of the 12-instruction
+// IEEE division sequence; r/rcut is r * (1/rcut).  Differences from the reference's arithmetic are at
+// the 1e-16 level, far inside the 1e-12 parity tolerance of the Jastrow tests.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
+struct RadShared {
+  double r, y, z1, z12, p, omp, c0, t5, q, b, inv_r;
+};
+
+template <int MODE>
+__device__ __forceinline__ RadShared rad_shared(double r, double inv_rcut) {
+  RadShared s;
+  s.r = r;
+  s.y = r * inv_rcut;
+  s.z1 = s.y - 1.0;
+  s.z12 = s.z1 * s.z1;
+  s.p = (3.0 * s.z12 + 4.0 * s.z1) * s.z12 + 1.0;
+  s.omp = 1.0 - s.p;
+  s.c0 = -12.0 * inv_rcut * inv_rcut * s.z12;
+  s.b = (s.z12 * s.z1 + 1.0) * (1.0 / 3.0);
+  s.inv_r = fast_rcp(r);
+  s.t5 = 0.0; s.q = 0.0;
+  if (MODE == 2) {
+    s.t5 = 5.0 + 2.0 * fast_rcp(s.z1);
+    s.q = 24.0 * s.y * s.y * s.z12;
   }
+  return s;
+}
+
+// aux = 1/(3+gamma) for the cusp function (host-computed)
+template <int MODE>
+__device__ __forceinline__ void rad_fn(int kind, double par, double aux, double rcut, const RadShared& s, double& val,
+                                       double& gfac, double& lap) {
+  if (kind == 0) {
+    const double obp = fast_rcp(1.0 + par * s.p);
+    val = s.omp * obp;
+    gfac = s.c0 * (1.0 + par) * obp * obp;
+    lap = (MODE == 2) ? gfac * (s.t5 - par * s.q * obp) : 0.0;
+  } else {
+    const double ogb = fast_rcp(1.0 + par * s.b);
+    const double c = ogb * ogb * s.inv_r;
+    val = (aux - s.b * ogb) * rcut;
+    gfac = -s.z12 * c;
+    lap = (MODE == 2) ? -2.0 * c * ((s.z1 - s.z12 * s.z12 * par * ogb) * s.y + s.z12) : 0.0;
+  }
+}
+
+// value of one radial function for r < rcut (sums maintenance: recompute / protocol update)
+__device__ __forceinline__ double jas_value1(int kind, double par, double aux, double rcut, double r) {
+  const RadShared s = rad_shared<0>(r, 1.0 / rcut);
+  double v, g, l;
+  rad_fn<0>(kind, par, aux, rcut, s, v, g, l);
+  return v;
 }
 
 // U_e(r), grad U_e, lap U_e (bare laplacian, without |grad|^2) for electron e placed at r, against
@@ -48,35 +96,42 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
                                          double rz, double& U, double (&g)[3], double& lapU) {
   const int lane = threadIdx.x & 63;
   const int edown = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0;
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
     const double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_b) {
+      const RadShared sh = rad_shared<MODE>(r, irb);
       const int col = edown + (j >= S.nup);
+      double sg = 0.0;
       for (int l = 0; l < S.nb; ++l) {
         double v, gf, lpl;
-        jas_radial(S.b_kind[l], S.b_param[l], S.rcut_b, r, v, gf, lpl);
+        rad_fn<MODE>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
         const double c = S.bcoeff[l * 3 + col];
         u += c * v;
-        if (MODE >= 1) { gx += c * gf * dx; gy += c * gf * dy; gz += c * gf * dz; }
+        if (MODE >= 1) sg += c * gf;
         if (MODE == 2) lp += c * lpl;
       }
+      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
   for (int I = lane; I < S.natom; I += 64) {
     const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_a) {
+      const RadShared sh = rad_shared<MODE>(r, ira);
+      double sg = 0.0;
       for (int k = 0; k < S.na; ++k) {
         double v, gf, lpl;
-        jas_radial(S.a_kind[k], S.a_param[k], S.rcut_a, r, v, gf, lpl);
+        rad_fn<MODE>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
         const double c = S.acoeff[(I * S.na + k) * 2 + edown];
         u += c * v;
-        if (MODE >= 1) { gx += c * gf * dx; gy += c * gf * dy; gz += c * gf * dz; }
+        if (MODE >= 1) sg += c * gf;
         if (MODE == 2) lp += c * lpl;
       }
+      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
   U = (MODE <= 1) ? wave_sum(u) : 0.0;
@@ -105,9 +160,9 @@ __device__ __forceinline__ void jas_commit(const SysDev& S, const JastrowState& 
 #pragma unroll
       for (int l = 0; l < PQA_MAXBAS; ++l) {
         if (l < S.nb) {
-          double vn = 0.0, vo = 0.0, t1, t2;
-          if (rn < S.rcut_b) jas_radial(S.b_kind[l], S.b_param[l], S.rcut_b, rn, vn, t1, t2);
-          if (ro < S.rcut_b) jas_radial(S.b_kind[l], S.b_param[l], S.rcut_b, ro, vo, t1, t2);
+          double vn = 0.0, vo = 0.0;
+          if (rn < S.rcut_b) vn = jas_value1(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, rn);
+          if (ro < S.rcut_b) vo = jas_value1(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, ro);
           if (grp) diff[1][l] += vn - vo; else diff[0][l] += vn - vo;
         }
       }
@@ -127,9 +182,9 @@ __device__ __forceinline__ void jas_commit(const SysDev& S, const JastrowState& 
     const double ro = sqrt((ox - ax) * (ox - ax) + (oy - ay) * (oy - ay) + (oz - az) * (oz - az));
     double* av = js.avalues + ((size_t)w * S.natom + I) * S.na * 2;
     for (int k = 0; k < S.na; ++k) {
-      double vn = 0.0, vo = 0.0, t1, t2;
-      if (rn < S.rcut_a) jas_radial(S.a_kind[k], S.a_param[k], S.rcut_a, rn, vn, t1, t2);
-      if (ro < S.rcut_a) jas_radial(S.a_kind[k], S.a_param[k], S.rcut_a, ro, vo, t1, t2);
+      double vn = 0.0, vo = 0.0;
+      if (rn < S.rcut_a) vn = jas_value1(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, rn);
+      if (ro < S.rcut_a) vo = jas_value1(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, ro);
       av[k * 2 + edown] += vn - vo;
     }
   }
@@ -167,11 +222,7 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
       for (int e = 0; e < S.nelec; ++e) {
         const double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
-        if (r < S.rcut_a) {
-          double v, t1, t2;
-          jas_radial(S.a_kind[k], S.a_param[k], S.rcut_a, r, v, t1, t2);
-          sum[e >= S.nup] += v;
-        }
+        if (r < S.rcut_a) sum[e >= S.nup] += jas_value1(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, r);
       }
       av[k * 2] = sum[0];
       av[k * 2 + 1] = sum[1];
@@ -190,8 +241,7 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
 #pragma unroll
         for (int l = 0; l < PQA_MAXBAS; ++l) {
           if (l < S.nb) {
-            double v, t1, t2;
-            jas_radial(S.b_kind[l], S.b_param[l], S.rcut_b, r, v, t1, t2);
+            const double v = jas_value1(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, r);
             if (t == 0) acc[0][l] += v; else if (t == 1) acc[1][l] += v; else acc[2][l] += v;
           }
         }

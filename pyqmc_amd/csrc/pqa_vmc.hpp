@@ -22,7 +22,7 @@ struct MoveBuf {
   const double* unif;   // tape [N][W] for this step or NULL
   uint8_t* accept;  // [W] accept flags of this move
   uint8_t* accept_rec;  // [N][W] record for this step or NULL
-  int* acc_count;   // accepted moves of this step
+  int* acc_w;       // [W] accepted moves of this walker in this step (no same-address atomics: they serialise at ~12 ns each)
   uint64_t seed;
   uint32_t step;
   double tstep;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   if (lane == 0) {
     mb.accept[w] = acc;
     if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
-    if (acc) atomicAdd(mb.acc_count, 1);
+    if (acc) mb.acc_w[w] += 1;
   }
   if (!acc) return;
   if (has_slater) {
@@ -127,4 +127,18 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
     double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
     x[0] = nx; x[1] = ny; x[2] = nz;
   }
+}
+
+// accepted-move count of one sweep: sum acc_w[0..W) -> *out, and reset acc_w.  One block, deterministic.
+__global__ __launch_bounds__(1024) void k_sum_reset_int(int* __restrict__ acc_w, long W, int* __restrict__ out) {
+  __shared__ int part[1024];
+  int s = 0;
+  for (long i = threadIdx.x; i < W; i += 1024) { s += acc_w[i]; acc_w[i] = 0; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = part[0];
 }
