@@ -50,10 +50,25 @@ struct SysDev {
 };
 
 // ---------------------------------------------------------------- wave-level reductions
+// Sum over the 64 lanes, result broadcast to every lane.  Uses DPP row shifts + row broadcasts (VALU
+// only, ~20 instructions) instead of __shfl_xor, which lowers to 12 dependent ds_bpermute_b32 round
+// trips through the LDS crossbar per reduction.  Fixed association order -> deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);  // lanes whose source is out of range / row-masked add +0.0
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, PQA_WAVE);
-  return v;
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1   inclusive scan inside each row of 16 lanes
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8   lane 15 of each row = row total
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
