@@ -15,6 +15,7 @@
 #include "pqa_common.hpp"
 #include "pqa_energy.hpp"
 #include "pqa_jastrow.hpp"
+#include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
 #include "pqa_vmc.hpp"
 
@@ -57,8 +58,10 @@ struct pqa_handle {
   // scratch
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
+  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
+  int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
   int saved_e = -1;
@@ -207,6 +210,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
+  if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -334,7 +338,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -806,13 +810,69 @@ extern "C" int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs) {
 extern "C" int pqa_get_configs(pqa_handle_t* h, double* configs) { return pqa_jastrow_get_state(h, nullptr, nullptr, configs); }
 
 // energy of the resident walkers into device buffer b_en (6,W)
-static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step) {
+static void transpose(pqa_handle* h, const double* in, double* out, long R, long C) {  // in [R][C] -> out [C][R]
+  if (R <= 0 || C <= 0) return;
+  hipLaunchKernelGGL(k_transpose, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, h->stream, in, out, R, C);
+}
+
+static LwState lw_state(pqa_handle* h) {
+  LwState L{};
+  L.xt = (double*)h->b_xt.p;
+  for (int s = 0; s < 2; ++s) {
+    L.Tt[s] = (double*)h->b_Tt[s].p; L.ct[s] = (double*)h->b_ct[s].p;
+    L.dsign[s] = h->st.dsign[s]; L.dlog[s] = h->st.dlog[s];
+  }
+  L.auxt = (double*)h->b_auxt.p;
+  return L;
+}
+
+// AoS (canonical, wave-per-walker kernels) -> SoA mirrors for the lane-per-walker kernels
+static int lw_from_aos(pqa_handle* h) {
+  const long W = h->W;
+  const int nel[2] = {h->nup, h->ndn};
+  TRY(ensure(h, h->b_xt, (size_t)W * h->N * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_auxt, (size_t)W * 8 * sizeof(double)));
+  TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 4 * sizeof(double)));
+  transpose(h, h->js.x, (double*)h->b_xt.p, W, (long)h->N * 3);
+  for (int s = 0; s < 2; ++s) {
+    const size_t n = nel[s];
+    TRY(ensure(h, h->b_Tt[s], W * n * n * sizeof(double)));
+    TRY(ensure(h, h->b_ct[s], W * n * 5 * h->nmo[s] * sizeof(double)));
+    transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(n * n));
+    transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
+  }
+  return check_launch(h, "k_transpose");
+}
+// SoA -> AoS: coordinates and inverses (what the ECP kernels read); with_cache also the orbital cache
+static int lw_to_aos(pqa_handle* h, bool with_cache) {
+  const long W = h->W;
+  const int nel[2] = {h->nup, h->ndn};
+  transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W);
+  for (int s = 0; s < 2; ++s) {
+    const long n = nel[s];
+    transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], n * n, W);
+    if (with_cache) transpose(h, (const double*)h->b_ct[s].p, h->st.cache[s], n * 5 * h->nmo[s], W);
+  }
+  return check_launch(h, "k_transpose");
+}
+
+static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
+                      bool soa_current = false) {
   const long W = h->W;
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)6 * W * sizeof(double)));
-  hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
-                     (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
-  TRY(check_launch(h, "k_kinetic_coulomb"));
+  if (soa_current) {
+    hipLaunchKernelGGL(k_kinetic_lw, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
+                       (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+    hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
+                       h->N, W, (double*)h->b_kc.p);
+    TRY(check_launch(h, "k_kinetic_lw"));
+    if (h->necp > 0) TRY(lw_to_aos(h, false));
+  } else {
+    hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
+                       (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
+    TRY(check_launch(h, "k_kinetic_coulomb"));
+  }
   const double* d_ecp = nullptr;
   h->last_ecp_points = 0;
   if (h->necp > 0) {
@@ -900,6 +960,13 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
   const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
+  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1;
+  int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
+  while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
+  const int nmax = std::max(h->nup, h->ndn);
+  if (lw) TRY(lw_from_aos(h));
+  const LwState L = lw_state(h);
+  const dim3 gw((unsigned)((W + 63) / 64));
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
@@ -915,22 +982,36 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
     for (int e = 0; e < N; ++e) {
       const int s = e >= h->nup;
+      const double* mo = (const double*)h->b_motmp.p;
+      if (lw) {
+        hipLaunchKernelGGL(k_propose_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W);
+        TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+        hipLaunchKernelGGL(k_accept_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, mo, W);
+        const dim3 gc(gw.x, (unsigned)G);
+        if (nmax <= 8) hipLaunchKernelGGL(k_commit_lw<8>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
+        else if (nmax <= 16) hipLaunchKernelGGL(k_commit_lw<16>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
+        else if (nmax <= 32) hipLaunchKernelGGL(k_commit_lw<32>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
+        else hipLaunchKernelGGL(k_commit_lw<64>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
+        hipLaunchKernelGGL(k_commit_row_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W);
+        continue;
+      }
       hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
                          (int)h->has_slater, (int)h->has_jastrow, W);
       if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
       hipLaunchKernelGGL(k_accept, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
-                         (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+                         (int)h->has_jastrow, mo, W);
     }
     hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
-                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step));
+                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw));
       hipLaunchKernelGGL(k_row_means, dim3(6), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * 6);
       TRY(check_launch(h, "k_row_means"));
     }
   }
+  if (lw) TRY(lw_to_aos(h, true));
   h->jas_stale = h->has_jastrow;
   std::vector<int> cnt(nsteps);
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));

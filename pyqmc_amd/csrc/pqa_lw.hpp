@@ -1,0 +1,301 @@
+// Lane-per-walker ("LW") kernels for the fused VMC sweep and the kinetic energy.
+//
+// Measured on MI355X (profiles/r01_*): with one walker per wavefront the per-move kernels are
+// VALU-issue bound — ~2.3-2.6 k instructions per walker-move, most of them replicated scalar work,
+// cross-lane reductions and half-empty lanes (32 orbitals, 24 ions on 64 lanes) — while moving
+// only ~20 KB per walker.  Mapping one WALKER per LANE over structure-of-arrays state removes the
+// reductions and the idle lanes (every load is a coalesced 512-B wave access) and cuts the issue
+// cost per walker-move by more than 10x.  The arithmetic and its reference semantics are unchanged:
+//   propose / accept : vmc_worker body, pyqmc/method/mc.py:115-137 (limdrift :76-89)
+//   Slater ratios    : slater.py:342-418 (single determinant), Sherman-Morrison slater.py:88-94
+//   Jastrow          : jastrowspin.py:296-385 with func3d.py radial functions
+//   kinetic, Coulomb : observables/energy.py:28-65, product Laplacian multiplywf.py:121-129
+// These kernels handle the single-determinant case; multi-determinant handles use the
+// wave-per-walker kernels of pqa_vmc.hpp.
+//
+// SoA state (walker index fastest):
+//   xt   [N][3][W]            coordinates
+//   Tt   [s] [n][n][W]        inverse, electron-major: Tt[i][k][w] = inverse[k][i]
+//   ct   [s] [n][5][nmo][W]   cached MO value/grad/lap rows of every electron
+#pragma once
+#include "pqa_common.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_vmc.hpp"
+
+struct LwState {
+  double* xt;
+  double* Tt[2];
+  double* ct[2];
+  double* dsign[2];  // [W] (single determinant) — shared with SlaterState
+  double* dlog[2];
+  double* auxt;      // [8][W]: scaled gaussian (3), limited drift (3), U_old, ratio
+};
+
+// ---------------------------------------------------------------- layout transposes
+// in [R][C] -> out [C][R] through a 32x33 LDS tile; block (32,8)
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in, double* __restrict__ out, long R, long C) {
+  __shared__ double tile[32][33];
+  const long c0 = (long)blockIdx.x * 32, r0 = (long)blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const long r = r0 + j, c = c0 + threadIdx.x;
+    if (r < R && c < C) tile[j][threadIdx.x] = in[r * C + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const long c = c0 + j, r = r0 + threadIdx.x;
+    if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][j];
+  }
+}
+
+// ---------------------------------------------------------------- per-lane Jastrow
+// U_e, grad U_e, (bare) lap U_e of electron e of walker w at position (rx,ry,rz); also optionally the
+// Coulomb sums of that electron (MODE 2 only): ee = sum_{j>e} 1/r, ei = -sum Z/r.
+template <int MODE>
+__device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
+                                              double rx, double ry, double rz, int has_jastrow, double& U,
+                                              double (&g)[3], double& lapU, double& ee, double& ei) {
+  const int edown = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
+  for (int j = 0; j < S.nelec; ++j) {
+    if (j == e) continue;
+    const double* xj = xt + (size_t)j * 3 * W + w;
+    const double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (MODE == 2 && j > e) see += fast_rcp(r);
+    if (has_jastrow && r < S.rcut_b) {
+      const RadShared sh = rad_shared<MODE>(r, irb);
+      const int col = edown + (j >= S.nup);
+      double sg = 0.0;
+      for (int l = 0; l < S.nb; ++l) {
+        double v, gf, lpl;
+        rad_fn<MODE>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
+        const double c = S.bcoeff[l * 3 + col];
+        u += c * v;
+        if (MODE >= 1) sg += c * gf;
+        if (MODE == 2) lp += c * lpl;
+      }
+      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
+    }
+  }
+  for (int I = 0; I < S.natom; ++I) {
+    const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
+    if (has_jastrow && r < S.rcut_a) {
+      const RadShared sh = rad_shared<MODE>(r, ira);
+      double sg = 0.0;
+      for (int k = 0; k < S.na; ++k) {
+        double v, gf, lpl;
+        rad_fn<MODE>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
+        const double c = S.acoeff[(I * S.na + k) * 2 + edown];
+        u += c * v;
+        if (MODE >= 1) sg += c * gf;
+        if (MODE == 2) lp += c * lpl;
+      }
+      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
+    }
+  }
+  U = u; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
+}
+
+// ---------------------------------------------------------------- propose
+__global__ __launch_bounds__(64) void k_propose_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* xe = L.xt + (size_t)e * 3 * W + w;
+  const double ex = xe[0], ey = xe[W], ez = xe[2 * W];
+  // Slater drift from the cached rows: r[c] = sum_j cache[i][c][occ_j] T[i][j]
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+  {
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+    const int* occ = S.det_occ[s];
+    for (int j = 0; j < n; ++j) {
+      const double t = Ti[(size_t)j * W];
+      const double* cj = ci + (size_t)occ[j] * W;
+      r0 += cj[0] * t;
+      r1 += cj[(size_t)nmo * W] * t;
+      r2 += cj[(size_t)2 * nmo * W] * t;
+      r3 += cj[(size_t)3 * nmo * W] * t;
+    }
+  }
+  double gx = finite_or(r1 / r0, 0.0), gy = finite_or(r2 / r0, 0.0), gz = finite_or(r3 / r0, 0.0);
+  double U0 = 0.0, g[3], lp, ee, ei;
+  jas_eval_lane<1>(S, L.xt, W, w, e, ex, ey, ez, has_jastrow, U0, g, lp, ee, ei);
+  gx += g[0]; gy += g[1]; gz += g[2];
+  limdrift3(gx, gy, gz);
+  double z0, z1, z2, z3;
+  if (mb.gauss) {
+    const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
+    z0 = zt[0]; z1 = zt[1]; z2 = zt[2];
+  } else {
+    normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
+    normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
+  }
+  const double sq = sqrt(mb.tstep);
+  z0 *= sq; z1 *= sq; z2 *= sq;
+  double* np_ = mb.newpos + 3 * w;
+  np_[0] = ex + z0 + gx * mb.tstep;
+  np_[1] = ey + z1 + gy * mb.tstep;
+  np_[2] = ez + z2 + gz * mb.tstep;
+  double* a = L.auxt + w;
+  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = U0;
+}
+
+// ---------------------------------------------------------------- accept decision
+// motmp: [W][5][nmo] orbitals at the proposed positions (k_orb output)
+__global__ __launch_bounds__(64) void k_accept_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow,
+                                                  const double* __restrict__ motmp, long W) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* row = motmp + (size_t)w * 5 * nmo;
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+  {
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const int* occ = S.det_occ[s];
+    for (int j = 0; j < n; ++j) {
+      const double t = Ti[(size_t)j * W];
+      const int o = occ[j];
+      r0 += row[o] * t;
+      r1 += row[nmo + o] * t;
+      r2 += row[2 * nmo + o] * t;
+      r3 += row[3 * nmo + o] * t;
+    }
+  }
+  double gx = finite_or(r1 / r0, 0.0), gy = finite_or(r2 / r0, 0.0), gz = finite_or(r3 / r0, 0.0);
+  double val = finite_or(r0, 1.0);
+  const double nx = mb.newpos[3 * w], ny = mb.newpos[3 * w + 1], nz = mb.newpos[3 * w + 2];
+  const double* a = L.auxt + w;
+  double U = 0.0, g[3], lp, ee, ei;
+  jas_eval_lane<1>(S, L.xt, W, w, e, nx, ny, nz, has_jastrow, U, g, lp, ee, ei);
+  gx += g[0]; gy += g[1]; gz += g[2];
+  if (has_jastrow) val *= exp(U - a[6 * W]);
+  limdrift3(gx, gy, gz);
+  const double a0 = a[0], a1 = a[W], a2 = a[2 * W];
+  const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
+  const double bx = a0 + mb.tstep * (a[3 * W] + gx), by = a1 + mb.tstep * (a[4 * W] + gy), bz = a2 + mb.tstep * (a[5 * W] + gz);
+  const double bwd = bx * bx + by * by + bz * bz;
+  const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
+  const double ratio = val * val * t_prob;
+  double u;
+  if (mb.unif) u = mb.unif[(size_t)e * W + w];
+  else {
+    const Philox p = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
+    u = u01(p.c[0], p.c[1]);
+  }
+  const bool acc = ratio > u;
+  mb.accept[w] = acc;
+  if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
+  if (acc) {
+    mb.acc_w[w] += 1;
+    L.auxt[7 * W + w] = r0;  // determinant ratio for the Sherman-Morrison update
+    double* xe = L.xt + (size_t)e * 3 * W + w;
+    xe[0] = nx; xe[W] = ny; xe[2 * W] = nz;
+  }
+}
+
+// ---------------------------------------------------------------- commit (Sherman-Morrison)
+// thread = (walker, row group g of G): rows j = g, g+G, ... of the inverse are independent given
+//   V[k] = new orbital row,  R[k] = T[i][k]/ratio:
+//   T[j][k] -= R[k] * sum_k' V[k'] T[j][k']   (j != i),     T[i][k] = R[k]
+// Group 0 also refreshes the orbital cache row and the determinant sign/log.  NMAX >= n.
+template <int NMAX>
+__global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
+                                                  long W, int G) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (w >= W || !mb.accept[w]) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* row = motmp + (size_t)w * 5 * nmo;
+  const int* occ = S.det_occ[s];
+  double* T = L.Tt[s] + w;
+  const double inv_ratio = 1.0 / L.auxt[7 * W + w];
+  double V[NMAX], R[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    V[k] = (k < n) ? row[occ[k]] : 0.0;
+    R[k] = (k < n) ? T[((size_t)i * n + k) * W] * inv_ratio : 0.0;
+  }
+  for (int j = g; j < n; j += G) {
+    if (j == i) continue;
+    double* Tj = T + (size_t)j * n * W;
+    double t[NMAX];
+    double tmp = 0.0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      t[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+      tmp += V[k] * t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if (k < n) Tj[(size_t)k * W] = t[k] - R[k] * tmp;
+  }
+  // every group must have read row i (for R) before it is overwritten: row i is written by the LAST
+  // kernel in stream order instead (k_commit_row_lw), so no inter-block ordering is needed here.
+}
+
+// second half of the commit: T[i][:] = R, cache row, sign/log.  thread = walker.
+__global__ __launch_bounds__(64) void k_commit_row_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
+                                                      long W) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  if (w >= W || !mb.accept[w]) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double ratio = L.auxt[7 * W + w];
+  const double inv_ratio = 1.0 / ratio;
+  double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+  for (int k = 0; k < n; ++k) Ti[(size_t)k * W] *= inv_ratio;
+  const double* row = motmp + (size_t)w * 5 * nmo;
+  double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+  for (int k = 0; k < 5 * nmo; ++k) c[(size_t)k * W] = row[k];
+  L.dsign[s][w] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);
+  L.dlog[s][w] += log(fabs(ratio));
+}
+
+// ---------------------------------------------------------------- kinetic + Coulomb
+// thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
+__global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  const int e = blockIdx.y;
+  if (w >= W) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  {
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+    const int* occ = S.det_occ[s];
+    for (int j = 0; j < n; ++j) {
+      const double t = Ti[(size_t)j * W];
+      const double* cj = ci + (size_t)occ[j] * W;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) r[c] += cj[(size_t)c * nmo * W] * t;
+    }
+  }
+  const double gs0 = r[1] / r[0], gs1 = r[2] / r[0], gs2 = r[3] / r[0], ls = r[4] / r[0];
+  const double* xe = L.xt + (size_t)e * 3 * W + w;
+  double U, gj[3], lj, ee, ei;
+  jas_eval_lane<2>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, U, gj, lj, ee, ei);
+  lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
+  const double gx = gs0 + gj[0], gy = gs1 + gj[1], gz = gs2 + gj[2];
+  const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);
+  const size_t o = (size_t)e * W + w, NW = (size_t)S.nelec * W;
+  part[o] = -0.5 * lap;
+  part[NW + o] = gx * gx + gy * gy + gz * gz;
+  part[2 * NW + o] = ee;
+  part[3 * NW + o] = ei;
+}
+
+// out rows ke, ee, ei, grad2 (layout of k_kinetic_coulomb) = sums over electrons of part
+__global__ void k_kinetic_reduce(const double* __restrict__ part, int N, long W, double* __restrict__ out) {
+  const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  const size_t NW = (size_t)N * W;
+  double ke = 0.0, g2 = 0.0, ee = 0.0, ei = 0.0;
+  for (int e = 0; e < N; ++e) {
+    const size_t o = (size_t)e * W + w;
+    ke += part[o]; g2 += part[NW + o]; ee += part[2 * NW + o]; ei += part[3 * NW + o];
+  }
+  out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = g2;
+}
