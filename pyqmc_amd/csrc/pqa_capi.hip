@@ -58,7 +58,7 @@ struct pqa_handle {
   // scratch
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
-  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
+  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
   int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
@@ -338,7 +338,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -964,7 +964,11 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
   while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
   const int nmax = std::max(h->nup, h->ndn);
-  if (lw) TRY(lw_from_aos(h));
+  if (lw) {
+    TRY(lw_from_aos(h));
+    TRY(ensure(h, h->b_part, (size_t)G * 8 * W * sizeof(double)));
+    TRY(ensure(h, h->b_rbuf, (size_t)std::max(nmax, 1) * W * sizeof(double)));
+  }
   const LwState L = lw_state(h);
   const dim3 gw((unsigned)((W + 63) / 64));
   for (int step = 0; step < nsteps; ++step) {
@@ -984,15 +988,21 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       const int s = e >= h->nup;
       const double* mo = (const double*)h->b_motmp.p;
       if (lw) {
-        hipLaunchKernelGGL(k_propose_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W);
+        const dim3 gg(gw.x, (unsigned)G);
+        double* part = (double*)h->b_part.p;
+        double* rbuf = (double*)h->b_rbuf.p;
+        hipLaunchKernelGGL(k_move_part_lw, gg, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
+                           (const double*)nullptr, W, G, part);
+        hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, G, (const double*)part);
         TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-        hipLaunchKernelGGL(k_accept_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, mo, W);
-        const dim3 gc(gw.x, (unsigned)G);
-        if (nmax <= 8) hipLaunchKernelGGL(k_commit_lw<8>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
-        else if (nmax <= 16) hipLaunchKernelGGL(k_commit_lw<16>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
-        else if (nmax <= 32) hipLaunchKernelGGL(k_commit_lw<32>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
-        else hipLaunchKernelGGL(k_commit_lw<64>, gc, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W, G);
-        hipLaunchKernelGGL(k_commit_row_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, mo, W);
+        hipLaunchKernelGGL(k_move_part_lw, gg, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
+                           W, G, part);
+        hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, G,
+                           (const double*)part, rbuf);
+        if (nmax <= 8) hipLaunchKernelGGL(k_commit_lw<8>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
+        else if (nmax <= 16) hipLaunchKernelGGL(k_commit_lw<16>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
+        else if (nmax <= 32) hipLaunchKernelGGL(k_commit_lw<32>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
+        else hipLaunchKernelGGL(k_commit_lw<64>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
         continue;
       }
       hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,

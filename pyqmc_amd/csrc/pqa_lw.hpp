@@ -48,20 +48,22 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
 }
 
 // ---------------------------------------------------------------- per-lane Jastrow
-// U_e, grad U_e, (bare) lap U_e of electron e of walker w at position (rx,ry,rz); also optionally the
-// Coulomb sums of that electron (MODE 2 only): ee = sum_{j>e} 1/r, ei = -sum Z/r.
+// Contribution of the pairs j = j0, j0+dj, ... and ions I = j0, j0+dj, ... to U_e, grad U_e, (bare) lap U_e
+// of electron e of walker w at (rx,ry,rz); MODE 2 also returns that share of the Coulomb sums
+// ee = sum_{j>e} 1/r, ei = -sum Z/r.  (j0,dj) = (0,1) gives the full sums.
 template <int MODE>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
-                                              double rx, double ry, double rz, int has_jastrow, double& U,
+                                              double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei) {
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
-  for (int j = 0; j < S.nelec; ++j) {
-    if (j == e) continue;
+#pragma unroll 4
+  for (int j = j0; j < S.nelec; j += dj) {
     const double* xj = xt + (size_t)j * 3 * W + w;
     const double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (j == e) continue;
     if (MODE == 2 && j > e) see += fast_rcp(r);
     if (has_jastrow && r < S.rcut_b) {
       const RadShared sh = rad_shared<MODE>(r, irb);
@@ -78,7 +80,7 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
       if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
-  for (int I = 0; I < S.natom; ++I) {
+  for (int I = j0; I < S.natom; I += dj) {
     const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
@@ -99,32 +101,70 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
   U = u; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
 }
 
-// ---------------------------------------------------------------- propose
-__global__ __launch_bounds__(64) void k_propose_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W) {
+// ---------------------------------------------------------------- move kernels
+// Every per-walker loop (orbital slots for the Slater ratios, other electrons and ions for the Jastrow) is
+// split over G thread groups (grid.y) so that even W/64 < #SIMDs fills the chip and no thread walks a long
+// chain of dependent loads; partial sums land in part[G][8][W] and a finish kernel (thread = walker) adds
+// them in group order (deterministic) and does the per-walker scalar work.
+//   part rows: 0..3 Slater sums (value, d/dx, d/dy, d/dz), 4 U, 5..7 grad U
+
+// pos: proposal [W][3] (accept) or NULL = current position of e from xt (propose)
+// rows: [W][5][nmo] orbital rows at `pos` (accept) or NULL = cached rows ct (propose)
+__global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e, int has_jastrow, const double* __restrict__ pos,
+                                                     const double* __restrict__ rows, long W, int G, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
   if (w >= W) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  const double* xe = L.xt + (size_t)e * 3 * W + w;
-  const double ex = xe[0], ey = xe[W], ez = xe[2 * W];
-  // Slater drift from the cached rows: r[c] = sum_j cache[i][c][occ_j] T[i][j]
+  double px, py, pz;
+  if (pos) { px = pos[3 * w]; py = pos[3 * w + 1]; pz = pos[3 * w + 2]; }
+  else { const double* xe = L.xt + (size_t)e * 3 * W + w; px = xe[0]; py = xe[W]; pz = xe[2 * W]; }
   double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
   {
     const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
-    const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
     const int* occ = S.det_occ[s];
-    for (int j = 0; j < n; ++j) {
-      const double t = Ti[(size_t)j * W];
-      const double* cj = ci + (size_t)occ[j] * W;
-      r0 += cj[0] * t;
-      r1 += cj[(size_t)nmo * W] * t;
-      r2 += cj[(size_t)2 * nmo * W] * t;
-      r3 += cj[(size_t)3 * nmo * W] * t;
+    if (rows) {
+      const double* row = rows + (size_t)w * 5 * nmo;
+#pragma unroll 4
+      for (int j = g; j < n; j += G) {
+        const double t = Ti[(size_t)j * W];
+        const int o = occ[j];
+        r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
+      }
+    } else {
+      const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+#pragma unroll 4
+      for (int j = g; j < n; j += G) {
+        const double t = Ti[(size_t)j * W];
+        const double* cj = ci + (size_t)occ[j] * W;
+        r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
+      }
     }
   }
-  double gx = finite_or(r1 / r0, 0.0), gy = finite_or(r2 / r0, 0.0), gz = finite_or(r3 / r0, 0.0);
-  double U0 = 0.0, g[3], lp, ee, ei;
-  jas_eval_lane<1>(S, L.xt, W, w, e, ex, ey, ez, has_jastrow, U0, g, lp, ee, ei);
-  gx += g[0]; gy += g[1]; gz += g[2];
+  double U, gg[3], lp, ee, ei;
+  jas_eval_lane<1>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
+  double* p = part + (size_t)g * 8 * W + w;
+  p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
+}
+
+__device__ __forceinline__ void lw_sum_parts(const double* __restrict__ part, long W, long w, int G, double (&v)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const double* p = part + (size_t)g * 8 * W + w;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] += p[(size_t)c * W];
+  }
+}
+
+// drift at the current position, proposal r' = r + sqrt(tau) z + tau limdrift(grad)   (mc.py:117-121)
+__global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, long W, int G,
+                                                       const double* __restrict__ part) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  if (w >= W) return;
+  double v[8];
+  lw_sum_parts(part, W, w, G, v);
+  double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
   limdrift3(gx, gy, gz);
   double z0, z1, z2, z3;
   if (mb.gauss) {
@@ -136,43 +176,28 @@ __global__ __launch_bounds__(64) void k_propose_lw(SysDev S, LwState L, MoveBuf 
   }
   const double sq = sqrt(mb.tstep);
   z0 *= sq; z1 *= sq; z2 *= sq;
+  const double* xe = L.xt + (size_t)e * 3 * W + w;
   double* np_ = mb.newpos + 3 * w;
-  np_[0] = ex + z0 + gx * mb.tstep;
-  np_[1] = ey + z1 + gy * mb.tstep;
-  np_[2] = ez + z2 + gz * mb.tstep;
+  np_[0] = xe[0] + z0 + gx * mb.tstep;
+  np_[1] = xe[W] + z1 + gy * mb.tstep;
+  np_[2] = xe[2 * W] + z2 + gz * mb.tstep;
   double* a = L.auxt + w;
-  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = U0;
+  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[4];
 }
 
-// ---------------------------------------------------------------- accept decision
-// motmp: [W][5][nmo] orbitals at the proposed positions (k_orb output)
-__global__ __launch_bounds__(64) void k_accept_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow,
-                                                  const double* __restrict__ motmp, long W) {
+// Metropolis decision (mc.py:124-132); accepted walkers: move the coordinate, update sign/log of the
+// determinant, and stage R[k] = T[i][k]/ratio in Rbuf[n][W] for the commit kernel.
+__global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W, int G,
+                                                      const double* __restrict__ part, double* __restrict__ Rbuf) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   if (w >= W) return;
-  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  const double* row = motmp + (size_t)w * 5 * nmo;
-  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-  {
-    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
-    const int* occ = S.det_occ[s];
-    for (int j = 0; j < n; ++j) {
-      const double t = Ti[(size_t)j * W];
-      const int o = occ[j];
-      r0 += row[o] * t;
-      r1 += row[nmo + o] * t;
-      r2 += row[2 * nmo + o] * t;
-      r3 += row[3 * nmo + o] * t;
-    }
-  }
-  double gx = finite_or(r1 / r0, 0.0), gy = finite_or(r2 / r0, 0.0), gz = finite_or(r3 / r0, 0.0);
-  double val = finite_or(r0, 1.0);
-  const double nx = mb.newpos[3 * w], ny = mb.newpos[3 * w + 1], nz = mb.newpos[3 * w + 2];
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup;
+  double v[8];
+  lw_sum_parts(part, W, w, G, v);
+  double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
   const double* a = L.auxt + w;
-  double U = 0.0, g[3], lp, ee, ei;
-  jas_eval_lane<1>(S, L.xt, W, w, e, nx, ny, nz, has_jastrow, U, g, lp, ee, ei);
-  gx += g[0]; gy += g[1]; gz += g[2];
-  if (has_jastrow) val *= exp(U - a[6 * W]);
+  double val = finite_or(v[0], 1.0);
+  if (has_jastrow) val *= exp(v[4] - a[6 * W]);
   limdrift3(gx, gy, gz);
   const double a0 = a[0], a1 = a[W], a2 = a[2 * W];
   const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
@@ -189,22 +214,27 @@ __global__ __launch_bounds__(64) void k_accept_lw(SysDev S, LwState L, MoveBuf m
   const bool acc = ratio > u;
   mb.accept[w] = acc;
   if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
-  if (acc) {
-    mb.acc_w[w] += 1;
-    L.auxt[7 * W + w] = r0;  // determinant ratio for the Sherman-Morrison update
-    double* xe = L.xt + (size_t)e * 3 * W + w;
-    xe[0] = nx; xe[W] = ny; xe[2 * W] = nz;
-  }
+  if (!acc) return;
+  mb.acc_w[w] += 1;
+  double* xe = L.xt + (size_t)e * 3 * W + w;
+  xe[0] = mb.newpos[3 * w]; xe[W] = mb.newpos[3 * w + 1]; xe[2 * W] = mb.newpos[3 * w + 2];
+  const double dr = v[0];  // determinant ratio
+  L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+  L.dlog[s][w] += log(fabs(dr));
+  const double inv = 1.0 / dr;
+  const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+#pragma unroll 8
+  for (int k = 0; k < n; ++k) Rbuf[(size_t)k * W + w] = Ti[(size_t)k * W] * inv;
 }
 
-// ---------------------------------------------------------------- commit (Sherman-Morrison)
+// ---------------------------------------------------------------- commit (Sherman-Morrison, slater.py:88-94)
 // thread = (walker, row group g of G): rows j = g, g+G, ... of the inverse are independent given
-//   V[k] = new orbital row,  R[k] = T[i][k]/ratio:
+//   V[k] = new orbital row and R[k] = T_old[i][k]/ratio (staged in Rbuf, so row i itself can be rewritten):
 //   T[j][k] -= R[k] * sum_k' V[k'] T[j][k']   (j != i),     T[i][k] = R[k]
-// Group 0 also refreshes the orbital cache row and the determinant sign/log.  NMAX >= n.
+// The 5*nmo cached orbital values of electron i are refreshed in slices by the same groups.  NMAX >= n.
 template <int NMAX>
 __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
-                                                  long W, int G) {
+                                                  const double* __restrict__ Rbuf, long W, int G) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int g = blockIdx.y;
   if (w >= W || !mb.accept[w]) return;
@@ -212,16 +242,20 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
   const double* row = motmp + (size_t)w * 5 * nmo;
   const int* occ = S.det_occ[s];
   double* T = L.Tt[s] + w;
-  const double inv_ratio = 1.0 / L.auxt[7 * W + w];
   double V[NMAX], R[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     V[k] = (k < n) ? row[occ[k]] : 0.0;
-    R[k] = (k < n) ? T[((size_t)i * n + k) * W] * inv_ratio : 0.0;
+    R[k] = (k < n) ? Rbuf[(size_t)k * W + w] : 0.0;
   }
   for (int j = g; j < n; j += G) {
-    if (j == i) continue;
     double* Tj = T + (size_t)j * n * W;
+    if (j == i) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if (k < n) Tj[(size_t)k * W] = R[k];
+      continue;
+    }
     double t[NMAX];
     double tmp = 0.0;
 #pragma unroll
@@ -233,25 +267,9 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
     for (int k = 0; k < NMAX; ++k)
       if (k < n) Tj[(size_t)k * W] = t[k] - R[k] * tmp;
   }
-  // every group must have read row i (for R) before it is overwritten: row i is written by the LAST
-  // kernel in stream order instead (k_commit_row_lw), so no inter-block ordering is needed here.
-}
-
-// second half of the commit: T[i][:] = R, cache row, sign/log.  thread = walker.
-__global__ __launch_bounds__(64) void k_commit_row_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
-                                                      long W) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  if (w >= W || !mb.accept[w]) return;
-  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  const double ratio = L.auxt[7 * W + w];
-  const double inv_ratio = 1.0 / ratio;
-  double* Ti = L.Tt[s] + (size_t)i * n * W + w;
-  for (int k = 0; k < n; ++k) Ti[(size_t)k * W] *= inv_ratio;
-  const double* row = motmp + (size_t)w * 5 * nmo;
   double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
-  for (int k = 0; k < 5 * nmo; ++k) c[(size_t)k * W] = row[k];
-  L.dsign[s][w] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);
-  L.dlog[s][w] += log(fabs(ratio));
+#pragma unroll 8
+  for (int k = g; k < 5 * nmo; k += G) c[(size_t)k * W] = row[k];
 }
 
 // ---------------------------------------------------------------- kinetic + Coulomb
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_
   const double gs0 = r[1] / r[0], gs1 = r[2] / r[0], gs2 = r[3] / r[0], ls = r[4] / r[0];
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double U, gj[3], lj, ee, ei;
-  jas_eval_lane<2>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, U, gj, lj, ee, ei);
+  jas_eval_lane<2>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
   lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
   const double gx = gs0 + gj[0], gy = gs1 + gj[1], gz = gs2 + gj[2];
   const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);
