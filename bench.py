@@ -122,11 +122,10 @@ def main():
         torch.cuda.synchronize()
 
     def reduce_block(en):
-        """per-block energy accumulation across ranks (the path's only exchange step)"""
-        t = torch.tensor(np.concatenate([en.sum(axis=0), [en.shape[0]]]), dtype=torch.float64, device=f"cuda:{local_rank}")
-        if dist is not None:
-            dist.all_reduce(t)
-        return (t[:6] / t[6]).cpu().numpy()
+        """per-block energy accumulation across ranks (the path's only exchange step; RCCL all-reduce of 7 fp64)"""
+        from pyqmc_amd.dist import allreduce_block
+
+        return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=f"cuda:{local_rank}")[0]
 
     if args.warmup > 0:
         _, en_w, _ = dev.vmc_sweeps(args.tstep, args.warmup, seed=seed, energy=True)
