@@ -229,3 +229,116 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       }
   }
 }
+
+// ---------------------------------------------------------------- wave-specialised variant
+// Same math and tables as k_orb<.., TP=64>, different schedule: a block has 8 waves; waves 0-3 are
+// PRODUCERS (phase-1 work: exp-bound AO evaluation of chunk c into LDS buffer c&1), waves 4-7 are
+// CONSUMERS (phase-2 work: MFMA contraction of chunk c-1 from buffer (c-1)&1, B operand prefetched
+// one chunk ahead from L2).  One barrier per chunk; a producer and a consumer wave share each SIMD,
+// so the VALU/transcendental pipe and the matrix pipe run concurrently inside ONE block — which is
+// what a launch of only W/64 = 256 blocks (one per CU) needs.
+template <int NCOMP, int NT, int KC>
+__global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
+                                                double* __restrict__ out) {
+  constexpr int KS = KC / 4;
+  __shared__ double tile[2][NCOMP][KC][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool producer = wv < 4;
+  const int grp = wv & 3;  // producer: shell group; consumer: 16-point tile
+  const long p0 = (long)blockIdx.x * 64;
+  const long pmine = (p0 + lane < P) ? p0 + lane : P - 1;
+  double px = 0.0, py = 0.0, pz = 0.0;
+  if (producer) load_point(pa, pmine, px, py, pz);
+
+  d4 acc[NT][NCOMP];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[u][c] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  const double* __restrict__ C = T.cpad[spin];
+  const int ldc = T.ldc[spin];
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int* __restrict__ cw_off = T.cw_off[0];
+  const int* __restrict__ cw_shell = T.cw_shell[0];
+  double bq[KS][NT];  // B operand of the chunk the consumer will contract NEXT iteration
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) bq[ks][u] = 0.0;
+
+  for (int ch = 0; ch <= T.nchunk; ++ch) {
+    if (producer) {
+      if (ch < T.nchunk) {
+        double (*tb)[KC][64] = tile[ch & 1];
+        const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch];
+        const int nk4 = (nk + 3) & ~3;
+        const int s_end = cw_off[ch * 4 + grp + 1];
+        for (int si = cw_off[ch * 4 + grp]; si < s_end; ++si) {
+          const int sh = cw_shell[si];
+          const int ia = S.shell_atom[sh], q0 = S.shell_prim_off[sh], kb = S.shell_ao_off[sh] - a0;
+          const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
+          shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + q0, S.prim_coef + q0, S.shell_prim_off[sh + 1] - q0,
+                            [&](int m, double v, double gx, double gy, double gz, double lp) {
+                              const int k = kb + m;
+                              const int col = lane ^ ((k & 1) << 4);
+                              tb[0][k][col] = v;
+                              if (NCOMP > 1) { tb[1 % NCOMP][k][col] = gx; tb[2 % NCOMP][k][col] = gy; tb[3 % NCOMP][k][col] = gz; }
+                              if (NCOMP == 5) tb[4 % NCOMP][k][col] = lp;
+                            });
+        }
+        for (int idx = tid; idx < (nk4 - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows (256 producer threads)
+          const int rc = idx >> 6;
+          tb[rc % NCOMP][nk + rc / NCOMP][idx & 63] = 0.0;
+        }
+      }
+    } else {
+      // contract chunk ch-1 with the B values fetched during the previous iteration ...
+      double bcur[KS][NT];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) bcur[ks][u] = bq[ks][u];
+      // ... and start fetching B for chunk ch (rows beyond its nk4 belong to the next chunk or the tail pad: unused)
+      if (ch < T.nchunk) {
+        const double* crow = C + (long)(T.chunk_row0[ch] + kq) * ldc + i16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int u = 0; u < NT; ++u) bq[ks][u] = crow[(long)ks * 4 * ldc + 16 * u];
+      }
+      if (ch > 0) {
+        double (*tb)[KC][64] = tile[(ch - 1) & 1];
+        const int nk4 = (T.chunk_nk[ch - 1] + 3) & ~3;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks * 4 < nk4) {
+            const int k = ks * 4 + kq;
+            const int col = (16 * grp + i16) ^ ((k & 1) << 4);
+#pragma unroll
+            for (int c = 0; c < NCOMP; ++c) {
+              const double a = tb[c][k][col];
+#pragma unroll
+              for (int u = 0; u < NT; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[ks][u], acc[u][c], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (producer) return;
+  const int nmo = S.nmo[spin];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int j = 16 * u + i16;
+    if (j >= nmo) continue;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long pp = p0 + 16 * grp + kq + 4 * r;
+        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+      }
+  }
+}

@@ -61,6 +61,7 @@ struct pqa_handle {
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
+  int orb_ws = 1;  // wave-specialised orbital kernel (PQA_ORB_WS=0: phase-alternating k_orb)
   int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
@@ -211,6 +212,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipEventCreate(&h->ev1));
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
+  if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -259,7 +261,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
       TRY(upload_table<double>(h, nullptr, (size_t)h->nao * std::max(h->nmo[s], 1), &h->d_mo[s])); S.mo[s] = h->d_mo[s];
       for (int t = 0; t < 2; ++t)
-        TRY(upload_table<double>(h, nullptr, (size_t)std::max(h->chunks[t].rows_pad, 1) * 16 * h->nt[s], &h->d_cpad[t][s]));
+        TRY(upload_table<double>(h, nullptr, (size_t)(std::max(h->chunks[t].rows_pad, 1) + 32) * 16 * h->nt[s], &h->d_cpad[t][s]));
       if (h->nmo[s] > 0) TRY(set_mo(h, s, mo_src[s]));
     }
     TRY(upload_table(h, sys->det_coeff, (size_t)h->ndet, &h->d_detcoeff)); S.det_coeff = h->d_detcoeff;
@@ -393,6 +395,16 @@ extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int
 }
 
 // ---------------------------------------------------------------- orbital kernel launch
+template <int NCOMP, int KC>
+static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+  const dim3 grid((unsigned)((P + 63) / 64)), block(512);
+  switch (h->nt[spin]) {
+    case 1: hipLaunchKernelGGL((k_orb_ws<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb_ws<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb_ws<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+  }
+}
+
 template <int NCOMP, int KC, int TP>
 static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
@@ -423,6 +435,11 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   // that, 32-point tiles double the number of resident blocks (PQA_ORB_TP overrides for A/B runs)
   int tp = (P >= (long)64 * 1024) ? 64 : 32;
   if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
+  if (h->orb_ws) {
+    if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
+    else if (ncomp == 1) launch_orb_ws<1, 32>(h, 1, spin, pa, P, out);
+    else FAIL("orbital kernel supports ncomp 1 or 5");
+  } else
   if (ncomp == 5) { if (tp == 64) launch_orb_t<5, 16, 64>(h, 0, spin, pa, P, out); else launch_orb_t<5, 16, 32>(h, 0, spin, pa, P, out); }
   else if (ncomp == 1) { if (tp == 64) launch_orb_t<1, 32, 64>(h, 1, spin, pa, P, out); else launch_orb_t<1, 32, 32>(h, 1, spin, pa, P, out); }
   else FAIL("orbital kernel supports ncomp 1 or 5");
