@@ -237,12 +237,29 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
 // one chunk ahead from L2).  One barrier per chunk; a producer and a consumer wave share each SIMD,
 // so the VALU/transcendental pipe and the matrix pipe run concurrently inside ONE block — which is
 // what a launch of only W/64 = 256 blocks (one per CU) needs.
+#define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident tables of k_orb_ws
+#define PQA_WS_MAXP 640
 template <int NCOMP, int NT, int KC>
 __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                                 double* __restrict__ out) {
   constexpr int KS = KC / 4;
   __shared__ double tile[2][NCOMP][KC][64];
+  // basis tables staged once per block: the producer loop then never waits on dependent global/scalar
+  // loads (shell -> atom -> coordinates -> primitives), which is what bounded it before
+  __shared__ double sh_xyz[PQA_WS_MAXSH][3];
+  __shared__ int sh_meta[PQA_WS_MAXSH][4];  // l, nprim, first primitive, first AO
+  __shared__ double pr_exp[PQA_WS_MAXP], pr_coef[PQA_WS_MAXP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int sh = tid; sh < S.nshell; sh += 512) {
+    const int ia = S.shell_atom[sh];
+    sh_xyz[sh][0] = S.atom_xyz[3 * ia]; sh_xyz[sh][1] = S.atom_xyz[3 * ia + 1]; sh_xyz[sh][2] = S.atom_xyz[3 * ia + 2];
+    sh_meta[sh][0] = S.shell_l[sh];
+    sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
+    sh_meta[sh][2] = S.shell_prim_off[sh];
+    sh_meta[sh][3] = S.shell_ao_off[sh];
+  }
+  for (int p = tid; p < S.nprim; p += 512) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
+  __syncthreads();
   const bool producer = wv < 4;
   const int grp = wv & 3;  // producer: shell group; consumer: 16-point tile
   const long p0 = (long)blockIdx.x * 64;
@@ -276,9 +293,9 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
         const int s_end = cw_off[ch * 4 + grp + 1];
         for (int si = cw_off[ch * 4 + grp]; si < s_end; ++si) {
           const int sh = cw_shell[si];
-          const int ia = S.shell_atom[sh], q0 = S.shell_prim_off[sh], kb = S.shell_ao_off[sh] - a0;
-          const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
-          shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + q0, S.prim_coef + q0, S.shell_prim_off[sh + 1] - q0,
+          const int q0 = sh_meta[sh][2], kb = sh_meta[sh][3] - a0;
+          const double x = px - sh_xyz[sh][0], y = py - sh_xyz[sh][1], z = pz - sh_xyz[sh][2];
+          shell_eval<NCOMP>(sh_meta[sh][0], x, y, z, pr_exp + q0, pr_coef + q0, sh_meta[sh][1],
                             [&](int m, double v, double gx, double gy, double gz, double lp) {
                               const int k = kb + m;
                               const int col = lane ^ ((k & 1) << 4);

@@ -61,7 +61,7 @@ struct pqa_handle {
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
-  int orb_ws = 1;  // wave-specialised orbital kernel (PQA_ORB_WS=0: phase-alternating k_orb)
+  int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
   int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
@@ -433,9 +433,12 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   }
   // 64-point tiles need >= ~4 blocks per CU to overlap their exp and MFMA phases across blocks; below
   // that, 32-point tiles double the number of resident blocks (PQA_ORB_TP overrides for A/B runs)
-  int tp = (P >= (long)64 * 1024) ? 64 : 32;
+  int tp = (P >= (long)64 * 512) ? 64 : 32;
   if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
-  if (h->orb_ws) {
+  // measured on MI355X: below ~2 blocks per CU the wave-specialised schedule wins (its
+  // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
+  const bool want_ws = h->orb_ws < 0 ? (P < (long)64 * 512) : (h->orb_ws != 0);
+  if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
     if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
     else if (ncomp == 1) launch_orb_ws<1, 32>(h, 1, spin, pa, P, out);
     else FAIL("orbital kernel supports ncomp 1 or 5");
