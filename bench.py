@@ -25,6 +25,18 @@ sys.path.insert(0, ROOT)
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
+def pmc_traffic(point_comps_per_launch):
+    """HBM bytes per k_orb launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate runs, profiles/r01_pmc_summary.json): measured bytes per (point, component) x this run's
+    average launch size.  None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {"bytes_per_launch": d["k_orb5_bytes_per_point_component"] * point_comps_per_launch,
+            "algorithmic_bytes_per_launch": (32 * 8 + 24 / 5) * point_comps_per_launch, "source": "profiles/r01_pmc_summary.json"}
+
+
 def build_wf(device):
     import numpy as np
 
@@ -74,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--walkers", type=int, default=16384, help="walkers per GPU (weak scaling)")
+    ap.add_argument("--walkers", type=int, default=32768, help="walkers per GPU (weak scaling)")
     ap.add_argument("--tstep", type=float, default=0.3)
     ap.add_argument("--cpu-walkers", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +183,7 @@ def main():
             achieved = flops / (orb_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_orb (fused GTO AO evaluation + AO->MO fp64 MFMA contraction)",
                                "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(point_comps / launches),
                                "launches": launches, "avg_launch_ms": orb_ms / launches,
                                "kernel_share_of_step": orb_ms / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}

@@ -419,7 +419,8 @@ static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P
 static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
   if (P <= 0 || h->nmo[spin] == 0) return 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profile) {
+  const bool prof = h->profile && ncomp == 5;  // account the dominant (move) launches only
+  if (prof) {
     if (h->prof_used == h->prof_events.size()) {
       hipEvent_t a, b;
       HIPCHK(hipEventCreate(&a));
@@ -447,7 +448,7 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   else if (ncomp == 1) { if (tp == 64) launch_orb_t<1, 32, 64>(h, 1, spin, pa, P, out); else launch_orb_t<1, 32, 32>(h, 1, spin, pa, P, out); }
   else FAIL("orbital kernel supports ncomp 1 or 5");
   TRY(check_launch(h, "k_orb"));
-  if (h->profile) {
+  if (prof) {
     HIPCHK(hipEventRecord(e1, h->stream));
     h->prof_launches += 1;
     h->prof_pc += (double)P * ncomp;
