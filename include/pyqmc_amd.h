@@ -142,6 +142,15 @@ int pqa_get_configs(pqa_handle_t* h, double* configs);
    unif (N, necp, W) replay the reference's random draws; NULL -> device Philox stream `seed`. */
 int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out);
 
+/* EnergyAccumulator.nonlocal_tmoves -> eval_ecp.compute_tmoves (eval_ecp.py:43-80) for electron e of the resident
+   walkers: the candidate T-moves over every ECP atom's quadrature points (P = pqa_tmove_npoints() per walker).
+   rot (necp,3,3), unif (necp,W): the reference's per-atom random rotation / mask uniforms.  Outputs: ratio (W,P)
+   Psi(candidate)/Psi (1 where the walker fails the ECP mask for that atom), weight (W,P) = sum_l (exp(-tau v_l)-1)
+   (2l+1)P_l w_i (0 there), pos (W,P,3) candidate positions (current position there). */
+int pqa_tmove_npoints(pqa_handle_t* h);
+int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif, double* ratio,
+               double* weight, double* pos);
+
 /* vmc_worker move loop (mc.py:112-137) fused on the device, nsteps sweeps over all electrons,
    optionally followed each sweep by the energy accumulator (mc.py:142-148).
    gauss (nsteps,N,W,3) standard normals and unif (nsteps,N,W): replay tapes, or NULL -> Philox(seed).

@@ -7,6 +7,7 @@ does, and raises if ``pyqmc_amd/lib/libpyqmc_amd.so`` is not built.
 
 from . import systems  # noqa: F401
 from .configs import OpenConfigs, OpenElectron  # noqa: F401
+from .dmc import branch, dmc_propagate, rundmc  # noqa: F401
 from .energy import EnergyAccumulator  # noqa: F401
 from .func3d import CutoffCuspFunction, PolyPadeFunction, default_jastrow_basis  # noqa: F401
 from .systems import initial_guess  # noqa: F401

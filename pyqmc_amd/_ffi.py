@@ -65,6 +65,8 @@ _PROTOTYPES = {
     "pqa_wf_value": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "pqa_get_configs": (C.c_int, [_H, C.c_void_p]),
     "pqa_energy": (C.c_int, [_H, C.c_double, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "pqa_tmove_npoints": (C.c_int, [_H]),
+    "pqa_tmoves": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_vmc_sweeps": (C.c_int, [_H, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_timer_start": (C.c_int, [_H]),

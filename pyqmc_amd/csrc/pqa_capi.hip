@@ -58,6 +58,9 @@ struct pqa_handle {
   // scratch
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
+  DevBuf b_tpos, b_twgt, b_tlive, b_trat;
+  int tm_P = 0;
+  int *d_ptk = nullptr, *d_pti = nullptr;
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
@@ -313,6 +316,17 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     }
   }
   TRY(upload_table(h, quad.data(), quad.size(), &h->d_quad));
+  {  // flat (atom, quadrature index) list of the T-move candidates of one electron
+    std::vector<int> ptk, pti;
+    for (int k = 0; k < h->necp; ++k) {
+      const int nch = sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k];
+      const int naip = nch <= 2 ? 6 : 12;
+      for (int i = 0; i < naip; ++i) { ptk.push_back(k); pti.push_back(i); }
+    }
+    h->tm_P = (int)ptk.size();
+    TRY(upload_table(h, ptk.data(), ptk.size(), &h->d_ptk));
+    TRY(upload_table(h, pti.data(), pti.size(), &h->d_pti));
+  }
   return 0;
 }
 
@@ -340,7 +354,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1053,6 +1067,44 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   }
   if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * 6 * sizeof(double), hipMemcpyDefault));
   return 0;
+}
+
+extern "C" int pqa_tmove_npoints(pqa_handle_t* h) { return h->tm_P; }
+
+extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif,
+                          double* ratio, double* weight, double* pos) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  const long W = h->W;
+  const int P = h->tm_P, s = e >= h->nup;
+  if (P == 0) return 0;
+  if (!rot || !unif) FAIL("pqa_tmoves needs the rotation and mask-uniform tapes");
+  h->saved_valid = false;
+  const size_t np = (size_t)W * P;
+  TRY(ensure(h, h->b_rot, (size_t)h->necp * 9 * sizeof(double)));
+  TRY(ensure(h, h->b_eunif, (size_t)h->necp * W * sizeof(double)));
+  TRY(ensure(h, h->b_tpos, np * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_twgt, np * sizeof(double)));
+  TRY(ensure(h, h->b_tlive, np));
+  TRY(ensure(h, h->b_trat, np * sizeof(double)));
+  TRY(copy_in(h, h->b_rot.p, rot, (size_t)h->necp * 9 * sizeof(double)));
+  TRY(copy_in(h, h->b_eunif.p, unif, (size_t)h->necp * W * sizeof(double)));
+  hipLaunchKernelGGL(k_tmove_points, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, tau, threshold,
+                     (const double*)h->b_rot.p, (const double*)h->b_eunif.p, (const double*)h->d_quad, (const int*)h->d_ptk,
+                     (const int*)h->d_pti, P, W, (double*)h->b_tpos.p, (double*)h->b_twgt.p, (uint8_t*)h->b_tlive.p);
+  TRY(check_launch(h, "k_tmove_points"));
+  if (h->has_slater) {
+    TRY(ensure(h, h->b_motmp, np * std::max(h->nmo[s], 1) * sizeof(double)));
+    TRY(launch_orb(h, s, plain_points((const double*)h->b_tpos.p, (long)np), (long)np, 1, (double*)h->b_motmp.p));
+  }
+  hipLaunchKernelGGL(k_tmove_ratio, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, e, (int)h->has_slater,
+                     (int)h->has_jastrow, (const double*)h->b_motmp.p, (const double*)h->b_tpos.p, (const uint8_t*)h->b_tlive.p, P,
+                     (double*)h->b_trat.p);
+  TRY(check_launch(h, "k_tmove_ratio"));
+  TRY(copy_in(h, ratio, h->b_trat.p, np * sizeof(double)));
+  TRY(copy_in(h, weight, h->b_twgt.p, np * sizeof(double)));
+  return copy_out(h, pos, h->b_tpos.p, np * 3 * sizeof(double));
 }
 
 // ---------------------------------------------------------------- measurement

@@ -287,3 +287,77 @@ __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a,
   }
   if (threadIdx.x == 0) out[blockIdx.x] = part[0] / (double)W;
 }
+
+// ---------------------------------------------------------------- T-move candidates (DMC)
+// eval_ecp.compute_tmoves (eval_ecp.py:43-80) for ONE electron e: every ECP atom's quadrature points.
+// Point q of walker w belongs to ECP atom pt_k[q], quadrature index pt_i[q].  Outputs per (w,q):
+//   pos (3)   position of the candidate (the current position of e where the walker fails the ECP mask)
+//   weight    sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i   (0 where masked out)
+//   live      1 where the walker passed the mask for that atom
+// rot [necp][3][3], unif [necp][W].  grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, int e, double tau, double threshold,
+                                                     const double* __restrict__ rot, const double* __restrict__ unif,
+                                                     const double* __restrict__ quad, const int* __restrict__ pt_k,
+                                                     const int* __restrict__ pt_i, int P, long W, double* __restrict__ pos,
+                                                     double* __restrict__ weight, uint8_t* __restrict__ live) {
+  const long w = blockIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
+  for (int q = threadIdx.x; q < P; q += 64) {
+    const int k = pt_k[q], i = pt_i[q], ia = S.ecp_atom[k];
+    const double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double v[PQA_MAXCHAN], prob;
+    int nch;
+    ecp_radial(S, k, r, threshold, v, nch, prob);
+    const bool pass = nch > 1 && prob > unif[(size_t)k * W + w];
+    double px = ex, py = ey, pz = ez, wt = 0.0;
+    if (pass) {
+      const int naip = (nch <= 2) ? 6 : 12;
+      const double* qd = quad + ((nch <= 2) ? 0 : 18) + 3 * i;
+      const double* R = rot + (size_t)k * 9;
+      const double vx = R[0] * qd[0] + R[1] * qd[1] + R[2] * qd[2];
+      const double vy = R[3] * qd[0] + R[4] * qd[1] + R[5] * qd[2];
+      const double vz = R[6] * qd[0] + R[7] * qd[1] + R[8] * qd[2];
+      const double rix = r * vx, riy = r * vy, riz = r * vz;
+      const double cosv = (dx * rix + dy * riy + dz * riz) / (r * sqrt(rix * rix + riy * riy + riz * riz));
+      for (int c = 0; c < nch - 1; ++c) wt += (exp(-tau * (v[c] / prob)) - 1.0) * (2 * c + 1) * legendre_l(c, cosv);
+      wt *= 1.0 / naip;
+      px = (ex - dx) + rix; py = (ey - dy) + riy; pz = (ez - dz) + riz;
+    }
+    const size_t o = (size_t)w * P + q;
+    pos[3 * o] = px; pos[3 * o + 1] = py; pos[3 * o + 2] = pz;
+    weight[o] = wt;
+    live[o] = pass;
+  }
+}
+
+// ratio[w][q] = Psi(candidate)/Psi for live candidates, 1 otherwise.  mo: [W*P][nmo_s].  LDS: max(ndet_s) doubles.
+__global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, JastrowState js, int e, int has_slater,
+                                                    int has_jastrow, const double* __restrict__ mo,
+                                                    const double* __restrict__ pos, const uint8_t* __restrict__ live, int P,
+                                                    double* __restrict__ ratio) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const int s = e >= S.nup, nmo = S.nmo[s];
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double U0 = 0.0, g[3], lp;
+  if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp);
+  for (int q = 0; q < P; ++q) {
+    const size_t o = (size_t)w * P + q;
+    double rat = 1.0;
+    if (live[o]) {  // wave-uniform
+      if (has_slater) {
+        double r1[1];
+        slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + o * nmo, r1, lds);
+        rat = r1[0];
+      }
+      if (has_jastrow) {
+        double U;
+        jas_eval<0>(S, xw, e, pos[3 * o], pos[3 * o + 1], pos[3 * o + 2], U, g, lp);
+        rat *= exp(U - U0);
+      }
+    }
+    if (threadIdx.x == 0) ratio[o] = rat;
+  }
+}

@@ -46,3 +46,53 @@ def combine_blocks(block_avgs, counts):
     w = np.asarray(counts, dtype=float)
     w = w / w.sum()
     return {k: sum(b[k] * wi for b, wi in zip(block_avgs, w)) for k in block_avgs[0]}
+
+
+def branch_distributed(configs, weights, base_u=None):
+    """Stochastic-comb branching (``pyqmc/method/dmc.py:342-376``) of an ensemble sharded over ranks.
+
+    The reference gathers all walkers to the master, branches and re-splits (dmc.py:286-287, :566).  Here every
+    rank all-gathers the weights (8 B per walker) and the coordinates, rank 0 broadcasts the single uniform of
+    the comb, every rank computes the same global resampling indices and keeps the slice that belongs to its
+    shard — so shards stay exactly the size they had and no master exists.  Wave-function internals are not
+    exchanged: like the reference (dmc.py:155) the caller recomputes them at the next propagate.
+    Returns (configs, weights, info, global weight std).
+    """
+    import torch
+    import torch.distributed as dist
+
+    from .dmc import comb_indices
+
+    x = np.ascontiguousarray(configs.configs)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        from .dmc import branch
+
+        wstd = float(np.std(weights))
+        return (*branch(configs, weights, base_u), wstd)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n_local = torch.tensor([len(weights)], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    nmax, row = max(counts), int(np.prod(x.shape[1:]))
+    pad_w = torch.zeros(nmax, dtype=torch.float64, device=dev)
+    pad_w[: len(weights)] = torch.from_numpy(np.asarray(weights, dtype=np.float64))
+    pad_x = torch.zeros(nmax, row, dtype=torch.float64, device=dev)
+    pad_x[: len(weights)] = torch.from_numpy(x.reshape(len(weights), row))
+    all_w = [torch.zeros_like(pad_w) for _ in range(world)]
+    all_x = [torch.zeros_like(pad_x) for _ in range(world)]
+    dist.all_gather(all_w, pad_w)
+    dist.all_gather(all_x, pad_x)
+    gw = np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_w, counts)])
+    gx = np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_x, counts)])
+    u = torch.tensor([np.random.rand() if base_u is None else base_u], dtype=torch.float64, device=dev)
+    dist.broadcast(u, src=0)
+    newinds, wtot = comb_indices(gw, float(u.item()))
+    unique, cnt = np.unique(newinds, return_counts=True)
+    lo = int(np.sum(counts[:rank]))
+    mine = newinds[lo : lo + counts[rank]]
+    configs.configs = gx[mine].reshape((len(mine),) + x.shape[1:])
+    new_w = np.full(len(mine), wtot / len(gw))
+    info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique))}
+    return configs, new_w, info, float(np.std(gw))

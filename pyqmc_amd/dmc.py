@@ -1,0 +1,222 @@
+"""Diffusion Monte Carlo over the wave-function protocol — counterpart of ``pyqmc/method/dmc.py``.
+
+Everything numerical (orbitals, ratios, gradients, Sherman–Morrison, Jastrow, local energy, ECP
+T-move candidates) runs in the HIP library through the protocol objects; what is left on the host is
+the reference's own driver logic: drift limiting (``limdrift`` dmc.py:22-35), accept/reject with
+fixed-node rejection (``propose_drift_diffusion`` :49-70), T-move selection (``propose_tmoves``
+:73-120), weight update (``dmc_propagate`` :123-221, ``compute_S`` :224-235), the stochastic comb
+(``branch`` :342-376) and the block loop of ``rundmc`` (:413-591, without the HDF5 side).
+
+``rng`` (optional) supplies the random draws so tests can replay the reference's:
+``normal(W)->(W,3)``, ``rand(W)->(W,)``, ``rand1()->float``, ``rot()->(3,3)``, ``random(W)->(W,)``.
+"""
+
+import numpy as np
+
+
+class _NumpyRNG:
+    """The draws of the reference, from numpy's global generator."""
+
+    def normal(self, W):
+        return np.random.normal(size=(W, 3))
+
+    def rand(self, W):
+        return np.random.rand(W)
+
+    def rand1(self):
+        return np.random.rand()
+
+    def random(self, W):
+        return np.random.random(size=W)
+
+    def rot(self):
+        q = np.random.normal(size=4)
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def limdrift(g, tau, acyrus=0.5):
+    """Umrigar's drift limiter; returns the drift already multiplied by an effective time step."""
+    v2 = np.einsum("ij,ij->i", g, g)
+    big = v2 > 1e-8
+    safe = np.where(big, v2, 1.0)
+    taueff = np.where(big, (np.sqrt(1 + 2 * tau * acyrus * safe) - 1) / (acyrus * safe), tau)
+    return g * taueff[:, None]
+
+
+def compute_S(e_trial, e_est, branchcut, v2, tau, eloc, nelec):
+    e_cut = np.clip(e_est - eloc, -branchcut, branchcut)
+    return e_trial - e_est + e_cut / np.sqrt(1 + (v2 * tau / nelec) ** 2)
+
+
+def _energy(acc, configs, wf, rng, N, necp, W):
+    """EnergyAccumulator call with the reference's per-(electron, atom) draws taken from ``rng``."""
+    if rng is None or necp == 0:
+        return acc(configs, wf)
+    unif, rot = np.empty((N, necp, W)), np.empty((N, necp, 3, 3))
+    for e in range(N):
+        for k in range(necp):
+            unif[e, k] = rng.random(W)
+            rot[e, k] = rng.rot()
+    return acc(configs, wf, rot=rot, unif=unif)
+
+
+def propose_tmoves(wf, configs, acc, tstep, e, rng, necp):
+    W = configs.configs.shape[0]
+    if isinstance(rng, _NumpyRNG):
+        moves = acc.nonlocal_tmoves(configs, wf, e, tstep)
+    else:
+        unif, rot = np.empty((necp, W)), np.empty((necp, 3, 3))
+        for k in range(necp):
+            unif[k] = rng.random(W)
+            rot[k] = rng.rot()
+        moves = acc.nonlocal_tmoves(configs, wf, e, tstep, rot=rot, unif=unif)
+    ratio, weight = moves["ratio"], moves["weight"]
+    amp = ratio * weight
+    fwd = np.maximum(amp, 0.0)
+    norm = 1.0 + fwd.sum(axis=1)  # Eq. 34 of Anderson & Umrigar
+    cdf = np.cumsum(fwd / norm[:, None], axis=1)
+    u = np.array([rng.rand1() for _ in range(W)])
+    sel = (cdf < u[:, None]).sum(axis=1)  # == searchsorted(cdf[w], u[w]) per walker
+    chosen = sel < amp.shape[1]
+    rows = np.nonzero(chosen)[0]
+    newpos = configs.configs[:, e, :].copy()
+    newpos[rows] = moves["configs"].configs[rows, sel[rows]]
+    back = amp.copy()
+    rr = 1.0 / ratio[rows, sel[rows]]
+    back[rows] *= rr[:, None]
+    back[rows, sel[rows]] = rr * weight[rows, sel[rows]]  # the move back to the original position
+    back_norm = 1.0 + np.maximum(back, 0.0).sum(axis=1)
+    acceptance = np.where(chosen, norm / back_norm, 0.0)
+    return configs.make_irreducible(e, newpos), chosen, acceptance
+
+
+def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps=5, accumulators=None,
+                  ekey=("energy", "total"), rng=None):
+    """Propagate ``nsteps`` DMC steps without branching; returns (block averages, configs, weights) with the
+    reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``)."""
+    assert accumulators is not None, "Need an energy accumulator for DMC"
+    acc = accumulators[ekey[0]]
+    replay = rng is not None
+    rng = rng if replay else _NumpyRNG()
+    W, N = configs.configs.shape[:2]
+    necp = getattr(acc._device(wf), "necp", 0)
+    wf.recompute(configs)
+    en = _energy(acc, configs, wf, rng if replay else None, N, necp, W)
+    eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
+    steps = []
+    for _ in range(nsteps):
+        r2_acc, r2_prop = np.zeros(W), np.zeros(W)
+        n_acc, n_tm = np.zeros(W), np.zeros(W)
+        if acc.has_nonlocal_moves():
+            for e in range(N):
+                ep, chosen, prob = propose_tmoves(wf, configs, acc, tstep, e, rng, necp)
+                accept = chosen & (prob > rng.rand(W))
+                configs.move(e, ep, accept)
+                wf.updateinternals(e, ep, configs, mask=accept)
+                n_tm += accept
+        for e in range(N):
+            drift = limdrift(np.real(wf.gradient(e, configs.electron(e)).T), tstep)
+            gauss = np.sqrt(tstep) * rng.normal(W)
+            ep = configs.make_irreducible(e, configs.configs[:, e, :] + gauss + drift)
+            g, psi_ratio, saved = wf.gradient_value(e, ep)
+            back = gauss + drift + limdrift(np.real(g.T), tstep)
+            t_prob = np.exp((np.einsum("ij,ij->i", gauss, gauss) - np.einsum("ij,ij->i", back, back)) / (2 * tstep))
+            ratio = np.abs(psi_ratio) ** 2 * t_prob
+            if wf.dtype == float:
+                ratio = ratio * np.sign(psi_ratio)  # fixed node: a sign change is never accepted
+            accept = ratio > rng.rand(W)
+            r2 = np.einsum("ij,ij->i", gauss + drift, gauss + drift)
+            configs.move(e, ep, accept)
+            wf.updateinternals(e, ep, configs, mask=accept, saved_values=saved)
+            r2_prop += r2
+            r2_acc += np.where(accept, r2, 0.0)
+            n_acc += accept
+        eloc_old, v2_old = eloc, v2
+        en = _energy(acc, configs, wf, rng if replay else None, N, necp, W)
+        eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
+        S = 0.5 * (compute_S(e_trial, e_est, branchcut_start, v2, tstep, eloc, N)
+                   + compute_S(e_trial, e_est, branchcut_start, v2_old, tstep, eloc_old, N))
+        weights *= np.exp(tstep * (r2_acc / r2_prop) * S)
+        wavg = np.mean(weights)
+        avg = {ekey[0] + k: np.dot(weights, v) / (W * wavg) for k, v in en.items()}
+        for name, other in accumulators.items():
+            if name != ekey[0]:
+                avg.update({name + k: np.einsum("...i,i...->...", weights, v) / (W * wavg) for k, v in other(configs, wf).items()})
+        avg.update(weight=wavg, acceptance=np.mean(n_acc) / N, tmove_acceptance=np.mean(n_tm) / N)
+        steps.append(avg)
+    wts = np.array([d["weight"] for d in steps])
+    out = {k: np.mean([d[k] * w for d, w in zip(steps, wts / wts.mean())], axis=0) for k in steps[0]}
+    out["weight"] = wts.mean()
+    return out, configs, weights
+
+
+def comb_indices(weights, base_u):
+    """Stochastic comb: resampling indices for walkers with the given weights (global order)."""
+    W = len(weights)
+    cum = np.cumsum(weights)
+    wtot = cum[-1]
+    teeth = (base_u * wtot + np.linspace(0, wtot, W, endpoint=False)) % wtot
+    return np.searchsorted(cum, teeth), wtot
+
+
+def branch(configs, weights, base_u=None):
+    """Single-process branching: walkers resampled in proportion to their weights, weights reset to the mean."""
+    base_u = np.random.rand() if base_u is None else base_u
+    newinds, wtot = comb_indices(weights, base_u)
+    unique, counts = np.unique(newinds, return_counts=True)
+    configs.resample(newinds)
+    weights.fill(wtot / len(weights))
+    return configs, weights, {"max branches": int(counts.max()), "Number of walkers killed": int(len(weights) - len(unique))}
+
+
+def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=None, accumulators=None, verbose=False,
+           ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False):
+    """Block loop of the reference's ``rundmc`` (no restart files): VMC warm-up, energy reference, then
+    propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every rank calls this with
+    its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo)."""
+    from . import dist as pdist
+    from .vmc import vmc
+
+    nsteps_per_block = max(1, int(0.1 / tstep)) if nsteps_per_block is None else nsteps_per_block
+    acc = accumulators[ekey[0]]
+    _, configs = vmc(wf, configs, nblocks=vmc_warmup, accumulators={}, verbose=verbose)
+    wf.recompute(configs)
+    en = np.real(acc(configs, wf)[ekey[1]])
+    if distributed:
+        (m1, m2), _ = pdist.allreduce_block([en.sum(), (en**2).sum()], len(en))
+        eref, esigma = m1, np.sqrt(max(m2 - m1 * m1, 0.0))
+    else:
+        eref, esigma = en.mean(), en.std()
+    e_trial = e_est = eref
+    W = configs.configs.shape[0]
+    weights = np.ones(W) if weights is None else weights
+    rows = []
+    for block in range(nblocks):
+        blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
+                                              nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey)
+        if distributed:  # weighted recombination of the per-rank block averages (dmc.py:238-304)
+            keys = sorted(k for k in blk if k != "weight")
+            sums, _ = pdist.allreduce_block([blk[k] * blk["weight"] * W for k in keys] + [blk["weight"] * W, W], 1)
+            wsum, wtot_n = sums[-2], sums[-1]
+            blk = {k: s / wsum for k, s in zip(keys, sums[:-2])}
+            blk["weight"] = wsum / wtot_n
+            configs, weights, info, wstd = pdist.branch_distributed(configs, weights)
+            blk["weight_std"] = wstd
+            mean_w = float(pdist.allreduce_block([weights.sum()], len(weights))[0][0])
+        else:
+            blk["weight_std"] = np.std(weights)
+            configs, weights, info = branch(configs, weights)
+            mean_w = np.mean(weights)
+        blk.update(info, e_trial=e_trial, e_est=e_est, block=block, esigma=esigma, tstep=tstep, nsteps_per_block=nsteps_per_block)
+        rows.append(blk)
+        en_b = np.array([r[ekey[0] + ekey[1]] for r in rows])
+        wt_b = np.array([r["weight"] for r in rows])
+        warm = len(en_b) // 4
+        e_est = float(np.real(np.average(en_b[warm:], weights=wt_b[warm:])))  # estimate_energy, dmc.py:594-603
+        e_trial = e_est - feedback * float(np.real(np.log(mean_w)))
+        if verbose:
+            print(f"block {block}: E={blk[ekey[0] + ekey[1]]:.6f} e_trial={e_trial:.6f} e_est={e_est:.6f} sigma(w)={blk['weight_std']:.3g} {info}")
+    return ({k: np.asarray([r[k] for r in rows]) for k in rows[0]} if rows else {}), configs, weights

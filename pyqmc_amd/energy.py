@@ -41,6 +41,33 @@ class EnergyAccumulator:
     def avg(self, configs, wf):
         return {k: np.mean(v, axis=0) for k, v in self(configs, wf).items()}
 
+    def nonlocal_tmoves(self, configs, wf, e, tau, rot=None, unif=None):
+        """``EnergyAccumulator.nonlocal_tmoves`` (accumulators.py:80-86) -> ``eval_ecp.compute_tmoves``
+        (eval_ecp.py:43-80): dict with ``ratio`` (W,P), ``weight`` (W,P) and ``configs`` (an electron object with
+        (W,P,3) candidate positions) over all ECP atoms' quadrature points.  ``rot`` (necp,3,3) / ``unif`` (necp,W)
+        replay the reference's draws; by default they are drawn from ``numpy.random`` like the reference does."""
+        from . import _ffi
+
+        dev = self._device(wf)
+        W, P = dev.W, dev.call_int("pqa_tmove_npoints")
+        if P == 0:
+            return {"ratio": np.ones((W, 0)), "weight": np.zeros((W, 0))}
+        necp = dev.necp
+        if unif is None:
+            unif = np.random.random(size=(necp, W))
+        if rot is None:
+            q = np.random.normal(size=(necp, 4))
+            q /= np.linalg.norm(q, axis=1, keepdims=True)
+            w_, x, y, z = q.T
+            rot = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)], -1),
+                            np.stack([2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)], -1),
+                            np.stack([2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)], -1)], -2)
+        rot, unif = _ffi.f64(rot), _ffi.f64(unif)
+        ratio, weight, pos = np.empty((W, P)), np.empty((W, P)), np.empty((W, P, 3))
+        dev.call("pqa_tmoves", int(e), float(tau), float(self.threshold), _ffi.ptr(rot), _ffi.ptr(unif), _ffi.ptr(ratio),
+                 _ffi.ptr(weight), _ffi.ptr(pos))
+        return {"ratio": ratio, "weight": weight, "configs": configs.make_irreducible(e, pos)}
+
     def has_nonlocal_moves(self):
         return self.mol._ecp != {}
 

@@ -119,6 +119,9 @@ class DeviceWF:
     def call(self, name, *args):
         _ffi.check(self._h, getattr(_ffi.lib(), name)(self._h, *args))
 
+    def call_int(self, name, *args):
+        return int(getattr(_ffi.lib(), name)(self._h, *args))
+
     def set_param(self, name, value):
         a = _ffi.f64(value)
         self.call("pqa_set_param", name.encode(), _ffi.ptr(a), a.size)

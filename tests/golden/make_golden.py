@@ -323,6 +323,74 @@ def g_vmc():
     save("g11_vmc", **out)
 
 
+# ------------------------------------------------------------------ G12 DMC propagate + branch
+def g_dmc():
+    import pyqmc.method.dmc as refdmc
+    import pyqmc.wf.orbitals as reforb
+
+    # The un-JIT-ed stand-in for the numba AO evaluator cannot reshape a zero-point result (an all-False
+    # T-move mask); PySCF / real numba return an empty array there.  Give the stub the same behaviour.
+    orig_aos = reforb.MoleculeOrbitalEvaluator.aos
+
+    def aos(self, eval_str, configs, mask=None):
+        coords = configs.configs if mask is None else configs.configs[mask]
+        if coords.size == 0:
+            nao = self.parameters["mo_coeff_alpha"].shape[0]
+            shape = (1, *coords.shape[:-1], nao) if "deriv" not in eval_str else (1, 4 if "deriv1" in eval_str else 5, *coords.shape[:-1], nao)
+            return np.zeros(shape)
+        return orig_aos(self, eval_str, configs, mask)
+
+    reforb.MoleculeOrbitalEvaluator.aos = aos
+    out = {}
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    wf = make_wf(mol, mf)
+    W, nsteps, tstep = 7, 2, 0.02
+    configs = walkers(mol, W, 61)
+    rng = np.random.default_rng(4)
+    configs.configs[:, :2, :] = mol.atom_coords()[0] + 0.3 * rng.standard_normal((W, 2, 3))  # exercise the ECP mask / T-moves
+    out["start"] = configs.configs.copy()
+    weights = 1.0 + 0.1 * rng.standard_normal(W)
+    out["weights0"] = weights.copy()
+    e_trial, e_est, branchcut = -17.0, -17.1, 3.0
+    out["params"] = np.array([tstep, branchcut, e_trial, e_est, nsteps])
+    accepts = []
+    orig = wf.updateinternals
+
+    def spy(e, epos, cfg, mask=None, saved_values=None):
+        accepts.append(np.asarray(mask).copy())
+        return orig(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(900) as t:
+        df, configs, weights = refdmc.dmc_propagate(wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps=nsteps,
+                                                    accumulators={"energy": pyq.EnergyAccumulator(mol)})
+    wf.updateinternals = orig
+    out["normal"] = np.asarray(t.log["normal"])
+    rand = t.log["rand"]
+    out["rand_scalar"] = np.asarray([float(r) for r in rand if np.ndim(r) == 0])
+    out["rand_vector"] = np.asarray([r for r in rand if np.ndim(r) == 1])
+    out["rand_is_scalar"] = np.asarray([np.ndim(r) == 0 for r in rand])
+    out["rot"] = np.asarray(t.log["rot"])
+    out["random"] = np.asarray(t.log["random"])
+    out["accepts"] = np.asarray(accepts)
+    out["final"] = configs.configs.copy()
+    out["weights"] = weights
+    for k, v in df.items():
+        out["df_" + k] = np.asarray(v)
+    out["df_keys"] = np.asarray(sorted(df.keys()))
+    # branch (dmc.py:342-376)
+    w2 = np.abs(1.0 + 0.4 * rng.standard_normal(64))
+    cfg2 = OpenConfigs(rng.standard_normal((64, 8, 3)))
+    out["branch_weights"], out["branch_configs"] = w2.copy(), cfg2.configs.copy()
+    with Tapes(901) as t:
+        cfg2, wnew, info = refdmc.branch(cfg2, w2.copy())
+    out["branch_u"] = np.asarray(float(t.log["rand"][0]))
+    out["branch_newconfigs"], out["branch_newweights"] = cfg2.configs.copy(), wnew
+    out["branch_info"] = np.asarray([info["max branches"], info["Number of walkers killed"]])
+    save("g12_dmc", **out)
+
+
 if __name__ == "__main__":
     g_sherman_morrison()
     g_ao()
@@ -330,3 +398,4 @@ if __name__ == "__main__":
     g_protocol()
     g_energy()
     g_vmc()
+    g_dmc()

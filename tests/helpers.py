@@ -111,3 +111,26 @@ def run_protocol(wf, g, names=("slater", "jastrow", "wf")):
             err[f"e{e}_{nm}_post_log"] = relerr(l, g[f"e{e}_{nm}_post_log"])
             err[f"e{e}_{nm}_post_sign"] = relerr(s, g[f"e{e}_{nm}_post_sign"])
     return err
+
+
+class ReplayTape:
+    """Replays the reference's recorded random draws (tests/golden/g12_dmc.npz) in call order."""
+
+    def __init__(self, g):
+        self._n, self._rs, self._rv = iter(g["normal"]), iter(g["rand_scalar"]), iter(g["rand_vector"])
+        self._rot, self._rnd = iter(g["rot"]), iter(g["random"])
+
+    def normal(self, W):
+        return next(self._n)
+
+    def rand(self, W):
+        return next(self._rv)
+
+    def rand1(self):
+        return float(next(self._rs))
+
+    def rot(self):
+        return next(self._rot)
+
+    def random(self, W):
+        return next(self._rnd)

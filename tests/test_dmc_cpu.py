@@ -1,0 +1,133 @@
+"""Host logic of the DMC driver (pyqmc_amd/dmc.py) and of the distributed branching, on CPU.
+
+The driver only talks to the wave-function protocol and the accumulator interface, so here the ORACLE
+objects stand in for the GPU engine; the replayed random draws are the reference's own
+(tests/golden/g12_dmc.npz), so the driver must reproduce the reference's dmc_propagate exactly."""
+
+import os
+import socket
+
+import numpy as np
+
+import helpers
+from helpers import golden, relerr
+from pyqmc_amd import dist as pdist
+from pyqmc_amd import dmc, systems
+from pyqmc_amd.configs import OpenConfigs
+
+
+class OracleAccumulator:
+    """EnergyAccumulator interface over the oracle (test double for the device accumulator)."""
+
+    def __init__(self, mol, threshold=10.0):
+        self.mol, self.threshold = mol, threshold
+
+    class _Dev:
+        def __init__(self, necp):
+            self.necp = necp
+
+    def _device(self, wf):
+        from oracle import energy as oenergy
+
+        return self._Dev(len(oenergy.ecp_atoms(self.mol)))
+
+    def __call__(self, configs, wf, rot=None, unif=None):
+        from oracle import energy as oenergy
+
+        return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif)
+
+    def has_nonlocal_moves(self):
+        return bool(self.mol._ecp)
+
+    def nonlocal_tmoves(self, configs, wf, e, tau, rot=None, unif=None):
+        from oracle import dmc as odmc
+
+        class T:
+            def __init__(s):
+                s.r, s.u = iter(rot), iter(unif)
+
+            def rot(s):
+                return next(s.r)
+
+            def random(s, W):
+                return next(s.u)
+
+        ratio, weight, pos = odmc.compute_tmoves(self.mol, configs, wf, e, self.threshold, tau, T())
+        return {"ratio": ratio, "weight": weight, "configs": configs.make_irreducible(e, pos)}
+
+
+def test_driver_reproduces_reference_dmc_propagate():
+    g = golden("g12_dmc")
+    mol = systems.water()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    df, configs, weights = dmc.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+                                             float(e_trial), float(e_est), nsteps=int(nsteps),
+                                             accumulators={"energy": OracleAccumulator(mol)}, rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert relerr(configs.configs, g["final"]) < 1e-10 and relerr(weights, g["weights"]) < 1e-9
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert relerr(df[k], g["df_" + k]) < 1e-9, k
+
+
+def test_limdrift_and_compute_S_match_oracle():
+    from oracle import dmc as odmc
+
+    rng = np.random.default_rng(0)
+    gvec = rng.standard_normal((50, 3)) * np.logspace(-6, 2, 50)[:, None]
+    assert np.allclose(dmc.limdrift(gvec, 0.02), odmc.limdrift(gvec, 0.02), rtol=1e-14, atol=0)
+    v2, eloc = rng.random(20) * 50, rng.standard_normal(20) * 5
+    assert np.allclose(dmc.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc, 8), odmc.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc.copy(), 8), rtol=1e-14)
+
+
+def test_branch_matches_reference_golden():
+    g = golden("g12_dmc")
+    cfg = OpenConfigs(g["branch_configs"].copy())
+    cfg, w, info = dmc.branch(cfg, g["branch_weights"].copy(), float(g["branch_u"]))
+    assert np.array_equal(cfg.configs, g["branch_newconfigs"]) and relerr(w, g["branch_newweights"]) < 1e-14
+    assert [info["max branches"], info["Number of walkers killed"]] == g["branch_info"].tolist()
+
+
+def _branch_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = golden("g12_dmc")
+        lo, hi = pdist.shard_bounds(len(g["branch_weights"]), world)[rank]
+        cfg = OpenConfigs(g["branch_configs"][lo:hi].copy())
+        cfg, w, info, wstd = pdist.branch_distributed(cfg, g["branch_weights"][lo:hi].copy(), base_u=float(g["branch_u"]))
+        q.put((rank, cfg.configs, w, info, wstd))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_branch_two_ranks_gloo():
+    """Sharded stochastic comb == the reference's gather -> branch -> re-split (dmc.py:286-287,342-376,566)."""
+    import torch.multiprocessing as mp
+
+    g = golden("g12_dmc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_branch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    joined = np.concatenate([r[1] for r in res])
+    assert np.array_equal(joined, g["branch_newconfigs"])
+    assert relerr(np.concatenate([r[2] for r in res]), g["branch_newweights"]) < 1e-14
+    for r in res:
+        assert [r[3]["max branches"], r[3]["Number of walkers killed"]] == g["branch_info"].tolist()
+        assert abs(r[4] - np.std(g["branch_weights"])) < 1e-14

@@ -249,3 +249,43 @@ def dev_ii(mol):
     from oracle import energy as oenergy
 
     return oenergy.coulomb(mol, OpenConfigs(np.zeros((1, sum(mol.nelec), 3)) + np.arange(sum(mol.nelec))[None, :, None]))[2]
+
+
+def test_dmc_propagate_golden():
+    """dmc_propagate (dmc.py:123-221: ECP T-moves, drift-diffusion with fixed-node rejection, weight update) with
+    every wave-function / energy / T-move quantity from the HIP library, replaying the reference's random draws."""
+    import pyqmc_amd as pa
+
+    g = golden("g12_dmc")
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    df, configs, weights = pa.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+                                            float(e_trial), float(e_est), nsteps=int(nsteps),
+                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert note("dmc_final", relerr(configs.configs, g["final"])) < 1e-9
+    assert note("dmc_weights", relerr(weights, g["weights"])) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert note("dmc_" + k, relerr(df[k], g["df_" + k])) < 1e-8, k
+
+
+def test_rundmc_smoke():
+    """Block loop (rundmc, dmc.py:413-591 without files): VMC warm-up, propagate, branch, trial-energy feedback."""
+    import pyqmc_amd as pa
+
+    np.random.seed(7)
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    configs = pa.initial_guess(mol, 256, rng=np.random.default_rng(3))
+    df, configs, weights = pa.rundmc(wf, configs, tstep=0.02, nblocks=3, nsteps_per_block=2, vmc_warmup=2,
+                                     accumulators={"energy": pa.EnergyAccumulator(mol)})
+    assert df["energytotal"].shape == (3,) and np.all(np.isfinite(df["energytotal"]))
+    for k in ("weight", "e_trial", "e_est", "esigma", "weight_std", "max branches", "Number of walkers killed", "tmove_acceptance", "acceptance", "block"):
+        assert k in df, k
+    assert np.allclose(weights, weights[0]) and configs.configs.shape == (256, 8, 3)
+    assert 0.5 < df["acceptance"].mean() <= 1.0

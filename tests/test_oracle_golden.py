@@ -129,3 +129,28 @@ def test_g11_vmc_trajectory(tag, mol):
         assert relerr(blk[k], g[f"{tag}_blk_{k}"]) < 1e-8, k
     # output-dict contract of the reference's vmc_worker (C1 plumbing)
     assert set(g[tag + "_blk_keys"].tolist()) == set(blk.keys())
+
+
+def test_g12_dmc_propagate_and_branch():
+    """dmc_propagate (dmc.py:123-221: T-moves, drift-diffusion with fixed-node rejection, weights) and branch
+    (:342-376) replayed with the reference's own random draws."""
+    from oracle import dmc as odmc
+
+    g = golden("g12_dmc")
+    mol = systems.water()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    rec = []
+    df, configs, weights = odmc.dmc_propagate(mol, wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep),
+                                              float(branchcut), float(e_trial), float(e_est), int(nsteps),
+                                              helpers.ReplayTape(g), record=rec)
+    acc = np.asarray([r[2] for r in rec])
+    assert np.array_equal(acc, g["accepts"]) and acc[:8].any()  # some T-moves were accepted
+    assert relerr(configs.configs, g["final"]) < 1e-10 and relerr(weights, g["weights"]) < 1e-9
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert relerr(df[k], g["df_" + k]) < 1e-9, k
+    newinds, wnew, info = odmc.branch(g["branch_configs"], g["branch_weights"], float(g["branch_u"]))
+    assert np.array_equal(g["branch_configs"][newinds], g["branch_newconfigs"])
+    assert relerr(wnew, g["branch_newweights"]) < 1e-14
+    assert [info["max branches"], info["Number of walkers killed"]] == g["branch_info"].tolist()
