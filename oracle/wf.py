@@ -363,3 +363,89 @@ class MultiplyWF:
             for j in range(i + 1, len(g)):
                 cross += np.sum(g[i] * g[j], axis=0)
         return np.sum(g, axis=0), np.sum(l, axis=0) + 2 * cross
+
+
+class ThreeBodyJastrow:
+    """Electron-electron-ion Jastrow e^U (``pyqmc/wf/three_body_jastrow.py:19-655``):
+
+        U = 1/2 sum_e P_e,   P_e = sum_{j != e} sum_I sum_{klm} C_{Iklm,s(e,j)} a_k(r_eI) a_l(r_jI) b_m(r_ej),
+
+    C = (c + c^T_{kl})/2 (:94-96), spin index s = [e down] + [j down].  Moving electron e changes U by
+    P_e(new) - P_e(old) (testvalue :323-341); gradient_laplacian returns (grad U, lap U + |grad U|^2) (:541-655).
+    Restated directly from these formulas (the reference spreads them over several einsum calls)."""
+
+    def __init__(self, mol, a_basis, b_basis, rcut):
+        self._nup, self._ndn = mol.nelec
+        self._nelec = self._nup + self._ndn
+        self.atoms = np.asarray(mol.atom_coords(), dtype=float)
+        self.a_basis, self.b_basis, self.rcut = list(a_basis), list(b_basis), float(rcut)
+        self.parameters = {"ccoeff": np.zeros((len(self.atoms), len(a_basis), len(a_basis), len(b_basis), 3))}
+        self.dtype = float
+
+    def _C(self):
+        c = self.parameters["ccoeff"]
+        return 0.5 * (c + c.swapaxes(1, 2))
+
+    def _terms(self, e, pos, xw, want):
+        """P, grad P (3,...), lap P of electron e at pos (Wm,3) against walkers xw (Wm,N,3)."""
+        others = np.arange(self._nelec) != e
+        edown = int(e >= self._nup)
+        xo = xw[:, others]  # (W, N-1, 3)
+        sig = edown + (np.nonzero(others)[0] >= self._nup).astype(int)  # spin index per j
+        C = self._C()[..., sig]  # (A,k,l,m,N-1)
+        de_I = pos[:, None, :] - self.atoms[None]  # (W,A,3)
+        de_j = pos[:, None, :] - xo  # (W,N-1,3)
+        dj_I = xo[:, :, None, :] - self.atoms[None, None]  # (W,N-1,A,3)
+        aj = jastrow_basis.evaluate(self.a_basis, self.rcut, dj_I, np.linalg.norm(dj_I, axis=-1), "value")  # (W,N-1,A,l)
+        if want == "value":
+            ae = jastrow_basis.evaluate(self.a_basis, self.rcut, de_I, np.linalg.norm(de_I, axis=-1), "value")
+            b = jastrow_basis.evaluate(self.b_basis, self.rcut, de_j, np.linalg.norm(de_j, axis=-1), "value")
+            return np.einsum("wIk,wjIl,wjm,Iklmj->w", ae, aj, b, C), None, None
+        gae, ae = jastrow_basis.evaluate(self.a_basis, self.rcut, de_I, np.linalg.norm(de_I, axis=-1), "gradient_value")
+        gb, b = jastrow_basis.evaluate(self.b_basis, self.rcut, de_j, np.linalg.norm(de_j, axis=-1), "gradient_value")
+        P = np.einsum("wIk,wjIl,wjm,Iklmj->w", ae, aj, b, C)
+        grad = np.einsum("wIkx,wjIl,wjm,Iklmj->xw", gae, aj, b, C) + np.einsum("wIk,wjIl,wjmx,Iklmj->xw", ae, aj, gb, C)
+        if want == "gradient_value":
+            return P, grad, None
+        _, lae = jastrow_basis.evaluate(self.a_basis, self.rcut, de_I, np.linalg.norm(de_I, axis=-1), "gradient_laplacian")
+        _, lb = jastrow_basis.evaluate(self.b_basis, self.rcut, de_j, np.linalg.norm(de_j, axis=-1), "gradient_laplacian")
+        lap = (np.einsum("wIk,wjIl,wjm,Iklmj->w", lae, aj, b, C) + 2.0 * np.einsum("wIkx,wjIl,wjmx,Iklmj->w", gae, aj, gb, C)
+               + np.einsum("wIk,wjIl,wjm,Iklmj->w", ae, aj, lb, C))
+        return P, grad, lap
+
+    def recompute(self, configs):
+        self._x = configs.configs.copy()
+        return self.value()
+
+    def value(self):
+        u = np.zeros(len(self._x))
+        for e in range(self._nelec):
+            u += 0.5 * self._terms(e, self._x[:, e], self._x, "value")[0]
+        return np.ones(len(u)), u
+
+    def testvalue(self, e, epos, mask=None):
+        W = self._x.shape[0]
+        mask = np.ones(W, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        xw = self._x[mask]
+        old = self._terms(e, xw[:, e], xw, "value")[0]
+        x = epos.configs[mask]
+        if x.ndim == 3:
+            new = np.stack([self._terms(e, x[:, q], xw, "value")[0] for q in range(x.shape[1])], axis=1)
+            return np.exp(new - old[:, None]), None
+        return np.exp(self._terms(e, x, xw, "value")[0] - old), None
+
+    def gradient_value(self, e, epos):
+        P, grad, _ = self._terms(e, epos.configs, self._x, "gradient_value")
+        old = self._terms(e, self._x[:, e], self._x, "value")[0]
+        return grad, np.exp(P - old), None
+
+    def gradient(self, e, epos):
+        return self._terms(e, epos.configs, self._x, "gradient_value")[1]
+
+    def gradient_laplacian(self, e, epos):
+        _, grad, lap = self._terms(e, epos.configs, self._x, "gradient_laplacian")
+        return grad, lap + np.sum(grad**2, axis=0)
+
+    def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        mask = np.ones(len(self._x), dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        self._x[mask, e, :] = epos.configs[mask]

@@ -323,6 +323,100 @@ def g_vmc():
     save("g11_vmc", **out)
 
 
+# ------------------------------------------------------------------ G7 three-body Jastrow (+ multi-determinant: config C4 shape)
+def g_jastrow3():
+    import pyqmc.wftools as wftools
+
+    out = {}
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = systems.random_determinants(mol, mf, 12)
+    out["det_json"] = np.asarray(repr(dets))
+    wf, _ = pyq.generate_wf(mol, mf, jastrow=[pyq.generate_jastrow, wftools.generate_jastrow3], jastrow_kws=[{}, {}],
+                            slater_kws=dict(evaluate_orbitals_with="numba", determinants=dets))
+    rng = np.random.default_rng(11)
+    j2, j3 = wf.wf_factors[1], wf.wf_factors[2]
+    j2.parameters["acoeff"] = 0.05 * rng.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * rng.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    j3.parameters["ccoeff"] = 0.1 * np.random.default_rng(12).standard_normal(j3.parameters["ccoeff"].shape)
+    out["ccoeff"] = j3.parameters["ccoeff"].copy()
+    W = 5
+    configs = walkers(mol, W, 71)
+    out["configs"] = configs.configs.copy()
+    names = {"j3": j3, "wf": wf}
+    for nm, w in names.items():
+        s_, l_ = w.recompute(configs)
+        out[f"{nm}_recompute_log"] = l_
+    prng = np.random.default_rng(13)
+    out["electrons"] = np.asarray([0, 3, 4, 7])
+    for e in out["electrons"]:
+        e = int(e)
+        newpos = configs.configs[:, e, :] + 0.3 * prng.standard_normal((W, 3))
+        aux = configs.configs[:, e, None, :] + 0.4 * prng.standard_normal((W, 6, 3))
+        mask = prng.random(W) > 0.35
+        mask[0] = True
+        accept = prng.random(W) > 0.4
+        out[f"e{e}_newpos"], out[f"e{e}_aux"], out[f"e{e}_mask"], out[f"e{e}_accept"] = newpos, aux, mask, accept
+        ep, ea = configs.make_irreducible(e, newpos), configs.make_irreducible(e, aux)
+        for nm, w in names.items():
+            p = f"e{e}_{nm}_"
+            g, v, _ = w.gradient_value(e, ep)
+            out[p + "gv_grad"], out[p + "gv_val"] = g, v
+            out[p + "grad"] = w.gradient(e, ep)
+            g, l = w.gradient_laplacian(e, ep)
+            out[p + "gl_grad"], out[p + "gl_lap"] = g, l
+            out[p + "testvalue"] = w.testvalue(e, ep)[0]
+            out[p + "testvalue_aux"] = w.testvalue(e, ea, mask)[0]
+        # NOTE reference defect: ThreeBodyJastrow.updateinternals (three_body_jastrow.py:149-189) takes the OLD
+        # position of electron e from its `configs` argument, but vmc_worker/dmc_propagate move `configs` first
+        # (mc.py:135-136), which leaves its P_i sums stale (6.6e-3 error in log psi here).  The factor is
+        # self-consistent (4e-16 vs recompute) when updated BEFORE the move, so the goldens use that order.
+        wf.updateinternals(e, ep, configs, mask=accept)
+        configs.move(e, ep, accept)
+        for nm, w in names.items():
+            out[f"e{e}_{nm}_post_log"] = w.value()[1]
+    out["final_configs"] = configs.configs.copy()
+    for nm, w in names.items():
+        out[f"{nm}_final_recompute_log"] = w.recompute(configs)[1]
+    # energy + short VMC trajectory of the full C4-shaped wave function
+    with Tapes(300) as t:
+        en = pyq.EnergyAccumulator(mol)(configs, wf)
+    for k, v in en.items():
+        out["energy_" + k] = np.asarray(v)
+    out["energy_rot"] = np.asarray(t.log["rot"]).reshape(8, 3, 3, 3)
+    out["energy_unif"] = np.asarray(t.log["random"]).reshape(8, 3, W)
+    start = walkers(mol, W, 72)
+    out["vmc_start"] = start.configs.copy()
+    accepts = []
+    orig = wf.updateinternals
+    shadow = {"x": start.configs.copy()}  # walkers as they were before the driver's configs.move
+
+    def spy(e, ep, c, mask=None, saved_values=None):
+        accepts.append(np.asarray(mask).copy())
+        moved = c.configs[:, e].copy()
+        c.configs[:, e] = shadow["x"][:, e]  # present the un-moved walkers to updateinternals (see NOTE above)
+        orig(e, ep, c, mask=mask, saved_values=saved_values)
+        c.configs[:, e] = moved
+        shadow["x"][:, e] = moved
+
+    wf.updateinternals = spy
+    with Tapes(301) as t:
+        blk, cfg = vmc_worker(wf, start, 0.3, 2, {"energy": pyq.EnergyAccumulator(mol)})
+    wf.updateinternals = orig
+    out["vmc_gauss"] = np.asarray(t.log["normal"]).reshape(2, 8, W, 3)
+    out["vmc_unif"] = np.asarray(t.log["rand"]).reshape(2, 8, W)
+    out["vmc_ecp_rot"] = np.asarray(t.log["rot"]).reshape(2, 8, 3, 3, 3)
+    out["vmc_ecp_unif"] = np.asarray(t.log["random"]).reshape(2, 8, 3, W)
+    out["vmc_accepts"] = np.asarray(accepts).reshape(2, 8, W)
+    out["vmc_final"] = cfg.configs.copy()
+    for k, v in blk.items():
+        if "time" not in k:
+            out["vmc_blk_" + k] = np.asarray(v)
+    save("g7_jastrow3_multidet", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -398,4 +492,5 @@ if __name__ == "__main__":
     g_protocol()
     g_energy()
     g_vmc()
+    g_jastrow3()
     g_dmc()

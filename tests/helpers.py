@@ -134,3 +134,59 @@ class ReplayTape:
 
     def random(self, W):
         return next(self._rnd)
+
+
+def ccoeff_params(mol, na=4, nb=4, seed=12):
+    return 0.1 * np.random.default_rng(seed).standard_normal((mol.natm, na, na, nb, 3))
+
+
+def oracle_wf3(mol, mf, determinants=None):
+    """Slater x two-body x three-body Jastrow (config C4 shape), parameters as in make_golden.g_jastrow3."""
+    from oracle import jastrow_basis, wf as owf
+
+    base = oracle_wf(mol, mf, determinants)
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False)
+    j3 = owf.ThreeBodyJastrow(mol, ab, bb, rcut)
+    j3.parameters["ccoeff"] = ccoeff_params(mol)
+    return owf.MultiplyWF(base.wf_factors[0], base.wf_factors[1], j3)
+
+
+def gpu_wf3(mol, mf, determinants=None):
+    import pyqmc_amd as pa
+
+    wf = pa.generate_wf(mol, mf, determinants=determinants, jastrow3=True)
+    a, b = jastrow_params(mol)
+    wf.parameters["wf2acoeff"] = a
+    wf.parameters["wf2bcoeff"] = b
+    wf.parameters["wf3ccoeff"] = ccoeff_params(mol)
+    return wf
+
+
+def run_protocol3(wf, g):
+    """Replay make_golden.g_jastrow3's protocol section on the three-body factor and on the product."""
+    configs = OpenConfigs(g["configs"].copy())
+    names = {"j3": wf.wf_factors[2], "wf": wf}
+    err = {}
+    for nm, w in names.items():
+        err[f"{nm}_recompute_log"] = relerr(w.recompute(configs)[1], g[f"{nm}_recompute_log"])
+    for e in g["electrons"]:
+        e = int(e)
+        ep = configs.make_irreducible(e, g[f"e{e}_newpos"])
+        ea = configs.make_irreducible(e, g[f"e{e}_aux"])
+        mask, accept = g[f"e{e}_mask"], g[f"e{e}_accept"]
+        for nm, w in names.items():
+            p = f"e{e}_{nm}_"
+            gr, v, _ = w.gradient_value(e, ep)
+            err[p + "gv_grad"], err[p + "gv_val"] = relerr(gr, g[p + "gv_grad"]), relerr(v, g[p + "gv_val"])
+            err[p + "grad"] = relerr(w.gradient(e, ep), g[p + "grad"])
+            gr, l = w.gradient_laplacian(e, ep)
+            err[p + "gl_grad"], err[p + "gl_lap"] = relerr(gr, g[p + "gl_grad"]), relerr(l, g[p + "gl_lap"])
+            err[p + "testvalue"] = relerr(w.testvalue(e, ep)[0], g[p + "testvalue"])
+            err[p + "testvalue_aux"] = relerr(w.testvalue(e, ea, mask)[0], g[p + "testvalue_aux"])
+        configs.move(e, ep, accept)
+        wf.updateinternals(e, ep, configs, mask=accept)
+        for nm, w in names.items():
+            err[f"e{e}_{nm}_post_log"] = relerr(w.value()[1], g[f"e{e}_{nm}_post_log"])
+    for nm, w in names.items():
+        err[f"{nm}_final_recompute_log"] = relerr(w.recompute(configs)[1], g[f"{nm}_final_recompute_log"])
+    return err

@@ -154,3 +154,30 @@ def test_g12_dmc_propagate_and_branch():
     assert np.array_equal(g["branch_configs"][newinds], g["branch_newconfigs"])
     assert relerr(wnew, g["branch_newweights"]) < 1e-14
     assert [info["max branches"], info["Number of walkers killed"]] == g["branch_info"].tolist()
+
+
+def test_g7_three_body_jastrow_multidet():
+    """ThreeBodyJastrow (three_body_jastrow.py:19-655) alone and inside the 12-determinant x 2-body x 3-body
+    product (BASELINE config C4 shape): protocol triangle, EnergyAccumulator dict, vmc_worker trajectory."""
+    import ast
+
+    g = golden("g7_jastrow3_multidet")
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = ast.literal_eval(str(g["det_json"]))
+    wf = helpers.oracle_wf3(mol, mf, dets)
+    err = helpers.run_protocol3(wf, g)
+    bad = {k: v for k, v in err.items() if v > 1e-10}
+    assert not bad, bad
+    configs = OpenConfigs(g["final_configs"].copy())
+    wf.recompute(configs)
+    en = oenergy.energy(mol, configs, wf, 10.0, g["energy_rot"], g["energy_unif"])
+    for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+        assert relerr(en[k], g["energy_" + k]) < 1e-9, k
+    rec = []
+    blk, cfg = ovmc.vmc_worker(mol, wf, OpenConfigs(g["vmc_start"].copy()), 0.3, g["vmc_gauss"], g["vmc_unif"], g["vmc_ecp_rot"],
+                               g["vmc_ecp_unif"], record=rec)
+    assert np.array_equal(np.asarray(rec).reshape(g["vmc_accepts"].shape), g["vmc_accepts"])
+    assert relerr(cfg.configs, g["vmc_final"]) < 1e-9
+    for k in ("energyke", "energyecp", "energytotal", "acceptance"):
+        assert relerr(blk[k], g["vmc_blk_" + k]) < 1e-8, k
