@@ -73,6 +73,16 @@ typedef struct {
   const double* ecp_term_exp;
   const double* ecp_term_coef;
   int32_t has_slater; /* 0: Jastrow-only handle */
+  /* three-body (electron-electron-ion) Jastrow (three_body_jastrow.py:19-63): its own a/b radial bases and
+     ccoeff (natom, na3, na3, nb3, 3) as stored in wf.parameters["ccoeff"] (symmetrised in k,l by the library,
+     :94-96).  na3 = 0: no three-body factor. */
+  int32_t na3, nb3;
+  const int32_t* a3_kind;
+  const double* a3_param;
+  const int32_t* b3_kind;
+  const double* b3_param;
+  double rcut_a3, rcut_b3;
+  const double* ccoeff;
 } pqa_system_t;
 
 /* ---- lifetime --------------------------------------------------------------------- */
@@ -82,7 +92,7 @@ const char* pqa_last_error(const pqa_handle_t* h); /* h may be NULL: last create
 int pqa_device_count(void);
 
 /* wf.parameters[...] (slater.py:193-210, jastrowspin.py:48-53): names "det_coeff",
-   "mo_coeff_alpha", "mo_coeff_beta", "acoeff", "bcoeff".  Takes effect immediately for
+   "mo_coeff_alpha", "mo_coeff_beta", "acoeff", "bcoeff", "ccoeff".  Takes effect immediately for
    evaluations; cached walker state is refreshed by the next recompute, as in the reference. */
 int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n);
 int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int64_t n);
@@ -128,6 +138,17 @@ int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, in
 int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask);
 /* test access: _avalues (W,natom,na,2), _bvalues (W,nb,3), _configscurrent (W,N,3); any may be NULL */
 int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs);
+
+/* ---- three-body Jastrow factor (ThreeBodyJastrow, three_body_jastrow.py) -------------- */
+/* recompute :66-104 / value :191-195 -> U3 (W) */
+int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval);
+int pqa_j3_value(pqa_handle_t* h, double* logval);
+/* testvalue :323-341 (mode 0), gradient_value :454-539 (mode 1), gradient_laplacian :541-655 (mode 2);
+   argument and output layout as pqa_jastrow_eval */
+int pqa_j3_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx, int mode, double* out);
+/* updateinternals :149-189: the factor keeps no partial sums here, so this only moves the stored walker
+   coordinates when the handle has no two-body factor to do it */
+int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask);
 
 /* ---- fused device-resident path --------------------------------------------------------- */
 /* MultiplyWF.recompute (multiplywf.py:81-88) for all factors of the handle; also fills the

@@ -37,6 +37,9 @@ class SystemStruct(C.Structure):
         ("necp", C.c_int32), ("ecp_atom", c_int32_p), ("ecp_chan_off", c_int32_p), ("ecp_term_off", c_int32_p),
         ("ecp_term_n", c_int32_p), ("ecp_term_exp", c_double_p), ("ecp_term_coef", c_double_p),
         ("has_slater", C.c_int32),
+        ("na3", C.c_int32), ("nb3", C.c_int32),
+        ("a3_kind", c_int32_p), ("a3_param", c_double_p), ("b3_kind", c_int32_p), ("b3_param", c_double_p),
+        ("rcut_a3", C.c_double), ("rcut_b3", C.c_double), ("ccoeff", c_double_p),
     ]
 
 
@@ -61,6 +64,10 @@ _PROTOTYPES = {
     "pqa_jastrow_eval": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "pqa_jastrow_update": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "pqa_jastrow_get_state": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pqa_j3_recompute": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pqa_j3_value": (C.c_int, [_H, C.c_void_p]),
+    "pqa_j3_eval": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "pqa_j3_update": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "pqa_wf_recompute": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pqa_wf_value": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "pqa_get_configs": (C.c_int, [_H, C.c_void_p]),

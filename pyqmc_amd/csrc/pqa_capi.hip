@@ -41,7 +41,11 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
-  bool has_slater = false, has_jastrow = false;
+  bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
+  bool has_j2 = false, has_j3 = false;
+  int na3 = 0, nb3 = 0;
+  double* d_c3 = nullptr;
+  DevBuf b_j3u;
   double ii_energy = 0.0;
   std::vector<int> shell_l, shell_np, shell_ao;
   SysDev S{};
@@ -208,6 +212,21 @@ extern "C" int pqa_device_count(void) {
 
 extern "C" const char* pqa_last_error(const pqa_handle_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// ccoeff (natom,na3,na3,nb3,3) -> C = (c + c^T_kl)/2 (three_body_jastrow.py:94-96)
+static int set_c3(pqa_handle* h, const double* c) {
+  const int A = h->natom, na = h->na3, nb = h->nb3;
+  std::vector<double> sym((size_t)A * na * na * nb * 3);
+  for (int I = 0; I < A; ++I)
+    for (int k = 0; k < na; ++k)
+      for (int l = 0; l < na; ++l)
+        for (int m = 0; m < nb * 3; ++m) {
+          const size_t a = (((size_t)I * na + k) * na + l) * nb * 3 + m, b = (((size_t)I * na + l) * na + k) * nb * 3 + m;
+          sym[a] = 0.5 * (c[a] + c[b]);
+        }
+  HIPCHK(hipMemcpy(h->d_c3, sym.data(), sym.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -219,9 +238,11 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
-  h->has_jastrow = sys->na > 0 || sys->nb > 0;
-  h->na = sys->na; h->nb = sys->nb; h->necp = sys->necp;
-  if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS) FAIL("more than 8 Jastrow basis functions per kind");
+  h->has_j2 = sys->na > 0 || sys->nb > 0;
+  h->has_j3 = sys->na3 > 0 && sys->nb3 > 0;
+  h->has_jastrow = h->has_j2 || h->has_j3;
+  h->na = sys->na; h->nb = sys->nb; h->necp = sys->necp; h->na3 = h->has_j3 ? sys->na3 : 0; h->nb3 = h->has_j3 ? sys->nb3 : 0;
+  if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS || h->na3 > PQA_MAXBAS || h->nb3 > PQA_MAXBAS) FAIL("more than 8 Jastrow basis functions per kind");
   if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 64 electrons per spin channel is not supported by the one-wave determinant tile");
   SysDev& S = h->S;
   S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;
@@ -288,6 +309,17 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; S.b_aux[k] = 1.0 / (3.0 + sys->b_param[k]); }
   TRY(upload_table(h, sys->acoeff, (size_t)h->natom * h->na * 2, &h->d_acoeff)); S.acoeff = h->d_acoeff;
   TRY(upload_table(h, sys->bcoeff, (size_t)h->nb * 3, &h->d_bcoeff)); S.bcoeff = h->d_bcoeff;
+  S.na3 = h->na3; S.nb3 = h->nb3; S.rcut_a3 = sys->rcut_a3; S.rcut_b3 = sys->rcut_b3;
+  for (int k = 0; k < h->na3; ++k) { S.a3_kind[k] = sys->a3_kind[k]; S.a3_param[k] = sys->a3_param[k]; S.a3_aux[k] = 1.0 / (3.0 + sys->a3_param[k]); }
+  for (int k = 0; k < h->nb3; ++k) { S.b3_kind[k] = sys->b3_kind[k]; S.b3_param[k] = sys->b3_param[k]; S.b3_aux[k] = 1.0 / (3.0 + sys->b3_param[k]); }
+  TRY(upload_table<double>(h, nullptr, (size_t)h->natom * h->na3 * h->na3 * h->nb3 * 3, &h->d_c3)); S.c3 = h->d_c3;
+  if (h->has_j3 && sys->ccoeff) TRY(set_c3(h, sys->ccoeff));
+  {  // the three-body scratch sits behind whatever else a kernel keeps in dynamic LDS
+    const size_t n = std::max(sys->nelec_up, sys->nelec_dn);
+    const size_t other = std::max((n * (n + 1) + 3 * n + 64) * sizeof(double),
+                                  (size_t)std::max(sys->has_slater ? std::max(sys->ndet_up, sys->ndet_dn) : 1, 1) * 5 * sizeof(double));
+    S.j3_off = (int)((other + 7) / 8);
+  }
   S.necp = h->necp;
   if (h->necp > 0) {
     const int nchan = sys->ecp_chan_off[h->necp];
@@ -354,7 +386,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -376,6 +408,11 @@ extern "C" int pqa_set_param(pqa_handle_t* h, const char* name, const double* da
   } else if (k == "bcoeff") {
     if (!expect((int64_t)h->nb * 3)) FAIL("bcoeff size mismatch");
     HIPCHK(hipMemcpy(h->d_bcoeff, data, n * sizeof(double), hipMemcpyDefault));
+  } else if (k == "ccoeff") {
+    if (!h->has_j3 || !expect((int64_t)h->natom * h->na3 * h->na3 * h->nb3 * 3)) FAIL("ccoeff size mismatch");
+    std::vector<double> host((size_t)n);
+    HIPCHK(hipMemcpy(host.data(), data, n * sizeof(double), hipMemcpyDefault));
+    TRY(set_c3(h, host.data()));
   } else if (k == "det_coeff") {
     if (!h->has_slater || !expect(h->ndet)) FAIL("det_coeff size mismatch");
     HIPCHK(hipMemcpy(h->d_detcoeff, data, n * sizeof(double), hipMemcpyDefault));
@@ -552,7 +589,8 @@ static int ensure_walkers(pqa_handle* h, long W) {
       h->st.cache[s] = (double*)h->b_cache[s].p;
     }
   }
-  if (h->has_jastrow) {
+  TRY(ensure(h, h->b_j3u, W * sizeof(double)));
+  if (h->has_j2) {
     TRY(ensure(h, h->b_aval, (size_t)W * h->natom * h->na * 2 * sizeof(double)));
     TRY(ensure(h, h->b_bval, (size_t)W * h->nb * 3 * sizeof(double)));
     h->js.avalues = (double*)h->b_aval.p;
@@ -566,7 +604,7 @@ static int ensure_walkers(pqa_handle* h, long W) {
 }
 
 static int jas_refresh(pqa_handle* h) {
-  if (h->has_jastrow && h->jas_stale && h->W > 0) {
+  if (h->has_j2 && h->jas_stale && h->W > 0) {
     hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js);
     TRY(check_launch(h, "k_jastrow_recompute"));
   }
@@ -574,12 +612,15 @@ static int jas_refresh(pqa_handle* h) {
   return 0;
 }
 
+static size_t lds_j3(const pqa_handle* h) {  // bytes needed by kernels that call jas_eval with the three-body term
+  return h->has_j3 ? ((size_t)h->S.j3_off + (size_t)h->natom * (3 + 6 * h->na3 * h->nb3)) * sizeof(double) : 0;
+}
 static size_t lds_sm(const pqa_handle* h) {
   const size_t n = std::max(h->nup, h->ndn);
-  return (n * (n + 1) + 2 * n + 64 + n) * sizeof(double);
+  return std::max((n * (n + 1) + 2 * n + 64 + n) * sizeof(double), lds_j3(h));
 }
 static size_t lds_det(const pqa_handle* h, int ncomp) {
-  return (size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double);
+  return std::max((size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double), lds_j3(h));
 }
 
 static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants from js.x
@@ -728,7 +769,7 @@ extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, 
 // ---------------------------------------------------------------- Jastrow
 extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
   HIPCHK(hipSetDevice(h->device));
-  if (!h->has_jastrow) FAIL("handle has no Jastrow factor");
+  if (!h->has_j2) FAIL("handle has no two-body Jastrow factor");
   if (h->W != W) TRY(ensure_walkers(h, W));
   h->jas_stale = false;
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
@@ -739,17 +780,17 @@ extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int
 
 extern "C" int pqa_jastrow_value(pqa_handle_t* h, double* logval) {
   HIPCHK(hipSetDevice(h->device));
-  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   TRY(jas_refresh(h));
   hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
   TRY(check_launch(h, "k_jastrow_value"));
   return copy_out(h, logval, h->b_ju.p, h->W * sizeof(double));
 }
 
-extern "C" int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
-                                int mode, double* out) {
+static int jastrow_eval_parts(pqa_handle_t* h, int parts, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                              int mode, double* out) {
   HIPCHK(hipSetDevice(h->device));
-  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  if (!((parts & 1) ? h->has_j2 : h->has_j3) || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
   if (mode < 0 || mode > 2 || (mode > 0 && npt != 1)) FAIL("bad mode / npt combination");
   if (nrow <= 0 || npt <= 0) return 0;
@@ -765,15 +806,74 @@ extern "C" int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64
     TRY(copy_in(h, h->b_widx.p, widx, (size_t)nrow * sizeof(int)));
     dw = (const int*)h->b_widx.p;
   }
-  hipLaunchKernelGGL(k_jastrow_eval, dim3((unsigned)nrow), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_pts.p,
-                     (long)nrow, npt, dw, mode, (double*)h->b_out.p);
+  hipLaunchKernelGGL(k_jastrow_eval, dim3((unsigned)nrow), dim3(64), lds_j3(h), h->stream, h->S, h->js, e, (const double*)h->b_pts.p,
+                     (long)nrow, npt, dw, mode, parts, (double*)h->b_out.p);
   TRY(check_launch(h, "k_jastrow_eval"));
   return copy_out(h, out, h->b_out.p, nout * sizeof(double));
 }
 
+extern "C" int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
+                                int mode, double* out) {
+  return jastrow_eval_parts(h, 1, e, pts, nrow, npt, widx, mode, out);
+}
+
+extern "C" int pqa_j3_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx, int mode,
+                           double* out) {
+  return jastrow_eval_parts(h, 2, e, pts, nrow, npt, widx, mode, out);
+}
+
+static int j3_value_dev(pqa_handle* h) {
+  hipLaunchKernelGGL(k_j3_value, dim3((unsigned)h->W), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p);
+  return check_launch(h, "k_j3_value");
+}
+
+extern "C" int pqa_j3_value(pqa_handle_t* h, double* logval) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
+  TRY(j3_value_dev(h));
+  return copy_out(h, logval, h->b_j3u.p, h->W * sizeof(double));
+}
+
+extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_j3) FAIL("handle has no three-body Jastrow factor");
+  if (h->has_j2 && h->W == W) {  // the two-body factor owns the stored coordinates: evaluate from a scratch copy
+    double* keep = h->js.x;
+    TRY(ensure(h, h->b_pts, (size_t)W * h->N * 3 * sizeof(double)));
+    TRY(copy_in(h, h->b_pts.p, configs, (size_t)W * h->N * 3 * sizeof(double)));
+    h->js.x = (double*)h->b_pts.p;
+    int rc = j3_value_dev(h);
+    h->js.x = keep;
+    if (rc) return rc;
+    return copy_out(h, logval, h->b_j3u.p, W * sizeof(double));
+  }
+  if (h->W != W) TRY(ensure_walkers(h, W));
+  TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
+  return pqa_j3_value(h, logval);
+}
+
+extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  if (h->has_j2) return 0;  // coordinates are moved by the two-body factor's update
+  const long W = h->W;
+  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
+  TRY(copy_in(h, h->b_newpos.p, epos, (size_t)W * 3 * sizeof(double)));
+  const uint8_t* dm = nullptr;
+  if (mask) {
+    TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
+    dm = (const uint8_t*)h->b_mask.p;
+  }
+  hipLaunchKernelGGL(k_move_x, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, h->js, h->N, e, (const double*)h->b_newpos.p, dm, W);
+  TRY(check_launch(h, "k_move_x"));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
   HIPCHK(hipSetDevice(h->device));
-  if (!h->has_jastrow || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
+  if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
   const long W = h->W;
   TRY(jas_refresh(h));
@@ -795,8 +895,8 @@ extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* b
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   TRY(jas_refresh(h));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (avalues && h->has_jastrow) HIPCHK(hipMemcpy(avalues, h->js.avalues, (size_t)h->W * h->natom * h->na * 2 * sizeof(double), hipMemcpyDefault));
-  if (bvalues && h->has_jastrow) HIPCHK(hipMemcpy(bvalues, h->js.bvalues, (size_t)h->W * h->nb * 3 * sizeof(double), hipMemcpyDefault));
+  if (avalues && h->has_j2) HIPCHK(hipMemcpy(avalues, h->js.avalues, (size_t)h->W * h->natom * h->na * 2 * sizeof(double), hipMemcpyDefault));
+  if (bvalues && h->has_j2) HIPCHK(hipMemcpy(bvalues, h->js.bvalues, (size_t)h->W * h->nb * 3 * sizeof(double), hipMemcpyDefault));
   if (configs) HIPCHK(hipMemcpy(configs, h->js.x, (size_t)h->W * h->N * 3 * sizeof(double), hipMemcpyDefault));
   return 0;
 }
@@ -810,14 +910,19 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
     TRY(copy_in(h, sg.data(), h->b_sign.p, W * sizeof(double)));
     TRY(copy_in(h, lg.data(), h->b_log.p, W * sizeof(double)));
   }
-  if (h->has_jastrow) {
+  std::vector<double> j3u(W, 0.0);
+  if (h->has_j2) {
     TRY(jas_refresh(h));
     hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
     TRY(check_launch(h, "k_jastrow_value"));
     TRY(copy_in(h, ju.data(), h->b_ju.p, W * sizeof(double)));
   }
+  if (h->has_j3) {
+    TRY(j3_value_dev(h));
+    TRY(copy_in(h, j3u.data(), h->b_j3u.p, W * sizeof(double)));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (long w = 0; w < W; ++w) lg[w] += ju[w];
+  for (long w = 0; w < W; ++w) lg[w] += ju[w] + j3u[w];
   if (sign) HIPCHK(hipMemcpy(sign, sg.data(), W * sizeof(double), hipMemcpyDefault));
   if (logabs) HIPCHK(hipMemcpy(logabs, lg.data(), W * sizeof(double), hipMemcpyDefault));
   return 0;
@@ -829,7 +934,7 @@ extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t 
   h->jas_stale = false;
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
   if (h->has_slater) TRY(slater_rebuild(h));
-  if (h->has_jastrow) {
+  if (h->has_j2) {
     hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
     TRY(check_launch(h, "k_jastrow_recompute"));
   }
@@ -995,7 +1100,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
   const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
-  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1;
+  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3;
   int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
   while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
   const int nmax = std::max(h->nup, h->ndn);
@@ -1057,7 +1162,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     }
   }
   if (lw) TRY(lw_to_aos(h, true));
-  h->jas_stale = h->has_jastrow;
+  h->jas_stale = h->has_j2;
   std::vector<int> cnt(nsteps);
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));
   if (acceptance) {

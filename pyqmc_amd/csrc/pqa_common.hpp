@@ -39,6 +39,17 @@ struct SysDev {
   double rcut_a, rcut_b;
   const double* acoeff;  // [natom][na][2]
   const double* bcoeff;  // [nb][3]
+  // three-body Jastrow (three_body_jastrow.py:19-63): own a/b bases, C = (c + c^T_kl)/2 as [natom][na3][na3][nb3][3]
+  int na3, nb3;
+  int a3_kind[PQA_MAXBAS];
+  double a3_param[PQA_MAXBAS];
+  double a3_aux[PQA_MAXBAS];
+  int b3_kind[PQA_MAXBAS];
+  double b3_param[PQA_MAXBAS];
+  double b3_aux[PQA_MAXBAS];
+  double rcut_a3, rcut_b3;
+  const double* c3;
+  int j3_off;  // offset (in doubles) of the three-body scratch inside a kernel's dynamic LDS
   int necp;
   const int* ecp_atom;
   const int* ecp_chan_off;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
     }
     double gj[3] = {0.0, 0.0, 0.0}, lj = 0.0, U;
     if (has_jastrow) {
-      jas_eval<2>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U, gj, lj);
+      jas_eval<2>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U, gj, lj, 3, lds + S.j3_off);
       lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
     }
     const double gx = gs[0] + gj[0], gy = gs[1] + gj[1], gz = gs[2] + gj[2];
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, Jast
       }
       if (has_jastrow) {
         double g[3], lp, U;
-        if (e != last_e) { jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp); last_e = e; }
-        jas_eval<0>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp);
+        if (e != last_e) { jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
+        jas_eval<0>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp, 3, lds + S.j3_off);
         ratio *= exp(U - U0);
       }
       tot += ratio * B.wgt[s][p];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, Ja
   const int s = e >= S.nup, nmo = S.nmo[s];
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double U0 = 0.0, g[3], lp;
-  if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp);
+  if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
   for (int q = 0; q < P; ++q) {
     const size_t o = (size_t)w * P + q;
     double rat = 1.0;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, Ja
       }
       if (has_jastrow) {
         double U;
-        jas_eval<0>(S, xw, e, pos[3 * o], pos[3 * o + 1], pos[3 * o + 2], U, g, lp);
+        jas_eval<0>(S, xw, e, pos[3 * o], pos[3 * o + 1], pos[3 * o + 2], U, g, lp, 3, lds + S.j3_off);
         rat *= exp(U - U0);
       }
     }

@@ -89,15 +89,114 @@ __device__ __forceinline__ double jas_value1(int kind, double par, double aux, d
   return v;
 }
 
+// ---------------------------------------------------------------- three-body term
+// P_e(r) = sum_{j != e} sum_I sum_{klm} C_{Iklm,s} a_k(|r-R_I|) a_l(|r_j-R_I|) b_m(|r-r_j|),  s = [e down] + [j down]
+// (three_body_jastrow.py:66-147; moving electron e changes U by P_e(new) - P_e(old), :323-341), with
+// grad/lap w.r.t. r (:374-655):  grad = sum (grad a_k) a_l b_m + a_k a_l grad b_m,
+//                                 lap  = sum (lap a_k) a_l b_m + 2 grad a_k . grad b_m a_l + a_k a_l lap b_m.
+// Phase 1 (lanes over ions): contract C with the moving electron's a-functions into LDS tables
+//   E0/Eg/El[I][l][m][s'] = sum_k C[I][k][l][m][edown+s'] * {a_k, (da_k/dr)/r, lap a_k}(r_eI)   and d_eI.
+// Phase 2 (lanes over the other electrons j): loop ions, a_l(r_jI) recomputed from the stored coordinates.
+// scr: natom * (3 + 6*na3*nb3) doubles of LDS.  Adds into U, g, lapU.  Block = one wave.
+__device__ __forceinline__ int j3_stride(const SysDev& S) { return 3 + 6 * S.na3 * S.nb3; }
+
+template <int MODE>
+__device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restrict__ xw, int e, double rx, double ry,
+                                          double rz, double* scr, double& U, double (&g)[3], double& lapU) {
+  const int lane = threadIdx.x & 63;
+  const int edown = e >= S.nup, na = S.na3, nb = S.nb3, str = j3_stride(S), nlm = na * nb * 2;
+  const double ira = 1.0 / S.rcut_a3, irb = 1.0 / S.rcut_b3;
+  for (int I = lane; I < S.natom; I += 64) {
+    const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    double* row = scr + (size_t)I * str;
+    row[0] = dx; row[1] = dy; row[2] = dz;
+    double av[PQA_MAXBAS], ag[PQA_MAXBAS], al[PQA_MAXBAS];
+    const bool in = r < S.rcut_a3;
+    const RadShared sh = rad_shared<2>(in ? r : 0.5 * S.rcut_a3, ira);
+#pragma unroll
+    for (int k = 0; k < PQA_MAXBAS; ++k) {
+      av[k] = ag[k] = al[k] = 0.0;
+      if (k < na && in) rad_fn<2>(S.a3_kind[k], S.a3_param[k], S.a3_aux[k], S.rcut_a3, sh, av[k], ag[k], al[k]);
+    }
+    const double* CI = S.c3 + (size_t)I * na * na * nb * 3;
+    for (int l = 0; l < na; ++l)
+      for (int m = 0; m < nb; ++m)
+        for (int sp = 0; sp < 2; ++sp) {
+          double e0 = 0.0, eg = 0.0, el = 0.0;
+#pragma unroll
+          for (int k = 0; k < PQA_MAXBAS; ++k) {
+            if (k < na) {
+              const double c = CI[((k * na + l) * nb + m) * 3 + edown + sp];
+              e0 += c * av[k]; eg += c * ag[k]; el += c * al[k];
+            }
+          }
+          const int o = 3 + (l * nb + m) * 2 + sp;
+          row[o] = e0; row[o + nlm] = eg; row[o + 2 * nlm] = el;
+        }
+  }
+  __syncthreads();
+  double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0;
+  for (int j = lane; j < S.nelec; j += 64) {
+    if (j == e) continue;
+    const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
+    const double dx = rx - jx, dy = ry - jy, dz = rz - jz;
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (!(r < S.rcut_b3)) continue;
+    double bv[PQA_MAXBAS], bg[PQA_MAXBAS], bl[PQA_MAXBAS];
+    const RadShared shb = rad_shared<2>(r, irb);
+#pragma unroll
+    for (int m = 0; m < PQA_MAXBAS; ++m) {
+      bv[m] = bg[m] = bl[m] = 0.0;
+      if (m < nb) rad_fn<2>(S.b3_kind[m], S.b3_param[m], S.b3_aux[m], S.rcut_b3, shb, bv[m], bg[m], bl[m]);
+    }
+    const int sp = j >= S.nup;
+    for (int I = 0; I < S.natom; ++I) {
+      const double ax = jx - S.atom_xyz[3 * I], ay = jy - S.atom_xyz[3 * I + 1], az = jz - S.atom_xyz[3 * I + 2];
+      const double rj = sqrt(ax * ax + ay * ay + az * az);
+      if (!(rj < S.rcut_a3)) continue;
+      const RadShared sha = rad_shared<0>(rj, ira);
+      const double* row = scr + (size_t)I * str;
+      double s0 = 0.0, sga = 0.0, sgb = 0.0, sla = 0.0, scr_ = 0.0, slb = 0.0;
+      for (int l = 0; l < na; ++l) {
+        double aj, t1, t2;
+        rad_fn<0>(S.a3_kind[l], S.a3_param[l], S.a3_aux[l], S.rcut_a3, sha, aj, t1, t2);
+#pragma unroll
+        for (int m = 0; m < PQA_MAXBAS; ++m) {
+          if (m < nb) {
+            const int o = 3 + (l * nb + m) * 2 + sp;
+            const double e0 = row[o] * aj;
+            s0 += e0 * bv[m];
+            if (MODE >= 1) { sga += row[o + nlm] * aj * bv[m]; sgb += e0 * bg[m]; }
+            if (MODE == 2) { sla += row[o + 2 * nlm] * aj * bv[m]; scr_ += row[o + nlm] * aj * bg[m]; slb += e0 * bl[m]; }
+          }
+        }
+      }
+      u += s0;
+      if (MODE >= 1) {
+        gx += row[0] * sga + dx * sgb; gy += row[1] * sga + dy * sgb; gz += row[2] * sga + dz * sgb;
+      }
+      if (MODE == 2) lp += sla + 2.0 * (row[0] * dx + row[1] * dy + row[2] * dz) * scr_ + slb;
+    }
+  }
+  if (MODE <= 1) U += wave_sum(u);
+  if (MODE >= 1) { g[0] += wave_sum(gx); g[1] += wave_sum(gy); g[2] += wave_sum(gz); }
+  if (MODE == 2) lapU += wave_sum(lp);
+  __syncthreads();
+}
+
 // U_e(r), grad U_e, lap U_e (bare laplacian, without |grad|^2) for electron e placed at r, against
 // the walker coordinates xw (electron e itself skipped).  MODE 0: value; 1: value+grad; 2: grad+lap.
+// parts: bit 0 = one/two-body terms (JastrowSpin), bit 1 = three-body term (needs scr, see jas3_eval).
 template <int MODE>
 __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restrict__ xw, int e, double rx, double ry,
-                                         double rz, double& U, double (&g)[3], double& lapU) {
+                                         double rz, double& U, double (&g)[3], double& lapU, int parts = 1,
+                                         double* scr = nullptr) {
   const int lane = threadIdx.x & 63;
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0;
+  if (parts & 1) {
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
     const double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
@@ -134,9 +233,12 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
       if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
+  }
   U = (MODE <= 1) ? wave_sum(u) : 0.0;
+  g[0] = g[1] = g[2] = 0.0;
   if (MODE >= 1) { g[0] = wave_sum(gx); g[1] = wave_sum(gy); g[2] = wave_sum(gz); }
   lapU = (MODE == 2) ? wave_sum(lp) : 0.0;
+  if ((parts & 2) && S.na3 > 0 && scr) jas3_eval<MODE>(S, xw, e, rx, ry, rz, scr, U, g, lapU);
 }
 
 // Commit the move of electron e of walker w to rn: patch _avalues/_bvalues with (new - old) and move
@@ -264,22 +366,24 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
 // mode 2: out (4,nrow): grad U_e(pt), lap U_e + |grad U_e|^2           (gradient_laplacian)
 __global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowState js, int e, const double* __restrict__ pts,
                                                      long nrow, int npt, const int* __restrict__ widx, int mode,
-                                                     double* __restrict__ out) {
+                                                     int parts, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  double* scr = lds + S.j3_off;
   const long r = blockIdx.x;
   const long w = widx ? widx[r] : r;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double g[3], lp, U0 = 0.0, U;
-  if (mode <= 1) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp);
+  if (mode <= 1) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, parts, scr);
   for (int q = 0; q < npt; ++q) {
     const double* p = pts + (size_t)(r * npt + q) * 3;
     if (mode == 0) {
-      jas_eval<0>(S, xw, e, p[0], p[1], p[2], U, g, lp);
+      jas_eval<0>(S, xw, e, p[0], p[1], p[2], U, g, lp, parts, scr);
       if (threadIdx.x == 0) out[r * npt + q] = exp(U - U0);
     } else if (mode == 1) {
-      jas_eval<1>(S, xw, e, p[0], p[1], p[2], U, g, lp);
+      jas_eval<1>(S, xw, e, p[0], p[1], p[2], U, g, lp, parts, scr);
       if (threadIdx.x == 0) { out[r] = g[0]; out[nrow + r] = g[1]; out[2 * nrow + r] = g[2]; out[3 * nrow + r] = exp(U - U0); }
     } else {
-      jas_eval<2>(S, xw, e, p[0], p[1], p[2], U, g, lp);
+      jas_eval<2>(S, xw, e, p[0], p[1], p[2], U, g, lp, parts, scr);
       if (threadIdx.x == 0) {
         out[r] = g[0]; out[nrow + r] = g[1]; out[2 * nrow + r] = g[2];
         out[3 * nrow + r] = lp + g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
@@ -293,4 +397,26 @@ __global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowState js
   const long w = blockIdx.x;
   if (mask && !mask[w]) return;
   jas_commit(S, js, w, e, epos[3 * w], epos[3 * w + 1], epos[3 * w + 2]);
+}
+
+// three-body log value U3 = 1/2 sum_e P_e(x_e)  (three_body_jastrow.py:98-101)
+__global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState js, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double tot = 0.0;
+  for (int e = 0; e < S.nelec; ++e) {
+    double U = 0.0, g[3] = {0.0, 0.0, 0.0}, lp = 0.0;
+    jas3_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], lds + S.j3_off, U, g, lp);
+    tot += 0.5 * U;
+  }
+  if (threadIdx.x == 0) out[w] = tot;
+}
+
+// move the stored coordinate of electron e for the masked walkers (handles without a two-body factor)
+__global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict__ epos, const uint8_t* __restrict__ mask, long W) {
+  const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W || (mask && !mask[w])) return;
+  double* x = js.x + ((size_t)w * N + e) * 3;
+  x[0] = epos[3 * w]; x[1] = epos[3 * w + 1]; x[2] = epos[3 * w + 2];
 }

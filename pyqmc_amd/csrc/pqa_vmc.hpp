@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
   }
   if (has_jastrow) {
     double g[3], lp;
-    jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp);
+    jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp, 3, lds + S.j3_off);
     gx += g[0]; gy += g[1]; gz += g[2];
   }
   limdrift3(gx, gy, gz);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   }
   if (has_jastrow) {
     double g[3], lp, U;
-    jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp);
+    jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp, 3, lds + S.j3_off);
     gx += g[0]; gy += g[1]; gz += g[2];
     val *= exp(U - a[6]);
   }

@@ -24,13 +24,15 @@ _serial = itertools.count(1)
 class DeviceWF:
     """Owner of one ``pqa_handle_t`` (one walker shard on one GPU)."""
 
-    def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1):
+    def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1,
+                 a3_basis=None, b3_basis=None):
         self.mol = mol
         self.nelec = tuple(int(n) for n in mol.nelec)
         self.N = sum(self.nelec)
         self.natom = int(mol.natm)
         self.has_slater = mo_coeff is not None
         self.has_jastrow = a_basis is not None or b_basis is not None
+        self.has_j3 = a3_basis is not None and b3_basis is not None
         keep = self._keep = {}  # host arrays referenced by the struct must outlive pqa_create
         s = _ffi.SystemStruct()
         s.natom, s.nelec_up, s.nelec_dn = self.natom, self.nelec[0], self.nelec[1]
@@ -89,6 +91,17 @@ class DeviceWF:
             setd("b_param", bp)
             setd("acoeff", np.zeros((self.natom, self.na, 2)))
             setd("bcoeff", np.zeros((self.nb, 3)))
+        self.na3 = self.nb3 = 0
+        if self.has_j3:
+            ak, ap, ra = tables.jastrow_basis_arrays(a3_basis)
+            bk, bp, rb = tables.jastrow_basis_arrays(b3_basis)
+            self.na3, self.nb3 = len(ak), len(bk)
+            s.na3, s.nb3, s.rcut_a3, s.rcut_b3 = self.na3, self.nb3, ra, rb
+            seti("a3_kind", ak)
+            setd("a3_param", ap)
+            seti("b3_kind", bk)
+            setd("b3_param", bp)
+            setd("ccoeff", np.zeros((self.natom, self.na3, self.na3, self.nb3, 3)))
         et = tables.ecp_tables(mol)
         self.necp = len(et["ecp_atom"])
         s.necp = self.necp
@@ -414,6 +427,66 @@ class JastrowSpin:
         return a, b, x
 
 
+class ThreeBodyJastrow:
+    """Electron-electron-ion Jastrow factor (protocol of ``pyqmc/wf/three_body_jastrow.py:19-655``).
+    ``a_basis``/``b_basis``: lists of ``pyqmc_amd.func3d`` descriptors; parameter ``ccoeff``
+    (natom, na, na, nb, 3).  The device keeps no per-electron partial sums for this factor: the one-electron sum
+    P_e is re-evaluated from the stored walker coordinates, so the result does not depend on whether the driver
+    moves ``configs`` before or after ``updateinternals`` (the reference's does, see tests/golden/make_golden.py)."""
+
+    def __init__(self, mol, a_basis, b_basis, device=0, _dev=None):
+        self._mol = mol
+        self._nelec = int(np.sum(mol.nelec))
+        if _dev is None:
+            _dev = DeviceWF(mol, a3_basis=list(a_basis), b3_basis=list(b_basis), device=device)
+        self._dev = _dev
+        self.parameters = _DeviceParams(_dev, {"ccoeff": np.zeros((_dev.natom, _dev.na3, _dev.na3, _dev.nb3, 3))})
+        self.dtype = float
+
+    def recompute(self, configs):
+        self.parameters.push()
+        x = _ffi.f64(configs.configs)
+        W = x.shape[0]
+        u = np.empty(W)
+        self._dev.call("pqa_j3_recompute", _ffi.ptr(x), W, _ffi.ptr(u))
+        self._dev.W = W
+        return np.ones(W), u
+
+    def value(self):
+        u = np.empty(self._dev.W)
+        self._dev.call("pqa_j3_value", _ffi.ptr(u))
+        return np.ones(len(u)), u
+
+    def _eval(self, e, epos, mask, mode):
+        m, _ = _mask_args(mask, self._dev.W)
+        pts, widx, aux = _points(epos, m)
+        nrow, npt = pts.shape[0], pts.shape[1]
+        out = np.empty(nrow * npt) if mode == 0 else np.empty((4, nrow))
+        if nrow:
+            self._dev.call("pqa_j3_eval", int(e), _ffi.ptr(pts), nrow, npt, _ffi.ptr(widx), mode, _ffi.ptr(out))
+        return out, nrow, npt, aux
+
+    def testvalue(self, e, epos, mask=None):
+        r, nrow, npt, aux = self._eval(e, epos, mask, 0)
+        return (r.reshape(nrow, npt) if aux else r), None
+
+    def gradient_value(self, e, epos):
+        r, *_ = self._eval(e, epos, None, 1)
+        return r[:3], r[3], None
+
+    def gradient(self, e, epos):
+        return self._eval(e, epos, None, 1)[0][:3]
+
+    def gradient_laplacian(self, e, epos):
+        r, *_ = self._eval(e, epos, None, 2)
+        return r[:3], r[3]
+
+    def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        _, m8 = _mask_args(mask, self._dev.W)
+        x = _ffi.f64(epos.configs)
+        self._dev.call("pqa_j3_update", int(e), _ffi.ptr(x), _ffi.ptr(m8))
+
+
 class Parameters:
     """"wf{i}{key}" view over the factors' parameter dicts (``multiplywf.py:18-68``)."""
 
@@ -499,7 +572,7 @@ class MultiplyWF:
         return np.sum(g, axis=0), np.sum(l, axis=0) + 2 * cross
 
 
-def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None):
+def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None, jastrow3=False, jastrow3_kws=None):
     """Slater x two-body-Jastrow product on ONE device handle — the counterpart of
     ``pyqmc.wftools.generate_wf`` (wftools.py:195-241) with the default Jastrow of
     ``generate_jastrow`` (:99-152: e-e cusp fixed at -1/4, -1/2, -1/4; ion cusp only for
@@ -515,8 +588,11 @@ def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None
         ion_cusp = []
     abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
     mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
+    a3 = b3 = None
+    if jastrow3:  # wftools.generate_jastrow3 (:155-162): default basis without ion cusp
+        a3, b3 = func3d.default_jastrow_basis(mol, False, **dict(jastrow3_kws or {}))
     dev = DeviceWF(mol, mo_coeff=mf.mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
-                   tol=-1 if tol is None else tol)
+                   tol=-1 if tol is None else tol, a3_basis=a3, b3_basis=b3)
     sl = Slater(mol, mf, _dev=dev)
     ja = JastrowSpin(mol, abasis, bbasis, _dev=dev)
     acoeff = np.zeros((mol.natm, len(abasis), 2))
@@ -528,4 +604,6 @@ def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None
     bcoeff[0] = [-0.25, -0.5, -0.25]
     ja.parameters["acoeff"] = acoeff
     ja.parameters["bcoeff"] = bcoeff
+    if jastrow3:
+        return MultiplyWF(sl, ja, ThreeBodyJastrow(mol, a3, b3, _dev=dev))
     return MultiplyWF(sl, ja)

@@ -289,3 +289,39 @@ def test_rundmc_smoke():
         assert k in df, k
     assert np.allclose(weights, weights[0]) and configs.configs.shape == (256, 8, 3)
     assert 0.5 < df["acceptance"].mean() <= 1.0
+
+
+def test_three_body_jastrow_multidet_golden():
+    """Config C4 shape: 12-determinant Slater x two-body x three-body Jastrow (three_body_jastrow.py:19-655) —
+    protocol triangle of the three-body factor and of the product, EnergyAccumulator dict, fused vmc_worker
+    trajectory, all against the reference's outputs."""
+    import ast
+
+    import pyqmc_amd as pa
+
+    g = golden("g7_jastrow3_multidet")
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = ast.literal_eval(str(g["det_json"]))
+    wf = helpers.gpu_wf3(mol, mf, dets)
+    err = helpers.run_protocol3(wf, g)
+    for k, v in err.items():
+        note("j3:" + k, v)
+    bad = {k: v for k, v in err.items() if not v < 1e-9}
+    assert not bad, bad
+    configs = OpenConfigs(g["final_configs"].copy())
+    wf.recompute(configs)
+    en = pa.EnergyAccumulator(mol)(configs, wf, rot=g["energy_rot"], unif=g["energy_unif"])
+    for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+        assert note("j3_energy_" + k, relerr(en[k], g["energy_" + k])) < 1e-8, k
+    tapes = dict(gauss=g["vmc_gauss"], unif=g["vmc_unif"], ecp_rot=g["vmc_ecp_rot"], ecp_unif=g["vmc_ecp_unif"], record=[])
+    blk, cfg = pa.vmc_worker(wf, OpenConfigs(g["vmc_start"].copy()), 0.3, 2, {"energy": pa.EnergyAccumulator(mol)}, tapes=tapes)
+    assert np.array_equal(tapes["record"][0], g["vmc_accepts"])
+    assert note("j3_vmc_final", relerr(cfg.configs, g["vmc_final"])) < 1e-9
+    for k in ("energyke", "energyecp", "energytotal", "acceptance"):
+        assert note("j3_vmc_" + k, relerr(blk[k], g["vmc_blk_" + k])) < 1e-8, k
+    # standalone factor on its own handle
+    ab, bb = pa.default_jastrow_basis(mol)
+    j3 = pa.ThreeBodyJastrow(mol, ab, bb)
+    j3.parameters["ccoeff"] = helpers.ccoeff_params(mol)
+    assert relerr(j3.recompute(OpenConfigs(g["configs"].copy()))[1], g["j3_recompute_log"]) < 1e-11
