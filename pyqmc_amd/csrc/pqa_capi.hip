@@ -65,7 +65,8 @@ struct pqa_handle {
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
-  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf;  // lane-per-walker SoA mirrors (pqa_lw.hpp)
+  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
+  int lw_kb = 8;  // electrons per Sherman-Morrison block (PQA_LW_KB; 0 = update every row on every move)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
@@ -235,6 +236,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
+  if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -386,7 +388,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1104,10 +1106,13 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
   while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
   const int nmax = std::max(h->nup, h->ndn);
+  const int KB = (h->lw_kb > 0) ? std::min(h->lw_kb, std::max(nmax, 1)) : std::max(nmax, 1);  // KB = n: plain per-move update
   if (lw) {
     TRY(lw_from_aos(h));
     TRY(ensure(h, h->b_part, (size_t)G * 8 * W * sizeof(double)));
-    TRY(ensure(h, h->b_rbuf, (size_t)std::max(nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_rbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_vbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_act, (size_t)KB * W));
   }
   const LwState L = lw_state(h);
   const dim3 gw((unsigned)((W + 63) / 64));
@@ -1130,7 +1135,11 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       if (lw) {
         const dim3 gg(gw.x, (unsigned)G);
         double* part = (double*)h->b_part.p;
-        double* rbuf = (double*)h->b_rbuf.p;
+        const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
+        const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
+        double* rbuf = (double*)h->b_rbuf.p + (size_t)q * n_s * W;
+        double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
+        uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
         hipLaunchKernelGGL(k_move_part_lw, gg, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
                            (const double*)nullptr, W, G, part);
         hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, G, (const double*)part);
@@ -1138,11 +1147,18 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
         hipLaunchKernelGGL(k_move_part_lw, gg, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
                            W, G, part);
         hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, G,
-                           (const double*)part, rbuf);
-        if (nmax <= 8) hipLaunchKernelGGL(k_commit_lw<8>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
-        else if (nmax <= 16) hipLaunchKernelGGL(k_commit_lw<16>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
-        else if (nmax <= 32) hipLaunchKernelGGL(k_commit_lw<32>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
-        else hipLaunchKernelGGL(k_commit_lw<64>, gg, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, W, G);
+                           (const double*)part, rbuf, vbuf, act, mo);
+        const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
+        const dim3 gcm(gw.x, (unsigned)Gc);
+#define PQA_COMMIT(NM) hipLaunchKernelGGL(k_commit_lw<NM>, gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi)
+        if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
+#undef PQA_COMMIT
+        if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
+          const int nq = j_hi - j_lo;
+#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
+          if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#undef PQA_FLUSH
+        }
         continue;
       }
       hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,

@@ -325,3 +325,25 @@ def test_three_body_jastrow_multidet_golden():
     j3 = pa.ThreeBodyJastrow(mol, ab, bb)
     j3.parameters["ccoeff"] = helpers.ccoeff_params(mol)
     assert relerr(j3.recompute(OpenConfigs(g["configs"].copy()))[1], g["j3_recompute_log"]) < 1e-11
+
+
+def test_blocked_sherman_morrison_is_bitwise_identical(monkeypatch):
+    """The blocked (delayed) Sherman-Morrison of the lane-per-walker sweep applies per row the same operations in
+    the same order as updating every row on every move: trajectories and inverses must be bit-identical."""
+    import pyqmc_amd as pa
+
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
+    res = []
+    for kb in ("8", "0", "5"):
+        monkeypatch.setenv("PQA_LW_KB", kb)
+        wf = helpers.gpu_wf(mol, mf)
+        dev = wf.fused_device()
+        wf.recompute(OpenConfigs(start.copy()))
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=77, energy=True)
+        inv = [wf.wf_factors[0]._get_state(s)[0] for s in (0, 1)]
+        res.append((dev.configs(), dev.value()[1], en, inv))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
