@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--cpu-walkers", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the orbital kernel with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for control-flow tests)")
+    ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: all ranks use GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
@@ -103,13 +105,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
 
@@ -126,6 +133,8 @@ def main():
     wf.recompute(cfg)
     seed = 20260928 + 7919 * rank
 
+    red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+
     def fence():
         dev.sync()
         torch.cuda.synchronize()
@@ -137,7 +146,7 @@ def main():
         """per-block energy accumulation across ranks (the path's only exchange step; RCCL all-reduce of 7 fp64)"""
         from pyqmc_amd.dist import allreduce_block
 
-        return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=f"cuda:{local_rank}")[0]
+        return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=red_dev)[0]
 
     if args.warmup > 0:
         _, en_w, _ = dev.vmc_sweeps(args.tstep, args.warmup, seed=seed, energy=True)
@@ -157,7 +166,7 @@ def main():
         dev.profile_enable(False)
     ecp_pts = dev.last_ecp_points()
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
