@@ -139,19 +139,39 @@ struct ChunkTab {
   int ldc[2];
 };
 
+#define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
+#define PQA_WS_MAXP 640
+
 // out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), TP = 64 or 32 points.
 //  phase 1 (VALU/exp bound): thread = (point, lane group); each group evaluates its share of the chunk's
 //          shells and writes the XOR-swizzled LDS tile [comp][k][point ^ ((k&1)<<4)]
 //  phase 2 (MFMA): TP=64: wave wv owns the 16-point tile wv and all NT orbital tiles;
 //                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
-template <int NCOMP, int NT, int KC, int TP>
+template <int NCOMP, int NT, int KC, int TP, bool LDSTAB>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
   constexpr int G = 256 / TP;                         // lane groups in phase 1
   constexpr int NU = (TP == 64) ? NT : (NT + 1) / 2;  // orbital tiles per wave in phase 2
+  constexpr int KS = KC / 4;
   __shared__ double tile[NCOMP][KC][TP];
+  // LDSTAB: basis tables staged once per block so phase 1 never waits on chains of dependent scalar loads
+  __shared__ double sh_xyz[LDSTAB ? PQA_WS_MAXSH : 1][3];
+  __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][4];  // l, nprim, first primitive, first AO
+  __shared__ double pr_exp[LDSTAB ? PQA_WS_MAXP : 1], pr_coef[LDSTAB ? PQA_WS_MAXP : 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (LDSTAB) {
+    for (int sh = tid; sh < S.nshell; sh += 256) {
+      const int ia = S.shell_atom[sh];
+      sh_xyz[sh][0] = S.atom_xyz[3 * ia]; sh_xyz[sh][1] = S.atom_xyz[3 * ia + 1]; sh_xyz[sh][2] = S.atom_xyz[3 * ia + 2];
+      sh_meta[sh][0] = S.shell_l[sh];
+      sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
+      sh_meta[sh][2] = S.shell_prim_off[sh];
+      sh_meta[sh][3] = S.shell_ao_off[sh];
+    }
+    for (int p = tid; p < S.nprim; p += 256) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
+    __syncthreads();
+  }
   const int pl = tid & (TP - 1), grp = tid / TP;
   const long p0 = (long)blockIdx.x * TP;
   const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
@@ -175,12 +195,35 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   for (int ch = 0; ch < T.nchunk; ++ch) {
     const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch], row0 = T.chunk_row0[ch];
     const int nk4 = (nk + 3) & ~3;
+    // B operand of this chunk: issue the L2 loads now, consume them after phase 1
+    double bq[KS][NU];
+    {
+      const double* crow = C + (long)(row0 + kq) * ldc + i16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int ut = u0 + u * ustep;
+          bq[ks][u] = (ut < NT) ? crow[(long)ks * 4 * ldc + 16 * ut] : 0.0;
+        }
+    }
     const int s_end = cw_off[ch * G + grp + 1];
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
       const int sh = cw_shell[si];
-      const int ia = S.shell_atom[sh], q0 = S.shell_prim_off[sh], kb = S.shell_ao_off[sh] - a0;
-      const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
-      shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + q0, S.prim_coef + q0, S.shell_prim_off[sh + 1] - q0,
+      int l_, np_, q0, kb;
+      double x, y, z;
+      const double *pe, *pc;
+      if (LDSTAB) {
+        l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3] - a0;
+        x = px - sh_xyz[sh][0]; y = py - sh_xyz[sh][1]; z = pz - sh_xyz[sh][2];
+        pe = pr_exp + q0; pc = pr_coef + q0;
+      } else {
+        const int ia = S.shell_atom[sh];
+        q0 = S.shell_prim_off[sh]; kb = S.shell_ao_off[sh] - a0; l_ = S.shell_l[sh]; np_ = S.shell_prim_off[sh + 1] - q0;
+        x = px - S.atom_xyz[3 * ia]; y = py - S.atom_xyz[3 * ia + 1]; z = pz - S.atom_xyz[3 * ia + 2];
+        pe = S.prim_exp + q0; pc = S.prim_coef + q0;
+      }
+      shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_,
                         [&](int m, double v, double gx, double gy, double gz, double lp) {
                           const int k = kb + m;
                           const int col = pl ^ ((k & 1) << 4);
@@ -194,21 +237,17 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       tile[rc % NCOMP][nk + rc / NCOMP][idx & (TP - 1)] = 0.0;
     }
     __syncthreads();
-    for (int k0 = 0; k0 < nk4; k0 += 4) {
-      const int k = k0 + kq;
-      const double* crow = C + (long)(row0 + k) * ldc + i16;
-      double b[NU];
 #pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int ut = u0 + u * ustep;
-        b[u] = (ut < NT) ? crow[16 * ut] : 0.0;
-      }
-      const int col = (16 * ptile + i16) ^ ((k & 1) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks * 4 < nk4) {
+        const int k = ks * 4 + kq;
+        const int col = (16 * ptile + i16) ^ ((k & 1) << 4);
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        const double a = tile[c][k][col];
+        for (int c = 0; c < NCOMP; ++c) {
+          const double a = tile[c][k][col];
 #pragma unroll
-        for (int u = 0; u < NU; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc[u][c], 0, 0, 0);
+          for (int u = 0; u < NU; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[ks][u], acc[u][c], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -237,8 +276,6 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
 // one chunk ahead from L2).  One barrier per chunk; a producer and a consumer wave share each SIMD,
 // so the VALU/transcendental pipe and the matrix pipe run concurrently inside ONE block — which is
 // what a launch of only W/64 = 256 blocks (one per CU) needs.
-#define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident tables of k_orb_ws
-#define PQA_WS_MAXP 640
 template <int NCOMP, int NT, int KC>
 __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                                 double* __restrict__ out) {

@@ -74,6 +74,7 @@ struct pqa_handle {
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
+  int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
   int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
@@ -241,6 +242,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
   if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
+  if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
@@ -463,14 +465,19 @@ static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   }
 }
 
-template <int NCOMP, int KC, int TP>
-static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+template <int NCOMP, int KC, int TP, bool LT>
+static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
   }
+}
+template <int NCOMP, int KC, int TP>
+static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+  if (h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab) launch_orb_t2<NCOMP, KC, TP, true>(h, tabi, spin, pa, P, out);
+  else launch_orb_t2<NCOMP, KC, TP, false>(h, tabi, spin, pa, P, out);
 }
 
 // out[p][ncomp][nmo_spin]
