@@ -65,7 +65,11 @@ struct pqa_handle {
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
-  DevBuf b_xt, b_auxt, b_kpart, b_part, b_srow;
+  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
+  // electrons per Sherman-Morrison block (PQA_LW_KB); 0 = update every row on every move.  Blocking is bitwise
+  // identical and cuts HBM traffic 2.5x, but measured 9 % slower at W = 32768 (the flush re-reads the block's V/R
+  // vectors from L1/L2 for every row), so it is off by default.
+  int lw_kb = 0;
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
@@ -237,6 +241,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
+  if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
   if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
@@ -390,7 +395,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_srow, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -747,7 +752,7 @@ extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, con
     dm = (const uint8_t*)h->b_mask.p;
   }
   hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
-                     5 * nmo, dm, 1, 1);
+                     5 * nmo, dm, 1);
   TRY(check_launch(h, "k_sm_update"));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -968,25 +973,40 @@ static LwState lw_state(pqa_handle* h) {
   LwState L{};
   L.xt = (double*)h->b_xt.p;
   for (int s = 0; s < 2; ++s) {
-    L.T[s] = h->st.T[s]; L.cache[s] = h->st.cache[s];
+    L.Tt[s] = (double*)h->b_Tt[s].p; L.ct[s] = (double*)h->b_ct[s].p;
     L.dsign[s] = h->st.dsign[s]; L.dlog[s] = h->st.dlog[s];
   }
   L.auxt = (double*)h->b_auxt.p;
   return L;
 }
 
-// coordinates AoS (canonical, wave-per-walker kernels) -> SoA mirror for the lane-per-walker kernels, and back
+// AoS (canonical, wave-per-walker kernels) -> SoA mirrors for the lane-per-walker kernels
 static int lw_from_aos(pqa_handle* h) {
   const long W = h->W;
+  const int nel[2] = {h->nup, h->ndn};
   TRY(ensure(h, h->b_xt, (size_t)W * h->N * 3 * sizeof(double)));
   TRY(ensure(h, h->b_auxt, (size_t)W * 8 * sizeof(double)));
   TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 4 * sizeof(double)));
-  TRY(ensure(h, h->b_srow, (size_t)W * h->N * 5 * sizeof(double)));
   transpose(h, h->js.x, (double*)h->b_xt.p, W, (long)h->N * 3);
+  for (int s = 0; s < 2; ++s) {
+    const size_t n = nel[s];
+    TRY(ensure(h, h->b_Tt[s], W * n * n * sizeof(double)));
+    TRY(ensure(h, h->b_ct[s], W * n * 5 * h->nmo[s] * sizeof(double)));
+    transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(n * n));
+    transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
+  }
   return check_launch(h, "k_transpose");
 }
-static int lw_to_aos(pqa_handle* h) {
-  transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, h->W);
+// SoA -> AoS: coordinates and inverses (what the ECP kernels read); with_cache also the orbital cache
+static int lw_to_aos(pqa_handle* h, bool with_cache) {
+  const long W = h->W;
+  const int nel[2] = {h->nup, h->ndn};
+  transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W);
+  for (int s = 0; s < 2; ++s) {
+    const long n = nel[s];
+    transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], n * n, W);
+    if (with_cache) transpose(h, (const double*)h->b_ct[s].p, h->st.cache[s], n * 5 * h->nmo[s], W);
+  }
   return check_launch(h, "k_transpose");
 }
 
@@ -996,18 +1016,12 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)6 * W * sizeof(double)));
   if (soa_current) {
-    const double* srow = nullptr;
-    if (h->nup == 32 && h->ndn == 32) {
-      for (int s = 0; s < 2; ++s)
-        hipLaunchKernelGGL(k_slater_rows_ww32, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, lw_state(h), s, W, (double*)h->b_srow.p);
-      srow = (const double*)h->b_srow.p;
-    }
     hipLaunchKernelGGL(k_kinetic_lw, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
-                       (int)h->has_jastrow, W, srow, (double*)h->b_kpart.p);
+                       (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));
-    if (h->necp > 0) TRY(lw_to_aos(h));
+    if (h->necp > 0) TRY(lw_to_aos(h, false));
   } else {
     hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
                        (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
@@ -1101,13 +1115,19 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
   const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3;
+  int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
+  while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
   int Gm = 1;  // groups of the (latency-bound) partial-sum kernels: ~4 waves per SIMD
   while (Gm < 16 && (long)Gm * W < 4096L * 64) Gm *= 2;
   if (h->lw_gm > 0) Gm = std::min(h->lw_gm, 32);
   const int nmax = std::max(h->nup, h->ndn);
+  const int KB = (h->lw_kb > 0) ? std::min(h->lw_kb, std::max(nmax, 1)) : std::max(nmax, 1);  // KB = n: plain per-move update
   if (lw) {
     TRY(lw_from_aos(h));
-    TRY(ensure(h, h->b_part, (size_t)Gm * 8 * W * sizeof(double)));
+    TRY(ensure(h, h->b_part, (size_t)std::max(G, Gm) * 8 * W * sizeof(double)));
+    TRY(ensure(h, h->b_rbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_vbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_act, (size_t)KB * W));
   }
   const LwState L = lw_state(h);
   const dim3 gw((unsigned)((W + 63) / 64));
@@ -1128,7 +1148,13 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       const int s = e >= h->nup;
       const double* mo = (const double*)h->b_motmp.p;
       if (lw) {
+        const dim3 gg(gw.x, (unsigned)G);
         double* part = (double*)h->b_part.p;
+        const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
+        const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
+        double* rbuf = (double*)h->b_rbuf.p + (size_t)q * n_s * W;
+        double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
+        uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
         const dim3 gm(gw.x, (unsigned)Gm);
         hipLaunchKernelGGL(k_move_part_lw, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
                            (const double*)nullptr, W, Gm, part);
@@ -1137,12 +1163,18 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
         hipLaunchKernelGGL(k_move_part_lw, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
                            W, Gm, part);
         hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
-                           (const double*)part);
-        if ((s ? h->ndn : h->nup) == 32)
-          hipLaunchKernelGGL(k_commit_ww32, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, L, mb, e, mo, W);
-        else
-          hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, mo, 5 * h->nmo[s],
-                             (const uint8_t*)mb.accept, 1, 0);
+                           (const double*)part, rbuf, vbuf, act, mo);
+        const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
+        const dim3 gcm(gw.x, (unsigned)Gc);
+#define PQA_COMMIT(NM) hipLaunchKernelGGL(k_commit_lw<NM>, gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi)
+        if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
+#undef PQA_COMMIT
+        if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
+          const int nq = j_hi - j_lo;
+#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
+          if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#undef PQA_FLUSH
+        }
         continue;
       }
       hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
@@ -1161,7 +1193,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       TRY(check_launch(h, "k_row_means"));
     }
   }
-  if (lw) TRY(lw_to_aos(h));
+  if (lw) TRY(lw_to_aos(h, true));
   h->jas_stale = h->has_j2;
   std::vector<int> cnt(nsteps);
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));

@@ -10,7 +10,6 @@
 #define PQA_MAXAIP 12
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-struct __attribute__((aligned(16))) double4_ { double x, y, z, w; };  // two 16-B loads/stores
 
 // Device view of the system tables (all pointers are device memory).
 struct SysDev {

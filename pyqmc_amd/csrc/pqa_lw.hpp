@@ -13,13 +13,10 @@
 // These kernels handle the single-determinant case; multi-determinant handles use the
 // wave-per-walker kernels of pqa_vmc.hpp.
 //
-// State seen by these kernels:
-//   xt   [N][3][W]            coordinates, SoA (walker fastest): every Jastrow load is a coalesced wave access
-//   T    [s] [W][n][n]        inverse, canonical AoS: a partial-sum thread only gathers its slice of ONE 256-B row
-//   cache[s] [W][n][5][nmo]   cached MO value/grad/lap rows, canonical AoS (same argument)
-// Keeping T and the cache in AoS lets the Sherman-Morrison commit run as a register-resident wave-per-walker
-// kernel that touches accepted walkers only (an SoA commit drags every walker's inverse through HBM because
-// accepted and rejected walkers share cache lines: 307 MB vs 184 MB per launch at W = 16384, PMC-measured).
+// SoA state (walker index fastest):
+//   xt   [N][3][W]            coordinates
+//   Tt   [s] [n][n][W]        inverse, electron-major: Tt[i][k][w] = inverse[k][i]
+//   ct   [s] [n][5][nmo][W]   cached MO value/grad/lap rows of every electron
 #pragma once
 #include "pqa_common.hpp"
 #include "pqa_jastrow.hpp"
@@ -27,8 +24,8 @@
 
 struct LwState {
   double* xt;
-  double* T[2];      // AoS [W][n][n]   (single determinant)
-  double* cache[2];  // AoS [W][n][5][nmo]
+  double* Tt[2];
+  double* ct[2];
   double* dsign[2];  // [W] (single determinant) — shared with SlaterState
   double* dlog[2];
   double* auxt;      // [8][W]: scaled gaussian (3), limited drift (3), U_old, ratio
@@ -124,14 +121,24 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
   else { const double* xe = L.xt + (size_t)e * 3 * W + w; px = xe[0]; py = xe[W]; pz = xe[2 * W]; }
   double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
   {
-    const double* Ti = L.T[s] + ((size_t)w * n + i) * n;
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
     const int* occ = S.det_occ[s];
-    const double* row = rows ? rows + (size_t)w * 5 * nmo : L.cache[s] + ((size_t)w * n + i) * 5 * nmo;
+    if (rows) {
+      const double* row = rows + (size_t)w * 5 * nmo;
 #pragma unroll 4
-    for (int j = g; j < n; j += G) {
-      const double t = Ti[j];
-      const int o = occ[j];
-      r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
+      for (int j = g; j < n; j += G) {
+        const double t = Ti[(size_t)j * W];
+        const int o = occ[j];
+        r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
+      }
+    } else {
+      const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+#pragma unroll 4
+      for (int j = g; j < n; j += G) {
+        const double t = Ti[(size_t)j * W];
+        const double* cj = ci + (size_t)occ[j] * W;
+        r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
+      }
     }
   }
   double U, gg[3], lp, ee, ei;
@@ -179,12 +186,14 @@ __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, Move
 }
 
 // Metropolis decision (mc.py:124-132); accepted walkers: move the coordinate, update sign/log of the
-// determinant and leave the determinant ratio in auxt[7] for the commit kernel.
+// determinant, and stage R[k] = T[i][k]/ratio in Rbuf[n][W] for the commit kernel.
 __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W, int G,
-                                                      const double* __restrict__ part) {
+                                                      const double* __restrict__ part, double* __restrict__ Rbuf,
+                                                      double* __restrict__ Vbuf, uint8_t* __restrict__ act,
+                                                      const double* __restrict__ motmp) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   if (w >= W) return;
-  const int s = e >= S.nup;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   double v[8];
   lw_sum_parts(part, W, w, G, v);
   double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
@@ -206,116 +215,134 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   }
   const bool acc = ratio > u;
   mb.accept[w] = acc;
+  act[w] = acc;
   if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
   if (!acc) return;
   mb.acc_w[w] += 1;
   double* xe = L.xt + (size_t)e * 3 * W + w;
   xe[0] = mb.newpos[3 * w]; xe[W] = mb.newpos[3 * w + 1]; xe[2 * W] = mb.newpos[3 * w + 2];
+  {
+    const double* row = motmp + (size_t)w * 5 * nmo;
+    const int* occ = S.det_occ[s];
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) Vbuf[(size_t)k * W + w] = row[occ[k]];
+  }
   const double dr = v[0];  // determinant ratio
   L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
   L.dlog[s][w] += log(fabs(dr));
-  L.auxt[7 * W + w] = dr;
+  const double inv = 1.0 / dr;
+  const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+#pragma unroll 8
+  for (int k = 0; k < n; ++k) Rbuf[(size_t)k * W + w] = Ti[(size_t)k * W] * inv;
 }
 
 // ---------------------------------------------------------------- commit (Sherman-Morrison, slater.py:88-94)
-// n = 32: the 8-KB inverse of one accepted walker lives in the registers of ONE wave — lane l holds the
-// contiguous half-row T[l/2][16(l&1) .. +15] (8 x global_load_dwordx4, consecutive lanes = consecutive 128 B:
-// perfectly coalesced, no LDS):
-//   tmp[r] = V . T[r]         (16 FMAs per lane + one exchange with the partner lane)
-//   ratio  = tmp[i],  R = T[i]/ratio  (read straight from global: row i is only rewritten by its own lanes)
-//   T[r]  -= R tmp[r]  (r != i),  T[i] = R
-// and the 5*nmo cached orbital values of electron i are refreshed.  Rejected walkers exit at once, so HBM traffic
-// is 16 KB per ACCEPTED walker.  (A blocked/delayed variant that touches T once per 8 moves was measured 9 %
-// slower in the SoA form — its flush re-reads the block's V/R vectors from cache for every row — and was dropped.)
-__global__ __launch_bounds__(64) void k_commit_ww32(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
-                                                    long W) {
-  const long w = blockIdx.x;
-  if (!mb.accept[w]) return;
-  const int lane = threadIdx.x;
-  const int s = e >= S.nup, i = e - s * S.nup, nmo = S.nmo[s];
-  const int r = lane >> 1, h = lane & 1;
-  double* Tw = L.T[s] + (size_t)w * 1024;
+// Blocked update.  Electrons of one spin are moved in index order, so a ratio or drift only ever needs the
+// inverse rows of electrons that have not moved yet in this sweep plus the current one.  The electrons are
+// grouped in blocks of KB; an accepted move of electron i updates immediately only the KB rows of its block
+//   T[j][k] -= R[k] * (V . T[j])   (j != i),     T[i][k] = R[k],     R = T_old[i]/ratio, V = new orbital row
+// and leaves (V, R) in the block buffers Vb/Rb[q][n][W] (q = position in the block, act[q][W] = accepted).
+// After the last electron of a block k_flush_lw applies the block's accepted updates, in order, to every
+// row outside the block while that row sits in registers.  Per row the arithmetic and its order are exactly
+// those of updating after every move, so the inverse is bitwise identical — but it crosses HBM once per
+// block instead of once per move (512*KB + 16384/KB bytes per move at n = 32: 2.7x less at KB = 8).
+// thread = (walker, row group g of G).  The 5*nmo cached orbital values of electron i are refreshed in slices
+// by the same groups.  NMAX >= n.
+template <int NMAX>
+__global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
+                                                  const double* __restrict__ Rbuf, const double* __restrict__ Vbuf, long W,
+                                                  int G, int j_lo, int j_hi) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (w >= W || !mb.accept[w]) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  double* T = L.Tt[s] + w;
+  double V[NMAX], R[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    V[k] = (k < n) ? Vbuf[(size_t)k * W + w] : 0.0;
+    R[k] = (k < n) ? Rbuf[(size_t)k * W + w] : 0.0;
+  }
+  for (int j = j_lo + g; j < j_hi; j += G) {
+    double* Tj = T + (size_t)j * n * W;
+    if (j == i) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if (k < n) Tj[(size_t)k * W] = R[k];
+      continue;
+    }
+    double t[NMAX];
+    double tmp = 0.0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      t[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+      tmp += V[k] * t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if (k < n) Tj[(size_t)k * W] = t[k] - R[k] * tmp;
+  }
   const double* row = motmp + (size_t)w * 5 * nmo;
-  const int* occ = S.det_occ[s];
-  double t[16], V[16], R[16];
-  const double4_* src = reinterpret_cast<const double4_*>(Tw + (size_t)lane * 16);
-  const double4_* ri = reinterpret_cast<const double4_*>(Tw + (size_t)i * 32 + 16 * h);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const double4_ a = src[q], b = ri[q];
-    t[4 * q] = a.x; t[4 * q + 1] = a.y; t[4 * q + 2] = a.z; t[4 * q + 3] = a.w;
-    R[4 * q] = b.x; R[4 * q + 1] = b.y; R[4 * q + 2] = b.z; R[4 * q + 3] = b.w;
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) V[k] = row[occ[16 * h + k]];
-  double tmp = 0.0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) tmp += V[k] * t[k];
-  tmp += __shfl_xor(tmp, 1, 64);  // partner half-row
-  const double inv = 1.0 / L.auxt[7 * W + w];  // determinant ratio = tmp of row i (computed identically upstream)
-  __syncthreads();                 // every lane has read row i before its owners overwrite it
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const double Rk = R[k] * inv;
-    t[k] = (r == i) ? Rk : t[k] - Rk * tmp;
-  }
-  double4_* dst = reinterpret_cast<double4_*>(Tw + (size_t)lane * 16);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dst[q] = double4_{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-  double* c = L.cache[s] + ((size_t)w * 32 + i) * 5 * nmo;
-  for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
+  double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+#pragma unroll 8
+  for (int k = g; k < 5 * nmo; k += G) c[(size_t)k * W] = row[k];
 }
 
-// Slater part of the kinetic energy, wave per walker: r_c(i) = sum_j cache[i][c][occ_j] T[i][j] for all electrons of
-// spin s at once (lane = (electron, half-row), 128-B loads).  out [W][N][5].  n = 32, single determinant, occ = identity
-// is NOT assumed (gathers through occ).
-__global__ __launch_bounds__(64) void k_slater_rows_ww32(SysDev S, LwState L, int s, long W, double* __restrict__ out) {
-  const long w = blockIdx.x;
-  const int lane = threadIdx.x, r = lane >> 1, h = lane & 1, nmo = S.nmo[s];
-  const double* Tw = L.T[s] + (size_t)w * 1024 + (size_t)lane * 16;
-  const double* cw = L.cache[s] + ((size_t)w * 32 + r) * 5 * nmo;
-  const int* occ = S.det_occ[s];
-  double t[16], acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+// rows outside [j_lo, j_hi) of spin s: apply the block's nq buffered updates in order.  Vb/Rb: [KB][n][W], act: [KB][W]
+template <int NMAX>
+__global__ __launch_bounds__(64) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
+                                                 const double* __restrict__ Rb, const uint8_t* __restrict__ act, long W, int G,
+                                                 int j_lo, int j_hi, int nq) {
+  const long w = (long)blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (w >= W) return;
+  const int n = s ? S.ndn : S.nup;
+  bool any = false;
+  for (int q = 0; q < nq; ++q) any = any || act[(size_t)q * W + w];
+  if (!any) return;
+  double* T = L.Tt[s] + w;
+  const int nout = n - (j_hi - j_lo);
+  for (int jj = g; jj < nout; jj += G) {
+    const int j = (jj < j_lo) ? jj : jj + (j_hi - j_lo);
+    double* Tj = T + (size_t)j * n * W;
+    double t[NMAX];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) t[k] = Tw[k];
+    for (int k = 0; k < NMAX; ++k) t[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+    for (int q = 0; q < nq; ++q) {
+      if (!act[(size_t)q * W + w]) continue;
+      const double* Vq = Vb + (size_t)q * n * W + w;
+      const double* Rq = Rb + (size_t)q * n * W + w;
+      double tmp = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int o = occ[16 * h + k];
+      for (int k = 0; k < NMAX; ++k)
+        if (k < n) tmp += Vq[(size_t)k * W] * t[k];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) acc[c] += cw[c * nmo + o] * t[k];
-  }
+      for (int k = 0; k < NMAX; ++k)
+        if (k < n) t[k] = t[k] - Rq[(size_t)k * W] * tmp;
+    }
 #pragma unroll
-  for (int c = 0; c < 5; ++c) acc[c] += __shfl_xor(acc[c], 1, 64);
-  if (h == 0) {
-    double* o = out + ((size_t)w * S.nelec + (s ? S.nup : 0) + r) * 5;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) o[c] = acc[c];
+    for (int k = 0; k < NMAX; ++k)
+      if (k < n) Tj[(size_t)k * W] = t[k];
   }
 }
 
 // ---------------------------------------------------------------- kinetic + Coulomb
-// thread = (walker, electron), walker fastest.  srow [W][N][5]: Slater row sums from k_slater_rows_ww32 (or NULL:
-// computed here).  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
-__global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, const double* __restrict__ srow,
-                                                   double* __restrict__ part) {
+// thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
+__global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int e = blockIdx.y;
   if (w >= W) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if (srow) {
-    const double* q = srow + ((size_t)w * S.nelec + e) * 5;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) r[c] = q[c];
-  } else {
-    const double* Ti = L.T[s] + ((size_t)w * n + i) * n;
-    const double* ci = L.cache[s] + ((size_t)w * n + i) * 5 * nmo;
+  {
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
     const int* occ = S.det_occ[s];
     for (int j = 0; j < n; ++j) {
-      const double t = Ti[j];
-      const int o = occ[j];
+      const double t = Ti[(size_t)j * W];
+      const double* cj = ci + (size_t)occ[j] * W;
 #pragma unroll
-      for (int c = 0; c < 5; ++c) r[c] += ci[c * nmo + o] * t;
+      for (int c = 0; c < 5; ++c) r[c] += cj[(size_t)c * nmo * W] * t;
     }
   }
   const double gs0 = r[1] / r[0], gs1 = r[2] / r[0], gs2 = r[3] / r[0], ls = r[4] / r[0];

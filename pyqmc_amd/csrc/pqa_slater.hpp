@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void k_slater_eval(SysDev S, SlaterState st, in
 // the row-per-lane accesses below are bank-conflict free); every row is split over R = 64/n lane
 // groups so all 64 lanes work for n <= 32.  LDS: n(n+1) + 2n + 64 doubles.
 __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterState& st, int s, int i, long w,
-                                               const double* __restrict__ morow, double* lds, bool upd_det = true) {
+                                               const double* __restrict__ morow, double* lds) {
   const int lane = threadIdx.x & 63;
   const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], ld = n + 1;
   double* L = lds;
@@ -284,7 +284,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
         if (c >= n) { c -= n; ++r; }
       }
     }
-    if (lane == 0 && upd_det) {
+    if (lane == 0) {
       const size_t o = (size_t)w * D + d;
       st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)
       st.dlog[s][o] += log(fabs(ratio));
@@ -295,14 +295,13 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
 
 // grid = W; mo rows [w][NCOMP_STRIDE][nmo] (value component first); mask (W) bytes
 __global__ __launch_bounds__(64) void k_sm_update(SysDev S, SlaterState st, int e, const double* __restrict__ mo,
-                                                  int row_stride, const uint8_t* __restrict__ mask, int to_cache,
-                                                  int upd_det) {
+                                                  int row_stride, const uint8_t* __restrict__ mask, int to_cache) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   if (mask && !mask[w]) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   const double* row = mo + (size_t)w * row_stride;
-  sm_update_wave(S, st, s, i, w, row, lds, upd_det != 0);
+  sm_update_wave(S, st, s, i, w, row, lds);
   if (to_cache) {  // keep the per-electron orbital cache current (value, grad, lap rows)
     double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
     for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[k] = row[k];
