@@ -350,3 +350,26 @@ def test_lane_and_wave_per_walker_sweeps_agree(monkeypatch):
     assert note("lw_vs_ww_log", np.max(np.abs(res[0][1][ok] - res[1][1][ok]))) < 1e-9
     for r in res:  # updated state equals a fresh recompute in both modes
         assert np.max(np.abs(r[1] - r[4])) < 1e-9
+
+
+def test_blocked_sherman_morrison_is_bitwise_identical(monkeypatch):
+    """The optional blocked (delayed) Sherman-Morrison of the lane-per-walker sweep (PQA_LW_KB) applies per row the
+    same operations in the same order as updating every row on every move: trajectories and inverses must be
+    bit-identical."""
+    import pyqmc_amd as pa
+
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
+    res = []
+    for kb in ("8", "0", "5"):
+        monkeypatch.setenv("PQA_LW_KB", kb)
+        wf = helpers.gpu_wf(mol, mf)
+        dev = wf.fused_device()
+        wf.recompute(OpenConfigs(start.copy()))
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=77, energy=True)
+        inv = [wf.wf_factors[0]._get_state(s)[0] for s in (0, 1)]
+        res.append((dev.configs(), dev.value()[1], en, inv))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
