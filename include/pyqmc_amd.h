@@ -83,6 +83,13 @@ typedef struct {
   const double* b3_param;
   double rcut_a3, rcut_b3;
   const double* ccoeff;
+  /* periodic boundary conditions (PeriodicConfigs coord.py:137-252, MinimalImageDistance distance.py:83-159).
+     pbc = 0: open system.  1: lattice vectors mutually orthogonal — displacements are folded in fractional
+     coordinates (diagonal_dist / orthogonal_dist, :143-159).  2: general cell — fold, then argmin over the 27
+     neighbouring cells (general_dist, :129-141).  Walker positions handed to the library are expected inside
+     the cell (enforce_pbc, pbc/pbc.py:18-49), as PeriodicConfigs keeps them. */
+  int32_t pbc;
+  double lattice[9]; /* rows = lattice vectors of the simulation cell, bohr */
 } pqa_system_t;
 
 /* ---- lifetime --------------------------------------------------------------------- */

@@ -188,6 +188,13 @@ class JastrowSpin:
         self._nelec = self._nup + self._ndn
         self.atoms = np.asarray(mol.atom_coords(), dtype=float)
         self.a_basis, self.b_basis, self.rcut = list(a_basis), list(b_basis), float(rcut)
+        # periodic cell: every displacement goes through the minimal-image rule (configs.dist, jastrowspin.py:82-98)
+        if hasattr(mol, "a"):
+            from .pbc import minimal_image
+
+            self._mi = minimal_image(mol.lattice_vectors())
+        else:
+            self._mi = lambda d: d
         self.parameters = {
             "bcoeff": np.zeros((len(b_basis), 3)),
             "acoeff": np.zeros((len(self.atoms), len(a_basis), 2)),
@@ -195,9 +202,11 @@ class JastrowSpin:
         self.dtype = float
 
     def _a(self, d, want):
+        d = self._mi(d)
         return jastrow_basis.evaluate(self.a_basis, self.rcut, d, np.linalg.norm(d, axis=-1), want)
 
     def _b(self, d, want):
+        d = self._mi(d)
         return jastrow_basis.evaluate(self.b_basis, self.rcut, d, np.linalg.norm(d, axis=-1), want)
 
     def _others(self, e):
@@ -381,6 +390,12 @@ class ThreeBodyJastrow:
         self.a_basis, self.b_basis, self.rcut = list(a_basis), list(b_basis), float(rcut)
         self.parameters = {"ccoeff": np.zeros((len(self.atoms), len(a_basis), len(a_basis), len(b_basis), 3))}
         self.dtype = float
+        if hasattr(mol, "a"):  # minimal-image displacements (configs.dist, three_body_jastrow.py:70-92)
+            from .pbc import minimal_image
+
+            self._mi = minimal_image(mol.lattice_vectors())
+        else:
+            self._mi = lambda d: d
 
     def _C(self):
         c = self.parameters["ccoeff"]
@@ -393,9 +408,9 @@ class ThreeBodyJastrow:
         xo = xw[:, others]  # (W, N-1, 3)
         sig = edown + (np.nonzero(others)[0] >= self._nup).astype(int)  # spin index per j
         C = self._C()[..., sig]  # (A,k,l,m,N-1)
-        de_I = pos[:, None, :] - self.atoms[None]  # (W,A,3)
-        de_j = pos[:, None, :] - xo  # (W,N-1,3)
-        dj_I = xo[:, :, None, :] - self.atoms[None, None]  # (W,N-1,A,3)
+        de_I = self._mi(pos[:, None, :] - self.atoms[None])  # (W,A,3)
+        de_j = self._mi(pos[:, None, :] - xo)  # (W,N-1,3)
+        dj_I = self._mi(xo[:, :, None, :] - self.atoms[None, None])  # (W,N-1,A,3)
         aj = jastrow_basis.evaluate(self.a_basis, self.rcut, dj_I, np.linalg.norm(dj_I, axis=-1), "value")  # (W,N-1,A,l)
         if want == "value":
             ae = jastrow_basis.evaluate(self.a_basis, self.rcut, de_I, np.linalg.norm(de_I, axis=-1), "value")

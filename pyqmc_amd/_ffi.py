@@ -40,6 +40,7 @@ class SystemStruct(C.Structure):
         ("na3", C.c_int32), ("nb3", C.c_int32),
         ("a3_kind", c_int32_p), ("a3_param", c_double_p), ("b3_kind", c_int32_p), ("b3_param", c_double_p),
         ("rcut_a3", C.c_double), ("rcut_b3", C.c_double), ("ccoeff", c_double_p),
+        ("pbc", C.c_int32), ("lattice", C.c_double * 9),
     ]
 
 

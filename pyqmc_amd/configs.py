@@ -1,9 +1,10 @@
 """Walker containers with the interface of ``pyqmc/configurations/coord.py:21-112``.
 
-Only the open-boundary container is provided in this round (the PBC container,
-``coord.py:137-252``, belongs to the diamond configs C3/C5).  The arrays are
-ordinary host ``numpy`` arrays — this is the *boundary* type handed across the
-wave-function protocol; device-resident walker state lives behind the C ABI.
+``OpenConfigs``/``OpenElectron`` (``coord.py:21-112``) and ``PeriodicConfigs``/``PeriodicElectron``
+(``coord.py:115-252``) with ``enforce_pbc`` (``pyqmc/pbc/pbc.py:18-49``) and the minimal-image distance
+(``distance.py:83-159``).  The arrays are ordinary host ``numpy`` arrays — this is the *boundary* type
+handed across the wave-function protocol; device-resident walker state lives behind the C ABI, where the
+same minimal-image convention is applied by ``min_image`` (``csrc/pqa_common.hpp``).
 """
 
 import copy
@@ -79,3 +80,141 @@ class OpenConfigs:
 
     def reshape(self, shape):
         self.configs = self.configs.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------ periodic
+
+
+def enforce_pbc(lattvecs, epos):
+    """Fold positions into the cell spanned by the rows of ``lattvecs`` (``pbc/pbc.py:18-49``).
+
+    Returns (positions in the cell, integer-valued float ``wrap`` such that
+    ``epos == final + wrap @ lattvecs``).  Fractional coordinates are ``epos @ inv(lattvecs)`` and are
+    split with ``divmod(., 1)`` exactly as the reference does, so the in-cell interval is [0, 1)."""
+    frac = np.einsum("...ij,jk->...ik", epos, np.linalg.inv(lattvecs))
+    wrap, rem = np.divmod(frac, 1)
+    return np.dot(rem, lattvecs), wrap
+
+
+def _is_diagonal(m, tol):
+    return np.all(np.abs(m - np.diag(np.diagonal(m))) < tol)
+
+
+class MinimalImageDistance(RawDistance):
+    """Displacements reduced to the nearest periodic image (``distance.py:83-159``).
+
+    ``kind`` is chosen like the reference (:95-107): "diagonal" (lattice vectors along x, y, z),
+    "orthogonal" (mutually orthogonal rows) or "general" (argmin over the 27 neighbouring cells)."""
+
+    def __init__(self, latvec):
+        latvec = np.asarray(latvec, dtype=float)
+        tol = 1e-10
+        if _is_diagonal(latvec, tol):
+            self.kind = "diagonal"
+        elif _is_diagonal(latvec @ latvec.T, tol):
+            self.kind = "orthogonal"
+        else:
+            self.kind = "general"
+        self._latvec = latvec
+        self._invvec = np.linalg.inv(latvec)
+        grid = np.meshgrid(*[np.arange(3)] * 3)  # same cell order as distance.py:113-117
+        self.point_list = np.stack([g.ravel() for g in grid], axis=0).T - 1
+        self.shifts = self.point_list @ latvec
+
+    def _minimal_dist(self, d):
+        if self.kind == "diagonal":
+            d = np.array(d, dtype=float)
+            for i in range(3):
+                L = self._latvec[i, i]
+                d[..., i] = (d[..., i] + L / 2) % L - L / 2
+            return d
+        if self.kind == "orthogonal":
+            frac = np.einsum("...ij,jk->...ik", d, self._invvec)
+            frac = (frac + 0.5) % 1 - 0.5
+            return np.einsum("...ij,jk->...ik", frac, self._latvec)
+        cand = d[np.newaxis] + self.shifts.reshape((-1,) + (1,) * (d.ndim - 1) + (3,))
+        best = np.argmin(np.sum(cand**2, axis=-1), axis=0)
+        return np.take_along_axis(cand, best[np.newaxis, ..., np.newaxis], axis=0)[0]
+
+    def dist_i(self, a, b):
+        return self._minimal_dist(super().dist_i(a, b))
+
+    def dist_matrix(self, configs):
+        d, ij = super().dist_matrix(configs)
+        return (self._minimal_dist(d) if len(ij) else d), ij
+
+    def pairwise(self, config1, config2):
+        return self._minimal_dist(super().pairwise(config1, config2))
+
+
+class PeriodicElectron:
+    """Positions of one electron inside the cell plus the integer ``wrap`` that brought them there
+    (``coord.py:115-134``)."""
+
+    def __init__(self, epos, lattice_vectors, dist, wrap=None):
+        self.configs = epos
+        self.lvecs = lattice_vectors
+        self.wrap = wrap if wrap is not None else np.zeros_like(epos)
+        self.dist = dist
+
+    def mask(self, mask):
+        return PeriodicElectron(self.configs[mask], self.lvecs, self.dist, wrap=self.wrap[mask])
+
+
+class PeriodicConfigs:
+    """(nconf,nelec,3) walker positions folded into the simulation cell, with per-electron ``wrap`` counters
+    (``coord.py:137-252``)."""
+
+    def __init__(self, configs, lattice_vectors, wrap=None, dist=None):
+        lattice_vectors = np.asarray(lattice_vectors, dtype=float)
+        folded, w = enforce_pbc(lattice_vectors, np.asarray(configs, dtype=float))
+        self.configs = np.ascontiguousarray(folded)
+        self.wrap = w if wrap is None else w + wrap
+        self.lvecs = lattice_vectors
+        self.dist = dist if dist is not None else MinimalImageDistance(lattice_vectors)
+
+    def electron(self, e):
+        return PeriodicElectron(self.configs[:, e], self.lvecs, self.dist, wrap=self.wrap[:, e])
+
+    def select_electrons(self, es):
+        return PeriodicConfigs(self.configs[:, es], self.lvecs, wrap=self.wrap[:, es], dist=self.dist)
+
+    def mask(self, mask):
+        return PeriodicConfigs(self.configs[mask], self.lvecs, wrap=self.wrap[mask], dist=self.dist)
+
+    def make_irreducible(self, e, vec, mask=None):
+        """Fold proposed positions ``vec`` ((nconf,3) or (nconf,naip,3)) for electron ``e`` into the cell and
+        carry the electron's wrap counters along (``coord.py:164-178``)."""
+        if mask is None:
+            mask = np.ones(vec.shape[:-1], dtype=bool)
+        folded, dw = enforce_pbc(self.lvecs, vec[mask])
+        epos = vec.copy()
+        epos[mask] = folded
+        wrap = self.wrap[:, e, :].copy()
+        if vec.ndim == 3:
+            wrap = np.repeat(self.wrap[:, e][:, np.newaxis], vec.shape[1], axis=1)
+        wrap[mask] += dw
+        return PeriodicElectron(epos, self.lvecs, self.dist, wrap=wrap)
+
+    def move(self, e, new, accept):
+        self.configs[accept, e, :] = new.configs[accept, :]
+        self.wrap[accept, e, :] = new.wrap[accept, :]
+
+    def resample(self, newinds):
+        self.configs = self.configs[newinds]
+        self.wrap = self.wrap[newinds]
+
+    def split(self, npartitions):
+        return [PeriodicConfigs(c, self.lvecs, w, dist=self.dist)
+                for c, w in zip(np.array_split(self.configs, npartitions), np.array_split(self.wrap, npartitions))]
+
+    def join(self, configslist, axis=0):
+        self.configs = np.concatenate([c.configs for c in configslist], axis=axis)
+        self.wrap = np.concatenate([c.wrap for c in configslist], axis=axis)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def reshape(self, shape):
+        self.configs = self.configs.reshape(shape)
+        self.wrap = self.wrap.reshape(shape)

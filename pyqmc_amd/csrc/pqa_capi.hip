@@ -255,6 +255,18 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 64 electrons per spin channel is not supported by the one-wave determinant tile");
   SysDev& S = h->S;
   S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;
+  S.pbc = sys->pbc;
+  if (S.pbc < 0 || S.pbc > 2) FAIL("pbc must be 0 (open), 1 (orthogonal cell) or 2 (general cell)");
+  if (S.pbc) {
+    const double* a = sys->lattice;
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    if (!(fabs(det) > 1e-12)) FAIL("singular lattice");
+    for (int i = 0; i < 9; ++i) S.lat[i] = a[i];
+    const double id = 1.0 / det;  // inverse by cofactors: linv[r][c] = cof(c,r) / det
+    S.linv[0] = (a[4] * a[8] - a[5] * a[7]) * id; S.linv[1] = (a[2] * a[7] - a[1] * a[8]) * id; S.linv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    S.linv[3] = (a[5] * a[6] - a[3] * a[8]) * id; S.linv[4] = (a[0] * a[8] - a[2] * a[6]) * id; S.linv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    S.linv[6] = (a[3] * a[7] - a[4] * a[6]) * id; S.linv[7] = (a[1] * a[6] - a[0] * a[7]) * id; S.linv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+  }
   double* tmp_d; int* tmp_i;
   TRY(upload_table(h, sys->atom_xyz, (size_t)h->natom * 3, &tmp_d)); S.atom_xyz = tmp_d;
   TRY(upload_table(h, sys->atom_charge, (size_t)h->natom, &tmp_d)); S.atom_charge = tmp_d;
@@ -1083,6 +1095,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
 }
 
 extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
+  if (h->S.pbc) FAIL("periodic energies (Ewald) are not implemented yet");
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   h->saved_valid = false;
@@ -1095,6 +1108,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
                               double* energy_mean, uint8_t* accept_rec) {
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
+  if (h->S.pbc) FAIL("the fused sweep does not fold walkers into a periodic cell yet; use the protocol path");
   if (nsteps <= 0) return 0;
   const long W = h->W;
   const int N = h->N;
@@ -1213,6 +1227,7 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  if (h->S.pbc) FAIL("periodic T-moves are not implemented yet");
   const long W = h->W;
   const int P = h->tm_P, s = e >= h->nup;
   if (P == 0) return 0;

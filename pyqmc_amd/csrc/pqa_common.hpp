@@ -50,6 +50,10 @@ struct SysDev {
   double rcut_a3, rcut_b3;
   const double* c3;
   int j3_off;  // offset (in doubles) of the three-body scratch inside a kernel's dynamic LDS
+  // periodic boundary conditions: 0 open, 1 fold fractional coordinates (orthogonal lattice vectors,
+  // distance.py:143-159), 2 fold + argmin over the 27 neighbouring cells (distance.py:129-141)
+  int pbc;
+  double lat[9], linv[9];  // rows = lattice vectors; linv = inverse (frac = d . linv)
   int necp;
   const int* ecp_atom;
   const int* ecp_chan_off;
@@ -59,6 +63,40 @@ struct SysDev {
   const double* ecp_term_coef;
   int ecp_naip_max;
 };
+
+// ---------------------------------------------------------------- minimal image
+// Displacement -> nearest periodic image (MinimalImageDistance, distance.py:83-159).  Folding the fractional
+// coordinates into [-1/2, 1/2) is the reference's diagonal/orthogonal rule; for skewed cells the 26 neighbours
+// of the folded vector are searched as well (the reference searches the neighbours of the raw difference of two
+// in-cell points; both find the global minimum, ties aside).
+__device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& dy, double& dz) {
+  if (S.pbc == 0) return;
+  double f0 = dx * S.linv[0] + dy * S.linv[3] + dz * S.linv[6];
+  double f1 = dx * S.linv[1] + dy * S.linv[4] + dz * S.linv[7];
+  double f2 = dx * S.linv[2] + dy * S.linv[5] + dz * S.linv[8];
+  f0 -= floor(f0 + 0.5); f1 -= floor(f1 + 0.5); f2 -= floor(f2 + 0.5);
+  dx = f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6];
+  dy = f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7];
+  dz = f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8];
+  if (S.pbc == 2) {
+    double bx = dx, by = dy, bz = dz, best = dx * dx + dy * dy + dz * dz;
+    for (int i = -1; i <= 1; ++i)
+      for (int j = -1; j <= 1; ++j)
+        for (int k = -1; k <= 1; ++k) {
+          const double cx = dx + i * S.lat[0] + j * S.lat[3] + k * S.lat[6];
+          const double cy = dy + i * S.lat[1] + j * S.lat[4] + k * S.lat[7];
+          const double cz = dz + i * S.lat[2] + j * S.lat[5] + k * S.lat[8];
+          const double c2 = cx * cx + cy * cy + cz * cz;
+          if (c2 < best) { best = c2; bx = cx; by = cy; bz = cz; }
+        }
+    dx = bx; dy = by; dz = bz;
+  }
+}
+
+__device__ __forceinline__ double mi_norm(const SysDev& S, double dx, double dy, double dz) {
+  min_image(S, dx, dy, dz);
+  return sqrt(dx * dx + dy * dy + dz * dz);
+}
 
 // ---------------------------------------------------------------- wave-level reductions
 // Sum over the 64 lanes, result broadcast to every lane.  Uses DPP row shifts + row broadcasts (VALU

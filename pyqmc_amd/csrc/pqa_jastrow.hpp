@@ -107,7 +107,8 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
   const int edown = e >= S.nup, na = S.na3, nb = S.nb3, str = j3_stride(S), nlm = na * nb * 2;
   const double ira = 1.0 / S.rcut_a3, irb = 1.0 / S.rcut_b3;
   for (int I = lane; I < S.natom; I += 64) {
-    const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     double* row = scr + (size_t)I * str;
     row[0] = dx; row[1] = dy; row[2] = dz;
@@ -140,7 +141,8 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
     const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
-    const double dx = rx - jx, dy = ry - jy, dz = rz - jz;
+    double dx = rx - jx, dy = ry - jy, dz = rz - jz;
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (!(r < S.rcut_b3)) continue;
     double bv[PQA_MAXBAS], bg[PQA_MAXBAS], bl[PQA_MAXBAS];
@@ -152,8 +154,7 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
     }
     const int sp = j >= S.nup;
     for (int I = 0; I < S.natom; ++I) {
-      const double ax = jx - S.atom_xyz[3 * I], ay = jy - S.atom_xyz[3 * I + 1], az = jz - S.atom_xyz[3 * I + 2];
-      const double rj = sqrt(ax * ax + ay * ay + az * az);
+      const double rj = mi_norm(S, jx - S.atom_xyz[3 * I], jy - S.atom_xyz[3 * I + 1], jz - S.atom_xyz[3 * I + 2]);
       if (!(rj < S.rcut_a3)) continue;
       const RadShared sha = rad_shared<0>(rj, ira);
       const double* row = scr + (size_t)I * str;
@@ -199,7 +200,8 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
   if (parts & 1) {
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
-    const double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
+    double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_b) {
       const RadShared sh = rad_shared<MODE>(r, irb);
@@ -217,7 +219,8 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
     }
   }
   for (int I = lane; I < S.natom; I += 64) {
-    const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_a) {
       const RadShared sh = rad_shared<MODE>(r, ira);
@@ -256,8 +259,8 @@ __device__ __forceinline__ void jas_commit(const SysDev& S, const JastrowState& 
     for (int j = lane; j < S.nelec; j += 64) {
       if (j == e) continue;
       const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
-      const double rn = sqrt((rx - jx) * (rx - jx) + (ry - jy) * (ry - jy) + (rz - jz) * (rz - jz));
-      const double ro = sqrt((ox - jx) * (ox - jx) + (oy - jy) * (oy - jy) + (oz - jz) * (oz - jz));
+      const double rn = mi_norm(S, rx - jx, ry - jy, rz - jz);
+      const double ro = mi_norm(S, ox - jx, oy - jy, oz - jz);
       const int grp = j >= S.nup;
 #pragma unroll
       for (int l = 0; l < PQA_MAXBAS; ++l) {
@@ -280,8 +283,8 @@ __device__ __forceinline__ void jas_commit(const SysDev& S, const JastrowState& 
   }
   for (int I = lane; I < S.natom; I += 64) {
     const double ax = S.atom_xyz[3 * I], ay = S.atom_xyz[3 * I + 1], az = S.atom_xyz[3 * I + 2];
-    const double rn = sqrt((rx - ax) * (rx - ax) + (ry - ay) * (ry - ay) + (rz - az) * (rz - az));
-    const double ro = sqrt((ox - ax) * (ox - ax) + (oy - ay) * (oy - ay) + (oz - az) * (oz - az));
+    const double rn = mi_norm(S, rx - ax, ry - ay, rz - az);
+    const double ro = mi_norm(S, ox - ax, oy - ay, oz - az);
     double* av = js.avalues + ((size_t)w * S.natom + I) * S.na * 2;
     for (int k = 0; k < S.na; ++k) {
       double vn = 0.0, vo = 0.0;
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
     for (int k = 0; k < S.na; ++k) {
       double sum[2] = {0.0, 0.0};
       for (int e = 0; e < S.nelec; ++e) {
-        const double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
+        double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
+        min_image(S, dx, dy, dz);
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         if (r < S.rcut_a) sum[e >= S.nup] += jas_value1(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, r);
       }
@@ -336,7 +340,8 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
   for (int i = 0; i < S.nelec; ++i) {
     const double ix = xw[3 * i], iy = xw[3 * i + 1], iz = xw[3 * i + 2];
     for (int j = i + 1 + lane; j < S.nelec; j += 64) {
-      const double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
+      double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
+      min_image(S, dx, dy, dz);
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
       if (r < S.rcut_b) {
         const int t = (i >= S.nup) + (j >= S.nup);  // 0 upup, 1 updown, 2 downdown

@@ -61,7 +61,8 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
 #pragma unroll 4
   for (int j = j0; j < S.nelec; j += dj) {
     const double* xj = xt + (size_t)j * 3 * W + w;
-    const double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
+    double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (j == e) continue;
     if (MODE == 2 && j > e) see += fast_rcp(r);
@@ -81,7 +82,8 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
     }
   }
   for (int I = j0; I < S.natom; I += dj) {
-    const double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
     if (has_jastrow && r < S.rcut_a) {

@@ -49,9 +49,11 @@ def expand_beta_qwalk(beta0, n):
 
 
 def default_jastrow_basis(mol, ion_cusp=False, na=4, nb=3, rcut=None, cusp_gamma=None, beta_a=0.2, beta_b=0.5):
-    """wftools.py:76-96 (open boundary: rcut = 7.5)."""
+    """wftools.py:76-96: rcut = 7.5 for molecules, min_i pi/|b_i| (half the smallest lattice-plane spacing)
+    for a periodic cell."""
     cusp_gamma = 24 if cusp_gamma is None else cusp_gamma
-    rcut = 7.5 if rcut is None else rcut
+    if rcut is None:
+        rcut = float(np.amin(np.pi / np.linalg.norm(mol.reciprocal_vectors(), axis=1))) if hasattr(mol, "a") else 7.5
     abasis = [CutoffCuspFunction(cusp_gamma, rcut)] if ion_cusp else []
     abasis += [PolyPadeFunction(b, rcut) for b in expand_beta_qwalk(beta_a, na)]
     bbasis = [CutoffCuspFunction(cusp_gamma, rcut)] + [PolyPadeFunction(b, rcut) for b in expand_beta_qwalk(beta_b, nb)]

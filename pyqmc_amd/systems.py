@@ -111,6 +111,28 @@ class Mol:
         return int(sum(sum(2 * sh[0] + 1 for sh in self._basis[n]) for n in self._names))
 
 
+class Cell(Mol):
+    """Duck-typed stand-in for the subset of ``pyscf.pbc.gto.Cell`` the hot path reads: ``Mol`` plus the
+    lattice (``a``, ``lattice_vectors()``, ``reciprocal_vectors()``, ``vol``; rows are lattice vectors in
+    bohr).  ``hasattr(cell, "a")`` is what switches the reference to ``PeriodicConfigs``/Ewald
+    (``mc.py:69``, ``accumulators.py:52``, ``wftools.py:82-83``)."""
+
+    def __init__(self, symbols, coords_bohr, a, **kw):
+        super().__init__(symbols, coords_bohr, **kw)
+        self.a = np.asarray(a, dtype=float).reshape(3, 3)
+        self.dimension = 3
+
+    def lattice_vectors(self):
+        return self.a
+
+    def reciprocal_vectors(self):
+        return 2 * np.pi * np.linalg.inv(self.a).T
+
+    @property
+    def vol(self):
+        return float(abs(np.linalg.det(self.a)))
+
+
 class MeanField:
     """Duck-typed UHF-like container (``mo_coeff (2,nao,nmo)``, ``mo_occ (2,nmo)``)."""
 
@@ -152,6 +174,27 @@ def helium():
 
 def carbon_dimer(r=2.35):
     return Mol(["C", "C"], [(0.0, 0.0, 0.0), (0.0, 0.0, r)])
+
+
+_DIAMOND_A = 3.5668 / 0.529177210903  # conventional cubic lattice constant, bohr (benchmarks/c_solid_benchmark.py)
+_DIAMOND_FRAC = [(0, 0, 0), (0, .5, .5), (.5, 0, .5), (.5, .5, 0),
+                 (.25, .25, .25), (.25, .75, .75), (.75, .25, .75), (.75, .75, .25)]
+
+
+def diamond_cubic(n=1):
+    """Diamond, conventional cubic cell repeated n x n x n (8 n^3 C atoms, 32 n^3 valence electrons) —
+    the shape of BASELINE.json's C3 (``benchmarks/c_solid_benchmark.py``).  Diagonal lattice."""
+    a = _DIAMOND_A
+    xyz = [(np.array(f) + np.array([i, j, k])) * a for i in range(n) for j in range(n) for k in range(n)
+           for f in _DIAMOND_FRAC]
+    return Cell(["C"] * len(xyz), xyz, np.eye(3) * a * n)
+
+
+def diamond_primitive():
+    """Diamond primitive (fcc) cell: 2 C atoms, 8 valence electrons, non-orthogonal lattice vectors."""
+    a = _DIAMOND_A
+    lat = 0.5 * a * np.array([[0., 1., 1.], [1., 0., 1.], [1., 1., 0.]])
+    return Cell(["C", "C"], [(0, 0, 0), (a / 4, a / 4, a / 4)], lat)
 
 
 def random_mf(mol, seed=20260928, nvirt=0, scale_virtual=1.0):
@@ -202,7 +245,7 @@ def random_determinants(mol, mf, ndet, seed=7):
 def initial_guess(mol, nconfig, r=1.0, rng=None):
     """Electrons near atoms in proportion to charge — semantics of ``mc.initial_guess``
     (``pyqmc/method/mc.py:25-73``), with an explicit generator instead of the global one."""
-    from pyqmc_amd.configs import OpenConfigs
+    from pyqmc_amd.configs import OpenConfigs, PeriodicConfigs
 
     rng = np.random.default_rng(1234) if rng is None else rng
     epos = np.zeros((nconfig, int(np.sum(mol.nelec)), 3))
@@ -217,4 +260,6 @@ def initial_guess(mol, nconfig, r=1.0, rng=None):
             inds = np.argpartition(rng.random((nconfig, len(wts))), totleft, axis=1)[:, :totleft]
             epos[:, ind0 + nassigned : ind0 + mol.nelec[s], :] = mol.atom_coords()[inds]
     epos += r * rng.standard_normal(epos.shape)
+    if hasattr(mol, "a"):  # mc.py:69-72
+        return PeriodicConfigs(epos, mol.lattice_vectors())
     return OpenConfigs(epos)

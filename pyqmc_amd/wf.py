@@ -109,6 +109,15 @@ class DeviceWF:
             seti(k, et[k])
         setd("ecp_term_exp", et["ecp_term_exp"])
         setd("ecp_term_coef", et["ecp_term_coef"])
+        self.pbc = hasattr(mol, "a")
+        if self.pbc:
+            from .configs import MinimalImageDistance
+
+            lat = np.asarray(mol.lattice_vectors(), dtype=float)
+            s.pbc = 2 if MinimalImageDistance(lat).kind == "general" else 1
+            s.lattice[:] = list(lat.ravel())
+            if self.has_slater:
+                raise NotImplementedError("periodic Slater determinants (lattice-summed orbitals) are not implemented yet")
         self._struct = s
         self._h = C.c_void_p()
         lib = _ffi.lib()
@@ -570,6 +579,43 @@ class MultiplyWF:
             for j in range(i + 1, len(g)):
                 cross += np.sum(g[i] * g[j], axis=0)
         return np.sum(g, axis=0), np.sum(l, axis=0) + 2 * cross
+
+
+def _ion_cusp_list(mol, ion_cusp):
+    if ion_cusp is None:
+        charges = mol.atom_charges()
+        return [mol.atom_symbol(i) for i in range(mol.natm) if mol.atom_symbol(i) not in mol._ecp and charges[i] > 0]
+    if ion_cusp is True:
+        return [mol.atom_symbol(i) for i in range(mol.natm)]
+    return [] if ion_cusp is False else list(ion_cusp)
+
+
+def generate_jastrow(mol, ion_cusp=None, device=0, **kws):
+    """Stand-alone two-body Jastrow factor with the defaults of ``wftools.generate_jastrow`` (wftools.py:99-152).
+    Returns (jastrow, to_opt)."""
+    ion_cusp = _ion_cusp_list(mol, ion_cusp)
+    abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
+    ja = JastrowSpin(mol, abasis, bbasis, device=device)
+    acoeff = np.zeros((mol.natm, len(abasis), 2))
+    if ion_cusp:
+        coefs = np.array(mol.atom_charges(), dtype=float)
+        coefs[[mol.atom_symbol(i) not in ion_cusp for i in range(mol.natm)]] = 0.0
+        acoeff[:, 0, :] = coefs[:, None]
+    bcoeff = np.zeros((len(bbasis), 3))
+    bcoeff[0] = [-0.25, -0.5, -0.25]
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = acoeff, bcoeff
+    to_opt = {"acoeff": np.ones(acoeff.shape, dtype=bool), "bcoeff": np.ones(bcoeff.shape, dtype=bool)}
+    if ion_cusp:
+        to_opt["acoeff"][:, 0, :] = False
+    to_opt["bcoeff"][0, [0, 1, 2]] = False
+    return ja, to_opt
+
+
+def generate_jastrow3(mol, device=0, **kws):
+    """``wftools.generate_jastrow3`` (wftools.py:155-162): default radial bases without ion cusp, zero ccoeff."""
+    a3, b3 = func3d.default_jastrow_basis(mol, False, **kws)
+    j3 = ThreeBodyJastrow(mol, a3, b3, device=device)
+    return j3, {"ccoeff": np.ones(j3.parameters["ccoeff"].shape, dtype=bool)}
 
 
 def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None, jastrow3=False, jastrow3_kws=None):

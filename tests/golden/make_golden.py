@@ -417,6 +417,115 @@ def g_jastrow3():
     save("g7_jastrow3_multidet", **out)
 
 
+
+# ------------------------------------------------------------------ G13 periodic containers, minimal image, PBC Jastrow
+def pbc_protocol(prefix, cell, names, W, seed, electrons, out, update_first=False, naip=6):
+    """protocol_dump for wave-function factors living on PeriodicConfigs.  ``update_first``: see the NOTE in
+    g_jastrow3 (needed whenever a ThreeBodyJastrow is among the factors)."""
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    rng = np.random.default_rng(seed)
+    start = systems.initial_guess(cell, W, rng=np.random.default_rng(seed)).configs
+    configs = PeriodicConfigs(start.copy(), cell.lattice_vectors())
+    out[prefix + "configs"], out[prefix + "wrap"] = configs.configs.copy(), configs.wrap.copy()
+    for nm, w in names.items():
+        out[f"{prefix}{nm}_recompute_sign"], out[f"{prefix}{nm}_recompute_log"] = w.recompute(configs)
+    out[prefix + "electrons"] = np.asarray(electrons)
+    top = list(names.values())[-1]
+    for e in electrons:
+        newpos = configs.configs[:, e, :] + 0.6 * rng.standard_normal((W, 3))
+        aux = configs.configs[:, e, None, :] + 0.8 * rng.standard_normal((W, naip, 3))
+        mask = rng.random(W) > 0.35
+        mask[0] = True
+        accept = rng.random(W) > 0.4
+        out[f"{prefix}e{e}_newpos"], out[f"{prefix}e{e}_aux"] = newpos, aux
+        out[f"{prefix}e{e}_mask"], out[f"{prefix}e{e}_accept"] = mask, accept
+        ep = configs.make_irreducible(e, newpos)
+        ea = configs.make_irreducible(e, aux, mask)
+        out[f"{prefix}e{e}_ep_configs"], out[f"{prefix}e{e}_ep_wrap"] = ep.configs.copy(), ep.wrap.copy()
+        out[f"{prefix}e{e}_ea_configs"], out[f"{prefix}e{e}_ea_wrap"] = ea.configs.copy(), ea.wrap.copy()
+        for nm, w in names.items():
+            p = f"{prefix}e{e}_{nm}_"
+            g, v, _ = w.gradient_value(e, ep)
+            out[p + "gv_grad"], out[p + "gv_val"] = g, v
+            out[p + "grad"] = w.gradient(e, ep)
+            g, l = w.gradient_laplacian(e, ep)
+            out[p + "gl_grad"], out[p + "gl_lap"] = g, l
+            g, l = w.gradient_laplacian(e, configs.electron(e))
+            out[p + "gl0_grad"], out[p + "gl0_lap"] = g, l
+            out[p + "testvalue"] = w.testvalue(e, ep)[0]
+            out[p + "testvalue_mask"] = w.testvalue(e, ep, mask)[0]
+            out[p + "testvalue_aux"] = w.testvalue(e, ea, mask)[0]
+        if update_first:
+            top.updateinternals(e, ep, configs, mask=accept)
+            configs.move(e, ep, accept)
+        else:
+            configs.move(e, ep, accept)
+            top.updateinternals(e, ep, configs, mask=accept)
+        for nm, w in names.items():
+            out[f"{prefix}e{e}_{nm}_post_sign"], out[f"{prefix}e{e}_{nm}_post_log"] = w.value()
+    out[prefix + "final_configs"], out[prefix + "final_wrap"] = configs.configs.copy(), configs.wrap.copy()
+    for nm, w in names.items():
+        out[f"{prefix}{nm}_final_recompute_sign"], out[f"{prefix}{nm}_final_recompute_log"] = w.recompute(configs)
+
+
+def g_pbc():
+    import pyqmc.wftools as wftools
+    from pyqmc.configurations.coord import PeriodicConfigs
+    from pyqmc.configurations.distance import MinimalImageDistance
+    from pyqmc.pbc.pbc import enforce_pbc
+
+    out = {}
+    # the known-answer table of the reference's tests/unit/test_pbcs.py:19-72 (inputs only; outputs from the call)
+    tri = np.array([[1.2, 0, 0], [0.6, 1.2 * np.sqrt(3) / 2, 0], [0, 0, 0.8]])
+    trans = np.array([[0.1, 0.1, 0.1], [1.3, 0, 0.2], [0.9, 1.8 * np.sqrt(3) / 2, 0], [0, 0, 1.1],
+                      [2.34, 1.35099963, 0], [0.48, 1.24707658, 0], [-2.52, 2.28630707, -0.32]]) + 1e-14
+    out["tri_lat"], out["tri_in"] = tri, trans
+    out["tri_pos"], out["tri_wrap"] = enforce_pbc(tri, trans)
+    rng = np.random.default_rng(131)
+    rot = scipy.spatial.transform.Rotation.from_rotvec([0.3, -0.5, 0.4]).as_matrix()
+    lats = {"diag": np.diag([2.0, 3.0, 4.0]), "ortho": np.diag([2.0, 3.0, 4.0]) @ rot,
+            "general": systems.diamond_primitive().lattice_vectors(), "tri": tri}
+    for tag, lat in lats.items():
+        x = rng.standard_normal((5, 6, 3)) * 3.0
+        pos, wrap = enforce_pbc(lat, x)
+        mid = MinimalImageDistance(lat)
+        vec = pos[:, 0] + 0.7 * rng.standard_normal((5, 3))
+        out[f"mi_{tag}_lat"], out[f"mi_{tag}_x"], out[f"mi_{tag}_pos"], out[f"mi_{tag}_wrap"] = lat, x, pos, wrap
+        out[f"mi_{tag}_vec"] = vec
+        out[f"mi_{tag}_dist_i"] = mid.dist_i(pos, vec)
+        out[f"mi_{tag}_dist_matrix"] = mid.dist_matrix(pos)[0]
+        out[f"mi_{tag}_pairwise"] = mid.pairwise(pos[:, :2], pos[:, 2:])
+        cfg = PeriodicConfigs(x.copy(), lat)
+        aux = x[:, 1, None, :] + rng.standard_normal((5, 4, 3))
+        m = rng.random((5, 4)) > 0.3
+        el = cfg.make_irreducible(1, aux, m)
+        out[f"mi_{tag}_aux"], out[f"mi_{tag}_auxmask"] = aux, m
+        out[f"mi_{tag}_aux_pos"], out[f"mi_{tag}_aux_wrap"] = el.configs, el.wrap
+    save("g13_pbc", **out)
+
+    # Jastrow factors under PBC: cubic diamond (diagonal lattice, default rcut = min pi/|b_i|, wftools.py:82-83) and
+    # the primitive fcc cell (27-image rule) with a cut-off beyond half the plane spacing
+    out = {}
+    for tag, cell, W, electrons, kws in (("cubic", systems.diamond_cubic(), 4, [0, 9, 16, 31], {}),
+                                         ("prim", systems.diamond_primitive(), 6, [0, 3, 4, 7], {"rcut": 4.0})):
+        rng = np.random.default_rng(17)
+        j2, _ = wftools.generate_jastrow(cell, **kws)
+        j2.parameters["acoeff"] = 0.05 * rng.standard_normal(j2.parameters["acoeff"].shape)
+        b = 0.05 * rng.standard_normal(j2.parameters["bcoeff"].shape)
+        b[0] = [-0.25, -0.5, -0.25]
+        j2.parameters["bcoeff"] = b
+        out[f"{tag}_acoeff"], out[f"{tag}_bcoeff"] = j2.parameters["acoeff"], j2.parameters["bcoeff"]
+        out[f"{tag}_rcut"] = np.asarray(j2.a_basis.rcut)
+        pbc_protocol(f"{tag}_", cell, {"jastrow": j2}, W, 41, electrons, out)
+    cell = systems.diamond_primitive()
+    j3, _ = wftools.generate_jastrow3(cell, rcut=3.0)
+    j3.parameters["ccoeff"] = 0.1 * np.random.default_rng(12).standard_normal(j3.parameters["ccoeff"].shape)
+    out["prim3_ccoeff"] = j3.parameters["ccoeff"].copy()
+    pbc_protocol("prim3_", cell, {"j3": j3}, 5, 43, [1, 6], out, update_first=True)
+    save("g14_pbc_jastrow", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -494,3 +603,4 @@ if __name__ == "__main__":
     g_vmc()
     g_jastrow3()
     g_dmc()
+    g_pbc()

@@ -190,3 +190,63 @@ def run_protocol3(wf, g):
     for nm, w in names.items():
         err[f"{nm}_final_recompute_log"] = relerr(w.recompute(configs)[1], g[f"{nm}_final_recompute_log"])
     return err
+
+
+def run_protocol_pbc(names, g, prefix, cell, update_first=False):
+    """Replay make_golden.pbc_protocol on wave-function factors (oracle or HIP) living on PeriodicConfigs.
+    ``names``: {golden name: factor}; the last one receives updateinternals.  Also checks the container itself
+    (folded positions and wrap counters of make_irreducible / move) against the reference's."""
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    configs = PeriodicConfigs(g[prefix + "configs"].copy(), cell.lattice_vectors(), wrap=g[prefix + "wrap"].copy())
+    err = {}
+    for nm, w in names.items():
+        s, l = w.recompute(configs)
+        err[f"{nm}_recompute_log"] = relerr(l, g[f"{prefix}{nm}_recompute_log"])
+        err[f"{nm}_recompute_sign"] = relerr(s, g[f"{prefix}{nm}_recompute_sign"])
+    top = list(names.values())[-1]
+    for e in g[prefix + "electrons"]:
+        e = int(e)
+        q = f"{prefix}e{e}_"
+        mask, accept = g[q + "mask"], g[q + "accept"]
+        ep = configs.make_irreducible(e, g[q + "newpos"])
+        ea = configs.make_irreducible(e, g[q + "aux"], mask)
+        err[f"e{e}_container"] = max(relerr(ep.configs, g[q + "ep_configs"]), relerr(ep.wrap, g[q + "ep_wrap"]),
+                                     relerr(ea.configs, g[q + "ea_configs"]), relerr(ea.wrap, g[q + "ea_wrap"]))
+        for nm, w in names.items():
+            p = f"{q}{nm}_"
+            o = f"e{e}_{nm}_"
+            gr, v, _ = w.gradient_value(e, ep)
+            err[o + "gv_grad"], err[o + "gv_val"] = relerr(gr, g[p + "gv_grad"]), relerr(v, g[p + "gv_val"])
+            err[o + "grad"] = relerr(w.gradient(e, ep), g[p + "grad"])
+            gr, l = w.gradient_laplacian(e, ep)
+            err[o + "gl_grad"], err[o + "gl_lap"] = relerr(gr, g[p + "gl_grad"]), relerr(l, g[p + "gl_lap"])
+            gr, l = w.gradient_laplacian(e, configs.electron(e))
+            err[o + "gl0_grad"], err[o + "gl0_lap"] = relerr(gr, g[p + "gl0_grad"]), relerr(l, g[p + "gl0_lap"])
+            err[o + "testvalue"] = relerr(w.testvalue(e, ep)[0], g[p + "testvalue"])
+            err[o + "testvalue_mask"] = relerr(w.testvalue(e, ep, mask)[0], g[p + "testvalue_mask"])
+            err[o + "testvalue_aux"] = relerr(w.testvalue(e, ea, mask)[0], g[p + "testvalue_aux"])
+        if update_first:
+            top.updateinternals(e, ep, configs, mask=accept)
+            configs.move(e, ep, accept)
+        else:
+            configs.move(e, ep, accept)
+            top.updateinternals(e, ep, configs, mask=accept)
+        for nm, w in names.items():
+            s, l = w.value()
+            err[f"e{e}_{nm}_post_log"] = relerr(l, g[f"{q}{nm}_post_log"])
+    err["final_container"] = max(relerr(configs.configs, g[prefix + "final_configs"]), relerr(configs.wrap, g[prefix + "final_wrap"]))
+    for nm, w in names.items():
+        err[f"{nm}_final_recompute_log"] = relerr(w.recompute(configs)[1], g[f"{prefix}{nm}_final_recompute_log"])
+    return err
+
+
+PBC_JASTROW_CASES = {"cubic": (systems.diamond_cubic, {}), "prim": (systems.diamond_primitive, {"rcut": 4.0})}
+
+
+def pbc_jastrow_coeffs(cell, nb=4, na=4):
+    rng = np.random.default_rng(17)
+    a = 0.05 * rng.standard_normal((cell.natm, na, 2))
+    b = 0.05 * rng.standard_normal((nb, 3))
+    b[0] = [-0.25, -0.5, -0.25]
+    return a, b

@@ -1,0 +1,114 @@
+"""Periodic containers / minimal image (host boundary types and the oracle restatement) against outputs of the
+real reference (tests/golden/g13_pbc.npz, g14_pbc_jastrow.npz; generator tests/golden/make_golden.py:g_pbc).
+g13 includes the inputs of the reference's own known-answer test tests/unit/test_pbcs.py:19-72."""
+
+import numpy as np
+import pytest
+
+from helpers import PBC_JASTROW_CASES, golden, pbc_jastrow_coeffs, relerr, run_protocol_pbc
+from pyqmc_amd import configs as pc
+from pyqmc_amd import systems
+
+
+@pytest.mark.parametrize("impl", ["host", "oracle"])
+def test_enforce_pbc_known_answers(impl):
+    from oracle import pbc as opbc
+
+    f = pc.enforce_pbc if impl == "host" else opbc.enforce_pbc
+    g = golden("g13_pbc")
+    pos, wrap = f(g["tri_lat"], g["tri_in"])
+    # the table the reference's test asserts (test_pbcs.py:42-58), restated as data
+    s3 = np.sqrt(3) / 2
+    table_pos = np.array([[0.1, 0.1, 0.1], [0.1, 0, 0.2], [0.3, 0.6 * s3, 0.0], [0, 0, 0.3], [0.54, 0.31176915, 0],
+                          [1.08, 0.2078461, 0], [1.08, 0.2078461, 0.48]]) + 1e-14
+    table_wrap = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [-1, 1, 0], [-4, 2, -1]])
+    assert np.allclose(pos, table_pos, rtol=1e-8, atol=1e-8) and np.allclose(wrap, table_wrap, atol=1e-8)
+    assert relerr(pos, g["tri_pos"]) < 1e-15 and np.array_equal(wrap, g["tri_wrap"])
+    for tag in ("diag", "ortho", "general", "tri"):
+        pos, wrap = f(g[f"mi_{tag}_lat"], g[f"mi_{tag}_x"])
+        assert relerr(pos, g[f"mi_{tag}_pos"]) < 1e-15 and np.array_equal(wrap, g[f"mi_{tag}_wrap"])
+        frac = pos @ np.linalg.inv(g[f"mi_{tag}_lat"])
+        assert np.all(frac >= -1e-14) and np.all(frac < 1 + 1e-14)  # test_pbcs.py:75-95
+
+
+@pytest.mark.parametrize("tag,kind", [("diag", "diagonal"), ("ortho", "orthogonal"), ("general", "general"), ("tri", "general")])
+def test_minimal_image_distance(tag, kind):
+    from oracle import pbc as opbc
+
+    g = golden("g13_pbc")
+    lat, pos, vec = g[f"mi_{tag}_lat"], g[f"mi_{tag}_pos"], g[f"mi_{tag}_vec"]
+    mid = pc.MinimalImageDistance(lat)
+    assert mid.kind == kind == opbc.lattice_kind(lat)
+    assert relerr(mid.dist_i(pos, vec), g[f"mi_{tag}_dist_i"]) < 1e-14
+    assert relerr(mid.dist_matrix(pos)[0], g[f"mi_{tag}_dist_matrix"]) < 1e-14
+    assert relerr(mid.pairwise(pos[:, :2], pos[:, 2:]), g[f"mi_{tag}_pairwise"]) < 1e-14
+    mi = opbc.minimal_image(lat)
+    assert relerr(mi(vec[:, None, :] - pos), g[f"mi_{tag}_dist_i"]) < 1e-14
+    # general and folded rules agree where both apply (the reference's tests/unit/test_minimal_image.py:29-62)
+    if kind != "general":
+        gen = pc.MinimalImageDistance(lat)
+        gen.kind = "general"
+        assert relerr(gen.dist_i(pos, vec), g[f"mi_{tag}_dist_i"]) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["diag", "ortho", "general", "tri"])
+def test_periodic_configs_container(tag):
+    g = golden("g13_pbc")
+    lat, x = g[f"mi_{tag}_lat"], g[f"mi_{tag}_x"]
+    cfg = pc.PeriodicConfigs(x.copy(), lat)
+    assert relerr(cfg.configs, g[f"mi_{tag}_pos"]) < 1e-15 and np.array_equal(cfg.wrap, g[f"mi_{tag}_wrap"])
+    el = cfg.make_irreducible(1, g[f"mi_{tag}_aux"], g[f"mi_{tag}_auxmask"])
+    assert relerr(el.configs, g[f"mi_{tag}_aux_pos"]) < 1e-15 and np.array_equal(el.wrap, g[f"mi_{tag}_aux_wrap"])
+    # unfolding with the wrap counters recovers the original coordinates
+    assert np.allclose(cfg.configs + cfg.wrap @ lat, x, atol=1e-12)
+    # split / join / resample / electron keep positions and counters together (coord.py:191-222)
+    parts = cfg.split(2)
+    back = cfg.copy()
+    back.join(parts)
+    # (split re-folds through the constructor like the reference, coord.py:210-214: equal to rounding)
+    assert np.allclose(back.configs, cfg.configs, atol=1e-14) and np.array_equal(back.wrap, cfg.wrap)
+    back.resample(np.array([4, 4, 0, 1, 2]))
+    assert np.array_equal(back.wrap[0], cfg.wrap[4]) and np.allclose(back.configs[2], cfg.configs[0], atol=1e-14)
+    e = cfg.electron(3)
+    assert np.array_equal(e.configs, cfg.configs[:, 3]) and np.array_equal(e.wrap, cfg.wrap[:, 3])
+    acc = np.array([True, False, True, False, True])
+    new = cfg.make_irreducible(3, cfg.configs[:, 3] + 5.0)
+    cfg.move(3, new, acc)
+    assert np.array_equal(cfg.configs[acc, 3], new.configs[acc]) and np.array_equal(cfg.wrap[~acc, 3], g[f"mi_{tag}_wrap"][~acc, 3])
+
+
+def test_initial_guess_periodic():
+    cell = systems.diamond_cubic()
+    cfg = systems.initial_guess(cell, 7)
+    assert isinstance(cfg, pc.PeriodicConfigs) and cfg.configs.shape == (7, 32, 3)
+    frac = cfg.configs @ np.linalg.inv(cell.lattice_vectors())
+    assert np.all(frac >= 0) and np.all(frac < 1)
+
+
+@pytest.mark.parametrize("tag", ["cubic", "prim"])
+def test_oracle_periodic_jastrow_matches_reference(tag):
+    from oracle import jastrow_basis, wf as owf
+
+    g = golden("g14_pbc_jastrow")
+    make, kws = PBC_JASTROW_CASES[tag]
+    cell = make()
+    rcut = kws.get("rcut", float(np.amin(np.pi / np.linalg.norm(cell.reciprocal_vectors(), axis=1))))
+    assert abs(rcut - float(g[f"{tag}_rcut"])) < 1e-14
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(cell, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(cell)
+    assert np.array_equal(ja.parameters["acoeff"], g[f"{tag}_acoeff"])
+    err = run_protocol_pbc({"jastrow": ja}, g, f"{tag}_", cell)
+    assert max(err.values()) < 1e-11, {k: v for k, v in err.items() if v > 1e-12}
+
+
+def test_oracle_periodic_three_body_matches_reference():
+    from oracle import jastrow_basis, wf as owf
+
+    g = golden("g14_pbc_jastrow")
+    cell = systems.diamond_primitive()
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=3.0)
+    j3 = owf.ThreeBodyJastrow(cell, ab, bb, rcut)
+    j3.parameters["ccoeff"] = g["prim3_ccoeff"]
+    err = run_protocol_pbc({"j3": j3}, g, "prim3_", cell, update_first=True)
+    assert max(err.values()) < 1e-10, {k: v for k, v in err.items() if v > 1e-11}
