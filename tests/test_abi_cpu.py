@@ -40,7 +40,7 @@ def test_struct_layout_matches_header():
         if not decl:
             continue
         names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
-        fields += [n.strip().lstrip("*") for n in names.split(",")]
+        fields += [re.sub(r"\[\d+\]$", "", n.strip().lstrip("*")) for n in names.split(",")]
     assert fields == [f[0] for f in _ffi.SystemStruct._fields_]
 
 
