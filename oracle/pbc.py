@@ -47,3 +47,126 @@ def minimal_image(latvec):
         return np.take_along_axis(cand, best[None, ..., None], axis=0)[0]
 
     return f
+
+
+# ------------------------------------------------------------------------------------ periodic orbitals
+# Restatement of the reference's in-repo periodic GTO evaluator and k-point MO evaluator:
+#   cut-offs            max_Ls                         pyqmc/wf/numba/pbcgto.py:549-591
+#   lattice-summed AOs  _pbc_eval_gto(_grad,_lap)      pbcgto.py:99-506   (r2 > atom cut: skip image; per-shell cut)
+#   Bloch phases        phases = exp(i Ls.k)           pbcgto.py:620
+#   k-point wrapper     PBCOrbitalEvaluatorKpoints     pyqmc/wf/orbitals.py:118-255 (fold into the primitive cell,
+#                       wrap phase (-1)^round(k.R/pi) :34-35,203-213, per-k MO blocks :221-239)
+# Pinned by tests/golden/g15_pbc_orbitals.npz (outputs of those reference functions, make_golden.py:g_pbc_slater).
+# Only real Bloch phases (k-points with e^{ik.L} = +-1) and zero supercell twist are restated.
+
+
+def max_distance_in_cell(lvecs):
+    combos = np.array([[1.0, 1.0, 1.0], [-1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 1.0, -1.0]])
+    vecs = combos @ lvecs
+    return vecs[np.argmax(np.sum(vecs**2, axis=-1))] / 2
+
+
+def gto_cutoffs(table, Ls, lvecs, expcutoff):
+    """(num_Ls per atom, r^2 cut per atom, r^2 cut per shell) — pbcgto.py:549-591.  ``table``: oracle.gto.AOTable."""
+    natom = len(table.coords)
+    v = max_distance_in_cell(lvecs)
+    r2 = np.sum((v - Ls) ** 2, axis=-1)
+    num, acut, lcut = np.ones(natom, dtype=int), np.zeros(natom), np.zeros(len(table.shells))
+    num[:] = 0
+    for i, (ia, l, exps, coefs, off) in enumerate(table.shells):
+        log_c = np.log(np.abs(coefs))
+        if l == 0:
+            lcut[i] = np.amax((expcutoff + log_c) / exps)
+        else:
+            lconst = 0.5 * np.log(0.5 * l / np.amin(exps)) * l
+            lcut[i] = np.amax((expcutoff + log_c + lconst) / exps)
+        acut[ia] = max(acut[ia], lcut[i])
+        with np.errstate(divide="ignore"):
+            min_exp = np.amin(exps[None, :] * r2[:, None] - log_c[None, :] - 0.5 * np.log(r2)[:, None] * l, axis=1)
+        where = np.where(min_exp < expcutoff)[0]
+        num[ia] = max(num[ia], where.max() + 1 if len(where) else 1)
+    return num, acut, lcut
+
+
+class PeriodicAOTable:
+    """Primitive-cell AO tables + sorted lattice translations + cut-offs (PeriodicAtomicOrbitalEvaluator,
+    pbcgto.py:594-636).  ``Ls`` must already be sorted by norm (:603)."""
+
+    def __init__(self, cell, kpts, Ls, precision=1e-2):
+        from . import gto
+
+        self.table = gto.AOTable(cell)
+        self.kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+        self.Ls = np.asarray(Ls, dtype=float)
+        self.num_Ls, self.atom_cut, self.shell_cut = gto_cutoffs(self.table, self.Ls, cell.lattice_vectors(),
+                                                                 -3.5 * np.log(precision))
+        ph = np.exp(1j * self.Ls @ self.kpts.T)
+        if np.abs(ph.imag).max() > 1e-9:
+            raise NotImplementedError("complex Bloch phases are not restated yet")
+        self.phases = ph.real
+
+
+def eval_ao_pbc(pt, pts, ncomp):
+    """(nk, ncomp, npts, nao) lattice-summed AOs at points inside the primitive cell."""
+    from . import gto
+
+    t = pt.table
+    pts = np.asarray(pts, dtype=float).reshape(-1, 3)
+    out = np.zeros((len(pt.kpts), ncomp, len(pts), t.nao))
+    deriv = ncomp > 1
+    for ia in range(len(t.coords)):
+        shells = [(i, s) for i, s in enumerate(t.shells) if s[0] == ia]
+        for j in range(pt.num_Ls[ia]):
+            v = pts - t.coords[ia] - pt.Ls[j]
+            r2 = np.sum(v * v, axis=1)
+            keep = ~(r2 > pt.atom_cut[ia])
+            if not keep.any():
+                continue
+            vk, r2k = v[keep], r2[keep]
+            S, dS = gto.solid_harmonics(vk, t.max_l, deriv)
+            for i, (_, l, exps, coefs, off) in shells:
+                sel = r2k < pt.shell_cut[i] if ncomp == 1 else ~(r2k > pt.shell_cut[i])  # pbcgto.py:254 vs :356
+                if not sel.any():
+                    continue
+                prim = np.exp(-r2k[sel, None] * exps[None, :]) * coefs[None, :]
+                R = prim.sum(axis=1)
+                sl = slice(l * l, (l + 1) * (l + 1))
+                val = np.zeros((ncomp, sel.sum(), 2 * l + 1))
+                val[0] = S[sel][:, sl] * R[:, None]
+                if deriv:
+                    dR = -(2.0 * (prim * exps[None, :]).sum(axis=1))[:, None] * vk[sel]
+                    for c in range(3):
+                        val[1 + c] = dS[sel][:, sl, c] * R[:, None] + S[sel][:, sl] * dR[:, c : c + 1]
+                if ncomp == 5:
+                    lapR = (prim * (2.0 * exps[None, :]) * (2.0 * exps[None, :] * r2k[sel, None] - 3.0)).sum(axis=1)
+                    val[4] = S[sel][:, sl] * lapR[:, None] + 2.0 * np.einsum("pmi,pi->pm", dS[sel][:, sl, :], dR)
+                idx = np.nonzero(keep)[0][sel]
+                for k in range(len(pt.kpts)):
+                    out[k][:, idx, off : off + 2 * l + 1] += pt.phases[j, k] * val
+    return out
+
+
+class PeriodicOrbitals:
+    """MO evaluator for a supercell built from k-points of a primitive cell (orbitals.py:118-255).
+    mo_coeff[s][k]: (nao_prim, nmo_k); MO columns of a spin are the k blocks concatenated (:154-160)."""
+
+    def __init__(self, supercell, kpts, mo_coeff, Ls, precision=1e-2):
+        self.prim = supercell.original_cell
+        self.S = np.asarray(supercell.S, dtype=float)
+        self.Lprim = self.prim.lattice_vectors()
+        self.aotab = PeriodicAOTable(self.prim, kpts, Ls, precision)
+        self.kpts = self.aotab.kpts
+        self.mo = [[np.asarray(m, dtype=float) for m in mo_coeff[s]] for s in (0, 1)]
+        twist = self.kpts @ (self.S @ self.Lprim).T / (2 * np.pi)
+        if np.abs(twist - np.round(twist)).max() > 1e-9:
+            raise NotImplementedError("non-zero supercell twist needs the walkers' wrap counters (not restated yet)")
+
+    def aos(self, pts, ncomp):
+        pts = np.asarray(pts, dtype=float).reshape(-1, 3)
+        prim_pts, primwrap = enforce_pbc(self.Lprim, pts)
+        ao = eval_ao_pbc(self.aotab, prim_pts, ncomp)
+        kdotR = self.kpts @ self.Lprim.T @ primwrap.T  # (nk, npts); zero twist: the supercell wrap drops out
+        return ao * ((-1.0) ** np.round(kdotR / np.pi))[:, None, :, None]
+
+    def mos(self, ao, s):
+        return np.concatenate([ao[k] @ self.mo[s][k] for k in range(len(self.kpts))], axis=-1)

@@ -51,12 +51,26 @@ class Slater:
         }
         self.dtype = float
 
+    @classmethod
+    def periodic(cls, supercell, kpts, mo_coeff, Ls, determinants=None, precision=1e-2):
+        """Slater determinant of Bloch orbitals (slater.py:181-225 with PBCOrbitalEvaluatorKpoints).  mo_coeff[s][k]
+        (nao_prim, nmo_k); determinants index the k-concatenated MO list (determinant_tools.flatten_determinants)."""
+        from .pbc import PeriodicOrbitals
+
+        orb = PeriodicOrbitals(supercell, kpts, mo_coeff, Ls, precision)
+        self = cls(supercell, [np.concatenate(orb.mo[s], axis=1) for s in (0, 1)], determinants)
+        self._orb = orb  # the MO blocks live in orb.mo; parameters["mo_coeff_*"] are their concatenation (orbitals.py:157-160)
+        return self
+
     # -- helpers ---------------------------------------------------------
     def _spin(self, e):
         s = int(e >= self._nelec[0])
         return s, e - s * self._nelec[0]
 
     def _mo(self, pts, s, ncomp):
+        if getattr(self, "_orb", None) is not None:
+            ao = self._orb.aos(pts, ncomp)
+            return ao, self._orb.mos(ao, s)
         c = self.parameters["mo_coeff_alpha" if s == 0 else "mo_coeff_beta"]
         ao = gto.eval_ao(self.table, pts, ncomp)
         return ao, gto.eval_mo(ao, c)

@@ -41,6 +41,9 @@ class SystemStruct(C.Structure):
         ("a3_kind", c_int32_p), ("a3_param", c_double_p), ("b3_kind", c_int32_p), ("b3_param", c_double_p),
         ("rcut_a3", C.c_double), ("rcut_b3", C.c_double), ("ccoeff", c_double_p),
         ("pbc", C.c_int32), ("lattice", C.c_double * 9),
+        ("nL", C.c_int32), ("Ls", c_double_p), ("num_Ls", c_int32_p), ("atom_cut", c_double_p), ("shell_cut", c_double_p),
+        ("lattice_prim", C.c_double * 9), ("img_n", c_int32_p), ("atom_n", c_int32_p), ("member", C.POINTER(C.c_uint8)),
+        ("member_class", c_int32_p), ("member_M", C.c_int32), ("n_member_class", C.c_int32),
     ]
 
 

@@ -92,6 +92,56 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 #undef EMIT
 }
 
+// Lattice-summed shell (numba/pbcgto.py:205-225, :340-365, :470-506): the shell's functions summed over the images
+// Ls[j], j < num_Ls[atom] of its centre that lie within the atom's and the shell's r^2 cut-offs.  sh / ia / l are
+// wave-uniform at every call site, so the image table is read through the scalar cache and only the distance test
+// diverges between lanes.
+// The point's primitive-cell wrap W = floor(r . inv(lattice_prim)) (enforce_pbc, pbc/pbc.py:37-43), needed by the
+// membership rule only.
+struct PrimWrap { int w0, w1, w2; };
+__device__ __forceinline__ PrimWrap prim_wrap(const SysDev& S, double px, double py, double pz) {
+  PrimWrap w = {0, 0, 0};
+  if (S.member) {
+    w.w0 = (int)floor(px * S.lprim_inv[0] + py * S.lprim_inv[3] + pz * S.lprim_inv[6]);
+    w.w1 = (int)floor(px * S.lprim_inv[1] + py * S.lprim_inv[4] + pz * S.lprim_inv[7]);
+    w.w2 = (int)floor(px * S.lprim_inv[2] + py * S.lprim_inv[5] + pz * S.lprim_inv[8]);
+  }
+  return w;
+}
+
+template <int NCOMP, class Sink>
+__device__ __forceinline__ void shell_eval_pbc(const SysDev& S, int sh, int ia, int l, double x, double y, double z,
+                                               PrimWrap pw, const double* __restrict__ pexp,
+                                               const double* __restrict__ pcoef, int np, Sink&& sink) {
+  double acc[7][NCOMP];
+#pragma unroll
+  for (int m = 0; m < 7; ++m)
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[m][c] = 0.0;
+  const int nimg = S.num_Ls[ia];
+  const double cut = fmin(S.atom_cut[ia], S.shell_cut[sh]);
+  for (int j = 0; j < nimg; ++j) {
+    const double xj = x - S.Ls[3 * j], yj = y - S.Ls[3 * j + 1], zj = z - S.Ls[3 * j + 2];
+    if (xj * xj + yj * yj + zj * zj > cut) continue;
+    if (S.member) {  // would the reference have looked at this image?
+      const int M = S.member_M, side = 2 * M + 1;
+      const int n0 = S.atom_n[3 * ia] + S.img_n[3 * j] - pw.w0 + M;
+      const int n1 = S.atom_n[3 * ia + 1] + S.img_n[3 * j + 1] - pw.w1 + M;
+      const int n2 = S.atom_n[3 * ia + 2] + S.img_n[3 * j + 2] - pw.w2 + M;
+      if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
+      if (!S.member[((size_t)S.member_class[ia] * side + n0) * side * side + n1 * side + n2]) continue;
+    }
+    shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
+      acc[m][0] += v;
+      if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
+      if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
+    });
+  }
+#pragma unroll
+  for (int m = 0; m < 7; ++m)
+    if (m < 2 * l + 1) sink(m, acc[m][0], acc[m][1 % NCOMP], acc[m][2 % NCOMP], acc[m][3 % NCOMP], acc[m][4 % NCOMP]);
+}
+
 // ---------------------------------------------------------------- AO only (test / A-B entry)
 // out (NCOMP, P, nao); one thread per point.
 template <int NCOMP>
@@ -102,14 +152,17 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
   for (int sh = 0; sh < S.nshell; ++sh) {
     const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
     const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
-    shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0,
-                      [&](int m, double v, double gx, double gy, double gz, double lp) {
-                        double* o = out + p * S.nao + ao0 + m;
-                        const long cs = P * (long)S.nao;
-                        o[0] = v;
-                        if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
-                        if (NCOMP == 5) o[4 * cs] = lp;
-                      });
+    auto store = [&](int m, double v, double gx, double gy, double gz, double lp) {
+      double* o = out + p * S.nao + ao0 + m;
+      const long cs = P * (long)S.nao;
+      o[0] = v;
+      if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
+      if (NCOMP == 5) o[4 * cs] = lp;
+    };
+    if (S.nL > 0)
+      shell_eval_pbc<NCOMP>(S, sh, ia, S.shell_l[sh], x, y, z, prim_wrap(S, px, py, pz), S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
+    else
+      shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
   }
 }
 
@@ -148,7 +201,7 @@ struct ChunkTab {
 //  phase 2 (MFMA): TP=64: wave wv owns the 16-point tile wv and all NT orbital tiles;
 //                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
-template <int NCOMP, int NT, int KC, int TP, bool LDSTAB>
+template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, bool PBC = false>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
   constexpr int G = 256 / TP;                         // lane groups in phase 1
@@ -210,7 +263,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     const int s_end = cw_off[ch * G + grp + 1];
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
       const int sh = cw_shell[si];
-      int l_, np_, q0, kb;
+      int l_, np_, q0, kb, ia_ = 0;
       double x, y, z;
       const double *pe, *pc;
       if (LDSTAB) {
@@ -219,18 +272,20 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         pe = pr_exp + q0; pc = pr_coef + q0;
       } else {
         const int ia = S.shell_atom[sh];
+        ia_ = ia;
         q0 = S.shell_prim_off[sh]; kb = S.shell_ao_off[sh] - a0; l_ = S.shell_l[sh]; np_ = S.shell_prim_off[sh + 1] - q0;
         x = px - S.atom_xyz[3 * ia]; y = py - S.atom_xyz[3 * ia + 1]; z = pz - S.atom_xyz[3 * ia + 2];
         pe = S.prim_exp + q0; pc = S.prim_coef + q0;
       }
-      shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_,
-                        [&](int m, double v, double gx, double gy, double gz, double lp) {
-                          const int k = kb + m;
-                          const int col = pl ^ ((k & 1) << 4);
-                          tile[0][k][col] = v;
-                          if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
-                          if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
-                        });
+      auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
+        const int k = kb + m;
+        const int col = pl ^ ((k & 1) << 4);
+        tile[0][k][col] = v;
+        if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
+        if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+      };
+      if (PBC) shell_eval_pbc<NCOMP>(S, sh, ia_, l_, x, y, z, prim_wrap(S, px, py, pz), pe, pc, np_, to_tile);
+      else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
       const int rc = idx / TP;

@@ -290,6 +290,38 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     TRY(upload_table(h, sys->shell_ao_off, (size_t)sys->nshell, &tmp_i)); S.shell_ao_off = tmp_i;
     TRY(upload_table(h, sys->prim_exp, (size_t)sys->nprim, &tmp_d)); S.prim_exp = tmp_d;
     TRY(upload_table(h, sys->prim_coef, (size_t)sys->nprim, &tmp_d)); S.prim_coef = tmp_d;
+    S.nL = 0;
+    if (S.pbc) {
+      if (sys->nL <= 0 || !sys->Ls || !sys->num_Ls || !sys->atom_cut || !sys->shell_cut) FAIL("periodic orbitals need the lattice-sum tables (Ls, num_Ls, atom_cut, shell_cut)");
+      std::vector<int> nl((size_t)h->natom);
+      HIPCHK(hipMemcpy(nl.data(), sys->num_Ls, nl.size() * sizeof(int), hipMemcpyDefault));
+      for (int v : nl)
+        if (v < 1 || v > sys->nL) FAIL("num_Ls out of range");
+      S.nL = sys->nL;
+      TRY(upload_table(h, sys->Ls, (size_t)sys->nL * 3, &tmp_d)); S.Ls = tmp_d;
+      TRY(upload_table(h, sys->num_Ls, (size_t)h->natom, &tmp_i)); S.num_Ls = tmp_i;
+      TRY(upload_table(h, sys->atom_cut, (size_t)h->natom, &tmp_d)); S.atom_cut = tmp_d;
+      TRY(upload_table(h, sys->shell_cut, (size_t)sys->nshell, &tmp_d)); S.shell_cut = tmp_d;
+      S.member = nullptr;
+      if (sys->member) {
+        if (!sys->img_n || !sys->atom_n || !sys->member_class || sys->member_M < 0 || sys->n_member_class < 1) FAIL("incomplete image-membership tables");
+        const double* a = sys->lattice_prim;
+        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+        if (!(fabs(det) > 1e-12)) FAIL("singular primitive lattice");
+        const double id = 1.0 / det;
+        double* v = S.lprim_inv;
+        v[0] = (a[4] * a[8] - a[5] * a[7]) * id; v[1] = (a[2] * a[7] - a[1] * a[8]) * id; v[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+        v[3] = (a[5] * a[6] - a[3] * a[8]) * id; v[4] = (a[0] * a[8] - a[2] * a[6]) * id; v[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+        v[6] = (a[3] * a[7] - a[4] * a[6]) * id; v[7] = (a[1] * a[6] - a[0] * a[7]) * id; v[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+        const size_t side = 2 * (size_t)sys->member_M + 1;
+        unsigned char* tmp_b;
+        TRY(upload_table(h, sys->member, (size_t)sys->n_member_class * side * side * side, &tmp_b)); S.member = tmp_b;
+        TRY(upload_table(h, sys->member_class, (size_t)h->natom, &tmp_i)); S.member_class = tmp_i;
+        TRY(upload_table(h, sys->img_n, (size_t)sys->nL * 3, &tmp_i)); S.img_n = tmp_i;
+        TRY(upload_table(h, sys->atom_n, (size_t)h->natom * 3, &tmp_i)); S.atom_n = tmp_i;
+        S.member_M = sys->member_M;
+      }
+    }
     h->nmo[0] = sys->nmo_up; h->nmo[1] = sys->nmo_dn;
     h->ndet = sys->ndet; h->ndet_s[0] = sys->ndet_up; h->ndet_s[1] = sys->ndet_dn;
     S.ndet = h->ndet;
@@ -486,6 +518,16 @@ static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
   }
 }
+// periodic orbitals: lattice-summed shells, 64-point tiles, tables through the scalar cache
+template <int NCOMP, int KC>
+static void launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+  const dim3 grid((unsigned)((P + 63) / 64)), block(256);
+  switch (h->nt[spin]) {
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+  }
+}
 template <int NCOMP, int KC, int TP>
 static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   if (h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab) launch_orb_t2<NCOMP, KC, TP, true>(h, tabi, spin, pa, P, out);
@@ -516,6 +558,11 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   // measured on MI355X: below ~2 blocks per CU the wave-specialised schedule wins (its
   // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
   const bool want_ws = h->orb_ws < 0 ? (P < (long)64 * 512) : (h->orb_ws != 0);
+  if (h->S.nL > 0) {
+    if (ncomp == 5) launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
+    else if (ncomp == 1) launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
+    else FAIL("orbital kernel supports ncomp 1 or 5");
+  } else
   if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
     if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
     else if (ncomp == 1) launch_orb_ws<1, 32>(h, 1, spin, pa, P, out);

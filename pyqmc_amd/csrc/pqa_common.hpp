@@ -54,6 +54,20 @@ struct SysDev {
   // distance.py:143-159), 2 fold + argmin over the 27 neighbouring cells (distance.py:129-141)
   int pbc;
   double lat[9], linv[9];  // rows = lattice vectors; linv = inverse (frac = d . linv)
+  // periodic Gamma-point orbitals (numba/pbcgto.py:99-653): AO = sum over lattice translations Ls[j], j < num_Ls[atom],
+  // skipping images with r^2 > atom_cut[atom] or r^2 > shell_cut[shell].  nL = 0: open system.
+  int nL;
+  const double* Ls;
+  const int* num_Ls;
+  const double* atom_cut;
+  const double* shell_cut;
+  // reference image-membership rule (see include/pyqmc_amd.h): member == nullptr -> every image inside the cut-offs
+  const unsigned char* member;
+  const int* member_class;
+  const int* img_n;
+  const int* atom_n;
+  int member_M;
+  double lprim_inv[9];
   int necp;
   const int* ecp_atom;
   const int* ecp_chan_off;

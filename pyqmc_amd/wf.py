@@ -25,7 +25,7 @@ class DeviceWF:
     """Owner of one ``pqa_handle_t`` (one walker shard on one GPU)."""
 
     def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1,
-                 a3_basis=None, b3_basis=None):
+                 a3_basis=None, b3_basis=None, eval_gto_precision=None, image_rule="reference"):
         self.mol = mol
         self.nelec = tuple(int(n) for n in mol.nelec)
         self.N = sum(self.nelec)
@@ -117,7 +117,22 @@ class DeviceWF:
             s.pbc = 2 if MinimalImageDistance(lat).kind == "general" else 1
             s.lattice[:] = list(lat.ravel())
             if self.has_slater:
-                raise NotImplementedError("periodic Slater determinants (lattice-summed orbitals) are not implemented yet")
+                from . import pbc as _pbc
+
+                pt = _pbc.periodic_tables(mol, eval_gto_precision, image_rule=image_rule)
+                s.nL = len(pt["Ls"])
+                setd("Ls", pt["Ls"])
+                seti("num_Ls", pt["num_Ls"])
+                setd("atom_cut", pt["atom_cut"])
+                setd("shell_cut", pt["shell_cut"])
+                if pt["member"] is not None:
+                    s.lattice_prim[:] = list(np.asarray(pt["lattice_prim"], dtype=float).ravel())
+                    seti("img_n", pt["img_n"])
+                    seti("atom_n", pt["atom_n"])
+                    seti("member_class", pt["member_class"])
+                    keep["member"] = np.ascontiguousarray(pt["member"], dtype=np.uint8)
+                    s.member = keep["member"].ctypes.data_as(C.POINTER(C.c_uint8))
+                    s.member_M, s.n_member_class = int(pt["member_M"]), int(pt["member"].shape[0])
         self._struct = s
         self._h = C.c_void_p()
         lib = _ffi.lib()
@@ -268,6 +283,46 @@ def _points(epos, mask):
     return pts, widx, aux
 
 
+def orbital_inputs(mol, mf, determinants=None):
+    """(mol, mo_coeff (2)[nao, nmo], determinants) the device is built from — the role of
+    ``pyscftools.orbital_evaluator_from_pyscf`` (pyscftools.py:105-191).  Open systems pass through.  A periodic
+    ``mol`` (a ``pyqmc_amd.pbc.get_supercell`` result, or a plain cell = supercell with S = 1) takes a k-point mean
+    field (``kpts``, ``mo_coeff[s][k]``, ``mo_occ[s][k]``): the orbitals of the k-points that fold onto the
+    supercell's Gamma point are truncated to the used columns per k (:170-173), determinants given per k are
+    flattened onto the k-concatenated MO list (determinant_tools.py:91-104) and the Bloch phases are folded into
+    real supercell coefficients (``pbc.fold_mo_coeff``)."""
+    mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
+    if not hasattr(mol, "a"):
+        return mol, mf.mo_coeff, determinants
+    from . import pbc as _pbc
+
+    if not hasattr(mol, "original_cell"):
+        mol = _pbc.get_supercell(mol, np.eye(3))
+    kpts = np.asarray(mf.kpts, dtype=float).reshape(-1, 3)
+    want = _pbc.get_supercell_kpts(mol)
+    rec = mol.original_cell.reciprocal_vectors()
+
+    def same(k1, k2):
+        d = (k1 - k2) @ np.linalg.inv(rec)
+        return np.abs(d - np.round(d)).max() < 1e-9
+
+    kinds = [next((i for i, k in enumerate(kpts) if same(k, w)), None) for w in want]
+    if any(i is None for i in kinds):
+        raise ValueError(f"the mean field lacks some of the {len(want)} k-points that fold onto the supercell (pyscftools.py:161-166)")
+    if determinants is None:
+        determinants = [(1.0, [[list(np.nonzero(np.asarray(o) > 0.5)[0]) for o in mf.mo_occ[sp]] for sp in (0, 1)])]
+    if len(determinants[0][1][0]) and hasattr(determinants[0][1][0][0], "__len__"):  # per-k occupations
+        max_orb = np.amax([[[int(np.max(k, initial=-1)) + 1 for k in sp] for sp in det] for _, det in determinants], axis=0)
+        offs = np.pad(np.cumsum(max_orb[:, kinds], axis=1)[:, :-1], ((0, 0), (1, 0)))
+        flat = [(wt, [[int(i) + int(offs[sp][ki]) for ki, k in enumerate(kinds) for i in det[sp][k]] for sp in (0, 1)])
+                for wt, det in determinants]
+        mo = [[np.asarray(mf.mo_coeff[sp][k])[:, : max_orb[sp][k]] for k in kinds] for sp in (0, 1)]
+    else:  # already flat: indices into the concatenation of the full per-k blocks
+        flat = determinants
+        mo = [[np.asarray(mf.mo_coeff[sp][k]) for k in kinds] for sp in (0, 1)]
+    return mol, _pbc.fold_mo_coeff(mol, kpts[kinds], mo), flat
+
+
 class Slater:
     """Multi-determinant Slater factor (protocol of ``pyqmc/wf/slater.py:97-460``).
 
@@ -275,13 +330,14 @@ class Slater:
     objects exposing the same attributes); ``determinants`` is the list format of the
     reference's ``determinants=`` argument (slater.py:166-180)."""
 
-    def __init__(self, mol, mf, determinants=None, tol=None, device=0, _dev=None):
+    def __init__(self, mol, mf, determinants=None, tol=None, device=0, eval_gto_precision=None, image_rule="reference",
+                 _dev=None):
+        if _dev is None:
+            mol, mo_coeff, determinants = orbital_inputs(mol, mf, determinants)
+            _dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, device=device,
+                            tol=-1 if tol is None else tol, eval_gto_precision=eval_gto_precision, image_rule=image_rule)
         self._mol = mol
         self._nelec = tuple(mol.nelec)
-        if _dev is None:
-            mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
-            _dev = DeviceWF(mol, mo_coeff=mf.mo_coeff, determinants=determinants, device=device,
-                            tol=-1 if tol is None else tol)
         self._dev = _dev
         self.parameters = _DeviceParams(_dev, {"det_coeff": _dev.det_coeff.copy(),
                                                "mo_coeff_alpha": _dev.mo_coeff[0].copy(),
@@ -618,7 +674,8 @@ def generate_jastrow3(mol, device=0, **kws):
     return j3, {"ccoeff": np.ones(j3.parameters["ccoeff"].shape, dtype=bool)}
 
 
-def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None, jastrow3=False, jastrow3_kws=None):
+def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None, jastrow3=False, jastrow3_kws=None,
+                eval_gto_precision=None, image_rule="reference"):
     """Slater x two-body-Jastrow product on ONE device handle — the counterpart of
     ``pyqmc.wftools.generate_wf`` (wftools.py:195-241) with the default Jastrow of
     ``generate_jastrow`` (:99-152: e-e cusp fixed at -1/4, -1/2, -1/4; ion cusp only for
@@ -633,12 +690,13 @@ def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None
     elif ion_cusp is False:
         ion_cusp = []
     abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
-    mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
+    mol, mo_coeff, determinants = orbital_inputs(mol, mf, determinants)
     a3 = b3 = None
     if jastrow3:  # wftools.generate_jastrow3 (:155-162): default basis without ion cusp
         a3, b3 = func3d.default_jastrow_basis(mol, False, **dict(jastrow3_kws or {}))
-    dev = DeviceWF(mol, mo_coeff=mf.mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
-                   tol=-1 if tol is None else tol, a3_basis=a3, b3_basis=b3)
+    dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
+                   tol=-1 if tol is None else tol, a3_basis=a3, b3_basis=b3, eval_gto_precision=eval_gto_precision,
+                   image_rule=image_rule)
     sl = Slater(mol, mf, _dev=dev)
     ja = JastrowSpin(mol, abasis, bbasis, _dev=dev)
     acoeff = np.zeros((mol.natm, len(abasis), 2))

@@ -250,3 +250,37 @@ def pbc_jastrow_coeffs(cell, nb=4, na=4):
     b = 0.05 * rng.standard_normal((nb, 3))
     b[0] = [-0.25, -0.5, -0.25]
     return a, b
+
+
+PBC_SLATER_CASES = {
+    "gamma": np.eye(3),
+    "fcc2cubic": np.array([[-1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 1.0, -1.0]]),
+    "k222": 2.0 * np.eye(3),
+}
+
+
+def pbc_slater_case(tag):
+    """(supercell, k-point mean field) exactly as make_golden.g_pbc_slater built them."""
+    from pyqmc_amd import pbc
+
+    sup = pbc.get_supercell(systems.diamond_primitive(), PBC_SLATER_CASES[tag])
+    return sup, pbc.random_kmf(sup)
+
+
+def unfold_ao(sup, kpts, ao_super):
+    """(…, nao_super) Gamma-point AOs of the supercell -> (nk, …, nao_prim) Bloch sums sum_c e^{ik.T_c} AO[(a,c,mu)]."""
+    from pyqmc_amd import pbc
+
+    prim = sup.original_cell
+    copies = pbc.get_supercell_copies(prim.lattice_vectors(), sup.S)
+    phase = np.exp(1j * copies @ np.asarray(kpts).T).real  # (ncopy, nk)
+    nao_atom = [sum(2 * sh[0] + 1 for sh in prim._basis[n]) for n in prim._names]
+    out = np.zeros((len(kpts),) + ao_super.shape[:-1] + (sum(nao_atom),))
+    row = col = 0
+    for na in nao_atom:
+        for c in range(len(copies)):
+            for k in range(len(kpts)):
+                out[k][..., col : col + na] += phase[c, k] * ao_super[..., row : row + na]
+            row += na
+        col += na
+    return out

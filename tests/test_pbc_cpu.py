@@ -112,3 +112,66 @@ def test_oracle_periodic_three_body_matches_reference():
     j3.parameters["ccoeff"] = g["prim3_ccoeff"]
     err = run_protocol_pbc({"j3": j3}, g, "prim3_", cell, update_first=True)
     assert max(err.values()) < 1e-10, {k: v for k, v in err.items() if v > 1e-11}
+
+
+# ------------------------------------------------------------------ periodic orbitals / Slater (oracle vs reference)
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_oracle_periodic_orbitals_match_reference(tag):
+    from helpers import pbc_slater_case
+    from oracle import pbc as opbc
+
+    g = golden("g15_pbc_orbitals")
+    sup, mf = pbc_slater_case(tag)
+    assert np.allclose(mf.kpts, g[f"{tag}_kpts"], atol=1e-14) and np.allclose(sup.atom_coords(), g[f"{tag}_atoms"], atol=1e-13)
+    orb = opbc.PeriodicOrbitals(sup, mf.kpts, mf.mo_coeff, g[f"{tag}_Ls"])
+    assert np.array_equal(orb.aotab.num_Ls, g[f"{tag}_num_Ls"])
+    assert relerr(orb.aotab.atom_cut, g[f"{tag}_atom_cut"]) < 1e-14 and relerr(orb.aotab.shell_cut, g[f"{tag}_shell_cut"]) < 1e-14
+    for nm, nc in (("val", 1), ("grad", 4), ("lap", 5)):
+        ao = orb.aos(g[f"{tag}_pts"].reshape(-1, 3), nc)
+        ref = g[f"{tag}_ao_{nm}"]
+        ref = ref.reshape((ref.shape[0], nc, -1, ref.shape[-1]))
+        assert relerr(ao, ref) < 1e-12, nm
+        assert relerr(orb.mos(ao, 0), g[f"{tag}_mo_{nm}"].reshape((nc, -1, g[f"{tag}_mo_{nm}"].shape[-1]))) < 1e-12
+
+
+def test_product_periodic_tables_match_reference():
+    """Cut-offs, the reference's num_Ls and the folded coefficient matrix (host set-up of the device path)."""
+    from helpers import pbc_slater_case, unfold_ao
+    from pyqmc_amd import pbc
+
+    g = golden("g15_pbc_orbitals")
+    for tag in ("gamma", "fcc2cubic", "k222"):
+        sup, mf = pbc_slater_case(tag)
+        t = pbc.periodic_tables(sup)
+        assert np.array_equal(t["num_Ls_prim"], g[f"{tag}_num_Ls"])
+        ncopy = sup.scale
+        assert relerr(t["atom_cut"][::ncopy], g[f"{tag}_atom_cut"]) < 1e-14
+        assert relerr(t["shell_cut"].reshape(2, ncopy, -1)[:, 0].ravel(), g[f"{tag}_shell_cut"]) < 1e-14
+        # every translation the reference looks at is reachable through the membership grid
+        n = np.rint(g[f"{tag}_Ls"][: t["num_Ls_prim"].max()] @ np.linalg.inv(sup.original_cell.lattice_vectors())).astype(int)
+        M = t["member_M"]
+        assert t["member"][0][n[:, 0] + M, n[:, 1] + M, n[:, 2] + M].all() and t["member"][0].sum() == len(n)
+        C = pbc.fold_mo_coeff(sup, mf.kpts, mf.mo_coeff)
+        assert C[0].shape == (sup.nao(), sup.nelec[0])
+        # folding identity on random numbers: sum_k AO_k C_k == AO_super C_super when AO_k = unfold(AO_super)
+        ao = np.random.default_rng(0).standard_normal((3, sup.nao()))
+        aok = unfold_ao(sup, mf.kpts, ao)
+        mo = np.concatenate([aok[k] @ mf.mo_coeff[0][k] for k in range(len(mf.kpts))], axis=-1)
+        assert relerr(ao @ C[0], mo) < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic", "k222"])
+def test_oracle_periodic_slater_jastrow_matches_reference(tag):
+    from helpers import pbc_slater_case
+    from oracle import jastrow_basis, wf as owf
+
+    g = golden("g15_pbc_orbitals")
+    sup, mf = pbc_slater_case(tag)
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, g[f"{tag}_Ls"])
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    wf = owf.MultiplyWF(sl, ja)
+    err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": wf}, g, f"{tag}_", sup)
+    assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
