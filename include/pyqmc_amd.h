@@ -188,6 +188,20 @@ int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* 
 int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs);
 int pqa_get_configs(pqa_handle_t* h, double* configs);
 
+/* Periodic Coulomb energy: tables of the Ewald sum (Ewald.__init__ / set_up_reciprocal_ewald_sum / set_ewald_constants,
+   observables/ewald.py:95-190; built by pyqmc_amd/ewald.py).  gpoints (ng,3): reciprocal vectors of the positive half
+   space with weight > 1e-10 (:372-388); gweight (ng) = 4 pi exp(-G^2/4 alpha^2) / (V G^2); ion_cos/ion_sin (ng): real and
+   imaginary part of sum_I Z_I exp(i G.R_I) (:233-234); ee_const / ei_const: self + charged-system terms for this electron
+   count (:180-184); ii: ion-ion energy incl. its constants (:353).  The real-space sum runs over the 27 cells of
+   nlatvec = 1 (:113-123).  Required before pqa_energy / energies in pqa_vmc_sweeps on a handle with pbc != 0. */
+int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,
+                  const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii);
+
+/* Wrap counters (PeriodicConfigs.wrap, coord.py:137-189) accumulated by the accepted moves of the LAST pqa_vmc_sweeps
+   call: wrap (W, nelec, 3) int32, to be added to the caller's counters.  The walkers themselves stay folded into the
+   cell (make_irreducible, mc.py:121). */
+int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap);
+
 /* EnergyAccumulator.__call__ (accumulators.py:60-75) on the device-resident walkers:
    out (6, W) rows ke, ee, ei, ecp, grad2, total (kinetic energy.py:57-65, Coulomb :28-54, ECP
    eval_ecp.py:21-146).  threshold as eval_ecp.ecp_mask (:135-146).  rot (N, necp, 3, 3) and

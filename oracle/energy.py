@@ -103,6 +103,10 @@ def ecp_ea(mol, configs, wf, e, atom_index, threshold, rot, unif, naip=None):
     if naip is None:
         naip = 6 if nl <= 2 else 12
     r_vec = x[:, e, :] - apos
+    if hasattr(mol, "a"):  # configs.dist.dist_i is the minimal-image displacement in a periodic cell (eval_ecp.py:95)
+        from .pbc import minimal_image
+
+        r_vec = minimal_image(mol.lattice_vectors())(r_vec)
     r = np.linalg.norm(r_vec, axis=-1)
     v = v_l(channels, r)
     if threshold > 0:  # eval_ecp.py:135-146
@@ -148,9 +152,14 @@ def ecp(mol, configs, wf, threshold, rot_tape, unif_tape, naip=None):
     return tot
 
 
-def energy(mol, configs, wf, threshold, rot_tape, unif_tape, naip=None):
-    """accumulators.py:60-75."""
-    ee, ei, ii = coulomb(mol, configs)
+def energy(mol, configs, wf, threshold, rot_tape, unif_tape, naip=None, ewald_kws=None):
+    """accumulators.py:60-75 (Ewald for a periodic cell, :52-53)."""
+    if hasattr(mol, "a"):
+        from .pbc import Ewald
+
+        ee, ei, ii = Ewald(mol, **(ewald_kws or {})).energy(configs)
+    else:
+        ee, ei, ii = coulomb(mol, configs)
     ecp_val = ecp(mol, configs, wf, threshold, rot_tape, unif_tape, naip) if mol._ecp else np.zeros(len(ee))
     ke, grad2 = kinetic(configs, wf)
     return {"ke": ke, "ee": ee, "ei": ei, "ecp": ecp_val, "grad2": grad2, "total": ke + ee + ei + ecp_val + ii}

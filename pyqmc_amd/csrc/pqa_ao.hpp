@@ -148,7 +148,8 @@ template <int NCOMP>
 __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  const double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  if (S.nL > 0) fold_cell(S, px, py, pz);  // periodic orbitals are tabulated for points inside the cell
   for (int sh = 0; sh < S.nshell; ++sh) {
     const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
     const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
   double px, py, pz;
   load_point(pa, pmine, px, py, pz);
+  if (PBC) fold_cell(S, px, py, pz);  // callers may hand over quadrature / proposal points outside the cell
 
   d4 acc[NU][NCOMP];
 #pragma unroll

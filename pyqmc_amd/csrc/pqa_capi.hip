@@ -47,6 +47,8 @@ struct pqa_handle {
   double* d_c3 = nullptr;
   DevBuf b_j3u;
   double ii_energy = 0.0;
+  EwaldDev ew{};  // periodic Coulomb tables (pqa_set_ewald)
+  bool ew_set = false;
   std::vector<int> shell_l, shell_np, shell_ao;
   SysDev S{};
   ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
@@ -60,7 +62,8 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap;
+  long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
   int tm_P = 0;
@@ -439,7 +442,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1075,8 +1078,12 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)6 * W * sizeof(double)));
   if (soa_current) {
-    hipLaunchKernelGGL(k_kinetic_lw, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
-                       (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+    if (h->S.pbc)
+      hipLaunchKernelGGL(k_kinetic_lw<true>, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
+                         (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+    else
+      hipLaunchKernelGGL(k_kinetic_lw<false>, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
+                         (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));
@@ -1085,6 +1092,14 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
                        (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_coulomb"));
+  }
+  if (h->S.pbc) {
+    if (!h->ew_set) FAIL("periodic Coulomb energy needs the Ewald tables (pqa_set_ewald)");
+    const bool soa = soa_current && h->necp == 0;  // with ECPs the coordinates were just transposed back
+    const double* x = soa ? (const double*)h->b_xt.p : h->js.x;
+    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(64), (size_t)h->N * 3 * sizeof(double), h->stream, h->S, h->ew, x,
+                       soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
+    TRY(check_launch(h, "k_ewald"));
   }
   const double* d_ecp = nullptr;
   h->last_ecp_points = 0;
@@ -1141,8 +1156,31 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
   return check_launch(h, "k_energy_assemble");
 }
 
+extern "C" int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,
+                             const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->S.pbc) FAIL("Ewald tables on an open-boundary handle");
+  if (ng < 0 || !(alpha > 0.0)) FAIL("bad Ewald parameters");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double* d;
+  TRY(upload_table(h, gpoints, (size_t)ng * 3, &d)); h->ew.g = d;
+  TRY(upload_table(h, gweight, (size_t)ng, &d)); h->ew.gweight = d;
+  TRY(upload_table(h, ion_cos, (size_t)ng, &d)); h->ew.ion_cos = d;
+  TRY(upload_table(h, ion_sin, (size_t)ng, &d)); h->ew.ion_sin = d;
+  h->ew.ng = ng; h->ew.alpha = alpha; h->ew.ee_const = ee_const; h->ew.ei_const = ei_const;
+  h->ii_energy = ii;
+  h->ew_set = true;
+  return 0;
+}
+
+extern "C" int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->S.pbc) FAIL("open-boundary handle has no wrap counters");
+  if (h->wrap_W != h->W || h->W == 0) FAIL("no fused sweep has run on the resident walkers");
+  return copy_out(h, wrap, h->b_wrap.p, (size_t)h->W * h->N * 3 * sizeof(int));
+}
+
 extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
-  if (h->S.pbc) FAIL("periodic energies (Ewald) are not implemented yet");
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   h->saved_valid = false;
@@ -1155,7 +1193,6 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
                               double* energy_mean, uint8_t* accept_rec) {
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
-  if (h->S.pbc) FAIL("the fused sweep does not fold walkers into a periodic cell yet; use the protocol path");
   if (nsteps <= 0) return 0;
   const long W = h->W;
   const int N = h->N;
@@ -1170,6 +1207,12 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
   HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
+  if (h->S.pbc) {  // wrap counters of this call's accepted moves (pqa_get_wrap)
+    TRY(ensure(h, h->b_dwrap, (size_t)W * 3 * sizeof(int)));
+    TRY(ensure(h, h->b_wrap, (size_t)W * N * 3 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->b_wrap.p, 0, (size_t)W * N * 3 * sizeof(int), h->stream));
+    h->wrap_W = W;
+  }
   if (gauss) TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
   if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
@@ -1196,6 +1239,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
     mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
+    if (h->S.pbc) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }
     if (gauss) {
       TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
       mb.gauss = (const double*)h->b_gauss.p;
@@ -1217,12 +1261,20 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
         double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
         uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
         const dim3 gm(gw.x, (unsigned)Gm);
-        hipLaunchKernelGGL(k_move_part_lw, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
-                           (const double*)nullptr, W, Gm, part);
+        if (h->S.pbc)
+          hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
+                             (const double*)nullptr, W, Gm, part);
+        else
+          hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
+                             (const double*)nullptr, W, Gm, part);
         hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
         TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-        hipLaunchKernelGGL(k_move_part_lw, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
-                           W, Gm, part);
+        if (h->S.pbc)
+          hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
+                             W, Gm, part);
+        else
+          hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
+                             W, Gm, part);
         hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
                            (const double*)part, rbuf, vbuf, act, mo);
         const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
@@ -1274,7 +1326,6 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
-  if (h->S.pbc) FAIL("periodic T-moves are not implemented yet");
   const long W = h->W;
   const int P = h->tm_P, s = e >= h->nup;
   if (P == 0) return 0;

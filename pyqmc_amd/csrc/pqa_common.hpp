@@ -107,6 +107,24 @@ __device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& d
   }
 }
 
+// Position -> inside the cell (enforce_pbc, pbc/pbc.py:37-48: fractional coordinates split by divmod(., 1)); dw receives
+// the integer wrap that was removed.
+__device__ __forceinline__ void fold_cell(const SysDev& S, double& x, double& y, double& z, int* dw = nullptr) {
+  if (S.pbc == 0) {
+    if (dw) dw[0] = dw[1] = dw[2] = 0;
+    return;
+  }
+  double f0 = x * S.linv[0] + y * S.linv[3] + z * S.linv[6];
+  double f1 = x * S.linv[1] + y * S.linv[4] + z * S.linv[7];
+  double f2 = x * S.linv[2] + y * S.linv[5] + z * S.linv[8];
+  const double w0 = floor(f0), w1 = floor(f1), w2 = floor(f2);
+  f0 -= w0; f1 -= w1; f2 -= w2;
+  x = f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6];
+  y = f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7];
+  z = f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8];
+  if (dw) { dw[0] = (int)w0; dw[1] = (int)w1; dw[2] = (int)w2; }
+}
+
 __device__ __forceinline__ double mi_norm(const SysDev& S, double dx, double dy, double dz) {
   min_image(S, dx, dy, dz);
   return sqrt(dx * dx + dy * dy + dz * dz);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
     grad2 += gx * gx + gy * gy + gz * gz;
   }
   double ee = 0.0, ei = 0.0;
-  for (int i = 0; i < S.nelec; ++i) {
+  for (int i = 0; i < (S.pbc ? 0 : S.nelec); ++i) {  // periodic cells: k_ewald fills ee / ei
     const double ix = xw[3 * i], iy = xw[3 * i + 1], iz = xw[3 * i + 2];
     for (int j = i + 1 + lane; j < S.nelec; j += 64) {
       const double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
@@ -53,6 +53,71 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
   ee = wave_sum(ee);
   ei = wave_sum(ei);
   if (lane == 0) { out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = grad2; }
+}
+
+// ---------------------------------------------------------------- Ewald (observables/ewald.py:238-354)
+// ee = sum_{i<j} sum_n erfc(a r_ijn)/r_ijn + sum_G w_G |sum_i e^{iG.x_i}|^2 + ee_const          (:262-275, :293-300)
+// ei = sum_{i,I} -Z_I sum_n erfc(a r_iIn)/r_iIn + 2 sum_G w_G (-Re(rho_I) C_G - Im(rho_I) S_G) + ei_const  (:255-259, :301-304)
+// with r_n = |minimal-image displacement + n . lattice|, n in {-1,0,1}^3 (real_cij :391-398, nlatvec = 1), G over the
+// positive half space with w_G > 1e-10 (:372-388), rho_I = sum_I Z_I e^{iG.R_I} (:233-234) and the self + charged
+// constants of :186-190.  One wave per walker; x is [W][N][3] (stride form lets the lane-per-walker state pass its
+// transposed coordinates: element (w,e,c) at x[w*sw + e*se + c*sc]).
+struct EwaldDev {
+  int ng;
+  const double* g;        // [ng][3]
+  const double* gweight;  // [ng]
+  const double* ion_cos;  // [ng] Re rho_I
+  const double* ion_sin;  // [ng] Im rho_I
+  double alpha, ee_const, ei_const;
+};
+__global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
+                                              long W, double* __restrict__ out) {
+  extern __shared__ double lds[];  // [N][3] coordinates of this walker
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int k = lane; k < S.nelec * 3; k += 64) lds[k] = x[w * sw + (k / 3) * se + (k % 3) * sc];
+  __syncthreads();
+  auto real_sum = [&](double dx, double dy, double dz) {
+    min_image(S, dx, dy, dz);
+    double acc = 0.0;
+    for (int a = -1; a <= 1; ++a)
+      for (int b = -1; b <= 1; ++b)
+        for (int c = -1; c <= 1; ++c) {
+          const double rx = dx + a * S.lat[0] + b * S.lat[3] + c * S.lat[6];
+          const double ry = dy + a * S.lat[1] + b * S.lat[4] + c * S.lat[7];
+          const double rz = dz + a * S.lat[2] + b * S.lat[5] + c * S.lat[8];
+          const double r = sqrt(rx * rx + ry * ry + rz * rz);
+          acc += erfc(E.alpha * r) / r;
+        }
+    return acc;
+  };
+  double ee = 0.0, ei = 0.0;
+  const int npair = S.nelec * (S.nelec - 1) / 2;
+  for (int p = lane; p < npair; p += 64) {  // pair p -> (i<j), row-major upper triangle
+    int i = 0, rem = p;
+    while (rem >= S.nelec - 1 - i) { rem -= S.nelec - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    ee += real_sum(lds[3 * i] - lds[3 * j], lds[3 * i + 1] - lds[3 * j + 1], lds[3 * i + 2] - lds[3 * j + 2]);
+  }
+  for (int q = lane; q < S.nelec * S.natom; q += 64) {
+    const int e = q / S.natom, I = q % S.natom;
+    ei -= S.atom_charge[I] * real_sum(lds[3 * e] - S.atom_xyz[3 * I], lds[3 * e + 1] - S.atom_xyz[3 * I + 1],
+                                      lds[3 * e + 2] - S.atom_xyz[3 * I + 2]);
+  }
+  for (int g = lane; g < E.ng; g += 64) {
+    const double gx = E.g[3 * g], gy = E.g[3 * g + 1], gz = E.g[3 * g + 2];
+    double sc_ = 0.0, ss_ = 0.0;
+    for (int e = 0; e < S.nelec; ++e) {
+      double sn, cs;
+      sincos(gx * lds[3 * e] + gy * lds[3 * e + 1] + gz * lds[3 * e + 2], &sn, &cs);
+      sc_ += cs; ss_ += sn;
+    }
+    ee += E.gweight[g] * (ss_ * ss_ + sc_ * sc_);
+    ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
+  }
+  ee = wave_sum(ee);
+  ei = wave_sum(ei);
+  if (lane == 0) { out[W + w] = ee + E.ee_const; out[2 * W + w] = ei + E.ei_const; }
 }
 
 // ---------------------------------------------------------------- ECP
@@ -119,8 +184,9 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
   int c_up = 0, c_dn = 0;
   for (int q = lane; q < S.nelec * S.necp; q += 64) {
     const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
-    const double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
-                 dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+    double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
+           dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+    min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     double v[PQA_MAXCHAN], prob;
     int nch;
@@ -172,8 +238,9 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
     bool pass = false;
     if (q < S.nelec * S.necp) {
       const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
-      const double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
-                   dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+      double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
+             dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+      min_image(S, dx, dy, dz);
       double v[PQA_MAXCHAN], prob;
       int nch;
       ecp_radial(S, k, sqrt(dx * dx + dy * dy + dz * dz), B.threshold, v, nch, prob);
@@ -186,7 +253,8 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
       const int qq = q0 + src;
       const int e = qq / S.necp, k = qq % S.necp, ia = S.ecp_atom[k], s = e >= S.nup;
       const double ax = S.atom_xyz[3 * ia], ay = S.atom_xyz[3 * ia + 1], az = S.atom_xyz[3 * ia + 2];
-      const double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
+      double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
+      min_image(S, dx, dy, dz);
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
       double v[PQA_MAXCHAN], prob;
       int nch;
@@ -305,7 +373,8 @@ __global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, 
   const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
   for (int q = threadIdx.x; q < P; q += 64) {
     const int k = pt_k[q], i = pt_i[q], ia = S.ecp_atom[k];
-    const double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+    double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+    min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     double v[PQA_MAXCHAN], prob;
     int nch;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
 // Contribution of the pairs j = j0, j0+dj, ... and ions I = j0, j0+dj, ... to U_e, grad U_e, (bare) lap U_e
 // of electron e of walker w at (rx,ry,rz); MODE 2 also returns that share of the Coulomb sums
 // ee = sum_{j>e} 1/r, ei = -sum Z/r.  (j0,dj) = (0,1) gives the full sums.
-template <int MODE>
+template <int MODE, bool PBC>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei) {
@@ -62,7 +62,7 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
   for (int j = j0; j < S.nelec; j += dj) {
     const double* xj = xt + (size_t)j * 3 * W + w;
     double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
-    min_image(S, dx, dy, dz);
+    if (PBC) min_image(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (j == e) continue;
     if (MODE == 2 && j > e) see += fast_rcp(r);
@@ -83,7 +83,7 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
   }
   for (int I = j0; I < S.natom; I += dj) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
-    min_image(S, dx, dy, dz);
+    if (PBC) min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
     if (has_jastrow && r < S.rcut_a) {
@@ -112,6 +112,7 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
 
 // pos: proposal [W][3] (accept) or NULL = current position of e from xt (propose)
 // rows: [W][5][nmo] orbital rows at `pos` (accept) or NULL = cached rows ct (propose)
+template <bool PBC>
 __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e, int has_jastrow, const double* __restrict__ pos,
                                                      const double* __restrict__ rows, long W, int G, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
     }
   }
   double U, gg[3], lp, ee, ei;
-  jas_eval_lane<1>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
+  jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
   double* p = part + (size_t)g * 8 * W + w;
   p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
 }
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, Move
   np_[0] = xe[0] + z0 + gx * mb.tstep;
   np_[1] = xe[W] + z1 + gy * mb.tstep;
   np_[2] = xe[2 * W] + z2 + gz * mb.tstep;
+  if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
   double* a = L.auxt + w;
   a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[4];
 }
@@ -223,6 +225,10 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   mb.acc_w[w] += 1;
   double* xe = L.xt + (size_t)e * 3 * W + w;
   xe[0] = mb.newpos[3 * w]; xe[W] = mb.newpos[3 * w + 1]; xe[2 * W] = mb.newpos[3 * w + 2];
+  if (mb.wrap) {
+    int* wr = mb.wrap + ((size_t)w * S.nelec + e) * 3;
+    wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
+  }
   {
     const double* row = motmp + (size_t)w * 5 * nmo;
     const int* occ = S.det_occ[s];
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(64) void k_flush_lw(SysDev S, LwState L, int s, con
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
+template <bool PBC>
 __global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int e = blockIdx.y;
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_
   const double gs0 = r[1] / r[0], gs1 = r[2] / r[0], gs2 = r[3] / r[0], ls = r[4] / r[0];
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double U, gj[3], lj, ee, ei;
-  jas_eval_lane<2>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
+  jas_eval_lane<2, PBC>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
   lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
   const double gx = gs0 + gj[0], gy = gs1 + gj[1], gz = gs2 + gj[2];
   const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);

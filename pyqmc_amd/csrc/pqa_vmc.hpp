@@ -22,6 +22,8 @@ struct MoveBuf {
   const double* unif;   // tape [N][W] for this step or NULL
   uint8_t* accept;  // [W] accept flags of this move
   uint8_t* accept_rec;  // [N][W] record for this step or NULL
+  int* dwrap;       // [W][3] wrap removed when the proposal was folded into the periodic cell (NULL: open system)
+  int* wrap;        // [W][N][3] wraps accumulated by accepted moves since the last recompute (NULL: open system)
   int* acc_w;       // [W] accepted moves of this walker in this step (no same-address atomics: they serialise at ~12 ns each)
   uint64_t seed;
   uint32_t step;
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
     np_[0] = ex + z0 + gx * mb.tstep;  // mc.py:120
     np_[1] = ey + z1 + gy * mb.tstep;
     np_[2] = ez + z2 + gz * mb.tstep;
+    if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
     double* a = mb.aux + 8 * w;
     a[0] = z0; a[1] = z1; a[2] = z2; a[3] = gx; a[4] = gy; a[5] = gz; a[6] = U0;
   }
@@ -126,6 +129,10 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   if (lane == 0) {
     double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
     x[0] = nx; x[1] = ny; x[2] = nz;
+    if (mb.wrap) {
+      int* wr = mb.wrap + ((size_t)w * S.nelec + e) * 3;
+      wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
+    }
   }
 }
 

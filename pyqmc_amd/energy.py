@@ -13,8 +13,12 @@ KEYS = ("ke", "ee", "ei", "ecp", "grad2", "total")
 
 
 class EnergyAccumulator:
-    def __init__(self, mol, threshold=10, naip=None, seed=0, check_configs=True):
+    def __init__(self, mol, threshold=10, naip=None, seed=0, check_configs=True, **kwargs):
+        """``kwargs``: ``ewald_gmax`` / ``nlatvec`` of the periodic Coulomb sum (accumulators.py:48-53, ewald.py:95)."""
         self.mol = mol
+        self._ewald_kws = kwargs
+        if kwargs and not hasattr(mol, "a"):
+            raise TypeError(f"unexpected arguments {sorted(kwargs)} for an open-boundary system")
         self.threshold = threshold
         if naip is not None:
             raise NotImplementedError("naip is chosen per atom as in eval_ecp.py:239-240 (6 or 12)")
@@ -34,6 +38,8 @@ class EnergyAccumulator:
         if self.check_configs and not np.array_equal(dev.configs(), configs.configs):
             raise ValueError("walkers on the device differ from `configs`: call wf.recompute(configs) "
                              "(or keep wf.updateinternals in step with configs.move) first")
+        if dev.pbc:
+            dev.set_ewald(**self._ewald_kws)
         self._calls += 1
         out = dev.energy(self.threshold, rot=rot, unif=unif, seed=self.seed + self._calls)
         return {k: out[i] for i, k in enumerate(KEYS)}

@@ -45,6 +45,8 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     wf.recompute(configs)
     block_avg = {}
     thr = next(iter(accumulators.values())).threshold if accumulators else 10.0
+    if dev.pbc and accumulators:
+        dev.set_ewald(**next(iter(accumulators.values()))._ewald_kws)
     t0 = time.perf_counter()
     acc, en, rec = dev.vmc_sweeps(tstep, nsteps, gauss=tapes.get("gauss"), unif=tapes.get("unif"), threshold=thr,
                                   ecp_rot=tapes.get("ecp_rot"), ecp_unif=tapes.get("ecp_unif"), seed=seed,
@@ -60,6 +62,8 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     block_avg["move time"] = (t1 - t0) / nsteps
     block_avg["accumulator time"] = 0.0
     configs.configs[...] = dev.configs()
+    if dev.pbc:  # walkers stay folded into the cell; their wrap counters advance (coord.py:180-189)
+        configs.wrap += dev.wrap_delta()
     return block_avg, configs
 
 

@@ -142,6 +142,9 @@ class DeviceWF:
             raise _ffi.PqaError(f"pqa_create failed ({rc}): {msg.decode() if msg else '?'}")
         self.device = int(device)
         self.W = 0
+        self._ewald_key = None
+        if self.pbc:
+            self.set_ewald()
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -164,6 +167,24 @@ class DeviceWF:
         self.call("pqa_set_param", name.encode(), _ffi.ptr(a), a.size)
 
     # fused device-resident entry points ---------------------------------
+    def set_ewald(self, ewald_gmax=200, nlatvec=1):
+        """Upload the Ewald tables (``Ewald(cell, ewald_gmax, nlatvec)``, observables/ewald.py:95-107)."""
+        if self._ewald_key == (ewald_gmax, nlatvec):
+            return
+        from .ewald import ewald_tables
+
+        t = ewald_tables(self.mol, ewald_gmax, nlatvec)
+        self.call("pqa_set_ewald", t["alpha"], len(t["gweight"]), _ffi.ptr(t["gpoints"]), _ffi.ptr(t["gweight"]),
+                  _ffi.ptr(t["ion_cos"]), _ffi.ptr(t["ion_sin"]), t["ee_const"], t["ei_const"], t["ii"])
+        self._ewald_key = (ewald_gmax, nlatvec)
+        self.ewald = t
+
+    def wrap_delta(self):
+        """(W, nelec, 3) wraps accumulated by the last fused sweep call."""
+        out = np.zeros((self.W, self.N, 3), dtype=np.int32)
+        self.call("pqa_get_wrap", _ffi.ptr(out))
+        return out
+
     def recompute(self, configs):
         x = _ffi.f64(configs)
         W = x.shape[0]

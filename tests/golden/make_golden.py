@@ -630,6 +630,80 @@ def g_pbc_slater():
     save("g15_pbc_orbitals", **out)
 
 
+
+# ------------------------------------------------------------------ G16 periodic energies (Ewald, ECP, kinetic) + VMC trajectory
+def ref_pbc_wf(tag):
+    import pyqmc.wftools as wftools
+    from pyqmc.wf.multiplywf import MultiplyWF
+    from pyqmc_amd import pbc as mypbc
+
+    prim = systems.diamond_primitive()
+    sup = mypbc.get_supercell(prim, PBC_SLATER_CASES[tag][0])
+    mf = mypbc.random_kmf(sup)
+    Ls = mypbc.lattice_points_within(prim.lattice_vectors(), 30.0)
+    _, _, sl = ref_pbc_objects(sup, mf.kpts, mf.mo_coeff, Ls)
+    j2, _ = wftools.generate_jastrow(sup)
+    jr = np.random.default_rng(17)
+    j2.parameters["acoeff"] = 0.05 * jr.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * jr.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    return sup, MultiplyWF(sl, j2)
+
+
+def g_pbc_energy():
+    import pyqmc.observables.ewald as refewald
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    for tag, W in (("gamma", 4), ("fcc2cubic", 2)):
+        sup, wf = ref_pbc_wf(tag)
+        N, natm_ecp = sum(sup.nelec), sup.natm
+        configs = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(61)).configs.copy(), sup.lattice_vectors())
+        out[f"{tag}_configs"] = configs.configs.copy()
+        ew = refewald.Ewald(sup, ewald_gmax=200 if tag == "gamma" else 10)
+        ee, ei, ii = ew.energy(configs)
+        out[f"{tag}_ewald_ee"], out[f"{tag}_ewald_ei"], out[f"{tag}_ewald_ii"] = ee, ei, np.asarray(ii)
+        out[f"{tag}_ewald_alpha"], out[f"{tag}_ewald_ng"] = np.asarray(ew.alpha), np.asarray(len(ew.gweight))
+        out[f"{tag}_ewald_gpoints"], out[f"{tag}_ewald_gweight"] = np.asarray(ew.gpoints), np.asarray(ew.gweight)
+        wf.recompute(configs)
+        for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+            with Tapes(700 + len(out)) as t:
+                en = pyq.EnergyAccumulator(sup, threshold=thr, ewald_gmax=10)(configs, wf)
+            for k, v in en.items():
+                out[f"{tag}_{thr_tag}_{k}"] = np.asarray(v)
+            out[f"{tag}_{thr_tag}_rot"] = np.asarray(t.log["rot"]).reshape(N, natm_ecp, 3, 3)
+            out[f"{tag}_{thr_tag}_unif"] = np.asarray(t.log["random"]).reshape(N, natm_ecp, W)
+        if tag == "gamma":  # VMC trajectory with energies, walkers crossing the cell boundary
+            nsteps, tstep = 2, 0.5
+            start = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(62)).configs.copy(), sup.lattice_vectors())
+            out["vmc_start"], out["vmc_start_wrap"] = start.configs.copy(), start.wrap.copy()
+            accepts = []
+            orig = wf.updateinternals
+
+            def spy(e, epos, cfg, mask=None, saved_values=None):
+                accepts.append(np.asarray(mask).copy())
+                return orig(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+            wf.updateinternals = spy
+            with Tapes(801) as t:
+                blk, cfg = vmc_worker(wf, start, tstep, nsteps, {"energy": pyq.EnergyAccumulator(sup, ewald_gmax=10)})
+            wf.updateinternals = orig
+            out["vmc_tstep"], out["vmc_nsteps"] = tstep, nsteps
+            out["vmc_gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+            out["vmc_unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+            out["vmc_ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm_ecp, 3, 3)
+            out["vmc_ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm_ecp, W)
+            out["vmc_accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+            out["vmc_final"], out["vmc_final_wrap"] = cfg.configs.copy(), cfg.wrap.copy()
+            out["vmc_final_log"] = wf.value()[1]
+            for k, v in blk.items():
+                if "time" not in k:
+                    out["vmc_blk_" + k] = np.asarray(v)
+            print("wrap moved:", np.abs(cfg.wrap - out["vmc_start_wrap"]).sum(), "acceptance", blk["acceptance"])
+    save("g16_pbc_energy", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -709,3 +783,4 @@ if __name__ == "__main__":
     g_dmc()
     g_pbc()
     g_pbc_slater()
+    g_pbc_energy()

@@ -284,3 +284,29 @@ def unfold_ao(sup, kpts, ao_super):
             row += na
         col += na
     return out
+
+
+def oracle_pbc_wf(tag, Ls=None):
+    """Oracle Slater x Jastrow for a PBC_SLATER_CASES entry, parameters as make_golden.ref_pbc_wf."""
+    from oracle import jastrow_basis, wf as owf
+    from pyqmc_amd import pbc
+
+    sup, mf = pbc_slater_case(tag)
+    if Ls is None:
+        Ls = pbc.lattice_points_within(sup.original_cell.lattice_vectors(), 30.0)
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, Ls)
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    return sup, owf.MultiplyWF(sl, ja)
+
+
+def gpu_pbc_wf(tag, **kw):
+    import pyqmc_amd as pa
+
+    sup, mf = pbc_slater_case(tag)
+    wf = pa.generate_wf(sup, mf, **kw)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    return sup, wf

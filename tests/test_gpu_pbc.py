@@ -39,18 +39,6 @@ def test_periodic_three_body_jastrow_matches_reference():
     assert max(err.values()) < 1e-9, {k: v for k, v in err.items() if v > 1e-10}
 
 
-def test_periodic_entry_points_fail_loudly_until_implemented():
-    """No silent open-boundary answer for a periodic system."""
-    import pyqmc_amd as pa
-    from pyqmc_amd import _ffi
-
-    cell = systems.diamond_primitive()
-    ja, _ = pa.wf.generate_jastrow(cell)
-    ja.recompute(systems.initial_guess(cell, 4))
-    with pytest.raises(_ffi.PqaError):
-        ja._dev.energy(10.0)
-
-
 # ------------------------------------------------------------------ periodic orbitals and Slater determinants
 @pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
 def test_periodic_orbitals_match_reference(tag):
@@ -98,3 +86,87 @@ def test_periodic_slater_jastrow_matches_reference(tag):
     wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
     err = run_protocol_pbc({"slater": wf.wf_factors[0], "jastrow": wf.wf_factors[1], "wf": wf}, g, f"{tag}_", sup)
     assert max(err.values()) < 2e-9, {k: v for k, v in err.items() if v > 1e-10}
+
+
+# ------------------------------------------------------------------ periodic energies and VMC
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_periodic_energy_matches_reference(tag):
+    """EnergyAccumulator on a periodic cell: Ewald ee / ei / ii (observables/ewald.py), kinetic energy through the
+    lattice-summed orbitals and the ECP integrator with minimal-image electron-ion vectors and folded quadrature
+    points, against the reference with its own random draws replayed."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g16_pbc_energy")
+    sup, wf = helpers.gpu_pbc_wf(tag)
+    cfg = PeriodicConfigs(g[f"{tag}_configs"].copy(), sup.lattice_vectors())
+    wf.recompute(cfg)
+    for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+        en = pa.EnergyAccumulator(sup, threshold=thr, ewald_gmax=10)(cfg, wf, rot=g[f"{tag}_{thr_tag}_rot"], unif=g[f"{tag}_{thr_tag}_unif"])
+        for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+            assert helpers.relerr(en[k], g[f"{tag}_{thr_tag}_{k}"]) < 2e-9, (thr_tag, k)
+    # Ewald alone, default reciprocal range
+    en = pa.EnergyAccumulator(sup, threshold=-1.0)(cfg, wf, rot=g[f"{tag}_det_rot"], unif=g[f"{tag}_det_unif"])
+    assert helpers.relerr(en["ee"], g[f"{tag}_ewald_ee"]) < 1e-12 and helpers.relerr(en["ei"], g[f"{tag}_ewald_ei"]) < 1e-12
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
+    """vmc_worker on PeriodicConfigs replayed with the reference's random draws: identical accept decisions, final
+    folded coordinates AND wrap counters, block energies — fused device sweep and protocol path."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g16_pbc_energy")
+    sup, wf = helpers.gpu_pbc_wf("gamma")
+    cfg = PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    tstep, nsteps = float(g["vmc_tstep"]), int(g["vmc_nsteps"])
+    acc = pa.EnergyAccumulator(sup, ewald_gmax=10)
+    if fused:
+        tapes = dict(gauss=g["vmc_gauss"], unif=g["vmc_unif"], ecp_rot=g["vmc_ecp_rot"], ecp_unif=g["vmc_ecp_unif"], record=[])
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, tapes=tapes)
+        accepts = tapes["record"][0]
+    else:
+        gz, un = iter(g["vmc_gauss"].reshape(-1, *g["vmc_gauss"].shape[2:])), iter(g["vmc_unif"].reshape(-1, g["vmc_unif"].shape[-1]))
+        monkeypatch.setattr(np.random, "normal", lambda scale, size: scale * next(gz))
+        monkeypatch.setattr(np.random, "rand", lambda n: next(un))
+        rots, eun = iter(g["vmc_ecp_rot"]), iter(g["vmc_ecp_unif"])
+        accepts = []
+        orig = wf.updateinternals
+        monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
+        monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
+    assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
+    assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    assert helpers.relerr(wf.value()[1], g["vmc_final_log"]) < 1e-9
+    for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
+        assert helpers.relerr(blk[k], g[f"vmc_blk_{k}"]) < 1e-8, k
+
+
+def test_periodic_fused_sweep_lane_and_wave_paths_agree(monkeypatch):
+    """64-electron 2x2x2 diamond supercell (config C5 shape): the lane-per-walker and the wave-per-walker fused sweeps
+    take the same decisions, keep the walkers inside the cell and agree with a fresh recompute."""
+    import pyqmc_amd as pa
+
+    sup, mf = helpers.pbc_slater_case("k222")
+    start = pa.initial_guess(sup, 200, rng=np.random.default_rng(5))
+    res = []
+    for lw in ("1", "0"):
+        monkeypatch.setenv("PQA_LW", lw)
+        _, wf = helpers.gpu_pbc_wf("k222")
+        dev = wf.fused_device()
+        cfg = start.copy()
+        wf.recompute(cfg)
+        acc, en, rec = dev.vmc_sweeps(0.3, 1, seed=77, energy=True, record=True)
+        x = dev.configs()
+        frac = x @ np.linalg.inv(sup.lattice_vectors())
+        assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12
+        res.append((x, dev.value()[1], en, rec, dev.recompute(x)[1], dev.wrap_delta()))
+    same = res[0][3] == res[1][3]
+    assert same.mean() > 0.9999
+    ok = same.all(axis=(0, 1))
+    assert helpers.relerr(res[0][0][ok], res[1][0][ok]) < 1e-10 and np.array_equal(res[0][5][ok], res[1][5][ok])
+    assert np.abs(res[0][5]).sum() > 0  # some walkers did cross the boundary
+    for r in res:
+        assert np.max(np.abs(r[1] - r[4])) < 1e-8

@@ -175,3 +175,53 @@ def test_oracle_periodic_slater_jastrow_matches_reference(tag):
     wf = owf.MultiplyWF(sl, ja)
     err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": wf}, g, f"{tag}_", sup)
     assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
+
+
+# ------------------------------------------------------------------ periodic energies (oracle + host tables vs reference)
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_ewald_tables_and_oracle_match_reference(tag):
+    from helpers import pbc_slater_case
+    from oracle import pbc as opbc
+    from pyqmc_amd import ewald
+
+    g = golden("g16_pbc_energy")
+    sup, _ = pbc_slater_case(tag)
+    t = ewald.ewald_tables(sup)  # default gmax = 200; the reference ran 200 (gamma) / 10 (fcc2cubic): same survivors
+    assert len(t["gweight"]) == int(g[f"{tag}_ewald_ng"]) and abs(t["alpha"] - float(g[f"{tag}_ewald_alpha"])) < 1e-14
+    assert relerr(t["gpoints"], g[f"{tag}_ewald_gpoints"]) < 1e-14 and relerr(t["gweight"], g[f"{tag}_ewald_gweight"]) < 1e-13
+    assert abs(t["ii"] - float(g[f"{tag}_ewald_ii"])) < 1e-11 * abs(t["ii"])
+    cfg = pc.PeriodicConfigs(g[f"{tag}_configs"].copy(), sup.lattice_vectors())
+    ee, ei, ii = opbc.Ewald(sup).energy(cfg)
+    assert relerr(ee, g[f"{tag}_ewald_ee"]) < 1e-12 and relerr(ei, g[f"{tag}_ewald_ei"]) < 1e-12
+    assert abs(ii - float(g[f"{tag}_ewald_ii"])) < 1e-11 * abs(ii)
+
+
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_oracle_periodic_energy_matches_reference(tag):
+    from helpers import oracle_pbc_wf
+    from oracle import energy as oenergy
+
+    g = golden("g16_pbc_energy")
+    sup, wf = oracle_pbc_wf(tag)
+    cfg = pc.PeriodicConfigs(g[f"{tag}_configs"].copy(), sup.lattice_vectors())
+    wf.recompute(cfg)
+    for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+        en = oenergy.energy(sup, cfg, wf, thr, g[f"{tag}_{thr_tag}_rot"], g[f"{tag}_{thr_tag}_unif"])
+        for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+            assert relerr(en[k], g[f"{tag}_{thr_tag}_{k}"]) < 1e-9, (thr_tag, k)
+
+
+def test_oracle_periodic_vmc_trajectory_matches_reference():
+    from helpers import oracle_pbc_wf
+    from oracle import vmc as ovmc
+
+    g = golden("g16_pbc_energy")
+    sup, wf = oracle_pbc_wf("gamma")
+    cfg = pc.PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    rec = []
+    blk, cfg = ovmc.vmc_worker(sup, wf, cfg, float(g["vmc_tstep"]), g["vmc_gauss"], g["vmc_unif"],
+                               g["vmc_ecp_rot"], g["vmc_ecp_unif"], record=rec)
+    assert np.array_equal(np.asarray(rec).reshape(g["vmc_accepts"].shape), g["vmc_accepts"])
+    assert relerr(cfg.configs, g["vmc_final"]) < 1e-11 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    for k in ("ke", "ee", "ei", "ecp", "total"):
+        assert abs(blk["energy" + k] - float(g["vmc_blk_energy" + k])) < 1e-9 * max(1.0, abs(float(g["vmc_blk_energy" + k]))), k
