@@ -75,11 +75,16 @@ def branch_distributed(configs, weights, base_u=None):
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
-    nmax, row = max(counts), int(np.prod(x.shape[1:]))
+    nx = int(np.prod(x.shape[1:]))
+    payload = x.reshape(len(weights), nx)
+    periodic = hasattr(configs, "wrap")  # PeriodicConfigs: the wrap counters travel with the coordinates (coord.py:191-198)
+    if periodic:
+        payload = np.concatenate([payload, np.asarray(configs.wrap, dtype=np.float64).reshape(len(weights), nx)], axis=1)
+    nmax, row = max(counts), payload.shape[1]
     pad_w = torch.zeros(nmax, dtype=torch.float64, device=dev)
     pad_w[: len(weights)] = torch.from_numpy(np.asarray(weights, dtype=np.float64))
     pad_x = torch.zeros(nmax, row, dtype=torch.float64, device=dev)
-    pad_x[: len(weights)] = torch.from_numpy(x.reshape(len(weights), row))
+    pad_x[: len(weights)] = torch.from_numpy(np.ascontiguousarray(payload))
     all_w = [torch.zeros_like(pad_w) for _ in range(world)]
     all_x = [torch.zeros_like(pad_x) for _ in range(world)]
     dist.all_gather(all_w, pad_w)
@@ -92,7 +97,9 @@ def branch_distributed(configs, weights, base_u=None):
     unique, cnt = np.unique(newinds, return_counts=True)
     lo = int(np.sum(counts[:rank]))
     mine = newinds[lo : lo + counts[rank]]
-    configs.configs = gx[mine].reshape((len(mine),) + x.shape[1:])
+    configs.configs = np.ascontiguousarray(gx[mine][:, :nx]).reshape((len(mine),) + x.shape[1:])
+    if periodic:
+        configs.wrap = np.ascontiguousarray(gx[mine][:, nx:]).reshape((len(mine),) + x.shape[1:])
     new_w = np.full(len(mine), wtot / len(gw))
     info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique))}
     return configs, new_w, info, float(np.std(gw))

@@ -704,6 +704,67 @@ def g_pbc_energy():
     save("g16_pbc_energy", **out)
 
 
+
+# ------------------------------------------------------------------ G17 periodic DMC propagate (T-moves, Ewald, wrap counters)
+def g_pbc_dmc():
+    import pyqmc.method.dmc as refdmc
+    import pyqmc.wf.orbitals as reforb
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    # like g_dmc: the un-JIT-ed AO path cannot take an empty point list (an all-False T-move mask)
+    orig_aos = reforb.PBCOrbitalEvaluatorKpoints.aos
+
+    def aos(self, eval_str, configs, mask=None):
+        coords = configs.configs if mask is None else configs.configs[mask]
+        if coords.size == 0:
+            nao, nk = self.parameters["mo_coeff_alpha"].shape[0], len(self._kpts)
+            comp = () if "deriv" not in eval_str else ((4,) if "deriv1" in eval_str else (5,))
+            return np.zeros((nk, *comp, *coords.shape[:-1], nao))
+        return orig_aos(self, eval_str, configs, mask)
+
+    reforb.PBCOrbitalEvaluatorKpoints.aos = aos
+    out = {}
+    sup, wf = ref_pbc_wf("gamma")
+    W, nsteps, tstep = 5, 2, 0.1
+    rng = np.random.default_rng(4)
+    configs = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(63)).configs.copy(), sup.lattice_vectors())
+    # pull electrons close to the carbon cores so the ECP mask passes and T-moves get accepted
+    near = sup.atom_coords()[[0, 1, 0, 1]][None] + 0.25 * rng.standard_normal((W, 4, 3))
+    configs = PeriodicConfigs(np.concatenate([near, configs.configs[:, 4:]], axis=1)[:, [0, 4, 1, 5, 2, 6, 3, 7]], sup.lattice_vectors())
+    out["start"], out["start_wrap"] = configs.configs.copy(), configs.wrap.copy()
+    weights = 1.0 + 0.1 * rng.standard_normal(W)
+    out["weights0"] = weights.copy()
+    e_trial, e_est, branchcut = -10.0, -10.2, 3.0
+    out["params"] = np.array([tstep, branchcut, e_trial, e_est, nsteps])
+    accepts = []
+    orig = wf.updateinternals
+
+    def spy(e, epos, cfg, mask=None, saved_values=None):
+        accepts.append(np.asarray(mask).copy())
+        return orig(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(950) as t:
+        df, configs, weights = refdmc.dmc_propagate(wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps=nsteps,
+                                                    accumulators={"energy": pyq.EnergyAccumulator(sup, ewald_gmax=10)})
+    wf.updateinternals = orig
+    reforb.PBCOrbitalEvaluatorKpoints.aos = orig_aos
+    out["normal"] = np.asarray(t.log["normal"])
+    rand = t.log["rand"]
+    out["rand_scalar"] = np.asarray([float(r) for r in rand if np.ndim(r) == 0])
+    out["rand_vector"] = np.asarray([r for r in rand if np.ndim(r) == 1])
+    out["rot"] = np.asarray(t.log["rot"])
+    out["random"] = np.asarray(t.log["random"])
+    out["accepts"] = np.asarray(accepts)
+    out["final"], out["final_wrap"] = configs.configs.copy(), configs.wrap.copy()
+    out["weights"] = weights
+    for k, v in df.items():
+        out["df_" + k] = np.asarray(v)
+    out["df_keys"] = np.asarray(sorted(df.keys()))
+    print("pbc dmc: wrap moved", np.abs(out["final_wrap"] - out["start_wrap"]).sum(), "tmove acc", df.get("tmove_acceptance"))
+    save("g17_pbc_dmc", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -784,3 +845,4 @@ if __name__ == "__main__":
     g_pbc()
     g_pbc_slater()
     g_pbc_energy()
+    g_pbc_dmc()

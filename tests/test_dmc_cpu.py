@@ -92,7 +92,17 @@ def test_branch_matches_reference_golden():
     assert [info["max branches"], info["Number of walkers killed"]] == g["branch_info"].tolist()
 
 
-def _branch_worker(rank, world, port, q):
+def _periodic_branch_input(g):
+    """The golden ensemble placed in a big periodic box, with distinguishable wrap counters."""
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    x = g["branch_configs"]
+    lat = np.eye(3) * 1000.0
+    wrap = np.arange(x.size, dtype=float).reshape(x.shape) % 7 - 3
+    return PeriodicConfigs(x + 500.0, lat, wrap=wrap.copy()), wrap
+
+
+def _branch_worker(rank, world, port, q, periodic=False):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -100,9 +110,12 @@ def _branch_worker(rank, world, port, q):
     try:
         g = golden("g12_dmc")
         lo, hi = pdist.shard_bounds(len(g["branch_weights"]), world)[rank]
-        cfg = OpenConfigs(g["branch_configs"][lo:hi].copy())
+        if periodic:
+            cfg = _periodic_branch_input(g)[0].mask(slice(lo, hi))
+        else:
+            cfg = OpenConfigs(g["branch_configs"][lo:hi].copy())
         cfg, w, info, wstd = pdist.branch_distributed(cfg, g["branch_weights"][lo:hi].copy(), base_u=float(g["branch_u"]))
-        q.put((rank, cfg.configs, w, info, wstd))
+        q.put((rank, cfg.configs, w, info, wstd, getattr(cfg, "wrap", None)))
     finally:
         dist.destroy_process_group()
 
@@ -131,3 +144,51 @@ def test_distributed_branch_two_ranks_gloo():
     for r in res:
         assert [r[3]["max branches"], r[3]["Number of walkers killed"]] == g["branch_info"].tolist()
         assert abs(r[4] - np.std(g["branch_weights"])) < 1e-14
+
+
+def test_distributed_branch_periodic_walkers_keep_their_wrap_counters():
+    """PeriodicConfigs through the sharded comb: coordinates AND wrap counters of every surviving walker arrive
+    together (the reference resamples both arrays with the same indices, coord.py:191-198)."""
+    import torch.multiprocessing as mp
+
+    g = golden("g12_dmc")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_branch_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg0, wrap0 = _periodic_branch_input(g)
+    newinds, _ = dmc.comb_indices(g["branch_weights"], float(g["branch_u"]))
+    # (mask() re-folds through the constructor like the reference, coord.py:159-162: equal to the last bit or two)
+    assert np.allclose(np.concatenate([r[1] for r in res]), cfg0.configs[newinds], rtol=0, atol=1e-10)
+    assert np.array_equal(np.concatenate([r[5] for r in res]), cfg0.wrap[newinds])
+    assert np.allclose(np.concatenate([r[1] for r in res]) - 500.0, g["branch_newconfigs"], atol=1e-9)
+
+
+def test_driver_reproduces_reference_periodic_dmc_propagate():
+    """dmc_propagate on PeriodicConfigs (diamond, Ewald energies, T-moves through make_irreducible): the driver over the
+    oracle reproduces the reference's run, wrap counters included (tests/golden/g17_pbc_dmc.npz)."""
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g17_pbc_dmc")
+    sup, wf = helpers.oracle_pbc_wf("gamma")
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = dmc.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                         nsteps=int(nsteps), accumulators={"energy": OracleAccumulator(sup)}, rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert relerr(cfg.configs, g["final"]) < 1e-10 and np.array_equal(cfg.wrap, g["final_wrap"]) and relerr(weights, g["weights"]) < 1e-9
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert relerr(df[k], g["df_" + k]) < 1e-9, k

@@ -170,3 +170,40 @@ def test_periodic_fused_sweep_lane_and_wave_paths_agree(monkeypatch):
     assert np.abs(res[0][5]).sum() > 0  # some walkers did cross the boundary
     for r in res:
         assert np.max(np.abs(r[1] - r[4])) < 1e-8
+
+
+def test_periodic_dmc_propagate_matches_reference():
+    """dmc_propagate (dmc.py:123-221) on a periodic cell with every wave-function / Ewald / ECP / T-move quantity from
+    the HIP library, replaying the reference's random draws: identical decisions, coordinates, wrap counters, weights."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g17_pbc_dmc")
+    sup, wf = helpers.gpu_pbc_wf("gamma")
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = pa.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                        nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                                        rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert helpers.relerr(cfg.configs, g["final"]) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
+    assert helpers.relerr(weights, g["weights"]) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert helpers.relerr(df[k], g["df_" + k]) < 1e-8, k
+
+
+def test_periodic_rundmc_smoke():
+    import pyqmc_amd as pa
+
+    np.random.seed(11)
+    sup, wf = helpers.gpu_pbc_wf("fcc2cubic")
+    configs = pa.initial_guess(sup, 128, rng=np.random.default_rng(3))
+    df, configs, weights = pa.rundmc(wf, configs, tstep=0.02, nblocks=2, nsteps_per_block=2, vmc_warmup=2,
+                                     accumulators={"energy": pa.EnergyAccumulator(sup)})
+    assert df["energytotal"].shape == (2,) and np.all(np.isfinite(df["energytotal"]))
+    frac = configs.configs @ np.linalg.inv(sup.lattice_vectors())
+    assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12 and configs.wrap.shape == configs.configs.shape
