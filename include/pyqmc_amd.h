@@ -91,8 +91,10 @@ typedef struct {
   int32_t pbc;
   double lattice[9]; /* rows = lattice vectors of the simulation cell, bohr */
   /* Periodic orbitals (PBCOrbitalEvaluatorKpoints orbitals.py:118-255 over the lattice-summed AOs of
-     numba/pbcgto.py:99-653), evaluated as Gamma-point orbitals of the simulation cell: every AO is summed over the
-     cell translations Ls[j], j < num_Ls[atom of the shell], skipping an image when r^2 > atom_cut[atom]
+     numba/pbcgto.py:99-653), evaluated as Gamma-point orbitals of the simulation cell: the displacement point - atom
+     is folded into the cell-centred parallelepiped, then every AO is summed over the cell translations Ls[j],
+     j < num_Ls[atom of the shell] (all with |Ls[j]| <= sqrt(atom_cut) + half the cell's longest body diagonal),
+     skipping an image when r^2 > atom_cut[atom]
      (pbcgto.py:213-214) or r^2 > shell_cut[shell] (:222, :356); cut-offs as max_Ls (:565-583).  Bloch orbitals
      of a primitive cell at the k-points of a zero-twist supercell are brought to this form on the host by folding
      the (real) Bloch phases into mo_up / mo_dn (pyqmc_amd/pbc.py:fold_mo_coeff).  nL = 0 with pbc != 0: no
@@ -105,8 +107,9 @@ typedef struct {
   /* Optional: reproduce which images the reference looks at.  The reference folds a point into the PRIMITIVE cell
      (wrap W = floor(r . inv(lattice_prim)), orbitals.py:201) and sums only the first num_Ls[a] entries of its
      norm-sorted primitive translation list (pbcgto.py:603-616, max_Ls :549-591), which is not a superset of what
-     the cut-offs admit.  With member != NULL an image j of atom A is kept only if the primitive translation
-     atom_n[A] + img_n[j] - W is marked in member[member_class[A]], a (2M+1)^3 byte grid indexed
+     the cut-offs admit.  With member != NULL an image of atom A displaced by the cell translation
+     (f + Ls[j]) (f = the fold applied to point - atom) is kept only if the primitive translation
+     atom_n[A] + n(f) + img_n[j] - W is marked in member[member_class[A]], a (2M+1)^3 byte grid indexed
      [n0+M][n1+M][n2+M].  member = NULL: every image inside the cut-offs counts. */
   double lattice_prim[9];
   const int32_t* img_n;        /* nL*3: Ls[j] in units of the primitive lattice vectors */

@@ -92,15 +92,17 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 #undef EMIT
 }
 
-// Lattice-summed shell (numba/pbcgto.py:205-225, :340-365, :470-506): the shell's functions summed over the images
-// Ls[j], j < num_Ls[atom] of its centre that lie within the atom's and the shell's r^2 cut-offs.  sh / ia / l are
-// wave-uniform at every call site, so the image table is read through the scalar cache and only the distance test
-// diverges between lanes.
-// The point's primitive-cell wrap W = floor(r . inv(lattice_prim)) (enforce_pbc, pbc/pbc.py:37-43), needed by the
-// membership rule only.
+// ---------------------------------------------------------------- lattice-summed shells
+// Periodic AO = sum over the images of its centre that lie within the atom's and the shell's r^2 cut-offs
+// (numba/pbcgto.py:205-225, :340-365, :470-506).  The displacement point - atom is first folded to the cell-centred
+// parallelepiped (|d0| <= half the longest body diagonal), so only the cell translations Ls[j] with
+// |Ls[j]| <= sqrt(atom_cut) + that radius can contribute: num_Ls[atom] of them, a few dozen instead of hundreds.
+// Which of those pass the atom test (and the reference's membership rule, see include/pyqmc_amd.h) is worked out
+// ONCE per (point, atom) into a 64-bit mask that all shells of the atom reuse.  sh / ia / l / j are wave-uniform at
+// every call site: tables come through the scalar cache, only the tests diverge between lanes.
 struct PrimWrap { int w0, w1, w2; };
 __device__ __forceinline__ PrimWrap prim_wrap(const SysDev& S, double px, double py, double pz) {
-  PrimWrap w = {0, 0, 0};
+  PrimWrap w = {0, 0, 0};  // W = floor(r . inv(lattice_prim)) (enforce_pbc, pbc/pbc.py:37-43): membership rule only
   if (S.member) {
     w.w0 = (int)floor(px * S.lprim_inv[0] + py * S.lprim_inv[3] + pz * S.lprim_inv[6]);
     w.w1 = (int)floor(px * S.lprim_inv[1] + py * S.lprim_inv[4] + pz * S.lprim_inv[7]);
@@ -109,33 +111,84 @@ __device__ __forceinline__ PrimWrap prim_wrap(const SysDev& S, double px, double
   return w;
 }
 
+struct PbcCtx {
+  int ia = -1;
+  double x0, y0, z0;        // folded displacement point - atom
+  int b0, b1, b2;           // membership index of image j = b + img_n[j]
+  unsigned long long mask[2];  // images j < 128 that pass the atom cut-off and the membership rule
+};
+
+__device__ __forceinline__ bool pbc_image_ok(const SysDev& S, const PbcCtx& c, int j, double r2) {
+  if (r2 > S.atom_cut[c.ia]) return false;
+  if (S.member) {  // would the reference have looked at this image?
+    const int side = 2 * S.member_M + 1;
+    const int n0 = c.b0 + S.img_n[3 * j], n1 = c.b1 + S.img_n[3 * j + 1], n2 = c.b2 + S.img_n[3 * j + 2];
+    if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) return false;
+    if (!S.member[((size_t)S.member_class[c.ia] * side + n0) * side * side + n1 * side + n2]) return false;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int ia, double x, double y, double z, PrimWrap pw) {
+  if (c.ia == ia) return;
+  c.ia = ia;
+  const double f0 = floor(x * S.linv[0] + y * S.linv[3] + z * S.linv[6] + 0.5);
+  const double f1 = floor(x * S.linv[1] + y * S.linv[4] + z * S.linv[7] + 0.5);
+  const double f2 = floor(x * S.linv[2] + y * S.linv[5] + z * S.linv[8] + 0.5);
+  c.x0 = x - (f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6]);
+  c.y0 = y - (f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7]);
+  c.z0 = z - (f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8]);
+  if (S.member) {  // atom image R_A + (f + m) . lattice  <->  primitive translation atom_n + (f + m) . supercell
+    const int i0 = (int)f0, i1 = (int)f1, i2 = (int)f2;
+    c.b0 = S.atom_n[3 * ia] + i0 * S.supercell[0] + i1 * S.supercell[3] + i2 * S.supercell[6] - pw.w0 + S.member_M;
+    c.b1 = S.atom_n[3 * ia + 1] + i0 * S.supercell[1] + i1 * S.supercell[4] + i2 * S.supercell[7] - pw.w1 + S.member_M;
+    c.b2 = S.atom_n[3 * ia + 2] + i0 * S.supercell[2] + i1 * S.supercell[5] + i2 * S.supercell[8] - pw.w2 + S.member_M;
+  }
+  const int nimg = min(S.num_Ls[ia], 128);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned long long m = 0ull;
+    for (int j = 64 * h; j < min(nimg, 64 * h + 64); ++j) {
+      const double xj = c.x0 - S.Ls[3 * j], yj = c.y0 - S.Ls[3 * j + 1], zj = c.z0 - S.Ls[3 * j + 2];
+      if (pbc_image_ok(S, c, j, xj * xj + yj * yj + zj * zj)) m |= 1ull << (j & 63);
+    }
+    c.mask[h] = m;
+  }
+}
+
 template <int NCOMP, class Sink>
-__device__ __forceinline__ void shell_eval_pbc(const SysDev& S, int sh, int ia, int l, double x, double y, double z,
-                                               PrimWrap pw, const double* __restrict__ pexp,
+__device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
                                                const double* __restrict__ pcoef, int np, Sink&& sink) {
   double acc[7][NCOMP];
 #pragma unroll
   for (int m = 0; m < 7; ++m)
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) acc[m][c] = 0.0;
-  const int nimg = S.num_Ls[ia];
-  const double cut = fmin(S.atom_cut[ia], S.shell_cut[sh]);
-  for (int j = 0; j < nimg; ++j) {
-    const double xj = x - S.Ls[3 * j], yj = y - S.Ls[3 * j + 1], zj = z - S.Ls[3 * j + 2];
-    if (xj * xj + yj * yj + zj * zj > cut) continue;
-    if (S.member) {  // would the reference have looked at this image?
-      const int M = S.member_M, side = 2 * M + 1;
-      const int n0 = S.atom_n[3 * ia] + S.img_n[3 * j] - pw.w0 + M;
-      const int n1 = S.atom_n[3 * ia + 1] + S.img_n[3 * j + 1] - pw.w1 + M;
-      const int n2 = S.atom_n[3 * ia + 2] + S.img_n[3 * j + 2] - pw.w2 + M;
-      if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
-      if (!S.member[((size_t)S.member_class[ia] * side + n0) * side * side + n1 * side + n2]) continue;
-    }
+    for (int k = 0; k < NCOMP; ++k) acc[m][k] = 0.0;
+  const int nimg = S.num_Ls[c.ia];
+  const double scut = S.shell_cut[sh];
+  auto add = [&](double xj, double yj, double zj) {
     shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       acc[m][0] += v;
       if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
       if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
     });
+  };
+  // Each lane walks ITS OWN list of admitted images (the set bits of its mask): the points of a wave sit anywhere in
+  // the cell, so iterating over image indices in lock-step would make every lane wait for the union of all lanes'
+  // images (~30 per atom) instead of the handful it needs itself.  Iterations = max over lanes of the count.
+  unsigned long long m0 = c.mask[0], m1 = c.mask[1];
+  while (__any((m0 | m1) != 0ull)) {
+    int j = -1;
+    if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
+    else if (m1) { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
+    const int jj = j < 0 ? 0 : j;
+    const double xj = c.x0 - S.Ls[3 * jj], yj = c.y0 - S.Ls[3 * jj + 1], zj = c.z0 - S.Ls[3 * jj + 2];
+    if (j >= 0 && xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj);
+  }
+  for (int j = 128; j < nimg; ++j) {  // beyond the mask (very small cells): direct tests
+    const double xj = c.x0 - S.Ls[3 * j], yj = c.y0 - S.Ls[3 * j + 1], zj = c.z0 - S.Ls[3 * j + 2];
+    const double r2 = xj * xj + yj * yj + zj * zj;
+    if (r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj);
   }
 #pragma unroll
   for (int m = 0; m < 7; ++m)
@@ -150,6 +203,8 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
   if (p >= P) return;
   double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
   if (S.nL > 0) fold_cell(S, px, py, pz);  // periodic orbitals are tabulated for points inside the cell
+  PbcCtx ctx;
+  const PrimWrap pw = prim_wrap(S, px, py, pz);
   for (int sh = 0; sh < S.nshell; ++sh) {
     const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
     const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
@@ -160,9 +215,10 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
       if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
       if (NCOMP == 5) o[4 * cs] = lp;
     };
-    if (S.nL > 0)
-      shell_eval_pbc<NCOMP>(S, sh, ia, S.shell_l[sh], x, y, z, prim_wrap(S, px, py, pz), S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
-    else
+    if (S.nL > 0) {
+      pbc_ctx_update(S, ctx, ia, x, y, z, pw);
+      shell_eval_pbc<NCOMP>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
+    } else
       shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
   }
 }
@@ -232,6 +288,8 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   double px, py, pz;
   load_point(pa, pmine, px, py, pz);
   if (PBC) fold_cell(S, px, py, pz);  // callers may hand over quadrature / proposal points outside the cell
+  PbcCtx ctx;
+  const PrimWrap pw = PBC ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};
 
   d4 acc[NU][NCOMP];
 #pragma unroll
@@ -286,8 +344,10 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
         if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
       };
-      if (PBC) shell_eval_pbc<NCOMP>(S, sh, ia_, l_, x, y, z, prim_wrap(S, px, py, pz), pe, pc, np_, to_tile);
-      else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
+      if (PBC) {
+        pbc_ctx_update(S, ctx, ia_, x, y, z, pw);
+        shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
+      } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
       const int rc = idx / TP;

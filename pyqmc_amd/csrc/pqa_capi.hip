@@ -323,6 +323,12 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         TRY(upload_table(h, sys->img_n, (size_t)sys->nL * 3, &tmp_i)); S.img_n = tmp_i;
         TRY(upload_table(h, sys->atom_n, (size_t)h->natom * 3, &tmp_i)); S.atom_n = tmp_i;
         S.member_M = sys->member_M;
+        for (int i = 0; i < 9; ++i) {  // supercell matrix = lattice . inv(lattice_prim), must be integer
+          double v_ = 0.0;
+          for (int k = 0; k < 3; ++k) v_ += sys->lattice[3 * (i / 3) + k] * S.lprim_inv[3 * k + (i % 3)];
+          S.supercell[i] = (int)lround(v_);
+          if (fabs(v_ - S.supercell[i]) > 1e-6) FAIL("lattice is not an integer multiple of lattice_prim");
+        }
       }
     }
     h->nmo[0] = sys->nmo_up; h->nmo[1] = sys->nmo_dn;

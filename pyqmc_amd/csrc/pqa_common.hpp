@@ -67,6 +67,7 @@ struct SysDev {
   const int* img_n;
   const int* atom_n;
   int member_M;
+  int supercell[9];  // lattice = supercell . lattice_prim (integers)
   double lprim_inv[9];
   int necp;
   const int* ecp_atom;

@@ -121,7 +121,8 @@ def periodic_tables(supercell, eval_gto_precision=None, Ls_prim=None, image_rule
     """Lattice-sum tables for the supercell's Gamma-point AOs.
 
     Every AO centred on supercell atom A = (primitive atom a, copy c) is summed over the supercell translations
-    ``Ls[j]``, j < ``num_Ls[A]`` — all that can come within the atom's cut-off of a point in the cell — subject to
+    ``Ls[j]``, j < ``num_Ls[A]`` — all that can come within the atom's cut-off of the (folded) displacement
+    point - atom — subject to
     the reference's r^2 cut-offs (``atom_cut``, ``shell_cut``; pbcgto.py:565-583, expcutoff :604).  With
     ``image_rule="reference"`` an image is additionally kept only if the reference would have looked at it: the
     reference folds the point into the primitive cell (wrap W, orbitals.py:201) and sums the first ``num_Ls[a]``
@@ -137,7 +138,9 @@ def periodic_tables(supercell, eval_gto_precision=None, Ls_prim=None, image_rule
     bt = tables.basis_tables(supercell)
     acut, lcut = gto_cutoffs(bt, expcutoff)
     lat, lprim = supercell.lattice_vectors(), prim.lattice_vectors()
-    reach = np.sqrt(acut) + cell_diameter(lat)
+    # the device folds (point - atom) into the cell-centred parallelepiped first, so an image only matters if it is
+    # within sqrt(cut) + half the longest body diagonal of the origin
+    reach = (np.sqrt(acut) + 0.5 * cell_diameter(lat)) * (1 + 1e-9)
     Ls = lattice_points_within(lat, reach.max())
     norms = np.linalg.norm(Ls, axis=1)
     num = np.array([int(np.searchsorted(norms, r, side="right")) for r in reach], dtype=np.int32)

@@ -1,0 +1,43 @@
+"""Throughput of the fused VMC sweep on periodic diamond cells (not the headline bench; see bench.py).
+
+    python tools/pbc_bench.py [--case k222|cubic] [--walkers W] [--steps K]
+
+k222 : 2x2x2 supercell of the primitive cell, 16 atoms, 64 electrons, 8 k-points (BASELINE config C5 shape)
+cubic: conventional cubic cell as a 4-fold supercell of the primitive cell, 8 atoms, 32 electrons (config C3 shape)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyqmc_amd as pa  # noqa: E402
+from pyqmc_amd import pbc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="k222")
+ap.add_argument("--walkers", type=int, default=8192)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--rule", default="reference")
+ap.add_argument("--no-energy", action="store_true")
+a = ap.parse_args()
+S = {"k222": 2.0 * np.eye(3), "cubic": np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]), "gamma": np.eye(3)}[a.case]
+sup = pbc.get_supercell(pa.systems.diamond_primitive(), S)
+mf = pbc.random_kmf(sup)
+wf = pa.generate_wf(sup, mf, image_rule=a.rule)
+dev = wf.fused_device()
+cfg = pa.initial_guess(sup, a.walkers, rng=np.random.default_rng(1))
+wf.recompute(cfg)
+dev.vmc_sweeps(0.3, a.warmup, seed=1, energy=not a.no_energy)
+dev.sync()
+t0 = time.perf_counter()
+acc, en, _ = dev.vmc_sweeps(0.3, a.steps, seed=2, energy=not a.no_energy)
+dev.sync()
+dt = time.perf_counter() - t0
+print(json.dumps({"case": a.case, "nelec": int(sum(sup.nelec)), "natom": sup.natm, "walkers": a.walkers, "ms_per_step": 1e3 * dt / a.steps,
+                  "walker_steps_per_s": a.walkers * a.steps / dt, "acceptance": float(acc[-1]),
+                  "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule}))
