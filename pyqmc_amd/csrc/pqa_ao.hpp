@@ -103,10 +103,10 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 struct PrimWrap { int w0, w1, w2; };
 __device__ __forceinline__ PrimWrap prim_wrap(const SysDev& S, double px, double py, double pz) {
   PrimWrap w = {0, 0, 0};  // W = floor(r . inv(lattice_prim)) (enforce_pbc, pbc/pbc.py:37-43): membership rule only
-  if (S.member) {
-    w.w0 = (int)floor(px * S.lprim_inv[0] + py * S.lprim_inv[3] + pz * S.lprim_inv[6]);
-    w.w1 = (int)floor(px * S.lprim_inv[1] + py * S.lprim_inv[4] + pz * S.lprim_inv[7]);
-    w.w2 = (int)floor(px * S.lprim_inv[2] + py * S.lprim_inv[5] + pz * S.lprim_inv[8]);
+  if (S.pb->member) {
+    w.w0 = (int)floor(px * S.pb->lprim_inv[0] + py * S.pb->lprim_inv[3] + pz * S.pb->lprim_inv[6]);
+    w.w1 = (int)floor(px * S.pb->lprim_inv[1] + py * S.pb->lprim_inv[4] + pz * S.pb->lprim_inv[7]);
+    w.w2 = (int)floor(px * S.pb->lprim_inv[2] + py * S.pb->lprim_inv[5] + pz * S.pb->lprim_inv[8]);
   }
   return w;
 }
@@ -119,12 +119,12 @@ struct PbcCtx {
 };
 
 __device__ __forceinline__ bool pbc_image_ok(const SysDev& S, const PbcCtx& c, int j, double r2) {
-  if (r2 > S.atom_cut[c.ia]) return false;
-  if (S.member) {  // would the reference have looked at this image?
-    const int side = 2 * S.member_M + 1;
-    const int n0 = c.b0 + S.img_n[3 * j], n1 = c.b1 + S.img_n[3 * j + 1], n2 = c.b2 + S.img_n[3 * j + 2];
+  if (r2 > S.pb->atom_cut[c.ia]) return false;
+  if (S.pb->member) {  // would the reference have looked at this image?
+    const int side = 2 * S.pb->member_M + 1;
+    const int n0 = c.b0 + S.pb->img_n[3 * j], n1 = c.b1 + S.pb->img_n[3 * j + 1], n2 = c.b2 + S.pb->img_n[3 * j + 2];
     if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) return false;
-    if (!S.member[((size_t)S.member_class[c.ia] * side + n0) * side * side + n1 * side + n2]) return false;
+    if (!S.pb->member[((size_t)S.pb->member_class[c.ia] * side + n0) * side * side + n1 * side + n2]) return false;
   }
   return true;
 }
@@ -132,24 +132,24 @@ __device__ __forceinline__ bool pbc_image_ok(const SysDev& S, const PbcCtx& c, i
 __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int ia, double x, double y, double z, PrimWrap pw) {
   if (c.ia == ia) return;
   c.ia = ia;
-  const double f0 = floor(x * S.linv[0] + y * S.linv[3] + z * S.linv[6] + 0.5);
-  const double f1 = floor(x * S.linv[1] + y * S.linv[4] + z * S.linv[7] + 0.5);
-  const double f2 = floor(x * S.linv[2] + y * S.linv[5] + z * S.linv[8] + 0.5);
-  c.x0 = x - (f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6]);
-  c.y0 = y - (f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7]);
-  c.z0 = z - (f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8]);
-  if (S.member) {  // atom image R_A + (f + m) . lattice  <->  primitive translation atom_n + (f + m) . supercell
+  const double f0 = floor(x * S.pb->linv[0] + y * S.pb->linv[3] + z * S.pb->linv[6] + 0.5);
+  const double f1 = floor(x * S.pb->linv[1] + y * S.pb->linv[4] + z * S.pb->linv[7] + 0.5);
+  const double f2 = floor(x * S.pb->linv[2] + y * S.pb->linv[5] + z * S.pb->linv[8] + 0.5);
+  c.x0 = x - (f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6]);
+  c.y0 = y - (f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7]);
+  c.z0 = z - (f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8]);
+  if (S.pb->member) {  // atom image R_A + (f + m) . lattice  <->  primitive translation atom_n + (f + m) . supercell
     const int i0 = (int)f0, i1 = (int)f1, i2 = (int)f2;
-    c.b0 = S.atom_n[3 * ia] + i0 * S.supercell[0] + i1 * S.supercell[3] + i2 * S.supercell[6] - pw.w0 + S.member_M;
-    c.b1 = S.atom_n[3 * ia + 1] + i0 * S.supercell[1] + i1 * S.supercell[4] + i2 * S.supercell[7] - pw.w1 + S.member_M;
-    c.b2 = S.atom_n[3 * ia + 2] + i0 * S.supercell[2] + i1 * S.supercell[5] + i2 * S.supercell[8] - pw.w2 + S.member_M;
+    c.b0 = S.pb->atom_n[3 * ia] + i0 * S.pb->supercell[0] + i1 * S.pb->supercell[3] + i2 * S.pb->supercell[6] - pw.w0 + S.pb->member_M;
+    c.b1 = S.pb->atom_n[3 * ia + 1] + i0 * S.pb->supercell[1] + i1 * S.pb->supercell[4] + i2 * S.pb->supercell[7] - pw.w1 + S.pb->member_M;
+    c.b2 = S.pb->atom_n[3 * ia + 2] + i0 * S.pb->supercell[2] + i1 * S.pb->supercell[5] + i2 * S.pb->supercell[8] - pw.w2 + S.pb->member_M;
   }
-  const int nimg = min(S.num_Ls[ia], 128);
+  const int nimg = min(S.pb->num_Ls[ia], 128);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     unsigned long long m = 0ull;
     for (int j = 64 * h; j < min(nimg, 64 * h + 64); ++j) {
-      const double xj = c.x0 - S.Ls[3 * j], yj = c.y0 - S.Ls[3 * j + 1], zj = c.z0 - S.Ls[3 * j + 2];
+      const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
       if (pbc_image_ok(S, c, j, xj * xj + yj * yj + zj * zj)) m |= 1ull << (j & 63);
     }
     c.mask[h] = m;
@@ -164,8 +164,8 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   for (int m = 0; m < 7; ++m)
 #pragma unroll
     for (int k = 0; k < NCOMP; ++k) acc[m][k] = 0.0;
-  const int nimg = S.num_Ls[c.ia];
-  const double scut = S.shell_cut[sh];
+  const int nimg = S.pb->num_Ls[c.ia];
+  const double scut = S.pb->shell_cut[sh];
   auto add = [&](double xj, double yj, double zj) {
     shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       acc[m][0] += v;
@@ -182,11 +182,11 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
     else if (m1) { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
     const int jj = j < 0 ? 0 : j;
-    const double xj = c.x0 - S.Ls[3 * jj], yj = c.y0 - S.Ls[3 * jj + 1], zj = c.z0 - S.Ls[3 * jj + 2];
+    const double xj = c.x0 - S.pb->Ls[3 * jj], yj = c.y0 - S.pb->Ls[3 * jj + 1], zj = c.z0 - S.pb->Ls[3 * jj + 2];
     if (j >= 0 && xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj);
   }
   for (int j = 128; j < nimg; ++j) {  // beyond the mask (very small cells): direct tests
-    const double xj = c.x0 - S.Ls[3 * j], yj = c.y0 - S.Ls[3 * j + 1], zj = c.z0 - S.Ls[3 * j + 2];
+    const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
     const double r2 = xj * xj + yj * yj + zj * zj;
     if (r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj);
   }
@@ -204,7 +204,7 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
   double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
   if (S.nL > 0) fold_cell(S, px, py, pz);  // periodic orbitals are tabulated for points inside the cell
   PbcCtx ctx;
-  const PrimWrap pw = prim_wrap(S, px, py, pz);
+  const PrimWrap pw = S.nL > 0 ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};  // S.pb is null for open systems
   for (int sh = 0; sh < S.nshell; ++sh) {
     const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
     const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];

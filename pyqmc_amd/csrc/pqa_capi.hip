@@ -259,16 +259,17 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   SysDev& S = h->S;
   S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;
   S.pbc = sys->pbc;
+  PbcDev P{};
   if (S.pbc < 0 || S.pbc > 2) FAIL("pbc must be 0 (open), 1 (orthogonal cell) or 2 (general cell)");
   if (S.pbc) {
     const double* a = sys->lattice;
     const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
     if (!(fabs(det) > 1e-12)) FAIL("singular lattice");
-    for (int i = 0; i < 9; ++i) S.lat[i] = a[i];
+    for (int i = 0; i < 9; ++i) P.lat[i] = a[i];
     const double id = 1.0 / det;  // inverse by cofactors: linv[r][c] = cof(c,r) / det
-    S.linv[0] = (a[4] * a[8] - a[5] * a[7]) * id; S.linv[1] = (a[2] * a[7] - a[1] * a[8]) * id; S.linv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
-    S.linv[3] = (a[5] * a[6] - a[3] * a[8]) * id; S.linv[4] = (a[0] * a[8] - a[2] * a[6]) * id; S.linv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
-    S.linv[6] = (a[3] * a[7] - a[4] * a[6]) * id; S.linv[7] = (a[1] * a[6] - a[0] * a[7]) * id; S.linv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    P.linv[0] = (a[4] * a[8] - a[5] * a[7]) * id; P.linv[1] = (a[2] * a[7] - a[1] * a[8]) * id; P.linv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    P.linv[3] = (a[5] * a[6] - a[3] * a[8]) * id; P.linv[4] = (a[0] * a[8] - a[2] * a[6]) * id; P.linv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    P.linv[6] = (a[3] * a[7] - a[4] * a[6]) * id; P.linv[7] = (a[1] * a[6] - a[0] * a[7]) * id; P.linv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
   }
   double* tmp_d; int* tmp_i;
   TRY(upload_table(h, sys->atom_xyz, (size_t)h->natom * 3, &tmp_d)); S.atom_xyz = tmp_d;
@@ -301,33 +302,33 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       for (int v : nl)
         if (v < 1 || v > sys->nL) FAIL("num_Ls out of range");
       S.nL = sys->nL;
-      TRY(upload_table(h, sys->Ls, (size_t)sys->nL * 3, &tmp_d)); S.Ls = tmp_d;
-      TRY(upload_table(h, sys->num_Ls, (size_t)h->natom, &tmp_i)); S.num_Ls = tmp_i;
-      TRY(upload_table(h, sys->atom_cut, (size_t)h->natom, &tmp_d)); S.atom_cut = tmp_d;
-      TRY(upload_table(h, sys->shell_cut, (size_t)sys->nshell, &tmp_d)); S.shell_cut = tmp_d;
-      S.member = nullptr;
+      TRY(upload_table(h, sys->Ls, (size_t)sys->nL * 3, &tmp_d)); P.Ls = tmp_d;
+      TRY(upload_table(h, sys->num_Ls, (size_t)h->natom, &tmp_i)); P.num_Ls = tmp_i;
+      TRY(upload_table(h, sys->atom_cut, (size_t)h->natom, &tmp_d)); P.atom_cut = tmp_d;
+      TRY(upload_table(h, sys->shell_cut, (size_t)sys->nshell, &tmp_d)); P.shell_cut = tmp_d;
+      P.member = nullptr;
       if (sys->member) {
         if (!sys->img_n || !sys->atom_n || !sys->member_class || sys->member_M < 0 || sys->n_member_class < 1) FAIL("incomplete image-membership tables");
         const double* a = sys->lattice_prim;
         const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
         if (!(fabs(det) > 1e-12)) FAIL("singular primitive lattice");
         const double id = 1.0 / det;
-        double* v = S.lprim_inv;
+        double* v = P.lprim_inv;
         v[0] = (a[4] * a[8] - a[5] * a[7]) * id; v[1] = (a[2] * a[7] - a[1] * a[8]) * id; v[2] = (a[1] * a[5] - a[2] * a[4]) * id;
         v[3] = (a[5] * a[6] - a[3] * a[8]) * id; v[4] = (a[0] * a[8] - a[2] * a[6]) * id; v[5] = (a[2] * a[3] - a[0] * a[5]) * id;
         v[6] = (a[3] * a[7] - a[4] * a[6]) * id; v[7] = (a[1] * a[6] - a[0] * a[7]) * id; v[8] = (a[0] * a[4] - a[1] * a[3]) * id;
         const size_t side = 2 * (size_t)sys->member_M + 1;
         unsigned char* tmp_b;
-        TRY(upload_table(h, sys->member, (size_t)sys->n_member_class * side * side * side, &tmp_b)); S.member = tmp_b;
-        TRY(upload_table(h, sys->member_class, (size_t)h->natom, &tmp_i)); S.member_class = tmp_i;
-        TRY(upload_table(h, sys->img_n, (size_t)sys->nL * 3, &tmp_i)); S.img_n = tmp_i;
-        TRY(upload_table(h, sys->atom_n, (size_t)h->natom * 3, &tmp_i)); S.atom_n = tmp_i;
-        S.member_M = sys->member_M;
+        TRY(upload_table(h, sys->member, (size_t)sys->n_member_class * side * side * side, &tmp_b)); P.member = tmp_b;
+        TRY(upload_table(h, sys->member_class, (size_t)h->natom, &tmp_i)); P.member_class = tmp_i;
+        TRY(upload_table(h, sys->img_n, (size_t)sys->nL * 3, &tmp_i)); P.img_n = tmp_i;
+        TRY(upload_table(h, sys->atom_n, (size_t)h->natom * 3, &tmp_i)); P.atom_n = tmp_i;
+        P.member_M = sys->member_M;
         for (int i = 0; i < 9; ++i) {  // supercell matrix = lattice . inv(lattice_prim), must be integer
           double v_ = 0.0;
-          for (int k = 0; k < 3; ++k) v_ += sys->lattice[3 * (i / 3) + k] * S.lprim_inv[3 * k + (i % 3)];
-          S.supercell[i] = (int)lround(v_);
-          if (fabs(v_ - S.supercell[i]) > 1e-6) FAIL("lattice is not an integer multiple of lattice_prim");
+          for (int k = 0; k < 3; ++k) v_ += sys->lattice[3 * (i / 3) + k] * P.lprim_inv[3 * k + (i % 3)];
+          P.supercell[i] = (int)lround(v_);
+          if (fabs(v_ - P.supercell[i]) > 1e-6) FAIL("lattice is not an integer multiple of lattice_prim");
         }
       }
     }
@@ -369,6 +370,11 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   S.na = h->na; S.nb = h->nb; S.rcut_a = sys->rcut_a; S.rcut_b = sys->rcut_b;
   for (int k = 0; k < h->na; ++k) { S.a_kind[k] = sys->a_kind[k]; S.a_param[k] = sys->a_param[k]; S.a_aux[k] = 1.0 / (3.0 + sys->a_param[k]); }
   for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; S.b_aux[k] = 1.0 / (3.0 + sys->b_param[k]); }
+  if (S.pbc) {  // all periodic tables sit behind one pointer (see SysDev)
+    PbcDev* dp;
+    TRY(upload_table(h, &P, (size_t)1, &dp));
+    S.pb = dp;
+  }
   TRY(upload_table(h, sys->acoeff, (size_t)h->natom * h->na * 2, &h->d_acoeff)); S.acoeff = h->d_acoeff;
   TRY(upload_table(h, sys->bcoeff, (size_t)h->nb * 3, &h->d_bcoeff)); S.bcoeff = h->d_bcoeff;
   S.na3 = h->na3; S.nb3 = h->nb3; S.rcut_a3 = sys->rcut_a3; S.rcut_b3 = sys->rcut_b3;
@@ -1152,8 +1158,12 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         for (int s = 0; s < 2; ++s)
           TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
     }
-    hipLaunchKernelGGL(k_ecp_accum, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                       (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+    if (h->S.pbc)
+      hipLaunchKernelGGL(k_ecp_accum<true>, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                         (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+    else
+      hipLaunchKernelGGL(k_ecp_accum<false>, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                         (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
     TRY(check_launch(h, "k_ecp_accum"));
     d_ecp = (const double*)h->b_ecp.p;
   }

@@ -11,6 +11,25 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Periodic-cell tables (device memory, read through the scalar cache).
+struct PbcDev {
+  double lat[9], linv[9];  // rows = lattice vectors; linv = inverse (frac = d . linv)
+  // periodic Gamma-point orbitals (numba/pbcgto.py:99-653): AO = sum over the cell translations Ls[j], j < num_Ls[atom],
+  // skipping images with r^2 > atom_cut[atom] or r^2 > shell_cut[shell]
+  const double* Ls;
+  const int* num_Ls;
+  const double* atom_cut;
+  const double* shell_cut;
+  // reference image-membership rule (see include/pyqmc_amd.h): member == nullptr -> every image inside the cut-offs
+  const unsigned char* member;
+  const int* member_class;
+  const int* img_n;
+  const int* atom_n;
+  int member_M;
+  int supercell[9];  // lattice = supercell . lattice_prim (integers)
+  double lprim_inv[9];
+};
+
 // Device view of the system tables (all pointers are device memory).
 struct SysDev {
   int natom, nup, ndn, nelec;
@@ -51,24 +70,12 @@ struct SysDev {
   const double* c3;
   int j3_off;  // offset (in doubles) of the three-body scratch inside a kernel's dynamic LDS
   // periodic boundary conditions: 0 open, 1 fold fractional coordinates (orthogonal lattice vectors,
-  // distance.py:143-159), 2 fold + argmin over the 27 neighbouring cells (distance.py:129-141)
+  // distance.py:143-159), 2 fold + argmin over the 27 neighbouring cells (distance.py:129-141).  Everything else a
+  // periodic system needs sits behind ONE pointer, so that the kernel-argument block (and with it the scalar-register
+  // footprint of every open-boundary kernel) does not grow with it.
   int pbc;
-  double lat[9], linv[9];  // rows = lattice vectors; linv = inverse (frac = d . linv)
-  // periodic Gamma-point orbitals (numba/pbcgto.py:99-653): AO = sum over lattice translations Ls[j], j < num_Ls[atom],
-  // skipping images with r^2 > atom_cut[atom] or r^2 > shell_cut[shell].  nL = 0: open system.
-  int nL;
-  const double* Ls;
-  const int* num_Ls;
-  const double* atom_cut;
-  const double* shell_cut;
-  // reference image-membership rule (see include/pyqmc_amd.h): member == nullptr -> every image inside the cut-offs
-  const unsigned char* member;
-  const int* member_class;
-  const int* img_n;
-  const int* atom_n;
-  int member_M;
-  int supercell[9];  // lattice = supercell . lattice_prim (integers)
-  double lprim_inv[9];
+  int nL;  // > 0: periodic orbital tables present (pb->Ls ...)
+  const struct PbcDev* pb;
   int necp;
   const int* ecp_atom;
   const int* ecp_chan_off;
@@ -86,21 +93,21 @@ struct SysDev {
 // in-cell points; both find the global minimum, ties aside).
 __device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& dy, double& dz) {
   if (S.pbc == 0) return;
-  double f0 = dx * S.linv[0] + dy * S.linv[3] + dz * S.linv[6];
-  double f1 = dx * S.linv[1] + dy * S.linv[4] + dz * S.linv[7];
-  double f2 = dx * S.linv[2] + dy * S.linv[5] + dz * S.linv[8];
+  double f0 = dx * S.pb->linv[0] + dy * S.pb->linv[3] + dz * S.pb->linv[6];
+  double f1 = dx * S.pb->linv[1] + dy * S.pb->linv[4] + dz * S.pb->linv[7];
+  double f2 = dx * S.pb->linv[2] + dy * S.pb->linv[5] + dz * S.pb->linv[8];
   f0 -= floor(f0 + 0.5); f1 -= floor(f1 + 0.5); f2 -= floor(f2 + 0.5);
-  dx = f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6];
-  dy = f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7];
-  dz = f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8];
+  dx = f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6];
+  dy = f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7];
+  dz = f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8];
   if (S.pbc == 2) {
     double bx = dx, by = dy, bz = dz, best = dx * dx + dy * dy + dz * dz;
     for (int i = -1; i <= 1; ++i)
       for (int j = -1; j <= 1; ++j)
         for (int k = -1; k <= 1; ++k) {
-          const double cx = dx + i * S.lat[0] + j * S.lat[3] + k * S.lat[6];
-          const double cy = dy + i * S.lat[1] + j * S.lat[4] + k * S.lat[7];
-          const double cz = dz + i * S.lat[2] + j * S.lat[5] + k * S.lat[8];
+          const double cx = dx + i * S.pb->lat[0] + j * S.pb->lat[3] + k * S.pb->lat[6];
+          const double cy = dy + i * S.pb->lat[1] + j * S.pb->lat[4] + k * S.pb->lat[7];
+          const double cz = dz + i * S.pb->lat[2] + j * S.pb->lat[5] + k * S.pb->lat[8];
           const double c2 = cx * cx + cy * cy + cz * cz;
           if (c2 < best) { best = c2; bx = cx; by = cy; bz = cz; }
         }
@@ -115,14 +122,14 @@ __device__ __forceinline__ void fold_cell(const SysDev& S, double& x, double& y,
     if (dw) dw[0] = dw[1] = dw[2] = 0;
     return;
   }
-  double f0 = x * S.linv[0] + y * S.linv[3] + z * S.linv[6];
-  double f1 = x * S.linv[1] + y * S.linv[4] + z * S.linv[7];
-  double f2 = x * S.linv[2] + y * S.linv[5] + z * S.linv[8];
+  double f0 = x * S.pb->linv[0] + y * S.pb->linv[3] + z * S.pb->linv[6];
+  double f1 = x * S.pb->linv[1] + y * S.pb->linv[4] + z * S.pb->linv[7];
+  double f2 = x * S.pb->linv[2] + y * S.pb->linv[5] + z * S.pb->linv[8];
   const double w0 = floor(f0), w1 = floor(f1), w2 = floor(f2);
   f0 -= w0; f1 -= w1; f2 -= w2;
-  x = f0 * S.lat[0] + f1 * S.lat[3] + f2 * S.lat[6];
-  y = f0 * S.lat[1] + f1 * S.lat[4] + f2 * S.lat[7];
-  z = f0 * S.lat[2] + f1 * S.lat[5] + f2 * S.lat[8];
+  x = f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6];
+  y = f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7];
+  z = f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8];
   if (dw) { dw[0] = (int)w0; dw[1] = (int)w1; dw[2] = (int)w2; }
 }
 

@@ -83,9 +83,9 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
     for (int a = -1; a <= 1; ++a)
       for (int b = -1; b <= 1; ++b)
         for (int c = -1; c <= 1; ++c) {
-          const double rx = dx + a * S.lat[0] + b * S.lat[3] + c * S.lat[6];
-          const double ry = dy + a * S.lat[1] + b * S.lat[4] + c * S.lat[7];
-          const double rz = dz + a * S.lat[2] + b * S.lat[5] + c * S.lat[8];
+          const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
+          const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
+          const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
           const double r = sqrt(rx * rx + ry * ry + rz * rz);
           acc += erfc(E.alpha * r) / r;
         }
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
 
 // pass C: ecp[w] = local + sum_points weight * Psi(aux)/Psi.  mo[s]: [npts_s][nmo_s] orbital values.
 // LDS: max(ndet_s) doubles.
+template <bool PBC>
 __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
                                                   int has_jastrow, const double* __restrict__ mo_up,
                                                   const double* __restrict__ mo_dn, long W, double* __restrict__ ecp) {
@@ -306,8 +307,8 @@ __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, Jast
       }
       if (has_jastrow) {
         double g[3], lp, U;
-        if (e != last_e) { jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
-        jas_eval<0>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp, 3, lds + S.j3_off);
+        if (e != last_e) { jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
+        jas_eval<0, PBC>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp, 3, lds + S.j3_off);
         ratio *= exp(U - U0);
       }
       tot += ratio * B.wgt[s][p];

@@ -189,7 +189,8 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
 // U_e(r), grad U_e, lap U_e (bare laplacian, without |grad|^2) for electron e placed at r, against
 // the walker coordinates xw (electron e itself skipped).  MODE 0: value; 1: value+grad; 2: grad+lap.
 // parts: bit 0 = one/two-body terms (JastrowSpin), bit 1 = three-body term (needs scr, see jas3_eval).
-template <int MODE>
+// PBC = false compiles the minimal-image code out (open-boundary instantiations of the hot kernels)
+template <int MODE, bool PBC = true>
 __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restrict__ xw, int e, double rx, double ry,
                                          double rz, double& U, double (&g)[3], double& lapU, int parts = 1,
                                          double* scr = nullptr) {
@@ -201,7 +202,7 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
     double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
-    min_image(S, dx, dy, dz);
+    if (PBC) min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_b) {
       const RadShared sh = rad_shared<MODE>(r, irb);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
   }
   for (int I = lane; I < S.natom; I += 64) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
-    min_image(S, dx, dy, dz);
+    if (PBC) min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_a) {
       const RadShared sh = rad_shared<MODE>(r, ira);
