@@ -310,3 +310,26 @@ def gpu_pbc_wf(tag, **kw):
     a, b = pbc_jastrow_coeffs(sup)
     wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
     return sup, wf
+
+
+def madelung_cases():
+    """The reference's known-answer Ewald systems (tests/unit/test_ewald.py:37-66, :141-184), restated as data:
+    [(name, supercell, configs (1,N,3), expected total Coulomb energy of the cell)].  Point charges: +1 / +2 ions at
+    the lattice sites, electrons at the anion sites; nearest-neighbour distance 1."""
+    from pyqmc_amd import pbc
+
+    out = []
+    L = 2.0
+    nacl = systems.Cell(["H"], [(0.0, 0.0, 0.0)], (np.ones((3, 3)) - np.eye(3)) * L / 2, nelec=(1, 0), ecp={})
+    out.append(("nacl_prim", pbc.get_supercell(nacl, np.eye(3)), np.ones((1, 1, 3)) * L / 2, -1.74756))
+    cfg = np.ones((1, 4, 3)) * L / 2
+    cfg[:, 1:, :] = np.eye(3) * L / 2
+    out.append(("nacl_conv", pbc.get_supercell(nacl, np.ones((3, 3)) - 2 * np.eye(3)), cfg, -4 * 1.74756))
+    L = 4 / np.sqrt(3)
+    caf2 = systems.Cell(["He"], [(0.0, 0.0, 0.0)], (np.ones((3, 3)) - np.eye(3)) * L / 2, nelec=(1, 1), ecp={})
+    cfg = np.ones((1, 2, 3)) * L / 4
+    cfg[0, 1, 1] *= -1
+    out.append(("caf2_prim", pbc.get_supercell(caf2, np.eye(3)), cfg, -5.03879))
+    cube = np.stack(np.meshgrid(*[[0, 1]] * 3, indexing="ij"), axis=-1).reshape((-1, 3))
+    out.append(("caf2_conv", pbc.get_supercell(caf2, np.ones((3, 3)) - 2 * np.eye(3)), np.reshape((cube + 0.5) * L / 2, (1, 8, 3)), -4 * 5.03879))
+    return out

@@ -207,3 +207,18 @@ def test_periodic_rundmc_smoke():
     assert df["energytotal"].shape == (2,) and np.all(np.isfinite(df["energytotal"]))
     frac = configs.configs @ np.linalg.inv(sup.lattice_vectors())
     assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12 and configs.wrap.shape == configs.configs.shape
+
+
+def test_ewald_madelung_constants_on_device():
+    """k_ewald on the reference's known-answer systems (NaCl, CaF2 Madelung constants, tests/unit/test_ewald.py) through a
+    Jastrow-only periodic handle."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    for name, sup, cfg, want in helpers.madelung_cases():
+        ja, _ = pa.wf.generate_jastrow(sup)
+        c = PeriodicConfigs(cfg, sup.lattice_vectors())
+        ja.recompute(c)
+        en = pa.EnergyAccumulator(sup)(c, ja)
+        coulomb = en["total"] - en["ke"] - en["ecp"]
+        assert abs(coulomb[0] - want) < 1e-4 * max(1, abs(want) / 1.7), (name, coulomb, want)

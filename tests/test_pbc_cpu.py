@@ -225,3 +225,24 @@ def test_oracle_periodic_vmc_trajectory_matches_reference():
     assert relerr(cfg.configs, g["vmc_final"]) < 1e-11 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
     for k in ("ke", "ee", "ei", "ecp", "total"):
         assert abs(blk["energy" + k] - float(g["vmc_blk_energy" + k])) < 1e-9 * max(1.0, abs(float(g["vmc_blk_energy" + k]))), k
+
+
+def test_ewald_madelung_constants_oracle_and_host_tables():
+    """NaCl and CaF2 Madelung constants (the reference's tests/unit/test_ewald.py:37-66,141-184, tolerance 1e-4) and
+    invariance under a rigid shift (:187-210, 1e-14 there for a cubic cell) — oracle sums with the product's tables."""
+    from helpers import madelung_cases
+    from oracle import pbc as opbc
+    from pyqmc_amd import ewald
+
+    for name, sup, cfg, want in madelung_cases():
+        ee, ei, ii = opbc.Ewald(sup).energy(pc.PeriodicConfigs(cfg, sup.lattice_vectors()))
+        assert abs((ee + ei + ii)[0] - want) < 1e-4 * max(1, abs(want) / 1.7), name
+        t = ewald.ewald_tables(sup)
+        assert abs(t["ii"] - ii) < 1e-12 * max(1.0, abs(ii)), name
+    # rigid shift of ions and electrons together
+    vals = []
+    for x in (0.1, 0.2):
+        cell = systems.Cell(["H"], [(4.0 * x,) * 3], np.eye(3) * 4.0, nelec=(1, 0), ecp={})
+        cfg = pc.PeriodicConfigs(np.full((1, 1, 3), 4.0 * x) + np.array([0.1, 0.2, 0.1]), cell.lattice_vectors())
+        vals.append(np.concatenate([np.ravel(v) for v in opbc.Ewald(cell, ewald_gmax=25).energy(cfg)]))
+    assert np.linalg.norm(vals[1] - vals[0]) < 1e-13
