@@ -62,7 +62,7 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass;
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
@@ -454,7 +454,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1135,7 +1135,9 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(ensure(h, h->b_ecnt, 2 * W * sizeof(int)));
     TRY(ensure(h, h->b_eoff, 2 * (W + 1) * sizeof(long)));
     TRY(ensure(h, h->b_ecp, W * sizeof(double)));
+    TRY(ensure(h, h->b_epass, (size_t)W * ((nrot + 63) / 64) * sizeof(unsigned long long)));
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
+    B.passbits = (unsigned long long*)h->b_epass.p;
     hipLaunchKernelGGL(k_ecp_count, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
     TRY(check_launch(h, "k_ecp_count/k_scan2"));

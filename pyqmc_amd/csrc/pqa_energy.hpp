@@ -134,6 +134,7 @@ struct EcpBuf {
   double* pts[2];        // [npts_s][3]
   double* wgt[2];        // [npts_s]  sum_l (v_l/prob)(2l+1)P_l(cos) w_i
   int* pte[2];           // [npts_s]  electron index of the point
+  unsigned long long* passbits;  // [W][ceil(N*necp/64)] (electron, atom) pairs that passed the stochastic mask
 };
 
 __device__ __forceinline__ double legendre_l(int l, double x) {
@@ -166,6 +167,7 @@ __device__ __forceinline__ void ecp_radial(const SysDev& S, int k, double r, dou
 }
 
 __device__ __forceinline__ bool ecp_pass(const SysDev& S, const EcpBuf& B, long w, long W, int e, int k, double prob) {
+  if (!(prob > 0.0)) return false;  // u >= 0: nothing to draw (atoms whose non-local channels vanish)
   double u;
   if (B.unif) u = B.unif[((size_t)e * S.necp + k) * W + w];
   else {
@@ -182,20 +184,28 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double loc = 0.0;
   int c_up = 0, c_dn = 0;
-  for (int q = lane; q < S.nelec * S.necp; q += 64) {
-    const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
-    double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
-           dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
-    min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
-    const double r = sqrt(dx * dx + dy * dy + dz * dz);
-    double v[PQA_MAXCHAN], prob;
-    int nch;
-    ecp_radial(S, k, r, B.threshold, v, nch, prob);
-    loc += v[nch - 1];
-    if (nch > 1 && ecp_pass(S, B, w, W, e, k, prob)) {
-      const int naip = (nch <= 2) ? 6 : 12;
-      if (e < S.nup) c_up += naip; else c_dn += naip;
+  const int npair = S.nelec * S.necp, nblk = (npair + 63) / 64;
+  for (int q0 = 0; q0 < npair; q0 += 64) {
+    const int q = q0 + lane;
+    bool pass = false;
+    if (q < npair) {
+      const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
+      double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
+             dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
+      min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      double v[PQA_MAXCHAN], prob;
+      int nch;
+      ecp_radial(S, k, r, B.threshold, v, nch, prob);
+      loc += v[nch - 1];
+      pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
+      if (pass) {
+        const int naip = (nch <= 2) ? 6 : 12;
+        if (e < S.nup) c_up += naip; else c_dn += naip;
+      }
     }
+    const unsigned long long m = __ballot(pass);  // remembered for k_ecp_fill: it only visits the pairs that passed
+    if (lane == 0) B.passbits[(size_t)w * nblk + q0 / 64] = m;
   }
   loc = wave_sum(loc);
 #pragma unroll
@@ -233,20 +243,9 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   long run[2] = {B.off[w], B.off[(W + 1) + w]};
+  const int nblk = (S.nelec * S.necp + 63) / 64;
   for (int q0 = 0; q0 < S.nelec * S.necp; q0 += 64) {
-    const int q = q0 + lane;
-    bool pass = false;
-    if (q < S.nelec * S.necp) {
-      const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
-      double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
-             dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
-      min_image(S, dx, dy, dz);
-      double v[PQA_MAXCHAN], prob;
-      int nch;
-      ecp_radial(S, k, sqrt(dx * dx + dy * dy + dz * dz), B.threshold, v, nch, prob);
-      pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
-    }
-    unsigned long long m = __ballot(pass);
+    unsigned long long m = B.passbits[(size_t)w * nblk + q0 / 64];  // the mask k_ecp_count drew
     while (m) {  // whole wave cooperates on one (electron, atom) entry at a time, in e-major order
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
