@@ -62,7 +62,8 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2];
+  int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
@@ -247,6 +248,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
   if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
+  if (const char* ew = getenv("PQA_ECP_WAVE")) h->ecp_wave = atoi(ew);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -454,7 +456,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1]};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1138,6 +1140,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(ensure(h, h->b_epass, (size_t)W * ((nrot + 63) / 64) * sizeof(unsigned long long)));
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
+    B.has_j2 = h->has_j2 ? 1 : 0;
     hipLaunchKernelGGL(k_ecp_count, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
     TRY(check_launch(h, "k_ecp_count/k_scan2"));
@@ -1150,6 +1153,11 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       TRY(ensure(h, h->b_epts[s], n * 3 * sizeof(double)));
       TRY(ensure(h, h->b_ewgt[s], n * sizeof(double)));
       TRY(ensure(h, h->b_epte[s], n * sizeof(int)));
+      TRY(ensure(h, h->b_eptw[s], n * sizeof(int)));
+      TRY(ensure(h, h->b_econ[s], n * sizeof(double)));
+      TRY(ensure(h, h->b_eu0[s], n * sizeof(double)));
+      B.ptw[s] = (int*)h->b_eptw[s].p;
+      B.u0[s] = (double*)h->b_eu0[s].p;
       TRY(ensure(h, h->b_emo[s], n * std::max(h->nmo[s], 1) * sizeof(double)));
       B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
     }
@@ -1160,6 +1168,20 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         for (int s = 0; s < 2; ++s)
           TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
     }
+    if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
+      for (int s = 0; s < 2; ++s) {
+        if (tot[s] <= 0) continue;
+        const dim3 g((unsigned)((tot[s] + 255) / 256));
+        if (h->S.pbc)
+          hipLaunchKernelGGL(k_ecp_point<true>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p);
+        else
+          hipLaunchKernelGGL(k_ecp_point<false>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p);
+      }
+      hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
+                         (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p);
+    } else
     if (h->S.pbc)
       hipLaunchKernelGGL(k_ecp_accum<true>, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
                          (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);

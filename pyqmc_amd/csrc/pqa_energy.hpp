@@ -134,6 +134,9 @@ struct EcpBuf {
   double* pts[2];        // [npts_s][3]
   double* wgt[2];        // [npts_s]  sum_l (v_l/prob)(2l+1)P_l(cos) w_i
   int* pte[2];           // [npts_s]  electron index of the point
+  int* ptw[2];           // [npts_s]  walker index of the point (thread-per-point accumulation)
+  double* u0[2];         // [npts_s]  two-body Jastrow exponent U_e at the electron's CURRENT position (same for the 6/12 points of an entry)
+  int has_j2;            // fill u0
   unsigned long long* passbits;  // [W][ceil(N*necp/64)] (electron, atom) pairs that passed the stochastic mask
 };
 
@@ -259,6 +262,11 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
       int nch;
       ecp_radial(S, k, r, B.threshold, v, nch, prob);
       const int naip = (nch <= 2) ? 6 : 12;
+      double U0 = 0.0;
+      if (B.has_j2) {  // once per (electron, atom) entry, by the whole wave, instead of once per point later
+        double g_[3], lp_;
+        jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g_, lp_, 1);
+      }
       if (lane < naip) {
         const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
         const double* R = B.rot + ((size_t)e * S.necp + k) * 9;
@@ -275,6 +283,8 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
         B.pts[s][3 * slot + 2] = (xw[3 * e + 2] - dz) + riz;
         B.wgt[s][slot] = wsum * (1.0 / naip);
         B.pte[s][slot] = e;
+        B.ptw[s][slot] = (int)w;
+        B.u0[s][slot] = U0;
       }
       run[s] += naip;
     }
@@ -354,6 +364,81 @@ __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a,
     __syncthreads();
   }
   if (threadIdx.x == 0) out[blockIdx.x] = part[0] / (double)W;
+}
+
+// pass C, thread-per-point variant (single determinant, no three-body factor): contrib[p] = weight_p * Psi(aux_p)/Psi.
+// One wave per walker (k_ecp_accum) walks ~38 points one after another with every load and reduction latency
+// exposed; here each point is one thread: a 32-term dot with the walker's inverse row for the determinant ratio and
+// one loop over the other electrons and the ions for U(new) - U(old).  k_ecp_sum then adds a walker's points in slot
+// order, so the result does not depend on scheduling.
+template <bool PBC>
+__global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int s, int has_slater,
+                                                   int has_jastrow, const double* __restrict__ mo, long npts,
+                                                   double* __restrict__ contrib) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  const int e = B.pte[s][p];
+  const long w = B.ptw[s][p];
+  const int n = s ? S.ndn : S.nup, i = e - s * S.nup, nmo = S.nmo[s];
+  double ratio = 1.0;
+  if (has_slater) {
+    const double* Ti = st.T[s] + ((size_t)w * n + i) * n;
+    const double* row = mo + (size_t)p * nmo;
+    const int* occ = S.det_occ[s];
+    double r = 0.0;
+    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[k];
+    ratio = r;
+  }
+  if (has_jastrow) {
+    const double* xw = js.x + (size_t)w * S.nelec * 3;
+    const double nx = B.pts[s][3 * p], ny = B.pts[s][3 * p + 1], nz = B.pts[s][3 * p + 2];
+    const int edown = e >= S.nup;
+    const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+    double du = 0.0;
+    auto norm = [&](double dx, double dy, double dz) {
+      if (PBC) min_image(S, dx, dy, dz);
+      return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    for (int j = 0; j < S.nelec; ++j) {
+      if (j == e) continue;
+      const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
+      const double rn = norm(nx - jx, ny - jy, nz - jz);
+      const int col = edown + (j >= S.nup);
+      if (rn < S.rcut_b) {
+        const RadShared sh = rad_shared<0>(rn, irb);
+        for (int l = 0; l < S.nb; ++l) {
+          double v, g, lp;
+          rad_fn<0>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, g, lp);
+          du += S.bcoeff[l * 3 + col] * v;
+        }
+      }
+    }
+    for (int I = 0; I < S.natom; ++I) {
+      const double ax = S.atom_xyz[3 * I], ay = S.atom_xyz[3 * I + 1], az = S.atom_xyz[3 * I + 2];
+      const double rn = norm(nx - ax, ny - ay, nz - az);
+      if (rn < S.rcut_a) {
+        const RadShared sh = rad_shared<0>(rn, ira);
+        for (int k = 0; k < S.na; ++k) {
+          double v, g, lp;
+          rad_fn<0>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, g, lp);
+          du += S.acoeff[(I * S.na + k) * 2 + edown] * v;
+        }
+      }
+    }
+    ratio *= exp(du - B.u0[s][p]);  // U_e(new) - U_e(old); the old-position sum comes from k_ecp_fill
+  }
+  contrib[p] = ratio * B.wgt[s][p];
+}
+
+// ecp[w] = local + sum of the walker's point contributions, spin up then spin down, in slot order
+__global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restrict__ c_up, const double* __restrict__ c_dn, long W,
+                                                 double* __restrict__ ecp) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  double tot = 0.0;
+  for (long p = B.off[w]; p < B.off[w + 1]; ++p) tot += c_up[p];
+  for (long p = B.off[(W + 1) + w]; p < B.off[(W + 1) + w + 1]; ++p) tot += c_dn[p];
+  ecp[w] = B.local[w] + tot;
 }
 
 // ---------------------------------------------------------------- T-move candidates (DMC)

@@ -373,3 +373,23 @@ def test_blocked_sherman_morrison_is_bitwise_identical(monkeypatch):
     for other in res[1:]:
         assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
         assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
+
+
+def test_ecp_point_and_wave_accumulation_agree(monkeypatch):
+    """The thread-per-point ECP accumulation (default for single-determinant wave functions) and the wave-per-walker
+    one (PQA_ECP_WAVE=1; always used with several determinants or a three-body factor) give the same energies."""
+    import pyqmc_amd as pa
+
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PQA_ECP_WAVE", flag)
+        wf = helpers.gpu_wf(mol, mf)
+        cfg = OpenConfigs(start.copy())
+        wf.recompute(cfg)
+        out.append(pa.EnergyAccumulator(mol, seed=3)(cfg, wf))
+    assert np.count_nonzero(out[0]["ecp"]) > 250
+    for k in out[0]:
+        assert note("ecp_point_vs_wave_" + k, relerr(out[0][k], out[1][k])) < 1e-12, k
