@@ -198,7 +198,7 @@ def main():
                                "launches": launches, "avg_launch_ms": orb_ms / launches,
                                "kernel_share_of_step": orb_ms / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.tstep)
         print(json.dumps(out), flush=True)
     if dist is not None:
