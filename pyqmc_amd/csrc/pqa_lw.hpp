@@ -256,27 +256,34 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
 // block instead of once per move (512*KB + 16384/KB bytes per move at n = 32: 2.7x less at KB = 8).
 // thread = (walker, row group g of G).  The 5*nmo cached orbital values of electron i are refreshed in slices
 // by the same groups.  NMAX >= n.
-template <int NMAX>
+template <int NMAX, bool FULLLINE>
 __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
                                                   const double* __restrict__ Rbuf, const double* __restrict__ Vbuf, long W,
                                                   int G, int j_lo, int j_hi) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int g = blockIdx.y;
-  if (w >= W || !mb.accept[w]) return;
+  if (w >= W) return;
+  // Rejected walkers take part in the loads and stores of the inverse rows (writing back what they read): a cache
+  // line holds 8 walkers, so it is fetched and written whenever one of them accepted anyway, and with every lane
+  // storing, the wave writes whole lines instead of byte-masked fragments.
+  const bool acc = mb.accept[w] != 0;
+  if (FULLLINE ? !__any(acc) : !acc) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   double* T = L.Tt[s] + w;
   double V[NMAX], R[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
-    V[k] = (k < n) ? Vbuf[(size_t)k * W + w] : 0.0;
-    R[k] = (k < n) ? Rbuf[(size_t)k * W + w] : 0.0;
+    V[k] = (k < n && acc) ? Vbuf[(size_t)k * W + w] : 0.0;
+    R[k] = (k < n && acc) ? Rbuf[(size_t)k * W + w] : 0.0;
   }
   for (int j = j_lo + g; j < j_hi; j += G) {
     double* Tj = T + (size_t)j * n * W;
     if (j == i) {
+      if (acc) {
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k)
-        if (k < n) Tj[(size_t)k * W] = R[k];
+        for (int k = 0; k < NMAX; ++k)
+          if (k < n) Tj[(size_t)k * W] = R[k];
+      }
       continue;
     }
     double t[NMAX];
@@ -288,8 +295,9 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
     }
 #pragma unroll
     for (int k = 0; k < NMAX; ++k)
-      if (k < n) Tj[(size_t)k * W] = t[k] - R[k] * tmp;
+      if (k < n) Tj[(size_t)k * W] = acc ? t[k] - R[k] * tmp : t[k];
   }
+  if (!acc) return;
   const double* row = motmp + (size_t)w * 5 * nmo;
   double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
 #pragma unroll 8
