@@ -12,6 +12,10 @@
 #pragma once
 #include "pqa_common.hpp"
 
+#ifndef PQA_PRIM_UNROLL
+#define PQA_PRIM_UNROLL 1
+#endif
+
 // p-th point lives at base + (p / group) * group_stride + (p % group) * 3
 struct PointAddr {
   const double* base;
@@ -42,6 +46,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
   const double r2 = x * x + y * y + z * z;
   double R = 0.0, dRs = 0.0, lapR = 0.0;
+#pragma unroll PQA_PRIM_UNROLL
   for (int p = 0; p < np; ++p) {
     const double a = pexp[p];
     const double t = pcoef[p] * exp(-a * r2);
@@ -236,12 +241,14 @@ __global__ void k_mo_valu(const double* __restrict__ ao, const double* __restric
 }
 
 // ---------------------------------------------------------------- fused AO -> MO, MFMA
-// AO index space is cut into chunks of <= KC functions made of whole shells; each chunk's shells
-// are pre-assigned to the G = 256/TP lane groups of a block (balanced by primitive count on the host).
+// The shells are packed into chunks of <= KC functions and, inside a chunk, into the G = 256/TP lane groups of a
+// block so that EVERY chunk gives every group the same amount of work (a barrier ends each chunk, so an unbalanced
+// chunk idles three waves).  The contraction does not care in which order the AOs arrive: a chunk's tile rows are
+// its shells in packing order (shell_kb), and the coefficient matrices are stored in that permuted row order.
 struct ChunkTab {
   int nchunk;
   const int* chunk_nk;    // AOs in chunk
-  const int* chunk_ao0;   // first AO
+  const int* shell_kb;    // [nshell] first tile row of the shell inside its chunk
   const int* chunk_row0;  // first row in the zero-padded coefficient matrices
   const int* cw_off[2];   // [nchunk*G+1] for G = 4 (TP=64) and G = 8 (TP=32)
   const int* cw_shell[2]; // shells for (chunk, group)
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       sh_meta[sh][0] = S.shell_l[sh];
       sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
       sh_meta[sh][2] = S.shell_prim_off[sh];
-      sh_meta[sh][3] = S.shell_ao_off[sh];
+      sh_meta[sh][3] = T.shell_kb[sh];
     }
     for (int p = tid; p < S.nprim; p += 256) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
     __syncthreads();
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   const int* __restrict__ cw_shell = T.cw_shell[TP == 64 ? 0 : 1];
 
   for (int ch = 0; ch < T.nchunk; ++ch) {
-    const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch], row0 = T.chunk_row0[ch];
+    const int nk = T.chunk_nk[ch], row0 = T.chunk_row0[ch];
     const int nk4 = (nk + 3) & ~3;
     // B operand of this chunk: issue the L2 loads now, consume them after phase 1
     double bq[KS][NU];
@@ -327,13 +334,13 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       double x, y, z;
       const double *pe, *pc;
       if (LDSTAB) {
-        l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3] - a0;
+        l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3];
         x = px - sh_xyz[sh][0]; y = py - sh_xyz[sh][1]; z = pz - sh_xyz[sh][2];
         pe = pr_exp + q0; pc = pr_coef + q0;
       } else {
         const int ia = S.shell_atom[sh];
         ia_ = ia;
-        q0 = S.shell_prim_off[sh]; kb = S.shell_ao_off[sh] - a0; l_ = S.shell_l[sh]; np_ = S.shell_prim_off[sh + 1] - q0;
+        q0 = S.shell_prim_off[sh]; kb = T.shell_kb[sh]; l_ = S.shell_l[sh]; np_ = S.shell_prim_off[sh + 1] - q0;
         x = px - S.atom_xyz[3 * ia]; y = py - S.atom_xyz[3 * ia + 1]; z = pz - S.atom_xyz[3 * ia + 2];
         pe = S.prim_exp + q0; pc = S.prim_coef + q0;
       }
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
     sh_meta[sh][0] = S.shell_l[sh];
     sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
     sh_meta[sh][2] = S.shell_prim_off[sh];
-    sh_meta[sh][3] = S.shell_ao_off[sh];
+    sh_meta[sh][3] = T.shell_kb[sh];
   }
   for (int p = tid; p < S.nprim; p += 512) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   __syncthreads();
@@ -442,12 +449,12 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
     if (producer) {
       if (ch < T.nchunk) {
         double (*tb)[KC][64] = tile[ch & 1];
-        const int nk = T.chunk_nk[ch], a0 = T.chunk_ao0[ch];
+        const int nk = T.chunk_nk[ch];
         const int nk4 = (nk + 3) & ~3;
         const int s_end = cw_off[ch * 4 + grp + 1];
         for (int si = cw_off[ch * 4 + grp]; si < s_end; ++si) {
           const int sh = cw_shell[si];
-          const int q0 = sh_meta[sh][2], kb = sh_meta[sh][3] - a0;
+          const int q0 = sh_meta[sh][2], kb = sh_meta[sh][3];
           const double x = px - sh_xyz[sh][0], y = py - sh_xyz[sh][1], z = pz - sh_xyz[sh][2];
           shell_eval<NCOMP>(sh_meta[sh][0], x, y, z, pr_exp + q0, pr_coef + q0, sh_meta[sh][1],
                             [&](int m, double v, double gx, double gy, double gz, double lp) {

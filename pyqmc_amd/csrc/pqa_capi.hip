@@ -27,7 +27,8 @@ struct DevBuf {
 };
 
 struct ChunkHost {
-  std::vector<int> nk, ao0, row0;
+  std::vector<int> nk, row0;
+  std::vector<int> shell_kb, shell_chunk;  // per shell: first tile row inside its chunk, chunk index
   std::vector<int> cw_off[2], cw_shell[2];  // shell lists per (chunk, lane group) for 4 and 8 groups
   int rows_pad = 0;
 };
@@ -162,38 +163,74 @@ static int check_launch(pqa_handle* h, const char* what) {
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
   for (int g = 0; g < 2; ++g) c.cw_off[g].push_back(0);
-  int sh = 0, rows = 0;
-  while (sh < h->nshell) {
-    const int first = sh;
-    int nk = 0;
-    while (sh < h->nshell && nk + (2 * h->shell_l[sh] + 1) <= KC) nk += 2 * h->shell_l[sh++] + 1;
-    c.nk.push_back(nk);
-    c.ao0.push_back(h->shell_ao[first]);
-    c.row0.push_back(rows);
-    rows += (nk + 3) & ~3;
-    // longest-processing-time assignment of the chunk's shells to the lane groups of a block
-    std::vector<int> order;
-    for (int s = first; s < sh; ++s) order.push_back(s);
-    auto cost = [&](int s) { return 12 * h->shell_np[s] + 6 * (2 * h->shell_l[s] + 1); };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
-    for (int g = 0; g < 2; ++g) {
-      const int G = g ? 8 : 4;
-      std::vector<std::vector<int>> lists(G);
-      std::vector<int> load(G, 0);
-      for (int s : order) {
-        int best = 0;
-        for (int q = 1; q < G; ++q)
-          if (load[q] < load[best]) best = q;
-        lists[best].push_back(s);
-        load[best] += cost(s);
+  c.shell_kb.assign((size_t)h->nshell, 0);
+  c.shell_chunk.assign((size_t)h->nshell, 0);
+  // phase-1 cost of a shell: radial part per primitive + angular part / tile stores per function
+  auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * (2 * h->shell_l[s] + 1) + 40; };
+  auto nfun = [&](int s) { return 2 * h->shell_l[s] + 1; };
+  int nao = 0;
+  for (int s = 0; s < h->nshell; ++s) nao += nfun(s);
+  // Longest-processing-time packing over (chunk, group) slots under the chunk's row capacity; if a shell does not
+  // fit anywhere a chunk is added.  4 groups per chunk (64-point tiles) is the layout that is balanced; the
+  // 8-group lists (32-point tiles) are a second LPT inside each chunk.
+  std::vector<int> order((size_t)h->nshell);
+  for (int s = 0; s < h->nshell; ++s) order[s] = s;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+  int nchunk = std::max((nao + KC - 1) / KC, 1);
+  std::vector<std::vector<int>> load, rows_used_dummy;
+  std::vector<int> rows;
+  std::vector<std::vector<std::vector<int>>> slot;  // [chunk][group] -> shells
+  for (;;) {
+    load.assign((size_t)nchunk, std::vector<int>(4, 0));
+    rows.assign((size_t)nchunk, 0);
+    slot.assign((size_t)nchunk, std::vector<std::vector<int>>(4));
+    bool ok = true;
+    for (int s : order) {
+      int bc = -1, bg = -1;
+      for (int ch = 0; ch < nchunk; ++ch) {
+        if (rows[ch] + nfun(s) > KC) continue;
+        for (int g = 0; g < 4; ++g)
+          if (bc < 0 || load[ch][g] < load[bc][bg]) { bc = ch; bg = g; }
       }
-      for (int q = 0; q < G; ++q) {
-        for (int s : lists[q]) c.cw_shell[g].push_back(s);
-        c.cw_off[g].push_back((int)c.cw_shell[g].size());
-      }
+      if (bc < 0) { ok = false; break; }
+      slot[bc][bg].push_back(s);
+      load[bc][bg] += cost(s);
+      rows[bc] += nfun(s);
+    }
+    if (ok) break;
+    ++nchunk;
+  }
+  int row0 = 0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (rows[ch] == 0) continue;  // (possible after a capacity retry)
+    const int ci = (int)c.nk.size();
+    c.nk.push_back(rows[ch]);
+    c.row0.push_back(row0);
+    row0 += (rows[ch] + 3) & ~3;
+    int kb = 0;
+    std::vector<int> members;
+    for (int g = 0; g < 4; ++g)
+      for (int s : slot[ch][g]) { c.shell_kb[s] = kb; c.shell_chunk[s] = ci; kb += nfun(s); members.push_back(s); }
+    for (int g = 0; g < 4; ++g) {
+      for (int s : slot[ch][g]) c.cw_shell[0].push_back(s);
+      c.cw_off[0].push_back((int)c.cw_shell[0].size());
+    }
+    std::stable_sort(members.begin(), members.end(), [&](int a, int b) { return cost(a) > cost(b); });
+    std::vector<std::vector<int>> l8(8);
+    std::vector<int> load8(8, 0);
+    for (int s : members) {
+      int best = 0;
+      for (int q = 1; q < 8; ++q)
+        if (load8[q] < load8[best]) best = q;
+      l8[best].push_back(s);
+      load8[best] += cost(s);
+    }
+    for (int q = 0; q < 8; ++q) {
+      for (int s : l8[q]) c.cw_shell[1].push_back(s);
+      c.cw_off[1].push_back((int)c.cw_shell[1].size());
     }
   }
-  c.rows_pad = rows;
+  c.rows_pad = row0;
 }
 
 // zero-padded coefficient matrix for one chunk table / spin
@@ -201,9 +238,10 @@ static int upload_cpad(pqa_handle* h, int t, int s, const double* mo_host) {
   const ChunkHost& c = h->chunks[t];
   const int ldc = 16 * h->nt[s], nmo = h->nmo[s];
   std::vector<double> pad((size_t)std::max(c.rows_pad, 1) * ldc, 0.0);
-  for (size_t ch = 0; ch < c.nk.size(); ++ch)
-    for (int k = 0; k < c.nk[ch]; ++k)
-      for (int j = 0; j < nmo; ++j) pad[(size_t)(c.row0[ch] + k) * ldc + j] = mo_host[(size_t)(c.ao0[ch] + k) * nmo + j];
+  for (int sh = 0; sh < h->nshell; ++sh)  // tile row (chunk, shell_kb + m)  <-  AO shell_ao[sh] + m
+    for (int m = 0; m < 2 * h->shell_l[sh] + 1; ++m)
+      for (int j = 0; j < nmo; ++j)
+        pad[(size_t)(c.row0[c.shell_chunk[sh]] + c.shell_kb[sh] + m) * ldc + j] = mo_host[(size_t)(h->shell_ao[sh] + m) * nmo + j];
   HIPCHK(hipMemcpy(h->d_cpad[t][s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -362,7 +400,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       ChunkTab& T = h->tab[t];
       T.nchunk = (int)c.nk.size();
       TRY(upload_table(h, c.nk.data(), c.nk.size(), &tmp_i)); T.chunk_nk = tmp_i;
-      TRY(upload_table(h, c.ao0.data(), c.ao0.size(), &tmp_i)); T.chunk_ao0 = tmp_i;
+      TRY(upload_table(h, c.shell_kb.data(), c.shell_kb.size(), &tmp_i)); T.shell_kb = tmp_i;
       TRY(upload_table(h, c.row0.data(), c.row0.size(), &tmp_i)); T.chunk_row0 = tmp_i;
       for (int g = 0; g < 2; ++g) {
         TRY(upload_table(h, c.cw_off[g].data(), c.cw_off[g].size(), &tmp_i)); T.cw_off[g] = tmp_i;
