@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pyqmc_amd as pa
-npts = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+npts = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mol = pa.systems.water_cluster(); mf = pa.systems.random_mf(mol)
 dev = pa.DeviceWF(mol, mo_coeff=mf.mo_coeff)
 rng = np.random.default_rng(0)
