@@ -327,7 +327,11 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
           bq[ks][u] = (ut < NT) ? crow[(long)ks * 4 * ldc + 16 * ut] : 0.0;
         }
     }
+#ifdef PQA_ABL_NOP1
+    const int s_end = 0;
+#else
     const int s_end = cw_off[ch * G + grp + 1];
+#endif
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
       const int sh = cw_shell[si];
       int l_, np_, q0, kb, ia_ = 0;
@@ -370,7 +374,11 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         for (int c = 0; c < NCOMP; ++c) {
           const double a = tile[c][k][col];
 #pragma unroll
+#ifdef PQA_ABL_NOMFMA
+          for (int u = 0; u < NU; ++u) acc[u][c][0] += a * bq[ks][u];
+#else
           for (int u = 0; u < NU; ++u) acc[u][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[ks][u], acc[u][c], 0, 0, 0);
+#endif
         }
       }
     }
