@@ -1177,7 +1177,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(ensure(h, h->b_ecnt, 2 * W * sizeof(int)));
     TRY(ensure(h, h->b_eoff, 2 * (W + 1) * sizeof(long)));
     TRY(ensure(h, h->b_ecp, W * sizeof(double)));
-    TRY(ensure(h, h->b_epass, (size_t)W * ((nrot + 63) / 64) * sizeof(unsigned long long)));
+    TRY(ensure(h, h->b_epass, (size_t)W * h->necp * ((h->N + 63) / 64) * sizeof(unsigned long long)));
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
     B.has_j2 = h->has_j2 ? 1 : 0;

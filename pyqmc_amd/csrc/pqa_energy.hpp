@@ -181,34 +181,40 @@ __device__ __forceinline__ bool ecp_pass(const SysDev& S, const EcpBuf& B, long 
 }
 
 // pass A: local part + number of auxiliary points per spin.  grid = W, block = 64.
+// Lanes run over the electrons, the loop over the ECP atoms: the atom (its channel / term tables, its coordinates) is
+// wave-uniform, so the tables come through the scalar cache and the channel loops do not diverge between O and H.
+// passbits[w][k][e-block]: which electrons passed the stochastic mask at atom k (k_ecp_fill walks them atom-major).
 __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, EcpBuf B, long W) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double loc = 0.0;
   int c_up = 0, c_dn = 0;
-  const int npair = S.nelec * S.necp, nblk = (npair + 63) / 64;
-  for (int q0 = 0; q0 < npair; q0 += 64) {
-    const int q = q0 + lane;
-    bool pass = false;
-    if (q < npair) {
-      const int e = q / S.necp, k = q % S.necp, ia = S.ecp_atom[k];
-      double dx = xw[3 * e] - S.atom_xyz[3 * ia], dy = xw[3 * e + 1] - S.atom_xyz[3 * ia + 1],
-             dz = xw[3 * e + 2] - S.atom_xyz[3 * ia + 2];
-      min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
-      const double r = sqrt(dx * dx + dy * dy + dz * dz);
-      double v[PQA_MAXCHAN], prob;
-      int nch;
-      ecp_radial(S, k, r, B.threshold, v, nch, prob);
-      loc += v[nch - 1];
-      pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
-      if (pass) {
-        const int naip = (nch <= 2) ? 6 : 12;
-        if (e < S.nup) c_up += naip; else c_dn += naip;
+  const int neb = (S.nelec + 63) / 64;
+  for (int eb = 0; eb < neb; ++eb) {
+    const int e = eb * 64 + lane;
+    const bool live = e < S.nelec;
+    const double ex = live ? xw[3 * e] : 0.0, ey = live ? xw[3 * e + 1] : 0.0, ez = live ? xw[3 * e + 2] : 0.0;
+    for (int k = 0; k < S.necp; ++k) {
+      const int ia = S.ecp_atom[k];
+      bool pass = false;
+      if (live) {
+        double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+        min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
+        const double r = sqrt(dx * dx + dy * dy + dz * dz);
+        double v[PQA_MAXCHAN], prob;
+        int nch;
+        ecp_radial(S, k, r, B.threshold, v, nch, prob);
+        loc += v[nch - 1];
+        pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
+        if (pass) {
+          const int naip = (nch <= 2) ? 6 : 12;
+          if (e < S.nup) c_up += naip; else c_dn += naip;
+        }
       }
+      const unsigned long long m = __ballot(pass);
+      if (lane == 0) B.passbits[((size_t)w * S.necp + k) * neb + eb] = m;
     }
-    const unsigned long long m = __ballot(pass);  // remembered for k_ecp_fill: it only visits the pairs that passed
-    if (lane == 0) B.passbits[(size_t)w * nblk + q0 / 64] = m;
   }
   loc = wave_sum(loc);
 #pragma unroll
@@ -246,14 +252,14 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   long run[2] = {B.off[w], B.off[(W + 1) + w]};
-  const int nblk = (S.nelec * S.necp + 63) / 64;
-  for (int q0 = 0; q0 < S.nelec * S.necp; q0 += 64) {
-    unsigned long long m = B.passbits[(size_t)w * nblk + q0 / 64];  // the mask k_ecp_count drew
-    while (m) {  // whole wave cooperates on one (electron, atom) entry at a time, in e-major order
+  const int neb = (S.nelec + 63) / 64;
+  for (int q0 = 0; q0 < S.necp * neb; ++q0) {
+    const int k = q0 / neb, eb = q0 % neb;
+    unsigned long long m = B.passbits[(size_t)w * S.necp * neb + q0];  // the mask k_ecp_count drew
+    while (m) {  // whole wave cooperates on one (electron, atom) entry at a time, atom-major
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
-      const int qq = q0 + src;
-      const int e = qq / S.necp, k = qq % S.necp, ia = S.ecp_atom[k], s = e >= S.nup;
+      const int e = eb * 64 + src, ia = S.ecp_atom[k], s = e >= S.nup;
       const double ax = S.atom_xyz[3 * ia], ay = S.atom_xyz[3 * ia + 1], az = S.atom_xyz[3 * ia + 2];
       double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
       min_image(S, dx, dy, dz);
