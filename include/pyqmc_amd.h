@@ -191,6 +191,15 @@ int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* 
 int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs);
 int pqa_get_configs(pqa_handle_t* h, double* configs);
 
+/* testvalue_many (Slater slater.py:448-460, JastrowSpin jastrowspin.py:421-455, ThreeBodyJastrow
+   three_body_jastrow.py:343-372, MultiplyWF multiplywf.py:112-114; used by the density-matrix accumulators
+   observables/obdm.py:175, tbdm.py:239): for ONE auxiliary position per row, the ratio Psi(electron es[i] moved there)/Psi
+   for each of the ne listed electrons.  pts (nrow,3); widx (nrow) walker index per row or NULL (nrow = W);
+   factors: bit 0 Slater, bit 1 two-body Jastrow, bit 2 three-body Jastrow (their product is returned);
+   out (nrow, ne). */
+int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
+                       int factors, double* out);
+
 /* Periodic Coulomb energy: tables of the Ewald sum (Ewald.__init__ / set_up_reciprocal_ewald_sum / set_ewald_constants,
    observables/ewald.py:95-190; built by pyqmc_amd/ewald.py).  gpoints (ng,3): reciprocal vectors of the positive half
    space with weight > 1e-10 (:372-388); gweight (ng) = 4 pi exp(-G^2/4 alpha^2) / (V G^2); ion_cos/ion_sin (ng): real and

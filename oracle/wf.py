@@ -20,7 +20,14 @@ def _phase(x):
     return np.sign(x) if not np.iscomplexobj(x) else x / np.abs(x)
 
 
-class Slater:
+class _ManyMixin:
+    def testvalue_many(self, es, epos, mask=None):
+        """``testvalue_many`` of every factor (slater.py:448-460, jastrowspin.py:421-455, three_body_jastrow.py:343-372,
+        multiplywf.py:112-114): column i is ``testvalue(es[i], epos)`` — one auxiliary position, several electrons."""
+        return np.stack([np.asarray(self.testvalue(int(e), epos, mask)[0]) for e in np.atleast_1d(es)], axis=1)
+
+
+class Slater(_ManyMixin):
     """Multi-determinant Slater wave function (``pyqmc/wf/slater.py:97-460``).
 
     mol: Mol-like; mo_coeff: (2, nao, nmo_s) per spin (already truncated to the used
@@ -192,7 +199,7 @@ class Slater:
         self._dets[s][1][mask] += np.log(np.abs(ratio))
 
 
-class JastrowSpin:
+class JastrowSpin(_ManyMixin):
     """One- and two-body spin Jastrow e^U (``pyqmc/wf/jastrowspin.py:20-419``).
 
     a_basis / b_basis: lists of ("pade",beta)/("cusp",gamma) with common rcut."""
@@ -346,7 +353,7 @@ class JastrowSpin:
         self._x[mask, e, :] = epos.configs[mask]
 
 
-class MultiplyWF:
+class MultiplyWF(_ManyMixin):
     """Product of factors (``pyqmc/wf/multiplywf.py:71-132``)."""
 
     def __init__(self, *wf_factors):
@@ -388,7 +395,7 @@ class MultiplyWF:
         return np.sum(g, axis=0), np.sum(l, axis=0) + 2 * cross
 
 
-class ThreeBodyJastrow:
+class ThreeBodyJastrow(_ManyMixin):
     """Electron-electron-ion Jastrow e^U (``pyqmc/wf/three_body_jastrow.py:19-655``):
 
         U = 1/2 sum_e P_e,   P_e = sum_{j != e} sum_I sum_{klm} C_{Iklm,s(e,j)} a_k(r_eI) a_l(r_jI) b_m(r_ej),

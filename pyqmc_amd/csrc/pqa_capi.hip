@@ -63,7 +63,7 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2];
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves;
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
   long wrap_W = 0;
@@ -496,7 +496,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1]};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -836,6 +836,44 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
   TRY(copy_out(h, out, h->b_out.p, (size_t)P * ncomp * sizeof(double)));
   if (keep_saved && npt == 1 && !widx && ncomp == 5) { h->saved_valid = true; h->saved_e = e; }
   return 0;
+}
+
+extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
+                                  int factors, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  if (nrow <= 0 || ne <= 0) return 0;
+  if (!widx && nrow != h->W) FAIL("nrow must equal the number of walkers when widx is NULL");
+  if ((factors & 1) && !h->has_slater) FAIL("handle has no Slater factor");
+  if ((factors & 2) && !h->has_j2) FAIL("handle has no two-body Jastrow factor");
+  if ((factors & 4) && !h->has_j3) FAIL("handle has no three-body Jastrow factor");
+  if (!(factors & 7)) FAIL("no factor selected");
+  std::vector<int> he((size_t)ne);
+  HIPCHK(hipMemcpy(he.data(), es, (size_t)ne * sizeof(int), hipMemcpyDefault));
+  for (int e : he)
+    if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_pts, (size_t)nrow * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_out, (size_t)nrow * ne * sizeof(double)));
+  TRY(ensure(h, h->b_tves, (size_t)ne * sizeof(int)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)nrow * 3 * sizeof(double)));
+  TRY(copy_in(h, h->b_tves.p, he.data(), (size_t)ne * sizeof(int)));
+  const int* dw = nullptr;
+  if (widx) {
+    TRY(ensure(h, h->b_widx, (size_t)nrow * sizeof(int)));
+    TRY(copy_in(h, h->b_widx.p, widx, (size_t)nrow * sizeof(int)));
+    dw = (const int*)h->b_widx.p;
+  }
+  if (factors & 1)
+    for (int s = 0; s < 2; ++s) {
+      TRY(ensure(h, h->b_emo[s], (size_t)nrow * std::max(h->nmo[s], 1) * sizeof(double)));
+      TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, nrow), nrow, 1, (double*)h->b_emo[s].p));
+    }
+  hipLaunchKernelGGL(k_testvalue_many, dim3((unsigned)nrow), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js,
+                     (const int*)h->b_tves.p, ne, (const double*)h->b_pts.p, (const double*)h->b_emo[0].p,
+                     (const double*)h->b_emo[1].p, (long)nrow, dw, factors, (double*)h->b_out.p);
+  TRY(check_launch(h, "k_testvalue_many"));
+  return copy_out(h, out, h->b_out.p, (size_t)nrow * ne * sizeof(double));
 }
 
 extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {

@@ -521,3 +521,39 @@ __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, Ja
     if (threadIdx.x == 0) ratio[o] = rat;
   }
 }
+
+// ---------------------------------------------------------------- testvalue_many (density-matrix accumulators)
+// out[r][idx] = Psi(electron es[idx] moved to pts[r]) / Psi for every listed electron, ONE auxiliary position per row
+// (Slater.testvalue_many slater.py:448-460, JastrowSpin.testvalue_many jastrowspin.py:421-455, ThreeBodyJastrow
+// three_body_jastrow.py:343-372, product multiplywf.py:112-114).  factors: bit 0 Slater, bit 1 two-body, bit 2 three-body.
+// mo_up / mo_dn: [nrow][nmo_s] orbital values at the auxiliary positions.  Block = one wave per row.
+__global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st, JastrowState js, const int* __restrict__ es, int ne,
+                                                       const double* __restrict__ pts, const double* __restrict__ mo_up,
+                                                       const double* __restrict__ mo_dn, long nrow,
+                                                       const int* __restrict__ widx, int factors, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long r = blockIdx.x;
+  const long w = widx ? widx[r] : r;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double px = pts[3 * r], py = pts[3 * r + 1], pz = pts[3 * r + 2];
+  const int parts = (factors >> 1) & 3;
+  for (int idx = 0; idx < ne; ++idx) {
+    const int e = es[idx], s = e >= S.nup, i = e - s * S.nup;
+    double val = 1.0;
+    if (factors & 1) {
+      double r1[1];
+      slater_ratios<1>(S, st, s, i, w, (s ? mo_dn : mo_up) + (size_t)r * S.nmo[s], r1, lds);
+      val *= r1[0];
+      __syncthreads();
+    }
+    if (parts) {
+      double g[3], lp, U0, U;
+      jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, parts, lds + S.j3_off);
+      __syncthreads();
+      jas_eval<0>(S, xw, e, px, py, pz, U, g, lp, parts, lds + S.j3_off);
+      __syncthreads();
+      val *= exp(U - U0);
+    }
+    if (threadIdx.x == 0) out[(size_t)r * ne + idx] = val;
+  }
+}

@@ -304,6 +304,24 @@ def _points(epos, mask):
     return pts, widx, aux
 
 
+def _testvalue_many(dev, factors, e, epos, mask):
+    """(nrow, len(e)) ratios Psi(e_i -> epos)/Psi for ONE auxiliary position per walker (``testvalue_many``)."""
+    es = np.ascontiguousarray(np.atleast_1d(e), dtype=np.int32)
+    x = np.asarray(epos.configs, dtype=float)
+    if x.ndim != 2:
+        raise ValueError("testvalue_many takes one position per walker: epos.configs (nconf, 3)")
+    widx = None
+    if mask is not None:
+        mask = np.asarray(mask, dtype=bool)
+        widx = np.ascontiguousarray(np.nonzero(mask)[0], dtype=np.int32)
+        x = x[mask]
+    pts = np.ascontiguousarray(x)
+    out = np.empty((len(pts), len(es)))
+    if len(pts) and len(es):
+        dev.call("pqa_testvalue_many", _ffi.ptr(es), len(es), _ffi.ptr(pts), len(pts), _ffi.ptr(widx), int(factors), _ffi.ptr(out))
+    return out
+
+
 def orbital_inputs(mol, mf, determinants=None):
     """(mol, mo_coeff (2)[nao, nmo], determinants) the device is built from — the role of
     ``pyscftools.orbital_evaluator_from_pyscf`` (pyscftools.py:105-191).  Open systems pass through.  A periodic
@@ -421,6 +439,10 @@ class Slater:
         r = r[0].reshape(nrow, npt) if aux else r[0]
         return r, None
 
+    def testvalue_many(self, e, epos, mask=None):
+        """slater.py:448-460: ratios for moving each electron of ``e`` to ``epos`` -> (nconf[mask], len(e))."""
+        return _testvalue_many(self._dev, 1, e, epos, mask)
+
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
         s = self._spin(e)
         flag = C.c_int()
@@ -484,6 +506,10 @@ class JastrowSpin:
     def testvalue(self, e, epos, mask=None):
         r, nrow, npt, aux = self._eval(e, epos, mask, 0)
         return (r.reshape(nrow, npt) if aux else r), None
+
+    def testvalue_many(self, e, epos, mask=None):
+        """jastrowspin.py:421-455 -> (nconf[mask], len(e))."""
+        return _testvalue_many(self._dev, 2, e, epos, mask)
 
     def gradient_value(self, e, epos):
         r, *_ = self._eval(e, epos, None, 1)
@@ -555,6 +581,10 @@ class ThreeBodyJastrow:
     def testvalue(self, e, epos, mask=None):
         r, nrow, npt, aux = self._eval(e, epos, mask, 0)
         return (r.reshape(nrow, npt) if aux else r), None
+
+    def testvalue_many(self, e, epos, mask=None):
+        """three_body_jastrow.py:343-372 -> (nconf[mask], len(e))."""
+        return _testvalue_many(self._dev, 4, e, epos, mask)
 
     def gradient_value(self, e, epos):
         r, *_ = self._eval(e, epos, None, 1)
@@ -644,6 +674,16 @@ class MultiplyWF:
     def testvalue(self, e, epos, mask=None):
         vals, saved = zip(*[w.testvalue(e, epos, mask=mask) for w in self.wf_factors])
         return np.prod(vals, axis=0), saved
+
+    def testvalue_many(self, e, epos, mask=None):
+        """multiplywf.py:112-114; one fused call when all factors share a device handle."""
+        dev = self.fused_device()
+        if dev is not None:
+            bits = 0
+            for w in self.wf_factors:
+                bits |= {Slater: 1, JastrowSpin: 2, ThreeBodyJastrow: 4}[type(w)]
+            return _testvalue_many(dev, bits, e, epos, mask)
+        return np.prod([w.testvalue_many(e, epos, mask=mask) for w in self.wf_factors], axis=0)
 
     def gradient_value(self, e, epos):
         g, v, s = zip(*[w.gradient_value(e, epos) for w in self.wf_factors])

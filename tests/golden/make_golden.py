@@ -765,6 +765,56 @@ def g_pbc_dmc():
     save("g17_pbc_dmc", **out)
 
 
+
+# ------------------------------------------------------------------ G18 testvalue_many (density-matrix accumulators)
+def g_testvalue_many():
+    import pyqmc.wftools as wftools
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    # open: 12-determinant H2O, Slater x two-body x three-body
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = systems.random_determinants(mol, mf, 12)
+    wf, _ = pyq.generate_wf(mol, mf, jastrow=[pyq.generate_jastrow, wftools.generate_jastrow3], jastrow_kws=[{}, {}],
+                            slater_kws=dict(evaluate_orbitals_with="numba", determinants=dets))
+    rng = np.random.default_rng(11)
+    j2, j3 = wf.wf_factors[1], wf.wf_factors[2]
+    j2.parameters["acoeff"] = 0.05 * rng.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * rng.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    j3.parameters["ccoeff"] = 0.1 * np.random.default_rng(12).standard_normal(j3.parameters["ccoeff"].shape)
+    W = 6
+    configs = walkers(mol, W, 81)
+    out["h2o_configs"] = configs.configs.copy()
+    wf.recompute(configs)
+    prng = np.random.default_rng(82)
+    aux = prng.standard_normal((W, 3)) * 1.5
+    mask = prng.random(W) > 0.3
+    mask[0] = True
+    es = np.array([0, 3, 4, 7, 5])
+    out["h2o_aux"], out["h2o_mask"], out["h2o_es"] = aux, mask, es
+    epos = configs.make_irreducible(0, aux)
+    for nm, w in (("slater", wf.wf_factors[0]), ("j2", j2), ("j3", j3), ("wf", wf)):
+        out[f"h2o_{nm}"] = w.testvalue_many(es, epos)
+        # (no masked goldens: the reference's testvalue_many allocate for all walkers and fail on a real mask,
+        #  slater.py:454, jastrowspin.py:438; its accumulators never pass one)
+    # periodic: diamond 4-fold supercell, Slater x two-body
+    sup, pwf = ref_pbc_wf("fcc2cubic")
+    W = 3
+    cfg = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(83)).configs.copy(), sup.lattice_vectors())
+    out["pbc_configs"], out["pbc_wrap"] = cfg.configs.copy(), cfg.wrap.copy()
+    pwf.recompute(cfg)
+    aux = (prng.random((W, 3)) * 3 - 1) @ sup.lattice_vectors()
+    es = np.array([1, 15, 16, 30])
+    out["pbc_aux"], out["pbc_es"] = aux, es
+    epos = cfg.make_irreducible(0, aux)
+    for nm, w in (("slater", pwf.wf_factors[0]), ("j2", pwf.wf_factors[1]), ("wf", pwf)):
+        out[f"pbc_{nm}"] = w.testvalue_many(es, epos)
+    save("g18_testvalue_many", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -846,3 +896,4 @@ if __name__ == "__main__":
     g_pbc_slater()
     g_pbc_energy()
     g_pbc_dmc()
+    g_testvalue_many()

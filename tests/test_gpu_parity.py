@@ -393,3 +393,32 @@ def test_ecp_point_and_wave_accumulation_agree(monkeypatch):
     assert np.count_nonzero(out[0]["ecp"]) > 250
     for k in out[0]:
         assert note("ecp_point_vs_wave_" + k, relerr(out[0][k], out[1][k])) < 1e-12, k
+
+
+def test_testvalue_many_golden():
+    """testvalue_many (slater.py:448-460, jastrowspin.py:421-455, three_body_jastrow.py:343-372, multiplywf.py:112-114):
+    every factor and the fused product against the reference, open (12 determinants x 2-body x 3-body) and periodic
+    (diamond supercell); a mask returns the masked rows of the full result."""
+    import ast
+
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g18_testvalue_many")
+    g7 = golden("g7_jastrow3_multidet")
+    mol = systems.water()
+    wf = helpers.gpu_wf3(mol, systems.random_mf(mol, nvirt=6), ast.literal_eval(str(g7["det_json"])))
+    cfg = OpenConfigs(g["h2o_configs"].copy())
+    wf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g["h2o_aux"])
+    for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("j3", wf.wf_factors[2]), ("wf", wf)):
+        full = w.testvalue_many(g["h2o_es"], epos)
+        assert note("tvmany_" + nm, relerr(full, g[f"h2o_{nm}"])) < 1e-10, nm
+        assert np.array_equal(w.testvalue_many(g["h2o_es"], epos, mask=g["h2o_mask"]), full[g["h2o_mask"]])
+    # column i equals testvalue(es[i])
+    assert relerr(wf.testvalue_many(np.array([5]), epos)[:, 0], wf.testvalue(5, epos)[0]) < 1e-13
+    sup, pwf = helpers.gpu_pbc_wf("fcc2cubic")
+    cfg = PeriodicConfigs(g["pbc_configs"].copy(), sup.lattice_vectors(), wrap=g["pbc_wrap"].copy())
+    pwf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g["pbc_aux"])
+    for nm, w in (("slater", pwf.wf_factors[0]), ("j2", pwf.wf_factors[1]), ("wf", pwf)):
+        assert note("tvmany_pbc_" + nm, relerr(w.testvalue_many(g["pbc_es"], epos), g[f"pbc_{nm}"])) < 2e-9, nm

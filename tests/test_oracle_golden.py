@@ -181,3 +181,28 @@ def test_g7_three_body_jastrow_multidet():
     assert relerr(cfg.configs, g["vmc_final"]) < 1e-9
     for k in ("energyke", "energyecp", "energytotal", "acceptance"):
         assert relerr(blk[k], g["vmc_blk_" + k]) < 1e-8, k
+
+
+def test_testvalue_many_matches_reference():
+    """testvalue_many (used by the density-matrix accumulators) on the 12-determinant Slater x 2-body x 3-body H2O wave
+    function and on a periodic diamond supercell (tests/golden/g18_testvalue_many.npz)."""
+    import ast
+
+    from helpers import oracle_pbc_wf, oracle_wf3
+    from pyqmc_amd.configs import OpenConfigs, PeriodicConfigs
+
+    g = golden("g18_testvalue_many")
+    g7 = golden("g7_jastrow3_multidet")
+    mol = systems.water()
+    wf = oracle_wf3(mol, systems.random_mf(mol, nvirt=6), ast.literal_eval(str(g7["det_json"])))
+    cfg = OpenConfigs(g["h2o_configs"].copy())
+    wf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g["h2o_aux"])
+    for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("j3", wf.wf_factors[2]), ("wf", wf)):
+        assert relerr(w.testvalue_many(g["h2o_es"], epos), g[f"h2o_{nm}"]) < 1e-10, nm
+    sup, pwf = oracle_pbc_wf("fcc2cubic")
+    cfg = PeriodicConfigs(g["pbc_configs"].copy(), sup.lattice_vectors(), wrap=g["pbc_wrap"].copy())
+    pwf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g["pbc_aux"])
+    for nm, w in (("slater", pwf.wf_factors[0]), ("j2", pwf.wf_factors[1]), ("wf", pwf)):
+        assert relerr(w.testvalue_many(g["pbc_es"], epos), g[f"pbc_{nm}"]) < 1e-9, nm
