@@ -191,6 +191,15 @@ int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* 
 int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs);
 int pqa_get_configs(pqa_handle_t* h, double* configs);
 
+/* Slater.pgradient (slater.py:462-542): d Psi / Psi with respect to the determinant coefficients, d_det (W, ndet)
+   (:495-505), and to the orbital coefficients of each spin, d_mo_* (W, nao, nmo_s) (:507-533, _testcol :382-388),
+   from the resident state (call after recompute / updateinternals).  Any output may be NULL. */
+int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn);
+
+/* ThreeBodyJastrow.pgradient (three_body_jastrow.py:657-719): dU/dccoeff, d_ccoeff (W, natom, na3, na3, nb3, 3), from the
+   stored walker coordinates. */
+int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff);
+
 /* testvalue_many (Slater slater.py:448-460, JastrowSpin jastrowspin.py:421-455, ThreeBodyJastrow
    three_body_jastrow.py:343-372, MultiplyWF multiplywf.py:112-114; used by the density-matrix accumulators
    observables/obdm.py:175, tbdm.py:239): for ONE auxiliary position per row, the ratio Psi(electron es[i] moved there)/Psi

@@ -99,6 +99,7 @@ class Slater(_ManyMixin):
         """slater.py:227-260: AO -> MO -> per unique determinant slogdet and inverse."""
         x = configs.configs
         nconf, nelec, _ = x.shape
+        self._x_last = x.copy()
         self._dets, self._inverse = [], []
         for s in (0, 1):
             b, e = self._nelec[0] * s, self._nelec[0] + self._nelec[1] * s
@@ -121,6 +122,32 @@ class Slater(_ManyMixin):
             sign = np.nan_to_num(tot / np.abs(tot))
             logv = np.nan_to_num(np.log(np.abs(tot)) + ref)
         return sign, logv
+
+    def pgradient(self):
+        """slater.py:462-542: d Psi/Psi w.r.t. det_coeff (W, ndet) and mo_coeff_* (W, nao, nmo) — needs the walker
+        coordinates of the last recompute (the reference keeps the AO values ``_aovals`` for this)."""
+        sign, logv = self.value()
+        lu = self._dets[0][1][:, self._det_map[0]]
+        ld = self._dets[1][1][:, self._det_map[1]]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ddet = np.where(sign[:, None] != 0,
+                            self._dets[0][0][:, self._det_map[0]] * self._dets[1][0][:, self._det_map[1]]
+                            * np.exp(lu + ld - logv[:, None]) / sign[:, None], 0.0)
+        out = {"det_coeff": ddet}
+        W = len(sign)
+        for s, name in ((0, "mo_coeff_alpha"), (1, "mo_coeff_beta")):
+            b, e = self._nelec[0] * s, self._nelec[0] + self._nelec[1] * s
+            ao, _ = self._mo(self._x_last[:, b:e].reshape(-1, 3), s, 1)
+            ao = ao[0].reshape(W, e - b, -1)  # (W, n, nao)
+            nmo = self.parameters[name].shape[1]
+            g = np.zeros((W, ao.shape[-1], nmo))
+            for di, coeff in enumerate(self.parameters["det_coeff"]):
+                u = self._det_map[s][di]
+                for col, m in enumerate(self._det_occup[s][u]):  # _testcol: sum_e ao[w,e,a] inverse[w,u,col,e]
+                    g[:, :, m] += coeff * ddet[:, di, None] * np.einsum("wea,we->wa", ao, self._inverse[s][:, u, col, :])
+            if g.size:
+                out[name] = g
+        return out
 
     def _row_ratios(self, e, mo_rows, mask=None):
         """Ratio of replacing row ``e`` by mo_rows[...] for each leading component.
@@ -197,6 +224,7 @@ class Slater(_ManyMixin):
         self._inverse[s][mask] = inv
         self._dets[s][0][mask] *= _phase(ratio)
         self._dets[s][1][mask] += np.log(np.abs(ratio))
+        self._x_last[mask, e] = epos.configs[mask]
 
 
 class JastrowSpin(_ManyMixin):
@@ -268,6 +296,10 @@ class JastrowSpin(_ManyMixin):
         u = np.sum(self._bvalues * self.parameters["bcoeff"], axis=(2, 1))
         u += np.einsum("ijkl,jkl->i", self._avalues, self.parameters["acoeff"])
         return np.ones(len(u)), u
+
+    def pgradient(self):
+        """jastrowspin.py:457-464: the stored sums."""
+        return {"bcoeff": self._bvalues.copy(), "acoeff": self._avalues.copy()}
 
     def _new_partials(self, e, x_new, mask):
         """a- and b- partial sums of electron e placed at x_new (Wm[,naip],3)
@@ -354,6 +386,10 @@ class JastrowSpin(_ManyMixin):
 
 
 class MultiplyWF(_ManyMixin):
+    def pgradient(self):
+        """multiplywf.py:131-132, as {"wf{i}{key}": array}."""
+        return {f"wf{i + 1}{k}": v for i, w in enumerate(self.wf_factors) for k, v in w.pgradient().items()}
+
     """Product of factors (``pyqmc/wf/multiplywf.py:71-132``)."""
 
     def __init__(self, *wf_factors):
@@ -421,6 +457,25 @@ class ThreeBodyJastrow(_ManyMixin):
     def _C(self):
         c = self.parameters["ccoeff"]
         return 0.5 * (c + c.swapaxes(1, 2))
+
+    def pgradient(self):
+        """three_body_jastrow.py:657-719: dU/dc[I,k,l,m,sp] = 1/2 (X + X^T_kl), X = sum over pairs (i,j) of spin class sp of
+        a_k(r_iI) a_l(r_jI) b_m(r_ij) (sp: up-up i<j, up-down, down-down i<j)."""
+        x = self._x
+        W, N = x.shape[:2]
+        nup = self._nup
+        dI = self._mi(x[:, :, None, :] - self.atoms[None, None])  # (W,N,A,3)
+        a = jastrow_basis.evaluate(self.a_basis, self.rcut, dI, np.linalg.norm(dI, axis=-1), "value")  # (W,N,A,k)
+        out = np.zeros((W, len(self.atoms), len(self.a_basis), len(self.a_basis), len(self.b_basis), 3))
+        for sp, (ri, rj) in enumerate(((range(nup), range(nup)), (range(nup), range(nup, N)), (range(nup, N), range(nup, N)))):
+            for i in ri:
+                js = [j for j in rj if (j > i or sp == 1)]
+                if not js:
+                    continue
+                d = self._mi(x[:, i, None, :] - x[:, js])
+                b = jastrow_basis.evaluate(self.b_basis, self.rcut, d, np.linalg.norm(d, axis=-1), "value")  # (W,nj,m)
+                out[..., sp] += np.einsum("wIk,wjIl,wjm->wIklm", a[:, i], a[:, js], b)
+        return {"ccoeff": 0.5 * (out + out.swapaxes(2, 3))}
 
     def _terms(self, e, pos, xw, want):
         """P, grad P (3,...), lap P of electron e at pos (Wm,3) against walkers xw (Wm,N,3)."""

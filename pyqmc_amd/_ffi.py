@@ -55,6 +55,8 @@ _PROTOTYPES = {
     "pqa_device_count": (C.c_int, []),
     "pqa_set_param": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int64]),
     "pqa_get_param": (C.c_int, [_H, C.c_char_p, C.c_void_p, C.c_int64]),
+    "pqa_slater_pgradient": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pqa_j3_pgradient": (C.c_int, [_H, C.c_void_p]),
     "pqa_testvalue_many": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "pqa_set_ewald": (C.c_int, [_H, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "pqa_get_wrap": (C.c_int, [_H, C.c_void_p]),

@@ -63,7 +63,8 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet;
+  int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
   long wrap_W = 0;
@@ -388,6 +389,17 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
       S.nmo[s] = h->nmo[s]; S.ndet_s[s] = h->ndet_s[s];
       TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
+      {
+        std::vector<int> occ_h((size_t)h->ndet_s[s] * nel[s]), cm((size_t)h->ndet_s[s] * std::max(h->nmo[s], 1), -1);
+        if (!occ_h.empty()) HIPCHK(hipMemcpy(occ_h.data(), occ_src[s], occ_h.size() * sizeof(int), hipMemcpyDefault));
+        for (int u = 0; u < h->ndet_s[s]; ++u)
+          for (int k = 0; k < nel[s]; ++k) {
+            const int m = occ_h[(size_t)u * nel[s] + k];
+            if (m < 0 || m >= h->nmo[s]) FAIL("determinant occupation outside the orbital range");
+            cm[(size_t)u * h->nmo[s] + m] = k;
+          }
+        TRY(upload_table(h, cm.data(), cm.size(), &h->d_colmap[s]));
+      }
       TRY(upload_table<double>(h, nullptr, (size_t)h->nao * std::max(h->nmo[s], 1), &h->d_mo[s])); S.mo[s] = h->d_mo[s];
       for (int t = 0; t < 2; ++t)
         TRY(upload_table<double>(h, nullptr, (size_t)(std::max(h->chunks[t].rows_pad, 1) + 32) * 16 * h->nt[s], &h->d_cpad[t][s]));
@@ -496,7 +508,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -876,6 +888,37 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
   return copy_out(h, out, h->b_out.p, (size_t)nrow * ne * sizeof(double));
 }
 
+extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
+  const long W = h->W;
+  TRY(slater_value_dev(h));  // sign / log of the determinant expansion -> b_sign, b_log
+  TRY(ensure(h, h->b_pgdet, (size_t)W * h->ndet * sizeof(double)));
+  hipLaunchKernelGGL(k_pgrad_det, dim3((unsigned)((W * h->ndet + 255) / 256)), dim3(256), 0, h->stream, h->S, h->st,
+                     (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
+  TRY(check_launch(h, "k_pgrad_det"));
+  if (d_det) TRY(copy_out(h, d_det, h->b_pgdet.p, (size_t)W * h->ndet * sizeof(double)));
+  double* outs[2] = {d_mo_up, d_mo_dn};
+  if (!d_mo_up && !d_mo_dn) return 0;
+  const size_t nao_all = (size_t)W * h->N * h->nao;
+  if (nao_all * sizeof(double) > ((size_t)16 << 30)) FAIL("orbital-coefficient gradients need the AO values of all electrons: too many walkers for one call");
+  TRY(ensure(h, h->b_ao, nao_all * sizeof(double)));
+  hipLaunchKernelGGL(k_ao<1>, dim3((unsigned)((W * h->N + 63) / 64)), dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N,
+                     (double*)h->b_ao.p);
+  TRY(check_launch(h, "k_ao"));
+  for (int s = 0; s < 2; ++s) {
+    const int n = s ? h->ndn : h->nup;
+    if (!outs[s] || n == 0 || h->nmo[s] == 0) continue;
+    const size_t nout = (size_t)W * h->nao * h->nmo[s];
+    TRY(ensure(h, h->b_out, nout * sizeof(double)));
+    hipLaunchKernelGGL(k_pgrad_mo, dim3((unsigned)W), dim3(256), (size_t)h->ndet_s[s] * sizeof(double), h->stream, h->S, h->st, s,
+                       (const double*)h->b_ao.p, (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
+    TRY(check_launch(h, "k_pgrad_mo"));
+    TRY(copy_out(h, outs[s], h->b_out.p, nout * sizeof(double)));
+  }
+  return 0;
+}
+
 extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
@@ -1000,6 +1043,20 @@ extern "C" int pqa_j3_value(pqa_handle_t* h, double* logval) {
   if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
   TRY(j3_value_dev(h));
   return copy_out(h, logval, h->b_j3u.p, h->W * sizeof(double));
+}
+
+extern "C" int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
+  const long W = h->W;
+  const size_t E = (size_t)h->natom * h->na3 * h->na3 * h->nb3 * 3;
+  const size_t lds = ((size_t)h->N * h->natom * h->na3 + (size_t)h->N * (h->N - 1) / 2 * h->nb3) * sizeof(double);
+  if (lds > 150 * 1024) FAIL("three-body parameter gradient: the a/b value tables of one walker do not fit LDS");
+  TRY(ensure(h, h->b_out, (size_t)W * E * sizeof(double)));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_j3_pgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_j3_pgrad, dim3((unsigned)W), dim3(64), lds, h->stream, h->S, h->js, (double*)h->b_out.p);
+  TRY(check_launch(h, "k_j3_pgrad"));
+  return copy_out(h, d_ccoeff, h->b_out.p, (size_t)W * E * sizeof(double));
 }
 
 extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {

@@ -426,3 +426,55 @@ __global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict
   double* x = js.x + ((size_t)w * N + e) * 3;
   x[0] = epos[3 * w]; x[1] = epos[3 * w + 1]; x[2] = epos[3 * w + 2];
 }
+
+// ---------------------------------------------------------------- three-body parameter gradient
+// dU/dc[I][k][l][m][sp] = 1/2 (X + X^T_kl),  X[I][k][l][m][sp] = sum over pairs (i,j) of spin class sp
+//   a_k(r_iI) a_l(r_jI) b_m(r_ij):  sp 0 = up-up (i<j), 1 = up (i) - down (j), 2 = down-down (i<j)
+// (ThreeBodyJastrow.pgradient, three_body_jastrow.py:657-719).  One wave per walker; LDS: a-values of every electron
+// [N][natom][na] followed by b-values of every pair [N(N-1)/2][nb] (row-major upper triangle); out (W, natom, na, na, nb, 3).
+__global__ __launch_bounds__(64) void k_j3_pgrad(SysDev S, JastrowState js, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x, N = S.nelec, A = S.natom, na = S.na3, nb = S.nb3;
+  const double* xw = js.x + (size_t)w * N * 3;
+  double* av = lds;
+  double* bv = lds + (size_t)N * A * na;
+  for (int q = lane; q < N * A; q += 64) {
+    const int e = q / A, I = q % A;
+    const double r = mi_norm(S, xw[3 * e] - S.atom_xyz[3 * I], xw[3 * e + 1] - S.atom_xyz[3 * I + 1], xw[3 * e + 2] - S.atom_xyz[3 * I + 2]);
+    for (int k = 0; k < na; ++k)
+      av[(size_t)q * na + k] = (r < S.rcut_a3) ? jas_value1(S.a3_kind[k], S.a3_param[k], S.a3_aux[k], S.rcut_a3, r) : 0.0;
+  }
+  const int npair = N * (N - 1) / 2;
+  for (int p = lane; p < npair; p += 64) {
+    int i = 0, rem = p;
+    while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const double r = mi_norm(S, xw[3 * i] - xw[3 * j], xw[3 * i + 1] - xw[3 * j + 1], xw[3 * i + 2] - xw[3 * j + 2]);
+    for (int m = 0; m < nb; ++m)
+      bv[(size_t)p * nb + m] = (r < S.rcut_b3) ? jas_value1(S.b3_kind[m], S.b3_param[m], S.b3_aux[m], S.rcut_b3, r) : 0.0;
+  }
+  __syncthreads();
+  const int E = A * na * na * nb * 3;
+  for (int idx = lane; idx < E; idx += 64) {
+    int t = idx;
+    const int sp = t % 3; t /= 3;
+    const int m = t % nb; t /= nb;
+    const int l = t % na; t /= na;
+    const int k = t % na; t /= na;
+    const int I = t;
+    // pair ranges of the spin class: i in [i0,i1), j in [max(i+1,j0), j1)
+    const int i0 = (sp == 2) ? S.nup : 0, i1 = (sp == 0 || sp == 1) ? S.nup : N;
+    const int j0 = (sp == 0) ? 0 : S.nup, j1 = (sp == 0) ? S.nup : N;
+    double acc = 0.0;
+    for (int i = i0; i < i1; ++i) {
+      const double aik = av[((size_t)i * A + I) * na + k], ail = av[((size_t)i * A + I) * na + l];
+      const long rowoff = (long)i * (N - 1) - (long)i * (i - 1) / 2 - (i + 1);  // pair (i,j) -> rowoff + j
+      for (int j = (j0 > i + 1 ? j0 : i + 1); j < j1; ++j) {
+        const double b = bv[(size_t)(rowoff + j) * nb + m];
+        acc += 0.5 * (aik * av[((size_t)j * A + I) * na + l] + ail * av[((size_t)j * A + I) * na + k]) * b;
+      }
+    }
+    out[(size_t)w * E + idx] = acc;
+  }
+}

@@ -316,3 +316,55 @@ __global__ void k_has_zero(const double* dlog, long count, int* flag) {
     if (!(v >= -DBL_MAX && v <= DBL_MAX)) atomicOr(flag, 1);
   }
 }
+
+// ---------------------------------------------------------------- parameter gradients (Slater.pgradient, slater.py:462-542)
+// d_det[w][di] = D_up D_dn / Psi for determinant di (:495-505).
+__global__ void k_pgrad_det(SysDev S, SlaterState st, const double* __restrict__ psi_sign, const double* __restrict__ psi_log,
+                            long W, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W * S.ndet) return;
+  const long w = idx / S.ndet;
+  const int di = (int)(idx % S.ndet), u0 = S.det_map[di], u1 = S.det_map[S.ndet + di];
+  const double sg = psi_sign[w];
+  double v = 0.0;
+  if (sg != 0.0) {
+    double sgn = 1.0, lg = 0.0;
+    if (S.nup > 0) { sgn *= st.dsign[0][w * S.ndet_s[0] + u0]; lg += st.dlog[0][w * S.ndet_s[0] + u0]; }
+    if (S.ndn > 0) { sgn *= st.dsign[1][w * S.ndet_s[1] + u1]; lg += st.dlog[1][w * S.ndet_s[1] + u1]; }
+    v = sgn * exp(lg - psi_log[w]) / sg;
+  }
+  out[idx] = v;
+}
+
+// d_mo[w][a][m] = sum_di coeff[di] d_det[w][di] * sum_e ao[w][e][a] inverse_det[col(m)][e]   for m occupied in the
+// determinant (:507-533; _testcol :382-388).  ao: [W*N][nao] values of all electrons (walker-major, electron order of x);
+// colmap: [ndet_s][nmo_s] column of orbital m in unique determinant u or -1.  grid = (W), block = 256.
+__global__ __launch_bounds__(256) void k_pgrad_mo(SysDev S, SlaterState st, int s, const double* __restrict__ ao,
+                                                  const double* __restrict__ d_det, const int* __restrict__ colmap,
+                                                  double* __restrict__ out) {
+  extern __shared__ double wu[];  // [ndet_s] weight of every unique determinant of this spin
+  const long w = blockIdx.x;
+  const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], nmo = S.nmo[s], nao = S.nao;
+  for (int u = threadIdx.x; u < D; u += blockDim.x) {
+    double acc = 0.0;
+    for (int di = 0; di < S.ndet; ++di)
+      if (S.det_map[s * S.ndet + di] == u) acc += S.det_coeff[di] * d_det[w * S.ndet + di];
+    wu[u] = acc;
+  }
+  __syncthreads();
+  const double* aow = ao + ((size_t)w * S.nelec + (size_t)s * S.nup) * nao;
+  const double* Tw = st.T[s] + (size_t)w * D * n * n;
+  for (int idx = threadIdx.x; idx < nao * nmo; idx += blockDim.x) {
+    const int a = idx / nmo, m = idx % nmo;
+    double acc = 0.0;
+    for (int u = 0; u < D; ++u) {
+      const int col = colmap[u * nmo + m];
+      if (col < 0) continue;
+      const double* Tu = Tw + (size_t)u * n * n;
+      double t = 0.0;
+      for (int e = 0; e < n; ++e) t += aow[(size_t)e * nao + a] * Tu[e * n + col];
+      acc += wu[u] * t;
+    }
+    out[((size_t)w * nao + a) * nmo + m] = acc;
+  }
+}

@@ -443,6 +443,20 @@ class Slater:
         """slater.py:448-460: ratios for moving each electron of ``e`` to ``epos`` -> (nconf[mask], len(e))."""
         return _testvalue_many(self._dev, 1, e, epos, mask)
 
+    def pgradient(self):
+        """slater.py:462-542: d Psi / Psi w.r.t. ``det_coeff`` (nconf, ndet) and the orbital coefficients
+        (nconf, nao, nmo_s); zero-sized entries are dropped like the reference does (:537-541)."""
+        d = self._dev
+        if d.pbc:
+            raise NotImplementedError("orbital-coefficient gradients of periodic Slater determinants (per-k parameterisation) are not implemented yet")
+        W = d.W
+        out = {"det_coeff": np.empty((W, d.ndet)), "mo_coeff_alpha": np.empty((W, d.nao, d.nmo[0])),
+               "mo_coeff_beta": np.empty((W, d.nao, d.nmo[1]))}
+        d.call("pqa_slater_pgradient", _ffi.ptr(out["det_coeff"]),
+               _ffi.ptr(out["mo_coeff_alpha"]) if out["mo_coeff_alpha"].size else None,
+               _ffi.ptr(out["mo_coeff_beta"]) if out["mo_coeff_beta"].size else None)
+        return {k: v for k, v in out.items() if v.size}
+
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
         s = self._spin(e)
         flag = C.c_int()
@@ -586,6 +600,13 @@ class ThreeBodyJastrow:
         """three_body_jastrow.py:343-372 -> (nconf[mask], len(e))."""
         return _testvalue_many(self._dev, 4, e, epos, mask)
 
+    def pgradient(self):
+        """three_body_jastrow.py:657-719: dU/dccoeff (nconf, natom, na, na, nb, 3)."""
+        d = self._dev
+        out = np.empty((d.W, d.natom, d.na3, d.na3, d.nb3, 3))
+        d.call("pqa_j3_pgradient", _ffi.ptr(out))
+        return {"ccoeff": out}
+
     def gradient_value(self, e, epos):
         r, *_ = self._eval(e, epos, None, 1)
         return r[:3], r[3], None
@@ -674,6 +695,10 @@ class MultiplyWF:
     def testvalue(self, e, epos, mask=None):
         vals, saved = zip(*[w.testvalue(e, epos, mask=mask) for w in self.wf_factors])
         return np.prod(vals, axis=0), saved
+
+    def pgradient(self):
+        """multiplywf.py:131-132."""
+        return Parameters([w.pgradient() for w in self.wf_factors])
 
     def testvalue_many(self, e, epos, mask=None):
         """multiplywf.py:112-114; one fused call when all factors share a device handle."""

@@ -796,6 +796,11 @@ def g_testvalue_many():
     es = np.array([0, 3, 4, 7, 5])
     out["h2o_aux"], out["h2o_mask"], out["h2o_es"] = aux, mask, es
     epos = configs.make_irreducible(0, aux)
+    # parameter gradients of the same state (slater.py:462-542, jastrowspin.py:457-464, three_body_jastrow.py:657-719)
+    pg = wf.pgradient()
+    for k in pg.keys():
+        out["h2o_pgrad_" + k] = np.asarray(pg[k])
+    out["h2o_pgrad_keys"] = np.asarray(sorted(pg.keys()))
     for nm, w in (("slater", wf.wf_factors[0]), ("j2", j2), ("j3", j3), ("wf", wf)):
         out[f"h2o_{nm}"] = w.testvalue_many(es, epos)
         # (no masked goldens: the reference's testvalue_many allocate for all walkers and fail on a real mask,

@@ -416,6 +416,11 @@ def test_testvalue_many_golden():
         assert np.array_equal(w.testvalue_many(g["h2o_es"], epos, mask=g["h2o_mask"]), full[g["h2o_mask"]])
     # column i equals testvalue(es[i])
     assert relerr(wf.testvalue_many(np.array([5]), epos)[:, 0], wf.testvalue(5, epos)[0]) < 1e-13
+    # parameter gradients of the same state (Slater.pgradient slater.py:462-542, JastrowSpin :457-464, ThreeBodyJastrow :657-719)
+    pg = wf.pgradient()
+    assert sorted(pg.keys()) == g["h2o_pgrad_keys"].tolist()
+    for k, v in pg.items():
+        assert note("pgrad_" + k, relerr(v, g["h2o_pgrad_" + k])) < 1e-9, k
     sup, pwf = helpers.gpu_pbc_wf("fcc2cubic")
     cfg = PeriodicConfigs(g["pbc_configs"].copy(), sup.lattice_vectors(), wrap=g["pbc_wrap"].copy())
     pwf.recompute(cfg)

@@ -200,6 +200,10 @@ def test_testvalue_many_matches_reference():
     epos = cfg.make_irreducible(0, g["h2o_aux"])
     for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("j3", wf.wf_factors[2]), ("wf", wf)):
         assert relerr(w.testvalue_many(g["h2o_es"], epos), g[f"h2o_{nm}"]) < 1e-10, nm
+    pg = wf.pgradient()  # parameter gradients of the same state (slater.py:462-542, jastrowspin.py:457-464, three_body_jastrow.py:657-719)
+    assert sorted(pg.keys()) == g["h2o_pgrad_keys"].tolist()
+    for k, v in pg.items():
+        assert relerr(v, g["h2o_pgrad_" + k]) < 1e-10, k
     sup, pwf = oracle_pbc_wf("fcc2cubic")
     cfg = PeriodicConfigs(g["pbc_configs"].copy(), sup.lattice_vectors(), wrap=g["pbc_wrap"].copy())
     pwf.recompute(cfg)
