@@ -178,7 +178,7 @@ static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   for (int s = 0; s < h->nshell; ++s) order[s] = s;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
   int nchunk = std::max((nao + KC - 1) / KC, 1);
-  std::vector<std::vector<int>> load, rows_used_dummy;
+  std::vector<std::vector<int>> load;
   std::vector<int> rows;
   std::vector<std::vector<std::vector<int>>> slot;  // [chunk][group] -> shells
   for (;;) {
@@ -282,6 +282,11 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0));
   HIPCHK(hipEventCreate(&h->ev1));
+  // A/B switches for the schedule variants compared in DESIGN.md sections 3-4 (all default to the measured best;
+  // none of them changes results beyond summation order, tests/test_gpu_parity.py cross-checks the pairs):
+  //   PQA_ORB_TP 32|64 point tile of k_orb, PQA_ORB_WS 0|1 wave-specialised k_orb, PQA_ORB_NOTAB 1 basis tables from
+  //   global memory, PQA_LW 0 wave-per-walker sweep, PQA_LW_KB k blocked Sherman-Morrison, PQA_LW_GM g partial-sum
+  //   groups, PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
