@@ -200,6 +200,26 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     if (m < 2 * l + 1) sink(m, acc[m][0], acc[m][1 % NCOMP], acc[m][2 % NCOMP], acc[m][3 % NCOMP], acc[m][4 % NCOMP]);
 }
 
+// Pre-pass of a periodic k_orb launch: thread = (point, atom).  Folds the point into the cell, folds point - atom into
+// the cell-centred parallelepiped and works out which of the atom's candidate images are admitted (atom cut-off and
+// membership rule) — once, instead of once per lane group inside k_orb, and in a kernel that is not register-bound.
+__global__ __launch_bounds__(256) void k_pbc_prepass(SysDev S, PointAddr pa, long P, double* __restrict__ d0,
+                                                     unsigned long long* __restrict__ mask) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int ia = blockIdx.y;
+  if (p >= P) return;
+  double px, py, pz;
+  load_point(pa, p, px, py, pz);
+  fold_cell(S, px, py, pz);
+  PbcCtx c;
+  pbc_ctx_update(S, c, ia, px - S.atom_xyz[3 * ia], py - S.atom_xyz[3 * ia + 1], pz - S.atom_xyz[3 * ia + 2], prim_wrap(S, px, py, pz));
+  d0[((size_t)ia * 3 + 0) * P + p] = c.x0;
+  d0[((size_t)ia * 3 + 1) * P + p] = c.y0;
+  d0[((size_t)ia * 3 + 2) * P + p] = c.z0;
+  mask[((size_t)ia * 2 + 0) * P + p] = c.mask[0];
+  mask[((size_t)ia * 2 + 1) * P + p] = c.mask[1];
+}
+
 // ---------------------------------------------------------------- AO only (test / A-B entry)
 // out (NCOMP, P, nao); one thread per point.
 template <int NCOMP>
@@ -254,6 +274,10 @@ struct ChunkTab {
   const int* cw_shell[2]; // shells for (chunk, group)
   const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
   int ldc[2];
+  // periodic launches only: per (atom, point) folded displacement [natom][3][P] and admission mask [natom][2][P],
+  // written by k_pbc_prepass for the points of THIS launch
+  const double* pbc_d0;
+  const unsigned long long* pbc_mask;
 };
 
 #define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
@@ -356,7 +380,15 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
       };
       if (PBC) {
-        pbc_ctx_update(S, ctx, ia_, x, y, z, pw);
+        if (ctx.ia != ia_) {  // per (point, atom) data of k_pbc_prepass; images beyond the 128-bit mask need b0..b2 too
+          ctx.ia = ia_;
+          ctx.x0 = T.pbc_d0[((size_t)ia_ * 3 + 0) * P + pmine];
+          ctx.y0 = T.pbc_d0[((size_t)ia_ * 3 + 1) * P + pmine];
+          ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
+          ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
+          ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
+          if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
+        }
         shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }

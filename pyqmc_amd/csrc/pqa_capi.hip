@@ -63,7 +63,7 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask;
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
@@ -513,7 +513,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -594,13 +594,21 @@ static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
 }
 // periodic orbitals: lattice-summed shells, 64-point tiles, tables through the scalar cache
 template <int NCOMP, int KC>
-static void launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
+  TRY(ensure(h, h->b_pbcd0, (size_t)h->natom * 3 * P * sizeof(double)));
+  TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * 2 * P * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + 255) / 256), (unsigned)h->natom), dim3(256), 0, h->stream, h->S, pa, P,
+                     (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p);
+  ChunkTab T = h->tab[tabi];
+  T.pbc_d0 = (const double*)h->b_pbcd0.p;
+  T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
   const dim3 grid((unsigned)((P + 63) / 64)), block(256);
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, 64, false, true>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
   }
+  return 0;
 }
 template <int NCOMP, int KC, int TP>
 static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
@@ -633,8 +641,8 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
   const bool want_ws = h->orb_ws < 0 ? (P < (long)64 * 512) : (h->orb_ws != 0);
   if (h->S.nL > 0) {
-    if (ncomp == 5) launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
-    else if (ncomp == 1) launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
+    if (ncomp == 5) TRY((launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out)));
+    else if (ncomp == 1) TRY((launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out)));
     else FAIL("orbital kernel supports ncomp 1 or 5");
   } else
   if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
