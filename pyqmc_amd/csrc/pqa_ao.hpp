@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   __shared__ double tile[NCOMP][KC][TP];
   // LDSTAB: basis tables staged once per block so phase 1 never waits on chains of dependent scalar loads
   __shared__ double sh_xyz[LDSTAB ? PQA_WS_MAXSH : 1][3];
-  __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][4];  // l, nprim, first primitive, first AO
+  __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][5];  // l, nprim, first primitive, tile row in chunk, atom
   __shared__ double pr_exp[LDSTAB ? PQA_WS_MAXP : 1], pr_coef[LDSTAB ? PQA_WS_MAXP : 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (LDSTAB) {
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
       sh_meta[sh][2] = S.shell_prim_off[sh];
       sh_meta[sh][3] = T.shell_kb[sh];
+      sh_meta[sh][4] = ia;
     }
     for (int p = tid; p < S.nprim; p += 256) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
     __syncthreads();
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       double x, y, z;
       const double *pe, *pc;
       if (LDSTAB) {
-        l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3];
+        l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3]; ia_ = sh_meta[sh][4];
         x = px - sh_xyz[sh][0]; y = py - sh_xyz[sh][1]; z = pz - sh_xyz[sh][2];
         pe = pr_exp + q0; pc = pr_coef + q0;
       } else {

@@ -603,11 +603,16 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
   const dim3 grid((unsigned)((P + 63) / 64)), block(256);
+  // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
+  // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
+  const bool lt = h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab;
+#define PQA_ORB_PBC(NT, LT) hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, 64, LT, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out)
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, 64, false, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); break;
+    case 1: if (lt) PQA_ORB_PBC(1, true); else PQA_ORB_PBC(1, false); break;
+    case 2: if (lt) PQA_ORB_PBC(2, true); else PQA_ORB_PBC(2, false); break;
+    default: if (lt) PQA_ORB_PBC(4, true); else PQA_ORB_PBC(4, false); break;
   }
+#undef PQA_ORB_PBC
   return 0;
 }
 template <int NCOMP, int KC, int TP>
