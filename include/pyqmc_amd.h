@@ -214,9 +214,13 @@ int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double*
    space with weight > 1e-10 (:372-388); gweight (ng) = 4 pi exp(-G^2/4 alpha^2) / (V G^2); ion_cos/ion_sin (ng): real and
    imaginary part of sum_I Z_I exp(i G.R_I) (:233-234); ee_const / ei_const: self + charged-system terms for this electron
    count (:180-184); ii: ion-ion energy incl. its constants (:353).  The real-space sum runs over the 27 cells of
-   nlatvec = 1 (:113-123).  Required before pqa_energy / energies in pqa_vmc_sweeps on a handle with pbc != 0. */
+   nlatvec = 1 (:113-123).  gidx (ng,3) int32 / recip (3,3): optional integer decomposition gpoints = gidx . recip
+   (recip = 2 pi inv(lattice)^T, :374-388); with it the structure factors e^{iG.x} are built from three base phases per
+   electron by complex multiplication instead of one sincos per (G, electron).  NULL: direct sincos.
+   Required before pqa_energy / energies in pqa_vmc_sweeps on a handle with pbc != 0. */
 int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,
-                  const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii);
+                  const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii,
+                  const int32_t* gidx, const double* recip);
 
 /* Wrap counters (PeriodicConfigs.wrap, coord.py:137-189) accumulated by the accepted moves of the LAST pqa_vmc_sweeps
    call: wrap (W, nelec, 3) int32, to be added to the caller's counters.  The walkers themselves stay folded into the

@@ -58,7 +58,8 @@ _PROTOTYPES = {
     "pqa_slater_pgradient": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_j3_pgradient": (C.c_int, [_H, C.c_void_p]),
     "pqa_testvalue_many": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
-    "pqa_set_ewald": (C.c_int, [_H, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "pqa_set_ewald": (C.c_int, [_H, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                C.c_void_p, C.c_void_p]),
     "pqa_get_wrap": (C.c_int, [_H, C.c_void_p]),
     "pqa_eval_ao": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "pqa_eval_mo": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

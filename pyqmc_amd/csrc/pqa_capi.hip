@@ -1264,7 +1264,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     if (!h->ew_set) FAIL("periodic Coulomb energy needs the Ewald tables (pqa_set_ewald)");
     const bool soa = soa_current && h->necp == 0;  // with ECPs the coordinates were just transposed back
     const double* x = soa ? (const double*)h->b_xt.p : h->js.x;
-    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(64), (size_t)h->N * 3 * sizeof(double), h->stream, h->S, h->ew, x,
+    const size_t lds_ew = ((size_t)h->N * 3 + (h->ew.gn ? (size_t)h->N * 3 * (h->ew.nmax + 1) * 2 : 0)) * sizeof(double);
+    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(64), lds_ew, h->stream, h->S, h->ew, x,
                        soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_ewald"));
   }
@@ -1350,7 +1351,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
 }
 
 extern "C" int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,
-                             const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii) {
+                             const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii,
+                             const int32_t* gidx, const double* recip) {
   HIPCHK(hipSetDevice(h->device));
   if (!h->S.pbc) FAIL("Ewald tables on an open-boundary handle");
   if (ng < 0 || !(alpha > 0.0)) FAIL("bad Ewald parameters");
@@ -1361,6 +1363,20 @@ extern "C" int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const do
   TRY(upload_table(h, ion_cos, (size_t)ng, &d)); h->ew.ion_cos = d;
   TRY(upload_table(h, ion_sin, (size_t)ng, &d)); h->ew.ion_sin = d;
   h->ew.ng = ng; h->ew.alpha = alpha; h->ew.ee_const = ee_const; h->ew.ei_const = ei_const;
+  h->ew.gn = nullptr; h->ew.nmax = 0;
+  if (gidx && recip && ng > 0) {
+    std::vector<int> gi((size_t)ng * 3);
+    HIPCHK(hipMemcpy(gi.data(), gidx, gi.size() * sizeof(int), hipMemcpyDefault));
+    int nmax = 0;
+    for (int v : gi) nmax = std::max(nmax, std::abs(v));
+    const size_t lds = ((size_t)h->N * 3 + (size_t)h->N * 3 * (nmax + 1) * 2) * sizeof(double);
+    if (lds <= 64 * 1024) {  // otherwise stay with the direct sincos form
+      int* dgi;
+      TRY(upload_table(h, gi.data(), gi.size(), &dgi));
+      h->ew.gn = dgi; h->ew.nmax = nmax;
+      HIPCHK(hipMemcpy(h->ew.recip, recip, 9 * sizeof(double), hipMemcpyDefault));
+    }
+  }
   h->ii_energy = ii;
   h->ew_set = true;
   return 0;

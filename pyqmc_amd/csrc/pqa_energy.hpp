@@ -69,6 +69,9 @@ struct EwaldDev {
   const double* ion_cos;  // [ng] Re rho_I
   const double* ion_sin;  // [ng] Im rho_I
   double alpha, ee_const, ei_const;
+  const int* gn;          // [ng][3] integer coordinates of g in the reciprocal basis, or nullptr (direct sincos)
+  double recip[9];        // rows: reciprocal basis vectors (g = gn . recip)
+  int nmax;               // max |gn| component
 };
 __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
                                               long W, double* __restrict__ out) {
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
           const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
           const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
           const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
-          const double r = sqrt(rx * rx + ry * ry + rz * rz);
+          const double r2 = rx * rx + ry * ry + rz * rz;
+          if (E.alpha * E.alpha * r2 > 40.0) continue;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
+          const double r = sqrt(r2);
           acc += erfc(E.alpha * r) / r;
         }
     return acc;
@@ -104,16 +109,54 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
     ei -= S.atom_charge[I] * real_sum(lds[3 * e] - S.atom_xyz[3 * I], lds[3 * e + 1] - S.atom_xyz[3 * I + 1],
                                       lds[3 * e + 2] - S.atom_xyz[3 * I + 2]);
   }
-  for (int g = lane; g < E.ng; g += 64) {
-    const double gx = E.g[3 * g], gy = E.g[3 * g + 1], gz = E.g[3 * g + 2];
-    double sc_ = 0.0, ss_ = 0.0;
-    for (int e = 0; e < S.nelec; ++e) {
+  if (E.gn) {
+    // e^{i g.x_e} = prod_a (e^{i b_a.x_e})^{n_a}: powers 0..nmax of the three base phases of every electron go to LDS
+    // (complex multiplication recurrence), a (g, electron) term is then two complex products instead of a sincos.
+    const int M = E.nmax + 1;
+    double* ph = lds + S.nelec * 3;  // [N][3][M][2]
+    for (int q = lane; q < S.nelec * 3; q += 64) {
+      const int e = q / 3, a = q % 3;
       double sn, cs;
-      sincos(gx * lds[3 * e] + gy * lds[3 * e + 1] + gz * lds[3 * e + 2], &sn, &cs);
-      sc_ += cs; ss_ += sn;
+      sincos(E.recip[3 * a] * lds[3 * e] + E.recip[3 * a + 1] * lds[3 * e + 1] + E.recip[3 * a + 2] * lds[3 * e + 2], &sn, &cs);
+      double* t = ph + (size_t)q * M * 2;
+      double cr = 1.0, ci = 0.0;
+      for (int m = 0; m < M; ++m) {
+        t[2 * m] = cr; t[2 * m + 1] = ci;
+        const double nr = cr * cs - ci * sn;
+        ci = cr * sn + ci * cs;
+        cr = nr;
+      }
     }
-    ee += E.gweight[g] * (ss_ * ss_ + sc_ * sc_);
-    ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
+    __syncthreads();
+    for (int g = lane; g < E.ng; g += 64) {
+      const int n0 = E.gn[3 * g], n1 = E.gn[3 * g + 1], n2 = E.gn[3 * g + 2];
+      const int m0 = abs(n0), m1 = abs(n1), m2 = abs(n2);
+      const double f0 = n0 < 0 ? -1.0 : 1.0, f1 = n1 < 0 ? -1.0 : 1.0, f2 = n2 < 0 ? -1.0 : 1.0;
+      double sc_ = 0.0, ss_ = 0.0;
+      for (int e = 0; e < S.nelec; ++e) {
+        const double* t = ph + (size_t)e * 3 * M * 2;
+        const double ar = t[2 * m0], ai = f0 * t[2 * m0 + 1];
+        const double br = t[2 * (M + m1)], bi = f1 * t[2 * (M + m1) + 1];
+        const double cr = t[2 * (2 * M + m2)], ci = f2 * t[2 * (2 * M + m2) + 1];
+        const double abr = ar * br - ai * bi, abi = ar * bi + ai * br;
+        sc_ += abr * cr - abi * ci;
+        ss_ += abr * ci + abi * cr;
+      }
+      ee += E.gweight[g] * (ss_ * ss_ + sc_ * sc_);
+      ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
+    }
+  } else {
+    for (int g = lane; g < E.ng; g += 64) {
+      const double gx = E.g[3 * g], gy = E.g[3 * g + 1], gz = E.g[3 * g + 2];
+      double sc_ = 0.0, ss_ = 0.0;
+      for (int e = 0; e < S.nelec; ++e) {
+        double sn, cs;
+        sincos(gx * lds[3 * e] + gy * lds[3 * e + 1] + gz * lds[3 * e + 2], &sn, &cs);
+        sc_ += cs; ss_ += sn;
+      }
+      ee += E.gweight[g] * (ss_ * ss_ + sc_ * sc_);
+      ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
+    }
   }
   ee = wave_sum(ee);
   ei = wave_sum(ei);

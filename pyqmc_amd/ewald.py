@@ -32,7 +32,7 @@ def positive_gpoints(gmax, recvec, alpha, cellvolume):
     g2 = np.einsum("jk,jk->j", gpoints, gpoints)
     gweight = 4 * np.pi * np.exp(-g2 / (4 * alpha**2)) / (cellvolume * g2)
     big = gweight > 1e-10
-    return gpoints[big], gweight[big]
+    return gpoints[big], gweight[big], np.ascontiguousarray(gpts.T[big], dtype=np.int32)
 
 
 def ewald_tables(cell, ewald_gmax=200, nlatvec=1):
@@ -45,7 +45,7 @@ def ewald_tables(cell, ewald_gmax=200, nlatvec=1):
     vol = np.linalg.det(latvec)
     recvec = np.linalg.inv(latvec).T
     alpha = 5.0 / np.amin(1 / np.linalg.norm(recvec, axis=1))
-    gpoints, gweight = positive_gpoints(ewald_gmax, recvec, alpha, vol)
+    gpoints, gweight, gidx = positive_gpoints(ewald_gmax, recvec, alpha, vol)
     i_sum, ii_sum2 = charges.sum(), np.sum(charges**2)
     ii_sum = (i_sum**2 - ii_sum2) / 2
     ijconst = -np.pi / (vol * alpha**2)
@@ -65,6 +65,7 @@ def ewald_tables(cell, ewald_gmax=200, nlatvec=1):
     ion_ion = real + gweight @ np.abs(ion_exp) ** 2
     return {
         "alpha": float(alpha), "gpoints": np.ascontiguousarray(gpoints), "gweight": np.ascontiguousarray(gweight),
+        "gidx": gidx, "recip": np.ascontiguousarray(recvec * 2 * np.pi),  # gpoints == gidx @ recip
         "ion_cos": np.ascontiguousarray(ion_exp.real), "ion_sin": np.ascontiguousarray(ion_exp.imag),
         "ee_const": float(ne * (ne - 1) / 2 * ijconst + ne * squareconst),
         "ei_const": float(-ne * i_sum * ijconst),

@@ -175,7 +175,8 @@ class DeviceWF:
 
         t = ewald_tables(self.mol, ewald_gmax, nlatvec)
         self.call("pqa_set_ewald", t["alpha"], len(t["gweight"]), _ffi.ptr(t["gpoints"]), _ffi.ptr(t["gweight"]),
-                  _ffi.ptr(t["ion_cos"]), _ffi.ptr(t["ion_sin"]), t["ee_const"], t["ei_const"], t["ii"])
+                  _ffi.ptr(t["ion_cos"]), _ffi.ptr(t["ion_sin"]), t["ee_const"], t["ei_const"], t["ii"], _ffi.ptr(t["gidx"]),
+                  _ffi.ptr(t["recip"]))
         self._ewald_key = (ewald_gmax, nlatvec)
         self.ewald = t
 
