@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # fp64 peaks of MI355X (AMD datasheet; MI355X_MICROARCH.md lists no fp64 row): vector = matrix = 78.6 TFLOP/s
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
@@ -164,6 +165,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     launches, orb_ms, point_comps = (0, 0.0, 0.0) if args.no_profile else dev.profile_query()
+    c_launches, c_ms = (0, 0.0) if args.no_profile else dev.profile_query_commit()
     if not args.no_profile:
         dev.profile_enable(False)
     ecp_pts = dev.last_ecp_points()
@@ -198,6 +200,25 @@ def main():
                                "launches": launches, "avg_launch_ms": orb_ms / launches,
                                "kernel_share_of_step": orb_ms / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}
+        if not args.no_profile and c_launches:
+            # The kernel with the largest share of the step is the Sherman-Morrison commit, which streams every accepted
+            # walker's inverse through HBM once per move.  Algorithmic bytes per accepted move (n = 32, nmo = 32):
+            # inverse read + written 2*8*n^2, update vectors V, R read 2*8*n, new orbital row read + cached 2*8*5*nmo.
+            n_s, nmo_s = 32, 32
+            bytes_move = 2 * 8 * n_s * n_s + 2 * 8 * n_s + 2 * 8 * 5 * nmo_s
+            accepted = float(np.mean(acc)) * W * 64 * args.steps
+            ach = accepted * bytes_move / (c_ms * 1e-3) / 1e9
+            traffic = None
+            path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(path):
+                d = json.load(open(path)).get("k_commit_lw")
+                if d:
+                    traffic = {"bytes_per_launch": d["bytes_per_walker"] * W, "source": "profiles/r01_pmc_summary.json"}
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_commit_lw (Sherman-Morrison update of the inverse, lane-per-walker)",
+                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": traffic, "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
+                                   "kernel_share_of_step": c_ms / (1e3 * elapsed),
+                                   "algorithmic_bytes_per_accepted_move": bytes_move}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.tstep)
         print(json.dumps(out), flush=True)

@@ -91,6 +91,10 @@ struct pqa_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_events;  // Sherman-Morrison commit launches of the fused sweep
+  size_t prof2_used = 0;
+  long prof2_launches = 0;
+  double prof2_ms = 0.0;
   size_t prof_used = 0;
   long prof_launches = 0;
   double prof_ms = 0.0, prof_pc = 0.0;
@@ -517,6 +521,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : h->prof2_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1490,8 +1495,21 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
         const dim3 gcm(gw.x, (unsigned)Gc);
 #define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
                             else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
+        hipEvent_t ce1 = nullptr;
+        if (h->profile) {
+          if (h->prof2_used == h->prof2_events.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            h->prof2_events.emplace_back(a, b);
+          }
+          HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
+          ce1 = h->prof2_events[h->prof2_used].second;
+          ++h->prof2_used;
+        }
         if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
 #undef PQA_COMMIT
+        if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
         if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
           const int nq = j_hi - j_lo;
 #define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
@@ -1592,6 +1610,7 @@ extern "C" int pqa_profile_enable(pqa_handle_t* h, int enable) {
   HIPCHK(hipStreamSynchronize(h->stream));
   h->profile = enable != 0;
   h->prof_used = 0; h->prof_launches = 0; h->prof_ms = 0.0; h->prof_pc = 0.0;
+  h->prof2_used = 0; h->prof2_launches = 0; h->prof2_ms = 0.0;
   return 0;
 }
 extern "C" int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, double* point_comps) {
@@ -1606,6 +1625,19 @@ extern "C" int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* tot
   if (launches) *launches = h->prof_launches;
   if (total_ms) *total_ms = h->prof_ms;
   if (point_comps) *point_comps = h->prof_pc;
+  return 0;
+}
+extern "C" int pqa_profile_query_commit(pqa_handle_t* h, int64_t* launches, double* total_ms) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < h->prof2_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof2_events[i].first, h->prof2_events[i].second));
+    h->prof2_ms += ms;
+  }
+  h->prof2_used = 0;
+  if (launches) *launches = h->prof2_launches;
+  if (total_ms) *total_ms = h->prof2_ms;
   return 0;
 }
 extern "C" int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints) {

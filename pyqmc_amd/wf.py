@@ -245,6 +245,12 @@ class DeviceWF:
         self.call("pqa_profile_query", C.byref(n), C.byref(ms), C.byref(pc))
         return n.value, ms.value, pc.value
 
+    def profile_query_commit(self):
+        """(launches, total ms) of the Sherman-Morrison commit kernel since ``profile_enable``."""
+        n, ms = C.c_int64(), C.c_double()
+        self.call("pqa_profile_query_commit", C.byref(n), C.byref(ms))
+        return n.value, ms.value
+
     def last_ecp_points(self):
         n = C.c_int64()
         self.call("pqa_last_ecp_points", C.byref(n))
