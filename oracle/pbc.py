@@ -101,9 +101,7 @@ class PeriodicAOTable:
         self.num_Ls, self.atom_cut, self.shell_cut = gto_cutoffs(self.table, self.Ls, cell.lattice_vectors(),
                                                                  -3.5 * np.log(precision))
         ph = np.exp(1j * self.Ls @ self.kpts.T)
-        if np.abs(ph.imag).max() > 1e-9:
-            raise NotImplementedError("complex Bloch phases are not restated yet")
-        self.phases = ph.real
+        self.phases = ph.real if np.abs(ph.imag).max() < 1e-9 else ph  # np.real_if_close, pbcgto.py:620-621
 
 
 def eval_ao_pbc(pt, pts, ncomp):
@@ -112,7 +110,7 @@ def eval_ao_pbc(pt, pts, ncomp):
 
     t = pt.table
     pts = np.asarray(pts, dtype=float).reshape(-1, 3)
-    out = np.zeros((len(pt.kpts), ncomp, len(pts), t.nao))
+    out = np.zeros((len(pt.kpts), ncomp, len(pts), t.nao), dtype=pt.phases.dtype)
     deriv = ncomp > 1
     for ia in range(len(t.coords)):
         shells = [(i, s) for i, s in enumerate(t.shells) if s[0] == ia]
@@ -156,7 +154,8 @@ class PeriodicOrbitals:
         self.Lprim = self.prim.lattice_vectors()
         self.aotab = PeriodicAOTable(self.prim, kpts, Ls, precision)
         self.kpts = self.aotab.kpts
-        self.mo = [[np.asarray(m, dtype=float) for m in mo_coeff[s]] for s in (0, 1)]
+        self.mo = [[np.asarray(m) for m in mo_coeff[s]] for s in (0, 1)]
+        self.complex = np.iscomplexobj(self.aotab.phases) or any(np.iscomplexobj(m) for sp in self.mo for m in sp)
         twist = self.kpts @ (self.S @ self.Lprim).T / (2 * np.pi)
         if np.abs(twist - np.round(twist)).max() > 1e-9:
             raise NotImplementedError("non-zero supercell twist needs the walkers' wrap counters (not restated yet)")
@@ -166,7 +165,8 @@ class PeriodicOrbitals:
         prim_pts, primwrap = enforce_pbc(self.Lprim, pts)
         ao = eval_ao_pbc(self.aotab, prim_pts, ncomp)
         kdotR = self.kpts @ self.Lprim.T @ primwrap.T  # (nk, npts); zero twist: the supercell wrap drops out
-        return ao * ((-1.0) ** np.round(kdotR / np.pi))[:, None, :, None]
+        wrap_phase = np.exp(1j * kdotR) if self.complex else (-1.0) ** np.round(kdotR / np.pi)  # orbitals.py:34-39
+        return ao * wrap_phase[:, None, :, None]
 
     def mos(self, ao, s):
         return np.concatenate([ao[k] @ self.mo[s][k] for k in range(len(self.kpts))], axis=-1)

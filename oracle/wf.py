@@ -66,6 +66,7 @@ class Slater(_ManyMixin):
 
         orb = PeriodicOrbitals(supercell, kpts, mo_coeff, Ls, precision)
         self = cls(supercell, [np.concatenate(orb.mo[s], axis=1) for s in (0, 1)], determinants)
+        self.dtype = complex if orb.complex else float  # slater.py:212-216
         self._orb = orb  # the MO blocks live in orb.mo; parameters["mo_coeff_*"] are their concatenation (orbitals.py:157-160)
         return self
 

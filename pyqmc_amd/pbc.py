@@ -211,9 +211,9 @@ class KMeanField:
         return self
 
 
-def random_kmf(supercell, seed=20260928, nvirt=0):
-    """Seeded real Bloch coefficients at the supercell's Gamma-compatible k-points, electrons spread evenly over
-    the k-points (what an insulator's KRHF gives)."""
+def random_kmf(supercell, seed=20260928, nvirt=0, complex_coeff=False):
+    """Seeded Bloch coefficients at the supercell's Gamma-compatible k-points, electrons spread evenly over the
+    k-points (what an insulator's KRHF gives).  ``complex_coeff``: randn + i randn before orthonormalisation."""
     prim = supercell.original_cell
     kpts = get_supercell_kpts(supercell)
     rng = np.random.default_rng(seed)
@@ -223,7 +223,10 @@ def random_kmf(supercell, seed=20260928, nvirt=0):
         per_k, rem = divmod(supercell.nelec[s], len(kpts))
         for k in range(len(kpts)):
             n = per_k + (k < rem)
-            q, _ = np.linalg.qr(rng.standard_normal((nao, nao)))
+            a = rng.standard_normal((nao, nao))
+            if complex_coeff:
+                a = a + 1j * rng.standard_normal((nao, nao))
+            q, _ = np.linalg.qr(a)
             mo[s].append(q[:, : n + nvirt])
             o = np.zeros(n + nvirt)
             o[:n] = 1.0

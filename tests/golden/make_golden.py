@@ -548,9 +548,9 @@ def ref_pbc_objects(supercell, kpts, mo_coeff, Ls, determinants=None, precision=
                                                             ev.splits, ev.l_splits, expcutoff=-3.5 * np.log(precision))
     ev.Lmax = ev.num_Ls.max()
     ev.phases = np.real_if_close(np.exp(1j * ev.Ls @ kpts.T))
-    assert ev.phases.dtype == float
     ev.dtype = ev.phases.dtype
-    ev.get_wrapphase = orbitals.get_wrapphase_real
+    cplx = ev.dtype == complex or any(np.iscomplexobj(m) for sp in mo_coeff for m in sp)
+    ev.get_wrapphase = orbitals.get_wrapphase_complex if ev.dtype == complex else orbitals.get_wrapphase_real
     ev.dist = RawDistance()
     ev._gto_func = dict(GTOval_sph=pbcgto._pbc_eval_gto, GTOval_sph_deriv1=pbcgto._pbc_eval_gto_grad,
                         GTOval_sph_deriv2=pbcgto._pbc_eval_gto_lap)
@@ -562,8 +562,8 @@ def ref_pbc_objects(supercell, kpts, mo_coeff, Ls, determinants=None, precision=
     oe.param_split = [np.cumsum(nelec_per_kpt[spin]) for spin in [0, 1]]
     oe.parm_names = ["mo_coeff_alpha", "mo_coeff_beta"]
     oe.parameters = {"mo_coeff_alpha": np.concatenate(mo_coeff[0], axis=1), "mo_coeff_beta": np.concatenate(mo_coeff[1], axis=1)}
-    oe.mo_dtype = float
-    oe.get_wrapphase = orbitals.get_wrapphase_real
+    oe.mo_dtype = complex if cplx else float  # orbitals.py:161-166
+    oe.get_wrapphase = orbitals.get_wrapphase_complex if cplx else orbitals.get_wrapphase_real
     oe.eval_gto = ev.eval_gto
     if determinants is None:
         determinants = [(1.0, [list(range(supercell.nelec[0])), list(range(supercell.nelec[1]))])]
@@ -573,7 +573,7 @@ def ref_pbc_objects(supercell, kpts, mo_coeff, Ls, determinants=None, precision=
     sl.myparameters["det_coeff"], sl._det_occup, sl._det_map = determinant_tools.create_packed_objects(determinants, tol=-1)
     sl.orbitals = oe
     sl.parameters = rslater.JoinParameters([sl.myparameters, oe.parameters])
-    sl.dtype, sl.get_phase = float, np.sign
+    sl.dtype, sl.get_phase = (complex, rslater.get_complex_phase) if cplx else (float, np.sign)  # slater.py:212-216
     sl._gtoval, sl._gtoval_deriv1, sl._gtoval_deriv2 = "GTOval_sph", "GTOval_sph_deriv1", "GTOval_sph_deriv2"
     return ev, oe, sl
 
@@ -820,6 +820,45 @@ def g_testvalue_many():
     save("g18_testvalue_many", **out)
 
 
+
+# ------------------------------------------------------------------ G19 complex Bloch orbitals (k-points off the TRIM set, zero twist)
+def ref_pbc_wf_complex():
+    import pyqmc.wftools as wftools
+    from pyqmc.wf.multiplywf import MultiplyWF
+    from pyqmc_amd import pbc as mypbc
+
+    prim = systems.diamond_primitive()
+    sup = mypbc.get_supercell(prim, np.diag([3.0, 1.0, 1.0]))
+    mf = mypbc.random_kmf(sup, complex_coeff=True)
+    Ls = mypbc.lattice_points_within(prim.lattice_vectors(), 30.0)
+    ev, oe, sl = ref_pbc_objects(sup, mf.kpts, mf.mo_coeff, Ls)
+    j2, _ = wftools.generate_jastrow(sup)
+    jr = np.random.default_rng(17)
+    j2.parameters["acoeff"] = 0.05 * jr.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * jr.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    return sup, mf, Ls, oe, sl, j2, MultiplyWF(sl, j2)
+
+
+def g_pbc_complex():
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    sup, mf, Ls, oe, sl, j2, wf = ref_pbc_wf_complex()
+    assert sl.dtype == complex
+    out["kpts"], out["Ls"], out["atoms"] = mf.kpts, Ls, sup.atom_coords()
+    rng = np.random.default_rng(93)
+    pts = PeriodicConfigs((rng.random((1, 8, 3)) * 3 - 1) @ sup.lattice_vectors(), sup.lattice_vectors())
+    out["pts"] = pts.configs.copy()
+    for nm, es in (("val", "GTOval_sph"), ("lap", "GTOval_sph_deriv2")):
+        ao = oe.aos(es, pts)
+        out[f"ao_{nm}"] = ao
+        out[f"mo_{nm}"] = oe.mos(ao, 0)
+    pbc_protocol("", sup, {"slater": sl, "jastrow": j2, "wf": wf}, 3, 53, [0, 5, 12, 23], out)
+    save("g19_pbc_complex", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -902,3 +941,4 @@ if __name__ == "__main__":
     g_pbc_energy()
     g_pbc_dmc()
     g_testvalue_many()
+    g_pbc_complex()

@@ -333,3 +333,11 @@ def madelung_cases():
     cube = np.stack(np.meshgrid(*[[0, 1]] * 3, indexing="ij"), axis=-1).reshape((-1, 3))
     out.append(("caf2_conv", pbc.get_supercell(caf2, np.ones((3, 3)) - 2 * np.eye(3)), np.reshape((cube + 0.5) * L / 2, (1, 8, 3)), -4 * 5.03879))
     return out
+
+
+def pbc_complex_case():
+    """3x1x1 diamond supercell with complex Bloch coefficients at k = 0, 1/3, 2/3 b1 (make_golden.ref_pbc_wf_complex)."""
+    from pyqmc_amd import pbc
+
+    sup = pbc.get_supercell(systems.diamond_primitive(), np.diag([3.0, 1.0, 1.0]))
+    return sup, pbc.random_kmf(sup, complex_coeff=True)

@@ -246,3 +246,28 @@ def test_ewald_madelung_constants_oracle_and_host_tables():
         cfg = pc.PeriodicConfigs(np.full((1, 1, 3), 4.0 * x) + np.array([0.1, 0.2, 0.1]), cell.lattice_vectors())
         vals.append(np.concatenate([np.ravel(v) for v in opbc.Ewald(cell, ewald_gmax=25).energy(cfg)]))
     assert np.linalg.norm(vals[1] - vals[0]) < 1e-13
+
+
+# ------------------------------------------------------------------ complex Bloch orbitals (oracle vs reference)
+def test_oracle_complex_periodic_slater_matches_reference():
+    """k-points off the time-reversal-invariant set (3x1x1 supercell: k = 0, 1/3, 2/3 b1) with complex coefficients: complex
+    AOs / MOs, complex determinant phases, gradients, ratios (tests/golden/g19_pbc_complex.npz)."""
+    from helpers import pbc_complex_case
+    from oracle import jastrow_basis, pbc as opbc, wf as owf
+
+    g = golden("g19_pbc_complex")
+    sup, mf = pbc_complex_case()
+    orb = opbc.PeriodicOrbitals(sup, mf.kpts, mf.mo_coeff, g["Ls"])
+    for nm, nc in (("val", 1), ("lap", 5)):
+        ao = orb.aos(g["pts"].reshape(-1, 3), nc)
+        ref = g[f"ao_{nm}"]
+        assert relerr(ao, ref.reshape((ref.shape[0], nc, -1, ref.shape[-1]))) < 1e-12, nm
+        assert relerr(orb.mos(ao, 0), g[f"mo_{nm}"].reshape((nc, -1, g[f"mo_{nm}"].shape[-1]))) < 1e-12
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, g["Ls"])
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    wf = owf.MultiplyWF(sl, ja)
+    err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": wf}, g, "", sup)
+    assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
