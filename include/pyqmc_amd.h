@@ -117,6 +117,13 @@ typedef struct {
   const uint8_t* member;       /* n_member_class * (2M+1)^3 */
   const int32_t* member_class; /* natom */
   int32_t member_M, n_member_class;
+  /* Complex orbitals (slater.py:212-216: Bloch coefficients at k-points off the time-reversal-invariant set).  With
+     complex_orbitals != 0, mo_up / mo_dn hold [Re C | Im C] (nao x nmo_*, nmo_* = twice the number of orbitals),
+     determinant occupations still index orbitals, and every complex output of the Slater entry points (sign of
+     recompute / value, ratios of pqa_slater_eval, inverse / phases of pqa_slater_get_state) is (re, im) interleaved,
+     i.e. the buffers are numpy complex128 arrays of the documented shapes.  Implemented for the wave-function protocol
+     entry points; the fused sweep / energy entries refuse complex handles. */
+  int32_t complex_orbitals;
 } pqa_system_t;
 
 /* ---- lifetime --------------------------------------------------------------------- */

@@ -13,6 +13,7 @@
 #include "../../include/pyqmc_amd.h"
 #include "pqa_ao.hpp"
 #include "pqa_common.hpp"
+#include "pqa_cslater.hpp"
 #include "pqa_energy.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_lw.hpp"
@@ -42,6 +43,7 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
+  bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
   bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
   bool has_j2 = false, has_j3 = false;
   int na3 = 0, nb3 = 0;
@@ -302,6 +304,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
+  h->cplx = h->has_slater && sys->complex_orbitals != 0;
+  if (h->cplx && ((sys->nmo_up | sys->nmo_dn) & 1)) FAIL("complex orbitals: nmo_up / nmo_dn count the real columns [Re C | Im C] and must be even");
   h->has_j2 = sys->na > 0 || sys->nb > 0;
   h->has_j3 = sys->na3 > 0 && sys->nb3 > 0;
   h->has_jastrow = h->has_j2 || h->has_j3;
@@ -744,8 +748,9 @@ static int ensure_walkers(pqa_handle* h, long W) {
     const int nel[2] = {h->nup, h->ndn};
     for (int s = 0; s < 2; ++s) {
       const size_t D = h->ndet_s[s], n = nel[s];
-      TRY(ensure(h, h->b_T[s], W * D * n * n * sizeof(double)));
-      TRY(ensure(h, h->b_dsign[s], W * D * sizeof(double)));
+      const size_t cf = h->cplx ? 2 : 1;
+      TRY(ensure(h, h->b_T[s], cf * W * D * n * n * sizeof(double)));
+      TRY(ensure(h, h->b_dsign[s], cf * W * D * sizeof(double)));
       TRY(ensure(h, h->b_dlog[s], W * D * sizeof(double)));
       TRY(ensure(h, h->b_cache[s], W * n * 5 * h->nmo[s] * sizeof(double)));
       h->st.T[s] = (double*)h->b_T[s].p;
@@ -761,7 +766,7 @@ static int ensure_walkers(pqa_handle* h, long W) {
     h->js.avalues = (double*)h->b_aval.p;
     h->js.bvalues = (double*)h->b_bval.p;
   }
-  TRY(ensure(h, h->b_sign, W * sizeof(double)));
+  TRY(ensure(h, h->b_sign, (h->cplx ? 2 : 1) * W * sizeof(double)));
   TRY(ensure(h, h->b_log, W * sizeof(double)));
   TRY(ensure(h, h->b_ju, W * sizeof(double)));
   TRY(ensure(h, h->b_mask, W));
@@ -797,15 +802,17 @@ static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants fr
     pa.group = nel[s];
     pa.group_stride = (long)h->N * 3;
     TRY(launch_orb(h, s, pa, h->W * nel[s], 5, h->st.cache[s]));
-    const size_t lds = ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
-    hipLaunchKernelGGL(k_build_invert, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
+    const size_t lds = (h->cplx ? 2 : 1) * ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
+    if (h->cplx) hipLaunchKernelGGL(k_build_invert_c, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
+    else hipLaunchKernelGGL(k_build_invert, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     TRY(check_launch(h, "k_build_invert"));
   }
   return 0;
 }
 
 static int slater_value_dev(pqa_handle* h) {
-  hipLaunchKernelGGL(k_slater_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
+  if (h->cplx) hipLaunchKernelGGL(k_slater_value_c, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
+  else hipLaunchKernelGGL(k_slater_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
   return check_launch(h, "k_slater_value");
 }
 
@@ -834,7 +841,7 @@ extern "C" int pqa_slater_value(pqa_handle_t* h, double* sign, double* logabs) {
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   TRY(slater_value_dev(h));
-  TRY(copy_in(h, sign, h->b_sign.p, h->W * sizeof(double)));
+  TRY(copy_in(h, sign, h->b_sign.p, (h->cplx ? 2 : 1) * h->W * sizeof(double)));
   return copy_out(h, logabs, h->b_log.p, h->W * sizeof(double));
 }
 
@@ -851,7 +858,8 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
   h->saved_valid = false;
   TRY(ensure(h, h->b_pts, (size_t)P * 3 * sizeof(double)));
   TRY(ensure(h, h->b_motmp, (size_t)P * ncomp * nmo * sizeof(double)));
-  TRY(ensure(h, h->b_out, (size_t)P * ncomp * sizeof(double)));
+  const size_t cf = h->cplx ? 2 : 1;
+  TRY(ensure(h, h->b_out, cf * (size_t)P * ncomp * sizeof(double)));
   TRY(copy_in(h, h->b_pts.p, pts, (size_t)P * 3 * sizeof(double)));
   const int* dw = nullptr;
   if (widx) {
@@ -861,6 +869,14 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
   }
   TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, P), P, ncomp, (double*)h->b_motmp.p));
   const dim3 grid((unsigned)nrow), block(64);
+  if (h->cplx) {
+    if (ncomp == 1)
+      hipLaunchKernelGGL(k_slater_eval_c<1>, grid, block, 2 * lds_det(h, 1), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                         (long)nrow, npt, dw, (double*)h->b_out.p);
+    else
+      hipLaunchKernelGGL(k_slater_eval_c<5>, grid, block, 2 * lds_det(h, 5), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                         (long)nrow, npt, dw, (double*)h->b_out.p);
+  } else
   if (ncomp == 1)
     hipLaunchKernelGGL(k_slater_eval<1>, grid, block, lds_det(h, 1), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
                        (long)nrow, npt, dw, (double*)h->b_out.p);
@@ -868,7 +884,7 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
     hipLaunchKernelGGL(k_slater_eval<5>, grid, block, lds_det(h, 5), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
                        (long)nrow, npt, dw, (double*)h->b_out.p);
   TRY(check_launch(h, "k_slater_eval"));
-  TRY(copy_out(h, out, h->b_out.p, (size_t)P * ncomp * sizeof(double)));
+  TRY(copy_out(h, out, h->b_out.p, cf * (size_t)P * ncomp * sizeof(double)));
   if (keep_saved && npt == 1 && !widx && ncomp == 5) { h->saved_valid = true; h->saved_e = e; }
   return 0;
 }
@@ -876,6 +892,7 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
 extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
                                   int factors, double* out) {
   HIPCHK(hipSetDevice(h->device));
+  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (nrow <= 0 || ne <= 0) return 0;
   if (!widx && nrow != h->W) FAIL("nrow must equal the number of walkers when widx is NULL");
@@ -912,6 +929,7 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
 }
 
 extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn) {
+  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   const long W = h->W;
@@ -971,8 +989,10 @@ extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, con
     TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
     dm = (const uint8_t*)h->b_mask.p;
   }
-  hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
-                     5 * nmo, dm, 1);
+  if (h->cplx) hipLaunchKernelGGL(k_sm_update_c, dim3((unsigned)W), dim3(64), 2 * lds_sm(h), h->stream, h->S, h->st, e,
+                                  (const double*)h->b_motmp.p, 5 * nmo, dm, 1);
+  else hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+                          5 * nmo, dm, 1);
   TRY(check_launch(h, "k_sm_update"));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -983,18 +1003,20 @@ extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, 
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   const size_t W = h->W, D = h->ndet_s[spin], n = spin ? h->ndn : h->nup;
   HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t cf = h->cplx ? 2 : 1;  // complex: (re, im) interleaved in every output
   if (inverse) {
-    std::vector<double> T(W * D * n * n), inv(W * D * n * n);
+    std::vector<double> T(cf * W * D * n * n), inv(cf * W * D * n * n);
     HIPCHK(hipMemcpy(T.data(), h->st.T[spin], T.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (size_t m = 0; m < W * D; ++m)
       for (size_t i = 0; i < n; ++i)
-        for (size_t k = 0; k < n; ++k) inv[(m * n + k) * n + i] = T[(m * n + i) * n + k];
+        for (size_t k = 0; k < n; ++k)
+          for (size_t q = 0; q < cf; ++q) inv[((m * n + k) * n + i) * cf + q] = T[((m * n + i) * n + k) * cf + q];
     HIPCHK(hipMemcpy(inverse, inv.data(), inv.size() * sizeof(double), hipMemcpyDefault));
   }
-  if (dets) {
-    std::vector<double> d(2 * W * D);
-    HIPCHK(hipMemcpy(d.data(), h->st.dsign[spin], W * D * sizeof(double), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(d.data() + W * D, h->st.dlog[spin], W * D * sizeof(double), hipMemcpyDeviceToHost));
+  if (dets) {  // [phase (W,D) (complex: interleaved)] followed by [log (W,D)]
+    std::vector<double> d((cf + 1) * W * D);
+    HIPCHK(hipMemcpy(d.data(), h->st.dsign[spin], cf * W * D * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d.data() + cf * W * D, h->st.dlog[spin], W * D * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(dets, d.data(), d.size() * sizeof(double), hipMemcpyDefault));
   }
   return 0;
@@ -1152,10 +1174,11 @@ extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* b
 // ---------------------------------------------------------------- fused path
 static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
   const long W = h->W;
-  std::vector<double> sg(W, 1.0), lg(W, 0.0), ju(W, 0.0);
+  const size_t cf = h->cplx ? 2 : 1;
+  std::vector<double> sg(cf * W, 1.0), lg(W, 0.0), ju(W, 0.0);
   if (h->has_slater) {
     TRY(slater_value_dev(h));
-    TRY(copy_in(h, sg.data(), h->b_sign.p, W * sizeof(double)));
+    TRY(copy_in(h, sg.data(), h->b_sign.p, cf * W * sizeof(double)));
     TRY(copy_in(h, lg.data(), h->b_log.p, W * sizeof(double)));
   }
   std::vector<double> j3u(W, 0.0);
@@ -1171,7 +1194,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   for (long w = 0; w < W; ++w) lg[w] += ju[w] + j3u[w];
-  if (sign) HIPCHK(hipMemcpy(sign, sg.data(), W * sizeof(double), hipMemcpyDefault));
+  if (sign) HIPCHK(hipMemcpy(sign, sg.data(), cf * W * sizeof(double), hipMemcpyDefault));
   if (logabs) HIPCHK(hipMemcpy(logabs, lg.data(), W * sizeof(double), hipMemcpyDefault));
   return 0;
 }
@@ -1395,6 +1418,7 @@ extern "C" int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap) {
 }
 
 extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
+  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   h->saved_valid = false;
@@ -1406,6 +1430,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
                               const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
                               double* energy_mean, uint8_t* accept_rec) {
   HIPCHK(hipSetDevice(h->device));
+  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   if (nsteps <= 0) return 0;
   const long W = h->W;
@@ -1552,6 +1577,7 @@ extern "C" int pqa_tmove_npoints(pqa_handle_t* h) { return h->tm_P; }
 extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif,
                           double* ratio, double* weight, double* pos) {
   HIPCHK(hipSetDevice(h->device));
+  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
   const long W = h->W;

@@ -1,0 +1,279 @@
+// Complex Slater determinants (Bloch orbitals at k-points off the time-reversal-invariant set), wave-per-walker.
+//
+// Same algorithms as pqa_slater.hpp in complex arithmetic (slater.py:212-216 dtype = complex, get_phase = z/|z|):
+// build + invert :227-260, value determinant_tools.py:74-88, row-replacement ratios :301-380, Sherman-Morrison :88-94.
+// Conventions of the complex mode (SysDev.cplx != 0):
+//   * the orbital kernel sees REAL coefficient matrices [Re C | Im C] (nao x 2 nmo) — S.nmo[s] counts those real
+//     columns, the number of orbitals is S.nmo[s] / 2; an MO row is [ncomp][2 nmo] with the real parts first;
+//   * determinant occupations index orbitals (0 .. nmo-1);
+//   * T[s] is [W][D][n][n] complex, (re, im) interleaved, electron-major like the real layout;
+//   * dsign[s] is [W][D] complex unit phases (interleaved), dlog[s] [W][D] real.
+#pragma once
+#include "pqa_slater.hpp"
+
+struct cx {
+  double r, i;
+};
+__device__ __forceinline__ cx cmul(cx a, cx b) { return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; }
+__device__ __forceinline__ cx cadd(cx a, cx b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ cx csub(cx a, cx b) { return {a.r - b.r, a.i - b.i}; }
+__device__ __forceinline__ cx cscale(cx a, double f) { return {a.r * f, a.i * f}; }
+__device__ __forceinline__ double cabs2(cx a) { return a.r * a.r + a.i * a.i; }
+__device__ __forceinline__ cx cdiv(cx a, cx b) {
+  const double d = 1.0 / cabs2(b);
+  return {(a.r * b.r + a.i * b.i) * d, (a.i * b.r - a.r * b.i) * d};
+}
+__device__ __forceinline__ cx cphase(cx a) {  // z / |z| (nan for 0, like numpy)
+  const double m = sqrt(cabs2(a));
+  return {a.r / m, a.i / m};
+}
+__device__ __forceinline__ cx wave_sum_cx(cx a) { return {wave_sum(a.r), wave_sum(a.i)}; }
+
+// ---------------------------------------------------------------- build + invert
+// grid = W * ndet_s blocks of 64 threads; dynamic LDS: 2 * n * (n+1) doubles + n ints.
+__global__ __launch_bounds__(64) void k_build_invert_c(SysDev S, SlaterState st, int s, long W) {
+  extern __shared__ double lds[];
+  const int n = s ? S.ndn : S.nup, nmo2 = S.nmo[s], nmo = nmo2 / 2, D = S.ndet_s[s];
+  if (n == 0) return;
+  const long w = blockIdx.x / D;
+  const int d = blockIdx.x % D;
+  const int lane = threadIdx.x, ld = n + 1;
+  double* Mr = lds;
+  double* Mi = lds + (size_t)n * ld;
+  int* perm = (int*)(lds + (size_t)2 * n * ld);
+  const int* occ = S.det_occ[s] + (size_t)d * n;
+  const double* cw = st.cache[s] + (size_t)w * n * 5 * nmo2;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx % n;
+    Mr[j * ld + i] = cw[(size_t)i * 5 * nmo2 + occ[j]];
+    Mi[j * ld + i] = cw[(size_t)i * 5 * nmo2 + nmo + occ[j]];
+  }
+  __syncthreads();
+  cx phase = {1.0, 0.0};
+  double logd = 0.0;
+  bool singular = false;
+  for (int k = 0; k < n; ++k) {
+    double v = (lane >= k && lane < n) ? Mr[lane * ld + k] * Mr[lane * ld + k] + Mi[lane * ld + k] * Mi[lane * ld + k] : -1.0;
+    int idx = lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off, 64);
+      const int oi = __shfl_xor(idx, off, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int p = idx;
+    if (!(v > 0.0) || !(v <= DBL_MAX)) { singular = true; break; }
+    if (p != k && lane < n) {
+      double t = Mr[k * ld + lane]; Mr[k * ld + lane] = Mr[p * ld + lane]; Mr[p * ld + lane] = t;
+      t = Mi[k * ld + lane]; Mi[k * ld + lane] = Mi[p * ld + lane]; Mi[p * ld + lane] = t;
+    }
+    if (p != k) phase = cscale(phase, -1.0);
+    if (lane == 0) perm[k] = p;
+    __syncthreads();
+    const cx piv = {Mr[k * ld + k], Mi[k * ld + k]};
+    logd += 0.5 * log(cabs2(piv));
+    phase = cmul(phase, cphase(piv));
+    __syncthreads();
+    cx rk = {0.0, 0.0};
+    if (lane < n) {
+      const cx one = {1.0, 0.0};
+      rk = (lane == k) ? cdiv(one, piv) : cdiv(cx{Mr[k * ld + lane], Mi[k * ld + lane]}, piv);
+      Mr[k * ld + lane] = rk.r; Mi[k * ld + lane] = rk.i;
+    }
+    for (int r = 0; r < n; ++r) {
+      if (r == k) continue;
+      const cx f = {Mr[r * ld + k], Mi[r * ld + k]};
+      if (lane < n) {
+        const cx cur = (lane == k) ? cx{0.0, 0.0} : cx{Mr[r * ld + lane], Mi[r * ld + lane]};
+        const cx nv = csub(cur, cmul(f, rk));
+        Mr[r * ld + lane] = nv.r; Mi[r * ld + lane] = nv.i;
+      }
+    }
+    __syncthreads();
+  }
+  double* Tw = st.T[s] + ((size_t)w * D + d) * n * n * 2;
+  double* ph = st.dsign[s] + ((size_t)w * D + d) * 2;
+  if (singular) {
+    for (int idx = lane; idx < 2 * n * n; idx += 64) Tw[idx] = 0.0;
+    if (lane == 0) { ph[0] = 0.0; ph[1] = 0.0; st.dlog[s][w * D + d] = -INFINITY; }
+    return;
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = perm[k];
+    if (p != k && lane < n) {
+      double t = Mr[lane * ld + k]; Mr[lane * ld + k] = Mr[lane * ld + p]; Mr[lane * ld + p] = t;
+      t = Mi[lane * ld + k]; Mi[lane * ld + k] = Mi[lane * ld + p]; Mi[lane * ld + p] = t;
+    }
+    __syncthreads();
+  }
+  for (int idx = lane; idx < n * n; idx += 64) {
+    Tw[2 * idx] = Mr[(idx / n) * ld + idx % n];
+    Tw[2 * idx + 1] = Mi[(idx / n) * ld + idx % n];
+  }
+  if (lane == 0) { ph[0] = phase.r; ph[1] = phase.i; st.dlog[s][w * D + d] = logd; }
+}
+
+// ---------------------------------------------------------------- multi-determinant bookkeeping
+__device__ __forceinline__ cx det_weight_c(const SysDev& S, const SlaterState& st, long w, int Dd, double ref) {
+  cx ph = {1.0, 0.0};
+  if (S.nup > 0) { const double* p = st.dsign[0] + ((size_t)w * S.ndet_s[0] + S.det_map[Dd]) * 2; ph = cmul(ph, cx{p[0], p[1]}); }
+  if (S.ndn > 0) { const double* p = st.dsign[1] + ((size_t)w * S.ndet_s[1] + S.det_map[S.ndet + Dd]) * 2; ph = cmul(ph, cx{p[0], p[1]}); }
+  const double l = det_logsum(S, st, w, Dd);
+  const double ex = (l == -INFINITY) ? 0.0 : exp(l - ref);
+  return cscale(ph, S.det_coeff[Dd] * ex);
+}
+
+// (phase, log|Psi_S|) of one walker — determinant_tools.compute_value (:74-88) with get_phase = z/|z|
+__device__ __forceinline__ void slater_value_wave_c(const SysDev& S, const SlaterState& st, long w, cx& phase, double& logv) {
+  const double ref = det_ref(S, st, w);
+  cx t = {0.0, 0.0};
+  for (int Dd = threadIdx.x & 63; Dd < S.ndet; Dd += 64) t = cadd(t, det_weight_c(S, st, w, Dd, ref));
+  t = wave_sum_cx(t);
+  const double m = sqrt(cabs2(t));
+  phase = {clamp_nan_to_num(t.r / m), clamp_nan_to_num(t.i / m)};
+  logv = clamp_nan_to_num(log(m) + ref);
+}
+
+__global__ __launch_bounds__(64) void k_slater_value_c(SysDev S, SlaterState st, double* sign, double* logv) {
+  const long w = blockIdx.x;
+  cx ph;
+  double lv;
+  slater_value_wave_c(S, st, w, ph, lv);
+  if (threadIdx.x == 0) { sign[2 * w] = ph.r; sign[2 * w + 1] = ph.i; logv[w] = lv; }
+}
+
+// Ratios (new row)/(current) of electron i for NCOMP stacked rows mo[c][2 nmo] (re block, im block).
+// scratch: >= ndet_s * NCOMP * 2 doubles of LDS (multi-determinant only).
+template <int NCOMP>
+__device__ __forceinline__ void slater_ratios_c(const SysDev& S, const SlaterState& st, int s, int i, long w,
+                                                const double* __restrict__ mo, cx (&out)[NCOMP], double* scratch) {
+  const int lane = threadIdx.x & 63;
+  const int n = s ? S.ndn : S.nup, nmo2 = S.nmo[s], nmo = nmo2 / 2, D = S.ndet_s[s];
+  auto dots = [&](int d, cx (&part)[NCOMP]) {
+    const double* Trow = st.T[s] + ((((size_t)w * D + d) * n + i) * n) * 2;
+    const int* occ = S.det_occ[s] + (size_t)d * n;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) part[c] = {0.0, 0.0};
+    for (int j = lane; j < n; j += 64) {
+      const cx t = {Trow[2 * j], Trow[2 * j + 1]};
+      const int o = occ[j];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) part[c] = cadd(part[c], cmul(cx{mo[c * nmo2 + o], mo[c * nmo2 + nmo + o]}, t));
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) part[c] = wave_sum_cx(part[c]);
+  };
+  if (S.ndet == 1) {
+    dots(0, out);
+    return;
+  }
+  for (int d = 0; d < D; ++d) {
+    cx part[NCOMP];
+    dots(d, part);
+    if (lane == 0)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) { scratch[(d * NCOMP + c) * 2] = part[c].r; scratch[(d * NCOMP + c) * 2 + 1] = part[c].i; }
+  }
+  __syncthreads();
+  const double ref = det_ref(S, st, w);
+  cx num[NCOMP], den = {0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) num[c] = {0.0, 0.0};
+  for (int Dd = lane; Dd < S.ndet; Dd += 64) {
+    const cx wt = det_weight_c(S, st, w, Dd, ref);
+    const int ds = S.det_map[s * S.ndet + Dd];
+    den = cadd(den, wt);
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) num[c] = cadd(num[c], cmul(wt, cx{scratch[(ds * NCOMP + c) * 2], scratch[(ds * NCOMP + c) * 2 + 1]}));
+  }
+  den = wave_sum_cx(den);
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) out[c] = cdiv(wave_sum_cx(num[c]), den);
+  __syncthreads();
+}
+
+// out (NCOMP, nrow*npt) complex (interleaved); mo rows [(r*npt+q)][NCOMP][2 nmo]; LDS: max(ndet_s)*NCOMP*2 doubles
+template <int NCOMP>
+__global__ __launch_bounds__(64) void k_slater_eval_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, long nrow,
+                                                      int npt, const int* __restrict__ widx, double* __restrict__ out) {
+  extern __shared__ double lds[];
+  const long r = blockIdx.x;
+  const long w = widx ? widx[r] : r;
+  const int s = e >= S.nup, i = e - s * S.nup, nmo2 = S.nmo[s];
+  for (int q = 0; q < npt; ++q) {
+    cx rat[NCOMP];
+    slater_ratios_c<NCOMP>(S, st, s, i, w, mo + ((size_t)(r * npt + q) * NCOMP) * nmo2, rat, lds);
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) {
+        const size_t o = ((size_t)c * nrow * npt + r * npt + q) * 2;
+        out[o] = rat[c].r; out[o + 1] = rat[c].i;
+      }
+  }
+}
+
+// ---------------------------------------------------------------- Sherman-Morrison (slater.py:88-94, :286-291)
+// lane = row j of the tile.  LDS: 2 n (n+1) + 2 n + 2 n doubles.
+__device__ __forceinline__ void sm_update_wave_c(const SysDev& S, const SlaterState& st, int s, int i, long w,
+                                                 const double* __restrict__ morow, double* lds) {
+  const int lane = threadIdx.x & 63;
+  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s] / 2, D = S.ndet_s[s], ld = n + 1;
+  double* Lr = lds;
+  double* Li = Lr + (size_t)n * ld;
+  double* Vr = Li + (size_t)n * ld;
+  double* Vi = Vr + n;
+  double* Rr = Vi + n;
+  double* Ri = Rr + n;
+  for (int d = 0; d < D; ++d) {
+    double* Tw = st.T[s] + ((size_t)w * D + d) * n * n * 2;
+    const int* occ = S.det_occ[s] + (size_t)d * n;
+    for (int idx = lane; idx < n * n; idx += 64) {
+      Lr[(idx / n) * ld + idx % n] = Tw[2 * idx];
+      Li[(idx / n) * ld + idx % n] = Tw[2 * idx + 1];
+    }
+    for (int k = lane; k < n; k += 64) { Vr[k] = morow[occ[k]]; Vi[k] = morow[nmo + occ[k]]; }
+    __syncthreads();
+    cx tmp = {0.0, 0.0};
+    if (lane < n)
+      for (int k = 0; k < n; ++k) tmp = cadd(tmp, cmul(cx{Vr[k], Vi[k]}, cx{Lr[lane * ld + k], Li[lane * ld + k]}));
+    const cx ratio = {__shfl(tmp.r, i, 64), __shfl(tmp.i, i, 64)};
+    if (lane < n) {
+      const cx q = cdiv(cx{Lr[i * ld + lane], Li[i * ld + lane]}, ratio);
+      Rr[lane] = q.r; Ri[lane] = q.i;
+    }
+    __syncthreads();
+    if (lane < n) {
+      for (int k = 0; k < n; ++k) {
+        const cx rk = {Rr[k], Ri[k]};
+        const cx nv = (lane == i) ? rk : csub(cx{Lr[lane * ld + k], Li[lane * ld + k]}, cmul(rk, tmp));
+        Lr[lane * ld + k] = nv.r; Li[lane * ld + k] = nv.i;
+      }
+    }
+    __syncthreads();
+    for (int idx = lane; idx < n * n; idx += 64) {
+      Tw[2 * idx] = Lr[(idx / n) * ld + idx % n];
+      Tw[2 * idx + 1] = Li[(idx / n) * ld + idx % n];
+    }
+    if (lane == 0) {
+      double* ph = st.dsign[s] + ((size_t)w * D + d) * 2;
+      const cx np_ = cmul(cx{ph[0], ph[1]}, cphase(ratio));
+      ph[0] = np_.r; ph[1] = np_.i;
+      st.dlog[s][(size_t)w * D + d] += 0.5 * log(cabs2(ratio));
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, int row_stride,
+                                                    const uint8_t* __restrict__ mask, int to_cache) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  if (mask && !mask[w]) return;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo2 = S.nmo[s];
+  const double* row = mo + (size_t)w * row_stride;
+  sm_update_wave_c(S, st, s, i, w, row, lds);
+  if (to_cache) {
+    double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo2;
+    for (int k = threadIdx.x; k < 5 * nmo2; k += 64) c[k] = row[k];
+  }
+}

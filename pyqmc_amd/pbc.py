@@ -173,8 +173,8 @@ def periodic_tables(supercell, eval_gto_precision=None, Ls_prim=None, image_rule
 
 # ------------------------------------------------------------------ folding k-point MOs onto the supercell
 def fold_mo_coeff(supercell, kpts, mo_coeff):
-    """mo_coeff[s][k] (nao_prim, nmo_k) at primitive k-points -> real (2)[nao_super, sum_k nmo_k] matrices in the
-    AO order of ``tables.basis_tables(supercell)`` (atoms primitive-atom-major, copies inside)."""
+    """mo_coeff[s][k] (nao_prim, nmo_k) at primitive k-points -> (2)[nao_super, sum_k nmo_k] matrices (real when every Bloch
+    phase and coefficient is, complex otherwise) in the AO order of ``tables.basis_tables(supercell)`` (atoms primitive-atom-major, copies inside)."""
     prim = supercell.original_cell
     kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
     copies = get_supercell_copies(prim.lattice_vectors(), supercell.S)
@@ -184,16 +184,17 @@ def fold_mo_coeff(supercell, kpts, mo_coeff):
     if np.abs(twist - np.round(twist)).max() > 1e-9:
         raise NotImplementedError("non-zero supercell twist (needs the walkers' wrap counters on the device) is not implemented yet")
     phase = np.exp(1j * copies @ kpts.T)  # (ncopy, nk)
-    if np.abs(phase.imag).max() > 1e-9 or any(np.iscomplexobj(m) and np.abs(np.imag(m)).max() > 1e-12 for s in (0, 1) for m in mo_coeff[s]):
-        raise NotImplementedError("complex Bloch orbitals (twists / k-meshes off the time-reversal-invariant points) are not implemented yet")
-    phase = phase.real
+    cplx = np.abs(phase.imag).max() > 1e-9 or any(np.iscomplexobj(m) and np.abs(np.imag(m)).max(initial=0.0) > 1e-12
+                                                   for s in (0, 1) for m in mo_coeff[s])
+    if not cplx:
+        phase = phase.real
     nao_atom = [sum(2 * sh[0] + 1 for sh in prim._basis[n]) for n in prim._names]
     off = np.concatenate([[0], np.cumsum(nao_atom)])
     out = []
     for s in (0, 1):
         blocks = []
         for k in range(len(kpts)):
-            C = np.real(np.asarray(mo_coeff[s][k]))
+            C = np.asarray(mo_coeff[s][k]) if cplx else np.real(np.asarray(mo_coeff[s][k]))
             rows = [phase[c, k] * C[off[a] : off[a + 1]] for a in range(len(nao_atom)) for c in range(len(copies))]
             blocks.append(np.concatenate(rows, axis=0))
         out.append(np.concatenate(blocks, axis=1))

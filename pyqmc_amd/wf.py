@@ -31,6 +31,7 @@ class DeviceWF:
         self.N = sum(self.nelec)
         self.natom = int(mol.natm)
         self.has_slater = mo_coeff is not None
+        self.cplx = False
         self.has_jastrow = a_basis is not None or b_basis is not None
         self.has_j3 = a3_basis is not None and b3_basis is not None
         keep = self._keep = {}  # host arrays referenced by the struct must outlive pqa_create
@@ -65,13 +66,16 @@ class DeviceWF:
             nmo = [int(o.max(initial=-1)) + 1 for o in (occ_up, occ_dn)]
             self.nmo = tuple(nmo)
             self.ndet, self.ndet_s = len(coef), (len(occ_up), len(occ_dn))
-            mo = [np.ascontiguousarray(np.asarray(mo_coeff[sp])[:, : nmo[sp]], dtype=float) for sp in (0, 1)]
-            if any(np.iscomplexobj(np.asarray(m)) for m in mo_coeff):
-                raise NotImplementedError("complex orbitals (twisted PBC) are not implemented yet")
+            self.cplx = any(np.iscomplexobj(np.asarray(m)) and np.abs(np.imag(m)).max(initial=0.0) > 0 for m in mo_coeff)
+            dt = complex if self.cplx else float
+            mo = [np.ascontiguousarray(np.asarray(mo_coeff[sp])[:, : nmo[sp]], dtype=dt) for sp in (0, 1)]
             self.mo_coeff = mo
-            s.nmo_up, s.nmo_dn = nmo
-            setd("mo_up", mo[0])
-            setd("mo_dn", mo[1])
+            # complex orbitals travel as the real matrix [Re C | Im C]: the orbital kernel stays a real GEMM
+            f = 2 if self.cplx else 1
+            s.nmo_up, s.nmo_dn = f * nmo[0], f * nmo[1]
+            s.complex_orbitals = int(self.cplx)
+            setd("mo_up", self._mo_to_device(mo[0]))
+            setd("mo_dn", self._mo_to_device(mo[1]))
             s.ndet, s.ndet_up, s.ndet_dn = self.ndet, len(occ_up), len(occ_dn)
             setd("det_coeff", coef)
             seti("det_occ_up", occ_up)
@@ -162,8 +166,16 @@ class DeviceWF:
     def call_int(self, name, *args):
         return int(getattr(_ffi.lib(), name)(self._h, *args))
 
+    def _mo_to_device(self, m):
+        m = np.asarray(m)
+        return np.ascontiguousarray(np.concatenate([m.real, m.imag], axis=1) if self.cplx else m, dtype=float)
+
+    @property
+    def cdtype(self):
+        return complex if self.cplx else float
+
     def set_param(self, name, value):
-        a = _ffi.f64(value)
+        a = self._mo_to_device(value) if name.startswith("mo_coeff") else _ffi.f64(value)
         self.call("pqa_set_param", name.encode(), _ffi.ptr(a), a.size)
 
     # fused device-resident entry points ---------------------------------
@@ -189,13 +201,13 @@ class DeviceWF:
     def recompute(self, configs):
         x = _ffi.f64(configs)
         W = x.shape[0]
-        sign, logv = np.empty(W), np.empty(W)
+        sign, logv = np.empty(W, dtype=self.cdtype), np.empty(W)
         self.call("pqa_wf_recompute", _ffi.ptr(x), W, _ffi.ptr(sign), _ffi.ptr(logv))
         self.W = W
         return sign, logv
 
     def value(self):
-        sign, logv = np.empty(self.W), np.empty(self.W)
+        sign, logv = np.empty(self.W, dtype=self.cdtype), np.empty(self.W)
         self.call("pqa_wf_value", _ffi.ptr(sign), _ffi.ptr(logv))
         return sign, logv
 
@@ -264,9 +276,10 @@ class DeviceWF:
 
     def eval_mo(self, spin, pts, ncomp, use_mfma=True):
         p = _ffi.f64(pts).reshape(-1, 3)
-        out = np.empty((ncomp, p.shape[0], self.nmo[spin]))
+        f = 2 if self.cplx else 1
+        out = np.empty((ncomp, p.shape[0], f * self.nmo[spin]))
         self.call("pqa_eval_mo", int(spin), _ffi.ptr(p), p.shape[0], ncomp, int(use_mfma), _ffi.ptr(out))
-        return out
+        return out[..., : self.nmo[spin]] + 1j * out[..., self.nmo[spin] :] if self.cplx else out
 
 
 class _DeviceParams(dict):
@@ -390,7 +403,7 @@ class Slater:
                                                "mo_coeff_beta": _dev.mo_coeff[1].copy()})
         self._det_occup = [o.tolist() for o in _dev.det_occup]
         self._det_map = _dev.det_map
-        self.dtype = float
+        self.dtype = _dev.cdtype  # slater.py:212-216
         self._saved = None
 
     def _spin(self, e):
@@ -400,14 +413,14 @@ class Slater:
         self.parameters.push()
         x = _ffi.f64(configs.configs)
         W = x.shape[0]
-        sign, logv = np.empty(W), np.empty(W)
+        sign, logv = np.empty(W, dtype=self._dev.cdtype), np.empty(W)
         self._dev.call("pqa_slater_recompute", _ffi.ptr(x), W, _ffi.ptr(sign), _ffi.ptr(logv))
         self._dev.W = W
         return sign, logv
 
     def value(self):
         W = self._dev.W
-        sign, logv = np.empty(W), np.empty(W)
+        sign, logv = np.empty(W, dtype=self._dev.cdtype), np.empty(W)
         self._dev.call("pqa_slater_value", _ffi.ptr(sign), _ffi.ptr(logv))
         return sign, logv
 
@@ -415,7 +428,7 @@ class Slater:
         m, _ = _mask_args(mask, self._dev.W)
         pts, widx, aux = _points(epos, m)
         nrow, npt = pts.shape[0], pts.shape[1]
-        out = np.empty((ncomp, nrow * npt))
+        out = np.empty((ncomp, nrow * npt), dtype=self._dev.cdtype)
         if nrow:
             self._dev.call("pqa_slater_eval", int(e), _ffi.ptr(pts), nrow, npt, _ffi.ptr(widx), ncomp, int(keep), _ffi.ptr(out))
         return out, nrow, npt, aux
@@ -483,6 +496,11 @@ class Slater:
     # test access to internals, in the reference's layout
     def _get_state(self, s):
         W, D, n = self._dev.W, self._dev.ndet_s[s], self._nelec[s]
+        if self._dev.cplx:  # phases complex (W,D) followed by logs (W,D)
+            inv, raw = np.empty((W, D, n, n), dtype=complex), np.empty(3 * W * D)
+            self._dev.call("pqa_slater_get_state", s, _ffi.ptr(inv), _ffi.ptr(raw))
+            ph = raw[: 2 * W * D].reshape(W, D, 2)
+            return inv, np.array([ph[..., 0] + 1j * ph[..., 1], raw[2 * W * D :].reshape(W, D)])
         inv, dets = np.empty((W, D, n, n)), np.empty((2, W, D))
         self._dev.call("pqa_slater_get_state", s, _ffi.ptr(inv), _ffi.ptr(dets))
         return inv, dets

@@ -222,3 +222,32 @@ def test_ewald_madelung_constants_on_device():
         en = pa.EnergyAccumulator(sup)(c, ja)
         coulomb = en["total"] - en["ke"] - en["ecp"]
         assert abs(coulomb[0] - want) < 1e-4 * max(1, abs(want) / 1.7), (name, coulomb, want)
+
+
+# ------------------------------------------------------------------ complex Bloch orbitals
+def test_complex_periodic_slater_matches_reference():
+    """k-points off the time-reversal-invariant set (3x1x1 diamond supercell: k = 0, 1/3, 2/3 b1, complex coefficients): complex
+    MOs, determinant phases, gradients, Laplacians, ratios, Sherman-Morrison updates against the reference
+    (tests/golden/g19_pbc_complex.npz) — the orbital kernel runs as a real GEMM on [Re C | Im C], the determinant kernels
+    in complex arithmetic (csrc/pqa_cslater.hpp)."""
+    import pyqmc_amd as pa
+    from helpers import pbc_complex_case
+
+    g = golden("g19_pbc_complex")
+    sup, mf = pbc_complex_case()
+    wf = pa.generate_wf(sup, mf)
+    sl = wf.wf_factors[0]
+    assert sl.dtype == complex
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    pts = g["pts"].reshape(-1, 3)
+    for nm, nc in (("val", 1), ("lap", 5)):
+        ref = g[f"mo_{nm}"]
+        mo = sl._dev.eval_mo(0, pts, nc)
+        assert helpers.relerr(mo, ref.reshape((nc, -1, ref.shape[-1]))) < 1e-12, nm
+    err = run_protocol_pbc({"slater": sl, "jastrow": wf.wf_factors[1], "wf": wf}, g, "", sup)
+    assert max(err.values()) < 2e-9, {k: v for k, v in err.items() if v > 1e-10}
+    cfg = systems.initial_guess(sup, 3)
+    wf.recompute(cfg)
+    with pytest.raises(pa._ffi.PqaError):  # fused entries refuse complex handles for now
+        pa.EnergyAccumulator(sup)(cfg, wf)
