@@ -128,7 +128,7 @@ def ecp_ea(mol, configs, wf, e, atom_index, threshold, rot, unif, naip=None):
         P[:, :, k] = (2 * l + 1) * legendre(cos, l) * wts[None]
     epos = np.repeat(x[:, e, None, :], naip, axis=1)
     epos[mask] = (x[mask, e, :] - rvm)[:, None] + r_i
-    val = np.zeros(W)
+    val = np.zeros(W, dtype=getattr(wf, "dtype", float))  # eval_ecp.py:89
     if np.any(mask):
         ratio = wf.testvalue(e, configs.make_irreducible(e, epos, mask), mask)[0]
         val[mask] = np.einsum("ij,ik,ijk->i", ratio, mv, P)
@@ -145,7 +145,7 @@ def ecp_atoms(mol):
 def ecp(mol, configs, wf, threshold, rot_tape, unif_tape, naip=None):
     """eval_ecp.py:21-40.  rot_tape (N, n_ecp_atoms, 3, 3); unif_tape (N, n_ecp_atoms, W)."""
     W, N = configs.configs.shape[:2]
-    tot = np.zeros(W)
+    tot = np.zeros(W, dtype=getattr(wf, "dtype", float))
     for e in range(N):
         for k, ia in enumerate(ecp_atoms(mol)):
             tot += ecp_ea(mol, configs, wf, e, ia, threshold, rot_tape[e, k], unif_tape[e, k], naip)["total"]

@@ -26,7 +26,7 @@ def limdrift(g, cutoff=1.0):
 
 
 def vmc_worker(mol, wf, configs, tstep, gauss, unif, ecp_rot=None, ecp_unif=None, threshold=10.0,
-               with_energy=True, record=None):
+               with_energy=True, record=None, ewald_kws=None):
     """Returns (block_avg dict, configs).  ``record`` (optional list) receives the
     per-move accept masks for trajectory comparison."""
     nsteps = gauss.shape[0]
@@ -58,7 +58,7 @@ def vmc_worker(mol, wf, configs, tstep, gauss, unif, ecp_rot=None, ecp_unif=None
         if with_energy:
             en = oenergy.energy(mol, configs, wf, threshold,
                                 None if ecp_rot is None else ecp_rot[step],
-                                None if ecp_unif is None else ecp_unif[step])
+                                None if ecp_unif is None else ecp_unif[step], ewald_kws=ewald_kws)
             for k, v in en.items():
                 block_avg["energy" + k] = block_avg.get("energy" + k, 0.0) + np.mean(v, axis=0) / nsteps
         t2 = time.perf_counter()

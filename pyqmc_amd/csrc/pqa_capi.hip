@@ -1271,7 +1271,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
                       bool soa_current = false) {
   const long W = h->W;
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
-  TRY(ensure(h, h->b_en, (size_t)6 * W * sizeof(double)));
+  TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
   if (soa_current) {
     if (h->S.pbc)
       hipLaunchKernelGGL(k_kinetic_lw<true>, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
@@ -1284,8 +1284,10 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(check_launch(h, "k_kinetic_lw"));
     if (h->necp > 0) TRY(lw_to_aos(h, false));
   } else {
-    hipLaunchKernelGGL(k_kinetic_coulomb, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
-                       (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
+    if (h->cplx) hipLaunchKernelGGL(k_kinetic_coulomb<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js,
+                                    (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
+    else hipLaunchKernelGGL(k_kinetic_coulomb<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
+                            (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_coulomb"));
   }
   if (h->S.pbc) {
@@ -1318,7 +1320,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(ensure(h, h->b_elocal, W * sizeof(double)));
     TRY(ensure(h, h->b_ecnt, 2 * W * sizeof(int)));
     TRY(ensure(h, h->b_eoff, 2 * (W + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_ecp, W * sizeof(double)));
+    TRY(ensure(h, h->b_ecp, (h->cplx ? 2 : 1) * W * sizeof(double)));
     TRY(ensure(h, h->b_epass, (size_t)W * h->necp * ((h->N + 63) / 64) * sizeof(unsigned long long)));
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
@@ -1350,6 +1352,14 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         for (int s = 0; s < 2; ++s)
           TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
     }
+    if (h->cplx) {  // complex determinants: wave-per-walker accumulation in complex arithmetic
+      if (h->S.pbc)
+        hipLaunchKernelGGL((k_ecp_accum<true, true>), dim3((unsigned)W), dim3(64), 2 * lds_det(h, 1), h->stream, h->S, h->st, h->js, B,
+                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+      else
+        hipLaunchKernelGGL((k_ecp_accum<false, true>), dim3((unsigned)W), dim3(64), 2 * lds_det(h, 1), h->stream, h->S, h->st, h->js, B,
+                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+    } else
     if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
       for (int s = 0; s < 2; ++s) {
         if (tot[s] <= 0) continue;
@@ -1374,7 +1384,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     d_ecp = (const double*)h->b_ecp.p;
   }
   hipLaunchKernelGGL(k_energy_assemble, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
-                     h->ii_energy, W, (double*)h->b_en.p);
+                     h->ii_energy, W, (double*)h->b_en.p, (int)h->cplx);
   return check_launch(h, "k_energy_assemble");
 }
 
@@ -1418,19 +1428,17 @@ extern "C" int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap) {
 }
 
 extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
-  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   h->saved_valid = false;
   TRY(energy_dev(h, threshold, rot, unif, seed, 0u));
-  return copy_out(h, out, h->b_en.p, (size_t)6 * h->W * sizeof(double));
+  return copy_out(h, out, h->b_en.p, (size_t)(h->cplx ? 7 : 6) * h->W * sizeof(double));
 }
 
 extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif, double threshold,
                               const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
                               double* energy_mean, uint8_t* accept_rec) {
   HIPCHK(hipSetDevice(h->device));
-  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   if (nsteps <= 0) return 0;
   const long W = h->W;
@@ -1442,7 +1450,8 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   TRY(ensure(h, h->b_accept, (size_t)W));
   TRY(ensure(h, h->b_acccnt, (size_t)nsteps * sizeof(int)));
   TRY(ensure(h, h->b_motmp, (size_t)W * 5 * std::max(nmo_max, 1) * sizeof(double)));
-  TRY(ensure(h, h->b_means, (size_t)nsteps * 6 * sizeof(double)));
+  const int nen = h->cplx ? 7 : 6;  // energy rows: complex determinants add Im(ecp) = Im(total)
+  TRY(ensure(h, h->b_means, (size_t)nsteps * nen * sizeof(double)));
   TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
   HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
@@ -1457,7 +1466,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
   const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
-  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3;
+  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && !h->cplx;
   int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
   while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
   int Gm = 1;  // groups of the (latency-bound) partial-sum kernels: ~4 waves per SIMD
@@ -1543,10 +1552,18 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
         }
         continue;
       }
-      hipLaunchKernelGGL(k_propose, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+      if (h->cplx) {
+        hipLaunchKernelGGL(k_propose<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+                           (int)h->has_slater, (int)h->has_jastrow, W);
+        if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+        hipLaunchKernelGGL(k_accept<true>, dim3((unsigned)W), dim3(64), 2 * lds_acc, h->stream, h->S, h->st, h->js, mb, e,
+                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+        continue;
+      }
+      hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
                          (int)h->has_slater, (int)h->has_jastrow, W);
       if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-      hipLaunchKernelGGL(k_accept, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
+      hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
                          (int)h->has_jastrow, mo, W);
     }
     hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
@@ -1555,7 +1572,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
                      ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw));
-      hipLaunchKernelGGL(k_row_means, dim3(6), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * 6);
+      hipLaunchKernelGGL(k_row_means, dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
       TRY(check_launch(h, "k_row_means"));
     }
   }
@@ -1568,7 +1585,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     for (int i = 0; i < nsteps; ++i) acc[i] = (double)cnt[i] / ((double)W * N);
     HIPCHK(hipMemcpy(acceptance, acc.data(), nsteps * sizeof(double), hipMemcpyDefault));
   }
-  if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * 6 * sizeof(double), hipMemcpyDefault));
+  if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * nen * sizeof(double), hipMemcpyDefault));
   return 0;
 }
 

@@ -12,6 +12,8 @@
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // out rows: ke, ee, ei, grad2 each (W).  LDS: max(ndet_s)*5 doubles (multi-determinant scratch).
+// CX: complex determinants — ke = -1/2 Re(lap Psi / Psi), grad2 = sum |grad Psi / Psi|^2 (energy.py:57-65).
+template <bool CX>
 __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
                                                         int has_jastrow, long W, double* __restrict__ out) {
   extern __shared__ double lds[];
@@ -20,13 +22,20 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double ke = 0.0, grad2 = 0.0;
   for (int e = 0; e < S.nelec; ++e) {
-    double gs[3] = {0.0, 0.0, 0.0}, ls = 0.0;
+    double gs[3] = {0.0, 0.0, 0.0}, ls = 0.0, gsi[3] = {0.0, 0.0, 0.0};  // gsi: imaginary part of the Slater gradient (CX)
     if (has_slater) {
       const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-      double r[5];
-      slater_ratios<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
-      gs[0] = r[1] / r[0]; gs[1] = r[2] / r[0]; gs[2] = r[3] / r[0];
-      ls = r[4] / r[0];
+      if (CX) {
+        cx r[5];
+        slater_ratios_c<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
+        for (int c = 0; c < 3; ++c) { const cx g = cdiv(r[1 + c], r[0]); gs[c] = g.r; gsi[c] = g.i; }
+        ls = cdiv(r[4], r[0]).r;  // only the real part of the Laplacian enters (gj is real)
+      } else {
+        double r[5];
+        slater_ratios<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
+        gs[0] = r[1] / r[0]; gs[1] = r[2] / r[0]; gs[2] = r[3] / r[0];
+        ls = r[4] / r[0];
+      }
     }
     double gj[3] = {0.0, 0.0, 0.0}, lj = 0.0, U;
     if (has_jastrow) {
@@ -37,6 +46,7 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
     const double lap = ls + lj + 2.0 * (gs[0] * gj[0] + gs[1] * gj[1] + gs[2] * gj[2]);
     ke += -0.5 * lap;
     grad2 += gx * gx + gy * gy + gz * gz;
+    if (CX) grad2 += gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2];
   }
   double ee = 0.0, ei = 0.0;
   for (int i = 0; i < (S.pbc ? 0 : S.nelec); ++i) {  // periodic cells: k_ewald fills ee / ei
@@ -342,14 +352,15 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
 
 // pass C: ecp[w] = local + sum_points weight * Psi(aux)/Psi.  mo[s]: [npts_s][nmo_s] orbital values.
 // LDS: max(ndet_s) doubles.
-template <bool PBC>
+// CX: complex determinants; the imaginary part of the walker's sum goes to ecp[W + w].
+template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
                                                   int has_jastrow, const double* __restrict__ mo_up,
                                                   const double* __restrict__ mo_dn, long W, double* __restrict__ ecp) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
-  double tot = 0.0;
+  double tot = 0.0, tot_im = 0.0;
   for (int s = 0; s < 2; ++s) {
     const double* mo = s ? mo_dn : mo_up;
     const int nmo = S.nmo[s];
@@ -357,22 +368,33 @@ __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, Jast
     double U0 = 0.0;
     for (long p = B.off[(size_t)s * (W + 1) + w]; p < B.off[(size_t)s * (W + 1) + w + 1]; ++p) {
       const int e = B.pte[s][p];
-      double ratio = 1.0;
+      double ratio = 1.0, ratio_im = 0.0;
       if (has_slater) {
-        double r1[1];
-        slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
-        ratio = r1[0];
+        if (CX) {
+          cx r1[1];
+          slater_ratios_c<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
+          ratio = r1[0].r; ratio_im = r1[0].i;
+        } else {
+          double r1[1];
+          slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
+          ratio = r1[0];
+        }
       }
       if (has_jastrow) {
         double g[3], lp, U;
         if (e != last_e) { jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
         jas_eval<0, PBC>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp, 3, lds + S.j3_off);
-        ratio *= exp(U - U0);
+        const double ej = exp(U - U0);
+        ratio *= ej; ratio_im *= ej;
       }
       tot += ratio * B.wgt[s][p];
+      if (CX) tot_im += ratio_im * B.wgt[s][p];
     }
   }
-  if (threadIdx.x == 0) ecp[w] = B.local[w] + tot;
+  if (threadIdx.x == 0) {
+    ecp[w] = B.local[w] + tot;
+    if (CX) ecp[W + w] = tot_im;
+  }
 }
 
 // uniformly random rotations from a normalised Gaussian quaternion (one per (electron, ECP atom))
@@ -391,13 +413,15 @@ __global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __res
 }
 
 // total = ke + ee + ei + ecp + ii ; rows of out: ke, ee, ei, ecp, grad2, total  (accumulators.py:68-75)
+// complex determinants: a 7th row holds Im(ecp) = Im(total) (eval_ecp.py:89, accumulators.py:74).
 __global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2*/, const double* __restrict__ ecp,
-                                  double ii, long W, double* __restrict__ out) {
+                                  double ii, long W, double* __restrict__ out, int cplx) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   const double ke = kc[w], ee = kc[W + w], ei = kc[2 * W + w], g2 = kc[3 * W + w], ec = ecp ? ecp[w] : 0.0;
   out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = ec; out[4 * W + w] = g2;
   out[5 * W + w] = ke + ee + ei + ec + ii;
+  if (cplx) out[6 * W + w] = ecp ? ecp[W + w] : 0.0;
 }
 
 // deterministic column means of a (nrow, W) array: one block of 256 threads per row

@@ -14,6 +14,7 @@
 #include "pqa_common.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_slater.hpp"
+#include "pqa_cslater.hpp"
 
 struct MoveBuf {
   double* newpos;   // [W][3]
@@ -36,6 +37,30 @@ __device__ __forceinline__ void limdrift3(double& gx, double& gy, double& gz) { 
 }
 __device__ __forceinline__ double finite_or(double v, double alt) { return (v >= -DBL_MAX && v <= DBL_MAX) ? v : alt; }
 
+// Slater part of a move: gradient of log|Psi_S| (real part for complex orbitals: the drift uses np.real(grad),
+// mc.py:118,126) and |ratio|^2, sanitised like gradient_value (slater.py:414-417).  CX: complex determinants.
+template <bool CX>
+__device__ __forceinline__ void slater_move_terms(const SysDev& S, const SlaterState& st, int s, int i, long w,
+                                                  const double* __restrict__ row, double* lds, double& gx, double& gy,
+                                                  double& gz, double& val2) {
+  if (CX) {
+    cx r[5];
+    slater_ratios_c<5>(S, st, s, i, w, row, r, lds);
+    const double d = 1.0 / cabs2(r[0]);  // Re(r_c / r_0) = (r_c . conj r_0) / |r_0|^2
+    gx += finite_or((r[1].r * r[0].r + r[1].i * r[0].i) * d, 0.0);
+    gy += finite_or((r[2].r * r[0].r + r[2].i * r[0].i) * d, 0.0);
+    gz += finite_or((r[3].r * r[0].r + r[3].i * r[0].i) * d, 0.0);
+    val2 = finite_or(cabs2(r[0]), 1.0);
+  } else {
+    double r[5];
+    slater_ratios<5>(S, st, s, i, w, row, r, lds);
+    gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
+    const double v = finite_or(r[0], 1.0);
+    val2 = v * v;
+  }
+}
+
+template <bool CX>
 __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
                                                 int has_slater, int has_jastrow, long W) {
   extern __shared__ double lds[];
@@ -45,9 +70,8 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
   double gx = 0.0, gy = 0.0, gz = 0.0, U0 = 0.0;
   if (has_slater) {
     const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-    double r[5];
-    slater_ratios<5>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, r, lds);
-    gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
+    double v2;
+    slater_move_terms<CX>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, lds, gx, gy, gz, v2);
   }
   if (has_jastrow) {
     double g[3], lp;
@@ -77,6 +101,7 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
 }
 
 // motmp: [W][5][nmo_s] orbitals at the proposed position.  LDS: n(n+1)+2n doubles (+ multi-det scratch).
+template <bool CX>
 __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
                                                int has_slater, int has_jastrow, const double* __restrict__ motmp, long W) {
   extern __shared__ double lds[];
@@ -86,26 +111,22 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   const double* a = mb.aux + 8 * w;
   const double nx = mb.newpos[3 * w], ny = mb.newpos[3 * w + 1], nz = mb.newpos[3 * w + 2];
-  double val = 1.0, gx = 0.0, gy = 0.0, gz = 0.0;
+  double val2 = 1.0, gx = 0.0, gy = 0.0, gz = 0.0;  // val2 = |Psi(new)/Psi|^2 (mc.py:131)
   const double* row = motmp + (size_t)w * 5 * nmo;
-  if (has_slater) {
-    double r[5];
-    slater_ratios<5>(S, st, s, i, w, row, r, lds);
-    gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
-    val *= finite_or(r[0], 1.0);  // slater.py:414-417
-  }
+  if (has_slater) slater_move_terms<CX>(S, st, s, i, w, row, lds, gx, gy, gz, val2);
   if (has_jastrow) {
     double g[3], lp, U;
     jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp, 3, lds + S.j3_off);
     gx += g[0]; gy += g[1]; gz += g[2];
-    val *= exp(U - a[6]);
+    const double ej = exp(U - a[6]);
+    val2 *= ej * ej;
   }
   limdrift3(gx, gy, gz);
   const double fwd = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
   const double bx = a[0] + mb.tstep * (a[3] + gx), by = a[1] + mb.tstep * (a[4] + gy), bz = a[2] + mb.tstep * (a[5] + gz);
   const double bwd = bx * bx + by * by + bz * bz;
   const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));  // mc.py:130
-  const double ratio = val * val * t_prob;
+  const double ratio = val2 * t_prob;
   double u;
   if (mb.unif) u = mb.unif[(size_t)e * W + w];
   else {
@@ -120,7 +141,8 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   }
   if (!acc) return;
   if (has_slater) {
-    sm_update_wave(S, st, s, i, w, row, lds);
+    if (CX) sm_update_wave_c(S, st, s, i, w, row, lds);
+    else sm_update_wave(S, st, s, i, w, row, lds);
     double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
     for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
   }

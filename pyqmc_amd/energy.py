@@ -42,6 +42,8 @@ class EnergyAccumulator:
             dev.set_ewald(**self._ewald_kws)
         self._calls += 1
         out = dev.energy(self.threshold, rot=rot, unif=unif, seed=self.seed + self._calls)
+        if np.iscomplexobj(out):  # complex orbitals: ecp and total are complex (eval_ecp.py:89), the rest real (energy.py:62-64)
+            return {k: (out[i] if k in ("ecp", "total") else out[i].real.copy()) for i, k in enumerate(KEYS)}
         return {k: out[i] for i, k in enumerate(KEYS)}
 
     def avg(self, configs, wf):

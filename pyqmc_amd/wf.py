@@ -217,17 +217,27 @@ class DeviceWF:
         return out
 
     def energy(self, threshold=10.0, rot=None, unif=None, seed=0):
-        """(6, W): ke, ee, ei, ecp, grad2, total of the resident walkers."""
-        out = np.empty((6, self.W))
+        """(6, W): ke, ee, ei, ecp, grad2, total of the resident walkers; complex (ecp and total carry an imaginary
+        part, eval_ecp.py:89) when the orbitals are."""
+        out = np.empty((7 if self.cplx else 6, self.W))
         rot = None if rot is None else _ffi.f64(rot)
         unif = None if unif is None else _ffi.f64(unif)
         self.call("pqa_energy", float(threshold), _ffi.ptr(rot), _ffi.ptr(unif), int(seed), _ffi.ptr(out))
-        return out
+        return self._complex_energy(out, 0) if self.cplx else out
+
+    @staticmethod
+    def _complex_energy(a, axis):
+        """rows/columns (ke, ee, ei, Re ecp, grad2, Re total, Im ecp) -> six complex entries (Im total = Im ecp)."""
+        a = np.moveaxis(a, axis, 0)
+        out = a[:6].astype(complex)
+        out[3] += 1j * a[6]
+        out[5] += 1j * a[6]
+        return np.moveaxis(out, 0, axis)
 
     def vmc_sweeps(self, tstep, nsteps, gauss=None, unif=None, threshold=10.0, ecp_rot=None, ecp_unif=None, seed=0,
                    energy=True, record=False):
         acc = np.empty(nsteps)
-        en = np.empty((nsteps, 6)) if energy else None
+        en = np.empty((nsteps, 7 if self.cplx else 6)) if energy else None
         rec = np.empty((nsteps, self.N, self.W), dtype=np.uint8) if record else None
         g = None if gauss is None else _ffi.f64(gauss)
         u = None if unif is None else _ffi.f64(unif)
@@ -235,6 +245,8 @@ class DeviceWF:
         eu = None if ecp_unif is None else _ffi.f64(ecp_unif)
         self.call("pqa_vmc_sweeps", float(tstep), int(nsteps), _ffi.ptr(g), _ffi.ptr(u), float(threshold), _ffi.ptr(er),
                   _ffi.ptr(eu), int(seed), _ffi.ptr(acc), _ffi.ptr(en), _ffi.ptr(rec))
+        if energy and self.cplx:
+            en = self._complex_energy(en, 1)
         return acc, en, (rec.astype(bool) if record else None)
 
     # measurement ----------------------------------------------------------

@@ -856,6 +856,43 @@ def g_pbc_complex():
         out[f"ao_{nm}"] = ao
         out[f"mo_{nm}"] = oe.mos(ao, 0)
     pbc_protocol("", sup, {"slater": sl, "jastrow": j2, "wf": wf}, 3, 53, [0, 5, 12, 23], out)
+    # energies (complex ecp / total) and a VMC trajectory
+    W, N, natm = 3, sum(sup.nelec), sup.natm
+    cfg = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(64)).configs.copy(), sup.lattice_vectors())
+    out["en_configs"] = cfg.configs.copy()
+    wf.recompute(cfg)
+    for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+        with Tapes(720 + len(thr_tag)) as t:
+            en = pyq.EnergyAccumulator(sup, threshold=thr, ewald_gmax=10)(cfg, wf)
+        for k, v in en.items():
+            out[f"en_{thr_tag}_{k}"] = np.asarray(v)
+        out[f"en_{thr_tag}_rot"] = np.asarray(t.log["rot"]).reshape(N, natm, 3, 3)
+        out[f"en_{thr_tag}_unif"] = np.asarray(t.log["random"]).reshape(N, natm, W)
+    nsteps, tstep = 2, 0.5
+    start = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(65)).configs.copy(), sup.lattice_vectors())
+    out["vmc_start"], out["vmc_start_wrap"] = start.configs.copy(), start.wrap.copy()
+    accepts = []
+    orig = wf.updateinternals
+
+    def spy(e, epos, c, mask=None, saved_values=None):
+        accepts.append(np.asarray(mask).copy())
+        return orig(e, epos, c, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(802) as t:
+        blk, cfg2 = vmc_worker(wf, start, tstep, nsteps, {"energy": pyq.EnergyAccumulator(sup, ewald_gmax=10)})
+    wf.updateinternals = orig
+    out["vmc_tstep"], out["vmc_nsteps"] = tstep, nsteps
+    out["vmc_gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+    out["vmc_unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+    out["vmc_ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm, 3, 3)
+    out["vmc_ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm, W)
+    out["vmc_accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+    out["vmc_final"], out["vmc_final_wrap"] = cfg2.configs.copy(), cfg2.wrap.copy()
+    out["vmc_final_sign"], out["vmc_final_log"] = wf.value()
+    for k, v in blk.items():
+        if "time" not in k:
+            out["vmc_blk_" + k] = np.asarray(v)
     save("g19_pbc_complex", **out)
 
 

@@ -247,7 +247,52 @@ def test_complex_periodic_slater_matches_reference():
         assert helpers.relerr(mo, ref.reshape((nc, -1, ref.shape[-1]))) < 1e-12, nm
     err = run_protocol_pbc({"slater": sl, "jastrow": wf.wf_factors[1], "wf": wf}, g, "", sup)
     assert max(err.values()) < 2e-9, {k: v for k, v in err.items() if v > 1e-10}
-    cfg = systems.initial_guess(sup, 3)
+    # complex local energies: ecp and total complex, the rest real (accumulators.py:60-75 with eval_ecp.py:89)
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    cfg = PeriodicConfigs(g["en_configs"].copy(), sup.lattice_vectors())
     wf.recompute(cfg)
-    with pytest.raises(pa._ffi.PqaError):  # fused entries refuse complex handles for now
-        pa.EnergyAccumulator(sup)(cfg, wf)
+    for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+        en = pa.EnergyAccumulator(sup, threshold=thr, ewald_gmax=10)(cfg, wf, rot=g[f"en_{thr_tag}_rot"], unif=g[f"en_{thr_tag}_unif"])
+        for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+            assert en[k].dtype == g[f"en_{thr_tag}_{k}"].dtype, k
+            assert helpers.relerr(en[k], g[f"en_{thr_tag}_{k}"]) < 2e-9, (thr_tag, k)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_complex_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
+    """vmc_worker with complex determinants (drift from Re grad, |ratio|^2 acceptance, complex block energies): fused
+    wave-per-walker sweep and protocol path, replaying the reference's draws."""
+    import pyqmc_amd as pa
+    from helpers import pbc_complex_case
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g19_pbc_complex")
+    sup, mf = pbc_complex_case()
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    cfg = PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    tstep, nsteps = float(g["vmc_tstep"]), int(g["vmc_nsteps"])
+    acc = pa.EnergyAccumulator(sup, ewald_gmax=10)
+    if fused:
+        tapes = dict(gauss=g["vmc_gauss"], unif=g["vmc_unif"], ecp_rot=g["vmc_ecp_rot"], ecp_unif=g["vmc_ecp_unif"], record=[])
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, tapes=tapes)
+        accepts = tapes["record"][0]
+    else:
+        gz, un = iter(g["vmc_gauss"].reshape(-1, *g["vmc_gauss"].shape[2:])), iter(g["vmc_unif"].reshape(-1, g["vmc_unif"].shape[-1]))
+        monkeypatch.setattr(np.random, "normal", lambda scale, size: scale * next(gz))
+        monkeypatch.setattr(np.random, "rand", lambda n: next(un))
+        rots, eun = iter(g["vmc_ecp_rot"]), iter(g["vmc_ecp_unif"])
+        accepts = []
+        orig = wf.updateinternals
+        monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
+        monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
+    assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
+    assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    sign, logv = wf.value()
+    assert helpers.relerr(logv, g["vmc_final_log"]) < 1e-9 and helpers.relerr(sign, g["vmc_final_sign"]) < 1e-8
+    for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
+        assert helpers.relerr(blk[k], g[f"vmc_blk_{k}"]) < 1e-8, k

@@ -271,3 +271,40 @@ def test_oracle_complex_periodic_slater_matches_reference():
     wf = owf.MultiplyWF(sl, ja)
     err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": wf}, g, "", sup)
     assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
+
+
+def _oracle_complex_wf(g):
+    from helpers import pbc_complex_case
+    from oracle import jastrow_basis, wf as owf
+
+    sup, mf = pbc_complex_case()
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, g["Ls"])
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    return sup, owf.MultiplyWF(sl, ja)
+
+
+def test_oracle_complex_energy_and_vmc_match_reference():
+    """Complex local energies (complex ecp and total, real ke / grad2) and a VMC trajectory (drift from the real part of the
+    gradient, |ratio|^2 acceptance) against the reference for the complex 3x1x1 wave function."""
+    from oracle import energy as oenergy, vmc as ovmc
+
+    g = golden("g19_pbc_complex")
+    sup, wf = _oracle_complex_wf(g)
+    cfg = pc.PeriodicConfigs(g["en_configs"].copy(), sup.lattice_vectors())
+    wf.recompute(cfg)
+    for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+        # (the reference ran ewald_gmax=10, which truncates the reciprocal sum of this elongated cell: same setting here)
+        en = oenergy.energy(sup, cfg, wf, thr, g[f"en_{thr_tag}_rot"], g[f"en_{thr_tag}_unif"], ewald_kws={"ewald_gmax": 10})
+        for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+            assert relerr(en[k], g[f"en_{thr_tag}_{k}"]) < 1e-9, (thr_tag, k)
+    cfg = pc.PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    rec = []
+    blk, cfg = ovmc.vmc_worker(sup, wf, cfg, float(g["vmc_tstep"]), g["vmc_gauss"], g["vmc_unif"], g["vmc_ecp_rot"], g["vmc_ecp_unif"], record=rec,
+                               ewald_kws={"ewald_gmax": 10})
+    assert np.array_equal(np.asarray(rec).reshape(g["vmc_accepts"].shape), g["vmc_accepts"])
+    assert relerr(cfg.configs, g["vmc_final"]) < 1e-11 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    for k in ("ke", "ee", "ei", "ecp", "total"):
+        assert abs(blk["energy" + k] - complex(g["vmc_blk_energy" + k])) < 1e-9 * max(1.0, abs(complex(g["vmc_blk_energy" + k]))), k
