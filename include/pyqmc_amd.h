@@ -124,6 +124,15 @@ typedef struct {
      i.e. the buffers are numpy complex128 arrays of the documented shapes.  Implemented for the wave-function protocol
      entry points; the fused sweep / energy entries refuse complex handles. */
   int32_t complex_orbitals;
+  /* Twisted boundary conditions (Bloch orbitals with psi(r + L) = exp(i k_t . L) psi(r) for the lattice vectors L of the
+     simulation cell; orbitals.py:201-213 get_wrapphase_complex).  twisted != 0 needs pbc, complex_orbitals and the
+     periodic orbital tables.  The AOs become complex lattice sums sum_L exp(i k_t . L) phi(r - R - L); a handle in this
+     mode takes UNFOLDED positions everywhere (position inside the cell + wrap . lattice, i.e. the electron's true
+     coordinate) — the orbital kernel folds a point itself and derives the wrap phase exp(i k_t . wrap . lattice) of
+     the reference from the integer wrap it removed; Jastrow, ECP and Ewald kernels use minimal-image displacements
+     and do not care.  The fused sweep leaves the walkers unfolded. */
+  int32_t twisted;
+  double twist_k[3]; /* cartesian, 1/bohr */
 } pqa_system_t;
 
 /* ---- lifetime --------------------------------------------------------------------- */

@@ -156,16 +156,18 @@ class PeriodicOrbitals:
         self.kpts = self.aotab.kpts
         self.mo = [[np.asarray(m) for m in mo_coeff[s]] for s in (0, 1)]
         self.complex = np.iscomplexobj(self.aotab.phases) or any(np.iscomplexobj(m) for sp in self.mo for m in sp)
-        twist = self.kpts @ (self.S @ self.Lprim).T / (2 * np.pi)
-        if np.abs(twist - np.round(twist)).max() > 1e-9:
-            raise NotImplementedError("non-zero supercell twist needs the walkers' wrap counters (not restated yet)")
 
     def aos(self, pts, ncomp):
+        """pts: TRUE (unfolded) positions.  Folding them into the supercell gives the container's wrap counters, folding
+        again into the primitive cell ``primwrap``; the wrap phase is exp(i k . (wrap @ S + primwrap) @ Lprim)
+        (orbitals.py:199-213; the real form (-1)^round(k.R/pi) :34-35 when nothing is complex)."""
         pts = np.asarray(pts, dtype=float).reshape(-1, 3)
-        prim_pts, primwrap = enforce_pbc(self.Lprim, pts)
+        cell_pts, wrap_s = enforce_pbc(self.S @ self.Lprim, pts)
+        prim_pts, primwrap = enforce_pbc(self.Lprim, cell_pts)
         ao = eval_ao_pbc(self.aotab, prim_pts, ncomp)
-        kdotR = self.kpts @ self.Lprim.T @ primwrap.T  # (nk, npts); zero twist: the supercell wrap drops out
-        wrap_phase = np.exp(1j * kdotR) if self.complex else (-1.0) ** np.round(kdotR / np.pi)  # orbitals.py:34-39
+        wrap = wrap_s @ self.S + primwrap
+        kdotR = self.kpts @ self.Lprim.T @ wrap.T  # (nk, npts)
+        wrap_phase = np.exp(1j * kdotR) if self.complex else (-1.0) ** np.round(kdotR / np.pi)
         return ao * wrap_phase[:, None, :, None]
 
     def mos(self, ao, s):

@@ -75,6 +75,14 @@ class Slater(_ManyMixin):
         s = int(e >= self._nelec[0])
         return s, e - s * self._nelec[0]
 
+    def _r(self, obj):
+        """Positions for the orbital evaluator: periodic orbitals take the TRUE (unfolded) coordinates, from which the
+        evaluator recovers the wrap counters the reference's ``aos`` reads off ``configs.wrap`` (orbitals.py:203-209)."""
+        x = np.asarray(obj.configs, dtype=float)
+        if getattr(self, "_orb", None) is not None and hasattr(obj, "wrap"):
+            x = x + np.asarray(obj.wrap, dtype=float) @ obj.lvecs
+        return x
+
     def _mo(self, pts, s, ncomp):
         if getattr(self, "_orb", None) is not None:
             ao = self._orb.aos(pts, ncomp)
@@ -98,7 +106,7 @@ class Slater(_ManyMixin):
     # -- protocol --------------------------------------------------------
     def recompute(self, configs):
         """slater.py:227-260: AO -> MO -> per unique determinant slogdet and inverse."""
-        x = configs.configs
+        x = self._r(configs)
         nconf, nelec, _ = x.shape
         self._x_last = x.copy()
         self._dets, self._inverse = [], []
@@ -167,7 +175,7 @@ class Slater(_ManyMixin):
     def gradient_value(self, e, epos):
         """slater.py:403-418."""
         s, _ = self._spin(e)
-        ao, mo = self._mo(epos.configs, s, 4)
+        ao, mo = self._mo(self._r(epos), s, 4)
         rat = self._row_ratios(e, mo)
         with np.errstate(divide="ignore", invalid="ignore"):
             grad = rat[1:] / rat[0]
@@ -179,14 +187,14 @@ class Slater(_ManyMixin):
     def gradient(self, e, epos):
         """slater.py:390-401."""
         s, _ = self._spin(e)
-        _, mo = self._mo(epos.configs, s, 4)
+        _, mo = self._mo(self._r(epos), s, 4)
         rat = self._row_ratios(e, mo)
         return rat[1:] / rat[0]
 
     def gradient_laplacian(self, e, epos):
         """slater.py:420-427."""
         s, _ = self._spin(e)
-        _, mo = self._mo(epos.configs, s, 5)
+        _, mo = self._mo(self._r(epos), s, 5)
         rat = self._row_ratios(e, mo)
         rat = rat / rat[:1]
         return rat[1:4], rat[4]
@@ -194,7 +202,7 @@ class Slater(_ManyMixin):
     def testvalue(self, e, epos, mask=None):
         """slater.py:429-446; epos (W,3) or (W,naip,3); mask selects walkers."""
         s, _ = self._spin(e)
-        x = epos.configs if mask is None else epos.configs[mask]
+        x = self._r(epos) if mask is None else self._r(epos)[mask]
         ao, mo = self._mo(x.reshape(-1, 3), s, 1)
         mo0 = mo[0].reshape(x.shape[:-1] + (-1,))
         if x.ndim == 3:
@@ -211,7 +219,7 @@ class Slater(_ManyMixin):
             self.recompute(configs)
             return
         if saved_values is None:
-            _, mo = self._mo(epos.configs[mask], s, 1)
+            _, mo = self._mo(self._r(epos)[mask], s, 1)
             mo = mo[0]
         else:
             mo = saved_values[1][mask]
@@ -225,7 +233,7 @@ class Slater(_ManyMixin):
         self._inverse[s][mask] = inv
         self._dets[s][0][mask] *= _phase(ratio)
         self._dets[s][1][mask] += np.log(np.abs(ratio))
-        self._x_last[mask, e] = epos.configs[mask]
+        self._x_last[mask, e] = self._r(epos)[mask]
 
 
 class JastrowSpin(_ManyMixin):

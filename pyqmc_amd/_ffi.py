@@ -44,7 +44,7 @@ class SystemStruct(C.Structure):
         ("nL", C.c_int32), ("Ls", c_double_p), ("num_Ls", c_int32_p), ("atom_cut", c_double_p), ("shell_cut", c_double_p),
         ("lattice_prim", C.c_double * 9), ("img_n", c_int32_p), ("atom_n", c_int32_p), ("member", C.POINTER(C.c_uint8)),
         ("member_class", c_int32_p), ("member_M", C.c_int32), ("n_member_class", C.c_int32),
-        ("complex_orbitals", C.c_int32),
+        ("complex_orbitals", C.c_int32), ("twisted", C.c_int32), ("twist_k", C.c_double * 3),
     ]
 
 

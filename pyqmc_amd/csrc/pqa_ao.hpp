@@ -121,6 +121,7 @@ struct PbcCtx {
   double x0, y0, z0;        // folded displacement point - atom
   int b0, b1, b2;           // membership index of image j = b + img_n[j]
   unsigned long long mask[2];  // images j < 128 that pass the atom cut-off and the membership rule
+  double cf = 1.0, sf = 0.0;   // twisted: (cos, sin)(k_t . f . lattice) of the fold f applied to point - atom
 };
 
 __device__ __forceinline__ bool pbc_image_ok(const SysDev& S, const PbcCtx& c, int j, double r2) {
@@ -143,6 +144,7 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
   c.x0 = x - (f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6]);
   c.y0 = y - (f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7]);
   c.z0 = z - (f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8]);
+  if (S.pb->twist) sincos(f0 * S.pb->ktl[0] + f1 * S.pb->ktl[1] + f2 * S.pb->ktl[2], &c.sf, &c.cf);
   if (S.pb->member) {  // atom image R_A + (f + m) . lattice  <->  primitive translation atom_n + (f + m) . supercell
     const int i0 = (int)f0, i1 = (int)f1, i2 = (int)f2;
     c.b0 = S.pb->atom_n[3 * ia] + i0 * S.pb->supercell[0] + i1 * S.pb->supercell[3] + i2 * S.pb->supercell[6] - pw.w0 + S.pb->member_M;
@@ -161,9 +163,11 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
   }
 }
 
+// part (twisted cells only): 0 -> real part, 1 -> imaginary part of sum_L exp(i k_t . L) phi(r - R - L); the caller
+// evaluates a shell once per part (register accumulators for both parts at once do not fit next to the MFMA tiles).
 template <int NCOMP, class Sink>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
-                                               const double* __restrict__ pcoef, int np, Sink&& sink) {
+                                               const double* __restrict__ pcoef, int np, Sink&& sink, int part = 0) {
   double acc[7][NCOMP];
 #pragma unroll
   for (int m = 0; m < 7; ++m)
@@ -171,11 +175,17 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     for (int k = 0; k < NCOMP; ++k) acc[m][k] = 0.0;
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
-  auto add = [&](double xj, double yj, double zj) {
+  const bool tw = S.pb->twist != 0;
+  auto add = [&](double xj, double yj, double zj, int j) {
+    double ph = 1.0;
+    if (tw) {  // exp(i k_t . (f . lattice + Ls[j])): cos or sin of the summed angle
+      const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
+      ph = part ? (c.sf * cj + c.cf * sj) : (c.cf * cj - c.sf * sj);
+    }
     shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
-      acc[m][0] += v;
-      if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
-      if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
+      acc[m][0] += ph * v;
+      if (NCOMP > 1) { acc[m][1 % NCOMP] += ph * gx; acc[m][2 % NCOMP] += ph * gy; acc[m][3 % NCOMP] += ph * gz; }
+      if (NCOMP == 5) acc[m][4 % NCOMP] += ph * lp;
     });
   };
   // Each lane walks ITS OWN list of admitted images (the set bits of its mask): the points of a wave sit anywhere in
@@ -188,12 +198,12 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     else if (m1) { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
     const int jj = j < 0 ? 0 : j;
     const double xj = c.x0 - S.pb->Ls[3 * jj], yj = c.y0 - S.pb->Ls[3 * jj + 1], zj = c.z0 - S.pb->Ls[3 * jj + 2];
-    if (j >= 0 && xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj);
+    if (j >= 0 && xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, jj);
   }
   for (int j = 128; j < nimg; ++j) {  // beyond the mask (very small cells): direct tests
     const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
     const double r2 = xj * xj + yj * yj + zj * zj;
-    if (r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj);
+    if (r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj, j);
   }
 #pragma unroll
   for (int m = 0; m < 7; ++m)
@@ -204,20 +214,40 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // the cell-centred parallelepiped and works out which of the atom's candidate images are admitted (atom cut-off and
 // membership rule) — once, instead of once per lane group inside k_orb, and in a kernel that is not register-bound.
 __global__ __launch_bounds__(256) void k_pbc_prepass(SysDev S, PointAddr pa, long P, double* __restrict__ d0,
-                                                     unsigned long long* __restrict__ mask) {
+                                                     unsigned long long* __restrict__ mask, double* __restrict__ theta) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const int ia = blockIdx.y;
   if (p >= P) return;
   double px, py, pz;
   load_point(pa, p, px, py, pz);
-  fold_cell(S, px, py, pz);
+  int dw[3];
+  fold_cell(S, px, py, pz, dw);
+  if (S.pb->twist && ia == 0) {  // wrap phase exp(i k_t . wrap . lattice) of the point (orbitals.py:203-213)
+    double sn, cs;
+    sincos(dw[0] * S.pb->ktl[0] + dw[1] * S.pb->ktl[1] + dw[2] * S.pb->ktl[2], &sn, &cs);
+    theta[2 * p] = cs; theta[2 * p + 1] = sn;
+  }
   PbcCtx c;
   pbc_ctx_update(S, c, ia, px - S.atom_xyz[3 * ia], py - S.atom_xyz[3 * ia + 1], pz - S.atom_xyz[3 * ia + 2], prim_wrap(S, px, py, pz));
   d0[((size_t)ia * 3 + 0) * P + p] = c.x0;
   d0[((size_t)ia * 3 + 1) * P + p] = c.y0;
   d0[((size_t)ia * 3 + 2) * P + p] = c.z0;
+  if (S.pb->twist) { d0[((size_t)S.natom * 3 + 2 * ia) * P + p] = c.cf; d0[((size_t)S.natom * 3 + 2 * ia + 1) * P + p] = c.sf; }
   mask[((size_t)ia * 2 + 0) * P + p] = c.mask[0];
   mask[((size_t)ia * 2 + 1) * P + p] = c.mask[1];
+}
+
+// Twisted cells: multiply every orbital row [ncomp][2 nmo] (re block | im block) by the point's wrap phase.
+__global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nmo = nmo2 / 2;
+  if (idx >= P * ncomp * nmo) return;
+  const long p = idx / ((long)ncomp * nmo);
+  const int c = (int)((idx / nmo) % ncomp), j = (int)(idx % nmo);
+  double* row = out + ((size_t)p * ncomp + c) * nmo2;
+  const double cs = theta[2 * p], sn = theta[2 * p + 1], re = row[j], im = row[nmo + j];
+  row[j] = re * cs - im * sn;
+  row[nmo + j] = re * sn + im * cs;
 }
 
 // ---------------------------------------------------------------- AO only (test / A-B entry)
@@ -358,7 +388,8 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     const int s_end = cw_off[ch * G + grp + 1];
 #endif
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
-      const int sh = cw_shell[si];
+      const int shx = cw_shell[si];  // twisted cells: shells appear twice, index + nshell = imaginary part
+      const int part = (PBC && shx >= S.nshell) ? 1 : 0, sh = shx - part * S.nshell;
       int l_, np_, q0, kb, ia_ = 0;
       double x, y, z;
       const double *pe, *pc;
@@ -388,9 +419,14 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
           ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
           ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
           ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
+          if (S.pb->twist) {
+            ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_) * P + pmine];
+            ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_ + 1) * P + pmine];
+          }
           if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
         }
-        shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
+        if (part) kb = T.shell_kb[shx];
+        shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, part);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows

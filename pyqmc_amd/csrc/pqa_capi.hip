@@ -43,6 +43,7 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
+  bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
   bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
   bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
   bool has_j2 = false, has_j3 = false;
@@ -65,7 +66,7 @@ struct pqa_handle {
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth;
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
@@ -170,18 +171,20 @@ static int check_launch(pqa_handle* h, const char* what) {
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
   for (int g = 0; g < 2; ++g) c.cw_off[g].push_back(0);
-  c.shell_kb.assign((size_t)h->nshell, 0);
-  c.shell_chunk.assign((size_t)h->nshell, 0);
+  // twisted cells: every shell appears twice (index + nshell = imaginary part of the complex lattice sum)
+  const int nsx = h->twist ? 2 * h->nshell : h->nshell;
+  c.shell_kb.assign((size_t)nsx, 0);
+  c.shell_chunk.assign((size_t)nsx, 0);
   // phase-1 cost of a shell: radial part per primitive + angular part / tile stores per function
-  auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * (2 * h->shell_l[s] + 1) + 40; };
-  auto nfun = [&](int s) { return 2 * h->shell_l[s] + 1; };
+  auto cost = [&](int s) { return 45 * h->shell_np[s % h->nshell] + 25 * (2 * h->shell_l[s % h->nshell] + 1) + 40; };
+  auto nfun = [&](int s) { return 2 * h->shell_l[s % h->nshell] + 1; };
   int nao = 0;
-  for (int s = 0; s < h->nshell; ++s) nao += nfun(s);
+  for (int s = 0; s < nsx; ++s) nao += nfun(s);
   // Longest-processing-time packing over (chunk, group) slots under the chunk's row capacity; if a shell does not
   // fit anywhere a chunk is added.  4 groups per chunk (64-point tiles) is the layout that is balanced; the
   // 8-group lists (32-point tiles) are a second LPT inside each chunk.
-  std::vector<int> order((size_t)h->nshell);
-  for (int s = 0; s < h->nshell; ++s) order[s] = s;
+  std::vector<int> order((size_t)nsx);
+  for (int s = 0; s < nsx; ++s) order[s] = s;
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
   int nchunk = std::max((nao + KC - 1) / KC, 1);
   std::vector<std::vector<int>> load;
@@ -249,6 +252,19 @@ static int upload_cpad(pqa_handle* h, int t, int s, const double* mo_host) {
     for (int m = 0; m < 2 * h->shell_l[sh] + 1; ++m)
       for (int j = 0; j < nmo; ++j)
         pad[(size_t)(c.row0[c.shell_chunk[sh]] + c.shell_kb[sh] + m) * ldc + j] = mo_host[(size_t)(h->shell_ao[sh] + m) * nmo + j];
+  if (h->twist) {  // rows of the imaginary AO parts: (i AO_im)(C_re + i C_im) = AO_im (-C_im + i C_re), columns [re | im]
+    const int nr = nmo / 2;
+    for (int sh = 0; sh < h->nshell; ++sh) {
+      const int sx = sh + h->nshell;
+      for (int m = 0; m < 2 * h->shell_l[sh] + 1; ++m)
+        for (int j = 0; j < nr; ++j) {
+          const double* src = mo_host + (size_t)(h->shell_ao[sh] + m) * nmo;
+          double* dst = pad.data() + (size_t)(c.row0[c.shell_chunk[sx]] + c.shell_kb[sx] + m) * ldc;
+          dst[j] = -src[nr + j];
+          dst[nr + j] = src[j];
+        }
+    }
+  }
   HIPCHK(hipMemcpy(h->d_cpad[t][s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -305,6 +321,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
   h->cplx = h->has_slater && sys->complex_orbitals != 0;
+  h->twist = sys->twisted != 0;
+  if (h->twist && !(h->cplx && sys->pbc && sys->nL > 0)) FAIL("twisted boundary conditions need pbc, complex_orbitals and the periodic orbital tables");
   if (h->cplx && ((sys->nmo_up | sys->nmo_dn) & 1)) FAIL("complex orbitals: nmo_up / nmo_dn count the real columns [Re C | Im C] and must be even");
   h->has_j2 = sys->na > 0 || sys->nb > 0;
   h->has_j3 = sys->na3 > 0 && sys->nb3 > 0;
@@ -362,6 +380,18 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, sys->num_Ls, (size_t)h->natom, &tmp_i)); P.num_Ls = tmp_i;
       TRY(upload_table(h, sys->atom_cut, (size_t)h->natom, &tmp_d)); P.atom_cut = tmp_d;
       TRY(upload_table(h, sys->shell_cut, (size_t)sys->nshell, &tmp_d)); P.shell_cut = tmp_d;
+      P.twist = h->twist ? 1 : 0;
+      if (h->twist) {
+        std::vector<double> ls((size_t)sys->nL * 3), ph((size_t)sys->nL * 2);
+        HIPCHK(hipMemcpy(ls.data(), sys->Ls, ls.size() * sizeof(double), hipMemcpyDefault));
+        for (int j = 0; j < sys->nL; ++j) {
+          const double a = sys->twist_k[0] * ls[3 * j] + sys->twist_k[1] * ls[3 * j + 1] + sys->twist_k[2] * ls[3 * j + 2];
+          ph[2 * j] = std::cos(a); ph[2 * j + 1] = std::sin(a);
+        }
+        TRY(upload_table(h, ph.data(), ph.size(), &tmp_d)); P.img_phase = tmp_d;
+        for (int a = 0; a < 3; ++a)
+          P.ktl[a] = sys->twist_k[0] * sys->lattice[3 * a] + sys->twist_k[1] * sys->lattice[3 * a + 1] + sys->twist_k[2] * sys->lattice[3 * a + 2];
+      }
       P.member = nullptr;
       if (sys->member) {
         if (!sys->img_n || !sys->atom_n || !sys->member_class || sys->member_M < 0 || sys->n_member_class < 1) FAIL("incomplete image-membership tables");
@@ -521,7 +551,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -604,10 +634,11 @@ static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
 // periodic orbitals: lattice-summed shells, 64-point tiles, tables through the scalar cache
 template <int NCOMP, int KC>
 static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  TRY(ensure(h, h->b_pbcd0, (size_t)h->natom * 3 * P * sizeof(double)));
+  TRY(ensure(h, h->b_pbcd0, (size_t)h->natom * (h->twist ? 5 : 3) * P * sizeof(double)));
   TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * 2 * P * sizeof(unsigned long long)));
+  if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
   hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + 255) / 256), (unsigned)h->natom), dim3(256), 0, h->stream, h->S, pa, P,
-                     (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p);
+                     (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
   ChunkTab T = h->tab[tabi];
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
@@ -622,6 +653,11 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     default: if (lt) PQA_ORB_PBC(4, true); else PQA_ORB_PBC(4, false); break;
   }
 #undef PQA_ORB_PBC
+  if (h->twist) {
+    const long nel = P * NCOMP * (h->nmo[spin] / 2);
+    hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
+                       (const double*)h->b_pbcth.p);
+  }
   return 0;
 }
 template <int NCOMP, int KC, int TP>
@@ -688,6 +724,7 @@ extern "C" int pqa_eval_ao(pqa_handle_t* h, const double* pts, int64_t npts, int
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater) FAIL("handle has no orbital tables");
   if (ncomp != 1 && ncomp != 4 && ncomp != 5) FAIL("ncomp must be 1, 4 or 5");
+  if (h->twist) FAIL("AO-only evaluation is not available for twisted cells (complex AOs); use pqa_eval_mo");
   if (npts <= 0) return 0;
   const size_t nout = (size_t)ncomp * npts * h->nao;
   TRY(ensure(h, h->b_pts, (size_t)npts * 3 * sizeof(double)));
@@ -1487,7 +1524,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
     mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
-    if (h->S.pbc) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }
+    if (h->S.pbc && !h->twist) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }  // twisted handles keep the walkers unfolded
     if (gauss) {
       TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
       mb.gauss = (const double*)h->b_gauss.p;

@@ -28,6 +28,10 @@ struct PbcDev {
   int member_M;
   int supercell[9];  // lattice = supercell . lattice_prim (integers)
   double lprim_inv[9];
+  // twisted boundary conditions: every image carries exp(i k_t . L); ktl[a] = k_t . lattice_a, img_phase[j] = (cos, sin)(k_t . Ls[j])
+  int twist;
+  double ktl[3];
+  const double* img_phase;
 };
 
 // Device view of the system tables (all pointers are device memory).

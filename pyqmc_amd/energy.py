@@ -35,7 +35,11 @@ class EnergyAccumulator:
 
     def __call__(self, configs, wf, rot=None, unif=None):
         dev = self._device(wf)
-        if self.check_configs and not np.array_equal(dev.configs(), configs.configs):
+        if getattr(dev, "twisted", False):  # twisted handles hold unfolded coordinates (include/pyqmc_amd.h)
+            same = np.allclose(dev.configs(), configs.configs + configs.wrap @ configs.lvecs, rtol=0, atol=1e-9)
+        else:
+            same = np.array_equal(dev.configs(), configs.configs)
+        if self.check_configs and not same:
             raise ValueError("walkers on the device differ from `configs`: call wf.recompute(configs) "
                              "(or keep wf.updateinternals in step with configs.move) first")
         if dev.pbc:

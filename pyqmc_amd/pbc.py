@@ -180,10 +180,7 @@ def fold_mo_coeff(supercell, kpts, mo_coeff):
     copies = get_supercell_copies(prim.lattice_vectors(), supercell.S)
     if len(kpts) != supercell.scale:
         raise ValueError(f"found {len(kpts)} k-points but the supercell folds {supercell.scale} (pyscftools.py:163-166)")
-    twist = kpts @ supercell.lattice_vectors().T / (2 * np.pi)
-    if np.abs(twist - np.round(twist)).max() > 1e-9:
-        raise NotImplementedError("non-zero supercell twist (needs the walkers' wrap counters on the device) is not implemented yet")
-    phase = np.exp(1j * copies @ kpts.T)  # (ncopy, nk)
+    phase = np.exp(1j * copies @ kpts.T)  # (ncopy, nk); a common twist stays in the AOs' lattice sums (see common_twist)
     cplx = np.abs(phase.imag).max() > 1e-9 or any(np.iscomplexobj(m) and np.abs(np.imag(m)).max(initial=0.0) > 1e-12
                                                    for s in (0, 1) for m in mo_coeff[s])
     if not cplx:
@@ -201,6 +198,19 @@ def fold_mo_coeff(supercell, kpts, mo_coeff):
     return out
 
 
+def common_twist(supercell, kpts):
+    """The twist the k-points share: k modulo the supercell's reciprocal lattice, as a cartesian vector with fractional
+    components in [-1/2, 1/2) — or None when it is zero.  Raises if the k-points do not share one."""
+    lat = supercell.lattice_vectors()
+    frac = np.asarray(kpts, dtype=float).reshape(-1, 3) @ lat.T / (2 * np.pi)
+    red = frac - np.floor(frac + 0.5 + 1e-12)
+    if np.abs(red - red[0]).max() > 1e-9:
+        raise ValueError("the k-points do not share one supercell twist")
+    if np.abs(red[0]).max() < 1e-9:
+        return None
+    return red[0] @ (2 * np.pi * np.linalg.inv(lat).T)
+
+
 class KMeanField:
     """Duck-typed k-point mean field: ``kpts`` (nk,3), ``mo_coeff[s][k]`` (nao_prim, nmo), ``mo_occ[s][k]`` (nmo,)."""
 
@@ -212,11 +222,13 @@ class KMeanField:
         return self
 
 
-def random_kmf(supercell, seed=20260928, nvirt=0, complex_coeff=False):
+def random_kmf(supercell, seed=20260928, nvirt=0, complex_coeff=False, twist=None):
     """Seeded Bloch coefficients at the supercell's Gamma-compatible k-points, electrons spread evenly over the
     k-points (what an insulator's KRHF gives).  ``complex_coeff``: randn + i randn before orthonormalisation."""
     prim = supercell.original_cell
     kpts = get_supercell_kpts(supercell)
+    if twist is not None:  # fractional twist in units of the supercell's reciprocal lattice vectors
+        kpts = kpts + np.asarray(twist, dtype=float) @ supercell.reciprocal_vectors()
     rng = np.random.default_rng(seed)
     nao = prim.nao()
     mo, occ = [[], []], [[], []]

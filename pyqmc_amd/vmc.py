@@ -61,9 +61,14 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     # the fused kernel interleaves moves and energy; report the split the reference reports as one number each
     block_avg["move time"] = (t1 - t0) / nsteps
     block_avg["accumulator time"] = 0.0
-    configs.configs[...] = dev.configs()
-    if dev.pbc:  # walkers stay folded into the cell; their wrap counters advance (coord.py:180-189)
-        configs.wrap += dev.wrap_delta()
+    if getattr(dev, "twisted", False):  # the handle keeps true (unfolded) coordinates: fold them back into the container
+        from .configs import enforce_pbc
+
+        configs.configs[...], configs.wrap[...] = enforce_pbc(configs.lvecs, dev.configs())
+    else:
+        configs.configs[...] = dev.configs()
+        if dev.pbc:  # walkers stay folded into the cell; their wrap counters advance (coord.py:180-189)
+            configs.wrap += dev.wrap_delta()
     return block_avg, configs
 
 

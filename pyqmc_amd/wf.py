@@ -25,8 +25,9 @@ class DeviceWF:
     """Owner of one ``pqa_handle_t`` (one walker shard on one GPU)."""
 
     def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1,
-                 a3_basis=None, b3_basis=None, eval_gto_precision=None, image_rule="reference"):
+                 a3_basis=None, b3_basis=None, eval_gto_precision=None, image_rule="reference", twist_k=None):
         self.mol = mol
+        self.twisted = twist_k is not None and float(np.abs(twist_k).max()) > 1e-12
         self.nelec = tuple(int(n) for n in mol.nelec)
         self.N = sum(self.nelec)
         self.natom = int(mol.natm)
@@ -114,6 +115,12 @@ class DeviceWF:
         setd("ecp_term_exp", et["ecp_term_exp"])
         setd("ecp_term_coef", et["ecp_term_coef"])
         self.pbc = hasattr(mol, "a")
+        if self.twisted:
+            if not (self.pbc and self.cplx):
+                raise ValueError("a twist needs a periodic cell and complex orbitals")
+            s.twisted = 1
+            s.twist_k[:] = [float(v) for v in twist_k]
+            self.lattice = np.asarray(mol.lattice_vectors(), dtype=float)
         if self.pbc:
             from .configs import MinimalImageDistance
 
@@ -323,9 +330,18 @@ def _mask_args(mask, W):
     return m, np.ascontiguousarray(m, dtype=np.uint8)
 
 
-def _points(epos, mask):
+def _xyz(dev, obj):
+    """Coordinates handed to the device: the container's folded positions, or — for a twisted handle, which derives the
+    wrap phase from the position itself (include/pyqmc_amd.h) — the unfolded ones ``configs + wrap @ lattice``."""
+    x = np.asarray(obj.configs, dtype=float)
+    if getattr(dev, "twisted", False):
+        x = x + np.asarray(obj.wrap, dtype=float) @ dev.lattice
+    return x
+
+
+def _points(epos, mask, dev=None):
     """-> (pts (nrow,npt,3), widx int32 or None, aux?)"""
-    x = np.asarray(epos.configs, dtype=float)
+    x = _xyz(dev, epos)
     aux = x.ndim == 3
     widx = None
     if mask is not None:
@@ -339,7 +355,7 @@ def _points(epos, mask):
 def _testvalue_many(dev, factors, e, epos, mask):
     """(nrow, len(e)) ratios Psi(e_i -> epos)/Psi for ONE auxiliary position per walker (``testvalue_many``)."""
     es = np.ascontiguousarray(np.atleast_1d(e), dtype=np.int32)
-    x = np.asarray(epos.configs, dtype=float)
+    x = _xyz(dev, epos)
     if x.ndim != 2:
         raise ValueError("testvalue_many takes one position per walker: epos.configs (nconf, 3)")
     widx = None
@@ -364,7 +380,7 @@ def orbital_inputs(mol, mf, determinants=None):
     real supercell coefficients (``pbc.fold_mo_coeff``)."""
     mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
     if not hasattr(mol, "a"):
-        return mol, mf.mo_coeff, determinants
+        return mol, mf.mo_coeff, determinants, None
     from . import pbc as _pbc
 
     if not hasattr(mol, "original_cell"):
@@ -377,9 +393,14 @@ def orbital_inputs(mol, mf, determinants=None):
         d = (k1 - k2) @ np.linalg.inv(rec)
         return np.abs(d - np.round(d)).max() < 1e-9
 
+    twist_k = _pbc.common_twist(mol, kpts)
+    if twist_k is not None and len(kpts) == mol.scale:  # the mean field holds exactly the k-points of one (non-zero) twist
+        want = want + twist_k
     kinds = [next((i for i, k in enumerate(kpts) if same(k, w)), None) for w in want]
     if any(i is None for i in kinds):
         raise ValueError(f"the mean field lacks some of the {len(want)} k-points that fold onto the supercell (pyscftools.py:161-166)")
+    if not (twist_k is not None and len(kpts) == mol.scale):
+        twist_k = None
     if determinants is None:
         determinants = [(1.0, [[list(np.nonzero(np.asarray(o) > 0.5)[0]) for o in mf.mo_occ[sp]] for sp in (0, 1)])]
     if len(determinants[0][1][0]) and hasattr(determinants[0][1][0][0], "__len__"):  # per-k occupations
@@ -391,7 +412,7 @@ def orbital_inputs(mol, mf, determinants=None):
     else:  # already flat: indices into the concatenation of the full per-k blocks
         flat = determinants
         mo = [[np.asarray(mf.mo_coeff[sp][k]) for k in kinds] for sp in (0, 1)]
-    return mol, _pbc.fold_mo_coeff(mol, kpts[kinds], mo), flat
+    return mol, _pbc.fold_mo_coeff(mol, kpts[kinds], mo), flat, twist_k
 
 
 class Slater:
@@ -404,9 +425,10 @@ class Slater:
     def __init__(self, mol, mf, determinants=None, tol=None, device=0, eval_gto_precision=None, image_rule="reference",
                  _dev=None):
         if _dev is None:
-            mol, mo_coeff, determinants = orbital_inputs(mol, mf, determinants)
+            mol, mo_coeff, determinants, twist_k = orbital_inputs(mol, mf, determinants)
             _dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, device=device,
-                            tol=-1 if tol is None else tol, eval_gto_precision=eval_gto_precision, image_rule=image_rule)
+                            tol=-1 if tol is None else tol, eval_gto_precision=eval_gto_precision, image_rule=image_rule,
+                            twist_k=twist_k)
         self._mol = mol
         self._nelec = tuple(mol.nelec)
         self._dev = _dev
@@ -423,7 +445,7 @@ class Slater:
 
     def recompute(self, configs):
         self.parameters.push()
-        x = _ffi.f64(configs.configs)
+        x = _ffi.f64(_xyz(self._dev, configs))
         W = x.shape[0]
         sign, logv = np.empty(W, dtype=self._dev.cdtype), np.empty(W)
         self._dev.call("pqa_slater_recompute", _ffi.ptr(x), W, _ffi.ptr(sign), _ffi.ptr(logv))
@@ -438,7 +460,7 @@ class Slater:
 
     def _ratios(self, e, epos, mask, ncomp, keep):
         m, _ = _mask_args(mask, self._dev.W)
-        pts, widx, aux = _points(epos, m)
+        pts, widx, aux = _points(epos, m, self._dev)
         nrow, npt = pts.shape[0], pts.shape[1]
         out = np.empty((ncomp, nrow * npt), dtype=self._dev.cdtype)
         if nrow:
@@ -500,7 +522,7 @@ class Slater:
             self.recompute(configs)
             return
         _, m8 = _mask_args(mask, self._dev.W)
-        x = _ffi.f64(epos.configs)
+        x = _ffi.f64(_xyz(self._dev, epos))
         use_saved = saved_values is not None and saved_values is self._saved and saved_values[1] == int(e)
         self._dev.call("pqa_slater_update", int(e), _ffi.ptr(x), _ffi.ptr(m8), int(use_saved))
         self._saved = None
@@ -533,7 +555,7 @@ class JastrowSpin:
 
     def recompute(self, configs):
         self.parameters.push()
-        x = _ffi.f64(configs.configs)
+        x = _ffi.f64(_xyz(self._dev, configs))
         W = x.shape[0]
         u = np.empty(W)
         self._dev.call("pqa_jastrow_recompute", _ffi.ptr(x), W, _ffi.ptr(u))
@@ -547,7 +569,7 @@ class JastrowSpin:
 
     def _eval(self, e, epos, mask, mode):
         m, _ = _mask_args(mask, self._dev.W)
-        pts, widx, aux = _points(epos, m)
+        pts, widx, aux = _points(epos, m, self._dev)
         nrow, npt = pts.shape[0], pts.shape[1]
         out = np.empty(nrow * npt) if mode == 0 else np.empty((4, nrow))
         if nrow:
@@ -575,7 +597,7 @@ class JastrowSpin:
 
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
         _, m8 = _mask_args(mask, self._dev.W)
-        x = _ffi.f64(epos.configs)
+        x = _ffi.f64(_xyz(self._dev, epos))
         self._dev.call("pqa_jastrow_update", int(e), _ffi.ptr(x), _ffi.ptr(m8))
 
     def pgradient(self):
@@ -608,7 +630,7 @@ class ThreeBodyJastrow:
 
     def recompute(self, configs):
         self.parameters.push()
-        x = _ffi.f64(configs.configs)
+        x = _ffi.f64(_xyz(self._dev, configs))
         W = x.shape[0]
         u = np.empty(W)
         self._dev.call("pqa_j3_recompute", _ffi.ptr(x), W, _ffi.ptr(u))
@@ -622,7 +644,7 @@ class ThreeBodyJastrow:
 
     def _eval(self, e, epos, mask, mode):
         m, _ = _mask_args(mask, self._dev.W)
-        pts, widx, aux = _points(epos, m)
+        pts, widx, aux = _points(epos, m, self._dev)
         nrow, npt = pts.shape[0], pts.shape[1]
         out = np.empty(nrow * npt) if mode == 0 else np.empty((4, nrow))
         if nrow:
@@ -657,7 +679,7 @@ class ThreeBodyJastrow:
 
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
         _, m8 = _mask_args(mask, self._dev.W)
-        x = _ffi.f64(epos.configs)
+        x = _ffi.f64(_xyz(self._dev, epos))
         self._dev.call("pqa_j3_update", int(e), _ffi.ptr(x), _ffi.ptr(m8))
 
 
@@ -713,7 +735,7 @@ class MultiplyWF:
         if d is not None:
             for w in self.wf_factors:
                 w.parameters.push()
-            return d.recompute(configs.configs)
+            return d.recompute(_xyz(d, configs))
         res = [w.recompute(configs) for w in self.wf_factors]
         return np.prod([r[0] for r in res], axis=0), np.sum([r[1] for r in res], axis=0)
 
@@ -813,13 +835,13 @@ def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None
     elif ion_cusp is False:
         ion_cusp = []
     abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
-    mol, mo_coeff, determinants = orbital_inputs(mol, mf, determinants)
+    mol, mo_coeff, determinants, twist_k = orbital_inputs(mol, mf, determinants)
     a3 = b3 = None
     if jastrow3:  # wftools.generate_jastrow3 (:155-162): default basis without ion cusp
         a3, b3 = func3d.default_jastrow_basis(mol, False, **dict(jastrow3_kws or {}))
     dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
                    tol=-1 if tol is None else tol, a3_basis=a3, b3_basis=b3, eval_gto_precision=eval_gto_precision,
-                   image_rule=image_rule)
+                   image_rule=image_rule, twist_k=twist_k)
     sl = Slater(mol, mf, _dev=dev)
     ja = JastrowSpin(mol, abasis, bbasis, _dev=dev)
     acoeff = np.zeros((mol.natm, len(abasis), 2))

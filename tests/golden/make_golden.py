@@ -896,6 +896,84 @@ def g_pbc_complex():
     save("g19_pbc_complex", **out)
 
 
+
+# ------------------------------------------------------------------ G20 twisted boundary conditions (complex AOs, wrap phases)
+TWIST_CASES = {"prim": (np.eye(3), (0.25, 0.1, -0.3), 4, [0, 3, 4, 7]), "s211": (np.diag([2.0, 1.0, 1.0]), (0.2, -0.15, 0.4), 3, [0, 7, 8, 15])}
+
+
+def ref_twisted_wf(tag):
+    import pyqmc.wftools as wftools
+    from pyqmc.wf.multiplywf import MultiplyWF
+    from pyqmc_amd import pbc as mypbc
+
+    S, twist, W, electrons = TWIST_CASES[tag]
+    prim = systems.diamond_primitive()
+    sup = mypbc.get_supercell(prim, S)
+    mf = mypbc.random_kmf(sup, complex_coeff=True, twist=twist)
+    Ls = mypbc.lattice_points_within(prim.lattice_vectors(), 30.0)
+    ev, oe, sl = ref_pbc_objects(sup, mf.kpts, mf.mo_coeff, Ls)
+    j2, _ = wftools.generate_jastrow(sup)
+    jr = np.random.default_rng(17)
+    j2.parameters["acoeff"] = 0.05 * jr.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * jr.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    return sup, mf, Ls, oe, sl, j2, MultiplyWF(sl, j2), W, electrons
+
+
+def g_pbc_twist():
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    for tag in TWIST_CASES:
+        sup, mf, Ls, oe, sl, j2, wf, W, electrons = ref_twisted_wf(tag)
+        out[f"{tag}_kpts"], out[f"{tag}_Ls"] = mf.kpts, Ls
+        rng = np.random.default_rng(95)
+        pts = PeriodicConfigs((rng.random((1, 8, 3)) * 5 - 2) @ sup.lattice_vectors(), sup.lattice_vectors())
+        out[f"{tag}_pts"], out[f"{tag}_pts_wrap"] = pts.configs.copy(), pts.wrap.copy()
+        for nm, es in (("val", "GTOval_sph"), ("lap", "GTOval_sph_deriv2")):
+            out[f"{tag}_mo_{nm}"] = oe.mos(oe.aos(es, pts), 0)
+        pbc_protocol(f"{tag}_", sup, {"slater": sl, "jastrow": j2, "wf": wf}, W, 57, electrons, out)
+        if tag == "prim":
+            N, natm = sum(sup.nelec), sup.natm
+            cfg = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(66)).configs.copy() + 20.0, sup.lattice_vectors())
+            out["en_configs"], out["en_wrap"] = cfg.configs.copy(), cfg.wrap.copy()
+            wf.recompute(cfg)
+            with Tapes(730) as t:
+                en = pyq.EnergyAccumulator(sup, ewald_gmax=10)(cfg, wf)
+            for k, v in en.items():
+                out[f"en_{k}"] = np.asarray(v)
+            out["en_rot"] = np.asarray(t.log["rot"]).reshape(N, natm, 3, 3)
+            out["en_unif"] = np.asarray(t.log["random"]).reshape(N, natm, W)
+            nsteps, tstep = 2, 0.5
+            start = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(67)).configs.copy(), sup.lattice_vectors())
+            out["vmc_start"], out["vmc_start_wrap"] = start.configs.copy(), start.wrap.copy()
+            accepts = []
+            orig = wf.updateinternals
+
+            def spy(e, epos, c, mask=None, saved_values=None):
+                accepts.append(np.asarray(mask).copy())
+                return orig(e, epos, c, mask=mask, saved_values=saved_values)
+
+            wf.updateinternals = spy
+            with Tapes(803) as t:
+                blk, cfg2 = vmc_worker(wf, start, tstep, nsteps, {"energy": pyq.EnergyAccumulator(sup, ewald_gmax=10)})
+            wf.updateinternals = orig
+            out["vmc_tstep"], out["vmc_nsteps"] = tstep, nsteps
+            out["vmc_gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+            out["vmc_unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+            out["vmc_ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm, 3, 3)
+            out["vmc_ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm, W)
+            out["vmc_accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+            out["vmc_final"], out["vmc_final_wrap"] = cfg2.configs.copy(), cfg2.wrap.copy()
+            out["vmc_final_sign"], out["vmc_final_log"] = wf.value()
+            for k, v in blk.items():
+                if "time" not in k:
+                    out["vmc_blk_" + k] = np.asarray(v)
+            print("twisted vmc: wrap moved", np.abs(cfg2.wrap - out["vmc_start_wrap"]).sum())
+    save("g20_pbc_twist", **out)
+
+
 # ------------------------------------------------------------------ G12 DMC propagate + branch
 def g_dmc():
     import pyqmc.method.dmc as refdmc
@@ -979,3 +1057,4 @@ if __name__ == "__main__":
     g_pbc_dmc()
     g_testvalue_many()
     g_pbc_complex()
+    g_pbc_twist()

@@ -341,3 +341,15 @@ def pbc_complex_case():
 
     sup = pbc.get_supercell(systems.diamond_primitive(), np.diag([3.0, 1.0, 1.0]))
     return sup, pbc.random_kmf(sup, complex_coeff=True)
+
+
+TWIST_CASES = {"prim": (np.eye(3), (0.25, 0.1, -0.3)), "s211": (np.diag([2.0, 1.0, 1.0]), (0.2, -0.15, 0.4))}
+
+
+def twist_case(tag):
+    """Twisted diamond cells of make_golden.ref_twisted_wf: (supercell, k-point mean field with complex coefficients)."""
+    from pyqmc_amd import pbc
+
+    S, twist = TWIST_CASES[tag]
+    sup = pbc.get_supercell(systems.diamond_primitive(), S)
+    return sup, pbc.random_kmf(sup, complex_coeff=True, twist=twist)

@@ -296,3 +296,73 @@ def test_complex_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
     assert helpers.relerr(logv, g["vmc_final_log"]) < 1e-9 and helpers.relerr(sign, g["vmc_final_sign"]) < 1e-8
     for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
         assert helpers.relerr(blk[k], g[f"vmc_blk_{k}"]) < 1e-8, k
+
+
+# ------------------------------------------------------------------ twisted boundary conditions
+def _gpu_twisted_wf(tag):
+    import pyqmc_amd as pa
+    from helpers import twist_case
+
+    sup, mf = twist_case(tag)
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    assert wf.fused_device().twisted and wf.wf_factors[0].dtype == complex
+    return sup, wf
+
+
+@pytest.mark.parametrize("tag", ["prim", "s211"])
+def test_twisted_slater_matches_reference(tag):
+    """Non-zero supercell twist (one twisted k-point in the primitive cell; two in a 2x1x1 supercell): complex
+    lattice-summed AOs sum_L exp(i k_t.L) phi(r-R-L) on the device and the wrap phase of electrons that left the cell,
+    derived from the unfolded positions the handle works with — MOs and the whole protocol against the reference."""
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g20_pbc_twist")
+    sup, wf = _gpu_twisted_wf(tag)
+    sl = wf.wf_factors[0]
+    pts = PeriodicConfigs(g[f"{tag}_pts"].copy(), sup.lattice_vectors(), wrap=g[f"{tag}_pts_wrap"].copy())
+    unfolded = (pts.configs + pts.wrap @ sup.lattice_vectors()).reshape(-1, 3)
+    for nm, nc in (("val", 1), ("lap", 5)):
+        ref = g[f"{tag}_mo_{nm}"]
+        assert helpers.relerr(sl._dev.eval_mo(0, unfolded, nc), ref.reshape((nc, -1, ref.shape[-1]))) < 1e-12, nm
+    err = run_protocol_pbc({"slater": sl, "jastrow": wf.wf_factors[1], "wf": wf}, g, f"{tag}_", sup)
+    assert max(err.values()) < 2e-9, {k: v for k, v in err.items() if v > 1e-10}
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_twisted_energy_and_vmc_match_reference(fused, monkeypatch):
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g20_pbc_twist")
+    sup, wf = _gpu_twisted_wf("prim")
+    cfg = PeriodicConfigs(g["en_configs"].copy(), sup.lattice_vectors(), wrap=g["en_wrap"].copy())
+    wf.recompute(cfg)
+    en = pa.EnergyAccumulator(sup, ewald_gmax=10)(cfg, wf, rot=g["en_rot"], unif=g["en_unif"])
+    for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+        assert helpers.relerr(en[k], g[f"en_{k}"]) < 2e-9, k
+    cfg = PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    tstep, nsteps = float(g["vmc_tstep"]), int(g["vmc_nsteps"])
+    acc = pa.EnergyAccumulator(sup, ewald_gmax=10)
+    if fused:
+        tapes = dict(gauss=g["vmc_gauss"], unif=g["vmc_unif"], ecp_rot=g["vmc_ecp_rot"], ecp_unif=g["vmc_ecp_unif"], record=[])
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, tapes=tapes)
+        accepts = tapes["record"][0]
+    else:
+        gz, un = iter(g["vmc_gauss"].reshape(-1, *g["vmc_gauss"].shape[2:])), iter(g["vmc_unif"].reshape(-1, g["vmc_unif"].shape[-1]))
+        monkeypatch.setattr(np.random, "normal", lambda scale, size: scale * next(gz))
+        monkeypatch.setattr(np.random, "rand", lambda n: next(un))
+        rots, eun = iter(g["vmc_ecp_rot"]), iter(g["vmc_ecp_unif"])
+        accepts = []
+        orig = wf.updateinternals
+        monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
+        monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
+        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
+    assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
+    assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    sign, logv = wf.value()
+    assert helpers.relerr(logv, g["vmc_final_log"]) < 1e-9 and helpers.relerr(sign, g["vmc_final_sign"]) < 1e-8
+    for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
+        assert helpers.relerr(blk[k], g[f"vmc_blk_{k}"]) < 1e-8, k

@@ -308,3 +308,53 @@ def test_oracle_complex_energy_and_vmc_match_reference():
     assert relerr(cfg.configs, g["vmc_final"]) < 1e-11 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
     for k in ("ke", "ee", "ei", "ecp", "total"):
         assert abs(blk["energy" + k] - complex(g["vmc_blk_energy" + k])) < 1e-9 * max(1.0, abs(complex(g["vmc_blk_energy" + k]))), k
+
+
+# ------------------------------------------------------------------ twisted boundary conditions (oracle vs reference)
+def _oracle_twisted_wf(tag, g):
+    from helpers import twist_case
+    from oracle import jastrow_basis, wf as owf
+
+    sup, mf = twist_case(tag)
+    assert np.allclose(mf.kpts, g[f"{tag}_kpts"], atol=1e-14)
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, g[f"{tag}_Ls"])
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    return sup, sl, ja, owf.MultiplyWF(sl, ja)
+
+
+@pytest.mark.parametrize("tag", ["prim", "s211"])
+def test_oracle_twisted_slater_matches_reference(tag):
+    """Non-zero supercell twist: complex lattice-summed AOs and the wrap phase exp(i k . wrap . lattice) of electrons that
+    left the cell (orbitals.py:203-213), through the protocol incl. moves across the boundary (g20_pbc_twist.npz)."""
+    g = golden("g20_pbc_twist")
+    sup, sl, ja, wf = _oracle_twisted_wf(tag, g)
+    pts = pc.PeriodicConfigs(g[f"{tag}_pts"].copy(), sup.lattice_vectors(), wrap=g[f"{tag}_pts_wrap"].copy())
+    for nm, nc in (("val", 1), ("lap", 5)):
+        _, mo = sl._mo(sl._r(pts).reshape(-1, 3), 0, nc)
+        ref = g[f"{tag}_mo_{nm}"]
+        assert relerr(mo, ref.reshape((nc, -1, ref.shape[-1]))) < 1e-12, nm
+    err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": wf}, g, f"{tag}_", sup)
+    assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
+
+
+def test_oracle_twisted_energy_and_vmc_match_reference():
+    from oracle import energy as oenergy, vmc as ovmc
+
+    g = golden("g20_pbc_twist")
+    sup, sl, ja, wf = _oracle_twisted_wf("prim", g)
+    cfg = pc.PeriodicConfigs(g["en_configs"].copy(), sup.lattice_vectors(), wrap=g["en_wrap"].copy())
+    wf.recompute(cfg)
+    en = oenergy.energy(sup, cfg, wf, 10.0, g["en_rot"], g["en_unif"], ewald_kws={"ewald_gmax": 10})
+    for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+        assert relerr(en[k], g[f"en_{k}"]) < 1e-9, k
+    cfg = pc.PeriodicConfigs(g["vmc_start"].copy(), sup.lattice_vectors(), wrap=g["vmc_start_wrap"].copy())
+    rec = []
+    blk, cfg = ovmc.vmc_worker(sup, wf, cfg, float(g["vmc_tstep"]), g["vmc_gauss"], g["vmc_unif"], g["vmc_ecp_rot"], g["vmc_ecp_unif"], record=rec,
+                               ewald_kws={"ewald_gmax": 10})
+    assert np.array_equal(np.asarray(rec).reshape(g["vmc_accepts"].shape), g["vmc_accepts"])
+    assert relerr(cfg.configs, g["vmc_final"]) < 1e-11 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
+    for k in ("ke", "ee", "ei", "ecp", "total"):
+        assert abs(blk["energy" + k] - complex(g["vmc_blk_energy" + k])) < 1e-9 * max(1.0, abs(complex(g["vmc_blk_energy" + k]))), k
