@@ -165,7 +165,7 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
 
 // part (twisted cells only): 0 -> real part, 1 -> imaginary part of sum_L exp(i k_t . L) phi(r - R - L); the caller
 // evaluates a shell once per part (register accumulators for both parts at once do not fit next to the MFMA tiles).
-template <int NCOMP, class Sink>
+template <int NCOMP, bool TW = false, class Sink>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
                                                const double* __restrict__ pcoef, int np, Sink&& sink, int part = 0) {
   double acc[7][NCOMP];
@@ -175,17 +175,17 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     for (int k = 0; k < NCOMP; ++k) acc[m][k] = 0.0;
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
-  const bool tw = S.pb->twist != 0;
   auto add = [&](double xj, double yj, double zj, int j) {
     double ph = 1.0;
-    if (tw) {  // exp(i k_t . (f . lattice + Ls[j])): cos or sin of the summed angle
+    if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos or sin of the summed angle
       const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
       ph = part ? (c.sf * cj + c.cf * sj) : (c.cf * cj - c.sf * sj);
     }
     shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
-      acc[m][0] += ph * v;
-      if (NCOMP > 1) { acc[m][1 % NCOMP] += ph * gx; acc[m][2 % NCOMP] += ph * gy; acc[m][3 % NCOMP] += ph * gz; }
-      if (NCOMP == 5) acc[m][4 % NCOMP] += ph * lp;
+      if (TW) { v *= ph; gx *= ph; gy *= ph; gz *= ph; lp *= ph; }
+      acc[m][0] += v;
+      if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
+      if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
     });
   };
   // Each lane walks ITS OWN list of admitted images (the set bits of its mask): the points of a wave sit anywhere in
@@ -319,7 +319,8 @@ struct ChunkTab {
 //  phase 2 (MFMA): TP=64: wave wv owns the 16-point tile wv and all NT orbital tiles;
 //                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
-template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, bool PBC = false>
+// PBC: 0 open system, 1 periodic (real lattice sums), 2 periodic with a twist (complex lattice sums, shells twice)
+template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, int PBC = 0>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
   constexpr int G = 256 / TP;                         // lane groups in phase 1
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
 #endif
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
       const int shx = cw_shell[si];  // twisted cells: shells appear twice, index + nshell = imaginary part
-      const int part = (PBC && shx >= S.nshell) ? 1 : 0, sh = shx - part * S.nshell;
+      const int part = (PBC == 2 && shx >= S.nshell) ? 1 : 0, sh = shx - part * S.nshell;
       int l_, np_, q0, kb, ia_ = 0;
       double x, y, z;
       const double *pe, *pc;
@@ -419,14 +420,14 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
           ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
           ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
           ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
-          if (S.pb->twist) {
+          if (PBC == 2) {
             ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_) * P + pmine];
             ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_ + 1) * P + pmine];
           }
           if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
         }
         if (part) kb = T.shell_kb[shx];
-        shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, part);
+        shell_eval_pbc<NCOMP, PBC == 2>(S, ctx, sh, l_, pe, pc, np_, to_tile, part);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows

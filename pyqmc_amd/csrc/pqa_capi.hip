@@ -646,7 +646,8 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
   // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
   const bool lt = h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab;
-#define PQA_ORB_PBC(NT, LT) hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, 64, LT, true>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out)
+#define PQA_ORB_PBC(NT, LT) do { if (h->twist) hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, 64, LT, 2>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); \
+                                 else hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, 64, LT, 1>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); } while (0)
   switch (h->nt[spin]) {
     case 1: if (lt) PQA_ORB_PBC(1, true); else PQA_ORB_PBC(1, false); break;
     case 2: if (lt) PQA_ORB_PBC(2, true); else PQA_ORB_PBC(2, false); break;
