@@ -268,6 +268,34 @@ int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gaus
                    double threshold, const double* ecp_rot, const double* ecp_unif, uint64_t seed,
                    double* acceptance, double* energy_mean, uint8_t* accept_rec);
 
+/* dmc_propagate's step loop (pyqmc/method/dmc.py:123-221) fused on the device for real wave functions, open or
+   periodic: per step (1) one T-move per electron (compute_tmoves eval_ecp.py:43-80, propose_tmoves dmc.py:73-120,
+   masked updateinternals :160-168), (2) one drift-diffusion move per electron with Umrigar's limited drift
+   (limdrift :22-35) and fixed-node rejection (propose_drift_diffusion :38-70), (3) the energy accumulator, the
+   branching factor compute_S (:224-235), weights *= exp(tau r2_acc/r2_prop (S_new+S_old)/2) and the weighted step
+   averages (:196-215).  No branching: the caller combs between calls, as rundmc does (:342-376).
+   The walkers must be resident and current (pqa_wf_recompute); the starting energy is evaluated first (:146-149).
+   weights (W) in/out.  step_avg (nsteps,7): sum_w w_w row_w / sum_w w_w for rows ke, ee, ei, ecp, grad2, total,
+   then the mean weight.  step_acc (nsteps,2): acceptance and T-move acceptance (accepted / (W nelec)).
+   tapes NULL -> device Philox streams keyed by (seed, walker, electron, step); otherwise every pointer the system
+   needs must be set (the ECP ones only when the system has ECP atoms):
+     gauss (nsteps,N,W,3) standard normals, unif (nsteps,N,W)                      drift-diffusion moves
+     tm_rot (nsteps,N,necp,3,3), tm_unif (nsteps,N,necp,W), tm_u1, tm_u2 (nsteps,N,W)  T-move grid, mask, selection, acceptance
+     ecp_rot (nsteps+1,N,necp,3,3), ecp_unif (nsteps+1,N,necp,W)                  energy draws; index 0 = starting energy */
+typedef struct {
+  const double* gauss;
+  const double* unif;
+  const double* tm_rot;
+  const double* tm_unif;
+  const double* tm_u1;
+  const double* tm_u2;
+  const double* ecp_rot;
+  const double* ecp_unif;
+} pqa_dmc_tapes_t;
+int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double branchcut, double e_trial, double e_est,
+                  double threshold, double* weights, const pqa_dmc_tapes_t* tapes, uint64_t seed, double* step_avg,
+                  double* step_acc);
+
 /* ---- measurement -------------------------------------------------------------------- */
 /* HIP-event timing on the handle's own stream (torch.cuda.Event only sees torch's stream). */
 int pqa_timer_start(pqa_handle_t* h);

@@ -19,6 +19,12 @@ c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 
 
+class DmcTapes(C.Structure):
+    """pqa_dmc_tapes_t (include/pyqmc_amd.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("gauss", "unif", "tm_rot", "tm_unif", "tm_u1", "tm_u2", "ecp_rot", "ecp_unif")]
+
+
 class SystemStruct(C.Structure):
     """Mirror of ``pqa_system_t``."""
 
@@ -87,6 +93,8 @@ _PROTOTYPES = {
     "pqa_tmoves": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_vmc_sweeps": (C.c_int, [_H, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pqa_dmc_steps": (C.c_int, [_H, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                C.c_uint64, C.c_void_p, C.c_void_p]),
     "pqa_timer_start": (C.c_int, [_H]),
     "pqa_timer_stop": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "pqa_sync": (C.c_int, [_H]),

@@ -14,6 +14,7 @@
 #include "pqa_ao.hpp"
 #include "pqa_common.hpp"
 #include "pqa_cslater.hpp"
+#include "pqa_dmc.hpp"
 #include "pqa_energy.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_lw.hpp"
@@ -73,6 +74,7 @@ struct pqa_handle {
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
+  DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
@@ -551,7 +553,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1624,6 +1626,161 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     HIPCHK(hipMemcpy(acceptance, acc.data(), nsteps * sizeof(double), hipMemcpyDefault));
   }
   if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * nen * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused DMC propagation
+// nsteps steps of dmc_propagate (pyqmc/method/dmc.py:123-221) without leaving the device: T-moves, drift-diffusion with
+// fixed-node rejection, local energy, weight update, weighted step averages.  Walker-per-wave kernels (the AoS state).
+extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double branchcut, double e_trial, double e_est, double threshold,
+                             double* weights, const pqa_dmc_tapes_t* tp, uint64_t seed, double* step_avg, double* step_acc) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->cplx) FAIL("pqa_dmc_steps: complex orbitals are not implemented (fixed-phase DMC runs through the protocol entry points)");
+  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
+  if (nsteps <= 0) return 0;
+  if (!weights || !step_avg || !step_acc) FAIL("pqa_dmc_steps: weights / step_avg / step_acc must not be NULL");
+  const long W = h->W;
+  const int N = h->N, necp = h->necp, P = h->tm_P;
+  const bool tmoves = necp > 0 && P > 0;
+  if (tp && (!tp->gauss || !tp->unif)) FAIL("pqa_dmc_steps: a tape set needs gauss and unif");
+  if (tp && necp > 0 && (!tp->ecp_rot || !tp->ecp_unif)) FAIL("pqa_dmc_steps: a tape set needs ecp_rot and ecp_unif for ECP systems");
+  if (tp && tmoves && (!tp->tm_rot || !tp->tm_unif || !tp->tm_u1 || !tp->tm_u2)) FAIL("pqa_dmc_steps: a tape set needs the four T-move tapes");
+  h->saved_valid = false;
+  const int nmo_max = std::max(std::max(h->nmo[0], h->nmo[1]), 1);
+  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_aux, (size_t)W * 8 * sizeof(double)));
+  TRY(ensure(h, h->b_accept, (size_t)W));
+  TRY(ensure(h, h->b_acccnt, (size_t)nsteps * 2 * sizeof(int)));
+  TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo_max * sizeof(double)));
+  TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
+  TRY(ensure(h, h->b_tmacc, (size_t)W * sizeof(int)));
+  TRY(ensure(h, h->b_dmcw, (size_t)W * sizeof(double)));
+  TRY(ensure(h, h->b_dmcold, (size_t)2 * W * sizeof(double)));
+  TRY(ensure(h, h->b_dmcr2, (size_t)2 * W * sizeof(double)));
+  TRY(ensure(h, h->b_dmcout, (size_t)nsteps * 7 * sizeof(double)));
+  HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * 2 * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->b_tmacc.p, 0, (size_t)W * sizeof(int), h->stream));
+  HIPCHK(hipMemsetAsync(h->b_dmcr2.p, 0, (size_t)2 * W * sizeof(double), h->stream));
+  TRY(copy_in(h, h->b_dmcw.p, weights, (size_t)W * sizeof(double)));
+  if (h->S.pbc) {
+    TRY(ensure(h, h->b_dwrap, (size_t)W * 3 * sizeof(int)));
+    TRY(ensure(h, h->b_wrap, (size_t)W * N * 3 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->b_wrap.p, 0, (size_t)W * N * 3 * sizeof(int), h->stream));
+    h->wrap_W = W;
+  }
+  if (tp) {
+    TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
+    TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
+  }
+  const size_t nrot = (size_t)N * std::max(necp, 1);
+  const int nkw = (std::max(necp, 1) + 63) / 64;
+  if (tmoves) {
+    TRY(ensure(h, h->b_tmcnt, (size_t)W * sizeof(int)));
+    TRY(ensure(h, h->b_tmoff, (size_t)(W + 1) * sizeof(long)));
+    TRY(ensure(h, h->b_tmpass, (size_t)W * nkw * sizeof(unsigned long long)));
+    TRY(ensure(h, h->b_tmidx, (size_t)(W + 1) * sizeof(int)));
+    TRY(ensure(h, h->b_tmapos, (size_t)W * 3 * sizeof(double)));
+    TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * W * sizeof(double)));
+    TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
+  }
+  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  const dim3 gw256((unsigned)((W + 255) / 256));
+  double* eold = (double*)h->b_dmcold.p;
+  double* r2 = (double*)h->b_dmcr2.p;
+  // energy of the starting configuration (dmc.py:146-149)
+  TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
+  hipLaunchKernelGGL(k_dmc_keep, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
+  for (int step = 0; step < nsteps; ++step) {
+    MoveBuf mb{};
+    mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
+    mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
+    mb.dmc = 1; mb.r2_acc = r2; mb.r2_prop = r2 + W;
+    if (h->S.pbc) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }
+    if (tmoves) {
+      TmBuf B{};
+      B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold;
+      B.cnt = (int*)h->b_tmcnt.p; B.off = (long*)h->b_tmoff.p; B.pass = (unsigned long long*)h->b_tmpass.p;
+      B.tm_acc = (int*)h->b_tmacc.p; B.acc_idx = (int*)h->b_tmidx.p + 1; B.nacc = (int*)h->b_tmidx.p;
+      B.acc_pos = (double*)h->b_tmapos.p;
+      if (tp) TRY(copy_in(h, h->b_rot.p, tp->tm_rot + (size_t)step * nrot * 9, nrot * 9 * sizeof(double)));
+      else {
+        hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed ^ 0x9E3779B97F4A7C15ull,
+                           (uint32_t)step, (double*)h->b_rot.p);
+        TRY(check_launch(h, "k_gen_rot"));
+      }
+      for (int e = 0; e < N; ++e) {
+        const int s = e >= h->nup;
+        B.rot = (const double*)h->b_rot.p + (size_t)e * necp * 9;
+        if (tp) {
+          double* u = (double*)h->b_tmu.p;
+          TRY(copy_in(h, u, tp->tm_u1 + ((size_t)step * N + e) * W, (size_t)W * sizeof(double)));
+          TRY(copy_in(h, u + W, tp->tm_u2 + ((size_t)step * N + e) * W, (size_t)W * sizeof(double)));
+          TRY(copy_in(h, u + 2 * W, tp->tm_unif + ((size_t)step * N + e) * necp * W, (size_t)necp * W * sizeof(double)));
+          B.u1 = u; B.u2 = u + W; B.unif = u + 2 * W;
+        }
+        hipLaunchKernelGGL(k_tm_count, gw256, dim3(256), 0, h->stream, h->S, h->js, B, e, W);
+        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
+        TRY(check_launch(h, "k_tm_count/k_scan1"));
+        long tot = 0;
+        TRY(copy_out(h, &tot, B.off + W, sizeof(long)));
+        if (tot == 0) continue;  // nobody passed the mask: no walker moves (and no further draws are consumed in Philox mode)
+        TRY(ensure(h, h->b_tpos, (size_t)tot * 3 * sizeof(double)));
+        TRY(ensure(h, h->b_twgt, (size_t)tot * sizeof(double)));
+        TRY(ensure(h, h->b_tmamp, (size_t)tot * 2 * sizeof(double)));
+        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot;
+        hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, e, W);
+        TRY(check_launch(h, "k_tm_fill"));
+        if (h->has_slater) {
+          TRY(ensure(h, h->b_emo[0], (size_t)tot * nmo_max * sizeof(double)));
+          TRY(launch_orb(h, s, plain_points(B.pts, tot), tot, 1, (double*)h->b_emo[0].p));
+        }
+        hipLaunchKernelGGL(k_tm_select, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, mb, e,
+                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, W);
+        hipLaunchKernelGGL(k_tm_compact, dim3(1), dim3(1024), 0, h->stream, B, mb, W);
+        TRY(check_launch(h, "k_tm_select/k_tm_compact"));
+        int nacc = 0;
+        TRY(copy_out(h, &nacc, B.nacc, sizeof(int)));
+        if (nacc == 0) continue;
+        if (h->has_slater) TRY(launch_orb(h, s, plain_points(B.acc_pos, nacc), nacc, 5, (double*)h->b_motmp.p));
+        hipLaunchKernelGGL(k_tm_commit, dim3((unsigned)nacc), dim3(64), lds_sm(h), h->stream, h->S, h->st, h->js, B, mb, e,
+                           (int)h->has_slater, (const double*)h->b_motmp.p);
+        TRY(check_launch(h, "k_tm_commit"));
+      }
+      hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_tmacc.p, W, (int*)h->b_acccnt.p + 2 * step + 1);
+    }
+    if (tp) {
+      TRY(copy_in(h, h->b_gauss.p, tp->gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
+      TRY(copy_in(h, h->b_unif.p, tp->unif + (size_t)step * N * W, (size_t)N * W * sizeof(double)));
+      mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
+    }
+    for (int e = 0; e < N; ++e) {
+      const int s = e >= h->nup;
+      hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+                         (int)h->has_slater, (int)h->has_jastrow, W);
+      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+      hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
+                         (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+    }
+    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + 2 * step);
+    TRY(check_launch(h, "k_propose/k_accept (dmc)"));
+    TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot + (size_t)(step + 1) * nrot * 9 : nullptr,
+                   (tp && necp) ? tp->ecp_unif + (size_t)(step + 1) * nrot * W : nullptr, seed, (uint32_t)(step + 1), false));
+    hipLaunchKernelGGL(k_dmc_weights, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
+                       (double*)h->b_dmcw.p, tstep, branchcut, e_trial, e_est, N, W);
+    hipLaunchKernelGGL(k_dmc_averages, dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
+                       (double*)h->b_dmcout.p + (size_t)step * 7);
+    TRY(check_launch(h, "k_dmc_weights/k_dmc_averages"));
+  }
+  h->jas_stale = h->has_j2;
+  std::vector<int> cnt((size_t)nsteps * 2);
+  TRY(copy_in(h, step_avg, h->b_dmcout.p, (size_t)nsteps * 7 * sizeof(double)));
+  TRY(copy_in(h, weights, h->b_dmcw.p, (size_t)W * sizeof(double)));
+  TRY(copy_out(h, cnt.data(), h->b_acccnt.p, cnt.size() * sizeof(int)));
+  for (int i = 0; i < nsteps; ++i) {
+    step_acc[2 * i] = (double)cnt[2 * i] / ((double)W * N);
+    step_acc[2 * i + 1] = (double)cnt[2 * i + 1] / ((double)W * N);
+  }
   return 0;
 }
 

@@ -1,0 +1,315 @@
+// pqa_dmc.hpp — the DMC step on the device (real wave functions; open and periodic systems).
+//
+// One DMC step of the reference's dmc_propagate (pyqmc/method/dmc.py:123-221) is
+//   (1) per electron, one T-move: compute_tmoves (eval_ecp.py:43-80) -> propose_tmoves (dmc.py:73-120) -> accept -> update
+//   (2) per electron, one drift-diffusion move with Umrigar's limited drift and fixed-node rejection (dmc.py:38-70):
+//       the VMC kernels k_propose / k_accept in their `dmc` mode (pqa_vmc.hpp)
+//   (3) local energy, branching factor compute_S (dmc.py:224-235), weight update and weighted averages.
+// The kernels here are (1) and (3).  Unlike the host-driven pqa_tmoves (dense [W][P] candidate table, kept for the
+// protocol-level API) the fused path compacts the candidates of the walkers that pass the stochastic ECP mask, the same
+// count -> scan -> fill -> orbitals -> ratio pipeline as the energy's ECP term: dead candidates carry weight 0 and can never
+// be the first crossing of the cumulative distribution, so leaving them out selects the same move.
+#pragma once
+#include "pqa_energy.hpp"
+#include "pqa_vmc.hpp"
+
+#define PQA_STREAM_TMMASK 6u
+#define PQA_STREAM_TM_U1 7u
+#define PQA_STREAM_TM_U2 8u
+
+struct TmBuf {
+  const double* rot;    // [necp][3][3] rotations of this electron's quadrature grids
+  const double* unif;   // [necp][W] mask uniforms of this electron or NULL -> Philox
+  const double* u1;     // [W] selection uniforms or NULL
+  const double* u2;     // [W] acceptance uniforms or NULL
+  const double* quad;   // [6+12][3]
+  uint64_t seed;
+  uint32_t step;
+  double tau, threshold;
+  int* cnt;             // [W] live candidates of the walker
+  long* off;            // [W+1] exclusive scan of cnt
+  unsigned long long* pass;  // [W][ceil(necp/64)] ECP atoms whose mask the walker passed
+  double* pts;          // [ncand][3]
+  double* wgt;          // [ncand] sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i
+  double* amp;          // [ncand] ratio * weight
+  double* rat;          // [ncand] Psi(candidate)/Psi
+  int* tm_acc;          // [W] accepted T-moves of the walker in this step
+  int* nacc;            // [1] accepted walkers of this electron
+  int* acc_idx;         // [W] their indices, ascending
+  double* acc_pos;      // [W][3] their new positions
+};
+
+// pass A: which ECP atoms pass the mask for electron e of each walker, and how many candidates that makes
+__global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, int e, long W) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
+  const int nkw = (S.necp + 63) / 64;
+  int c = 0;
+  for (int kw = 0; kw < nkw; ++kw) {
+    unsigned long long m = 0ull;
+    for (int k = kw * 64; k < S.necp && k < kw * 64 + 64; ++k) {
+      const int ia = S.ecp_atom[k];
+      double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+      min_image(S, dx, dy, dz);
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      double v[PQA_MAXCHAN], prob;
+      int nch;
+      ecp_radial(S, k, r, B.threshold, v, nch, prob);
+      double u;
+      if (B.unif) u = B.unif[(size_t)k * W + w];
+      else {
+        const Philox p = philox(B.seed, (uint32_t)w, (uint32_t)(e * S.necp + k), PQA_STREAM_TMMASK, B.step);
+        u = u01(p.c[0], p.c[1]);
+      }
+      if (nch > 1 && prob > u) {
+        m |= 1ull << (k - kw * 64);
+        c += (nch <= 2) ? 6 : 12;
+      }
+    }
+    B.pass[(size_t)w * nkw + kw] = m;
+  }
+  B.cnt[w] = c;
+}
+
+// exclusive scan of cnt[W] -> off[W+1]; one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan1(const int* __restrict__ c, long* __restrict__ o, long W) {
+  __shared__ long part[1024];
+  const long per = (W + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < W) ? b + per : W;
+  long sum = 0;
+  for (long i = b; i < e; ++i) sum += c[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long run = 0;
+    for (int t = 0; t < 1024; ++t) { const long v = part[t]; part[t] = run; run += v; }
+    o[W] = run;
+  }
+  __syncthreads();
+  long run = part[threadIdx.x];
+  for (long i = b; i < e; ++i) { o[i] = run; run += c[i]; }
+}
+
+// pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
+// grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, int e, long W) {
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (B.cnt[w] == 0) return;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
+  const int nkw = (S.necp + 63) / 64;
+  long run = B.off[w];
+  for (int kw = 0; kw < nkw; ++kw) {
+    unsigned long long m = B.pass[(size_t)w * nkw + kw];
+    while (m) {
+      const int k = kw * 64 + __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int ia = S.ecp_atom[k];
+      double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+      min_image(S, dx, dy, dz);
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      double v[PQA_MAXCHAN], prob;
+      int nch;
+      ecp_radial(S, k, r, B.threshold, v, nch, prob);
+      const int naip = (nch <= 2) ? 6 : 12;
+      if (lane < naip) {
+        const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
+        const double* R = B.rot + (size_t)k * 9;
+        const double vx = R[0] * qd[0] + R[1] * qd[1] + R[2] * qd[2];
+        const double vy = R[3] * qd[0] + R[4] * qd[1] + R[5] * qd[2];
+        const double vz = R[6] * qd[0] + R[7] * qd[1] + R[8] * qd[2];
+        const double rix = r * vx, riy = r * vy, riz = r * vz;
+        const double cosv = (dx * rix + dy * riy + dz * riz) / (r * sqrt(rix * rix + riy * riy + riz * riz));
+        double wt = 0.0;
+        for (int c = 0; c < nch - 1; ++c) wt += (exp(-B.tau * (v[c] / prob)) - 1.0) * (2 * c + 1) * legendre_l(c, cosv);
+        wt *= 1.0 / naip;
+        double* p = B.pts + 3 * (size_t)(run + lane);
+        p[0] = (ex - dx) + rix; p[1] = (ey - dy) + riy; p[2] = (ez - dz) + riz;
+        B.wgt[run + lane] = wt;
+      }
+      run += naip;
+    }
+  }
+}
+
+// ratios at the walker's candidates, then the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120:
+//   fwd_q = max(ratio_q weight_q, 0), norm = 1 + sum fwd, move q chosen with probability fwd_q / norm (else stay);
+//   backward amplitudes seen from the chosen point: ratio_q weight_q / ratio_sel for the other candidates and
+//   weight_sel / ratio_sel for the way back; accept with probability norm / back_norm.
+// mo: [ncand][nmo_s] orbital values at the candidates.  Writes newpos / dwrap / accept for every walker.
+// grid = W, block = 64, LDS like k_tmove_ratio.
+__global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, JastrowState js, TmBuf B, MoveBuf mb, int e,
+                                                  int has_slater, int has_jastrow, const double* __restrict__ mo, long W) {
+  extern __shared__ double lds[];
+  const long w = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int s = e >= S.nup, nmo = S.nmo[s];
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const long p0 = B.off[w], p1 = B.off[w + 1];
+  const int n = (int)(p1 - p0);
+  if (n == 0) {
+    if (lane == 0) {
+      mb.accept[w] = 0;
+      mb.newpos[3 * w] = xw[3 * e]; mb.newpos[3 * w + 1] = xw[3 * e + 1]; mb.newpos[3 * w + 2] = xw[3 * e + 2];
+    }
+    return;
+  }
+  double U0 = 0.0, g[3], lp;
+  if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
+  for (long p = p0; p < p1; ++p) {
+    double rat = 1.0;
+    if (has_slater) {
+      double r1[1];
+      slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
+      rat = r1[0];
+    }
+    if (has_jastrow) {
+      double U;
+      jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
+      rat *= exp(U - U0);
+    }
+    if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
+  }
+  if (lane != 0) return;
+  double norm = 1.0;
+  for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
+  double u1, u2;
+  if (B.u1) { u1 = B.u1[w]; u2 = B.u2[w]; }
+  else {
+    const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
+    const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
+    u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
+  }
+  int sel = 0;
+  double cdf = 0.0;
+  for (long p = p0; p < p1; ++p) {
+    cdf += fmax(B.amp[p], 0.0) / norm;
+    if (cdf < u1) ++sel;
+  }
+  bool acc = false;
+  double nx = xw[3 * e], ny = xw[3 * e + 1], nz = xw[3 * e + 2];
+  if (sel < n) {
+    const double rr = 1.0 / B.rat[p0 + sel];
+    double back = 1.0;
+    for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
+    acc = norm / back > u2;
+    nx = B.pts[3 * (p0 + sel)]; ny = B.pts[3 * (p0 + sel) + 1]; nz = B.pts[3 * (p0 + sel) + 2];
+  }
+  if (mb.dwrap) {
+    // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
+    // folded coordinates (dmc.py:100), so the reference's wrap counters do not see a T-move across the cell boundary;
+    // identical results means the same here: fold, and leave the counters alone.
+    fold_cell(S, nx, ny, nz);
+    mb.dwrap[3 * w] = 0; mb.dwrap[3 * w + 1] = 0; mb.dwrap[3 * w + 2] = 0;
+  }
+  mb.newpos[3 * w] = nx; mb.newpos[3 * w + 1] = ny; mb.newpos[3 * w + 2] = nz;
+  mb.accept[w] = acc;
+}
+
+// ascending list of the walkers whose T-move was accepted, with their new positions; one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_tm_compact(TmBuf B, MoveBuf mb, long W) {
+  __shared__ int part[1024];
+  const long per = (W + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < W) ? b + per : W;
+  int c = 0;
+  for (long i = b; i < e; ++i) c += mb.accept[i] ? 1 : 0;
+  part[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    *B.nacc = run;
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (long i = b; i < e; ++i)
+    if (mb.accept[i]) {
+      B.acc_idx[run] = (int)i;
+      B.acc_pos[3 * run] = mb.newpos[3 * i]; B.acc_pos[3 * run + 1] = mb.newpos[3 * i + 1]; B.acc_pos[3 * run + 2] = mb.newpos[3 * i + 2];
+      B.tm_acc[i] += 1;
+      ++run;
+    }
+}
+
+// commit of the accepted T-moves: Sherman-Morrison update, orbital-row cache, coordinates and wrap counters
+// (updateinternals with mask, dmc.py:167-168).  mo5: [nacc][5][nmo_s] rows at the new positions.  grid = nacc, block = 64.
+__global__ __launch_bounds__(64) void k_tm_commit(SysDev S, SlaterState st, JastrowState js, TmBuf B, MoveBuf mb, int e, int has_slater,
+                                                  const double* __restrict__ mo5) {
+  extern __shared__ double lds[];
+  const long a = blockIdx.x;
+  const long w = B.acc_idx[a];
+  const int lane = threadIdx.x;
+  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  if (has_slater) {
+    const double* row = mo5 + (size_t)a * 5 * nmo;
+    sm_update_wave(S, st, s, i, w, row, lds);
+    double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
+    for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
+  }
+  if (lane == 0) {
+    double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
+    x[0] = B.acc_pos[3 * a]; x[1] = B.acc_pos[3 * a + 1]; x[2] = B.acc_pos[3 * a + 2];
+    if (mb.wrap) {
+      int* wr = mb.wrap + ((size_t)w * S.nelec + e) * 3;
+      wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- weights and averages
+__device__ __forceinline__ double dmc_S(double e_trial, double e_est, double branchcut, double v2, double tau, double eloc, int nelec) {
+  const double d = e_est - eloc;  // dmc.py:224-235
+  const double e_cut = fmin(fmax(d, -branchcut), branchcut);
+  const double t = v2 * tau / nelec;
+  return e_trial - e_est + e_cut / sqrt(1.0 + t * t);
+}
+
+// weights *= exp(tau (r2_acc / r2_prop) (S_new + S_old)/2); the new energy becomes the old one; statistics reset.
+// en: rows ke, ee, ei, ecp, grad2, total of the NEW configuration.  eold/v2old: [W].
+__global__ __launch_bounds__(256) void k_dmc_weights(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old,
+                                                     double* __restrict__ r2_acc, double* __restrict__ r2_prop,
+                                                     double* __restrict__ weights, double tau, double branchcut, double e_trial,
+                                                     double e_est, int nelec, long W) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  const double eloc = en[5 * W + w], v2 = en[4 * W + w];
+  const double Sm = 0.5 * (dmc_S(e_trial, e_est, branchcut, v2, tau, eloc, nelec) +
+                           dmc_S(e_trial, e_est, branchcut, v2old[w], tau, eold[w], nelec));
+  weights[w] *= exp(tau * (r2_acc[w] / r2_prop[w]) * Sm);
+  eold[w] = eloc; v2old[w] = v2;
+  r2_acc[w] = 0.0; r2_prop[w] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old, long W) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  if (w >= W) return;
+  eold[w] = en[5 * W + w]; v2old[w] = en[4 * W + w];
+}
+
+// out[0..5] = sum_w weights[w] en[k][w] / sum_w weights[w] (the reference's dot(weights, v)/(W wavg), dmc.py:205-209),
+// out[6] = mean weight.  One block of 1024 threads, deterministic.
+__global__ __launch_bounds__(1024) void k_dmc_averages(const double* __restrict__ en, const double* __restrict__ weights, long W,
+                                                       double* __restrict__ out) {
+  __shared__ double part[7][1024];
+  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (long i = threadIdx.x; i < W; i += 1024) {
+    const double wt = weights[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += wt * en[(size_t)k * W + i];
+    s[6] += wt;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) part[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) out[threadIdx.x] = part[threadIdx.x][0] / part[6][0];
+  if (threadIdx.x == 6) out[6] = part[6][0] / (double)W;
+}

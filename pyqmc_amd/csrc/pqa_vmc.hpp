@@ -29,6 +29,10 @@ struct MoveBuf {
   uint64_t seed;
   uint32_t step;
   double tstep;
+  // DMC drift-diffusion (dmc.py:38-70): Umrigar's limited drift, fixed-node rejection, per-walker diffusion statistics
+  int dmc;
+  double* r2_prop;  // [W] sum over electrons of |gauss + drift|^2 of every proposal
+  double* r2_acc;   // [W] the same for accepted proposals
 };
 
 __device__ __forceinline__ void limdrift3(double& gx, double& gy, double& gz) {  // mc.py:76-89, cutoff 1
@@ -36,13 +40,19 @@ __device__ __forceinline__ void limdrift3(double& gx, double& gy, double& gz) { 
   if (tot > 1.0) { gx /= tot; gy /= tot; gz /= tot; }
 }
 __device__ __forceinline__ double finite_or(double v, double alt) { return (v >= -DBL_MAX && v <= DBL_MAX) ? v : alt; }
+// Umrigar's limiter (dmc.py:22-35, acyrus = 0.5): g -> g * tau_eff, tau_eff = (sqrt(1 + 2 tau a |g|^2) - 1) / (a |g|^2)
+__device__ __forceinline__ void limdrift_dmc(double& gx, double& gy, double& gz, double tau) {
+  const double v2 = gx * gx + gy * gy + gz * gz, a = 0.5;
+  const double te = (v2 > 1e-8) ? (sqrt(1.0 + 2.0 * tau * a * v2) - 1.0) / (a * v2) : tau;
+  gx *= te; gy *= te; gz *= te;
+}
 
 // Slater part of a move: gradient of log|Psi_S| (real part for complex orbitals: the drift uses np.real(grad),
 // mc.py:118,126) and |ratio|^2, sanitised like gradient_value (slater.py:414-417).  CX: complex determinants.
 template <bool CX>
 __device__ __forceinline__ void slater_move_terms(const SysDev& S, const SlaterState& st, int s, int i, long w,
                                                   const double* __restrict__ row, double* lds, double& gx, double& gy,
-                                                  double& gz, double& val2) {
+                                                  double& gz, double& val2, double* sgn = nullptr) {
   if (CX) {
     cx r[5];
     slater_ratios_c<5>(S, st, s, i, w, row, r, lds);
@@ -57,6 +67,7 @@ __device__ __forceinline__ void slater_move_terms(const SysDev& S, const SlaterS
     gx += finite_or(r[1] / r[0], 0.0); gy += finite_or(r[2] / r[0], 0.0); gz += finite_or(r[3] / r[0], 0.0);
     const double v = finite_or(r[0], 1.0);
     val2 = v * v;
+    if (sgn) *sgn = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);  // np.sign of the determinant ratio (the Jastrow ratio is positive)
   }
 }
 
@@ -78,7 +89,8 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
     jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp, 3, lds + S.j3_off);
     gx += g[0]; gy += g[1]; gz += g[2];
   }
-  limdrift3(gx, gy, gz);
+  if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (already times tau_eff)
+  else limdrift3(gx, gy, gz);
   if (threadIdx.x == 0) {
     double z0, z1, z2, z3;
     if (mb.gauss) {
@@ -90,10 +102,11 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
     }
     const double sq = sqrt(mb.tstep);
     z0 *= sq; z1 *= sq; z2 *= sq;
+    const double df = mb.dmc ? 1.0 : mb.tstep;
     double* np_ = mb.newpos + 3 * w;
-    np_[0] = ex + z0 + gx * mb.tstep;  // mc.py:120
-    np_[1] = ey + z1 + gy * mb.tstep;
-    np_[2] = ez + z2 + gz * mb.tstep;
+    np_[0] = ex + z0 + gx * df;  // mc.py:120 / dmc.py:52
+    np_[1] = ey + z1 + gy * df;
+    np_[2] = ez + z2 + gz * df;
     if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
     double* a = mb.aux + 8 * w;
     a[0] = z0; a[1] = z1; a[2] = z2; a[3] = gx; a[4] = gy; a[5] = gz; a[6] = U0;
@@ -113,7 +126,8 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
   const double nx = mb.newpos[3 * w], ny = mb.newpos[3 * w + 1], nz = mb.newpos[3 * w + 2];
   double val2 = 1.0, gx = 0.0, gy = 0.0, gz = 0.0;  // val2 = |Psi(new)/Psi|^2 (mc.py:131)
   const double* row = motmp + (size_t)w * 5 * nmo;
-  if (has_slater) slater_move_terms<CX>(S, st, s, i, w, row, lds, gx, gy, gz, val2);
+  double sgn = 1.0;
+  if (has_slater) slater_move_terms<CX>(S, st, s, i, w, row, lds, gx, gy, gz, val2, &sgn);
   if (has_jastrow) {
     double g[3], lp, U;
     jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp, 3, lds + S.j3_off);
@@ -121,12 +135,19 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
     const double ej = exp(U - a[6]);
     val2 *= ej * ej;
   }
-  limdrift3(gx, gy, gz);
+  double bx, by, bz;
+  if (mb.dmc) {  // dmc.py:57-60: backward = gauss + drift(old) + drift(new)
+    limdrift_dmc(gx, gy, gz, mb.tstep);
+    bx = a[0] + a[3] + gx; by = a[1] + a[4] + gy; bz = a[2] + a[5] + gz;
+  } else {
+    limdrift3(gx, gy, gz);
+    bx = a[0] + mb.tstep * (a[3] + gx); by = a[1] + mb.tstep * (a[4] + gy); bz = a[2] + mb.tstep * (a[5] + gz);
+  }
   const double fwd = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
-  const double bx = a[0] + mb.tstep * (a[3] + gx), by = a[1] + mb.tstep * (a[4] + gy), bz = a[2] + mb.tstep * (a[5] + gz);
   const double bwd = bx * bx + by * by + bz * bz;
   const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));  // mc.py:130
-  const double ratio = val2 * t_prob;
+  double ratio = val2 * t_prob;
+  if (mb.dmc && !CX) ratio *= sgn;  // fixed node: a sign change is never accepted (dmc.py:64-66)
   double u;
   if (mb.unif) u = mb.unif[(size_t)e * W + w];
   else {
@@ -134,6 +155,11 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
     u = u01(p.c[0], p.c[1]);
   }
   const bool acc = ratio > u;
+  if (mb.dmc && lane == 0) {  // dmc.py:68 r2 = |gauss + drift|^2
+    const double r2 = (a[0] + a[3]) * (a[0] + a[3]) + (a[1] + a[4]) * (a[1] + a[4]) + (a[2] + a[5]) * (a[2] + a[5]);
+    mb.r2_prop[w] += r2;
+    if (acc) mb.r2_acc[w] += r2;
+  }
   if (lane == 0) {
     mb.accept[w] = acc;
     if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;

@@ -93,12 +93,92 @@ def propose_tmoves(wf, configs, acc, tstep, e, rng, necp):
     return configs.make_irreducible(e, newpos), chosen, acceptance
 
 
+def _record_tapes(rng, nsteps, N, necp, W, tmoves):
+    """Draw everything ``nsteps`` steps consume from ``rng`` in the reference's order (dmc.py:146-196) and lay it out as
+    the replay tapes of ``pqa_dmc_steps``."""
+    t = {"gauss": np.empty((nsteps, N, W, 3)), "unif": np.empty((nsteps, N, W))}
+    if necp:
+        t["ecp_rot"], t["ecp_unif"] = np.empty((nsteps + 1, N, necp, 3, 3)), np.empty((nsteps + 1, N, necp, W))
+    if tmoves:
+        t["tm_rot"], t["tm_unif"] = np.empty((nsteps, N, necp, 3, 3)), np.empty((nsteps, N, necp, W))
+        t["tm_u1"], t["tm_u2"] = np.empty((nsteps, N, W)), np.empty((nsteps, N, W))
+
+    def energy_draws(i):
+        for e in range(N):
+            for k in range(necp):
+                t["ecp_unif"][i, e, k] = rng.random(W)
+                t["ecp_rot"][i, e, k] = rng.rot()
+
+    energy_draws(0)
+    for i in range(nsteps):
+        if tmoves:
+            for e in range(N):
+                for k in range(necp):
+                    t["tm_unif"][i, e, k] = rng.random(W)
+                    t["tm_rot"][i, e, k] = rng.rot()
+                t["tm_u1"][i, e] = [rng.rand1() for _ in range(W)]
+                t["tm_u2"][i, e] = rng.rand(W)
+        for e in range(N):
+            t["gauss"][i, e] = rng.normal(W)
+            t["unif"][i, e] = rng.rand(W)
+        energy_draws(i + 1)
+    return t
+
+
+_fused_calls = [0]
+
+
+def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, acc, name, rng):
+    """``dmc_propagate`` through ``pqa_dmc_steps``: the whole step loop stays on the device."""
+    from .energy import KEYS
+
+    W, N = configs.configs.shape[:2]
+    necp = getattr(dev, "necp", 0)
+    tmoves = acc.has_nonlocal_moves() and necp > 0
+    wf.recompute(configs)
+    if dev.pbc:
+        dev.set_ewald(**acc._ewald_kws)
+    tapes = None if rng is None else _record_tapes(rng, nsteps, N, necp, W, tmoves)
+    _fused_calls[0] += 1
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    avg, stat = dev.dmc_steps(tstep, nsteps, w, branchcut, e_trial, e_est, threshold=acc.threshold, tapes=tapes,
+                              seed=acc.seed + 7919 * _fused_calls[0])
+    weights[:] = w
+    configs.configs[...] = dev.configs()
+    if dev.pbc:
+        configs.wrap += dev.wrap_delta()
+    wts = avg[:, 6]
+    rel = wts / wts.mean()
+    out = {name + k: np.mean(avg[:, i] * rel) for i, k in enumerate(KEYS[:6])}
+    out["acceptance"] = np.mean(stat[:, 0] * rel)
+    out["tmove_acceptance"] = np.mean(stat[:, 1] * rel)
+    out["weight"] = wts.mean()
+    return out, configs, weights
+
+
+def fused_dmc_supported(wf, accumulators, ekey):
+    """The device step loop covers real wave functions on one handle with the energy accumulator as the only one."""
+    from .energy import EnergyAccumulator
+
+    dev = wf.fused_device() if hasattr(wf, "fused_device") else getattr(wf, "_dev", None)
+    if dev is None or getattr(dev, "cplx", False) or set(accumulators) != {ekey[0]} or ekey[1] != "total":
+        return None
+    return dev if isinstance(accumulators[ekey[0]], EnergyAccumulator) else None
+
+
 def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps=5, accumulators=None,
-                  ekey=("energy", "total"), rng=None):
+                  ekey=("energy", "total"), rng=None, fused=True):
     """Propagate ``nsteps`` DMC steps without branching; returns (block averages, configs, weights) with the
-    reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``)."""
+    reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``).
+
+    ``fused=True`` (default) runs the step loop on the device (``pqa_dmc_steps``) whenever the wave function is real and
+    the energy accumulator is the only accumulator; otherwise, or with ``fused=False``, the loop below drives the
+    protocol entry points step by step like the reference does."""
     assert accumulators is not None, "Need an energy accumulator for DMC"
     acc = accumulators[ekey[0]]
+    dev = fused_dmc_supported(wf, accumulators, ekey) if fused else None
+    if dev is not None:
+        return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, acc, ekey[0], rng)
     replay = rng is not None
     rng = rng if replay else _NumpyRNG()
     W, N = configs.configs.shape[:2]

@@ -256,6 +256,25 @@ class DeviceWF:
             en = self._complex_energy(en, 1)
         return acc, en, (rec.astype(bool) if record else None)
 
+    def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0):
+        """``pqa_dmc_steps``: ``nsteps`` DMC steps on the resident walkers.  ``weights`` (W) is updated in place.
+        ``tapes``: dict of the replay arrays of ``pqa_dmc_tapes_t`` or None (device Philox streams).
+        Returns (step_avg (nsteps,7), step_acc (nsteps,2))."""
+        assert weights.dtype == np.float64 and weights.flags.c_contiguous and weights.shape == (self.W,)
+        avg, acc = np.empty((nsteps, 7)), np.empty((nsteps, 2))
+        tp, keep = None, []
+        if tapes is not None:
+            tp = _ffi.DmcTapes()
+            for name, _ in _ffi.DmcTapes._fields_:
+                a = tapes.get(name)
+                if a is not None:
+                    a = _ffi.f64(a)
+                    keep.append(a)
+                    setattr(tp, name, a.ctypes.data)
+        self.call("pqa_dmc_steps", float(tstep), int(nsteps), float(branchcut), float(e_trial), float(e_est), float(threshold),
+                  _ffi.ptr(weights), None if tp is None else C.addressof(tp), int(seed), _ffi.ptr(avg), _ffi.ptr(acc))
+        return avg, acc
+
     # measurement ----------------------------------------------------------
     def sync(self):
         self.call("pqa_sync")

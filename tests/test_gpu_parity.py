@@ -265,13 +265,60 @@ def test_dmc_propagate_golden():
     wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
     df, configs, weights = pa.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
                                             float(e_trial), float(e_est), nsteps=int(nsteps),
-                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g))
+                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g), fused=False)
     assert np.array_equal(np.asarray(accepts), g["accepts"])
     assert note("dmc_final", relerr(configs.configs, g["final"])) < 1e-9
     assert note("dmc_weights", relerr(weights, g["weights"])) < 1e-8
     assert set(df.keys()) == set(g["df_keys"].tolist())
     for k in df:
         assert note("dmc_" + k, relerr(df[k], g["df_" + k])) < 1e-8, k
+
+
+def test_fused_dmc_steps_golden():
+    """pqa_dmc_steps (the whole dmc_propagate step loop on the device: compacted T-move candidates, heat-bath selection,
+    Umrigar drift, fixed-node rejection, compute_S weights, weighted averages) replaying the reference's draws."""
+    import pyqmc_amd as pa
+
+    g = golden("g12_dmc")
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    df, configs, weights = pa.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+                                            float(e_trial), float(e_est), nsteps=int(nsteps),
+                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g))
+    assert note("fdmc_final", relerr(configs.configs, g["final"])) < 1e-9
+    assert note("fdmc_weights", relerr(weights, g["weights"])) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert note("fdmc_" + k, relerr(df[k], g["df_" + k])) < 1e-8, k
+    # the state left on the device is consistent: a fresh recompute gives the same values
+    ph0, v0 = wf.value()
+    ph1, v1 = wf.recompute(configs)
+    assert np.array_equal(ph0, ph1) and relerr(v0, v1) < 1e-10
+
+
+def test_fused_dmc_philox_statistics():
+    """Device-RNG mode of pqa_dmc_steps against the host-driven loop on independent draws: same population, same
+    trial function, so block energies, acceptance and T-move acceptance agree within the statistical error."""
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    W = 1024
+    start = pa.initial_guess(mol, W, rng=np.random.default_rng(5))
+    _, start = pa.vmc(wf, start, nblocks=1, nsteps_per_block=20, accumulators={})
+    acc = pa.EnergyAccumulator(mol)
+    wf.recompute(start)
+    e0 = acc(start, wf)["total"]
+    args = (0.02, 10 * e0.std(), e0.mean(), e0.mean())
+    np.random.seed(3)
+    a, ca, wa = pa.dmc_propagate(wf, OpenConfigs(start.configs.copy()), np.ones(W), *args, nsteps=6, accumulators={"energy": acc})
+    b, cb, wb = pa.dmc_propagate(wf, OpenConfigs(start.configs.copy()), np.ones(W), *args, nsteps=6, accumulators={"energy": acc}, fused=False)
+    err = 4 * e0.std() / np.sqrt(W)
+    assert abs(a["energytotal"] - b["energytotal"]) < err, (a["energytotal"], b["energytotal"], err)
+    assert abs(a["acceptance"] - b["acceptance"]) < 0.02 and abs(a["tmove_acceptance"] - b["tmove_acceptance"]) < 0.01
+    assert a["tmove_acceptance"] > 0 and 0.9 < a["weight"] / b["weight"] < 1.1
+    assert not np.array_equal(ca.configs, start.configs) and np.all(np.isfinite(wa))
 
 
 def test_rundmc_smoke():

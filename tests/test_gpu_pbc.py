@@ -187,8 +187,27 @@ def test_periodic_dmc_propagate_matches_reference():
     cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
     df, cfg, weights = pa.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
                                         nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
-                                        rng=helpers.ReplayTape(g))
+                                        rng=helpers.ReplayTape(g), fused=False)
     assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert helpers.relerr(cfg.configs, g["final"]) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
+    assert helpers.relerr(weights, g["weights"]) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert helpers.relerr(df[k], g["df_" + k]) < 1e-8, k
+
+
+def test_periodic_fused_dmc_steps_match_reference():
+    """pqa_dmc_steps on the periodic cell (T-move candidates folded into the cell, wrap counters, Ewald energies)."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g17_pbc_dmc")
+    sup, wf = helpers.gpu_pbc_wf("gamma")
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = pa.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                        nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                                        rng=helpers.ReplayTape(g))
     assert helpers.relerr(cfg.configs, g["final"]) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
     assert helpers.relerr(weights, g["weights"]) < 1e-8
     assert set(df.keys()) == set(g["df_keys"].tolist())

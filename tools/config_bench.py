@@ -1,0 +1,70 @@
+"""Throughput of the BASELINE.json configurations other than the headline one (synthetic tables, see pyqmc_amd.systems).
+
+    python tools/config_bench.py c3|c4|c5 [--walkers W] [--steps K]
+
+c3: diamond conventional cell (8 atoms, 32 e-) with a k-point twist, Slater-Jastrow VMC (complex wave-per-walker sweep)
+c4: H2O, 50 determinants x 2-body x 3-body Jastrow, VMC (wave-per-walker sweep)
+c5: diamond 2x2x2 supercell (64 e-, 8 k-points), DMC tstep = 0.02 (pqa_dmc_steps; --host: dmc_propagate over the protocol)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pyqmc_amd as pa  # noqa: E402
+from pyqmc_amd import pbc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config")
+ap.add_argument("--walkers", type=int, default=0)
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--host", action="store_true", help="c5: drive the DMC step from the host over the protocol entry points")
+a = ap.parse_args()
+prim = pa.systems.diamond_primitive()
+if a.config == "c3":
+    W = a.walkers or 8192
+    sup = pbc.get_supercell(prim, np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
+    mf = pbc.random_kmf(sup, complex_coeff=True, twist=(0.25, 0.1, -0.3))
+    wf = pa.generate_wf(sup, mf)
+    cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
+elif a.config == "c4":
+    W = a.walkers or 2048
+    mol = pa.systems.water()
+    mf = pa.systems.random_mf(mol, nvirt=8)
+    wf = pa.generate_wf(mol, mf, determinants=pa.systems.random_determinants(mol, mf, 50), jastrow3=True)
+    wf.parameters["wf3ccoeff"] = 0.05 * np.random.default_rng(2).standard_normal(wf.parameters["wf3ccoeff"].shape)
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(1))
+    sup = mol
+elif a.config == "c5":
+    W = a.walkers or 4096
+    sup = pbc.get_supercell(prim, 2.0 * np.eye(3))
+    wf = pa.generate_wf(sup, pbc.random_kmf(sup))
+    cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
+else:
+    raise SystemExit("config must be c3, c4 or c5")
+dev = wf.fused_device()
+wf.recompute(cfg)
+if a.config == "c5":
+    acc = {"energy": pa.EnergyAccumulator(sup)}
+    weights = np.ones(W)
+    pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=1, accumulators=acc, fused=not a.host)
+    t0 = time.perf_counter()
+    blk, cfg, weights = pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc, fused=not a.host)
+    dt = time.perf_counter() - t0
+    kind = "DMC (host-driven protocol path)" if a.host else "DMC (pqa_dmc_steps)"
+    extra = {k: float(np.real(blk[k])) for k in ("acceptance", "tmove_acceptance", "weight")}
+else:
+    dev.vmc_sweeps(0.3, 1, seed=1, energy=True)
+    dev.sync()
+    t0 = time.perf_counter()
+    dev.vmc_sweeps(0.3, a.steps, seed=2, energy=True)
+    dev.sync()
+    dt = time.perf_counter() - t0
+    kind = "VMC fused sweep + energy"
+    extra = {}
+print(json.dumps({"config": a.config, "kind": kind, "nelec": int(sum(sup.nelec)), "walkers": W, "steps": a.steps,
+                  "ms_per_step": 1e3 * dt / a.steps, "walker_steps_per_s": W * a.steps / dt, **extra}))
