@@ -1278,7 +1278,7 @@ static LwState lw_state(pqa_handle* h) {
 }
 
 // AoS (canonical, wave-per-walker kernels) -> SoA mirrors for the lane-per-walker kernels
-static int lw_from_aos(pqa_handle* h) {
+static int lw_from_aos(pqa_handle* h, bool with_cache = true) {
   const long W = h->W;
   const int nel[2] = {h->nup, h->ndn};
   TRY(ensure(h, h->b_xt, (size_t)W * h->N * 3 * sizeof(double)));
@@ -1290,7 +1290,7 @@ static int lw_from_aos(pqa_handle* h) {
     TRY(ensure(h, h->b_Tt[s], W * n * n * sizeof(double)));
     TRY(ensure(h, h->b_ct[s], W * n * 5 * h->nmo[s] * sizeof(double)));
     transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(n * n));
-    transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
+    if (with_cache) transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
   }
   return check_launch(h, "k_transpose");
 }
@@ -1475,6 +1475,108 @@ extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, 
   return copy_out(h, out, h->b_en.p, (size_t)(h->cplx ? 7 : 6) * h->W * sizeof(double));
 }
 
+// ---------------------------------------------------------------- one sweep over the electrons (shared by VMC and DMC)
+struct LwCtx {
+  int G = 1, Gm = 1, KB = 1, nmax = 1;
+};
+// Geometry of the lane-per-walker kernels and, when `lw`, the SoA copy of the state and its scratch.
+static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
+  const long W = h->W;
+  c.G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
+  while (c.G < 16 && (long)c.G * W < 2048L * 64) c.G *= 2;
+  c.Gm = 1;  // groups of the (latency-bound) partial-sum kernels: ~4 waves per SIMD
+  while (c.Gm < 16 && (long)c.Gm * W < 4096L * 64) c.Gm *= 2;
+  if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 32);
+  c.nmax = std::max(h->nup, h->ndn);
+  c.KB = (h->lw_kb > 0) ? std::min(h->lw_kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
+  if (lw) {
+    TRY(lw_from_aos(h));
+    TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 8 * W * sizeof(double)));
+    TRY(ensure(h, h->b_rbuf, (size_t)c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_vbuf, (size_t)c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_act, (size_t)c.KB * W));
+  }
+  return 0;
+}
+// One proposal per electron, in index order, on the SoA state (lw) or the AoS state; mb.dmc selects the DMC variant.
+static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) {
+  const long W = h->W;
+  const int N = h->N, G = lc.G, Gm = lc.Gm, KB = lc.KB, nmax = lc.nmax;
+  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  const LwState L = lw_state(h);
+  const dim3 gw((unsigned)((W + 63) / 64));
+  for (int e = 0; e < N; ++e) {
+    const int s = e >= h->nup;
+    const double* mo = (const double*)h->b_motmp.p;
+    if (lw) {
+      const dim3 gg(gw.x, (unsigned)G);
+      double* part = (double*)h->b_part.p;
+      const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
+      const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
+      double* rbuf = (double*)h->b_rbuf.p + (size_t)q * n_s * W;
+      double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
+      uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
+      const dim3 gm(gw.x, (unsigned)Gm);
+      if (h->S.pbc)
+        hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
+                           (const double*)nullptr, W, Gm, part);
+      else
+        hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
+                           (const double*)nullptr, W, Gm, part);
+      hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
+      TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+      if (h->S.pbc)
+        hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
+                           W, Gm, part);
+      else
+        hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
+                           W, Gm, part);
+      hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
+                         (const double*)part, rbuf, vbuf, act, mo);
+      const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
+      const dim3 gcm(gw.x, (unsigned)Gc);
+#define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
+                          else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
+      hipEvent_t ce1 = nullptr;
+      if (h->profile) {
+        if (h->prof2_used == h->prof2_events.size()) {
+          hipEvent_t a, b;
+          HIPCHK(hipEventCreate(&a));
+          HIPCHK(hipEventCreate(&b));
+          h->prof2_events.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
+        ce1 = h->prof2_events[h->prof2_used].second;
+        ++h->prof2_used;
+      }
+      if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
+#undef PQA_COMMIT
+      if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
+      if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
+        const int nq = j_hi - j_lo;
+#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
+        if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#undef PQA_FLUSH
+      }
+      continue;
+    }
+    if (h->cplx) {
+      hipLaunchKernelGGL(k_propose<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+                         (int)h->has_slater, (int)h->has_jastrow, W);
+      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+      hipLaunchKernelGGL(k_accept<true>, dim3((unsigned)W), dim3(64), 2 * lds_acc, h->stream, h->S, h->st, h->js, mb, e,
+                         (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+      continue;
+    }
+    hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
+                       (int)h->has_slater, (int)h->has_jastrow, W);
+    if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+    hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
+                       (int)h->has_jastrow, mo, W);
+  }
+  return 0;
+}
+
 extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif, double threshold,
                               const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
                               double* energy_mean, uint8_t* accept_rec) {
@@ -1504,25 +1606,10 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (gauss) TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
   if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
-  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
   const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && !h->cplx;
-  int G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
-  while (G < 16 && (long)G * W < 2048L * 64) G *= 2;
-  int Gm = 1;  // groups of the (latency-bound) partial-sum kernels: ~4 waves per SIMD
-  while (Gm < 16 && (long)Gm * W < 4096L * 64) Gm *= 2;
-  if (h->lw_gm > 0) Gm = std::min(h->lw_gm, 32);
-  const int nmax = std::max(h->nup, h->ndn);
-  const int KB = (h->lw_kb > 0) ? std::min(h->lw_kb, std::max(nmax, 1)) : std::max(nmax, 1);  // KB = n: plain per-move update
-  if (lw) {
-    TRY(lw_from_aos(h));
-    TRY(ensure(h, h->b_part, (size_t)std::max(G, Gm) * 8 * W * sizeof(double)));
-    TRY(ensure(h, h->b_rbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_vbuf, (size_t)KB * std::max(nmax, 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_act, (size_t)KB * W));
-  }
-  const LwState L = lw_state(h);
-  const dim3 gw((unsigned)((W + 63) / 64));
+  LwCtx lc;
+  TRY(lw_setup(h, lw, lc));
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
@@ -1537,75 +1624,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       mb.unif = (const double*)h->b_unif.p;
     }
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
-    for (int e = 0; e < N; ++e) {
-      const int s = e >= h->nup;
-      const double* mo = (const double*)h->b_motmp.p;
-      if (lw) {
-        const dim3 gg(gw.x, (unsigned)G);
-        double* part = (double*)h->b_part.p;
-        const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
-        const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
-        double* rbuf = (double*)h->b_rbuf.p + (size_t)q * n_s * W;
-        double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
-        uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
-        const dim3 gm(gw.x, (unsigned)Gm);
-        if (h->S.pbc)
-          hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
-                             (const double*)nullptr, W, Gm, part);
-        else
-          hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
-                             (const double*)nullptr, W, Gm, part);
-        hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
-        TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-        if (h->S.pbc)
-          hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
-                             W, Gm, part);
-        else
-          hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
-                             W, Gm, part);
-        hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
-                           (const double*)part, rbuf, vbuf, act, mo);
-        const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
-        const dim3 gcm(gw.x, (unsigned)Gc);
-#define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
-                            else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
-        hipEvent_t ce1 = nullptr;
-        if (h->profile) {
-          if (h->prof2_used == h->prof2_events.size()) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b));
-            h->prof2_events.emplace_back(a, b);
-          }
-          HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
-          ce1 = h->prof2_events[h->prof2_used].second;
-          ++h->prof2_used;
-        }
-        if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
-#undef PQA_COMMIT
-        if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
-        if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
-          const int nq = j_hi - j_lo;
-#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
-          if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
-#undef PQA_FLUSH
-        }
-        continue;
-      }
-      if (h->cplx) {
-        hipLaunchKernelGGL(k_propose<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
-                           (int)h->has_slater, (int)h->has_jastrow, W);
-        if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-        hipLaunchKernelGGL(k_accept<true>, dim3((unsigned)W), dim3(64), 2 * lds_acc, h->stream, h->S, h->st, h->js, mb, e,
-                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
-        continue;
-      }
-      hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
-                         (int)h->has_slater, (int)h->has_jastrow, W);
-      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-      hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
-                         (int)h->has_jastrow, mo, W);
-    }
+    TRY(sweep_electrons(h, mb, lw, lc));
     hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
@@ -1653,14 +1672,12 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   TRY(ensure(h, h->b_acccnt, (size_t)nsteps * 2 * sizeof(int)));
   TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo_max * sizeof(double)));
   TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
-  TRY(ensure(h, h->b_tmacc, (size_t)W * sizeof(int)));
   TRY(ensure(h, h->b_dmcw, (size_t)W * sizeof(double)));
   TRY(ensure(h, h->b_dmcold, (size_t)2 * W * sizeof(double)));
   TRY(ensure(h, h->b_dmcr2, (size_t)2 * W * sizeof(double)));
   TRY(ensure(h, h->b_dmcout, (size_t)nsteps * 7 * sizeof(double)));
   HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * 2 * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
-  HIPCHK(hipMemsetAsync(h->b_tmacc.p, 0, (size_t)W * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_dmcr2.p, 0, (size_t)2 * W * sizeof(double), h->stream));
   TRY(copy_in(h, h->b_dmcw.p, weights, (size_t)W * sizeof(double)));
   if (h->S.pbc) {
@@ -1676,18 +1693,23 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   const size_t nrot = (size_t)N * std::max(necp, 1);
   const int nkw = (std::max(necp, 1) + 63) / 64;
   if (tmoves) {
-    TRY(ensure(h, h->b_tmcnt, (size_t)W * sizeof(int)));
-    TRY(ensure(h, h->b_tmoff, (size_t)(W + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_tmpass, (size_t)W * nkw * sizeof(unsigned long long)));
-    TRY(ensure(h, h->b_tmidx, (size_t)(W + 1) * sizeof(int)));
-    TRY(ensure(h, h->b_tmapos, (size_t)W * 3 * sizeof(double)));
-    TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * W * sizeof(double)));
+    const size_t NW = (size_t)N * W;
+    TRY(ensure(h, h->b_tmcnt, NW * sizeof(int)));
+    TRY(ensure(h, h->b_tmoff, (NW + 1) * sizeof(long)));
+    TRY(ensure(h, h->b_tmpass, NW * nkw * sizeof(unsigned long long)));
+    TRY(ensure(h, h->b_tmacc, NW + 4 * sizeof(long)));
+    TRY(ensure(h, h->b_tmidx, (NW + 2) * sizeof(int)));
+    TRY(ensure(h, h->b_tmapos, NW * 3 * sizeof(double)));
+    if (tp) TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * NW * sizeof(double)));
     TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
   }
-  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3;
+  LwCtx lc;
+  TRY(lw_setup(h, lw, lc));
   const dim3 gw256((unsigned)((W + 255) / 256));
   double* eold = (double*)h->b_dmcold.p;
   double* r2 = (double*)h->b_dmcr2.p;
+  std::vector<long> tm_accepted((size_t)nsteps, 0);
   // energy of the starting configuration (dmc.py:146-149)
   TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
   hipLaunchKernelGGL(k_dmc_keep, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
@@ -1698,80 +1720,89 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     mb.dmc = 1; mb.r2_acc = r2; mb.r2_prop = r2 + W;
     if (h->S.pbc) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }
     if (tmoves) {
+      const size_t NW = (size_t)N * W;
       TmBuf B{};
       B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold;
       B.cnt = (int*)h->b_tmcnt.p; B.off = (long*)h->b_tmoff.p; B.pass = (unsigned long long*)h->b_tmpass.p;
-      B.tm_acc = (int*)h->b_tmacc.p; B.acc_idx = (int*)h->b_tmidx.p + 1; B.nacc = (int*)h->b_tmidx.p;
-      B.acc_pos = (double*)h->b_tmapos.p;
-      if (tp) TRY(copy_in(h, h->b_rot.p, tp->tm_rot + (size_t)step * nrot * 9, nrot * 9 * sizeof(double)));
-      else {
+      long* d_tot = (long*)h->b_tmacc.p;  // [2] totals, then the accept flags
+      B.acc = (uint8_t*)h->b_tmacc.p + 4 * sizeof(long);
+      B.nacc = (int*)h->b_tmidx.p; B.acc_idx = (int*)h->b_tmidx.p + 2; B.acc_pos = (double*)h->b_tmapos.p;
+      if (tp) {
+        double* u = (double*)h->b_tmu.p;
+        TRY(copy_in(h, h->b_rot.p, tp->tm_rot + (size_t)step * nrot * 9, nrot * 9 * sizeof(double)));
+        TRY(copy_in(h, u, tp->tm_u1 + (size_t)step * NW, NW * sizeof(double)));
+        TRY(copy_in(h, u + NW, tp->tm_u2 + (size_t)step * NW, NW * sizeof(double)));
+        TRY(copy_in(h, u + 2 * NW, tp->tm_unif + (size_t)step * NW * necp, NW * necp * sizeof(double)));
+        B.u1 = u; B.u2 = u + NW; B.unif = u + 2 * NW;
+      } else {
         hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed ^ 0x9E3779B97F4A7C15ull,
                            (uint32_t)step, (double*)h->b_rot.p);
         TRY(check_launch(h, "k_gen_rot"));
       }
-      for (int e = 0; e < N; ++e) {
-        const int s = e >= h->nup;
-        B.rot = (const double*)h->b_rot.p + (size_t)e * necp * 9;
-        if (tp) {
-          double* u = (double*)h->b_tmu.p;
-          TRY(copy_in(h, u, tp->tm_u1 + ((size_t)step * N + e) * W, (size_t)W * sizeof(double)));
-          TRY(copy_in(h, u + W, tp->tm_u2 + ((size_t)step * N + e) * W, (size_t)W * sizeof(double)));
-          TRY(copy_in(h, u + 2 * W, tp->tm_unif + ((size_t)step * N + e) * necp * W, (size_t)necp * W * sizeof(double)));
-          B.u1 = u; B.u2 = u + W; B.unif = u + 2 * W;
-        }
-        hipLaunchKernelGGL(k_tm_count, gw256, dim3(256), 0, h->stream, h->S, h->js, B, e, W);
-        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
-        TRY(check_launch(h, "k_tm_count/k_scan1"));
-        long tot = 0;
-        TRY(copy_out(h, &tot, B.off + W, sizeof(long)));
-        if (tot == 0) continue;  // nobody passed the mask: no walker moves (and no further draws are consumed in Philox mode)
-        TRY(ensure(h, h->b_tpos, (size_t)tot * 3 * sizeof(double)));
-        TRY(ensure(h, h->b_twgt, (size_t)tot * sizeof(double)));
-        TRY(ensure(h, h->b_tmamp, (size_t)tot * 2 * sizeof(double)));
-        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot;
-        hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, e, W);
+      B.rot = (const double*)h->b_rot.p;
+      HIPCHK(hipMemsetAsync(B.acc, 0, NW, h->stream));
+      hipLaunchKernelGGL(k_tm_count, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W);
+      hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, (long)NW, (long)NW, (long)h->nup * W, d_tot);
+      TRY(check_launch(h, "k_tm_count/k_scan1"));
+      long tot[2] = {0, 0};  // all candidates, spin-up candidates
+      TRY(copy_out(h, tot, d_tot, 2 * sizeof(long)));
+      if (tot[0] > 0) {
+        TRY(ensure(h, h->b_tpos, (size_t)tot[0] * 3 * sizeof(double)));
+        TRY(ensure(h, h->b_twgt, (size_t)tot[0] * sizeof(double)));
+        TRY(ensure(h, h->b_tmamp, (size_t)tot[0] * 2 * sizeof(double)));
+        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot[0];
+        hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W, (unsigned)N), dim3(64), 0, h->stream, h->S, h->js, B, W);
         TRY(check_launch(h, "k_tm_fill"));
-        if (h->has_slater) {
-          TRY(ensure(h, h->b_emo[0], (size_t)tot * nmo_max * sizeof(double)));
-          TRY(launch_orb(h, s, plain_points(B.pts, tot), tot, 1, (double*)h->b_emo[0].p));
+        const long cnt_s[2] = {tot[1], tot[0] - tot[1]}, base_s[2] = {0, tot[1]};
+        if (h->has_slater)
+          for (int s = 0; s < 2; ++s) {
+            if (cnt_s[s] == 0) continue;
+            TRY(ensure(h, h->b_emo[s], (size_t)cnt_s[s] * nmo_max * sizeof(double)));
+            TRY(launch_orb(h, s, plain_points(B.pts + 3 * base_s[s], cnt_s[s]), cnt_s[s], 1, (double*)h->b_emo[s].p));
+          }
+        const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
+        for (int e = 0; e < N; ++e) {
+          const int s = e >= h->nup;
+          if (cnt_s[s] == 0) continue;
+          hipLaunchKernelGGL(k_tm_select, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, e, (int)h->has_slater,
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, base_s[s], W);
         }
-        hipLaunchKernelGGL(k_tm_select, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, mb, e,
-                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, W);
-        hipLaunchKernelGGL(k_tm_compact, dim3(1), dim3(1024), 0, h->stream, B, mb, W);
+        hipLaunchKernelGGL(k_tm_compact, dim3(1), dim3(1024), 0, h->stream, B, (const double*)h->js.x, N, h->nup, W);
         TRY(check_launch(h, "k_tm_select/k_tm_compact"));
-        int nacc = 0;
-        TRY(copy_out(h, &nacc, B.nacc, sizeof(int)));
-        if (nacc == 0) continue;
-        if (h->has_slater) TRY(launch_orb(h, s, plain_points(B.acc_pos, nacc), nacc, 5, (double*)h->b_motmp.p));
-        hipLaunchKernelGGL(k_tm_commit, dim3((unsigned)nacc), dim3(64), lds_sm(h), h->stream, h->S, h->st, h->js, B, mb, e,
-                           (int)h->has_slater, (const double*)h->b_motmp.p);
-        TRY(check_launch(h, "k_tm_commit"));
+        int nacc[2] = {0, 0};
+        TRY(copy_out(h, nacc, B.nacc, 2 * sizeof(int)));
+        tm_accepted[step] = nacc[0];
+        if (h->has_slater) {  // gradient / Laplacian rows of the moved electrons, one launch per spin
+          const long na_s[2] = {nacc[1], nacc[0] - nacc[1]}, a0_s[2] = {0, nacc[1]};
+          for (int s = 0; s < 2; ++s) {
+            if (na_s[s] == 0) continue;
+            TRY(ensure(h, h->b_emo[s], (size_t)na_s[s] * 5 * nmo_max * sizeof(double)));
+            TRY(launch_orb(h, s, plain_points(B.acc_pos + 3 * a0_s[s], na_s[s]), na_s[s], 5, (double*)h->b_emo[s].p));
+            hipLaunchKernelGGL(k_tm_cache, dim3((unsigned)na_s[s]), dim3(64), 0, h->stream, h->S, h->st, (const int*)(B.acc_idx + a0_s[s]),
+                               (const double*)h->b_emo[s].p, s, W, lw ? (double*)h->b_ct[s].p : (double*)nullptr);
+          }
+          TRY(check_launch(h, "k_tm_cache"));
+        }
       }
-      hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_tmacc.p, W, (int*)h->b_acccnt.p + 2 * step + 1);
     }
     if (tp) {
       TRY(copy_in(h, h->b_gauss.p, tp->gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
       TRY(copy_in(h, h->b_unif.p, tp->unif + (size_t)step * N * W, (size_t)N * W * sizeof(double)));
       mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
     }
-    for (int e = 0; e < N; ++e) {
-      const int s = e >= h->nup;
-      hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
-                         (int)h->has_slater, (int)h->has_jastrow, W);
-      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-      hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
-                         (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
-    }
+    if (lw && tmoves) TRY(lw_from_aos(h, false));  // the T-moves worked on the AoS coordinates and inverses
+    TRY(sweep_electrons(h, mb, lw, lc));
     hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + 2 * step);
     TRY(check_launch(h, "k_propose/k_accept (dmc)"));
     TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot + (size_t)(step + 1) * nrot * 9 : nullptr,
-                   (tp && necp) ? tp->ecp_unif + (size_t)(step + 1) * nrot * W : nullptr, seed, (uint32_t)(step + 1), false));
+                   (tp && necp) ? tp->ecp_unif + (size_t)(step + 1) * nrot * W : nullptr, seed, (uint32_t)(step + 1), lw));
     hipLaunchKernelGGL(k_dmc_weights, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
                        (double*)h->b_dmcw.p, tstep, branchcut, e_trial, e_est, N, W);
     hipLaunchKernelGGL(k_dmc_averages, dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
                        (double*)h->b_dmcout.p + (size_t)step * 7);
     TRY(check_launch(h, "k_dmc_weights/k_dmc_averages"));
   }
+  if (lw) TRY(lw_to_aos(h, true));
   h->jas_stale = h->has_j2;
   std::vector<int> cnt((size_t)nsteps * 2);
   TRY(copy_in(h, step_avg, h->b_dmcout.p, (size_t)nsteps * 7 * sizeof(double)));
@@ -1779,7 +1810,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, cnt.size() * sizeof(int)));
   for (int i = 0; i < nsteps; ++i) {
     step_acc[2 * i] = (double)cnt[2 * i] / ((double)W * N);
-    step_acc[2 * i + 1] = (double)cnt[2 * i + 1] / ((double)W * N);
+    step_acc[2 * i + 1] = (double)tm_accepted[i] / ((double)W * N);
   }
   return 0;
 }

@@ -8,7 +8,9 @@
 // The kernels here are (1) and (3).  Unlike the host-driven pqa_tmoves (dense [W][P] candidate table, kept for the
 // protocol-level API) the fused path compacts the candidates of the walkers that pass the stochastic ECP mask, the same
 // count -> scan -> fill -> orbitals -> ratio pipeline as the energy's ECP term: dead candidates carry weight 0 and can never
-// be the first crossing of the cumulative distribution, so leaving them out selects the same move.
+// be the first crossing of the cumulative distribution, so leaving them out selects the same move.  The orbital
+// evaluation is batched over all electrons of the step (two launches per spin and step instead of two per electron:
+// a launch over a few hundred points costs the kernel's ~0.2-0.3 ms latency floor whatever its size).
 #pragma once
 #include "pqa_energy.hpp"
 #include "pqa_vmc.hpp"
@@ -18,30 +20,35 @@
 #define PQA_STREAM_TM_U2 8u
 
 struct TmBuf {
-  const double* rot;    // [necp][3][3] rotations of this electron's quadrature grids
-  const double* unif;   // [necp][W] mask uniforms of this electron or NULL -> Philox
-  const double* u1;     // [W] selection uniforms or NULL
-  const double* u2;     // [W] acceptance uniforms or NULL
+  const double* rot;    // [N][necp][3][3] rotations of the quadrature grids of this step
+  const double* unif;   // [N][necp][W] mask uniforms or NULL -> Philox
+  const double* u1;     // [N][W] selection uniforms or NULL
+  const double* u2;     // [N][W] acceptance uniforms or NULL
   const double* quad;   // [6+12][3]
   uint64_t seed;
   uint32_t step;
   double tau, threshold;
-  int* cnt;             // [W] live candidates of the walker
-  long* off;            // [W+1] exclusive scan of cnt
-  unsigned long long* pass;  // [W][ceil(necp/64)] ECP atoms whose mask the walker passed
+  int* cnt;             // [N][W] live candidates of (electron, walker)
+  long* off;            // [N*W+1] exclusive scan of cnt: electron-major, so one spin's candidates are contiguous
+  unsigned long long* pass;  // [N][W][ceil(necp/64)] ECP atoms whose mask the (electron, walker) passed
   double* pts;          // [ncand][3]
   double* wgt;          // [ncand] sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i
   double* amp;          // [ncand] ratio * weight
   double* rat;          // [ncand] Psi(candidate)/Psi
-  int* tm_acc;          // [W] accepted T-moves of the walker in this step
-  int* nacc;            // [1] accepted walkers of this electron
-  int* acc_idx;         // [W] their indices, ascending
-  double* acc_pos;      // [W][3] their new positions
+  uint8_t* acc;         // [N][W] accepted T-moves of this step
+  int* nacc;            // [2] accepted (electron, walker) pairs: all, spin-up
+  int* acc_idx;         // [N*W] their indices e*W + w, ascending (spin-up first)
+  double* acc_pos;      // [N*W][3] their new positions
 };
 
-// pass A: which ECP atoms pass the mask for electron e of each walker, and how many candidates that makes
-__global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, int e, long W) {
+// pass A: which ECP atoms pass the mask for electron e of each walker, and how many candidates that makes.
+// The candidates of ALL electrons are laid out before the sequential T-move loop starts: electron e has not moved
+// when its turn comes, and the mask / rotation draws do not depend on the state, so positions, weights and orbital
+// values are those the reference computes one electron at a time (dmc.py:160-168); only the ratios need the loop.
+// grid = (ceil(W/256), N), block = 256.
+__global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y;
   if (w >= W) return;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmB
       int nch;
       ecp_radial(S, k, r, B.threshold, v, nch, prob);
       double u;
-      if (B.unif) u = B.unif[(size_t)k * W + w];
+      if (B.unif) u = B.unif[((size_t)e * S.necp + k) * W + w];
       else {
         const Philox p = philox(B.seed, (uint32_t)w, (uint32_t)(e * S.necp + k), PQA_STREAM_TMMASK, B.step);
         u = u01(p.c[0], p.c[1]);
@@ -68,16 +75,18 @@ __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmB
         c += (nch <= 2) ? 6 : 12;
       }
     }
-    B.pass[(size_t)w * nkw + kw] = m;
+    B.pass[((size_t)e * W + w) * nkw + kw] = m;
   }
-  B.cnt[w] = c;
+  B.cnt[(size_t)e * W + w] = c;
 }
 
-// exclusive scan of cnt[W] -> off[W+1]; one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan1(const int* __restrict__ c, long* __restrict__ o, long W) {
+// exclusive scan of cnt[n] -> off[n+1]; one block of 1024 threads.  marks[0..nmark): indices whose offsets are copied
+// to out (the totals the host needs), so one small read-back serves the launch geometry.
+__global__ __launch_bounds__(1024) void k_scan1(const int* __restrict__ c, long* __restrict__ o, long n, long mark0, long mark1,
+                                                long* __restrict__ out) {
   __shared__ long part[1024];
-  const long per = (W + 1023) / 1024;
-  const long b = (long)threadIdx.x * per, e = (b + per < W) ? b + per : W;
+  const long per = (n + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
   long sum = 0;
   for (long i = b; i < e; ++i) sum += c[i];
   part[threadIdx.x] = sum;
@@ -85,25 +94,33 @@ __global__ __launch_bounds__(1024) void k_scan1(const int* __restrict__ c, long*
   if (threadIdx.x == 0) {
     long run = 0;
     for (int t = 0; t < 1024; ++t) { const long v = part[t]; part[t] = run; run += v; }
-    o[W] = run;
+    o[n] = run;
+    if (mark0 == n) out[0] = run;
+    if (mark1 == n) out[1] = run;
   }
   __syncthreads();
   long run = part[threadIdx.x];
-  for (long i = b; i < e; ++i) { o[i] = run; run += c[i]; }
+  for (long i = b; i < e; ++i) {
+    o[i] = run;
+    if (i == mark0) out[0] = run;
+    if (i == mark1) out[1] = run;
+    run += c[i];
+  }
 }
 
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
-// grid = W, block = 64.
-__global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, int e, long W) {
+// grid = (W, N), block = 64.
+__global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = blockIdx.x;
+  const int e = blockIdx.y;
   const int lane = threadIdx.x;
-  if (B.cnt[w] == 0) return;
+  if (B.cnt[(size_t)e * W + w] == 0) return;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
   const int nkw = (S.necp + 63) / 64;
-  long run = B.off[w];
+  long run = B.off[(size_t)e * W + w];
   for (int kw = 0; kw < nkw; ++kw) {
-    unsigned long long m = B.pass[(size_t)w * nkw + kw];
+    unsigned long long m = B.pass[((size_t)e * W + w) * nkw + kw];
     while (m) {
       const int k = kw * 64 + __ffsll((long long)m) - 1;
       m &= m - 1;
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
       const int naip = (nch <= 2) ? 6 : 12;
       if (lane < naip) {
         const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
-        const double* R = B.rot + (size_t)k * 9;
+        const double* R = B.rot + ((size_t)e * S.necp + k) * 9;
         const double vx = R[0] * qd[0] + R[1] * qd[1] + R[2] * qd[2];
         const double vy = R[3] * qd[0] + R[4] * qd[1] + R[5] * qd[2];
         const double vz = R[6] * qd[0] + R[7] * qd[1] + R[8] * qd[2];
@@ -135,26 +152,26 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
   }
 }
 
-// ratios at the walker's candidates, then the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120:
+// The sequential part of the T-move of electron e: ratios at the walker's candidates against the CURRENT inverse and
+// Jastrow state, the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120,
 //   fwd_q = max(ratio_q weight_q, 0), norm = 1 + sum fwd, move q chosen with probability fwd_q / norm (else stay);
 //   backward amplitudes seen from the chosen point: ratio_q weight_q / ratio_sel for the other candidates and
-//   weight_sel / ratio_sel for the way back; accept with probability norm / back_norm.
-// mo: [ncand][nmo_s] orbital values at the candidates.  Writes newpos / dwrap / accept for every walker.
-// grid = W, block = 64, LDS like k_tmove_ratio.
-__global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, JastrowState js, TmBuf B, MoveBuf mb, int e,
-                                                  int has_slater, int has_jastrow, const double* __restrict__ mo, long W) {
+//   weight_sel / ratio_sel for the way back; accept with probability norm / back_norm,
+// and, for an accepted move, the commit (updateinternals with mask, dmc.py:167-168): Sherman-Morrison update with the
+// candidate's orbital VALUE row (already evaluated) and the coordinate.  The gradient / Laplacian rows of the cache are
+// refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
+// mo: [ncand of this spin][nmo_s] orbital values, p_base: first candidate of this spin.  grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, JastrowState js, TmBuf B, int e, int has_slater,
+                                                  int has_jastrow, const double* __restrict__ mo, long p_base, long W) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   const int s = e >= S.nup, nmo = S.nmo[s];
-  const double* xw = js.x + (size_t)w * S.nelec * 3;
-  const long p0 = B.off[w], p1 = B.off[w + 1];
+  double* xw = js.x + (size_t)w * S.nelec * 3;
+  const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
   const int n = (int)(p1 - p0);
   if (n == 0) {
-    if (lane == 0) {
-      mb.accept[w] = 0;
-      mb.newpos[3 * w] = xw[3 * e]; mb.newpos[3 * w + 1] = xw[3 * e + 1]; mb.newpos[3 * w + 2] = xw[3 * e + 2];
-    }
+    if (lane == 0) B.acc[(size_t)e * W + w] = 0;
     return;
   }
   double U0 = 0.0, g[3], lp;
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, Jast
     double rat = 1.0;
     if (has_slater) {
       double r1[1];
-      slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)p * nmo, r1, lds);
+      slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
       rat = r1[0];
     }
     if (has_jastrow) {
@@ -173,90 +190,95 @@ __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, Jast
     }
     if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
   }
-  if (lane != 0) return;
-  double norm = 1.0;
-  for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
-  double u1, u2;
-  if (B.u1) { u1 = B.u1[w]; u2 = B.u2[w]; }
-  else {
-    const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
-    const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
-    u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
+  int sel = n, acc = 0;
+  if (lane == 0) {
+    double norm = 1.0;
+    for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
+    double u1, u2;
+    if (B.u1) { u1 = B.u1[(size_t)e * W + w]; u2 = B.u2[(size_t)e * W + w]; }
+    else {
+      const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
+      const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
+      u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
+    }
+    sel = 0;
+    double cdf = 0.0;
+    for (long p = p0; p < p1; ++p) {
+      cdf += fmax(B.amp[p], 0.0) / norm;
+      if (cdf < u1) ++sel;
+    }
+    if (sel < n) {
+      const double rr = 1.0 / B.rat[p0 + sel];
+      double back = 1.0;
+      for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
+      acc = norm / back > u2;
+    }
+    B.acc[(size_t)e * W + w] = (uint8_t)acc;
   }
-  int sel = 0;
-  double cdf = 0.0;
-  for (long p = p0; p < p1; ++p) {
-    cdf += fmax(B.amp[p], 0.0) / norm;
-    if (cdf < u1) ++sel;
-  }
-  bool acc = false;
-  double nx = xw[3 * e], ny = xw[3 * e + 1], nz = xw[3 * e + 2];
-  if (sel < n) {
-    const double rr = 1.0 / B.rat[p0 + sel];
-    double back = 1.0;
-    for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
-    acc = norm / back > u2;
-    nx = B.pts[3 * (p0 + sel)]; ny = B.pts[3 * (p0 + sel) + 1]; nz = B.pts[3 * (p0 + sel) + 2];
-  }
-  if (mb.dwrap) {
+  acc = __shfl(acc, 0, 64);
+  sel = __shfl(sel, 0, 64);
+  if (!acc) return;
+  __syncthreads();
+  if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
+  if (lane == 0) {
     // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
     // folded coordinates (dmc.py:100), so the reference's wrap counters do not see a T-move across the cell boundary;
     // identical results means the same here: fold, and leave the counters alone.
+    double nx = B.pts[3 * (p0 + sel)], ny = B.pts[3 * (p0 + sel) + 1], nz = B.pts[3 * (p0 + sel) + 2];
     fold_cell(S, nx, ny, nz);
-    mb.dwrap[3 * w] = 0; mb.dwrap[3 * w + 1] = 0; mb.dwrap[3 * w + 2] = 0;
+    xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz;
   }
-  mb.newpos[3 * w] = nx; mb.newpos[3 * w + 1] = ny; mb.newpos[3 * w + 2] = nz;
-  mb.accept[w] = acc;
 }
 
-// ascending list of the walkers whose T-move was accepted, with their new positions; one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_tm_compact(TmBuf B, MoveBuf mb, long W) {
+// ascending list of the (electron, walker) pairs whose T-move was accepted in this step, with their (new) positions;
+// nacc[0] = all, nacc[1] = spin-up pairs (index < nup*W).  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_tm_compact(TmBuf B, const double* __restrict__ x, int nelec, int nup, long W) {
   __shared__ int part[1024];
-  const long per = (W + 1023) / 1024;
-  const long b = (long)threadIdx.x * per, e = (b + per < W) ? b + per : W;
+  const long n = (long)nelec * W, nu = (long)nup * W;
+  const long per = (n + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
   int c = 0;
-  for (long i = b; i < e; ++i) c += mb.accept[i] ? 1 : 0;
+  for (long i = b; i < e; ++i) c += B.acc[i] ? 1 : 0;
   part[threadIdx.x] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
     for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
-    *B.nacc = run;
+    B.nacc[0] = run;
+    B.nacc[1] = run;  // overwritten below by the thread that crosses into spin-down, if any
   }
   __syncthreads();
   int run = part[threadIdx.x];
-  for (long i = b; i < e; ++i)
-    if (mb.accept[i]) {
+  for (long i = b; i < e; ++i) {
+    if (i == nu) B.nacc[1] = run;
+    if (B.acc[i]) {
+      const long el = i / W, w = i - el * W;
+      const double* xe = x + ((size_t)w * nelec + el) * 3;
       B.acc_idx[run] = (int)i;
-      B.acc_pos[3 * run] = mb.newpos[3 * i]; B.acc_pos[3 * run + 1] = mb.newpos[3 * i + 1]; B.acc_pos[3 * run + 2] = mb.newpos[3 * i + 2];
-      B.tm_acc[i] += 1;
+      B.acc_pos[3 * run] = xe[0]; B.acc_pos[3 * run + 1] = xe[1]; B.acc_pos[3 * run + 2] = xe[2];
       ++run;
     }
+  }
 }
 
-// commit of the accepted T-moves: Sherman-Morrison update, orbital-row cache, coordinates and wrap counters
-// (updateinternals with mask, dmc.py:167-168).  mo5: [nacc][5][nmo_s] rows at the new positions.  grid = nacc, block = 64.
-__global__ __launch_bounds__(64) void k_tm_commit(SysDev S, SlaterState st, JastrowState js, TmBuf B, MoveBuf mb, int e, int has_slater,
-                                                  const double* __restrict__ mo5) {
-  extern __shared__ double lds[];
+// orbital-row cache (value, gradient, Laplacian) of the accepted T-moves of one spin.  mo5: [count][5][nmo_s] rows at the
+// new positions, idx: the matching (e*W + w) entries.  ct: the walker-fastest copy [n][5 nmo][W] of the lane-per-walker
+// sweep when that holds the live cache, else NULL (st.cache).  grid = count, block = 64.
+__global__ __launch_bounds__(64) void k_tm_cache(SysDev S, SlaterState st, const int* __restrict__ idx, const double* __restrict__ mo5,
+                                                 int s, long W, double* __restrict__ ct) {
   const long a = blockIdx.x;
-  const long w = B.acc_idx[a];
-  const int lane = threadIdx.x;
-  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  if (has_slater) {
-    const double* row = mo5 + (size_t)a * 5 * nmo;
-    sm_update_wave(S, st, s, i, w, row, lds);
-    double* c = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
-    for (int k = lane; k < 5 * nmo; k += 64) c[k] = row[k];
+  const long i = idx[a];
+  const int e = (int)(i / W);
+  const long w = i - (long)e * W;
+  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const double* row = mo5 + (size_t)a * 5 * nmo;
+  if (ct) {
+    double* c = ct + (size_t)(e - s * S.nup) * 5 * nmo * W + w;
+    for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[(size_t)k * W] = row[k];
+    return;
   }
-  if (lane == 0) {
-    double* x = js.x + (size_t)w * S.nelec * 3 + 3 * e;
-    x[0] = B.acc_pos[3 * a]; x[1] = B.acc_pos[3 * a + 1]; x[2] = B.acc_pos[3 * a + 2];
-    if (mb.wrap) {
-      int* wr = mb.wrap + ((size_t)w * S.nelec + e) * 3;
-      wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
-    }
-  }
+  double* c = st.cache[s] + ((size_t)w * n + (e - s * S.nup)) * 5 * nmo;
+  for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[k] = row[k];
 }
 
 // ---------------------------------------------------------------- weights and averages

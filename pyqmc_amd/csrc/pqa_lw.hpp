@@ -168,7 +168,8 @@ __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, Move
   double v[8];
   lw_sum_parts(part, W, w, G, v);
   double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
-  limdrift3(gx, gy, gz);
+  if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (dmc.py:50-52)
+  else limdrift3(gx, gy, gz);
   double z0, z1, z2, z3;
   if (mb.gauss) {
     const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
@@ -181,9 +182,10 @@ __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, Move
   z0 *= sq; z1 *= sq; z2 *= sq;
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double* np_ = mb.newpos + 3 * w;
-  np_[0] = xe[0] + z0 + gx * mb.tstep;
-  np_[1] = xe[W] + z1 + gy * mb.tstep;
-  np_[2] = xe[2 * W] + z2 + gz * mb.tstep;
+  const double df = mb.dmc ? 1.0 : mb.tstep;
+  np_[0] = xe[0] + z0 + gx * df;
+  np_[1] = xe[W] + z1 + gy * df;
+  np_[2] = xe[2 * W] + z2 + gz * df;
   if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
   double* a = L.auxt + w;
   a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[4];
@@ -204,13 +206,23 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   const double* a = L.auxt + w;
   double val = finite_or(v[0], 1.0);
   if (has_jastrow) val *= exp(v[4] - a[6 * W]);
-  limdrift3(gx, gy, gz);
   const double a0 = a[0], a1 = a[W], a2 = a[2 * W];
   const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
-  const double bx = a0 + mb.tstep * (a[3 * W] + gx), by = a1 + mb.tstep * (a[4 * W] + gy), bz = a2 + mb.tstep * (a[5 * W] + gz);
+  double bx, by, bz;
+  if (mb.dmc) {  // dmc.py:57-60: backward = gauss + drift(old) + drift(new)
+    limdrift_dmc(gx, gy, gz, mb.tstep);
+    bx = a0 + a[3 * W] + gx; by = a1 + a[4 * W] + gy; bz = a2 + a[5 * W] + gz;
+  } else {
+    limdrift3(gx, gy, gz);
+    bx = a0 + mb.tstep * (a[3 * W] + gx); by = a1 + mb.tstep * (a[4 * W] + gy); bz = a2 + mb.tstep * (a[5 * W] + gz);
+  }
   const double bwd = bx * bx + by * by + bz * bz;
   const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
-  const double ratio = val * val * t_prob;
+  double ratio = val * val * t_prob;
+  if (mb.dmc) {
+    const double dv = finite_or(v[0], 1.0);  // the Jastrow ratio is positive: np.sign(psi_ratio) is the determinant's
+    ratio *= (dv > 0.0) ? 1.0 : ((dv < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
+  }
   double u;
   if (mb.unif) u = mb.unif[(size_t)e * W + w];
   else {
@@ -218,6 +230,12 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
     u = u01(p.c[0], p.c[1]);
   }
   const bool acc = ratio > u;
+  if (mb.dmc) {  // dmc.py:68 r2 = |gauss + drift|^2
+    const double rx = a0 + a[3 * W], ry = a1 + a[4 * W], rz = a2 + a[5 * W];
+    const double r2 = rx * rx + ry * ry + rz * rz;
+    mb.r2_prop[w] += r2;
+    if (acc) mb.r2_acc[w] += r2;
+  }
   mb.accept[w] = acc;
   act[w] = acc;
   if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
