@@ -74,7 +74,7 @@ struct pqa_handle {
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
-  DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
+  DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_tmtile, b_tmaoff, b_tmptw, b_tmmarks, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
@@ -553,7 +553,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1648,6 +1648,17 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   return 0;
 }
 
+// device-wide exclusive scan c[n] -> o[n+1]; marks[k] = o[k*Wm] for k = 0..n/Wm (pqa_dmc.hpp)
+static int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks) {
+  const long nt = (n + 1023) / 1024;
+  TRY(ensure(h, h->b_tmtile, (size_t)(nt + 1) * sizeof(long)));
+  long* tile = (long*)h->b_tmtile.p;
+  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nt), dim3(1024), 0, h->stream, c, o, n, tile);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, tile, nt);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nt), dim3(1024), 0, h->stream, o, n, (const long*)tile, nt, Wm, marks);
+  return check_launch(h, "k_scan_local/tiles/add");
+}
+
 // ---------------------------------------------------------------- fused DMC propagation
 // nsteps steps of dmc_propagate (pyqmc/method/dmc.py:123-221) without leaving the device: T-moves, drift-diffusion with
 // fixed-node rejection, local energy, weight update, weighted step averages.  Walker-per-wave kernels (the AoS state).
@@ -1697,8 +1708,10 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     TRY(ensure(h, h->b_tmcnt, NW * sizeof(int)));
     TRY(ensure(h, h->b_tmoff, (NW + 1) * sizeof(long)));
     TRY(ensure(h, h->b_tmpass, NW * nkw * sizeof(unsigned long long)));
-    TRY(ensure(h, h->b_tmacc, NW + 4 * sizeof(long)));
-    TRY(ensure(h, h->b_tmidx, (NW + 2) * sizeof(int)));
+    TRY(ensure(h, h->b_tmacc, NW * sizeof(int)));
+    TRY(ensure(h, h->b_tmaoff, (NW + 1) * sizeof(long)));
+    TRY(ensure(h, h->b_tmmarks, (size_t)(N + 1) * sizeof(long)));
+    TRY(ensure(h, h->b_tmidx, NW * sizeof(int)));
     TRY(ensure(h, h->b_tmapos, NW * 3 * sizeof(double)));
     if (tp) TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * NW * sizeof(double)));
     TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
@@ -1724,9 +1737,9 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
       TmBuf B{};
       B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold;
       B.cnt = (int*)h->b_tmcnt.p; B.off = (long*)h->b_tmoff.p; B.pass = (unsigned long long*)h->b_tmpass.p;
-      long* d_tot = (long*)h->b_tmacc.p;  // [2] totals, then the accept flags
-      B.acc = (uint8_t*)h->b_tmacc.p + 4 * sizeof(long);
-      B.nacc = (int*)h->b_tmidx.p; B.acc_idx = (int*)h->b_tmidx.p + 2; B.acc_pos = (double*)h->b_tmapos.p;
+      long* d_marks = (long*)h->b_tmmarks.p;
+      B.acc = (int*)h->b_tmacc.p; B.acc_off = (long*)h->b_tmaoff.p;
+      B.acc_idx = (int*)h->b_tmidx.p; B.acc_pos = (double*)h->b_tmapos.p;
       if (tp) {
         double* u = (double*)h->b_tmu.p;
         TRY(copy_in(h, h->b_rot.p, tp->tm_rot + (size_t)step * nrot * 9, nrot * 9 * sizeof(double)));
@@ -1740,20 +1753,23 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
         TRY(check_launch(h, "k_gen_rot"));
       }
       B.rot = (const double*)h->b_rot.p;
-      HIPCHK(hipMemsetAsync(B.acc, 0, NW, h->stream));
+      HIPCHK(hipMemsetAsync(B.acc, 0, NW * sizeof(int), h->stream));
       hipLaunchKernelGGL(k_tm_count, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W);
-      hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, (long)NW, (long)NW, (long)h->nup * W, d_tot);
-      TRY(check_launch(h, "k_tm_count/k_scan1"));
-      long tot[2] = {0, 0};  // all candidates, spin-up candidates
-      TRY(copy_out(h, tot, d_tot, 2 * sizeof(long)));
-      if (tot[0] > 0) {
-        TRY(ensure(h, h->b_tpos, (size_t)tot[0] * 3 * sizeof(double)));
-        TRY(ensure(h, h->b_twgt, (size_t)tot[0] * sizeof(double)));
-        TRY(ensure(h, h->b_tmamp, (size_t)tot[0] * 2 * sizeof(double)));
-        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot[0];
+      TRY(check_launch(h, "k_tm_count"));
+      TRY(scan_ints(h, (const int*)B.cnt, B.off, (long)NW, W, d_marks));
+      std::vector<long> eoff((size_t)N + 1);  // first candidate of every electron
+      TRY(copy_out(h, eoff.data(), d_marks, eoff.size() * sizeof(long)));
+      const long tot = eoff[N], tot_up = eoff[h->nup];
+      if (tot > 0) {
+        TRY(ensure(h, h->b_tpos, (size_t)tot * 3 * sizeof(double)));
+        TRY(ensure(h, h->b_twgt, (size_t)tot * sizeof(double)));
+        TRY(ensure(h, h->b_tmamp, (size_t)tot * 2 * sizeof(double)));
+        TRY(ensure(h, h->b_tmptw, (size_t)tot * sizeof(int)));
+        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot;
+        B.ptw = (int*)h->b_tmptw.p;
         hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W, (unsigned)N), dim3(64), 0, h->stream, h->S, h->js, B, W);
         TRY(check_launch(h, "k_tm_fill"));
-        const long cnt_s[2] = {tot[1], tot[0] - tot[1]}, base_s[2] = {0, tot[1]};
+        const long cnt_s[2] = {tot_up, tot - tot_up}, base_s[2] = {0, tot_up};
         if (h->has_slater)
           for (int s = 0; s < 2; ++s) {
             if (cnt_s[s] == 0) continue;
@@ -1763,14 +1779,19 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
         for (int e = 0; e < N; ++e) {
           const int s = e >= h->nup;
-          if (cnt_s[s] == 0) continue;
+          const long ne = eoff[e + 1] - eoff[e];
+          if (ne == 0) continue;
+          hipLaunchKernelGGL(k_tm_ratio, dim3((unsigned)ne), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, e, (int)h->has_slater,
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, base_s[s], eoff[e]);
           hipLaunchKernelGGL(k_tm_select, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, e, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, base_s[s], W);
+                             (const double*)h->b_emo[s].p, base_s[s], W);
         }
-        hipLaunchKernelGGL(k_tm_compact, dim3(1), dim3(1024), 0, h->stream, B, (const double*)h->js.x, N, h->nup, W);
-        TRY(check_launch(h, "k_tm_select/k_tm_compact"));
-        int nacc[2] = {0, 0};
-        TRY(copy_out(h, nacc, B.nacc, 2 * sizeof(int)));
+        TRY(check_launch(h, "k_tm_ratio/k_tm_select"));
+        TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
+        hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
+        TRY(check_launch(h, "k_tm_gather"));
+        TRY(copy_out(h, eoff.data(), d_marks, eoff.size() * sizeof(long)));
+        const long nacc[2] = {eoff[N], eoff[h->nup]};
         tm_accepted[step] = nacc[0];
         if (h->has_slater) {  // gradient / Laplacian rows of the moved electrons, one launch per spin
           const long na_s[2] = {nacc[1], nacc[0] - nacc[1]}, a0_s[2] = {0, nacc[1]};

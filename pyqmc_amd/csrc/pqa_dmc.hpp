@@ -35,8 +35,9 @@ struct TmBuf {
   double* wgt;          // [ncand] sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i
   double* amp;          // [ncand] ratio * weight
   double* rat;          // [ncand] Psi(candidate)/Psi
-  uint8_t* acc;         // [N][W] accepted T-moves of this step
-  int* nacc;            // [2] accepted (electron, walker) pairs: all, spin-up
+  int* ptw;             // [ncand] walker of the candidate
+  int* acc;             // [N][W] accepted T-moves of this step (0/1)
+  long* acc_off;        // [N*W+1] exclusive scan of acc
   int* acc_idx;         // [N*W] their indices e*W + w, ascending (spin-up first)
   double* acc_pos;      // [N*W][3] their new positions
 };
@@ -80,32 +81,57 @@ __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmB
   B.cnt[(size_t)e * W + w] = c;
 }
 
-// exclusive scan of cnt[n] -> off[n+1]; one block of 1024 threads.  marks[0..nmark): indices whose offsets are copied
-// to out (the totals the host needs), so one small read-back serves the launch geometry.
-__global__ __launch_bounds__(1024) void k_scan1(const int* __restrict__ c, long* __restrict__ o, long n, long mark0, long mark1,
-                                                long* __restrict__ out) {
+// Device-wide exclusive scan of c[n] -> o[n+1] in three small launches (a single block walking a million counters costs
+// ~2 ms; this is ~20 us): k_scan_local scans 1024-element tiles and emits tile totals, k_scan_tiles scans those (one block),
+// k_scan_add adds the tile offsets and copies o[k*W] (k = 0..n/W) to marks[] — the per-electron totals the host reads back
+// in one small copy to size the launches.
+__global__ __launch_bounds__(1024) void k_scan_local(const int* __restrict__ c, long* __restrict__ o, long n, long* __restrict__ tile_sum) {
+  __shared__ long wsum[16];
+  const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long v = (i < n) ? c[i] : 0;
+  long x = v;  // inclusive scan within the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wv] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long run = 0;
+    for (int t = 0; t < 16; ++t) { const long y = wsum[t]; wsum[t] = run; run += y; }
+    tile_sum[blockIdx.x] = run;
+  }
+  __syncthreads();
+  if (i < n) o[i] = wsum[wv] + x - v;
+}
+__global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long nt) {  // in place, t[nt] = total
   __shared__ long part[1024];
-  const long per = (n + 1023) / 1024;
-  const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
+  const long per = (nt + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < nt) ? b + per : nt;
   long sum = 0;
-  for (long i = b; i < e; ++i) sum += c[i];
+  for (long i = b; i < e; ++i) sum += t[i];
   part[threadIdx.x] = sum;
   __syncthreads();
   if (threadIdx.x == 0) {
     long run = 0;
-    for (int t = 0; t < 1024; ++t) { const long v = part[t]; part[t] = run; run += v; }
-    o[n] = run;
-    if (mark0 == n) out[0] = run;
-    if (mark1 == n) out[1] = run;
+    for (int k = 0; k < 1024; ++k) { const long v = part[k]; part[k] = run; run += v; }
+    t[nt] = run;
   }
   __syncthreads();
   long run = part[threadIdx.x];
-  for (long i = b; i < e; ++i) {
-    o[i] = run;
-    if (i == mark0) out[0] = run;
-    if (i == mark1) out[1] = run;
-    run += c[i];
+  for (long i = b; i < e; ++i) { const long v = t[i]; t[i] = run; run += v; }
+}
+__global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, long n, const long* __restrict__ tile_off, long nt, long W,
+                                                   long* __restrict__ marks) {
+  const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+  if (i < n) {
+    const long v = o[i] + tile_off[blockIdx.x];
+    o[i] = v;
+    if (i % W == 0) marks[i / W] = v;
   }
+  if (i == 0) { o[n] = tile_off[nt]; marks[n / W] = tile_off[nt]; }
 }
 
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
@@ -146,23 +172,49 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
         double* p = B.pts + 3 * (size_t)(run + lane);
         p[0] = (ex - dx) + rix; p[1] = (ey - dy) + riy; p[2] = (ez - dz) + riz;
         B.wgt[run + lane] = wt;
+        B.ptw[run + lane] = (int)w;
       }
       run += naip;
     }
   }
 }
 
-// The sequential part of the T-move of electron e: ratios at the walker's candidates against the CURRENT inverse and
-// Jastrow state, the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120,
+// The sequential part of the T-move of electron e, first half: ratios at the candidates against the CURRENT inverse and
+// Jastrow state, one wave per candidate (a walker's 6-24 candidates in parallel instead of in a loop).
+// mo: [ncand of this spin][nmo_s] orbital values, p_base: first candidate of this spin, pe0: first candidate of electron e.
+// grid = candidates of electron e, block = 64.
+__global__ __launch_bounds__(64) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int e, int has_slater,
+                                                 int has_jastrow, const double* __restrict__ mo, long p_base, long pe0) {
+  extern __shared__ double lds[];
+  const long p = pe0 + blockIdx.x;
+  const long w = B.ptw[p];
+  const int s = e >= S.nup, nmo = S.nmo[s];
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  double rat = 1.0;
+  if (has_slater) {
+    double r1[1];
+    slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
+    rat = r1[0];
+  }
+  if (has_jastrow) {
+    double U0, U, g[3], lp;
+    jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
+    jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
+    rat *= exp(U - U0);
+  }
+  if (threadIdx.x == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
+}
+
+// Second half: the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120,
 //   fwd_q = max(ratio_q weight_q, 0), norm = 1 + sum fwd, move q chosen with probability fwd_q / norm (else stay);
 //   backward amplitudes seen from the chosen point: ratio_q weight_q / ratio_sel for the other candidates and
 //   weight_sel / ratio_sel for the way back; accept with probability norm / back_norm,
 // and, for an accepted move, the commit (updateinternals with mask, dmc.py:167-168): Sherman-Morrison update with the
 // candidate's orbital VALUE row (already evaluated) and the coordinate.  The gradient / Laplacian rows of the cache are
 // refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
-// mo: [ncand of this spin][nmo_s] orbital values, p_base: first candidate of this spin.  grid = W, block = 64.
+// grid = W, block = 64.
 __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, JastrowState js, TmBuf B, int e, int has_slater,
-                                                  int has_jastrow, const double* __restrict__ mo, long p_base, long W) {
+                                                  const double* __restrict__ mo, long p_base, long W) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
@@ -170,26 +222,7 @@ __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, Jast
   double* xw = js.x + (size_t)w * S.nelec * 3;
   const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
   const int n = (int)(p1 - p0);
-  if (n == 0) {
-    if (lane == 0) B.acc[(size_t)e * W + w] = 0;
-    return;
-  }
-  double U0 = 0.0, g[3], lp;
-  if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
-  for (long p = p0; p < p1; ++p) {
-    double rat = 1.0;
-    if (has_slater) {
-      double r1[1];
-      slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
-      rat = r1[0];
-    }
-    if (has_jastrow) {
-      double U;
-      jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
-      rat *= exp(U - U0);
-    }
-    if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
-  }
+  if (n == 0) return;  // acc was cleared for the whole step
   int sel = n, acc = 0;
   if (lane == 0) {
     double norm = 1.0;
@@ -213,12 +246,11 @@ __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, Jast
       for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
       acc = norm / back > u2;
     }
-    B.acc[(size_t)e * W + w] = (uint8_t)acc;
+    B.acc[(size_t)e * W + w] = acc;
   }
   acc = __shfl(acc, 0, 64);
   sel = __shfl(sel, 0, 64);
   if (!acc) return;
-  __syncthreads();
   if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
   if (lane == 0) {
     // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
@@ -230,35 +262,15 @@ __global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, Jast
   }
 }
 
-// ascending list of the (electron, walker) pairs whose T-move was accepted in this step, with their (new) positions;
-// nacc[0] = all, nacc[1] = spin-up pairs (index < nup*W).  One block of 1024 threads.
-__global__ __launch_bounds__(1024) void k_tm_compact(TmBuf B, const double* __restrict__ x, int nelec, int nup, long W) {
-  __shared__ int part[1024];
-  const long n = (long)nelec * W, nu = (long)nup * W;
-  const long per = (n + 1023) / 1024;
-  const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
-  int c = 0;
-  for (long i = b; i < e; ++i) c += B.acc[i] ? 1 : 0;
-  part[threadIdx.x] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
-    B.nacc[0] = run;
-    B.nacc[1] = run;  // overwritten below by the thread that crosses into spin-down, if any
-  }
-  __syncthreads();
-  int run = part[threadIdx.x];
-  for (long i = b; i < e; ++i) {
-    if (i == nu) B.nacc[1] = run;
-    if (B.acc[i]) {
-      const long el = i / W, w = i - el * W;
-      const double* xe = x + ((size_t)w * nelec + el) * 3;
-      B.acc_idx[run] = (int)i;
-      B.acc_pos[3 * run] = xe[0]; B.acc_pos[3 * run + 1] = xe[1]; B.acc_pos[3 * run + 2] = xe[2];
-      ++run;
-    }
-  }
+// ascending list of the (electron, walker) pairs whose T-move was accepted in this step, with their (new) positions:
+// entry acc_off[i] of the list for every flagged i = e*W + w.  grid = ceil(N*W/256), block = 256.
+__global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __restrict__ x, int nelec, long W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)nelec * W || !B.acc[i]) return;
+  const long el = i / W, w = i - el * W, a = B.acc_off[i];
+  const double* xe = x + ((size_t)w * nelec + el) * 3;
+  B.acc_idx[a] = (int)i;
+  B.acc_pos[3 * a] = xe[0]; B.acc_pos[3 * a + 1] = xe[1]; B.acc_pos[3 * a + 2] = xe[2];
 }
 
 // orbital-row cache (value, gradient, Laplacian) of the accepted T-moves of one spin.  mo5: [count][5][nmo_s] rows at the
