@@ -125,9 +125,6 @@ def _record_tapes(rng, nsteps, N, necp, W, tmoves):
     return t
 
 
-_fused_calls = [0]
-
-
 def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, acc, name, rng):
     """``dmc_propagate`` through ``pqa_dmc_steps``: the whole step loop stays on the device."""
     from .energy import KEYS
@@ -139,10 +136,11 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     if dev.pbc:
         dev.set_ewald(**acc._ewald_kws)
     tapes = None if rng is None else _record_tapes(rng, nsteps, N, necp, W, tmoves)
-    _fused_calls[0] += 1
     w = np.ascontiguousarray(weights, dtype=np.float64)
+    # like vmc_worker: the device Philox streams are keyed by a seed drawn from numpy's global generator, so
+    # numpy.random.seed() controls reproducibility and ranks that seed numpy differently get independent streams
     avg, stat = dev.dmc_steps(tstep, nsteps, w, branchcut, e_trial, e_est, threshold=acc.threshold, tapes=tapes,
-                              seed=acc.seed + 7919 * _fused_calls[0])
+                              seed=int(np.random.randint(0, 2**31 - 1)))
     weights[:] = w
     configs.configs[...] = dev.configs()
     if dev.pbc:

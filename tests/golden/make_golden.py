@@ -1042,7 +1042,109 @@ def g_dmc():
     save("g12_dmc", **out)
 
 
+# ------------------------------------------------------------------ G21 parameter-gradient accumulators (SR)
+def h2o_multidet_wf():
+    """The 12-determinant H2O Slater x two-body x three-body wave function of g_testvalue_many."""
+    import pyqmc.wftools as wftools
+
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = systems.random_determinants(mol, mf, 12)
+    wf, _ = pyq.generate_wf(mol, mf, jastrow=[pyq.generate_jastrow, wftools.generate_jastrow3], jastrow_kws=[{}, {}],
+                            slater_kws=dict(evaluate_orbitals_with="numba", determinants=dets))
+    rng = np.random.default_rng(11)
+    j2, j3 = wf.wf_factors[1], wf.wf_factors[2]
+    j2.parameters["acoeff"] = 0.05 * rng.standard_normal(j2.parameters["acoeff"].shape)
+    b = 0.05 * rng.standard_normal(j2.parameters["bcoeff"].shape)
+    b[0] = [-0.25, -0.5, -0.25]
+    j2.parameters["bcoeff"] = b
+    j3.parameters["ccoeff"] = 0.1 * np.random.default_rng(12).standard_normal(j3.parameters["ccoeff"].shape)
+    return mol, wf
+
+
+def sr_to_opt(parameters, seed=21):
+    """A partial optimisation mask: first determinant coefficient and the cusp row frozen, random subsets elsewhere."""
+    rng = np.random.default_rng(seed)
+    to_opt = {}
+    for k, v in parameters.items():
+        m = rng.random(np.shape(v)) > (0.9 if np.size(v) > 100 else 0.4)
+        if k.endswith("det_coeff"):
+            m[:] = True
+            m[0] = False
+        if k.endswith("bcoeff"):
+            m[0] = False
+        if k.endswith("mo_coeff_beta"):
+            m[:] = False  # a key that drops out entirely
+        to_opt[k] = m
+    return to_opt
+
+
+def g_sr():
+    """LinearTransform (accumulators.py:98-185) and StochasticReconfiguration (stochastic_reconfiguration.py:49-176) on the
+    multi-determinant H2O wave function.  The energy accumulator is replaced by recorded arrays (the ECP energy draws a
+    random quadrature rotation), with two walkers inside the nodal cut-off."""
+    from pyqmc.observables.accumulators import LinearTransform
+    from pyqmc.observables.stochastic_reconfiguration import StochasticReconfiguration
+
+    mol, wf = h2o_multidet_wf()
+    W = 6
+    configs = walkers(mol, W, 81)
+    wf.recompute(configs)
+    rng = np.random.default_rng(210)
+    en = {"total": -17.0 + rng.standard_normal(W), "grad2": np.abs(rng.standard_normal(W)) * 40 + 5.0, "ke": rng.standard_normal(W)}
+    en["grad2"][1], en["grad2"][4] = 3.0e6, 2.5e7
+
+    class Recorded:
+        def __call__(self, configs, wf):
+            return {k: v.copy() for k, v in en.items()}
+
+        def keys(self):
+            return set(en)
+
+        def shapes(self):
+            return {k: () for k in en}
+
+    to_opt = sr_to_opt(wf.parameters)
+    tr = LinearTransform(wf.parameters, to_opt)
+    sr = StochasticReconfiguration(Recorded(), tr, nodal_cutoff=1e-3, eps=1e-2)
+    out = {"configs": configs.configs.copy(), "en_keys": np.asarray(sorted(en)), "opt_keys": np.asarray(list(to_opt.keys()))}
+    for k, m in to_opt.items():
+        out["opt_" + k] = m
+    for k, v in en.items():
+        out["en_" + k] = v
+    out["nparams"] = np.asarray(tr.nparams)
+    out["ser_params"] = tr.serialize_parameters(wf.parameters)
+    out["ser_grads"] = np.asarray(tr.serialize_gradients(wf.pgradient()))
+    d = sr(configs, wf)
+    for k in ("dpH", "dppsi", "dpidpj"):
+        out["call_" + k] = np.asarray(d[k])
+    weights = np.abs(1.0 + 0.3 * rng.standard_normal(W))
+    out["weights"] = weights
+    for tag, wts in (("avg", None), ("wavg", weights)):
+        d = sr.avg(configs, wf, weights=wts)
+        out[tag + "_keys"] = np.asarray(sorted(d))
+        for k, v in d.items():
+            out[tag + "_" + k] = np.asarray(v)
+    data = sr.avg(configs, wf, weights=weights)
+    for strat in ("pseudo_inverse", "regularized_inverse"):
+        sr.inverse_strategy = strat
+        dp, report = sr.delta_p([0.1, 0.25], data)
+        out["dp_" + strat] = np.asarray(dp)
+        out["report_" + strat] = np.asarray([report["pgrad"], report["SRdot"]])
+    x = tr.serialize_parameters(wf.parameters) + 0.01 * rng.standard_normal(tr.nparams)
+    out["deser_x"] = x
+    new = tr.deserialize(wf, x)
+    out["deser_keys"] = np.asarray(sorted(new))
+    for k, v in new.items():
+        out["deser_" + k] = np.asarray(v)
+    save("g21_sr", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g_sherman_morrison()
     g_ao()
     g_func3d()
@@ -1058,3 +1160,4 @@ if __name__ == "__main__":
     g_testvalue_many()
     g_pbc_complex()
     g_pbc_twist()
+    g_sr()

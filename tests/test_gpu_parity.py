@@ -474,3 +474,11 @@ def test_testvalue_many_golden():
     epos = cfg.make_irreducible(0, g["pbc_aux"])
     for nm, w in (("slater", pwf.wf_factors[0]), ("j2", pwf.wf_factors[1]), ("wf", pwf)):
         assert note("tvmany_pbc_" + nm, relerr(w.testvalue_many(g["pbc_es"], epos), g[f"pbc_{nm}"])) < 2e-9, nm
+
+
+def test_sr_golden():
+    """StochasticReconfiguration / LinearTransform (stochastic_reconfiguration.py:49-176, accumulators.py:98-185) over
+    pgradient() from the HIP kernels: serialised gradients, per-walker and averaged moments, SR step, deserialisation."""
+    from test_accumulators_cpu import check_sr_against_golden, h2o_multidet
+
+    check_sr_against_golden(h2o_multidet(helpers.gpu_wf3), golden("g21_sr"), 1e-9, note)
