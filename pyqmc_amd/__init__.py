@@ -13,6 +13,8 @@ from .func3d import CutoffCuspFunction, PolyPadeFunction, default_jastrow_basis 
 from .systems import initial_guess  # noqa: F401
 from .vmc import vmc, vmc_worker  # noqa: F401
 from .wf import DeviceWF, JastrowSpin, MultiplyWF, Slater, ThreeBodyJastrow, generate_wf  # noqa: F401
+from . import obdm  # noqa: F401
 from .accumulators import LinearTransform, PGradTransform, StochasticReconfiguration  # noqa: F401
+from .obdm import OBDMAccumulator  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1140,6 +1140,40 @@ def g_sr():
     save("g21_sr", **out)
 
 
+# ------------------------------------------------------------------ G22 one-body density matrix accumulator
+def g_obdm():
+    """OBDMAccumulator (obdm.py:26-213) on the H2O Slater-Jastrow wave function and on the 12-determinant one, with
+    numpy.random seeded: two successive evaluations (the auxiliary walkers carry over) and an average."""
+    import pyqmc.observables.obdm as refobdm
+    from pyqmc.wf.orbitals import MoleculeOrbitalEvaluator
+
+    out = {}
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=6)
+    dets = systems.random_determinants(mol, mf, 12)
+    cases = {"sj": make_wf(mol, systems.random_mf(mol)), "md": make_wf(mol, mf, determinants=dets)}
+    orb = np.asarray(mf.mo_coeff)[:, :7] if np.ndim(mf.mo_coeff) == 2 else np.asarray(mf.mo_coeff[0])[:, :7]
+    out["orb_coeff"] = orb
+    W = 7
+    for tag, wf in cases.items():
+        configs = walkers(mol, W, 61)
+        out[tag + "_configs"] = configs.configs.copy()
+        wf.recompute(configs)
+        for sub, kw in (("up", dict(spin=0)), ("some", dict(electrons=np.array([1, 5, 6]), naux=10)), ("all", dict())):
+            acc = refobdm.OBDMAccumulator(mol, orb, nsweeps=3, tstep=0.4, warmup=6, **kw)
+            acc.orbitals = MoleculeOrbitalEvaluator(mol, [orb, orb], evaluate_orbitals_with="numba")
+            np.random.seed(220 + len(out))
+            out[f"{tag}_{sub}_seed"] = np.asarray(220 + len(out))
+            for call in (0, 1):
+                d = acc(configs, wf)
+                out[f"{tag}_{sub}_value{call}"], out[f"{tag}_{sub}_norm{call}"] = d["value"], d["norm"]
+            d = acc.avg(configs, wf)
+            out[f"{tag}_{sub}_avg_value"], out[f"{tag}_{sub}_avg_norm"] = d["value"], d["norm"]
+            out[f"{tag}_{sub}_aux_final"] = acc._extra_config.configs.copy()
+    out["normalized"] = refobdm.normalize_obdm(out["sj_all_avg_value"], out["sj_all_avg_norm"])
+    save("g22_obdm", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1161,3 +1195,4 @@ if __name__ == "__main__":
     g_pbc_complex()
     g_pbc_twist()
     g_sr()
+    g_obdm()

@@ -482,3 +482,20 @@ def test_sr_golden():
     from test_accumulators_cpu import check_sr_against_golden, h2o_multidet
 
     check_sr_against_golden(h2o_multidet(helpers.gpu_wf3), golden("g21_sr"), 1e-9, note)
+
+
+def test_obdm_golden():
+    """OBDMAccumulator (obdm.py:26-213): basis orbitals from a coefficient-only device handle (pqa_eval_mo -> k_orb),
+    Psi(R')/Psi(R) from k_testvalue_many, the reference's seeded numpy draws; single- and multi-determinant H2O."""
+    import pyqmc_amd as pa
+    from test_obdm_cpu import check_obdm_against_golden, h2o_wfs
+
+    g = golden("g22_obdm")
+    mol, wfs = h2o_wfs(helpers.gpu_wf)
+    orb = g["orb_coeff"]
+    ev = pa.obdm.OrbitalEvaluator(mol, orb)
+    pts = np.random.default_rng(0).standard_normal((33, 3)) * 2
+    from oracle import gto
+
+    assert note("obdm_orbitals", relerr(ev.mos(pts), gto.eval_ao(gto.AOTable(mol), pts, 1)[0] @ orb)) < 1e-12
+    check_obdm_against_golden(wfs, g, lambda kw: pa.obdm.OBDMAccumulator(mol, orb, nsweeps=3, tstep=0.4, warmup=6, **kw), 1e-8, note)

@@ -385,3 +385,31 @@ def test_twisted_energy_and_vmc_match_reference(fused, monkeypatch):
     assert helpers.relerr(logv, g["vmc_final_log"]) < 1e-9 and helpers.relerr(sign, g["vmc_final_sign"]) < 1e-8
     for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
         assert helpers.relerr(blk[k], g[f"vmc_blk_{k}"]) < 1e-8, k
+
+
+def test_periodic_obdm_orbitals_and_accumulator():
+    """obdm.OrbitalEvaluator with k-points (the role of PBCOrbitalEvaluatorKpoints in obdm.py:85-91): the folded
+    coefficient-only handle reproduces the oracle's Bloch orbitals at points inside and outside the cell, and the
+    accumulator runs on a periodic wave function (auxiliary walkers folded by make_irreducible, testvalue_many over
+    minimal images) with its invariants: norm >= 0 summing to norb, Hermitian-symmetric expectation within noise."""
+    import pyqmc_amd as pa
+    from oracle import pbc as opbc
+
+    sup, wf = helpers.gpu_pbc_wf("fcc2cubic")
+    _, kmf = helpers.pbc_slater_case("fcc2cubic")
+    kpts = np.asarray(kmf.kpts)
+    orb = [np.asarray(kmf.mo_coeff[0][k])[:, :3] for k in range(len(kpts))]
+    ev = pa.obdm.OrbitalEvaluator(sup, orb, kpts=kpts)
+    assert ev.norb == 3 * len(kpts) and ev.mo_dtype is float
+    pts = (np.random.default_rng(4).random((40, 3)) * 3 - 1) @ sup.lattice_vectors()
+    ref = opbc.PeriodicOrbitals(sup, kpts, [orb, orb], golden("g15_pbc_orbitals")["fcc2cubic_Ls"])
+    assert helpers.relerr(ev.mos(pts), ref.mos(ref.aos(pts, 1), 0)[0]) < 1e-9
+    np.random.seed(9)
+    cfg = pa.initial_guess(sup, 24, rng=np.random.default_rng(2))
+    wf.recompute(cfg)
+    acc = pa.OBDMAccumulator(sup, orb, kpts=kpts, nsweeps=2, warmup=4, spin=0)
+    d = acc(cfg, wf)
+    assert d["value"].shape == (24, ev.norb, ev.norb) and d["norm"].shape == (24, ev.norb)
+    assert np.all(d["norm"] >= 0) and np.allclose(d["norm"].sum(axis=1), ev.norb) and np.all(np.isfinite(d["value"]))
+    frac = acc._extra_config.configs @ np.linalg.inv(sup.lattice_vectors())
+    assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12  # the auxiliary walkers live in the cell
