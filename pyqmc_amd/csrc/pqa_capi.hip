@@ -85,6 +85,8 @@ struct pqa_handle {
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
+  struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
+  TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
   int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
   int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
@@ -644,12 +646,30 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   ChunkTab T = h->tab[tabi];
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
-  // 32-point tiles: twice the blocks, and the 8 lane groups halve each thread's share of a chunk's lattice sums — the
-  // periodic launch is a latency chain per block rather than a throughput problem (measured on the 2x2x2 diamond
-  // supercell: 28.5 -> 21.9 ms/step at 1024 walkers, 107.5 -> 100.0 at 32768, 213.5 -> 197.5 at 65536; PQA_ORB_TP=64
-  // restores the wide tile)
+  // Tile width.  32-point tiles: twice the blocks, and the 8 lane groups halve each thread's share of a chunk's lattice
+  // sums; 64-point tiles: half the B-operand and table traffic per point.  Which wins depends on cell and launch size
+  // (2x2x2 diamond supercell, 16 atoms: 32 wins at every size, 28.5 -> 21.9 ms/step at 1024 walkers, 107.5 -> 100.0 at
+  // 32768; 8-atom cubic cell: 32 wins up to 16384 points, 64 wins by 14 % at 32768), both give bit-identical rows, so
+  // large launches time each twice per size class (four stream synchronisations in the handle's lifetime per class) and
+  // keep the faster; small ones take 32.  PQA_ORB_TP pins it.
   int tp = 32;
+  pqa_handle::TpTune* tune = nullptr;
+  int tune_slot = -1;
+  hipEvent_t te0 = nullptr, te1 = nullptr;
   if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
+  else if (P >= 16384) {
+    int b = 0;
+    while ((2L << b) <= P && b < 46) ++b;
+    tune = &h->tp_tune[tabi & 1][b];
+    if (tune->choice) tp = tune->choice;
+    else {
+      tune_slot = tune->n[0] <= tune->n[1] ? 0 : 1;  // alternate; best of two samples each
+      tp = tune_slot ? 64 : 32;
+      HIPCHK(hipEventCreate(&te0));
+      HIPCHK(hipEventCreate(&te1));
+      HIPCHK(hipEventRecord(te0, h->stream));
+    }
+  }
   const dim3 grid((unsigned)((P + tp - 1) / tp)), block(256);
   // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
   // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
@@ -663,6 +683,16 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     default: if (lt) PQA_ORB_PBC(4, true); else PQA_ORB_PBC(4, false); break;
   }
 #undef PQA_ORB_PBC2
+  if (tune_slot >= 0) {
+    HIPCHK(hipEventRecord(te1, h->stream));
+    HIPCHK(hipEventSynchronize(te1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, te0, te1));
+    HIPCHK(hipEventDestroy(te0));
+    HIPCHK(hipEventDestroy(te1));
+    tune->ms[tune_slot] = std::min(tune->ms[tune_slot], ms);
+    if (++tune->n[tune_slot] >= 2 && tune->n[1 - tune_slot] >= 2) tune->choice = tune->ms[1] < tune->ms[0] ? 64 : 32;
+  }
 #undef PQA_ORB_PBC
   if (h->twist) {
     const long nel = P * NCOMP * (h->nmo[spin] / 2);

@@ -413,3 +413,19 @@ def test_periodic_obdm_orbitals_and_accumulator():
     assert np.all(d["norm"] >= 0) and np.allclose(d["norm"].sum(axis=1), ev.norb) and np.all(np.isfinite(d["value"]))
     frac = acc._extra_config.configs @ np.linalg.inv(sup.lattice_vectors())
     assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12  # the auxiliary walkers live in the cell
+
+
+def test_periodic_orbital_tile_widths_are_bitwise_identical(monkeypatch):
+    """The periodic k_orb picks its point-tile width (32 / 64) by timing both on large launches; that is only legitimate
+    because the two instantiations produce the same bits (same chunk composition => same MFMA accumulation order)."""
+    import pyqmc_amd as pa
+
+    sup, mf = helpers.pbc_slater_case("fcc2cubic")
+    pts = (np.random.default_rng(8).random((700, 3)) * 3 - 1) @ sup.lattice_vectors()
+    rows = {}
+    for tp in ("32", "64"):
+        monkeypatch.setenv("PQA_ORB_TP", tp)
+        dev = pa.generate_wf(sup, mf).fused_device()
+        rows[tp] = [dev.eval_mo(0, pts, nc) for nc in (1, 5)]
+    for a, b in zip(rows["32"], rows["64"]):
+        assert np.array_equal(a, b)
