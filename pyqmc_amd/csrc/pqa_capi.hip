@@ -103,6 +103,8 @@ struct pqa_handle {
   long prof2_launches = 0;
   double prof2_ms = 0.0;
   size_t prof_used = 0;
+  unsigned prof_tick = 0, prof2_tick = 0;  // the event pairs bracket every 4th eligible launch (PQA_PROF_STRIDE)
+  unsigned prof_stride = 4;
   long prof_launches = 0;
   double prof_ms = 0.0, prof_pc = 0.0;
 };
@@ -314,6 +316,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   global memory, PQA_LW 0 wave-per-walker sweep, PQA_LW_KB k blocked Sherman-Morrison, PQA_LW_GM g partial-sum
   //   groups, PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
+  if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
   if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
@@ -711,7 +714,9 @@ static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P
 static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
   if (P <= 0 || h->nmo[spin] == 0) return 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool prof = h->profile && ncomp == 5;  // account the dominant (move) launches only
+  // account the dominant (move) launches only, and only a 1-in-prof_stride sample of them: an event pair costs ~2 us of
+  // stream time, 512 pairs per step were 1.2 ms of a 27 ms step
+  const bool prof = h->profile && ncomp == 5 && (h->prof_tick++ % h->prof_stride) == 0;
   if (prof) {
     if (h->prof_used == h->prof_events.size()) {
       hipEvent_t a, b;
@@ -1576,7 +1581,7 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
 #define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
                           else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
       hipEvent_t ce1 = nullptr;
-      if (h->profile) {
+      if (h->profile && (h->prof2_tick++ % h->prof_stride) == 0) {
         if (h->prof2_used == h->prof2_events.size()) {
           hipEvent_t a, b;
           HIPCHK(hipEventCreate(&a));
