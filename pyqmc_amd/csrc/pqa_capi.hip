@@ -19,6 +19,7 @@
 #include "pqa_jastrow.hpp"
 #include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
+#include "pqa_tile.hpp"
 #include "pqa_vmc.hpp"
 
 static thread_local std::string g_create_error;
@@ -89,7 +90,8 @@ struct pqa_handle {
   TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
   int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
-  int lw_mode = 1;  // lane-per-walker fused sweep (single determinant); PQA_LW=0 selects the wave-per-walker kernels
+  int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
+  bool tile_attr_set = false;
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
   int saved_e = -1;
@@ -1523,6 +1525,42 @@ extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, 
   return copy_out(h, out, h->b_en.p, (size_t)(h->cplx ? 7 : 6) * h->W * sizeof(double));
 }
 
+// ---------------------------------------------------------------- walker-tile sweep (pqa_tile.hpp)
+static bool tile_eligible(const pqa_handle* h) {
+  if (h->lw_mode != 2 || !h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc) return false;
+  if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32) return false;
+  const int nmo_pad = 16 * std::max(h->nt[0], h->nt[1]);
+  return tile_lds_bytes(h->N, nmo_pad, h->nshell, (int)h->S.nprim) <= 160 * 1024 - 512;
+}
+// One sweep over all electrons for every walker, in one launch.  mb carries the step's tapes / seeds as for the other paths.
+static int sweep_tile(pqa_handle* h, const MoveBuf& mb) {
+  const ChunkHost& c = h->chunks[0];
+  TileTab TT{};
+  TT.nmo_pad = 16 * std::max(h->nt[0], h->nt[1]);
+  TT.pass_chunk[0] = 0;
+  const int nch = (int)c.nk.size();
+  int ch = 0;
+  while (ch < nch) {  // greedy: consecutive chunks while their padded rows fit the LDS tile
+    if (TT.npass == PQA_TILE_MAXPASS) FAIL("walker-tile sweep: too many AO passes for this basis");
+    const int base = c.row0[ch];
+    int end = ch;
+    while (end < nch && c.row0[end] + ((c.nk[end] + 3) & ~3) - base <= PQA_TILE_KT) ++end;
+    if (end == ch) FAIL("walker-tile sweep: a chunk does not fit the AO tile");
+    ch = end;
+    TT.pass_chunk[++TT.npass] = ch;
+  }
+  const size_t lds = tile_lds_bytes(h->N, TT.nmo_pad, h->nshell, (int)h->S.nprim);
+  const dim3 grid((unsigned)((h->W + PQA_TILE_NW - 1) / PQA_TILE_NW)), block(1024);
+  if (!h->tile_attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    h->tile_attr_set = true;
+  }
+  if (mb.dmc) hipLaunchKernelGGL(k_sweep_tile<true>, grid, block, lds, h->stream, h->S, h->st, h->js, mb, h->tab[0], TT, (int)h->has_jastrow, h->W);
+  else hipLaunchKernelGGL(k_sweep_tile<false>, grid, block, lds, h->stream, h->S, h->st, h->js, mb, h->tab[0], TT, (int)h->has_jastrow, h->W);
+  return check_launch(h, "k_sweep_tile");
+}
+
 // ---------------------------------------------------------------- one sweep over the electrons (shared by VMC and DMC)
 struct LwCtx {
   int G = 1, Gm = 1, KB = 1, nmax = 1;
@@ -1655,7 +1693,8 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
-  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && !h->cplx;
+  const bool tile = tile_eligible(h);
+  const bool lw = !tile && h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && !h->cplx;
   LwCtx lc;
   TRY(lw_setup(h, lw, lc));
   for (int step = 0; step < nsteps; ++step) {
@@ -1672,7 +1711,8 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       mb.unif = (const double*)h->b_unif.p;
     }
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
-    TRY(sweep_electrons(h, mb, lw, lc));
+    if (tile) TRY(sweep_tile(h, mb));
+    else TRY(sweep_electrons(h, mb, lw, lc));
     hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));

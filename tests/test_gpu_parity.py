@@ -383,19 +383,22 @@ def test_lane_and_wave_per_walker_sweeps_agree(monkeypatch):
     mf = systems.random_mf(mol)
     start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
     res = []
-    for lw in ("1", "0"):
+    for lw in ("1", "0", "2"):  # lane-per-walker, wave-per-walker, walker-tile (one launch per sweep, state on chip)
         monkeypatch.setenv("PQA_LW", lw)
         wf = helpers.gpu_wf(mol, mf)
         dev = wf.fused_device()
         wf.recompute(OpenConfigs(start.copy()))
-        acc, en, rec = dev.vmc_sweeps(0.3, 1, seed=77, energy=True, record=True)
-        res.append((dev.configs(), dev.value()[1], en, rec, dev.recompute(dev.configs())[1]))
-    same = res[0][3] == res[1][3]
-    assert same.mean() > 0.9999  # a decision can only flip on a ~1e-13 near-tie
-    ok = same.all(axis=(0, 1))  # walkers whose whole trajectory agrees
-    assert note("lw_vs_ww_configs", relerr(res[0][0][ok], res[1][0][ok])) < 1e-10
-    assert note("lw_vs_ww_log", np.max(np.abs(res[0][1][ok] - res[1][1][ok]))) < 1e-9
-    for r in res:  # updated state equals a fresh recompute in both modes
+        acc, en, rec = dev.vmc_sweeps(0.3, 2, seed=77, energy=True, record=True)
+        res.append((dev.configs(), dev.value()[1], en, rec, dev.recompute(dev.configs())[1], acc))
+    for other, tag in ((1, "ww"), (2, "tile")):
+        same = res[0][3] == res[other][3]
+        assert same.mean() > 0.9999, tag  # a decision can only flip on a ~1e-13 near-tie
+        ok = same.all(axis=(0, 1, 2)) if same.ndim == 4 else same.all(axis=(0, 1))  # walkers whose whole trajectory agrees
+        assert ok.mean() > 0.98
+        assert note(f"lw_vs_{tag}_configs", relerr(res[0][0][ok], res[other][0][ok])) < 1e-10
+        assert note(f"lw_vs_{tag}_log", np.max(np.abs(res[0][1][ok] - res[other][1][ok]))) < 1e-9
+        assert abs(res[0][5] - res[other][5]).max() < 1e-3 and relerr(res[0][2], res[other][2]) < 1e-3
+    for r in res:  # updated state equals a fresh recompute in every mode
         assert np.max(np.abs(r[1] - r[4])) < 1e-9
 
 
