@@ -268,6 +268,12 @@ int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gaus
                    double threshold, const double* ecp_rot, const double* ecp_unif, uint64_t seed,
                    double* acceptance, double* energy_mean, uint8_t* accept_rec);
 
+/* branch (pyqmc/method/dmc.py:342-376) without the recompute that follows it in the reference (:155): walker w of the
+   resident ensemble becomes a copy of walker newinds[w] — coordinates, inverses, determinant signs / logs, orbital-row
+   cache and Jastrow sums are gathered on the device (the counterpart of configs.resample(newinds) coord.py:64-70,
+   191-198 for the wave-function state).  newinds (W) int32 in [0, W). */
+int pqa_resample(pqa_handle_t* h, const int32_t* newinds);
+
 /* dmc_propagate's step loop (pyqmc/method/dmc.py:123-221) fused on the device for real wave functions, open or
    periodic: per step (1) one T-move per electron (compute_tmoves eval_ecp.py:43-80, propose_tmoves dmc.py:73-120,
    masked updateinternals :160-168), (2) one drift-diffusion move per electron with Umrigar's limited drift

@@ -93,6 +93,7 @@ _PROTOTYPES = {
     "pqa_tmoves": (C.c_int, [_H, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_vmc_sweeps": (C.c_int, [_H, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pqa_resample": (C.c_int, [_H, C.c_void_p]),
     "pqa_dmc_steps": (C.c_int, [_H, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                 C.c_uint64, C.c_void_p, C.c_void_p]),
     "pqa_timer_start": (C.c_int, [_H]),

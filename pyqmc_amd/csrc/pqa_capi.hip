@@ -67,6 +67,7 @@ struct pqa_handle {
   SlaterState st{};
   JastrowState js{};
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
+  DevBuf b_alt_x, b_alt_T[2], b_alt_dsign[2], b_alt_dlog[2], b_alt_cache[2], b_alt_aval, b_alt_bval, b_alt_j3u, b_rsidx;  // pqa_resample's other halves
   // scratch
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth;
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
@@ -565,7 +566,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1733,6 +1734,65 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     HIPCHK(hipMemcpy(acceptance, acc.data(), nsteps * sizeof(double), hipMemcpyDefault));
   }
   if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * nen * sizeof(double), hipMemcpyDefault));
+  return 0;
+}
+
+// ---------------------------------------------------------------- branching on the device
+// dst row w <- src row idx[w]; rows of `row` doubles.  grid = (W, ceil(row / 1024)), block = 256 (4 doubles per thread)
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ src, double* __restrict__ dst, const int* __restrict__ idx,
+                                                     long row) {
+  const long w = blockIdx.x;
+  const double* s = src + (size_t)idx[w] * row;
+  double* d = dst + (size_t)w * row;
+  for (long k = (long)blockIdx.y * 1024 + threadIdx.x; k < row && k < ((long)blockIdx.y + 1) * 1024; k += 256) d[k] = s[k];
+}
+static int gather_swap(pqa_handle* h, DevBuf& cur, DevBuf& alt, const int* d_idx, size_t row_doubles) {
+  if (row_doubles == 0 || !cur.p) return 0;
+  TRY(ensure(h, alt, (size_t)h->W * row_doubles * sizeof(double)));
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)h->W, (unsigned)((row_doubles + 1023) / 1024)), dim3(256), 0, h->stream,
+                     (const double*)cur.p, (double*)alt.p, d_idx, (long)row_doubles);
+  std::swap(cur, alt);
+  return 0;
+}
+extern "C" int pqa_resample(pqa_handle_t* h, const int32_t* newinds) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  if (!newinds) FAIL("pqa_resample: newinds must not be NULL");
+  const long W = h->W;
+  for (long w = 0; w < W; ++w)
+    if (newinds[w] < 0 || newinds[w] >= W) FAIL("pqa_resample: index out of range");
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_rsidx, (size_t)W * sizeof(int)));
+  TRY(copy_in(h, h->b_rsidx.p, newinds, (size_t)W * sizeof(int)));
+  const int* idx = (const int*)h->b_rsidx.p;
+  const size_t cf = h->cplx ? 2 : 1;
+  TRY(gather_swap(h, h->b_x, h->b_alt_x, idx, (size_t)h->N * 3));
+  h->js.x = (double*)h->b_x.p;
+  if (h->has_slater) {
+    const int nel[2] = {h->nup, h->ndn};
+    for (int s = 0; s < 2; ++s) {
+      const size_t D = h->ndet_s[s], n = nel[s];
+      TRY(gather_swap(h, h->b_T[s], h->b_alt_T[s], idx, cf * D * n * n));
+      TRY(gather_swap(h, h->b_dsign[s], h->b_alt_dsign[s], idx, cf * D));
+      TRY(gather_swap(h, h->b_dlog[s], h->b_alt_dlog[s], idx, D));
+      TRY(gather_swap(h, h->b_cache[s], h->b_alt_cache[s], idx, n * 5 * h->nmo[s]));
+      h->st.T[s] = (double*)h->b_T[s].p;
+      h->st.dsign[s] = (double*)h->b_dsign[s].p;
+      h->st.dlog[s] = (double*)h->b_dlog[s].p;
+      h->st.cache[s] = (double*)h->b_cache[s].p;
+    }
+  }
+  if (h->has_j2) {
+    if (!h->jas_stale) {
+      TRY(gather_swap(h, h->b_aval, h->b_alt_aval, idx, (size_t)h->natom * h->na * 2));
+      TRY(gather_swap(h, h->b_bval, h->b_alt_bval, idx, (size_t)h->nb * 3));
+    }
+    h->js.avalues = (double*)h->b_aval.p;
+    h->js.bvalues = (double*)h->b_bval.p;
+  }
+  TRY(gather_swap(h, h->b_j3u, h->b_alt_j3u, idx, 1));
+  TRY(check_launch(h, "k_gather_rows"));
+  HIPCHK(hipStreamSynchronize(h->stream));  // newinds may be freed by the caller
   return 0;
 }
 

@@ -125,14 +125,15 @@ def _record_tapes(rng, nsteps, N, necp, W, tmoves):
     return t
 
 
-def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, acc, name, rng):
+def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, acc, name, rng, state_current=False):
     """``dmc_propagate`` through ``pqa_dmc_steps``: the whole step loop stays on the device."""
     from .energy import KEYS
 
     W, N = configs.configs.shape[:2]
     necp = getattr(dev, "necp", 0)
     tmoves = acc.has_nonlocal_moves() and necp > 0
-    wf.recompute(configs)
+    if not state_current:  # the reference recomputes at the start of every block (dmc.py:155)
+        wf.recompute(configs)
     if dev.pbc:
         dev.set_ewald(**acc._ewald_kws)
     tapes = None if rng is None else _record_tapes(rng, nsteps, N, necp, W, tmoves)
@@ -165,18 +166,21 @@ def fused_dmc_supported(wf, accumulators, ekey):
 
 
 def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps=5, accumulators=None,
-                  ekey=("energy", "total"), rng=None, fused=True):
+                  ekey=("energy", "total"), rng=None, fused=True, state_current=False):
     """Propagate ``nsteps`` DMC steps without branching; returns (block averages, configs, weights) with the
     reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``).
 
     ``fused=True`` (default) runs the step loop on the device (``pqa_dmc_steps``) whenever the wave function is real and
     the energy accumulator is the only accumulator; otherwise, or with ``fused=False``, the loop below drives the
-    protocol entry points step by step like the reference does."""
+    protocol entry points step by step like the reference does.  ``state_current=True`` (fused path only) promises that
+    the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on the device
+    (``DeviceWF.resample``) — and skips the initial recompute."""
     assert accumulators is not None, "Need an energy accumulator for DMC"
     acc = accumulators[ekey[0]]
     dev = fused_dmc_supported(wf, accumulators, ekey) if fused else None
     if dev is not None:
-        return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, acc, ekey[0], rng)
+        return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, acc, ekey[0], rng,
+                                state_current=state_current)
     replay = rng is not None
     rng = rng if replay else _NumpyRNG()
     W, N = configs.configs.shape[:2]
@@ -240,21 +244,29 @@ def comb_indices(weights, base_u):
     return np.searchsorted(cum, teeth), wtot
 
 
-def branch(configs, weights, base_u=None):
-    """Single-process branching: walkers resampled in proportion to their weights, weights reset to the mean."""
+def branch(configs, weights, base_u=None, on_resample=None):
+    """Single-process branching: walkers resampled in proportion to their weights, weights reset to the mean.
+    ``on_resample(newinds)`` lets the wave-function state follow the walkers (``DeviceWF.resample``)."""
     base_u = np.random.rand() if base_u is None else base_u
     newinds, wtot = comb_indices(weights, base_u)
     unique, counts = np.unique(newinds, return_counts=True)
     configs.resample(newinds)
+    if on_resample is not None:
+        on_resample(newinds)
     weights.fill(wtot / len(weights))
     return configs, weights, {"max branches": int(counts.max()), "Number of walkers killed": int(len(weights) - len(unique))}
 
 
 def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=None, accumulators=None, verbose=False,
-           ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False):
+           ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False, recompute_every=10):
     """Block loop of the reference's ``rundmc`` (no restart files): VMC warm-up, energy reference, then
     propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every rank calls this with
-    its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo)."""
+    its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo).
+
+    Single-process runs on the fused path branch ON THE DEVICE: the comb's indices gather the wave-function state
+    (``pqa_resample``) instead of recomputing it from the resampled coordinates as the reference does after every
+    branch (dmc.py:155); a full recompute every ``recompute_every`` blocks bounds the round-off the Sherman-Morrison
+    updates accumulate (``recompute_every=1`` is the reference's schedule)."""
     from . import dist as pdist
     from .vmc import vmc
 
@@ -272,9 +284,12 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     W = configs.configs.shape[0]
     weights = np.ones(W) if weights is None else weights
     rows = []
+    dev = None if distributed else fused_dmc_supported(wf, accumulators, ekey)
+    current = False
     for block in range(nblocks):
         blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
-                                              nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey)
+                                              nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey,
+                                              state_current=current and block % max(int(recompute_every), 1) != 0)
         if distributed:  # weighted recombination of the per-rank block averages (dmc.py:238-304)
             keys = sorted(k for k in blk if k != "weight")
             sums, _ = pdist.allreduce_block([blk[k] * blk["weight"] * W for k in keys] + [blk["weight"] * W, W], 1)
@@ -286,7 +301,8 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
             mean_w = float(pdist.allreduce_block([weights.sum()], len(weights))[0][0])
         else:
             blk["weight_std"] = np.std(weights)
-            configs, weights, info = branch(configs, weights)
+            configs, weights, info = branch(configs, weights, on_resample=None if dev is None else dev.resample)
+            current = dev is not None
             mean_w = np.mean(weights)
         blk.update(info, e_trial=e_trial, e_est=e_est, block=block, esigma=esigma, tstep=tstep, nsteps_per_block=nsteps_per_block)
         rows.append(blk)

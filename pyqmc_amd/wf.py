@@ -256,6 +256,12 @@ class DeviceWF:
             en = self._complex_energy(en, 1)
         return acc, en, (rec.astype(bool) if record else None)
 
+    def resample(self, newinds):
+        """``pqa_resample``: walker w of the resident state becomes a copy of walker ``newinds[w]``."""
+        idx = np.ascontiguousarray(newinds, dtype=np.int32)
+        assert idx.shape == (self.W,)
+        self.call("pqa_resample", _ffi.ptr(idx))
+
     def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0):
         """``pqa_dmc_steps``: ``nsteps`` DMC steps on the resident walkers.  ``weights`` (W) is updated in place.
         ``tapes``: dict of the replay arrays of ``pqa_dmc_tapes_t`` or None (device Philox streams).

@@ -502,3 +502,70 @@ def test_obdm_golden():
 
     assert note("obdm_orbitals", relerr(ev.mos(pts), gto.eval_ao(gto.AOTable(mol), pts, 1)[0] @ orb)) < 1e-12
     check_obdm_against_golden(wfs, g, lambda kw: pa.obdm.OBDMAccumulator(mol, orb, nsweeps=3, tstep=0.4, warmup=6, **kw), 1e-8, note)
+
+
+@pytest.mark.parametrize("kind", ["sj", "multidet3"])
+def test_device_resample_is_a_gather_of_the_state(kind):
+    """pqa_resample (branching without the reference's recompute, dmc.py:155,342-376): afterwards walker w carries
+    walker newinds[w]'s coordinates and wave-function state bit for bit, every protocol quantity agrees with a fresh
+    recompute of the resampled coordinates, and the fused DMC step continues from it."""
+    import ast
+
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    if kind == "sj":
+        build = lambda: helpers.gpu_wf(mol, systems.random_mf(mol))  # noqa: E731
+    else:
+        dets = ast.literal_eval(str(golden("g7_jastrow3_multidet")["det_json"]))
+        build = lambda: helpers.gpu_wf3(mol, systems.random_mf(mol, nvirt=6), dets)  # noqa: E731
+    W = 96
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(31))
+    idx = np.random.default_rng(32).integers(0, W, W)
+    idx[:5] = [7, 7, 7, 0, W - 1]
+    a, b = build(), build()
+    sa, la = a.recompute(cfg)
+    a.fused_device().vmc_sweeps(0.3, 2, seed=4, energy=False)  # a state produced by Sherman-Morrison updates, Jastrow sums stale
+    x_old, (s_old, l_old) = a.fused_device().configs(), a.value()
+    a.fused_device().resample(idx)
+    assert np.array_equal(a.fused_device().configs(), x_old[idx])
+    s_new, l_new = a.value()
+    assert np.array_equal(s_new, s_old[idx]) and np.array_equal(l_new, l_old[idx])
+    cfg_b = OpenConfigs(x_old[idx].copy())
+    sb, lb = b.recompute(cfg_b)
+    assert np.array_equal(sb, s_new) and note(f"resample_{kind}_log", np.max(np.abs(lb - l_new))) < 1e-9
+    e = 5
+    ep = cfg_b.electron(e)
+    ga, la_ = a.gradient_laplacian(e, ep)
+    gb, lb_ = b.gradient_laplacian(e, ep)
+    assert relerr(ga, gb) < 1e-8 and relerr(la_, lb_) < 1e-8
+    np.random.seed(1)
+    acc = pa.EnergyAccumulator(mol)
+    ea, eb = acc(cfg_b, a), acc(cfg_b, b)  # same numpy draws? no: separate calls draw separately -> compare deterministic keys
+    for k in ("ke", "ee", "ei", "grad2"):
+        assert relerr(ea[k], eb[k]) < 1e-8, k
+    with pytest.raises(RuntimeError):
+        a.fused_device().resample(np.full(W, W))
+
+
+def test_rundmc_device_branching_statistics():
+    """rundmc with branching on the device (state gathered, recompute every 10 blocks) against the reference schedule
+    (recompute after every branch): same population dynamics within the statistical error."""
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    res = []
+    for every in (10, 1):
+        np.random.seed(12)
+        wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+        configs = pa.initial_guess(mol, 512, rng=np.random.default_rng(3))
+        df, configs, weights = pa.rundmc(wf, configs, tstep=0.02, nblocks=6, nsteps_per_block=3, vmc_warmup=3,
+                                         accumulators={"energy": pa.EnergyAccumulator(mol)}, recompute_every=every)
+        s0, l0 = wf.value()
+        s1, l1 = wf.recompute(configs)
+        assert np.array_equal(s0, s1) and np.max(np.abs(l0 - l1)) < 1e-8  # the carried state is the state of `configs`
+        res.append(df)
+    a, b = res
+    assert np.all(np.isfinite(a["energytotal"])) and a["energytotal"].shape == (6,)
+    assert abs(a["energytotal"][2:].mean() - b["energytotal"][2:].mean()) < 6 * max(a["esigma"][0], 1e-3) / np.sqrt(512)
+    assert abs(a["acceptance"].mean() - b["acceptance"].mean()) < 0.02

@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("config")
 ap.add_argument("--walkers", type=int, default=0)
 ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--rundmc", type=int, default=0, help="c5: time rundmc blocks (5 steps + branching each) with this recompute_every instead of bare steps")
 ap.add_argument("--host", action="store_true", help="c5: drive the DMC step from the host over the protocol entry points")
 a = ap.parse_args()
 prim = pa.systems.diamond_primitive()
@@ -48,7 +49,18 @@ else:
     raise SystemExit("config must be c3, c4 or c5")
 dev = wf.fused_device()
 wf.recompute(cfg)
-if a.config == "c5":
+if a.config == "c5" and a.rundmc:
+    acc = {"energy": pa.EnergyAccumulator(sup)}
+    np.random.seed(1)
+    nb = max(a.steps, 2)
+    pa.rundmc(wf, cfg, tstep=0.02, nblocks=1, nsteps_per_block=5, vmc_warmup=1, accumulators=acc, recompute_every=a.rundmc)
+    t0 = time.perf_counter()
+    df, cfg, weights = pa.rundmc(wf, cfg, tstep=0.02, nblocks=nb, nsteps_per_block=5, vmc_warmup=0, accumulators=acc, recompute_every=a.rundmc)
+    dt = time.perf_counter() - t0
+    a.steps = 5 * nb
+    kind = f"rundmc blocks: 5 steps + stochastic comb (recompute every {a.rundmc} blocks)"
+    extra = {"acceptance": float(df["acceptance"].mean()), "tmove_acceptance": float(df["tmove_acceptance"].mean()), "weight": float(df["weight"].mean())}
+elif a.config == "c5":
     acc = {"energy": pa.EnergyAccumulator(sup)}
     weights = np.ones(W)
     pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=1, accumulators=acc, fused=not a.host)
