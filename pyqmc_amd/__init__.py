@@ -16,5 +16,6 @@ from .wf import DeviceWF, JastrowSpin, MultiplyWF, Slater, ThreeBodyJastrow, gen
 from . import obdm  # noqa: F401
 from .accumulators import LinearTransform, PGradTransform, StochasticReconfiguration  # noqa: F401
 from .obdm import OBDMAccumulator  # noqa: F401
+from .tbdm import TBDMAccumulator  # noqa: F401
 
 __version__ = "0.1.0"

@@ -32,45 +32,53 @@ class _OneElectronView:
 
 
 class OrbitalEvaluator:
-    """``orb_coeff`` as an orbital evaluator on the device: the role ``MoleculeOrbitalEvaluator(mol, [C, C])`` /
-    ``PBCOrbitalEvaluatorKpoints(mol, [C, C], kpts)`` play in obdm.py:79-91.  Periodic: ``orb_coeff[k]`` (nao_prim, norb_k)
-    at the k-points ``kpts`` that fold onto the supercell; the orbitals are concatenated over k."""
+    """``orb_coeff`` as an orbital evaluator on the device: the role ``MoleculeOrbitalEvaluator(mol, [C_up, C_dn])`` /
+    ``PBCOrbitalEvaluatorKpoints(mol, [C_up, C_dn], kpts)`` play in obdm.py:79-91 and tbdm.py:87-104.  ``orb_coeff`` is
+    one (nao, norb) matrix used for both spins or a pair of them.  Periodic: per spin a list ``[k]`` of (nao_prim, norb_k)
+    blocks at the k-points ``kpts`` that fold onto the supercell; the orbitals are concatenated over k."""
 
     def __init__(self, mol, orb_coeff, kpts=None, eval_gto_precision=None, device=0):
         twist = None
         if kpts is None:
             if hasattr(mol, "a"):
                 raise ValueError("kpts is required if the system is periodic")
-            coeff = np.asarray(orb_coeff)
+            single = isinstance(orb_coeff, np.ndarray) and orb_coeff.ndim == 2
+            pair = [np.asarray(orb_coeff)] * 2 if single else [np.asarray(orb_coeff[0]), np.asarray(orb_coeff[1])]
         else:
             if not hasattr(mol, "original_cell"):
                 mol = _pbc.get_supercell(mol, np.eye(3))
             kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
-            coeff = _pbc.fold_mo_coeff(mol, kpts, [list(orb_coeff), list(orb_coeff)])[0]
+            single = isinstance(orb_coeff[0], np.ndarray) and orb_coeff[0].ndim == 2  # [k] blocks shared by both spins
+            per_spin = [list(orb_coeff), list(orb_coeff)] if single else [list(orb_coeff[0]), list(orb_coeff[1])]
+            pair = _pbc.fold_mo_coeff(mol, kpts, per_spin)
             twist = _pbc.common_twist(mol, kpts)
-        self.norb = coeff.shape[-1]
+        self._nmo = [int(c.shape[-1]) for c in pair]
+        self.norb = self._nmo[0]
         self.mol = mol
-        dets = [(1.0, [[self.norb - 1], [self.norb - 1]])]  # nmo = highest occupied index + 1
+        dets = [(1.0, [[self._nmo[0] - 1], [self._nmo[1] - 1]])]  # nmo_s = highest occupied index + 1
         kw = {} if eval_gto_precision is None else {"eval_gto_precision": eval_gto_precision}
-        self.dev = DeviceWF(_OneElectronView(mol), mo_coeff=[coeff, coeff], determinants=dets, device=device, twist_k=twist, **kw)
+        self.dev = DeviceWF(_OneElectronView(mol), mo_coeff=pair, determinants=dets, device=device, twist_k=twist, **kw)
         self.mo_dtype = complex if self.dev.cplx else float
 
-    def mos(self, points):
-        """(npts, norb) orbital values at ``points`` (npts, 3) (any position: periodic handles fold internally)."""
-        return self.dev.eval_mo(0, np.asarray(points, dtype=float).reshape(-1, 3), 1)[0]
+    def nmo(self):
+        return list(self._nmo)
+
+    def mos(self, points, spin=0):
+        """(npts, norb_spin) orbital values at ``points`` (npts, 3) (any position: periodic handles fold internally)."""
+        return self.dev.eval_mo(int(spin), np.asarray(points, dtype=float).reshape(-1, 3), 1)[0]
 
 
-def sample_onebody(configs, orbitals, nsamples=1, tstep=0.5):
-    """Metropolis samples of f(r) = sum_i |phi_i(r)|^2 for the one-electron walkers ``configs`` (n,1,3)
-    (obdm.py:215-250).  Returns (accept (nsamples,n), list of configs, list of orbital values (n,norb))."""
+def sample_onebody(configs, orbitals, nsamples=1, tstep=0.5, spin=0):
+    """Metropolis samples of f(r) = sum_i |phi_i(r)|^2 (orbitals of ``spin``) for the one-electron walkers ``configs``
+    (n,1,3) (obdm.py:215-250).  Returns (accept (nsamples,n), list of configs, list of orbital values (n,norb))."""
     n = configs.configs.shape[0]
-    borb = orbitals.mos(configs.configs)
+    borb = orbitals.mos(configs.configs, spin)
     fsum = (np.abs(borb) ** 2).sum(axis=1)
     allaccept, allconfigs, allorbs = np.zeros((nsamples, n)), [], []
     for s in range(nsamples):
         shift = np.sqrt(tstep) * np.random.randn(*configs.configs.shape)
         newconfigs = configs.make_irreducible(0, (configs.configs + shift)[:, 0])
-        borbnew = orbitals.mos(newconfigs.configs)
+        borbnew = orbitals.mos(newconfigs.configs, spin)
         fsumnew = (np.abs(borbnew) ** 2).sum(axis=1)
         accept = fsumnew / fsum > np.random.rand(n)
         configs.move(0, newconfigs, accept)

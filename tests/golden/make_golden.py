@@ -1174,6 +1174,46 @@ def g_obdm():
     save("g22_obdm", **out)
 
 
+# ------------------------------------------------------------------ G23 two-body density matrix accumulator
+def g_tbdm():
+    """TBDMAccumulator (tbdm.py:63-283) on the H2O Slater-Jastrow wave function, sectors (0,1) and (0,0), numpy.random seeded."""
+    import pyqmc.observables.tbdm as reftbdm
+    from pyqmc.wf.orbitals import MoleculeOrbitalEvaluator
+
+    out = {}
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=3)
+    wf = make_wf(mol, systems.random_mf(mol))
+    C = np.asarray(mf.mo_coeff)
+    orb = [C[0][:, :5], C[1][:, 1:5]]  # different bases (and sizes) for the two spins
+    out["orb_up"], out["orb_dn"] = orb[0], orb[1]
+    W = 5
+    configs = walkers(mol, W, 71)
+    out["configs"] = configs.configs.copy()
+    wf.recompute(configs)
+    rng = np.random.default_rng(230)
+    some = rng.integers(0, 4, size=(30, 4))
+    out["ijkl_some"] = some
+    for tag, kw in (("ud", dict(spin=(0, 1))), ("uu", dict(spin=(0, 0), ijkl=some, naux=9)), ("du", dict(spin=(1, 0), ijkl=some))):
+        acc = reftbdm.TBDMAccumulator(mol, orb, nsweeps=2, tstep=0.4, warmup=4, **kw)
+        acc.orbitals = MoleculeOrbitalEvaluator(mol, orb, evaluate_orbitals_with="numba")
+        np.random.seed(231 + len(out))
+        out[tag + "_seed"] = np.asarray(231 + len(out))
+        for call in (0, 1):
+            d = acc(configs, wf)
+            for k in ("value", "norm_a", "norm_b"):
+                out[f"{tag}_{k}{call}"] = d[k]
+        d = acc.avg(configs, wf)
+        for k in ("value", "norm_a", "norm_b"):
+            out[f"{tag}_avg_{k}"] = d[k]
+        out[tag + "_aux_final_a"], out[tag + "_aux_final_b"] = acc._aux_configs[0].configs.copy(), acc._aux_configs[1].configs.copy()
+        out[tag + "_final_log"] = wf.value()[1]  # the state after all the there-and-back updates
+    nmo = (5, 4)
+    full = out["ud_avg_value"].reshape(nmo[0], nmo[0], nmo[1], nmo[1])
+    out["normalized"] = reftbdm.normalize_tbdm(full, out["ud_avg_norm_a"], out["ud_avg_norm_b"])
+    save("g23_tbdm", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1196,3 +1236,4 @@ if __name__ == "__main__":
     g_pbc_twist()
     g_sr()
     g_obdm()
+    g_tbdm()
