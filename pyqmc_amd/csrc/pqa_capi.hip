@@ -87,6 +87,10 @@ struct pqa_handle {
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
+  // AO rows per chunk of the PERIODIC 5-component launch: 32 halves the number of (phase 1, barrier, MFMA, barrier)
+  // rounds of a block's latency chain — 2x2x2 diamond supercell +4.5-10 % at every walker count, 8-atom cell +11 % at 8192
+  // walkers, -4 % at 32768 (PQA_ORB_KC5=16 restores the 16-row chunks; the open-system kernel keeps 16: 0.36 vs 0.29 of peak)
+  int orb_kc5 = 32;
   struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
   TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
@@ -324,6 +328,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   global memory, PQA_LW 0 wave-per-walker sweep, PQA_LW_KB k blocked Sherman-Morrison, PQA_LW_GM g partial-sum
   //   groups, PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
+  if (const char* kc = getenv("PQA_ORB_KC5")) h->orb_kc5 = atoi(kc);
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
@@ -745,7 +750,7 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
   // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
   const bool want_ws = h->orb_ws < 0 ? (P < (long)64 * 512) : (h->orb_ws != 0);
   if (h->S.nL > 0) {
-    if (ncomp == 5) TRY((launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out)));
+    if (ncomp == 5) { if (h->orb_kc5 == 32) TRY((launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out))); else TRY((launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out))); }
     else if (ncomp == 1) TRY((launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out)));
     else FAIL("orbital kernel supports ncomp 1 or 5");
   } else
