@@ -300,8 +300,8 @@ struct ChunkTab {
   const int* chunk_nk;    // AOs in chunk
   const int* shell_kb;    // [nshell] first tile row of the shell inside its chunk
   const int* chunk_row0;  // first row in the zero-padded coefficient matrices
-  const int* cw_off[2];   // [nchunk*G+1] for G = 4 (TP=64) and G = 8 (TP=32)
-  const int* cw_shell[2]; // shells for (chunk, group)
+  const int* cw_off[3];   // [nchunk*G+1] for G = 4 (TP=64), G = 8 (TP=32) and G = 16 (TP=16)
+  const int* cw_shell[3]; // shells for (chunk, group)
   const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
   int ldc[2];
   // periodic launches only: per (atom, point) folded displacement [natom][3][P] and admission mask [natom][2][P],
@@ -313,18 +313,19 @@ struct ChunkTab {
 #define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
 #define PQA_WS_MAXP 640
 
-// out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), TP = 64 or 32 points.
+// out[p][c][j], p < P, c < NCOMP, j < nmo.  Block = 256 threads (4 waves), TP = 64, 32 or 16 points.
 //  phase 1 (VALU/exp bound): thread = (point, lane group); each group evaluates its share of the chunk's
 //          shells and writes the XOR-swizzled LDS tile [comp][k][point ^ ((k&1)<<4)]
 //  phase 2 (MFMA): TP=64: wave wv owns the 16-point tile wv and all NT orbital tiles;
 //                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
+//                  TP=16: one point tile, wave wv owns orbital tiles wv, wv+4, ... (small launches: more blocks, 16 lane groups)
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
 // PBC: 0 open system, 1 periodic (real lattice sums), 2 periodic with a twist (complex lattice sums, shells twice)
 template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, int PBC = 0>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
   constexpr int G = 256 / TP;                         // lane groups in phase 1
-  constexpr int NU = (TP == 64) ? NT : (NT + 1) / 2;  // orbital tiles per wave in phase 2
+  constexpr int NU = (TP == 64) ? NT : ((TP == 32) ? (NT + 1) / 2 : (NT + 3) / 4);  // orbital tiles per wave in phase 2
   constexpr int KS = KC / 4;
   __shared__ double tile[NCOMP][KC][TP];
   // LDSTAB: basis tables staged once per block so phase 1 never waits on chains of dependent scalar loads
@@ -363,10 +364,11 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   const double* __restrict__ C = T.cpad[spin];
   const int ldc = T.ldc[spin];
   const int i16 = lane & 15, kq = lane >> 4;
-  const int ptile = (TP == 64) ? wv : (wv & 1);
-  const int u0 = (TP == 64) ? 0 : (wv >> 1), ustep = (TP == 64) ? 1 : 2;
-  const int* __restrict__ cw_off = T.cw_off[TP == 64 ? 0 : 1];
-  const int* __restrict__ cw_shell = T.cw_shell[TP == 64 ? 0 : 1];
+  const int ptile = (TP == 64) ? wv : ((TP == 32) ? (wv & 1) : 0);
+  const int u0 = (TP == 64) ? 0 : ((TP == 32) ? (wv >> 1) : wv), ustep = (TP == 64) ? 1 : ((TP == 32) ? 2 : 4);
+  constexpr int TI = (TP == 64) ? 0 : ((TP == 32) ? 1 : 2);
+  const int* __restrict__ cw_off = T.cw_off[TI];
+  const int* __restrict__ cw_shell = T.cw_shell[TI];
 
   for (int ch = 0; ch < T.nchunk; ++ch) {
     const int nk = T.chunk_nk[ch], row0 = T.chunk_row0[ch];
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       }
       auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
         const int k = kb + m;
-        const int col = pl ^ ((k & 1) << 4);
+        const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
         tile[0][k][col] = v;
         if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
         if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     for (int ks = 0; ks < KS; ++ks) {
       if (ks * 4 < nk4) {
         const int k = ks * 4 + kq;
-        const int col = (16 * ptile + i16) ^ ((k & 1) << 4);
+        const int col = (TP >= 32) ? ((16 * ptile + i16) ^ ((k & 1) << 4)) : i16;
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {
           const double a = tile[c][k][col];

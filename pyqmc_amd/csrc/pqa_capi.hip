@@ -32,7 +32,7 @@ struct DevBuf {
 struct ChunkHost {
   std::vector<int> nk, row0;
   std::vector<int> shell_kb, shell_chunk;  // per shell: first tile row inside its chunk, chunk index
-  std::vector<int> cw_off[2], cw_shell[2];  // shell lists per (chunk, lane group) for 4 and 8 groups
+  std::vector<int> cw_off[3], cw_shell[3];  // shell lists per (chunk, lane group) for 4, 8 and 16 groups
   int rows_pad = 0;
 };
 
@@ -188,7 +188,7 @@ static int check_launch(pqa_handle* h, const char* what) {
 // ---------------------------------------------------------------- chunk tables for k_orb
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
-  for (int g = 0; g < 2; ++g) c.cw_off[g].push_back(0);
+  for (int g = 0; g < 3; ++g) c.cw_off[g].push_back(0);
   // twisted cells: every shell appears twice (index + nshell = imaginary part of the complex lattice sum)
   const int nsx = h->twist ? 2 * h->nshell : h->nshell;
   c.shell_kb.assign((size_t)nsx, 0);
@@ -256,6 +256,19 @@ static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
     for (int q = 0; q < 8; ++q) {
       for (int s : l8[q]) c.cw_shell[1].push_back(s);
       c.cw_off[1].push_back((int)c.cw_shell[1].size());
+    }
+    std::vector<std::vector<int>> l16(16);  // 16-point tiles: 16 lane groups
+    std::vector<int> load16(16, 0);
+    for (int s : members) {
+      int best = 0;
+      for (int q = 1; q < 16; ++q)
+        if (load16[q] < load16[best]) best = q;
+      l16[best].push_back(s);
+      load16[best] += cost(s);
+    }
+    for (int q = 0; q < 16; ++q) {
+      for (int s : l16[q]) c.cw_shell[2].push_back(s);
+      c.cw_off[2].push_back((int)c.cw_shell[2].size());
     }
   }
   c.rows_pad = row0;
@@ -477,7 +490,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, c.nk.data(), c.nk.size(), &tmp_i)); T.chunk_nk = tmp_i;
       TRY(upload_table(h, c.shell_kb.data(), c.shell_kb.size(), &tmp_i)); T.shell_kb = tmp_i;
       TRY(upload_table(h, c.row0.data(), c.row0.size(), &tmp_i)); T.chunk_row0 = tmp_i;
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < 3; ++g) {
         TRY(upload_table(h, c.cw_off[g].data(), c.cw_off[g].size(), &tmp_i)); T.cw_off[g] = tmp_i;
         TRY(upload_table(h, c.cw_shell[g].data(), c.cw_shell[g].size(), &tmp_i)); T.cw_shell[g] = tmp_i;
       }
@@ -668,11 +681,13 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   // 32768; 8-atom cubic cell: 32 wins up to 16384 points, 64 wins by 14 % at 32768), both give bit-identical rows, so
   // large launches time each twice per size class (four stream synchronisations in the handle's lifetime per class) and
   // keep the faster; small ones take 32.  PQA_ORB_TP pins it.
-  int tp = 32;
+  // small launches: 16-point tiles (2x2x2 diamond: 19.8 -> 15.6 ms/step at 1024 walkers, 25.5 -> 21.9 at 4096, +3.5 % at 8192;
+  // the twisted 8-atom cell loses 13 % at 8192, hence the threshold)
+  int tp = (P <= 4096) ? 16 : 32;
   pqa_handle::TpTune* tune = nullptr;
   int tune_slot = -1;
   hipEvent_t te0 = nullptr, te1 = nullptr;
-  if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
+  if (h->orb_tp == 16 || h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
   else if (P >= 16384) {
     int b = 0;
     while ((2L << b) <= P && b < 46) ++b;
@@ -692,7 +707,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   const bool lt = h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab;
 #define PQA_ORB_PBC2(NT, LT, TPV) do { if (h->twist) hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, TPV, LT, 2>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); \
                                        else hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, TPV, LT, 1>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); } while (0)
-#define PQA_ORB_PBC(NT, LT) do { if (tp == 64) PQA_ORB_PBC2(NT, LT, 64); else PQA_ORB_PBC2(NT, LT, 32); } while (0)
+#define PQA_ORB_PBC(NT, LT) do { if (tp == 64) PQA_ORB_PBC2(NT, LT, 64); else if (tp == 16) PQA_ORB_PBC2(NT, LT, 16); else PQA_ORB_PBC2(NT, LT, 32); } while (0)
   switch (h->nt[spin]) {
     case 1: if (lt) PQA_ORB_PBC(1, true); else PQA_ORB_PBC(1, false); break;
     case 2: if (lt) PQA_ORB_PBC(2, true); else PQA_ORB_PBC(2, false); break;

@@ -416,16 +416,17 @@ def test_periodic_obdm_orbitals_and_accumulator():
 
 
 def test_periodic_orbital_tile_widths_are_bitwise_identical(monkeypatch):
-    """The periodic k_orb picks its point-tile width (32 / 64) by timing both on large launches; that is only legitimate
+    """The periodic k_orb picks its point-tile width (16 for small launches, 32 / 64 by timing both on large ones); that is only legitimate
     because the two instantiations produce the same bits (same chunk composition => same MFMA accumulation order)."""
     import pyqmc_amd as pa
 
     sup, mf = helpers.pbc_slater_case("fcc2cubic")
     pts = (np.random.default_rng(8).random((700, 3)) * 3 - 1) @ sup.lattice_vectors()
     rows = {}
-    for tp in ("32", "64"):
+    for tp in ("16", "32", "64"):
         monkeypatch.setenv("PQA_ORB_TP", tp)
         dev = pa.generate_wf(sup, mf).fused_device()
         rows[tp] = [dev.eval_mo(0, pts, nc) for nc in (1, 5)]
-    for a, b in zip(rows["32"], rows["64"]):
-        assert np.array_equal(a, b)
+    for other in ("16", "64"):
+        for a, b in zip(rows["32"], rows[other]):
+            assert np.array_equal(a, b)
