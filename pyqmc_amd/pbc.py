@@ -198,6 +198,33 @@ def fold_mo_coeff(supercell, kpts, mo_coeff):
     return out
 
 
+def unfold_mo_gradient(supercell, kpts, d_super, nmo_k):
+    """Chain rule of ``fold_mo_coeff`` for real phases: derivatives w.r.t. the folded supercell coefficients
+    ``d_super`` (..., nao_super, sum_k nmo_k) -> derivatives w.r.t. the per-k blocks, concatenated over k like the
+    reference's ``mo_coeff_alpha`` parameter (..., nao_prim, sum_k nmo_k) (orbitals.py:154-160, slater.py:511-527):
+    d/dC_k[(a,m), n] = sum_c cos(k . T_c) d/dC_super[(a,c,m), (k,n)]."""
+    prim = supercell.original_cell
+    kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
+    copies = get_supercell_copies(prim.lattice_vectors(), supercell.S)
+    phase = np.exp(1j * copies @ kpts.T)
+    if np.abs(phase.imag).max() > 1e-9:
+        raise NotImplementedError("orbital-coefficient gradients with complex Bloch phases")
+    phase = phase.real
+    nao_atom = [sum(2 * sh[0] + 1 for sh in prim._basis[n]) for n in prim._names]
+    ncopy = len(copies)
+    lead = d_super.shape[:-2]
+    out = np.zeros(lead + (sum(nao_atom), d_super.shape[-1]))
+    col = np.concatenate([[0], np.cumsum(nmo_k)])
+    row = prow = 0
+    for na in nao_atom:
+        blk = d_super[..., row : row + ncopy * na, :].reshape(lead + (ncopy, na, d_super.shape[-1]))
+        for k in range(len(kpts)):
+            out[..., prow : prow + na, col[k] : col[k + 1]] = np.einsum("c,...cmn->...mn", phase[:, k], blk[..., col[k] : col[k + 1]])
+        row += ncopy * na
+        prow += na
+    return out
+
+
 def common_twist(supercell, kpts):
     """The twist the k-points share: k modulo the supercell's reciprocal lattice, as a cartesian vector with fractional
     components in [-1/2, 1/2) — or None when it is zero.  Raises if the k-points do not share one."""

@@ -329,20 +329,25 @@ class DeviceWF:
 class _DeviceParams(dict):
     """``wf.parameters``: a dict of host arrays whose assignments are pushed to the device."""
 
-    def __init__(self, dev, items):
+    def __init__(self, dev, items, to_device=None):
         super().__init__(items)
         self._dev = dev
+        self._to_device = to_device or {}  # key -> map from the parameter's public layout to the device's
+
+    def _send(self, key, value):
+        f = self._to_device.get(key)
+        self._dev.set_param(key, value if f is None else f(value))
 
     def __setitem__(self, key, value):
         value = np.array(value, dtype=float)
         if key in self and value.shape != np.shape(self[key]):
             raise ValueError(f"parameter {key} has shape {np.shape(self[key])}, got {value.shape}")
         super().__setitem__(key, value)
-        self._dev.set_param(key, value)
+        self._send(key, value)
 
     def push(self):
         for k, v in self.items():
-            self._dev.set_param(k, v)
+            self._send(k, v)
 
 
 def _mask_args(mask, W):
@@ -395,7 +400,7 @@ def _testvalue_many(dev, factors, e, epos, mask):
     return out
 
 
-def orbital_inputs(mol, mf, determinants=None):
+def orbital_inputs(mol, mf, determinants=None, with_fold=False):
     """(mol, mo_coeff (2)[nao, nmo], determinants) the device is built from — the role of
     ``pyscftools.orbital_evaluator_from_pyscf`` (pyscftools.py:105-191).  Open systems pass through.  A periodic
     ``mol`` (a ``pyqmc_amd.pbc.get_supercell`` result, or a plain cell = supercell with S = 1) takes a k-point mean
@@ -405,7 +410,7 @@ def orbital_inputs(mol, mf, determinants=None):
     real supercell coefficients (``pbc.fold_mo_coeff``)."""
     mf = mf.to_uhf() if hasattr(mf, "to_uhf") else mf
     if not hasattr(mol, "a"):
-        return mol, mf.mo_coeff, determinants, None
+        return (mol, mf.mo_coeff, determinants, None) + ((None,) if with_fold else ())
     from . import pbc as _pbc
 
     if not hasattr(mol, "original_cell"):
@@ -437,7 +442,9 @@ def orbital_inputs(mol, mf, determinants=None):
     else:  # already flat: indices into the concatenation of the full per-k blocks
         flat = determinants
         mo = [[np.asarray(mf.mo_coeff[sp][k]) for k in kinds] for sp in (0, 1)]
-    return mol, _pbc.fold_mo_coeff(mol, kpts[kinds], mo), flat, twist_k
+    out = (mol, _pbc.fold_mo_coeff(mol, kpts[kinds], mo), flat, twist_k)
+    # with_fold: what maps the reference's per-k parameter layout (nao_prim, sum_k nmo_k) to the folded matrices and back
+    return out + (({"kpts": kpts[kinds], "blocks": mo, "nmo_k": [[b.shape[1] for b in mo[sp]] for sp in (0, 1)]},) if with_fold else ())
 
 
 class Slater:
@@ -448,18 +455,29 @@ class Slater:
     reference's ``determinants=`` argument (slater.py:166-180)."""
 
     def __init__(self, mol, mf, determinants=None, tol=None, device=0, eval_gto_precision=None, image_rule="reference",
-                 _dev=None):
+                 _dev=None, _fold=None):
         if _dev is None:
-            mol, mo_coeff, determinants, twist_k = orbital_inputs(mol, mf, determinants)
+            mol, mo_coeff, determinants, twist_k, _fold = orbital_inputs(mol, mf, determinants, with_fold=True)
             _dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, device=device,
                             tol=-1 if tol is None else tol, eval_gto_precision=eval_gto_precision, image_rule=image_rule,
                             twist_k=twist_k)
         self._mol = mol
         self._nelec = tuple(mol.nelec)
         self._dev = _dev
-        self.parameters = _DeviceParams(_dev, {"det_coeff": _dev.det_coeff.copy(),
-                                               "mo_coeff_alpha": _dev.mo_coeff[0].copy(),
-                                               "mo_coeff_beta": _dev.mo_coeff[1].copy()})
+        self._fold = _fold if (_fold is not None and not _dev.cplx) else None
+        items = {"det_coeff": _dev.det_coeff.copy(), "mo_coeff_alpha": _dev.mo_coeff[0].copy(), "mo_coeff_beta": _dev.mo_coeff[1].copy()}
+        to_device = {}
+        if self._fold is not None:
+            # periodic (real) determinants: the parameters have the reference's layout — per-k blocks (nao_prim, nmo_k)
+            # concatenated over k (orbitals.py:154-160) — and are folded into supercell coefficients when pushed
+            from . import pbc as _pbc
+
+            for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
+                items[key] = np.concatenate([np.real(b) for b in self._fold["blocks"][sp]], axis=1)
+                split = np.cumsum(self._fold["nmo_k"][sp])[:-1]
+                to_device[key] = (lambda v, split=split: np.real(_pbc.fold_mo_coeff(
+                    self._mol, self._fold["kpts"], [np.split(np.asarray(v), split, axis=1)] * 2)[0]))
+        self.parameters = _DeviceParams(_dev, items, to_device)
         self._det_occup = [o.tolist() for o in _dev.det_occup]
         self._det_map = _dev.det_map
         self.dtype = _dev.cdtype  # slater.py:212-216
@@ -526,14 +544,20 @@ class Slater:
         """slater.py:462-542: d Psi / Psi w.r.t. ``det_coeff`` (nconf, ndet) and the orbital coefficients
         (nconf, nao, nmo_s); zero-sized entries are dropped like the reference does (:537-541)."""
         d = self._dev
-        if d.pbc:
-            raise NotImplementedError("orbital-coefficient gradients of periodic Slater determinants (per-k parameterisation) are not implemented yet")
+        if d.pbc and self._fold is None:
+            raise NotImplementedError("orbital-coefficient gradients of complex periodic Slater determinants are not implemented")
         W = d.W
         out = {"det_coeff": np.empty((W, d.ndet)), "mo_coeff_alpha": np.empty((W, d.nao, d.nmo[0])),
                "mo_coeff_beta": np.empty((W, d.nao, d.nmo[1]))}
         d.call("pqa_slater_pgradient", _ffi.ptr(out["det_coeff"]),
                _ffi.ptr(out["mo_coeff_alpha"]) if out["mo_coeff_alpha"].size else None,
                _ffi.ptr(out["mo_coeff_beta"]) if out["mo_coeff_beta"].size else None)
+        if self._fold is not None:  # periodic: chain rule back to the per-k blocks of the parameter (slater.py:511-527)
+            from . import pbc as _pbc
+
+            for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
+                if out[key].size:
+                    out[key] = _pbc.unfold_mo_gradient(self._mol, self._fold["kpts"], out[key], self._fold["nmo_k"][sp])
         return {k: v for k, v in out.items() if v.size}
 
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
@@ -860,14 +884,14 @@ def generate_wf(mol, mf, determinants=None, jastrow_kws=None, device=0, tol=None
     elif ion_cusp is False:
         ion_cusp = []
     abasis, bbasis = func3d.default_jastrow_basis(mol, len(ion_cusp) > 0, **kws)
-    mol, mo_coeff, determinants, twist_k = orbital_inputs(mol, mf, determinants)
+    mol, mo_coeff, determinants, twist_k, fold = orbital_inputs(mol, mf, determinants, with_fold=True)
     a3 = b3 = None
     if jastrow3:  # wftools.generate_jastrow3 (:155-162): default basis without ion cusp
         a3, b3 = func3d.default_jastrow_basis(mol, False, **dict(jastrow3_kws or {}))
     dev = DeviceWF(mol, mo_coeff=mo_coeff, determinants=determinants, a_basis=abasis, b_basis=bbasis, device=device,
                    tol=-1 if tol is None else tol, a3_basis=a3, b3_basis=b3, eval_gto_precision=eval_gto_precision,
                    image_rule=image_rule, twist_k=twist_k)
-    sl = Slater(mol, mf, _dev=dev)
+    sl = Slater(mol, mf, _dev=dev, _fold=fold)
     ja = JastrowSpin(mol, abasis, bbasis, _dev=dev)
     acoeff = np.zeros((mol.natm, len(abasis), 2))
     if ion_cusp:

@@ -1214,6 +1214,28 @@ def g_tbdm():
     save("g23_tbdm", **out)
 
 
+# ------------------------------------------------------------------ G24 parameter gradients of a periodic Slater-Jastrow
+def g_pbc_pgrad():
+    """wf.pgradient() (slater.py:462-542 with PBCOrbitalEvaluatorKpoints.pgradient orbitals.py:239-254) on the diamond
+    cells with real Bloch phases, plus the parameter arrays themselves: the orbital coefficients are per-k blocks
+    (nao_prim, nmo_k) concatenated over k."""
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    for tag, W in (("gamma", 4), ("fcc2cubic", 3)):
+        sup, wf = ref_pbc_wf(tag)
+        cfg = PeriodicConfigs(systems.initial_guess(sup, W, rng=np.random.default_rng(240)).configs.copy(), sup.lattice_vectors())
+        out[tag + "_configs"] = cfg.configs.copy()
+        wf.recompute(cfg)
+        pg = wf.pgradient()
+        out[tag + "_keys"] = np.asarray(sorted(pg.keys()))
+        for k, v in pg.items():
+            out[f"{tag}_pgrad_{k}"] = np.asarray(v)
+        for k, v in wf.parameters.items():
+            out[f"{tag}_param_{k}"] = np.asarray(v)
+    save("g24_pbc_pgrad", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1237,3 +1259,4 @@ if __name__ == "__main__":
     g_sr()
     g_obdm()
     g_tbdm()
+    g_pbc_pgrad()

@@ -430,3 +430,38 @@ def test_periodic_orbital_tile_widths_are_bitwise_identical(monkeypatch):
     for other in ("16", "64"):
         for a, b in zip(rows["32"], rows[other]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_periodic_pgradient_matches_reference(tag):
+    """pgradient() of a periodic Slater-Jastrow (slater.py:462-542, orbitals.py:239-254): the orbital coefficients are
+    exposed in the reference's layout — per-k blocks (nao_prim, nmo_k) concatenated over k — folded into supercell
+    coefficients when pushed, and the device gradient (w.r.t. the folded matrix) is mapped back by the chain rule."""
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g24_pbc_pgrad")
+    sup, wf = helpers.gpu_pbc_wf(tag)
+    for k in ("wf1det_coeff", "wf1mo_coeff_alpha", "wf1mo_coeff_beta", "wf2acoeff", "wf2bcoeff"):
+        assert np.shape(wf.parameters[k]) == g[f"{tag}_param_{k}"].shape, k
+        assert helpers.relerr(wf.parameters[k], g[f"{tag}_param_{k}"]) < 1e-13, k
+    cfg = PeriodicConfigs(g[tag + "_configs"].copy(), sup.lattice_vectors())
+    s0, l0 = wf.recompute(cfg)
+    pg = wf.pgradient()
+    assert sorted(pg.keys()) == g[tag + "_keys"].tolist()
+    for k, v in pg.items():
+        assert v.shape == g[f"{tag}_pgrad_{k}"].shape and helpers.relerr(v, g[f"{tag}_pgrad_{k}"]) < 1e-8, k
+    # assigning in the reference's layout reaches the device: same values give the same wave function, a finite
+    # difference along one coefficient reproduces its logarithmic derivative
+    wf.parameters["wf1mo_coeff_alpha"] = g[f"{tag}_param_wf1mo_coeff_alpha"].copy()
+    s1, l1 = wf.recompute(cfg)
+    assert np.array_equal(s0, s1) and np.max(np.abs(l0 - l1)) < 1e-12
+    C = g[f"{tag}_param_wf1mo_coeff_alpha"].copy()
+    mu, col, h = 5, C.shape[1] - 1, 1e-5
+    vals = []
+    for sgn in (1, -1):
+        Cp = C.copy()
+        Cp[mu, col] += sgn * h
+        wf.parameters["wf1mo_coeff_alpha"] = Cp
+        vals.append(wf.recompute(cfg)[1])
+    wf.parameters["wf1mo_coeff_alpha"] = C
+    assert np.allclose((vals[0] - vals[1]) / (2 * h), pg["wf1mo_coeff_alpha"][:, mu, col], rtol=2e-5, atol=1e-7)
