@@ -221,7 +221,7 @@ int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff);
    observables/obdm.py:175, tbdm.py:239): for ONE auxiliary position per row, the ratio Psi(electron es[i] moved there)/Psi
    for each of the ne listed electrons.  pts (nrow,3); widx (nrow) walker index per row or NULL (nrow = W);
    factors: bit 0 Slater, bit 1 two-body Jastrow, bit 2 three-body Jastrow (their product is returned);
-   out (nrow, ne). */
+   out (nrow, ne) doubles, or (nrow, ne, 2) = (re, im) on a handle with complex orbitals. */
 int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
                        int factors, double* out);
 

@@ -1003,7 +1003,6 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
 extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
                                   int factors, double* out) {
   HIPCHK(hipSetDevice(h->device));
-  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (nrow <= 0 || ne <= 0) return 0;
   if (!widx && nrow != h->W) FAIL("nrow must equal the number of walkers when widx is NULL");
@@ -1017,7 +1016,8 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
     if (e < 0 || e >= h->N) FAIL("electron index out of range");
   h->saved_valid = false;
   TRY(ensure(h, h->b_pts, (size_t)nrow * 3 * sizeof(double)));
-  TRY(ensure(h, h->b_out, (size_t)nrow * ne * sizeof(double)));
+  const size_t cf = h->cplx ? 2 : 1;  // complex handles return (re, im) pairs
+  TRY(ensure(h, h->b_out, cf * nrow * ne * sizeof(double)));
   TRY(ensure(h, h->b_tves, (size_t)ne * sizeof(int)));
   TRY(copy_in(h, h->b_pts.p, pts, (size_t)nrow * 3 * sizeof(double)));
   TRY(copy_in(h, h->b_tves.p, he.data(), (size_t)ne * sizeof(int)));
@@ -1032,11 +1032,16 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
       TRY(ensure(h, h->b_emo[s], (size_t)nrow * std::max(h->nmo[s], 1) * sizeof(double)));
       TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, nrow), nrow, 1, (double*)h->b_emo[s].p));
     }
-  hipLaunchKernelGGL(k_testvalue_many, dim3((unsigned)nrow), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js,
-                     (const int*)h->b_tves.p, ne, (const double*)h->b_pts.p, (const double*)h->b_emo[0].p,
-                     (const double*)h->b_emo[1].p, (long)nrow, dw, factors, (double*)h->b_out.p);
+  if (h->cplx)
+    hipLaunchKernelGGL(k_testvalue_many<true>, dim3((unsigned)nrow), dim3(64), 2 * lds_det(h, 1), h->stream, h->S, h->st, h->js,
+                       (const int*)h->b_tves.p, ne, (const double*)h->b_pts.p, (const double*)h->b_emo[0].p,
+                       (const double*)h->b_emo[1].p, (long)nrow, dw, factors, (double*)h->b_out.p);
+  else
+    hipLaunchKernelGGL(k_testvalue_many<false>, dim3((unsigned)nrow), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js,
+                       (const int*)h->b_tves.p, ne, (const double*)h->b_pts.p, (const double*)h->b_emo[0].p,
+                       (const double*)h->b_emo[1].p, (long)nrow, dw, factors, (double*)h->b_out.p);
   TRY(check_launch(h, "k_testvalue_many"));
-  return copy_out(h, out, h->b_out.p, (size_t)nrow * ne * sizeof(double));
+  return copy_out(h, out, h->b_out.p, cf * nrow * ne * sizeof(double));
 }
 
 extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn) {

@@ -9,6 +9,7 @@
 #include "pqa_common.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_slater.hpp"
+#include "pqa_cslater.hpp"
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // out rows: ke, ee, ei, grad2 each (W).  LDS: max(ndet_s)*5 doubles (multi-determinant scratch).
@@ -594,6 +595,7 @@ __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, Ja
 // (Slater.testvalue_many slater.py:448-460, JastrowSpin.testvalue_many jastrowspin.py:421-455, ThreeBodyJastrow
 // three_body_jastrow.py:343-372, product multiplywf.py:112-114).  factors: bit 0 Slater, bit 1 two-body, bit 2 three-body.
 // mo_up / mo_dn: [nrow][nmo_s] orbital values at the auxiliary positions.  Block = one wave per row.
+template <bool CX>
 __global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st, JastrowState js, const int* __restrict__ es, int ne,
                                                        const double* __restrict__ pts, const double* __restrict__ mo_up,
                                                        const double* __restrict__ mo_dn, long nrow,
@@ -606,11 +608,17 @@ __global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st,
   const int parts = (factors >> 1) & 3;
   for (int idx = 0; idx < ne; ++idx) {
     const int e = es[idx], s = e >= S.nup, i = e - s * S.nup;
-    double val = 1.0;
+    double vr = 1.0, vi = 0.0;  // CX: complex determinant ratio (rows [Re | Im]), real Jastrow factor
     if (factors & 1) {
-      double r1[1];
-      slater_ratios<1>(S, st, s, i, w, (s ? mo_dn : mo_up) + (size_t)r * S.nmo[s], r1, lds);
-      val *= r1[0];
+      if (CX) {
+        cx r1[1];
+        slater_ratios_c<1>(S, st, s, i, w, (s ? mo_dn : mo_up) + (size_t)r * S.nmo[s], r1, lds);
+        vr = r1[0].r; vi = r1[0].i;
+      } else {
+        double r1[1];
+        slater_ratios<1>(S, st, s, i, w, (s ? mo_dn : mo_up) + (size_t)r * S.nmo[s], r1, lds);
+        vr = r1[0];
+      }
       __syncthreads();
     }
     if (parts) {
@@ -619,8 +627,12 @@ __global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st,
       __syncthreads();
       jas_eval<0>(S, xw, e, px, py, pz, U, g, lp, parts, lds + S.j3_off);
       __syncthreads();
-      val *= exp(U - U0);
+      const double f = exp(U - U0);
+      vr *= f; vi *= f;
     }
-    if (threadIdx.x == 0) out[(size_t)r * ne + idx] = val;
+    if (threadIdx.x == 0) {
+      if (CX) { out[2 * ((size_t)r * ne + idx)] = vr; out[2 * ((size_t)r * ne + idx) + 1] = vi; }
+      else out[(size_t)r * ne + idx] = vr;
+    }
   }
 }

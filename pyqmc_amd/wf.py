@@ -394,10 +394,11 @@ def _testvalue_many(dev, factors, e, epos, mask):
         widx = np.ascontiguousarray(np.nonzero(mask)[0], dtype=np.int32)
         x = x[mask]
     pts = np.ascontiguousarray(x)
-    out = np.empty((len(pts), len(es)))
+    cplx = bool(getattr(dev, "cplx", False)) and bool(factors & 1)  # complex determinant ratios; Jastrow factors stay real
+    out = np.empty((len(pts), len(es)), dtype=complex if getattr(dev, "cplx", False) else float)
     if len(pts) and len(es):
         dev.call("pqa_testvalue_many", _ffi.ptr(es), len(es), _ffi.ptr(pts), len(pts), _ffi.ptr(widx), int(factors), _ffi.ptr(out))
-    return out
+    return out if cplx else np.real(out)
 
 
 def orbital_inputs(mol, mf, determinants=None, with_fold=False):

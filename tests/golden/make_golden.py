@@ -1236,6 +1236,30 @@ def g_pbc_pgrad():
     save("g24_pbc_pgrad", **out)
 
 
+# ------------------------------------------------------------------ G25 testvalue_many with complex determinants
+def g_complex_testvalue_many():
+    """testvalue_many (slater.py:448-460, multiplywf.py:112-114) for complex Bloch orbitals at zero twist and for a
+    twisted cell, auxiliary positions inside and outside the cell (wrap phase of the moved electron)."""
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    sup, mf, Ls, oe, sl, j2, wf = ref_pbc_wf_complex()
+    cases = {"cplx": (sup, sl, j2, wf, 3, np.array([0, 5, 6, 11]))}
+    sup2, mf2, Ls2, oe2, sl2, j22, wf2, W2, el2 = ref_twisted_wf("s211")
+    cases["twist"] = (sup2, sl2, j22, wf2, 3, np.array([1, 7, 8, 15]))
+    for tag, (cell, slater, jas, full, W, es) in cases.items():
+        rng = np.random.default_rng(250 + len(out))
+        cfg = PeriodicConfigs(systems.initial_guess(cell, W, rng=rng).configs.copy(), cell.lattice_vectors())
+        out[tag + "_configs"], out[tag + "_wrap"] = cfg.configs.copy(), cfg.wrap.copy()
+        full.recompute(cfg)
+        aux = (rng.random((W, 3)) * 4 - 1.5) @ cell.lattice_vectors()
+        out[tag + "_aux"], out[tag + "_es"] = aux, es
+        epos = cfg.make_irreducible(0, aux)
+        for nm, w in (("slater", slater), ("j2", jas), ("wf", full)):
+            out[f"{tag}_{nm}"] = np.asarray(w.testvalue_many(es, epos))
+    save("g25_complex_testvalue_many", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1260,3 +1284,4 @@ if __name__ == "__main__":
     g_obdm()
     g_tbdm()
     g_pbc_pgrad()
+    g_complex_testvalue_many()

@@ -465,3 +465,33 @@ def test_periodic_pgradient_matches_reference(tag):
         vals.append(wf.recompute(cfg)[1])
     wf.parameters["wf1mo_coeff_alpha"] = C
     assert np.allclose((vals[0] - vals[1]) / (2 * h), pg["wf1mo_coeff_alpha"][:, mu, col], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["cplx", "twist"])
+def test_complex_testvalue_many_matches_reference(tag):
+    """testvalue_many with complex determinants (k_testvalue_many<true>: complex ratio dots on [Re | Im] orbital rows, real
+    Jastrow factor): complex Bloch coefficients at zero twist and a twisted 2x1x1 cell, auxiliary positions inside and
+    outside the cell (the handle derives the moved electron's wrap phase from the unfolded position)."""
+    import pyqmc_amd as pa
+    from helpers import pbc_complex_case
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g25_complex_testvalue_many")
+    if tag == "cplx":
+        sup, mf = pbc_complex_case()
+        wf = pa.generate_wf(sup, mf)
+        wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = pbc_jastrow_coeffs(sup)
+    else:
+        sup, wf = _gpu_twisted_wf("s211")
+    cfg = PeriodicConfigs(g[tag + "_configs"].copy(), sup.lattice_vectors(), wrap=g[tag + "_wrap"].copy())
+    wf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g[tag + "_aux"])
+    es = g[tag + "_es"]
+    for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("wf", wf)):
+        got = w.testvalue_many(es, epos)
+        assert got.dtype == g[f"{tag}_{nm}"].dtype and got.shape == g[f"{tag}_{nm}"].shape, nm
+        assert helpers.relerr(got, g[f"{tag}_{nm}"]) < 2e-9, nm
+    # column i equals testvalue(es[i]); a mask returns the masked rows
+    assert helpers.relerr(wf.testvalue_many(np.array([int(es[1])]), epos)[:, 0], wf.testvalue(int(es[1]), epos)[0]) < 1e-12
+    mask = np.array([True, False, True])
+    assert np.array_equal(wf.testvalue_many(es, epos, mask=mask), wf.testvalue_many(es, epos)[mask])

@@ -377,3 +377,15 @@ def test_unfold_mo_gradient_is_the_adjoint_of_fold_mo_coeff():
     lhs = np.einsum("ab,wab->w", folded, Y)
     rhs = np.einsum("ab,wab->w", np.concatenate(X, axis=1), back)
     assert np.allclose(lhs, rhs, rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_complex_testvalue_many_matches_reference():
+    """testvalue_many of the complex 3x1x1 wave function (tests/golden/g25_complex_testvalue_many.npz): pins the oracle's
+    complex ratio path used by the density-matrix accumulators; the device twin is in tests/test_gpu_pbc.py."""
+    g19, g = golden("g19_pbc_complex"), golden("g25_complex_testvalue_many")
+    sup, wf = _oracle_complex_wf(g19)
+    cfg = pc.PeriodicConfigs(g["cplx_configs"].copy(), sup.lattice_vectors(), wrap=g["cplx_wrap"].copy())
+    wf.recompute(cfg)
+    epos = cfg.make_irreducible(0, g["cplx_aux"])
+    for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("wf", wf)):
+        assert relerr(w.testvalue_many(g["cplx_es"], epos), g[f"cplx_{nm}"]) < 1e-9, nm
