@@ -41,7 +41,9 @@ __device__ __forceinline__ void load_point(const PointAddr& a, long p, double& x
 
 // Evaluate one contracted shell at displacement (x,y,z) from its centre and hand each of its
 // 2l+1 functions to sink(m, value, dx, dy, dz, lap).  NCOMP = 1 | 4 | 5 selects how much is computed.
-template <int NCOMP, class Sink>
+// LMAX < 3 compiles the f-shell branch out (callers that know the basis has none: its seven functions set the register
+// high-water mark of the routine).
+template <int NCOMP, int LMAX = 3, class Sink>
 __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, const double* __restrict__ pexp,
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
   const double r2 = x * x + y * y + z * z;
@@ -80,7 +82,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
       EMIT(3, SH_DXY * x * z, SH_DXY * z, 0.0, SH_DXY * x);
       EMIT(4, SH_DX2 * (x * x - y * y), 2.0 * SH_DX2 * x, -2.0 * SH_DX2 * y, 0.0);
       break;
-    default: {  // l == 3
+    default: if (LMAX >= 3) {  // l == 3
       const double x2 = x * x, y2 = y * y, z2 = z * z;
       EMIT(0, SH_F3 * y * (3.0 * x2 - y2), SH_F3 * 6.0 * x * y, SH_F3 * 3.0 * (x2 - y2), 0.0);
       EMIT(1, SH_F2 * x * y * z, SH_F2 * y * z, SH_F2 * x * z, SH_F2 * x * y);

@@ -22,13 +22,14 @@
 #include "pqa_vmc.hpp"
 
 #define PQA_TILE_NW 16      // walkers (waves) per block
-#define PQA_TILE_KT 96      // AO rows per pass of the orbital evaluation
+#define PQA_TILE_KT 64      // AO rows per pass of the orbital evaluation
 #define PQA_TILE_MAXPASS 8
 
 struct TileTab {
   int npass;
   int pass_chunk[PQA_TILE_MAXPASS + 1];  // chunk range of each pass (chunks of the ncomp = 5 table, rows <= KT per pass)
   int nmo_pad;                           // 16 * nt
+  int rows_pad;                          // padded AO rows of the coefficient matrices (all chunks)
 };
 
 // dynamic LDS layout (doubles unless noted)
@@ -36,28 +37,56 @@ struct TileLds {
   double* xs;      // [NW][3 N]        coordinates
   double* tile;    // [5][KT][16]      AO tile of one pass
   double* rnew;    // [NW][5][nmo_pad] orbital rows at the proposals
-  double* rold;    // [NW][5][nmo_pad] cached rows of the current positions (staging)
+  double* rold;    // [NW][5][nmo_pad] cached rows of the current positions: ALIASES the AO tile (free during the proposal)
+  double* Cs;      // [rows_pad][nmo_pad] coefficient matrix of the current spin (B operand of the MFMA phase)
+  double* wsc;     // [NW][16] per-wave scalars parked across the orbital phase: z (3), drift (3), U0, proposal (3), sign, log, r2 sums
   double* sh_xyz;  // [nshell][3]
   double* pr_exp;  // [nprim]
   double* pr_coef; // [nprim]
-  int* sh_meta;    // [nshell][4]: l, nprim, first primitive, tile row (chunk row0 + row in chunk)
+  int* sh_meta;    // [nshell][4]: l, nprim, first primitive, absolute padded AO row (chunk row0 + row in chunk)
+  int* sh_list;    // [nshell] shells in chunk order (the order of ChunkTab::cw_shell[0])
   int* occ;        // [2][32]
 };
-__host__ __device__ inline size_t tile_lds_bytes(int N, int nmo_pad, int nshell, int nprim) {
-  size_t d = (size_t)PQA_TILE_NW * 3 * N + 5 * PQA_TILE_KT * 16 + 2 * (size_t)PQA_TILE_NW * 5 * nmo_pad + 3 * (size_t)nshell + 2 * (size_t)nprim;
-  return d * sizeof(double) + ((size_t)4 * nshell + 64) * sizeof(int);
+__host__ __device__ inline size_t tile_lds_bytes(int N, int nmo_pad, int nshell, int nprim, int rows_pad) {
+  size_t d = (size_t)PQA_TILE_NW * 3 * N + 5 * PQA_TILE_KT * 16 + (size_t)PQA_TILE_NW * 5 * nmo_pad + (size_t)rows_pad * nmo_pad +
+             3 * (size_t)nshell + 2 * (size_t)nprim + (size_t)PQA_TILE_NW * 16;
+  return d * sizeof(double) + ((size_t)5 * nshell + 64) * sizeof(int);
 }
 
-// dot of an orbital row (slot order through occ) with the register inverse: returns sum_k row[occ[k]] T[j][k] for the
-// lane's own row j (both halves of the wave hold the full sum)
-__device__ __forceinline__ double tile_rowdot(const double* __restrict__ row, const int* __restrict__ occ, const double (&t)[16], int h) {
-  double s = 0.0;
+// dots of the value and gradient rows (slot order through occ) with the register inverse: d[c] = sum_k row_c[occ[k]] T[j][k]
+// for the lane's own electron row j, c = value, d/dx, d/dy, d/dz (both halves of the wave end up with the full sums).
+// One pass over the 16 columns serves the four rows: four separate passes let the scheduler hoist 4 x 32 LDS loads at once,
+// which alone overflowed the 128-register budget.
+__device__ __forceinline__ void tile_rowdots4(const double* __restrict__ rows, int nmo_pad, const int* __restrict__ occ, const double (&t)[16],
+                                              int h, double (&d)[4]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) s += row[occ[16 * h + q]] * t[q];
-  return s + __shfl_xor(s, 32, 64);
+  for (int q = 0; q < 16; ++q) {
+    const double* r = rows + occ[16 * h + q];
+    const double tq = t[q];
+    s0 += r[0] * tq; s1 += r[nmo_pad] * tq; s2 += r[2 * nmo_pad] * tq; s3 += r[3 * nmo_pad] * tq;
+  }
+  d[0] = s0 + __shfl_xor(s0, 32, 64); d[1] = s1 + __shfl_xor(s1, 32, 64);
+  d[2] = s2 + __shfl_xor(s2, 32, 64); d[3] = s3 + __shfl_xor(s3, 32, 64);
 }
 
-template <bool DMC>
+// The sweep's random numbers, drawn ahead of it from the same Philox streams the other sweep kernels use (so the three
+// paths make the same decisions): gauss [N][W][3] standard normals, unif [N][W].  Keeping Box-Muller (sincos, log) out of
+// k_sweep_tile matters: its argument reduction alone costs that kernel dozens of spilled registers.
+__global__ __launch_bounds__(256) void k_tile_draws(uint64_t seed, uint32_t step, int N, long W, double* __restrict__ gauss, double* __restrict__ unif) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * W) return;
+  const int e = (int)(idx / W);
+  const long w = idx - (long)e * W;
+  double z0, z1, z2, z3;
+  normal2(philox(seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, step), z0, z1);
+  normal2(philox(seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, step), z2, z3);
+  gauss[3 * idx] = z0; gauss[3 * idx + 1] = z1; gauss[3 * idx + 2] = z2;
+  const Philox p = philox(seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, step);
+  unif[idx] = u01(p.c[0], p.c[1]);
+}
+
+template <bool DMC, int LMAX>
 __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, ChunkTab T, TileTab TT,
                                                      int has_jastrow, long W) {
   extern __shared__ double lds_raw[];
@@ -67,12 +96,15 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
   L.xs = lds_raw;
   L.tile = L.xs + (size_t)PQA_TILE_NW * 3 * N;
   L.rnew = L.tile + 5 * PQA_TILE_KT * 16;
-  L.rold = L.rnew + (size_t)PQA_TILE_NW * 5 * nmo_pad;
-  L.sh_xyz = L.rold + (size_t)PQA_TILE_NW * 5 * nmo_pad;
+  L.rold = L.tile;
+  L.Cs = L.rnew + (size_t)PQA_TILE_NW * 5 * nmo_pad;
+  L.wsc = L.Cs + (size_t)TT.rows_pad * nmo_pad;
+  L.sh_xyz = L.wsc + (size_t)PQA_TILE_NW * 16;
   L.pr_exp = L.sh_xyz + 3 * (size_t)S.nshell;
   L.pr_coef = L.pr_exp + S.nprim;
   L.sh_meta = (int*)(L.pr_coef + S.nprim);
-  L.occ = L.sh_meta + 4 * (size_t)S.nshell;
+  L.sh_list = L.sh_meta + 4 * (size_t)S.nshell;
+  L.occ = L.sh_list + S.nshell;
 
   const long w_raw = (long)blockIdx.x * PQA_TILE_NW + wv;
   const bool live = w_raw < W;
@@ -84,7 +116,13 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
     L.sh_meta[4 * sh] = S.shell_l[sh];
     L.sh_meta[4 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
     L.sh_meta[4 * sh + 2] = S.shell_prim_off[sh];
-    L.sh_meta[4 * sh + 3] = T.shell_kb[sh];  // row inside its chunk; the chunk's row0 is added per pass
+  }
+  for (int pos = tid; pos < S.nshell; pos += 1024) {  // cw_shell[0] lists every shell once, chunk by chunk
+    const int sh = T.cw_shell[0][pos];
+    int ch = 0;
+    while (pos >= T.cw_off[0][4 * (ch + 1)]) ++ch;
+    L.sh_list[pos] = sh;
+    L.sh_meta[4 * sh + 3] = T.chunk_row0[ch] + T.shell_kb[sh];
   }
   for (int p = tid; p < S.nprim; p += 1024) { L.pr_exp[p] = S.prim_exp[p]; L.pr_coef[p] = S.prim_coef[p]; }
   for (int k = tid; k < 64; k += 1024) {
@@ -105,9 +143,11 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
   const int i16 = lane & 15, kq = lane >> 4;
   const int mc = wv % 5, mu = wv / 5;  // MFMA role of waves 0..9: component mc, orbital tile mu
   int n_acc = 0;
-  double r2p = 0.0, r2a = 0.0;
+  double* ws = L.wsc + (size_t)wv * 16;
+  if (lane == 0) { ws[12] = 0.0; ws[13] = 0.0; }  // r2 sums (DMC)
 
-  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {  // unrolled: st.T[s], T.cpad[s], S.nmo[s] ... become static selections of kernel arguments
     const int n = s ? S.ndn : S.nup, nmo = S.nmo[s];
     if (n == 0) continue;
     const int* occ = L.occ + 32 * s;
@@ -118,9 +158,12 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
 #pragma unroll
       for (int q = 0; q < 16; ++q) t[q] = (j < n && 16 * h + q < n) ? Tg[(size_t)j * n + 16 * h + q] : 0.0;
     }
-    double dsign = st.dsign[s][w], dlog = st.dlog[s][w];
-    const double* __restrict__ C = T.cpad[s];
+    if (lane == 0) { ws[10] = st.dsign[s][w]; ws[11] = st.dlog[s][w]; }
     const int ldc = T.ldc[s];
+    __syncthreads();  // (the previous spin's MFMA reads of Cs are done)
+    for (int k = tid; k < TT.rows_pad * ldc; k += 1024) L.Cs[k] = T.cpad[s][k];
+    __syncthreads();
+    const double* __restrict__ C = L.Cs;
     const bool mfma_wave = wv < 10 && 16 * mu < nmo_pad;
 
     for (int i = 0; i < n; ++i) {
@@ -130,13 +173,13 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
         const double* cg = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
         for (int k = lane; k < 5 * nmo; k += 64) rold[(k / nmo) * nmo_pad + (k % nmo)] = cg[k];
       }
+      {  // scope: everything the later phases need is parked in ws (LDS), nothing stays in registers
       const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
       double gx, gy, gz, U0 = 0.0;
       {
-        const double r0 = __shfl(tile_rowdot(rold, occ, t, h), i, 64);
-        const double r1 = __shfl(tile_rowdot(rold + nmo_pad, occ, t, h), i, 64);
-        const double r2 = __shfl(tile_rowdot(rold + 2 * nmo_pad, occ, t, h), i, 64);
-        const double r3 = __shfl(tile_rowdot(rold + 3 * nmo_pad, occ, t, h), i, 64);
+        double d4_[4];
+        tile_rowdots4(rold, nmo_pad, occ, t, h, d4_);
+        const double r0 = __shfl(d4_[0], i, 64), r1 = __shfl(d4_[1], i, 64), r2 = __shfl(d4_[2], i, 64), r3 = __shfl(d4_[3], i, 64);
         gx = finite_or(r1 / r0, 0.0); gy = finite_or(r2 / r0, 0.0); gz = finite_or(r3 / r0, 0.0);
       }
 #ifndef PQA_TILE_ABL_NOJAS
@@ -147,18 +190,19 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
       }
 #endif
       if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else limdrift3(gx, gy, gz);
-      double z0, z1, z2, z3;
-      if (mb.gauss) {
+      double z0, z1, z2;  // standard normals of this move: the replay tape, or what k_tile_draws generated from the Philox streams
+      {
         const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
         z0 = zt[0]; z1 = zt[1]; z2 = zt[2];
-      } else {
-        normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
-        normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
       }
       const double sq = sqrt(mb.tstep), df = DMC ? 1.0 : mb.tstep;
       z0 *= sq; z1 *= sq; z2 *= sq;
-      const double nx = ex + z0 + gx * df, ny = ey + z1 + gy * df, nz = ez + z2 + gz * df;
-      if (lane == 0) { rnew[0] = nx; rnew[1] = ny; rnew[2] = nz; }  // the proposal travels through rnew's first slots
+      if (lane == 0) {
+        const double nx = ex + z0 + gx * df, ny = ey + z1 + gy * df, nz = ez + z2 + gz * df;
+        rnew[0] = nx; rnew[1] = ny; rnew[2] = nz;  // the proposal travels through rnew's first slots
+        ws[0] = z0; ws[1] = z1; ws[2] = z2; ws[3] = gx; ws[4] = gy; ws[5] = gz; ws[6] = U0; ws[7] = nx; ws[8] = ny; ws[9] = nz;
+      }
+      }
       __syncthreads();
       // ================= orbital rows at the 16 proposals of the block (k_orb's two phases on a 16-point tile)
       double px, py, pz;
@@ -174,15 +218,11 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
         const int s_lo = T.cw_off[0][4 * ch0], s_hi = T.cw_off[0][4 * ch1];
 #ifndef PQA_TILE_ABL_NOAO
         for (int it = tid; it < (s_hi - s_lo) * 16; it += 1024) {
-          const int sh = T.cw_shell[0][s_lo + (it >> 4)];
-          // chunk of the shell: its rows start at chunk_row0[chunk]; shell_kb is relative to the chunk.  The shells of a
-          // pass are listed chunk by chunk, so the chunk index is recovered from the running offsets.
-          int ch = ch0;
-          while (s_lo + (it >> 4) >= T.cw_off[0][4 * (ch + 1)]) ++ch;
-          const int krow = T.chunk_row0[ch] - row_base + L.sh_meta[4 * sh + 3];
+          const int sh = L.sh_list[s_lo + (it >> 4)];
+          const int krow = L.sh_meta[4 * sh + 3] - row_base;
           const int l_ = L.sh_meta[4 * sh], np_ = L.sh_meta[4 * sh + 1], q0 = L.sh_meta[4 * sh + 2];
           const int pl = it & 15;
-          shell_eval<5>(l_, px - L.sh_xyz[3 * sh], py - L.sh_xyz[3 * sh + 1], pz - L.sh_xyz[3 * sh + 2], L.pr_exp + q0, L.pr_coef + q0, np_,
+          shell_eval<5, LMAX>(l_, px - L.sh_xyz[3 * sh], py - L.sh_xyz[3 * sh + 1], pz - L.sh_xyz[3 * sh + 2], L.pr_exp + q0, L.pr_coef + q0, np_,
                         [&](int m, double v, double ax, double ay, double az, double lp) {
                           double* tl = L.tile + (size_t)(krow + m) * 16 + pl;
                           tl[0] = v; tl[PQA_TILE_KT * 16] = ax; tl[2 * PQA_TILE_KT * 16] = ay; tl[3 * PQA_TILE_KT * 16] = az;
@@ -209,27 +249,29 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
       }
       __syncthreads();
       // ================= Metropolis at the proposal
-      const double tmp0 = tile_rowdot(rnew, occ, t, h);  // sum_k V[k] T[j][k] for the lane's row: reused by the update
+      double dn[4];
+      tile_rowdots4(rnew, nmo_pad, occ, t, h, dn);
+      const double tmp0 = dn[0];  // sum_k V[k] T[j][k] for the lane's row: reused by the update
       double val2, sgn = 1.0, hx, hy, hz;
       const double dr = __shfl(tmp0, i, 64);
       {
-        const double r1 = __shfl(tile_rowdot(rnew + nmo_pad, occ, t, h), i, 64);
-        const double r2 = __shfl(tile_rowdot(rnew + 2 * nmo_pad, occ, t, h), i, 64);
-        const double r3 = __shfl(tile_rowdot(rnew + 3 * nmo_pad, occ, t, h), i, 64);
+        const double r1 = __shfl(dn[1], i, 64), r2 = __shfl(dn[2], i, 64), r3 = __shfl(dn[3], i, 64);
         hx = finite_or(r1 / dr, 0.0); hy = finite_or(r2 / dr, 0.0); hz = finite_or(r3 / dr, 0.0);
         const double v = finite_or(dr, 1.0);
         val2 = v * v;
         sgn = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
       }
+      const double nx = ws[7], ny = ws[8], nz = ws[9];
 #ifndef PQA_TILE_ABL_NOJAS
       if (has_jastrow) {
         double g[3], lp, U;
         jas_eval<1, false>(S, xw, e, nx, ny, nz, U, g, lp, 1);
         hx += g[0]; hy += g[1]; hz += g[2];
-        const double ej = exp(U - U0);
+        const double ej = exp(U - ws[6]);
         val2 *= ej * ej;
       }
 #endif
+      const double z0 = ws[0], z1 = ws[1], z2 = ws[2], gx = ws[3], gy = ws[4], gz = ws[5];
       double bx, by, bz;
       if (DMC) {
         limdrift_dmc(hx, hy, hz, mb.tstep);
@@ -241,17 +283,12 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
       const double fwd = z0 * z0 + z1 * z1 + z2 * z2, bwd = bx * bx + by * by + bz * bz;
       double ratio = val2 * exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
       if (DMC) ratio *= sgn;
-      double u;
-      if (mb.unif) u = mb.unif[(size_t)e * W + w];
-      else {
-        const Philox p = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
-        u = u01(p.c[0], p.c[1]);
-      }
+      const double u = mb.unif[(size_t)e * W + w];
       const bool accd = ratio > u;  // wave-uniform: every lane computed the same numbers
-      if (DMC) {
+      if (DMC && lane == 0) {
         const double r2 = (z0 + gx) * (z0 + gx) + (z1 + gy) * (z1 + gy) + (z2 + gz) * (z2 + gz);
-        r2p += r2;
-        if (accd) r2a += r2;
+        ws[12] += r2;
+        if (accd) ws[13] += r2;
       }
       if (live && lane == 0 && mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = accd;
       if (accd) {
@@ -263,13 +300,15 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
           const double R = __shfl(t[q], i + 32 * h, 64) * inv;
           t[q] = (j == i) ? R : t[q] - R * tmp0;
         }
-        dsign *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
-        dlog += log(fabs(dr));
+        if (lane == 0) {
+          ws[10] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+          ws[11] += log(fabs(dr));
+          xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz;
+        }
         if (live) {
           double* cg = st.cache[s] + ((size_t)w * n + i) * 5 * nmo;
           for (int k = lane; k < 5 * nmo; k += 64) cg[k] = rnew[(k / nmo) * nmo_pad + (k % nmo)];
         }
-        if (lane == 0) { xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz; }
       }
       __syncthreads();  // rnew / xw settled before the next electron's proposal reuses them
     }
@@ -278,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
 #pragma unroll
       for (int q = 0; q < 16; ++q)
         if (j < n && 16 * h + q < n) Tg[(size_t)j * n + 16 * h + q] = t[q];
-      if (lane == 0) { st.dsign[s][w] = dsign; st.dlog[s][w] = dlog; }
+      if (lane == 0) { st.dsign[s][w] = ws[10]; st.dlog[s][w] = ws[11]; }
     }
   }
   if (live) {
@@ -286,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
     for (int k = lane; k < 3 * N; k += 64) xg[k] = xw[k];
     if (lane == 0) {
       mb.acc_w[w] += n_acc;
-      if (DMC) { mb.r2_prop[w] += r2p; mb.r2_acc[w] += r2a; }
+      if (DMC) { mb.r2_prop[w] += ws[12]; mb.r2_acc[w] += ws[13]; }
     }
   }
 }
