@@ -1586,7 +1586,7 @@ static int sweep_tile(pqa_handle* h, const MoveBuf& mb_in) {
     TT.pass_chunk[++TT.npass] = ch;
   }
   const size_t lds = tile_lds_bytes(h->N, TT.nmo_pad, h->nshell, (int)h->S.nprim, TT.rows_pad);
-  const dim3 grid((unsigned)((h->W + PQA_TILE_NW - 1) / PQA_TILE_NW)), block(1024);
+  const dim3 grid((unsigned)((h->W + PQA_TILE_NW - 1) / PQA_TILE_NW)), block(PQA_TILE_NT);
   int lmax = 0;
   for (int sh = 0; sh < h->nshell; ++sh) lmax = std::max(lmax, h->shell_l[sh]);
   if (!h->tile_attr_set) {

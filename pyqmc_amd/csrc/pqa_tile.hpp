@@ -3,10 +3,10 @@
 // The lane-per-walker sweep (pqa_lw.hpp) launches six kernels per electron and streams every walker's inverse through
 // HBM once per move (k_commit_lw, 31 % of the step) and its coordinates and orbital rows twice (k_move_part_lw, 25 %).
 // Walkers are independent Markov chains, so nothing forces a global synchronisation between electrons: here a block of
-// 16 waves owns 16 walkers for the whole sweep,
+// PQA_TILE_NW waves owns as many walkers for the whole sweep,
 //   * wave = walker: the transposed inverse T[j][k] of the current spin lives in REGISTERS (lane = electron row j and
 //     column half h, 16 doubles per lane for n <= 32), the walker's coordinates in LDS;
-//   * block = one 16-point MFMA tile: the orbital rows at the 16 proposals are evaluated cooperatively exactly like
+//   * block = one (partly filled) 16-point MFMA tile: the orbital rows at the block's proposals are evaluated cooperatively like
 //     k_orb does it (phase 1: thread = (shell, point) -> LDS AO tile; phase 2: v_mfma_f64_16x16x4_f64 against the padded
 //     coefficient matrix), the result never leaves LDS;
 //   * per electron: drift from the cached orbital row (HBM, 1.3 KB) and the register inverse, Jastrow sums from LDS
@@ -21,7 +21,10 @@
 #include "pqa_jastrow.hpp"
 #include "pqa_vmc.hpp"
 
-#define PQA_TILE_NW 16      // walkers (waves) per block
+#ifndef PQA_TILE_NW
+#define PQA_TILE_NW 12      // walkers (waves) per block: 16 -> 128 VGPRs per lane (spills), 12 -> 168 (best measured), 8 -> 256, no spills (A/B via -DPQA_TILE_NW)
+#endif
+#define PQA_TILE_NT (64 * PQA_TILE_NW)
 #define PQA_TILE_KT 64      // AO rows per pass of the orbital evaluation
 #define PQA_TILE_MAXPASS 8
 
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void k_tile_draws(uint64_t seed, uint32_t step
 }
 
 template <bool DMC, int LMAX>
-__global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, ChunkTab T, TileTab TT,
+__global__ __launch_bounds__(PQA_TILE_NT) void k_sweep_tile(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, ChunkTab T, TileTab TT,
                                                      int has_jastrow, long W) {
   extern __shared__ double lds_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -110,26 +113,26 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
   const bool live = w_raw < W;
   const long w = live ? w_raw : W - 1;  // tail waves shadow the last walker and write nothing
   // ---- stage tables, coordinates; clear the AO tile (its K-padding rows are never written again)
-  for (int sh = tid; sh < S.nshell; sh += 1024) {
+  for (int sh = tid; sh < S.nshell; sh += PQA_TILE_NT) {
     const int ia = S.shell_atom[sh];
     L.sh_xyz[3 * sh] = S.atom_xyz[3 * ia]; L.sh_xyz[3 * sh + 1] = S.atom_xyz[3 * ia + 1]; L.sh_xyz[3 * sh + 2] = S.atom_xyz[3 * ia + 2];
     L.sh_meta[4 * sh] = S.shell_l[sh];
     L.sh_meta[4 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
     L.sh_meta[4 * sh + 2] = S.shell_prim_off[sh];
   }
-  for (int pos = tid; pos < S.nshell; pos += 1024) {  // cw_shell[0] lists every shell once, chunk by chunk
+  for (int pos = tid; pos < S.nshell; pos += PQA_TILE_NT) {  // cw_shell[0] lists every shell once, chunk by chunk
     const int sh = T.cw_shell[0][pos];
     int ch = 0;
     while (pos >= T.cw_off[0][4 * (ch + 1)]) ++ch;
     L.sh_list[pos] = sh;
     L.sh_meta[4 * sh + 3] = T.chunk_row0[ch] + T.shell_kb[sh];
   }
-  for (int p = tid; p < S.nprim; p += 1024) { L.pr_exp[p] = S.prim_exp[p]; L.pr_coef[p] = S.prim_coef[p]; }
-  for (int k = tid; k < 64; k += 1024) {
+  for (int p = tid; p < S.nprim; p += PQA_TILE_NT) { L.pr_exp[p] = S.prim_exp[p]; L.pr_coef[p] = S.prim_coef[p]; }
+  for (int k = tid; k < 64; k += PQA_TILE_NT) {
     const int s = k >> 5, q = k & 31, n = s ? S.ndn : S.nup;
     L.occ[k] = q < n ? S.det_occ[s][q] : 0;
   }
-  for (int k = tid; k < 5 * PQA_TILE_KT * 16; k += 1024) L.tile[k] = 0.0;
+  for (int k = tid; k < 5 * PQA_TILE_KT * 16; k += PQA_TILE_NT) L.tile[k] = 0.0;
   double* xw = L.xs + (size_t)wv * 3 * N;
   {
     const double* xg = js.x + (size_t)w * N * 3;
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
   double* rnew = L.rnew + (size_t)wv * 5 * nmo_pad;
   double* rold = L.rold + (size_t)wv * 5 * nmo_pad;
   const int i16 = lane & 15, kq = lane >> 4;
-  const int mc = wv % 5, mu = wv / 5;  // MFMA role of waves 0..9: component mc, orbital tile mu
+  // MFMA roles: (component c, orbital tile u) = (role % 5, role / 5), role = wv, wv + NW, ...  (10 roles for 32 orbitals)
+  constexpr int NROLE = (10 + PQA_TILE_NW - 1) / PQA_TILE_NW;
   int n_acc = 0;
   double* ws = L.wsc + (size_t)wv * 16;
   if (lane == 0) { ws[12] = 0.0; ws[13] = 0.0; }  // r2 sums (DMC)
@@ -161,10 +165,10 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
     if (lane == 0) { ws[10] = st.dsign[s][w]; ws[11] = st.dlog[s][w]; }
     const int ldc = T.ldc[s];
     __syncthreads();  // (the previous spin's MFMA reads of Cs are done)
-    for (int k = tid; k < TT.rows_pad * ldc; k += 1024) L.Cs[k] = T.cpad[s][k];
+    for (int k = tid; k < TT.rows_pad * ldc; k += PQA_TILE_NT) L.Cs[k] = T.cpad[s][k];
     __syncthreads();
     const double* __restrict__ C = L.Cs;
-    const bool mfma_wave = wv < 10 && 16 * mu < nmo_pad;
+    const int nrole = 5 * (nmo_pad / 16);
 
     for (int i = 0; i < n; ++i) {
       const int e = s * S.nup + i;
@@ -207,21 +211,23 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
       // ================= orbital rows at the 16 proposals of the block (k_orb's two phases on a 16-point tile)
       double px, py, pz;
       {
-        const double* pr = L.rnew + (size_t)(tid & 15) * 5 * nmo_pad;
+        const double* pr = L.rnew + (size_t)(tid % PQA_TILE_NW) * 5 * nmo_pad;  // thread's point in phase 1: tid mod NW
         px = pr[0]; py = pr[1]; pz = pr[2];
       }
       __syncthreads();  // every thread holds its point: rnew may now be overwritten
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      d4 acc[NROLE];
+#pragma unroll
+      for (int k = 0; k < NROLE; ++k) acc[k] = (d4){0.0, 0.0, 0.0, 0.0};
       for (int ps = 0; ps < TT.npass; ++ps) {
         const int ch0 = TT.pass_chunk[ps], ch1 = TT.pass_chunk[ps + 1];
         const int row_base = T.chunk_row0[ch0];
         const int s_lo = T.cw_off[0][4 * ch0], s_hi = T.cw_off[0][4 * ch1];
 #ifndef PQA_TILE_ABL_NOAO
-        for (int it = tid; it < (s_hi - s_lo) * 16; it += 1024) {
-          const int sh = L.sh_list[s_lo + (it >> 4)];
+        for (int it = tid; it < (s_hi - s_lo) * PQA_TILE_NW; it += PQA_TILE_NT) {  // NT is a multiple of NW: it mod NW == tid mod NW
+          const int sh = L.sh_list[s_lo + it / PQA_TILE_NW];
           const int krow = L.sh_meta[4 * sh + 3] - row_base;
           const int l_ = L.sh_meta[4 * sh], np_ = L.sh_meta[4 * sh + 1], q0 = L.sh_meta[4 * sh + 2];
-          const int pl = it & 15;
+          const int pl = it % PQA_TILE_NW;
           shell_eval<5, LMAX>(l_, px - L.sh_xyz[3 * sh], py - L.sh_xyz[3 * sh + 1], pz - L.sh_xyz[3 * sh + 2], L.pr_exp + q0, L.pr_coef + q0, np_,
                         [&](int m, double v, double ax, double ay, double az, double lp) {
                           double* tl = L.tile + (size_t)(krow + m) * 16 + pl;
@@ -232,20 +238,31 @@ __global__ __launch_bounds__(1024) void k_sweep_tile(SysDev S, SlaterState st, J
 #endif
         __syncthreads();
 #ifndef PQA_TILE_ABL_NOMFMA
-        if (mfma_wave) {
+        {
           const int nrow = T.chunk_row0[ch1 - 1] + ((T.chunk_nk[ch1 - 1] + 3) & ~3) - row_base;  // padded rows of this pass
-          const double* a_ = L.tile + (size_t)mc * PQA_TILE_KT * 16 + (size_t)kq * 16 + i16;
-          const double* b_ = C + (size_t)(row_base + kq) * ldc + 16 * mu + i16;
+#pragma unroll
+          for (int k = 0; k < NROLE; ++k) {
+            const int role = wv + k * PQA_TILE_NW;
+            if (role < nrole) {
+              const double* a_ = L.tile + (size_t)(role % 5) * PQA_TILE_KT * 16 + (size_t)kq * 16 + i16;
+              const double* b_ = C + (size_t)(row_base + kq) * ldc + 16 * (role / 5) + i16;
 #pragma unroll 4
-          for (int ks = 0; ks < nrow / 4; ++ks)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[(size_t)ks * 64], b_[(size_t)ks * 4 * ldc], acc, 0, 0, 0);
+              for (int ks = 0; ks < nrow / 4; ++ks)
+                acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[(size_t)ks * 64], b_[(size_t)ks * 4 * ldc], acc[k], 0, 0, 0);
+            }
+          }
         }
 #endif
         __syncthreads();
       }
-      if (mfma_wave) {  // lane holds D[point = kq + 4r][orbital = 16 mu + i16]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) L.rnew[((size_t)(kq + 4 * r) * 5 + mc) * nmo_pad + 16 * mu + i16] = acc[r];
+      for (int k = 0; k < NROLE; ++k) {  // lane holds D[point = kq + 4r][orbital = 16 u + i16] of its role
+        const int role = wv + k * PQA_TILE_NW;
+        if (role < nrole) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kq + 4 * r < PQA_TILE_NW) L.rnew[((size_t)(kq + 4 * r) * 5 + role % 5) * nmo_pad + 16 * (role / 5) + i16] = acc[k][r];
+        }
       }
       __syncthreads();
       // ================= Metropolis at the proposal
