@@ -1,6 +1,8 @@
 """Throughput of the BASELINE.json configurations other than the headline one (synthetic tables, see pyqmc_amd.systems).
 
-    python tools/config_bench.py c3|c4|c5 [--walkers W] [--steps K]
+    python tools/config_bench.py c2|c3|c4|c5 [--walkers W] [--steps K]
+
+c2: H2O single-determinant Slater-Jastrow VMC, 4096 walkers (lane-per-walker sweep; launch-latency bound at this size)
 
 c3: diamond conventional cell (8 atoms, 32 e-) with a k-point twist, Slater-Jastrow VMC (complex wave-per-walker sweep)
 c4: H2O, 50 determinants x 2-body x 3-body Jastrow, VMC (wave-per-walker sweep)
@@ -26,7 +28,12 @@ ap.add_argument("--rundmc", type=int, default=0, help="c5: time rundmc blocks (5
 ap.add_argument("--host", action="store_true", help="c5: drive the DMC step from the host over the protocol entry points")
 a = ap.parse_args()
 prim = pa.systems.diamond_primitive()
-if a.config == "c3":
+if a.config == "c2":
+    W = a.walkers or 4096
+    sup = mol = pa.systems.water()
+    wf = pa.generate_wf(mol, pa.systems.random_mf(mol))
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(1))
+elif a.config == "c3":
     W = a.walkers or 8192
     sup = pbc.get_supercell(prim, np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
     mf = pbc.random_kmf(sup, complex_coeff=True, twist=(0.25, 0.1, -0.3))
@@ -46,7 +53,7 @@ elif a.config == "c5":
     wf = pa.generate_wf(sup, pbc.random_kmf(sup))
     cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
 else:
-    raise SystemExit("config must be c3, c4 or c5")
+    raise SystemExit("config must be c2, c3, c4 or c5")
 dev = wf.fused_device()
 wf.recompute(cfg)
 if a.config == "c5" and a.rundmc:

@@ -7,6 +7,8 @@ python $R/tools_prof.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
 python $R/tools_prof.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
+python $R/tools/config_bench.py c2 --walkers 4096 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
+python $R/tools/config_bench.py c2 --walkers 65536 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 8192 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 32768 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c4 --walkers 2048 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
