@@ -1411,7 +1411,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     const bool soa = soa_current && h->necp == 0;  // with ECPs the coordinates were just transposed back
     const double* x = soa ? (const double*)h->b_xt.p : h->js.x;
     const size_t lds_ew = ((size_t)h->N * 3 + (h->ew.gn ? (size_t)h->N * 3 * (h->ew.nmax + 1) * 2 : 0)) * sizeof(double);
-    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(64), lds_ew, h->stream, h->S, h->ew, x,
+    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(PQA_EWALD_T), lds_ew, h->stream, h->S, h->ew, x,
                        soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_ewald"));
   }

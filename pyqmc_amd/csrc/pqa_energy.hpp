@@ -84,12 +84,13 @@ struct EwaldDev {
   double recip[9];        // rows: reciprocal basis vectors (g = gn . recip)
   int nmax;               // max |gn| component
 };
-__global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
+#define PQA_EWALD_T 256  // threads per walker: the phase tables cost ~20 KB of LDS per block, so one wave per block left 1-2 waves per SIMD
+__global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
                                               long W, double* __restrict__ out) {
   extern __shared__ double lds[];  // [N][3] coordinates of this walker
   const long w = blockIdx.x;
-  const int lane = threadIdx.x;
-  for (int k = lane; k < S.nelec * 3; k += 64) lds[k] = x[w * sw + (k / 3) * se + (k % 3) * sc];
+  const int lane = threadIdx.x;  // 0 .. PQA_EWALD_T-1: the block's threads share the pair / ion / g-point loops
+  for (int k = lane; k < S.nelec * 3; k += PQA_EWALD_T) lds[k] = x[w * sw + (k / 3) * se + (k % 3) * sc];
   __syncthreads();
   auto real_sum = [&](double dx, double dy, double dz) {
     min_image(S, dx, dy, dz);
@@ -109,13 +110,13 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
   };
   double ee = 0.0, ei = 0.0;
   const int npair = S.nelec * (S.nelec - 1) / 2;
-  for (int p = lane; p < npair; p += 64) {  // pair p -> (i<j), row-major upper triangle
+  for (int p = lane; p < npair; p += PQA_EWALD_T) {  // pair p -> (i<j), row-major upper triangle
     int i = 0, rem = p;
     while (rem >= S.nelec - 1 - i) { rem -= S.nelec - 1 - i; ++i; }
     const int j = i + 1 + rem;
     ee += real_sum(lds[3 * i] - lds[3 * j], lds[3 * i + 1] - lds[3 * j + 1], lds[3 * i + 2] - lds[3 * j + 2]);
   }
-  for (int q = lane; q < S.nelec * S.natom; q += 64) {
+  for (int q = lane; q < S.nelec * S.natom; q += PQA_EWALD_T) {
     const int e = q / S.natom, I = q % S.natom;
     ei -= S.atom_charge[I] * real_sum(lds[3 * e] - S.atom_xyz[3 * I], lds[3 * e + 1] - S.atom_xyz[3 * I + 1],
                                       lds[3 * e + 2] - S.atom_xyz[3 * I + 2]);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
     // (complex multiplication recurrence), a (g, electron) term is then two complex products instead of a sincos.
     const int M = E.nmax + 1;
     double* ph = lds + S.nelec * 3;  // [N][3][M][2]
-    for (int q = lane; q < S.nelec * 3; q += 64) {
+    for (int q = lane; q < S.nelec * 3; q += PQA_EWALD_T) {
       const int e = q / 3, a = q % 3;
       double sn, cs;
       sincos(E.recip[3 * a] * lds[3 * e] + E.recip[3 * a + 1] * lds[3 * e + 1] + E.recip[3 * a + 2] * lds[3 * e + 2], &sn, &cs);
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
       }
     }
     __syncthreads();
-    for (int g = lane; g < E.ng; g += 64) {
+    for (int g = lane; g < E.ng; g += PQA_EWALD_T) {
       const int n0 = E.gn[3 * g], n1 = E.gn[3 * g + 1], n2 = E.gn[3 * g + 2];
       const int m0 = abs(n0), m1 = abs(n1), m2 = abs(n2);
       const double f0 = n0 < 0 ? -1.0 : 1.0, f1 = n1 < 0 ? -1.0 : 1.0, f2 = n2 < 0 ? -1.0 : 1.0;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
       ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
     }
   } else {
-    for (int g = lane; g < E.ng; g += 64) {
+    for (int g = lane; g < E.ng; g += PQA_EWALD_T) {
       const double gx = E.g[3 * g], gy = E.g[3 * g + 1], gz = E.g[3 * g + 2];
       double sc_ = 0.0, ss_ = 0.0;
       for (int e = 0; e < S.nelec; ++e) {
@@ -171,7 +172,14 @@ __global__ __launch_bounds__(64) void k_ewald(SysDev S, EwaldDev E, const double
   }
   ee = wave_sum(ee);
   ei = wave_sum(ei);
-  if (lane == 0) { out[W + w] = ee + E.ee_const; out[2 * W + w] = ei + E.ei_const; }
+  __shared__ double part[2][PQA_EWALD_T / 64];
+  if ((lane & 63) == 0) { part[0][lane >> 6] = ee; part[1][lane >> 6] = ei; }
+  __syncthreads();
+  if (lane == 0) {
+    double se = 0.0, si = 0.0;
+    for (int k = 0; k < PQA_EWALD_T / 64; ++k) { se += part[0][k]; si += part[1][k]; }
+    out[W + w] = se + E.ee_const; out[2 * W + w] = si + E.ei_const;
+  }
 }
 
 // ---------------------------------------------------------------- ECP
