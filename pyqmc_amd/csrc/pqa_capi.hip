@@ -1966,16 +1966,9 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
             TRY(launch_orb(h, s, plain_points(B.pts + 3 * base_s[s], cnt_s[s]), cnt_s[s], 1, (double*)h->b_emo[s].p));
           }
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
-        for (int e = 0; e < N; ++e) {
-          const int s = e >= h->nup;
-          const long ne = eoff[e + 1] - eoff[e];
-          if (ne == 0) continue;
-          hipLaunchKernelGGL(k_tm_ratio, dim3((unsigned)ne), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, e, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, base_s[s], eoff[e]);
-          hipLaunchKernelGGL(k_tm_select, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, e, (int)h->has_slater,
-                             (const double*)h->b_emo[s].p, base_s[s], W);
-        }
-        TRY(check_launch(h, "k_tm_ratio/k_tm_select"));
+        hipLaunchKernelGGL(k_tm_walker, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                           (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W);
+        TRY(check_launch(h, "k_tm_walker"));
         TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
         hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
         TRY(check_launch(h, "k_tm_gather"));

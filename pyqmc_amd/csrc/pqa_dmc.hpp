@@ -179,86 +179,86 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
   }
 }
 
-// The sequential part of the T-move of electron e, first half: ratios at the candidates against the CURRENT inverse and
-// Jastrow state, one wave per candidate (a walker's 6-24 candidates in parallel instead of in a loop).
-// mo: [ncand of this spin][nmo_s] orbital values, p_base: first candidate of this spin, pe0: first candidate of electron e.
-// grid = candidates of electron e, block = 64.
-__global__ __launch_bounds__(64) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int e, int has_slater,
-                                                 int has_jastrow, const double* __restrict__ mo, long p_base, long pe0) {
-  extern __shared__ double lds[];
-  const long p = pe0 + blockIdx.x;
-  const long w = B.ptw[p];
-  const int s = e >= S.nup, nmo = S.nmo[s];
-  const double* xw = js.x + (size_t)w * S.nelec * 3;
-  double rat = 1.0;
-  if (has_slater) {
-    double r1[1];
-    slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
-    rat = r1[0];
-  }
-  if (has_jastrow) {
-    double U0, U, g[3], lp;
-    jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
-    jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
-    rat *= exp(U - U0);
-  }
-  if (threadIdx.x == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
-}
-
-// Second half: the heat-bath selection and the detailed-balance acceptance of dmc.py:73-120,
-//   fwd_q = max(ratio_q weight_q, 0), norm = 1 + sum fwd, move q chosen with probability fwd_q / norm (else stay);
-//   backward amplitudes seen from the chosen point: ratio_q weight_q / ratio_sel for the other candidates and
-//   weight_sel / ratio_sel for the way back; accept with probability norm / back_norm,
-// and, for an accepted move, the commit (updateinternals with mask, dmc.py:167-168): Sherman-Morrison update with the
-// candidate's orbital VALUE row (already evaluated) and the coordinate.  The gradient / Laplacian rows of the cache are
-// refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
-// grid = W, block = 64.
-__global__ __launch_bounds__(64) void k_tm_select(SysDev S, SlaterState st, JastrowState js, TmBuf B, int e, int has_slater,
-                                                  const double* __restrict__ mo, long p_base, long W) {
+// The sequential part of the T-move phase, for ALL electrons of one walker in one block: walkers are independent, so
+// nothing forces a launch per electron (64 x 2 launches of latency-bound kernels were 8-11 % of a DMC step); a walker has
+// candidates for ~2-3 of its 64 electrons, the rest cost one offset compare.  Per electron e with candidates:
+//   ratios Psi(candidate)/Psi against the CURRENT inverse and Jastrow state (the walker's earlier T-moves included);
+//   heat-bath selection and detailed-balance acceptance of dmc.py:73-120,
+//     fwd_q = max(ratio_q weight_q, 0), norm = 1 + sum fwd, move q chosen with probability fwd_q / norm (else stay);
+//     backward amplitudes seen from the chosen point: ratio_q weight_q / ratio_sel for the other candidates and
+//     weight_sel / ratio_sel for the way back; accept with probability norm / back_norm;
+//   for an accepted move the commit (updateinternals with mask, dmc.py:167-168): Sherman-Morrison update with the
+//   candidate's orbital VALUE row (already evaluated) and the coordinate.  The gradient / Laplacian rows of the cache are
+//   refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
+// mo_up / mo_dn: [ncand of the spin][nmo_s] orbital values; tot_up: first spin-down candidate.  grid = W, block = 64.
+__global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, JastrowState js, TmBuf B, int has_slater, int has_jastrow,
+                                                  const double* __restrict__ mo_up, const double* __restrict__ mo_dn, long tot_up, long W) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
-  const int s = e >= S.nup, nmo = S.nmo[s];
   double* xw = js.x + (size_t)w * S.nelec * 3;
-  const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
-  const int n = (int)(p1 - p0);
-  if (n == 0) return;  // acc was cleared for the whole step
-  int sel = n, acc = 0;
-  if (lane == 0) {
-    double norm = 1.0;
-    for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
-    double u1, u2;
-    if (B.u1) { u1 = B.u1[(size_t)e * W + w]; u2 = B.u2[(size_t)e * W + w]; }
-    else {
-      const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
-      const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
-      u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
-    }
-    sel = 0;
-    double cdf = 0.0;
+  for (int e = 0; e < S.nelec; ++e) {
+    const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
+    const int n = (int)(p1 - p0);
+    if (n == 0) continue;  // (acc was cleared for the whole step)
+    const int s = e >= S.nup, nmo = S.nmo[s];
+    const double* mo = s ? mo_dn : mo_up;
+    const long p_base = s ? tot_up : 0;
+    double U0 = 0.0, g[3], lp;
+    if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
     for (long p = p0; p < p1; ++p) {
-      cdf += fmax(B.amp[p], 0.0) / norm;
-      if (cdf < u1) ++sel;
+      double rat = 1.0;
+      if (has_slater) {
+        double r1[1];
+        slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
+        rat = r1[0];
+      }
+      if (has_jastrow) {
+        double U;
+        jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
+        rat *= exp(U - U0);
+      }
+      if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
     }
-    if (sel < n) {
-      const double rr = 1.0 / B.rat[p0 + sel];
-      double back = 1.0;
-      for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
-      acc = norm / back > u2;
+    int sel = n, acc = 0;
+    if (lane == 0) {
+      double norm = 1.0;
+      for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
+      double u1, u2;
+      if (B.u1) { u1 = B.u1[(size_t)e * W + w]; u2 = B.u2[(size_t)e * W + w]; }
+      else {
+        const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
+        const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
+        u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
+      }
+      sel = 0;
+      double cdf = 0.0;
+      for (long p = p0; p < p1; ++p) {
+        cdf += fmax(B.amp[p], 0.0) / norm;
+        if (cdf < u1) ++sel;
+      }
+      if (sel < n) {
+        const double rr = 1.0 / B.rat[p0 + sel];
+        double back = 1.0;
+        for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
+        acc = norm / back > u2;
+      }
+      B.acc[(size_t)e * W + w] = acc;
     }
-    B.acc[(size_t)e * W + w] = acc;
-  }
-  acc = __shfl(acc, 0, 64);
-  sel = __shfl(sel, 0, 64);
-  if (!acc) return;
-  if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
-  if (lane == 0) {
-    // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
-    // folded coordinates (dmc.py:100), so the reference's wrap counters do not see a T-move across the cell boundary;
-    // identical results means the same here: fold, and leave the counters alone.
-    double nx = B.pts[3 * (p0 + sel)], ny = B.pts[3 * (p0 + sel) + 1], nz = B.pts[3 * (p0 + sel) + 2];
-    fold_cell(S, nx, ny, nz);
-    xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz;
+    acc = __shfl(acc, 0, 64);
+    sel = __shfl(sel, 0, 64);
+    if (!acc) continue;
+    __syncthreads();
+    if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
+    if (lane == 0) {
+      // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
+      // folded coordinates (dmc.py:100), so the reference's wrap counters do not see a T-move across the cell boundary;
+      // identical results means the same here: fold, and leave the counters alone.
+      double nx = B.pts[3 * (p0 + sel)], ny = B.pts[3 * (p0 + sel) + 1], nz = B.pts[3 * (p0 + sel) + 2];
+      fold_cell(S, nx, ny, nz);
+      xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz;
+    }
+    __syncthreads();  // the next electron's ratios see the new coordinate and inverse
   }
 }
 
