@@ -202,24 +202,29 @@ def main():
                                "kernel_share_of_step": (orb_ms / launches) * 64 * args.steps / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}
         if not args.no_profile and c_launches:
-            # The kernel with the largest share of the step is the Sherman-Morrison commit, which streams every accepted
-            # walker's inverse through HBM once per move.  Algorithmic bytes per accepted move (n = 32, nmo = 32):
-            # inverse read + written 2*8*n^2, update vectors V, R read 2*8*n, new orbital row read + cached 2*8*5*nmo.
-            n_s, nmo_s = 32, 32
-            bytes_move = 2 * 8 * n_s * n_s + 2 * 8 * n_s + 2 * 8 * 5 * nmo_s
-            accepted = float(np.mean(acc)) * W * c_launches  # accepted moves of the timed launches (1 in 4, see above)
-            ach = accepted * bytes_move / (c_ms * 1e-3) / 1e9
+            # The streaming kernel of the step: k_flush_lw, the deferred half of the blocked Sherman-Morrison update.  After
+            # every block of KB moves of a spin it carries the n - KB rows outside the block through HBM once (read + write)
+            # for every walker with an accepted move in the block, plus that walker's KB update-vector pairs (V, R).
+            # Algorithmic bytes per such walker (n = 32, KB from the library's rule / PQA_LW_KB):
+            n_s = 32
+            kb = int(os.environ.get("PQA_LW_KB", "-1"))
+            kb = 4 if kb < 0 else (n_s if kb == 0 else min(kb, n_s))
+            bytes_walker = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s
+            a_ = float(np.mean(acc))
+            touched = W * (1.0 - (1.0 - a_) ** kb)  # walkers with >= 1 accepted move among the block's KB (independent moves)
+            ach = touched * c_launches * bytes_walker / (c_ms * 1e-3) / 1e9
             traffic = None
             path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
             if os.path.exists(path):
-                d = json.load(open(path)).get("k_commit_lw")
+                d = json.load(open(path)).get("k_flush_lw")
                 if d:
                     traffic = {"bytes_per_launch": d["bytes_per_walker"] * W, "source": "profiles/r01_pmc_summary.json"}
-            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_commit_lw (Sherman-Morrison update of the inverse, lane-per-walker)",
+            flushes_per_step = 2 * (n_s // kb) if kb < n_s else 0
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_flush_lw (blocked Sherman-Morrison: rows outside the electron block, once per block of KB moves)",
                                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                    "traffic": traffic, "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
-                                   "kernel_share_of_step": (c_ms / c_launches) * 64 * args.steps / (1e3 * elapsed),
-                                   "algorithmic_bytes_per_accepted_move": bytes_move}
+                                   "kernel_share_of_step": (c_ms / c_launches) * flushes_per_step * args.steps / (1e3 * elapsed),
+                                   "algorithmic_bytes_per_touched_walker": bytes_walker, "block_KB": kb}
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)
             out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.tstep)
         print(json.dumps(out), flush=True)

@@ -311,7 +311,8 @@ int pqa_sync(pqa_handle_t* h);
    with events; query returns launches, total ms, total points*ncomp processed since enable. */
 int pqa_profile_enable(pqa_handle_t* h, int enable);
 int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, double* point_comps);
-/* same accounting for the Sherman-Morrison commit launches of the fused lane-per-walker sweep (the HBM-bound kernel) */
+/* same accounting for the streaming kernel of the fused lane-per-walker sweep: the flush launches of the blocked
+   Sherman-Morrison update (rows outside the current electron block, once per block of KB moves; none when KB = n) */
 int pqa_profile_query_commit(pqa_handle_t* h, int64_t* launches, double* total_ms);
 /* points evaluated by the ECP integrator in the last pqa_energy call (data dependent) */
 int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints);

@@ -80,10 +80,10 @@ struct pqa_handle {
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
   DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
-  // electrons per Sherman-Morrison block (PQA_LW_KB); 0 = update every row on every move.  Blocking is bitwise
-  // identical and cuts HBM traffic 2.5x, but measured 9 % slower at W = 32768 (the flush re-reads the block's V/R
-  // vectors from L1/L2 for every row), so it is off by default.
-  int lw_kb = 0;
+  // electrons per Sherman-Morrison block (PQA_LW_KB): -1 automatic (4 for >= 16 electrons per spin), 0 = update every row on
+  // every move.  Blocking is bitwise identical and cuts the inverse's HBM traffic ~3x; it pays since k_flush_lw stages the
+  // block's update vectors in LDS (1.26 -> 0.27 ms per flush at 65536 walkers): commit + flush 15.5 -> 8.4 ms per step.
+  int lw_kb = -1;
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
@@ -1616,7 +1616,8 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   while (c.Gm < 16 && (long)c.Gm * W < 4096L * 64) c.Gm *= 2;
   if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 32);
   c.nmax = std::max(h->nup, h->ndn);
-  c.KB = (h->lw_kb > 0) ? std::min(h->lw_kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
+  const int kb = h->lw_kb < 0 ? (c.nmax >= 16 ? 4 : 0) : h->lw_kb;
+  c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
   if (lw) {
     TRY(lw_from_aos(h));
     TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 8 * W * sizeof(double)));
@@ -1665,26 +1666,26 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
       const dim3 gcm(gw.x, (unsigned)Gc);
 #define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
                           else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
-      hipEvent_t ce1 = nullptr;
-      if (h->profile && (h->prof2_tick++ % h->prof_stride) == 0) {
-        if (h->prof2_used == h->prof2_events.size()) {
-          hipEvent_t a, b;
-          HIPCHK(hipEventCreate(&a));
-          HIPCHK(hipEventCreate(&b));
-          h->prof2_events.emplace_back(a, b);
-        }
-        HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
-        ce1 = h->prof2_events[h->prof2_used].second;
-        ++h->prof2_used;
-      }
       if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
 #undef PQA_COMMIT
-      if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
       if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
         const int nq = j_hi - j_lo;
-#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, gg, dim3(64), 0, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, G, j_lo, j_hi, nq)
+        hipEvent_t ce1 = nullptr;
+        if (h->profile && true) {
+          if (h->prof2_used == h->prof2_events.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            h->prof2_events.emplace_back(a, b);
+          }
+          HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
+          ce1 = h->prof2_events[h->prof2_used].second;
+          ++h->prof2_used;
+        }
+#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, dim3((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)), dim3(256), (size_t)2 * nq * n_s * PQA_FLUSH_WB * sizeof(double), h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq)
         if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
 #undef PQA_FLUSH
+        if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
       }
       continue;
     }

@@ -302,7 +302,7 @@ class DeviceWF:
         return n.value, ms.value, pc.value
 
     def profile_query_commit(self):
-        """(launches, total ms) of the Sherman-Morrison commit kernel since ``profile_enable``."""
+        """(launches, total ms) of the Sherman-Morrison flush kernel (``k_flush_lw``) since ``profile_enable``."""
         n, ms = C.c_int64(), C.c_double()
         self.call("pqa_profile_query_commit", C.byref(n), C.byref(ms))
         return n.value, ms.value
