@@ -100,3 +100,25 @@ def test_default_jastrow_basis_and_configs_container():
     d, ij = c.dist.dist_matrix(c.configs)
     assert d.shape == (2, 6, 3) and ij[0] == (0, 1) and np.array_equal(d[:, 0], c.configs[:, 0] - c.configs[:, 1])
     assert [x.configs.shape[0] for x in pa.OpenConfigs(np.zeros((5, 2, 3))).split(2)] == [3, 2]
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is the line `python bench.py` printed on MI355X for this tree: the keys of the driver's
+    contract, the roofline object of the dominant compute kernel and the CPU baseline object must be there."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "walker-steps/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_walkers"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    h = d["roofline_hbm"]
+    assert h["bound"] == "hbm" and h["peak"] == 8000.0 and 0 < h["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
