@@ -123,13 +123,18 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
   if (pos) { px = pos[3 * w]; py = pos[3 * w + 1]; pz = pos[3 * w + 2]; }
   else { const double* xe = L.xt + (size_t)e * 3 * W + w; px = xe[0]; py = xe[W]; pz = xe[2 * W]; }
   double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#ifndef PQA_MP_NOSLATER
   {
     const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
     const int* occ = S.det_occ[s];
+    // group g takes a CONTIGUOUS range of orbital slots: the proposal's rows are point-major (k_orb's output, 1280 B per
+    // walker), so a thread's consecutive slots share 64-byte lines (4 lines per thread and component instead of 8
+    // lines used 8 bytes each when the slots were dealt round-robin: 53 -> 22 us of this kernel)
+    const int nj = (n + G - 1) / G, jb = g * nj, je = (jb + nj < n) ? jb + nj : n;
     if (rows) {
       const double* row = rows + (size_t)w * 5 * nmo;
 #pragma unroll 4
-      for (int j = g; j < n; j += G) {
+      for (int j = jb; j < je; ++j) {
         const double t = Ti[(size_t)j * W];
         const int o = occ[j];
         r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
@@ -137,15 +142,18 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
     } else {
       const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
 #pragma unroll 4
-      for (int j = g; j < n; j += G) {
+      for (int j = jb; j < je; ++j) {
         const double t = Ti[(size_t)j * W];
         const double* cj = ci + (size_t)occ[j] * W;
         r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
       }
     }
   }
-  double U, gg[3], lp, ee, ei;
+#endif
+  double U = 0.0, gg[3] = {0.0, 0.0, 0.0}, lp, ee, ei;
+#ifndef PQA_MP_NOJAS
   jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
+#endif
   double* p = part + (size_t)g * 8 * W + w;
   p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
 }
@@ -318,8 +326,9 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
   if (!acc) return;
   const double* row = motmp + (size_t)w * 5 * nmo;
   double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+  const int nk = (5 * nmo + G - 1) / G, kb = g * nk, ke = (kb + nk < 5 * nmo) ? kb + nk : 5 * nmo;  // contiguous slice: whole lines of the point-major row
 #pragma unroll 8
-  for (int k = g; k < 5 * nmo; k += G) c[(size_t)k * W] = row[k];
+  for (int k = kb; k < ke; ++k) c[(size_t)k * W] = row[k];
 }
 
 // rows outside [j_lo, j_hi) of spin s: apply the block's nq buffered updates in order.  Vb/Rb: [KB][n][W], act: [KB][W].
