@@ -165,26 +165,33 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
   }
 }
 
-// part (twisted cells only): 0 -> real part, 1 -> imaginary part of sum_L exp(i k_t . L) phi(r - R - L); the caller
-// evaluates a shell once per part (register accumulators for both parts at once do not fit next to the MFMA tiles).
-template <int NCOMP, bool TW = false, class Sink>
+// Twisted cells (TW): the lattice sum sum_L exp(i k_t . L) phi(r - R - L) is complex; one walk over the admitted images
+// accumulates its real and imaginary parts (the shell's values are evaluated once per image and weighted by cos / sin of
+// the image phase) and hands them to sink(m, ...) and sink_im(m, ...).  Untwisted: sink only.
+template <int NCOMP, bool TW = false, class Sink, class SinkIm>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
-                                               const double* __restrict__ pcoef, int np, Sink&& sink, int part = 0) {
-  double acc[7][NCOMP];
+                                               const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im) {
+  double acc[7][NCOMP], aim[TW ? 7 : 1][NCOMP];
 #pragma unroll
   for (int m = 0; m < 7; ++m)
 #pragma unroll
-    for (int k = 0; k < NCOMP; ++k) acc[m][k] = 0.0;
+    for (int k = 0; k < NCOMP; ++k) { acc[m][k] = 0.0; if (TW) aim[TW ? m : 0][k] = 0.0; }
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
   auto add = [&](double xj, double yj, double zj, int j) {
-    double ph = 1.0;
-    if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos or sin of the summed angle
+    double pr = 1.0, pi = 0.0;
+    if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos and sin of the summed angle
       const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
-      ph = part ? (c.sf * cj + c.cf * sj) : (c.cf * cj - c.sf * sj);
+      pr = c.cf * cj - c.sf * sj;
+      pi = c.sf * cj + c.cf * sj;
     }
     shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
-      if (TW) { v *= ph; gx *= ph; gy *= ph; gz *= ph; lp *= ph; }
+      if (TW) {
+        aim[TW ? m : 0][0] += pi * v;
+        if (NCOMP > 1) { aim[TW ? m : 0][1 % NCOMP] += pi * gx; aim[TW ? m : 0][2 % NCOMP] += pi * gy; aim[TW ? m : 0][3 % NCOMP] += pi * gz; }
+        if (NCOMP == 5) aim[TW ? m : 0][4 % NCOMP] += pi * lp;
+        v *= pr; gx *= pr; gy *= pr; gz *= pr; lp *= pr;
+      }
       acc[m][0] += v;
       if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
       if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
@@ -209,7 +216,15 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   }
 #pragma unroll
   for (int m = 0; m < 7; ++m)
-    if (m < 2 * l + 1) sink(m, acc[m][0], acc[m][1 % NCOMP], acc[m][2 % NCOMP], acc[m][3 % NCOMP], acc[m][4 % NCOMP]);
+    if (m < 2 * l + 1) {
+      sink(m, acc[m][0], acc[m][1 % NCOMP], acc[m][2 % NCOMP], acc[m][3 % NCOMP], acc[m][4 % NCOMP]);
+      if (TW) sink_im(m, aim[TW ? m : 0][0], aim[TW ? m : 0][1 % NCOMP], aim[TW ? m : 0][2 % NCOMP], aim[TW ? m : 0][3 % NCOMP], aim[TW ? m : 0][4 % NCOMP]);
+    }
+}
+template <int NCOMP, class Sink>
+__device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
+                                               const double* __restrict__ pcoef, int np, Sink&& sink) {
+  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink);
 }
 
 // Pre-pass of a periodic k_orb launch: thread = (point, atom).  Folds the point into the cell, folds point - atom into
@@ -322,7 +337,7 @@ struct ChunkTab {
 //                  TP=32: wave wv owns point tile wv&1 and orbital tiles (wv>>1), (wv>>1)+2, ...
 //                  TP=16: one point tile, wave wv owns orbital tiles wv, wv+4, ... (small launches: more blocks, 16 lane groups)
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
-// PBC: 0 open system, 1 periodic (real lattice sums), 2 periodic with a twist (complex lattice sums, shells twice)
+// PBC: 0 open system, 1 periodic (real lattice sums), 2 periodic with a twist (complex lattice sums: real and imaginary tile rows per shell)
 template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, int PBC = 0>
 __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
@@ -393,8 +408,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     const int s_end = cw_off[ch * G + grp + 1];
 #endif
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
-      const int shx = cw_shell[si];  // twisted cells: shells appear twice, index + nshell = imaginary part
-      const int part = (PBC == 2 && shx >= S.nshell) ? 1 : 0, sh = shx - part * S.nshell;
+      const int sh = cw_shell[si];
       int l_, np_, q0, kb, ia_ = 0;
       double x, y, z;
       const double *pe, *pc;
@@ -430,8 +444,17 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
           }
           if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
         }
-        if (part) kb = T.shell_kb[shx];
-        shell_eval_pbc<NCOMP, PBC == 2>(S, ctx, sh, l_, pe, pc, np_, to_tile, part);
+        if (PBC == 2) {  // twisted: the shell's imaginary rows follow its real rows in the tile
+          const int kbi = kb + 2 * l_ + 1;
+          auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
+            const int k = kbi + m;
+            const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
+            tile[0][k][col] = v;
+            if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
+            if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+          };
+          shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im);
+        } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows

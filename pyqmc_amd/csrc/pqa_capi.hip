@@ -189,13 +189,15 @@ static int check_launch(pqa_handle* h, const char* what) {
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
   for (int g = 0; g < 3; ++g) c.cw_off[g].push_back(0);
-  // twisted cells: every shell appears twice (index + nshell = imaginary part of the complex lattice sum)
-  const int nsx = h->twist ? 2 * h->nshell : h->nshell;
-  c.shell_kb.assign((size_t)nsx, 0);
-  c.shell_chunk.assign((size_t)nsx, 0);
+  // twisted cells: a shell's complex lattice sum occupies 2 (2l+1) tile rows, real parts then imaginary parts, in ONE
+  // chunk, so that a single walk over the images fills both (evaluating the parts as two separate shells doubled the
+  // exp work).  shell_kb / shell_chunk keep an entry sh + nshell for the imaginary rows (coefficient upload).
+  const int nsx = h->nshell, tw = h->twist ? 2 : 1;
+  c.shell_kb.assign((size_t)tw * h->nshell, 0);
+  c.shell_chunk.assign((size_t)tw * h->nshell, 0);
   // phase-1 cost of a shell: radial part per primitive + angular part / tile stores per function
-  auto cost = [&](int s) { return 45 * h->shell_np[s % h->nshell] + 25 * (2 * h->shell_l[s % h->nshell] + 1) + 40; };
-  auto nfun = [&](int s) { return 2 * h->shell_l[s % h->nshell] + 1; };
+  auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * tw * (2 * h->shell_l[s] + 1) + 40; };
+  auto nfun = [&](int s) { return tw * (2 * h->shell_l[s] + 1); };
   int nao = 0;
   for (int s = 0; s < nsx; ++s) nao += nfun(s);
   // Longest-processing-time packing over (chunk, group) slots under the chunk's row capacity; if a shell does not
@@ -238,7 +240,12 @@ static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
     int kb = 0;
     std::vector<int> members;
     for (int g = 0; g < 4; ++g)
-      for (int s : slot[ch][g]) { c.shell_kb[s] = kb; c.shell_chunk[s] = ci; kb += nfun(s); members.push_back(s); }
+      for (int s : slot[ch][g]) {
+        c.shell_kb[s] = kb; c.shell_chunk[s] = ci;
+        if (tw == 2) { c.shell_kb[s + h->nshell] = kb + nfun(s) / 2; c.shell_chunk[s + h->nshell] = ci; }
+        kb += nfun(s);
+        members.push_back(s);
+      }
     for (int g = 0; g < 4; ++g) {
       for (int s : slot[ch][g]) c.cw_shell[0].push_back(s);
       c.cw_off[0].push_back((int)c.cw_shell[0].size());
