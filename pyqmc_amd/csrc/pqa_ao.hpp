@@ -387,7 +387,11 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   const int* __restrict__ cw_off = T.cw_off[TI];
   const int* __restrict__ cw_shell = T.cw_shell[TI];
 
-  for (int ch = 0; ch < T.nchunk; ++ch) {
+  // gridDim.y > 1: the chunks (the K dimension) are split over that many blocks per point tile, each adding its partial
+  // sums to a zeroed output with hardware fp64 atomics — for small launches, where a block's serial chain over the chunks,
+  // not throughput, sets the time.  Two partial sums commute, so the result is deterministic for a split of 2.
+  const int nsplit = gridDim.y, ch_lo = (int)((long)blockIdx.y * T.nchunk / nsplit), ch_hi = (int)((long)(blockIdx.y + 1) * T.nchunk / nsplit);
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
     const int nk = T.chunk_nk[ch], row0 = T.chunk_row0[ch];
     const int nk4 = (nk + 3) & ~3;
     // B operand of this chunk: issue the L2 loads now, consume them after phase 1
@@ -493,7 +497,10 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long pp = p0 + 16 * ptile + kq + 4 * r;
-        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+        if (pp < P) {
+          if (nsplit > 1) unsafeAtomicAdd(&out[(pp * NCOMP + c) * nmo + j], acc[u][c][r]);
+          else out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+        }
       }
   }
 }

@@ -87,6 +87,8 @@ struct pqa_handle {
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
+  int orb_nosplit = 0;  // PQA_ORB_NOSPLIT=1: never split the chunk loop of small periodic launches (A/B)
+  long orb_split_max = 8192;  // largest periodic launch whose chunk loop is split over two blocks (PQA_ORB_SPLIT_MAX)
   // AO rows per chunk of the PERIODIC 5-component launch: 32 halves the number of (phase 1, barrier, MFMA, barrier)
   // rounds of a block's latency chain — 2x2x2 diamond supercell +4.5-10 % at every walker count, 8-atom cell +11 % at 8192
   // walkers, -4 % at 32768 (PQA_ORB_KC5=16 restores the 16-row chunks; the open-system kernel keeps 16: 0.36 vs 0.29 of peak)
@@ -348,6 +350,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   global memory, PQA_LW 0 wave-per-walker sweep, PQA_LW_KB k blocked Sherman-Morrison, PQA_LW_GM g partial-sum
   //   groups, PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
+  if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
+  if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
   if (const char* kc = getenv("PQA_ORB_KC5")) h->orb_kc5 = atoi(kc);
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
@@ -708,7 +712,10 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
       HIPCHK(hipEventRecord(te0, h->stream));
     }
   }
-  const dim3 grid((unsigned)((P + tp - 1) / tp)), block(256);
+  // small launches: split the chunk loop over two blocks per point tile (k_orb: gridDim.y), output accumulated atomically
+  const int nsplit = (P <= h->orb_split_max && T.nchunk >= 4 && !h->orb_nosplit) ? 2 : 1;
+  if (nsplit > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)P * NCOMP * h->nmo[spin] * sizeof(double), h->stream));
+  const dim3 grid((unsigned)((P + tp - 1) / tp), (unsigned)nsplit), block(256);
   // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
   // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
   const bool lt = h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab;
