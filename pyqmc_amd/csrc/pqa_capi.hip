@@ -346,9 +346,13 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipEventCreate(&h->ev1));
   // A/B switches for the schedule variants compared in DESIGN.md sections 3-4 (all default to the measured best;
   // none of them changes results beyond summation order, tests/test_gpu_parity.py cross-checks the pairs):
-  //   PQA_ORB_TP 32|64 point tile of k_orb, PQA_ORB_WS 0|1 wave-specialised k_orb, PQA_ORB_NOTAB 1 basis tables from
-  //   global memory, PQA_LW 0 wave-per-walker sweep, PQA_LW_KB k blocked Sherman-Morrison, PQA_LW_GM g partial-sum
-  //   groups, PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation.
+  //   PQA_ORB_TP 16|32|64 point tile of k_orb (periodic: pins the automatic choice), PQA_ORB_WS 0|1 wave-specialised k_orb,
+  //   PQA_ORB_NOTAB 1 basis tables from global memory, PQA_ORB_KC5 16|32 AO rows per chunk of the periodic 5-component
+  //   launch, PQA_ORB_NOSPLIT 1 / PQA_ORB_SPLIT_MAX n chunk loop of small periodic launches on one block,
+  //   PQA_LW 0 wave-per-walker sweep | 1 lane-per-walker (default) | 2 walker-tile kernel, PQA_LW_KB k electrons per
+  //   Sherman-Morrison block (0: update every row per move; default 4), PQA_LW_GM g partial-sum groups,
+  //   PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation,
+  //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
