@@ -110,6 +110,7 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
   };
   double ee = 0.0, ei = 0.0;
   const int npair = S.nelec * (S.nelec - 1) / 2;
+#ifndef PQA_EW_NOREAL
   for (int p = lane; p < npair; p += PQA_EWALD_T) {  // pair p -> (i<j), row-major upper triangle
     int i = 0, rem = p;
     while (rem >= S.nelec - 1 - i) { rem -= S.nelec - 1 - i; ++i; }
@@ -121,6 +122,8 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
     ei -= S.atom_charge[I] * real_sum(lds[3 * e] - S.atom_xyz[3 * I], lds[3 * e + 1] - S.atom_xyz[3 * I + 1],
                                       lds[3 * e + 2] - S.atom_xyz[3 * I + 2]);
   }
+#endif
+#ifndef PQA_EW_NORECIP
   if (E.gn) {
     // e^{i g.x_e} = prod_a (e^{i b_a.x_e})^{n_a}: powers 0..nmax of the three base phases of every electron go to LDS
     // (complex multiplication recurrence), a (g, electron) term is then two complex products instead of a sincos.
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
       ei += 2.0 * E.gweight[g] * (-E.ion_cos[g] * sc_ - E.ion_sin[g] * ss_);
     }
   }
+#endif
   ee = wave_sum(ee);
   ei = wave_sum(ei);
   __shared__ double part[2][PQA_EWALD_T / 64];
