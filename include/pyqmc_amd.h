@@ -302,6 +302,39 @@ int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double branchcut, d
                   double threshold, double* weights, const pqa_dmc_tapes_t* tapes, uint64_t seed, double* step_avg,
                   double* step_acc);
 
+/* ---- density matrices and parameter-gradient moments ---------------------------- */
+/* Auxiliary one-electron Metropolis walk of the density-matrix estimators (sample_onebody,
+   pyqmc/observables/obdm.py:215-250) on a handle whose orbitals are the estimator's basis (built from orb_coeff alone):
+   n walkers distributed as f(r) = sum_i |phi_i(r)|^2 (orbitals of `spin`), nsamples proposals r + sqrt(tstep) z each,
+   accepted with probability f(r')/f(r).  The walk stays on the device (one orbital launch + one accept kernel per
+   sample).  pos (n,3) in/out; periodic handles take and return UNFOLDED coordinates (the orbital kernel folds every point
+   itself and gives twisted cells their wrap phase, orbitals.py:201-213).  gauss (nsamples,n,3) standard normals and unif
+   (nsamples,n): replay tapes in the reference's draw order, or both NULL -> Philox(seed).  The last nkeep samples
+   (positions, orbital rows, densities) stay resident in `slot` (0 or 1) for pqa_obdm_accumulate / pqa_tbdm_accumulate;
+   keep_pos (nkeep,n,3) receives their positions (may be NULL), accept (nsamples,n) the decisions as 0/1 (may be NULL). */
+int pqa_dm_walk(pqa_handle_t* h, int slot, int spin, int64_t n, int nsamples, double tstep, double* pos, const double* gauss,
+                const double* unif, uint64_t seed, int nkeep, double* keep_pos, double* accept);
+/* Basis orbitals at the configurations' electrons (OBDMAccumulator.evaluate_orbitals obdm.py:199-201, tbdm.py:203-212):
+   pts (npts,3) = (nconf, nelec_listed, 3), kept on the device in `slot`. */
+int pqa_dm_points(pqa_handle_t* h, int slot, int spin, const double* pts, int64_t npts);
+/* One sweep of the one-body estimator (obdm.py:170-190) for kept sample k of `slot`: configuration n uses auxiliary walker
+   assign[n]; ratio (nconf,nelec) = Psi(r_e -> r')/Psi from wf.testvalue_many (interleaved complex if ratio_complex).
+   first != 0 starts new accumulators value (nconf,norb,norb), norm (nconf,norb); otherwise adds. */
+int pqa_obdm_accumulate(pqa_handle_t* h, int slot, int k, int64_t nconf, int nelec, const int32_t* assign, const double* ratio,
+                        int ratio_complex, int first);
+/* One sweep of the two-body estimator (tbdm.py:232-277): slot 0 / 1 hold the walks and electron orbitals of the first /
+   second spin of the sector.  ratio (nconf,nea,neb) = Psi(r_a -> r1', r_b -> r2')/Psi, 0 for a pair naming one electron
+   twice; ijkl (4,ntuple) int32.  Accumulates value (nconf,ntuple), norm_a (nconf,norb_a), norm_b (nconf,norb_b). */
+int pqa_tbdm_accumulate(pqa_handle_t* h, int k, int64_t nconf, int nea, int neb, const int32_t* assign_a, const int32_t* assign_b,
+                        const double* ratio, int ratio_complex, const int32_t* ijkl, int ntuple, int first);
+/* Read an accumulator times `scale`: which = 0 value (ncol = entries per configuration, doubled when complex), 1 norm /
+   norm_a, 2 norm_b (ncol = orbitals).  mean = 0: (nconf,ncol); mean != 0: (ncol,) averaged over the configurations on
+   the device (the accumulators' avg(), obdm.py:195-197). */
+int pqa_dm_fetch(pqa_handle_t* h, int which, int ncol, double scale, int mean, double* out);
+/* C (P,Q) = A^T B for A (n,P), B (n,Q) on the fp64 matrix cores: the moment matrix dpidpj = dp^T diag(w f) dp of
+   StochasticReconfiguration.avg (stochastic_reconfiguration.py:106-114). */
+int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* A, const double* B, double* C);
+
 /* ---- measurement -------------------------------------------------------------------- */
 /* HIP-event timing on the handle's own stream (torch.cuda.Event only sees torch's stream). */
 int pqa_timer_start(pqa_handle_t* h);

@@ -11,7 +11,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpyqmc_amd.so")
+LIB_PATH = os.environ.get("PQA_LIB") or os.path.join(_HERE, "lib", "libpyqmc_amd.so")  # PQA_LIB: A/B of two builds (tools/)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "pyqmc_amd.h")
 
 c_double_p = C.POINTER(C.c_double)
@@ -96,6 +96,14 @@ _PROTOTYPES = {
     "pqa_resample": (C.c_int, [_H, C.c_void_p]),
     "pqa_dmc_steps": (C.c_int, [_H, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                 C.c_uint64, C.c_void_p, C.c_void_p]),
+    "pqa_dm_walk": (C.c_int, [_H, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                              C.c_void_p, C.c_void_p]),
+    "pqa_dm_points": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "pqa_obdm_accumulate": (C.c_int, [_H, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pqa_tbdm_accumulate": (C.c_int, [_H, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_int]),
+    "pqa_dm_fetch": (C.c_int, [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
+    "pqa_gram": (C.c_int, [_H, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_timer_start": (C.c_int, [_H]),
     "pqa_timer_stop": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "pqa_sync": (C.c_int, [_H]),

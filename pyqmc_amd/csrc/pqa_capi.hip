@@ -20,6 +20,7 @@
 #include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
 #include "pqa_tile.hpp"
+#include "pqa_dm.hpp"
 #include "pqa_vmc.hpp"
 
 static thread_local std::string g_create_error;
@@ -98,6 +99,13 @@ struct pqa_handle {
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
   int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
+  // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
+  // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
+  struct DmSlot { DevBuf pos, row, f, newpos, keep_pos, keep_row, keep_f, cfg; long n = 0, ncfg = 0; int nkeep = 0, spin = 0; };
+  DmSlot dm[2];
+  DevBuf dm_val, dm_norm[2], dm_tmp, dm_ijkl, dm_assign[2], dm_ratio, dm_acc;
+  long dm_nconf = 0, dm_nval = 0;
+  int dm_cx = 0;
   bool tile_attr_set = false;
   bool saved_valid = false;
   bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
@@ -601,6 +609,11 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
                     &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
   for (DevBuf* b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  for (auto& d : h->dm)
+    for (DevBuf* b : {&d.pos, &d.row, &d.f, &d.newpos, &d.keep_pos, &d.keep_row, &d.keep_f, &d.cfg})
+      if (b->p) (void)hipFree(b->p);
+  for (DevBuf* b : {&h->dm_val, &h->dm_norm[0], &h->dm_norm[1], &h->dm_tmp, &h->dm_ijkl, &h->dm_assign[0], &h->dm_assign[1], &h->dm_ratio, &h->dm_acc})
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : h->prof2_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -2077,6 +2090,178 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
 }
 
 // ---------------------------------------------------------------- measurement
+// ---------------------------------------------------------------- density-matrix sampling (pqa_dm.hpp)
+extern "C" int pqa_dm_walk(pqa_handle_t* h, int slot, int spin, int64_t n, int nsamples, double tstep, double* pos, const double* gauss,
+                           const double* unif, uint64_t seed, int nkeep, double* keep_pos, double* accept) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater) FAIL("handle has no orbital tables");
+  if (slot < 0 || slot > 1 || spin < 0 || spin > 1) FAIL("pqa_dm_walk: slot and spin must be 0 or 1");
+  if (n <= 0 || nsamples < 0 || nkeep < 0 || nkeep > nsamples) FAIL("pqa_dm_walk: bad sizes");
+  if ((gauss == nullptr) != (unif == nullptr)) FAIL("pqa_dm_walk: give both tapes or neither");
+  if (h->nmo[spin] == 0) FAIL("pqa_dm_walk: no orbitals for this spin");
+  auto& d = h->dm[slot];
+  const int nmo2 = h->nmo[spin];  // complex handles count [Re | Im] columns
+  d.n = n; d.nkeep = nkeep; d.spin = spin;
+  h->saved_valid = false;
+  TRY(ensure(h, d.pos, (size_t)n * 3 * sizeof(double)));
+  TRY(ensure(h, d.newpos, (size_t)n * 3 * sizeof(double)));
+  TRY(ensure(h, d.row, (size_t)n * nmo2 * sizeof(double)));
+  TRY(ensure(h, d.f, (size_t)n * sizeof(double)));
+  TRY(ensure(h, d.keep_pos, (size_t)std::max(nkeep, 1) * n * 3 * sizeof(double)));
+  TRY(ensure(h, d.keep_row, (size_t)std::max(nkeep, 1) * n * nmo2 * sizeof(double)));
+  TRY(ensure(h, d.keep_f, (size_t)std::max(nkeep, 1) * n * sizeof(double)));
+  TRY(ensure(h, h->b_motmp, (size_t)n * nmo2 * sizeof(double)));
+  const int CH = 64;  // samples per tape upload
+  if (gauss) {
+    TRY(ensure(h, h->b_gauss, (size_t)CH * n * 3 * sizeof(double)));
+    TRY(ensure(h, h->b_unif, (size_t)CH * n * sizeof(double)));
+  }
+  if (accept) TRY(ensure(h, h->dm_acc, (size_t)CH * n * sizeof(double)));
+  TRY(copy_in(h, d.pos.p, pos, (size_t)n * 3 * sizeof(double)));
+  const dim3 g256((unsigned)((n + 255) / 256));
+  TRY(launch_orb(h, spin, plain_points((const double*)d.pos.p, n), n, 1, (double*)d.row.p));
+  hipLaunchKernelGGL(k_dm_density, g256, dim3(256), 0, h->stream, (const double*)d.row.p, (long)n, nmo2, (double*)d.f.p);
+  TRY(check_launch(h, "k_dm_density"));
+  const double sq = sqrt(tstep);
+  for (int s0 = 0; s0 < nsamples; s0 += CH) {
+    const int ns = std::min(CH, nsamples - s0);
+    if (gauss) {
+      TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)s0 * n * 3, (size_t)ns * n * 3 * sizeof(double)));
+      TRY(copy_in(h, h->b_unif.p, unif + (size_t)s0 * n, (size_t)ns * n * sizeof(double)));
+    }
+    for (int k = 0; k < ns; ++k) {
+      const int s = s0 + k, kk = s - (nsamples - nkeep);
+      hipLaunchKernelGGL(k_dm_propose, g256, dim3(256), 0, h->stream, (const double*)d.pos.p,
+                         gauss ? (const double*)h->b_gauss.p + (size_t)k * n * 3 : (const double*)nullptr, seed, (uint32_t)s, sq, (long)n,
+                         (double*)d.newpos.p);
+      TRY(launch_orb(h, spin, plain_points((const double*)d.newpos.p, n), n, 1, (double*)h->b_motmp.p));
+      hipLaunchKernelGGL(k_dm_accept, dim3((unsigned)n), dim3(64), 0, h->stream, (double*)d.pos.p, (double*)d.row.p, (double*)d.f.p,
+                         (const double*)d.newpos.p, (const double*)h->b_motmp.p,
+                         unif ? (const double*)h->b_unif.p + (size_t)k * n : (const double*)nullptr, seed, (uint32_t)s, (long)n, nmo2,
+                         accept ? (double*)h->dm_acc.p + (size_t)k * n : (double*)nullptr,
+                         kk >= 0 ? (double*)d.keep_pos.p + (size_t)kk * n * 3 : (double*)nullptr,
+                         kk >= 0 ? (double*)d.keep_row.p + (size_t)kk * n * nmo2 : (double*)nullptr,
+                         kk >= 0 ? (double*)d.keep_f.p + (size_t)kk * n : (double*)nullptr);
+    }
+    TRY(check_launch(h, "k_dm_propose/k_dm_accept"));
+    if (accept) TRY(copy_out(h, accept + (size_t)s0 * n, h->dm_acc.p, (size_t)ns * n * sizeof(double)));
+  }
+  TRY(copy_out(h, pos, d.pos.p, (size_t)n * 3 * sizeof(double)));
+  if (keep_pos && nkeep > 0) TRY(copy_out(h, keep_pos, d.keep_pos.p, (size_t)nkeep * n * 3 * sizeof(double)));
+  return 0;
+}
+
+extern "C" int pqa_dm_points(pqa_handle_t* h, int slot, int spin, const double* pts, int64_t npts) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater) FAIL("handle has no orbital tables");
+  if (slot < 0 || slot > 1 || spin < 0 || spin > 1 || npts <= 0) FAIL("pqa_dm_points: bad arguments");
+  auto& d = h->dm[slot];
+  const int nmo2 = h->nmo[spin];
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_pts, (size_t)npts * 3 * sizeof(double)));
+  TRY(ensure(h, d.cfg, (size_t)npts * nmo2 * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)npts * 3 * sizeof(double)));
+  d.ncfg = npts;
+  return launch_orb(h, spin, plain_points((const double*)h->b_pts.p, npts), npts, 1, (double*)d.cfg.p);
+}
+
+static int dm_prepare(pqa_handle* h, long nconf, long nval, int cx, int first, long nnorm_a, long nnorm_b) {
+  if (first) { h->dm_nconf = nconf; h->dm_nval = nval; h->dm_cx = cx; }
+  else if (h->dm_nconf != nconf || h->dm_nval != nval || h->dm_cx != cx) FAIL("density-matrix accumulation: shape changed since the first sweep");
+  TRY(ensure(h, h->dm_val, (size_t)nconf * nval * (cx ? 2 : 1) * sizeof(double)));
+  TRY(ensure(h, h->dm_norm[0], (size_t)nconf * std::max(nnorm_a, 1L) * sizeof(double)));
+  TRY(ensure(h, h->dm_norm[1], (size_t)nconf * std::max(nnorm_b, 1L) * sizeof(double)));
+  return 0;
+}
+
+extern "C" int pqa_obdm_accumulate(pqa_handle_t* h, int slot, int k, int64_t nconf, int nelec, const int32_t* assign, const double* ratio,
+                                   int ratio_complex, int first) {
+  HIPCHK(hipSetDevice(h->device));
+  if (slot < 0 || slot > 1) FAIL("pqa_obdm_accumulate: slot must be 0 or 1");
+  auto& d = h->dm[slot];
+  if (k < 0 || k >= d.nkeep) FAIL("pqa_obdm_accumulate: sample was not kept by pqa_dm_walk");
+  if (d.ncfg != nconf * nelec) FAIL("pqa_obdm_accumulate: pqa_dm_points was called with another number of points");
+  const int oc = h->cplx ? 1 : 0, rc = ratio_complex ? 1 : 0, nmo2 = h->nmo[d.spin], norb = nmo2 / (oc ? 2 : 1);
+  TRY(dm_prepare(h, nconf, (long)norb * norb, rc | oc, first, norb, 0));
+  TRY(ensure(h, h->dm_assign[0], (size_t)nconf * sizeof(int)));
+  TRY(ensure(h, h->dm_ratio, (size_t)nconf * nelec * (rc ? 2 : 1) * sizeof(double)));
+  TRY(copy_in(h, h->dm_assign[0].p, assign, (size_t)nconf * sizeof(int)));
+  TRY(copy_in(h, h->dm_ratio.p, ratio, (size_t)nconf * nelec * (rc ? 2 : 1) * sizeof(double)));
+  hipLaunchKernelGGL(k_obdm_acc, dim3((unsigned)nconf), dim3(256), (size_t)2 * norb * sizeof(double), h->stream,
+                     (const double*)d.keep_row.p + (size_t)k * d.n * nmo2, (const double*)d.keep_f.p + (size_t)k * d.n,
+                     (const int*)h->dm_assign[0].p, (const double*)d.cfg.p, (const double*)h->dm_ratio.p, rc, oc, nelec, norb, first,
+                     (double*)h->dm_val.p, (double*)h->dm_norm[0].p);
+  return check_launch(h, "k_obdm_acc");
+}
+
+extern "C" int pqa_tbdm_accumulate(pqa_handle_t* h, int k, int64_t nconf, int nea, int neb, const int32_t* assign_a, const int32_t* assign_b,
+                                   const double* ratio, int ratio_complex, const int32_t* ijkl, int ntuple, int first) {
+  HIPCHK(hipSetDevice(h->device));
+  auto& da = h->dm[0];
+  auto& db = h->dm[1];
+  if (k < 0 || k >= da.nkeep || k >= db.nkeep) FAIL("pqa_tbdm_accumulate: sample was not kept by pqa_dm_walk");
+  if (da.ncfg != nconf * nea || db.ncfg != nconf * neb) FAIL("pqa_tbdm_accumulate: pqa_dm_points was called with other numbers of points");
+  const int oc = h->cplx ? 1 : 0, rc = ratio_complex ? 1 : 0;
+  const int na2 = h->nmo[da.spin], nb2 = h->nmo[db.spin], na = na2 / (oc ? 2 : 1), nb = nb2 / (oc ? 2 : 1);
+  const size_t lds = (size_t)2 * ((size_t)nea * nb + (size_t)na * nb) * sizeof(double);
+  if (lds > 64 * 1024) FAIL("pqa_tbdm_accumulate: orbital basis too large for the per-walker LDS tiles");
+  TRY(dm_prepare(h, nconf, ntuple, rc | oc, first, na, nb));
+  TRY(ensure(h, h->dm_assign[0], (size_t)nconf * sizeof(int)));
+  TRY(ensure(h, h->dm_assign[1], (size_t)nconf * sizeof(int)));
+  TRY(ensure(h, h->dm_ratio, (size_t)nconf * nea * neb * (rc ? 2 : 1) * sizeof(double)));
+  TRY(ensure(h, h->dm_ijkl, (size_t)4 * ntuple * sizeof(int)));
+  TRY(copy_in(h, h->dm_assign[0].p, assign_a, (size_t)nconf * sizeof(int)));
+  TRY(copy_in(h, h->dm_assign[1].p, assign_b, (size_t)nconf * sizeof(int)));
+  TRY(copy_in(h, h->dm_ratio.p, ratio, (size_t)nconf * nea * neb * (rc ? 2 : 1) * sizeof(double)));
+  TRY(copy_in(h, h->dm_ijkl.p, ijkl, (size_t)4 * ntuple * sizeof(int)));
+  hipLaunchKernelGGL(k_tbdm_acc, dim3((unsigned)nconf), dim3(256), lds, h->stream,
+                     (const double*)da.keep_row.p + (size_t)k * da.n * na2, (const double*)da.keep_f.p + (size_t)k * da.n,
+                     (const double*)db.keep_row.p + (size_t)k * db.n * nb2, (const double*)db.keep_f.p + (size_t)k * db.n,
+                     (const int*)h->dm_assign[0].p, (const int*)h->dm_assign[1].p, (const double*)da.cfg.p, (const double*)db.cfg.p,
+                     (const double*)h->dm_ratio.p, rc, oc, nea, neb, na, nb, (const int*)h->dm_ijkl.p, ntuple, first,
+                     (double*)h->dm_val.p, (double*)h->dm_norm[0].p, (double*)h->dm_norm[1].p);
+  return check_launch(h, "k_tbdm_acc");
+}
+
+// which: 0 value (dm_nval entries per configuration, interleaved complex if any input was), 1 norm (first / a), 2 norm b of
+// `ncol` entries; mean != 0: average over the configurations on the device
+extern "C" int pqa_dm_fetch(pqa_handle_t* h, int which, int ncol, double scale, int mean, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->dm_nconf <= 0) FAIL("pqa_dm_fetch: nothing accumulated");
+  const double* src;
+  long cols;
+  if (which == 0) { src = (const double*)h->dm_val.p; cols = h->dm_nval * (h->dm_cx ? 2 : 1); }
+  else if (which == 1 || which == 2) { src = (const double*)h->dm_norm[which - 1].p; cols = ncol; }
+  else FAIL("pqa_dm_fetch: which must be 0, 1 or 2");
+  if (which == 0 && ncol != cols) FAIL("pqa_dm_fetch: ncol does not match the accumulated value");
+  const long nout = mean ? cols : h->dm_nconf * cols;
+  TRY(ensure(h, h->dm_tmp, (size_t)nout * sizeof(double)));
+  if (mean) hipLaunchKernelGGL(k_col_means, dim3((unsigned)cols), dim3(256), 0, h->stream, src, h->dm_nconf, cols, scale, (double*)h->dm_tmp.p);
+  else hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, src, nout, scale, (double*)h->dm_tmp.p);
+  TRY(check_launch(h, "pqa_dm_fetch"));
+  return copy_out(h, out, h->dm_tmp.p, (size_t)nout * sizeof(double));
+}
+
+extern "C" int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* A, const double* B, double* C) {
+  HIPCHK(hipSetDevice(h->device));
+  if (n <= 0 || P <= 0 || Q <= 0) FAIL("pqa_gram: bad sizes");
+  const int tiles = ((P + 15) / 16) * ((Q + 15) / 16);
+  int nslice = (int)std::min<long>(std::max<long>(1, 1024 / tiles), std::max<long>(1, n / 64));
+  DevBuf &a = h->b_pts, &b = h->b_out, &part = h->dm_tmp, &c = h->dm_acc;
+  TRY(ensure(h, a, (size_t)n * P * sizeof(double)));
+  TRY(ensure(h, b, (size_t)n * Q * sizeof(double)));
+  TRY(ensure(h, part, (size_t)nslice * P * Q * sizeof(double)));
+  TRY(ensure(h, c, (size_t)P * Q * sizeof(double)));
+  TRY(copy_in(h, a.p, A, (size_t)n * P * sizeof(double)));
+  TRY(copy_in(h, b.p, B, (size_t)n * Q * sizeof(double)));
+  hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)((P + 15) / 16), (unsigned)((Q + 15) / 16), (unsigned)nslice), dim3(64), 0, h->stream,
+                     (const double*)a.p, (const double*)b.p, (long)n, P, Q, nslice, (double*)part.p);
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)(((long)P * Q + 255) / 256)), dim3(256), 0, h->stream, (const double*)part.p, (long)P * Q,
+                     nslice, (double*)c.p);
+  TRY(check_launch(h, "k_gram_mfma"));
+  return copy_out(h, C, c.p, (size_t)P * Q * sizeof(double));
+}
+
 extern "C" int pqa_sync(pqa_handle_t* h) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));

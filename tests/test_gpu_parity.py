@@ -487,6 +487,50 @@ def test_sr_golden():
     check_sr_against_golden(h2o_multidet(helpers.gpu_wf3), golden("g21_sr"), 1e-9, note)
 
 
+def test_gram_on_the_matrix_cores_matches_numpy():
+    """pqa_gram (k_gram_mfma: v_mfma_f64_16x16x4_f64, slices of the configuration axis summed in fixed order): A^T B for
+    shapes that do not fill the 16x16 tiles or the 4-row steps, real and complex (four real products), and
+    bit-reproducible."""
+    from pyqmc_amd import accumulators
+
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    gram = accumulators.device_gram(wf)
+    rng = np.random.default_rng(0)
+    for n, p, q in ((1001, 37, 21), (3, 5, 5), (4096, 130, 128)):
+        a, b = rng.standard_normal((n, p)), rng.standard_normal((n, q))
+        c = gram(a, b)
+        assert note(f"gram_{n}_{p}_{q}", relerr(c, a.T @ b)) < 1e-13
+        assert np.array_equal(c, gram(a, b))
+    a = rng.standard_normal((257, 9)) + 1j * rng.standard_normal((257, 9))
+    b = rng.standard_normal((257, 4)) + 1j * rng.standard_normal((257, 4))
+    assert relerr(gram(a, b), a.T @ b) < 1e-13
+
+
+def test_device_density_walk_matches_the_oracle_walk():
+    """pqa_dm_walk (k_dm_propose / k_orb / k_dm_accept per sample, walkers resident on the device) against the oracle's
+    restatement of sample_onebody (obdm.py:215-250) on the same numpy draws: identical decisions, positions 1e-12, and the
+    orbital values it reports belong to the walkers it reports."""
+    import pyqmc_amd as pa
+    from oracle import dm as odm
+    from test_obdm_cpu import OracleOrbitals
+
+    mol = systems.water()
+    orb = np.asarray(systems.random_mf(mol).mo_coeff[0])[:, :4]
+    ev, ref = pa.obdm.OrbitalEvaluator(mol, orb), OracleOrbitals(mol, orb)
+    start = pa.initial_guess(mol, 40, rng=np.random.default_rng(1))
+    start.reshape((-1, 1, 3))
+    res = []
+    for walk, orbs in ((lambda c: pa.obdm.sample_onebody(c, ev, nsamples=25, tstep=0.5), ev), (lambda c: odm.density_walk(c, ref, 0, 25, 0.5), ref)):
+        np.random.seed(8)
+        cfg = start.copy()
+        acc, snaps, vals = walk(cfg)
+        assert relerr(vals[-1], orbs.mos(snaps[-1].configs)) < 1e-12 and np.array_equal(cfg.configs, snaps[-1].configs)
+        res.append((acc, np.stack([c.configs for c in snaps]), np.stack(vals)))
+    assert np.array_equal(res[0][0], res[1][0]) and 0.2 < res[0][0].mean() < 0.95
+    assert note("dm_walk_pos", relerr(res[0][1], res[1][1])) < 1e-12 and note("dm_walk_orb", relerr(res[0][2], res[1][2])) < 1e-11
+
+
 def test_obdm_golden():
     """OBDMAccumulator (obdm.py:26-213): basis orbitals from a coefficient-only device handle (pqa_eval_mo -> k_orb),
     Psi(R')/Psi(R) from k_testvalue_many, the reference's seeded numpy draws; single- and multi-determinant H2O."""

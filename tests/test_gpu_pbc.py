@@ -415,6 +415,40 @@ def test_periodic_obdm_orbitals_and_accumulator():
     assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12  # the auxiliary walkers live in the cell
 
 
+def test_twisted_obdm_is_invariant_under_lattice_translations_of_the_electrons():
+    """Twisted cell (complex Bloch orbitals, s211 of g20): the estimator multiplies conj(Psi(R')/Psi(R)) by
+    conj(phi_k(r_e)); translating electron e by a lattice vector L multiplies Psi(R) by exp(i k.L) and phi_k(r_e) by the
+    same phase (orbitals.py:201-213), so the density matrix must not change.  That only holds when the basis orbitals at
+    the electrons carry the wrap phase: the same folded configurations with wrap counters 0 and with non-zero wrap counters
+    (same physical state) must give the same values; so must the true (unfolded) coordinates handed over directly."""
+    import pyqmc_amd as pa
+    from helpers import twist_case
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    sup, wf = _gpu_twisted_wf("s211")
+    _, kmf = twist_case("s211")
+    kpts = np.asarray(kmf.kpts)
+    orb = [np.asarray(kmf.mo_coeff[0][k])[:, :2] for k in range(len(kpts))]
+    lat = sup.lattice_vectors()
+    base = pa.initial_guess(sup, 12, rng=np.random.default_rng(3))
+    wrap = np.random.default_rng(4).integers(-2, 3, size=base.configs.shape).astype(float)
+    out = []
+    for w in (np.zeros_like(wrap), wrap):
+        cfg = PeriodicConfigs(base.configs.copy(), lat, wrap=w.copy())
+        assert np.allclose(cfg.configs, base.configs, atol=1e-12) and np.array_equal(cfg.wrap, w)  # same folded positions, other wrap counters
+        wf.recompute(cfg)
+        acc = pa.OBDMAccumulator(sup, orb, kpts=kpts, nsweeps=2, warmup=3, tstep=0.4)
+        assert acc.dtype is complex
+        np.random.seed(21)
+        out.append(acc(cfg, wf))
+    assert np.iscomplexobj(out[0]["value"]) and np.abs(out[0]["value"].imag).max() > 1e-6
+    assert helpers.relerr(out[1]["value"], out[0]["value"]) < 1e-9 and helpers.relerr(out[1]["norm"], out[0]["norm"]) < 1e-12
+    # the auxiliary walk in unfolded coordinates reports walkers inside the cell with their wrap counters
+    aux = acc._extra_config
+    frac = aux.configs @ np.linalg.inv(lat)
+    assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12 and np.abs(aux.wrap).max() >= 0
+
+
 def test_periodic_orbital_tile_widths_are_bitwise_identical(monkeypatch):
     """The periodic k_orb picks its point-tile width (16 for small launches, 32 / 64 by timing both on large ones); that is only legitimate
     because the two instantiations produce the same bits (same chunk composition => same MFMA accumulation order)."""
