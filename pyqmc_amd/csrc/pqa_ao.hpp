@@ -11,6 +11,7 @@
 // v_mfma_f64_16x16x4_f64.
 #pragma once
 #include "pqa_common.hpp"
+#include "pqa_sph_high.hpp"
 
 #ifndef PQA_PRIM_UNROLL
 #define PQA_PRIM_UNROLL 1
@@ -38,6 +39,32 @@ __device__ __forceinline__ void load_point(const PointAddr& a, long p, double& x
 #define SH_F1 0.4570457994644658    // 1/4 sqrt(21/(2 pi))
 #define SH_F0 0.3731763325901154    // 1/4 sqrt(7/pi)
 #define SH_F2C 1.445305721320277    // 1/4 sqrt(105/pi)
+
+// g and h shells (l = 4, 5; the reference supports l <= 5, numba/gto.py:107-118): real solid harmonic m of shell l and
+// its gradient from the generated monomial tables (tools/gen_solid_harmonics.py).  Deliberately a compact run-time loop
+// instead of unrolled expressions: these shells appear only in quadruple-zeta and larger basis sets, and written out they
+// would set the register high-water mark of every orbital kernel.  l, m are wave-uniform: the table comes through the
+// scalar cache.
+__device__ __forceinline__ double sph_ipow(double x, int n) {
+  double r = 1.0;
+#pragma unroll 1
+  for (int q = 0; q < n; ++q) r *= x;
+  return r;
+}
+__device__ __forceinline__ void sph_high(int l, int m, double x, double y, double z, double& s, double& sx, double& sy, double& sz) {
+  s = sx = sy = sz = 0.0;
+  const int t1 = SPH_HI_OFF[l - 4][m + 1];
+#pragma unroll 1
+  for (int t = SPH_HI_OFF[l - 4][m]; t < t1; ++t) {
+    const SphTerm q = SPH_HI_TERM[t];
+    const double xa = sph_ipow(x, q.i - 1), ya = sph_ipow(y, q.j - 1), za = sph_ipow(z, q.k - 1);  // x^(i-1) ... (1 for i <= 1)
+    const double xi = q.i ? xa * x : 1.0, yj = q.j ? ya * y : 1.0, zk = q.k ? za * z : 1.0;
+    s += q.c * xi * yj * zk;
+    if (q.i) sx += q.c * q.i * xa * yj * zk;
+    if (q.j) sy += q.c * q.j * xi * ya * zk;
+    if (q.k) sz += q.c * q.k * xi * yj * za;
+  }
+}
 
 // Evaluate one contracted shell at displacement (x,y,z) from its centre and hand each of its
 // 2l+1 functions to sink(m, value, dx, dy, dz, lap).  NCOMP = 1 | 4 | 5 selects how much is computed.
@@ -82,7 +109,16 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
       EMIT(3, SH_DXY * x * z, SH_DXY * z, 0.0, SH_DXY * x);
       EMIT(4, SH_DX2 * (x * x - y * y), 2.0 * SH_DX2 * x, -2.0 * SH_DX2 * y, 0.0);
       break;
-    default: if (LMAX >= 3) {  // l == 3
+    default: if (LMAX >= 3) {
+      if (l > 3) {
+#pragma unroll 1
+        for (int m = 0; m < 2 * l + 1; ++m) {
+          double s4, s4x, s4y, s4z;
+          sph_high(l, m, x, y, z, s4, s4x, s4y, s4z);
+          EMIT(m, s4, s4x, s4y, s4z);
+        }
+        break;
+      }
       const double x2 = x * x, y2 = y * y, z2 = z * z;
       EMIT(0, SH_F3 * y * (3.0 * x2 - y2), SH_F3 * 6.0 * x * y, SH_F3 * 3.0 * (x2 - y2), 0.0);
       EMIT(1, SH_F2 * x * y * z, SH_F2 * y * z, SH_F2 * x * z, SH_F2 * x * y);
@@ -178,6 +214,44 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     for (int k = 0; k < NCOMP; ++k) { acc[m][k] = 0.0; if (TW) aim[TW ? m : 0][k] = 0.0; }
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
+  if (l > 3) {  // g, h shells: one function at a time (run-time m cannot index the register accumulators below); the images
+    // are walked 2l+1 times — slow, and rare (see sph_high)
+#pragma unroll 1
+    for (int m = 0; m < 2 * l + 1; ++m) {
+      double a1[NCOMP], b1[NCOMP];
+#pragma unroll
+      for (int k = 0; k < NCOMP; ++k) a1[k] = b1[k] = 0.0;
+#pragma unroll 1
+      for (int j = 0; j < nimg; ++j) {
+        const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
+        const double r2 = xj * xj + yj * yj + zj * zj;
+        const bool in = j < 128 ? ((c.mask[j >> 6] >> (j & 63)) & 1ull) != 0ull : pbc_image_ok(S, c, j, r2);
+        if (!in || r2 > scut) continue;
+        double pr = 1.0, pi = 0.0;
+        if (TW) {
+          const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
+          pr = c.cf * cj - c.sf * sj;
+          pi = c.sf * cj + c.cf * sj;
+        }
+        double R = 0.0, dRs = 0.0, lapR = 0.0;
+#pragma unroll 1
+        for (int p = 0; p < np; ++p) {
+          const double a = pexp[p], t = pcoef[p] * exp(-a * r2);
+          R += t; dRs += a * t; lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
+        }
+        dRs *= -2.0;
+        double s4, s4x, s4y, s4z;
+        sph_high(l, m, xj, yj, zj, s4, s4x, s4y, s4z);
+        double v[5] = {s4 * R, s4x * R + s4 * dRs * xj, s4y * R + s4 * dRs * yj, s4z * R + s4 * dRs * zj,
+                       s4 * lapR + 2.0 * dRs * (s4x * xj + s4y * yj + s4z * zj)};
+#pragma unroll
+        for (int k = 0; k < NCOMP; ++k) { a1[k] += pr * v[k]; if (TW) b1[k] += pi * v[k]; }
+      }
+      sink(m, a1[0], a1[1 % NCOMP], a1[2 % NCOMP], a1[3 % NCOMP], a1[4 % NCOMP]);
+      if (TW) sink_im(m, b1[0], b1[1 % NCOMP], b1[2 % NCOMP], b1[3 % NCOMP], b1[4 % NCOMP]);
+    }
+    return;
+  }
   auto add = [&](double xj, double yj, double zj, int j) {
     double pr = 1.0, pi = 0.0;
     if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos and sin of the summed angle

@@ -413,7 +413,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (h->has_slater) {
     S.nshell = sys->nshell; S.nprim = sys->nprim; S.nao = sys->nao;
     for (int s = 0; s < sys->nshell; ++s) {
-      if (sys->shell_l[s] < 0 || sys->shell_l[s] > 3) FAIL("only s,p,d,f shells (l <= 3) are implemented");
+      if (sys->shell_l[s] < 0 || sys->shell_l[s] > 5) FAIL("shells up to h (l <= 5, as numba/gto.py:107-118) are implemented");
+      if (h->twist && sys->shell_l[s] > 3) FAIL("twisted cells: g and h shells do not fit the 16-row chunk of the orbital kernel (2 (2l+1) rows per shell)");
       h->shell_l.push_back(sys->shell_l[s]);
       h->shell_np.push_back(sys->shell_prim_off[s + 1] - sys->shell_prim_off[s]);
       h->shell_ao.push_back(sys->shell_ao_off[s]);
@@ -1586,6 +1587,8 @@ extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, 
 static bool tile_eligible(const pqa_handle* h) {
   if (h->lw_mode != 2 || !h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc) return false;
   if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32) return false;
+  for (int l : h->shell_l)
+    if (l > 3) return false;
   const int nmo_pad = 16 * std::max(h->nt[0], h->nt[1]);
   return tile_lds_bytes(h->N, nmo_pad, h->nshell, (int)h->S.nprim, h->chunks[0].rows_pad) <= 160 * 1024 - 512;
 }

@@ -29,9 +29,14 @@ def allreduce_block(local_sums, local_count, device=None):
 
     local_sums: (k,) sums over this rank's walkers (and steps); local_count: number of samples behind
     them.  Returns (means (k,), total_count).  Works without an initialised process group (single rank).
+    ``device``: where the reduction tensor lives; default: the current GPU under the RCCL backend ("nccl" only reduces
+    device tensors), the host otherwise.
     """
     import torch
     import torch.distributed as dist
+
+    if device is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
 
     t = torch.tensor(np.concatenate([np.asarray(local_sums, dtype=np.float64).ravel(), [float(local_count)]]),
                      dtype=torch.float64, device=device)

@@ -13,8 +13,11 @@ KEYS = ("ke", "ee", "ei", "ecp", "grad2", "total")
 
 
 class EnergyAccumulator:
-    def __init__(self, mol, threshold=10, naip=None, seed=0, check_configs=True, **kwargs):
-        """``kwargs``: ``ewald_gmax`` / ``nlatvec`` of the periodic Coulomb sum (accumulators.py:48-53, ewald.py:95)."""
+    def __init__(self, mol, threshold=10, naip=None, seed=None, check_configs=True, **kwargs):
+        """``kwargs``: ``ewald_gmax`` / ``nlatvec`` of the periodic Coulomb sum (accumulators.py:48-53, ewald.py:95).
+        ``seed``: key of the device's ECP rotation / mask streams; None (default) draws a fresh key from ``numpy.random``
+        at every evaluation, so ``np.random.seed`` controls the run as it does in the reference (eval_ecp.py:255-275, :135-146)
+        and accumulators on different ranks do not replay one another's rotations; an integer makes the sequence explicit."""
         self.mol = mol
         self._ewald_kws = kwargs
         if kwargs and not hasattr(mol, "a"):
@@ -22,7 +25,7 @@ class EnergyAccumulator:
         self.threshold = threshold
         if naip is not None:
             raise NotImplementedError("naip is chosen per atom as in eval_ecp.py:239-240 (6 or 12)")
-        self.seed = int(seed)
+        self.seed = None if seed is None else int(seed)
         self._calls = 0
         self.check_configs = check_configs
 
@@ -45,7 +48,11 @@ class EnergyAccumulator:
         if dev.pbc:
             dev.set_ewald(**self._ewald_kws)
         self._calls += 1
-        out = dev.energy(self.threshold, rot=rot, unif=unif, seed=self.seed + self._calls)
+        if rot is not None and unif is not None:
+            key = 0  # every draw is replayed: the device streams are not used
+        else:
+            key = int(np.random.randint(0, 2**31 - 1)) if self.seed is None else self.seed + self._calls
+        out = dev.energy(self.threshold, rot=rot, unif=unif, seed=key)
         if np.iscomplexobj(out):  # complex orbitals: ecp and total are complex (eval_ecp.py:89), the rest real (energy.py:62-64)
             return {k: (out[i] if k in ("ecp", "total") else out[i].real.copy()) for i, k in enumerate(KEYS)}
         return {k: out[i] for i, k in enumerate(KEYS)}
@@ -62,8 +69,8 @@ class EnergyAccumulator:
 
         dev = self._device(wf)
         W, P = dev.W, dev.call_int("pqa_tmove_npoints")
-        if P == 0:
-            return {"ratio": np.ones((W, 0)), "weight": np.zeros((W, 0))}
+        if P == 0:  # no ECP atom: empty candidate lists (the callers index all three keys, dmc.py:96-101)
+            return {"ratio": np.ones((W, 0)), "weight": np.zeros((W, 0)), "configs": configs.make_irreducible(e, np.zeros((W, 0, 3)))}
         necp = dev.necp
         if unif is None:
             unif = np.random.random(size=(necp, W))

@@ -176,6 +176,13 @@ def carbon_dimer(r=2.35):
     return Mol(["C", "C"], [(0.0, 0.0, 0.0), (0.0, 0.0, r)])
 
 
+def carbon_dimer_high_l(r=2.35):
+    """C2 with f, g and h shells added to the carbon tables (one contracted g shell): exercises l = 3..5, the range of
+    the reference's evaluator (numba/gto.py:107-118) beyond the double-zeta shells of the BASELINE configurations."""
+    extra = [[3, [0.761, 1.0]], [4, [2.1, 0.6], [0.7, 0.5]], [4, [0.43, 1.0]], [5, [1.05, 1.0]]]
+    return Mol(["C", "C"], [(0.0, 0.0, 0.0), (0.3, -0.2, r)], basis={"C": _C_BASIS + extra})
+
+
 _DIAMOND_A = 3.5668 / 0.529177210903  # conventional cubic lattice constant, bohr (benchmarks/c_solid_benchmark.py)
 _DIAMOND_FRAC = [(0, 0, 0), (0, .5, .5), (.5, 0, .5), (.5, .5, 0),
                  (.25, .25, .25), (.25, .75, .75), (.75, .25, .75), (.75, .75, .25)]

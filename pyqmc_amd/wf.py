@@ -26,6 +26,12 @@ class DeviceWF:
 
     def __init__(self, mol, mo_coeff=None, determinants=None, a_basis=None, b_basis=None, device=0, tol=-1,
                  a3_basis=None, b3_basis=None, eval_gto_precision=None, image_rule="reference", twist_k=None):
+        # what it takes to build this handle again (copy / pickle: the reference ships pickled wave functions to its worker
+        # processes, mc.py:161, and its tests copy them, testwf.py:44): constructor arguments, parameters pushed since, walkers
+        self._ctor = dict(mol=mol, mo_coeff=mo_coeff, determinants=determinants, a_basis=a_basis, b_basis=b_basis, device=device, tol=tol,
+                          a3_basis=a3_basis, b3_basis=b3_basis, eval_gto_precision=eval_gto_precision, image_rule=image_rule,
+                          twist_k=twist_k)
+        self._pushed = {}
         self.mol = mol
         self.twisted = twist_k is not None and float(np.abs(twist_k).max()) > 1e-12
         self.nelec = tuple(int(n) for n in mol.nelec)
@@ -182,8 +188,29 @@ class DeviceWF:
         return complex if self.cplx else float
 
     def set_param(self, name, value):
+        self._pushed[name] = np.array(value, copy=True)
         a = self._mo_to_device(value) if name.startswith("mo_coeff") else _ffi.f64(value)
         self.call("pqa_set_param", name.encode(), _ffi.ptr(a), a.size)
+
+    # ---- copy / pickle: a handle cannot be aliased or serialised, it is REBUILT ------------------------------
+    def __getstate__(self):
+        """Host-side recipe of the handle: tables (constructor arguments), parameters pushed since, resident walkers.
+        Device state (inverses, caches, Jastrow sums) is recomputed from the walkers on the other side."""
+        return {"ctor": self._ctor, "pushed": self._pushed, "configs": self.configs() if self.W else None, "ewald": self._ewald_key}
+
+    def __setstate__(self, st):
+        self.__init__(**st["ctor"])
+        for name, value in st["pushed"].items():
+            self.set_param(name, value)
+        if st["ewald"] is not None and st["ewald"] != self._ewald_key:
+            self.set_ewald(*st["ewald"])
+        if st["configs"] is not None:
+            self.recompute(st["configs"])
+
+    def __copy__(self):  # a shallow copy would share one device handle between two "independent" wave functions
+        import copy
+
+        return copy.deepcopy(self)
 
     # fused device-resident entry points ---------------------------------
     def set_ewald(self, ewald_gmax=200, nlatvec=1):
@@ -339,15 +366,50 @@ class _DeviceParams(dict):
         self._dev.set_param(key, value if f is None else f(value))
 
     def __setitem__(self, key, value):
-        value = np.array(value, dtype=float)
-        if key in self and value.shape != np.shape(self[key]):
-            raise ValueError(f"parameter {key} has shape {np.shape(self[key])}, got {value.shape}")
+        value = np.array(value)
+        if key in self:
+            have = np.asarray(self[key])
+            if value.shape != have.shape:
+                raise ValueError(f"parameter {key} has shape {have.shape}, got {value.shape}")
+            if np.iscomplexobj(value) and not np.iscomplexobj(have):
+                if np.any(value.imag != 0):
+                    raise TypeError(f"parameter {key} is real on the device; refusing to drop the imaginary part of a complex value")
+                value = value.real
+            value = value.astype(have.dtype)
+        else:
+            value = value.astype(complex if np.iscomplexobj(value) else float)
         super().__setitem__(key, value)
         self._send(key, value)
 
     def push(self):
         for k, v in self.items():
             self._send(k, v)
+
+    def __reduce__(self):  # the device binding (and the closures of _to_device) do not travel: the owning factor re-wraps
+        return (dict, (dict(self),))
+
+
+class _DeviceFactor:
+    """Copy / pickle behaviour shared by the factors: the state is every attribute plus the parameter VALUES; the shared
+    DeviceWF is rebuilt once per copy (``copy.deepcopy`` / ``pickle`` memoise it), and the parameters are bound to it again."""
+
+    def _bind_parameters(self, items):
+        self.parameters = _DeviceParams(self._dev, items)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["parameters"] = {k: np.array(v, copy=True) for k, v in self.parameters.items()}
+        return d
+
+    def __setstate__(self, d):
+        items = d.pop("parameters")
+        self.__dict__.update(d)
+        self._bind_parameters(items)
+
+    def __copy__(self):
+        import copy
+
+        return copy.deepcopy(self)
 
 
 def _mask_args(mask, W):
@@ -448,7 +510,7 @@ def orbital_inputs(mol, mf, determinants=None, with_fold=False):
     return out + (({"kpts": kpts[kinds], "blocks": mo, "nmo_k": [[b.shape[1] for b in mo[sp]] for sp in (0, 1)]},) if with_fold else ())
 
 
-class Slater:
+class Slater(_DeviceFactor):
     """Multi-determinant Slater factor (protocol of ``pyqmc/wf/slater.py:97-460``).
 
     ``mol``/``mf`` are the duck-typed containers of ``pyqmc_amd.systems`` (or PySCF-like
@@ -467,6 +529,16 @@ class Slater:
         self._dev = _dev
         self._fold = _fold if (_fold is not None and not _dev.cplx) else None
         items = {"det_coeff": _dev.det_coeff.copy(), "mo_coeff_alpha": _dev.mo_coeff[0].copy(), "mo_coeff_beta": _dev.mo_coeff[1].copy()}
+        if self._fold is not None:
+            for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
+                items[key] = np.concatenate([np.real(b) for b in self._fold["blocks"][sp]], axis=1)
+        self._bind_parameters(items)
+        self._det_occup = [o.tolist() for o in _dev.det_occup]
+        self._det_map = _dev.det_map
+        self.dtype = _dev.cdtype  # slater.py:212-216
+        self._saved = None
+
+    def _bind_parameters(self, items):
         to_device = {}
         if self._fold is not None:
             # periodic (real) determinants: the parameters have the reference's layout — per-k blocks (nao_prim, nmo_k)
@@ -474,15 +546,10 @@ class Slater:
             from . import pbc as _pbc
 
             for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
-                items[key] = np.concatenate([np.real(b) for b in self._fold["blocks"][sp]], axis=1)
                 split = np.cumsum(self._fold["nmo_k"][sp])[:-1]
                 to_device[key] = (lambda v, split=split: np.real(_pbc.fold_mo_coeff(
                     self._mol, self._fold["kpts"], [np.split(np.asarray(v), split, axis=1)] * 2)[0]))
-        self.parameters = _DeviceParams(_dev, items, to_device)
-        self._det_occup = [o.tolist() for o in _dev.det_occup]
-        self._det_map = _dev.det_map
-        self.dtype = _dev.cdtype  # slater.py:212-216
-        self._saved = None
+        self.parameters = _DeviceParams(self._dev, items, to_device)
 
     def _spin(self, e):
         return int(e >= self._nelec[0])
@@ -590,7 +657,7 @@ class Slater:
         return inv, dets
 
 
-class JastrowSpin:
+class JastrowSpin(_DeviceFactor):
     """One- and two-body Jastrow factor (protocol of ``pyqmc/wf/jastrowspin.py:20-419``).
     ``a_basis``/``b_basis``: lists of ``pyqmc_amd.func3d`` descriptors."""
 
@@ -600,7 +667,7 @@ class JastrowSpin:
         if _dev is None:
             _dev = DeviceWF(mol, a_basis=list(a_basis), b_basis=list(b_basis), device=device)
         self._dev = _dev
-        self.parameters = _DeviceParams(_dev, {"bcoeff": np.zeros((_dev.nb, 3)), "acoeff": np.zeros((_dev.natom, _dev.na, 2))})
+        self._bind_parameters({"bcoeff": np.zeros((_dev.nb, 3)), "acoeff": np.zeros((_dev.natom, _dev.na, 2))})
         self.dtype = float
 
     def recompute(self, configs):
@@ -662,7 +729,7 @@ class JastrowSpin:
         return a, b, x
 
 
-class ThreeBodyJastrow:
+class ThreeBodyJastrow(_DeviceFactor):
     """Electron-electron-ion Jastrow factor (protocol of ``pyqmc/wf/three_body_jastrow.py:19-655``).
     ``a_basis``/``b_basis``: lists of ``pyqmc_amd.func3d`` descriptors; parameter ``ccoeff``
     (natom, na, na, nb, 3).  The device keeps no per-electron partial sums for this factor: the one-electron sum
@@ -675,7 +742,7 @@ class ThreeBodyJastrow:
         if _dev is None:
             _dev = DeviceWF(mol, a3_basis=list(a_basis), b3_basis=list(b_basis), device=device)
         self._dev = _dev
-        self.parameters = _DeviceParams(_dev, {"ccoeff": np.zeros((_dev.natom, _dev.na3, _dev.na3, _dev.nb3, 3))})
+        self._bind_parameters({"ccoeff": np.zeros((_dev.natom, _dev.na3, _dev.na3, _dev.nb3, 3))})
         self.dtype = float
 
     def recompute(self, configs):
@@ -773,6 +840,19 @@ class MultiplyWF:
         self.wf_factors = list(wf_factors)
         self.parameters = Parameters([wf.parameters for wf in wf_factors])
         self.dtype = complex if any(wf.dtype == complex for wf in wf_factors) else float
+
+    def __getstate__(self):
+        return {"wf_factors": self.wf_factors}
+
+    def __setstate__(self, d):  # the "wf{i}key" view must point at the factors' re-bound parameter dicts
+        self.__init__(*d["wf_factors"])
+
+    def __copy__(self):
+        """An independent wave function on a handle of its own (``copy.copy(wf)`` in testwf.py:44,77,108): the factors
+        share ONE rebuilt DeviceWF, resident walkers included."""
+        import copy
+
+        return copy.deepcopy(self)
 
     def fused_device(self):
         """The shared DeviceWF when every factor lives on one handle (enables the fused entry points)."""

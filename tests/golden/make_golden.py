@@ -146,6 +146,18 @@ def g_ao():
     save("g2_ao", **out)
 
 
+def g_ao_high_l():
+    """f, g and h shells (l = 3..5): the reference's AO evaluator (numba/gto.py:89-254 with the sphericart harmonics
+    numba/spherical_harmonics.py:636-739) on a carbon dimer with added high-l shells."""
+    rng = np.random.default_rng(12)
+    mol = systems.carbon_dimer_high_l()
+    ev = refgto.AtomicOrbitalEvaluator(mol)
+    pts = np.concatenate([rng.standard_normal((40, 3)) * 1.2 + mol.atom_coords()[rng.integers(mol.natm, size=40)],
+                          np.linspace(0.1, 5, 8)[:, None] * np.array([0.3, -0.5, 0.8])[None]])
+    save("g26_ao_high_l", pts=pts, val=ev.eval_gto("GTOval_sph", pts), deriv1=ev.eval_gto("GTOval_sph_deriv1", pts),
+         deriv2=ev.eval_gto("GTOval_sph_deriv2", pts), max_l=np.array(ev.max_l))
+
+
 # ------------------------------------------------------------------ G4 func3d
 def g_func3d():
     r = np.concatenate([np.linspace(0.05, 2.2, 40), [1.5, 1.5 - 1e-9, 1.5 + 1e-9, 7.4999, 7.5, 9.0]])
@@ -1267,6 +1279,7 @@ if __name__ == "__main__":
         sys.exit(0)
     g_sherman_morrison()
     g_ao()
+    g_ao_high_l()
     g_func3d()
     g_protocol()
     g_energy()

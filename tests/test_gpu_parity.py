@@ -50,6 +50,26 @@ def test_ao_golden(tag, mol):
     assert note(f"ao_{tag}_d2", relerr(dev.eval_ao(pts, 5), g[tag + "_deriv2"])) < 1e-12
 
 
+def test_ao_high_l_golden():
+    """f, g and h shells (l <= 5 as numba/gto.py:107-118; golden g26 from the reference): the AO-only kernel and the
+    fused AO->MO MFMA kernel (whose g/h branch is the compact table loop of pqa_ao.hpp:sph_high)."""
+    import pyqmc_amd as pa
+    from oracle import gto
+
+    g = golden("g26_ao_high_l")
+    mol = systems.carbon_dimer_high_l()
+    mf = systems.random_mf(mol)
+    dev = pa.DeviceWF(mol, mo_coeff=mf.mo_coeff)
+    pts = g["pts"]
+    assert note("ao_highl_val", relerr(dev.eval_ao(pts, 1)[0], g["val"])) < 1e-12
+    assert note("ao_highl_d1", relerr(dev.eval_ao(pts, 4), g["deriv1"])) < 1e-12
+    assert note("ao_highl_d2", relerr(dev.eval_ao(pts, 5), g["deriv2"])) < 1e-12
+    for s in (0, 1):
+        c = np.asarray(mf.mo_coeff[s])[:, : dev.nmo[s]]
+        assert note(f"mo_highl_{s}", relerr(dev.eval_mo(s, pts, 5), g["deriv2"] @ c)) < 1e-12
+        assert relerr(dev.eval_mo(s, pts, 1), g["val"][None] @ c) < 1e-12
+
+
 @pytest.mark.parametrize("mol,npts", [(systems.water(), 37), (systems.water_cluster(), 200), (systems.helium(), 1)])
 def test_mo_mfma_vs_valu_vs_oracle(mol, npts):
     """The fused MFMA kernel against the plain VALU contraction and the oracle; asymmetric
@@ -485,6 +505,52 @@ def test_sr_golden():
     from test_accumulators_cpu import check_sr_against_golden, h2o_multidet
 
     check_sr_against_golden(h2o_multidet(helpers.gpu_wf3), golden("g21_sr"), 1e-9, note)
+
+
+def test_wave_function_copy_and_pickle_rebuild_an_independent_handle():
+    """wave functions are pickled into worker processes (mc.py:161) and copied by the reference's tests
+    (testwf.py:44,77,108).  A copy / unpickled object owns a NEW device handle rebuilt from tables, parameters and resident
+    walkers: same values, and moving an electron or changing a parameter on one does not touch the other."""
+    import copy
+    import pickle
+
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    def cases():
+        mol = systems.water()
+        yield "h2o_j3", mol, helpers.gpu_wf3(mol, systems.random_mf(mol, nvirt=6), None), OpenConfigs(pa.initial_guess(mol, 12, rng=np.random.default_rng(2)).configs)
+        sup, pwf = helpers.gpu_pbc_wf("fcc2cubic")
+        yield "pbc", sup, pwf, pa.initial_guess(sup, 10, rng=np.random.default_rng(3))
+
+    for tag, mol, wf, cfg in cases():
+        sign, logv = wf.recompute(cfg)
+        e = 1
+        epos = cfg.make_irreducible(e, cfg.configs[:, e] + 0.2)
+        g0, r0, _ = wf.gradient_value(e, epos)
+        for how, clone in (("copy", copy.copy(wf)), ("pickle", pickle.loads(pickle.dumps(wf)))):
+            assert clone.fused_device() is not None and clone.fused_device() is not wf.fused_device(), (tag, how)
+            assert all(f._dev is clone.fused_device() for f in clone.wf_factors)
+            s1, l1 = clone.value()  # resident walkers travelled with it
+            assert np.array_equal(s1, sign) and note(f"{how}_{tag}_log", np.max(np.abs(l1 - logv))) < 1e-12
+            g1, r1, _ = clone.gradient_value(e, epos)
+            assert relerr(g1, g0) < 1e-12 and relerr(r1, r0) < 1e-12
+            for k in wf.parameters:
+                assert np.array_equal(np.asarray(clone.parameters[k]), np.asarray(wf.parameters[k])), k
+            # independence: accept the move on the clone only ...
+            clone.updateinternals(e, epos, cfg)
+            assert np.max(np.abs(clone.value()[1] - l1)) > 1e-6 and np.max(np.abs(wf.value()[1] - logv)) < 1e-12
+            # ... and change a parameter on the clone only
+            key = "wf2bcoeff"
+            new = np.asarray(clone.parameters[key]).copy()
+            new[1] += 0.05
+            clone.parameters[key] = new
+            assert not np.array_equal(np.asarray(wf.parameters[key]), new)
+            l2 = clone.recompute(cfg)[1]
+            assert np.max(np.abs(l2 - logv)) > 1e-8 and np.max(np.abs(wf.recompute(cfg)[1] - logv)) < 1e-12
+        fac = copy.copy(wf.wf_factors[1])  # a single factor copies to a handle of its own as well
+        assert fac._dev is not wf.fused_device() and relerr(fac.recompute(cfg)[1], wf.wf_factors[1].recompute(cfg)[1]) < 1e-12
+        wf.recompute(cfg)
 
 
 def test_gram_on_the_matrix_cores_matches_numpy():

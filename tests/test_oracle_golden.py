@@ -36,6 +36,17 @@ def test_g2_ao(tag, mol):
     assert relerr(gto.eval_ao(table, pts, 5), g[tag + "_deriv2"]) < 1e-12
 
 
+def test_g26_ao_high_l():
+    """f, g, h shells (numba/gto.py:107-118 supports l <= 5): oracle (l <= 3 written out, l = 4, 5 from the generated
+    monomial tables) against the reference's evaluator."""
+    g = golden("g26_ao_high_l")
+    table = gto.AOTable(systems.carbon_dimer_high_l())
+    assert table.max_l == int(np.max(g["max_l"])) == 5
+    for nc, key in ((1, "val"), (4, "deriv1"), (5, "deriv2")):
+        out = gto.eval_ao(table, g["pts"], nc)
+        assert relerr(out[0] if nc == 1 else out, g[key]) < 1e-13, key
+
+
 def test_g4_func3d():
     g = golden("g4_func3d")
     r, rvec = g["r"], g["rvec"]
