@@ -335,6 +335,12 @@ int pqa_dm_fetch(pqa_handle_t* h, int which, int ncol, double scale, int mean, d
    StochasticReconfiguration.avg (stochastic_reconfiguration.py:106-114). */
 int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* A, const double* B, double* C);
 
+/* The random numbers the fused sweeps (pqa_vmc_sweeps, pqa_dmc_steps without tapes) draw for sweep `step` of `seed`:
+   gauss (N,W,3) standard normals and unif (N,W) Metropolis uniforms of walkers 0..W-1 — Philox4x32-10 keyed by
+   (seed; walker, electron, stream, step).  Test entry: lets the CPU oracle replay a device-RNG trajectory (the role
+   np.random.seed plays for the reference's vmc_worker, mc.py:119,131). */
+int pqa_philox_tapes(pqa_handle_t* h, uint64_t seed, int step, int64_t W, double* gauss, double* unif);
+
 /* ---- measurement -------------------------------------------------------------------- */
 /* HIP-event timing on the handle's own stream (torch.cuda.Event only sees torch's stream). */
 int pqa_timer_start(pqa_handle_t* h);

@@ -2265,6 +2265,21 @@ extern "C" int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* 
   return copy_out(h, C, c.p, (size_t)P * Q * sizeof(double));
 }
 
+// The standard normals and Metropolis uniforms the fused sweeps draw for (seed, step): gauss (N,W,3), unif (N,W) for
+// walkers 0..W-1 (the streams are keyed by walker index, so any prefix of an ensemble can be asked for).
+extern "C" int pqa_philox_tapes(pqa_handle_t* h, uint64_t seed, int step, int64_t W, double* gauss, double* unif) {
+  HIPCHK(hipSetDevice(h->device));
+  if (W <= 0 || step < 0 || !gauss || !unif) FAIL("pqa_philox_tapes: bad arguments");
+  const size_t NW = (size_t)h->N * W;
+  TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_unif, NW * sizeof(double)));
+  hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)step, h->N, (long)W,
+                     (double*)h->b_gauss.p, (double*)h->b_unif.p);
+  TRY(check_launch(h, "k_tile_draws"));
+  TRY(copy_in(h, gauss, h->b_gauss.p, NW * 3 * sizeof(double)));
+  return copy_out(h, unif, h->b_unif.p, NW * sizeof(double));
+}
+
 extern "C" int pqa_sync(pqa_handle_t* h) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -283,6 +283,13 @@ class DeviceWF:
             en = self._complex_energy(en, 1)
         return acc, en, (rec.astype(bool) if record else None)
 
+    def philox_tapes(self, seed, nsteps, W):
+        """The draws ``vmc_sweeps(..., seed=seed)`` makes for walkers 0..W-1: gauss (nsteps,N,W,3), unif (nsteps,N,W)."""
+        gauss, unif = np.empty((nsteps, self.N, W, 3)), np.empty((nsteps, self.N, W))
+        for s in range(nsteps):
+            self.call("pqa_philox_tapes", int(seed), s, int(W), _ffi.ptr(gauss[s]), _ffi.ptr(unif[s]))
+        return gauss, unif
+
     def resample(self, newinds):
         """``pqa_resample``: walker w of the resident state becomes a copy of walker ``newinds[w]``."""
         idx = np.ascontiguousarray(newinds, dtype=np.int32)

@@ -70,7 +70,28 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / scale) if b.size else 0.0
 
 
-def run_protocol(wf, g, names=("slater", "jastrow", "wf")):
+def relerr_elem(a, b, floor=1e-6):
+    """Element-wise relative error max |a - b| / (|b| + floor * max|b|): entries larger than ``floor`` times the largest one
+    are compared RELATIVELY (``relerr`` above measures everything against the global maximum, so the small entries of, say,
+    an inverse with |max| ~ 200 are only checked absolutely); the floor keeps exact zeros and cancellation noise finite."""
+    a, b = np.asarray(a), np.asarray(b)
+    if not b.size:
+        return 0.0
+    scale = np.abs(b) + floor * max(float(np.max(np.abs(b))), 1e-300)
+    return float(np.max(np.abs(a - b) / scale))
+
+
+def g5_tolerance(key, loose=1.0):
+    """SURVEY.md section 8(c) G5 tolerances: ratios / values / logs 1e-11, gradients 1e-10, Laplacians 1e-9 (element-wise
+    relative, helpers.relerr_elem); ``loose`` scales them for ill-conditioned fixtures."""
+    if "lap" in key:
+        return 1e-9 * loose
+    if "grad" in key:
+        return 1e-10 * loose
+    return 1e-11 * loose
+
+
+def run_protocol(wf, g, names=("slater", "jastrow", "wf"), relerr=relerr):
     """Replay ``make_golden.protocol_dump`` on ``wf`` (oracle or HIP) and return
     {quantity: relative error vs golden}."""
     configs = OpenConfigs(g["configs"].copy())

@@ -1,0 +1,218 @@
+"""Every BASELINE.json configuration at its BASELINE walker count on the device (the golden fixtures stop at a few dozen
+walkers): size-independent properties of the fused paths — the updated state equals a fresh recompute, the same Philox
+seed reproduces the run bit for bit — plus a direct comparison with the CPU oracle: the first walkers of the big ensemble
+are replayed by the oracle on the random numbers the device drew (``pqa_philox_tapes``), walkers being independent
+Markov chains.  Paths that switch on launch size (orbital tile width and its timing-based choice, K-split, partial-sum
+group counts, buffer regrowth) are only reached at these sizes.
+
+M   (H2O)8, 64 e-, single determinant x 2-body Jastrow, 65536 walkers        (bench.py)
+C2  H2O, single determinant, 4096 walkers
+C3  diamond 8-atom cubic cell, k-point twist (complex determinants), 8192 walkers
+C4  H2O, 50 determinants x 2-body x 3-body Jastrow, 2048 walkers per GPU
+C5  diamond 2x2x2 supercell (64 e-, 8 k-points), DMC tstep 0.02 with T-moves, 4096 walkers per GPU
+"""
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import relerr
+from pyqmc_amd import pbc, systems
+from pyqmc_amd.configs import OpenConfigs, PeriodicConfigs
+
+pytestmark = pytest.mark.gpu
+
+NCHECK = 8  # walkers replayed by the oracle
+_report = {}
+
+
+def note(key, value):
+    _report[key] = float(value)
+    return value
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_report():
+    yield
+    import json
+    import os
+
+    os.makedirs(os.path.join(helpers.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(helpers.ROOT, "gpurun_out", "parity_report_fullsize.json"), "w") as f:
+        json.dump(_report, f, indent=1, sort_keys=True)
+
+
+def _oracle_pbc(sup, mf):
+    from oracle import jastrow_basis, wf as owf
+
+    lprim = sup.original_cell.lattice_vectors()
+    Ls = pbc.lattice_points_within(lprim, 30.0 + pbc.cell_diameter(lprim))  # the list periodic_tables builds its image rule from
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, Ls)
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = helpers.pbc_jastrow_coeffs(sup)
+    return owf.MultiplyWF(sl, ja)
+
+
+def _gpu_pbc(sup, mf):
+    import pyqmc_amd as pa
+
+    wf = pa.generate_wf(sup, mf)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = helpers.pbc_jastrow_coeffs(sup)
+    return wf
+
+
+def build(cfg):
+    """-> (mol, device wf, oracle wf builder, walkers)"""
+    import pyqmc_amd as pa
+
+    if cfg == "M":
+        mol = systems.water_cluster()
+        mf = systems.random_mf(mol)
+        return mol, helpers.gpu_wf(mol, mf), lambda: helpers.oracle_wf(mol, mf), 65536
+    if cfg == "C2":
+        mol = systems.water()
+        mf = systems.random_mf(mol)
+        return mol, helpers.gpu_wf(mol, mf), lambda: helpers.oracle_wf(mol, mf), 4096
+    if cfg == "C3":
+        sup = pbc.get_supercell(systems.diamond_primitive(), np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
+        mf = pbc.random_kmf(sup, complex_coeff=True, twist=(0.25, 0.1, -0.3))
+        return sup, _gpu_pbc(sup, mf), lambda: _oracle_pbc(sup, mf), 8192
+    if cfg == "C4":
+        mol = systems.water()
+        mf = systems.random_mf(mol, nvirt=8)
+        dets = systems.random_determinants(mol, mf, 50)
+        return mol, helpers.gpu_wf3(mol, mf, dets), lambda: helpers.oracle_wf3(mol, mf, dets), 2048
+    if cfg == "C5":
+        sup = pbc.get_supercell(systems.diamond_primitive(), 2.0 * np.eye(3))
+        mf = pbc.random_kmf(sup)
+        return sup, _gpu_pbc(sup, mf), lambda: _oracle_pbc(sup, mf), 4096
+    raise KeyError(cfg)
+
+
+def _container(mol, x, wrap=None):
+    return PeriodicConfigs(x, mol.lattice_vectors(), wrap=wrap) if hasattr(mol, "a") else OpenConfigs(x)
+
+
+@pytest.mark.parametrize("cfg", ["M", "C2", "C3", "C4", "C5"])
+def test_vmc_sweep_at_baseline_size(cfg):
+    import pyqmc_amd as pa
+    from oracle import vmc as ovmc
+
+    mol, wf, make_oracle, W = build(cfg)
+    dev = wf.fused_device()
+    if cfg == "C4":
+        assert dev.ndet == 50
+    if cfg == "C3":
+        assert dev.twisted and dev.cplx
+    start = pa.initial_guess(mol, W, rng=np.random.default_rng(17))
+    nsteps, seed, tstep = 2, 4242, 0.3
+    runs = []
+    for rep in range(2):
+        wf.recompute(start.copy())
+        acc, en, rec = dev.vmc_sweeps(tstep, nsteps, seed=seed, energy=True, record=(rep == 0))
+        runs.append((dev.configs(), dev.value()[1], en.copy(), acc.copy(), rec))
+    x, logv, en, acc, rec = runs[0]
+    # (1) the same seed reproduces the run bit for bit (coordinates, log|Psi|, walker-mean energies)
+    assert np.array_equal(x, runs[1][0]) and np.array_equal(logv, runs[1][1]) and np.array_equal(en, runs[1][2])
+    assert np.all(np.isfinite(np.asarray(en, dtype=complex).view(float))) and 0.05 < acc.mean() < 0.99
+    # (2) Sherman-Morrison / Jastrow-updated state equals a fresh recompute of the final coordinates
+    fresh = dev.recompute(x)[1]
+    ok = np.isfinite(fresh)
+    assert ok.mean() > 0.999
+    assert note(f"{cfg}_update_vs_recompute", np.max(np.abs(fresh[ok] - logv[ok]))) < (1e-9 if cfg in ("M", "C5") else 1e-11)
+    # (3) the first walkers, replayed by the oracle on the device's own draws: same decisions, same coordinates
+    gauss, unif = dev.philox_tapes(seed, nsteps, NCHECK)
+    owf = make_oracle()
+    ocfg = start.copy()
+    ocfg = _container(mol, ocfg.configs[:NCHECK].copy(), None if not hasattr(ocfg, "wrap") else ocfg.wrap[:NCHECK].copy())
+    record = []
+    _, ocfg = ovmc.vmc_worker(mol, owf, ocfg, tstep, gauss, unif, with_energy=False, record=record)
+    odec = np.asarray(record).reshape(nsteps, -1, NCHECK)
+    same = odec == rec[:, :, :NCHECK]
+    note(f"{cfg}_decisions_equal", same.mean())
+    assert same.mean() > 0.995  # a near-tie (|ratio - u| ~ 1e-12) may flip; such a walker is excluded below
+    good = same.all(axis=(0, 1))
+    assert good.sum() >= NCHECK - 1
+    ox = ocfg.configs + (ocfg.wrap @ mol.lattice_vectors() if (cfg == "C3") else 0.0)  # twisted handles keep true coordinates
+    assert note(f"{cfg}_vs_oracle_configs", relerr(x[:NCHECK][good], ox[good])) < 1e-11
+    assert note(f"{cfg}_vs_oracle_log", np.max(np.abs(owf.recompute(ocfg)[1][good] - logv[:NCHECK][good]))) < 1e-9
+
+
+def test_dmc_steps_at_baseline_size():
+    """C5 at 4096 walkers: the fused DMC step (T-moves, drift-diffusion, weights) is reproducible bit for bit from its
+    seed, leaves a state that equals a fresh recompute, keeps the walkers in the cell and the weights finite and close to 1
+    at tstep 0.02 around the trial energy."""
+    import pyqmc_amd as pa
+
+    sup, wf, _, W = build("C5")
+    dev = wf.fused_device()
+    start = pa.initial_guess(sup, W, rng=np.random.default_rng(3))
+    wf.recompute(start.copy())
+    dev.vmc_sweeps(0.3, 2, seed=5, energy=False)
+    x0 = dev.configs()
+    wf.recompute(_container(sup, x0))
+    en0 = dev.energy(10.0, seed=9)
+    etrial = float(np.mean(en0[5]))
+    outs = []
+    for rep in range(2):
+        wf.recompute(_container(sup, x0))
+        w = np.ones(W)
+        avg, acc = dev.dmc_steps(0.02, 3, w, 10.0 * float(np.std(en0[5])), etrial, etrial, seed=77)
+        outs.append((dev.configs(), dev.value()[1], avg.copy(), acc.copy(), w.copy()))
+    a, b = outs
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    x, logv, avg, acc, w = a
+    assert np.all(np.isfinite(w)) and 0.5 < w.mean() < 2.0 and np.all(np.isfinite(avg))
+    assert 0.9 < acc[:, 0].mean() <= 1.0 and 0.0 < acc[:, 1].mean() < 0.2  # drift-diffusion and T-move acceptance
+    frac = x @ np.linalg.inv(sup.lattice_vectors())
+    assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12
+    assert note("C5_dmc_update_vs_recompute", np.max(np.abs(dev.recompute(x)[1] - logv))) < 1e-9
+
+
+def test_vmc_philox_energy_statistics():
+    """north_star: energies within statistical error of the reference path.  H2O Slater-Jastrow: (a) the device's Philox
+    mode against its own replay mode on numpy tapes, two independent ensembles of 65536 walkers; (b) the device against the
+    CPU oracle on an independent numpy-drawn ensemble.  Same distribution => the means agree within 4 combined standard
+    errors; the standard errors themselves are recorded (parity_report_fullsize.json).  With the synthetic (random-orbital)
+    trial function the local energy has a standard deviation of ~5 Ha, so 65536 walkers give ~19 mHa per snapshot — the
+    1 mHa of north_star needs a real trial function (sigma ~ 0.3 Ha), not more kernel work."""
+    import pyqmc_amd as pa
+    from oracle import energy as oenergy, vmc as ovmc
+
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    wf = helpers.gpu_wf(mol, mf)
+    dev = wf.fused_device()
+    tstep, nequil, W = 0.3, 30, 65536
+
+    def device_energy(seed, tapes):
+        start = pa.initial_guess(mol, W, rng=np.random.default_rng(seed))
+        wf.recompute(start)
+        if tapes:
+            rng = np.random.default_rng(seed + 100)
+            for _ in range(nequil):  # one sweep per call keeps the tape small
+                dev.vmc_sweeps(tstep, 1, gauss=rng.standard_normal((1, 8, W, 3)), unif=rng.random((1, 8, W)), energy=False)
+        else:
+            dev.vmc_sweeps(tstep, nequil, seed=seed, energy=False)
+        e = dev.energy(-1.0, seed=seed)[5]  # deterministic ECP quadrature (threshold <= 0): no extra noise
+        return float(np.mean(e)), float(np.std(e) / np.sqrt(W))
+
+    e_phi, s_phi = device_energy(1, False)
+    e_tap, s_tap = device_energy(2, True)
+    note("vmc_stat_philox_mean", e_phi), note("vmc_stat_philox_stderr", s_phi), note("vmc_stat_tape_mean", e_tap)
+    assert abs(e_phi - e_tap) < 4.0 * np.hypot(s_phi, s_tap), (e_phi, e_tap, s_phi, s_tap)
+    # CPU oracle, independent draws
+    Wo = 512
+    rng = np.random.default_rng(7)
+    owf = helpers.oracle_wf(mol, mf)
+    cfg = pa.initial_guess(mol, Wo, rng=rng)
+    _, cfg = ovmc.vmc_worker(mol, owf, cfg, tstep, rng.standard_normal((nequil, 8, Wo, 3)), rng.random((nequil, 8, Wo)), with_energy=False)
+    from scipy.spatial.transform import Rotation
+
+    rot = Rotation.random(8 * mol.natm, random_state=11).as_matrix().reshape(8, mol.natm, 3, 3)  # random grids, like the device's
+    eo = oenergy.energy(mol, cfg, owf, -1.0, rot, np.zeros((8, mol.natm, Wo)))["total"]  # threshold <= 0: the mask uniforms are never compared
+    e_orc, s_orc = float(np.mean(eo)), float(np.std(eo) / np.sqrt(Wo))
+    note("vmc_stat_oracle_mean", e_orc), note("vmc_stat_oracle_stderr", s_orc)
+    assert abs(e_phi - e_orc) < 4.0 * np.hypot(s_phi, s_orc), (e_phi, e_orc, s_phi, s_orc)

@@ -97,11 +97,13 @@ def test_protocol_golden(name):
     (tests/unit/test_wf_derivatives.py:40-72) replayed against reference outputs."""
     mol, mf, dets, g = helpers.case(name)
     wf = helpers.gpu_wf(mol, mf, dets)
-    err = helpers.run_protocol(wf, g)
+    err = helpers.run_protocol(wf, g, relerr=helpers.relerr_elem)
     for k, v in err.items():
         note(f"{name}:{k}", v)
-    tol = 2e-8 if name == "g5_protocol_cluster" else 1e-9
-    bad = {k: v for k, v in err.items() if not v < tol}
+    # element-wise relative errors against SURVEY G5's tolerances (ratios 1e-11, gradients 1e-10, Laplacians 1e-9); the
+    # 64-electron fixture force-accepts a |ratio| ~ 9e-5 move (condition number ~1e7 afterwards): two orders looser
+    loose = 1e2 if name == "g5_protocol_cluster" else 1.0
+    bad = {k: v for k, v in err.items() if not v < helpers.g5_tolerance(k, loose)}
     assert not bad, bad
 
 
@@ -114,8 +116,9 @@ def test_internals_golden(name):
     sl, ja = wf.wf_factors
     for s in (0, 1):
         inv, dets_ = sl._get_state(s)
-        assert note(f"{name}:inverse{s}", relerr(inv, g[f"slater_inverse{s}"])) < 1e-9
-        assert note(f"{name}:dets{s}", relerr(dets_, g[f"slater_dets{s}"])) < 1e-10
+        # G5: inverse 1e-11 element-wise relative (the ill-conditioned 64-electron fixture: see test_protocol_golden)
+        assert note(f"{name}:inverse{s}", helpers.relerr_elem(inv, g[f"slater_inverse{s}"])) < (1e-8 if name == "g5_protocol_cluster" else 1e-11)
+        assert note(f"{name}:dets{s}", helpers.relerr_elem(dets_, g[f"slater_dets{s}"])) < 1e-11
     a, b, x = ja._get_state()
     assert note(f"{name}:avalues", relerr(a, g["jastrow_avalues"])) < 1e-12
     assert note(f"{name}:bvalues", relerr(b, g["jastrow_bvalues"])) < 1e-12
