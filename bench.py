@@ -26,16 +26,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
-def pmc_traffic(point_comps_per_launch):
-    """HBM bytes per k_orb launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
-    in separate runs, profiles/r01_pmc_summary.json): measured bytes per (point, component) x this run's
-    average launch size.  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if not os.path.exists(path):
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
+
+
+def pmc_kernel(key, walkers):
+    """Counter-measured HBM bytes per launch of a kernel class, scaled to this run's walker count: rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE (separate passes) of this very command at HEAD, calibrated on a known byte count
+    (tools/pmc_calib.hip) as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  None when the summary is absent."""
+    if not os.path.exists(PMC_SUMMARY):
         return None
-    d = json.load(open(path))
-    return {"bytes_per_launch": d["k_orb5_bytes_per_point_component"] * point_comps_per_launch,
-            "algorithmic_bytes_per_launch": (32 * 8 + 24 / 5) * point_comps_per_launch, "source": "profiles/r01_pmc_summary.json"}
+    d = json.load(open(PMC_SUMMARY))
+    k = d.get("kernels", {}).get(key)
+    if not k:
+        return None
+    per_walker = k["bytes_per_launch"] / d["walkers"]
+    return {"bytes_per_launch": per_walker * walkers, "bytes_per_walker": per_walker, "fetch_calibration": d["calibration"]["applied_fetch_factor"],
+            "write_calibration": d["calibration"]["applied_write_factor"], "measured_at_walkers": d["walkers"], "source": "profiles/r02_pmc_summary.json"}
 
 
 def build_wf(device):
@@ -55,33 +61,100 @@ def build_wf(device):
     return mol, mf, wf
 
 
-def cpu_baseline(walkers, tstep, nsteps=3):
-    """The oracle (NumPy restatement of the reference algorithm, reference structure: two
-    gradient_value calls per move, per-(electron, atom) ECP loop, energy after every sweep) timed on
-    one host core for one step of `walkers` walkers; the reference's own timers (move + accumulator,
-    mc.py:114-152) define what is counted."""
+def socket_cores():
+    """One logical CPU per physical core of socket 0 (`lscpu -p`), CPU model name."""
+    import subprocess
+
+    cpus, seen, model = [], set(), "unknown"
+    try:
+        for line in subprocess.run(["lscpu", "-p=CPU,CORE,SOCKET"], capture_output=True, text=True, check=True).stdout.splitlines():
+            if line.startswith("#"):
+                continue
+            cpu, core, sock = (int(x) for x in line.split(",")[:3])
+            if sock == 0 and core not in seen:
+                seen.add(core)
+                cpus.append(cpu)
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, check=True).stdout.splitlines():
+            if line.startswith("Model name"):
+                model = line.split(":", 1)[1].strip()
+    except Exception:
+        cpus = list(range(os.cpu_count() or 1))
+    usable = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(cpus)
+    return [c for c in cpus if c in usable] or sorted(usable), model
+
+
+def cgroup_cpu_quota():
+    """CPUs the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def cpu_baseline(walkers_per_core, tstep, nsteps=2, max_procs=0):
+    """SURVEY 8(d) / BASELINE.md section 3: the NumPy oracle (reference algorithm and structure: two gradient_value calls per
+    move, per-(electron, atom) ECP loop, energy after every sweep; the reference's own timers mc.py:114-152 define what is
+    counted) in P concurrent single-thread processes, P = physical cores of one socket, each pinned to its core with its own
+    `walkers_per_core` walkers — the reference's own scaling model (vmc_parallel, mc.py:156-173: independent workers).  All
+    workers start together; throughput = total walker-steps / (last end - first start)."""
+    import multiprocessing as mp
+
+    from oracle import baseline_worker
+
+    cpus, model = socket_cores()
+    socket = len(cpus)
+    quota = cgroup_cpu_quota()
+    if quota and quota < len(cpus):  # a container limited to fewer CPUs than the socket has: more processes would only time-slice
+        cpus = cpus[: int(quota)]
+    if max_procs > 0:
+        cpus = cpus[:max_procs]
+    P = len(cpus)
+    start_at = time.time() + 20.0 + 0.05 * P  # imports + wave-function set-up of every worker happen before this
+    ctx = mp.get_context("spawn")  # never fork a process that has HIP / RCCL state
+    with ctx.Pool(P) as pool:
+        res = pool.map(baseline_worker.run, [(i, walkers_per_core, nsteps, tstep, cpus[i], start_at) for i in range(P)], chunksize=1)
+    t_begin, t_end = min(r[1] for r in res), max(r[2] for r in res)
+    late = max(r[1] for r in res) - start_at
+    total = sum(r[3] for r in res)
+    per_core = [r[3] / (r[2] - r[1]) for r in res]
+    return {"value": total / (t_end - t_begin), "unit": "walker-steps/s", "cores": P, "kind": "port",
+            "per_core": float(sum(per_core) / P), "cpu_model": model, "socket_physical_cores": socket, "cgroup_cpu_quota": quota,
+            "socket_extrapolated": float(sum(per_core) / P) * socket,
+            "sample": f"{P} concurrent single-thread processes (one per physical core of socket 0, pinned"
+                      + (f"; the container's cgroup allows {quota:g} CPUs of the socket's {socket} cores, so P = {P}: `socket_extrapolated` = per-core rate x {socket} "
+                         "assumes the reference's own perfect worker scaling" if quota and quota < socket else "")
+                      + f"), each {walkers_per_core} walkers x "
+                      f"{nsteps} steps of the same sweep + energy evaluation: {total} walker-steps in {t_end - t_begin:.1f} s "
+                      f"(latest worker started {late:.2f} s after the common start); NumPy oracle, OMP/MKL threads = 1"}
+
+
+def extra_measurements(pa, wf, dev, mol, W, args):
+    """SURVEY 8(d) reporting grid, outside the timed region of `value`: sweep-only (the reference's "move time") next to
+    sweep + energy at the bench's walker count, and sweep + energy at W/GPU in {4096, 16384, 65536}."""
     import numpy as np
 
-    import pyqmc_amd as pa
-    from oracle import vmc as ovmc
-    from tests import helpers
+    def rate(walkers, energy, steps=4):
+        if walkers != dev.W:
+            wf.recompute(pa.initial_guess(mol, walkers, rng=np.random.default_rng(77)))
+        dev.vmc_sweeps(args.tstep, 1, seed=5, energy=energy)
+        dev.sync()
+        t0 = time.perf_counter()
+        dev.vmc_sweeps(args.tstep, steps, seed=6, energy=energy)
+        dev.sync()
+        dt = time.perf_counter() - t0
+        return {"walker_steps_per_s": walkers * steps / dt, "ms_per_step": 1e3 * dt / steps}
 
-    mol = pa.systems.water_cluster()
-    mf = pa.systems.random_mf(mol)
-    owf = helpers.oracle_wf(mol, mf)
-    rng = np.random.default_rng(5)
-    cfg = pa.initial_guess(mol, walkers, rng=rng)
-    N, necp = 64, mol.natm
-    gauss, unif = rng.standard_normal((nsteps, N, walkers, 3)), rng.random((nsteps, N, walkers))
-    rot = np.broadcast_to(np.eye(3), (nsteps, N, necp, 3, 3)).copy()
-    eunif = rng.random((nsteps, N, necp, walkers))
-    owf.recompute(cfg)  # set-up (the reference's vmc_worker also starts from a recompute) stays outside the clock
-    t0 = time.perf_counter()
-    ovmc.vmc_worker(mol, owf, cfg, tstep, gauss, unif, rot, eunif)
-    secs = time.perf_counter() - t0
-    return {"value": walkers * nsteps / secs, "unit": "walker-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{walkers} walkers x {nsteps} steps of the same sweep + energy evaluation ({secs:.1f} s), "
-                      "NumPy oracle on one host core, OMP/MKL threads pinned to 1"}
+    out = {"sweep_only": rate(W, False), "sweep_plus_energy": rate(W, True), "by_walkers_per_gpu": {}}
+    for w in (4096, 16384, 65536):
+        out["by_walkers_per_gpu"][str(w)] = out["sweep_plus_energy"] if w == W else rate(w, True)
+    return out
 
 
 def main():
@@ -91,7 +164,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (weak scaling); 65536 is the measured throughput optimum")
     ap.add_argument("--tstep", type=float, default=0.3)
-    ap.add_argument("--cpu-walkers", type=int, default=512)
+    ap.add_argument("--cpu-walkers", type=int, default=256, help="walkers per CPU-baseline process")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = physical cores of one socket)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sweep-only and walker-count grid measurements (extra)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the orbital kernel with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for control-flow tests)")
@@ -151,11 +226,13 @@ def main():
 
         return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=red_dev)[0]
 
+    if not args.no_profile:
+        dev.profile_enable(True)  # during the warm-up too: the event pairs are created there, not inside the timed region
     if args.warmup > 0:
         _, en_w, _ = dev.vmc_sweeps(args.tstep, args.warmup, seed=seed, energy=True)
         reduce_block(en_w)  # also warms torch's allocator / RCCL communicator outside the timed region
     if not args.no_profile:
-        dev.profile_enable(True)
+        dev.profile_enable(True)  # reset the accounting; the events stay
     fence()
     t0 = time.perf_counter()
     dev.timer_start()
@@ -166,6 +243,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches, orb_ms, point_comps = (0, 0.0, 0.0) if args.no_profile else dev.profile_query()
     c_launches, c_ms = (0, 0.0) if args.no_profile else dev.profile_query_commit()
+    p_launches, p_ms, p_groups = (0, 0.0, 1) if args.no_profile else dev.profile_query_part()
     if not args.no_profile:
         dev.profile_enable(False)
     ecp_pts = dev.last_ecp_points()
@@ -196,37 +274,45 @@ def main():
             achieved = flops / (orb_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_orb (fused GTO AO evaluation + AO->MO fp64 MFMA contraction)",
                                "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(point_comps / launches),
+                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_kernel("k_orb5", W),
+                               "algorithmic_bytes_per_launch": (5 * nmo * 8 + 24) * (point_comps / launches / 5),
                                "launches": launches, "avg_launch_ms": orb_ms / launches,
-                               "launches_timed": "1 in 4 of the step's 64 move launches (an event pair per launch cost 4 % of the step)",
+                               "launches_timed": "1 in 4 of the step's 64 move launches (an event pair costs ~2 us of stream time)",
                                "kernel_share_of_step": (orb_ms / launches) * 64 * args.steps / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}
+        n_s, N = 32, 64
+        if not args.no_profile and p_launches:
+            # The Jastrow distance sweep of north_star lives in k_move_part_lw (two launches per move: old and proposed position):
+            # per walker it streams the coordinates of all electrons (N x 24 B), one row of the inverse (n x 8 B), four
+            # component rows of the orbital values (4 n x 8 B), and writes 8 partial sums per group.  `achieved` prices those
+            # ALGORITHMIC bytes against the event-measured launch time; `traffic` is what the HBM counters saw.
+            alg = N * 24 + n_s * 8 + 4 * n_s * 8 + p_groups * 64
+            ach = alg * W / (p_ms / p_launches * 1e-3) / 1e9
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_move_part_lw (Slater ratio sums + Jastrow e-e / e-ion distance sums of one proposal; 128 launches per step)",
+                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": pmc_kernel("k_move_part_lw", W), "launches": p_launches, "avg_launch_ms": p_ms / p_launches,
+                                   "kernel_share_of_step": (p_ms / p_launches) * 2 * N * args.steps / (1e3 * elapsed),
+                                   "algorithmic_bytes_per_walker": alg, "partial_sum_groups": p_groups}
         if not args.no_profile and c_launches:
-            # The streaming kernel of the step: k_flush_lw, the deferred half of the blocked Sherman-Morrison update.  After
-            # every block of KB moves of a spin it carries the n - KB rows outside the block through HBM once (read + write)
-            # for every walker with an accepted move in the block, plus that walker's KB update-vector pairs (V, R).
-            # Algorithmic bytes per such walker (n = 32, KB from the library's rule / PQA_LW_KB):
-            n_s = 32
+            # k_flush_lw, the deferred half of the blocked Sherman-Morrison update: after every block of KB moves of a spin it
+            # carries the n - KB rows outside the block through HBM (read + write) plus the block's KB update-vector pairs.
+            # Walkers are interleaved in every cache line, so ALL walkers' rows cross HBM: algorithmic bytes per walker.
             kb = int(os.environ.get("PQA_LW_KB", "-1"))
             kb = 4 if kb < 0 else (n_s if kb == 0 else min(kb, n_s))
-            bytes_walker = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s
-            a_ = float(np.mean(acc))
-            touched = W * (1.0 - (1.0 - a_) ** kb)  # walkers with >= 1 accepted move among the block's KB (independent moves)
-            ach = touched * c_launches * bytes_walker / (c_ms * 1e-3) / 1e9
-            traffic = None
-            path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-            if os.path.exists(path):
-                d = json.load(open(path)).get("k_flush_lw")
-                if d:
-                    traffic = {"bytes_per_launch": d["bytes_per_walker"] * W, "source": "profiles/r01_pmc_summary.json"}
+            alg = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s
+            ach = alg * W / (c_ms / c_launches * 1e-3) / 1e9
             flushes_per_step = 2 * (n_s // kb) if kb < n_s else 0
-            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_flush_lw (blocked Sherman-Morrison: rows outside the electron block, once per block of KB moves)",
-                                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": traffic, "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
-                                   "kernel_share_of_step": (c_ms / c_launches) * flushes_per_step * args.steps / (1e3 * elapsed),
-                                   "algorithmic_bytes_per_touched_walker": bytes_walker, "block_KB": kb}
+            out["roofline_hbm_flush"] = {"bound": "hbm", "kernel": "k_flush_lw (blocked Sherman-Morrison: rows outside the electron block, once per block of KB moves)",
+                                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "traffic": pmc_kernel("k_flush_lw", W), "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
+                                         "kernel_share_of_step": (c_ms / c_launches) * flushes_per_step * args.steps / (1e3 * elapsed),
+                                         "algorithmic_bytes_per_walker": alg, "block_KB": kb}
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_measurements(pa, wf, dev, mol, W, args)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.tstep)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_walkers, args.tstep, max_procs=args.cpu_procs)
+            out["speedup_vs_cpu_measured"] = value / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_socket_extrapolated"] = value / out["cpu_baseline"]["socket_extrapolated"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

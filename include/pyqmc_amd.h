@@ -353,6 +353,10 @@ int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, doub
 /* same accounting for the streaming kernel of the fused lane-per-walker sweep: the flush launches of the blocked
    Sherman-Morrison update (rows outside the current electron block, once per block of KB moves; none when KB = n) */
 int pqa_profile_query_commit(pqa_handle_t* h, int64_t* launches, double* total_ms);
+/* and for the partial-sum kernel of the fused sweep (k_move_part_lw: Slater ratio sums + the Jastrow distance sums of the
+   proposal, jastrowspin.py:296-340): launches bracketed (the proposal-side launch of every prof-stride-th electron), their
+   total ms, and the number of partial-sum groups per walker the launch geometry uses at the resident walker count */
+int pqa_profile_query_part(pqa_handle_t* h, int64_t* launches, double* total_ms, int* groups);
 /* points evaluated by the ECP integrator in the last pqa_energy call (data dependent) */
 int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints);
 

@@ -69,8 +69,9 @@ __device__ __forceinline__ void sph_high(int l, int m, double x, double y, doubl
 // Evaluate one contracted shell at displacement (x,y,z) from its centre and hand each of its
 // 2l+1 functions to sink(m, value, dx, dy, dz, lap).  NCOMP = 1 | 4 | 5 selects how much is computed.
 // LMAX < 3 compiles the f-shell branch out (callers that know the basis has none: its seven functions set the register
-// high-water mark of the routine).
-template <int NCOMP, int LMAX = 3, class Sink>
+// high-water mark of the routine); LMAX < 5 the g/h branch (the periodic kernels: their register budget is exhausted — with it
+// k_orb<5,..,PBC=1> went from 213 to 228 VGPRs, 2 to 1 waves per SIMD and +70 % time; periodic cells take l <= 3).
+template <int NCOMP, int LMAX = 5, class Sink>
 __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, const double* __restrict__ pexp,
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
   const double r2 = x * x + y * y + z * z;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
       EMIT(4, SH_DX2 * (x * x - y * y), 2.0 * SH_DX2 * x, -2.0 * SH_DX2 * y, 0.0);
       break;
     default: if (LMAX >= 3) {
-      if (l > 3) {
+      if (LMAX >= 5 && l > 3) {
 #pragma unroll 1
         for (int m = 0; m < 2 * l + 1; ++m) {
           double s4, s4x, s4y, s4z;
@@ -214,44 +215,6 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     for (int k = 0; k < NCOMP; ++k) { acc[m][k] = 0.0; if (TW) aim[TW ? m : 0][k] = 0.0; }
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
-  if (l > 3) {  // g, h shells: one function at a time (run-time m cannot index the register accumulators below); the images
-    // are walked 2l+1 times — slow, and rare (see sph_high)
-#pragma unroll 1
-    for (int m = 0; m < 2 * l + 1; ++m) {
-      double a1[NCOMP], b1[NCOMP];
-#pragma unroll
-      for (int k = 0; k < NCOMP; ++k) a1[k] = b1[k] = 0.0;
-#pragma unroll 1
-      for (int j = 0; j < nimg; ++j) {
-        const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
-        const double r2 = xj * xj + yj * yj + zj * zj;
-        const bool in = j < 128 ? ((c.mask[j >> 6] >> (j & 63)) & 1ull) != 0ull : pbc_image_ok(S, c, j, r2);
-        if (!in || r2 > scut) continue;
-        double pr = 1.0, pi = 0.0;
-        if (TW) {
-          const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
-          pr = c.cf * cj - c.sf * sj;
-          pi = c.sf * cj + c.cf * sj;
-        }
-        double R = 0.0, dRs = 0.0, lapR = 0.0;
-#pragma unroll 1
-        for (int p = 0; p < np; ++p) {
-          const double a = pexp[p], t = pcoef[p] * exp(-a * r2);
-          R += t; dRs += a * t; lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
-        }
-        dRs *= -2.0;
-        double s4, s4x, s4y, s4z;
-        sph_high(l, m, xj, yj, zj, s4, s4x, s4y, s4z);
-        double v[5] = {s4 * R, s4x * R + s4 * dRs * xj, s4y * R + s4 * dRs * yj, s4z * R + s4 * dRs * zj,
-                       s4 * lapR + 2.0 * dRs * (s4x * xj + s4y * yj + s4z * zj)};
-#pragma unroll
-        for (int k = 0; k < NCOMP; ++k) { a1[k] += pr * v[k]; if (TW) b1[k] += pi * v[k]; }
-      }
-      sink(m, a1[0], a1[1 % NCOMP], a1[2 % NCOMP], a1[3 % NCOMP], a1[4 % NCOMP]);
-      if (TW) sink_im(m, b1[0], b1[1 % NCOMP], b1[2 % NCOMP], b1[3 % NCOMP], b1[4 % NCOMP]);
-    }
-    return;
-  }
   auto add = [&](double xj, double yj, double zj, int j) {
     double pr = 1.0, pi = 0.0;
     if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos and sin of the summed angle
@@ -259,7 +222,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
       pr = c.cf * cj - c.sf * sj;
       pi = c.sf * cj + c.cf * sj;
     }
-    shell_eval<NCOMP>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
+    shell_eval<NCOMP, 3>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       if (TW) {
         aim[TW ? m : 0][0] += pi * v;
         if (NCOMP > 1) { aim[TW ? m : 0][1 % NCOMP] += pi * gx; aim[TW ? m : 0][2 % NCOMP] += pi * gy; aim[TW ? m : 0][3 % NCOMP] += pi * gz; }

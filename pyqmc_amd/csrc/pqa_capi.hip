@@ -117,6 +117,10 @@ struct pqa_handle {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_events;  // Sherman-Morrison commit launches of the fused sweep
   size_t prof2_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof3_events;  // partial-sum launches (k_move_part_lw) of the fused sweep
+  size_t prof3_used = 0;
+  long prof3_launches = 0;
+  double prof3_ms = 0.0;
   long prof2_launches = 0;
   double prof2_ms = 0.0;
   size_t prof_used = 0;
@@ -414,7 +418,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     S.nshell = sys->nshell; S.nprim = sys->nprim; S.nao = sys->nao;
     for (int s = 0; s < sys->nshell; ++s) {
       if (sys->shell_l[s] < 0 || sys->shell_l[s] > 5) FAIL("shells up to h (l <= 5, as numba/gto.py:107-118) are implemented");
-      if (h->twist && sys->shell_l[s] > 3) FAIL("twisted cells: g and h shells do not fit the 16-row chunk of the orbital kernel (2 (2l+1) rows per shell)");
+      if (sys->nL > 0 && sys->shell_l[s] > 3) FAIL("periodic orbitals: shells up to f (l <= 3); g and h shells are implemented for open systems only");
       h->shell_l.push_back(sys->shell_l[s]);
       h->shell_np.push_back(sys->shell_prim_off[s + 1] - sys->shell_prim_off[s]);
       h->shell_ao.push_back(sys->shell_ao_off[s]);
@@ -618,6 +622,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
     if (b->p) (void)hipFree(b->p);
   for (auto& pr : h->prof_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : h->prof2_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : h->prof3_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1688,12 +1693,25 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
                            (const double*)nullptr, W, Gm, part);
       hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
       TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
+      hipEvent_t pe1 = nullptr;
+      if (h->profile && (e % (4 * (int)h->prof_stride)) == 0) {  // sparsely sampled (4 of a step's 128 launches at the default stride): an event pair costs ~2 us of stream time
+        if (h->prof3_used == h->prof3_events.size()) {
+          hipEvent_t a, b;
+          HIPCHK(hipEventCreate(&a));
+          HIPCHK(hipEventCreate(&b));
+          h->prof3_events.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(h->prof3_events[h->prof3_used].first, h->stream));
+        pe1 = h->prof3_events[h->prof3_used].second;
+        ++h->prof3_used;
+      }
       if (h->S.pbc)
         hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
                            W, Gm, part);
       else
         hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
                            W, Gm, part);
+      if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
       hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
                          (const double*)part, rbuf, vbuf, act, mo);
       const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
@@ -1705,7 +1723,7 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
       if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
         const int nq = j_hi - j_lo;
         hipEvent_t ce1 = nullptr;
-        if (h->profile && true) {
+        if (h->profile && ((j_lo / std::max(KB, 1)) % 4) == 0) {  // every 4th flush of a spin
           if (h->prof2_used == h->prof2_events.size()) {
             hipEvent_t a, b;
             HIPCHK(hipEventCreate(&a));
@@ -2305,6 +2323,7 @@ extern "C" int pqa_profile_enable(pqa_handle_t* h, int enable) {
   h->profile = enable != 0;
   h->prof_used = 0; h->prof_launches = 0; h->prof_ms = 0.0; h->prof_pc = 0.0;
   h->prof2_used = 0; h->prof2_launches = 0; h->prof2_ms = 0.0;
+  h->prof3_used = 0; h->prof3_launches = 0; h->prof3_ms = 0.0;
   return 0;
 }
 extern "C" int pqa_profile_query(pqa_handle_t* h, int64_t* launches, double* total_ms, double* point_comps) {
@@ -2332,6 +2351,24 @@ extern "C" int pqa_profile_query_commit(pqa_handle_t* h, int64_t* launches, doub
   h->prof2_used = 0;
   if (launches) *launches = h->prof2_launches;
   if (total_ms) *total_ms = h->prof2_ms;
+  return 0;
+}
+extern "C" int pqa_profile_query_part(pqa_handle_t* h, int64_t* launches, double* total_ms, int* groups) {
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < h->prof3_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof3_events[i].first, h->prof3_events[i].second));
+    h->prof3_ms += ms;
+  }
+  h->prof3_used = 0;
+  if (launches) *launches = h->prof3_launches;
+  if (total_ms) *total_ms = h->prof3_ms;
+  if (groups) {
+    LwCtx lc;
+    TRY(lw_setup(h, false, lc));
+    *groups = lc.Gm;
+  }
   return 0;
 }
 extern "C" int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints) {

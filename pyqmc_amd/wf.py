@@ -341,6 +341,12 @@ class DeviceWF:
         self.call("pqa_profile_query_commit", C.byref(n), C.byref(ms))
         return n.value, ms.value
 
+    def profile_query_part(self):
+        """(launches, total ms, partial-sum groups per walker) of the bracketed k_move_part_lw launches."""
+        n, ms, g = C.c_int64(), C.c_double(), C.c_int()
+        self.call("pqa_profile_query_part", C.byref(n), C.byref(ms), C.byref(g))
+        return n.value, ms.value, g.value
+
     def last_ecp_points(self):
         n = C.c_int64()
         self.call("pqa_last_ecp_points", C.byref(n))

@@ -1,4 +1,4 @@
-"""Per-kernel mean of a PMC counter from a rocprofv3 rocpd database: python tools_pmc.py db [out.csv]"""
+"""Per-kernel mean of a PMC counter from a rocprofv3 rocpd database: python tools/pmc_counters.py db [out.csv]"""
 import csv, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select kernel_name, counter_name, count(*), avg(value), sum(value), avg(duration) from counters_collection "

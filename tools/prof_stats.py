@@ -1,4 +1,4 @@
-"""Summarise a rocprofv3 rocpd database (kernel trace) as CSV: python tools_prof.py db out.csv"""
+"""Summarise a rocprofv3 rocpd database (kernel trace) as CSV: python tools/prof_stats.py db out.csv"""
 import csv, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()

@@ -1,12 +1,23 @@
-# Regenerates the measured evidence under gpurun_out/evidence (copy what is to be judged into profiles/):
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/refresh_evidence.sh'
+# Regenerates the measured evidence under gpurun_out/evidence at HEAD (copy what is to be judged into profiles/, named per round):
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/refresh_evidence.sh'
+# 1 bench line; 2 rocprofv3 kernel-trace summary of the same command; 3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no
+# trace options) of the bench at its default walker count + the counter calibration (tools/pmc_calib) -> pmc_summary.json;
+# 4 the other BASELINE configurations; 5 their kernel summaries.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-python $R/bench.py > $O/bench.json 2> $O/bench.err < /dev/null
-rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --steps 10 --warmup 2 > /dev/null 2>&1 < /dev/null
-python $R/tools_prof.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
+W=${BENCH_WALKERS:-65536}
+lscpu > $O/host_lscpu.txt
+python $R/bench.py --walkers $W > $O/bench.json 2> $O/bench.err < /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --walkers $W --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d /tmp/pm_$c -o t -- python $R/bench.py --walkers $W --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extra > /dev/null 2>&1 < /dev/null
+  python $R/tools/pmc_counters.py /tmp/pm_$c/t_results.db $O/pmc_$c.csv
+  rocprofv3 --pmc $c -d /tmp/pc_$c -o t -- $R/tools/pmc_calib > $O/pmc_calib_$c.txt 2>&1 < /dev/null
+done
+python $R/tools/pmc_summary.py /tmp/pm_FETCH_SIZE/t_results.db /tmp/pm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db $W $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
-python $R/tools_prof.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
+python $R/tools/prof_stats.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
 python $R/tools/config_bench.py c2 --walkers 4096 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c2 --walkers 65536 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 8192 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
@@ -16,7 +27,6 @@ python $R/tools/config_bench.py c4 --walkers 16384 --steps 4 2>/dev/null | tail 
 python $R/tools/config_bench.py c5 --walkers 4096 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c5 --walkers 32768 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
-python $R/tools/config_bench.py c5 --walkers 256 --steps 1 --host 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 > /dev/null 2>&1 < /dev/null
-python $R/tools_prof.py /tmp/pd/d_results.db $O/dmc_c5_kernel_stats.csv
+python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/dmc_c5_kernel_stats.csv
 ls -la $O

@@ -14,5 +14,5 @@ PY
 for v in BASE NOREAL NORECIP; do
   lib=$R/tools/scratch/lib_$v.so; [ $v = BASE ] && lib=$R/pyqmc_amd/lib/libpyqmc_amd.so
   rocprofv3 --kernel-trace --stats -d /tmp/ew_$v -o t -- python /tmp/ew.py $lib > /dev/null 2>&1 < /dev/null
-  echo "$v: $(python $R/tools_prof.py /tmp/ew_$v/t_results.db | grep k_ewald | cut -c1-20,75-130)"
+  echo "$v: $(python $R/tools/prof_stats.py /tmp/ew_$v/t_results.db | grep k_ewald | cut -c1-20,75-130)"
 done
