@@ -157,6 +157,73 @@ def extra_measurements(pa, wf, dev, mol, W, args):
     return out
 
 
+def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
+    """--mode dmc: BASELINE config C5 (diamond 2x2x2 supercell, 64 e-, 8 k-points, tstep 0.02, T-moves, Ewald) — blocks of 5
+    fused DMC steps (pqa_dmc_steps) followed by the block reduction and the distributed stochastic comb, whose walker
+    exchange (only re-assigned walkers, device buffers over RCCL) is INSIDE the timed region."""
+    import numpy as np
+
+    import pyqmc_amd as pa
+    from pyqmc_amd import dist as pdist
+    from pyqmc_amd import pbc
+    from pyqmc_amd.dmc import dmc_propagate
+
+    W = args.walkers if args.walkers != 65536 else 4096  # C5: 32768 walkers over 8 GPUs
+    sup = pbc.get_supercell(pa.systems.diamond_primitive(), 2.0 * np.eye(3))
+    wf = pa.generate_wf(sup, pbc.random_kmf(sup), device=local_rank)
+    dev = wf.fused_device()
+    np.random.seed(1234 + rank)
+    cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(99 + rank))
+    acc = {"energy": pa.EnergyAccumulator(sup)}
+    wf.recompute(cfg)
+    dev.vmc_sweeps(0.3, 2, seed=7 + rank, energy=False)
+    cfg.configs[...] = dev.configs()
+    cfg.wrap += dev.wrap_delta()
+    wf.recompute(cfg)
+    en = np.real(acc["energy"](cfg, wf)["total"])
+    (m1, m2), _ = pdist.allreduce_block([en.sum(), (en**2).sum()], len(en), device=red_dev)
+    eref, esig = float(m1), float(np.sqrt(max(m2 - m1 * m1, 0.0)))
+    weights = np.ones(W)
+    nsb = 5
+    stats = {"moved": 0, "bytes": 0, "blocks": 0}
+
+    def block(current):
+        nonlocal cfg, weights
+        blk, cfg, weights = dmc_propagate(wf, cfg, weights, 0.02, 10 * esig, eref, eref, nsteps=nsb, accumulators=acc, state_current=current)
+        pdist.allreduce_block([blk["energytotal"] * blk["weight"] * W, blk["weight"] * W], W, device=red_dev)
+        cfg, weights, info, _ = pdist.branch_distributed(cfg, weights, dev=dev)
+        stats["moved"] += info["walkers moved"]; stats["bytes"] += info["bytes exchanged"]; stats["blocks"] += 1
+        return blk
+
+    for i in range(max(args.warmup, 1)):
+        block(i > 0)
+    stats.update(moved=0, bytes=0, blocks=0)
+    nblocks = max((args.steps + nsb - 1) // nsb, 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(nblocks):
+        blk = block(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    if rank == 0:
+        steps = nblocks * nsb
+        print(json.dumps({
+            "metric": "walker-steps/sec (DMC, diamond 2x2x2 supercell 64e- Slater-Jastrow, tstep 0.02)", "value": W * world * steps / elapsed,
+            "unit": "walker-steps/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1) * nsb, "ms_per_step": 1e3 * elapsed / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config C5: diamond 2x2x2 supercell (16 atoms, 64 e-, 8 k-points, ccECP-shaped synthetic tables), DMC "
+                                   "tstep 0.02 with T-moves and Ewald energies; blocks of 5 steps + block reduction + distributed stochastic comb",
+                       "walkers_per_gpu": W, "global_walkers": W * world, "parallelism": f"walker-sharded x{world}"},
+            "energy_total": float(blk["energytotal"]), "acceptance": float(blk["acceptance"]), "tmove_acceptance": float(blk["tmove_acceptance"]),
+            "branching": {"blocks": stats["blocks"], "walkers_moved_per_block": stats["moved"] / max(stats["blocks"], 1),
+                          "bytes_sent_per_block_rank0": stats["bytes"] / max(stats["blocks"], 1),
+                          "exchange": "all-gather of weights + point-to-point coordinates of re-assigned walkers only (RCCL)"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +231,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (weak scaling); 65536 is the measured throughput optimum")
     ap.add_argument("--tstep", type=float, default=0.3)
+    ap.add_argument("--mode", default="vmc", choices=["vmc", "dmc"], help="vmc: the headline metric (default); dmc: config C5 with branching")
     ap.add_argument("--cpu-walkers", type=int, default=256, help="walkers per CPU-baseline process")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = physical cores of one socket)")
     ap.add_argument("--no-extra", action="store_true", help="skip the sweep-only and walker-count grid measurements (extra)")
@@ -204,6 +272,19 @@ def main():
         dist.barrier()
     import pyqmc_amd as pa
 
+    red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "dmc":
+        dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     mol, mf, wf = build_wf(local_rank)
     dev = wf.fused_device()
     W = args.walkers

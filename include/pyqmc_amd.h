@@ -274,6 +274,17 @@ int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gaus
    191-198 for the wave-function state).  newinds (W) int32 in [0, W). */
 int pqa_resample(pqa_handle_t* h, const int32_t* newinds);
 
+/* Distributed branching (pyqmc/method/dmc.py:342-376 over ranks): after every rank has computed the
+   identical global comb, a walker whose new owner differs from its old one travels as coordinates only.
+   pqa_get_walkers: coordinates (n,N,3) of the resident walkers idx[k] (duplicates allowed) into `out` — host memory or a
+   device buffer handed straight to RCCL.
+   pqa_branch_exchange: the rank's new ensemble = the resident walkers keep_src[0..nkeep) (their whole wave-function state is
+   gathered on the device, as pqa_resample) followed by nrecv received walkers with coordinates recv_x (nrecv,N,3; host or
+   device), for which ALONE the state is recomputed (the reference recomputes every walker after a branch, dmc.py:155).
+   nkeep + nrecv must equal the resident walker count. */
+int pqa_get_walkers(pqa_handle_t* h, const int32_t* idx, int64_t n, double* out);
+int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int64_t nkeep, const double* recv_x, int64_t nrecv);
+
 /* dmc_propagate's step loop (pyqmc/method/dmc.py:123-221) fused on the device for real wave functions, open or
    periodic: per step (1) one T-move per electron (compute_tmoves eval_ecp.py:43-80, propose_tmoves dmc.py:73-120,
    masked updateinternals :160-168), (2) one drift-diffusion move per electron with Umrigar's limited drift

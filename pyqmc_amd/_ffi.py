@@ -94,6 +94,8 @@ _PROTOTYPES = {
     "pqa_vmc_sweeps": (C.c_int, [_H, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_resample": (C.c_int, [_H, C.c_void_p]),
+    "pqa_get_walkers": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pqa_branch_exchange": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "pqa_dmc_steps": (C.c_int, [_H, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                 C.c_uint64, C.c_void_p, C.c_void_p]),
     "pqa_dm_walk": (C.c_int, [_H, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,

@@ -1890,6 +1890,70 @@ extern "C" int pqa_resample(pqa_handle_t* h, const int32_t* newinds) {
   return 0;
 }
 
+// ---------------------------------------------------------------- distributed branching (one walker exchange per block)
+// dst row k <- src row idx[k] for k < n (k_gather_rows with a destination that is NOT one of the handle's buffers)
+extern "C" int pqa_get_walkers(pqa_handle_t* h, const int32_t* idx, int64_t n, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  if (n <= 0) return 0;
+  for (int64_t k = 0; k < n; ++k)
+    if (idx[k] < 0 || idx[k] >= h->W) FAIL("pqa_get_walkers: index out of range");
+  const size_t row = (size_t)h->N * 3;
+  TRY(ensure(h, h->b_rsidx, (size_t)n * sizeof(int)));
+  TRY(ensure(h, h->b_pts, (size_t)n * row * sizeof(double)));
+  TRY(copy_in(h, h->b_rsidx.p, idx, (size_t)n * sizeof(int)));
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n, (unsigned)((row + 1023) / 1024)), dim3(256), 0, h->stream, (const double*)h->js.x,
+                     (double*)h->b_pts.p, (const int*)h->b_rsidx.p, (long)row);
+  TRY(check_launch(h, "k_gather_rows"));
+  return copy_out(h, out, h->b_pts.p, (size_t)n * row * sizeof(double));
+}
+
+// Wave-function state of walkers [w0, w0 + n) from their coordinates: the recompute pipeline run on a view of the state.
+static int recompute_range(pqa_handle* h, long w0, long n) {
+  if (n <= 0) return 0;
+  const JastrowState js0 = h->js;
+  const SlaterState st0 = h->st;
+  const long W0 = h->W;
+  const size_t cf = h->cplx ? 2 : 1;
+  const int nel[2] = {h->nup, h->ndn};
+  h->js.x += (size_t)w0 * h->N * 3;
+  if (h->has_j2) { h->js.avalues += (size_t)w0 * h->natom * h->na * 2; h->js.bvalues += (size_t)w0 * h->nb * 3; }
+  if (h->has_slater)
+    for (int s = 0; s < 2; ++s) {
+      const size_t D = h->ndet_s[s], ne = nel[s];
+      h->st.T[s] += cf * w0 * D * ne * ne; h->st.dsign[s] += cf * w0 * D; h->st.dlog[s] += (size_t)w0 * D;
+      h->st.cache[s] += (size_t)w0 * ne * 5 * h->nmo[s];
+    }
+  h->W = n;
+  int rc = 0;
+  if (h->has_slater) rc = slater_rebuild(h);
+  if (!rc && h->has_j2 && !h->jas_stale) {
+    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)n), dim3(64), 0, h->stream, h->S, h->js);
+    rc = check_launch(h, "k_jastrow_recompute");
+  }
+  if (!rc && h->has_j3) {
+    hipLaunchKernelGGL(k_j3_value, dim3((unsigned)n), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p + w0);
+    rc = check_launch(h, "k_j3_value");
+  }
+  h->js = js0; h->st = st0; h->W = W0;
+  return rc;
+}
+
+extern "C" int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int64_t nkeep, const double* recv_x, int64_t nrecv) {
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call recompute)");
+  if (nkeep < 0 || nrecv < 0 || nkeep + nrecv != h->W) FAIL("pqa_branch_exchange: kept + received walkers must equal the resident count");
+  std::vector<int32_t> idx((size_t)h->W, 0);
+  for (int64_t k = 0; k < nkeep; ++k) idx[k] = keep_src[k];
+  TRY(pqa_resample(h, idx.data()));  // received slots gather walker 0's state: overwritten below
+  if (nrecv > 0) {
+    TRY(copy_in(h, h->js.x + (size_t)nkeep * h->N * 3, recv_x, (size_t)nrecv * h->N * 3 * sizeof(double)));
+    TRY(recompute_range(h, nkeep, nrecv));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // device-wide exclusive scan c[n] -> o[n+1]; marks[k] = o[k*Wm] for k = 0..n/Wm (pqa_dmc.hpp)
 static int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks) {
   const long nt = (n + 1023) / 1024;

@@ -53,58 +53,122 @@ def combine_blocks(block_avgs, counts):
     return {k: sum(b[k] * wi for b, wi in zip(block_avgs, w)) for k in block_avgs[0]}
 
 
-def branch_distributed(configs, weights, base_u=None):
-    """Stochastic-comb branching (``pyqmc/method/dmc.py:342-376``) of an ensemble sharded over ranks.
+def exchange_plan(newinds, counts, rank):
+    """Who sends what to whom after the global comb ``newinds`` (global source index per global new slot; shards are the
+    contiguous blocks of sizes ``counts``).  Returns for ``rank``:
+    ``keep``  local source indices of the new walkers whose source already lives here (in comb order),
+    ``recv``  {src_rank: number of walkers arriving from it} and ``send`` {dst_rank: local indices (duplicates allowed) of the
+    walkers to ship there}, both in comb order so that sender and receiver agree on the sequence."""
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    owner = np.searchsorted(offs, newinds, side="right") - 1  # rank that holds each SOURCE walker
+    lo, hi = offs[rank], offs[rank + 1]
+    mine = newinds[lo:hi]
+    mine_owner = owner[lo:hi]
+    keep = (mine[mine_owner == rank] - lo).astype(np.int32)
+    recv = {int(q): int(np.sum(mine_owner == q)) for q in np.unique(mine_owner) if q != rank}
+    send = {}
+    for q in range(len(counts)):
+        if q == rank:
+            continue
+        src = newinds[offs[q] : offs[q + 1]]
+        sel = src[(src >= lo) & (src < hi)]
+        if len(sel):
+            send[q] = (sel - lo).astype(np.int32)
+    return keep, recv, send
 
-    The reference gathers all walkers to the master, branches and re-splits (dmc.py:286-287, :566).  Here every
-    rank all-gathers the weights (8 B per walker) and the coordinates, rank 0 broadcasts the single uniform of
-    the comb, every rank computes the same global resampling indices and keeps the slice that belongs to its
-    shard — so shards stay exactly the size they had and no master exists.  Wave-function internals are not
-    exchanged: like the reference (dmc.py:155) the caller recomputes them at the next propagate.
-    Returns (configs, weights, info, global weight std).
-    """
+
+def branch_distributed(configs, weights, base_u=None, dev=None):
+    """Stochastic-comb branching (``pyqmc/method/dmc.py:342-376``) of an ensemble sharded over ranks, as SURVEY.md section
+    8(e) specifies it: all-gather of the WEIGHTS only (8 B per walker), one broadcast uniform, the identical comb on every
+    rank, and then one point-to-point exchange of just the walkers whose new owner differs from their old one —
+    coordinates (+ wrap counters), 1.5-3 KB each — where the reference gathers every walker to the master, branches and
+    re-splits (dmc.py:286-287, :566).  Shards keep their sizes; no master exists.
+
+    ``dev`` (a ``DeviceWF`` holding this shard's walkers): the outgoing coordinates are gathered on the device
+    (``pqa_get_walkers``) straight into the buffer RCCL sends from, the walkers that stay keep their whole wave-function
+    state (``pqa_branch_exchange`` gathers it like ``pqa_resample``) and only the RECEIVED walkers are recomputed.  Without
+    ``dev`` the coordinates come from ``configs`` and the caller recomputes, like the reference (dmc.py:155).
+
+    The new local order is: walkers that stayed (comb order), then arrivals by source rank (comb order) — walkers are
+    exchangeable and carry equal weights after the comb.  Returns (configs, weights, info, global weight std); ``info`` also
+    reports ``walkers moved`` (global) and ``bytes exchanged`` (sent by this rank)."""
     import torch
     import torch.distributed as dist
 
     from .dmc import comb_indices
 
-    x = np.ascontiguousarray(configs.configs)
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         from .dmc import branch
 
         wstd = float(np.std(weights))
-        return (*branch(configs, weights, base_u), wstd)
+        cfg, w, info = branch(configs, weights, base_u, on_resample=None if dev is None else dev.resample)
+        return cfg, w, {**info, "walkers moved": 0, "bytes exchanged": 0}, wstd
     world, rank = dist.get_world_size(), dist.get_rank()
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    n_local = torch.tensor([len(weights)], dtype=torch.int64, device=dev)
+    tdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    n_local = torch.tensor([len(weights)], dtype=torch.int64, device=tdev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
-    nx = int(np.prod(x.shape[1:]))
-    payload = x.reshape(len(weights), nx)
-    periodic = hasattr(configs, "wrap")  # PeriodicConfigs: the wrap counters travel with the coordinates (coord.py:191-198)
-    if periodic:
-        payload = np.concatenate([payload, np.asarray(configs.wrap, dtype=np.float64).reshape(len(weights), nx)], axis=1)
-    nmax, row = max(counts), payload.shape[1]
-    pad_w = torch.zeros(nmax, dtype=torch.float64, device=dev)
+    pad_w = torch.zeros(max(counts), dtype=torch.float64, device=tdev)
     pad_w[: len(weights)] = torch.from_numpy(np.asarray(weights, dtype=np.float64))
-    pad_x = torch.zeros(nmax, row, dtype=torch.float64, device=dev)
-    pad_x[: len(weights)] = torch.from_numpy(np.ascontiguousarray(payload))
     all_w = [torch.zeros_like(pad_w) for _ in range(world)]
-    all_x = [torch.zeros_like(pad_x) for _ in range(world)]
     dist.all_gather(all_w, pad_w)
-    dist.all_gather(all_x, pad_x)
     gw = np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_w, counts)])
-    gx = np.concatenate([t[:c].cpu().numpy() for t, c in zip(all_x, counts)])
-    u = torch.tensor([np.random.rand() if base_u is None else base_u], dtype=torch.float64, device=dev)
+    u = torch.tensor([np.random.rand() if base_u is None else base_u], dtype=torch.float64, device=tdev)
     dist.broadcast(u, src=0)
     newinds, wtot = comb_indices(gw, float(u.item()))
     unique, cnt = np.unique(newinds, return_counts=True)
-    lo = int(np.sum(counts[:rank]))
-    mine = newinds[lo : lo + counts[rank]]
-    configs.configs = np.ascontiguousarray(gx[mine][:, :nx]).reshape((len(mine),) + x.shape[1:])
+    # The comb starts at a random offset u * sum(w) (dmc.py:358-361), so its slot -> source map is a cyclic shift of a
+    # monotone one: taken literally nearly every walker would change ranks.  Only the MULTISET of sources matters (walkers
+    # are exchangeable and leave the comb with equal weights), so the slots are filled in source order: copies stay on or
+    # next to the rank that holds the source.
+    newinds = np.sort(newinds)
+    keep, recv, send = exchange_plan(newinds, counts, rank)
+    x = configs.configs
+    nx = int(np.prod(x.shape[1:]))
+    periodic = hasattr(configs, "wrap")  # PeriodicConfigs: the wrap counters travel with the coordinates (coord.py:191-198)
+    row = nx * (2 if periodic else 1)
+    ops, inbox, outbox, sent_bytes = [], {}, {}, 0
+    for q, idx in sorted(send.items()):
+        buf = torch.empty((len(idx), row), dtype=torch.float64, device=tdev)
+        if dev is not None and tdev.type == "cuda":
+            if periodic:  # coordinates gathered on the device, the (host-side) wrap counters appended
+                xs = torch.empty((len(idx), nx), dtype=torch.float64, device=tdev)
+                dev.get_walkers(idx, out=xs.data_ptr())
+                buf[:, :nx] = xs
+                buf[:, nx:] = torch.from_numpy(np.ascontiguousarray(np.asarray(configs.wrap, dtype=np.float64)[idx].reshape(len(idx), nx))).to(tdev)
+            else:
+                dev.get_walkers(idx, out=buf.data_ptr())
+        else:
+            src = dev.get_walkers(idx).reshape(len(idx), nx) if dev is not None else x[idx].reshape(len(idx), nx)
+            buf[:, :nx] = torch.from_numpy(np.ascontiguousarray(src))
+            if periodic:
+                buf[:, nx:] = torch.from_numpy(np.ascontiguousarray(np.asarray(configs.wrap, dtype=np.float64)[idx].reshape(len(idx), nx)))
+        outbox[q] = buf
+        sent_bytes += buf.numel() * 8
+        ops.append(dist.P2POp(dist.isend, buf, q))
+    for q, n in sorted(recv.items()):
+        inbox[q] = torch.empty((n, row), dtype=torch.float64, device=tdev)
+        ops.append(dist.P2POp(dist.irecv, inbox[q], q))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    nrecv = sum(recv.values())
+    got = torch.cat([inbox[q] for q in sorted(inbox)], dim=0) if nrecv else torch.empty((0, row), dtype=torch.float64, device=tdev)
+    got_host = got.cpu().numpy()
+    if dev is not None:  # state follows the walkers that stay; arrivals are recomputed (device pointer under RCCL)
+        gx = got[:, :nx].contiguous()
+        if tdev.type == "cuda":
+            torch.cuda.current_stream().synchronize()  # the library reads gx on its own HIP stream: torch's work must be done
+        dev.branch_exchange(keep, gx.data_ptr() if (nrecv and tdev.type == "cuda") else (gx.cpu().numpy() if nrecv else None), nrecv)
+    shape = (len(keep) + nrecv,) + x.shape[1:]
+    configs.configs = np.ascontiguousarray(np.concatenate([x[keep].reshape(len(keep), nx), got_host[:, :nx]], axis=0)).reshape(shape)
     if periodic:
-        configs.wrap = np.ascontiguousarray(gx[mine][:, nx:]).reshape((len(mine),) + x.shape[1:])
-    new_w = np.full(len(mine), wtot / len(gw))
-    info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique))}
+        w0 = np.asarray(configs.wrap)
+        configs.wrap = np.concatenate([w0[keep].reshape(len(keep), nx), got_host[:, nx:]], axis=0).reshape(shape).astype(w0.dtype)
+    new_w = np.full(shape[0], wtot / len(gw))
+    moved = int(np.sum(np.searchsorted(np.concatenate([[0], np.cumsum(counts)]), newinds, side="right") - 1
+                       != np.repeat(np.arange(world), counts)))
+    info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique)), "walkers moved": moved,
+            "bytes exchanged": int(sent_bytes)}
     return configs, new_w, info, float(np.std(gw))

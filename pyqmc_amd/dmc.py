@@ -263,8 +263,9 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every rank calls this with
     its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo).
 
-    Single-process runs on the fused path branch ON THE DEVICE: the comb's indices gather the wave-function state
-    (``pqa_resample``) instead of recomputing it from the resampled coordinates as the reference does after every
+    Runs on the fused path branch ON THE DEVICE: the comb's indices gather the wave-function state (``pqa_resample``;
+    sharded runs: ``dist.branch_distributed`` -> ``pqa_branch_exchange``, which also recomputes the walkers that arrived
+    from other ranks) instead of recomputing everything from the resampled coordinates as the reference does after every
     branch (dmc.py:155); a full recompute every ``recompute_every`` blocks bounds the round-off the Sherman-Morrison
     updates accumulate (``recompute_every=1`` is the reference's schedule)."""
     from . import dist as pdist
@@ -284,7 +285,7 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     W = configs.configs.shape[0]
     weights = np.ones(W) if weights is None else weights
     rows = []
-    dev = None if distributed else fused_dmc_supported(wf, accumulators, ekey)
+    dev = fused_dmc_supported(wf, accumulators, ekey)  # device-resident branching: single process AND sharded runs
     current = False
     for block in range(nblocks):
         blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
@@ -296,7 +297,10 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
             wsum, wtot_n = sums[-2], sums[-1]
             blk = {k: s / wsum for k, s in zip(keys, sums[:-2])}
             blk["weight"] = wsum / wtot_n
-            configs, weights, info, wstd = pdist.branch_distributed(configs, weights)
+            # weights all-gathered, identical comb on every rank, only re-assigned walkers exchanged (device buffers under
+            # RCCL); the state of walkers that stay is gathered on the device, arrivals alone are recomputed
+            configs, weights, info, wstd = pdist.branch_distributed(configs, weights, dev=dev)
+            current = dev is not None
             blk["weight_std"] = wstd
             mean_w = float(pdist.allreduce_block([weights.sum()], len(weights))[0][0])
         else:

@@ -296,6 +296,24 @@ class DeviceWF:
         assert idx.shape == (self.W,)
         self.call("pqa_resample", _ffi.ptr(idx))
 
+    def get_walkers(self, idx, out=None):
+        """``pqa_get_walkers``: coordinates (n,N,3) of the resident walkers ``idx``; ``out``: raw pointer (int) of a device or
+        host buffer to fill instead of returning a new host array."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if out is not None:
+            self.call("pqa_get_walkers", _ffi.ptr(idx), len(idx), C.c_void_p(out))
+            return None
+        res = np.empty((len(idx), self.N, 3))
+        self.call("pqa_get_walkers", _ffi.ptr(idx), len(idx), _ffi.ptr(res))
+        return res
+
+    def branch_exchange(self, keep_src, recv_x, nrecv):
+        """``pqa_branch_exchange``: new ensemble = resident walkers ``keep_src`` (state gathered) + ``nrecv`` received walkers
+        (``recv_x``: host array or raw device pointer), whose state alone is recomputed."""
+        keep = np.ascontiguousarray(keep_src, dtype=np.int32)
+        ptr = C.c_void_p(recv_x) if isinstance(recv_x, int) else _ffi.ptr(None if recv_x is None else _ffi.f64(recv_x))
+        self.call("pqa_branch_exchange", _ffi.ptr(keep), len(keep), ptr, int(nrecv))
+
     def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0):
         """``pqa_dmc_steps``: ``nsteps`` DMC steps on the resident walkers.  ``weights`` (W) is updated in place.
         ``tapes``: dict of the replay arrays of ``pqa_dmc_tapes_t`` or None (device Philox streams).

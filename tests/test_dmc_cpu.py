@@ -138,12 +138,58 @@ def test_distributed_branch_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    joined = np.concatenate([r[1] for r in res])
-    assert np.array_equal(joined, g["branch_newconfigs"])
+    # together the ranks hold exactly the reference's resampled ensemble, bit for bit, as a multiset (walkers are exchangeable
+    # and carry equal weights after the comb; slots are filled in source order so that few walkers change ranks)
+    assert np.array_equal(_sorted_rows(np.concatenate([r[1] for r in res])), _sorted_rows(g["branch_newconfigs"]))
     assert relerr(np.concatenate([r[2] for r in res]), g["branch_newweights"]) < 1e-14
     for r in res:
         assert [r[3]["max branches"], r[3]["Number of walkers killed"]] == g["branch_info"].tolist()
         assert abs(r[4] - np.std(g["branch_weights"])) < 1e-14
+
+
+def _sorted_rows(x):
+    rows = np.asarray(x).reshape(len(x), -1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+def test_distributed_branch_four_ranks_moves_only_reassigned_walkers():
+    """weights all-gathered, identical comb everywhere, and ONLY the walkers whose new owner differs from the old
+    one cross ranks.  World size 4 over gloo: every rank ends with exactly its slice of the single-process comb (bit for bit),
+    the number of walkers that crossed equals the plan's count and the bytes sent are those walkers' coordinates only."""
+    import torch.multiprocessing as mp
+
+    g = golden("g12_dmc")
+    W = len(g["branch_weights"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_branch_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bounds = pdist.shard_bounds(W, 4)
+    counts = [hi - lo for lo, hi in bounds]
+    newinds = np.sort(dmc.comb_indices(g["branch_weights"], float(g["branch_u"]))[0])  # slots filled in source order
+    assert np.array_equal(_sorted_rows(np.concatenate([r[1] for r in res])), _sorted_rows(g["branch_newconfigs"]))  # = the reference's ensemble
+    owner_new = np.repeat(np.arange(4), counts)
+    owner_old = np.searchsorted(np.cumsum(counts), newinds, side="right")
+    moved = int(np.sum(owner_new != owner_old))
+    assert 0 < moved < W // 2  # the fixture's weights do send some walkers across, and keep most at home
+    sent = 0
+    for r, (lo, hi) in zip(res, bounds):
+        assert np.array_equal(_sorted_rows(r[1]), _sorted_rows(g["branch_configs"][newinds[lo:hi]]))
+        assert r[3]["walkers moved"] == moved and len(r[1]) == hi - lo
+        keep, recv, send = pdist.exchange_plan(newinds, counts, r[0])
+        assert r[3]["bytes exchanged"] == 8 * g["branch_configs"][0].size * sum(len(v) for v in send.values())
+        assert len(keep) + sum(recv.values()) == hi - lo
+        sent += r[3]["bytes exchanged"]
+    assert sent == moved * 8 * g["branch_configs"][0].size  # nothing but the re-assigned walkers travelled
 
 
 def test_distributed_branch_periodic_walkers_keep_their_wrap_counters():
@@ -168,9 +214,10 @@ def test_distributed_branch_periodic_walkers_keep_their_wrap_counters():
     cfg0, wrap0 = _periodic_branch_input(g)
     newinds, _ = dmc.comb_indices(g["branch_weights"], float(g["branch_u"]))
     # (mask() re-folds through the constructor like the reference, coord.py:159-162: equal to the last bit or two)
-    assert np.allclose(np.concatenate([r[1] for r in res]), cfg0.configs[newinds], rtol=0, atol=1e-10)
-    assert np.array_equal(np.concatenate([r[5] for r in res]), cfg0.wrap[newinds])
-    assert np.allclose(np.concatenate([r[1] for r in res]) - 500.0, g["branch_newconfigs"], atol=1e-9)
+    n = len(newinds)
+    both = np.concatenate([np.concatenate([r[1] for r in res]).reshape(n, -1), np.concatenate([r[5] for r in res]).reshape(n, -1)], axis=1)
+    ref = np.concatenate([cfg0.configs[newinds].reshape(n, -1), cfg0.wrap[newinds].reshape(n, -1)], axis=1)  # a walker's wrap counters stay with it
+    assert np.allclose(_sorted_rows(np.round(both, 8)), _sorted_rows(np.round(ref, 8)), rtol=0, atol=1e-8)
 
 
 def test_driver_reproduces_reference_periodic_dmc_propagate():

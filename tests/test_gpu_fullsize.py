@@ -216,3 +216,74 @@ def test_vmc_philox_energy_statistics():
     e_orc, s_orc = float(np.mean(eo)), float(np.std(eo) / np.sqrt(Wo))
     note("vmc_stat_oracle_mean", e_orc), note("vmc_stat_oracle_stderr", s_orc)
     assert abs(e_phi - e_orc) < 4.0 * np.hypot(s_phi, s_orc), (e_phi, e_orc, s_phi, s_orc)
+
+
+def _exchange_worker(rank, world, port, q, periodic):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pyqmc_amd as pa
+        from pyqmc_amd import dist as pdist
+
+        if periodic:
+            mol, wf = helpers.gpu_pbc_wf("fcc2cubic")
+        else:
+            mol = systems.water()
+            wf = helpers.gpu_wf3(mol, systems.random_mf(mol, nvirt=6), None)
+        dev = wf.fused_device()
+        W = 48 + 5 * rank  # unequal shards
+        cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(10 + rank))
+        wf.recompute(cfg)
+        dev.vmc_sweeps(0.3, 1, seed=3 + rank, energy=False)  # a state produced by updates, not by a recompute
+        cfg.configs[...] = dev.configs()
+        if periodic:
+            cfg.wrap += dev.wrap_delta()
+        before = (cfg.configs.copy(), None if not periodic else cfg.wrap.copy(), dev.value()[1].copy())
+        weights = np.random.default_rng(50 + rank).random(W) ** 3 * (0.3 if rank == 0 else 3.0)  # rank 1 outweighs rank 0: copies must cross
+        cfg, w, info, wstd = pdist.branch_distributed(cfg, weights.copy(), base_u=0.37, dev=dev)
+        after_log = dev.value()[1].copy()  # state that followed / was recomputed for the walkers now here
+        assert np.array_equal(dev.configs(), cfg.configs) or periodic
+        fresh = wf.recompute(cfg)[1]
+        q.put((rank, before, weights, cfg.configs, None if not periodic else cfg.wrap, w, info, after_log, fresh))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_distributed_branching_exchanges_walkers_between_device_handles(periodic):
+    """SURVEY 8(e) on real device handles (two ranks, gloo, both on this GPU): the comb's re-assigned walkers leave one
+    handle as coordinates (pqa_get_walkers) and enter the other (pqa_branch_exchange), where ONLY they are recomputed; the
+    walkers that stay carry their updated state along.  Afterwards every rank's device state equals a fresh recompute of
+    its new walkers, and the ranks together hold exactly the single-process comb's ensemble."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from pyqmc_amd import dmc
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q, periodic)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x0 = np.concatenate([r[1][0] for r in res])
+    gw = np.concatenate([r[2] for r in res])
+    newinds = np.sort(dmc.comb_indices(gw, 0.37)[0])
+    rows = lambda a: a.reshape(len(a), -1)[np.lexsort(a.reshape(len(a), -1).T[::-1])]
+    assert np.array_equal(rows(np.concatenate([r[3] for r in res])), rows(x0[newinds]))  # the single-process comb's ensemble
+    assert res[0][6]["walkers moved"] > 0 and res[0][6]["bytes exchanged"] + res[1][6]["bytes exchanged"] > 0
+    for r in res:
+        assert len(r[3]) == len(r[2]) and np.allclose(r[5], gw.sum() / len(gw))
+        assert note(f"exchange_state_vs_recompute_{int(periodic)}_{r[0]}", np.max(np.abs(r[7] - r[8]))) < 1e-9
