@@ -258,7 +258,8 @@ def branch(configs, weights, base_u=None, on_resample=None):
 
 
 def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=None, accumulators=None, verbose=False,
-           ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False, recompute_every=10):
+           ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False, recompute_every=10,
+           hdf_file=None):
     """Block loop of the reference's ``rundmc`` (no restart files): VMC warm-up, energy reference, then
     propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every rank calls this with
     its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo).
@@ -267,8 +268,13 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     sharded runs: ``dist.branch_distributed`` -> ``pqa_branch_exchange``, which also recomputes the walkers that arrived
     from other ranks) instead of recomputing everything from the resampled coordinates as the reference does after every
     branch (dmc.py:155); a full recompute every ``recompute_every`` blocks bounds the round-off the Sherman-Morrison
-    updates accumulate (``recompute_every=1`` is the reference's schedule)."""
+    updates accumulate (``recompute_every=1`` is the reference's schedule).
+    ``hdf_file``: per-block output, walkers and weights in the reference's on-disk layout (``dmc_file`` dmc.py:379-391;
+    ``pyqmc_amd.blockfile``), written by rank 0 of a sharded run for its own shard."""
     from . import dist as pdist
+    from .blockfile import BlockFile
+
+    out = None if hdf_file is None else BlockFile(hdf_file)
     from .vmc import vmc
 
     nsteps_per_block = max(1, int(0.1 / tstep)) if nsteps_per_block is None else nsteps_per_block
@@ -310,6 +316,8 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
             mean_w = np.mean(weights)
         blk.update(info, e_trial=e_trial, e_est=e_est, block=block, esigma=esigma, tstep=tstep, nsteps_per_block=nsteps_per_block)
         rows.append(blk)
+        if out is not None:
+            out.append(blk, {}, configs, weights)  # the reference's DMC file has no attributes: tstep is a per-block dataset
         en_b = np.array([r[ekey[0] + ekey[1]] for r in rows])
         wt_b = np.array([r["weight"] for r in rows])
         warm = len(en_b) // 4

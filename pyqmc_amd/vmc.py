@@ -107,16 +107,34 @@ def _vmc_worker_protocol(wf, configs, tstep, nsteps, accumulators):
     return block_avg, configs
 
 
-def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=None, verbose=False, seed=None, fused=None):
-    """Block loop of ``pyqmc.method.mc.vmc`` (mc.py:176-274) without the HDF5 side
-    (checkpointing is out of scope): returns (dict of arrays of length nblocks, configs)."""
+def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=None, verbose=False, seed=None, fused=None,
+        hdf_file=None, continue_from=None):
+    """Block loop of ``pyqmc.method.mc.vmc`` (mc.py:176-274): returns (dict of arrays over the blocks run, configs).
+    ``hdf_file``: block output in the reference's on-disk layout (``pyqmc_amd.blockfile``: HDF5 when h5py exists, NumPy
+    archives otherwise); an existing file — or ``continue_from`` — restarts from its walkers at ``block[-1] + 1``, and
+    ``nblocks`` counts the blocks of all calls together, as in the reference (mc.py:223-243)."""
+    from .blockfile import BlockFile
+
     accumulators = accumulators or {}
+    out = None if hdf_file is None else BlockFile(hdf_file)
+    source = out if continue_from is None else BlockFile(continue_from)
+    if continue_from is not None:
+        if not source.exists():
+            raise RuntimeError(f"cannot continue from {continue_from}; the file does not exist!")
+        if out is not None and out.exists():
+            raise RuntimeError(f"continue_from is not None but hdf_file={hdf_file} already exists! Delete or rename {hdf_file} and try again.")
+    first = 0
+    if source is not None and source.exists() and source.last_block() is not None:
+        first = source.last_block() + 1
+        source.load_walkers(configs)
     df = {}
-    for block in range(nblocks):
+    for block in range(first, nblocks):
         blk, configs = vmc_worker(wf, configs, tstep, nsteps_per_block, accumulators, fused=fused,
                                   seed=None if seed is None else seed + block)
         blk["block"] = block
         blk["nconfig"] = nsteps_per_block * configs.configs.shape[0]
+        if out is not None:
+            out.append(blk, {"tstep": tstep}, configs)
         if verbose:
             print(f"block {block}: " + ", ".join(f"{k}={np.real(v):.6g}" for k, v in blk.items() if "total" in k or k == "acceptance"))
         for k, v in blk.items():

@@ -1272,6 +1272,92 @@ def g_complex_testvalue_many():
     save("g25_complex_testvalue_many", **out)
 
 
+# ------------------------------------------------------------------ G27 on-disk layout (hdftools)
+class _FakeDataset:
+    def __init__(self, shape, dtype):
+        self.a = np.zeros(shape, dtype=dtype if dtype is not None else float)
+
+    shape = property(lambda self: self.a.shape)
+    dtype = property(lambda self: self.a.dtype)
+
+    def resize(self, shape, axis=None):
+        shape = tuple(shape) if axis is None else self.a.shape[:axis] + (shape,) + self.a.shape[axis + 1:]
+        new = np.zeros(shape, dtype=self.a.dtype)
+        sl = tuple(slice(0, min(o, n)) for o, n in zip(self.a.shape, shape))
+        new[sl] = self.a[sl]
+        self.a = new
+
+    def __setitem__(self, k, v):
+        self.a[k] = v
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+
+class _FakeH5File(dict):
+    """In-memory stand-in for h5py.File: records what the reference creates (names, shapes, dtypes, attributes)."""
+    store = {}
+
+    def __new__(cls, path, mode="r"):
+        if path not in cls.store:
+            cls.store[path] = dict.__new__(cls)
+            cls.store[path].attrs = {}
+        return cls.store[path]
+
+    def __init__(self, path, mode="r"):
+        pass
+
+    def create_dataset(self, name, shape=None, maxshape=None, dtype=None, chunks=None, data=None):
+        self[name] = _FakeDataset(shape, dtype)
+        return self[name]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def g_hdf_layout():
+    """Names, shapes and dtype kinds of everything the reference's vmc (mc.py:92-99,262-265) and rundmc (dmc.py:379-391)
+    put into their HDF5 file, recorded through an in-memory h5py stand-in (no HDF5 library in this image)."""
+    import json
+
+    import pyqmc.method.dmc as refdmc
+    import pyqmc.method.mc as refmc
+
+    import pyqmc.wf.orbitals as reforb
+
+    orig_aos = reforb.MoleculeOrbitalEvaluator.aos
+
+    def aos(self, eval_str, configs, mask=None):  # the un-JIT-ed AO stand-in cannot reshape a zero-point result (see g_dmc)
+        coords = configs.configs if mask is None else configs.configs[mask]
+        if coords.size == 0:
+            nao = self.parameters["mo_coeff_alpha"].shape[0]
+            return np.zeros((1, *coords.shape[:-1], nao) if "deriv" not in eval_str else (1, 4 if "deriv1" in eval_str else 5, *coords.shape[:-1], nao))
+        return orig_aos(self, eval_str, configs, mask)
+
+    reforb.MoleculeOrbitalEvaluator.aos = aos
+    fake = types.SimpleNamespace(File=_FakeH5File)
+    refmc.h5py = refdmc.h5py = fake
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    out = {}
+    np.random.seed(3)
+    wf = make_wf(mol, mf)
+    cfg = walkers(mol, 6, 1)
+    refmc.vmc(wf, cfg, nblocks=3, nsteps_per_block=2, tstep=0.3, accumulators={"energy": pyq.EnergyAccumulator(mol)}, hdf_file="vmc.h5")
+    f = _FakeH5File.store["vmc.h5"]
+    out["vmc"] = {k: [list(v.shape), v.dtype.kind] for k, v in f.items()}
+    out["vmc_attrs"] = sorted(f.attrs)
+    refdmc.rundmc(wf, walkers(mol, 6, 2), tstep=0.05, nblocks=2, nsteps_per_block=2, vmc_warmup=1,
+                  accumulators={"energy": pyq.EnergyAccumulator(mol)}, hdf_file="dmc.h5")
+    f = _FakeH5File.store["dmc.h5"]
+    out["dmc"] = {k: [list(v.shape), v.dtype.kind] for k, v in f.items()}
+    out["dmc_attrs"] = sorted(f.attrs)
+    save("g27_hdf_layout", layout=np.array(json.dumps(out, sort_keys=True)))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1298,3 +1384,4 @@ if __name__ == "__main__":
     g_tbdm()
     g_pbc_pgrad()
     g_complex_testvalue_many()
+    g_hdf_layout()

@@ -556,6 +556,40 @@ def test_wave_function_copy_and_pickle_rebuild_an_independent_handle():
         wf.recompute(cfg)
 
 
+def test_vmc_and_dmc_write_the_reference_layout(tmp_path):
+    """vmc(hdf_file=...) and rundmc(hdf_file=...) write what the reference's loops write (golden g27: names, shapes,
+    dtype kinds; mc.py:92-99, dmc.py:379-391) — through the NumPy-archive back end here (no HDF5 library in the image) — and
+    vmc continues an existing file from its walkers at block[-1] + 1 (mc.py:235-243)."""
+    import json
+
+    import pyqmc_amd as pa
+    from pyqmc_amd import blockfile
+
+    lay = json.loads(str(golden("g27_hdf_layout")["layout"]))
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    np.random.seed(4)
+    acc = {"energy": pa.EnergyAccumulator(mol)}
+    path = str(tmp_path / "vmc.hdf5")
+    df, cfg = pa.vmc(wf, pa.initial_guess(mol, 6, rng=np.random.default_rng(1)), nblocks=3, nsteps_per_block=2, tstep=0.3, accumulators=acc, hdf_file=path)
+    store = blockfile.BlockFile(path)
+    assert {k: [list(s), kind] for k, (s, kind) in store.listing().items()} == lay["vmc"] and sorted(store.attrs()) == lay["vmc_attrs"]
+    assert np.array_equal(store.datasets()["energytotal"], df["energytotal"]) and np.array_equal(store._state()["configs"], cfg.configs)
+    # continue: two more blocks, starting from the stored walkers
+    fresh = pa.initial_guess(mol, 6, rng=np.random.default_rng(9))
+    df2, cfg2 = pa.vmc(wf, fresh, nblocks=5, nsteps_per_block=2, tstep=0.3, accumulators=acc, hdf_file=path)
+    assert df2["block"].tolist() == [3, 4] and store.datasets()["block"].tolist() == [0, 1, 2, 3, 4]
+    assert np.array_equal(store._state()["configs"], cfg2.configs)
+    out = blockfile.read_mc_output(path, warmup=1)
+    assert abs(out["energytotal"] - store.datasets()["energytotal"][1:].mean()) < 1e-14
+    path = str(tmp_path / "dmc.hdf5")
+    df, cfg, w = pa.rundmc(wf, pa.initial_guess(mol, 6, rng=np.random.default_rng(2)), tstep=0.05, nblocks=2, nsteps_per_block=2, vmc_warmup=1,
+                           accumulators=acc, hdf_file=path)
+    store = blockfile.BlockFile(path)
+    assert {k: [list(s), kind] for k, (s, kind) in store.listing().items()} == lay["dmc"] and sorted(store.attrs()) == lay["dmc_attrs"]
+    assert np.array_equal(store._state()["weights"], w)
+
+
 def test_gram_on_the_matrix_cores_matches_numpy():
     """pqa_gram (k_gram_mfma: v_mfma_f64_16x16x4_f64, slices of the configuration axis summed in fixed order): A^T B for
     shapes that do not fill the 16x16 tiles or the 4-row steps, real and complex (four real products), and
