@@ -16,6 +16,15 @@
 #ifndef PQA_PRIM_UNROLL
 #define PQA_PRIM_UNROLL 1
 #endif
+// Primitive screening (opt-in, -DPQA_PRIM_SCREEN=1): skip a primitive with alpha r^2 > 60 (it contributes < 8.8e-27 of its
+// coefficient).  MEASURED AND DROPPED as a default (round 2, tools/scratch/ab_screen.sh): the test is per lane and the exp
+// sequence is only saved when EVERY lane of the wave skips; the 64 points of a wave are 64 different walkers (or, in periodic
+// cells, each lane's own image), some lane is nearly always close, and the extra compare + branch cost more than the rare
+// skip saves: open-system k_orb<5> 136.7 -> 141.4 us per 65536 points, periodic steps 1-2 % slower.
+#ifndef PQA_PRIM_SCREEN
+#define PQA_PRIM_SCREEN 0
+#endif
+#define PQA_PRIM_CUT 60.0
 
 // p-th point lives at base + (p / group) * group_stride + (p % group) * 3
 struct PointAddr {
@@ -79,6 +88,9 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 #pragma unroll PQA_PRIM_UNROLL
   for (int p = 0; p < np; ++p) {
     const double a = pexp[p];
+#if PQA_PRIM_SCREEN
+    if (a * r2 > PQA_PRIM_CUT) continue;
+#endif
     const double t = pcoef[p] * exp(-a * r2);
     R += t;
     if (NCOMP > 1) dRs += a * t;
