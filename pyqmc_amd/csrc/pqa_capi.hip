@@ -1399,10 +1399,10 @@ static int lw_from_aos(pqa_handle* h, bool with_cache = true) {
   TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 4 * sizeof(double)));
   transpose(h, h->js.x, (double*)h->b_xt.p, W, (long)h->N * 3);
   for (int s = 0; s < 2; ++s) {
-    const size_t n = nel[s];
-    TRY(ensure(h, h->b_Tt[s], W * n * n * sizeof(double)));
+    const size_t n = nel[s], cf = h->cplx ? 2 : 1;
+    TRY(ensure(h, h->b_Tt[s], cf * W * n * n * sizeof(double)));
     TRY(ensure(h, h->b_ct[s], W * n * 5 * h->nmo[s] * sizeof(double)));
-    transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(n * n));
+    transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(cf * n * n));
     if (with_cache) transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
   }
   return check_launch(h, "k_transpose");
@@ -1414,7 +1414,7 @@ static int lw_to_aos(pqa_handle* h, bool with_cache) {
   transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W);
   for (int s = 0; s < 2; ++s) {
     const long n = nel[s];
-    transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], n * n, W);
+    transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], (h->cplx ? 2 : 1) * n * n, W);
     if (with_cache) transpose(h, (const double*)h->b_ct[s].p, h->st.cache[s], n * 5 * h->nmo[s], W);
   }
   return check_launch(h, "k_transpose");
@@ -1426,12 +1426,14 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
   if (soa_current) {
-    if (h->S.pbc)
-      hipLaunchKernelGGL(k_kinetic_lw<true>, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
-                         (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+    const dim3 gk((unsigned)((W + 63) / 64), (unsigned)h->N);
+    if (h->cplx) {
+      if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+    } else if (h->S.pbc)
+      hipLaunchKernelGGL(k_kinetic_lw<true>, gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     else
-      hipLaunchKernelGGL(k_kinetic_lw<false>, dim3((unsigned)((W + 63) / 64), (unsigned)h->N), dim3(64), 0, h->stream, h->S, lw_state(h),
-                         (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));
@@ -1659,9 +1661,10 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
   if (lw) {
     TRY(lw_from_aos(h));
-    TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 8 * W * sizeof(double)));
-    TRY(ensure(h, h->b_rbuf, (size_t)c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_vbuf, (size_t)c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
+    const size_t cf = h->cplx ? 2 : 1;
+    TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 12 * W * sizeof(double)));
+    TRY(ensure(h, h->b_rbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
+    TRY(ensure(h, h->b_vbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
     TRY(ensure(h, h->b_act, (size_t)c.KB * W));
   }
   return 0;
@@ -1681,17 +1684,19 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
       double* part = (double*)h->b_part.p;
       const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
       const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
-      double* rbuf = (double*)h->b_rbuf.p + (size_t)q * n_s * W;
-      double* vbuf = (double*)h->b_vbuf.p + (size_t)q * n_s * W;
+      const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
+      double* rbuf = (double*)h->b_rbuf.p + (size_t)q * cfi * n_s * W;
+      double* vbuf = (double*)h->b_vbuf.p + (size_t)q * cfi * n_s * W;
       uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
       const dim3 gm(gw.x, (unsigned)Gm);
-      if (h->S.pbc)
-        hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
-                           (const double*)nullptr, W, Gm, part);
-      else
-        hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)nullptr,
-                           (const double*)nullptr, W, Gm, part);
-      hipLaunchKernelGGL(k_propose_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
+#define PQA_MOVE_PART(POS, ROWS) do { \
+        if (h->cplx) { if (h->S.pbc) hipLaunchKernelGGL((k_move_part_lw<true, true>), gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); \
+                       else hipLaunchKernelGGL((k_move_part_lw<false, true>), gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); } \
+        else if (h->S.pbc) hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); \
+        else hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); } while (0)
+      PQA_MOVE_PART(nullptr, nullptr);
+      if (h->cplx) hipLaunchKernelGGL(k_propose_fin_lw<true>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
+      else hipLaunchKernelGGL(k_propose_fin_lw<false>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
       TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
       hipEvent_t pe1 = nullptr;
       if (h->profile && (e % (4 * (int)h->prof_stride)) == 0) {  // sparsely sampled (4 of a step's 128 launches at the default stride): an event pair costs ~2 us of stream time
@@ -1705,20 +1710,19 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
         pe1 = h->prof3_events[h->prof3_used].second;
         ++h->prof3_used;
       }
-      if (h->S.pbc)
-        hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
-                           W, Gm, part);
-      else
-        hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)mb.newpos, mo,
-                           W, Gm, part);
+      PQA_MOVE_PART(mb.newpos, mo);
+#undef PQA_MOVE_PART
       if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
-      hipLaunchKernelGGL(k_accept_fin_lw, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
-                         (const double*)part, rbuf, vbuf, act, mo);
+      if (h->cplx) hipLaunchKernelGGL(k_accept_fin_lw<true>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
+                                      (const double*)part, rbuf, vbuf, act, mo);
+      else hipLaunchKernelGGL(k_accept_fin_lw<false>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
+                              (const double*)part, rbuf, vbuf, act, mo);
       const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
       const dim3 gcm(gw.x, (unsigned)Gc);
-#define PQA_COMMIT(NM) do { if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
+#define PQA_COMMIT(NM) do { if (h->cplx) hipLaunchKernelGGL((k_commit_lw<NM, true, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
+                          else if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
                           else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
-      if (nmax <= 8) PQA_COMMIT(8); else if (nmax <= 16) PQA_COMMIT(16); else if (nmax <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
+      if (rowlen <= 8) PQA_COMMIT(8); else if (rowlen <= 16) PQA_COMMIT(16); else if (rowlen <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
 #undef PQA_COMMIT
       if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
         const int nq = j_hi - j_lo;
@@ -1734,8 +1738,10 @@ static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCt
           ce1 = h->prof2_events[h->prof2_used].second;
           ++h->prof2_used;
         }
-#define PQA_FLUSH(NM) hipLaunchKernelGGL(k_flush_lw<NM>, dim3((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)), dim3(256), (size_t)2 * nq * n_s * PQA_FLUSH_WB * sizeof(double), h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq)
-        if (nmax <= 8) PQA_FLUSH(8); else if (nmax <= 16) PQA_FLUSH(16); else if (nmax <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#define PQA_FLUSH(NM) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * PQA_FLUSH_WB * sizeof(double); const dim3 gf((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)); \
+        if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
+        else hipLaunchKernelGGL((k_flush_lw<NM, false>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
+        if (rowlen <= 8) PQA_FLUSH(8); else if (rowlen <= 16) PQA_FLUSH(16); else if (rowlen <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
 #undef PQA_FLUSH
         if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
       }
@@ -1789,7 +1795,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
   const size_t nrot = (size_t)N * std::max(h->necp, 1);
   const bool tile = tile_eligible(h);
-  const bool lw = !tile && h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && !h->cplx;
+  const bool lw = !tile && h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && (!h->cplx || std::max(h->nup, h->ndn) <= 32);
   LwCtx lc;
   TRY(lw_setup(h, lw, lc));
   for (int step = 0; step < nsteps; ++step) {

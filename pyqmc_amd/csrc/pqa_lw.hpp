@@ -17,6 +17,10 @@
 //   xt   [N][3][W]            coordinates
 //   Tt   [s] [n][n][W]        inverse, electron-major: Tt[i][k][w] = inverse[k][i]
 //   ct   [s] [n][5][nmo][W]   cached MO value/grad/lap rows of every electron
+// Complex determinants (CX instantiations; conventions of pqa_cslater.hpp): nmo counts REAL columns [Re | Im], so orbital o of a
+// row is (row[o], row[nmo/2 + o]); the inverse is (re, im) interleaved in the walker-major layout, i.e. planes
+// Tt[i][k][2][W] after the transpose; dsign is a unit phase [W][2]; V / R buffers hold 2 n planes.  The drift uses
+// Re(grad Psi / Psi) and the acceptance |ratio|^2 (mc.py:118,131).
 #pragma once
 #include "pqa_common.hpp"
 #include "pqa_jastrow.hpp"
@@ -112,21 +116,24 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
 
 // pos: proposal [W][3] (accept) or NULL = current position of e from xt (propose)
 // rows: [W][5][nmo] orbital rows at `pos` (accept) or NULL = cached rows ct (propose)
-template <bool PBC>
+#define PQA_LW_PART_ROWS(CX) ((CX) ? 12 : 8)
+template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e, int has_jastrow, const double* __restrict__ pos,
                                                      const double* __restrict__ rows, long W, int G, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int g = blockIdx.y;
   if (w >= W) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  constexpr int CF = CX ? 2 : 1;
   double px, py, pz;
   if (pos) { px = pos[3 * w]; py = pos[3 * w + 1]; pz = pos[3 * w + 2]; }
   else { const double* xe = L.xt + (size_t)e * 3 * W + w; px = xe[0]; py = xe[W]; pz = xe[2 * W]; }
-  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;  // q: imaginary parts (CX)
 #ifndef PQA_MP_NOSLATER
   {
-    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
     const int* occ = S.det_occ[s];
+    const int nh = nmo / CF;  // orbitals
     // group g takes a CONTIGUOUS range of orbital slots: the proposal's rows are point-major (k_orb's output, 1280 B per
     // walker), so a thread's consecutive slots share 64-byte lines (4 lines per thread and component instead of 8
     // lines used 8 bytes each when the slots were dealt round-robin: 53 -> 22 us of this kernel)
@@ -135,17 +142,34 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
       const double* row = rows + (size_t)w * 5 * nmo;
 #pragma unroll 4
       for (int j = jb; j < je; ++j) {
-        const double t = Ti[(size_t)j * W];
         const int o = occ[j];
-        r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
+        if (CX) {
+          const double tr = Ti[(size_t)(2 * j) * W], ti = Ti[(size_t)(2 * j + 1) * W];
+          const double a0 = row[o], b0 = row[nh + o], a1 = row[nmo + o], b1 = row[nmo + nh + o];
+          const double a2 = row[2 * nmo + o], b2 = row[2 * nmo + nh + o], a3 = row[3 * nmo + o], b3 = row[3 * nmo + nh + o];
+          r0 += a0 * tr - b0 * ti; q0 += a0 * ti + b0 * tr; r1 += a1 * tr - b1 * ti; q1 += a1 * ti + b1 * tr;
+          r2 += a2 * tr - b2 * ti; q2 += a2 * ti + b2 * tr; r3 += a3 * tr - b3 * ti; q3 += a3 * ti + b3 * tr;
+        } else {
+          const double t = Ti[(size_t)j * W];
+          r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
+        }
       }
     } else {
       const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
 #pragma unroll 4
       for (int j = jb; j < je; ++j) {
-        const double t = Ti[(size_t)j * W];
         const double* cj = ci + (size_t)occ[j] * W;
-        r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
+        if (CX) {
+          const double tr = Ti[(size_t)(2 * j) * W], ti = Ti[(size_t)(2 * j + 1) * W];
+          const double* dj = cj + (size_t)nh * W;  // imaginary parts
+          const double a0 = cj[0], b0 = dj[0], a1 = cj[(size_t)nmo * W], b1 = dj[(size_t)nmo * W];
+          const double a2 = cj[(size_t)2 * nmo * W], b2 = dj[(size_t)2 * nmo * W], a3 = cj[(size_t)3 * nmo * W], b3 = dj[(size_t)3 * nmo * W];
+          r0 += a0 * tr - b0 * ti; q0 += a0 * ti + b0 * tr; r1 += a1 * tr - b1 * ti; q1 += a1 * ti + b1 * tr;
+          r2 += a2 * tr - b2 * ti; q2 += a2 * ti + b2 * tr; r3 += a3 * tr - b3 * ti; q3 += a3 * ti + b3 * tr;
+        } else {
+          const double t = Ti[(size_t)j * W];
+          r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
+        }
       }
     }
   }
@@ -154,28 +178,51 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
 #ifndef PQA_MP_NOJAS
   jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
 #endif
-  double* p = part + (size_t)g * 8 * W + w;
-  p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
+  constexpr int PR = PQA_LW_PART_ROWS(CX);
+  double* p = part + (size_t)g * PR * W + w;
+  if (CX) {  // rows: Re r0, Im r0, Re r1, Im r1, ..., then U, grad U
+    p[0] = r0; p[W] = q0; p[2 * W] = r1; p[3 * W] = q1; p[4 * W] = r2; p[5 * W] = q2; p[6 * W] = r3; p[7 * W] = q3;
+    p[8 * W] = U; p[9 * W] = gg[0]; p[10 * W] = gg[1]; p[11 * W] = gg[2];
+  } else {
+    p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
+  }
 }
 
-__device__ __forceinline__ void lw_sum_parts(const double* __restrict__ part, long W, long w, int G, double (&v)[8]) {
+template <int PR>
+__device__ __forceinline__ void lw_sum_parts(const double* __restrict__ part, long W, long w, int G, double (&v)[PR]) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = 0.0;
+  for (int c = 0; c < PR; ++c) v[c] = 0.0;
   for (int g = 0; g < G; ++g) {
-    const double* p = part + (size_t)g * 8 * W + w;
+    const double* p = part + (size_t)g * PR * W + w;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] += p[(size_t)c * W];
+    for (int c = 0; c < PR; ++c) v[c] += p[(size_t)c * W];
+  }
+}
+// Slater part of the summed partials -> gradient of log|Psi_S| (real part for complex orbitals), determinant ratio (re, im)
+template <bool CX, int PR>
+__device__ __forceinline__ void lw_slater_terms(const double (&v)[PR], double& gx, double& gy, double& gz, double& dr, double& di) {
+  if (CX) {
+    dr = v[0]; di = v[1];
+    const double d = 1.0 / (dr * dr + di * di);  // Re(r_c / r_0) = Re(r_c conj r_0) / |r_0|^2
+    gx = finite_or((v[2] * dr + v[3] * di) * d, 0.0); gy = finite_or((v[4] * dr + v[5] * di) * d, 0.0); gz = finite_or((v[6] * dr + v[7] * di) * d, 0.0);
+  } else {
+    dr = v[0]; di = 0.0;
+    gx = finite_or(v[1] / v[0], 0.0); gy = finite_or(v[2] / v[0], 0.0); gz = finite_or(v[3] / v[0], 0.0);
   }
 }
 
 // drift at the current position, proposal r' = r + sqrt(tau) z + tau limdrift(grad)   (mc.py:117-121)
+template <bool CX = false>
 __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, long W, int G,
                                                        const double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   if (w >= W) return;
-  double v[8];
-  lw_sum_parts(part, W, w, G, v);
-  double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
+  constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4;
+  double v[PR];
+  lw_sum_parts<PR>(part, W, w, G, v);
+  double gx, gy, gz, dr, di;
+  lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
+  gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
   if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (dmc.py:50-52)
   else limdrift3(gx, gy, gz);
   double z0, z1, z2, z3;
@@ -196,11 +243,12 @@ __global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, Move
   np_[2] = xe[2 * W] + z2 + gz * df;
   if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
   double* a = L.auxt + w;
-  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[4];
+  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[JU];
 }
 
 // Metropolis decision (mc.py:124-132); accepted walkers: move the coordinate, update sign/log of the
-// determinant, and stage R[k] = T[i][k]/ratio in Rbuf[n][W] for the commit kernel.
+// determinant, and stage R[k] = T[i][k]/ratio in Rbuf[n][W] (complex: [n][2][W]) for the commit kernel.
+template <bool CX = false>
 __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W, int G,
                                                       const double* __restrict__ part, double* __restrict__ Rbuf,
                                                       double* __restrict__ Vbuf, uint8_t* __restrict__ act,
@@ -208,12 +256,17 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   if (w >= W) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  double v[8];
-  lw_sum_parts(part, W, w, G, v);
-  double gx = finite_or(v[1] / v[0], 0.0) + v[5], gy = finite_or(v[2] / v[0], 0.0) + v[6], gz = finite_or(v[3] / v[0], 0.0) + v[7];
+  constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4, CF = CX ? 2 : 1;
+  double v[PR];
+  lw_sum_parts<PR>(part, W, w, G, v);
+  double gx, gy, gz, dr, di;
+  lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
+  gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
   const double* a = L.auxt + w;
-  double val = finite_or(v[0], 1.0);
-  if (has_jastrow) val *= exp(v[4] - a[6 * W]);
+  double val2;  // |Psi(new)/Psi|^2 (mc.py:131)
+  if (CX) val2 = finite_or(dr * dr + di * di, 1.0);
+  else { const double val = finite_or(dr, 1.0); val2 = val * val; }
+  if (has_jastrow) { const double ej = exp(v[JU] - a[6 * W]); val2 *= ej * ej; }
   const double a0 = a[0], a1 = a[W], a2 = a[2 * W];
   const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
   double bx, by, bz;
@@ -226,9 +279,9 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   }
   const double bwd = bx * bx + by * by + bz * bz;
   const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
-  double ratio = val * val * t_prob;
-  if (mb.dmc) {
-    const double dv = finite_or(v[0], 1.0);  // the Jastrow ratio is positive: np.sign(psi_ratio) is the determinant's
+  double ratio = val2 * t_prob;
+  if (mb.dmc && !CX) {
+    const double dv = finite_or(dr, 1.0);  // the Jastrow ratio is positive: np.sign(psi_ratio) is the determinant's
     ratio *= (dv > 0.0) ? 1.0 : ((dv < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
   }
   double u;
@@ -258,16 +311,34 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
   {
     const double* row = motmp + (size_t)w * 5 * nmo;
     const int* occ = S.det_occ[s];
+    const int nh = nmo / CF;
 #pragma unroll 8
-    for (int k = 0; k < n; ++k) Vbuf[(size_t)k * W + w] = row[occ[k]];
+    for (int k = 0; k < n; ++k) {
+      if (CX) { Vbuf[(size_t)(2 * k) * W + w] = row[occ[k]]; Vbuf[(size_t)(2 * k + 1) * W + w] = row[nh + occ[k]]; }
+      else Vbuf[(size_t)k * W + w] = row[occ[k]];
+    }
   }
-  const double dr = v[0];  // determinant ratio
-  L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
-  L.dlog[s][w] += log(fabs(dr));
-  const double inv = 1.0 / dr;
-  const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+  const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
+  if (CX) {  // dsign *= ratio / |ratio|, dlog += log|ratio|; R = T_old[i] / ratio (complex)
+    const double m2 = dr * dr + di * di, m = sqrt(m2), ur = dr / m, ui = di / m;
+    double* ds = L.dsign[s] + 2 * w;
+    const double sr = ds[0], si = ds[1];
+    ds[0] = sr * ur - si * ui; ds[1] = sr * ui + si * ur;
+    L.dlog[s][w] += 0.5 * log(m2);
+    const double ir = dr / m2, ii = -di / m2;  // 1 / ratio
 #pragma unroll 8
-  for (int k = 0; k < n; ++k) Rbuf[(size_t)k * W + w] = Ti[(size_t)k * W] * inv;
+    for (int k = 0; k < n; ++k) {
+      const double tr = Ti[(size_t)(2 * k) * W], ti = Ti[(size_t)(2 * k + 1) * W];
+      Rbuf[(size_t)(2 * k) * W + w] = tr * ir - ti * ii;
+      Rbuf[(size_t)(2 * k + 1) * W + w] = tr * ii + ti * ir;
+    }
+  } else {
+    L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+    L.dlog[s][w] += log(fabs(dr));
+    const double inv = 1.0 / dr;
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) Rbuf[(size_t)k * W + w] = Ti[(size_t)k * W] * inv;
+  }
 }
 
 // ---------------------------------------------------------------- commit (Sherman-Morrison, slater.py:88-94)
@@ -282,7 +353,8 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
 // block instead of once per move (512*KB + 16384/KB bytes per move at n = 32: 2.7x less at KB = 8).
 // thread = (walker, row group g of G).  The 5*nmo cached orbital values of electron i are refreshed in slices
 // by the same groups.  NMAX >= n.
-template <int NMAX, bool FULLLINE>
+// NMAX >= doubles per row (n real, 2 n complex)
+template <int NMAX, bool FULLLINE, bool CX = false>
 __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
                                                   const double* __restrict__ Rbuf, const double* __restrict__ Vbuf, long W,
                                                   int G, int j_lo, int j_hi) {
@@ -295,33 +367,48 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
   const bool acc = mb.accept[w] != 0;
   if (FULLLINE ? !__any(acc) : !acc) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const int L_ = CX ? 2 * n : n;  // doubles per row
   double* T = L.Tt[s] + w;
   double V[NMAX], R[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
-    V[k] = (k < n && acc) ? Vbuf[(size_t)k * W + w] : 0.0;
-    R[k] = (k < n && acc) ? Rbuf[(size_t)k * W + w] : 0.0;
+    V[k] = (k < L_ && acc) ? Vbuf[(size_t)k * W + w] : 0.0;
+    R[k] = (k < L_ && acc) ? Rbuf[(size_t)k * W + w] : 0.0;
   }
   for (int j = j_lo + g; j < j_hi; j += G) {
-    double* Tj = T + (size_t)j * n * W;
+    double* Tj = T + (size_t)j * L_ * W;
     if (j == i) {
       if (acc) {
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
-          if (k < n) Tj[(size_t)k * W] = R[k];
+          if (k < L_) Tj[(size_t)k * W] = R[k];
       }
       continue;
     }
     double t[NMAX];
-    double tmp = 0.0;
+    double tmp = 0.0, tmi = 0.0;
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      t[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
-      tmp += V[k] * t[k];
+    for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
+    if (CX) {
+#pragma unroll
+      for (int k = 0; k < NMAX / 2; ++k) {  // tmp = sum_k V_k t_k (complex, no conjugation)
+        tmp += V[2 * k] * t[2 * k] - V[2 * k + 1] * t[2 * k + 1];
+        tmi += V[2 * k] * t[2 * k + 1] + V[2 * k + 1] * t[2 * k];
+      }
+#pragma unroll
+      for (int k = 0; k < NMAX / 2; ++k)
+        if (2 * k < L_) {
+          const double ur = R[2 * k] * tmp - R[2 * k + 1] * tmi, ui = R[2 * k] * tmi + R[2 * k + 1] * tmp;
+          Tj[(size_t)(2 * k) * W] = acc ? t[2 * k] - ur : t[2 * k];
+          Tj[(size_t)(2 * k + 1) * W] = acc ? t[2 * k + 1] - ui : t[2 * k + 1];
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) tmp += V[k] * t[k];
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if (k < L_) Tj[(size_t)k * W] = acc ? t[k] - R[k] * tmp : t[k];
     }
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k)
-      if (k < n) Tj[(size_t)k * W] = acc ? t[k] - R[k] * tmp : t[k];
   }
   if (!acc) return;
   const double* row = motmp + (size_t)w * 5 * nmo;
@@ -337,19 +424,20 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
 // itself (1.26 ms per flush at 65 536 walkers).  A row's arithmetic and its order are unchanged (bitwise identical).
 // 16 consecutive walkers are 128 contiguous bytes of every (row, column) plane: two full cache lines per access.
 #define PQA_FLUSH_WB 16
-template <int NMAX>
+template <int NMAX, bool CX = false>
 __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
                                                   const double* __restrict__ Rb, const uint8_t* __restrict__ act, long W,
                                                   int j_lo, int j_hi, int nq) {
   extern __shared__ double sh[];
   const int n = s ? S.ndn : S.nup;
+  const int L_ = CX ? 2 * n : n;  // doubles per row
   double* shV = sh;
-  double* shR = sh + (size_t)nq * n * PQA_FLUSH_WB;
+  double* shR = sh + (size_t)nq * L_ * PQA_FLUSH_WB;
   const int wl = threadIdx.x & (PQA_FLUSH_WB - 1), g = threadIdx.x / PQA_FLUSH_WB;
   const long w0 = (long)blockIdx.x * PQA_FLUSH_WB;
-  for (int idx = threadIdx.x; idx < nq * n * PQA_FLUSH_WB; idx += 256) {
+  for (int idx = threadIdx.x; idx < nq * L_ * PQA_FLUSH_WB; idx += 256) {
     const long ws = (w0 + (idx & (PQA_FLUSH_WB - 1)) < W) ? w0 + (idx & (PQA_FLUSH_WB - 1)) : W - 1;
-    const size_t src = (size_t)(idx / PQA_FLUSH_WB) * W + ws;  // idx / WB = q * n + k
+    const size_t src = (size_t)(idx / PQA_FLUSH_WB) * W + ws;  // idx / WB = q * L_ + k
     shV[idx] = Vb[src];
     shR[idx] = Rb[src];
   }
@@ -363,49 +451,87 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   const int nout = n - (j_hi - j_lo);
   for (int jj = g; jj < nout; jj += 256 / PQA_FLUSH_WB) {
     const int j = (jj < j_lo) ? jj : jj + (j_hi - j_lo);
-    double* Tj = T + (size_t)j * n * W;
+    double* Tj = T + (size_t)j * L_ * W;
     double t[NMAX];
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) t[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+    for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
     for (int q = 0; q < nq; ++q) {
       if (!((mask >> q) & 1u)) continue;
-      const double* Vq = shV + (size_t)q * n * PQA_FLUSH_WB + wl;
-      const double* Rq = shR + (size_t)q * n * PQA_FLUSH_WB + wl;
-      double tmp = 0.0;
+      const double* Vq = shV + (size_t)q * L_ * PQA_FLUSH_WB + wl;
+      const double* Rq = shR + (size_t)q * L_ * PQA_FLUSH_WB + wl;
+      if (CX) {
+        double tmp = 0.0, tmi = 0.0;
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k)
-        if (k < n) tmp += Vq[k * PQA_FLUSH_WB] * t[k];
+        for (int k = 0; k < NMAX / 2; ++k)
+          if (2 * k < L_) {
+            const double vr = Vq[(2 * k) * PQA_FLUSH_WB], vi = Vq[(2 * k + 1) * PQA_FLUSH_WB];
+            tmp += vr * t[2 * k] - vi * t[2 * k + 1];
+            tmi += vr * t[2 * k + 1] + vi * t[2 * k];
+          }
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k)
-        if (k < n) t[k] = t[k] - Rq[k * PQA_FLUSH_WB] * tmp;
+        for (int k = 0; k < NMAX / 2; ++k)
+          if (2 * k < L_) {
+            const double rr = Rq[(2 * k) * PQA_FLUSH_WB], ri = Rq[(2 * k + 1) * PQA_FLUSH_WB];
+            t[2 * k] -= rr * tmp - ri * tmi;
+            t[2 * k + 1] -= rr * tmi + ri * tmp;
+          }
+      } else {
+        double tmp = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if (k < L_) tmp += Vq[k * PQA_FLUSH_WB] * t[k];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if (k < L_) t[k] = t[k] - Rq[k * PQA_FLUSH_WB] * tmp;
+      }
     }
 #pragma unroll
     for (int k = 0; k < NMAX; ++k)
-      if (k < n) Tj[(size_t)k * W] = t[k];
+      if (k < L_) Tj[(size_t)k * W] = t[k];
   }
 }
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
-template <bool PBC>
+template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
   const int e = blockIdx.y;
   if (w >= W) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  constexpr int CF = CX ? 2 : 1;
+  double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   {
-    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+    const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
     const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
     const int* occ = S.det_occ[s];
+    const int nh = nmo / CF;
     for (int j = 0; j < n; ++j) {
-      const double t = Ti[(size_t)j * W];
       const double* cj = ci + (size_t)occ[j] * W;
+      if (CX) {
+        const double tr = Ti[(size_t)(2 * j) * W], ti = Ti[(size_t)(2 * j + 1) * W];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) r[c] += cj[(size_t)c * nmo * W] * t;
+        for (int c = 0; c < 5; ++c) {
+          const double a = cj[(size_t)c * nmo * W], b = cj[((size_t)c * nmo + nh) * W];
+          r[c] += a * tr - b * ti; q[c] += a * ti + b * tr;
+        }
+      } else {
+        const double t = Ti[(size_t)j * W];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) r[c] += cj[(size_t)c * nmo * W] * t;
+      }
     }
   }
-  const double gs0 = r[1] / r[0], gs1 = r[2] / r[0], gs2 = r[3] / r[0], ls = r[4] / r[0];
+  double gs0, gs1, gs2, ls, gi2 = 0.0;
+  if (CX) {  // grad Psi / Psi complex; only Re(lap) enters (the Jastrow gradient is real): energy.py:57-65 on complex ratios
+    const double d = 1.0 / (r[0] * r[0] + q[0] * q[0]);
+    gs0 = (r[1] * r[0] + q[1] * q[0]) * d; gs1 = (r[2] * r[0] + q[2] * q[0]) * d; gs2 = (r[3] * r[0] + q[3] * q[0]) * d;
+    const double i0 = (q[1] * r[0] - r[1] * q[0]) * d, i1 = (q[2] * r[0] - r[2] * q[0]) * d, i2 = (q[3] * r[0] - r[3] * q[0]) * d;
+    gi2 = i0 * i0 + i1 * i1 + i2 * i2;
+    ls = (r[4] * r[0] + q[4] * q[0]) * d;
+  } else {
+    gs0 = r[1] / r[0]; gs1 = r[2] / r[0]; gs2 = r[3] / r[0]; ls = r[4] / r[0];
+  }
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double U, gj[3], lj, ee, ei;
   jas_eval_lane<2, PBC>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
@@ -414,7 +540,7 @@ __global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_
   const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);
   const size_t o = (size_t)e * W + w, NW = (size_t)S.nelec * W;
   part[o] = -0.5 * lap;
-  part[NW + o] = gx * gx + gy * gy + gz * gz;
+  part[NW + o] = gx * gx + gy * gy + gz * gz + gi2;
   part[2 * NW + o] = ee;
   part[3 * NW + o] = ei;
 }

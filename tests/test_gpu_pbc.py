@@ -331,6 +331,34 @@ def _gpu_twisted_wf(tag):
 
 
 @pytest.mark.parametrize("tag", ["prim", "s211"])
+def test_complex_lane_and_wave_per_walker_sweeps_agree(tag, monkeypatch):
+    """Complex determinants (twisted cells): the lane-per-walker sweep (complex Sherman-Morrison on SoA planes, |ratio|^2
+    acceptance, Re(grad) drift; default) and the wave-per-walker complex kernels follow the same Philox streams — same
+    decisions, coordinates and energies to rounding, and both leave a state that equals a fresh recompute."""
+    import pyqmc_amd as pa
+
+    res = []
+    for lw in ("1", "0"):
+        monkeypatch.setenv("PQA_LW", lw)
+        sup, wf = _gpu_twisted_wf(tag)
+        dev = wf.fused_device()
+        cfg = pa.initial_guess(sup, 300, rng=np.random.default_rng(5))
+        wf.recompute(cfg)
+        acc, en, rec = dev.vmc_sweeps(0.3, 2, seed=77, energy=True, record=True)
+        x = dev.configs()
+        res.append((x, dev.value(), en, rec, dev.recompute(x), acc))
+    same = res[0][3] == res[1][3]
+    assert same.mean() > 0.9999
+    ok = same.all(axis=(0, 1))
+    assert ok.mean() > 0.98
+    assert helpers.relerr(res[0][0][ok], res[1][0][ok]) < 1e-10
+    assert np.max(np.abs(res[0][1][1][ok] - res[1][1][1][ok])) < 1e-9 and np.max(np.abs(res[0][1][0][ok] - res[1][1][0][ok])) < 1e-9
+    assert helpers.relerr(res[0][2], res[1][2]) < 1e-3 and np.iscomplexobj(res[0][2])
+    for r in res:  # updated phase and log|Psi| equal a fresh recompute
+        assert np.max(np.abs(r[1][1] - r[4][1])) < 1e-8 and np.max(np.abs(r[1][0] - r[4][0])) < 1e-8
+
+
+@pytest.mark.parametrize("tag", ["prim", "s211"])
 def test_twisted_slater_matches_reference(tag):
     """Non-zero supercell twist (one twisted k-point in the primitive cell; two in a 2x1x1 supercell): complex
     lattice-summed AOs sum_L exp(i k_t.L) phi(r-R-L) on the device and the wrap phase of electrons that left the cell,
