@@ -681,3 +681,122 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
       }
   }
 }
+
+// ---------------------------------------------------------------- whole-K variant for SMALL launches
+// A sweep launches the orbital kernel on one point per walker; at the BASELINE walker counts of the periodic configurations
+// (4096 - 8192 per GPU) that is a few hundred 16-point tiles, and k_orb's time there is the LATENCY of one block's chain —
+// chunks x (phase 1, barrier, MFMA, barrier), each phase-1 thread walking ~45 (shell, image) lattice sums — not throughput.
+// This variant shortens the chain 4x: a block of 1024 threads owns ONE 16-point tile, 64 lane groups split ALL shells of the
+// basis between them (a thread evaluates 1-2 shells, not 5-7), the AO tile of the whole basis [NCOMP][rows][16] sits in LDS
+// (up to ~150 KB: one block per CU), and after a single barrier the waves contract (component, orbital tile) pairs over the
+// full K with v_mfma_f64_16x16x4_f64.  Same shell routines, same coefficient layout (the chunk table's padded row order), so
+// rows are identical to k_orb's up to the MFMA accumulation order (one K loop instead of per-chunk partial sums).
+struct WideTab {
+  const int* off;     // [65] shells of lane group g: shell[off[g] .. off[g+1]); 64 groups (1024 threads) or 32 (512 threads)
+  const int* shell;
+  const int* row;     // [nshell] (twisted: [2 nshell], imaginary rows second) first padded tile row of the shell
+  int rows_pad;       // K: multiple of 4
+};
+__host__ __device__ inline size_t wide_lds_bytes(int ncomp, int rows_pad, int nshell, int nprim) {
+  return ((size_t)ncomp * rows_pad * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim) * sizeof(double) + (size_t)5 * nshell * sizeof(int);
+}
+
+// NTH threads: 1024 for open systems (94 VGPRs); periodic lattice sums need > 128 registers (at 1024 threads they spilled
+// 384 B, twisted 1024 B per lane, and lost to k_orb), so periodic launches take 512 threads = 32 lane groups.
+template <int NCOMP, int NT, int PBC, int NTH>
+__global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab Wt, int spin, PointAddr pa, long P, double* __restrict__ out) {
+  extern __shared__ double wl[];
+  const int K = Wt.rows_pad;
+  double* tile = wl;                                  // [NCOMP][K][16]
+  double* sh_xyz = tile + (size_t)NCOMP * K * 16;     // [nshell][3]
+  double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
+  double* pr_coef = pr_exp + S.nprim;
+  int* sh_meta = (int*)(pr_coef + S.nprim);           // [nshell][5]: l, nprim, first primitive, tile row, atom
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int sh = tid; sh < S.nshell; sh += NTH) {
+    const int ia = S.shell_atom[sh];
+    sh_xyz[3 * sh] = S.atom_xyz[3 * ia]; sh_xyz[3 * sh + 1] = S.atom_xyz[3 * ia + 1]; sh_xyz[3 * sh + 2] = S.atom_xyz[3 * ia + 2];
+    sh_meta[5 * sh] = S.shell_l[sh];
+    sh_meta[5 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
+    sh_meta[5 * sh + 2] = S.shell_prim_off[sh];
+    sh_meta[5 * sh + 3] = Wt.row[sh];
+    sh_meta[5 * sh + 4] = ia;
+  }
+  for (int p = tid; p < S.nprim; p += NTH) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
+  for (int k = tid; k < NCOMP * K * 16; k += NTH) tile[k] = 0.0;  // (the K padding rows stay zero)
+  __syncthreads();
+  const int pl = tid & 15, grp = tid >> 4;
+  const long p0 = (long)blockIdx.x * 16;
+  const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
+  double px, py, pz;
+  load_point(pa, pmine, px, py, pz);
+  if (PBC) fold_cell(S, px, py, pz);
+  PbcCtx ctx;
+  const PrimWrap pw = PBC ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};
+  const int s_end = Wt.off[grp + 1];
+  for (int si = Wt.off[grp]; si < s_end; ++si) {
+    const int sh = Wt.shell[si];
+    const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], kb = sh_meta[5 * sh + 3], ia_ = sh_meta[5 * sh + 4];
+    const double x = px - sh_xyz[3 * sh], y = py - sh_xyz[3 * sh + 1], z = pz - sh_xyz[3 * sh + 2];
+    const double *pe = pr_exp + q0, *pc = pr_coef + q0;
+    auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
+      double* t = tile + (size_t)(kb + m) * 16 + pl;
+      t[0] = v;
+      if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
+      if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+    };
+    if (PBC) {
+      if (ctx.ia != ia_) {
+        ctx.ia = ia_;
+        ctx.x0 = T.pbc_d0[((size_t)ia_ * 3 + 0) * P + pmine];
+        ctx.y0 = T.pbc_d0[((size_t)ia_ * 3 + 1) * P + pmine];
+        ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
+        ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
+        ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
+        if (PBC == 2) {
+          ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_) * P + pmine];
+          ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_ + 1) * P + pmine];
+        }
+        if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
+      }
+      if (PBC == 2) {
+        const int kbi = Wt.row[sh + S.nshell];
+        auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
+          double* t = tile + (size_t)(kbi + m) * 16 + pl;
+          t[0] = v;
+          if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
+          if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+        };
+        shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im);
+      } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
+    } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
+  }
+  __syncthreads();
+  // contraction: wave <-> (component c, orbital tile ut); D[point][orbital] += A[point][k] B[k][orbital], B straight from L2
+  const double* __restrict__ C = T.cpad[spin];
+  const int ldc = T.ldc[spin], nmo = S.nmo[spin];
+  const int i16 = lane & 15, kq = lane >> 4;
+  for (int role = wv; role < NCOMP * NT; role += NTH / 64) {
+    const int c = role % NCOMP, ut = role / NCOMP;
+    const double* a_ = tile + (size_t)c * K * 16 + (size_t)kq * 16 + i16;
+    const double* b_ = C + (size_t)kq * ldc + 16 * ut + i16;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    int ks = 0;
+    for (; ks + 8 <= K / 4; ks += 8) {
+      double av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { bv[u] = b_[(size_t)(ks + u) * 4 * ldc]; av[u] = a_[(size_t)(ks + u) * 64]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; ks < K / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[(size_t)ks * 64], b_[(size_t)ks * 4 * ldc], acc, 0, 0, 0);
+    const int j = 16 * ut + i16;
+    if (j < nmo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long pp = p0 + kq + 4 * r;
+        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[r];
+      }
+    }
+  }
+}

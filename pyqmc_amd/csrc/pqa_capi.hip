@@ -96,6 +96,10 @@ struct pqa_handle {
   int orb_kc5 = 32;
   struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
   TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
+  WideTab wide[2]{};  // lane-group shell lists of the whole-K small-launch kernel (k_orb_wide), per chunk table (64 groups; periodic: 32)
+  int orb_wide = -1;  // PQA_ORB_WIDE: -1 automatic (5-component launches of <= orb_wide_max points), 0 never, 1 whenever the tile fits LDS
+  long orb_wide_max = 8192;  // PQA_ORB_WIDE_MAX
+  std::vector<const void*> wide_attr;  // kernels whose dynamic-LDS limit has been raised
   int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
   int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
@@ -372,6 +376,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
+  if (const char* wd = getenv("PQA_ORB_WIDE")) h->orb_wide = atoi(wd);
+  if (const char* wm = getenv("PQA_ORB_WIDE_MAX")) h->orb_wide_max = atol(wm);
   if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
   if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
@@ -523,6 +529,33 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         TRY(upload_table(h, c.cw_shell[g].data(), c.cw_shell[g].size(), &tmp_i)); T.cw_shell[g] = tmp_i;
       }
       for (int s = 0; s < 2; ++s) { T.cpad[s] = h->d_cpad[t][s]; T.ldc[s] = 16 * h->nt[s]; }
+      // k_orb_wide: all shells dealt to 64 lane groups (longest processing time first), tile row of a shell = its padded row
+      const int tw = h->twist ? 2 : 1;
+      const int ngrp = h->S.pbc ? 32 : 64;  // lane groups of k_orb_wide: 512 threads for periodic cells, 1024 otherwise
+      std::vector<int> order((size_t)h->nshell), wrow((size_t)tw * h->nshell), woff(65, 0), wsh;
+      auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * tw * (2 * h->shell_l[s] + 1) + 40; };
+      for (int s = 0; s < h->nshell; ++s) order[s] = s;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+      std::vector<std::vector<int>> grp(64);
+      std::vector<int> load(64, 0);
+      for (int s : order) {
+        int best = 0;
+        for (int g = 1; g < ngrp; ++g)
+          if (load[g] < load[best]) best = g;
+        grp[best].push_back(s);
+        load[best] += cost(s);
+      }
+      for (int g = 0; g < 64; ++g) {
+        // shells of one atom next to each other: a thread re-reads the per-(point, atom) fold / mask only when the atom changes
+        std::stable_sort(grp[g].begin(), grp[g].end(), [&](int a, int b) { return sys->shell_atom[a] < sys->shell_atom[b]; });
+        for (int s : grp[g]) wsh.push_back(s);
+        woff[g + 1] = (int)wsh.size();
+      }
+      for (int s = 0; s < tw * h->nshell; ++s) wrow[s] = c.row0[c.shell_chunk[s]] + c.shell_kb[s];
+      TRY(upload_table(h, woff.data(), woff.size(), &tmp_i)); h->wide[t].off = tmp_i;
+      TRY(upload_table(h, wsh.data(), wsh.size(), &tmp_i)); h->wide[t].shell = tmp_i;
+      TRY(upload_table(h, wrow.data(), wrow.size(), &tmp_i)); h->wide[t].row = tmp_i;
+      h->wide[t].rows_pad = c.rows_pad;
     }
   }
   S.na = h->na; S.nb = h->nb; S.rcut_a = sys->rcut_a; S.rcut_b = sys->rcut_b;
@@ -698,6 +731,36 @@ static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
   }
 }
+// whole-K kernel for small 5-component launches (k_orb_wide, pqa_ao.hpp)
+static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
+  if (ncomp != 5 || h->orb_wide == 0 || h->wide[tabi].rows_pad <= 0) return false;
+  if (wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim) > (size_t)160 * 1024 - 256) return false;
+  if (h->orb_wide == 1) return true;
+  // measured (tools/scratch/ab_wide*.sh, 1 MI355X): (H2O)8 step 6.65 -> 4.73 ms at 1024 walkers, 7.64 -> 5.86 at 4096, 9.08 -> 7.84
+  // at 8192, even at 16384, slower at 32768 (one 1024-thread block per CU cannot overlap AO and MFMA phases of different
+  // tiles); periodic cells (512 threads, two lane-group chains per point like the K-split k_orb): 2x2x2 diamond +5 / +8 / +2.5 %
+  // at 1024 / 4096 / 8192 walkers, but the 8-atom cell (40 shells on 32 groups) and twisted cells (528 B of spills) lose
+  if (h->S.pbc) return !h->twist && h->nshell >= 64 && P <= h->orb_wide_max;
+  return P <= h->orb_wide_max + h->orb_wide_max / 2;
+}
+template <int PBCV>
+static int launch_orb_wide(pqa_handle* h, const ChunkTab& T, int tabi, int spin, PointAddr pa, long P, double* out) {
+  const size_t lds = wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim);
+  constexpr int NTH = PBCV ? 512 : 1024;
+  const dim3 grid((unsigned)((P + 15) / 16)), block(NTH);
+#define PQA_WIDE(NT) do { const void* fn = (const void*)k_orb_wide<5, NT, PBCV, NTH>; \
+    if (std::find(h->wide_attr.begin(), h->wide_attr.end(), fn) == h->wide_attr.end()) { \
+      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); h->wide_attr.push_back(fn); } \
+    hipLaunchKernelGGL((k_orb_wide<5, NT, PBCV, NTH>), grid, block, lds, h->stream, h->S, T, h->wide[tabi], spin, pa, P, out); } while (0)
+  switch (h->nt[spin]) {
+    case 1: PQA_WIDE(1); break;
+    case 2: PQA_WIDE(2); break;
+    default: PQA_WIDE(4); break;
+  }
+#undef PQA_WIDE
+  return 0;
+}
+
 // periodic orbitals: lattice-summed shells, 64-point tiles, tables through the scalar cache
 template <int NCOMP, int KC>
 static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
@@ -709,6 +772,15 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   ChunkTab T = h->tab[tabi];
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
+  if (wide_wanted(h, tabi, P, NCOMP)) {  // small launch: one 1024-thread block per 16-point tile, the whole basis in LDS
+    if (h->twist) TRY(launch_orb_wide<2>(h, T, tabi, spin, pa, P, out)); else TRY(launch_orb_wide<1>(h, T, tabi, spin, pa, P, out));
+    if (h->twist) {
+      const long nel = P * NCOMP * (h->nmo[spin] / 2);
+      hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
+                         (const double*)h->b_pbcth.p);
+    }
+    return 0;
+  }
   // Tile width.  32-point tiles: twice the blocks, and the 8 lane groups halve each thread's share of a chunk's lattice
   // sums; 64-point tiles: half the B-operand and table traffic per point.  Which wins depends on cell and launch size
   // (2x2x2 diamond supercell, 16 atoms: 32 wins at every size, 28.5 -> 21.9 ms/step at 1024 walkers, 107.5 -> 100.0 at
@@ -805,6 +877,9 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
     if (ncomp == 5) { if (h->orb_kc5 == 32) TRY((launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out))); else TRY((launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out))); }
     else if (ncomp == 1) TRY((launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out)));
     else FAIL("orbital kernel supports ncomp 1 or 5");
+  } else
+  if (wide_wanted(h, 0, P, ncomp)) {
+    TRY(launch_orb_wide<0>(h, h->tab[0], 0, spin, pa, P, out));
   } else
   if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
     if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
