@@ -74,6 +74,7 @@ struct pqa_handle {
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
+  int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
@@ -382,6 +383,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
   if (const char* ew = getenv("PQA_ECP_WAVE")) h->ecp_wave = atoi(ew);
+  if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
   if (const char* fl = getenv("PQA_LW_FULLLINE")) h->lw_fullline = atoi(fl);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
@@ -1496,23 +1498,30 @@ static int lw_to_aos(pqa_handle* h, bool with_cache) {
 }
 
 static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-                      bool soa_current = false) {
+                      bool soa_current = false, bool aos_T_needed = true) {
   const long W = h->W;
+  bool soa_T = false;
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
   if (soa_current) {
-    const dim3 gk((unsigned)((W + 63) / 64), (unsigned)h->N);
+    const dim3 gk((unsigned)((W + 63) / 64), (unsigned)((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB)), bk(64, PQA_KIN_EB);
     if (h->cplx) {
-      if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-      else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     } else if (h->S.pbc)
-      hipLaunchKernelGGL(k_kinetic_lw<true>, gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     else
-      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, dim3(64), 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));
-    if (h->necp > 0) TRY(lw_to_aos(h, false));
+    // the ECP kernels read walker-major coordinates; the inverse only when the wave-per-walker accumulation runs (or the
+    // caller works on the walker-major state next: the DMC step's T-moves) — the thread-per-point kernel takes the planes
+    soa_T = !aos_T_needed && !h->cplx && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_soa_t;
+    if (h->necp > 0) {
+      if (soa_T) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }
+      else TRY(lw_to_aos(h, false));
+    }
   } else {
     if (h->cplx) hipLaunchKernelGGL(k_kinetic_coulomb<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js,
                                     (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
@@ -1594,12 +1603,15 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       for (int s = 0; s < 2; ++s) {
         if (tot[s] <= 0) continue;
         const dim3 g((unsigned)((tot[s] + 255) / 256));
+        const long n_s = s ? h->ndn : h->nup;
+        const double* Tb = soa_T ? (const double*)h->b_Tt[s].p : (const double*)h->st.T[s];
+        const long sw = soa_T ? 1 : n_s * n_s, si = soa_T ? n_s * W : n_s, sk = soa_T ? W : 1;
         if (h->S.pbc)
           hipLaunchKernelGGL(k_ecp_point<true>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p);
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
         else
           hipLaunchKernelGGL(k_ecp_point<false>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p);
+                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
       }
       hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
                          (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p);
@@ -1894,7 +1906,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
-                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw));
+                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false));
       hipLaunchKernelGGL(k_row_means, dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
       TRY(check_launch(h, "k_row_means"));
     }

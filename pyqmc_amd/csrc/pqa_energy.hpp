@@ -460,7 +460,10 @@ __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a,
 template <bool PBC>
 __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int s, int has_slater,
                                                    int has_jastrow, const double* __restrict__ mo, long npts,
-                                                   double* __restrict__ contrib) {
+                                                   double* __restrict__ contrib, const double* __restrict__ Tbase, long sw, long si, long sk) {
+  // Tbase / sw / si / sk: element (walker, electron row, column) of the inverse at Tbase[w sw + i si + k sk] — the
+  // walker-major array (sw = n^2, si = n, sk = 1) or the lane-per-walker planes (sw = 1, si = n W, sk = W), which spares the
+  // fused sweep a transpose of every walker's inverse per energy evaluation (35 KB per walker moved for ~2 KB read here)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= npts) return;
   const int e = B.pte[s][p];
@@ -468,11 +471,11 @@ __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, Jas
   const int n = s ? S.ndn : S.nup, i = e - s * S.nup, nmo = S.nmo[s];
   double ratio = 1.0;
   if (has_slater) {
-    const double* Ti = st.T[s] + ((size_t)w * n + i) * n;
+    const double* Ti = Tbase + (size_t)w * sw + (size_t)i * si;
     const double* row = mo + (size_t)p * nmo;
     const int* occ = S.det_occ[s];
     double r = 0.0;
-    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[k];
+    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[(size_t)k * sk];
     ratio = r;
   }
   if (has_jastrow) {

@@ -493,11 +493,17 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
+// block = (64 walkers, PQA_KIN_EB electrons).  Every electron's thread walks ALL coordinates of its walker for the Jastrow and
+// Coulomb sums, so the 64 electron-blocks of a walker group pull the group's coordinates through the fabric 64 times (the
+// counters show 195 KB per walker against 96 KB of inverse + cache rows; the re-reads hit the Infinity Cache).  Sharing
+// them through one CU's L1 with 8 electrons per block was measured and LOST: 1.98 -> 3.08 ms per evaluation (512-thread
+// blocks halve the resident waves); 1 stays.
+#define PQA_KIN_EB 1
 template <bool PBC, bool CX = false>
-__global__ __launch_bounds__(64) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
+__global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  const int e = blockIdx.y;
-  if (w >= W) return;
+  const int e = blockIdx.y * PQA_KIN_EB + threadIdx.y;
+  if (w >= W || e >= S.nelec) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
   double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
