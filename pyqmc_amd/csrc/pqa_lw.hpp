@@ -55,56 +55,126 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
 // Contribution of the pairs j = j0, j0+dj, ... and ions I = j0, j0+dj, ... to U_e, grad U_e, (bare) lap U_e
 // of electron e of walker w at (rx,ry,rz); MODE 2 also returns that share of the Coulomb sums
 // ee = sum_{j>e} 1/r, ei = -sum Z/r.  (j0,dj) = (0,1) gives the full sums.
-template <int MODE, bool PBC>
-__device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
-                                              double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
-                                              double (&g)[3], double& lapU, double& ee, double& ei) {
+#ifndef PQA_JAS_PF
+#define PQA_JAS_PF 4
+#endif
+#define PQA_JAS_NF 4  // basis functions per kind whose tables the fast path keeps in scalar registers
+// FAST (nb, na <= PQA_JAS_NF, the reference's default Jastrow has 4 + 4): the function tables (kind, parameter, cusp constant,
+// the two coefficient columns electron e can meet) are read ONCE into scalar registers.  Indexed by the loop variable they
+// were scalar loads inside the innermost loop — two dependent load-and-wait pairs per function and pair, ~90 per thread —
+// and with four waves per SIMD those waits, not the arithmetic, set the kernel's time.  Same operations in the same order.
+template <int MODE, bool PBC, bool FAST>
+__device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
+                                                double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
+                                                double (&g)[3], double& lapU, double& ee, double& ei) {
+  constexpr int NF = PQA_JAS_NF;
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
-  double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
-#pragma unroll 4
-  for (int j = j0; j < S.nelec; j += dj) {
-    const double* xj = xt + (size_t)j * 3 * W + w;
-    double dx = rx - xj[0], dy = ry - xj[W], dz = rz - xj[2 * W];
-    if (PBC) min_image(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
-    const double r = sqrt(dx * dx + dy * dy + dz * dz);
-    if (j == e) continue;
-    if (MODE == 2 && j > e) see += fast_rcp(r);
-    if (has_jastrow && r < S.rcut_b) {
-      const RadShared sh = rad_shared<MODE>(r, irb);
-      const int col = edown + (j >= S.nup);
-      double sg = 0.0;
-      for (int l = 0; l < S.nb; ++l) {
-        double v, gf, lpl;
-        rad_fn<MODE>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
-        const double c = S.bcoeff[l * 3 + col];
-        u += c * v;
-        if (MODE >= 1) sg += c * gf;
-        if (MODE == 2) lp += c * lpl;
+  double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
+  int bk[NF], ak[NF];
+  double bp[NF], ba[NF], bc0[NF], bc1[NF], ap[NF], aa[NF];
+  if (FAST) {
+#pragma unroll
+    for (int l = 0; l < NF; ++l) {
+      bk[l] = S.b_kind[l]; bp[l] = S.b_param[l]; ba[l] = S.b_aux[l];
+      ak[l] = S.a_kind[l]; ap[l] = S.a_param[l]; aa[l] = S.a_aux[l];
+      bc0[l] = (has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + edown] : 0.0;
+      bc1[l] = (has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + edown + 1] : 0.0;
+    }
+  }
+  // The partners' coordinates are fetched PQA_JAS_PF at a time before any of them is used.
+  for (int jb = j0; jb < S.nelec; jb += PQA_JAS_PF * dj) {
+    double cx[PQA_JAS_PF], cy[PQA_JAS_PF], cz[PQA_JAS_PF];
+#pragma unroll
+    for (int u = 0; u < PQA_JAS_PF; ++u) {
+      const int j = jb + u * dj;
+      const double* xj = xt + (size_t)(j < S.nelec ? j : e) * 3 * W + w;  // past the end: any valid address, never used
+      cx[u] = xj[0]; cy[u] = xj[W]; cz[u] = xj[2 * W];
+    }
+#pragma unroll
+    for (int u = 0; u < PQA_JAS_PF; ++u) {
+      const int j = jb + u * dj;
+      if (j >= S.nelec || j == e) continue;
+      double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
+      if (PBC) min_image(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
+      const double r = sqrt(dx * dx + dy * dy + dz * dz);
+      if (MODE == 2 && j > e) see += fast_rcp(r);
+      if (has_jastrow && r < S.rcut_b) {
+        const RadShared sh = rad_shared<MODE>(r, irb);
+        const bool hi = j >= S.nup;
+        double sg = 0.0;
+        if (FAST) {
+#pragma unroll
+          for (int l = 0; l < NF; ++l) {
+            if (l < S.nb) {
+              double v, gf, lpl;
+              rad_fn<MODE>(bk[l], bp[l], ba[l], S.rcut_b, sh, v, gf, lpl);
+              const double c = hi ? bc1[l] : bc0[l];
+              u_ += c * v;
+              if (MODE >= 1) sg += c * gf;
+              if (MODE == 2) lp += c * lpl;
+            }
+          }
+        } else {
+          const int col = edown + (hi ? 1 : 0);
+          for (int l = 0; l < S.nb; ++l) {
+            double v, gf, lpl;
+            rad_fn<MODE>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
+            const double c = S.bcoeff[l * 3 + col];
+            u_ += c * v;
+            if (MODE >= 1) sg += c * gf;
+            if (MODE == 2) lp += c * lpl;
+          }
+        }
+        if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
       }
-      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
   for (int I = j0; I < S.natom; I += dj) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    double ac[NF];
+    if (FAST) {
+#pragma unroll
+      for (int k = 0; k < NF; ++k) ac[k] = (has_jastrow && k < S.na) ? S.acoeff[(I * S.na + k) * 2 + edown] : 0.0;
+    }
     if (PBC) min_image(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
     if (has_jastrow && r < S.rcut_a) {
       const RadShared sh = rad_shared<MODE>(r, ira);
       double sg = 0.0;
-      for (int k = 0; k < S.na; ++k) {
-        double v, gf, lpl;
-        rad_fn<MODE>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
-        const double c = S.acoeff[(I * S.na + k) * 2 + edown];
-        u += c * v;
-        if (MODE >= 1) sg += c * gf;
-        if (MODE == 2) lp += c * lpl;
+      if (FAST) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          if (k < S.na) {
+            double v, gf, lpl;
+            rad_fn<MODE>(ak[k], ap[k], aa[k], S.rcut_a, sh, v, gf, lpl);
+            u_ += ac[k] * v;
+            if (MODE >= 1) sg += ac[k] * gf;
+            if (MODE == 2) lp += ac[k] * lpl;
+          }
+        }
+      } else {
+        for (int k = 0; k < S.na; ++k) {
+          double v, gf, lpl;
+          rad_fn<MODE>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
+          const double c = S.acoeff[(I * S.na + k) * 2 + edown];
+          u_ += c * v;
+          if (MODE >= 1) sg += c * gf;
+          if (MODE == 2) lp += c * lpl;
+        }
       }
       if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
     }
   }
-  U = u; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
+  U = u_; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
+}
+template <int MODE, bool PBC>
+__device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
+                                              double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
+                                              double (&g)[3], double& lapU, double& ee, double& ei) {
+  if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei);
+  else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei);
 }
 
 // ---------------------------------------------------------------- move kernels
@@ -117,6 +187,8 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
 // pos: proposal [W][3] (accept) or NULL = current position of e from xt (propose)
 // rows: [W][5][nmo] orbital rows at `pos` (accept) or NULL = cached rows ct (propose)
 #define PQA_LW_PART_ROWS(CX) ((CX) ? 12 : 8)
+// (Forcing 6 or 8 waves per SIMD spills — 76 / 120 us against 66 — and twice the groups at the same occupancy changes nothing:
+// the kernel moves ~4 KB per walker at ~4 TB/s.)
 template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e, int has_jastrow, const double* __restrict__ pos,
                                                      const double* __restrict__ rows, long W, int G, double* __restrict__ part) {
@@ -493,16 +565,19 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
 
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
-// block = (64 walkers, PQA_KIN_EB electrons).  Every electron's thread walks ALL coordinates of its walker for the Jastrow and
-// Coulomb sums, so the 64 electron-blocks of a walker group pull the group's coordinates through the fabric 64 times (the
-// counters show 195 KB per walker against 96 KB of inverse + cache rows; the re-reads hit the Infinity Cache).  Sharing
-// them through one CU's L1 with 8 electrons per block was measured and LOST: 1.98 -> 3.08 ms per evaluation (512-thread
-// blocks halve the resident waves); 1 stays.
+// block = (64 walkers, PQA_KIN_EB electrons): one wave per electron, so the electron index — and with it the spin, the orbital
+// occupation list and every Jastrow table address — must stay wave-uniform (scalar loads): threadIdx.y goes through
+// readfirstlane.  (As a plain per-lane value it turned the occupation look-up of the inner loop into a dependent vector load:
+// 2.0 -> 3.3 ms per evaluation.)  Every electron's thread walks ALL coordinates of its walker for the Jastrow and Coulomb sums,
+// so the 64 electron-waves of a walker group pull the group's coordinates through the fabric 64 times (the counters show
+// 195 KB per walker against 96 KB of inverse + cache rows; the re-reads hit the Infinity Cache).
+#ifndef PQA_KIN_EB
 #define PQA_KIN_EB 1
+#endif
 template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  const int e = blockIdx.y * PQA_KIN_EB + threadIdx.y;
+  const int e = blockIdx.y * PQA_KIN_EB + (PQA_KIN_EB > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.y) : 0);
   if (w >= W || e >= S.nelec) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
