@@ -16,15 +16,18 @@
 #ifndef PQA_PRIM_UNROLL
 #define PQA_PRIM_UNROLL 1
 #endif
-// Primitive screening (opt-in, -DPQA_PRIM_SCREEN=1): skip a primitive with alpha r^2 > 60 (it contributes < 8.8e-27 of its
-// coefficient).  MEASURED AND DROPPED as a default (round 2, tools/scratch/ab_screen.sh): the test is per lane and the exp
-// sequence is only saved when EVERY lane of the wave skips; the 64 points of a wave are 64 different walkers (or, in periodic
-// cells, each lane's own image), some lane is nearly always close, and the extra compare + branch cost more than the rare
-// skip saves: open-system k_orb<5> 136.7 -> 141.4 us per 65536 points, periodic steps 1-2 % slower.
+// Primitive screening: skip a primitive with alpha r^2 > PQA_PRIM_CUT (it contributes < 2e-22 of its coefficient).  The test
+// is per lane and the exp sequence is only saved when EVERY lane of the wave skips.
+//  * open systems (-DPQA_PRIM_SCREEN=1, off): the 64 points of a wave are 64 different walkers, some lane is nearly always
+//    close, and the compare + branch cost more than the rare skip saves (round 2, tools/scratch/ab_screen.sh: k_orb<5>
+//    136.7 -> 141.4 us per 65536 points).
+//  * periodic cells (always on, SCREEN template argument): every lane walks the images of an atom NEAREST FIRST, so from the
+//    second image on all lanes sit at r^2 >~ (half the cell)^2 and the tight primitives of a contracted shell drop out for
+//    the whole wave.
 #ifndef PQA_PRIM_SCREEN
 #define PQA_PRIM_SCREEN 0
 #endif
-#define PQA_PRIM_CUT 60.0
+#define PQA_PRIM_CUT 50.0
 
 // p-th point lives at base + (p / group) * group_stride + (p % group) * 3
 struct PointAddr {
@@ -80,7 +83,7 @@ __device__ __forceinline__ void sph_high(int l, int m, double x, double y, doubl
 // LMAX < 3 compiles the f-shell branch out (callers that know the basis has none: its seven functions set the register
 // high-water mark of the routine); LMAX < 5 the g/h branch (the periodic kernels: their register budget is exhausted — with it
 // k_orb<5,..,PBC=1> went from 213 to 228 VGPRs, 2 to 1 waves per SIMD and +70 % time; periodic cells take l <= 3).
-template <int NCOMP, int LMAX = 5, class Sink>
+template <int NCOMP, int LMAX = 5, bool SCREEN = false, class Sink>
 __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, const double* __restrict__ pexp,
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
   const double r2 = x * x + y * y + z * z;
@@ -88,9 +91,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 #pragma unroll PQA_PRIM_UNROLL
   for (int p = 0; p < np; ++p) {
     const double a = pexp[p];
-#if PQA_PRIM_SCREEN
-    if (a * r2 > PQA_PRIM_CUT) continue;
-#endif
+    if ((SCREEN || PQA_PRIM_SCREEN) && a * r2 > PQA_PRIM_CUT) continue;
     const double t = pcoef[p] * exp(-a * r2);
     R += t;
     if (NCOMP > 1) dRs += a * t;
@@ -167,11 +168,23 @@ __device__ __forceinline__ PrimWrap prim_wrap(const SysDev& S, double px, double
   return w;
 }
 
+// Image lists.  k_pbc_prepass works out, once per (point, atom), which of the atom's candidate images are admitted (atom
+// cut-off and membership rule) and SORTS them by distance, nearest first, into a packed list of 16-bit image indices (4 per
+// 64-bit word, PQA_IMG_END after the last).  Every shell of the atom then walks a PREFIX of that list — the images inside
+// its own cut-off — and stops at the first one outside: a contracted shell with a short range looks at its 1-2 images
+// instead of every image the atom's most diffuse shell needs (13 in the 2x2x2 diamond cell), and because the k-th entries of
+// all lanes are their k-th NEAREST images the wave's lanes leave the loop together and the primitive screening above works.
+// A lane whose list does not fit (or an atom with more than 128 candidates) carries PQA_IMG_OVF and tests every candidate
+// image directly, as does the thread-per-point test kernel k_ao.
+#define PQA_IMG_END 0xFFFFu
+#define PQA_IMG_OVF 0xFFFEu
 struct PbcCtx {
   int ia = -1;
   double x0, y0, z0;        // folded displacement point - atom
-  int b0, b1, b2;           // membership index of image j = b + img_n[j]
-  unsigned long long mask[2];  // images j < 128 that pass the atom cut-off and the membership rule
+  int b0, b1, b2;           // membership index of image j = b + img_n[j] (direct tests only)
+  const unsigned long long* lp = nullptr;  // this lane's list: word w at lp[w * lstride]
+  long lstride = 0;
+  bool ovf = true;          // no list: test every candidate image
   double cf = 1.0, sf = 0.0;   // twisted: (cos, sin)(k_t . f . lattice) of the fold f applied to point - atom
 };
 
@@ -186,8 +199,8 @@ __device__ __forceinline__ bool pbc_image_ok(const SysDev& S, const PbcCtx& c, i
   return true;
 }
 
-__device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int ia, double x, double y, double z, PrimWrap pw) {
-  if (c.ia == ia) return;
+// fold point - atom into the cell-centred parallelepiped; membership base and twist phase of that fold
+__device__ __forceinline__ void pbc_ctx_base(const SysDev& S, PbcCtx& c, int ia, double x, double y, double z, PrimWrap pw) {
   c.ia = ia;
   const double f0 = floor(x * S.pb->linv[0] + y * S.pb->linv[3] + z * S.pb->linv[6] + 0.5);
   const double f1 = floor(x * S.pb->linv[1] + y * S.pb->linv[4] + z * S.pb->linv[7] + 0.5);
@@ -202,16 +215,12 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
     c.b1 = S.pb->atom_n[3 * ia + 1] + i0 * S.pb->supercell[1] + i1 * S.pb->supercell[4] + i2 * S.pb->supercell[7] - pw.w1 + S.pb->member_M;
     c.b2 = S.pb->atom_n[3 * ia + 2] + i0 * S.pb->supercell[2] + i1 * S.pb->supercell[5] + i2 * S.pb->supercell[8] - pw.w2 + S.pb->member_M;
   }
-  const int nimg = min(S.pb->num_Ls[ia], 128);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    unsigned long long m = 0ull;
-    for (int j = 64 * h; j < min(nimg, 64 * h + 64); ++j) {
-      const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
-      if (pbc_image_ok(S, c, j, xj * xj + yj * yj + zj * zj)) m |= 1ull << (j & 63);
-    }
-    c.mask[h] = m;
-  }
+}
+// list-less context (k_ao; lanes flagged PQA_IMG_OVF)
+__device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int ia, double x, double y, double z, PrimWrap pw) {
+  if (c.ia == ia) return;
+  pbc_ctx_base(S, c, ia, x, y, z, pw);
+  c.ovf = true;
 }
 
 // Twisted cells (TW): the lattice sum sum_L exp(i k_t . L) phi(r - R - L) is complex; one walk over the admitted images
@@ -234,7 +243,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
       pr = c.cf * cj - c.sf * sj;
       pi = c.sf * cj + c.cf * sj;
     }
-    shell_eval<NCOMP, 3>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
+    shell_eval<NCOMP, 3, true>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       if (TW) {
         aim[TW ? m : 0][0] += pi * v;
         if (NCOMP > 1) { aim[TW ? m : 0][1 % NCOMP] += pi * gx; aim[TW ? m : 0][2 % NCOMP] += pi * gy; aim[TW ? m : 0][3 % NCOMP] += pi * gz; }
@@ -246,22 +255,34 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
       if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
     });
   };
-  // Each lane walks ITS OWN list of admitted images (the set bits of its mask): the points of a wave sit anywhere in
-  // the cell, so iterating over image indices in lock-step would make every lane wait for the union of all lanes'
-  // images (~30 per atom) instead of the handful it needs itself.  Iterations = max over lanes of the count.
-  unsigned long long m0 = c.mask[0], m1 = c.mask[1];
-  while (__any((m0 | m1) != 0ull)) {
-    int j = -1;
-    if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
-    else if (m1) { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
-    const int jj = j < 0 ? 0 : j;
-    const double xj = c.x0 - S.pb->Ls[3 * jj], yj = c.y0 - S.pb->Ls[3 * jj + 1], zj = c.z0 - S.pb->Ls[3 * jj + 2];
-    if (j >= 0 && xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, jj);
+  // Each lane walks ITS OWN list of admitted images, nearest first, as far as this shell's cut-off reaches (the points of a
+  // wave sit anywhere in the cell: iterating over image indices in lock-step would make every lane wait for the union of
+  // all lanes' images).  Iterations = max over lanes of the number of images inside the shell's range.
+  {
+    bool alive = !c.ovf;
+    unsigned long long cur = 0ull;
+    int k = 0;
+    while (__any(alive)) {
+      if (alive) {
+        if ((k & 3) == 0) cur = c.lp[(size_t)(k >> 2) * c.lstride];
+        const int j = (int)(cur & 0xFFFFull);
+        cur >>= 16;
+        if (j == (int)PQA_IMG_END) alive = false;
+        else {
+          const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
+          if (xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, j);
+          else alive = false;  // sorted by distance: nothing further can be inside
+        }
+      }
+      ++k;
+    }
   }
-  for (int j = 128; j < nimg; ++j) {  // beyond the mask (very small cells): direct tests
-    const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
-    const double r2 = xj * xj + yj * yj + zj * zj;
-    if (r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj, j);
+  if (__any(c.ovf)) {  // list-less lanes: direct tests of every candidate image
+    for (int j = 0; j < nimg; ++j) {
+      const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
+      const double r2 = xj * xj + yj * yj + zj * zj;
+      if (c.ovf && r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj, j);
+    }
   }
 #pragma unroll
   for (int m = 0; m < 7; ++m)
@@ -277,12 +298,32 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 }
 
 // Pre-pass of a periodic k_orb launch: thread = (point, atom).  Folds the point into the cell, folds point - atom into
-// the cell-centred parallelepiped and works out which of the atom's candidate images are admitted (atom cut-off and
-// membership rule) — once, instead of once per lane group inside k_orb, and in a kernel that is not register-bound.
-__global__ __launch_bounds__(256) void k_pbc_prepass(SysDev S, PointAddr pa, long P, double* __restrict__ d0,
-                                                     unsigned long long* __restrict__ mask, double* __restrict__ theta) {
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+// the cell-centred parallelepiped, works out which of the atom's candidate images are admitted (atom cut-off and
+// membership rule) and writes them sorted by distance as the packed list described at PbcCtx — once, instead of once per
+// lane group inside k_orb, and in a kernel that is not register-bound.  lst: [natom][NW][P] words.
+#define PQA_PRE_CAP 32   // admitted images per (point, atom) the pre-pass can order (their 4-bit classes fill two words)
+#define PQA_PRE_NT 256
+#define PQA_MAXCLS 15    // distinct shell cut-offs per atom
+// Ordering without a sort: a shell only needs the images inside ITS cut-off to come first, and an atom's shells have a
+// handful of distinct cut-offs (five in the diamond basis).  So every admitted image gets the class of the smallest shell
+// cut-off that contains it, and the list is written class by class, with the lane's nearest image moved to the very front
+// (so that from the second entry on all lanes are far from the centre and the primitive screening bites).  Everything
+// lives in registers: an LDS sort cut the kernel's occupancy to 1.5 waves per SIMD and a selection sort in registers
+// recomputed n^2 distances — both 2.4 x slower than this.
+__global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
+                                                     unsigned long long* __restrict__ lst, double* __restrict__ theta) {
+  __shared__ double s_Ls[128][3];  // the candidates' lattice vectors (per-candidate scalar loads — load, wait, test — cost
+                                   // 79 dependent round trips per thread in the 2x2x2 diamond cell)
+  __shared__ double s_cut[PQA_MAXCLS + 1];
   const int ia = blockIdx.y;
+  const int ncls = S.pb->ncls[ia];
+  {
+    const int nl = min(S.pb->num_Ls[ia], 128);
+    for (int q = threadIdx.x; q < 3 * nl; q += PQA_PRE_NT) s_Ls[q / 3][q % 3] = S.pb->Ls[q];
+    if (threadIdx.x < PQA_MAXCLS) s_cut[threadIdx.x] = threadIdx.x < ncls ? S.pb->cls_cut[ia * PQA_MAXCLS + threadIdx.x] : 0.0;
+    __syncthreads();
+  }
+  const long p = (long)blockIdx.x * PQA_PRE_NT + threadIdx.x;
   if (p >= P) return;
   double px, py, pz;
   load_point(pa, p, px, py, pz);
@@ -294,13 +335,89 @@ __global__ __launch_bounds__(256) void k_pbc_prepass(SysDev S, PointAddr pa, lon
     theta[2 * p] = cs; theta[2 * p + 1] = sn;
   }
   PbcCtx c;
-  pbc_ctx_update(S, c, ia, px - S.atom_xyz[3 * ia], py - S.atom_xyz[3 * ia + 1], pz - S.atom_xyz[3 * ia + 2], prim_wrap(S, px, py, pz));
+  pbc_ctx_base(S, c, ia, px - S.atom_xyz[3 * ia], py - S.atom_xyz[3 * ia + 1], pz - S.atom_xyz[3 * ia + 2], prim_wrap(S, px, py, pz));
   d0[((size_t)ia * 3 + 0) * P + p] = c.x0;
   d0[((size_t)ia * 3 + 1) * P + p] = c.y0;
   d0[((size_t)ia * 3 + 2) * P + p] = c.z0;
   if (S.pb->twist) { d0[((size_t)S.natom * 3 + 2 * ia) * P + p] = c.cf; d0[((size_t)S.natom * 3 + 2 * ia + 1) * P + p] = c.sf; }
-  mask[((size_t)ia * 2 + 0) * P + p] = c.mask[0];
-  mask[((size_t)ia * 2 + 1) * P + p] = c.mask[1];
+  unsigned long long* out = lst + (size_t)ia * NW * P + p;  // word w at out[w * P]
+  const int nimg = S.pb->num_Ls[ia];
+  const int cap = min(4 * NW - 1, PQA_PRE_CAP);
+  if (nimg > 128 || ncls <= 0) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
+  // 1. distance test of every candidate
+  unsigned long long m0 = 0ull, m1 = 0ull;
+  {
+    const double acut = S.pb->atom_cut[ia];
+#pragma unroll 4
+    for (int j = 0; j < nimg; ++j) {
+      const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
+      if (xj * xj + yj * yj + zj * zj <= acut) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
+    }
+  }
+  // 2. the lane's own few survivors: membership rule, class, nearest
+  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull;  // admitted images; 4-bit class of the k-th admitted
+  int n = 0, jmin = -1;
+  double rmin = 1e300;
+  bool over = false;
+  while (m0 | m1) {
+    int j;
+    if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
+    else { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
+    const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
+    const double r2 = xj * xj + yj * yj + zj * zj;
+    if (!pbc_image_ok(S, c, j, r2)) continue;
+    int cls = 0;
+    while (cls < ncls && r2 > s_cut[cls]) ++cls;
+    if (cls >= ncls) continue;  // inside the atom's cut-off but outside every shell's
+    if (n >= cap) { over = true; break; }
+    if (j < 64) a0 |= 1ull << j; else a1 |= 1ull << (j - 64);
+    if (n < 16) cl0 |= (unsigned long long)cls << (4 * n); else cl1 |= (unsigned long long)cls << (4 * (n - 16));
+    if (r2 < rmin) { rmin = r2; jmin = j; }
+    ++n;
+  }
+  if (over) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
+  // 3. emit: nearest image, then class by class (index order inside a class)
+  unsigned long long w = 0ull;
+  int shf = 0, wi = 0;
+  auto emit = [&](int j) {
+    w |= (unsigned long long)j << shf;
+    shf += 16;
+    if (shf == 64) { out[(size_t)wi * P] = w; ++wi; w = 0ull; shf = 0; }
+  };
+  if (n > 0) emit(jmin);
+  for (int cls = 0; cls < ncls; ++cls) {
+    unsigned long long b0 = a0, b1 = a1, q0 = cl0, q1 = cl1;
+    int k = 0;
+    while (b0 | b1) {
+      int j;
+      if (b0) { j = __ffsll((long long)b0) - 1; b0 &= b0 - 1; }
+      else { j = 64 + __ffsll((long long)b1) - 1; b1 &= b1 - 1; }
+      const int cj = (int)((k < 16 ? q0 >> (4 * k) : q1 >> (4 * (k - 16))) & 15ull);
+      ++k;
+      if (cj == cls && j != jmin) emit(j);
+    }
+  }
+  for (; shf < 64; shf += 16) w |= (unsigned long long)PQA_IMG_END << shf;  // n <= 4 NW - 1: at least one terminator
+  out[(size_t)wi * P] = w;
+}
+
+// per (point, atom) data of k_pbc_prepass -> context of the shells of atom ia (k_orb, k_orb_wide)
+template <int PBC, class Tab>
+__device__ __forceinline__ void pbc_ctx_load(const SysDev& S, const Tab& T, PbcCtx& ctx, int ia, long P, long p, double x, double y,
+                                             double z, PrimWrap pw) {
+  if (ctx.ia == ia) return;
+  ctx.ia = ia;
+  ctx.x0 = T.pbc_d0[((size_t)ia * 3 + 0) * P + p];
+  ctx.y0 = T.pbc_d0[((size_t)ia * 3 + 1) * P + p];
+  ctx.z0 = T.pbc_d0[((size_t)ia * 3 + 2) * P + p];
+  if (PBC == 2) {
+    ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia) * P + p];
+    ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia + 1) * P + p];
+  }
+  ctx.lp = T.pbc_list + (size_t)ia * T.pbc_nw * P + p;
+  ctx.lstride = P;
+  ctx.ovf = (ctx.lp[0] & 0xFFFFull) == (unsigned long long)PQA_IMG_OVF;
+  if (ctx.ovf) pbc_ctx_base(S, ctx, ia, x, y, z, pw);  // membership base for the direct tests (same fold as the pre-pass)
 }
 
 // Twisted cells: multiply every orbital row [ncomp][2 nmo] (re block | im block) by the point's wrap phase.
@@ -370,10 +487,11 @@ struct ChunkTab {
   const int* cw_shell[3]; // shells for (chunk, group)
   const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
   int ldc[2];
-  // periodic launches only: per (atom, point) folded displacement [natom][3][P] and admission mask [natom][2][P],
+  // periodic launches only: per (atom, point) folded displacement [natom][3][P] and sorted image list [natom][pbc_nw][P],
   // written by k_pbc_prepass for the points of THIS launch
   const double* pbc_d0;
-  const unsigned long long* pbc_mask;
+  const unsigned long long* pbc_list;
+  int pbc_nw;
 };
 
 #define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
@@ -484,19 +602,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
       };
       if (PBC) {
-        if (ctx.ia != ia_) {  // per (point, atom) data of k_pbc_prepass; images beyond the 128-bit mask need b0..b2 too
-          ctx.ia = ia_;
-          ctx.x0 = T.pbc_d0[((size_t)ia_ * 3 + 0) * P + pmine];
-          ctx.y0 = T.pbc_d0[((size_t)ia_ * 3 + 1) * P + pmine];
-          ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
-          ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
-          ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
-          if (PBC == 2) {
-            ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_) * P + pmine];
-            ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_ + 1) * P + pmine];
-          }
-          if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
-        }
+        pbc_ctx_load<PBC>(S, T, ctx, ia_, P, pmine, x, y, z, pw);
         if (PBC == 2) {  // twisted: the shell's imaginary rows follow its real rows in the tile
           const int kbi = kb + 2 * l_ + 1;
           auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
@@ -746,19 +852,7 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
       if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
     };
     if (PBC) {
-      if (ctx.ia != ia_) {
-        ctx.ia = ia_;
-        ctx.x0 = T.pbc_d0[((size_t)ia_ * 3 + 0) * P + pmine];
-        ctx.y0 = T.pbc_d0[((size_t)ia_ * 3 + 1) * P + pmine];
-        ctx.z0 = T.pbc_d0[((size_t)ia_ * 3 + 2) * P + pmine];
-        ctx.mask[0] = T.pbc_mask[((size_t)ia_ * 2 + 0) * P + pmine];
-        ctx.mask[1] = T.pbc_mask[((size_t)ia_ * 2 + 1) * P + pmine];
-        if (PBC == 2) {
-          ctx.cf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_) * P + pmine];
-          ctx.sf = T.pbc_d0[((size_t)S.natom * 3 + 2 * ia_ + 1) * P + pmine];
-        }
-        if (S.pb->num_Ls[ia_] > 128) { ctx.ia = -1; pbc_ctx_update(S, ctx, ia_, x, y, z, pw); }
-      }
+      pbc_ctx_load<PBC>(S, T, ctx, ia_, P, pmine, x, y, z, pw);
       if (PBC == 2) {
         const int kbi = Wt.row[sh + S.nshell];
         auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {

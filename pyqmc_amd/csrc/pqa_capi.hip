@@ -46,6 +46,7 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
+  int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
   bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
   bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
@@ -57,6 +58,7 @@ struct pqa_handle {
   EwaldDev ew{};  // periodic Coulomb tables (pqa_set_ewald)
   bool ew_set = false;
   std::vector<int> shell_l, shell_np, shell_ao;
+  std::vector<int> shell_cost;  // phase-1 cost model of a shell (shell_costs): balances the lane groups of the orbital kernels
   SysDev S{};
   ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
   ChunkTab tab[2]{};
@@ -204,6 +206,41 @@ static int check_launch(pqa_handle* h, const char* what) {
   return 0;
 }
 
+// ---------------------------------------------------------------- phase-1 cost model of the shells
+// One evaluation of a shell costs a radial part per primitive and an angular part / tile stores per function.  An open
+// system evaluates every shell once per point.  A periodic one evaluates it once per image inside the SHELL's cut-off — the
+// wave walks max-over-lanes of that count, about 1.4 x the mean V_sphere(shell_cut) / V_cell plus one — and from the second
+// (farther) image on only the primitives that survive the screening at half the shortest lattice vector are evaluated.
+// Packing the lane groups with the per-evaluation cost alone gave a group holding two diffuse p shells (13 images each in
+// the 2x2x2 diamond cell) 2.3 x the average load, and a barrier ends every chunk.
+static void shell_costs(pqa_handle* h, const pqa_system_t* sys) {
+  const int tw = h->twist ? 2 : 1;
+  h->shell_cost.assign((size_t)h->nshell, 0);
+  std::vector<double> scut, pexp;
+  double vol = 0.0, half2 = 0.0;
+  if (sys->pbc && sys->nL > 0 && sys->shell_cut) {
+    scut.resize((size_t)h->nshell);
+    hipMemcpy(scut.data(), sys->shell_cut, scut.size() * sizeof(double), hipMemcpyDefault);
+    pexp.resize((size_t)sys->nprim);
+    hipMemcpy(pexp.data(), sys->prim_exp, pexp.size() * sizeof(double), hipMemcpyDefault);
+    const double* a = sys->lattice;
+    vol = fabs(a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]));
+    half2 = 1e300;
+    for (int i = 0; i < 3; ++i) half2 = std::min(half2, 0.25 * (a[3 * i] * a[3 * i] + a[3 * i + 1] * a[3 * i + 1] + a[3 * i + 2] * a[3 * i + 2]));
+  }
+  std::vector<int> poff((size_t)h->nshell + 1);
+  hipMemcpy(poff.data(), sys->shell_prim_off, poff.size() * sizeof(int), hipMemcpyDefault);
+  for (int s = 0; s < h->nshell; ++s) {
+    const int ang = 25 * tw * (2 * h->shell_l[s] + 1) + 40;
+    if (scut.empty() || !(vol > 0.0)) { h->shell_cost[s] = 45 * h->shell_np[s] + ang; continue; }
+    const double mean = 4.18879020478639 * scut[s] * std::sqrt(scut[s]) / vol;
+    const double iters = std::max(1.0, 1.4 * mean + 1.0);
+    int far = 0;  // primitives still evaluated beyond the nearest image
+    for (int q = poff[s]; q < poff[s + 1]; ++q) far += (pexp[q] * half2 <= 50.0) ? 1 : 0;
+    h->shell_cost[s] = (int)((45 * h->shell_np[s] + ang + 30) + (iters - 1.0) * (45 * far + ang + 30));
+  }
+}
+
 // ---------------------------------------------------------------- chunk tables for k_orb
 static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c = ChunkHost();
@@ -215,7 +252,7 @@ static void build_chunks(const pqa_handle* h, int KC, ChunkHost& c) {
   c.shell_kb.assign((size_t)tw * h->nshell, 0);
   c.shell_chunk.assign((size_t)tw * h->nshell, 0);
   // phase-1 cost of a shell: radial part per primitive + angular part / tile stores per function
-  auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * tw * (2 * h->shell_l[s] + 1) + 40; };
+  auto cost = [&](int s) { return h->shell_cost[s]; };
   auto nfun = [&](int s) { return tw * (2 * h->shell_l[s] + 1); };
   int nao = 0;
   for (int s = 0; s < nsx; ++s) nao += nfun(s);
@@ -449,6 +486,36 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, sys->num_Ls, (size_t)h->natom, &tmp_i)); P.num_Ls = tmp_i;
       TRY(upload_table(h, sys->atom_cut, (size_t)h->natom, &tmp_d)); P.atom_cut = tmp_d;
       TRY(upload_table(h, sys->shell_cut, (size_t)sys->nshell, &tmp_d)); P.shell_cut = tmp_d;
+      {  // distinct shell cut-offs per atom, ascending: the classes k_pbc_prepass orders an atom's images by
+        std::vector<double> sc((size_t)sys->nshell), cc((size_t)h->natom * PQA_MAXCLS, 0.0);
+        std::vector<int> sa((size_t)sys->nshell), nc((size_t)h->natom, 0);
+        HIPCHK(hipMemcpy(sc.data(), sys->shell_cut, sc.size() * sizeof(double), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(sa.data(), sys->shell_atom, sa.size() * sizeof(int), hipMemcpyDefault));
+        for (int a = 0; a < h->natom; ++a) {
+          std::vector<double> u;
+          for (int q = 0; q < sys->nshell; ++q)
+            if (sa[q] == a) u.push_back(sc[q]);
+          std::sort(u.begin(), u.end());
+          u.erase(std::unique(u.begin(), u.end()), u.end());
+          if ((int)u.size() > PQA_MAXCLS) continue;  // nc = 0: this atom's images are tested directly
+          nc[a] = (int)u.size();
+          for (size_t q = 0; q < u.size(); ++q) cc[(size_t)a * PQA_MAXCLS + q] = u[q];
+        }
+        TRY(upload_table(h, cc.data(), cc.size(), &tmp_d)); P.cls_cut = tmp_d;
+        TRY(upload_table(h, nc.data(), nc.size(), &tmp_i)); P.ncls = tmp_i;
+      }
+      {  // capacity of the per-(atom, point) image lists: the lattice points inside a sphere of the largest atom cut-off number
+         // V_sphere / V_cell on average; 1.5 x that + 8 with room for a terminator (lanes beyond it test images directly)
+        std::vector<double> ac((size_t)h->natom);
+        HIPCHK(hipMemcpy(ac.data(), sys->atom_cut, ac.size() * sizeof(double), hipMemcpyDefault));
+        const double* a = sys->lattice;
+        const double vol = fabs(a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]));
+        const double r2 = *std::max_element(ac.begin(), ac.end());
+        const double mean = 4.18879020478639 * r2 * std::sqrt(r2) / std::max(vol, 1e-12);
+        const int cap = (int)std::min(127.0, std::ceil(1.5 * mean + 8.0));
+        h->pbc_nw = cap / 4 + 1;
+        if (const char* e = getenv("PQA_PBC_NW")) h->pbc_nw = std::max(1, std::min(32, atoi(e)));
+      }
       P.twist = h->twist ? 1 : 0;
       if (h->twist) {
         std::vector<double> ls((size_t)sys->nL * 3), ph((size_t)sys->nL * 2);
@@ -493,6 +560,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     const int* occ_src[2] = {sys->det_occ_up, sys->det_occ_dn};
     const double* mo_src[2] = {sys->mo_up, sys->mo_dn};
     const int nel[2] = {h->nup, h->ndn};
+    shell_costs(h, sys);
     build_chunks(h, 16, h->chunks[0]);
     build_chunks(h, 32, h->chunks[1]);
     for (int s = 0; s < 2; ++s) {
@@ -535,7 +603,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       const int tw = h->twist ? 2 : 1;
       const int ngrp = h->S.pbc ? 32 : 64;  // lane groups of k_orb_wide: 512 threads for periodic cells, 1024 otherwise
       std::vector<int> order((size_t)h->nshell), wrow((size_t)tw * h->nshell), woff(65, 0), wsh;
-      auto cost = [&](int s) { return 45 * h->shell_np[s] + 25 * tw * (2 * h->shell_l[s] + 1) + 40; };
+      auto cost = [&](int s) { return h->shell_cost[s]; };
       for (int s = 0; s < h->nshell; ++s) order[s] = s;
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
       std::vector<std::vector<int>> grp(64);
@@ -767,13 +835,15 @@ static int launch_orb_wide(pqa_handle* h, const ChunkTab& T, int tabi, int spin,
 template <int NCOMP, int KC>
 static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   TRY(ensure(h, h->b_pbcd0, (size_t)h->natom * (h->twist ? 5 : 3) * P * sizeof(double)));
-  TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * 2 * P * sizeof(unsigned long long)));
+  const int NW = h->pbc_nw;
+  TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * NW * P * sizeof(unsigned long long)));
   if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
-  hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + 255) / 256), (unsigned)h->natom), dim3(256), 0, h->stream, h->S, pa, P,
+  hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
                      (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
   ChunkTab T = h->tab[tabi];
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
-  T.pbc_mask = (const unsigned long long*)h->b_pbcmask.p;
+  T.pbc_list = (const unsigned long long*)h->b_pbcmask.p;
+  T.pbc_nw = NW;
   if (wide_wanted(h, tabi, P, NCOMP)) {  // small launch: one 1024-thread block per 16-point tile, the whole basis in LDS
     if (h->twist) TRY(launch_orb_wide<2>(h, T, tabi, spin, pa, P, out)); else TRY(launch_orb_wide<1>(h, T, tabi, spin, pa, P, out));
     if (h->twist) {

@@ -20,6 +20,9 @@ struct PbcDev {
   const int* num_Ls;
   const double* atom_cut;
   const double* shell_cut;
+  // distinct shell cut-offs of every atom, ascending: cls_cut[atom][PQA_MAXCLS], ncls[atom] (0: more than PQA_MAXCLS, no lists)
+  const double* cls_cut;
+  const int* ncls;
   // reference image-membership rule (see include/pyqmc_amd.h): member == nullptr -> every image inside the cut-offs
   const unsigned char* member;
   const int* member_class;
