@@ -228,12 +228,18 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
 // the image phase) and hands them to sink(m, ...) and sink_im(m, ...).  Untwisted: sink only.
 template <int NCOMP, bool TW = false, class Sink, class SinkIm>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
-                                               const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im) {
-  double acc[7][NCOMP], aim[TW ? 7 : 1][NCOMP];
+                                               const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im, bool& accumulate) {
+  // The lattice sum is accumulated where the functions live (the lane's own column of the LDS tile; `accumulate` tells the
+  // sinks to add instead of store): 7 x NCOMP running sums in registers — twice that for a twisted cell — were 70 / 140 of
+  // the kernel's ~255 registers, pinned it at 2 (twisted: 1) waves per SIMD and spilled.
+  accumulate = false;
 #pragma unroll
   for (int m = 0; m < 7; ++m)
-#pragma unroll
-    for (int k = 0; k < NCOMP; ++k) { acc[m][k] = 0.0; if (TW) aim[TW ? m : 0][k] = 0.0; }
+    if (m < 2 * l + 1) {
+      sink(m, 0.0, 0.0, 0.0, 0.0, 0.0);
+      if (TW) sink_im(m, 0.0, 0.0, 0.0, 0.0, 0.0);
+    }
+  accumulate = true;
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
   auto add = [&](double xj, double yj, double zj, int j) {
@@ -245,14 +251,10 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     }
     shell_eval<NCOMP, 3, true>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       if (TW) {
-        aim[TW ? m : 0][0] += pi * v;
-        if (NCOMP > 1) { aim[TW ? m : 0][1 % NCOMP] += pi * gx; aim[TW ? m : 0][2 % NCOMP] += pi * gy; aim[TW ? m : 0][3 % NCOMP] += pi * gz; }
-        if (NCOMP == 5) aim[TW ? m : 0][4 % NCOMP] += pi * lp;
+        sink_im(m, pi * v, pi * gx, pi * gy, pi * gz, pi * lp);
         v *= pr; gx *= pr; gy *= pr; gz *= pr; lp *= pr;
       }
-      acc[m][0] += v;
-      if (NCOMP > 1) { acc[m][1 % NCOMP] += gx; acc[m][2 % NCOMP] += gy; acc[m][3 % NCOMP] += gz; }
-      if (NCOMP == 5) acc[m][4 % NCOMP] += lp;
+      sink(m, v, gx, gy, gz, lp);
     });
   };
   // Each lane walks ITS OWN list of admitted images, nearest first, as far as this shell's cut-off reaches (the points of a
@@ -284,17 +286,12 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
       if (c.ovf && r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj, j);
     }
   }
-#pragma unroll
-  for (int m = 0; m < 7; ++m)
-    if (m < 2 * l + 1) {
-      sink(m, acc[m][0], acc[m][1 % NCOMP], acc[m][2 % NCOMP], acc[m][3 % NCOMP], acc[m][4 % NCOMP]);
-      if (TW) sink_im(m, aim[TW ? m : 0][0], aim[TW ? m : 0][1 % NCOMP], aim[TW ? m : 0][2 % NCOMP], aim[TW ? m : 0][3 % NCOMP], aim[TW ? m : 0][4 % NCOMP]);
-    }
+  accumulate = false;
 }
 template <int NCOMP, class Sink>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
-                                               const double* __restrict__ pcoef, int np, Sink&& sink) {
-  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink);
+                                               const double* __restrict__ pcoef, int np, Sink&& sink, bool& accumulate) {
+  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink, accumulate);
 }
 
 // Pre-pass of a periodic k_orb launch: thread = (point, atom).  Folds the point into the cell, folds point - atom into
@@ -446,16 +443,23 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
   for (int sh = 0; sh < S.nshell; ++sh) {
     const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
     const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
+    bool accum = false;  // periodic: the lattice sum accumulates in place (shell_eval_pbc)
     auto store = [&](int m, double v, double gx, double gy, double gz, double lp) {
       double* o = out + p * S.nao + ao0 + m;
       const long cs = P * (long)S.nao;
-      o[0] = v;
-      if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
-      if (NCOMP == 5) o[4 * cs] = lp;
+      if (accum) {
+        o[0] += v;
+        if (NCOMP > 1) { o[cs] += gx; o[2 * cs] += gy; o[3 * cs] += gz; }
+        if (NCOMP == 5) o[4 * cs] += lp;
+      } else {
+        o[0] = v;
+        if (NCOMP > 1) { o[cs] = gx; o[2 * cs] = gy; o[3 * cs] = gz; }
+        if (NCOMP == 5) o[4 * cs] = lp;
+      }
     };
     if (S.nL > 0) {
       pbc_ctx_update(S, ctx, ia, x, y, z, pw);
-      shell_eval_pbc<NCOMP>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
+      shell_eval_pbc<NCOMP>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store, accum);
     } else
       shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
   }
@@ -594,12 +598,19 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
         x = px - S.atom_xyz[3 * ia]; y = py - S.atom_xyz[3 * ia + 1]; z = pz - S.atom_xyz[3 * ia + 2];
         pe = S.prim_exp + q0; pc = S.prim_coef + q0;
       }
+      bool accum = false;  // periodic: the lattice sum accumulates in the tile (shell_eval_pbc)
       auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
         const int k = kb + m;
         const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
-        tile[0][k][col] = v;
-        if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
-        if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+        if (PBC && accum) {
+          tile[0][k][col] += v;
+          if (NCOMP > 1) { tile[1 % NCOMP][k][col] += gx; tile[2 % NCOMP][k][col] += gy; tile[3 % NCOMP][k][col] += gz; }
+          if (NCOMP == 5) tile[4 % NCOMP][k][col] += lp;
+        } else {
+          tile[0][k][col] = v;
+          if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
+          if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+        }
       };
       if (PBC) {
         pbc_ctx_load<PBC>(S, T, ctx, ia_, P, pmine, x, y, z, pw);
@@ -608,12 +619,18 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
           auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
             const int k = kbi + m;
             const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
-            tile[0][k][col] = v;
-            if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
-            if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+            if (accum) {
+              tile[0][k][col] += v;
+              if (NCOMP > 1) { tile[1 % NCOMP][k][col] += gx; tile[2 % NCOMP][k][col] += gy; tile[3 % NCOMP][k][col] += gz; }
+              if (NCOMP == 5) tile[4 % NCOMP][k][col] += lp;
+            } else {
+              tile[0][k][col] = v;
+              if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
+              if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
+            }
           };
-          shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im);
-        } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
+          shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum);
+        } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, accum);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
@@ -845,11 +862,18 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
     const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], kb = sh_meta[5 * sh + 3], ia_ = sh_meta[5 * sh + 4];
     const double x = px - sh_xyz[3 * sh], y = py - sh_xyz[3 * sh + 1], z = pz - sh_xyz[3 * sh + 2];
     const double *pe = pr_exp + q0, *pc = pr_coef + q0;
+    bool accum = false;  // periodic: the lattice sum accumulates in the tile (shell_eval_pbc)
     auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
       double* t = tile + (size_t)(kb + m) * 16 + pl;
-      t[0] = v;
-      if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
-      if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+      if (PBC && accum) {
+        t[0] += v;
+        if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] += gx; t[(size_t)(2 % NCOMP) * K * 16] += gy; t[(size_t)(3 % NCOMP) * K * 16] += gz; }
+        if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] += lp;
+      } else {
+        t[0] = v;
+        if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
+        if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+      }
     };
     if (PBC) {
       pbc_ctx_load<PBC>(S, T, ctx, ia_, P, pmine, x, y, z, pw);
@@ -857,12 +881,18 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
         const int kbi = Wt.row[sh + S.nshell];
         auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
           double* t = tile + (size_t)(kbi + m) * 16 + pl;
-          t[0] = v;
-          if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
-          if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+          if (accum) {
+            t[0] += v;
+            if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] += gx; t[(size_t)(2 % NCOMP) * K * 16] += gy; t[(size_t)(3 % NCOMP) * K * 16] += gz; }
+            if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] += lp;
+          } else {
+            t[0] = v;
+            if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
+            if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
+          }
         };
-        shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im);
-      } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile);
+        shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum);
+      } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, accum);
     } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
   }
   __syncthreads();
