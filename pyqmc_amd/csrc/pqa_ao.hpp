@@ -184,6 +184,7 @@ struct PbcCtx {
   int b0, b1, b2;           // membership index of image j = b + img_n[j] (direct tests only)
   const unsigned long long* lp = nullptr;  // this lane's list: word w at lp[w * lstride]
   long lstride = 0;
+  int lcap = 0;             // entries the list can hold (bounds the walk)
   bool ovf = true;          // no list: test every candidate image
   double cf = 1.0, sf = 0.0;   // twisted: (cos, sin)(k_t . f . lattice) of the fold f applied to point - atom
 };
@@ -265,6 +266,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     unsigned long long cur = 0ull;
     int k = 0;
     while (__any(alive)) {
+      if (k >= c.lcap) alive = false;
       if (alive) {
         if ((k & 3) == 0) cur = c.lp[(size_t)(k >> 2) * c.lstride];
         const int j = (int)(cur & 0xFFFFull);
@@ -307,20 +309,36 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // (so that from the second entry on all lanes are far from the centre and the primitive screening bites).  Everything
 // lives in registers: an LDS sort cut the kernel's occupancy to 1.5 waves per SIMD and a selection sort in registers
 // recomputed n^2 distances — both 2.4 x slower than this.
+#define PQA_PRE_NWMAX 8   // list words the pre-pass can assemble in LDS (32 entries: PQA_PRE_CAP)
+#define PQA_PRE_MEMB 2048 // bytes of one atom class of the membership table staged in LDS (side^3; 729 for M = 4)
 __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
                                                      unsigned long long* __restrict__ lst, double* __restrict__ theta) {
-  __shared__ double s_Ls[128][3];  // the candidates' lattice vectors (per-candidate scalar loads — load, wait, test — cost
-                                   // 79 dependent round trips per thread in the 2x2x2 diamond cell)
+  // The candidates' lattice vectors, their membership offsets and the atom class's membership bytes are staged in LDS: as
+  // per-candidate scalar / gather loads (load, wait, test) they were 79 + 4 x 13 dependent round trips per thread in the
+  // 2x2x2 diamond cell — this kernel runs one wave per SIMD in a 4096-walker launch and is all latency.
+  __shared__ double s_Ls[128][3];
+  __shared__ int s_imgn[128][3];
+  __shared__ unsigned char s_memb[PQA_PRE_MEMB];
   __shared__ double s_cut[PQA_MAXCLS + 1];
-  const int ia = blockIdx.y;
+  __shared__ unsigned long long s_w[PQA_PRE_NWMAX][PQA_PRE_NT];   // the list being assembled, one column per thread
+  __shared__ unsigned char s_off[PQA_MAXCLS + 1][PQA_PRE_NT];     // next free position of every class
+  const int ia = blockIdx.y, tid = threadIdx.x;
   const int ncls = S.pb->ncls[ia];
+  const bool has_member = S.pb->member != nullptr;
+  const int side = 2 * S.pb->member_M + 1, side3 = side * side * side;
+  const bool memb_lds = has_member && side3 <= PQA_PRE_MEMB;
+  const unsigned char* gmemb = has_member ? S.pb->member + (size_t)S.pb->member_class[ia] * side3 : nullptr;
   {
     const int nl = min(S.pb->num_Ls[ia], 128);
-    for (int q = threadIdx.x; q < 3 * nl; q += PQA_PRE_NT) s_Ls[q / 3][q % 3] = S.pb->Ls[q];
-    if (threadIdx.x < PQA_MAXCLS) s_cut[threadIdx.x] = threadIdx.x < ncls ? S.pb->cls_cut[ia * PQA_MAXCLS + threadIdx.x] : 0.0;
+    for (int q = tid; q < 3 * nl; q += PQA_PRE_NT) {
+      s_Ls[q / 3][q % 3] = S.pb->Ls[q];
+      if (has_member) s_imgn[q / 3][q % 3] = S.pb->img_n[q];
+    }
+    if (memb_lds) for (int q = tid; q < side3; q += PQA_PRE_NT) s_memb[q] = gmemb[q];
+    if (tid < PQA_MAXCLS) s_cut[tid] = tid < ncls ? S.pb->cls_cut[ia * PQA_MAXCLS + tid] : 0.0;
     __syncthreads();
   }
-  const long p = (long)blockIdx.x * PQA_PRE_NT + threadIdx.x;
+  const long p = (long)blockIdx.x * PQA_PRE_NT + tid;
   if (p >= P) return;
   double px, py, pz;
   load_point(pa, p, px, py, pz);
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
   if (S.pb->twist) { d0[((size_t)S.natom * 3 + 2 * ia) * P + p] = c.cf; d0[((size_t)S.natom * 3 + 2 * ia + 1) * P + p] = c.sf; }
   unsigned long long* out = lst + (size_t)ia * NW * P + p;  // word w at out[w * P]
   const int nimg = S.pb->num_Ls[ia];
-  const int cap = min(4 * NW - 1, PQA_PRE_CAP);
+  const int nw = min(NW, PQA_PRE_NWMAX), cap = min(4 * nw - 1, PQA_PRE_CAP);
   if (nimg > 128 || ncls <= 0) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
   // 1. distance test of every candidate
   unsigned long long m0 = 0ull, m1 = 0ull;
@@ -351,51 +369,57 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
       if (xj * xj + yj * yj + zj * zj <= acut) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
     }
   }
-  // 2. the lane's own few survivors: membership rule, class, nearest
-  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull;  // admitted images; 4-bit class of the k-th admitted
-  int n = 0, jmin = -1;
+  // 2. the lane's own few survivors: membership rule, class (4 bits each, packed), nearest; class populations
+  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull;
+  int n = 0, jmin = -1, kmin = -1;
   double rmin = 1e300;
   bool over = false;
+  for (int q = 0; q <= ncls; ++q) s_off[q][tid] = 0;
   while (m0 | m1) {
     int j;
     if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
     else { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
+    if (has_member) {  // would the reference have looked at this image?  (pbc_image_ok)
+      const int n0 = c.b0 + s_imgn[j][0], n1 = c.b1 + s_imgn[j][1], n2 = c.b2 + s_imgn[j][2];
+      if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
+      const int mi = (n0 * side + n1) * side + n2;
+      if (!(memb_lds ? s_memb[mi] : gmemb[mi])) continue;
+    }
     const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
     const double r2 = xj * xj + yj * yj + zj * zj;
-    if (!pbc_image_ok(S, c, j, r2)) continue;
     int cls = 0;
     while (cls < ncls && r2 > s_cut[cls]) ++cls;
     if (cls >= ncls) continue;  // inside the atom's cut-off but outside every shell's
     if (n >= cap) { over = true; break; }
     if (j < 64) a0 |= 1ull << j; else a1 |= 1ull << (j - 64);
     if (n < 16) cl0 |= (unsigned long long)cls << (4 * n); else cl1 |= (unsigned long long)cls << (4 * (n - 16));
-    if (r2 < rmin) { rmin = r2; jmin = j; }
+    s_off[cls + 1][tid] += 1;
+    if (r2 < rmin) { rmin = r2; jmin = j; kmin = n; }
     ++n;
   }
   if (over) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
-  // 3. emit: nearest image, then class by class (index order inside a class)
-  unsigned long long w = 0ull;
-  int shf = 0, wi = 0;
-  auto emit = [&](int j) {
-    w |= (unsigned long long)j << shf;
-    shf += 16;
-    if (shf == 64) { out[(size_t)wi * P] = w; ++wi; w = 0ull; shf = 0; }
-  };
-  if (n > 0) emit(jmin);
-  for (int cls = 0; cls < ncls; ++cls) {
-    unsigned long long b0 = a0, b1 = a1, q0 = cl0, q1 = cl1;
+  // 3. nearest image first, then class by class (index order inside a class): counting scatter into the LDS column
+  const int nwords = n / 4 + 1;  // n entries + at least one terminator
+  for (int w = 0; w < nwords; ++w) s_w[w][tid] = ~0ull;  // PQA_IMG_END everywhere
+  if (n > 0) {
+    const int cmin = (int)((kmin < 16 ? cl0 >> (4 * kmin) : cl1 >> (4 * (kmin - 16))) & 15ull);
+    s_off[cmin + 1][tid] -= 1;  // the nearest image leaves its class ...
+    int run = 1;                // ... and takes position 0
+    for (int q = 0; q < ncls; ++q) { const int cnt = s_off[q + 1][tid]; s_off[q][tid] = (unsigned char)run; run += cnt; }
     int k = 0;
-    while (b0 | b1) {
+    while (a0 | a1) {
       int j;
-      if (b0) { j = __ffsll((long long)b0) - 1; b0 &= b0 - 1; }
-      else { j = 64 + __ffsll((long long)b1) - 1; b1 &= b1 - 1; }
-      const int cj = (int)((k < 16 ? q0 >> (4 * k) : q1 >> (4 * (k - 16))) & 15ull);
+      if (a0) { j = __ffsll((long long)a0) - 1; a0 &= a0 - 1; }
+      else { j = 64 + __ffsll((long long)a1) - 1; a1 &= a1 - 1; }
+      const int cj = (int)((k < 16 ? cl0 >> (4 * k) : cl1 >> (4 * (k - 16))) & 15ull);
+      int pos = 0;
+      if (k != kmin) { pos = s_off[cj][tid]; s_off[cj][tid] = (unsigned char)(pos + 1); }
       ++k;
-      if (cj == cls && j != jmin) emit(j);
+      const int sh16 = 16 * (pos & 3);
+      s_w[pos >> 2][tid] = (s_w[pos >> 2][tid] & ~(0xFFFFull << sh16)) | ((unsigned long long)j << sh16);
     }
   }
-  for (; shf < 64; shf += 16) w |= (unsigned long long)PQA_IMG_END << shf;  // n <= 4 NW - 1: at least one terminator
-  out[(size_t)wi * P] = w;
+  for (int w = 0; w < nwords; ++w) out[(size_t)w * P] = s_w[w][tid];
 }
 
 // per (point, atom) data of k_pbc_prepass -> context of the shells of atom ia (k_orb, k_orb_wide)
@@ -413,6 +437,7 @@ __device__ __forceinline__ void pbc_ctx_load(const SysDev& S, const Tab& T, PbcC
   }
   ctx.lp = T.pbc_list + (size_t)ia * T.pbc_nw * P + p;
   ctx.lstride = P;
+  ctx.lcap = 4 * T.pbc_nw;
   ctx.ovf = (ctx.lp[0] & 0xFFFFull) == (unsigned long long)PQA_IMG_OVF;
   if (ctx.ovf) pbc_ctx_base(S, ctx, ia, x, y, z, pw);  // membership base for the direct tests (same fold as the pre-pass)
 }
