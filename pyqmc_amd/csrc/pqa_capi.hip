@@ -46,6 +46,7 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
+  int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
   bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
@@ -427,6 +428,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->has_slater = sys->has_slater != 0;
   h->cplx = h->has_slater && sys->complex_orbitals != 0;
   h->twist = sys->twisted != 0;
+  // k_orb_wide: 1024 threads (64 lane groups) per 16-point tile; twisted cells need > 128 registers per thread: 512.  Untwisted
+  // periodic cells fit 128 since the lattice sums accumulate in the tile: C5 +3 % at 1024-8192 walkers over 512 threads.
+  h->wide_nth = (sys->pbc && h->twist) ? 512 : 1024;
+  if (const char* e = getenv("PQA_WIDE_NTH")) { if (sys->pbc && atoi(e) == 512) h->wide_nth = 512; }
   if (h->twist && !(h->cplx && sys->pbc && sys->nL > 0)) FAIL("twisted boundary conditions need pbc, complex_orbitals and the periodic orbital tables");
   if (h->cplx && ((sys->nmo_up | sys->nmo_dn) & 1)) FAIL("complex orbitals: nmo_up / nmo_dn count the real columns [Re C | Im C] and must be even");
   h->has_j2 = sys->na > 0 || sys->nb > 0;
@@ -601,7 +606,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       for (int s = 0; s < 2; ++s) { T.cpad[s] = h->d_cpad[t][s]; T.ldc[s] = 16 * h->nt[s]; }
       // k_orb_wide: all shells dealt to 64 lane groups (longest processing time first), tile row of a shell = its padded row
       const int tw = h->twist ? 2 : 1;
-      const int ngrp = h->S.pbc ? 32 : 64;  // lane groups of k_orb_wide: 512 threads for periodic cells, 1024 otherwise
+      const int ngrp = h->wide_nth / 16;  // lane groups of k_orb_wide (16 points per block)
       std::vector<int> order((size_t)h->nshell), wrow((size_t)tw * h->nshell), woff(65, 0), wsh;
       auto cost = [&](int s) { return h->shell_cost[s]; };
       for (int s = 0; s < h->nshell; ++s) order[s] = s;
@@ -810,13 +815,14 @@ static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
   // at 8192, even at 16384, slower at 32768 (one 1024-thread block per CU cannot overlap AO and MFMA phases of different
   // tiles); periodic cells (512 threads, two lane-group chains per point like the K-split k_orb): 2x2x2 diamond +5 / +8 / +2.5 %
   // at 1024 / 4096 / 8192 walkers, but the 8-atom cell (40 shells on 32 groups) and twisted cells (528 B of spills) lose
-  if (h->S.pbc) return !h->twist && h->nshell >= 64 && P <= h->orb_wide_max;
+  // after the image lists / in-tile accumulation (no spills any more): twisted 8-atom cell 451k -> 580k walker-steps/s at 4096
+  // walkers, 708k -> 756k at 8192; untwisted 8-atom cell even
+  if (h->S.pbc) return (h->twist || h->nshell >= 64) && P <= h->orb_wide_max;
   return P <= h->orb_wide_max + h->orb_wide_max / 2;
 }
-template <int PBCV>
+template <int PBCV, int NTH>
 static int launch_orb_wide(pqa_handle* h, const ChunkTab& T, int tabi, int spin, PointAddr pa, long P, double* out) {
   const size_t lds = wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim);
-  constexpr int NTH = PBCV ? 512 : 1024;
   const dim3 grid((unsigned)((P + 15) / 16)), block(NTH);
 #define PQA_WIDE(NT) do { const void* fn = (const void*)k_orb_wide<5, NT, PBCV, NTH>; \
     if (std::find(h->wide_attr.begin(), h->wide_attr.end(), fn) == h->wide_attr.end()) { \
@@ -845,7 +851,9 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   T.pbc_list = (const unsigned long long*)h->b_pbcmask.p;
   T.pbc_nw = NW;
   if (wide_wanted(h, tabi, P, NCOMP)) {  // small launch: one 1024-thread block per 16-point tile, the whole basis in LDS
-    if (h->twist) TRY(launch_orb_wide<2>(h, T, tabi, spin, pa, P, out)); else TRY(launch_orb_wide<1>(h, T, tabi, spin, pa, P, out));
+    if (h->twist) TRY((launch_orb_wide<2, 512>(h, T, tabi, spin, pa, P, out)));
+    else if (h->wide_nth == 1024) TRY((launch_orb_wide<1, 1024>(h, T, tabi, spin, pa, P, out)));
+    else TRY((launch_orb_wide<1, 512>(h, T, tabi, spin, pa, P, out)));
     if (h->twist) {
       const long nel = P * NCOMP * (h->nmo[spin] / 2);
       hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
@@ -951,7 +959,7 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
     else FAIL("orbital kernel supports ncomp 1 or 5");
   } else
   if (wide_wanted(h, 0, P, ncomp)) {
-    TRY(launch_orb_wide<0>(h, h->tab[0], 0, spin, pa, P, out));
+    TRY((launch_orb_wide<0, 1024>(h, h->tab[0], 0, spin, pa, P, out)));
   } else
   if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
     if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
