@@ -92,20 +92,34 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
   const int lane = threadIdx.x;  // 0 .. PQA_EWALD_T-1: the block's threads share the pair / ion / g-point loops
   for (int k = lane; k < S.nelec * 3; k += PQA_EWALD_T) lds[k] = x[w * sw + (k / 3) * se + (k % 3) * sc];
   __syncthreads();
+  // 27-image real-space sum of one pair.  Each lane first marks which of ITS 27 images are close enough to matter, then walks
+  // its own marks: the lanes of a wave hold different pairs, so stepping through the 27 images in lock-step evaluated erfc
+  // for nearly every image (some lane always needed it) although a lane needs ~12 of them.  Same terms in the same order.
   auto real_sum = [&](double dx, double dy, double dz) {
     min_image(S, dx, dy, dz);
+    const double a2 = E.alpha * E.alpha;
+    unsigned m = 0u;
+#pragma unroll
+    for (int idx = 0; idx < 27; ++idx) {
+      const int a = idx / 9 - 1, b = (idx / 3) % 3 - 1, c = idx % 3 - 1;
+      const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
+      const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
+      const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
+      if (!(a2 * (rx * rx + ry * ry + rz * rz) > 40.0)) m |= 1u << idx;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
+    }
     double acc = 0.0;
-    for (int a = -1; a <= 1; ++a)
-      for (int b = -1; b <= 1; ++b)
-        for (int c = -1; c <= 1; ++c) {
-          const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
-          const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
-          const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
-          const double r2 = rx * rx + ry * ry + rz * rz;
-          if (E.alpha * E.alpha * r2 > 40.0) continue;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
-          const double r = sqrt(r2);
-          acc += erfc(E.alpha * r) / r;
-        }
+    while (__any(m != 0u)) {
+      if (m) {
+        const int idx = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const int a = idx / 9 - 1, b = (idx / 3) % 3 - 1, c = idx % 3 - 1;
+        const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
+        const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
+        const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
+        const double r = sqrt(rx * rx + ry * ry + rz * rz);
+        acc += erfc(E.alpha * r) / r;
+      }
+    }
     return acc;
   };
   double ee = 0.0, ei = 0.0;
