@@ -70,14 +70,14 @@ if a.config == "c5" and a.rundmc:
 elif a.config == "c5":
     acc = {"energy": pa.EnergyAccumulator(sup)}
     weights = np.ones(W)
-    pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=1, accumulators=acc, fused=not a.host)
+    pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=2, accumulators=acc, fused=not a.host)
     t0 = time.perf_counter()
     blk, cfg, weights = pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc, fused=not a.host)
     dt = time.perf_counter() - t0
     kind = "DMC (host-driven protocol path)" if a.host else "DMC (pqa_dmc_steps)"
     extra = {k: float(np.real(blk[k])) for k in ("acceptance", "tmove_acceptance", "weight")}
 else:
-    dev.vmc_sweeps(0.3, 1, seed=1, energy=True)
+    dev.vmc_sweeps(0.3, 2, seed=1, energy=True)  # two warm-up steps: first launches load code objects, the tile-width tuner samples
     dev.sync()
     t0 = time.perf_counter()
     dev.vmc_sweeps(0.3, a.steps, seed=2, energy=True)

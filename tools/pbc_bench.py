@@ -21,7 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--case", default="k222")
 ap.add_argument("--walkers", type=int, default=8192)
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--warmup", type=int, default=1)
+ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--rule", default="reference")
 ap.add_argument("--no-energy", action="store_true")
 a = ap.parse_args()
