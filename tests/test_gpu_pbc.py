@@ -494,6 +494,29 @@ def test_periodic_orbital_tile_widths_are_bitwise_identical(monkeypatch):
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("tag", ["fcc2cubic", "k222", "twist_s211"])
+def test_periodic_image_lists_and_direct_tests_agree(tag, monkeypatch):
+    """The lattice sums walk per-(point, atom) image lists written by the pre-pass (ordered by shell range, nearest image
+    first).  A lane whose list does not fit its PQA_PBC_NW words tests every candidate image directly instead — the path
+    the thread-per-point AO kernel (eval_ao / use_mfma=False) always takes.  Forcing one-word lists (3 entries) sends
+    nearly every lane down the direct path: orbitals from list walks, from direct tests and from the AO kernel must agree
+    to rounding (the order of the image sum differs), for points inside and well outside the cell."""
+    import pyqmc_amd as pa
+
+    sup, mf = helpers.twist_case("s211") if tag == "twist_s211" else helpers.pbc_slater_case(tag)
+    pts = (np.random.default_rng(11).random((1500, 3)) * 4 - 1.5) @ sup.lattice_vectors()
+    rows = {}
+    for nw in ("", "1"):
+        if nw:
+            monkeypatch.setenv("PQA_PBC_NW", nw)
+        dev = pa.generate_wf(sup, mf).fused_device()
+        rows[nw] = [dev.eval_mo(0, pts, nc) for nc in (1, 5)] + ([dev.eval_mo(0, pts, 5, use_mfma=False)] if tag != "twist_s211" else [])
+    for a, b in zip(rows[""], rows["1"]):
+        assert helpers.relerr(a, b) < 1e-13
+    if tag != "twist_s211":  # (the thread-per-point AO kernel is real-only: no twisted lattice sums)
+        assert helpers.relerr(rows[""][1], rows[""][2]) < 1e-13
+
+
 @pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
 def test_periodic_pgradient_matches_reference(tag):
     """pgradient() of a periodic Slater-Jastrow (slater.py:462-542, orbitals.py:239-254): the orbital coefficients are
