@@ -207,6 +207,43 @@ static int check_launch(pqa_handle* h, const char* what) {
   return 0;
 }
 
+// ---------------------------------------------------------------- Voronoi-relevant lattice vectors (min_image)
+// v is relevant iff v/2 is strictly closer to 0 (and v) than to every other lattice point.  Candidates: coefficients in
+// {-2..2}^3 (all relevant vectors of any cell that is not absurdly skewed), tested against the points with coefficients in
+// {-4..4}^3.  One of each +- pair; three-dimensional lattices have at most 7 pairs.
+static int voronoi_vectors(const double* a, PbcDev& P) {
+  P.nvor = 0;
+  for (int q = 0; q < 7; ++q) { P.vor[q][0] = P.vor[q][1] = P.vor[q][2] = 0.0; P.vorh[q] = 1.0; }  // padding: never violated
+  auto vec = [&](int i, int j, int k, double* v) {
+    for (int c = 0; c < 3; ++c) v[c] = i * a[c] + j * a[3 + c] + k * a[6 + c];
+  };
+  for (int i = -2; i <= 2; ++i)
+    for (int j = -2; j <= 2; ++j)
+      for (int k = -2; k <= 2; ++k) {
+        if (i < 0 || (i == 0 && (j < 0 || (j == 0 && k <= 0)))) continue;  // one of each pair, not the origin
+        double v[3];
+        vec(i, j, k, v);
+        const double half = 0.5 * std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        bool relevant = true;
+        for (int p = -4; p <= 4 && relevant; ++p)
+          for (int q = -4; q <= 4 && relevant; ++q)
+            for (int r = -4; r <= 4; ++r) {
+              if ((p == 0 && q == 0 && r == 0) || (p == i && q == j && r == k)) continue;
+              double u[3];
+              vec(p, q, r, u);
+              const double d = std::sqrt((0.5 * v[0] - u[0]) * (0.5 * v[0] - u[0]) + (0.5 * v[1] - u[1]) * (0.5 * v[1] - u[1]) +
+                                         (0.5 * v[2] - u[2]) * (0.5 * v[2] - u[2]));
+              if (d <= half * (1.0 + 1e-9)) { relevant = false; break; }
+            }
+        if (!relevant) continue;
+        if (P.nvor >= 7) return 1;
+        for (int c = 0; c < 3; ++c) P.vor[P.nvor][c] = v[c];
+        P.vorh[P.nvor] = 2.0 * half * half;  // |v|^2 / 2
+        ++P.nvor;
+      }
+  return P.nvor >= 3 ? 0 : 1;
+}
+
 // ---------------------------------------------------------------- phase-1 cost model of the shells
 // One evaluation of a shell costs a radial part per primitive and an angular part / tile stores per function.  An open
 // system evaluates every shell once per point.  A periodic one evaluates it once per image inside the SHELL's cut-off — the
@@ -450,6 +487,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
     if (!(fabs(det) > 1e-12)) FAIL("singular lattice");
     for (int i = 0; i < 9; ++i) P.lat[i] = a[i];
+    if (S.pbc == 2 && voronoi_vectors(a, P)) FAIL("could not determine the Voronoi-relevant vectors of the lattice");
     const double id = 1.0 / det;  // inverse by cofactors: linv[r][c] = cof(c,r) / det
     P.linv[0] = (a[4] * a[8] - a[5] * a[7]) * id; P.linv[1] = (a[2] * a[7] - a[1] * a[8]) * id; P.linv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
     P.linv[3] = (a[5] * a[6] - a[3] * a[8]) * id; P.linv[4] = (a[0] * a[8] - a[2] * a[6]) * id; P.linv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
