@@ -46,6 +46,7 @@ struct pqa_handle {
   int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
+  bool tm_pre = true;   // T-move ratios of all candidates in one thread-per-candidate launch (PQA_TM_PRE=0: wave-per-walker loop only)
   int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
@@ -73,7 +74,7 @@ struct pqa_handle {
   DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
   DevBuf b_alt_x, b_alt_T[2], b_alt_dsign[2], b_alt_dlog[2], b_alt_cache[2], b_alt_aval, b_alt_bval, b_alt_j3u, b_rsidx;  // pqa_resample's other halves
   // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth;
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth, b_tmuold;
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
@@ -468,6 +469,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   // k_orb_wide: 1024 threads (64 lane groups) per 16-point tile; twisted cells need > 128 registers per thread: 512.  Untwisted
   // periodic cells fit 128 since the lattice sums accumulate in the tile: C5 +3 % at 1024-8192 walkers over 512 threads.
   h->wide_nth = (sys->pbc && h->twist) ? 512 : 1024;
+  if (const char* e = getenv("PQA_TM_PRE")) h->tm_pre = atoi(e) != 0;
   if (const char* e = getenv("PQA_WIDE_NTH")) { if (sys->pbc && atoi(e) == 512) h->wide_nth = 512; }
   if (h->twist && !(h->cplx && sys->pbc && sys->nL > 0)) FAIL("twisted boundary conditions need pbc, complex_orbitals and the periodic orbital tables");
   if (h->cplx && ((sys->nmo_up | sys->nmo_dn) & 1)) FAIL("complex orbitals: nmo_up / nmo_dn count the real columns [Re C | Im C] and must be even");
@@ -758,7 +760,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth, &h->b_tmuold};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& d : h->dm)
@@ -2291,9 +2293,22 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
             TRY(ensure(h, h->b_emo[s], (size_t)cnt_s[s] * nmo_max * sizeof(double)));
             TRY(launch_orb(h, s, plain_points(B.pts + 3 * base_s[s], cnt_s[s]), cnt_s[s], 1, (double*)h->b_emo[s].p));
           }
+        // ratios of all candidates against the state before the first T-move: one thread per candidate (k_tm_ratio)
+        const bool pre = h->ndet == 1 && !h->has_j3 && !h->cplx && h->tm_pre;
+        if (pre && h->has_jastrow) {
+          TRY(ensure(h, h->b_tmuold, (size_t)NW * sizeof(double)));
+          hipLaunchKernelGGL(k_tm_uold, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
+        }
+        if (pre)
+          for (int s = 0; s < 2; ++s) {
+            if (cnt_s[s] == 0) continue;
+            const dim3 g((unsigned)((cnt_s[s] + 255) / 256));
+            hipLaunchKernelGGL(k_tm_ratio, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater, (int)h->has_jastrow,
+                               (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, (const double*)h->b_tmuold.p);
+          }
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
         hipLaunchKernelGGL(k_tm_walker, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                           (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W);
+                           (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, pre ? 1 : 0);
         TRY(check_launch(h, "k_tm_walker"));
         TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
         hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);

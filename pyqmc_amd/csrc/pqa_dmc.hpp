@@ -179,6 +179,140 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
   }
 }
 
+// Ratios of ALL T-move candidates against the state at the start of the T-move phase, one THREAD per candidate (single
+// determinant, two-body Jastrow, real orbitals): the wave-per-walker loop of k_tm_walker spent ~35 us per candidate on
+// dependent loads and wave reductions — 2.1 ms of a 19 ms step at 4096 walkers for ~60 candidates per walker — where this
+// kernel takes < 1 ns per candidate in aggregate.  The ratios stay valid for a walker until one of its T-moves is accepted
+// (0.3 % of the electrons per step); from there on k_tm_walker recomputes that walker's ratios against the updated state.
+// mo: [npts][nmo_s] orbital values of this spin's candidates, p_base: their first candidate.
+// Psi(candidate p of electron e, walker w) / Psi by ONE thread: the candidate's orbital row against row e of the inverse,
+// and the two-body Jastrow sums at the candidate and at the electron's position (u_old < 0: computed here too).
+__device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const SlaterState& st, const JastrowState& js, const TmBuf& B, int s, int e,
+                                                    long w, long p, const double* __restrict__ row, int has_slater, int has_jastrow,
+                                                    bool have_uold, double u_old) {
+  const int n = s ? S.ndn : S.nup, i = e - s * S.nup;
+  double ratio = 1.0;
+  if (has_slater) {
+    const double* Ti = st.T[s] + ((size_t)w * n + i) * n;
+    const int* occ = S.det_occ[s];
+    double r = 0.0;
+    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[k];
+    ratio = r;
+  }
+  if (has_jastrow) {
+    const double* xw = js.x + (size_t)w * S.nelec * 3;
+    const double nx = B.pts[3 * p], ny = B.pts[3 * p + 1], nz = B.pts[3 * p + 2];
+    const double ox = xw[3 * e], oy = xw[3 * e + 1], oz = xw[3 * e + 2];
+    const int edown = e >= S.nup;
+    const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+    auto norm = [&](double dx, double dy, double dz) {
+      min_image(S, dx, dy, dz);
+      return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    auto u_b = [&](double rn, int col) {
+      double u = 0.0;
+      if (rn < S.rcut_b) {
+        const RadShared sh = rad_shared<0>(rn, irb);
+        for (int l = 0; l < S.nb; ++l) {
+          double v, g, lp;
+          rad_fn<0>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, g, lp);
+          u += S.bcoeff[l * 3 + col] * v;
+        }
+      }
+      return u;
+    };
+    auto u_a = [&](double rn, int I) {
+      double u = 0.0;
+      if (rn < S.rcut_a) {
+        const RadShared sh = rad_shared<0>(rn, ira);
+        for (int k = 0; k < S.na; ++k) {
+          double v, g, lp;
+          rad_fn<0>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, g, lp);
+          u += S.acoeff[(I * S.na + k) * 2 + edown] * v;
+        }
+      }
+      return u;
+    };
+    double un = 0.0, uo = 0.0;
+    for (int j = 0; j < S.nelec; ++j) {
+      if (j == e) continue;
+      const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
+      const int col = edown + (j >= S.nup);
+      un += u_b(norm(nx - jx, ny - jy, nz - jz), col);
+      if (!have_uold) uo += u_b(norm(ox - jx, oy - jy, oz - jz), col);
+    }
+    for (int I = 0; I < S.natom; ++I) {
+      const double ax = S.atom_xyz[3 * I], ay = S.atom_xyz[3 * I + 1], az = S.atom_xyz[3 * I + 2];
+      un += u_a(norm(nx - ax, ny - ay, nz - az), I);
+      if (!have_uold) uo += u_a(norm(ox - ax, oy - ay, oz - az), I);
+    }
+    ratio *= exp(un - (have_uold ? u_old : uo));
+  }
+  return ratio;
+}
+
+// U_e at the CURRENT position of every (electron, walker) that has candidates: -log of the denominator all of its candidates
+// share (computed once here instead of once per candidate).  uold: [N][W].  grid = (ceil(W/256), N), block = 256.
+__global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBuf B, long W, double* __restrict__ uold) {
+  const long w = (long)blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y;
+  if (w >= W || B.cnt[(size_t)e * W + w] == 0) return;
+  const double* xw = js.x + (size_t)w * S.nelec * 3;
+  const double ox = xw[3 * e], oy = xw[3 * e + 1], oz = xw[3 * e + 2];
+  const int edown = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  double uo = 0.0;
+  for (int j = 0; j < S.nelec; ++j) {
+    if (j == e) continue;
+    double dx = ox - xw[3 * j], dy = oy - xw[3 * j + 1], dz = oz - xw[3 * j + 2];
+    min_image(S, dx, dy, dz);
+    const double rn = sqrt(dx * dx + dy * dy + dz * dz);
+    if (rn < S.rcut_b) {
+      const RadShared sh = rad_shared<0>(rn, irb);
+      const int col = edown + (j >= S.nup);
+      double u = 0.0;
+      for (int l = 0; l < S.nb; ++l) {
+        double v, g, lp;
+        rad_fn<0>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, g, lp);
+        u += S.bcoeff[l * 3 + col] * v;
+      }
+      uo += u;
+    }
+  }
+  for (int I = 0; I < S.natom; ++I) {
+    double dx = ox - S.atom_xyz[3 * I], dy = oy - S.atom_xyz[3 * I + 1], dz = oz - S.atom_xyz[3 * I + 2];
+    min_image(S, dx, dy, dz);
+    const double rn = sqrt(dx * dx + dy * dy + dz * dz);
+    if (rn < S.rcut_a) {
+      const RadShared sh = rad_shared<0>(rn, ira);
+      double u = 0.0;
+      for (int k = 0; k < S.na; ++k) {
+        double v, g, lp;
+        rad_fn<0>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, g, lp);
+        u += S.acoeff[(I * S.na + k) * 2 + edown] * v;
+      }
+      uo += u;
+    }
+  }
+  uold[(size_t)e * W + w] = uo;
+}
+
+__global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int s, int has_slater, int has_jastrow,
+                                                  const double* __restrict__ mo, long p_base, long npts, long W, const double* __restrict__ uold) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= npts) return;
+  const long p = p_base + q, w = B.ptw[p];
+  int lo = s ? S.nup : 0, hi = (s ? S.nelec : S.nup) - 1;  // the candidate's electron: off is electron-major and ascending
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (B.off[(size_t)mid * W + w] <= p) lo = mid; else hi = mid - 1;
+  }
+  const double ratio = tm_candidate_ratio(S, st, js, B, s, lo, w, p, mo + (size_t)q * S.nmo[s], has_slater, has_jastrow, has_jastrow != 0,
+                                          has_jastrow ? uold[(size_t)lo * W + w] : 0.0);
+  B.rat[p] = ratio;
+  B.amp[p] = ratio * B.wgt[p];
+}
+
 // The sequential part of the T-move phase, for ALL electrons of one walker in one block: walkers are independent, so
 // nothing forces a launch per electron (64 x 2 launches of latency-bound kernels were 8-11 % of a DMC step); a walker has
 // candidates for ~2-3 of its 64 electrons, the rest cost one offset compare.  Per electron e with candidates:
@@ -192,11 +326,12 @@ __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf
 //   refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
 // mo_up / mo_dn: [ncand of the spin][nmo_s] orbital values; tot_up: first spin-down candidate.  grid = W, block = 64.
 __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, JastrowState js, TmBuf B, int has_slater, int has_jastrow,
-                                                  const double* __restrict__ mo_up, const double* __restrict__ mo_dn, long tot_up, long W) {
+                                                  const double* __restrict__ mo_up, const double* __restrict__ mo_dn, long tot_up, long W, int precomputed) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   double* xw = js.x + (size_t)w * S.nelec * 3;
+  bool fresh = precomputed != 0;  // B.rat / B.amp hold this walker's ratios (k_tm_ratio) until one of its T-moves is accepted
   for (int e = 0; e < S.nelec; ++e) {
     const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
     const int n = (int)(p1 - p0);
@@ -204,8 +339,16 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
     const int s = e >= S.nup, nmo = S.nmo[s];
     const double* mo = s ? mo_dn : mo_up;
     const long p_base = s ? tot_up : 0;
+    const bool fast = fresh && n <= 64;  // ratios from k_tm_ratio, one candidate per lane
     double U0 = 0.0, g[3], lp;
-    if (has_jastrow) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
+    if (has_jastrow && !fast) jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off);
+    // candidate q's ratio and amplitude stay in lane q's registers (the ratio loop leaves them wave-uniform): the heat-bath
+    // sums below used to re-read them from global memory one dependent load at a time, 3 n round trips per electron
+    const bool in_regs = n <= 64;
+    double my_rat = 1.0, my_amp = 0.0, my_wgt = 0.0;
+    if (fast) {
+      if (lane < n) { my_rat = B.rat[p0 + lane]; my_amp = B.amp[p0 + lane]; my_wgt = B.wgt[p0 + lane]; }
+    } else
     for (long p = p0; p < p1; ++p) {
       double rat = 1.0;
       if (has_slater) {
@@ -218,12 +361,18 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
         jas_eval<0>(S, xw, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], U, g, lp, 3, lds + S.j3_off);
         rat *= exp(U - U0);
       }
-      if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * B.wgt[p]; }
+      const double wg = B.wgt[p];
+      if (lane == (int)(p - p0)) { my_rat = rat; my_wgt = wg; my_amp = rat * wg; }
+      if (lane == 0) { B.rat[p] = rat; B.amp[p] = rat * wg; }
     }
+    // values of candidate q as seen by lane 0: register of lane q (or global memory for more than 64 candidates)
+    auto amp_of = [&](int q) { return in_regs ? __shfl(my_amp, q, 64) : B.amp[p0 + q]; };
+    auto rat_of = [&](int q) { return in_regs ? __shfl(my_rat, q, 64) : B.rat[p0 + q]; };
+    auto wgt_of = [&](int q) { return in_regs ? __shfl(my_wgt, q, 64) : B.wgt[p0 + q]; };
     int sel = n, acc = 0;
-    if (lane == 0) {
+    {  // (all lanes run the loops so that the shuffles are convergent; lane 0's results are the ones used)
       double norm = 1.0;
-      for (long p = p0; p < p1; ++p) norm += fmax(B.amp[p], 0.0);
+      for (int q = 0; q < n; ++q) norm += fmax(amp_of(q), 0.0);
       double u1, u2;
       if (B.u1) { u1 = B.u1[(size_t)e * W + w]; u2 = B.u2[(size_t)e * W + w]; }
       else {
@@ -233,21 +382,22 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
       }
       sel = 0;
       double cdf = 0.0;
-      for (long p = p0; p < p1; ++p) {
-        cdf += fmax(B.amp[p], 0.0) / norm;
+      for (int q = 0; q < n; ++q) {
+        cdf += fmax(amp_of(q), 0.0) / norm;
         if (cdf < u1) ++sel;
       }
       if (sel < n) {
-        const double rr = 1.0 / B.rat[p0 + sel];
+        const double rr = 1.0 / rat_of(sel);
         double back = 1.0;
-        for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * B.wgt[p0 + q] : B.amp[p0 + q] * rr, 0.0);
+        for (int q = 0; q < n; ++q) back += fmax((q == sel) ? rr * wgt_of(q) : amp_of(q) * rr, 0.0);
         acc = norm / back > u2;
       }
-      B.acc[(size_t)e * W + w] = acc;
+      if (lane == 0) B.acc[(size_t)e * W + w] = acc;
     }
     acc = __shfl(acc, 0, 64);
     sel = __shfl(sel, 0, 64);
     if (!acc) continue;
+    fresh = false;
     __syncthreads();
     if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
     if (lane == 0) {
