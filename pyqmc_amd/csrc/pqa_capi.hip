@@ -47,6 +47,7 @@ struct pqa_handle {
   int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
   int na = 0, nb = 0, necp = 0;
   bool tm_pre = true;   // T-move ratios of all candidates in one thread-per-candidate launch (PQA_TM_PRE=0: wave-per-walker loop only)
+  bool aos_stale = false;  // the lane-per-walker planes hold the live state; the walker-major arrays are converted back on demand (sync_aos)
   int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
@@ -159,6 +160,9 @@ struct pqa_handle {
     int rc_ = (x);      \
     if (rc_) return rc_; \
   } while (0)
+
+struct pqa_handle;
+static int sync_aos(pqa_handle* h);
 
 static int ensure(pqa_handle* h, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap && b.p) return 0;
@@ -1160,6 +1164,7 @@ static int slater_value_dev(pqa_handle* h) {
 }
 
 extern "C" int pqa_slater_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater) FAIL("handle has no Slater factor");
   if (!h->has_jastrow || h->W != W) {
@@ -1181,6 +1186,7 @@ extern "C" int pqa_slater_recompute(pqa_handle_t* h, const double* configs, int6
 }
 
 extern "C" int pqa_slater_value(pqa_handle_t* h, double* sign, double* logabs) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   TRY(slater_value_dev(h));
@@ -1190,6 +1196,7 @@ extern "C" int pqa_slater_value(pqa_handle_t* h, double* sign, double* logabs) {
 
 extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
                                int ncomp, int keep_saved, double* out) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
@@ -1234,6 +1241,7 @@ extern "C" int pqa_slater_eval(pqa_handle_t* h, int e, const double* pts, int64_
 
 extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, const double* pts, int64_t nrow, const int32_t* widx,
                                   int factors, double* out) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (nrow <= 0 || ne <= 0) return 0;
@@ -1277,6 +1285,7 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
 }
 
 extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn) {
+  TRY(sync_aos(h));
   if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
@@ -1309,6 +1318,7 @@ extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo
 }
 
 extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   TRY(ensure(h, h->b_flag, sizeof(int)));
@@ -1320,6 +1330,7 @@ extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
 }
 
 extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
@@ -1347,6 +1358,7 @@ extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, con
 }
 
 extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, double* dets) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   const size_t W = h->W, D = h->ndet_s[spin], n = spin ? h->ndn : h->nup;
@@ -1372,6 +1384,7 @@ extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, 
 
 // ---------------------------------------------------------------- Jastrow
 extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2) FAIL("handle has no two-body Jastrow factor");
   if (h->W != W) TRY(ensure_walkers(h, W));
@@ -1383,6 +1396,7 @@ extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int
 }
 
 extern "C" int pqa_jastrow_value(pqa_handle_t* h, double* logval) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   TRY(jas_refresh(h));
@@ -1418,11 +1432,13 @@ static int jastrow_eval_parts(pqa_handle_t* h, int parts, int e, const double* p
 
 extern "C" int pqa_jastrow_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx,
                                 int mode, double* out) {
+  TRY(sync_aos(h));
   return jastrow_eval_parts(h, 1, e, pts, nrow, npt, widx, mode, out);
 }
 
 extern "C" int pqa_j3_eval(pqa_handle_t* h, int e, const double* pts, int64_t nrow, int npt, const int32_t* widx, int mode,
                            double* out) {
+  TRY(sync_aos(h));
   return jastrow_eval_parts(h, 2, e, pts, nrow, npt, widx, mode, out);
 }
 
@@ -1432,6 +1448,7 @@ static int j3_value_dev(pqa_handle* h) {
 }
 
 extern "C" int pqa_j3_value(pqa_handle_t* h, double* logval) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
   TRY(j3_value_dev(h));
@@ -1439,6 +1456,7 @@ extern "C" int pqa_j3_value(pqa_handle_t* h, double* logval) {
 }
 
 extern "C" int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
   const long W = h->W;
@@ -1453,6 +1471,7 @@ extern "C" int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff) {
 }
 
 extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3) FAIL("handle has no three-body Jastrow factor");
   if (h->has_j2 && h->W == W) {  // the two-body factor owns the stored coordinates: evaluate from a scratch copy
@@ -1471,6 +1490,7 @@ extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t 
 }
 
 extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
@@ -1490,6 +1510,7 @@ extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const u
 }
 
 extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
@@ -1509,6 +1530,7 @@ extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, co
 }
 
 extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   TRY(jas_refresh(h));
@@ -1548,6 +1570,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
 }
 
 extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   TRY(ensure_walkers(h, W));
   h->jas_stale = false;
@@ -1561,6 +1584,7 @@ extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t 
 }
 
 extern "C" int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   return wf_value_host(h, sign, logabs);
@@ -1613,6 +1637,17 @@ static int lw_to_aos(pqa_handle* h, bool with_cache) {
     if (with_cache) transpose(h, (const double*)h->b_ct[s].p, h->st.cache[s], n * 5 * h->nmo[s], W);
   }
   return check_launch(h, "k_transpose");
+}
+
+// A fused call on the lane-per-walker kernels leaves the live state in the SoA planes and only marks the walker-major arrays
+// stale: back-to-back fused calls (the blocks of a VMC run) then skip both layout conversions (~13 GB of traffic per call at
+// 65536 walkers of the 64-electron system, 7 ms), and whoever needs the walker-major state — every protocol entry, the
+// energy entry, branching — converts it back first.
+static int sync_aos(pqa_handle* h) {
+  if (!h || !h->aos_stale) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  h->aos_stale = false;
+  return lw_to_aos(h, true);
 }
 
 static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
@@ -1788,6 +1823,7 @@ extern "C" int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap) {
 }
 
 extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   h->saved_valid = false;
@@ -1864,8 +1900,9 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   c.nmax = std::max(h->nup, h->ndn);
   const int kb = h->lw_kb < 0 ? (c.nmax >= 16 ? 4 : 0) : h->lw_kb;
   c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
+  if (!lw) TRY(sync_aos(h));
   if (lw) {
-    TRY(lw_from_aos(h));
+    if (!h->aos_stale) TRY(lw_from_aos(h));  // (stale walker-major arrays: the planes ARE the state)
     const size_t cf = h->cplx ? 2 : 1;
     TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 12 * W * sizeof(double)));
     TRY(ensure(h, h->b_rbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
@@ -2029,7 +2066,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       TRY(check_launch(h, "k_row_means"));
     }
   }
-  if (lw) TRY(lw_to_aos(h, true));
+  h->aos_stale = lw;  // converted back on demand (sync_aos)
   h->jas_stale = h->has_j2;
   std::vector<int> cnt(nsteps);
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));
@@ -2060,6 +2097,7 @@ static int gather_swap(pqa_handle* h, DevBuf& cur, DevBuf& alt, const int* d_idx
   return 0;
 }
 extern "C" int pqa_resample(pqa_handle_t* h, const int32_t* newinds) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (!newinds) FAIL("pqa_resample: newinds must not be NULL");
@@ -2104,6 +2142,7 @@ extern "C" int pqa_resample(pqa_handle_t* h, const int32_t* newinds) {
 // ---------------------------------------------------------------- distributed branching (one walker exchange per block)
 // dst row k <- src row idx[k] for k < n (k_gather_rows with a destination that is NOT one of the handle's buffers)
 extern "C" int pqa_get_walkers(pqa_handle_t* h, const int32_t* idx, int64_t n, double* out) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (n <= 0) return 0;
@@ -2151,6 +2190,7 @@ static int recompute_range(pqa_handle* h, long w0, long n) {
 }
 
 extern "C" int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int64_t nkeep, const double* recv_x, int64_t nrecv) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (nkeep < 0 || nrecv < 0 || nkeep + nrecv != h->W) FAIL("pqa_branch_exchange: kept + received walkers must equal the resident count");
@@ -2181,6 +2221,7 @@ static int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long
 // fixed-node rejection, local energy, weight update, weighted step averages.  Walker-per-wave kernels (the AoS state).
 extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double branchcut, double e_trial, double e_est, double threshold,
                              double* weights, const pqa_dmc_tapes_t* tp, uint64_t seed, double* step_avg, double* step_acc) {
+  TRY(sync_aos(h));  // (the starting energy and the first T-moves read the walker-major state)
   HIPCHK(hipSetDevice(h->device));
   if (h->cplx) FAIL("pqa_dmc_steps: complex orbitals are not implemented (fixed-phase DMC runs through the protocol entry points)");
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
@@ -2363,6 +2404,7 @@ extern "C" int pqa_tmove_npoints(pqa_handle_t* h) { return h->tm_P; }
 
 extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif,
                           double* ratio, double* weight, double* pos) {
+  TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   if (h->W == 0) FAIL("state not initialised (call recompute)");
