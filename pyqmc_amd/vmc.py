@@ -33,7 +33,15 @@ def _fusable(wf, accumulators):
     return dev if dev is not None and all(isinstance(a, EnergyAccumulator) for a in accumulators.values()) else None
 
 
-def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None, seed=None):
+def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None, seed=None, state_current=False, fetch_configs=True):
+    """One block of ``nsteps`` sweeps (mc.py:102-153): returns (block averages, configs).
+
+    ``state_current`` / ``fetch_configs`` are for block loops on the fused device path (``vmc`` below): the reference's worker
+    is a function of (wf, configs) and so recomputes the wave function from ``configs`` on entry and hands the walkers back
+    on exit — 100 MB each way over PCIe plus a full recompute per block at 65536 walkers of the 64-electron system.  A caller
+    that knows the device already holds the state of ``configs`` (it ran the previous block and touched nothing since) passes
+    ``state_current=True``; one that does not need the walkers on the host after this block passes ``fetch_configs=False``
+    (open systems only: periodic containers also carry the block's wrap counters)."""
     dev = _fusable(wf, accumulators) if fused in (None, True) else None
     if fused is True and dev is None:
         raise TypeError("fused VMC needs a pyqmc_amd wave function on one device handle and EnergyAccumulator only")
@@ -42,7 +50,8 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     tapes = tapes or {}
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
-    wf.recompute(configs)
+    if not state_current:
+        wf.recompute(configs)
     block_avg = {}
     thr = next(iter(accumulators.values())).threshold if accumulators else 10.0
     if dev.pbc and accumulators:
@@ -61,6 +70,8 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     # the fused kernel interleaves moves and energy; report the split the reference reports as one number each
     block_avg["move time"] = (t1 - t0) / nsteps
     block_avg["accumulator time"] = 0.0
+    if not fetch_configs and not dev.pbc:
+        return block_avg, configs  # (stale on the host until a later block fetches them)
     if getattr(dev, "twisted", False):  # the handle keeps true (unfolded) coordinates: fold them back into the container
         from .configs import enforce_pbc
 
@@ -108,7 +119,7 @@ def _vmc_worker_protocol(wf, configs, tstep, nsteps, accumulators):
 
 
 def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=None, verbose=False, seed=None, fused=None,
-        hdf_file=None, continue_from=None):
+        hdf_file=None, continue_from=None, recompute_every=10):
     """Block loop of ``pyqmc.method.mc.vmc`` (mc.py:176-274): returns (dict of arrays over the blocks run, configs).
     ``hdf_file``: block output in the reference's on-disk layout (``pyqmc_amd.blockfile``: HDF5 when h5py exists, NumPy
     archives otherwise); an existing file — or ``continue_from`` — restarts from its walkers at ``block[-1] + 1``, and
@@ -128,9 +139,17 @@ def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=No
         first = source.last_block() + 1
         source.load_walkers(configs)
     df = {}
+    dev = _fusable(wf, accumulators) if fused in (None, True) else None
+    current = False  # the device holds the wave-function state of the walkers it moved in the previous block
     for block in range(first, nblocks):
+        # fused path: the walkers stay on the device from block to block; the state is rebuilt from the (fetched) walkers every
+        # `recompute_every` blocks to bound the Sherman-Morrison round-off, and the host copy is refreshed when a block is
+        # written to disk, before such a rebuild, and at the end
+        rebuild_next = dev is not None and (block + 1 - first) % recompute_every == 0
+        fetch = out is not None or block == nblocks - 1 or rebuild_next
         blk, configs = vmc_worker(wf, configs, tstep, nsteps_per_block, accumulators, fused=fused,
-                                  seed=None if seed is None else seed + block)
+                                  seed=None if seed is None else seed + block, state_current=current, fetch_configs=fetch)
+        current = dev is not None and not rebuild_next
         blk["block"] = block
         blk["nconfig"] = nsteps_per_block * configs.configs.shape[0]
         if out is not None:

@@ -556,6 +556,34 @@ def test_wave_function_copy_and_pickle_rebuild_an_independent_handle():
         wf.recompute(cfg)
 
 
+@pytest.mark.parametrize("periodic", [False, True])
+def test_vmc_block_loop_keeps_the_walkers_on_the_device(periodic):
+    """pa.vmc keeps walkers and wave-function state on the device from block to block (no recompute from the host copy, no
+    per-block download for open systems) and rebuilds the state every `recompute_every` blocks.  Same seeds => the run must
+    reproduce the block-by-block rebuild (recompute_every=1, the reference's worker semantics) up to Sherman-Morrison
+    round-off: identical decisions, energies and final walkers to 1e-9."""
+    import pyqmc_amd as pa
+
+    runs = {}
+    for every in (1, 3, 100):
+        if periodic:
+            mol, wf = helpers.gpu_pbc_wf("fcc2cubic")
+        else:
+            mol = systems.water()
+            wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+        cfg = pa.initial_guess(mol, 40, rng=np.random.default_rng(3))
+        acc = {"energy": pa.EnergyAccumulator(mol, seed=11)}
+        runs[every] = pa.vmc(wf, cfg, nblocks=5, nsteps_per_block=3, tstep=0.3, accumulators=acc, seed=21, recompute_every=every)
+    df1, c1 = runs[1]
+    for every in (3, 100):
+        df, c = runs[every]
+        assert np.array_equal(df["acceptance"], df1["acceptance"])
+        assert relerr(df["energytotal"], df1["energytotal"]) < 1e-9
+        assert np.max(np.abs(c.configs - c1.configs)) < 1e-9
+        if periodic:
+            assert np.array_equal(c.wrap, c1.wrap)
+
+
 def test_vmc_and_dmc_write_the_reference_layout(tmp_path):
     """vmc(hdf_file=...) and rundmc(hdf_file=...) write what the reference's loops write (golden g27: names, shapes,
     dtype kinds; mc.py:92-99, dmc.py:379-391) — through the NumPy-archive back end here (no HDF5 library in the image) — and
