@@ -1717,7 +1717,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
     B.has_j2 = h->has_j2 ? 1 : 0;
-    hipLaunchKernelGGL(k_ecp_count, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+    if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+    else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, W);
     TRY(check_launch(h, "k_ecp_count/k_scan2"));
     long tot[2];
@@ -1738,7 +1739,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
     }
     if (tot[0] + tot[1] > 0) {
-      hipLaunchKernelGGL(k_ecp_fill, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+      if (h->S.pbc) hipLaunchKernelGGL(k_ecp_fill<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
+      else hipLaunchKernelGGL(k_ecp_fill<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
       TRY(check_launch(h, "k_ecp_fill"));
       if (h->has_slater)
         for (int s = 0; s < 2; ++s)

@@ -264,6 +264,8 @@ __device__ __forceinline__ bool ecp_pass(const SysDev& S, const EcpBuf& B, long 
 // Lanes run over the electrons, the loop over the ECP atoms: the atom (its channel / term tables, its coordinates) is
 // wave-uniform, so the tables come through the scalar cache and the channel loops do not diverge between O and H.
 // passbits[w][k][e-block]: which electrons passed the stochastic mask at atom k (k_ecp_fill walks them atom-major).
+// PBC = false compiles the minimal-image code out: its register demand cost the open-system launches a wave per SIMD.
+template <bool PBC>
 __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, EcpBuf B, long W) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
       bool pass = false;
       if (live) {
         double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
-        min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
+        if (PBC) min_image(S, dx, dy, dz);  // configs.dist.dist_i, eval_ecp.py:95
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         double v[PQA_MAXCHAN], prob;
         int nch;
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, lon
 }
 
 // pass B: emit auxiliary points, per-point weights and electron index.  grid = W, block = 64.
+template <bool PBC>
 __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpBuf B, long W) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
       const int e = eb * 64 + src, ia = S.ecp_atom[k], s = e >= S.nup;
       const double ax = S.atom_xyz[3 * ia], ay = S.atom_xyz[3 * ia + 1], az = S.atom_xyz[3 * ia + 2];
       double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
-      min_image(S, dx, dy, dz);
+      if (PBC) min_image(S, dx, dy, dz);
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
       double v[PQA_MAXCHAN], prob;
       int nch;
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
       double U0 = 0.0;
       if (B.has_j2) {  // once per (electron, atom) entry, by the whole wave, instead of once per point later
         double g_[3], lp_;
-        jas_eval<0>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g_, lp_, 1);
+        jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g_, lp_, 1);
       }
       if (lane < naip) {
         const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
