@@ -449,7 +449,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   PQA_LW 0 wave-per-walker sweep | 1 lane-per-walker (default) | 2 walker-tile kernel, PQA_LW_KB k electrons per
   //   Sherman-Morrison block (0: update every row per move; default 4), PQA_LW_GM g partial-sum groups,
   //   PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation,
-  //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled.
+  //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled,
+  //   PQA_PBC_NW n words (4 image indices each) per (point, atom) image list of the periodic pre-pass (default from the cell;
+  //   1 forces the direct-test fallback: tests), PQA_WIDE_NTH 512 k_orb_wide with 512 threads in untwisted periodic cells,
+  //   PQA_TM_PRE 0 T-move ratios by the wave-per-walker loop only.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
