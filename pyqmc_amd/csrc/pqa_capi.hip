@@ -1903,7 +1903,9 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   while (c.Gm < 16 && (long)c.Gm * W < 4096L * 64) c.Gm *= 2;
   if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 32);
   c.nmax = std::max(h->nup, h->ndn);
-  const int kb = h->lw_kb < 0 ? (c.nmax >= 16 ? 4 : 0) : h->lw_kb;
+  // block size of the delayed Sherman-Morrison update: 4 from 16 electrons per spin (8 flushes at 32), 5 from 24 (7 flushes at 32:
+  // 35.60 -> 35.32 ms per step of the 64-electron benchmark; 6 is slower again — the per-move commit touches KB rows)
+  const int kb = h->lw_kb < 0 ? (c.nmax >= 24 ? 5 : (c.nmax >= 16 ? 4 : 0)) : h->lw_kb;
   c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
   if (!lw) TRY(sync_aos(h));
   if (lw) {
