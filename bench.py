@@ -379,10 +379,10 @@ def main():
             # carries the n - KB rows outside the block through HBM (read + write) plus the block's KB update-vector pairs.
             # Walkers are interleaved in every cache line, so ALL walkers' rows cross HBM: algorithmic bytes per walker.
             kb = int(os.environ.get("PQA_LW_KB", "-1"))
-            kb = 4 if kb < 0 else (n_s if kb == 0 else min(kb, n_s))
-            alg = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s
+            kb = (5 if n_s >= 24 else 4) if kb < 0 else (n_s if kb == 0 else min(kb, n_s))  # the library's default (lw_setup)
+            alg = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s  # = 16 n_s^2 whatever the block size
             ach = alg * W / (c_ms / c_launches * 1e-3) / 1e9
-            flushes_per_step = 2 * (n_s // kb) if kb < n_s else 0
+            flushes_per_step = 2 * -(-n_s // kb) if kb < n_s else 0
             out["roofline_hbm_flush"] = {"bound": "hbm", "kernel": "k_flush_lw (blocked Sherman-Morrison: rows outside the electron block, once per block of KB moves)",
                                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                          "traffic": pmc_kernel("k_flush_lw", W), "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
