@@ -227,9 +227,13 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
 // Twisted cells (TW): the lattice sum sum_L exp(i k_t . L) phi(r - R - L) is complex; one walk over the admitted images
 // accumulates its real and imaginary parts (the shell's values are evaluated once per image and weighted by cos / sin of
 // the image phase) and hands them to sink(m, ...) and sink_im(m, ...).  Untwisted: sink only.
-template <int NCOMP, bool TW = false, class Sink, class SinkIm>
+// ls(j, lx, ly, lz, ph): lattice vector (and, twisted, the (cos, sin) phase) of image j — from the kernel's LDS copy where it has one:
+// the image walk alone (list decode, a per-lane gather of the vector, r^2, the range test) was a third of k_orb<5> and two thirds
+// of k_orb<1> in a periodic cell with the vectors gathered from global memory (compile-time ablation, tools/scratch/abl_pbc.sh).
+template <int NCOMP, bool TW = false, class Sink, class SinkIm, class LsGet>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
-                                               const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im, bool& accumulate) {
+                                               const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im, bool& accumulate,
+                                               LsGet&& ls) {
   // The lattice sum is accumulated where the functions live (the lane's own column of the LDS tile; `accumulate` tells the
   // sinks to add instead of store): 7 x NCOMP running sums in registers — twice that for a twisted cell — were 70 / 140 of
   // the kernel's ~255 registers, pinned it at 2 (twisted: 1) waves per SIMD and spilled.
@@ -243,10 +247,9 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   accumulate = true;
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
-  auto add = [&](double xj, double yj, double zj, int j) {
+  auto add = [&](double xj, double yj, double zj, int j, double cj, double sj) {
     double pr = 1.0, pi = 0.0;
     if (TW) {  // exp(i k_t . (f . lattice + Ls[j])): cos and sin of the summed angle
-      const double cj = S.pb->img_phase[2 * j], sj = S.pb->img_phase[2 * j + 1];
       pr = c.cf * cj - c.sf * sj;
       pi = c.sf * cj + c.cf * sj;
     }
@@ -273,8 +276,10 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
         cur >>= 16;
         if (j == (int)PQA_IMG_END) alive = false;
         else {
-          const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
-          if (xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, j);
+          double lx, ly, lz, cj = 1.0, sj = 0.0;
+          ls(j, lx, ly, lz, cj, sj);
+          const double xj = c.x0 - lx, yj = c.y0 - ly, zj = c.z0 - lz;
+          if (xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, j, cj, sj);
           else alive = false;  // sorted by distance: nothing further can be inside
         }
       }
@@ -285,7 +290,8 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
     for (int j = 0; j < nimg; ++j) {
       const double xj = c.x0 - S.pb->Ls[3 * j], yj = c.y0 - S.pb->Ls[3 * j + 1], zj = c.z0 - S.pb->Ls[3 * j + 2];
       const double r2 = xj * xj + yj * yj + zj * zj;
-      if (c.ovf && r2 <= scut && pbc_image_ok(S, c, j, r2)) add(xj, yj, zj, j);
+      if (c.ovf && r2 <= scut && pbc_image_ok(S, c, j, r2))
+        add(xj, yj, zj, j, TW ? S.pb->img_phase[2 * j] : 1.0, TW ? S.pb->img_phase[2 * j + 1] : 0.0);
     }
   }
   accumulate = false;
@@ -293,7 +299,8 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 template <int NCOMP, class Sink>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
                                                const double* __restrict__ pcoef, int np, Sink&& sink, bool& accumulate) {
-  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink, accumulate);
+  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink, accumulate,
+                               [&](int j, double& lx, double& ly, double& lz, double&, double&) { lx = S.pb->Ls[3 * j]; ly = S.pb->Ls[3 * j + 1]; lz = S.pb->Ls[3 * j + 2]; });
 }
 
 // Pre-pass of a periodic k_orb launch: thread = (point, atom).  Folds the point into the cell, folds point - atom into
@@ -523,6 +530,7 @@ struct ChunkTab {
   int pbc_nw;
 };
 
+#define PQA_LS_MAX 128     // candidate lattice vectors the periodic kernels keep in LDS
 #define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
 #define PQA_WS_MAXP 640
 
@@ -545,7 +553,14 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   __shared__ double sh_xyz[LDSTAB ? PQA_WS_MAXSH : 1][3];
   __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][5];  // l, nprim, first primitive, tile row in chunk, atom
   __shared__ double pr_exp[LDSTAB ? PQA_WS_MAXP : 1], pr_coef[LDSTAB ? PQA_WS_MAXP : 1];
+  __shared__ double sh_Ls[PBC ? PQA_LS_MAX : 1][3], sh_ph[PBC == 2 ? PQA_LS_MAX : 1][2];  // lattice vectors (phases) of the candidate images
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool ls_lds = PBC && S.nL <= PQA_LS_MAX;
+  if (PBC && ls_lds) {
+    for (int q = tid; q < 3 * S.nL; q += 256) sh_Ls[q / 3][q % 3] = S.pb->Ls[q];
+    if (PBC == 2) for (int q = tid; q < 2 * S.nL; q += 256) sh_ph[q / 2][q % 2] = S.pb->img_phase[q];
+    if (!LDSTAB) __syncthreads();
+  }
   if (LDSTAB) {
     for (int sh = tid; sh < S.nshell; sh += 256) {
       const int ia = S.shell_atom[sh];
@@ -582,6 +597,14 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   constexpr int TI = (TP == 64) ? 0 : ((TP == 32) ? 1 : 2);
   const int* __restrict__ cw_off = T.cw_off[TI];
   const int* __restrict__ cw_shell = T.cw_shell[TI];
+  auto ls_from_lds = [&](int j, double& lx, double& ly, double& lz, double& cj, double& sj) {
+    lx = sh_Ls[j][0]; ly = sh_Ls[j][1]; lz = sh_Ls[j][2];
+    if (PBC == 2) { cj = sh_ph[PBC == 2 ? j : 0][0]; sj = sh_ph[PBC == 2 ? j : 0][1]; }
+  };
+  auto ls_from_global = [&](int j, double& lx, double& ly, double& lz, double& cj, double& sj) {
+    lx = S.pb->Ls[3 * j]; ly = S.pb->Ls[3 * j + 1]; lz = S.pb->Ls[3 * j + 2];
+    if (PBC == 2) { cj = S.pb->img_phase[2 * j]; sj = S.pb->img_phase[2 * j + 1]; }
+  };
 
   // gridDim.y > 1: the chunks (the K dimension) are split over that many blocks per point tile, each adding its partial
   // sums to a zeroed output with hardware fp64 atomics — for small launches, where a block's serial chain over the chunks,
@@ -654,8 +677,10 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
               if (NCOMP == 5) tile[4 % NCOMP][k][col] = lp;
             }
           };
-          shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum);
-        } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, accum);
+          if (ls_lds) shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum, ls_from_lds);
+          else shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum, ls_from_global);
+        } else if (ls_lds) shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_from_lds);
+        else shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_from_global);
       } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
@@ -845,8 +870,9 @@ struct WideTab {
   const int* row;     // [nshell] (twisted: [2 nshell], imaginary rows second) first padded tile row of the shell
   int rows_pad;       // K: multiple of 4
 };
-__host__ __device__ inline size_t wide_lds_bytes(int ncomp, int rows_pad, int nshell, int nprim) {
-  return ((size_t)ncomp * rows_pad * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim) * sizeof(double) + (size_t)5 * nshell * sizeof(int);
+// nls: doubles of the periodic kernels' lattice-vector / phase table (5 per candidate image, 0 for open systems)
+__host__ __device__ inline size_t wide_lds_bytes(int ncomp, int rows_pad, int nshell, int nprim, int nls = 0) {
+  return ((size_t)ncomp * rows_pad * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + (size_t)nls) * sizeof(double) + (size_t)5 * nshell * sizeof(int);
 }
 
 // NTH threads: 1024 for open systems (94 VGPRs); periodic lattice sums need > 128 registers (at 1024 threads they spilled
@@ -859,7 +885,23 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
   double* sh_xyz = tile + (size_t)NCOMP * K * 16;     // [nshell][3]
   double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
   double* pr_coef = pr_exp + S.nprim;
-  int* sh_meta = (int*)(pr_coef + S.nprim);           // [nshell][5]: l, nprim, first primitive, tile row, atom
+  const bool ls_lds = PBC && S.nL <= PQA_LS_MAX;
+  double* w_Ls = pr_coef + S.nprim;                   // periodic: [nL][3] lattice vectors, [nL][2] phases
+  double* w_ph = w_Ls + (ls_lds ? 3 * (size_t)S.nL : 0);
+  int* sh_meta = (int*)(w_ph + (ls_lds ? 2 * (size_t)S.nL : 0));  // [nshell][5]: l, nprim, first primitive, tile row, atom
+  if (PBC && ls_lds) {
+    for (int q = threadIdx.x; q < 3 * S.nL; q += NTH) w_Ls[q] = S.pb->Ls[q];
+    if (PBC == 2) for (int q = threadIdx.x; q < 2 * S.nL; q += NTH) w_ph[q] = S.pb->img_phase[q];
+  }
+  auto ls_get = [&](int j, double& lx, double& ly, double& lz, double& cj, double& sj) {
+    if (ls_lds) {
+      lx = w_Ls[3 * j]; ly = w_Ls[3 * j + 1]; lz = w_Ls[3 * j + 2];
+      if (PBC == 2) { cj = w_ph[2 * j]; sj = w_ph[2 * j + 1]; }
+    } else {
+      lx = S.pb->Ls[3 * j]; ly = S.pb->Ls[3 * j + 1]; lz = S.pb->Ls[3 * j + 2];
+      if (PBC == 2) { cj = S.pb->img_phase[2 * j]; sj = S.pb->img_phase[2 * j + 1]; }
+    }
+  };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int sh = tid; sh < S.nshell; sh += NTH) {
     const int ia = S.shell_atom[sh];
@@ -916,8 +958,8 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
             if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] = lp;
           }
         };
-        shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum);
-      } else shell_eval_pbc<NCOMP>(S, ctx, sh, l_, pe, pc, np_, to_tile, accum);
+        shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum, ls_get);
+      } else shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_get);
     } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
   }
   __syncthreads();

@@ -856,7 +856,7 @@ static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
 // whole-K kernel for small 5-component launches (k_orb_wide, pqa_ao.hpp)
 static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
   if (ncomp != 5 || h->orb_wide == 0 || h->wide[tabi].rows_pad <= 0) return false;
-  if (wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim) > (size_t)160 * 1024 - 256) return false;
+  if (wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim, (h->S.pbc && h->S.nL <= PQA_LS_MAX) ? 5 * h->S.nL : 0) > (size_t)160 * 1024 - 256) return false;
   if (h->orb_wide == 1) return true;
   // measured (tools/scratch/ab_wide*.sh, 1 MI355X): (H2O)8 step 6.65 -> 4.73 ms at 1024 walkers, 7.64 -> 5.86 at 4096, 9.08 -> 7.84
   // at 8192, even at 16384, slower at 32768 (one 1024-thread block per CU cannot overlap AO and MFMA phases of different
@@ -869,7 +869,7 @@ static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
 }
 template <int PBCV, int NTH>
 static int launch_orb_wide(pqa_handle* h, const ChunkTab& T, int tabi, int spin, PointAddr pa, long P, double* out) {
-  const size_t lds = wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim);
+  const size_t lds = wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim, (h->S.pbc && h->S.nL <= PQA_LS_MAX) ? 5 * h->S.nL : 0);
   const dim3 grid((unsigned)((P + 15) / 16)), block(NTH);
 #define PQA_WIDE(NT) do { const void* fn = (const void*)k_orb_wide<5, NT, PBCV, NTH>; \
     if (std::find(h->wide_attr.begin(), h->wide_attr.end(), fn) == h->wide_attr.end()) { \
