@@ -92,7 +92,11 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
   for (int p = 0; p < np; ++p) {
     const double a = pexp[p];
     if ((SCREEN || PQA_PRIM_SCREEN) && a * r2 > PQA_PRIM_CUT) continue;
+#ifdef PQA_ABL_NOEXP  // ablation builds only (tools/scratch/abl_pbc.sh): wrong values, kernel timing only
+    const double t = pcoef[p] * (1.0 - 1e-3 * a * r2);
+#else
     const double t = pcoef[p] * exp(-a * r2);
+#endif
     R += t;
     if (NCOMP > 1) dRs += a * t;
     if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
@@ -238,12 +242,14 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   // sinks to add instead of store): 7 x NCOMP running sums in registers — twice that for a twisted cell — were 70 / 140 of
   // the kernel's ~255 registers, pinned it at 2 (twisted: 1) waves per SIMD and spilled.
   accumulate = false;
+#ifndef PQA_ABL_NOZERO
 #pragma unroll
   for (int m = 0; m < 7; ++m)
     if (m < 2 * l + 1) {
       sink(m, 0.0, 0.0, 0.0, 0.0, 0.0);
       if (TW) sink_im(m, 0.0, 0.0, 0.0, 0.0, 0.0);
     }
+#endif
   accumulate = true;
   const int nimg = S.pb->num_Ls[c.ia];
   const double scut = S.pb->shell_cut[sh];
@@ -265,7 +271,11 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   // wave sit anywhere in the cell: iterating over image indices in lock-step would make every lane wait for the union of
   // all lanes' images).  Iterations = max over lanes of the number of images inside the shell's range.
   {
+#ifdef PQA_ABL_NOWALK
+    bool alive = false;
+#else
     bool alive = !c.ovf;
+#endif
     unsigned long long cur = 0ull;
     int k = 0;
     while (__any(alive)) {
@@ -279,7 +289,11 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
           double lx, ly, lz, cj = 1.0, sj = 0.0;
           ls(j, lx, ly, lz, cj, sj);
           const double xj = c.x0 - lx, yj = c.y0 - ly, zj = c.z0 - lz;
+#ifdef PQA_ABL_NOADD
+          if (xj * xj + yj * yj + zj * zj <= scut) { if (xj == 1.2345e300) add(xj, yj, zj, j, cj, sj); }
+#else
           if (xj * xj + yj * yj + zj * zj <= scut) add(xj, yj, zj, j, cj, sj);
+#endif
           else alive = false;  // sorted by distance: nothing further can be inside
         }
       }
