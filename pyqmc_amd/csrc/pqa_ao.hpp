@@ -664,10 +664,10 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
         const int k = kb + m;
         const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
-        if (PBC && accum) {
-          tile[0][k][col] += v;
-          if (NCOMP > 1) { tile[1 % NCOMP][k][col] += gx; tile[2 % NCOMP][k][col] += gy; tile[3 % NCOMP][k][col] += gz; }
-          if (NCOMP == 5) tile[4 % NCOMP][k][col] += lp;
+        if (PBC && accum) {  // (LDS add without return: one LDS operation per value instead of a read and a write; only this lane touches the entry)
+          unsafeAtomicAdd(&tile[0][k][col], v);
+          if (NCOMP > 1) { unsafeAtomicAdd(&tile[1 % NCOMP][k][col], gx); unsafeAtomicAdd(&tile[2 % NCOMP][k][col], gy); unsafeAtomicAdd(&tile[3 % NCOMP][k][col], gz); }
+          if (NCOMP == 5) unsafeAtomicAdd(&tile[4 % NCOMP][k][col], lp);
         } else {
           tile[0][k][col] = v;
           if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
@@ -682,9 +682,9 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
             const int k = kbi + m;
             const int col = (TP >= 32) ? (pl ^ ((k & 1) << 4)) : pl;
             if (accum) {
-              tile[0][k][col] += v;
-              if (NCOMP > 1) { tile[1 % NCOMP][k][col] += gx; tile[2 % NCOMP][k][col] += gy; tile[3 % NCOMP][k][col] += gz; }
-              if (NCOMP == 5) tile[4 % NCOMP][k][col] += lp;
+              unsafeAtomicAdd(&tile[0][k][col], v);
+              if (NCOMP > 1) { unsafeAtomicAdd(&tile[1 % NCOMP][k][col], gx); unsafeAtomicAdd(&tile[2 % NCOMP][k][col], gy); unsafeAtomicAdd(&tile[3 % NCOMP][k][col], gz); }
+              if (NCOMP == 5) unsafeAtomicAdd(&tile[4 % NCOMP][k][col], lp);
             } else {
               tile[0][k][col] = v;
               if (NCOMP > 1) { tile[1 % NCOMP][k][col] = gx; tile[2 % NCOMP][k][col] = gy; tile[3 % NCOMP][k][col] = gz; }
@@ -947,9 +947,9 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
     auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
       double* t = tile + (size_t)(kb + m) * 16 + pl;
       if (PBC && accum) {
-        t[0] += v;
-        if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] += gx; t[(size_t)(2 % NCOMP) * K * 16] += gy; t[(size_t)(3 % NCOMP) * K * 16] += gz; }
-        if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] += lp;
+        unsafeAtomicAdd(t, v);
+        if (NCOMP > 1) { unsafeAtomicAdd(t + (size_t)(1 % NCOMP) * K * 16, gx); unsafeAtomicAdd(t + (size_t)(2 % NCOMP) * K * 16, gy); unsafeAtomicAdd(t + (size_t)(3 % NCOMP) * K * 16, gz); }
+        if (NCOMP == 5) unsafeAtomicAdd(t + (size_t)(4 % NCOMP) * K * 16, lp);
       } else {
         t[0] = v;
         if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
@@ -963,9 +963,9 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
         auto to_tile_im = [&](int m, double v, double gx, double gy, double gz, double lp) {
           double* t = tile + (size_t)(kbi + m) * 16 + pl;
           if (accum) {
-            t[0] += v;
-            if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] += gx; t[(size_t)(2 % NCOMP) * K * 16] += gy; t[(size_t)(3 % NCOMP) * K * 16] += gz; }
-            if (NCOMP == 5) t[(size_t)(4 % NCOMP) * K * 16] += lp;
+            unsafeAtomicAdd(t, v);
+            if (NCOMP > 1) { unsafeAtomicAdd(t + (size_t)(1 % NCOMP) * K * 16, gx); unsafeAtomicAdd(t + (size_t)(2 % NCOMP) * K * 16, gy); unsafeAtomicAdd(t + (size_t)(3 % NCOMP) * K * 16, gz); }
+            if (NCOMP == 5) unsafeAtomicAdd(t + (size_t)(4 % NCOMP) * K * 16, lp);
           } else {
             t[0] = v;
             if (NCOMP > 1) { t[(size_t)(1 % NCOMP) * K * 16] = gx; t[(size_t)(2 % NCOMP) * K * 16] = gy; t[(size_t)(3 % NCOMP) * K * 16] = gz; }
