@@ -307,6 +307,9 @@ def main():
 
         return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=red_dev)[0]
 
+    # three untimed settling steps before the W warm-up steps: the first launches of a process load code objects and find the
+    # clocks low (an evidence run of this round timed 37.3 ms per step right after 2 warm-up steps and 34.6 a minute later)
+    dev.vmc_sweeps(args.tstep, 3, seed=seed + 7, energy=True)
     if not args.no_profile:
         dev.profile_enable(True)  # during the warm-up too: the event pairs are created there, not inside the timed region
     if args.warmup > 0:
