@@ -323,7 +323,8 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // lane group inside k_orb, and in a kernel that is not register-bound.  lst: [natom][NW][P] words.
 #define PQA_PRE_CAP 32   // admitted images per (point, atom) the pre-pass can order (their 4-bit classes fill two words)
 #define PQA_PRE_NT 256
-#define PQA_MAXCLS 15    // distinct shell cut-offs per atom
+#define PQA_MAXCLS 15    // distinct shell cut-offs per atom the tables hold
+#define PQA_PRE_NCUT 10  // ... and the pre-pass handles (cut-offs in registers, class populations packed 6 bits each); more: direct tests
 // Ordering without a sort: a shell only needs the images inside ITS cut-off to come first, and an atom's shells have a
 // handful of distinct cut-offs (five in the diamond basis).  So every admitted image gets the class of the smallest shell
 // cut-off that contains it, and the list is written class by class, with the lane's nearest image moved to the very front
@@ -342,7 +343,6 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
   __shared__ unsigned char s_memb[PQA_PRE_MEMB];
   __shared__ double s_cut[PQA_MAXCLS + 1];
   __shared__ unsigned long long s_w[PQA_PRE_NWMAX][PQA_PRE_NT];   // the list being assembled, one column per thread
-  __shared__ unsigned char s_off[PQA_MAXCLS + 1][PQA_PRE_NT];     // next free position of every class
   const int ia = blockIdx.y, tid = threadIdx.x;
   const int ncls = S.pb->ncls[ia];
   const bool has_member = S.pb->member != nullptr;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
   unsigned long long* out = lst + (size_t)ia * NW * P + p;  // word w at out[w * P]
   const int nimg = S.pb->num_Ls[ia];
   const int nw = min(NW, PQA_PRE_NWMAX), cap = min(4 * nw - 1, PQA_PRE_CAP);
-  if (nimg > 128 || ncls <= 0) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
+  if (nimg > 128 || ncls <= 0 || ncls > PQA_PRE_NCUT) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
   // 1. distance test of every candidate
   unsigned long long m0 = 0ull, m1 = 0ull;
   {
@@ -390,43 +390,67 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
       if (xj * xj + yj * yj + zj * zj <= acut) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
     }
   }
-  // 2. the lane's own few survivors: membership rule, class (4 bits each, packed), nearest; class populations
-  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull;
+  // 2. membership rule: one look-up of the pre-tabulated candidate mask of this (atom class, fold) (create: member_masks), or
+  //    candidate by candidate where there is no table
+  if (has_member) {
+    if (S.pb->memb_mask) {
+      const int E = S.pb->memb_E, T = side + 2 * E;
+      const int i0 = c.b0 + E, i1 = c.b1 + E, i2 = c.b2 + E;
+      if ((unsigned)i0 < (unsigned)T && (unsigned)i1 < (unsigned)T && (unsigned)i2 < (unsigned)T) {
+        const unsigned long long* mm = S.pb->memb_mask + 2 * ((((size_t)S.pb->member_class[ia] * T + i0) * T + i1) * T + i2);
+        m0 &= mm[0]; m1 &= mm[1];
+      } else { m0 = 0ull; m1 = 0ull; }
+    } else {
+      unsigned long long k0 = 0ull, k1 = 0ull, b0_ = m0, b1_ = m1;
+      while (b0_ | b1_) {
+        int j;
+        if (b0_) { j = __ffsll((long long)b0_) - 1; b0_ &= b0_ - 1; }
+        else { j = 64 + __ffsll((long long)b1_) - 1; b1_ &= b1_ - 1; }
+        const int n0 = c.b0 + s_imgn[j][0], n1 = c.b1 + s_imgn[j][1], n2 = c.b2 + s_imgn[j][2];
+        if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
+        const int mi = (n0 * side + n1) * side + n2;
+        if (!(memb_lds ? s_memb[mi] : gmemb[mi])) continue;
+        if (j < 64) k0 |= 1ull << j; else k1 |= 1ull << (j - 64);
+      }
+      m0 = k0; m1 = k1;
+    }
+  }
+  // 3. the lane's own few admitted images: class (4 bits each, packed), nearest, class populations (6 bits each, packed)
+  double cut_r[PQA_PRE_NCUT];
+#pragma unroll
+  for (int q = 0; q < PQA_PRE_NCUT; ++q) cut_r[q] = q < ncls ? s_cut[q] : -1.0;  // (r^2 > -1 always: classes past the last count as "outside")
+  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull, cnt = 0ull;
   int n = 0, jmin = -1, kmin = -1;
   double rmin = 1e300;
   bool over = false;
-  for (int q = 0; q <= ncls; ++q) s_off[q][tid] = 0;
   while (m0 | m1) {
     int j;
     if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
     else { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
-    if (has_member) {  // would the reference have looked at this image?  (pbc_image_ok)
-      const int n0 = c.b0 + s_imgn[j][0], n1 = c.b1 + s_imgn[j][1], n2 = c.b2 + s_imgn[j][2];
-      if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
-      const int mi = (n0 * side + n1) * side + n2;
-      if (!(memb_lds ? s_memb[mi] : gmemb[mi])) continue;
-    }
     const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
     const double r2 = xj * xj + yj * yj + zj * zj;
     int cls = 0;
-    while (cls < ncls && r2 > s_cut[cls]) ++cls;
+#pragma unroll
+    for (int q = 0; q < PQA_PRE_NCUT; ++q) cls += (q < ncls && r2 > cut_r[q]) ? 1 : 0;
     if (cls >= ncls) continue;  // inside the atom's cut-off but outside every shell's
     if (n >= cap) { over = true; break; }
     if (j < 64) a0 |= 1ull << j; else a1 |= 1ull << (j - 64);
     if (n < 16) cl0 |= (unsigned long long)cls << (4 * n); else cl1 |= (unsigned long long)cls << (4 * (n - 16));
-    s_off[cls + 1][tid] += 1;
+    cnt += 1ull << (6 * cls);
     if (r2 < rmin) { rmin = r2; jmin = j; kmin = n; }
     ++n;
   }
   if (over) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
-  // 3. nearest image first, then class by class (index order inside a class): counting scatter into the LDS column
+  // 4. nearest image first, then class by class (index order inside a class): counting scatter into the LDS column
   const int nwords = n / 4 + 1;  // n entries + at least one terminator
   for (int w = 0; w < nwords; ++w) s_w[w][tid] = ~0ull;  // PQA_IMG_END everywhere
   if (n > 0) {
     const int cmin = (int)((kmin < 16 ? cl0 >> (4 * kmin) : cl1 >> (4 * (kmin - 16))) & 15ull);
-    s_off[cmin + 1][tid] -= 1;  // the nearest image leaves its class ...
-    int run = 1;                // ... and takes position 0
-    for (int q = 0; q < ncls; ++q) { const int cnt = s_off[q + 1][tid]; s_off[q][tid] = (unsigned char)run; run += cnt; }
+    cnt -= 1ull << (6 * cmin);  // the nearest image leaves its class ...
+    unsigned long long off = 0ull;  // ... and takes position 0; off: next free position of every class, 6 bits each
+    int run = 1;
+#pragma unroll
+    for (int q = 0; q < PQA_PRE_NCUT; ++q) { off |= (unsigned long long)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63ull); }
     int k = 0;
     while (a0 | a1) {
       int j;
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr 
       else { j = 64 + __ffsll((long long)a1) - 1; a1 &= a1 - 1; }
       const int cj = (int)((k < 16 ? cl0 >> (4 * k) : cl1 >> (4 * (k - 16))) & 15ull);
       int pos = 0;
-      if (k != kmin) { pos = s_off[cj][tid]; s_off[cj][tid] = (unsigned char)(pos + 1); }
+      if (k != kmin) { pos = (int)((off >> (6 * cj)) & 63ull); off += 1ull << (6 * cj); }
       ++k;
       const int sh16 = 16 * (pos & 3);
       s_w[pos >> 2][tid] = (s_w[pos >> 2][tid] & ~(0xFFFFull << sh16)) | ((unsigned long long)j << sh16);

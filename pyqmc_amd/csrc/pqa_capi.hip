@@ -212,6 +212,42 @@ static int check_launch(pqa_handle* h, const char* what) {
   return 0;
 }
 
+// ---------------------------------------------------------------- membership masks (k_pbc_prepass)
+// The reference's image-membership rule asks, for candidate image j of an atom, whether member[class][b + img_n[j]] is set,
+// b being the membership base of the (point, atom) pair (pbc_ctx_base).  Tabulated here for every base in an extended grid
+// (side + 2 E per axis, E = side >= every |img_n|) as a 128-bit mask over the candidates, so that the pre-pass replaces ~10
+// four-load tests per thread by one 16-byte look-up.  315 KB per atom class for M = 4.
+static int member_masks(pqa_handle* h, const pqa_system_t* sys, PbcDev& P) {
+  P.memb_mask = nullptr;
+  P.memb_E = 0;
+  const int side = 2 * sys->member_M + 1, E = side, T = side + 2 * E, nc = sys->n_member_class, nj = std::min(sys->nL, 128);
+  if ((size_t)nc * T * T * T * 16 > ((size_t)64 << 20)) return 0;  // (absurdly large rule: candidate-by-candidate tests)
+  std::vector<unsigned char> mem((size_t)nc * side * side * side);
+  std::vector<int> imgn((size_t)sys->nL * 3);
+  HIPCHK(hipMemcpy(mem.data(), sys->member, mem.size(), hipMemcpyDefault));
+  HIPCHK(hipMemcpy(imgn.data(), sys->img_n, imgn.size() * sizeof(int), hipMemcpyDefault));
+  for (int j = 0; j < nj; ++j)
+    for (int c = 0; c < 3; ++c)
+      if (std::abs(imgn[3 * j + c]) > E) return 0;  // a base outside the grid could still reach a member: no table
+  std::vector<unsigned long long> mask((size_t)nc * T * T * T * 2, 0ull);
+  for (int cl = 0; cl < nc; ++cl)
+    for (int i0 = 0; i0 < T; ++i0)
+      for (int i1 = 0; i1 < T; ++i1)
+        for (int i2 = 0; i2 < T; ++i2) {
+          unsigned long long* m = &mask[2 * ((((size_t)cl * T + i0) * T + i1) * T + i2)];
+          for (int j = 0; j < nj; ++j) {
+            const int n0 = i0 - E + imgn[3 * j], n1 = i1 - E + imgn[3 * j + 1], n2 = i2 - E + imgn[3 * j + 2];
+            if (n0 < 0 || n0 >= side || n1 < 0 || n1 >= side || n2 < 0 || n2 >= side) continue;
+            if (mem[(((size_t)cl * side + n0) * side + n1) * side + n2]) m[j >> 6] |= 1ull << (j & 63);
+          }
+        }
+  unsigned long long* d = nullptr;
+  TRY(upload_table(h, mask.data(), mask.size(), &d));
+  P.memb_mask = d;
+  P.memb_E = E;
+  return 0;
+}
+
 // ---------------------------------------------------------------- Voronoi-relevant lattice vectors (min_image)
 // v is relevant iff v/2 is strictly closer to 0 (and v) than to every other lattice point.  Candidates: coefficients in
 // {-2..2}^3 (all relevant vectors of any cell that is not absurdly skewed), tested against the points with coefficients in
@@ -598,6 +634,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         TRY(upload_table(h, sys->img_n, (size_t)sys->nL * 3, &tmp_i)); P.img_n = tmp_i;
         TRY(upload_table(h, sys->atom_n, (size_t)h->natom * 3, &tmp_i)); P.atom_n = tmp_i;
         P.member_M = sys->member_M;
+        TRY(member_masks(h, sys, P));
         for (int i = 0; i < 9; ++i) {  // supercell matrix = lattice . inv(lattice_prim), must be integer
           double v_ = 0.0;
           for (int k = 0; k < 3; ++k) v_ += sys->lattice[3 * (i / 3) + k] * P.lprim_inv[3 * k + (i % 3)];

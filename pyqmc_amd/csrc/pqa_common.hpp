@@ -28,6 +28,10 @@ struct PbcDev {
   const int* ncls;
   // reference image-membership rule (see include/pyqmc_amd.h): member == nullptr -> every image inside the cut-offs
   const unsigned char* member;
+  // membership of candidate image j for every (atom class, membership base b): masks[class][b0 + E][b1 + E][b2 + E][2] over a
+  // (side + 2 E)^3 grid of bases (create: member_masks); nullptr: no table, test candidate by candidate
+  const unsigned long long* memb_mask;
+  int memb_E;
   const int* member_class;
   const int* img_n;
   const int* atom_n;
