@@ -750,6 +750,30 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     TRY(upload_table(h, sys->ecp_term_n, (size_t)nterm, &tmp_i)); S.ecp_term_n = tmp_i;
     TRY(upload_table(h, sys->ecp_term_exp, (size_t)nterm, &tmp_d)); S.ecp_term_exp = tmp_d;
     TRY(upload_table(h, sys->ecp_term_coef, (size_t)nterm, &tmp_d)); S.ecp_term_coef = tmp_d;
+    {  // range of every ECP atom: r^2 beyond which all of its terms |c| r^n exp(-a r^2) stay below 1e-22 (k_ecp_count visits an
+       // electron's near atoms only; what it leaves out is below the last bit of the local energy and can never pass the mask)
+      std::vector<int> co((size_t)h->necp + 1), to((size_t)nchan + 1), tn((size_t)std::max(nterm, 1));
+      std::vector<double> te(tn.size()), tc(tn.size()), rc2((size_t)std::max(h->necp, 1), 0.0);
+      HIPCHK(hipMemcpy(co.data(), sys->ecp_chan_off, co.size() * sizeof(int), hipMemcpyDefault));
+      HIPCHK(hipMemcpy(to.data(), sys->ecp_term_off, to.size() * sizeof(int), hipMemcpyDefault));
+      if (nterm > 0) {
+        HIPCHK(hipMemcpy(tn.data(), sys->ecp_term_n, (size_t)nterm * sizeof(int), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(te.data(), sys->ecp_term_exp, (size_t)nterm * sizeof(double), hipMemcpyDefault));
+        HIPCHK(hipMemcpy(tc.data(), sys->ecp_term_coef, (size_t)nterm * sizeof(double), hipMemcpyDefault));
+      }
+      for (int k = 0; k < h->necp; ++k) {
+        double rc = 0.0;
+        for (int t = to[co[k]]; t < to[co[k + 1]]; ++t) {
+          if (tc[t] == 0.0) continue;
+          if (!(te[t] > 0.0)) { rc = 1e150; break; }  // no decay: never out of range
+          double r = 60.0;  // walk inwards until the term is visible
+          while (r > 0.02 && fabs(tc[t]) * std::pow(r, (double)tn[t]) * std::exp(-te[t] * r * r) < 1e-22) r -= 0.01;
+          rc = std::max(rc, r + 0.02);
+        }
+        rc2[k] = rc * rc;
+      }
+      TRY(upload_table(h, rc2.data(), rc2.size(), &tmp_d)); S.ecp_rc2 = tmp_d;
+    }
   }
   // quadrature directions (eval_ecp.py:278-336): octahedral 6, icosahedral 12
   std::vector<double> quad;

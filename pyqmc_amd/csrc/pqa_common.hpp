@@ -97,6 +97,7 @@ struct SysDev {
   const int* ecp_term_n;
   const double* ecp_term_exp;
   const double* ecp_term_coef;
+  const double* ecp_rc2;  // [necp] r^2 beyond which every term of the atom's ECP is below 1e-22 in magnitude (create: ecp_ranges)
   int ecp_naip_max;
 };
 

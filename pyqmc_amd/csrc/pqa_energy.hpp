@@ -287,10 +287,49 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
   double loc = 0.0;
   int c_up = 0, c_dn = 0;
   const int neb = (S.nelec + 63) / 64;
+  __shared__ unsigned long long pb[64];  // near-atom path: electrons of this block that passed the mask at atom k
   for (int eb = 0; eb < neb; ++eb) {
     const int e = eb * 64 + lane;
     const bool live = e < S.nelec;
     const double ex = live ? xw[3 * e] : 0.0, ey = live ? xw[3 * e + 1] : 0.0, ez = live ? xw[3 * e + 2] : 0.0;
+    if (S.necp <= 64) {
+      // Every lane (electron) marks the ECP atoms within range of it (S.ecp_rc2: beyond it every term is < 1e-22) and walks ITS
+      // OWN marks: an electron is in range of 0-2 atoms of the 24 of the water cluster, and with the atom loop in lock-step all
+      // 24 radial evaluations ran for every electron (the kernel was bound by their exp).  What the far atoms would have added to
+      // the local energy is below its last bit, and their mask probability is 0.
+      unsigned long long near = 0ull;
+      for (int k = 0; k < S.necp; ++k) {
+        const int ia = S.ecp_atom[k];
+        double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+        if (PBC) min_image(S, dx, dy, dz);
+        if (live && dx * dx + dy * dy + dz * dz < S.ecp_rc2[k]) near |= 1ull << k;
+      }
+      if (lane < S.necp) pb[lane] = 0ull;
+      __syncthreads();
+      while (__any(near != 0ull)) {
+        if (near) {
+          const int k = __ffsll((long long)near) - 1;
+          near &= near - 1;
+          const int ia = S.ecp_atom[k];
+          double dx = ex - S.atom_xyz[3 * ia], dy = ey - S.atom_xyz[3 * ia + 1], dz = ez - S.atom_xyz[3 * ia + 2];
+          if (PBC) min_image(S, dx, dy, dz);
+          const double r = sqrt(dx * dx + dy * dy + dz * dz);
+          double v[PQA_MAXCHAN], prob;
+          int nch;
+          ecp_radial(S, k, r, B.threshold, v, nch, prob);
+          loc += v[nch - 1];
+          if (nch > 1 && ecp_pass(S, B, w, W, e, k, prob)) {
+            const int naip = (nch <= 2) ? 6 : 12;
+            if (e < S.nup) c_up += naip; else c_dn += naip;
+            atomicOr(&pb[k], 1ull << lane);
+          }
+        }
+      }
+      __syncthreads();
+      if (lane < S.necp) B.passbits[((size_t)w * S.necp + lane) * neb + eb] = pb[lane];
+      __syncthreads();
+      continue;
+    }
     for (int k = 0; k < S.necp; ++k) {
       const int ia = S.ecp_atom[k];
       bool pass = false;
