@@ -660,6 +660,12 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       S.nmo[s] = h->nmo[s]; S.ndet_s[s] = h->ndet_s[s];
       TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
       {
+        std::vector<int> oc((size_t)std::max(nel[s], 1));
+        if (nel[s] > 0) HIPCHK(hipMemcpy(oc.data(), occ_src[s], (size_t)nel[s] * sizeof(int), hipMemcpyDefault));
+        S.occ_ident[s] = 1;
+        for (int k = 0; k < nel[s]; ++k) S.occ_ident[s] &= (oc[k] == k) ? 1 : 0;
+      }
+      {
         std::vector<int> occ_h((size_t)h->ndet_s[s] * nel[s]), cm((size_t)h->ndet_s[s] * std::max(h->nmo[s], 1), -1);
         if (!occ_h.empty()) HIPCHK(hipMemcpy(occ_h.data(), occ_src[s], occ_h.size() * sizeof(int), hipMemcpyDefault));
         for (int u = 0; u < h->ndet_s[s]; ++u)

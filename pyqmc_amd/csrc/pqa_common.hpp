@@ -61,6 +61,7 @@ struct SysDev {
   int ndet, ndet_s[2];
   const double* det_coeff;
   const int* det_occ[2];  // [ndet_s][n_s]
+  int occ_ident[2];       // the first determinant of the spin occupies orbitals 0..n-1 in order (rows can be read with wide loads)
   const int* det_map;     // [2][ndet]
   int na, nb;
   int a_kind[PQA_MAXBAS];

@@ -545,7 +545,18 @@ __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, Jas
     const double* row = mo + (size_t)p * nmo;
     const int* occ = S.det_occ[s];
     double r = 0.0;
-    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[(size_t)k * sk];
+    // The lanes of a wave walk 64 different 256-byte rows: with 8-byte loads that is 64 cache lines per load instruction and no
+    // reuse in L1 (0.26 of this kernel's 0.83 ms, compile-time ablation).  Where the determinant occupies the first n orbitals
+    // in order (the usual ground-state list) the row is read 32 bytes at a time instead.
+    if (S.occ_ident[s] && (n % 4) == 0 && (nmo % 4) == 0) {
+      const double4* row4 = reinterpret_cast<const double4*>(row);
+      for (int k4 = 0; k4 < n / 4; ++k4) {
+        const double4 q = row4[k4];
+        const double* Tk = Ti + (size_t)(4 * k4) * sk;
+        r += q.x * Tk[0]; r += q.y * Tk[sk]; r += q.z * Tk[2 * sk]; r += q.w * Tk[3 * sk];
+      }
+    } else
+      for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[(size_t)k * sk];
     ratio = r;
   }
   if (has_jastrow) {

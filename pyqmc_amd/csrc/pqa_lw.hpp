@@ -210,7 +210,21 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
     // walker), so a thread's consecutive slots share 64-byte lines (4 lines per thread and component instead of 8
     // lines used 8 bytes each when the slots were dealt round-robin: 53 -> 22 us of this kernel)
     const int nj = (n + G - 1) / G, jb = g * nj, je = (jb + nj < n) ? jb + nj : n;
-    if (rows) {
+    if (rows && !CX && S.occ_ident[s] && ((jb | (je - jb) | nmo) & 3) == 0) {
+      // ground-state occupation: the slots are the orbitals themselves, so the thread's slice of each component row is read 32
+      // bytes at a time (64 lanes on 64 different rows: a quarter of the load instructions / cache-line visits); same
+      // operations in the same order
+      const double* row = rows + (size_t)w * 5 * nmo;
+      for (int j = jb; j < je; j += 4) {
+        const double4 a0 = *reinterpret_cast<const double4*>(row + j), a1 = *reinterpret_cast<const double4*>(row + nmo + j);
+        const double4 a2 = *reinterpret_cast<const double4*>(row + 2 * nmo + j), a3 = *reinterpret_cast<const double4*>(row + 3 * nmo + j);
+        const double t0 = Ti[(size_t)j * W], t1 = Ti[(size_t)(j + 1) * W], t2 = Ti[(size_t)(j + 2) * W], t3 = Ti[(size_t)(j + 3) * W];
+        r0 += a0.x * t0; r1 += a1.x * t0; r2 += a2.x * t0; r3 += a3.x * t0;
+        r0 += a0.y * t1; r1 += a1.y * t1; r2 += a2.y * t1; r3 += a3.y * t1;
+        r0 += a0.z * t2; r1 += a1.z * t2; r2 += a2.z * t2; r3 += a3.z * t2;
+        r0 += a0.w * t3; r1 += a1.w * t3; r2 += a2.w * t3; r3 += a3.w * t3;
+      }
+    } else if (rows) {
       const double* row = rows + (size_t)w * 5 * nmo;
 #pragma unroll 4
       for (int j = jb; j < je; ++j) {
