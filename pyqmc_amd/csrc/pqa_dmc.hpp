@@ -196,7 +196,13 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
     const double* Ti = st.T[s] + ((size_t)w * n + i) * n;
     const int* occ = S.det_occ[s];
     double r = 0.0;
-    for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[k];
+    if (S.occ_ident[s] && ((n | S.nmo[s]) & 3) == 0) {  // ground-state occupation: both rows 32 bytes per load (same order of additions)
+      for (int k = 0; k < n; k += 4) {
+        const double4 a = *reinterpret_cast<const double4*>(row + k), t = *reinterpret_cast<const double4*>(Ti + k);
+        r += a.x * t.x; r += a.y * t.y; r += a.z * t.z; r += a.w * t.w;
+      }
+    } else
+      for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[k];
     ratio = r;
   }
   if (has_jastrow) {
