@@ -932,7 +932,9 @@ static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
   // at 1024 / 4096 / 8192 walkers, but the 8-atom cell (40 shells on 32 groups) and twisted cells (528 B of spills) lose
   // after the image lists / in-tile accumulation (no spills any more): twisted 8-atom cell 451k -> 580k walker-steps/s at 4096
   // walkers, 708k -> 756k at 8192; untwisted 8-atom cell even
-  if (h->S.pbc) return (h->twist || h->nshell >= 64) && P <= h->orb_wide_max;
+  // ... and with the image walk / accumulation as they are now it wins up to 32768 points (C3 +18 % at 24576 walkers, +7 % at
+  // 16384 and 32768; C5 +6 % at 12288, +1-2 % at 16384 and 32768): periodic threshold 4 x orb_wide_max
+  if (h->S.pbc) return (h->twist || h->nshell >= 64) && P <= 4 * h->orb_wide_max;
   return P <= h->orb_wide_max + h->orb_wide_max / 2;
 }
 template <int PBCV, int NTH>
