@@ -140,13 +140,16 @@ def extra_measurements(pa, wf, dev, mol, W, args):
     sweep + energy at the bench's walker count, and sweep + energy at W/GPU in {4096, 16384, 65536}."""
     import numpy as np
 
+    seeds = iter(range(5000, 6000))  # a fresh random stream per call: replaying one spreads the walkers unphysically (and makes the energy cheaper)
+
     def rate(walkers, energy, steps=4):
         if walkers != dev.W:
             wf.recompute(pa.initial_guess(mol, walkers, rng=np.random.default_rng(77)))
-        dev.vmc_sweeps(args.tstep, 1, seed=5, energy=energy)
+            dev.vmc_sweeps(args.tstep, 4, seed=next(seeds), energy=energy)  # leave the initial guess behind
+        dev.vmc_sweeps(args.tstep, 1, seed=next(seeds), energy=energy)
         dev.sync()
         t0 = time.perf_counter()
-        dev.vmc_sweeps(args.tstep, steps, seed=6, energy=energy)
+        dev.vmc_sweeps(args.tstep, steps, seed=next(seeds), energy=energy)
         dev.sync()
         dt = time.perf_counter() - t0
         return {"walker_steps_per_s": walkers * steps / dt, "ms_per_step": 1e3 * dt / steps}
@@ -231,6 +234,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (weak scaling); 65536 is the measured throughput optimum")
     ap.add_argument("--tstep", type=float, default=0.3)
+    ap.add_argument("--settle", type=int, default=30, help="untimed settling steps before the warm-up steps (clock ramp of a fresh process)")
     ap.add_argument("--mode", default="vmc", choices=["vmc", "dmc"], help="vmc: the headline metric (default); dmc: config C5 with branching")
     ap.add_argument("--cpu-walkers", type=int, default=256, help="walkers per CPU-baseline process")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = physical cores of one socket)")
@@ -307,9 +311,10 @@ def main():
 
         return allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=red_dev)[0]
 
-    # three untimed settling steps before the W warm-up steps: the first launches of a process load code objects and find the
-    # clocks low (an evidence run of this round timed 37.3 ms per step right after 2 warm-up steps and 34.6 a minute later)
-    dev.vmc_sweeps(args.tstep, 3, seed=seed + 7, energy=True)
+    # untimed settling steps before the W warm-up steps: the first launches of a process load code objects and find the
+    # clocks low (an evidence run of this round timed 37.3 ms per step right after 2 warm-up steps and 34.6 a minute later),
+    # and the walkers leave the initial guess (33.2 ms per step after 3 settling steps, 33.0 after 30, 90 or 200)
+    dev.vmc_sweeps(args.tstep, args.settle, seed=seed + 7, energy=True)
     if not args.no_profile:
         dev.profile_enable(True)  # during the warm-up too: the event pairs are created there, not inside the timed region
     if args.warmup > 0:
