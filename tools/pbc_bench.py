@@ -32,14 +32,27 @@ wf = pa.generate_wf(sup, mf, image_rule=a.rule)
 dev = wf.fused_device()
 cfg = pa.initial_guess(sup, a.walkers, rng=np.random.default_rng(1))
 wf.recompute(cfg)
+dev.profile_enable(True)  # event pairs are created during the warm-up
 dev.vmc_sweeps(0.3, a.warmup, seed=1, energy=not a.no_energy)
 dev.sync()
-dt = float("inf")
+dt, roof = float("inf"), None
 for rep in range(2):  # best of two timed passes: about one process in eight sees a 1.5-2x slow pass on these boxes
+    dev.profile_enable(True)
     t0 = time.perf_counter()
     acc, en, _ = dev.vmc_sweeps(0.3, a.steps, seed=2 + rep, energy=not a.no_energy)
     dev.sync()
-    dt = min(dt, time.perf_counter() - t0)
+    t = time.perf_counter() - t0
+    launches, orb_ms, point_comps = dev.profile_query()
+    if t < dt and launches:
+        # the periodic orbital evaluation of the moves (image-list pre-pass + lattice-summed AO phase + fp64 MFMA contraction),
+        # HIP events on the library's stream around 1 launch in 4; flops = the AO->MO contraction only (MFMA-eligible work)
+        nao, nmo = dev.nao, max(int(sup.nelec[0]), int(sup.nelec[1])) * (2 if np.iscomplexobj(np.asarray(mf.mo_coeff[0][0])) else 1)
+        flops = point_comps * 2.0 * nao * nmo
+        roof = {"bound": "mfma", "kernel": "k_pbc_prepass + k_orb<5, PBC> / k_orb_wide<5, PBC> (move launches)", "achieved": flops / (orb_ms * 1e-3) / 1e12,
+                "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (orb_ms * 1e-3) / 1e12 / 78.6, "launches": launches,
+                "avg_launch_ms": orb_ms / launches, "flops_per_point_component": 2 * nao * nmo, "traffic": None}
+    dt = min(dt, t)
+dev.profile_enable(False)
 print(json.dumps({"case": a.case, "nelec": int(sum(sup.nelec)), "natom": sup.natm, "walkers": a.walkers, "ms_per_step": 1e3 * dt / a.steps,
                   "walker_steps_per_s": a.walkers * a.steps / dt, "acceptance": float(acc[-1]),
-                  "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule}))
+                  "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule, "roofline": roof}))

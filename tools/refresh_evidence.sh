@@ -18,6 +18,10 @@ python $R/tools/pmc_summary.py /tmp/pm_FETCH_SIZE/t_results.db /tmp/pm_WRITE_SIZ
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
 python $R/tools/prof_stats.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do  # counter passes of the periodic case (separate runs, no trace options); calibration as above
+  rocprofv3 --pmc $c -d /tmp/pkm_$c -o t -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 1 --warmup 1 > /dev/null 2>&1 < /dev/null
+  python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_k222_pmc_$c.csv
+done
 python $R/tools/config_bench.py c2 --walkers 4096 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c2 --walkers 65536 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 4096 --steps 8 2>/dev/null | tail -1 >> $O/config_bench.jsonl
