@@ -580,3 +580,34 @@ def test_complex_testvalue_many_matches_reference(tag):
     assert helpers.relerr(wf.testvalue_many(np.array([int(es[1])]), epos)[:, 0], wf.testvalue(int(es[1]), epos)[0]) < 1e-12
     mask = np.array([True, False, True])
     assert np.array_equal(wf.testvalue_many(es, epos, mask=mask), wf.testvalue_many(es, epos)[mask])
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_event_brackets_do_not_change_the_sweep(periodic):
+    """The measurement entry points (pqa_profile_enable / pqa_profile_query*: HIP events around a sample of the orbital,
+    partial-sum and flush launches, read by bench.py and tools/pbc_bench.py) must leave the numbers alone: the same seeded
+    sweep with and without them gives identical acceptances and energies, and the queries report bracketed launches with a
+    positive duration on the open and on the periodic (pre-pass + lattice-sum) path."""
+    import pyqmc_amd as pa
+
+    if periodic:
+        sup, mf = helpers.pbc_slater_case("fcc2cubic")
+    else:
+        sup = systems.water()
+        mf = systems.random_mf(sup)
+    out = {}
+    for prof in (False, True):
+        wf = pa.generate_wf(sup, mf)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(sup, 256, rng=np.random.default_rng(3)))
+        dev.profile_enable(prof)
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=9, energy=True)
+        dev.sync()
+        if prof:
+            launches, ms, point_comps = dev.profile_query()
+            assert launches > 0 and ms > 0.0 and point_comps == launches * 256 * 5
+            p_launches, p_ms, groups = dev.profile_query_part()
+            assert p_launches > 0 and p_ms > 0.0 and groups >= 1
+            dev.profile_enable(False)
+        out[prof] = (np.array(acc), np.array(en))
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
