@@ -338,10 +338,21 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
   const int lane = threadIdx.x;
   double* xw = js.x + (size_t)w * S.nelec * 3;
   bool fresh = precomputed != 0;  // B.rat / B.amp hold this walker's ratios (k_tm_ratio) until one of its T-moves is accepted
+  // every electron's candidate range once (lane e: electrons e and e + 64), and a mask of the electrons that have any: read one
+  // electron at a time they were two dependent loads per electron, 128 round trips per walker for the ~15 that matter
+  long offs[2][2];
+  unsigned long long has[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int el = lane + 64 * hh;
+    offs[hh][0] = el < S.nelec ? B.off[(size_t)el * W + w] : 0;
+    offs[hh][1] = el < S.nelec ? B.off[(size_t)el * W + w + 1] : 0;
+    has[hh] = __ballot(offs[hh][1] > offs[hh][0]);
+  }
   for (int e = 0; e < S.nelec; ++e) {
-    const long p0 = B.off[(size_t)e * W + w], p1 = B.off[(size_t)e * W + w + 1];
+    if (!((has[e >> 6] >> (e & 63)) & 1ull)) continue;  // (acc was cleared for the whole step)
+    const long p0 = __shfl(e < 64 ? offs[0][0] : offs[1][0], e & 63, 64), p1 = __shfl(e < 64 ? offs[0][1] : offs[1][1], e & 63, 64);
     const int n = (int)(p1 - p0);
-    if (n == 0) continue;  // (acc was cleared for the whole step)
     const int s = e >= S.nup, nmo = S.nmo[s];
     const double* mo = s ? mo_dn : mo_up;
     const long p_base = s ? tot_up : 0;
@@ -376,6 +387,35 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
     auto rat_of = [&](int q) { return in_regs ? __shfl(my_rat, q, 64) : B.rat[p0 + q]; };
     auto wgt_of = [&](int q) { return in_regs ? __shfl(my_wgt, q, 64) : B.wgt[p0 + q]; };
     int sel = n, acc = 0;
+    if (in_regs) {
+      // the sums run in candidate order as before (same additions, same order); the terms — a division per candidate in the
+      // selection, a product in the way back — are formed by the candidates' own lanes at once instead of one per iteration
+      const double my_fwd = fmax(my_amp, 0.0);
+      double norm = 1.0;
+      for (int q = 0; q < n; ++q) norm += __shfl(my_fwd, q, 64);
+      double u1, u2;
+      if (B.u1) { u1 = B.u1[(size_t)e * W + w]; u2 = B.u2[(size_t)e * W + w]; }
+      else {
+        const Philox a = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U1, B.step);
+        const Philox b = philox(B.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_TM_U2, B.step);
+        u1 = u01(a.c[0], a.c[1]); u2 = u01(b.c[0], b.c[1]);
+      }
+      const double my_t = my_fwd / norm;
+      sel = 0;
+      double cdf = 0.0;
+      for (int q = 0; q < n; ++q) {
+        cdf += __shfl(my_t, q, 64);
+        if (cdf < u1) ++sel;
+      }
+      if (sel < n) {
+        const double rr = 1.0 / __shfl(my_rat, sel, 64);
+        const double my_b = fmax((lane == sel) ? rr * my_wgt : my_amp * rr, 0.0);
+        double back = 1.0;
+        for (int q = 0; q < n; ++q) back += __shfl(my_b, q, 64);
+        acc = norm / back > u2;
+      }
+      if (lane == 0) B.acc[(size_t)e * W + w] = acc;
+    } else
     {  // (all lanes run the loops so that the shuffles are convergent; lane 0's results are the ones used)
       double norm = 1.0;
       for (int q = 0; q < n; ++q) norm += fmax(amp_of(q), 0.0);
