@@ -509,7 +509,9 @@ __global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf m
 // in LDS once and shared by the row groups — read per row from global memory they were 4x the traffic of the inverse
 // itself (1.26 ms per flush at 65 536 walkers).  A row's arithmetic and its order are unchanged (bitwise identical).
 // 16 consecutive walkers are 128 contiguous bytes of every (row, column) plane: two full cache lines per access.
+#ifndef PQA_FLUSH_WB
 #define PQA_FLUSH_WB 16
+#endif
 template <int NMAX, bool CX = false>
 __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
                                                   const double* __restrict__ Rb, const uint8_t* __restrict__ act, long W,

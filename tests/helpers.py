@@ -364,7 +364,8 @@ def pbc_complex_case():
     return sup, pbc.random_kmf(sup, complex_coeff=True)
 
 
-TWIST_CASES = {"prim": (np.eye(3), (0.25, 0.1, -0.3)), "s211": (np.diag([2.0, 1.0, 1.0]), (0.2, -0.15, 0.4))}
+TWIST_CASES = {"prim": (np.eye(3), (0.25, 0.1, -0.3)), "s211": (np.diag([2.0, 1.0, 1.0]), (0.2, -0.15, 0.4)),
+               "s222": (2.0 * np.eye(3), (0.2, -0.15, 0.4))}  # s222: 32 electrons per spin (no golden; device paths against each other)
 
 
 def twist_case(tag):

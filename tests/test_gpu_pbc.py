@@ -330,11 +330,12 @@ def _gpu_twisted_wf(tag):
     return sup, wf
 
 
-@pytest.mark.parametrize("tag", ["prim", "s211"])
+@pytest.mark.parametrize("tag", ["prim", "s211", "s222"])
 def test_complex_lane_and_wave_per_walker_sweeps_agree(tag, monkeypatch):
     """Complex determinants (twisted cells): the lane-per-walker sweep (complex Sherman-Morrison on SoA planes, |ratio|^2
     acceptance, Re(grad) drift; default) and the wave-per-walker complex kernels follow the same Philox streams — same
-    decisions, coordinates and energies to rounding, and both leave a state that equals a fresh recompute."""
+    decisions, coordinates and energies to rounding, and both leave a state that equals a fresh recompute.  s222: 32 complex
+    electrons per spin, the largest the lane-per-walker kernels take (64 doubles per inverse row, 80 KB of flush staging)."""
     import pyqmc_amd as pa
 
     res = []
