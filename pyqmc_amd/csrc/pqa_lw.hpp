@@ -398,6 +398,13 @@ __global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveB
     const double* row = motmp + (size_t)w * 5 * nmo;
     const int* occ = S.det_occ[s];
     const int nh = nmo / CF;
+    if (!CX && S.occ_ident[s] && ((n | nmo) & 3) == 0) {  // ground-state occupation: the value row 32 bytes per load (k_move_part_lw)
+#pragma unroll 2
+      for (int k = 0; k < n; k += 4) {
+        const double4 a = *reinterpret_cast<const double4*>(row + k);
+        Vbuf[(size_t)k * W + w] = a.x; Vbuf[(size_t)(k + 1) * W + w] = a.y; Vbuf[(size_t)(k + 2) * W + w] = a.z; Vbuf[(size_t)(k + 3) * W + w] = a.w;
+      }
+    } else
 #pragma unroll 8
     for (int k = 0; k < n; ++k) {
       if (CX) { Vbuf[(size_t)(2 * k) * W + w] = row[occ[k]]; Vbuf[(size_t)(2 * k + 1) * W + w] = row[nh + occ[k]]; }
