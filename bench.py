@@ -230,8 +230,8 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (weak scaling); 65536 is the measured throughput optimum")
     ap.add_argument("--tstep", type=float, default=0.3)
     ap.add_argument("--settle", type=int, default=30, help="untimed settling steps before the warm-up steps (clock ramp of a fresh process)")
