@@ -584,13 +584,14 @@ def test_complex_testvalue_many_matches_reference(tag):
 
 
 @pytest.mark.parametrize("periodic", [False, True])
-def test_event_brackets_do_not_change_the_sweep(periodic):
+def test_event_brackets_do_not_change_the_sweep(periodic, monkeypatch):
     """The measurement entry points (pqa_profile_enable / pqa_profile_query*: HIP events around a sample of the orbital,
     partial-sum and flush launches, read by bench.py and tools/pbc_bench.py) must leave the numbers alone: the same seeded
     sweep with and without them gives identical acceptances and energies, and the queries report bracketed launches with a
     positive duration on the open and on the periodic (pre-pass + lattice-sum) path."""
     import pyqmc_amd as pa
 
+    monkeypatch.delenv("PQA_LW", raising=False)  # the partial-sum brackets belong to the (default) lane-per-walker sweep
     if periodic:
         sup, mf = helpers.pbc_slater_case("fcc2cubic")
     else:
