@@ -104,6 +104,13 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
   };
   const long w = blockIdx.x;
   const int lane = threadIdx.x;  // 0 .. PQA_EWALD_T-1: the block's threads share the pair / ion / g-point loops
+  __shared__ double img_l2[27];  // |L|^2 of the 27 images
+  if (lane < 27) {
+    const int a = lane / 9 - 1, b = (lane / 3) % 3 - 1, c = lane % 3 - 1;
+    const double lx = a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6], ly = a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
+    const double lz = a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
+    img_l2[lane] = lx * lx + ly * ly + lz * lz;
+  }
   for (int k = lane; k < S.nelec * 3; k += PQA_EWALD_T) lds[k] = x[w * sw + (k / 3) * se + (k % 3) * sc];
   __syncthreads();
   // 27-image real-space sum of one pair.  Each lane first marks which of ITS 27 images are close enough to matter, then walks
@@ -113,13 +120,18 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
     min_image(S, dx, dy, dz);
     const double a2 = E.alpha * E.alpha;
     unsigned m = 0u;
+    // the marking pass takes |d + L|^2 = |d|^2 + 2 d.L + |L|^2 (three dot products per pair, then three additions per image
+    // instead of nine multiply-adds); an image this estimate puts on the other side of the threshold than the direct form would
+    // carries erfc(x)/r < 4e-19, below the last bit of the pair's sum.  The admitted images are evaluated as before.
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    const double p0 = 2.0 * (dx * S.pb->lat[0] + dy * S.pb->lat[1] + dz * S.pb->lat[2]);
+    const double p1 = 2.0 * (dx * S.pb->lat[3] + dy * S.pb->lat[4] + dz * S.pb->lat[5]);
+    const double p2 = 2.0 * (dx * S.pb->lat[6] + dy * S.pb->lat[7] + dz * S.pb->lat[8]);
 #pragma unroll
     for (int idx = 0; idx < 27; ++idx) {
       const int a = idx / 9 - 1, b = (idx / 3) % 3 - 1, c = idx % 3 - 1;
-      const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
-      const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
-      const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
-      if (!(a2 * (rx * rx + ry * ry + rz * rz) > 40.0)) m |= 1u << idx;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
+      const double r2 = d2 + (a * p0 + b * p1 + c * p2) + img_l2[idx];
+      if (!(a2 * r2 > 40.0)) m |= 1u << idx;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
     }
     double acc = 0.0;
     while (__any(m != 0u)) {
@@ -130,8 +142,12 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
         const double rx = dx + a * S.pb->lat[0] + b * S.pb->lat[3] + c * S.pb->lat[6];
         const double ry = dy + a * S.pb->lat[1] + b * S.pb->lat[4] + c * S.pb->lat[7];
         const double rz = dz + a * S.pb->lat[2] + b * S.pb->lat[5] + c * S.pb->lat[8];
-        const double r = sqrt(rx * rx + ry * ry + rz * rz);
-        acc += erfc_fast(E.alpha * r) / r;
+        // 1/r from v_rsq_f64 + two Newton steps (1-2 ulp), r = r^2 (1/r): a third of the IEEE sqrt + division sequences
+        const double r2 = rx * rx + ry * ry + rz * rz, hr2 = 0.5 * r2;
+        double ir = __builtin_amdgcn_rsq(r2);
+        ir = ir * fma(-hr2 * ir, ir, 1.5);
+        ir = ir * fma(-hr2 * ir, ir, 1.5);
+        acc += erfc_fast(E.alpha * (r2 * ir)) * ir;
       }
     }
     return acc;
