@@ -37,6 +37,7 @@ class BlockFile:
 
     def __init__(self, path, backend=None):
         self.path = path
+        self._nblocks = None  # npz store: records written so far (counted once, then kept: append is O(1) per block)
         self.backend = backend or ("h5py" if h5py is not None else "npz")
         if self.backend == "h5py" and h5py is None:
             raise RuntimeError("h5py is not installed: use backend='npz' and convert with blockfile.to_hdf5 where it is")
@@ -85,7 +86,15 @@ class BlockFile:
                         f.create_dataset(k, v.shape, maxshape=(None,) + v.shape[1:], chunks=True, dtype=v.dtype)
                     f[k][...] = v
             return
-        n = len(self._block_index())
+        if self._nblocks is None:
+            idx = self._block_index()
+            self._nblocks = (idx[-1] + 1) if idx else 0
+        n = self._nblocks
+        # walkers first, record second: a crash in between leaves walkers one block AHEAD of the record (that block's averages
+        # are lost), never a record whose walkers are one block behind
+        tmp = self.path + ".state.tmp.npz"
+        np.savez(tmp, **state)
+        os.replace(tmp, self.path + ".state.npz")
         with zipfile.ZipFile(self.path + ".blocks.npz", "a", zipfile.ZIP_STORED) as z:
             for k, v in block.items():
                 buf = io.BytesIO()
@@ -95,9 +104,7 @@ class BlockFile:
                 buf = io.BytesIO()
                 np.save(buf, np.asarray(v))
                 z.writestr(f"__attrs__/{k}/{n:08d}.npy", buf.getvalue())
-        tmp = self.path + ".state.tmp.npz"
-        np.savez(tmp, **state)
-        os.replace(tmp, self.path + ".state.npz")
+        self._nblocks = n + 1
 
     # ---------------------------------------------------------------- reading
     def _block_index(self):

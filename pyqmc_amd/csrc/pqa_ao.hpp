@@ -488,13 +488,21 @@ __device__ __forceinline__ void pbc_ctx_load(const SysDev& S, const Tab& T, PbcC
 }
 
 // Twisted cells: multiply every orbital row [ncomp][2 nmo] (re block | im block) by the point's wrap phase.
-__global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta) {
+// rows of a two-slot output cleared before a K-split launch accumulates into them.  grid = (P, ceil(row / 256)), block = 256
+__global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ out, int row, const unsigned char* __restrict__ sel, long slot_stride) {
+  const long p = blockIdx.x;
+  const int k = blockIdx.y * 256 + threadIdx.x;
+  if (k < row) out[(size_t)(sel[p] ^ 1) * slot_stride + (size_t)p * row + k] = 0.0;
+}
+// sel / slot_stride: the two-slot output of ChunkTab (nullptr: plain rows)
+__global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta,
+                            const unsigned char* __restrict__ sel, long slot_stride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nmo = nmo2 / 2;
   if (idx >= P * ncomp * nmo) return;
   const long p = idx / ((long)ncomp * nmo);
   const int c = (int)((idx / nmo) % ncomp), j = (int)(idx % nmo);
-  double* row = out + ((size_t)p * ncomp + c) * nmo2;
+  double* row = out + (sel ? (size_t)(sel[p] ^ 1) * slot_stride : (size_t)0) + ((size_t)p * ncomp + c) * nmo2;
   const double cs = theta[2 * p], sn = theta[2 * p + 1], re = row[j], im = row[nmo + j];
   row[j] = re * cs - im * sn;
   row[nmo + j] = re * sn + im * cs;
@@ -566,7 +574,14 @@ struct ChunkTab {
   const double* pbc_d0;
   const unsigned long long* pbc_list;
   int pbc_nw;
+  // two-slot output (the lane-per-walker sweep's row cache, pqa_lw.hpp): point p's rows go to out + (out_sel[p] ^ 1) *
+  // out_slot_stride + p * NCOMP * nmo, i.e. into the slot the walker is not using.  nullptr: plain out[p][c][j].
+  const unsigned char* out_sel;
+  long out_slot_stride;
 };
+__device__ __forceinline__ double* orb_out(const ChunkTab& T, double* out, long p) {
+  return T.out_sel ? out + (size_t)(T.out_sel[p] ^ 1) * T.out_slot_stride : out;
+}
 
 #define PQA_LS_MAX 128     // candidate lattice vectors the periodic kernels keep in LDS
 #define PQA_WS_MAXSH 160   // shells / primitives that fit the LDS-resident basis tables
@@ -758,8 +773,9 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
       for (int r = 0; r < 4; ++r) {
         const long pp = p0 + 16 * ptile + kq + 4 * r;
         if (pp < P) {
-          if (nsplit > 1) unsafeAtomicAdd(&out[(pp * NCOMP + c) * nmo + j], acc[u][c][r]);
-          else out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+          double* o = orb_out(T, out, pp) + (pp * NCOMP + c) * nmo + j;
+          if (nsplit > 1) unsafeAtomicAdd(o, acc[u][c][r]);
+          else *o = acc[u][c][r];
         }
       }
   }
@@ -888,7 +904,7 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long pp = p0 + 16 * grp + kq + 4 * r;
-        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
+        if (pp < P) orb_out(T, out, pp)[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
       }
   }
 }
@@ -1024,7 +1040,7 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long pp = p0 + kq + 4 * r;
-        if (pp < P) out[(pp * NCOMP + c) * nmo + j] = acc[r];
+        if (pp < P) orb_out(T, out, pp)[(pp * NCOMP + c) * nmo + j] = acc[r];
       }
     }
   }

@@ -65,6 +65,8 @@ struct pqa_handle {
   SysDev S{};
   ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
   ChunkTab tab[2]{};
+  const unsigned char* out_sel = nullptr;  // two-slot output of the NEXT orbital launch (ChunkTab::out_sel; set by launch_orb)
+  long out_slot_stride = 0;
   double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
   double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
   double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
@@ -77,7 +79,6 @@ struct pqa_handle {
   // scratch
   DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth, b_tmuold;
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
-  int lw_fullline = 1;  // PQA_LW_FULLLINE: rejected walkers write their inverse rows back so stores cover whole lines
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
   int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
   long wrap_W = 0;
@@ -86,11 +87,12 @@ struct pqa_handle {
   DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_tmtile, b_tmaoff, b_tmptw, b_tmmarks, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
   int tm_P = 0;
   int *d_ptk = nullptr, *d_pti = nullptr;
-  DevBuf b_xt, b_Tt[2], b_ct[2], b_auxt, b_kpart, b_part, b_rbuf, b_vbuf, b_act;
+  DevBuf b_xt, b_Tt[2], b_rc[2], b_sel[2], b_auxt, b_kpart, b_rbuf, b_vbuf, b_act;
   // electrons per Sherman-Morrison block (PQA_LW_KB): -1 automatic (4 for >= 16 electrons per spin), 0 = update every row on
   // every move.  Blocking is bitwise identical and cuts the inverse's HBM traffic ~3x; it pays since k_flush_lw stages the
   // block's update vectors in LDS (1.26 -> 0.27 ms per flush at 65536 walkers): commit + flush 15.5 -> 8.4 ms per step.
   int lw_kb = -1;
+  int lw_nw = 0;  // PQA_LW_NW: walkers per block of k_step_lw (16, 32, 64; 0 = automatic)
   int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
   DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
   int orb_tp = 0;  // 0 = automatic
@@ -484,8 +486,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   PQA_ORB_NOTAB 1 basis tables from global memory, PQA_ORB_KC5 16|32 AO rows per chunk of the periodic 5-component
   //   launch, PQA_ORB_NOSPLIT 1 / PQA_ORB_SPLIT_MAX n chunk loop of small periodic launches on one block,
   //   PQA_LW 0 wave-per-walker sweep | 1 lane-per-walker (default) | 2 walker-tile kernel, PQA_LW_KB k electrons per
-  //   Sherman-Morrison block (0: update every row per move; default 4), PQA_LW_GM g partial-sum groups,
-  //   PQA_LW_FULLLINE 0 masked commit stores, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation,
+  //   Sherman-Morrison block (0: update every row per move; default 4), PQA_LW_GM g thread groups per walker and PQA_LW_NW
+  //   walkers per block of k_step_lw, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation,
   //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled,
   //   PQA_PBC_NW n words (4 image indices each) per (point, atom) image list of the periodic pre-pass (default from the cell;
   //   1 forces the direct-test fallback: tests), PQA_WIDE_NTH 512 k_orb_wide with 512 threads in untwisted periodic cells,
@@ -502,9 +504,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* kb = getenv("PQA_LW_KB")) h->lw_kb = atoi(kb);
   if (const char* nt = getenv("PQA_ORB_NOTAB")) h->orb_notab = atoi(nt);
   if (const char* gm = getenv("PQA_LW_GM")) h->lw_gm = atoi(gm);
+  if (const char* nw = getenv("PQA_LW_NW")) { const int v = atoi(nw); h->lw_nw = (v == 16 || v == 32 || v == 64) ? v : 0; }
   if (const char* ew = getenv("PQA_ECP_WAVE")) h->ecp_wave = atoi(ew);
   if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
-  if (const char* fl = getenv("PQA_LW_FULLLINE")) h->lw_fullline = atoi(fl);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -835,7 +837,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_ct[0], &h->b_ct[1], &h->b_auxt, &h->b_kpart, &h->b_part, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth, &h->b_tmuold};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_rc[0], &h->b_rc[1], &h->b_sel[0], &h->b_sel[1], &h->b_auxt, &h->b_kpart, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth, &h->b_tmuold};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& d : h->dm)
@@ -902,13 +904,19 @@ extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int
 }
 
 // ---------------------------------------------------------------- orbital kernel launch
+static ChunkTab tabx(const pqa_handle* h, int tabi) {  // the chunk table + where this launch's rows go
+  ChunkTab T = h->tab[tabi];
+  T.out_sel = h->out_sel;
+  T.out_slot_stride = h->out_slot_stride;
+  return T;
+}
 template <int NCOMP, int KC>
 static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   const dim3 grid((unsigned)((P + 63) / 64)), block(512);
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb_ws<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb_ws<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb_ws<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 1: hipLaunchKernelGGL((k_orb_ws<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb_ws<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb_ws<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
   }
 }
 
@@ -916,9 +924,9 @@ template <int NCOMP, int KC, int TP, bool LT>
 static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
   switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, h->tab[tabi], spin, pa, P, out); break;
+    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
+    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
+    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
   }
 }
 // whole-K kernel for small 5-component launches (k_orb_wide, pqa_ao.hpp)
@@ -963,7 +971,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
   hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
                      (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
-  ChunkTab T = h->tab[tabi];
+  ChunkTab T = tabx(h, tabi);
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_list = (const unsigned long long*)h->b_pbcmask.p;
   T.pbc_nw = NW;
@@ -974,7 +982,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     if (h->twist) {
       const long nel = P * NCOMP * (h->nmo[spin] / 2);
       hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
-                         (const double*)h->b_pbcth.p);
+                         (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
     }
     return 0;
   }
@@ -1006,7 +1014,11 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   }
   // small launches: split the chunk loop over two blocks per point tile (k_orb: gridDim.y), output accumulated atomically
   const int nsplit = (P <= h->orb_split_max && T.nchunk >= 4 && !h->orb_nosplit) ? 2 : 1;
-  if (nsplit > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)P * NCOMP * h->nmo[spin] * sizeof(double), h->stream));
+  if (nsplit > 1) {
+    if (h->out_sel) hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)P, (unsigned)((NCOMP * h->nmo[spin] + 255) / 256)), dim3(256), 0, h->stream, out,
+                                       NCOMP * h->nmo[spin], h->out_sel, h->out_slot_stride);
+    else HIPCHK(hipMemsetAsync(out, 0, (size_t)P * NCOMP * h->nmo[spin] * sizeof(double), h->stream));
+  }
   const dim3 grid((unsigned)((P + tp - 1) / tp), (unsigned)nsplit), block(256);
   // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
   // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
@@ -1034,7 +1046,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   if (h->twist) {
     const long nel = P * NCOMP * (h->nmo[spin] / 2);
     hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
-                       (const double*)h->b_pbcth.p);
+                       (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
   }
   return 0;
 }
@@ -1045,7 +1057,16 @@ static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P
 }
 
 // out[p][ncomp][nmo_spin]
-static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
+// out_sel / slot_stride: two-slot output (ChunkTab::out_sel), else plain rows
+static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out);
+static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out, const unsigned char* out_sel = nullptr,
+                      long slot_stride = 0) {
+  h->out_sel = out_sel; h->out_slot_stride = slot_stride;
+  const int rc = launch_orb_impl(h, spin, pa, P, ncomp, out);
+  h->out_sel = nullptr; h->out_slot_stride = 0;
+  return rc;
+}
+static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
   if (P <= 0 || h->nmo[spin] == 0) return 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   // account the dominant (move) launches only, and only a 1-in-prof_stride sample of them: an event pair costs ~2 us of
@@ -1076,7 +1097,7 @@ static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, 
     else FAIL("orbital kernel supports ncomp 1 or 5");
   } else
   if (wide_wanted(h, 0, P, ncomp)) {
-    TRY((launch_orb_wide<0, 1024>(h, h->tab[0], 0, spin, pa, P, out)));
+    TRY((launch_orb_wide<0, 1024>(h, tabx(h, 0), 0, spin, pa, P, out)));
   } else
   if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
     if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
@@ -1675,7 +1696,7 @@ static LwState lw_state(pqa_handle* h) {
   LwState L{};
   L.xt = (double*)h->b_xt.p;
   for (int s = 0; s < 2; ++s) {
-    L.Tt[s] = (double*)h->b_Tt[s].p; L.ct[s] = (double*)h->b_ct[s].p;
+    L.Tt[s] = (double*)h->b_Tt[s].p; L.rc[s] = (double*)h->b_rc[s].p; L.sel[s] = (uint8_t*)h->b_sel[s].p;
     L.dsign[s] = h->st.dsign[s]; L.dlog[s] = h->st.dlog[s];
   }
   L.auxt = (double*)h->b_auxt.p;
@@ -1693,9 +1714,15 @@ static int lw_from_aos(pqa_handle* h, bool with_cache = true) {
   for (int s = 0; s < 2; ++s) {
     const size_t n = nel[s], cf = h->cplx ? 2 : 1;
     TRY(ensure(h, h->b_Tt[s], cf * W * n * n * sizeof(double)));
-    TRY(ensure(h, h->b_ct[s], W * n * 5 * h->nmo[s] * sizeof(double)));
+    const int row = 5 * h->nmo[s];
+    TRY(ensure(h, h->b_rc[s], (size_t)2 * W * n * row * sizeof(double)));  // two slots per electron (pqa_lw.hpp)
+    TRY(ensure(h, h->b_sel[s], (size_t)W * n));
     transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(cf * n * n));
-    if (with_cache) transpose(h, h->st.cache[s], (double*)h->b_ct[s].p, W, (long)(n * 5 * h->nmo[s]));
+    if (n > 0 && row > 0) {
+      // (without the cache: the caller knows the row cache and its selectors are live — the T-move phase of the DMC step)
+      if (with_cache) hipLaunchKernelGGL(k_cache_to_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
+                                         (const double*)h->st.cache[s], (double*)h->b_rc[s].p, (uint8_t*)h->b_sel[s].p, (int)n, row, W);
+    }
   }
   return check_launch(h, "k_transpose");
 }
@@ -1707,7 +1734,10 @@ static int lw_to_aos(pqa_handle* h, bool with_cache) {
   for (int s = 0; s < 2; ++s) {
     const long n = nel[s];
     transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], (h->cplx ? 2 : 1) * n * n, W);
-    if (with_cache) transpose(h, (const double*)h->b_ct[s].p, h->st.cache[s], n * 5 * h->nmo[s], W);
+    const int row = 5 * h->nmo[s];
+    if (with_cache && n > 0 && row > 0)
+      hipLaunchKernelGGL(k_cache_from_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
+                         (const double*)h->b_rc[s].p, (const uint8_t*)h->b_sel[s].p, h->st.cache[s], (int)n, row, W);
   }
   return check_launch(h, "k_transpose");
 }
@@ -1965,16 +1995,16 @@ static int sweep_tile(pqa_handle* h, const MoveBuf& mb_in) {
 
 // ---------------------------------------------------------------- one sweep over the electrons (shared by VMC and DMC)
 struct LwCtx {
-  int G = 1, Gm = 1, KB = 1, nmax = 1;
+  int Gm = 1, KB = 1, nmax = 1;
 };
 // Geometry of the lane-per-walker kernels and, when `lw`, the SoA copy of the state and its scratch.
 static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   const long W = h->W;
-  c.G = 1;  // row groups of the Sherman-Morrison commit: enough threads to cover ~2 waves per SIMD
-  while (c.G < 16 && (long)c.G * W < 2048L * 64) c.G *= 2;
-  c.Gm = 1;  // groups of the (latency-bound) partial-sum kernels: ~4 waves per SIMD
-  while (c.Gm < 16 && (long)c.Gm * W < 4096L * 64) c.Gm *= 2;
-  if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 32);
+  // thread groups per walker in k_step_lw.  Measured (tools/scratch/r3_step_abl*.sh, (H2O)8 step in ms at 4 / 8 / 16 groups):
+  // 4096 walkers 6.38 / 5.15 / 4.67, 8192: 7.71 / 6.54 / 6.39, 16384: 10.7 / 9.8 / 11.1, 32768: 16.5 / 17.3 / 18.8, 65536: 30.8 / 32.7 / 37.3
+  c.Gm = 4;
+  while (c.Gm < 16 && (long)c.Gm * W < 2048L * 64) c.Gm *= 2;
+  if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 16);
   c.nmax = std::max(h->nup, h->ndn);
   // block size of the delayed Sherman-Morrison update: 4 from 16 electrons per spin (8 flushes at 32), 5 from 24 (7 flushes at 32:
   // 35.60 -> 35.32 ms per step of the 64-electron benchmark; 6 is slower again — the per-move commit touches KB rows)
@@ -1984,97 +2014,116 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   if (lw) {
     if (!h->aos_stale) TRY(lw_from_aos(h));  // (stale walker-major arrays: the planes ARE the state)
     const size_t cf = h->cplx ? 2 : 1;
-    TRY(ensure(h, h->b_part, (size_t)std::max(c.G, c.Gm) * 12 * W * sizeof(double)));
     TRY(ensure(h, h->b_rbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
     TRY(ensure(h, h->b_vbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
     TRY(ensure(h, h->b_act, (size_t)c.KB * W));
   }
   return 0;
 }
-// One proposal per electron, in index order, on the SoA state (lw) or the AoS state; mb.dmc selects the DMC variant.
-static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) {
+// Lane-per-walker sweep, two launches per move: k_orb at the proposal, then k_step_lw = decide electron e + propose electron
+// e + 1 (pqa_lw.hpp).  The two halves are launched apart where the blocked Sherman-Morrison update has to flush in between
+// (e + 1 opens a new electron block of the same spin: its inverse row is only current after k_flush_lw).
+template <bool PBC, bool CX>
+static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen) {
+  const dim3 grid((unsigned)((a.W + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
+  const size_t lds = (size_t)std::max(PQA_LW_PART_ROWS(CX) * a.G, 2 * rowlen) * a.NW * sizeof(double);
+#define PQA_STEP(NM) do { if (a.NW == 64) hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, true>), grid, block, lds, h->stream, h->S, L, mb, a); \
+                          else hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, false>), grid, block, lds, h->stream, h->S, L, mb, a); } while (0)
+  if (rowlen <= 8) PQA_STEP(8); else if (rowlen <= 16) PQA_STEP(16); else if (rowlen <= 32) PQA_STEP(32); else PQA_STEP(64);
+#undef PQA_STEP
+}
+static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb, const LwCtx& lc) {
   const long W = h->W;
-  const int N = h->N, G = lc.G, Gm = lc.Gm, KB = lc.KB, nmax = lc.nmax;
-  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  const int N = h->N, KB = lc.KB, nmax = lc.nmax;
   const LwState L = lw_state(h);
-  const dim3 gw((unsigned)((W + 63) / 64));
+  const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
+  // thread groups per walker (lc.Gm: ~4 waves per SIMD's worth of threads) and walkers per block: 256 threads at most, so more
+  // than 4 groups narrow the block to 32 or 16 walkers — which is also what spreads a small shard over the chip
+  const int G = std::min(lc.Gm, 16);
+  int NW = (G <= 4) ? 64 : 256 / G;
+  if (h->lw_nw > 0 && h->lw_nw * G <= 256) NW = h->lw_nw;
+  auto step = [&](int e_acc, int e_prop) {
+    StepArgs a{};
+    a.e_acc = e_acc; a.e_prop = e_prop; a.has_jastrow = (int)h->has_jastrow; a.G = G; a.NW = NW; a.W = W;
+    if (e_acc >= 0) {
+      const int s = e_acc >= h->nup, n_s = s ? h->ndn : h->nup, i_s = e_acc - (s ? h->nup : 0);
+      const int q = i_s % KB;
+      a.j_lo = i_s - q; a.j_hi = std::min(a.j_lo + KB, n_s);
+      a.Rbuf = (double*)h->b_rbuf.p + (size_t)q * cfi * n_s * W;
+      a.Vbuf = (double*)h->b_vbuf.p + (size_t)q * cfi * n_s * W;
+      a.act = (uint8_t*)h->b_act.p + (size_t)q * W;
+    }
+    if (h->cplx) { if (h->S.pbc) launch_step_lw<true, true>(h, L, mb, a, rowlen); else launch_step_lw<false, true>(h, L, mb, a, rowlen); }
+    else { if (h->S.pbc) launch_step_lw<true, false>(h, L, mb, a, rowlen); else launch_step_lw<false, false>(h, L, mb, a, rowlen); }
+  };
+  step(-1, 0);
   for (int e = 0; e < N; ++e) {
-    const int s = e >= h->nup;
-    const double* mo = (const double*)h->b_motmp.p;
-    if (lw) {
-      const dim3 gg(gw.x, (unsigned)G);
-      double* part = (double*)h->b_part.p;
-      const int n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
-      const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
-      const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
-      double* rbuf = (double*)h->b_rbuf.p + (size_t)q * cfi * n_s * W;
-      double* vbuf = (double*)h->b_vbuf.p + (size_t)q * cfi * n_s * W;
-      uint8_t* act = (uint8_t*)h->b_act.p + (size_t)q * W;
-      const dim3 gm(gw.x, (unsigned)Gm);
-#define PQA_MOVE_PART(POS, ROWS) do { \
-        if (h->cplx) { if (h->S.pbc) hipLaunchKernelGGL((k_move_part_lw<true, true>), gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); \
-                       else hipLaunchKernelGGL((k_move_part_lw<false, true>), gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); } \
-        else if (h->S.pbc) hipLaunchKernelGGL(k_move_part_lw<true>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); \
-        else hipLaunchKernelGGL(k_move_part_lw<false>, gm, dim3(64), 0, h->stream, h->S, L, e, (int)h->has_jastrow, (const double*)(POS), (const double*)(ROWS), W, Gm, part); } while (0)
-      PQA_MOVE_PART(nullptr, nullptr);
-      if (h->cplx) hipLaunchKernelGGL(k_propose_fin_lw<true>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
-      else hipLaunchKernelGGL(k_propose_fin_lw<false>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, W, Gm, (const double*)part);
-      TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-      hipEvent_t pe1 = nullptr;
-      if (h->profile && (e % (4 * (int)h->prof_stride)) == 0) {  // sparsely sampled (4 of a step's 128 launches at the default stride): an event pair costs ~2 us of stream time
-        if (h->prof3_used == h->prof3_events.size()) {
-          hipEvent_t a, b;
-          HIPCHK(hipEventCreate(&a));
-          HIPCHK(hipEventCreate(&b));
-          h->prof3_events.emplace_back(a, b);
-        }
+    const int s = e >= h->nup, n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
+    const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
+    // the proposal's rows go straight into the slot of electron i_s the walker is not using (accepting flips the selector)
+    TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_rc[s].p + (size_t)i_s * 2 * W * 5 * h->nmo[s],
+                   (const unsigned char*)h->b_sel[s].p + (size_t)i_s * W, (long)W * 5 * h->nmo[s]));
+    const bool block_done = (i_s == j_hi - 1);
+    const bool need_flush = block_done && (j_hi - j_lo < n_s);
+    // the next electron's inverse row is current after this move's commit unless it opens a new block of the SAME spin
+    const bool fuse_next = (e + 1 < N) && !(need_flush && i_s + 1 < n_s);
+    hipEvent_t pe1 = nullptr;
+    if (h->profile && (e % (4 * (int)h->prof_stride)) == 1) {  // sparsely sampled full (decide + propose) launches: an event pair costs ~2 us of stream time
+      if (h->prof3_used == h->prof3_events.size()) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        h->prof3_events.emplace_back(a, b);
+      }
+      if (fuse_next) {
         HIPCHK(hipEventRecord(h->prof3_events[h->prof3_used].first, h->stream));
         pe1 = h->prof3_events[h->prof3_used].second;
         ++h->prof3_used;
       }
-      PQA_MOVE_PART(mb.newpos, mo);
-#undef PQA_MOVE_PART
-      if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
-      if (h->cplx) hipLaunchKernelGGL(k_accept_fin_lw<true>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
-                                      (const double*)part, rbuf, vbuf, act, mo);
-      else hipLaunchKernelGGL(k_accept_fin_lw<false>, gw, dim3(64), 0, h->stream, h->S, L, mb, e, (int)h->has_jastrow, W, Gm,
-                              (const double*)part, rbuf, vbuf, act, mo);
-      const int Gc = std::min(G, std::max(j_hi - j_lo, 1));
-      const dim3 gcm(gw.x, (unsigned)Gc);
-#define PQA_COMMIT(NM) do { if (h->cplx) hipLaunchKernelGGL((k_commit_lw<NM, true, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
-                          else if (h->lw_fullline) hipLaunchKernelGGL((k_commit_lw<NM, true>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); \
-                          else hipLaunchKernelGGL((k_commit_lw<NM, false>), gcm, dim3(64), 0, h->stream, h->S, L, mb, e, mo, (const double*)rbuf, (const double*)vbuf, W, Gc, j_lo, j_hi); } while (0)
-      if (rowlen <= 8) PQA_COMMIT(8); else if (rowlen <= 16) PQA_COMMIT(16); else if (rowlen <= 32) PQA_COMMIT(32); else PQA_COMMIT(64);
-#undef PQA_COMMIT
-      if (i_s == j_hi - 1 && j_hi - j_lo < n_s) {  // block finished: bring every other row of this spin up to date
-        const int nq = j_hi - j_lo;
-        hipEvent_t ce1 = nullptr;
-        if (h->profile && ((j_lo / std::max(KB, 1)) % 4) == 0) {  // every 4th flush of a spin
-          if (h->prof2_used == h->prof2_events.size()) {
-            hipEvent_t a, b;
-            HIPCHK(hipEventCreate(&a));
-            HIPCHK(hipEventCreate(&b));
-            h->prof2_events.emplace_back(a, b);
-          }
-          HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
-          ce1 = h->prof2_events[h->prof2_used].second;
-          ++h->prof2_used;
-        }
-#define PQA_FLUSH(NM) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * PQA_FLUSH_WB * sizeof(double); const dim3 gf((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)); \
-        if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
-        else hipLaunchKernelGGL((k_flush_lw<NM, false>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
-        if (rowlen <= 8) PQA_FLUSH(8); else if (rowlen <= 16) PQA_FLUSH(16); else if (rowlen <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
-#undef PQA_FLUSH
-        if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
-      }
-      continue;
     }
+    step(e, fuse_next ? e + 1 : -1);
+    if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
+    if (need_flush) {  // block finished: bring every other row of this spin up to date
+      const int nq = j_hi - j_lo;
+      hipEvent_t ce1 = nullptr;
+      if (h->profile && ((j_lo / std::max(KB, 1)) % 4) == 0) {  // every 4th flush of a spin
+        if (h->prof2_used == h->prof2_events.size()) {
+          hipEvent_t a, b;
+          HIPCHK(hipEventCreate(&a));
+          HIPCHK(hipEventCreate(&b));
+          h->prof2_events.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
+        ce1 = h->prof2_events[h->prof2_used].second;
+        ++h->prof2_used;
+      }
+#define PQA_FLUSH(NM) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * PQA_FLUSH_WB * sizeof(double); const dim3 gf((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)); \
+      if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
+      else hipLaunchKernelGGL((k_flush_lw<NM, false>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
+      if (rowlen <= 8) PQA_FLUSH(8); else if (rowlen <= 16) PQA_FLUSH(16); else if (rowlen <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#undef PQA_FLUSH
+      if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
+    }
+    if (!fuse_next && e + 1 < N) step(-1, e + 1);
+  }
+  return 0;
+}
+
+// One proposal per electron, in index order, on the SoA state (lw: two launches per move, above) or the AoS state with the
+// wave-per-walker kernels (multi-determinant, three-body, large complex determinants); mb.dmc selects the DMC variant.
+static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) {
+  if (lw) return sweep_electrons_fused(h, mb, lc);
+  const long W = h->W;
+  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
+  for (int e = 0; e < h->N; ++e) {
+    const int s = e >= h->nup;
+    const double* mo = (const double*)h->b_motmp.p;
     if (h->cplx) {
       hipLaunchKernelGGL(k_propose<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
                          (int)h->has_slater, (int)h->has_jastrow, W);
       if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
       hipLaunchKernelGGL(k_accept<true>, dim3((unsigned)W), dim3(64), 2 * lds_acc, h->stream, h->S, h->st, h->js, mb, e,
-                         (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_motmp.p, W);
+                         (int)h->has_slater, (int)h->has_jastrow, mo, W);
       continue;
     }
     hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
@@ -2444,7 +2493,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
             TRY(ensure(h, h->b_emo[s], (size_t)na_s[s] * 5 * nmo_max * sizeof(double)));
             TRY(launch_orb(h, s, plain_points(B.acc_pos + 3 * a0_s[s], na_s[s]), na_s[s], 5, (double*)h->b_emo[s].p));
             hipLaunchKernelGGL(k_tm_cache, dim3((unsigned)na_s[s]), dim3(64), 0, h->stream, h->S, h->st, (const int*)(B.acc_idx + a0_s[s]),
-                               (const double*)h->b_emo[s].p, s, W, lw ? (double*)h->b_ct[s].p : (double*)nullptr);
+                               (const double*)h->b_emo[s].p, s, W, lw ? (double*)h->b_rc[s].p : (double*)nullptr, lw ? (const uint8_t*)h->b_sel[s].p : (const uint8_t*)nullptr);
           }
           TRY(check_launch(h, "k_tm_cache"));
         }

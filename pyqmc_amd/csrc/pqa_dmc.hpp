@@ -470,22 +470,17 @@ __global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __rest
 }
 
 // orbital-row cache (value, gradient, Laplacian) of the accepted T-moves of one spin.  mo5: [count][5][nmo_s] rows at the
-// new positions, idx: the matching (e*W + w) entries.  ct: the walker-fastest copy [n][5 nmo][W] of the lane-per-walker
-// sweep when that holds the live cache, else NULL (st.cache).  grid = count, block = 64.
+// new positions, idx: the matching (e*W + w) entries.  rc / sel: the two-slot row cache of the lane-per-walker sweep when that
+// holds the live cache (the row replaces the CURRENT slot's), else NULL (st.cache).  grid = count, block = 64.
 __global__ __launch_bounds__(64) void k_tm_cache(SysDev S, SlaterState st, const int* __restrict__ idx, const double* __restrict__ mo5,
-                                                 int s, long W, double* __restrict__ ct) {
+                                                 int s, long W, double* __restrict__ rc, const uint8_t* __restrict__ sel) {
   const long a = blockIdx.x;
   const long i = idx[a];
   const int e = (int)(i / W);
   const long w = i - (long)e * W;
-  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const int n = s ? S.ndn : S.nup, nmo = S.nmo[s], ie = e - s * S.nup;
   const double* row = mo5 + (size_t)a * 5 * nmo;
-  if (ct) {
-    double* c = ct + (size_t)(e - s * S.nup) * 5 * nmo * W + w;
-    for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[(size_t)k * W] = row[k];
-    return;
-  }
-  double* c = st.cache[s] + ((size_t)w * n + (e - s * S.nup)) * 5 * nmo;
+  double* c = rc ? rc + (((size_t)ie * 2 + sel[(size_t)ie * W + w]) * W + w) * 5 * nmo : st.cache[s] + ((size_t)w * n + ie) * 5 * nmo;
   for (int k = threadIdx.x; k < 5 * nmo; k += 64) c[k] = row[k];
 }
 

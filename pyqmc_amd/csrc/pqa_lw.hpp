@@ -16,7 +16,11 @@
 // SoA state (walker index fastest):
 //   xt   [N][3][W]            coordinates
 //   Tt   [s] [n][n][W]        inverse, electron-major: Tt[i][k][w] = inverse[k][i]
-//   ct   [s] [n][5][nmo][W]   cached MO value/grad/lap rows of every electron
+//   rc   [s] [n][2][W][5][nmo] cached MO value/grad/lap rows of every electron, TWO slots of point-major rows (the layout
+//                              the orbital kernel writes), sel [s][n][W] = the slot that holds the current position's row.
+//        A proposal of electron i is written by the orbital kernel straight into the walker's OTHER slot and accepting it
+//        flips the selector byte: no copy (round 2 kept the cache walker-fastest and copied / transposed every accepted row
+//        into it: 40 us of the ~160 us a move's bookkeeping kernel took at 65536 walkers, 3.8 ms of a 31.7 ms step).
 // Complex determinants (CX instantiations; conventions of pqa_cslater.hpp): nmo counts REAL columns [Re | Im], so orbital o of a
 // row is (row[o], row[nmo/2 + o]); the inverse is (re, im) interleaved in the walker-major layout, i.e. planes
 // Tt[i][k][2][W] after the transpose; dsign is a unit phase [W][2]; V / R buffers hold 2 n planes.  The drift uses
@@ -29,11 +33,16 @@
 struct LwState {
   double* xt;
   double* Tt[2];
-  double* ct[2];
+  double* rc[2];
+  uint8_t* sel[2];
   double* dsign[2];  // [W] (single determinant) — shared with SlaterState
   double* dlog[2];
   double* auxt;      // [8][W]: scaled gaussian (3), limited drift (3), U_old, ratio
 };
+// cached / proposed orbital row [5][nmo] of electron i (of spin s) of walker w in slot `slot`
+__device__ __forceinline__ double* lw_row(const LwState& L, int s, int i, int slot, long w, long W, int nmo) {
+  return L.rc[s] + (((size_t)i * 2 + slot) * W + w) * 5 * nmo;
+}
 
 // ---------------------------------------------------------------- layout transposes
 // in [R][C] -> out [C][R] through a 32x33 LDS tile; block (32,8)
@@ -51,6 +60,22 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
   }
 }
 
+// walker-major orbital cache [W][n][5 nmo] <-> the two-slot row cache.  to_rc: everything lands in slot 0 (selectors cleared);
+// from_rc: every electron's CURRENT slot.  grid = (W, n, ceil(row / 256)), block = 256.
+__global__ __launch_bounds__(256) void k_cache_to_rc(const double* __restrict__ aos, double* __restrict__ rc, uint8_t* __restrict__ sel, int n,
+                                                     int row, long W) {
+  const long w = blockIdx.x;
+  const int i = blockIdx.y, k = blockIdx.z * 256 + threadIdx.x;
+  if (k == 0) sel[(size_t)i * W + w] = 0;
+  if (k < row) rc[(((size_t)i * 2) * W + w) * row + k] = aos[((size_t)w * n + i) * row + k];
+}
+__global__ __launch_bounds__(256) void k_cache_from_rc(const double* __restrict__ rc, const uint8_t* __restrict__ sel, double* __restrict__ aos,
+                                                       int n, int row, long W) {
+  const long w = blockIdx.x;
+  const int i = blockIdx.y, k = blockIdx.z * 256 + threadIdx.x;
+  if (k < row) aos[((size_t)w * n + i) * row + k] = rc[(((size_t)i * 2 + sel[(size_t)i * W + w]) * W + w) * row + k];
+}
+
 // ---------------------------------------------------------------- per-lane Jastrow
 // Contribution of the pairs j = j0, j0+dj, ... and ions I = j0, j0+dj, ... to U_e, grad U_e, (bare) lap U_e
 // of electron e of walker w at (rx,ry,rz); MODE 2 also returns that share of the Coulomb sums
@@ -64,7 +89,7 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
 // were scalar loads inside the innermost loop — two dependent load-and-wait pairs per function and pair, ~90 per thread —
 // and with four waves per SIMD those waits, not the arithmetic, set the kernel's time.  Same operations in the same order.
 template <int MODE, bool PBC, bool FAST>
-__device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
+__device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                                 double (&g)[3], double& lapU, double& ee, double& ei) {
   constexpr int NF = PQA_JAS_NF;
@@ -170,7 +195,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* _
   U = u_; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
 }
 template <int MODE, bool PBC>
-__device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __restrict__ xt, long W, long w, int e,
+__device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei) {
   if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei);
@@ -189,32 +214,39 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* __r
 #define PQA_LW_PART_ROWS(CX) ((CX) ? 12 : 8)
 // (Forcing 6 or 8 waves per SIMD spills — 76 / 120 us against 66 — and twice the groups at the same occupancy changes nothing:
 // the kernel moves ~4 KB per walker at ~4 TB/s.)
-template <bool PBC, bool CX = false>
-__global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e, int has_jastrow, const double* __restrict__ pos,
-                                                     const double* __restrict__ rows, long W, int G, double* __restrict__ part) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  const int g = blockIdx.y;
-  if (w >= W) return;
+// Share of thread group g (of G) in the sums of electron e of walker w at (px, py, pz): Slater sums of the orbital row
+// `row` ([5][nmo], point-major: the proposal's row or the cached one) against the inverse row, Jastrow sums against the
+// walker's coordinates; p[] in the row order above.
+template <bool PBC, bool CX>
+__device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, int e, int has_jastrow, double px, double py, double pz,
+                                             const double* row, long W, long w, int g, int G,
+                                             double (&p)[PQA_LW_PART_ROWS(CX)]) {
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
-  double px, py, pz;
-  if (pos) { px = pos[3 * w]; py = pos[3 * w + 1]; pz = pos[3 * w + 2]; }
-  else { const double* xe = L.xt + (size_t)e * 3 * W + w; px = xe[0]; py = xe[W]; pz = xe[2 * W]; }
   double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;  // q: imaginary parts (CX)
 #ifndef PQA_MP_NOSLATER
   {
     const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
     const int* occ = S.det_occ[s];
     const int nh = nmo / CF;  // orbitals
-    // group g takes a CONTIGUOUS range of orbital slots: the proposal's rows are point-major (k_orb's output, 1280 B per
-    // walker), so a thread's consecutive slots share 64-byte lines (4 lines per thread and component instead of 8
-    // lines used 8 bytes each when the slots were dealt round-robin: 53 -> 22 us of this kernel)
+    // group g takes a CONTIGUOUS range of orbital slots: the rows are point-major (1280 B per walker at 32 orbitals), so a
+    // thread's consecutive slots share 64-byte lines
     const int nj = (n + G - 1) / G, jb = g * nj, je = (jb + nj < n) ? jb + nj : n;
-    if (rows && !CX && S.occ_ident[s] && ((jb | (je - jb) | nmo) & 3) == 0) {
-      // ground-state occupation: the slots are the orbitals themselves, so the thread's slice of each component row is read 32
-      // bytes at a time (64 lanes on 64 different rows: a quarter of the load instructions / cache-line visits); same
-      // operations in the same order
-      const double* row = rows + (size_t)w * 5 * nmo;
+    if (!CX && S.occ_ident[s] && ((jb | (je - jb) | nmo) & 7) == 0) {
+      // ground-state occupation, 8 slots at a time: a lane's slice of a component row is ONE 64-byte line, fetched by two
+      // adjacent 32-byte loads and used up at once (64 lanes sit on 64 different rows: nothing is shared between lanes, and a
+      // half-used line does not survive in L1 until the next slots come round).  Same operations in the same order per sum.
+      for (int j = jb; j < je; j += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = Ti[(size_t)(j + u) * W];
+#define PQA_ROW8(C, ACC) do { const double4 lo = *reinterpret_cast<const double4*>(row + (C) * nmo + j), hi = *reinterpret_cast<const double4*>(row + (C) * nmo + j + 4); \
+          ACC += lo.x * t[0]; ACC += lo.y * t[1]; ACC += lo.z * t[2]; ACC += lo.w * t[3]; ACC += hi.x * t[4]; ACC += hi.y * t[5]; ACC += hi.z * t[6]; ACC += hi.w * t[7]; } while (0)
+        PQA_ROW8(0, r0); PQA_ROW8(1, r1); PQA_ROW8(2, r2); PQA_ROW8(3, r3);
+#undef PQA_ROW8
+      }
+    } else if (!CX && S.occ_ident[s] && ((jb | (je - jb) | nmo) & 3) == 0) {
+      // ... 4 slots (32 bytes per load) where the slices are shorter
       for (int j = jb; j < je; j += 4) {
         const double4 a0 = *reinterpret_cast<const double4*>(row + j), a1 = *reinterpret_cast<const double4*>(row + nmo + j);
         const double4 a2 = *reinterpret_cast<const double4*>(row + 2 * nmo + j), a3 = *reinterpret_cast<const double4*>(row + 3 * nmo + j);
@@ -224,8 +256,7 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
         r0 += a0.z * t2; r1 += a1.z * t2; r2 += a2.z * t2; r3 += a3.z * t2;
         r0 += a0.w * t3; r1 += a1.w * t3; r2 += a2.w * t3; r3 += a3.w * t3;
       }
-    } else if (rows) {
-      const double* row = rows + (size_t)w * 5 * nmo;
+    } else {
 #pragma unroll 4
       for (int j = jb; j < je; ++j) {
         const int o = occ[j];
@@ -240,23 +271,6 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
           r0 += row[o] * t; r1 += row[nmo + o] * t; r2 += row[2 * nmo + o] * t; r3 += row[3 * nmo + o] * t;
         }
       }
-    } else {
-      const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
-#pragma unroll 4
-      for (int j = jb; j < je; ++j) {
-        const double* cj = ci + (size_t)occ[j] * W;
-        if (CX) {
-          const double tr = Ti[(size_t)(2 * j) * W], ti = Ti[(size_t)(2 * j + 1) * W];
-          const double* dj = cj + (size_t)nh * W;  // imaginary parts
-          const double a0 = cj[0], b0 = dj[0], a1 = cj[(size_t)nmo * W], b1 = dj[(size_t)nmo * W];
-          const double a2 = cj[(size_t)2 * nmo * W], b2 = dj[(size_t)2 * nmo * W], a3 = cj[(size_t)3 * nmo * W], b3 = dj[(size_t)3 * nmo * W];
-          r0 += a0 * tr - b0 * ti; q0 += a0 * ti + b0 * tr; r1 += a1 * tr - b1 * ti; q1 += a1 * ti + b1 * tr;
-          r2 += a2 * tr - b2 * ti; q2 += a2 * ti + b2 * tr; r3 += a3 * tr - b3 * ti; q3 += a3 * ti + b3 * tr;
-        } else {
-          const double t = Ti[(size_t)j * W];
-          r0 += cj[0] * t; r1 += cj[(size_t)nmo * W] * t; r2 += cj[(size_t)2 * nmo * W] * t; r3 += cj[(size_t)3 * nmo * W] * t;
-        }
-      }
     }
   }
 #endif
@@ -264,24 +278,11 @@ __global__ __launch_bounds__(64) void k_move_part_lw(SysDev S, LwState L, int e,
 #ifndef PQA_MP_NOJAS
   jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
 #endif
-  constexpr int PR = PQA_LW_PART_ROWS(CX);
-  double* p = part + (size_t)g * PR * W + w;
   if (CX) {  // rows: Re r0, Im r0, Re r1, Im r1, ..., then U, grad U
-    p[0] = r0; p[W] = q0; p[2 * W] = r1; p[3 * W] = q1; p[4 * W] = r2; p[5 * W] = q2; p[6 * W] = r3; p[7 * W] = q3;
-    p[8 * W] = U; p[9 * W] = gg[0]; p[10 * W] = gg[1]; p[11 * W] = gg[2];
+    p[0] = r0; p[1] = q0; p[2] = r1; p[3] = q1; p[4] = r2; p[5] = q2; p[6] = r3; p[7] = q3;
+    p[PQA_LW_PART_ROWS(CX) - 4] = U; p[PQA_LW_PART_ROWS(CX) - 3] = gg[0]; p[PQA_LW_PART_ROWS(CX) - 2] = gg[1]; p[PQA_LW_PART_ROWS(CX) - 1] = gg[2];
   } else {
-    p[0] = r0; p[W] = r1; p[2 * W] = r2; p[3 * W] = r3; p[4 * W] = U; p[5 * W] = gg[0]; p[6 * W] = gg[1]; p[7 * W] = gg[2];
-  }
-}
-
-template <int PR>
-__device__ __forceinline__ void lw_sum_parts(const double* __restrict__ part, long W, long w, int G, double (&v)[PR]) {
-#pragma unroll
-  for (int c = 0; c < PR; ++c) v[c] = 0.0;
-  for (int g = 0; g < G; ++g) {
-    const double* p = part + (size_t)g * PR * W + w;
-#pragma unroll
-    for (int c = 0; c < PR; ++c) v[c] += p[(size_t)c * W];
+    p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r3; p[4] = U; p[5] = gg[0]; p[6] = gg[1]; p[7] = gg[2];
   }
 }
 // Slater part of the summed partials -> gradient of log|Psi_S| (real part for complex orbitals), determinant ratio (re, im)
@@ -297,220 +298,15 @@ __device__ __forceinline__ void lw_slater_terms(const double (&v)[PR], double& g
   }
 }
 
-// drift at the current position, proposal r' = r + sqrt(tau) z + tau limdrift(grad)   (mc.py:117-121)
-template <bool CX = false>
-__global__ __launch_bounds__(64) void k_propose_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, long W, int G,
-                                                       const double* __restrict__ part) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  if (w >= W) return;
-  constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4;
-  double v[PR];
-  lw_sum_parts<PR>(part, W, w, G, v);
-  double gx, gy, gz, dr, di;
-  lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
-  gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
-  if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (dmc.py:50-52)
-  else limdrift3(gx, gy, gz);
-  double z0, z1, z2, z3;
-  if (mb.gauss) {
-    const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
-    z0 = zt[0]; z1 = zt[1]; z2 = zt[2];
-  } else {
-    normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
-    normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
-  }
-  const double sq = sqrt(mb.tstep);
-  z0 *= sq; z1 *= sq; z2 *= sq;
-  const double* xe = L.xt + (size_t)e * 3 * W + w;
-  double* np_ = mb.newpos + 3 * w;
-  const double df = mb.dmc ? 1.0 : mb.tstep;
-  np_[0] = xe[0] + z0 + gx * df;
-  np_[1] = xe[W] + z1 + gy * df;
-  np_[2] = xe[2 * W] + z2 + gz * df;
-  if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
-  double* a = L.auxt + w;
-  a[0] = z0; a[W] = z1; a[2 * W] = z2; a[3 * W] = gx; a[4 * W] = gy; a[5 * W] = gz; a[6 * W] = v[JU];
-}
-
-// Metropolis decision (mc.py:124-132); accepted walkers: move the coordinate, update sign/log of the
-// determinant, and stage R[k] = T[i][k]/ratio in Rbuf[n][W] (complex: [n][2][W]) for the commit kernel.
-template <bool CX = false>
-__global__ __launch_bounds__(64) void k_accept_fin_lw(SysDev S, LwState L, MoveBuf mb, int e, int has_jastrow, long W, int G,
-                                                      const double* __restrict__ part, double* __restrict__ Rbuf,
-                                                      double* __restrict__ Vbuf, uint8_t* __restrict__ act,
-                                                      const double* __restrict__ motmp) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  if (w >= W) return;
-  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4, CF = CX ? 2 : 1;
-  double v[PR];
-  lw_sum_parts<PR>(part, W, w, G, v);
-  double gx, gy, gz, dr, di;
-  lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
-  gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
-  const double* a = L.auxt + w;
-  double val2;  // |Psi(new)/Psi|^2 (mc.py:131)
-  if (CX) val2 = finite_or(dr * dr + di * di, 1.0);
-  else { const double val = finite_or(dr, 1.0); val2 = val * val; }
-  if (has_jastrow) { const double ej = exp(v[JU] - a[6 * W]); val2 *= ej * ej; }
-  const double a0 = a[0], a1 = a[W], a2 = a[2 * W];
-  const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
-  double bx, by, bz;
-  if (mb.dmc) {  // dmc.py:57-60: backward = gauss + drift(old) + drift(new)
-    limdrift_dmc(gx, gy, gz, mb.tstep);
-    bx = a0 + a[3 * W] + gx; by = a1 + a[4 * W] + gy; bz = a2 + a[5 * W] + gz;
-  } else {
-    limdrift3(gx, gy, gz);
-    bx = a0 + mb.tstep * (a[3 * W] + gx); by = a1 + mb.tstep * (a[4 * W] + gy); bz = a2 + mb.tstep * (a[5 * W] + gz);
-  }
-  const double bwd = bx * bx + by * by + bz * bz;
-  const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
-  double ratio = val2 * t_prob;
-  if (mb.dmc && !CX) {
-    const double dv = finite_or(dr, 1.0);  // the Jastrow ratio is positive: np.sign(psi_ratio) is the determinant's
-    ratio *= (dv > 0.0) ? 1.0 : ((dv < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
-  }
-  double u;
-  if (mb.unif) u = mb.unif[(size_t)e * W + w];
-  else {
-    const Philox p = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
-    u = u01(p.c[0], p.c[1]);
-  }
-  const bool acc = ratio > u;
-  if (mb.dmc) {  // dmc.py:68 r2 = |gauss + drift|^2
-    const double rx = a0 + a[3 * W], ry = a1 + a[4 * W], rz = a2 + a[5 * W];
-    const double r2 = rx * rx + ry * ry + rz * rz;
-    mb.r2_prop[w] += r2;
-    if (acc) mb.r2_acc[w] += r2;
-  }
-  mb.accept[w] = acc;
-  act[w] = acc;
-  if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
-  if (!acc) return;
-  mb.acc_w[w] += 1;
-  double* xe = L.xt + (size_t)e * 3 * W + w;
-  xe[0] = mb.newpos[3 * w]; xe[W] = mb.newpos[3 * w + 1]; xe[2 * W] = mb.newpos[3 * w + 2];
-  if (mb.wrap) {
-    int* wr = mb.wrap + ((size_t)w * S.nelec + e) * 3;
-    wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
-  }
-  {
-    const double* row = motmp + (size_t)w * 5 * nmo;
-    const int* occ = S.det_occ[s];
-    const int nh = nmo / CF;
-    if (!CX && S.occ_ident[s] && ((n | nmo) & 3) == 0) {  // ground-state occupation: the value row 32 bytes per load (k_move_part_lw)
-#pragma unroll 2
-      for (int k = 0; k < n; k += 4) {
-        const double4 a = *reinterpret_cast<const double4*>(row + k);
-        Vbuf[(size_t)k * W + w] = a.x; Vbuf[(size_t)(k + 1) * W + w] = a.y; Vbuf[(size_t)(k + 2) * W + w] = a.z; Vbuf[(size_t)(k + 3) * W + w] = a.w;
-      }
-    } else
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) {
-      if (CX) { Vbuf[(size_t)(2 * k) * W + w] = row[occ[k]]; Vbuf[(size_t)(2 * k + 1) * W + w] = row[nh + occ[k]]; }
-      else Vbuf[(size_t)k * W + w] = row[occ[k]];
-    }
-  }
-  const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
-  if (CX) {  // dsign *= ratio / |ratio|, dlog += log|ratio|; R = T_old[i] / ratio (complex)
-    const double m2 = dr * dr + di * di, m = sqrt(m2), ur = dr / m, ui = di / m;
-    double* ds = L.dsign[s] + 2 * w;
-    const double sr = ds[0], si = ds[1];
-    ds[0] = sr * ur - si * ui; ds[1] = sr * ui + si * ur;
-    L.dlog[s][w] += 0.5 * log(m2);
-    const double ir = dr / m2, ii = -di / m2;  // 1 / ratio
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) {
-      const double tr = Ti[(size_t)(2 * k) * W], ti = Ti[(size_t)(2 * k + 1) * W];
-      Rbuf[(size_t)(2 * k) * W + w] = tr * ir - ti * ii;
-      Rbuf[(size_t)(2 * k + 1) * W + w] = tr * ii + ti * ir;
-    }
-  } else {
-    L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
-    L.dlog[s][w] += log(fabs(dr));
-    const double inv = 1.0 / dr;
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) Rbuf[(size_t)k * W + w] = Ti[(size_t)k * W] * inv;
-  }
-}
-
-// ---------------------------------------------------------------- commit (Sherman-Morrison, slater.py:88-94)
-// Blocked update.  Electrons of one spin are moved in index order, so a ratio or drift only ever needs the
-// inverse rows of electrons that have not moved yet in this sweep plus the current one.  The electrons are
-// grouped in blocks of KB; an accepted move of electron i updates immediately only the KB rows of its block
+// ---------------------------------------------------------------- Sherman-Morrison (slater.py:88-94), blocked
+// Electrons of one spin are moved in index order, so a ratio or drift only ever needs the inverse rows of electrons that
+// have not moved yet in this sweep plus the current one.  The electrons are grouped in blocks of KB; an accepted move of
+// electron i updates immediately only the KB rows of its block (in k_step_lw)
 //   T[j][k] -= R[k] * (V . T[j])   (j != i),     T[i][k] = R[k],     R = T_old[i]/ratio, V = new orbital row
-// and leaves (V, R) in the block buffers Vb/Rb[q][n][W] (q = position in the block, act[q][W] = accepted).
-// After the last electron of a block k_flush_lw applies the block's accepted updates, in order, to every
-// row outside the block while that row sits in registers.  Per row the arithmetic and its order are exactly
-// those of updating after every move, so the inverse is bitwise identical — but it crosses HBM once per
-// block instead of once per move (512*KB + 16384/KB bytes per move at n = 32: 2.7x less at KB = 8).
-// thread = (walker, row group g of G).  The 5*nmo cached orbital values of electron i are refreshed in slices
-// by the same groups.  NMAX >= n.
-// NMAX >= doubles per row (n real, 2 n complex)
-template <int NMAX, bool FULLLINE, bool CX = false>
-__global__ __launch_bounds__(64) void k_commit_lw(SysDev S, LwState L, MoveBuf mb, int e, const double* __restrict__ motmp,
-                                                  const double* __restrict__ Rbuf, const double* __restrict__ Vbuf, long W,
-                                                  int G, int j_lo, int j_hi) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  const int g = blockIdx.y;
-  if (w >= W) return;
-  // Rejected walkers take part in the loads and stores of the inverse rows (writing back what they read): a cache
-  // line holds 8 walkers, so it is fetched and written whenever one of them accepted anyway, and with every lane
-  // storing, the wave writes whole lines instead of byte-masked fragments.
-  const bool acc = mb.accept[w] != 0;
-  if (FULLLINE ? !__any(acc) : !acc) return;
-  const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
-  const int L_ = CX ? 2 * n : n;  // doubles per row
-  double* T = L.Tt[s] + w;
-  double V[NMAX], R[NMAX];
-#pragma unroll
-  for (int k = 0; k < NMAX; ++k) {
-    V[k] = (k < L_ && acc) ? Vbuf[(size_t)k * W + w] : 0.0;
-    R[k] = (k < L_ && acc) ? Rbuf[(size_t)k * W + w] : 0.0;
-  }
-  for (int j = j_lo + g; j < j_hi; j += G) {
-    double* Tj = T + (size_t)j * L_ * W;
-    if (j == i) {
-      if (acc) {
-#pragma unroll
-        for (int k = 0; k < NMAX; ++k)
-          if (k < L_) Tj[(size_t)k * W] = R[k];
-      }
-      continue;
-    }
-    double t[NMAX];
-    double tmp = 0.0, tmi = 0.0;
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
-    if (CX) {
-#pragma unroll
-      for (int k = 0; k < NMAX / 2; ++k) {  // tmp = sum_k V_k t_k (complex, no conjugation)
-        tmp += V[2 * k] * t[2 * k] - V[2 * k + 1] * t[2 * k + 1];
-        tmi += V[2 * k] * t[2 * k + 1] + V[2 * k + 1] * t[2 * k];
-      }
-#pragma unroll
-      for (int k = 0; k < NMAX / 2; ++k)
-        if (2 * k < L_) {
-          const double ur = R[2 * k] * tmp - R[2 * k + 1] * tmi, ui = R[2 * k] * tmi + R[2 * k + 1] * tmp;
-          Tj[(size_t)(2 * k) * W] = acc ? t[2 * k] - ur : t[2 * k];
-          Tj[(size_t)(2 * k + 1) * W] = acc ? t[2 * k + 1] - ui : t[2 * k + 1];
-        }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k) tmp += V[k] * t[k];
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k)
-        if (k < L_) Tj[(size_t)k * W] = acc ? t[k] - R[k] * tmp : t[k];
-    }
-  }
-  if (!acc) return;
-  const double* row = motmp + (size_t)w * 5 * nmo;
-  double* c = L.ct[s] + (size_t)i * 5 * nmo * W + w;
-  const int nk = (5 * nmo + G - 1) / G, kb = g * nk, ke = (kb + nk < 5 * nmo) ? kb + nk : 5 * nmo;  // contiguous slice: whole lines of the point-major row
-#pragma unroll 8
-  for (int k = kb; k < ke; ++k) c[(size_t)k * W] = row[k];
-}
-
+// and leaves (V, R) in the block buffers Vb/Rb[q][n][W] (q = position in the block, act[q][W] = accepted).  After the last
+// electron of a block k_flush_lw applies the block's accepted updates, in order, to every row outside the block while that
+// row sits in registers.  Per row the arithmetic and its order are exactly those of updating after every move, so the
+// inverse is bitwise identical — but it crosses HBM once per block instead of once per move.
 // rows outside [j_lo, j_hi) of spin s: apply the block's nq buffered updates in order.  Vb/Rb: [KB][n][W], act: [KB][W].
 // Block = 16 walkers x 16 row groups: the block's update vectors (V_q, R_q of its 16 walkers, 2 nq n 16 doubles) are staged
 // in LDS once and shared by the row groups — read per row from global memory they were 4x the traffic of the inverse
@@ -586,6 +382,265 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   }
 }
 
+// ---------------------------------------------------------------- one launch per move (round 3)
+// k_step_lw = [decide electron e_acc: new-position sums, Metropolis test, Sherman-Morrison commit of the block rows, cache row,
+// coordinate]  followed by  [propose electron e_prop: old-position sums, drift, proposal] — what round 2 did in six launches
+// per move (two partial-sum launches, two thread-per-walker finish kernels, the commit) is ONE launch between two orbital
+// evaluations.  Block = NW walkers x G thread groups: the groups' partial sums meet in LDS (added in group order, exactly as
+// the finish kernels added the part[G] planes: bit-identical trajectories, checked against the six-launch build before it was
+// removed), every group repeats the per-walker scalar work (decision, proposal) and group 0 stores
+// it; the accepted walkers' update vectors V, R sit in LDS for the commit and go to the block buffers for the flush.  What a
+// move streams through HBM: the walker's coordinates once (were 2x + L2 re-reads by the finish kernels), no part[] planes, no
+// auxiliary round trips — and 2 dependent launches per move instead of 6 (the chain that sets the step time of small shards).
+// Either half can be switched off (e_acc < 0 / e_prop < 0): at a Sherman-Morrison block boundary the flush has to run
+// between the two halves.
+struct StepArgs {
+  int e_acc, e_prop;   // electron to decide / to propose (-1: skip that half)
+  int has_jastrow, G, NW;  // thread groups per walker, walkers per block (NW * G <= 256)
+  int j_lo, j_hi;      // Sherman-Morrison block of e_acc (rows of its spin)
+  long W;
+  double* Rbuf;        // block buffers, slot of e_acc: [L_][W]
+  double* Vbuf;
+  uint8_t* act;        // [W]
+};
+
+// Block = NW walkers x G groups, <= 256 threads.  WIDE: NW = 64, a wave is one group (g wave-uniform: table look-ups stay scalar
+// loads).  Otherwise NW = 16 or 32 and a wave holds 4 or 2 groups of the same walkers: small shards then spread over 4x / 2x
+// as many blocks — with 64 walkers per block 4096 walkers are 64 blocks on 64 of the 256 CUs, each issuing all 16 groups' work.
+template <bool PBC, bool CX, int NMAX, bool WIDE>
+__global__ __launch_bounds__(256) void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+  extern __shared__ double sh[];
+  constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4, CF = CX ? 2 : 1;
+  const int NW = WIDE ? 64 : a.NW;
+  const int lane = WIDE ? (int)(threadIdx.x & 63) : (int)threadIdx.x % NW;  // walker within the block
+  const int g = WIDE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)threadIdx.x / NW;
+  const int G = a.G;
+  const long W = a.W;
+  const long wr = (long)blockIdx.x * NW + lane;
+  const bool live = wr < W;
+  const long w = live ? wr : W - 1;  // lanes past the end shadow the last walker and store nothing
+  const bool lead = live && g == 0;
+  if (a.e_acc >= 0) {
+    const int e = a.e_acc;
+    const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+    const int L_ = CF * n;  // doubles per inverse row
+    // the proposal's orbital row: the orbital kernel wrote it into the slot the walker is NOT using
+    const int cur = L.sel[s][(size_t)i * W + w];
+    const double* row = lw_row(L, s, i, cur ^ 1, w, W, nmo);
+    double v[PR];
+    {
+      double p[PR];
+      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], row, W, w, g, G, p);
+#pragma unroll
+      for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < PR; ++c) v[c] = 0.0;
+    for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+      for (int c = 0; c < PR; ++c) v[c] += sh[(c * G + gg) * NW + lane];
+    }
+    // ---- Metropolis decision (mc.py:124-132; dmc.py:57-70), every group the same numbers
+    double gx, gy, gz, dr, di;
+    lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
+    gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
+    const double* ax = L.auxt + w;
+    double val2;  // |Psi(new)/Psi|^2 (mc.py:131)
+    if (CX) val2 = finite_or(dr * dr + di * di, 1.0);
+    else { const double val = finite_or(dr, 1.0); val2 = val * val; }
+    if (a.has_jastrow) { const double ej = exp(v[JU] - ax[6 * W]); val2 *= ej * ej; }
+    const double a0 = ax[0], a1 = ax[W], a2 = ax[2 * W], d0 = ax[3 * W], d1 = ax[4 * W], d2 = ax[5 * W];
+    const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
+    double bx, by, bz;
+    if (mb.dmc) {  // dmc.py:57-60: backward = gauss + drift(old) + drift(new)
+      limdrift_dmc(gx, gy, gz, mb.tstep);
+      bx = a0 + d0 + gx; by = a1 + d1 + gy; bz = a2 + d2 + gz;
+    } else {
+      limdrift3(gx, gy, gz);
+      bx = a0 + mb.tstep * (d0 + gx); by = a1 + mb.tstep * (d1 + gy); bz = a2 + mb.tstep * (d2 + gz);
+    }
+    const double bwd = bx * bx + by * by + bz * bz;
+    const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
+    double ratio = val2 * t_prob;
+    if (mb.dmc && !CX) {
+      const double dv = finite_or(dr, 1.0);  // the Jastrow ratio is positive: np.sign(psi_ratio) is the determinant's
+      ratio *= (dv > 0.0) ? 1.0 : ((dv < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
+    }
+    double u;
+    if (mb.unif) u = mb.unif[(size_t)e * W + w];
+    else {
+      const Philox ph = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
+      u = u01(ph.c[0], ph.c[1]);
+    }
+    const bool acc = ratio > u;
+    if (lead) {
+      if (mb.dmc) {  // dmc.py:68 r2 = |gauss + drift|^2
+        const double rx = a0 + d0, ry = a1 + d1, rz = a2 + d2;
+        const double r2 = rx * rx + ry * ry + rz * rz;
+        mb.r2_prop[w] += r2;
+        if (acc) mb.r2_acc[w] += r2;
+      }
+      a.act[w] = acc;
+      if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
+      if (acc) {
+        mb.acc_w[w] += 1;
+        L.sel[s][(size_t)i * W + w] = (uint8_t)(cur ^ 1);  // the proposal's row becomes the cached row
+        double* xe = L.xt + (size_t)e * 3 * W + w;
+        xe[0] = mb.newpos[3 * w]; xe[W] = mb.newpos[3 * w + 1]; xe[2 * W] = mb.newpos[3 * w + 2];
+        if (mb.wrap) {
+          int* wp = mb.wrap + ((size_t)w * S.nelec + e) * 3;
+          wp[0] += mb.dwrap[3 * w]; wp[1] += mb.dwrap[3 * w + 1]; wp[2] += mb.dwrap[3 * w + 2];
+        }
+        if (CX) {  // dsign *= ratio / |ratio|, dlog += log|ratio|
+          const double m2 = dr * dr + di * di, m = sqrt(m2), ur = dr / m, ui = di / m;
+          double* ds = L.dsign[s] + 2 * w;
+          const double sr = ds[0], si = ds[1];
+          ds[0] = sr * ur - si * ui; ds[1] = sr * ui + si * ur;
+          L.dlog[s][w] += 0.5 * log(m2);
+        } else {
+          L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+          L.dlog[s][w] += log(fabs(dr));
+        }
+      }
+    }
+    __syncthreads();  // the partial sums have been read: their LDS becomes the update vectors
+    // ---- V = new orbital row on the occupied slots, R = T_old[i] / ratio (slater.py:88-94); each group its slot range
+    double* shV = sh;
+    double* shR = sh + (size_t)L_ * NW;
+    {
+      const int* occ = S.det_occ[s];
+      const int nh = nmo / CF;
+      const double* Ti = L.Tt[s] + (size_t)i * L_ * W + w;
+      const int nj = (n + G - 1) / G, jb = g * nj, je = (jb + nj < n) ? jb + nj : n;
+      const bool st = acc && live;
+      if (CX) {
+        const double m2 = dr * dr + di * di;
+        const double ir = dr / m2, ii = -di / m2;  // 1 / ratio
+        for (int k = jb; k < je; ++k) {
+          const double vr = acc ? row[occ[k]] : 0.0, vi = acc ? row[nh + occ[k]] : 0.0;
+          const double tr = Ti[(size_t)(2 * k) * W], ti = Ti[(size_t)(2 * k + 1) * W];
+          const double rr = acc ? tr * ir - ti * ii : 0.0, ri = acc ? tr * ii + ti * ir : 0.0;
+          shV[(2 * k) * NW + lane] = vr; shV[(2 * k + 1) * NW + lane] = vi;
+          shR[(2 * k) * NW + lane] = rr; shR[(2 * k + 1) * NW + lane] = ri;
+          if (st) {
+            a.Vbuf[(size_t)(2 * k) * W + w] = vr; a.Vbuf[(size_t)(2 * k + 1) * W + w] = vi;
+            a.Rbuf[(size_t)(2 * k) * W + w] = rr; a.Rbuf[(size_t)(2 * k + 1) * W + w] = ri;
+          }
+        }
+      } else {
+        const double inv = 1.0 / dr;
+        for (int k = jb; k < je; ++k) {
+          const double vv = acc ? row[occ[k]] : 0.0;
+          const double rr = acc ? Ti[(size_t)k * W] * inv : 0.0;
+          shV[k * NW + lane] = vv;
+          shR[k * NW + lane] = rr;
+          if (st) { a.Vbuf[(size_t)k * W + w] = vv; a.Rbuf[(size_t)k * W + w] = rr; }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- rows of the electron block (k_flush_lw brings the others up to date when the block ends).  Rejected walkers take
+    // part in the loads and stores (writing back what they read): a cache line holds 8 walkers, so it is fetched and written
+    // whenever one of them accepted anyway, and with every lane storing the wave writes whole lines.
+#ifndef PQA_ST_NOCOMMIT
+    if (__any(acc)) {
+      double* T = L.Tt[s] + w;
+      for (int j = a.j_lo + g; j < a.j_hi; j += G) {
+        double* Tj = T + (size_t)j * L_ * W;
+        if (j == i) {
+          if (acc && live) {
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k)
+              if (k < L_) Tj[(size_t)k * W] = shR[k * NW + lane];
+          }
+          continue;
+        }
+        double t[NMAX];
+        double tmp = 0.0, tmi = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
+        if (CX) {
+#pragma unroll
+          for (int k = 0; k < NMAX / 2; ++k)
+            if (2 * k < L_) {  // tmp = sum_k V_k t_k (complex, no conjugation)
+              const double vr = shV[(2 * k) * NW + lane], vi = shV[(2 * k + 1) * NW + lane];
+              tmp += vr * t[2 * k] - vi * t[2 * k + 1];
+              tmi += vr * t[2 * k + 1] + vi * t[2 * k];
+            }
+          if (live) {
+#pragma unroll
+            for (int k = 0; k < NMAX / 2; ++k)
+              if (2 * k < L_) {
+                const double rr = shR[(2 * k) * NW + lane], ri = shR[(2 * k + 1) * NW + lane];
+                const double ur = rr * tmp - ri * tmi, ui = rr * tmi + ri * tmp;
+                Tj[(size_t)(2 * k) * W] = acc ? t[2 * k] - ur : t[2 * k];
+                Tj[(size_t)(2 * k + 1) * W] = acc ? t[2 * k + 1] - ui : t[2 * k + 1];
+              }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k)
+            if (k < L_) tmp += shV[k * NW + lane] * t[k];
+          if (live) {
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k)
+              if (k < L_) Tj[(size_t)k * W] = acc ? t[k] - shR[k * NW + lane] * tmp : t[k];
+          }
+        }
+      }
+    }
+#endif
+    __syncthreads();  // inverse rows, coordinate: visible to the other groups of this walker block
+  }
+  if (a.e_prop >= 0) {
+    // ---- drift at the current position, proposal r' = r + sqrt(tau) z + tau limdrift(grad)   (mc.py:117-121)
+    const int e = a.e_prop;
+    double v[PR];
+    {
+      double p[PR];
+      const int s = e >= S.nup, i = e - s * S.nup;
+      const double* xe = L.xt + (size_t)e * 3 * W + w;
+      const double* row = lw_row(L, s, i, L.sel[s][(size_t)i * W + w], w, W, S.nmo[s]);  // cached row of the current position
+      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, xe[0], xe[W], xe[2 * W], row, W, w, g, G, p);
+#pragma unroll
+      for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
+    }
+    __syncthreads();
+    if (!lead) return;
+#pragma unroll
+    for (int c = 0; c < PR; ++c) v[c] = 0.0;
+    for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+      for (int c = 0; c < PR; ++c) v[c] += sh[(c * G + gg) * NW + lane];
+    }
+    double gx, gy, gz, dr, di;
+    lw_slater_terms<CX, PR>(v, gx, gy, gz, dr, di);
+    gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
+    if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (dmc.py:50-52)
+    else limdrift3(gx, gy, gz);
+    double z0, z1, z2, z3;
+    if (mb.gauss) {
+      const double* zt = mb.gauss + ((size_t)e * W + w) * 3;
+      z0 = zt[0]; z1 = zt[1]; z2 = zt[2];
+    } else {
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
+    }
+    const double sq = sqrt(mb.tstep);
+    z0 *= sq; z1 *= sq; z2 *= sq;
+    const double* xe = L.xt + (size_t)e * 3 * W + w;
+    double* np_ = mb.newpos + 3 * w;
+    const double df = mb.dmc ? 1.0 : mb.tstep;
+    np_[0] = xe[0] + z0 + gx * df;
+    np_[1] = xe[W] + z1 + gy * df;
+    np_[2] = xe[2 * W] + z2 + gz * df;
+    if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
+    double* ao = L.auxt + w;
+    ao[0] = z0; ao[W] = z1; ao[2 * W] = z2; ao[3 * W] = gx; ao[4 * W] = gy; ao[5 * W] = gz; ao[6 * W] = v[JU];
+  }
+}
+
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
 // block = (64 walkers, PQA_KIN_EB electrons): one wave per electron, so the electron index — and with it the spin, the orbital
@@ -607,22 +662,38 @@ __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwStat
   double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   {
     const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
-    const double* ci = L.ct[s] + (size_t)i * 5 * nmo * W + w;
+    const double* row = lw_row(L, s, i, L.sel[s][(size_t)i * W + w], w, W, nmo);  // [5][nmo], this lane's own 1280-B row
     const int* occ = S.det_occ[s];
     const int nh = nmo / CF;
+    if (!CX && S.occ_ident[s] && ((n | nmo) & 7) == 0) {
+      // ground-state occupation: whole 64-byte lines of the lane's own row, two adjacent 32-byte loads each, used up at once
+      // (walking 4 slots of all five components first left every line half used until the next round: 320 lines per wave in
+      // flight, more than L1 keeps with 16 waves per CU — the kernel took 3.5 ms instead of 1.9)
+      for (int j = 0; j < n; j += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = Ti[(size_t)(j + u) * W];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const double4 lo = *reinterpret_cast<const double4*>(row + c * nmo + j), hi = *reinterpret_cast<const double4*>(row + c * nmo + j + 4);
+          r[c] += lo.x * t[0]; r[c] += lo.y * t[1]; r[c] += lo.z * t[2]; r[c] += lo.w * t[3];
+          r[c] += hi.x * t[4]; r[c] += hi.y * t[5]; r[c] += hi.z * t[6]; r[c] += hi.w * t[7];
+        }
+      }
+    } else
     for (int j = 0; j < n; ++j) {
-      const double* cj = ci + (size_t)occ[j] * W;
+      const double* cj = row + occ[j];
       if (CX) {
         const double tr = Ti[(size_t)(2 * j) * W], ti = Ti[(size_t)(2 * j + 1) * W];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-          const double a = cj[(size_t)c * nmo * W], b = cj[((size_t)c * nmo + nh) * W];
+          const double a = cj[c * nmo], b = cj[c * nmo + nh];
           r[c] += a * tr - b * ti; q[c] += a * ti + b * tr;
         }
       } else {
         const double t = Ti[(size_t)j * W];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) r[c] += cj[(size_t)c * nmo * W] * t;
+        for (int c = 0; c < 5; ++c) r[c] += cj[c * nmo] * t;
       }
     }
   }

@@ -259,10 +259,11 @@ def branch(configs, weights, base_u=None, on_resample=None):
 
 def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=None, accumulators=None, verbose=False,
            ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False, recompute_every=10,
-           hdf_file=None):
-    """Block loop of the reference's ``rundmc`` (no restart files): VMC warm-up, energy reference, then
-    propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every rank calls this with
-    its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo).
+           hdf_file=None, continue_from=None, blockoffset=0):
+    """Block loop of the reference's ``rundmc`` (dmc.py:413-591): VMC warm-up and energy reference — or, when ``hdf_file``
+    exists / ``continue_from`` is given, the walkers, weights, ``e_trial``, ``e_est``, ``esigma`` and block offset of that
+    file (dmc.py:466-500) — then propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every
+    rank calls this with its own walker shard and the energy sums / branching go through ``pyqmc_amd.dist`` (RCCL or gloo).
 
     Runs on the fused path branch ON THE DEVICE: the comb's indices gather the wave-function state (``pqa_resample``;
     sharded runs: ``dist.branch_distributed`` -> ``pqa_branch_exchange``, which also recomputes the walkers that arrived
@@ -270,30 +271,62 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     branch (dmc.py:155); a full recompute every ``recompute_every`` blocks bounds the round-off the Sherman-Morrison
     updates accumulate (``recompute_every=1`` is the reference's schedule).
     ``hdf_file``: per-block output, walkers and weights in the reference's on-disk layout (``dmc_file`` dmc.py:379-391;
-    ``pyqmc_amd.blockfile``), written by rank 0 of a sharded run for its own shard."""
+    ``pyqmc_amd.blockfile``).  A sharded run writes one file per rank — rank 0 ``hdf_file`` itself, rank r
+    ``hdf_file + ".rank<r>"`` — each with the (identical, all-reduced) block record and that rank's own walkers and
+    weights, so no two processes ever touch one file and every rank can continue from its own."""
     from . import dist as pdist
     from .blockfile import BlockFile
-
-    out = None if hdf_file is None else BlockFile(hdf_file)
     from .vmc import vmc
 
+    def rank_path(path):
+        if path is None or not distributed:
+            return path
+        import torch.distributed as td
+
+        r = td.get_rank() if td.is_available() and td.is_initialized() else 0
+        return path if r == 0 else f"{path}.rank{r}"
+
+    hdf_file, continue_from = rank_path(hdf_file), rank_path(continue_from)
+    out = None if hdf_file is None else BlockFile(hdf_file)
     nsteps_per_block = max(1, int(0.1 / tstep)) if nsteps_per_block is None else nsteps_per_block
     acc = accumulators[ekey[0]]
-    _, configs = vmc(wf, configs, nblocks=vmc_warmup, accumulators={}, verbose=verbose)
-    wf.recompute(configs)
-    en = np.real(acc(configs, wf)[ekey[1]])
-    if distributed:
-        (m1, m2), _ = pdist.allreduce_block([en.sum(), (en**2).sum()], len(en))
-        eref, esigma = m1, np.sqrt(max(m2 - m1 * m1, 0.0))
+    if continue_from is not None and out is not None and out.exists():  # dmc.py:467-470
+        raise RuntimeError(f"continue_from is set but hdf_file={hdf_file} already exists! Delete or rename {hdf_file} and try again.")
+    if continue_from is None and out is not None and out.exists():
+        continue_from = hdf_file
+    history = {}
+    if continue_from is not None:
+        src = BlockFile(continue_from)
+        if not src.exists():
+            raise FileNotFoundError(f"continue_from={continue_from}: no such block file")
+        data = src.datasets()
+        if "e_trial" not in data:
+            raise ValueError("Did not find e_trial in the restart file. This may mean that you are trying to restart from a different version of DMC")
+        blockoffset = int(data["block"][-1]) + 1
+        w_file = src.load_walkers(configs)
+        weights = weights if w_file is None else w_file
+        e_trial, e_est, esigma = float(np.real(data["e_trial"][-1])), float(np.real(data["e_est"][-1])), float(np.real(data["esigma"][-1]))
+        if continue_from == hdf_file:  # estimate_energy reads the whole file (dmc.py:594-603): the earlier blocks count
+            history = {"en": list(data[ekey[0] + ekey[1]]), "wt": list(data["weight"])}
+        if verbose:
+            print(f"Restarting calculation {continue_from} from block {blockoffset}")
     else:
-        eref, esigma = en.mean(), en.std()
-    e_trial = e_est = eref
+        _, configs = vmc(wf, configs, nblocks=vmc_warmup, accumulators={}, verbose=verbose)
+        wf.recompute(configs)
+        en = np.real(acc(configs, wf)[ekey[1]])
+        if distributed:
+            (m1, m2), _ = pdist.allreduce_block([en.sum(), (en**2).sum()], len(en))
+            eref, esigma = m1, np.sqrt(max(m2 - m1 * m1, 0.0))
+        else:
+            eref, esigma = en.mean(), en.std()
+        e_trial = e_est = eref
     W = configs.configs.shape[0]
     weights = np.ones(W) if weights is None else weights
     rows = []
+    en_hist, wt_hist = list(history.get("en", [])), list(history.get("wt", []))
     dev = fused_dmc_supported(wf, accumulators, ekey)  # device-resident branching: single process AND sharded runs
     current = False
-    for block in range(nblocks):
+    for block in range(blockoffset, nblocks):
         blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
                                               nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey,
                                               state_current=current and block % max(int(recompute_every), 1) != 0)
@@ -318,8 +351,9 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
         rows.append(blk)
         if out is not None:
             out.append(blk, {}, configs, weights)  # the reference's DMC file has no attributes: tstep is a per-block dataset
-        en_b = np.array([r[ekey[0] + ekey[1]] for r in rows])
-        wt_b = np.array([r["weight"] for r in rows])
+        en_hist.append(blk[ekey[0] + ekey[1]])
+        wt_hist.append(blk["weight"])
+        en_b, wt_b = np.array(en_hist), np.array(wt_hist)
         warm = len(en_b) // 4
         e_est = float(np.real(np.average(en_b[warm:], weights=wt_b[warm:])))  # estimate_energy, dmc.py:594-603
         e_trial = e_est - feedback * float(np.real(np.log(mean_w)))

@@ -34,6 +34,11 @@ class OracleAccumulator:
     def __call__(self, configs, wf, rot=None, unif=None):
         from oracle import energy as oenergy
 
+        if rot is None:  # no replay tape: draw like the reference does, from numpy's global generator
+            W, N = configs.configs.shape[:2]
+            necp, rng = self._device(wf).necp, dmc._NumpyRNG()
+            unif = np.array([[rng.random(W) for _ in range(necp)] for _ in range(N)])
+            rot = np.array([[rng.rot() for _ in range(necp)] for _ in range(N)])
         return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif)
 
     def has_nonlocal_moves(self):
@@ -52,6 +57,9 @@ class OracleAccumulator:
             def random(s, W):
                 return next(s.u)
 
+        if rot is None:
+            W, necp, rng = configs.configs.shape[0], self._device(wf).necp, dmc._NumpyRNG()
+            unif, rot = [rng.random(W) for _ in range(necp)], [rng.rot() for _ in range(necp)]
         ratio, weight, pos = odmc.compute_tmoves(self.mol, configs, wf, e, self.threshold, tau, T())
         return {"ratio": ratio, "weight": weight, "configs": configs.make_irreducible(e, pos)}
 
@@ -239,3 +247,93 @@ def test_driver_reproduces_reference_periodic_dmc_propagate():
     assert set(df.keys()) == set(g["df_keys"].tolist())
     for k in df:
         assert relerr(df[k], g["df_" + k]) < 1e-9, k
+
+
+def _small_dmc(path, nblocks, W=6, seed=3, distributed=False, **kw):
+    """rundmc over the ORACLE wave function (protocol route) on a handful of H2O walkers, block file at `path`."""
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    np.random.seed(seed)
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(seed))
+    return dmc.rundmc(wf, cfg, tstep=0.05, nblocks=nblocks, nsteps_per_block=1, vmc_warmup=1, distributed=distributed,
+                      accumulators={"energy": OracleAccumulator(mol)}, hdf_file=path, **kw)
+
+
+def test_rundmc_continues_an_existing_block_file(tmp_path):
+    """dmc.py:466-500: a second rundmc on the same hdf_file restarts from the stored walkers and weights, takes e_trial, e_est
+    and esigma from the file's last block, numbers its blocks from block[-1] + 1 and keeps estimating the energy from the
+    whole history; continue_from + an existing hdf_file is refused."""
+    import pytest
+
+    from pyqmc_amd import blockfile
+
+    path = str(tmp_path / "dmc.hdf5")
+    df1, cfg1, w1 = _small_dmc(path, 2)
+    store = blockfile.BlockFile(path)
+    assert store.datasets()["block"].tolist() == [0, 1]
+    df2, cfg2, w2 = _small_dmc(path, 4, seed=99)  # (other start walkers: they must be replaced by the file's)
+    d = store.datasets()
+    assert df2["block"].tolist() == [2, 3] and d["block"].tolist() == [0, 1, 2, 3]
+    # the first continued block ran with the parameters the file's last block recorded (dmc.py:489-491) ...
+    assert df2["e_trial"][0] == df1["e_trial"][-1] and df2["e_est"][0] == df1["e_est"][-1] and df2["esigma"][0] == df1["esigma"][-1]
+    # ... and the estimate after it averages the whole record (estimate_energy reads the file, dmc.py:594-603)
+    en, wt = d["energytotal"][:3], d["weight"][:3]
+    assert abs(df2["e_est"][1] - np.average(en[0:], weights=wt[0:]).real) < 1e-12
+    assert np.array_equal(store._state()["configs"], cfg2.configs) and np.array_equal(store._state()["weights"], w2)
+    assert _small_dmc(path, 4)[0] == {}  # nothing left to run
+    with pytest.raises(RuntimeError, match="already exists"):
+        _small_dmc(path, 6, continue_from=path)
+    # continue_from into a NEW file: offsets and walkers from the old one, record in the new one only
+    path2 = str(tmp_path / "dmc2.hdf5")
+    df3, _, _ = _small_dmc(path2, 5, continue_from=path)
+    assert df3["block"].tolist() == [4] and blockfile.BlockFile(path2).datasets()["block"].tolist() == [4]
+
+
+def _rundmc_worker(rank, world, port, path, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        df, cfg, w = _small_dmc(path, 2, W=4, seed=10 + rank, distributed=True)
+        df2, cfg2, w2 = _small_dmc(path, 3, W=4, seed=50 + rank, distributed=True)
+        q.put((rank, df["block"].tolist(), df2["block"].tolist(), cfg2.configs, w2, df2["energytotal"].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rundmc_writes_one_block_file_per_rank():
+    """N ranks must not append to one file.  Rank 0 owns hdf_file, rank r hdf_file.rank<r>; each holds the common
+    (all-reduced) block record and its OWN shard's walkers and weights, and each rank continues from its own file."""
+    import tempfile
+
+    import torch.multiprocessing as mp
+
+    from pyqmc_amd import blockfile
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "dmc.hdf5")
+        procs = [ctx.Process(target=_rundmc_worker, args=(r, 2, port, path, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        stores = [blockfile.BlockFile(path), blockfile.BlockFile(path + ".rank1")]
+        for r, st in zip(res, stores):
+            assert st.exists() and r[1] == [0, 1] and r[2] == [2]
+            d = st.datasets()
+            assert d["block"].tolist() == [0, 1, 2]
+            assert np.array_equal(st._state()["configs"], r[3]) and np.array_equal(st._state()["weights"], r[4])
+        # the block record is the all-reduced one: identical in both files; the shards are not
+        assert np.array_equal(stores[0].datasets()["energytotal"], stores[1].datasets()["energytotal"])
+        assert not np.array_equal(res[0][3], res[1][3])
