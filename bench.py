@@ -24,9 +24,13 @@ sys.path.insert(0, ROOT)
 # fp64 peaks of MI355X (AMD datasheet; MI355X_MICROARCH.md lists no fp64 row): vector = matrix = 78.6 TFLOP/s
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_MFMA_PEAK_TFLOPS = 78.6
+# what the part sustains (so `frac` can be read both ways): plain coalesced streaming reads 5.8-6.5 TB/s on these boxes
+# (tools/scratch/bw_probe.hip; the guide says ~6.3), v_mfma_f64_16x16x4_f64 alone 72 TFLOP/s at 8 waves/SIMD (tools/ubench.hip)
+HBM_ACHIEVABLE_GBS = 6300.0
+FP64_MFMA_ACHIEVABLE_TFLOPS = 72.0
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
 
 
 def pmc_kernel(key, walkers):
@@ -41,7 +45,7 @@ def pmc_kernel(key, walkers):
         return None
     per_walker = k["bytes_per_launch"] / d["walkers"]
     return {"bytes_per_launch": per_walker * walkers, "bytes_per_walker": per_walker, "fetch_calibration": d["calibration"]["applied_fetch_factor"],
-            "write_calibration": d["calibration"]["applied_write_factor"], "measured_at_walkers": d["walkers"], "source": "profiles/r02_pmc_summary.json"}
+            "write_calibration": d["calibration"]["applied_write_factor"], "measured_at_walkers": d["walkers"], "source": "profiles/" + os.path.basename(PMC_SUMMARY)}
 
 
 def build_wf(device):
@@ -363,36 +367,43 @@ def main():
             achieved = flops / (orb_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_orb (fused GTO AO evaluation + AO->MO fp64 MFMA contraction)",
                                "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_kernel("k_orb5", W),
+                               "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                               "peak_achievable": FP64_MFMA_ACHIEVABLE_TFLOPS, "frac_of_achievable": achieved / FP64_MFMA_ACHIEVABLE_TFLOPS,
+                               "traffic": pmc_kernel("k_orb5", W),
                                "algorithmic_bytes_per_launch": (5 * nmo * 8 + 24) * (point_comps / launches / 5),
                                "launches": launches, "avg_launch_ms": orb_ms / launches,
                                "launches_timed": "1 in 4 of the step's 64 move launches (an event pair costs ~2 us of stream time)",
                                "kernel_share_of_step": (orb_ms / launches) * 64 * args.steps / (1e3 * elapsed),
                                "flops_per_point_component": 2 * nao * nmo}
         n_s, N = 32, 64
+        kb = int(os.environ.get("PQA_LW_KB", "-1"))
+        kb = (5 if n_s >= 24 else 4) if kb < 0 else (n_s if kb == 0 else min(kb, n_s))  # the library's default (lw_setup)
         if not args.no_profile and p_launches:
-            # The Jastrow distance sweep of north_star lives in k_move_part_lw (two launches per move: old and proposed position):
-            # per walker it streams the coordinates of all electrons (N x 24 B), one row of the inverse (n x 8 B), four
-            # component rows of the orbital values (4 n x 8 B), and writes 8 partial sums per group.  `achieved` prices those
-            # ALGORITHMIC bytes against the event-measured launch time; `traffic` is what the HBM counters saw.
-            alg = N * 24 + n_s * 8 + 4 * n_s * 8 + p_groups * 64
+            # The Jastrow distance sweep of north_star lives in k_step_lw (one launch per move: decide electron e, propose e + 1).
+            # ALGORITHMIC bytes per walker and launch: the coordinates of all electrons once (N x 24 B), the proposal's value and
+            # gradient rows (4 n x 8 B) and inverse row e (n x 8), the KB - 1 other inverse rows of the electron block read and
+            # written + row e written, the update vectors V, R to the block buffers (2 n x 8), the cached rows (4 n x 8) and
+            # inverse row (n x 8) of electron e + 1, and ~100 B of per-walker scalars (proposal, drift, selector, flags).
+            # `achieved` prices those against the event-measured launch time; `traffic` is what the HBM counters saw.
+            alg = N * 24 + 4 * n_s * 8 + n_s * 8 + 2 * (kb - 1) * n_s * 8 + n_s * 8 + 2 * n_s * 8 + 4 * n_s * 8 + n_s * 8 + 100
             ach = alg * W / (p_ms / p_launches * 1e-3) / 1e9
-            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_move_part_lw (Slater ratio sums + Jastrow e-e / e-ion distance sums of one proposal; 128 launches per step)",
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": "k_step_lw (one launch per move: Slater ratio sums + Jastrow e-e / e-ion distance sums at the proposal, "
+                                                              "Metropolis test, Sherman-Morrison rows of the electron block, then the same sums and the proposal of the next electron)",
                                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": pmc_kernel("k_move_part_lw", W), "launches": p_launches, "avg_launch_ms": p_ms / p_launches,
-                                   "kernel_share_of_step": (p_ms / p_launches) * 2 * N * args.steps / (1e3 * elapsed),
-                                   "algorithmic_bytes_per_walker": alg, "partial_sum_groups": p_groups}
+                                   "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
+                                   "traffic": pmc_kernel("k_step_lw", W), "launches": p_launches, "avg_launch_ms": p_ms / p_launches,
+                                   "kernel_share_of_step": (p_ms / p_launches) * N * args.steps / (1e3 * elapsed),
+                                   "algorithmic_bytes_per_walker": alg, "thread_groups_per_walker": p_groups}
         if not args.no_profile and c_launches:
             # k_flush_lw, the deferred half of the blocked Sherman-Morrison update: after every block of KB moves of a spin it
             # carries the n - KB rows outside the block through HBM (read + write) plus the block's KB update-vector pairs.
             # Walkers are interleaved in every cache line, so ALL walkers' rows cross HBM: algorithmic bytes per walker.
-            kb = int(os.environ.get("PQA_LW_KB", "-1"))
-            kb = (5 if n_s >= 24 else 4) if kb < 0 else (n_s if kb == 0 else min(kb, n_s))  # the library's default (lw_setup)
             alg = 2 * 8 * (n_s - kb) * n_s + 2 * 8 * kb * n_s  # = 16 n_s^2 whatever the block size
             ach = alg * W / (c_ms / c_launches * 1e-3) / 1e9
             flushes_per_step = 2 * -(-n_s // kb) if kb < n_s else 0
             out["roofline_hbm_flush"] = {"bound": "hbm", "kernel": "k_flush_lw (blocked Sherman-Morrison: rows outside the electron block, once per block of KB moves)",
                                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                         "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_of_achievable": ach / HBM_ACHIEVABLE_GBS,
                                          "traffic": pmc_kernel("k_flush_lw", W), "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
                                          "kernel_share_of_step": (c_ms / c_launches) * flushes_per_step * args.steps / (1e3 * elapsed),
                                          "algorithmic_bytes_per_walker": alg, "block_KB": kb}

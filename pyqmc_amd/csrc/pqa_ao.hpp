@@ -762,6 +762,13 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
   }
   // epilogue: lane holds D[row = (lane>>4) + 4r][col = lane & 15]
   const int nmo = S.nmo[spin];
+  double* orow[4];  // the lane's four output rows (one selector look-up each, before the store loops: inside them every store
+                    // waited for its own dependent byte load)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long pp = p0 + 16 * ptile + kq + 4 * r;
+    orow[r] = (pp < P) ? orb_out(T, out, pp) + pp * NCOMP * nmo : nullptr;
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int ut = u0 + u * ustep;
@@ -771,9 +778,8 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long pp = p0 + 16 * ptile + kq + 4 * r;
-        if (pp < P) {
-          double* o = orb_out(T, out, pp) + (pp * NCOMP + c) * nmo + j;
+        if (orow[r]) {
+          double* o = orow[r] + c * nmo + j;
           if (nsplit > 1) unsafeAtomicAdd(o, acc[u][c][r]);
           else *o = acc[u][c][r];
         }
@@ -895,6 +901,12 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
   }
   if (producer) return;
   const int nmo = S.nmo[spin];
+  double* orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long pp = p0 + 16 * grp + kq + 4 * r;
+    orow[r] = (pp < P) ? orb_out(T, out, pp) + pp * NCOMP * nmo : nullptr;
+  }
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int j = 16 * u + i16;
@@ -902,10 +914,8 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long pp = p0 + 16 * grp + kq + 4 * r;
-        if (pp < P) orb_out(T, out, pp)[(pp * NCOMP + c) * nmo + j] = acc[u][c][r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (orow[r]) orow[r][c * nmo + j] = acc[u][c][r];
   }
 }
 
@@ -1021,6 +1031,12 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
   const double* __restrict__ C = T.cpad[spin];
   const int ldc = T.ldc[spin], nmo = S.nmo[spin];
   const int i16 = lane & 15, kq = lane >> 4;
+  double* orow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long pp = p0 + kq + 4 * r;
+    orow[r] = (pp < P) ? orb_out(T, out, pp) + pp * NCOMP * nmo : nullptr;
+  }
   for (int role = wv; role < NCOMP * NT; role += NTH / 64) {
     const int c = role % NCOMP, ut = role / NCOMP;
     const double* a_ = tile + (size_t)c * K * 16 + (size_t)kq * 16 + i16;
@@ -1038,10 +1054,8 @@ __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab 
     const int j = 16 * ut + i16;
     if (j < nmo) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long pp = p0 + kq + 4 * r;
-        if (pp < P) orb_out(T, out, pp)[(pp * NCOMP + c) * nmo + j] = acc[r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (orow[r]) orow[r][c * nmo + j] = acc[r];
     }
   }
 }
