@@ -120,23 +120,32 @@ def cpu_baseline(walkers_per_core, tstep, nsteps=2, max_procs=0):
     if max_procs > 0:
         cpus = cpus[:max_procs]
     P = len(cpus)
-    start_at = time.time() + 20.0 + 0.05 * P  # imports + wave-function set-up of every worker happen before this
     ctx = mp.get_context("spawn")  # never fork a process that has HIP / RCCL state
-    with ctx.Pool(P) as pool:
-        res = pool.map(baseline_worker.run, [(i, walkers_per_core, nsteps, tstep, cpus[i], start_at) for i in range(P)], chunksize=1)
-    t_begin, t_end = min(r[1] for r in res), max(r[2] for r in res)
-    late = max(r[1] for r in res) - start_at
-    total = sum(r[3] for r in res)
-    per_core = [r[3] / (r[2] - r[1]) for r in res]
-    return {"value": total / (t_end - t_begin), "unit": "walker-steps/s", "cores": P, "kind": "port",
-            "per_core": float(sum(per_core) / P), "cpu_model": model, "socket_physical_cores": socket, "cgroup_cpu_quota": quota,
-            "socket_extrapolated": float(sum(per_core) / P) * socket,
+
+    def leg(backend):
+        start_at = time.time() + 20.0 + 0.05 * P  # imports + wave-function set-up of every worker happen before this
+        with ctx.Pool(P) as pool:
+            res = pool.map(baseline_worker.run, [(i, walkers_per_core, nsteps, tstep, cpus[i], start_at, backend) for i in range(P)], chunksize=1)
+        t_begin, t_end = min(r[1] for r in res), max(r[2] for r in res)
+        per_core = [r[3] / (r[2] - r[1]) for r in res]
+        return {"value": sum(r[3] for r in res) / (t_end - t_begin), "per_core": float(sum(per_core) / P),
+                "ao_share_of_wall_time": float(sum(r[4] for r in res) / sum(r[2] - r[1] for r in res)),
+                "walker_steps": sum(r[3] for r in res), "seconds": t_end - t_begin, "late": max(r[1] for r in res) - start_at}
+
+    c_leg, np_leg = leg("c"), leg("numpy")
+    return {"value": c_leg["value"], "unit": "walker-steps/s", "cores": P, "kind": "port", "ao_backend": "c++ (oracle/ao_eval.c, gcc -O3 -ffast-math, single thread per process)",
+            "per_core": c_leg["per_core"], "ao_share_of_wall_time": c_leg["ao_share_of_wall_time"],
+            "cpu_model": model, "socket_physical_cores": socket, "cgroup_cpu_quota": quota,
+            "socket_extrapolated": c_leg["per_core"] * socket,
+            "compiled_ao": {k: c_leg[k] for k in ("value", "per_core", "ao_share_of_wall_time")},
+            "numpy_ao": {k: np_leg[k] for k in ("value", "per_core", "ao_share_of_wall_time")},
             "sample": f"{P} concurrent single-thread processes (one per physical core of socket 0, pinned"
                       + (f"; the container's cgroup allows {quota:g} CPUs of the socket's {socket} cores, so P = {P}: `socket_extrapolated` = per-core rate x {socket} "
                          "assumes the reference's own perfect worker scaling" if quota and quota < socket else "")
                       + f"), each {walkers_per_core} walkers x "
-                      f"{nsteps} steps of the same sweep + energy evaluation: {total} walker-steps in {t_end - t_begin:.1f} s "
-                      f"(latest worker started {late:.2f} s after the common start); NumPy oracle, OMP/MKL threads = 1"}
+                      f"{nsteps} steps of the same sweep + energy evaluation: {c_leg['walker_steps']} walker-steps in {c_leg['seconds']:.1f} s "
+                      f"(latest worker started {c_leg['late']:.2f} s after the common start); NumPy oracle with the AO routine compiled "
+                      f"(`compiled_ao`, the headline: the reference's default AO back end is compiled code) and, as a second leg, in NumPy (`numpy_ao`); OMP/MKL threads = 1"}
 
 
 def extra_measurements(pa, wf, dev, mol, W, args):

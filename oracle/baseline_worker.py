@@ -12,9 +12,12 @@ import time
 
 
 def run(args):
-    """args = (index, walkers, nsteps, tstep, cpu or None, start_at).  Builds the wave function and walkers, waits for the
-    common start time, runs the oracle's vmc_worker; returns (index, t_begin, t_end, walker_steps)."""
-    idx, walkers, nsteps, tstep, cpu, start_at = args
+    """args = (index, walkers, nsteps, tstep, cpu or None, start_at[, ao_backend]).  Builds the wave function and walkers, waits
+    for the common start time, runs the oracle's vmc_worker; returns (index, t_begin, t_end, walker_steps, ao_seconds).
+    ao_backend "c" (default): AOs from oracle/libao_eval.so — a compiled single-thread routine, as the reference's default AO
+    back end is (orbitals.py:46-51); "numpy": the oracle's vectorised NumPy routine."""
+    idx, walkers, nsteps, tstep, cpu, start_at = args[:6]
+    ao_backend = args[6] if len(args) > 6 else "c"
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ[v] = "1"
     if cpu is not None:
@@ -25,8 +28,11 @@ def run(args):
     import numpy as np
 
     import pyqmc_amd as pa
+    from oracle import gto as ogto
     from oracle import vmc as ovmc
     from tests import helpers
+
+    ogto.set_ao_backend(ao_backend)
 
     mol = pa.systems.water_cluster()
     mf = pa.systems.random_mf(mol)
@@ -40,6 +46,7 @@ def run(args):
     owf.recompute(cfg)  # set-up stays outside the clock, as the reference's vmc_worker starts from a recompute too
     while time.time() < start_at:  # all workers start together: the cores contend for memory bandwidth as in a production run
         time.sleep(0.01)
+    ogto.AO_SECONDS = 0.0
     t0 = time.time()
     ovmc.vmc_worker(mol, owf, cfg, tstep, gauss, unif, rot, eunif)
-    return idx, t0, time.time(), walkers * nsteps
+    return idx, t0, time.time(), walkers * nsteps, ogto.AO_SECONDS

@@ -221,3 +221,23 @@ def test_testvalue_many_matches_reference():
     epos = cfg.make_irreducible(0, g["pbc_aux"])
     for nm, w in (("slater", pwf.wf_factors[0]), ("j2", pwf.wf_factors[1]), ("wf", pwf)):
         assert relerr(w.testvalue_many(g["pbc_es"], epos), g[f"pbc_{nm}"]) < 1e-9, nm
+
+
+def test_compiled_ao_backend_of_the_oracle_matches_the_numpy_routine():
+    """oracle/ao_eval.c (the CPU baseline's AO evaluator: the same loops compiled, -ffast-math) against oracle/gto.py's NumPy
+    routine — itself pinned to the reference by g2 — on the metric system and on H2O: value, gradient, Laplacian."""
+    from oracle import gto
+
+    rng = np.random.default_rng(3)
+    try:
+        for mol in (systems.water_cluster(), systems.water()):
+            tab = gto.AOTable(mol)
+            pts = mol.atom_coords()[rng.integers(mol.natm, size=300)] + rng.standard_normal((300, 3)) * 1.5
+            for ncomp in (1, 4, 5):
+                gto.set_ao_backend("numpy")
+                a = gto.eval_ao(tab, pts, ncomp)
+                gto.set_ao_backend("c")
+                b = gto.eval_ao(tab, pts, ncomp)
+                assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-13 * max(1.0, np.max(np.abs(a)))
+    finally:
+        gto.set_ao_backend("numpy")
