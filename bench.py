@@ -173,6 +173,74 @@ def extra_measurements(pa, wf, dev, mol, W, args):
     return out
 
 
+def rank_table(torch, dist, rank, local_rank, world):
+    """One line per rank for the JSON: which device each process of the job really sits on, and the communicator's size as the
+    process group reports it (so an 8-GPU record shows 8 distinct devices over RCCL, not 8 processes on one)."""
+    p = torch.cuda.get_device_properties(local_rank)
+    bus = None
+    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    me = {"rank": rank, "local_rank": local_rank, "device": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "pci_bus_id": bus,
+          "hbm_gb": round(p.total_memory / 2**30, 1), "compute_units": p.multi_processor_count}
+    if dist is None:
+        return {"rccl_ranks": 1, "backend": None, "ranks": [me]}
+    table = [None] * world
+    dist.all_gather_object(table, me)
+    return {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks": table}
+
+
+def local_walkers(args, rank, world, weak_default, strong_default):
+    """Walkers of this rank and the `scaling` label: weak = --walkers (or the config's per-GPU count) on every GPU; strong =
+    --walkers (or the config's BASELINE total) split over the GPUs like the reference's configs.split (coord.py:72-80)."""
+    from pyqmc_amd.dist import shard_bounds
+
+    if args.scaling == "strong":
+        total = args.walkers if args.walkers > 0 else strong_default
+        lo, hi = shard_bounds(total, world)[rank]
+        return hi - lo, total
+    W = args.walkers if args.walkers > 0 else weak_default
+    return W, W * world
+
+
+def c4_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
+    """--mode c4: BASELINE config 4 (H2O, 50 determinants x 2-body x 3-body Jastrow, VMC; 16384 walkers over 8 GPUs) — the
+    wave-per-walker kernels.  Same timing contract as the headline; per block one all-reduce of the energy sums."""
+    import numpy as np
+
+    import pyqmc_amd as pa
+    from pyqmc_amd.dist import allreduce_block
+
+    W, total = local_walkers(args, rank, world, 2048, 16384)
+    mol = pa.systems.water()
+    mf = pa.systems.random_mf(mol, nvirt=8)
+    wf = pa.generate_wf(mol, mf, determinants=pa.systems.random_determinants(mol, mf, 50), jastrow3=True, device=local_rank)
+    wf.parameters["wf3ccoeff"] = 0.05 * np.random.default_rng(2).standard_normal(wf.parameters["wf3ccoeff"].shape)
+    dev = wf.fused_device()
+    wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(1234 + rank)))
+    seed = 20260928 + 7919 * rank
+    dev.vmc_sweeps(args.tstep, max(args.warmup, 1), seed=seed, energy=True)
+    fence()
+    t0 = time.perf_counter()
+    acc, en, _ = dev.vmc_sweeps(args.tstep, args.steps, seed=seed + 1, energy=True)
+    e_mean = allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device=red_dev)[0]
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    info = rank_table(torch, dist, rank, local_rank, world)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "walker-steps/sec (VMC sweep, H2O 50-determinant Slater x 2-body x 3-body Jastrow)", "value": total * args.steps / elapsed,
+            "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config C4: H2O ccECP-shaped tables, 8 e-, 50 determinants, 2-body (na=4, nb=4) and 3-body Jastrow; "
+                                   "one step = 8 single-electron moves + EnergyAccumulator per walker",
+                       "walkers_per_gpu": W, "global_walkers": total, "tstep": args.tstep, "parallelism": f"walker-sharded x{world}"},
+            "acceptance": float(np.mean(acc)), "energy_total_mean": float(np.real(e_mean[5])), **info}), flush=True)
+
+
 def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     """--mode dmc: BASELINE config C5 (diamond 2x2x2 supercell, 64 e-, 8 k-points, tstep 0.02, T-moves, Ewald) — blocks of 5
     fused DMC steps (pqa_dmc_steps) followed by the block reduction and the distributed stochastic comb, whose walker
@@ -184,7 +252,7 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     from pyqmc_amd import pbc
     from pyqmc_amd.dmc import dmc_propagate
 
-    W = args.walkers if args.walkers != 65536 else 4096  # C5: 32768 walkers over 8 GPUs
+    W, total = local_walkers(args, rank, world, 4096, 32768)  # C5: 32768 walkers over 8 GPUs
     sup = pbc.get_supercell(pa.systems.diamond_primitive(), 2.0 * np.eye(3))
     wf = pa.generate_wf(sup, pbc.random_kmf(sup), device=local_rank)
     dev = wf.fused_device()
@@ -225,16 +293,17 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    info = rank_table(torch, dist, rank, local_rank, world)
     if rank == 0:
         steps = nblocks * nsb
         print(json.dumps({
-            "metric": "walker-steps/sec (DMC, diamond 2x2x2 supercell 64e- Slater-Jastrow, tstep 0.02)", "value": W * world * steps / elapsed,
+            "metric": "walker-steps/sec (DMC, diamond 2x2x2 supercell 64e- Slater-Jastrow, tstep 0.02)", "value": total * steps / elapsed,
             "unit": "walker-steps/s", "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1) * nsb, "ms_per_step": 1e3 * elapsed / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config C5: diamond 2x2x2 supercell (16 atoms, 64 e-, 8 k-points, ccECP-shaped synthetic tables), DMC "
                                    "tstep 0.02 with T-moves and Ewald energies; blocks of 5 steps + block reduction + distributed stochastic comb",
-                       "walkers_per_gpu": W, "global_walkers": W * world, "parallelism": f"walker-sharded x{world}"},
-            "energy_total": float(blk["energytotal"]), "acceptance": float(blk["acceptance"]), "tmove_acceptance": float(blk["tmove_acceptance"]),
+                       "walkers_per_gpu": W, "global_walkers": total, "parallelism": f"walker-sharded x{world}"},
+            **info, "energy_total": float(blk["energytotal"]), "acceptance": float(blk["acceptance"]), "tmove_acceptance": float(blk["tmove_acceptance"]),
             "branching": {"blocks": stats["blocks"], "walkers_moved_per_block": stats["moved"] / max(stats["blocks"], 1),
                           "bytes_sent_per_block_rank0": stats["bytes"] / max(stats["blocks"], 1),
                           "exchange": "all-gather of weights + point-to-point coordinates of re-assigned walkers only (RCCL)"}}), flush=True)
@@ -245,10 +314,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--walkers", type=int, default=65536, help="walkers per GPU (weak scaling); 65536 is the measured throughput optimum")
+    ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (weak scaling; default 65536 for the headline, the measured throughput "
+                    "optimum; 4096 / 2048 for --mode dmc / c4) or in total (--scaling strong; default 32768 / 16384 for dmc / c4)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: fixed walkers per GPU (the headline contract); strong: "
+                    "a fixed ensemble split over the GPUs (BASELINE configs C4: 16384 and C5: 32768 walkers in total)")
     ap.add_argument("--tstep", type=float, default=0.3)
     ap.add_argument("--settle", type=int, default=30, help="untimed settling steps before the warm-up steps (clock ramp of a fresh process)")
-    ap.add_argument("--mode", default="vmc", choices=["vmc", "dmc"], help="vmc: the headline metric (default); dmc: config C5 with branching")
+    ap.add_argument("--mode", default="vmc", choices=["vmc", "dmc", "c4"], help="vmc: the headline metric (default); dmc: config C5 with branching; c4: config C4 (multi-determinant VMC)")
     ap.add_argument("--cpu-walkers", type=int, default=256, help="walkers per CPU-baseline process")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline processes (0 = physical cores of one socket)")
     ap.add_argument("--no-extra", action="store_true", help="skip the sweep-only and walker-count grid measurements (extra)")
@@ -296,15 +368,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "dmc":
-        dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence)
+    if args.mode in ("dmc", "c4"):
+        (dmc_bench if args.mode == "dmc" else c4_bench)(args, torch, dist, rank, local_rank, world, red_dev, fence)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
     mol, mf, wf = build_wf(local_rank)
     dev = wf.fused_device()
-    W = args.walkers
+    W, total_walkers = local_walkers(args, rank, world, 65536, 65536 * world)
     cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(1234 + rank))
     wf.recompute(cfg)
     seed = 20260928 + 7919 * rank
@@ -355,21 +427,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    info = rank_table(torch, dist, rank, local_rank, world)
     if rank == 0:
         nao, nmo = 184, 32
-        total_walkers = W * world
         value = total_walkers * args.steps / elapsed
         out = {
             "metric": "walker-steps/sec (VMC sweep, 64e- Slater-Jastrow)",
             "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "(H2O)8 cluster: 64 e- (32 up, 32 dn), 24 atoms, 184 AOs (ccECP cc-pVDZ-shaped synthetic "
                                    "tables), 1 determinant, 2-body Jastrow (na=4, nb=4), ccECP-shaped ECP threshold=10; "
                                    "one step = 64 single-electron moves + EnergyAccumulator per walker",
                        "walkers_per_gpu": W, "global_walkers": total_walkers, "tstep": args.tstep, "parallelism": f"walker-sharded x{world}"},
             "acceptance": float(np.mean(acc)), "energy_total_mean": float(e_mean[5]),
-            "ecp_points_per_walker_step": ecp_pts / W, "stream_event_ms": ev_ms,
+            "ecp_points_per_walker_step": ecp_pts / W, "stream_event_ms": ev_ms, **info,
         }
         if not args.no_profile and launches:
             flops = point_comps * 2.0 * nao * nmo  # AO->MO contraction only: the MFMA-eligible work of the kernel

@@ -77,7 +77,7 @@ def exchange_plan(newinds, counts, rank):
     return keep, recv, send
 
 
-def branch_distributed(configs, weights, base_u=None, dev=None):
+def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=None):
     """Stochastic-comb branching (``pyqmc/method/dmc.py:342-376``) of an ensemble sharded over ranks, as SURVEY.md section
     8(e) specifies it: all-gather of the WEIGHTS only (8 B per walker), one broadcast uniform, the identical comb on every
     rank, and then one point-to-point exchange of just the walkers whose new owner differs from their old one —
@@ -88,6 +88,10 @@ def branch_distributed(configs, weights, base_u=None, dev=None):
     (``pqa_get_walkers``) straight into the buffer RCCL sends from, the walkers that stay keep their whole wave-function
     state (``pqa_branch_exchange`` gathers it like ``pqa_resample``) and only the RECEIVED walkers are recomputed.  Without
     ``dev`` the coordinates come from ``configs`` and the caller recomputes, like the reference (dmc.py:155).
+    ``device_buffers``: pack / unpack through GPU tensors and hand raw device pointers to the library.  Default: exactly when
+    the backend is RCCL ("nccl").  ``True`` under gloo runs the same device-side packing, stream hand-off and pointer path
+    with the TRANSPORT alone going through host copies (gloo cannot send GPU tensors) — how the one-GPU test suite
+    exercises the code an 8-GPU run executes.
 
     The new local order is: walkers that stayed (comb order), then arrivals by source rank (comb order) — walkers are
     exchangeable and carry equal weights after the comb.  Returns (configs, weights, info, global weight std); ``info`` also
@@ -104,7 +108,10 @@ def branch_distributed(configs, weights, base_u=None, dev=None):
         cfg, w, info = branch(configs, weights, base_u, on_resample=None if dev is None else dev.resample)
         return cfg, w, {**info, "walkers moved": 0, "bytes exchanged": 0}, wstd
     world, rank = dist.get_world_size(), dist.get_rank()
-    tdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    nccl = dist.get_backend() == "nccl"
+    tdev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")  # what the transport moves
+    on_gpu = dev is not None and (nccl if device_buffers is None else bool(device_buffers))
+    bdev = torch.device("cuda", dev.device) if on_gpu else tdev  # where walkers are packed / unpacked
     n_local = torch.tensor([len(weights)], dtype=torch.int64, device=tdev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
@@ -130,23 +137,23 @@ def branch_distributed(configs, weights, base_u=None, dev=None):
     row = nx * (2 if periodic else 1)
     ops, inbox, outbox, sent_bytes = [], {}, {}, 0
     for q, idx in sorted(send.items()):
-        buf = torch.empty((len(idx), row), dtype=torch.float64, device=tdev)
-        if dev is not None and tdev.type == "cuda":
+        buf = torch.empty((len(idx), row), dtype=torch.float64, device=bdev)
+        if on_gpu:
             if periodic:  # coordinates gathered on the device, the (host-side) wrap counters appended
-                xs = torch.empty((len(idx), nx), dtype=torch.float64, device=tdev)
+                xs = torch.empty((len(idx), nx), dtype=torch.float64, device=bdev)
                 dev.get_walkers(idx, out=xs.data_ptr())
                 buf[:, :nx] = xs
-                buf[:, nx:] = torch.from_numpy(np.ascontiguousarray(np.asarray(configs.wrap, dtype=np.float64)[idx].reshape(len(idx), nx))).to(tdev)
+                buf[:, nx:] = torch.from_numpy(np.ascontiguousarray(np.asarray(configs.wrap, dtype=np.float64)[idx].reshape(len(idx), nx))).to(bdev)
             else:
-                dev.get_walkers(idx, out=buf.data_ptr())
+                dev.get_walkers(idx, out=buf.data_ptr())  # (the library synchronises its stream before returning)
         else:
             src = dev.get_walkers(idx).reshape(len(idx), nx) if dev is not None else x[idx].reshape(len(idx), nx)
             buf[:, :nx] = torch.from_numpy(np.ascontiguousarray(src))
             if periodic:
                 buf[:, nx:] = torch.from_numpy(np.ascontiguousarray(np.asarray(configs.wrap, dtype=np.float64)[idx].reshape(len(idx), nx)))
-        outbox[q] = buf
+        outbox[q] = buf if buf.device == tdev else buf.to(tdev)
         sent_bytes += buf.numel() * 8
-        ops.append(dist.P2POp(dist.isend, buf, q))
+        ops.append(dist.P2POp(dist.isend, outbox[q], q))
     for q, n in sorted(recv.items()):
         inbox[q] = torch.empty((n, row), dtype=torch.float64, device=tdev)
         ops.append(dist.P2POp(dist.irecv, inbox[q], q))
@@ -156,11 +163,11 @@ def branch_distributed(configs, weights, base_u=None, dev=None):
     nrecv = sum(recv.values())
     got = torch.cat([inbox[q] for q in sorted(inbox)], dim=0) if nrecv else torch.empty((0, row), dtype=torch.float64, device=tdev)
     got_host = got.cpu().numpy()
-    if dev is not None:  # state follows the walkers that stay; arrivals are recomputed (device pointer under RCCL)
-        gx = got[:, :nx].contiguous()
-        if tdev.type == "cuda":
-            torch.cuda.current_stream().synchronize()  # the library reads gx on its own HIP stream: torch's work must be done
-        dev.branch_exchange(keep, gx.data_ptr() if (nrecv and tdev.type == "cuda") else (gx.cpu().numpy() if nrecv else None), nrecv)
+    if dev is not None:  # state follows the walkers that stay; arrivals are recomputed (device pointer when packed on the GPU)
+        gx = got[:, :nx].to(bdev).contiguous()
+        if on_gpu:
+            torch.cuda.current_stream(bdev).synchronize()  # the library reads gx on its own HIP stream: torch's work must be done
+        dev.branch_exchange(keep, gx.data_ptr() if (nrecv and on_gpu) else (gx.cpu().numpy() if nrecv else None), nrecv)
     shape = (len(keep) + nrecv,) + x.shape[1:]
     configs.configs = np.ascontiguousarray(np.concatenate([x[keep].reshape(len(keep), nx), got_host[:, :nx]], axis=0)).reshape(shape)
     if periodic:
@@ -170,5 +177,5 @@ def branch_distributed(configs, weights, base_u=None, dev=None):
     moved = int(np.sum(np.searchsorted(np.concatenate([[0], np.cumsum(counts)]), newinds, side="right") - 1
                        != np.repeat(np.arange(world), counts)))
     info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique)), "walkers moved": moved,
-            "bytes exchanged": int(sent_bytes)}
+            "bytes exchanged": int(sent_bytes), "device_buffers": bool(on_gpu)}
     return configs, new_w, info, float(np.std(gw))

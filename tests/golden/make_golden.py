@@ -1358,6 +1358,63 @@ def g_hdf_layout():
     save("g27_hdf_layout", layout=np.array(json.dumps(out, sort_keys=True)))
 
 
+def g_chk_mol():
+    """SURVEY 8(f4), second half: the `mol` JSON of the reference's own PySCF checkpoint files (tests/files/*.hdf5, copied as data
+    to tests/golden/files/) -> what the REFERENCE builds from it.  The JSON is pulled out here with an independent regular
+    expression (no HDF5 library in the image, and not pyqmc_amd.chkfile, which is the thing under test); a duck-typed molecule
+    with the file's _basis / _ecp / _atom goes through the reference's AtomicOrbitalEvaluator (normalised shell tables,
+    numba/gto.py:435-470), its AO evaluator on random points, and its ECP functors (eval_ecp.py:160-200) on a radial grid.
+    Lattice vectors in bohr are `a` / pyscf's BOHR (Cell.lattice_vectors(); pyscf itself cannot run here: stated, not measured)."""
+    import json
+    import re
+
+    out = {}
+    for name in ("diamond_primitive", "li_cubic_ccecp"):
+        raw = open(os.path.join("/root/reference/tests/files", name + ".hdf5"), "rb").read()
+        m = re.search(rb'\{"atom": .*?"precision": [0-9.e+-]+\}', raw, re.S)
+        d = json.loads(m.group(0).decode())
+        syms = [a[0] for a in d["_atom"]]
+        xyz = np.array([a[1] for a in d["_atom"]])
+        ref_charges = [row[0] for row in d["_atm"]]
+
+        class M:
+            _basis, _ecp, _atom, natm, cart = d["_basis"], d["_ecp"], d["_atom"], len(syms), False
+
+            def atom_coords(self):
+                return xyz
+
+            def atom_pure_symbol(self, i):
+                return syms[i]
+
+            def atom_symbol(self, i):
+                return syms[i]
+
+            def atom_charges(self):
+                return np.array(ref_charges, dtype=float)
+
+        mol = M()
+        ev = refgto.AtomicOrbitalEvaluator(mol)
+        pts = np.random.default_rng(28).standard_normal((20, 3)) * 2.0 + xyz[0]
+        out[name + "_basis_ls"] = np.asarray(ev.basis_ls)
+        out[name + "_basis_arrays"] = np.asarray(ev.basis_arrays)
+        out[name + "_splits"] = np.asarray(ev.splits)
+        out[name + "_pts"] = pts
+        out[name + "_ao"] = np.asarray(ev.eval_gto("GTOval_sph", pts))
+        out[name + "_ao_lap"] = np.asarray(ev.eval_gto("GTOval_sph_deriv2", pts))
+        r = np.linspace(0.05, 4.0, 60)
+        for sym in d["_ecp"]:
+            ls, vl = eval_ecp.get_v_l(mol, sym, r)
+            out[f"{name}_ecp_{sym}_l"] = np.array(list(ls))
+            out[f"{name}_ecp_{sym}_v"] = vl
+        out[name + "_ecp_r"] = r
+        out[name + "_xyz"] = xyz
+        out[name + "_charges"] = np.array(ref_charges, dtype=float)
+        bohr_input = str(d.get("unit", "angstrom")).lower().startswith(("b", "au"))  # Cell.lattice_vectors(): a / BOHR unless the input unit was bohr
+        out[name + "_lattice_bohr"] = np.array(d["a"], dtype=float) / (1.0 if bohr_input else 0.52917721092)
+        out[name + "_syms"] = np.array(syms)
+    save("g28_chk_mol", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1385,3 +1442,4 @@ if __name__ == "__main__":
     g_pbc_pgrad()
     g_complex_testvalue_many()
     g_hdf_layout()
+    g_chk_mol()

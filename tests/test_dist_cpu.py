@@ -79,3 +79,66 @@ def test_two_rank_gloo_block_reduction():
     comb = pdist.combine_blocks(blocks, [r[4] for r in res])
     assert np.allclose([comb[k] for k in "abcd"], ref, rtol=1e-13)
     assert [r[4] for r in res] == [5, 4]
+
+
+def _c5_like_weights(W, seed):
+    """Weights as a C5 block leaves them (profiles/r02_branch_traffic.jsonl: sigma(w)/mean(w) = 0.18-0.19 after 5 steps at
+    tstep 0.02): log-normal around 1 with that spread."""
+    rng = np.random.default_rng(seed)
+    return np.exp(0.185 * rng.standard_normal(W) - 0.5 * 0.185**2)
+
+
+def _ws8_worker(rank, world, port, W, q):
+    import torch.distributed as dist
+
+    from pyqmc_amd.configs import OpenConfigs
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = pdist.shard_bounds(W, world)[rank]
+        x = np.arange(W * 6, dtype=float).reshape(W, 2, 3)[lo:hi]  # walker w carries its global index in every coordinate block
+        w = _c5_like_weights(W, 5)[lo:hi]
+        cfg, neww, info, wstd = pdist.branch_distributed(OpenConfigs(x.copy()), w.copy(), base_u=0.6180339887)
+        q.put((rank, cfg.configs, neww, info))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_branch_eight_ranks_c5_like_weights():
+    """The first 8-rank run of the branching step should be boring: world size 8 (gloo), 32768 walkers with weights spread like
+    a C5 block's.  Every rank keeps its shard size, the ranks together hold exactly the single-process comb's survivors, and
+    the walkers that crossed ranks are the population drift only — 0.1-1 % of the ensemble (DESIGN.md section 7 measured
+    55-149 of 32768 on real C5 weights), each counted once, with nothing else on the wire."""
+    import torch.multiprocessing as mp
+
+    from pyqmc_amd import dmc
+
+    W, world = 32768, 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ws8_worker, args=(r, world, port, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gw = _c5_like_weights(W, 5)
+    newinds = np.sort(dmc.comb_indices(gw, 0.6180339887)[0])
+    got = np.sort(np.concatenate([r[1][:, 0, 0] / 6 for r in res]).astype(np.int64))  # global source index of every survivor
+    assert np.array_equal(got, newinds)
+    bounds = pdist.shard_bounds(W, world)
+    moved = res[0][3]["walkers moved"]
+    assert all(r[3]["walkers moved"] == moved for r in res)
+    assert 0.001 * W < moved < 0.01 * W, moved
+    assert sum(r[3]["bytes exchanged"] for r in res) == moved * 6 * 8  # coordinates of the re-assigned walkers, nothing else
+    for r, (lo, hi) in zip(res, bounds):
+        assert len(r[1]) == hi - lo and np.allclose(r[2], gw.sum() / W, rtol=1e-14)
+        # most of a rank's new walkers were already its own: arrivals are a small minority on every rank
+        own = np.sum((r[1][:, 0, 0] / 6 >= lo) & (r[1][:, 0, 0] / 6 < hi))
+        assert own > 0.97 * (hi - lo)

@@ -218,7 +218,7 @@ def test_vmc_philox_energy_statistics():
     assert abs(e_phi - e_orc) < 4.0 * np.hypot(s_phi, s_orc), (e_phi, e_orc, s_phi, s_orc)
 
 
-def _exchange_worker(rank, world, port, q, periodic):
+def _exchange_worker(rank, world, port, q, periodic, device_buffers=None):
     import os
 
     import torch.distributed as dist
@@ -244,7 +244,8 @@ def _exchange_worker(rank, world, port, q, periodic):
             cfg.wrap += dev.wrap_delta()
         before = (cfg.configs.copy(), None if not periodic else cfg.wrap.copy(), dev.value()[1].copy())
         weights = np.random.default_rng(50 + rank).random(W) ** 3 * (0.3 if rank == 0 else 3.0)  # rank 1 outweighs rank 0: copies must cross
-        cfg, w, info, wstd = pdist.branch_distributed(cfg, weights.copy(), base_u=0.37, dev=dev)
+        cfg, w, info, wstd = pdist.branch_distributed(cfg, weights.copy(), base_u=0.37, dev=dev, device_buffers=device_buffers)
+        assert info["device_buffers"] == bool(device_buffers)
         after_log = dev.value()[1].copy()  # state that followed / was recomputed for the walkers now here
         assert np.array_equal(dev.configs(), cfg.configs) or periodic
         fresh = wf.recompute(cfg)[1]
@@ -253,12 +254,14 @@ def _exchange_worker(rank, world, port, q, periodic):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("periodic", [False, True])
-def test_distributed_branching_exchanges_walkers_between_device_handles(periodic):
+@pytest.mark.parametrize("periodic,device_buffers", [(False, None), (True, None), (False, True), (True, True)])
+def test_distributed_branching_exchanges_walkers_between_device_handles(periodic, device_buffers):
     """SURVEY 8(e) on real device handles (two ranks, gloo, both on this GPU): the comb's re-assigned walkers leave one
     handle as coordinates (pqa_get_walkers) and enter the other (pqa_branch_exchange), where ONLY they are recomputed; the
     walkers that stay carry their updated state along.  Afterwards every rank's device state equals a fresh recompute of
-    its new walkers, and the ranks together hold exactly the single-process comb's ensemble."""
+    its new walkers, and the ranks together hold exactly the single-process comb's ensemble.
+    device_buffers=True: walkers are packed into / unpacked from GPU tensors and the library gets raw device pointers after a
+    stream hand-off — the code path an RCCL run takes (dist.py), with only the transport itself going through gloo's host copies."""
     import socket
 
     import torch.multiprocessing as mp
@@ -271,7 +274,7 @@ def test_distributed_branching_exchanges_walkers_between_device_handles(periodic
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q, periodic)) for r in range(2)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q, periodic, device_buffers)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
@@ -286,4 +289,4 @@ def test_distributed_branching_exchanges_walkers_between_device_handles(periodic
     assert res[0][6]["walkers moved"] > 0 and res[0][6]["bytes exchanged"] + res[1][6]["bytes exchanged"] > 0
     for r in res:
         assert len(r[3]) == len(r[2]) and np.allclose(r[5], gw.sum() / len(gw))
-        assert note(f"exchange_state_vs_recompute_{int(periodic)}_{r[0]}", np.max(np.abs(r[7] - r[8]))) < 1e-9
+        assert note(f"exchange_state_vs_recompute_{int(periodic)}_{int(bool(device_buffers))}_{r[0]}", np.max(np.abs(r[7] - r[8]))) < 1e-9
