@@ -161,10 +161,16 @@ class PeriodicOrbitals:
         """pts: TRUE (unfolded) positions.  Folding them into the supercell gives the container's wrap counters, folding
         again into the primitive cell ``primwrap``; the wrap phase is exp(i k . (wrap @ S + primwrap) @ Lprim)
         (orbitals.py:199-213; the real form (-1)^round(k.R/pi) :34-35 when nothing is complex)."""
+        import time
+
+        from . import gto as _gto
+
+        t0 = time.perf_counter()
         pts = np.asarray(pts, dtype=float).reshape(-1, 3)
         cell_pts, wrap_s = enforce_pbc(self.S @ self.Lprim, pts)
         prim_pts, primwrap = enforce_pbc(self.Lprim, cell_pts)
         ao = eval_ao_pbc(self.aotab, prim_pts, ncomp)
+        _gto.AO_SECONDS += time.perf_counter() - t0  # (the CPU baselines report the AO share of their wall time)
         wrap = wrap_s @ self.S + primwrap
         kdotR = self.kpts @ self.Lprim.T @ wrap.T  # (nk, npts)
         wrap_phase = np.exp(1j * kdotR) if self.complex else (-1.0) ** np.round(kdotR / np.pi)

@@ -270,3 +270,126 @@ def initial_guess(mol, nconfig, r=1.0, rng=None):
     if hasattr(mol, "a"):  # mc.py:69-72
         return PeriodicConfigs(epos, mol.lattice_vectors())
     return OpenConfigs(epos)
+
+
+def model_mf(mol, screen=None, nrad=70, seed=None):
+    """Physically shaped orbitals without an SCF program (none exists where this package runs): eigenvectors of a model
+    one-electron Hamiltonian  h = -1/2 lap + sum_A [ -Z*_A / r_A + v_loc,A(r_A) ]  in the molecule's AO basis, with Slater-rule
+    screened charges Z* (``screen``: {symbol: Z*}; default O 4.55, C 3.25, H 1.0, He 1.7) standing in for the Hartree
+    potential and the local ECP channel v_loc of ``mol._ecp``; the lowest n_s eigenvectors per spin are occupied.  Matrix
+    elements by Becke-partitioned atom-centred quadrature (Gauss-Chebyshev radial x 50-point octahedral angular grid); the AO
+    values and Laplacians come from the same shell tables the device gets, through a plain NumPy evaluation here.
+
+    Any orbitals are a valid trial function and both sides of a parity test use the same coefficients; what this buys over
+    ``random_mf`` is a local energy whose standard deviation is ~1 Ha instead of ~5 Ha, so that an energy comparison "within
+    statistical error" (north_star) can actually fail.  Returns ``MeanField`` (mo_coeff (2, nao, nmo), all nao orbitals)."""
+    from .tables import basis_tables
+
+    screen = {"O": 4.55, "C": 3.25, "H": 1.0, "He": 1.7, **(screen or {})}
+    R = np.asarray(mol.atom_coords(), dtype=float)
+    na = mol.natm
+    # ---- atom-centred grids, Becke weights
+    i_ = np.arange(1, nrad + 1)
+    xk = np.cos(i_ * np.pi / (nrad + 1))  # Gauss-Chebyshev (second kind) mapped to r in (0, inf): r = rm (1 + x) / (1 - x)
+    rm = 1.0
+    r = rm * (1 + xk) / (1 - xk)
+    wr = (np.pi / (nrad + 1)) * np.sin(i_ * np.pi / (nrad + 1)) ** 2 * 2 * rm / (1 - xk) ** 2 / np.sqrt(1 - xk**2) * r**2
+    ang, wa = _octahedral50()
+    pts, wts, owner = [], [], []
+    for a in range(na):
+        p = R[a] + (r[:, None, None] * ang[None, :, :]).reshape(-1, 3)
+        pts.append(p); wts.append((wr[:, None] * wa[None, :] * 4 * np.pi).ravel()); owner.append(np.full(len(p), a))
+    pts, wts, owner = np.concatenate(pts), np.concatenate(wts), np.concatenate(owner)
+    d = np.linalg.norm(pts[:, None, :] - R[None, :, :], axis=2)  # (npts, natom)
+    cell = np.ones((len(pts), na))
+    for a in range(na):
+        for b in range(na):
+            if a == b:
+                continue
+            mu = (d[:, a] - d[:, b]) / np.linalg.norm(R[a] - R[b])
+            for _ in range(3):
+                mu = 1.5 * mu - 0.5 * mu**3
+            cell[:, a] *= 0.5 * (1 - mu)
+    w = wts * cell[np.arange(len(pts)), owner] / cell.sum(axis=1)
+    # ---- AO values and Laplacians on the grid (same normalised shell tables as the device)
+    t = basis_tables(mol)
+    nao = t["nao"]
+    val, lap = np.zeros((len(pts), nao)), np.zeros((len(pts), nao))
+    for sh in range(len(t["shell_l"])):
+        l, ia, off = int(t["shell_l"][sh]), int(t["shell_atom"][sh]), int(t["shell_ao_off"][sh])
+        if l > 2:
+            raise NotImplementedError("model_mf: shells up to d")
+        v = pts - R[ia]
+        r2 = np.sum(v * v, axis=1)
+        pe, pc = t["prim_exp"][t["shell_prim_off"][sh] : t["shell_prim_off"][sh + 1]], t["prim_coef"][t["shell_prim_off"][sh] : t["shell_prim_off"][sh + 1]]
+        e = np.exp(-r2[:, None] * pe[None, :]) * pc[None, :]
+        Rr, dRs, lapR = e.sum(1), -2.0 * (e * pe).sum(1), (e * 2 * pe * (2 * pe * r2[:, None] - 3)).sum(1)
+        x, y, z = v.T
+        if l == 0:
+            S, dS = [0.28209479177387814 + 0 * x], [np.zeros_like(v)]
+        elif l == 1:
+            c = 0.4886025119029199
+            S = [c * x, c * y, c * z]
+            dS = [np.tile([c, 0, 0], (len(x), 1)), np.tile([0, c, 0], (len(x), 1)), np.tile([0, 0, c], (len(x), 1))]
+        else:
+            a_, b_, c_ = 1.0925484305920792, 0.31539156525252005, 0.5462742152960396
+            zero = np.zeros_like(x)
+            S = [a_ * x * y, a_ * y * z, b_ * (2 * z * z - x * x - y * y), a_ * x * z, c_ * (x * x - y * y)]
+            dS = [np.stack([a_ * y, a_ * x, zero], 1), np.stack([zero, a_ * z, a_ * y], 1), np.stack([-2 * b_ * x, -2 * b_ * y, 4 * b_ * z], 1),
+                  np.stack([a_ * z, zero, a_ * x], 1), np.stack([2 * c_ * x, -2 * c_ * y, zero], 1)]
+        for m in range(2 * l + 1):
+            val[:, off + m] = S[m] * Rr
+            lap[:, off + m] = S[m] * lapR + 2.0 * dRs * np.sum(dS[m] * v, axis=1)  # lap S = 0
+    # ---- model potential
+    V = np.zeros(len(pts))
+    for a in range(na):
+        sym = mol.atom_pure_symbol(a)
+        V -= screen.get(sym, float(mol.atom_charges()[a])) / d[:, a]
+        if sym in mol._ecp:
+            for l, terms in mol._ecp[sym][1]:
+                if int(l) == -1:
+                    for n, expand in enumerate(terms):
+                        for al, c in expand:
+                            V += c * d[:, a] ** (n - 2) * np.exp(-al * d[:, a] ** 2)
+    wv = w[:, None] * val
+    Smat = val.T @ wv
+    Hmat = -0.5 * (wv.T @ lap) + val.T @ (wv * V[:, None])
+    Hmat = 0.5 * (Hmat + Hmat.T)
+    ev, L = np.linalg.eigh(Smat)
+    X = L / np.sqrt(ev)  # S^-1/2 (canonical)
+    eps, C = np.linalg.eigh(X.T @ Hmat @ X)
+    C = X @ C
+    mo = np.stack([C, C])
+    occ = np.zeros((2, nao))
+    for s in range(2):
+        occ[s, : mol.nelec[s]] = 1.0
+    mf = MeanField(mo, occ)
+    mf.mo_energy = eps
+    return mf
+
+
+def _octahedral50():
+    """50-point octahedral (Lebedev) rule, exact to l = 11: 6 vertices, 12 edge midpoints, 8 + 24 interior points
+    (weights 4/315, 64/2835, 27/1280, 14641/725760 of the sphere; the reference's ECP grids, eval_ecp.py:278-336, stop at the same rule)."""
+    pts, w = [], []
+    for i in range(3):
+        for s in (1, -1):
+            p = [0.0, 0.0, 0.0]; p[i] = s
+            pts.append(p); w.append(4.0 / 315.0)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            for si in (1, -1):
+                for sj in (1, -1):
+                    p = [0.0, 0.0, 0.0]; p[i] = si / np.sqrt(2); p[j] = sj / np.sqrt(2)
+                    pts.append(p); w.append(64.0 / 2835.0)
+    for sx in (1, -1):
+        for sy in (1, -1):
+            for sz in (1, -1):
+                pts.append([sx / np.sqrt(3), sy / np.sqrt(3), sz / np.sqrt(3)]); w.append(27.0 / 1280.0)
+    a, b = 1.0 / np.sqrt(11.0), 3.0 / np.sqrt(11.0)
+    for perm in ((a, a, b), (a, b, a), (b, a, a)):
+        for sx in (1, -1):
+            for sy in (1, -1):
+                for sz in (1, -1):
+                    pts.append([sx * perm[0], sy * perm[1], sz * perm[2]]); w.append(14641.0 / 725760.0)
+    return np.array(pts), np.array(w)
