@@ -627,7 +627,11 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
     for (int p = tid; p < S.nprim; p += 256) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
     __syncthreads();
   }
-  const int pl = tid & (TP - 1), grp = tid / TP;
+  // lane group: with 64-point tiles a wave IS one group, so the group index — and through it the shell list, every shell's
+  // table entries and the primitive loop's trip count — is wave-uniform: tell the compiler (scalar loads and a scalar loop
+  // instead of per-lane loads of the same value and an exec-masked loop; the per-shell look-ups were two dependent vector
+  // memory round trips each, ~22 shells per group and tile)
+  const int pl = tid & (TP - 1), grp = (TP == 64) ? __builtin_amdgcn_readfirstlane(tid / TP) : tid / TP;
   const long p0 = (long)blockIdx.x * TP;
   const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
   double px, py, pz;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, 
   for (int p = tid; p < S.nprim; p += 512) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   __syncthreads();
   const bool producer = wv < 4;
-  const int grp = wv & 3;  // producer: shell group; consumer: 16-point tile
+  const int grp = __builtin_amdgcn_readfirstlane(wv & 3);  // producer: shell group; consumer: 16-point tile (wave-uniform)
   const long p0 = (long)blockIdx.x * 64;
   const long pmine = (p0 + lane < P) ? p0 + lane : P - 1;
   double px = 0.0, py = 0.0, pz = 0.0;

@@ -302,7 +302,7 @@ def test_energy_statistics_against_the_oracle():
     Asserted: combined standard error <= 2 mHa and |E_device - E_oracle| < 3 combined standard errors."""
     import pyqmc_amd as pa
 
-    g = golden("g29_energy_stats")
+    g = helpers.golden("g29_energy_stats")
     mol = systems.water()
     mo = g["mo_coeff"]
     wf = helpers.gpu_wf(mol, systems.MeanField(mo, np.ones((2, mo.shape[2]))))
