@@ -652,6 +652,9 @@ __global__ __launch_bounds__(256) void k_step_lw(SysDev S, LwState L, MoveBuf mb
 #ifndef PQA_KIN_EB
 #define PQA_KIN_EB 1
 #endif
+#ifndef PQA_KIN_V
+#define PQA_KIN_V 1
+#endif
 template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   const long w = (long)blockIdx.x * 64 + threadIdx.x;
@@ -669,6 +672,35 @@ __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwStat
       // ground-state occupation: whole 64-byte lines of the lane's own row, two adjacent 32-byte loads each, used up at once
       // (walking 4 slots of all five components first left every line half used until the next round: 320 lines per wave in
       // flight, more than L1 keeps with 16 waves per CU — the kernel took 3.5 ms instead of 1.9)
+#if PQA_KIN_V == 1  // component-major: the lane streams its row front to back (adjacent lines back to back), inverse row in registers
+      if (n <= 32) {
+        double t[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t[u] = (u < n) ? Ti[(size_t)u * W] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+          for (int j = 0; j < 32; j += 8)
+            if (j < n) {
+              const double4 lo = *reinterpret_cast<const double4*>(row + c * nmo + j), hi = *reinterpret_cast<const double4*>(row + c * nmo + j + 4);
+              r[c] += lo.x * t[j]; r[c] += lo.y * t[j + 1]; r[c] += lo.z * t[j + 2]; r[c] += lo.w * t[j + 3];
+              r[c] += hi.x * t[j + 4]; r[c] += hi.y * t[j + 5]; r[c] += hi.z * t[j + 6]; r[c] += hi.w * t[j + 7];
+            }
+      } else
+#elif PQA_KIN_V == 2  // component-major, the inverse row re-read per component (coalesced, cache hits)
+      if (true) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+          for (int j = 0; j < n; j += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = Ti[(size_t)(j + u) * W];
+            const double4 lo = *reinterpret_cast<const double4*>(row + c * nmo + j), hi = *reinterpret_cast<const double4*>(row + c * nmo + j + 4);
+            r[c] += lo.x * t[0]; r[c] += lo.y * t[1]; r[c] += lo.z * t[2]; r[c] += lo.w * t[3];
+            r[c] += hi.x * t[4]; r[c] += hi.y * t[5]; r[c] += hi.z * t[6]; r[c] += hi.w * t[7];
+          }
+      } else
+#endif
       for (int j = 0; j < n; j += 8) {
         double t[8];
 #pragma unroll

@@ -1,96 +1,16 @@
-"""Diffusion Monte Carlo over the wave-function protocol — counterpart of ``pyqmc/method/dmc.py``.
+"""Diffusion Monte Carlo drivers — counterpart of ``pyqmc/method/dmc.py``.
 
-Everything numerical (orbitals, ratios, gradients, Sherman–Morrison, Jastrow, local energy, ECP
-T-move candidates) runs in the HIP library through the protocol objects; what is left on the host is
-the reference's own driver logic: drift limiting (``limdrift`` dmc.py:22-35), accept/reject with
-fixed-node rejection (``propose_drift_diffusion`` :49-70), T-move selection (``propose_tmoves``
-:73-120), weight update (``dmc_propagate`` :123-221, ``compute_S`` :224-235), the stochastic comb
-(``branch`` :342-376) and the block loop of ``rundmc`` (:413-591, without the HDF5 side).
+The step loop (T-moves, drift-diffusion with fixed-node rejection, weights: dmc.py:123-221) runs on the device
+(``pqa_dmc_steps``, csrc/pqa_dmc.hpp); here are its host wrapper, the stochastic comb (``branch`` dmc.py:342-376: an
+index computation on W weights) and the block loop of ``rundmc`` (:413-591) with restart files.  The reference's
+per-electron host loop is not restated: the parity tests drive the protocol entry points through
+``tests/helpers.protocol_dmc_propagate``, and an unmodified ``pyqmc.method.dmc`` runs over the wave-function objects.
 
-``rng`` (optional) supplies the random draws so tests can replay the reference's:
+``rng`` (optional, tests) supplies the random draws to replay the reference's:
 ``normal(W)->(W,3)``, ``rand(W)->(W,)``, ``rand1()->float``, ``rot()->(3,3)``, ``random(W)->(W,)``.
 """
 
 import numpy as np
-
-
-class _NumpyRNG:
-    """The draws of the reference, from numpy's global generator."""
-
-    def normal(self, W):
-        return np.random.normal(size=(W, 3))
-
-    def rand(self, W):
-        return np.random.rand(W)
-
-    def rand1(self):
-        return np.random.rand()
-
-    def random(self, W):
-        return np.random.random(size=W)
-
-    def rot(self):
-        q = np.random.normal(size=4)
-        w, x, y, z = q / np.linalg.norm(q)
-        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
-
-
-def limdrift(g, tau, acyrus=0.5):
-    """Umrigar's drift limiter; returns the drift already multiplied by an effective time step."""
-    v2 = np.einsum("ij,ij->i", g, g)
-    big = v2 > 1e-8
-    safe = np.where(big, v2, 1.0)
-    taueff = np.where(big, (np.sqrt(1 + 2 * tau * acyrus * safe) - 1) / (acyrus * safe), tau)
-    return g * taueff[:, None]
-
-
-def compute_S(e_trial, e_est, branchcut, v2, tau, eloc, nelec):
-    e_cut = np.clip(e_est - eloc, -branchcut, branchcut)
-    return e_trial - e_est + e_cut / np.sqrt(1 + (v2 * tau / nelec) ** 2)
-
-
-def _energy(acc, configs, wf, rng, N, necp, W):
-    """EnergyAccumulator call with the reference's per-(electron, atom) draws taken from ``rng``."""
-    if rng is None or necp == 0:
-        return acc(configs, wf)
-    unif, rot = np.empty((N, necp, W)), np.empty((N, necp, 3, 3))
-    for e in range(N):
-        for k in range(necp):
-            unif[e, k] = rng.random(W)
-            rot[e, k] = rng.rot()
-    return acc(configs, wf, rot=rot, unif=unif)
-
-
-def propose_tmoves(wf, configs, acc, tstep, e, rng, necp):
-    W = configs.configs.shape[0]
-    if isinstance(rng, _NumpyRNG):
-        moves = acc.nonlocal_tmoves(configs, wf, e, tstep)
-    else:
-        unif, rot = np.empty((necp, W)), np.empty((necp, 3, 3))
-        for k in range(necp):
-            unif[k] = rng.random(W)
-            rot[k] = rng.rot()
-        moves = acc.nonlocal_tmoves(configs, wf, e, tstep, rot=rot, unif=unif)
-    ratio, weight = moves["ratio"], moves["weight"]
-    amp = ratio * weight
-    fwd = np.maximum(amp, 0.0)
-    norm = 1.0 + fwd.sum(axis=1)  # Eq. 34 of Anderson & Umrigar
-    cdf = np.cumsum(fwd / norm[:, None], axis=1)
-    u = np.array([rng.rand1() for _ in range(W)])
-    sel = (cdf < u[:, None]).sum(axis=1)  # == searchsorted(cdf[w], u[w]) per walker
-    chosen = sel < amp.shape[1]
-    rows = np.nonzero(chosen)[0]
-    newpos = configs.configs[:, e, :].copy()
-    newpos[rows] = moves["configs"].configs[rows, sel[rows]]
-    back = amp.copy()
-    rr = 1.0 / ratio[rows, sel[rows]]
-    back[rows] *= rr[:, None]
-    back[rows, sel[rows]] = rr * weight[rows, sel[rows]]  # the move back to the original position
-    back_norm = 1.0 + np.maximum(back, 0.0).sum(axis=1)
-    acceptance = np.where(chosen, norm / back_norm, 0.0)
-    return configs.make_irreducible(e, newpos), chosen, acceptance
 
 
 def _record_tapes(rng, nsteps, N, necp, W, tmoves):
@@ -166,73 +86,23 @@ def fused_dmc_supported(wf, accumulators, ekey):
 
 
 def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps=5, accumulators=None,
-                  ekey=("energy", "total"), rng=None, fused=True, state_current=False):
+                  ekey=("energy", "total"), rng=None, state_current=False):
     """Propagate ``nsteps`` DMC steps without branching; returns (block averages, configs, weights) with the
     reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``).
 
-    ``fused=True`` (default) runs the step loop on the device (``pqa_dmc_steps``) whenever the wave function is real and
-    the energy accumulator is the only accumulator; otherwise, or with ``fused=False``, the loop below drives the
-    protocol entry points step by step like the reference does.  ``state_current=True`` (fused path only) promises that
-    the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on the device
-    (``DeviceWF.resample``) — and skips the initial recompute."""
+    The whole step loop of dmc.py:123-221 runs on the device (``pqa_dmc_steps``): real wave functions on one handle, the
+    energy accumulator as the only accumulator.  ``rng`` replays the reference's draws (tests); ``state_current=True``
+    promises that the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on
+    the device (``DeviceWF.resample``) — and skips the initial recompute.  Anything else (complex orbitals, further
+    accumulators inside the DMC loop) is not built here: the reference's own ``pyqmc.method.dmc.dmc_propagate`` runs over
+    these wave-function objects unmodified (``tests/helpers.protocol_dmc_propagate`` is that route)."""
     assert accumulators is not None, "Need an energy accumulator for DMC"
-    acc = accumulators[ekey[0]]
-    dev = fused_dmc_supported(wf, accumulators, ekey) if fused else None
-    if dev is not None:
-        return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, acc, ekey[0], rng,
-                                state_current=state_current)
-    replay = rng is not None
-    rng = rng if replay else _NumpyRNG()
-    W, N = configs.configs.shape[:2]
-    necp = getattr(acc._device(wf), "necp", 0)
-    wf.recompute(configs)
-    en = _energy(acc, configs, wf, rng if replay else None, N, necp, W)
-    eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
-    steps = []
-    for _ in range(nsteps):
-        r2_acc, r2_prop = np.zeros(W), np.zeros(W)
-        n_acc, n_tm = np.zeros(W), np.zeros(W)
-        if acc.has_nonlocal_moves():
-            for e in range(N):
-                ep, chosen, prob = propose_tmoves(wf, configs, acc, tstep, e, rng, necp)
-                accept = chosen & (prob > rng.rand(W))
-                configs.move(e, ep, accept)
-                wf.updateinternals(e, ep, configs, mask=accept)
-                n_tm += accept
-        for e in range(N):
-            drift = limdrift(np.real(wf.gradient(e, configs.electron(e)).T), tstep)
-            gauss = np.sqrt(tstep) * rng.normal(W)
-            ep = configs.make_irreducible(e, configs.configs[:, e, :] + gauss + drift)
-            g, psi_ratio, saved = wf.gradient_value(e, ep)
-            back = gauss + drift + limdrift(np.real(g.T), tstep)
-            t_prob = np.exp((np.einsum("ij,ij->i", gauss, gauss) - np.einsum("ij,ij->i", back, back)) / (2 * tstep))
-            ratio = np.abs(psi_ratio) ** 2 * t_prob
-            if wf.dtype == float:
-                ratio = ratio * np.sign(psi_ratio)  # fixed node: a sign change is never accepted
-            accept = ratio > rng.rand(W)
-            r2 = np.einsum("ij,ij->i", gauss + drift, gauss + drift)
-            configs.move(e, ep, accept)
-            wf.updateinternals(e, ep, configs, mask=accept, saved_values=saved)
-            r2_prop += r2
-            r2_acc += np.where(accept, r2, 0.0)
-            n_acc += accept
-        eloc_old, v2_old = eloc, v2
-        en = _energy(acc, configs, wf, rng if replay else None, N, necp, W)
-        eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
-        S = 0.5 * (compute_S(e_trial, e_est, branchcut_start, v2, tstep, eloc, N)
-                   + compute_S(e_trial, e_est, branchcut_start, v2_old, tstep, eloc_old, N))
-        weights *= np.exp(tstep * (r2_acc / r2_prop) * S)
-        wavg = np.mean(weights)
-        avg = {ekey[0] + k: np.dot(weights, v) / (W * wavg) for k, v in en.items()}
-        for name, other in accumulators.items():
-            if name != ekey[0]:
-                avg.update({name + k: np.einsum("...i,i...->...", weights, v) / (W * wavg) for k, v in other(configs, wf).items()})
-        avg.update(weight=wavg, acceptance=np.mean(n_acc) / N, tmove_acceptance=np.mean(n_tm) / N)
-        steps.append(avg)
-    wts = np.array([d["weight"] for d in steps])
-    out = {k: np.mean([d[k] * w for d, w in zip(steps, wts / wts.mean())], axis=0) for k in steps[0]}
-    out["weight"] = wts.mean()
-    return out, configs, weights
+    dev = fused_dmc_supported(wf, accumulators, ekey)
+    if dev is None:
+        raise NotImplementedError("pyqmc_amd.dmc_propagate runs real wave functions on one device handle with the EnergyAccumulator as the "
+                                  "only accumulator; drive pyqmc.method.dmc.dmc_propagate over the protocol objects for anything else")
+    return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators[ekey[0]], ekey[0], rng,
+                            state_current=state_current)
 
 
 def comb_indices(weights, base_u):
@@ -259,7 +129,7 @@ def branch(configs, weights, base_u=None, on_resample=None):
 
 def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=None, accumulators=None, verbose=False,
            ekey=("energy", "total"), vmc_warmup=10, branchcut_start=10, feedback=1.0, distributed=False, recompute_every=10,
-           hdf_file=None, continue_from=None, blockoffset=0):
+           hdf_file=None, continue_from=None, blockoffset=0, propagate=None, vmc_worker=None):
     """Block loop of the reference's ``rundmc`` (dmc.py:413-591): VMC warm-up and energy reference — or, when ``hdf_file``
     exists / ``continue_from`` is given, the walkers, weights, ``e_trial``, ``e_est``, ``esigma`` and block offset of that
     file (dmc.py:466-500) — then propagate -> branch -> trial-energy feedback per block.  With ``distributed=True`` every
@@ -273,7 +143,9 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     ``hdf_file``: per-block output, walkers and weights in the reference's on-disk layout (``dmc_file`` dmc.py:379-391;
     ``pyqmc_amd.blockfile``).  A sharded run writes one file per rank — rank 0 ``hdf_file`` itself, rank r
     ``hdf_file + ".rank<r>"`` — each with the (identical, all-reduced) block record and that rank's own walkers and
-    weights, so no two processes ever touch one file and every rank can continue from its own."""
+    weights, so no two processes ever touch one file and every rank can continue from its own.
+    ``propagate`` / ``vmc_worker``: callables with the signatures of ``dmc_propagate`` / ``vmc.vmc_worker`` to run the blocks
+    with instead of the device drivers (the CPU tests pass protocol-route drivers for the oracle's wave functions)."""
     from . import dist as pdist
     from .blockfile import BlockFile
     from .vmc import vmc
@@ -311,7 +183,7 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
         if verbose:
             print(f"Restarting calculation {continue_from} from block {blockoffset}")
     else:
-        _, configs = vmc(wf, configs, nblocks=vmc_warmup, accumulators={}, verbose=verbose)
+        _, configs = vmc(wf, configs, nblocks=vmc_warmup, accumulators={}, verbose=verbose, worker=vmc_worker)
         wf.recompute(configs)
         en = np.real(acc(configs, wf)[ekey[1]])
         if distributed:
@@ -324,12 +196,16 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
     weights = np.ones(W) if weights is None else weights
     rows = []
     en_hist, wt_hist = list(history.get("en", [])), list(history.get("wt", []))
-    dev = fused_dmc_supported(wf, accumulators, ekey)  # device-resident branching: single process AND sharded runs
+    dev = None if propagate is not None else fused_dmc_supported(wf, accumulators, ekey)  # device-resident branching: single process AND sharded runs
     current = False
     for block in range(blockoffset, nblocks):
-        blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
-                                              nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey,
-                                              state_current=current and block % max(int(recompute_every), 1) != 0)
+        if propagate is not None:
+            blk, configs, weights = propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
+                                              nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey)
+        else:
+            blk, configs, weights = dmc_propagate(wf, configs, weights, tstep, branchcut_start * esigma, e_trial, e_est,
+                                                  nsteps=nsteps_per_block, accumulators=accumulators, ekey=ekey,
+                                                  state_current=current and block % max(int(recompute_every), 1) != 0)
         if distributed:  # weighted recombination of the per-rank block averages (dmc.py:238-304)
             keys = sorted(k for k in blk if k != "weight")
             sums, _ = pdist.allreduce_block([blk[k] * blk["weight"] * W for k in keys] + [blk["weight"] * W, W], 1)

@@ -4,14 +4,16 @@
 ``pyqmc.method.mc.vmc_worker`` (``mc.py:102-153``): ``(block_avg dict, configs)`` with keys
 ``<acc><quantity>``, ``acceptance``, ``"move time"``, ``"accumulator time"``.
 
-Two ways to run it:
-  * fused (default when the wave function lives on one device handle and the only accumulators
-    are ``EnergyAccumulator``s): the whole electron loop and the energy evaluation run on the
-    GPU (``pqa_vmc_sweeps``); random numbers come from the device Philox stream seeded from
-    ``numpy.random`` (or from explicit tapes for trajectory-level parity tests);
-  * protocol: the reference's Python loop, calling the wave-function protocol once per electron
-    — the drop-in path an unmodified driver takes.  Host work here is only control flow and the
-    random numbers, exactly as in the reference.
+The electron loop always runs on the GPU (``pqa_vmc_sweeps``): random numbers come from the device
+Philox stream seeded from ``numpy.random`` (or from explicit tapes for trajectory-level parity
+tests).  With ``EnergyAccumulator``s only, the energy evaluation is fused into the same call; any
+other accumulator (density matrices, parameter gradients, ...) is called on the host after every
+device sweep, on the walkers fetched from the device, and talks to the wave function through the
+protocol entry points as it would in the reference.
+
+The reference's own per-electron Python loop (``mc.py:115-137``) is NOT restated here: an unmodified
+``pyqmc.method.mc.vmc_worker`` runs over these wave-function objects as they are,
+and the parity tests drive the protocol entry points through ``tests/helpers.protocol_vmc_worker``.
 """
 
 import time
@@ -21,19 +23,48 @@ import numpy as np
 from .energy import KEYS, EnergyAccumulator
 
 
-def limdrift(g, cutoff=1):
-    """mc.py:76-89."""
-    tot = np.linalg.norm(g, axis=1)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        return np.where((tot > cutoff)[:, None], cutoff * g / tot[:, None], g)
+def _fetch(dev, configs):
+    """Walkers of the device handle into the host container (periodic: folded positions + wrap counters)."""
+    if getattr(dev, "twisted", False):  # the handle keeps true (unfolded) coordinates: fold them back into the container
+        from .configs import enforce_pbc
+
+        configs.configs[...], configs.wrap[...] = enforce_pbc(configs.lvecs, dev.configs())
+    else:
+        configs.configs[...] = dev.configs()
+        if dev.pbc:  # walkers stay folded into the cell; their wrap counters advance (coord.py:180-189)
+            configs.wrap += dev.wrap_delta()
 
 
-def _fusable(wf, accumulators):
-    dev = wf.fused_device() if hasattr(wf, "fused_device") else None
-    return dev if dev is not None and all(isinstance(a, EnergyAccumulator) for a in accumulators.values()) else None
+def _vmc_worker_host_accumulators(dev, wf, configs, tstep, nsteps, accumulators, tapes, seed, state_current):
+    """Device sweeps, host accumulators: after every sweep (one ``pqa_vmc_sweeps`` call) the walkers come back and each
+    accumulator's ``avg(configs, wf)`` runs as in mc.py:142-148 — through the protocol entry points, on the state the sweep left."""
+    if seed is None:
+        seed = int(np.random.randint(0, 2**31 - 1))
+    if not state_current:
+        wf.recompute(configs)
+    block_avg = {}
+    t_move = t_acc = 0.0
+    acc_sum = 0.0
+    for step in range(nsteps):
+        t0 = time.perf_counter()
+        g, u = tapes.get("gauss"), tapes.get("unif")
+        acc, _, rec = dev.vmc_sweeps(tstep, 1, gauss=None if g is None else g[step : step + 1], unif=None if u is None else u[step : step + 1],
+                                     seed=seed + step, energy=False, record="record" in tapes)
+        if "record" in tapes:
+            tapes["record"].append(rec)
+        _fetch(dev, configs)
+        t1 = time.perf_counter()
+        for k, accumulator in accumulators.items():
+            for m, res in accumulator.avg(configs, wf).items():
+                block_avg[k + m] = block_avg.get(k + m, 0.0) + res / nsteps
+        t_move, t_acc, acc_sum = t_move + (t1 - t0), t_acc + (time.perf_counter() - t1), acc[-1]
+    block_avg["acceptance"] = acc_sum
+    block_avg["move time"] = t_move / nsteps
+    block_avg["accumulator time"] = t_acc / nsteps
+    return block_avg, configs
 
 
-def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None, seed=None, state_current=False, fetch_configs=True):
+def vmc_worker(wf, configs, tstep, nsteps, accumulators, tapes=None, seed=None, state_current=False, fetch_configs=True):
     """One block of ``nsteps`` sweeps (mc.py:102-153): returns (block averages, configs).
 
     ``state_current`` / ``fetch_configs`` are for block loops on the fused device path (``vmc`` below): the reference's worker
@@ -42,11 +73,12 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     that knows the device already holds the state of ``configs`` (it ran the previous block and touched nothing since) passes
     ``state_current=True``; one that does not need the walkers on the host after this block passes ``fetch_configs=False``
     (open systems only: periodic containers also carry the block's wrap counters)."""
-    dev = _fusable(wf, accumulators) if fused in (None, True) else None
-    if fused is True and dev is None:
-        raise TypeError("fused VMC needs a pyqmc_amd wave function on one device handle and EnergyAccumulator only")
+    dev = wf.fused_device() if hasattr(wf, "fused_device") else None
     if dev is None:
-        return _vmc_worker_protocol(wf, configs, tstep, nsteps, accumulators)
+        raise TypeError("pyqmc_amd.vmc_worker drives a wave function that lives on one device handle (generate_wf); for anything else "
+                        "run the reference's own pyqmc.method.mc.vmc_worker over the protocol objects (INTEGRATION.md)")
+    if not all(isinstance(a, EnergyAccumulator) for a in accumulators.values()):
+        return _vmc_worker_host_accumulators(dev, wf, configs, tstep, nsteps, accumulators, tapes or {}, seed, state_current)
     tapes = tapes or {}
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
@@ -72,58 +104,18 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, fused=None, tapes=None,
     block_avg["accumulator time"] = 0.0
     if not fetch_configs and not dev.pbc:
         return block_avg, configs  # (stale on the host until a later block fetches them)
-    if getattr(dev, "twisted", False):  # the handle keeps true (unfolded) coordinates: fold them back into the container
-        from .configs import enforce_pbc
-
-        configs.configs[...], configs.wrap[...] = enforce_pbc(configs.lvecs, dev.configs())
-    else:
-        configs.configs[...] = dev.configs()
-        if dev.pbc:  # walkers stay folded into the cell; their wrap counters advance (coord.py:180-189)
-            configs.wrap += dev.wrap_delta()
+    _fetch(dev, configs)
     return block_avg, configs
 
 
-def _vmc_worker_protocol(wf, configs, tstep, nsteps, accumulators):
-    """Line-for-line control flow of mc.py:102-153 over the protocol."""
-    nconf, nelec, _ = configs.configs.shape
-    block_avg = {}
-    wf.recompute(configs)
-    for _ in range(nsteps):
-        acc = 0.0
-        t0 = time.perf_counter()
-        for e in range(nelec):
-            g, _, _ = wf.gradient_value(e, configs.electron(e))
-            grad = limdrift(np.real(g.T))
-            gauss = np.random.normal(scale=np.sqrt(tstep), size=(nconf, 3))
-            newcoorde = configs.make_irreducible(e, configs.configs[:, e, :] + gauss + grad * tstep)
-            g, new_val, saved = wf.gradient_value(e, newcoorde)
-            new_grad = limdrift(np.real(g.T))
-            forward = np.sum(gauss**2, axis=1)
-            backward = np.sum((gauss + tstep * (grad + new_grad)) ** 2, axis=1)
-            t_prob = np.exp(1 / (2 * tstep) * (forward - backward))
-            ratio = np.abs(new_val) ** 2 * t_prob
-            accept = ratio > np.random.rand(nconf)
-            configs.move(e, newcoorde, accept)
-            wf.updateinternals(e, newcoorde, configs, mask=accept, saved_values=saved)
-            acc += np.mean(accept) / nelec
-        t1 = time.perf_counter()
-        for k, accumulator in accumulators.items():
-            dat = accumulator.avg(configs, wf)
-            for m, res in dat.items():
-                block_avg[k + m] = block_avg.get(k + m, 0.0) + res / nsteps
-        t2 = time.perf_counter()
-        block_avg["acceptance"] = acc
-        block_avg["move time"] = t1 - t0
-        block_avg["accumulator time"] = t2 - t1
-    return block_avg, configs
-
-
-def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=None, verbose=False, seed=None, fused=None,
-        hdf_file=None, continue_from=None, recompute_every=10):
+def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=None, verbose=False, seed=None,
+        hdf_file=None, continue_from=None, recompute_every=10, worker=None):
     """Block loop of ``pyqmc.method.mc.vmc`` (mc.py:176-274): returns (dict of arrays over the blocks run, configs).
     ``hdf_file``: block output in the reference's on-disk layout (``pyqmc_amd.blockfile``: HDF5 when h5py exists, NumPy
     archives otherwise); an existing file — or ``continue_from`` — restarts from its walkers at ``block[-1] + 1``, and
-    ``nblocks`` counts the blocks of all calls together, as in the reference (mc.py:223-243)."""
+    ``nblocks`` counts the blocks of all calls together, as in the reference (mc.py:223-243).  ``worker``: a
+    ``(wf, configs, tstep, nsteps, accumulators) -> (block, configs)`` callable to run the blocks with instead of the device
+    worker (the test suite passes a protocol-route worker for the CPU oracle's wave functions)."""
     from .blockfile import BlockFile
 
     accumulators = accumulators or {}
@@ -139,7 +131,7 @@ def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=No
         first = source.last_block() + 1
         source.load_walkers(configs)
     df = {}
-    dev = _fusable(wf, accumulators) if fused in (None, True) else None
+    dev = wf.fused_device() if worker is None and hasattr(wf, "fused_device") and all(isinstance(a, EnergyAccumulator) for a in accumulators.values()) else None
     current = False  # the device holds the wave-function state of the walkers it moved in the previous block
     for block in range(first, nblocks):
         # fused path: the walkers stay on the device from block to block; the state is rebuilt from the (fetched) walkers every
@@ -147,8 +139,11 @@ def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=No
         # written to disk, before such a rebuild, and at the end
         rebuild_next = dev is not None and (block + 1 - first) % recompute_every == 0
         fetch = out is not None or block == nblocks - 1 or rebuild_next
-        blk, configs = vmc_worker(wf, configs, tstep, nsteps_per_block, accumulators, fused=fused,
-                                  seed=None if seed is None else seed + block, state_current=current, fetch_configs=fetch)
+        if worker is not None:
+            blk, configs = worker(wf, configs, tstep, nsteps_per_block, accumulators)
+        else:
+            blk, configs = vmc_worker(wf, configs, tstep, nsteps_per_block, accumulators,
+                                      seed=None if seed is None else seed + block, state_current=current, fetch_configs=fetch)
         current = dev is not None and not rebuild_next
         blk["block"] = block
         blk["nconfig"] = nsteps_per_block * configs.configs.shape[0]

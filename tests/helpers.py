@@ -375,3 +375,199 @@ def twist_case(tag):
     S, twist = TWIST_CASES[tag]
     sup = pbc.get_supercell(systems.diamond_primitive(), S)
     return sup, pbc.random_kmf(sup, complex_coeff=True, twist=twist)
+
+
+# ---------------------------------------------------------------- protocol-route drivers (test harness only)
+# The product drivers (pyqmc_amd.vmc / pyqmc_amd.dmc) keep the electron loops on the device.  The drop-in claim — the
+# reference's own Python drivers run unmodified over the wave-function objects — is exercised here by loops with the
+# reference's control flow that call nothing but the protocol entry points (recompute, gradient, gradient_value,
+# updateinternals, testvalue through the accumulators).  They also drive the CPU oracle's objects in the CPU tests.
+import time as _time
+
+
+def vmc_limdrift(g, cutoff=1):
+    """mc.py:76-89."""
+    tot = np.linalg.norm(g, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where((tot > cutoff)[:, None], cutoff * g / tot[:, None], g)
+
+
+def protocol_vmc_worker(wf, configs, tstep, nsteps, accumulators):
+    """TEST HARNESS — the reference's ``vmc_worker`` control flow (mc.py:102-153) over the wave-function protocol: what an
+    unmodified ``pyqmc.method.mc`` does with the objects it is handed (the reference itself does not travel to the GPU box)."""
+    nconf, nelec, _ = configs.configs.shape
+    block_avg = {}
+    wf.recompute(configs)
+    for _ in range(nsteps):
+        acc = 0.0
+        t0 = _time.perf_counter()
+        for e in range(nelec):
+            g, _, _ = wf.gradient_value(e, configs.electron(e))
+            grad = vmc_limdrift(np.real(g.T))
+            gauss = np.random.normal(scale=np.sqrt(tstep), size=(nconf, 3))
+            newcoorde = configs.make_irreducible(e, configs.configs[:, e, :] + gauss + grad * tstep)
+            g, new_val, saved = wf.gradient_value(e, newcoorde)
+            new_grad = vmc_limdrift(np.real(g.T))
+            forward = np.sum(gauss**2, axis=1)
+            backward = np.sum((gauss + tstep * (grad + new_grad)) ** 2, axis=1)
+            t_prob = np.exp(1 / (2 * tstep) * (forward - backward))
+            ratio = np.abs(new_val) ** 2 * t_prob
+            accept = ratio > np.random.rand(nconf)
+            configs.move(e, newcoorde, accept)
+            wf.updateinternals(e, newcoorde, configs, mask=accept, saved_values=saved)
+            acc += np.mean(accept) / nelec
+        t1 = _time.perf_counter()
+        for k, accumulator in accumulators.items():
+            dat = accumulator.avg(configs, wf)
+            for m, res in dat.items():
+                block_avg[k + m] = block_avg.get(k + m, 0.0) + res / nsteps
+        t2 = _time.perf_counter()
+        block_avg["acceptance"] = acc
+        block_avg["move time"] = t1 - t0
+        block_avg["accumulator time"] = t2 - t1
+    return block_avg, configs
+
+
+
+class NumpyRNG:
+    """The draws of the reference, from numpy's global generator."""
+
+    def normal(self, W):
+        return np.random.normal(size=(W, 3))
+
+    def rand(self, W):
+        return np.random.rand(W)
+
+    def rand1(self):
+        return np.random.rand()
+
+    def random(self, W):
+        return np.random.random(size=W)
+
+    def rot(self):
+        q = np.random.normal(size=4)
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def limdrift(g, tau, acyrus=0.5):
+    """Umrigar's drift limiter; returns the drift already multiplied by an effective time step."""
+    v2 = np.einsum("ij,ij->i", g, g)
+    big = v2 > 1e-8
+    safe = np.where(big, v2, 1.0)
+    taueff = np.where(big, (np.sqrt(1 + 2 * tau * acyrus * safe) - 1) / (acyrus * safe), tau)
+    return g * taueff[:, None]
+
+
+def compute_S(e_trial, e_est, branchcut, v2, tau, eloc, nelec):
+    e_cut = np.clip(e_est - eloc, -branchcut, branchcut)
+    return e_trial - e_est + e_cut / np.sqrt(1 + (v2 * tau / nelec) ** 2)
+
+
+
+def _dmc_energy(acc, configs, wf, rng, N, necp, W):
+    """EnergyAccumulator call with the reference's per-(electron, atom) draws taken from ``rng``."""
+    if rng is None or necp == 0:
+        return acc(configs, wf)
+    unif, rot = np.empty((N, necp, W)), np.empty((N, necp, 3, 3))
+    for e in range(N):
+        for k in range(necp):
+            unif[e, k] = rng.random(W)
+            rot[e, k] = rng.rot()
+    return acc(configs, wf, rot=rot, unif=unif)
+
+
+def propose_tmoves(wf, configs, acc, tstep, e, rng, necp):
+    W = configs.configs.shape[0]
+    if isinstance(rng, NumpyRNG):
+        moves = acc.nonlocal_tmoves(configs, wf, e, tstep)
+    else:
+        unif, rot = np.empty((necp, W)), np.empty((necp, 3, 3))
+        for k in range(necp):
+            unif[k] = rng.random(W)
+            rot[k] = rng.rot()
+        moves = acc.nonlocal_tmoves(configs, wf, e, tstep, rot=rot, unif=unif)
+    ratio, weight = moves["ratio"], moves["weight"]
+    amp = ratio * weight
+    fwd = np.maximum(amp, 0.0)
+    norm = 1.0 + fwd.sum(axis=1)  # Eq. 34 of Anderson & Umrigar
+    cdf = np.cumsum(fwd / norm[:, None], axis=1)
+    u = np.array([rng.rand1() for _ in range(W)])
+    sel = (cdf < u[:, None]).sum(axis=1)  # == searchsorted(cdf[w], u[w]) per walker
+    chosen = sel < amp.shape[1]
+    rows = np.nonzero(chosen)[0]
+    newpos = configs.configs[:, e, :].copy()
+    newpos[rows] = moves["configs"].configs[rows, sel[rows]]
+    back = amp.copy()
+    rr = 1.0 / ratio[rows, sel[rows]]
+    back[rows] *= rr[:, None]
+    back[rows, sel[rows]] = rr * weight[rows, sel[rows]]  # the move back to the original position
+    back_norm = 1.0 + np.maximum(back, 0.0).sum(axis=1)
+    acceptance = np.where(chosen, norm / back_norm, 0.0)
+    return configs.make_irreducible(e, newpos), chosen, acceptance
+
+
+
+def protocol_dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps=5, accumulators=None,
+                           ekey=("energy", "total"), rng=None):
+    """TEST HARNESS — the reference's ``dmc_propagate`` control flow (dmc.py:123-221) over the wave-function protocol and the
+    accumulator interface, i.e. what an unmodified ``pyqmc.method.dmc`` does with the objects it is handed (the reference
+    itself is not available where the GPU tests run).  ``rng``: replayed draws (ReplayTape) or None (numpy's generator)."""
+    assert accumulators is not None
+    acc = accumulators[ekey[0]]
+    replay = rng is not None
+    rng = rng if replay else NumpyRNG()
+    W, N = configs.configs.shape[:2]
+    necp = getattr(acc._device(wf), "necp", 0)
+    wf.recompute(configs)
+    en = _dmc_energy(acc, configs, wf, rng if replay else None, N, necp, W)
+    eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
+    steps = []
+    for _ in range(nsteps):
+        r2_acc, r2_prop = np.zeros(W), np.zeros(W)
+        n_acc, n_tm = np.zeros(W), np.zeros(W)
+        if acc.has_nonlocal_moves():
+            for e in range(N):
+                ep, chosen, prob = propose_tmoves(wf, configs, acc, tstep, e, rng, necp)
+                accept = chosen & (prob > rng.rand(W))
+                configs.move(e, ep, accept)
+                wf.updateinternals(e, ep, configs, mask=accept)
+                n_tm += accept
+        for e in range(N):
+            drift = limdrift(np.real(wf.gradient(e, configs.electron(e)).T), tstep)
+            gauss = np.sqrt(tstep) * rng.normal(W)
+            ep = configs.make_irreducible(e, configs.configs[:, e, :] + gauss + drift)
+            g, psi_ratio, saved = wf.gradient_value(e, ep)
+            back = gauss + drift + limdrift(np.real(g.T), tstep)
+            t_prob = np.exp((np.einsum("ij,ij->i", gauss, gauss) - np.einsum("ij,ij->i", back, back)) / (2 * tstep))
+            ratio = np.abs(psi_ratio) ** 2 * t_prob
+            if wf.dtype == float:
+                ratio = ratio * np.sign(psi_ratio)  # fixed node: a sign change is never accepted
+            accept = ratio > rng.rand(W)
+            r2 = np.einsum("ij,ij->i", gauss + drift, gauss + drift)
+            configs.move(e, ep, accept)
+            wf.updateinternals(e, ep, configs, mask=accept, saved_values=saved)
+            r2_prop += r2
+            r2_acc += np.where(accept, r2, 0.0)
+            n_acc += accept
+        eloc_old, v2_old = eloc, v2
+        en = _dmc_energy(acc, configs, wf, rng if replay else None, N, necp, W)
+        eloc, v2 = np.real(en[ekey[1]]), en["grad2"]
+        S = 0.5 * (compute_S(e_trial, e_est, branchcut_start, v2, tstep, eloc, N)
+                   + compute_S(e_trial, e_est, branchcut_start, v2_old, tstep, eloc_old, N))
+        weights *= np.exp(tstep * (r2_acc / r2_prop) * S)
+        wavg = np.mean(weights)
+        avg = {ekey[0] + k: np.dot(weights, v) / (W * wavg) for k, v in en.items()}
+        for name, other in accumulators.items():
+            if name != ekey[0]:
+                avg.update({name + k: np.einsum("...i,i...->...", weights, v) / (W * wavg) for k, v in other(configs, wf).items()})
+        avg.update(weight=wavg, acceptance=np.mean(n_acc) / N, tmove_acceptance=np.mean(n_tm) / N)
+        steps.append(avg)
+    wts = np.array([d["weight"] for d in steps])
+    out = {k: np.mean([d[k] * w for d, w in zip(steps, wts / wts.mean())], axis=0) for k in steps[0]}
+    out["weight"] = wts.mean()
+    return out, configs, weights
+
+

@@ -2,7 +2,9 @@
 
 The driver only talks to the wave-function protocol and the accumulator interface, so here the ORACLE
 objects stand in for the GPU engine; the replayed random draws are the reference's own
-(tests/golden/g12_dmc.npz), so the driver must reproduce the reference's dmc_propagate exactly."""
+(tests/golden/g12_dmc.npz), so the protocol-route harness (tests/helpers.protocol_dmc_propagate: the reference's control flow
+over the protocol) must reproduce the reference's dmc_propagate exactly; rundmc's block loop, restart files and the
+distributed comb are the product's (pyqmc_amd.dmc / dist), driven here with the harness as propagator."""
 
 import os
 import socket
@@ -36,7 +38,7 @@ class OracleAccumulator:
 
         if rot is None:  # no replay tape: draw like the reference does, from numpy's global generator
             W, N = configs.configs.shape[:2]
-            necp, rng = self._device(wf).necp, dmc._NumpyRNG()
+            necp, rng = self._device(wf).necp, helpers.NumpyRNG()
             unif = np.array([[rng.random(W) for _ in range(necp)] for _ in range(N)])
             rot = np.array([[rng.rot() for _ in range(necp)] for _ in range(N)])
         return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif)
@@ -58,7 +60,7 @@ class OracleAccumulator:
                 return next(s.u)
 
         if rot is None:
-            W, necp, rng = configs.configs.shape[0], self._device(wf).necp, dmc._NumpyRNG()
+            W, necp, rng = configs.configs.shape[0], self._device(wf).necp, helpers.NumpyRNG()
             unif, rot = [rng.random(W) for _ in range(necp)], [rng.rot() for _ in range(necp)]
         ratio, weight, pos = odmc.compute_tmoves(self.mol, configs, wf, e, self.threshold, tau, T())
         return {"ratio": ratio, "weight": weight, "configs": configs.make_irreducible(e, pos)}
@@ -72,7 +74,7 @@ def test_driver_reproduces_reference_dmc_propagate():
     accepts = []
     orig = wf.updateinternals
     wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
-    df, configs, weights = dmc.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+    df, configs, weights = helpers.protocol_dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
                                              float(e_trial), float(e_est), nsteps=int(nsteps),
                                              accumulators={"energy": OracleAccumulator(mol)}, rng=helpers.ReplayTape(g))
     assert np.array_equal(np.asarray(accepts), g["accepts"])
@@ -87,9 +89,9 @@ def test_limdrift_and_compute_S_match_oracle():
 
     rng = np.random.default_rng(0)
     gvec = rng.standard_normal((50, 3)) * np.logspace(-6, 2, 50)[:, None]
-    assert np.allclose(dmc.limdrift(gvec, 0.02), odmc.limdrift(gvec, 0.02), rtol=1e-14, atol=0)
+    assert np.allclose(helpers.limdrift(gvec, 0.02), odmc.limdrift(gvec, 0.02), rtol=1e-14, atol=0)
     v2, eloc = rng.random(20) * 50, rng.standard_normal(20) * 5
-    assert np.allclose(dmc.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc, 8), odmc.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc.copy(), 8), rtol=1e-14)
+    assert np.allclose(helpers.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc, 8), odmc.compute_S(-1.0, -1.2, 2.0, v2, 0.02, eloc.copy(), 8), rtol=1e-14)
 
 
 def test_branch_matches_reference_golden():
@@ -240,7 +242,7 @@ def test_driver_reproduces_reference_periodic_dmc_propagate():
     orig = wf.updateinternals
     wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
     cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
-    df, cfg, weights = dmc.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+    df, cfg, weights = helpers.protocol_dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
                                          nsteps=int(nsteps), accumulators={"energy": OracleAccumulator(sup)}, rng=helpers.ReplayTape(g))
     assert np.array_equal(np.asarray(accepts), g["accepts"])
     assert relerr(cfg.configs, g["final"]) < 1e-10 and np.array_equal(cfg.wrap, g["final_wrap"]) and relerr(weights, g["weights"]) < 1e-9
@@ -258,7 +260,8 @@ def _small_dmc(path, nblocks, W=6, seed=3, distributed=False, **kw):
     np.random.seed(seed)
     cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(seed))
     return dmc.rundmc(wf, cfg, tstep=0.05, nblocks=nblocks, nsteps_per_block=1, vmc_warmup=1, distributed=distributed,
-                      accumulators={"energy": OracleAccumulator(mol)}, hdf_file=path, **kw)
+                      accumulators={"energy": OracleAccumulator(mol)}, hdf_file=path, propagate=helpers.protocol_dmc_propagate,
+                      vmc_worker=helpers.protocol_vmc_worker, **kw)
 
 
 def test_rundmc_continues_an_existing_block_file(tmp_path):

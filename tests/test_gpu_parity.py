@@ -176,7 +176,7 @@ def test_vmc_trajectory_golden(tag, mol, fused, monkeypatch):
         orig = wf.updateinternals
         monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
         monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
-        blk, configs = pa.vmc_worker(wf, configs, tstep, nsteps, {"energy": acc}, fused=False)
+        blk, configs = helpers.protocol_vmc_worker(wf, configs, tstep, nsteps, {"energy": acc})
         accepts = np.asarray(accepts).reshape(g[tag + "_accepts"].shape)
     assert np.array_equal(np.asarray(accepts, dtype=bool), g[tag + "_accepts"])
     assert note(f"vmc_{tag}_{fused}_final", relerr(configs.configs, g[tag + "_final"])) < 1e-9
@@ -286,9 +286,9 @@ def test_dmc_propagate_golden():
     accepts = []
     orig = wf.updateinternals
     wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
-    df, configs, weights = pa.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+    df, configs, weights = helpers.protocol_dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
                                             float(e_trial), float(e_est), nsteps=int(nsteps),
-                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g), fused=False)
+                                            accumulators={"energy": pa.EnergyAccumulator(mol)}, rng=helpers.ReplayTape(g))
     assert np.array_equal(np.asarray(accepts), g["accepts"])
     assert note("dmc_final", relerr(configs.configs, g["final"])) < 1e-9
     assert note("dmc_weights", relerr(weights, g["weights"])) < 1e-8
@@ -336,7 +336,7 @@ def test_fused_dmc_philox_statistics():
     args = (0.02, 10 * e0.std(), e0.mean(), e0.mean())
     np.random.seed(3)
     a, ca, wa = pa.dmc_propagate(wf, OpenConfigs(start.configs.copy()), np.ones(W), *args, nsteps=6, accumulators={"energy": acc})
-    b, cb, wb = pa.dmc_propagate(wf, OpenConfigs(start.configs.copy()), np.ones(W), *args, nsteps=6, accumulators={"energy": acc}, fused=False)
+    b, cb, wb = helpers.protocol_dmc_propagate(wf, OpenConfigs(start.configs.copy()), np.ones(W), *args, nsteps=6, accumulators={"energy": acc})
     err = 4 * e0.std() / np.sqrt(W)
     assert abs(a["energytotal"] - b["energytotal"]) < err, (a["energytotal"], b["energytotal"], err)
     assert abs(a["acceptance"] - b["acceptance"]) < 0.02 and abs(a["tmove_acceptance"] - b["tmove_acceptance"]) < 0.01

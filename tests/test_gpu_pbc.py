@@ -135,7 +135,7 @@ def test_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
         orig = wf.updateinternals
         monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
         monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
-        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        blk, cfg = helpers.protocol_vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc})
         accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
     assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
     assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
@@ -185,9 +185,9 @@ def test_periodic_dmc_propagate_matches_reference():
     orig = wf.updateinternals
     wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
     cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
-    df, cfg, weights = pa.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+    df, cfg, weights = helpers.protocol_dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
                                         nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
-                                        rng=helpers.ReplayTape(g), fused=False)
+                                        rng=helpers.ReplayTape(g))
     assert np.array_equal(np.asarray(accepts), g["accepts"])
     assert helpers.relerr(cfg.configs, g["final"]) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
     assert helpers.relerr(weights, g["weights"]) < 1e-8
@@ -307,7 +307,7 @@ def test_complex_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
         orig = wf.updateinternals
         monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
         monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
-        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        blk, cfg = helpers.protocol_vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc})
         accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
     assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
     assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])
@@ -406,7 +406,7 @@ def test_twisted_energy_and_vmc_match_reference(fused, monkeypatch):
         orig = wf.updateinternals
         monkeypatch.setattr(wf, "updateinternals", lambda e, ep, c, mask=None, saved_values=None: (accepts.append(mask.copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1])
         monkeypatch.setattr(acc, "avg", lambda c, w: {k: np.mean(v) for k, v in acc(c, w, rot=next(rots), unif=next(eun)).items()})
-        blk, cfg = pa.vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc}, fused=False)
+        blk, cfg = helpers.protocol_vmc_worker(wf, cfg, tstep, nsteps, {"energy": acc})
         accepts = np.asarray(accepts).reshape(g["vmc_accepts"].shape)
     assert np.array_equal(np.asarray(accepts, dtype=bool), g["vmc_accepts"])
     assert helpers.relerr(cfg.configs, g["vmc_final"]) < 1e-9 and np.array_equal(cfg.wrap, g["vmc_final_wrap"])

@@ -17,7 +17,9 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))  # --host: the protocol-route harness
 import pyqmc_amd as pa  # noqa: E402
+import helpers  # noqa: E402
 from pyqmc_amd import pbc  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -71,11 +73,11 @@ if a.config == "c5" and a.rundmc:
 elif a.config == "c5":
     acc = {"energy": pa.EnergyAccumulator(sup)}
     weights = np.ones(W)
-    pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=2, accumulators=acc, fused=not a.host)
+    (helpers.protocol_dmc_propagate if a.host else pa.dmc_propagate)(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=2, accumulators=acc)
     dt = float("inf")
     for _ in range(1 if a.host else a.repeat):  # best of `repeat` timed passes: about one process in eight sees a 1.5-2x slow pass
         t0 = time.perf_counter()
-        blk, cfg, weights = pa.dmc_propagate(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc, fused=not a.host)
+        blk, cfg, weights = (helpers.protocol_dmc_propagate if a.host else pa.dmc_propagate)(wf, cfg, weights, 0.02, 3.0, -40.0, -40.0, nsteps=a.steps, accumulators=acc)
         dt = min(dt, time.perf_counter() - t0)
     kind = "DMC (host-driven protocol path)" if a.host else "DMC (pqa_dmc_steps)"
     extra = {k: float(np.real(blk[k])) for k in ("acceptance", "tmove_acceptance", "weight")}

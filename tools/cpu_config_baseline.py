@@ -39,7 +39,7 @@ def worker(args):
     from oracle import gto as ogto
     from oracle import vmc as ovmc
     from pyqmc_amd import pbc, systems
-    from pyqmc_amd.dmc import _NumpyRNG
+    from helpers import NumpyRNG as _NumpyRNG
 
     ogto.set_ao_backend("c")
     W, nsteps = SIZES[name]
