@@ -26,9 +26,10 @@ def limdrift(g, cutoff=1.0):
 
 
 def vmc_worker(mol, wf, configs, tstep, gauss, unif, ecp_rot=None, ecp_unif=None, threshold=10.0,
-               with_energy=True, record=None, ewald_kws=None):
+               with_energy=True, record=None, ewald_kws=None, margins=None):
     """Returns (block_avg dict, configs).  ``record`` (optional list) receives the
-    per-move accept masks for trajectory comparison."""
+    per-move accept masks for trajectory comparison, ``margins`` (optional list) the per-move ``ratio - u`` of the
+    Metropolis test (how far each decision was from flipping)."""
     nsteps = gauss.shape[0]
     W, N, _ = configs.configs.shape
     block_avg = {}
@@ -54,6 +55,8 @@ def vmc_worker(mol, wf, configs, tstep, gauss, unif, ecp_rot=None, ecp_unif=None
             acc += np.mean(accept) / N
             if record is not None:
                 record.append(accept.copy())
+            if margins is not None:
+                margins.append(ratio - unif[step, e])
         t1 = time.perf_counter()
         if with_energy:
             en = oenergy.energy(mol, configs, wf, threshold,

@@ -13,6 +13,8 @@
 #include "pqa_common.hpp"
 #include "pqa_sph_high.hpp"
 
+#define PQA_STR_(x) #x
+#define PQA_UNROLL_N(n) _Pragma(PQA_STR_(unroll n))  // (a macro inside '#pragma unroll' does not survive -save-temps builds)
 #ifndef PQA_PRIM_UNROLL
 #define PQA_PRIM_UNROLL 1
 #endif
@@ -88,7 +90,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
   const double r2 = x * x + y * y + z * z;
   double R = 0.0, dRs = 0.0, lapR = 0.0;
-#pragma unroll PQA_PRIM_UNROLL
+  PQA_UNROLL_N(PQA_PRIM_UNROLL)
   for (int p = 0; p < np; ++p) {
     const double a = pexp[p];
     if ((SCREEN || PQA_PRIM_SCREEN) && a * r2 > PQA_PRIM_CUT) continue;

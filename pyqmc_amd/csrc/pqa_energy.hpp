@@ -131,7 +131,9 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
     for (int idx = 0; idx < 27; ++idx) {
       const int a = idx / 9 - 1, b = (idx / 3) % 3 - 1, c = idx % 3 - 1;
       const double r2 = d2 + (a * p0 + b * p1 + c * p2) + img_l2[idx];
-      if (!(a2 * r2 > 40.0)) m |= 1u << idx;  // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum
+      // erfc(x)/r < 4e-19 for x^2 > 40: below the last bit of the sum.  (r2 comes from |d|^2 + 2 d.L + |L|^2 and can cancel to
+      // a tiny NEGATIVE number next to a lattice point: such an image is marked — its true r2, recomputed below, is ~0.)
+      if (!(a2 * r2 > 40.0)) m |= 1u << idx;
     }
     double acc = 0.0;
     while (__any(m != 0u)) {
@@ -147,7 +149,9 @@ __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, con
         double ir = __builtin_amdgcn_rsq(r2);
         ir = ir * fma(-hr2 * ir, ir, 1.5);
         ir = ir * fma(-hr2 * ir, ir, 1.5);
-        acc += erfc_fast(E.alpha * (r2 * ir)) * ir;
+        // coincident particles (r2 == 0: rsq = inf and the Newton step makes inf * 0 = NaN): erfc(0)/0 = +inf, as the
+        // IEEE sequence gave; the term never enters an accepted configuration but must not poison the sum with NaN
+        acc += (r2 > 0.0) ? erfc_fast(E.alpha * (r2 * ir)) * ir : __builtin_inf();
       }
     }
     return acc;

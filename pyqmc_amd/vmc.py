@@ -119,6 +119,7 @@ def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=No
     from .blockfile import BlockFile
 
     accumulators = accumulators or {}
+    recompute_every = max(int(recompute_every), 1)
     out = None if hdf_file is None else BlockFile(hdf_file)
     source = out if continue_from is None else BlockFile(continue_from)
     if continue_from is not None:

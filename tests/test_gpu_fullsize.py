@@ -127,14 +127,17 @@ def test_vmc_sweep_at_baseline_size(cfg):
     owf = make_oracle()
     ocfg = start.copy()
     ocfg = _container(mol, ocfg.configs[:NCHECK].copy(), None if not hasattr(ocfg, "wrap") else ocfg.wrap[:NCHECK].copy())
-    record = []
-    _, ocfg = ovmc.vmc_worker(mol, owf, ocfg, tstep, gauss, unif, with_energy=False, record=record)
+    record, margins = [], []
+    _, ocfg = ovmc.vmc_worker(mol, owf, ocfg, tstep, gauss, unif, with_energy=False, record=record, margins=margins)
     odec = np.asarray(record).reshape(nsteps, -1, NCHECK)
     same = odec == rec[:, :, :NCHECK]
     note(f"{cfg}_decisions_equal", same.mean())
-    assert same.mean() > 0.995  # a near-tie (|ratio - u| ~ 1e-12) may flip; such a walker is excluded below
+    # every decision is the oracle's — except where the oracle's own Metropolis test was a near-tie (|ratio - u| < 1e-9, which
+    # round-off may legitimately flip); a walker is only excused from the comparisons below by such a near-tie (none occurs
+    # with these seeds: measured 1.0 for every configuration)
+    near_tie = np.abs(np.asarray(margins).reshape(nsteps, -1, NCHECK)) < 1e-9
+    assert np.all(same | near_tie), (int((~same).sum()), float(np.abs(np.asarray(margins)).min()))
     good = same.all(axis=(0, 1))
-    assert good.sum() >= NCHECK - 1
     ox = ocfg.configs + (ocfg.wrap @ mol.lattice_vectors() if (cfg == "C3") else 0.0)  # twisted handles keep true coordinates
     assert note(f"{cfg}_vs_oracle_configs", relerr(x[:NCHECK][good], ox[good])) < 1e-11
     assert note(f"{cfg}_vs_oracle_log", np.max(np.abs(owf.recompute(ocfg)[1][good] - logv[:NCHECK][good]))) < 1e-9

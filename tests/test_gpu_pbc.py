@@ -243,6 +243,47 @@ def test_ewald_madelung_constants_on_device():
         assert abs(coulomb[0] - want) < 1e-4 * max(1, abs(want) / 1.7), (name, coulomb, want)
 
 
+def test_ewald_edge_cases_coincident_particles_and_cutoff_boundary():
+    """k_ewald's 1/r comes from v_rsq_f64 + Newton steps and its erfc from a table cut at alpha^2 r^2 = 40.
+    (a) two coincident electrons: the pair term is +inf (as erfc(0)/0 was with the IEEE sequence), never NaN; a pair 1e-9 bohr
+    apart gives a large finite energy equal to the oracle's.  (b) an electron pair whose distance puts the nearest image EXACTLY
+    at alpha r = sqrt(40) (and hair-widths either side): the energy is continuous across the cut (the dropped term is < 4e-19)
+    and equals the oracle's Ewald sum."""
+    import pyqmc_amd as pa
+    from oracle import pbc as opbc
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    name, sup, cfg, want = helpers.madelung_cases()[3]  # CaF2 conventional cell: 8 electrons
+    ja, _ = pa.wf.generate_jastrow(sup)
+    ew = opbc.Ewald(sup)
+    acc = pa.EnergyAccumulator(sup)
+
+    def ee_energy(x):  # the electron-electron Ewald energy (the pair sums under test); (the Jastrow's own 1/r terms make ke NaN at r = 0)
+        c = PeriodicConfigs(x, sup.lattice_vectors())
+        ja.recompute(c)
+        with np.errstate(all="ignore"):
+            en = acc(c, ja)
+        return en["ee"][0], c
+
+    x = cfg.copy()
+    x[0, 1] = x[0, 0]  # (a) coincident
+    e, _ = ee_energy(x)
+    assert np.isinf(e) and e > 0
+    x[0, 1] = x[0, 0] + np.array([1e-9, 0.0, 0.0])
+    e, c = ee_energy(x)
+    ref = ew.energy(c)[0][0]
+    assert np.isfinite(e) and abs(e - ref) < 1e-6 * abs(ref)
+    rcut = np.sqrt(40.0) / ew.alpha  # (b)
+    vals = []
+    for d in (rcut * (1 - 1e-12), rcut, rcut * (1 + 1e-12)):
+        x = cfg.copy()
+        x[0, 1] = x[0, 0] + np.array([d, 0.0, 0.0])
+        e, c = ee_energy(x)
+        vals.append(e)
+        assert abs(e - ew.energy(c)[0][0]) < 1e-9 * max(1.0, abs(e))
+    assert max(vals) - min(vals) < 1e-9
+
+
 # ------------------------------------------------------------------ complex Bloch orbitals
 def test_complex_periodic_slater_matches_reference():
     """k-points off the time-reversal-invariant set (3x1x1 diamond supercell: k = 0, 1/3, 2/3 b1, complex coefficients): complex
