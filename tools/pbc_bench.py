@@ -28,6 +28,25 @@ a = ap.parse_args()
 S = {"k222": 2.0 * np.eye(3), "cubic": np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]), "gamma": np.eye(3)}[a.case]
 sup = pbc.get_supercell(pa.systems.diamond_primitive(), S)
 mf = pbc.random_kmf(sup)
+
+
+def pmc_traffic(case, walkers):
+    """Counter-measured HBM bytes of one move's orbital evaluation (image-list pre-pass + orbital kernel), per launch, scaled
+    from the walker count the counters were collected at: profiles/r03_pbc_<case>_pmc_summary.json (tools/refresh_evidence.sh:
+    separate FETCH_SIZE / WRITE_SIZE passes, calibrated by tools/pmc_calib).  None when no summary exists for the case."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r03_pbc_{case}_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    k = d.get("kernels", {})
+    parts = {name: k[name]["bytes_per_launch"] / d["walkers"] * walkers for name in ("k_pbc_prepass", "k_orb_wide", "k_orb5") if name in k}
+    if not parts:
+        return None
+    orb = parts.get("k_orb_wide", parts.get("k_orb5", 0.0))
+    return {"bytes_per_launch": parts.get("k_pbc_prepass", 0.0) + orb, "parts": parts, "measured_at_walkers": d["walkers"],
+            "fetch_calibration": d["calibration"]["applied_fetch_factor"], "source": "profiles/" + os.path.basename(path)}
+
+
 wf = pa.generate_wf(sup, mf, image_rule=a.rule)
 dev = wf.fused_device()
 cfg = pa.initial_guess(sup, a.walkers, rng=np.random.default_rng(1))
@@ -50,7 +69,7 @@ for rep in range(2):  # best of two timed passes: about one process in eight see
         flops = point_comps * 2.0 * nao * nmo
         roof = {"bound": "mfma", "kernel": "k_pbc_prepass + k_orb<5, PBC> / k_orb_wide<5, PBC> (move launches)", "achieved": flops / (orb_ms * 1e-3) / 1e12,
                 "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (orb_ms * 1e-3) / 1e12 / 78.6, "launches": launches,
-                "avg_launch_ms": orb_ms / launches, "flops_per_point_component": 2 * nao * nmo, "traffic": None}
+                "avg_launch_ms": orb_ms / launches, "flops_per_point_component": 2 * nao * nmo, "traffic": pmc_traffic(a.case, a.walkers)}
     dt = min(dt, t)
 dev.profile_enable(False)
 print(json.dumps({"case": a.case, "nelec": int(sum(sup.nelec)), "natom": sup.natm, "walkers": a.walkers, "ms_per_step": 1e3 * dt / a.steps,

@@ -6,22 +6,28 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 W=${BENCH_WALKERS:-65536}
 lscpu > $O/host_lscpu.txt
-python $R/bench.py --walkers $W > $O/bench.json 2> $O/bench.err < /dev/null
-rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --walkers $W --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 < /dev/null
-python $R/tools/prof_stats.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
+(cd $R && python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d /tmp/pm_$c -o t -- python $R/bench.py --walkers $W --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extra > /dev/null 2>&1 < /dev/null
+  rocprofv3 --pmc $c -d /tmp/pm_$c -o t -- python $R/bench.py --walkers $W --steps 2 --warmup 1 --settle 2 --no-cpu-baseline --no-profile --no-extra > /dev/null 2>&1 < /dev/null
   python $R/tools/pmc_counters.py /tmp/pm_$c/t_results.db $O/pmc_$c.csv
   rocprofv3 --pmc $c -d /tmp/pc_$c -o t -- $R/tools/pmc_calib > $O/pmc_calib_$c.txt 2>&1 < /dev/null
 done
 python $R/tools/pmc_summary.py /tmp/pm_FETCH_SIZE/t_results.db /tmp/pm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db $W $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
-for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
-rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
-python $R/tools/prof_stats.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
+cp $O/pmc_summary.json $R/profiles/r03_pmc_summary.json  # (this box's copy: bench.py reads its `traffic` fields from it)
+python $R/bench.py --walkers $W > $O/bench.json 2> $O/bench.err < /dev/null
+python $R/bench.py --mode dmc --steps 20 --warmup 2 > $O/bench_dmc.json 2>> $O/bench.err < /dev/null
+python $R/bench.py --mode c4 --steps 20 --warmup 2 > $O/bench_c4.json 2>> $O/bench.err < /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --walkers $W --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do  # counter passes of the periodic case (separate runs, no trace options); calibration as above
   rocprofv3 --pmc $c -d /tmp/pkm_$c -o t -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 1 --warmup 1 > /dev/null 2>&1 < /dev/null
   python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_k222_pmc_$c.csv
 done
+python $R/tools/pmc_summary.py /tmp/pkm_FETCH_SIZE/t_results.db /tmp/pkm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db 32768 $O/pbc_k222_pmc_summary.json > /dev/null 2>&1
+cp $O/pbc_k222_pmc_summary.json $R/profiles/r03_pbc_k222_pmc_summary.json
+for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
+rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
 python $R/tools/config_bench.py c2 --walkers 4096 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c2 --walkers 65536 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 4096 --steps 8 2>/dev/null | tail -1 >> $O/config_bench.jsonl
@@ -34,4 +40,6 @@ python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 2>/dev/null | tail
 python $R/tools/config_bench.py c5 --walkers 32768 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 > /dev/null 2>&1 < /dev/null
 python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/dmc_c5_kernel_stats.csv
+python $R/tools/cpu_config_baseline.py c2 c3 c4 c5 > $O/cpu_config_baseline.jsonl 2>> $O/bench.err
+cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
