@@ -253,7 +253,8 @@ int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const doubl
    walkers: the candidate T-moves over every ECP atom's quadrature points (P = pqa_tmove_npoints() per walker).
    rot (necp,3,3), unif (necp,W): the reference's per-atom random rotation / mask uniforms.  Outputs: ratio (W,P)
    Psi(candidate)/Psi (1 where the walker fails the ECP mask for that atom), weight (W,P) = sum_l (exp(-tau v_l)-1)
-   (2l+1)P_l w_i (0 there), pos (W,P,3) candidate positions (current position there). */
+   (2l+1)P_l w_i (0 there), pos (W,P,3) candidate positions (current position there).  ratio = NULL: positions and weights
+   only — complex handles take their (complex) ratios from pqa_wf_testvalue at those positions. */
 int pqa_tmove_npoints(pqa_handle_t* h);
 int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif, double* ratio,
                double* weight, double* pos);
@@ -285,15 +286,18 @@ int pqa_resample(pqa_handle_t* h, const int32_t* newinds);
 int pqa_get_walkers(pqa_handle_t* h, const int32_t* idx, int64_t n, double* out);
 int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int64_t nkeep, const double* recv_x, int64_t nrecv);
 
-/* dmc_propagate's step loop (pyqmc/method/dmc.py:123-221) fused on the device for real wave functions, open or
-   periodic: per step (1) one T-move per electron (compute_tmoves eval_ecp.py:43-80, propose_tmoves dmc.py:73-120,
+/* dmc_propagate's step loop (pyqmc/method/dmc.py:123-221) fused on the device, open or periodic systems, real and
+   (round 3) complex wave functions.  Complex: no node constraint in the drift-diffusion (dmc.py:64-66 is real-only),
+   weights from Re E_L, T-move amplitudes from Re[Psi(R')/Psi(R)] (the reference's propose_tmoves orders complex
+   amplitudes, which is undefined; golden g30 pins this rule), and step_avg has EIGHT numbers per step: the seven below,
+   then the weighted mean of Im ecp (= Im total).  Per step: per step (1) one T-move per electron (compute_tmoves eval_ecp.py:43-80, propose_tmoves dmc.py:73-120,
    masked updateinternals :160-168), (2) one drift-diffusion move per electron with Umrigar's limited drift
    (limdrift :22-35) and fixed-node rejection (propose_drift_diffusion :38-70), (3) the energy accumulator, the
    branching factor compute_S (:224-235), weights *= exp(tau r2_acc/r2_prop (S_new+S_old)/2) and the weighted step
    averages (:196-215).  No branching: the caller combs between calls, as rundmc does (:342-376).
    The walkers must be resident and current (pqa_wf_recompute); the starting energy is evaluated first (:146-149).
-   weights (W) in/out.  step_avg (nsteps,7): sum_w w_w row_w / sum_w w_w for rows ke, ee, ei, ecp, grad2, total,
-   then the mean weight.  step_acc (nsteps,2): acceptance and T-move acceptance (accepted / (W nelec)).
+   weights (W) in/out.  step_avg (nsteps,7) [complex: (nsteps,8)]: sum_w w_w row_w / sum_w w_w for rows ke, ee, ei, ecp,
+   grad2, total (real parts), then the mean weight.  step_acc (nsteps,2): acceptance and T-move acceptance (accepted / (W nelec)).
    tapes NULL -> device Philox streams keyed by (seed, walker, electron, step); otherwise every pointer the system
    needs must be set (the ECP ones only when the system has ECP atoms):
      gauss (nsteps,N,W,3) standard normals, unif (nsteps,N,W)                      drift-diffusion moves

@@ -25,7 +25,11 @@ def limdrift(g, tau, acyrus=0.5):
 
 def select_tmoves(ratio, weight, pos, current, select_u):
     """dmc.py:73-120 after the candidates are known.  select_u: (W,) uniforms (one per walker, in walker order).
-    -> newpos (W,3), move_selected (W,), acceptance (W,)"""
+    -> newpos (W,3), move_selected (W,), acceptance (W,).
+    Complex wave functions: the reference's lines order complex amplitudes with `>` / `<` and store 1 / ratio in a real
+    array, which has no defined meaning (and raises under NumPy 2); the rule followed — pinned by golden g30, generated from
+    the reference with the real part of the ratios handed to these very lines — is amplitudes from Re[Psi(R')/Psi(R)]."""
+    ratio = np.real(ratio)
     amp = ratio * weight
     fwd = np.where(amp > 0, amp, 0.0)
     norm = 1.0 + fwd.sum(axis=1)
@@ -96,7 +100,9 @@ def dmc_propagate(mol, wf, configs, weights, tstep, branchcut_start, e_trial, e_
             new_grad = limdrift(np.real(g.T), tstep)
             fwd = np.sum(gauss**2, axis=1)
             bwd = np.sum((gauss + grad + new_grad) ** 2, axis=1)
-            ratio = np.abs(wfratio) ** 2 * np.exp(1 / (2 * tstep) * (fwd - bwd)) * np.sign(wfratio)
+            ratio = np.abs(wfratio) ** 2 * np.exp(1 / (2 * tstep) * (fwd - bwd))
+            if not np.iscomplexobj(wfratio):
+                ratio = ratio * np.sign(wfratio)  # fixed node only for real wave functions (dmc.py:64-66)
             accept = ratio > tape.rand(W)
             r2 = np.sum((gauss + grad) ** 2, axis=1)
             configs.move(e, ep, accept)
@@ -135,7 +141,7 @@ def compute_tmoves(mol, configs, wf, e, threshold, tau, tape):
         d = oenergy.ecp_ea(mol, configs, wf, e, ia, threshold, rot, unif)
         npts = d["P_l"].shape[1]
         w = np.zeros((W, npts))
-        r = np.ones((W, npts))
+        r = np.ones((W, npts), dtype=np.asarray(d["ratio"]).dtype)
         w[d["mask"]] = np.einsum("ik,ijk->ij", np.exp(-tau * d["v_l"]) - 1, d["P_l"])
         r[d["mask"]] = d["ratio"]
         ratios.append(r)

@@ -2352,10 +2352,10 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
                              double* weights, const pqa_dmc_tapes_t* tp, uint64_t seed, double* step_avg, double* step_acc) {
   TRY(sync_aos(h));  // (the starting energy and the first T-moves read the walker-major state)
   HIPCHK(hipSetDevice(h->device));
-  if (h->cplx) FAIL("pqa_dmc_steps: complex orbitals are not implemented (fixed-phase DMC runs through the protocol entry points)");
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   if (nsteps <= 0) return 0;
   if (!weights || !step_avg || !step_acc) FAIL("pqa_dmc_steps: weights / step_avg / step_acc must not be NULL");
+  const int navg = h->cplx ? 8 : 7;  // numbers per step in step_avg (complex: + the weighted mean of Im ecp = Im total)
   const long W = h->W;
   const int N = h->N, necp = h->necp, P = h->tm_P;
   const bool tmoves = necp > 0 && P > 0;
@@ -2373,7 +2373,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   TRY(ensure(h, h->b_dmcw, (size_t)W * sizeof(double)));
   TRY(ensure(h, h->b_dmcold, (size_t)2 * W * sizeof(double)));
   TRY(ensure(h, h->b_dmcr2, (size_t)2 * W * sizeof(double)));
-  TRY(ensure(h, h->b_dmcout, (size_t)nsteps * 7 * sizeof(double)));
+  TRY(ensure(h, h->b_dmcout, (size_t)nsteps * navg * sizeof(double)));
   HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * 2 * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
   HIPCHK(hipMemsetAsync(h->b_dmcr2.p, 0, (size_t)2 * W * sizeof(double), h->stream));
@@ -2403,7 +2403,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     if (tp) TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * NW * sizeof(double)));
     TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
   }
-  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3;
+  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && (!h->cplx || std::max(h->nup, h->ndn) <= 32);
   LwCtx lc;
   TRY(lw_setup(h, lw, lc));
   const dim3 gw256((unsigned)((W + 255) / 256));
@@ -2418,11 +2418,11 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
     mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
     mb.dmc = 1; mb.r2_acc = r2; mb.r2_prop = r2 + W;
-    if (h->S.pbc) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }
+    if (h->S.pbc && !h->twist) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }  // twisted handles keep the walkers unfolded
     if (tmoves) {
       const size_t NW = (size_t)N * W;
       TmBuf B{};
-      B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold;
+      B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold; B.nofold = h->twist ? 1 : 0;
       B.cnt = (int*)h->b_tmcnt.p; B.off = (long*)h->b_tmoff.p; B.pass = (unsigned long long*)h->b_tmpass.p;
       long* d_marks = (long*)h->b_tmmarks.p;
       B.acc = (int*)h->b_tmacc.p; B.acc_off = (long*)h->b_tmaoff.p;
@@ -2477,8 +2477,10 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
                                (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, (const double*)h->b_tmuold.p);
           }
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
-        hipLaunchKernelGGL(k_tm_walker, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                           (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, pre ? 1 : 0);
+        if (h->cplx) hipLaunchKernelGGL(k_tm_walker<true>, dim3((unsigned)W), dim3(64), 2 * lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                                        (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, 0);
+        else hipLaunchKernelGGL(k_tm_walker<false>, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
+                                (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, pre ? 1 : 0);
         TRY(check_launch(h, "k_tm_walker"));
         TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
         hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
@@ -2513,13 +2515,13 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     hipLaunchKernelGGL(k_dmc_weights, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
                        (double*)h->b_dmcw.p, tstep, branchcut, e_trial, e_est, N, W);
     hipLaunchKernelGGL(k_dmc_averages, dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
-                       (double*)h->b_dmcout.p + (size_t)step * 7);
+                       (double*)h->b_dmcout.p + (size_t)step * navg, h->cplx ? 7 : 6);
     TRY(check_launch(h, "k_dmc_weights/k_dmc_averages"));
   }
   if (lw) TRY(lw_to_aos(h, true));
   h->jas_stale = h->has_j2;
   std::vector<int> cnt((size_t)nsteps * 2);
-  TRY(copy_in(h, step_avg, h->b_dmcout.p, (size_t)nsteps * 7 * sizeof(double)));
+  TRY(copy_in(h, step_avg, h->b_dmcout.p, (size_t)nsteps * navg * sizeof(double)));
   TRY(copy_in(h, weights, h->b_dmcw.p, (size_t)W * sizeof(double)));
   TRY(copy_out(h, cnt.data(), h->b_acccnt.p, cnt.size() * sizeof(int)));
   for (int i = 0; i < nsteps; ++i) {
@@ -2535,7 +2537,7 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
                           double* ratio, double* weight, double* pos) {
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
-  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
+  if (h->cplx && ratio) FAIL("pqa_tmoves: complex orbitals — pass ratio = NULL (positions and weights only) and take the ratios from pqa_wf_testvalue");
   if (h->W == 0) FAIL("state not initialised (call recompute)");
   if (e < 0 || e >= h->N) FAIL("electron index out of range");
   const long W = h->W;
@@ -2556,6 +2558,10 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
                      (const double*)h->b_rot.p, (const double*)h->b_eunif.p, (const double*)h->d_quad, (const int*)h->d_ptk,
                      (const int*)h->d_pti, P, W, (double*)h->b_tpos.p, (double*)h->b_twgt.p, (uint8_t*)h->b_tlive.p);
   TRY(check_launch(h, "k_tmove_points"));
+  if (!ratio) {  // candidate positions and weights only (dead candidates carry weight 0)
+    TRY(copy_in(h, weight, h->b_twgt.p, np * sizeof(double)));
+    return copy_out(h, pos, h->b_tpos.p, np * 3 * sizeof(double));
+  }
   if (h->has_slater) {
     TRY(ensure(h, h->b_motmp, np * std::max(h->nmo[s], 1) * sizeof(double)));
     TRY(launch_orb(h, s, plain_points((const double*)h->b_tpos.p, (long)np), (long)np, 1, (double*)h->b_motmp.p));

@@ -1,4 +1,4 @@
-// pqa_dmc.hpp — the DMC step on the device (real wave functions; open and periodic systems).
+// pqa_dmc.hpp — the DMC step on the device (real and, since round 3, complex wave functions; open and periodic systems).
 //
 // One DMC step of the reference's dmc_propagate (pyqmc/method/dmc.py:123-221) is
 //   (1) per electron, one T-move: compute_tmoves (eval_ecp.py:43-80) -> propose_tmoves (dmc.py:73-120) -> accept -> update
@@ -40,6 +40,7 @@ struct TmBuf {
   long* acc_off;        // [N*W+1] exclusive scan of acc
   int* acc_idx;         // [N*W] their indices e*W + w, ascending (spin-up first)
   double* acc_pos;      // [N*W][3] their new positions
+  int nofold;           // twisted handles keep TRUE (unfolded) coordinates: an accepted T-move is not folded into the cell
 };
 
 // pass A: which ECP atoms pass the mask for electron e of each walker, and how many candidates that makes.
@@ -331,6 +332,11 @@ __global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, Jast
 //   candidate's orbital VALUE row (already evaluated) and the coordinate.  The gradient / Laplacian rows of the cache are
 //   refreshed for all of the step's accepted T-moves at once afterwards (k_tm_cache): nothing reads them in between.
 // mo_up / mo_dn: [ncand of the spin][nmo_s] orbital values; tot_up: first spin-down candidate.  grid = W, block = 64.
+// CX: complex determinants (pqa_cslater.hpp).  The reference's selection lines order complex amplitudes with `>` / `<` and keep
+// 1 / ratio in a real array (dmc.py:83-101), which has no defined meaning; the rule followed — pinned by golden g30, generated
+// from the reference with the real part of the ratios handed to those very lines — is amplitudes from Re[Psi(R')/Psi(R)]:
+// `rat` below is that real part, the commit is the full complex Sherman-Morrison update.
+template <bool CX>
 __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, JastrowState js, TmBuf B, int has_slater, int has_jastrow,
                                                   const double* __restrict__ mo_up, const double* __restrict__ mo_dn, long tot_up, long W, int precomputed) {
   extern __shared__ double lds[];
@@ -369,9 +375,15 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
     for (long p = p0; p < p1; ++p) {
       double rat = 1.0;
       if (has_slater) {
-        double r1[1];
-        slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
-        rat = r1[0];
+        if (CX) {
+          cx r1[1];
+          slater_ratios_c<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
+          rat = r1[0].r;  // (the Jastrow ratio below is real and positive: Re[ratio] = Re[determinant ratio] * exp(dU))
+        } else {
+          double r1[1];
+          slater_ratios<1>(S, st, s, e - s * S.nup, w, mo + (size_t)(p - p_base) * nmo, r1, lds);
+          rat = r1[0];
+        }
       }
       if (has_jastrow) {
         double U;
@@ -445,13 +457,16 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
     if (!acc) continue;
     fresh = false;
     __syncthreads();
-    if (has_slater) sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
+    if (has_slater) {
+      if (CX) sm_update_wave_c(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
+      else sm_update_wave(S, st, s, e - s * S.nup, w, mo + (size_t)(p0 + sel - p_base) * nmo, lds);
+    }
     if (lane == 0) {
       // compute_tmoves folds the candidates (eval_ecp.py:66 make_irreducible) and propose_tmoves then takes only their
       // folded coordinates (dmc.py:100), so the reference's wrap counters do not see a T-move across the cell boundary;
       // identical results means the same here: fold, and leave the counters alone.
       double nx = B.pts[3 * (p0 + sel)], ny = B.pts[3 * (p0 + sel) + 1], nz = B.pts[3 * (p0 + sel) + 2];
-      fold_cell(S, nx, ny, nz);
+      if (!B.nofold) fold_cell(S, nx, ny, nz);
       xw[3 * e] = nx; xw[3 * e + 1] = ny; xw[3 * e + 2] = nz;
     }
     __syncthreads();  // the next electron's ratios see the new coordinate and inverse
@@ -515,26 +530,29 @@ __global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en,
 }
 
 // out[0..5] = sum_w weights[w] en[k][w] / sum_w weights[w] (the reference's dot(weights, v)/(W wavg), dmc.py:205-209),
-// out[6] = mean weight.  One block of 1024 threads, deterministic.
+// out[6] = mean weight; complex wave functions (nrow = 7: the energy buffer's row 6 is Im ecp = Im total) also out[7] = the
+// weighted mean of that row.  One block of 1024 threads, deterministic.
 __global__ __launch_bounds__(1024) void k_dmc_averages(const double* __restrict__ en, const double* __restrict__ weights, long W,
-                                                       double* __restrict__ out) {
-  __shared__ double part[7][1024];
-  double s[7] = {0, 0, 0, 0, 0, 0, 0};
+                                                       double* __restrict__ out, int nrow) {
+  __shared__ double part[8][1024];
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long i = threadIdx.x; i < W; i += 1024) {
     const double wt = weights[i];
 #pragma unroll
     for (int k = 0; k < 6; ++k) s[k] += wt * en[(size_t)k * W + i];
     s[6] += wt;
+    if (nrow > 6) s[7] += wt * en[(size_t)6 * W + i];
   }
 #pragma unroll
-  for (int k = 0; k < 7; ++k) part[k][threadIdx.x] = s[k];
+  for (int k = 0; k < 8; ++k) part[k][threadIdx.x] = s[k];
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off)
 #pragma unroll
-      for (int k = 0; k < 7; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + off];
+      for (int k = 0; k < 8; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + off];
     __syncthreads();
   }
   if (threadIdx.x < 6) out[threadIdx.x] = part[threadIdx.x][0] / part[6][0];
   if (threadIdx.x == 6) out[6] = part[6][0] / (double)W;
+  if (threadIdx.x == 7 && nrow > 6) out[7] = part[7][0] / part[6][0];
 }

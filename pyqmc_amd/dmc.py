@@ -63,12 +63,16 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     avg, stat = dev.dmc_steps(tstep, nsteps, w, branchcut, e_trial, e_est, threshold=acc.threshold, tapes=tapes,
                               seed=int(np.random.randint(0, 2**31 - 1)))
     weights[:] = w
-    configs.configs[...] = dev.configs()
-    if dev.pbc:
-        configs.wrap += dev.wrap_delta()
+    from .vmc import _fetch
+
+    _fetch(dev, configs)  # (periodic: folded positions + wrap counters; twisted handles keep true coordinates on the device)
     wts = avg[:, 6]
     rel = wts / wts.mean()
     out = {name + k: np.mean(avg[:, i] * rel) for i, k in enumerate(KEYS[:6])}
+    if avg.shape[1] > 7:  # complex wave function: ecp and total carry an imaginary part (eval_ecp.py:89), the other keys are real
+        im = np.mean(avg[:, 7] * rel)
+        for k in ("ecp", "total"):
+            out[name + k] = complex(out[name + k], im)
     out["acceptance"] = np.mean(stat[:, 0] * rel)
     out["tmove_acceptance"] = np.mean(stat[:, 1] * rel)
     out["weight"] = wts.mean()
@@ -76,11 +80,11 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
 
 
 def fused_dmc_supported(wf, accumulators, ekey):
-    """The device step loop covers real wave functions on one handle with the energy accumulator as the only one."""
+    """The device step loop covers wave functions on one handle (real or complex) with the energy accumulator as the only one."""
     from .energy import EnergyAccumulator
 
     dev = wf.fused_device() if hasattr(wf, "fused_device") else getattr(wf, "_dev", None)
-    if dev is None or getattr(dev, "cplx", False) or set(accumulators) != {ekey[0]} or ekey[1] != "total":
+    if dev is None or set(accumulators) != {ekey[0]} or ekey[1] != "total":
         return None
     return dev if isinstance(accumulators[ekey[0]], EnergyAccumulator) else None
 
@@ -90,16 +94,17 @@ def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, 
     """Propagate ``nsteps`` DMC steps without branching; returns (block averages, configs, weights) with the
     reference's keys (``<acc><quantity>``, ``weight``, ``acceptance``, ``tmove_acceptance``).
 
-    The whole step loop of dmc.py:123-221 runs on the device (``pqa_dmc_steps``): real wave functions on one handle, the
+    The whole step loop of dmc.py:123-221 runs on the device (``pqa_dmc_steps``): wave functions on one handle — real, or
+    complex (no node constraint, weights from Re E_L, T-move amplitudes from Re[Psi(R')/Psi(R)]: golden g30) — with the
     energy accumulator as the only accumulator.  ``rng`` replays the reference's draws (tests); ``state_current=True``
     promises that the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on
-    the device (``DeviceWF.resample``) — and skips the initial recompute.  Anything else (complex orbitals, further
-    accumulators inside the DMC loop) is not built here: the reference's own ``pyqmc.method.dmc.dmc_propagate`` runs over
+    the device (``DeviceWF.resample``) — and skips the initial recompute.  Further accumulators inside the DMC loop are
+    not built here: the reference's own ``pyqmc.method.dmc.dmc_propagate`` runs over
     these wave-function objects unmodified (``tests/helpers.protocol_dmc_propagate`` is that route)."""
     assert accumulators is not None, "Need an energy accumulator for DMC"
     dev = fused_dmc_supported(wf, accumulators, ekey)
     if dev is None:
-        raise NotImplementedError("pyqmc_amd.dmc_propagate runs real wave functions on one device handle with the EnergyAccumulator as the "
+        raise NotImplementedError("pyqmc_amd.dmc_propagate runs wave functions on one device handle with the EnergyAccumulator as the "
                                   "only accumulator; drive pyqmc.method.dmc.dmc_propagate over the protocol objects for anything else")
     return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators[ekey[0]], ekey[0], rng,
                             state_current=state_current)

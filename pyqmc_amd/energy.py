@@ -83,6 +83,16 @@ class EnergyAccumulator:
                             np.stack([2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)], -1)], -2)
         rot, unif = _ffi.f64(rot), _ffi.f64(unif)
         ratio, weight, pos = np.empty((W, P)), np.empty((W, P)), np.empty((W, P, 3))
+        if getattr(dev, "cplx", False):
+            # complex determinants: candidate positions and weights from the device, the (complex) ratios through the protocol's
+            # testvalue at those positions; candidates of atoms that failed the ECP mask keep ratio 1 like the reference's table
+            dev.call("pqa_tmoves", int(e), float(tau), float(self.threshold), _ffi.ptr(rot), _ffi.ptr(unif), None, _ffi.ptr(weight), _ffi.ptr(pos))
+            epos = configs.make_irreducible(e, pos)
+            live = weight != 0.0
+            ratio = np.ones((W, P), dtype=complex)
+            if live.any():
+                ratio[live] = np.asarray(wf.testvalue(e, epos)[0])[live]
+            return {"ratio": ratio, "weight": weight, "configs": epos}
         dev.call("pqa_tmoves", int(e), float(tau), float(self.threshold), _ffi.ptr(rot), _ffi.ptr(unif), _ffi.ptr(ratio),
                  _ffi.ptr(weight), _ffi.ptr(pos))
         return {"ratio": ratio, "weight": weight, "configs": configs.make_irreducible(e, pos)}

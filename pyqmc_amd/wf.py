@@ -317,9 +317,9 @@ class DeviceWF:
     def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0):
         """``pqa_dmc_steps``: ``nsteps`` DMC steps on the resident walkers.  ``weights`` (W) is updated in place.
         ``tapes``: dict of the replay arrays of ``pqa_dmc_tapes_t`` or None (device Philox streams).
-        Returns (step_avg (nsteps,7), step_acc (nsteps,2))."""
+        Returns (step_avg (nsteps,7) — (nsteps,8) for complex wave functions —, step_acc (nsteps,2))."""
         assert weights.dtype == np.float64 and weights.flags.c_contiguous and weights.shape == (self.W,)
-        avg, acc = np.empty((nsteps, 7)), np.empty((nsteps, 2))
+        avg, acc = np.empty((nsteps, 8 if self.cplx else 7)), np.empty((nsteps, 2))  # complex: + the weighted mean of Im ecp
         tp, keep = None, []
         if tapes is not None:
             tp = _ffi.DmcTapes()

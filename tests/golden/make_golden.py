@@ -1415,6 +1415,86 @@ def g_chk_mol():
     save("g28_chk_mol", **out)
 
 
+def g_pbc_complex_dmc():
+    """dmc_propagate on a COMPLEX periodic wave function (3x1x1 diamond supercell, k = 0, 1/3, 2/3 b1, complex coefficients) with
+    ECP T-moves.  The reference's propose_tmoves compares complex amplitudes with `> 0` / `< 0` and stores 1 / ratio into a real
+    array (dmc.py:83-101): under NumPy >= 2 the comparisons raise, under NumPy 1 they ordered by the real part first and the
+    assignment dropped the imaginary part.  The rule pinned here is the one that keeps every line of propose_tmoves as it is and
+    is what fixed-phase practice uses: T-move amplitudes are formed from Re[Psi(R')/Psi(R)] — realised by a shim around
+    EnergyAccumulator.nonlocal_tmoves that hands the reference the real part of the ratios.  Everything else (complex
+    drift-diffusion without a node constraint, complex ECP energies, weights from Re E_L) is the reference untouched."""
+    import pyqmc.method.dmc as refdmc
+    import pyqmc.wf.orbitals as reforb
+    from pyqmc.configurations.coord import PeriodicConfigs
+    from pyqmc.observables.accumulators import EnergyAccumulator as RefAcc
+
+    orig_aos = reforb.PBCOrbitalEvaluatorKpoints.aos
+
+    def aos(self, eval_str, configs, mask=None):  # the un-JIT-ed AO path cannot take an empty point list (see g_pbc_dmc)
+        coords = configs.configs if mask is None else configs.configs[mask]
+        if coords.size == 0:
+            nao, nk = self.parameters["mo_coeff_alpha"].shape[0], len(self._kpts)
+            comp = () if "deriv" not in eval_str else ((4,) if "deriv1" in eval_str else (5,))
+            return np.zeros((nk, *comp, *coords.shape[:-1], nao))
+        return orig_aos(self, eval_str, configs, mask)
+
+    reforb.PBCOrbitalEvaluatorKpoints.aos = aos
+    orig_tm = RefAcc.nonlocal_tmoves
+
+    def real_part_tmoves(self, configs, wf, e, tau):
+        m = orig_tm(self, configs, wf, e, tau)
+        m["ratio"] = np.real(m["ratio"])
+        return m
+
+    RefAcc.nonlocal_tmoves = real_part_tmoves
+    out = {}
+    sup, mf, Ls, oe, sl, j2, wf = ref_pbc_wf_complex()
+    assert sl.dtype == complex
+    W, nsteps, tstep = 4, 2, 0.1
+    rng = np.random.default_rng(6)
+    N = sum(sup.nelec)
+    base = systems.initial_guess(sup, W, rng=np.random.default_rng(66)).configs.copy()
+    # pull a few electrons close to carbon cores so the ECP mask passes and T-moves have weight
+    for k, e in enumerate((0, 3, 7, 12, 15, 20)):
+        base[:, e] = sup.atom_coords()[k % sup.natm][None] + 0.25 * rng.standard_normal((W, 3))
+    configs = PeriodicConfigs(base, sup.lattice_vectors())
+    out["start"], out["start_wrap"] = configs.configs.copy(), configs.wrap.copy()
+    weights = 1.0 + 0.1 * rng.standard_normal(W)
+    out["weights0"] = weights.copy()
+    e_trial, e_est, branchcut = -30.0, -30.5, 5.0
+    out["params"] = np.array([tstep, branchcut, e_trial, e_est, nsteps])
+    accepts = []
+    orig = wf.updateinternals
+
+    def spy(e, epos, cfg, mask=None, saved_values=None):
+        accepts.append(np.asarray(mask).copy())
+        return orig(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(951) as t:
+        df, configs, weights = refdmc.dmc_propagate(wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps=nsteps,
+                                                    accumulators={"energy": pyq.EnergyAccumulator(sup, ewald_gmax=10)})
+    wf.updateinternals = orig
+    reforb.PBCOrbitalEvaluatorKpoints.aos = orig_aos
+    RefAcc.nonlocal_tmoves = orig_tm
+    out["normal"] = np.asarray(t.log["normal"])
+    rand = t.log["rand"]
+    out["rand_scalar"] = np.asarray([float(r) for r in rand if np.ndim(r) == 0])
+    out["rand_vector"] = np.asarray([r for r in rand if np.ndim(r) == 1])
+    out["rot"] = np.asarray(t.log["rot"])
+    out["random"] = np.asarray(t.log["random"])
+    out["accepts"] = np.asarray(accepts)
+    out["final"], out["final_wrap"] = configs.configs.copy(), configs.wrap.copy()
+    out["weights"] = weights
+    for k, v in df.items():
+        out["df_" + k] = np.asarray(v)
+    out["df_keys"] = np.asarray(sorted(df.keys()))
+    nt = len(accepts) // 2  # first half of every step: the T-move updates
+    print("complex pbc dmc: tmove acc", df.get("tmove_acceptance"), "acc", df.get("acceptance"), "E", df.get("energytotal"),
+          "T-moves accepted", int(np.sum([a.sum() for a in accepts[:N]])), "+", int(np.sum([a.sum() for a in accepts[2 * N : 3 * N]])))
+    save("g30_pbc_complex_dmc", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python make_golden.py g_sr g_obdm
         for name in sys.argv[1:]:
@@ -1443,3 +1523,4 @@ if __name__ == "__main__":
     g_complex_testvalue_many()
     g_hdf_layout()
     g_chk_mol()
+    g_pbc_complex_dmc()

@@ -489,7 +489,7 @@ def propose_tmoves(wf, configs, acc, tstep, e, rng, necp):
             unif[k] = rng.random(W)
             rot[k] = rng.rot()
         moves = acc.nonlocal_tmoves(configs, wf, e, tstep, rot=rot, unif=unif)
-    ratio, weight = moves["ratio"], moves["weight"]
+    ratio, weight = np.real(moves["ratio"]), moves["weight"]  # complex wave functions: amplitudes from Re[Psi(R')/Psi(R)] (golden g30; oracle/dmc.py)
     amp = ratio * weight
     fwd = np.maximum(amp, 0.0)
     norm = 1.0 + fwd.sum(axis=1)  # Eq. 34 of Anderson & Umrigar

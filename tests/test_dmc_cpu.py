@@ -21,8 +21,8 @@ from pyqmc_amd.configs import OpenConfigs
 class OracleAccumulator:
     """EnergyAccumulator interface over the oracle (test double for the device accumulator)."""
 
-    def __init__(self, mol, threshold=10.0):
-        self.mol, self.threshold = mol, threshold
+    def __init__(self, mol, threshold=10.0, ewald_kws=None):
+        self.mol, self.threshold, self.ewald_kws = mol, threshold, ewald_kws
 
     class _Dev:
         def __init__(self, necp):
@@ -41,7 +41,7 @@ class OracleAccumulator:
             necp, rng = self._device(wf).necp, helpers.NumpyRNG()
             unif = np.array([[rng.random(W) for _ in range(necp)] for _ in range(N)])
             rot = np.array([[rng.rot() for _ in range(necp)] for _ in range(N)])
-        return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif)
+        return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif, ewald_kws=self.ewald_kws)
 
     def has_nonlocal_moves(self):
         return bool(self.mol._ecp)
@@ -249,6 +249,33 @@ def test_driver_reproduces_reference_periodic_dmc_propagate():
     assert set(df.keys()) == set(g["df_keys"].tolist())
     for k in df:
         assert relerr(df[k], g["df_" + k]) < 1e-9, k
+
+
+def test_protocol_route_reproduces_reference_complex_dmc_propagate():
+    """Complex wave function (3x1x1 diamond supercell, complex Bloch coefficients) through dmc_propagate with ECP T-moves: the
+    protocol-route harness over the oracle reproduces the reference run of golden g30 — accept decisions of both phases, walkers,
+    wrap counters, weights, complex block averages.  The T-move amplitudes use Re[Psi(R')/Psi(R)] (oracle/dmc.py:select_tmoves,
+    make_golden.py:g_pbc_complex_dmc say why); no node constraint in the drift-diffusion (dmc.py:64-66 is real-only)."""
+    from pyqmc_amd.configs import PeriodicConfigs
+    from test_pbc_cpu import _oracle_complex_wf
+
+    g = golden("g30_pbc_complex_dmc")
+    sup, wf = _oracle_complex_wf(golden("g19_pbc_complex"))
+    assert wf.dtype == complex
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = helpers.protocol_dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                                      nsteps=int(nsteps), accumulators={"energy": OracleAccumulator(sup, ewald_kws={"ewald_gmax": 10})},
+                                                      rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"]) and g["accepts"][: 2 * int(sum(sup.nelec))].sum() > 0
+    assert relerr(cfg.configs, g["final"]) < 1e-10 and np.array_equal(cfg.wrap, g["final_wrap"]) and relerr(weights, g["weights"]) < 1e-9
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert relerr(df[k], g["df_" + k]) < 1e-9, k
+    assert abs(np.imag(df["energytotal"])) > 1e-3  # a genuinely complex local energy went through the averages
 
 
 def _small_dmc(path, nblocks, W=6, seed=3, distributed=False, **kw):

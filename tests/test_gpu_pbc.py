@@ -215,6 +215,102 @@ def test_periodic_fused_dmc_steps_match_reference():
         assert helpers.relerr(df[k], g["df_" + k]) < 1e-8, k
 
 
+def note(key, val):  # recorded with the other measured errors (gpurun_out/parity_report.json, written by test_gpu_parity's fixture)
+    from test_gpu_parity import REPORT
+
+    REPORT["pbc_" + key] = float(val)
+    return float(val)
+
+
+def _complex_dmc_wf():
+    import pyqmc_amd as pa
+    from helpers import pbc_complex_case
+
+    sup, mf = pbc_complex_case()
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    assert wf.dtype == complex
+    return sup, wf
+
+
+def test_complex_dmc_propagate_protocol_route_matches_reference():
+    """Complex wave function (3x1x1 diamond supercell, complex Bloch coefficients), dmc_propagate with ECP T-moves through the
+    PROTOCOL entry points of the device wave function (tests/helpers.protocol_dmc_propagate: the reference's control flow;
+    EnergyAccumulator.nonlocal_tmoves takes candidate positions / weights from pqa_tmoves and the complex ratios from
+    testvalue): the reference's run of golden g30 — decisions of the T-move and drift-diffusion phases, walkers, wrap counters,
+    weights, complex block averages.  T-move amplitudes from Re[Psi(R')/Psi(R)] (make_golden.py:g_pbc_complex_dmc)."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g30_pbc_complex_dmc")
+    sup, wf = _complex_dmc_wf()
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    accepts = []
+    orig = wf.updateinternals
+    wf.updateinternals = lambda e, ep, c, mask=None, saved_values=None: (accepts.append(np.asarray(mask).copy()), orig(e, ep, c, mask=mask, saved_values=saved_values))[1]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = helpers.protocol_dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                                      nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                                                      rng=helpers.ReplayTape(g))
+    assert np.array_equal(np.asarray(accepts), g["accepts"])
+    assert note("cdmc_final", helpers.relerr(cfg.configs, g["final"])) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
+    assert note("cdmc_weights", helpers.relerr(weights, g["weights"])) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert helpers.relerr(df[k], g["df_" + k]) < 1e-8, k
+
+
+def test_complex_fused_dmc_steps_match_reference():
+    """pqa_dmc_steps with complex determinants (round 3): the whole step loop on the device — complex T-move ratios and
+    Sherman-Morrison commits in k_tm_walker<CX>, complex lane-per-walker drift-diffusion without a node constraint, complex ECP
+    energies, weights from Re E_L — replaying the reference's draws of golden g30: walkers, wrap counters, weights and the
+    (complex) block averages."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g30_pbc_complex_dmc")
+    sup, wf = _complex_dmc_wf()
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+    cfg = PeriodicConfigs(g["start"].copy(), sup.lattice_vectors(), wrap=g["start_wrap"].copy())
+    df, cfg, weights = pa.dmc_propagate(wf, cfg, g["weights0"].copy(), float(tstep), float(branchcut), float(e_trial), float(e_est),
+                                        nsteps=int(nsteps), accumulators={"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                                        rng=helpers.ReplayTape(g))
+    assert note("cfdmc_final", helpers.relerr(cfg.configs, g["final"])) < 1e-9 and np.array_equal(cfg.wrap, g["final_wrap"])
+    assert note("cfdmc_weights", helpers.relerr(weights, g["weights"])) < 1e-8
+    assert set(df.keys()) == set(g["df_keys"].tolist())
+    for k in df:
+        assert note("cfdmc_" + k, helpers.relerr(df[k], g["df_" + k])) < 1e-8, k
+    assert abs(np.imag(df["energytotal"])) > 1e-3
+
+
+def test_complex_fused_dmc_on_twisted_cell_is_consistent():
+    """Twisted cell (the handle keeps true, unfolded coordinates): the fused complex DMC step is reproducible from its seed,
+    leaves the walkers inside the cell with consistent wrap counters, and its updated state equals a fresh recompute."""
+    import pyqmc_amd as pa
+    from helpers import twist_case
+
+    sup, mf = twist_case("s211")
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    acc = {"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)}
+    W = 64
+    start = pa.initial_guess(sup, W, rng=np.random.default_rng(5))
+    outs = []
+    for rep in range(2):
+        np.random.seed(77)
+        cfg = start.copy()
+        df, cfg, w = pa.dmc_propagate(wf, cfg, np.ones(W), 0.02, 50.0, -20.0, -20.0, nsteps=3, accumulators=acc)
+        outs.append((cfg.configs.copy(), cfg.wrap.copy(), w.copy(), df["energytotal"], wf.value()[1].copy()))
+    assert all(np.array_equal(p, q) for p, q in zip(outs[0], outs[1]))
+    x, wrap, w, e, logv = outs[0]
+    frac = x @ np.linalg.inv(sup.lattice_vectors())
+    assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12 and np.all(np.isfinite(w)) and np.iscomplexobj(e)
+    fresh = wf.recompute(cfg)[1]
+    assert note("cfdmc_twist_update_vs_recompute", np.max(np.abs(fresh - logv))) < 1e-9
+
+
 def test_periodic_rundmc_smoke():
     import pyqmc_amd as pa
 
