@@ -407,8 +407,16 @@ struct StepArgs {
 // Block = NW walkers x G groups, <= 256 threads.  WIDE: NW = 64, a wave is one group (g wave-uniform: table look-ups stay scalar
 // loads).  Otherwise NW = 16 or 32 and a wave holds 4 or 2 groups of the same walkers: small shards then spread over 4x / 2x
 // as many blocks — with 64 walkers per block 4096 walkers are 64 blocks on 64 of the 256 CUs, each issuing all 16 groups' work.
+#ifndef PQA_STEP_MINW
+#define PQA_STEP_MINW 0  // > 0: minimum waves per SIMD the register allocation of k_step_lw must allow (A/B: tools/scratch/r3_ab_simple.sh)
+#endif
+#if PQA_STEP_MINW > 0
+#define PQA_STEP_BOUNDS __launch_bounds__(256, PQA_STEP_MINW)
+#else
+#define PQA_STEP_BOUNDS __launch_bounds__(256)
+#endif
 template <bool PBC, bool CX, int NMAX, bool WIDE>
-__global__ __launch_bounds__(256) void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+__global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
   extern __shared__ double sh[];
   constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4, CF = CX ? 2 : 1;
   const int NW = WIDE ? 64 : a.NW;
