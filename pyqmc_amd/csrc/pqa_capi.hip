@@ -16,6 +16,7 @@
 #include "pqa_cslater.hpp"
 #include "pqa_dmc.hpp"
 #include "pqa_energy.hpp"
+#include "pqa_ecp.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
@@ -81,6 +82,10 @@ struct pqa_handle {
   int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
   int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
   int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
+  int ecp_point_lw = 1;  // PQA_ECP_POINT_LW=0: k_ecp_point on the planes instead of k_ecp_point_lw (A/B)
+  long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
+  int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
+  int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
   DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
   DevBuf b_tpos, b_twgt, b_tlive, b_trat;
@@ -507,6 +512,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* nw = getenv("PQA_LW_NW")) { const int v = atoi(nw); h->lw_nw = (v == 16 || v == 32 || v == 64) ? v : 0; }
   if (const char* ew = getenv("PQA_ECP_WAVE")) h->ecp_wave = atoi(ew);
   if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
+  if (const char* ep = getenv("PQA_ECP_POINT_LW")) h->ecp_point_lw = atoi(ep);
+  if (const char* el = getenv("PQA_ECP_LDS")) h->ecp_lds = atoi(el);
+  if (const char* fw = getenv("PQA_FLUSH_WB8_MAX")) h->flush_wb8_max = atol(fw);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -751,6 +759,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (h->necp > 0) {
     const int nchan = sys->ecp_chan_off[h->necp];
     const int nterm = sys->ecp_term_off[nchan];
+    h->ecp_nchan = nchan; h->ecp_nterm = nterm;
     for (int k = 0; k < h->necp; ++k)
       if (sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k] > PQA_MAXCHAN) FAIL("ECP with more than 4 non-local channels");
     TRY(upload_table(h, sys->ecp_atom, (size_t)h->necp, &tmp_i)); S.ecp_atom = tmp_i;
@@ -1709,7 +1718,7 @@ static int lw_from_aos(pqa_handle* h, bool with_cache = true) {
   const int nel[2] = {h->nup, h->ndn};
   TRY(ensure(h, h->b_xt, (size_t)W * h->N * 3 * sizeof(double)));
   TRY(ensure(h, h->b_auxt, (size_t)W * 8 * sizeof(double)));
-  TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 4 * sizeof(double)));
+  TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 5 * sizeof(double)));
   transpose(h, h->js.x, (double*)h->b_xt.p, W, (long)h->N * 3);
   for (int s = 0; s < 2; ++s) {
     const size_t n = nel[s], cf = h->cplx ? 2 : 1;
@@ -1760,7 +1769,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
   if (soa_current) {
-    const dim3 gk((unsigned)((W + 63) / 64), (unsigned)((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB)), bk(64, PQA_KIN_EB);
+    const dim3 gk((unsigned)((((W + 63) / 64 + 7) / 8) * 8 * ((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB))), bk(64, PQA_KIN_EB);  // see k_kinetic_lw
     if (h->cplx) {
       if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
       else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
@@ -1820,6 +1829,15 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
     B.has_j2 = h->has_j2 ? 1 : 0;
+    B.ue = (soa_current && h->has_j2) ? (const double*)h->b_kpart.p + (size_t)4 * h->N * W : nullptr;  // k_kinetic_lw left U_e there
+    // second-generation list passes (pqa_ecp.hpp): tables in LDS, four walkers per block
+    const size_t tab_b = ecp_tab_bytes(h->necp, h->ecp_nchan, h->ecp_nterm);
+    const bool ecp_t = h->ecp_lds && h->necp <= 64 && (long)h->necp * ((h->N + 63) / 64) <= 64 && tab_b <= 32768;
+    const dim3 g_t((unsigned)((W + PQA_ECP_WB - 1) / PQA_ECP_WB)), b_t(64 * PQA_ECP_WB);
+    if (ecp_t) {
+      if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count_t<true>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+      else hipLaunchKernelGGL(k_ecp_count_t<false>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+    } else
     if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers)
@@ -1845,6 +1863,15 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
     }
     if (tot[0] + tot[1] > 0) {
+      if (ecp_t) {
+        if (B.ue) {
+          if (h->S.pbc) hipLaunchKernelGGL((k_ecp_fill_t<true, true>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+          else hipLaunchKernelGGL((k_ecp_fill_t<false, true>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+        } else {
+          if (h->S.pbc) hipLaunchKernelGGL((k_ecp_fill_t<true, false>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+          else hipLaunchKernelGGL((k_ecp_fill_t<false, false>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
+        }
+      } else
       if (h->S.pbc) hipLaunchKernelGGL(k_ecp_fill<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
       else hipLaunchKernelGGL(k_ecp_fill<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
       TRY(check_launch(h, "k_ecp_fill"));
@@ -1867,6 +1894,14 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         const long n_s = s ? h->ndn : h->nup;
         const double* Tb = soa_T ? (const double*)h->b_Tt[s].p : (const double*)h->st.T[s];
         const long sw = soa_T ? 1 : n_s * n_s, si = soa_T ? n_s * W : n_s, sk = soa_T ? W : 1;
+        if (soa_T && h->ecp_point_lw) {
+          if (h->S.pbc)
+            hipLaunchKernelGGL(k_ecp_point_lw<true>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
+                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
+          else
+            hipLaunchKernelGGL(k_ecp_point_lw<false>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
+                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
+        } else
         if (h->S.pbc)
           hipLaunchKernelGGL(k_ecp_point<true>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
                              (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
@@ -2097,10 +2132,12 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb, const LwCtx& 
         ce1 = h->prof2_events[h->prof2_used].second;
         ++h->prof2_used;
       }
-#define PQA_FLUSH(NM) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * PQA_FLUSH_WB * sizeof(double); const dim3 gf((unsigned)((W + PQA_FLUSH_WB - 1) / PQA_FLUSH_WB)); \
-      if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
-      else hipLaunchKernelGGL((k_flush_lw<NM, false>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
+#define PQA_FLUSH_W(NM, WB_) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * WB_ * sizeof(double); const dim3 gf((unsigned)((W + WB_ - 1) / WB_)); \
+      if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true, WB_>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
+      else hipLaunchKernelGGL((k_flush_lw<NM, false, WB_>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
+#define PQA_FLUSH(NM) do { if (W <= h->flush_wb8_max) PQA_FLUSH_W(NM, 8); else PQA_FLUSH_W(NM, PQA_FLUSH_WB); } while (0)
       if (rowlen <= 8) PQA_FLUSH(8); else if (rowlen <= 16) PQA_FLUSH(16); else if (rowlen <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
+#undef PQA_FLUSH_W
 #undef PQA_FLUSH
       if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
     }

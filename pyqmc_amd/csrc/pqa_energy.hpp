@@ -251,6 +251,7 @@ struct EcpBuf {
   int* ptw[2];           // [npts_s]  walker index of the point (thread-per-point accumulation)
   double* u0[2];         // [npts_s]  two-body Jastrow exponent U_e at the electron's CURRENT position (same for the 6/12 points of an entry)
   int has_j2;            // fill u0
+  const double* ue;      // [N][W] U_e of every electron at its own position (k_kinetic_lw), or NULL: the fill pass sums it itself
   unsigned long long* passbits;  // [W][ceil(N*necp/64)] (electron, atom) pairs that passed the stochastic mask
 };
 
@@ -274,7 +275,15 @@ __device__ __forceinline__ void ecp_radial(const SysDev& S, int k, double r, dou
     double sum = 0.0;
     for (int t = S.ecp_term_off[c0 + c]; t < S.ecp_term_off[c0 + c + 1]; ++t) {
       const int n = S.ecp_term_n[t];
-      const double rn = (n == 0) ? 1.0 : ((n == -1) ? 1.0 / r : ((n == 1) ? r : ((n == -2) ? 1.0 / (r * r) : pow(r, (double)n))));
+      // integer powers by multiplication (PySCF's r^(n-2), n = 0 ... 4, gives -2 ... 2): `pow` inlined here cost the kernels that
+      // call this ~80 vector registers (k_ecp_count: 157 -> the occupancy of 3 waves per SIMD)
+      double rn = 1.0;
+      if (n != 0) {
+        const int an = n < 0 ? -n : n;
+        double rp = r;
+        for (int q = 1; q < an; ++q) rp *= r;
+        rn = n < 0 ? 1.0 / rp : rp;
+      }
       sum += rn * S.ecp_term_coef[t] * exp(-S.ecp_term_exp[t] * r * r);
     }
     v[c] = sum;

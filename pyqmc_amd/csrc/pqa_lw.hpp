@@ -315,7 +315,9 @@ __device__ __forceinline__ void lw_slater_terms(const double (&v)[PR], double& g
 #ifndef PQA_FLUSH_WB
 #define PQA_FLUSH_WB 16
 #endif
-template <int NMAX, bool CX = false>
+// WB: walkers per block (16 rows groups at 16, 32 at 8: small walker counts get twice the blocks and one row per thread —
+// at 4 096 walkers a flush was 256 blocks of two-row threads, 40 us for 17 us of traffic)
+template <int NMAX, bool CX = false, int WB = PQA_FLUSH_WB>
 __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
                                                   const double* __restrict__ Rb, const uint8_t* __restrict__ act, long W,
                                                   int j_lo, int j_hi, int nq) {
@@ -323,12 +325,12 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   const int n = s ? S.ndn : S.nup;
   const int L_ = CX ? 2 * n : n;  // doubles per row
   double* shV = sh;
-  double* shR = sh + (size_t)nq * L_ * PQA_FLUSH_WB;
-  const int wl = threadIdx.x & (PQA_FLUSH_WB - 1), g = threadIdx.x / PQA_FLUSH_WB;
-  const long w0 = (long)blockIdx.x * PQA_FLUSH_WB;
-  for (int idx = threadIdx.x; idx < nq * L_ * PQA_FLUSH_WB; idx += 256) {
-    const long ws = (w0 + (idx & (PQA_FLUSH_WB - 1)) < W) ? w0 + (idx & (PQA_FLUSH_WB - 1)) : W - 1;
-    const size_t src = (size_t)(idx / PQA_FLUSH_WB) * W + ws;  // idx / WB = q * L_ + k
+  double* shR = sh + (size_t)nq * L_ * WB;
+  const int wl = threadIdx.x & (WB - 1), g = threadIdx.x / WB;
+  const long w0 = (long)blockIdx.x * WB;
+  for (int idx = threadIdx.x; idx < nq * L_ * WB; idx += 256) {
+    const long ws = (w0 + (idx & (WB - 1)) < W) ? w0 + (idx & (WB - 1)) : W - 1;
+    const size_t src = (size_t)(idx / WB) * W + ws;  // idx / WB = q * L_ + k
     shV[idx] = Vb[src];
     shR[idx] = Rb[src];
   }
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   if (!mask) return;
   double* T = L.Tt[s] + w;
   const int nout = n - (j_hi - j_lo);
-  for (int jj = g; jj < nout; jj += 256 / PQA_FLUSH_WB) {
+  for (int jj = g; jj < nout; jj += 256 / WB) {
     const int j = (jj < j_lo) ? jj : jj + (j_hi - j_lo);
     double* Tj = T + (size_t)j * L_ * W;
     double t[NMAX];
@@ -348,21 +350,21 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
     for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
     for (int q = 0; q < nq; ++q) {
       if (!((mask >> q) & 1u)) continue;
-      const double* Vq = shV + (size_t)q * L_ * PQA_FLUSH_WB + wl;
-      const double* Rq = shR + (size_t)q * L_ * PQA_FLUSH_WB + wl;
+      const double* Vq = shV + (size_t)q * L_ * WB + wl;
+      const double* Rq = shR + (size_t)q * L_ * WB + wl;
       if (CX) {
         double tmp = 0.0, tmi = 0.0;
 #pragma unroll
         for (int k = 0; k < NMAX / 2; ++k)
           if (2 * k < L_) {
-            const double vr = Vq[(2 * k) * PQA_FLUSH_WB], vi = Vq[(2 * k + 1) * PQA_FLUSH_WB];
+            const double vr = Vq[(2 * k) * WB], vi = Vq[(2 * k + 1) * WB];
             tmp += vr * t[2 * k] - vi * t[2 * k + 1];
             tmi += vr * t[2 * k + 1] + vi * t[2 * k];
           }
 #pragma unroll
         for (int k = 0; k < NMAX / 2; ++k)
           if (2 * k < L_) {
-            const double rr = Rq[(2 * k) * PQA_FLUSH_WB], ri = Rq[(2 * k + 1) * PQA_FLUSH_WB];
+            const double rr = Rq[(2 * k) * WB], ri = Rq[(2 * k + 1) * WB];
             t[2 * k] -= rr * tmp - ri * tmi;
             t[2 * k + 1] -= rr * tmi + ri * tmp;
           }
@@ -370,10 +372,10 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
         double tmp = 0.0;
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
-          if (k < L_) tmp += Vq[k * PQA_FLUSH_WB] * t[k];
+          if (k < L_) tmp += Vq[k * WB] * t[k];
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
-          if (k < L_) t[k] = t[k] - Rq[k * PQA_FLUSH_WB] * tmp;
+          if (k < L_) t[k] = t[k] - Rq[k * WB] * tmp;
       }
     }
 #pragma unroll
@@ -650,7 +652,7 @@ __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepA
 }
 
 // ---------------------------------------------------------------- kinetic + Coulomb
-// thread = (walker, electron), walker fastest.  part [4][N][W]: ke_e, grad2_e, ee_e, ei_e
+// thread = (walker, electron), walker fastest.  part [5][N][W]: ke_e, grad2_e, ee_e, ei_e, U_e (Jastrow exponent of electron e)
 // block = (64 walkers, PQA_KIN_EB electrons): one wave per electron, so the electron index — and with it the spin, the orbital
 // occupation list and every Jastrow table address — must stay wave-uniform (scalar loads): threadIdx.y goes through
 // readfirstlane.  (As a plain per-lane value it turned the occupation look-up of the inner loop into a dependent vector load:
@@ -665,8 +667,16 @@ __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepA
 #endif
 template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
-  const long w = (long)blockIdx.x * 64 + threadIdx.x;
-  const int e = blockIdx.y * PQA_KIN_EB + (PQA_KIN_EB > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.y) : 0);
+  // Block b -> (walker group, electron block): the electron blocks of ONE walker group sit 8 apart in the linear block order, so
+  // they land on the same XCD (blocks go to the XCDs round-robin) and run at about the same time: the group's coordinates, which
+  // every one of them walks, come out of that XCD's L2 after the first.  (With the electron on grid.y the 64 blocks of a group were
+  // 1 024 blocks apart and every one fetched the coordinates again: 195 KB per walker through the fabric against 98 KB of rows and
+  // inverses, at 6.2 TB/s — the kernel was bound by re-reads.)
+  const int neb_ = (S.nelec + PQA_KIN_EB - 1) / PQA_KIN_EB;
+  const long chunk = (long)blockIdx.x / (8 * neb_);
+  const int rem = (int)((long)blockIdx.x % (8 * neb_));
+  const long w = (chunk * 8 + (rem & 7)) * 64 + threadIdx.x;
+  const int e = (rem >> 3) * PQA_KIN_EB + (PQA_KIN_EB > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.y) : 0);
   if (w >= W || e >= S.nelec) return;
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
@@ -758,6 +768,7 @@ __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwStat
   part[NW + o] = gx * gx + gy * gy + gz * gz + gi2;
   part[2 * NW + o] = ee;
   part[3 * NW + o] = ei;
+  part[4 * NW + o] = U;  // U_e at the electron's own position: the ECP pass needs it for every (electron, atom) entry it integrates
 }
 
 // out rows ke, ee, ei, grad2 (layout of k_kinetic_coulomb) = sums over electrons of part
@@ -772,3 +783,4 @@ __global__ void k_kinetic_reduce(const double* __restrict__ part, int N, long W,
   }
   out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = g2;
 }
+
