@@ -84,6 +84,8 @@ struct pqa_handle {
   int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
   int ecp_point_lw = 1;  // PQA_ECP_POINT_LW=0: k_ecp_point on the planes instead of k_ecp_point_lw (A/B)
   long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
+  long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
+  int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
   int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
   int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
@@ -514,6 +516,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
   if (const char* ep = getenv("PQA_ECP_POINT_LW")) h->ecp_point_lw = atoi(ep);
   if (const char* el = getenv("PQA_ECP_LDS")) h->ecp_lds = atoi(el);
+  if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
+  if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
   if (const char* fw = getenv("PQA_FLUSH_WB8_MAX")) h->flush_wb8_max = atol(fw);
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
@@ -2061,14 +2065,35 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
 template <bool PBC, bool CX>
 static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen) {
   const dim3 grid((unsigned)((a.W + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
+  // small shards: the variant with every load issued at entry (k_step_pre, pqa_lw.hpp) where its scope covers the system
+  // (one block per CU at most: the kernel holds ~360 registers per lane, one wave per SIMD)
+  if (!CX && h->step_pre && a.NW < 64 && a.G >= 8 && grid.x <= 256 && h->S.occ_ident[0] && h->S.occ_ident[1] && h->S.nb <= PQA_JAS_NF && h->S.na <= PQA_JAS_NF &&
+      h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G) && rowlen <= 64) {
+#define PQA_STEP_P(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM) * a.NW * sizeof(double); \
+      hipLaunchKernelGGL((k_step_pre<PBC, NM>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
+    if (rowlen <= 8) PQA_STEP_P(8); else if (rowlen <= 16) PQA_STEP_P(16); else if (rowlen <= 32) PQA_STEP_P(32); else PQA_STEP_P(64);
+#undef PQA_STEP_P
+    return;
+  }
   const size_t lds = (size_t)std::max(PQA_LW_PART_ROWS(CX) * a.G, 2 * rowlen) * a.NW * sizeof(double);
 #define PQA_STEP(NM) do { if (a.NW == 64) hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, true>), grid, block, lds, h->stream, h->S, L, mb, a); \
                           else hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, false>), grid, block, lds, h->stream, h->S, L, mb, a); } while (0)
   if (rowlen <= 8) PQA_STEP(8); else if (rowlen <= 16) PQA_STEP(16); else if (rowlen <= 32) PQA_STEP(32); else PQA_STEP(64);
 #undef PQA_STEP
 }
-static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb, const LwCtx& lc) {
+static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCtx& lc) {
   const long W = h->W;
+  MoveBuf mb = mb_in;
+  if (!mb.gauss && !mb.unif && W <= h->draws_max) {
+    // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
+    // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD
+    const size_t NW = (size_t)h->N * W;
+    TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
+    TRY(ensure(h, h->b_unif, NW * sizeof(double)));
+    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W,
+                       (double*)h->b_gauss.p, (double*)h->b_unif.p);
+    mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
+  }
   const int N = h->N, KB = lc.KB, nmax = lc.nmax;
   const LwState L = lw_state(h);
   const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row

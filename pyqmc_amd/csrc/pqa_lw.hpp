@@ -651,6 +651,420 @@ __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepA
   }
 }
 
+// ---------------------------------------------------------------- k_step_lw for small shards: every load up front
+// At 4 096 walkers k_step_lw is 256 blocks of one wave per SIMD and its 30 us are a chain of ~11 dependent memory round trips
+// (selector -> row, inverse slice, partner coordinates, ion tables, auxiliaries, the block row of the commit, then the same
+// again for the proposal of the next electron) between 5 barriers — the step time of a small shard is 77 of those chains.
+// Almost none of the addresses depend on anything computed in the kernel: k_step_pre issues ALL loads of BOTH halves at entry
+// (one round trip; the orbital rows, whose slot depends on the selector byte, one more), keeps the partner coordinates of the
+// walker in registers across the two halves (the accepted proposal is patched in), takes the update vectors from the slices
+// already in registers, and hands the inverse row of the next electron — a block row this launch updates — to the proposal
+// half through LDS instead of a store / barrier / load.  Registers are no object here (one wave per SIMD).
+// Every sum is formed from the same operands in the same order as in k_step_lw / lw_move_sums / jas_eval_lane_t<.., FAST>; the
+// compiler contracts multiply-adds differently in the two inlining contexts, so a group's Jastrow gradient sum can differ in its
+// last bit: same decisions, walkers equal to ~1e-14 after a sweep (measured with the -DPQA_PRE_DBG builds, which swap single
+// parts back to the k_step_lw routines; tests/test_gpu_fullsize.py::test_prefetching_step_kernel_against_the_general_one).
+// Scope (the host falls back to k_step_lw otherwise): real orbitals, ground-state occupation lists, Jastrow tables of at most
+// PQA_JAS_NF functions per kind, G >= 8 groups with N <= PQA_PRE_NP G electrons, natom <= PQA_PRE_NA G ions, and a
+// Sherman-Morrison block of at most G rows.
+#define PQA_PRE_NP 8
+#ifndef PQA_PRE_DBG
+#define PQA_PRE_DBG 0  // bisecting aid: 1 / 2 decide / propose sums by lw_move_sums, 4 / 8 only their Jastrow part by jas_eval_lane
+#endif
+#define PQA_PRE_NA 4
+struct JasTabs {  // wave-uniform function tables (scalar registers)
+  int bk[PQA_JAS_NF], ak[PQA_JAS_NF];
+  double bp[PQA_JAS_NF], ba[PQA_JAS_NF], ap[PQA_JAS_NF], aa[PQA_JAS_NF];
+};
+// jas_eval_lane_t<1, PBC, true> for the partners j = g, g + G, ... and ions I = g, g + G, ... on coordinates and ion
+// coefficients that are already in registers
+template <bool PBC>
+__device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e, double rx, double ry, double rz, int has_jastrow, int g,
+                                        int G, const double (&pcx)[PQA_PRE_NP], const double (&pcy)[PQA_PRE_NP],
+                                        const double (&pcz)[PQA_PRE_NP], const double (&atx)[PQA_PRE_NA], const double (&aty)[PQA_PRE_NA],
+                                        const double (&atz)[PQA_PRE_NA], const double (&bc0)[PQA_JAS_NF], const double (&bc1)[PQA_JAS_NF],
+                                        const double (&ac)[PQA_PRE_NA][PQA_JAS_NF], double& U, double (&gr)[3]) {
+  constexpr int NF = PQA_JAS_NF;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#pragma unroll
+  for (int m = 0; m < PQA_PRE_NP; ++m) {
+    const int j = g + m * G;
+    if (j >= S.nelec || j == e) continue;
+    double dx = rx - pcx[m], dy = ry - pcy[m], dz = rz - pcz[m];
+    if (PBC) min_image(S, dx, dy, dz);
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (has_jastrow && r < S.rcut_b) {
+      const RadShared sh = rad_shared<1>(r, irb);
+      const bool hi = j >= S.nup;
+      double sg = 0.0;
+#pragma unroll
+      for (int l = 0; l < NF; ++l) {
+        if (l < S.nb) {
+          double v, gf, lpl;
+          rad_fn<1>(J.bk[l], J.bp[l], J.ba[l], S.rcut_b, sh, v, gf, lpl);
+          const double c = hi ? bc1[l] : bc0[l];
+          u_ += c * v;
+          sg += c * gf;
+        }
+      }
+      gx += sg * dx; gy += sg * dy; gz += sg * dz;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < PQA_PRE_NA; ++m) {
+    const int I = g + m * G;
+    if (I >= S.natom) continue;
+    double dx = rx - atx[m], dy = ry - aty[m], dz = rz - atz[m];
+    if (PBC) min_image(S, dx, dy, dz);
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (has_jastrow && r < S.rcut_a) {
+      const RadShared sh = rad_shared<1>(r, ira);
+      double sg = 0.0;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        if (k < S.na) {
+          double v, gf, lpl;
+          rad_fn<1>(J.ak[k], J.ap[k], J.aa[k], S.rcut_a, sh, v, gf, lpl);
+          u_ += ac[m][k] * v;
+          sg += ac[m][k] * gf;
+        }
+      }
+      gx += sg * dx; gy += sg * dy; gz += sg * dz;
+    }
+  }
+  U = u_; gr[0] = gx; gr[1] = gy; gr[2] = gz;
+}
+
+template <bool PBC, int NMAX>
+__global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+  extern __shared__ double sh[];
+  constexpr int PR = 8, JU = 4, NS = (NMAX + 7) / 8, NF = PQA_JAS_NF, NP = PQA_PRE_NP, NA = PQA_PRE_NA;
+  const int NW = a.NW, G = a.G;
+  const int lane = (int)threadIdx.x % NW, g = (int)threadIdx.x / NW;
+  const long W = a.W;
+  const long wr = (long)blockIdx.x * NW + lane;
+  const bool live = wr < W;
+  const long w = live ? wr : W - 1;  // lanes past the end shadow the last walker and store nothing
+  const bool lead = live && g == 0;
+  double* shP = sh;                           // [PR][G][NW] partial sums
+  double* shV = sh + (size_t)PR * G * NW;     // [NMAX][NW] update vectors
+  double* shR = shV + (size_t)NMAX * NW;
+  double* shT = shR + (size_t)NMAX * NW;      // [NMAX][NW] inverse row of the next electron after the commit
+  const int ea = a.e_acc, ep = a.e_prop;
+  const bool has_a = ea >= 0, has_p = ep >= 0;
+  const int s = has_a ? (ea >= S.nup) : 0, i = ea - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
+  const int s2 = has_p ? (ep >= S.nup) : 0, i2 = ep - s2 * S.nup, n2 = s2 ? S.ndn : S.nup, nmo2 = S.nmo[s2];
+  const int nj = (n + G - 1) / G, jb = g * nj, je = (jb + nj < n) ? jb + nj : n;
+  const int nj2 = (n2 + G - 1) / G, jb2 = g * nj2, je2 = (jb2 + nj2 < n2) ? jb2 + nj2 : n2;
+  const bool handoff = has_a && has_p && s2 == s;  // the proposal's inverse row is a block row of this launch's commit
+  // ---------------------------------------------------------------- all loads whose addresses are known now
+  JasTabs J;
+#pragma unroll
+  for (int l = 0; l < NF; ++l) {
+    J.bk[l] = S.b_kind[l]; J.bp[l] = S.b_param[l]; J.ba[l] = S.b_aux[l];
+    J.ak[l] = S.a_kind[l]; J.ap[l] = S.a_param[l]; J.aa[l] = S.a_aux[l];
+  }
+  double pcx[NP], pcy[NP], pcz[NP], atx[NA], aty[NA], atz[NA];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    const int j = g + m * G;
+    const double* xj = L.xt + (size_t)(j < S.nelec ? j : 0) * 3 * W + w;
+    pcx[m] = xj[0]; pcy[m] = xj[W]; pcz[m] = xj[2 * W];
+  }
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    const int I = (g + m * G < S.natom) ? g + m * G : 0;
+    atx[m] = S.atom_xyz[3 * I]; aty[m] = S.atom_xyz[3 * I + 1]; atz[m] = S.atom_xyz[3 * I + 2];
+  }
+  double bcA0[NF], bcA1[NF], bcP0[NF], bcP1[NF], acA[NA][NF], acP[NA][NF];
+#pragma unroll
+  for (int l = 0; l < NF; ++l) {
+    bcA0[l] = (a.has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + s] : 0.0;
+    bcA1[l] = (a.has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + s + 1] : 0.0;
+    bcP0[l] = (a.has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + s2] : 0.0;
+    bcP1[l] = (a.has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + s2 + 1] : 0.0;
+  }
+#pragma unroll
+  for (int m = 0; m < NA; ++m) {
+    const int I = (g + m * G < S.natom) ? g + m * G : 0;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      acA[m][k] = (a.has_jastrow && k < S.na) ? S.acoeff[(I * S.na + k) * 2 + s] : 0.0;
+      acP[m][k] = (a.has_jastrow && k < S.na) ? S.acoeff[(I * S.na + k) * 2 + s2] : 0.0;
+    }
+  }
+  int cur = 0, cur2 = 0;
+  double npx = 0.0, npy = 0.0, npz = 0.0, ax7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, uu = 0.0;
+  double tinv[NS], tb[NMAX], tinv2[NS], xe2[3] = {0.0, 0.0, 0.0}, zt[3] = {0.0, 0.0, 0.0};
+  const int jrow = a.j_lo + g;  // block row of this group (one per group: the host checks j_hi - j_lo <= G)
+  const bool has_row = has_a && jrow < a.j_hi;
+  if (has_a) {
+    cur = L.sel[s][(size_t)i * W + w];
+    npx = mb.newpos[3 * w]; npy = mb.newpos[3 * w + 1]; npz = mb.newpos[3 * w + 2];
+    const double* ax = L.auxt + w;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ax7[q] = ax[(size_t)q * W];
+    if (mb.unif) uu = mb.unif[(size_t)ea * W + w];
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) tinv[u] = (jb + u < je) ? Ti[(size_t)(jb + u) * W] : 0.0;
+    if (has_row) {
+      const double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) tb[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+    }
+  }
+  if (has_p) {
+    cur2 = L.sel[s2][(size_t)i2 * W + w];
+    const double* xe = L.xt + (size_t)ep * 3 * W + w;
+    xe2[0] = xe[0]; xe2[1] = xe[W]; xe2[2] = xe[2 * W];
+    if (mb.gauss) { const double* z = mb.gauss + ((size_t)ep * W + w) * 3; zt[0] = z[0]; zt[1] = z[1]; zt[2] = z[2]; }
+    if (!handoff) {
+      const double* Ti2 = L.Tt[s2] + (size_t)i2 * n2 * W + w;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) tinv2[u] = (jb2 + u < je2) ? Ti2[(size_t)(jb2 + u) * W] : 0.0;
+    }
+  }
+  // ---------------------------------------------------------------- second round trip: the orbital rows (slot = selector byte)
+  double rv[4][NS], rv2[4][NS];
+  if (has_a) {
+    const double* row = lw_row(L, s, i, cur ^ 1, w, W, nmo);  // the proposal's row: the slot the walker is NOT using
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < NS; ++u) rv[c][u] = (jb + u < je) ? row[c * nmo + jb + u] : 0.0;
+  }
+  if (has_p) {
+    const double* row2 = lw_row(L, s2, i2, cur2, w, W, nmo2);  // cached row of the current position
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int u = 0; u < NS; ++u) rv2[c][u] = (jb2 + u < je2) ? row2[c * nmo2 + jb2 + u] : 0.0;
+  }
+  bool acc = false;
+  if (has_a) {
+    const int e = ea;
+    {
+      double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+        if (jb + u < je) { const double t = tinv[u]; r0 += rv[0][u] * t; r1 += rv[1][u] * t; r2 += rv[2][u] * t; r3 += rv[3][u] * t; }
+      double U, gg[3];
+      jas_pre<PBC>(S, J, e, npx, npy, npz, a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcA0, bcA1, acA, U, gg);
+#if PQA_PRE_DBG & 1
+      double p[PR];
+      lw_move_sums<PBC, false>(S, L, e, a.has_jastrow, npx, npy, npz, lw_row(L, s, i, cur ^ 1, w, W, nmo), W, w, g, G, p);
+#elif PQA_PRE_DBG & 4
+      double lp_, ee_, ei_;
+      jas_eval_lane<1, PBC>(S, L.xt, W, w, e, npx, npy, npz, a.has_jastrow, g, G, U, gg, lp_, ee_, ei_);
+      const double p[PR] = {r0, r1, r2, r3, U, gg[0], gg[1], gg[2]};
+#else
+      const double p[PR] = {r0, r1, r2, r3, U, gg[0], gg[1], gg[2]};
+#endif
+#pragma unroll
+      for (int c = 0; c < PR; ++c) shP[(c * G + g) * NW + lane] = p[c];
+    }
+    __syncthreads();
+    double v[PR];
+#pragma unroll
+    for (int c = 0; c < PR; ++c) v[c] = 0.0;
+    for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+      for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+    }
+    // ---- Metropolis decision (mc.py:124-132; dmc.py:57-70), every group the same numbers: k_step_lw's lines
+    double gx, gy, gz, dr, di;
+    lw_slater_terms<false, PR>(v, gx, gy, gz, dr, di);
+    gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
+    double val2;
+    { const double val = finite_or(dr, 1.0); val2 = val * val; }
+    if (a.has_jastrow) { const double ej = exp(v[JU] - ax7[6]); val2 *= ej * ej; }
+    const double a0 = ax7[0], a1 = ax7[1], a2 = ax7[2], d0 = ax7[3], d1 = ax7[4], d2 = ax7[5];
+    const double fwd = a0 * a0 + a1 * a1 + a2 * a2;
+    double bx, by, bz;
+    if (mb.dmc) {
+      limdrift_dmc(gx, gy, gz, mb.tstep);
+      bx = a0 + d0 + gx; by = a1 + d1 + gy; bz = a2 + d2 + gz;
+    } else {
+      limdrift3(gx, gy, gz);
+      bx = a0 + mb.tstep * (d0 + gx); by = a1 + mb.tstep * (d1 + gy); bz = a2 + mb.tstep * (d2 + gz);
+    }
+    const double bwd = bx * bx + by * by + bz * bz;
+    const double t_prob = exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
+    double ratio = val2 * t_prob;
+    if (mb.dmc) {
+      const double dv = finite_or(dr, 1.0);
+      ratio *= (dv > 0.0) ? 1.0 : ((dv < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
+    }
+    double u;
+    if (mb.unif) u = uu;
+    else {
+      const Philox ph = philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_ACCEPT, mb.step);
+      u = u01(ph.c[0], ph.c[1]);
+    }
+    acc = ratio > u;
+    if (lead) {
+      if (mb.dmc) {
+        const double rx = a0 + d0, ry = a1 + d1, rz = a2 + d2;
+        const double r2 = rx * rx + ry * ry + rz * rz;
+        mb.r2_prop[w] += r2;
+        if (acc) mb.r2_acc[w] += r2;
+      }
+      a.act[w] = acc;
+#if !(PQA_PRE_DBG & 32)
+      if (mb.accept_rec) mb.accept_rec[(size_t)e * W + w] = acc;
+#endif
+      if (acc) {
+        mb.acc_w[w] += 1;
+        L.sel[s][(size_t)i * W + w] = (uint8_t)(cur ^ 1);
+        double* xe = L.xt + (size_t)e * 3 * W + w;
+        xe[0] = npx; xe[W] = npy; xe[2 * W] = npz;
+        if (mb.wrap) {
+          int* wp = mb.wrap + ((size_t)w * S.nelec + e) * 3;
+          wp[0] += mb.dwrap[3 * w]; wp[1] += mb.dwrap[3 * w + 1]; wp[2] += mb.dwrap[3 * w + 2];
+        }
+        L.dsign[s][w] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+        L.dlog[s][w] += log(fabs(dr));
+      }
+    }
+    // ---- V = new orbital row, R = T_old[i] / ratio (slater.py:88-94): this group's slots, from the registers
+    {
+      const double inv = 1.0 / dr;
+      const bool st = acc && live;
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        const int k = jb + u;
+        if (k < je) {
+          const double vv = acc ? rv[0][u] : 0.0;
+          const double rr = acc ? tinv[u] * inv : 0.0;
+          shV[k * NW + lane] = vv;
+          shR[k * NW + lane] = rr;
+          if (st) { a.Vbuf[(size_t)k * W + w] = vv; a.Rbuf[(size_t)k * W + w] = rr; }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- this group's row of the electron block
+    if (has_row) {
+      double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
+      const bool any = __any(acc);  // k_step_lw stores nothing where no lane of the wave accepted
+      if (jrow == i) {
+        if (acc && live) {
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k)
+            if (k < n) Tj[(size_t)k * W] = shR[k * NW + lane];
+        }
+      } else {
+        double tmp = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if (k < n) tmp += shV[k * NW + lane] * tb[k];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if (k < n) tb[k] = acc ? tb[k] - shR[k * NW + lane] * tmp : tb[k];
+        if (live && any) {
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k)
+            if (k < n) Tj[(size_t)k * W] = tb[k];
+        }
+        if (handoff && jrow == i2) {
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k)
+            if (k < n) shT[k * NW + lane] = tb[k];
+        }
+      }
+    }
+    __syncthreads();
+    // the accepted proposal replaces the electron's coordinate in the register copy
+#if PQA_PRE_DBG & 16
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+      const int j = g + m * G;
+      const double* xj = L.xt + (size_t)(j < S.nelec ? j : 0) * 3 * W + w;
+      pcx[m] = xj[0]; pcy[m] = xj[W]; pcz[m] = xj[2 * W];
+    }
+#else
+#pragma unroll
+    for (int m = 0; m < NP; ++m)
+      if (acc && g + m * G == e) { pcx[m] = npx; pcy[m] = npy; pcz[m] = npz; }
+#endif
+  }
+  if (has_p) {
+    // ---- drift at the current position, proposal r' = r + sqrt(tau) z + tau limdrift(grad)   (mc.py:117-121)
+    const int e = ep;
+    {
+      if (handoff) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) tinv2[u] = (jb2 + u < je2) ? shT[(jb2 + u) * NW + lane] : 0.0;
+      }
+      double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+        if (jb2 + u < je2) { const double t = tinv2[u]; r0 += rv2[0][u] * t; r1 += rv2[1][u] * t; r2 += rv2[2][u] * t; r3 += rv2[3][u] * t; }
+      double U, gg[3];
+      jas_pre<PBC>(S, J, e, xe2[0], xe2[1], xe2[2], a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcP0, bcP1, acP, U, gg);
+#if PQA_PRE_DBG & 32
+      {
+        double U2, g2[3], lp_, ee_, ei_;
+        jas_eval_lane<1, PBC>(S, L.xt, W, w, e, xe2[0], xe2[1], xe2[2], a.has_jastrow, g, G, U2, g2, lp_, ee_, ei_);
+        const int code = (U != U2 ? 1 : 0) | (gg[0] != g2[0] ? 2 : 0) | (gg[1] != g2[1] ? 4 : 0) | (gg[2] != g2[2] ? 8 : 0);
+        shV[g * NW + lane] = (double)(code ? (code | (g << 4)) : 0);
+      }
+#endif
+#if PQA_PRE_DBG & 2
+      double p[PR];
+      lw_move_sums<PBC, false>(S, L, e, a.has_jastrow, xe2[0], xe2[1], xe2[2], lw_row(L, s2, i2, cur2, w, W, nmo2), W, w, g, G, p);
+#elif PQA_PRE_DBG & 8
+      double lp_, ee_, ei_;
+      jas_eval_lane<1, PBC>(S, L.xt, W, w, e, xe2[0], xe2[1], xe2[2], a.has_jastrow, g, G, U, gg, lp_, ee_, ei_);
+      const double p[PR] = {r0, r1, r2, r3, U, gg[0], gg[1], gg[2]};
+#else
+      const double p[PR] = {r0, r1, r2, r3, U, gg[0], gg[1], gg[2]};
+#endif
+#pragma unroll
+      for (int c = 0; c < PR; ++c) shP[(c * G + g) * NW + lane] = p[c];
+    }
+    __syncthreads();
+    if (!lead) return;
+#if PQA_PRE_DBG & 32
+    if (mb.accept_rec) {
+      int code = 0;
+      for (int gg = 0; gg < G; ++gg) { const int c = (int)shV[gg * NW + lane]; if (c && !code) code = c; }
+      mb.accept_rec[(size_t)e * W + w] = (uint8_t)code;
+    }
+#endif
+    double v[PR];
+#pragma unroll
+    for (int c = 0; c < PR; ++c) v[c] = 0.0;
+    for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+      for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+    }
+    double gx, gy, gz, dr, di;
+    lw_slater_terms<false, PR>(v, gx, gy, gz, dr, di);
+    gx += v[JU + 1]; gy += v[JU + 2]; gz += v[JU + 3];
+    if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);
+    else limdrift3(gx, gy, gz);
+    double z0, z1, z2, z3;
+    if (mb.gauss) { z0 = zt[0]; z1 = zt[1]; z2 = zt[2]; }
+    else {
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_A, mb.step), z0, z1);
+      normal2(philox(mb.seed, (uint32_t)w, (uint32_t)e, PQA_STREAM_GAUSS_B, mb.step), z2, z3);
+    }
+    const double sq = sqrt(mb.tstep);
+    z0 *= sq; z1 *= sq; z2 *= sq;
+    double* np_ = mb.newpos + 3 * w;
+    const double df = mb.dmc ? 1.0 : mb.tstep;
+    np_[0] = xe2[0] + z0 + gx * df;
+    np_[1] = xe2[1] + z1 + gy * df;
+    np_[2] = xe2[2] + z2 + gz * df;
+    if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
+    double* ao = L.auxt + w;
+    ao[0] = z0; ao[W] = z1; ao[2 * W] = z2; ao[3 * W] = gx; ao[4 * W] = gy; ao[5 * W] = gz; ao[6 * W] = v[JU];
+  }
+}
+
 // ---------------------------------------------------------------- kinetic + Coulomb
 // thread = (walker, electron), walker fastest.  part [5][N][W]: ke_e, grad2_e, ee_e, ei_e, U_e (Jastrow exponent of electron e)
 // block = (64 walkers, PQA_KIN_EB electrons): one wave per electron, so the electron index — and with it the spin, the orbital

@@ -328,3 +328,34 @@ def test_energy_statistics_against_the_oracle():
     note("energy_stat_difference_mHa", 1e3 * (e_dev - e_orc)), note("energy_stat_combined_stderr_mHa", 1e3 * comb)
     assert comb <= 2e-3, (s_dev, s_orc)
     assert abs(e_dev - e_orc) < 3.0 * comb, (e_dev, e_orc, comb)
+
+
+@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C5", 4096)])
+def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
+    """Shards of at most 4096 walkers run k_step_pre (all loads of a move's decide / propose launch issued at entry, the next
+    electron's inverse row handed over in LDS).  It forms every sum from the same operands in the same order as k_step_lw; what
+    differs is the compiler's choice of fused multiply-adds in the two contexts: every Metropolis decision (and every T-move of
+    C5's DMC steps) the same, walkers, log-values, energies and weights equal to rounding."""
+    import pyqmc_amd as pa
+
+    outs = []
+    for pre in ("0", "1"):
+        monkeypatch.setenv("PQA_STEP_PRE", pre)  # read when the handle is created
+        mol, wf, _, _ = build(cfg)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(11)))
+        acc, en, rec = dev.vmc_sweeps(0.3, 2, seed=21, energy=True, record=True)
+        out = {"rec": rec, "x": dev.configs(), "logv": dev.value()[1], "en": np.asarray(en), "acc": np.asarray(acc)}
+        if cfg == "C5":
+            w = np.ones(W)
+            et = float(np.real(en[-1][5]))
+            avg, dacc = dev.dmc_steps(0.02, 2, w, 10.0, et, et, seed=5)
+            out.update(x2=dev.configs(), avg=avg.copy(), dacc=dacc.copy(), w=w.copy())
+        outs.append(out)
+    a, b = outs
+    assert np.array_equal(a["rec"], b["rec"]) and np.array_equal(a["acc"], b["acc"])
+    if cfg == "C5":
+        assert np.array_equal(a["dacc"], b["dacc"])
+    for k in a:
+        if k not in ("rec", "acc", "dacc"):
+            assert note(f"{cfg}_{W}_pre_vs_general_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-11

@@ -434,18 +434,22 @@ def test_blocked_sherman_morrison_is_bitwise_identical(monkeypatch):
     mol = systems.water_cluster()
     mf = systems.random_mf(mol)
     start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
-    res = []
-    for kb in ("8", "0", "5"):
-        monkeypatch.setenv("PQA_LW_KB", kb)
-        wf = helpers.gpu_wf(mol, mf)
-        dev = wf.fused_device()
-        wf.recompute(OpenConfigs(start.copy()))
-        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=77, energy=True)
-        inv = [wf.wf_factors[0]._get_state(s)[0] for s in (0, 1)]
-        res.append((dev.configs(), dev.value()[1], en, inv))
-    for other in res[1:]:
-        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
-        assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
+    # k_step_lw for every block size first (the small-shard kernel k_step_pre takes blocks of at most 16 rows and differs from
+    # k_step_lw in its fused multiply-adds), then k_step_pre with two block sizes
+    for pre, kbs in (("0", ("8", "0", "5")), ("1", ("8", "5", "3"))):
+        monkeypatch.setenv("PQA_STEP_PRE", pre)
+        res = []
+        for kb in kbs:
+            monkeypatch.setenv("PQA_LW_KB", kb)
+            wf = helpers.gpu_wf(mol, mf)
+            dev = wf.fused_device()
+            wf.recompute(OpenConfigs(start.copy()))
+            acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=77, energy=True)
+            inv = [wf.wf_factors[0]._get_state(s)[0] for s in (0, 1)]
+            res.append((dev.configs(), dev.value()[1], en, inv))
+        for other in res[1:]:
+            assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]) and np.array_equal(res[0][2], other[2])
+            assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
 
 
 def test_ecp_point_and_wave_accumulation_agree(monkeypatch):
