@@ -86,6 +86,7 @@ struct pqa_handle {
   long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
   long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
   int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
+  int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum (0: 4 up to 8192 walkers)
   int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
   int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
@@ -516,6 +517,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
   if (const char* ep = getenv("PQA_ECP_POINT_LW")) h->ecp_point_lw = atoi(ep);
   if (const char* el = getenv("PQA_ECP_LDS")) h->ecp_lds = atoi(el);
+  if (const char* ea = getenv("PQA_ECP_ACC_WAVES")) h->ecp_acc_waves = atoi(ea);
   if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
   if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
   if (const char* fw = getenv("PQA_FLUSH_WB8_MAX")) h->flush_wb8_max = atol(fw);
@@ -1792,10 +1794,16 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       else TRY(lw_to_aos(h, false));
     }
   } else {
-    if (h->cplx) hipLaunchKernelGGL(k_kinetic_coulomb<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js,
-                                    (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
-    else hipLaunchKernelGGL(k_kinetic_coulomb<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js,
-                            (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p);
+    {  // four waves per walker while the launch is too small to fill the chip with one
+      const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W <= 8192);
+      const size_t st_ = (size_t)(h->cplx ? 2 : 1) * lds_det(h, 5);
+      const int str_ = (int)(st_ / sizeof(double));
+#define PQA_KC(CXF, NV) hipLaunchKernelGGL((k_kinetic_coulomb<CXF, NV>), dim3((unsigned)W), dim3(64 * NV), NV * st_, h->stream, h->S, h->st, h->js, \
+                                           (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p, str_)
+      if (h->cplx) { if (kc4) PQA_KC(true, 4); else PQA_KC(true, 1); }
+      else { if (kc4) PQA_KC(false, 4); else PQA_KC(false, 1); }
+#undef PQA_KC
+    }
     TRY(check_launch(h, "k_kinetic_coulomb"));
   }
   if (h->S.pbc) {
@@ -1883,13 +1891,16 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         for (int s = 0; s < 2; ++s)
           TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
     }
+    // wave-per-walker accumulation (complex determinants, several determinants, three-body factor): four waves share a walker's
+    // points while the launch is too small to fill the chip with one
+    const bool acc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W <= 8192);
+#define PQA_ECP_ACC(PB, CXF, SC) do { const size_t st_ = (size_t)(SC) * lds_det(h, 1); const int str_ = (int)(st_ / sizeof(double)); \
+      if (acc4) hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 4>), dim3((unsigned)W), dim3(256), 4 * st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
+                                   (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); \
+      else hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 1>), dim3((unsigned)W), dim3(64), st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
+                              (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); } while (0)
     if (h->cplx) {  // complex determinants: wave-per-walker accumulation in complex arithmetic
-      if (h->S.pbc)
-        hipLaunchKernelGGL((k_ecp_accum<true, true>), dim3((unsigned)W), dim3(64), 2 * lds_det(h, 1), h->stream, h->S, h->st, h->js, B,
-                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
-      else
-        hipLaunchKernelGGL((k_ecp_accum<false, true>), dim3((unsigned)W), dim3(64), 2 * lds_det(h, 1), h->stream, h->S, h->st, h->js, B,
-                           (int)h->has_slater, (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+      if (h->S.pbc) PQA_ECP_ACC(true, true, 2); else PQA_ECP_ACC(false, true, 2);
     } else
     if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
       for (int s = 0; s < 2; ++s) {
@@ -1915,13 +1926,10 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       }
       hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
                          (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p);
-    } else
-    if (h->S.pbc)
-      hipLaunchKernelGGL(k_ecp_accum<true>, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                         (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
-    else
-      hipLaunchKernelGGL(k_ecp_accum<false>, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                         (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p);
+    } else {
+      if (h->S.pbc) PQA_ECP_ACC(true, false, 1); else PQA_ECP_ACC(false, false, 1);
+    }
+#undef PQA_ECP_ACC
     TRY(check_launch(h, "k_ecp_accum"));
     d_ecp = (const double*)h->b_ecp.p;
   }

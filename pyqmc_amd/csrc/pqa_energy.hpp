@@ -15,15 +15,23 @@
 // ---------------------------------------------------------------- kinetic + Coulomb
 // out rows: ke, ee, ei, grad2 each (W).  LDS: max(ndet_s)*5 doubles (multi-determinant scratch).
 // CX: complex determinants — ke = -1/2 Re(lap Psi / Psi), grad2 = sum |grad Psi / Psi|^2 (energy.py:57-65).
-template <bool CX>
-__global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
-                                                        int has_jastrow, long W, double* __restrict__ out) {
-  extern __shared__ double lds[];
+// NWV waves per walker: wave v takes the electrons v, v + NWV, ... (own LDS slice of lds_stride doubles) and the pair / ion
+// rows i = v, v + NWV, ... of the Coulomb sums; the block adds the waves' sums in wave order.  All waves run the same number of
+// rounds (the helpers use block barriers): a surplus round repeats the last electron and adds nothing.
+template <bool CX, int NWV = 1>
+__global__ __launch_bounds__(64 * NWV) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
+                                                              int has_jastrow, long W, double* __restrict__ out, int lds_stride) {
+  extern __shared__ double lds_all[];
+  __shared__ double wsum[4][NWV];
+  const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  double* lds = lds_all + (size_t)wv * lds_stride;
   const long w = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double ke = 0.0, grad2 = 0.0;
-  for (int e = 0; e < S.nelec; ++e) {
+  for (int eb = 0; eb < S.nelec; eb += NWV) {
+    const bool valid = eb + wv < S.nelec;
+    const int e = valid ? eb + wv : S.nelec - 1;
     double gs[3] = {0.0, 0.0, 0.0}, ls = 0.0, gsi[3] = {0.0, 0.0, 0.0};  // gsi: imaginary part of the Slater gradient (CX)
     if (has_slater) {
       const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
@@ -46,12 +54,14 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
     }
     const double gx = gs[0] + gj[0], gy = gs[1] + gj[1], gz = gs[2] + gj[2];
     const double lap = ls + lj + 2.0 * (gs[0] * gj[0] + gs[1] * gj[1] + gs[2] * gj[2]);
-    ke += -0.5 * lap;
-    grad2 += gx * gx + gy * gy + gz * gz;
-    if (CX) grad2 += gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2];
+    if (valid) {
+      ke += -0.5 * lap;
+      grad2 += gx * gx + gy * gy + gz * gz;
+      if (CX) grad2 += gsi[0] * gsi[0] + gsi[1] * gsi[1] + gsi[2] * gsi[2];
+    }
   }
   double ee = 0.0, ei = 0.0;
-  for (int i = 0; i < (S.pbc ? 0 : S.nelec); ++i) {  // periodic cells: k_ewald fills ee / ei
+  for (int i = wv; i < (S.pbc ? 0 : S.nelec); i += NWV) {  // periodic cells: k_ewald fills ee / ei
     const double ix = xw[3 * i], iy = xw[3 * i + 1], iz = xw[3 * i + 2];
     for (int j = i + 1 + lane; j < S.nelec; j += 64) {
       const double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
@@ -64,7 +74,15 @@ __global__ __launch_bounds__(64) void k_kinetic_coulomb(SysDev S, SlaterState st
   }
   ee = wave_sum(ee);
   ei = wave_sum(ei);
-  if (lane == 0) { out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = grad2; }
+  if (NWV > 1) {
+    if (lane == 0) { wsum[0][wv] = ke; wsum[1][wv] = ee; wsum[2][wv] = ei; wsum[3][wv] = grad2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ke = ee = ei = grad2 = 0.0;
+      for (int v = 0; v < NWV; ++v) { ke += wsum[0][v]; ee += wsum[1][v]; ei += wsum[2][v]; grad2 += wsum[3][v]; }
+    }
+  }
+  if (threadIdx.x == 0) { out[w] = ke; out[W + w] = ee; out[2 * W + w] = ei; out[3 * W + w] = grad2; }
 }
 
 // ---------------------------------------------------------------- Ewald (observables/ewald.py:238-354)
@@ -463,13 +481,23 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
 }
 
 // pass C: ecp[w] = local + sum_points weight * Psi(aux)/Psi.  mo[s]: [npts_s][nmo_s] orbital values.
-// LDS: max(ndet_s) doubles.
+// Block = NWV waves on ONE walker: wave v takes the points first + v, first + v + NWV, ... of each spin's list, with its own
+// LDS slice (lds_stride doubles: multi-determinant scratch / three-body tables), and the block adds the waves' sums in wave
+// order.  The points of a walker are independent, and one wave walking all ~36 of them one after the other — multi-determinant
+// ratio, three-body factor — was 0.7 ms per evaluation whatever the walker count below ~4 000 (the 50-determinant molecule at
+// 2 048 walkers per GPU).  The helpers synchronise with block barriers, so all waves make the same calls: every wave runs the
+// same number of rounds (surplus rounds repeat the last point with weight 0) and re-evaluates the old-position exponent when
+// ANY wave meets a new electron.
 // CX: complex determinants; the imaginary part of the walker's sum goes to ecp[W + w].
-template <bool PBC, bool CX = false>
-__global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
-                                                  int has_jastrow, const double* __restrict__ mo_up,
-                                                  const double* __restrict__ mo_dn, long W, double* __restrict__ ecp) {
-  extern __shared__ double lds[];
+template <bool PBC, bool CX = false, int NWV = 1>
+__global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
+                                                        int has_jastrow, const double* __restrict__ mo_up,
+                                                        const double* __restrict__ mo_dn, long W, double* __restrict__ ecp,
+                                                        int lds_stride) {
+  extern __shared__ double lds_all[];
+  __shared__ double wsum[2][NWV];
+  const int wv = (NWV > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  double* lds = lds_all + (size_t)wv * lds_stride;
   const long w = blockIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   double tot = 0.0, tot_im = 0.0;
@@ -478,7 +506,10 @@ __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, Jast
     const int nmo = S.nmo[s];
     int last_e = -1;
     double U0 = 0.0;
-    for (long p = B.off[(size_t)s * (W + 1) + w]; p < B.off[(size_t)s * (W + 1) + w + 1]; ++p) {
+    const long p0 = B.off[(size_t)s * (W + 1) + w], p1 = B.off[(size_t)s * (W + 1) + w + 1];
+    for (long pb = p0; pb < p1; pb += NWV) {
+      const bool valid = pb + wv < p1;
+      const long p = valid ? pb + wv : p1 - 1;
       const int e = B.pte[s][p];
       double ratio = 1.0, ratio_im = 0.0;
       if (has_slater) {
@@ -494,13 +525,24 @@ __global__ __launch_bounds__(64) void k_ecp_accum(SysDev S, SlaterState st, Jast
       }
       if (has_jastrow) {
         double g[3], lp, U;
-        if (e != last_e) { jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
+        const bool fresh = (NWV > 1) ? (bool)__syncthreads_or(e != last_e) : (e != last_e);
+        if (fresh) { jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g, lp, 3, lds + S.j3_off); last_e = e; }
         jas_eval<0, PBC>(S, xw, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], U, g, lp, 3, lds + S.j3_off);
         const double ej = exp(U - U0);
         ratio *= ej; ratio_im *= ej;
       }
-      tot += ratio * B.wgt[s][p];
-      if (CX) tot_im += ratio_im * B.wgt[s][p];
+      if (valid) {
+        tot += ratio * B.wgt[s][p];
+        if (CX) tot_im += ratio_im * B.wgt[s][p];
+      }
+    }
+  }
+  if (NWV > 1) {
+    if ((threadIdx.x & 63) == 0) { wsum[0][wv] = tot; wsum[1][wv] = tot_im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      tot = 0.0; tot_im = 0.0;
+      for (int v = 0; v < NWV; ++v) { tot += wsum[0][v]; tot_im += wsum[1][v]; }
     }
   }
   if (threadIdx.x == 0) {

@@ -106,6 +106,47 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
   const int lane = threadIdx.x & 63;
   const int edown = e >= S.nup, na = S.na3, nb = S.nb3, str = j3_stride(S), nlm = na * nb * 2;
   const double ira = 1.0 / S.rcut_a3, irb = 1.0 / S.rcut_b3;
+  if (S.natom <= 64) {
+    // Phase 1 over ALL lanes.  With lanes = ions only, a molecule of three atoms had three lanes walk the na nb 2 contractions
+    // one coefficient load after the other (96 dependent round trips, ~40 us per call: nearly all of k_propose / k_accept /
+    // k_ecp_accum for the 50-determinant water molecule).  Now lane I evaluates its ion's radial functions, and the
+    // (ion, l, m, spin) contractions are spread over the wave, each taking its ion's function values by shuffle and its na
+    // coefficients with independent loads.  Same sums in the same order.
+    const int I0 = lane < S.natom ? lane : 0;
+    double dx = rx - S.atom_xyz[3 * I0], dy = ry - S.atom_xyz[3 * I0 + 1], dz = rz - S.atom_xyz[3 * I0 + 2];
+    min_image(S, dx, dy, dz);
+    const double r = sqrt(dx * dx + dy * dy + dz * dz);
+    if (lane < S.natom) { double* row = scr + (size_t)lane * str; row[0] = dx; row[1] = dy; row[2] = dz; }
+    double av[PQA_MAXBAS], ag[PQA_MAXBAS], al[PQA_MAXBAS];
+    const bool in = r < S.rcut_a3;
+    const RadShared sh = rad_shared<2>(in ? r : 0.5 * S.rcut_a3, ira);
+#pragma unroll
+    for (int k = 0; k < PQA_MAXBAS; ++k) {
+      av[k] = ag[k] = al[k] = 0.0;
+      if (k < na && in) rad_fn<2>(S.a3_kind[k], S.a3_param[k], S.a3_aux[k], S.rcut_a3, sh, av[k], ag[k], al[k]);
+    }
+    const int nitem = S.natom * nlm;
+    for (int t0 = 0; t0 < nitem; t0 += 64) {
+      const int t = t0 + lane;
+      const bool live = t < nitem;
+      const int I = live ? t / nlm : 0, rem = live ? t - I * nlm : 0;
+      const int l = rem / (2 * nb), m = (rem >> 1) % nb, sp = rem & 1;
+      const double* CI = S.c3 + (size_t)I * na * na * nb * 3;
+      double cc[PQA_MAXBAS];
+#pragma unroll
+      for (int k = 0; k < PQA_MAXBAS; ++k) cc[k] = (k < na) ? CI[((k * na + l) * nb + m) * 3 + edown + sp] : 0.0;
+      double e0 = 0.0, eg = 0.0, el = 0.0;
+#pragma unroll
+      for (int k = 0; k < PQA_MAXBAS; ++k) {
+        const double a0 = __shfl(av[k], I, 64), a1 = __shfl(ag[k], I, 64), a2 = __shfl(al[k], I, 64);
+        if (k < na) { e0 += cc[k] * a0; eg += cc[k] * a1; el += cc[k] * a2; }
+      }
+      if (live) {
+        double* row = scr + (size_t)I * str;
+        row[3 + rem] = e0; row[3 + rem + nlm] = eg; row[3 + rem + 2 * nlm] = el;
+      }
+    }
+  } else
   for (int I = lane; I < S.natom; I += 64) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
     min_image(S, dx, dy, dz);

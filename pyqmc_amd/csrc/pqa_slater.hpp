@@ -164,6 +164,36 @@ __device__ __forceinline__ void slater_ratios(const SysDev& S, const SlaterState
     for (int c = 0; c < NCOMP; ++c) out[c] = wave_sum(part[c]);
     return;
   }
+  if (n <= 16) {
+    // Few electrons per spin (the 50-determinant water molecule has 4): one determinant per pass left 60 of the 64 lanes idle and
+    // cost a wave-wide reduction per determinant and component — k_ecp_accum walked ~30 unique determinants x 36 points one after
+    // the other (0.9 ms per evaluation at 2 048 walkers).  Lanes = (determinant of the pass, slot): 64 / GS determinants at a
+    // time, a butterfly over the GS = 2^k >= n lanes of a determinant.  It adds the same pairs as wave_sum's scan does for lanes
+    // 0 .. n-1 (adjacent pairs, then pairs of pairs; the other lanes hold zeros there): the ratios are bitwise the same.
+    const int GS = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16)));
+    const int DP = 64 / GS, g = lane / GS, j = lane & (GS - 1);
+    for (int d0 = 0; d0 < D; d0 += DP) {
+      const int d = d0 + g;
+      const bool act = d < D && j < n;
+      double part[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) part[c] = 0.0;
+      if (act) {
+        const double t = st.T[s][(((size_t)w * D + d) * n + i) * n + j];
+        const int o = S.det_occ[s][(size_t)d * n + j];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) part[c] += mo[c * nmo + o] * t;
+      }
+      for (int off = 1; off < GS; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) part[c] += __shfl_xor(part[c], off, 64);
+      }
+      if (act && j == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) scratch[d * NCOMP + c] = part[c];
+      }
+    }
+  } else
   for (int d = 0; d < D; ++d) {
     const double* Trow = st.T[s] + (((size_t)w * D + d) * n + i) * n;
     const int* occ = S.det_occ[s] + (size_t)d * n;
@@ -231,6 +261,36 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
                                                const double* __restrict__ morow, double* lds) {
   const int lane = threadIdx.x & 63;
   const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], ld = n + 1;
+  if (n <= 8) {
+    // Small determinants (the 50-determinant molecule: 4 x 4, ~30 unique per spin): the staged update below is five block barriers
+    // per determinant, one determinant at a time — most of k_accept's 77 us.  Here a lane holds ONE element T[r][c] of a determinant
+    // and 64 / GS^2 determinants (GS = 2^k >= n) go through at once; the row dots, the ratio and the pivot row travel by shuffles.
+    // Same products, same order of additions as below (for n <= 8 every lane group there holds one column: the row dot is the
+    // sequential sum of the n rounded products).
+    const int GS = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)), E = GS * GS, DP = 64 / E;
+    const int g = lane / E, r = (lane & (E - 1)) / GS, c = lane & (GS - 1);
+    for (int d0 = 0; d0 < D; d0 += DP) {
+      const int d = d0 + g;
+      const bool act = d < D && r < n && c < n;
+      double* Tw = st.T[s] + ((size_t)w * D + (d < D ? d : 0)) * n * n;
+      double t = act ? Tw[r * n + c] : 0.0;
+      const double v = act ? morow[S.det_occ[s][(size_t)d * n + c]] : 0.0;
+      const double p = v * t;
+      double tmp = 0.0;
+      for (int k = 0; k < GS; ++k) tmp += __shfl(p, g * E + r * GS + k, 64);
+      const double ratio = __shfl(tmp, g * E + i * GS, 64);
+      const double rr = __shfl(t, g * E + i * GS + c, 64) / ratio;  // inv_ratio[c] = inv[c][i] / ratio
+      if (r == i) t = rr;
+      else t -= rr * tmp;
+      if (act) Tw[r * n + c] = t;
+      if (d < D && r == 0 && c == 0) {
+        const size_t o = (size_t)w * D + d;
+        st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)
+        st.dlog[s][o] += log(fabs(ratio));
+      }
+    }
+    return;
+  }
   double* L = lds;
   double* V = lds + (size_t)n * ld;
   double* Rr = V + n;
