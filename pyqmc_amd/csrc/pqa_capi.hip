@@ -1909,7 +1909,9 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         const long n_s = s ? h->ndn : h->nup;
         const double* Tb = soa_T ? (const double*)h->b_Tt[s].p : (const double*)h->st.T[s];
         const long sw = soa_T ? 1 : n_s * n_s, si = soa_T ? n_s * W : n_s, sk = soa_T ? W : 1;
-        if (soa_T && h->ecp_point_lw) {
+        // (the planes are the live state whenever this evaluation follows a lane-per-walker sweep, also where the walker-major copy
+        // was refreshed for the caller's next step — the DMC loop's T-moves)
+        if (soa_current && !h->cplx && h->ecp_point_lw) {
           if (h->S.pbc)
             hipLaunchKernelGGL(k_ecp_point_lw<true>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
                                (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
