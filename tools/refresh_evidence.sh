@@ -40,6 +40,13 @@ python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 2>/dev/null | tail
 python $R/tools/config_bench.py c5 --walkers 32768 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 > /dev/null 2>&1 < /dev/null
 python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/dmc_c5_kernel_stats.csv
+rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/config_bench.py c5 --walkers 4096 --steps 10 > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/dmc_c5_4096_kernel_stats.csv
+rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/config_bench.py c4 --walkers 2048 --steps 4 > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/c4_2048_kernel_stats.csv
+for w in 1024 2048 4096 8192 16384 32768; do echo -n "{\"walkers\": $w, \"line\": \"" >> $O/small_shards.txt; python $R/tools/scratch/lib_bench.py $R/pyqmc_amd/lib/libpyqmc_amd.so $w 2>/dev/null | tr -d '\n' >> $O/small_shards.txt; echo "\"}" >> $O/small_shards.txt; done
+rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/scratch/lib_bench.py $R/pyqmc_amd/lib/libpyqmc_amd.so 4096 > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/m_4096_kernel_stats.csv
 python $R/tools/cpu_config_baseline.py c2 c3 c4 c5 > $O/cpu_config_baseline.jsonl 2>> $O/bench.err
 cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
