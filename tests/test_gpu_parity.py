@@ -452,6 +452,49 @@ def test_blocked_sherman_morrison_is_bitwise_identical(monkeypatch):
             assert all(np.array_equal(a, b) for a, b in zip(res[0][3], other[3]))
 
 
+@pytest.mark.parametrize("var,values", [("PQA_ECP_LDS", ("0", "1")), ("PQA_ECP_POINT_LW", ("0", "1"))])
+def test_ecp_second_generation_passes_agree_with_the_first(var, values, monkeypatch):
+    """The ECP list passes with their tables in LDS / 16-lane entry groups and the point kernel with batched loads (pqa_ecp.hpp)
+    against the first-generation kernels they replace on the fused path: same Philox masks and rotations, so the same points;
+    energies of a fused sweep's evaluations equal to rounding (the old-position Jastrow exponent is summed in another order)."""
+    import pyqmc_amd as pa
+
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    start = pa.initial_guess(mol, 700, rng=np.random.default_rng(6)).configs
+    out = []
+    for flag in values:
+        monkeypatch.setenv(var, flag)
+        wf = helpers.gpu_wf(mol, mf)
+        dev = wf.fused_device()
+        wf.recompute(OpenConfigs(start.copy()))
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=13, energy=True)
+        out.append((dev.configs(), np.asarray(en)))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert note(f"ecp_{var.lower()}_energy", np.max(np.abs(out[0][1] - out[1][1]) / np.abs(out[1][1]))) < 1e-12
+
+
+def test_four_waves_per_walker_in_the_wave_per_walker_energy_kernels(monkeypatch):
+    """k_ecp_accum / k_kinetic_coulomb with four waves per walker (default up to 8192 walkers) against one wave per walker:
+    multi-determinant x three-body wave function, same points, sums added in another order."""
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=8)
+    dets = systems.random_determinants(mol, mf, 50)
+    start = pa.initial_guess(mol, 300, rng=np.random.default_rng(8)).configs
+    out = []
+    for flag in ("1", "4"):
+        monkeypatch.setenv("PQA_ECP_ACC_WAVES", flag)
+        wf = helpers.gpu_wf3(mol, mf, dets)
+        cfg = OpenConfigs(start.copy())
+        wf.recompute(cfg)
+        out.append(pa.EnergyAccumulator(mol, seed=3)(cfg, wf))
+    assert np.count_nonzero(out[0]["ecp"]) > 100
+    for k in out[0]:
+        assert note("energy_waves_1_vs_4_" + k, relerr(out[0][k], out[1][k])) < 1e-12, k
+
+
 def test_ecp_point_and_wave_accumulation_agree(monkeypatch):
     """The thread-per-point ECP accumulation (default for single-determinant wave functions) and the wave-per-walker
     one (PQA_ECP_WAVE=1; always used with several determinants or a three-body factor) give the same energies."""
