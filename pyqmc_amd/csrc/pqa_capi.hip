@@ -537,7 +537,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->has_j3 = sys->na3 > 0 && sys->nb3 > 0;
   h->has_jastrow = h->has_j2 || h->has_j3;
   h->na = sys->na; h->nb = sys->nb; h->necp = sys->necp; h->na3 = h->has_j3 ? sys->na3 : 0; h->nb3 = h->has_j3 ? sys->nb3 : 0;
-  if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS || h->na3 > PQA_MAXBAS || h->nb3 > PQA_MAXBAS) FAIL("more than 8 Jastrow basis functions per kind");
+  if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS) FAIL("more than 16 two-body Jastrow basis functions per kind");
+  if (h->na3 > PQA_MAXBAS3 || h->nb3 > PQA_MAXBAS3) FAIL("more than 8 three-body Jastrow basis functions per kind");
   if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 64 electrons per spin channel is not supported by the one-wave determinant tile");
   SysDev& S = h->S;
   S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;

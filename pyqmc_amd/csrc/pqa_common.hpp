@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 #define PQA_WAVE 64
-#define PQA_MAXBAS 8      // max Jastrow basis functions per kind
+#define PQA_MAXBAS 16     // max two-body Jastrow basis functions per kind (hot kernels loop to na / nb; only the protocol kernels' register arrays have this length)
+#define PQA_MAXBAS3 8     // max three-body basis functions per kind (fully unrolled register arrays in jas3_eval)
 #define PQA_MAXN 64       // max electrons per spin handled by one wave (LU / Sherman-Morrison tile)
 #define PQA_MAXCHAN 5     // ECP channels per atom incl. local
 #define PQA_MAXAIP 12
@@ -75,12 +76,12 @@ struct SysDev {
   const double* bcoeff;  // [nb][3]
   // three-body Jastrow (three_body_jastrow.py:19-63): own a/b bases, C = (c + c^T_kl)/2 as [natom][na3][na3][nb3][3]
   int na3, nb3;
-  int a3_kind[PQA_MAXBAS];
-  double a3_param[PQA_MAXBAS];
-  double a3_aux[PQA_MAXBAS];
-  int b3_kind[PQA_MAXBAS];
-  double b3_param[PQA_MAXBAS];
-  double b3_aux[PQA_MAXBAS];
+  int a3_kind[PQA_MAXBAS3];
+  double a3_param[PQA_MAXBAS3];
+  double a3_aux[PQA_MAXBAS3];
+  int b3_kind[PQA_MAXBAS3];
+  double b3_param[PQA_MAXBAS3];
+  double b3_aux[PQA_MAXBAS3];
   double rcut_a3, rcut_b3;
   const double* c3;
   int j3_off;  // offset (in doubles) of the three-body scratch inside a kernel's dynamic LDS

@@ -808,3 +808,42 @@ def test_tbdm_golden():
     ev = pa.obdm.OrbitalEvaluator(mol, orb)
     assert ev.nmo() == [5, 4]
     check_tbdm_against_golden(wf, g, lambda kw: tbdm.TBDMAccumulator(mol, orb, nsweeps=2, tstep=0.4, warmup=4, **kw), 1e-8, note)
+
+
+def test_two_body_jastrow_with_more_than_eight_basis_functions():
+    """Up to 16 two-body Jastrow basis functions per kind (the reference has no limit; round 2 stopped at 8): 11 electron-ion and
+    13 electron-electron functions.  Protocol entry points and the fused sweep (whose kernels leave their four-function fast path)
+    against the oracle on the device's own Philox draws."""
+    import pyqmc_amd as pa
+    from oracle import jastrow_basis, vmc as ovmc, wf as owf
+
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    na, nb = 11, 12
+    wf = pa.generate_wf(mol, mf, jastrow_kws=dict(na=na, nb=nb))
+    a, b = helpers.jastrow_params(mol, na=na, nb=nb + 1)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, na=na, nb=nb)
+    ja = owf.JastrowSpin(mol, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = a, b
+    ow = owf.MultiplyWF(owf.Slater(mol, mf.mo_coeff), ja)
+    W = 48
+    start = pa.initial_guess(mol, W, rng=np.random.default_rng(4)).configs
+    cfg = OpenConfigs(start.copy())
+    sign, logv = wf.recompute(cfg)
+    ocfg0 = OpenConfigs(start.copy())
+    osign, ologv = ow.recompute(ocfg0)
+    assert note("jastrow13_recompute", relerr(logv, ologv)) < 1e-11
+    e = 3
+    epos = start[:, e] + 0.1
+    g, val, _ = wf.gradient_value(e, cfg.make_irreducible(e, epos))
+    og, oval, _ = ow.gradient_value(e, ocfg0.make_irreducible(e, epos))
+    assert note("jastrow13_gradient_value", max(relerr(g, og), relerr(val, oval))) < 1e-10
+    assert note("jastrow13_laplacian", relerr(wf.gradient_laplacian(e, cfg.make_irreducible(e, epos))[1], ow.gradient_laplacian(e, ocfg0.make_irreducible(e, epos))[1])) < 1e-9
+    dev = wf.fused_device()
+    gauss, unif = dev.philox_tapes(31, 1, W)
+    acc, en, rec = dev.vmc_sweeps(0.3, 1, seed=31, energy=False, record=True)
+    record = []
+    _, ocfg = ovmc.vmc_worker(mol, ow, OpenConfigs(start.copy()), 0.3, gauss, unif, with_energy=False, record=record)
+    assert np.array_equal(rec[0], np.asarray(record))
+    assert note("jastrow13_fused_sweep", np.max(np.abs(dev.configs() - ocfg.configs))) < 1e-10
