@@ -86,7 +86,7 @@ struct pqa_handle {
   long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
   long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
   int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
-  int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum (0: 4 up to 8192 walkers)
+  int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
   int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
   int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
@@ -1796,7 +1796,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     }
   } else {
     {  // four waves per walker while the launch is too small to fill the chip with one
-      const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W <= 8192);
+      const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
       const size_t st_ = (size_t)(h->cplx ? 2 : 1) * lds_det(h, 5);
       const int str_ = (int)(st_ / sizeof(double));
 #define PQA_KC(CXF, NV) hipLaunchKernelGGL((k_kinetic_coulomb<CXF, NV>), dim3((unsigned)W), dim3(64 * NV), NV * st_, h->stream, h->S, h->st, h->js, \
@@ -1893,8 +1893,9 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
           TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
     }
     // wave-per-walker accumulation (complex determinants, several determinants, three-body factor): four waves share a walker's
-    // points while the launch is too small to fill the chip with one
-    const bool acc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W <= 8192);
+    // points while the launch is too small to fill the chip with one (measured after the three-body / determinant-pass fixes: C4
+    // +7 % at 2048 walkers, even at 4096, -7 % at 8192; the 32-electron twisted cell +1 % at 1024, -1.5 % at 2048, -6 % at 8192)
+    const bool acc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
 #define PQA_ECP_ACC(PB, CXF, SC) do { const size_t st_ = (size_t)(SC) * lds_det(h, 1); const int str_ = (int)(st_ / sizeof(double)); \
       if (acc4) hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 4>), dim3((unsigned)W), dim3(256), 4 * st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
                                    (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); \

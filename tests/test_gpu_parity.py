@@ -475,7 +475,7 @@ def test_ecp_second_generation_passes_agree_with_the_first(var, values, monkeypa
 
 
 def test_four_waves_per_walker_in_the_wave_per_walker_energy_kernels(monkeypatch):
-    """k_ecp_accum / k_kinetic_coulomb with four waves per walker (default up to 8192 walkers) against one wave per walker:
+    """k_ecp_accum / k_kinetic_coulomb with four waves per walker (default while walkers x electrons <= 32768) against one wave per walker:
     multi-determinant x three-body wave function, same points, sums added in another order."""
     import pyqmc_amd as pa
 
