@@ -1789,7 +1789,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     TRY(check_launch(h, "k_kinetic_lw"));
     // the ECP kernels read walker-major coordinates; the inverse only when the wave-per-walker accumulation runs (or the
     // caller works on the walker-major state next: the DMC step's T-moves) — the thread-per-point kernel takes the planes
-    soa_T = !aos_T_needed && !h->cplx && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_soa_t;
+    soa_T = !aos_T_needed && (!h->cplx || h->ecp_point_lw) && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_soa_t;
     if (h->necp > 0) {
       if (soa_T) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }
       else TRY(lw_to_aos(h, false));
@@ -1868,7 +1868,7 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
       TRY(ensure(h, h->b_ewgt[s], n * sizeof(double)));
       TRY(ensure(h, h->b_epte[s], n * sizeof(int)));
       TRY(ensure(h, h->b_eptw[s], n * sizeof(int)));
-      TRY(ensure(h, h->b_econ[s], n * sizeof(double)));
+      TRY(ensure(h, h->b_econ[s], (h->cplx ? 2 : 1) * n * sizeof(double)));
       TRY(ensure(h, h->b_eu0[s], n * sizeof(double)));
       B.ptw[s] = (int*)h->b_eptw[s].p;
       B.u0[s] = (double*)h->b_eu0[s].p;
@@ -1901,7 +1901,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
                                    (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); \
       else hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 1>), dim3((unsigned)W), dim3(64), st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
                               (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); } while (0)
-    if (h->cplx) {  // complex determinants: wave-per-walker accumulation in complex arithmetic
+    const bool cx_points = h->cplx && soa_current && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_point_lw;  // thread per point on the complex planes
+    if (h->cplx && !cx_points) {  // complex determinants: wave-per-walker accumulation in complex arithmetic
       if (h->S.pbc) PQA_ECP_ACC(true, true, 2); else PQA_ECP_ACC(false, true, 2);
     } else
     if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
@@ -1913,6 +1914,14 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
         const long sw = soa_T ? 1 : n_s * n_s, si = soa_T ? n_s * W : n_s, sk = soa_T ? W : 1;
         // (the planes are the live state whenever this evaluation follows a lane-per-walker sweep, also where the walker-major copy
         // was refreshed for the caller's next step — the DMC loop's T-moves)
+        if (cx_points) {
+          if (h->S.pbc)
+            hipLaunchKernelGGL((k_ecp_point_lw<true, true>), g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
+                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
+          else
+            hipLaunchKernelGGL((k_ecp_point_lw<false, true>), g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
+                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
+        } else
         if (soa_current && !h->cplx && h->ecp_point_lw) {
           if (h->S.pbc)
             hipLaunchKernelGGL(k_ecp_point_lw<true>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
@@ -1929,7 +1938,8 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
                              (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
       }
       hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
-                         (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p);
+                         (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p, cx_points ? std::max<long>(tot[0], 1) : 0L,
+                         cx_points ? std::max<long>(tot[1], 1) : 0L);
     } else {
       if (h->S.pbc) PQA_ECP_ACC(true, false, 1); else PQA_ECP_ACC(false, false, 1);
     }

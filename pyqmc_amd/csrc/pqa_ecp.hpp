@@ -266,7 +266,10 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, Jastro
 // every coefficient (indexed by the partner's spin: a vector load inside the innermost loop): ~270 us per wave for ~20 us of
 // arithmetic.  Here the inverse column and the orbital row are fetched 16 slots at a time before any product, and the Jastrow
 // exponent comes from jas_eval_lane on the SoA coordinate planes.  Same operations in the same order as k_ecp_point.
-template <bool PBC>
+// CX: complex determinants (inverse planes [row][2 k + re|im][W], orbital rows [re block | im block]); the imaginary parts of the
+// contributions go to contrib[npts + p].  (k_ecp_accum walked a walker's points one after the other on one wave, 16 of its lanes
+// busy in the 16-electron dots: 0.99 ms per evaluation of the twisted 32-electron cell at 8 192 walkers, 11 % of its step.)
+template <bool PBC, bool CX = false>
 __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBuf B, int s, int has_slater, int has_jastrow,
                                                       const double* __restrict__ mo, long npts, long W, double* __restrict__ contrib) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
@@ -274,10 +277,41 @@ __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBu
   const int e = B.pte[s][p];
   const long w = B.ptw[s][p];
   const int n = s ? S.ndn : S.nup, i = e - s * S.nup, nmo = S.nmo[s];
-  double ratio = 1.0;
+  double ratio = 1.0, ratio_im = 0.0;
   if (has_slater) {
-    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
     const double* row = mo + (size_t)p * nmo;
+    if (CX) {
+      const double* Ti = L.Tt[s] + (size_t)i * 2 * n * W + w;
+      const int* occ = S.det_occ[s];
+      const int nh = nmo / 2;
+      double rr = 0.0, ri = 0.0;
+      const bool lines = S.occ_ident[s] && ((n | nh) & 7) == 0;  // whole 64-byte lines of the point's row (see k_kinetic_lw)
+      for (int k0 = 0; k0 < n; k0 += 8) {
+        double tr[8], ti[8], a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = (k0 + u < n) ? k0 + u : n - 1;
+          tr[u] = Ti[(size_t)(2 * k) * W]; ti[u] = Ti[(size_t)(2 * k + 1) * W];
+        }
+        if (lines) {
+          const double4 al = *reinterpret_cast<const double4*>(row + k0), ah = *reinterpret_cast<const double4*>(row + k0 + 4);
+          const double4 bl = *reinterpret_cast<const double4*>(row + nh + k0), bh = *reinterpret_cast<const double4*>(row + nh + k0 + 4);
+          a[0] = al.x; a[1] = al.y; a[2] = al.z; a[3] = al.w; a[4] = ah.x; a[5] = ah.y; a[6] = ah.z; a[7] = ah.w;
+          b[0] = bl.x; b[1] = bl.y; b[2] = bl.z; b[3] = bl.w; b[4] = bh.x; b[5] = bh.y; b[6] = bh.z; b[7] = bh.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int o = occ[(k0 + u < n) ? k0 + u : n - 1];
+            a[u] = row[o]; b[u] = row[nh + o];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < n) { rr += a[u] * tr[u] - b[u] * ti[u]; ri += a[u] * ti[u] + b[u] * tr[u]; }
+      }
+      ratio = rr; ratio_im = ri;
+    } else {
+    const double* Ti = L.Tt[s] + (size_t)i * n * W + w;
     double r = 0.0;
     if (S.occ_ident[s] && (n % 16) == 0 && (nmo % 4) == 0) {
       for (int k0 = 0; k0 < n; k0 += 16) {
@@ -297,11 +331,14 @@ __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBu
       for (int k = 0; k < n; ++k) r += row[occ[k]] * Ti[(size_t)k * W];
     }
     ratio = r;
+    }
   }
   if (has_jastrow) {
     double U, g[3], lp, ee, ei;
     jas_eval_lane<0, PBC>(S, L.xt, W, w, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], 1, 0, 1, U, g, lp, ee, ei);
-    ratio *= exp(U - B.u0[s][p]);  // U_e(new) - U_e(old); the old-position sum comes from the fill pass
+    const double ej = exp(U - B.u0[s][p]);  // U_e(new) - U_e(old); the old-position sum comes from the fill pass
+    ratio *= ej; ratio_im *= ej;
   }
   contrib[p] = ratio * B.wgt[s][p];
+  if (CX) contrib[npts + p] = ratio_im * B.wgt[s][p];
 }

@@ -672,14 +672,16 @@ __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, Jas
 }
 
 // ecp[w] = local + sum of the walker's point contributions, spin up then spin down, in slot order
+// n_up / n_dn > 0: complex contributions, imaginary parts at c[n + p]; their sum goes to ecp[W + w]
 __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restrict__ c_up, const double* __restrict__ c_dn, long W,
-                                                 double* __restrict__ ecp) {
+                                                 double* __restrict__ ecp, long n_up = 0, long n_dn = 0) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
-  double tot = 0.0;
-  for (long p = B.off[w]; p < B.off[w + 1]; ++p) tot += c_up[p];
-  for (long p = B.off[(W + 1) + w]; p < B.off[(W + 1) + w + 1]; ++p) tot += c_dn[p];
+  double tot = 0.0, tim = 0.0;
+  for (long p = B.off[w]; p < B.off[w + 1]; ++p) { tot += c_up[p]; if (n_up > 0) tim += c_up[n_up + p]; }
+  for (long p = B.off[(W + 1) + w]; p < B.off[(W + 1) + w + 1]; ++p) { tot += c_dn[p]; if (n_dn > 0) tim += c_dn[n_dn + p]; }
   ecp[w] = B.local[w] + tot;
+  if (n_up > 0 || n_dn > 0) ecp[W + w] = tim;
 }
 
 // ---------------------------------------------------------------- T-move candidates (DMC)

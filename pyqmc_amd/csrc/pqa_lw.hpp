@@ -256,6 +256,22 @@ __device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, 
         r0 += a0.z * t2; r1 += a1.z * t2; r2 += a2.z * t2; r3 += a3.z * t2;
         r0 += a0.w * t3; r1 += a1.w * t3; r2 += a2.w * t3; r3 += a3.w * t3;
       }
+    } else if (CX && S.occ_ident[s] && ((jb | (je - jb) | nh) & 3) == 0) {
+      // complex rows, 4 slots (32 bytes of the real and of the imaginary block per component) at a time: element by element every
+      // 8-byte load of the wave is 64 line requests (see k_kinetic_lw)
+      for (int j = jb; j < je; j += 4) {
+        double tr[4], ti[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { tr[u] = Ti[(size_t)(2 * (j + u)) * W]; ti[u] = Ti[(size_t)(2 * (j + u) + 1) * W]; }
+        const double4 a0 = *reinterpret_cast<const double4*>(row + j), b0 = *reinterpret_cast<const double4*>(row + nh + j);
+        const double4 a1 = *reinterpret_cast<const double4*>(row + nmo + j), b1 = *reinterpret_cast<const double4*>(row + nmo + nh + j);
+        const double4 a2 = *reinterpret_cast<const double4*>(row + 2 * nmo + j), b2 = *reinterpret_cast<const double4*>(row + 2 * nmo + nh + j);
+        const double4 a3 = *reinterpret_cast<const double4*>(row + 3 * nmo + j), b3 = *reinterpret_cast<const double4*>(row + 3 * nmo + nh + j);
+#define PQA_CXS(U, X) do { r0 += a0.X * tr[U] - b0.X * ti[U]; q0 += a0.X * ti[U] + b0.X * tr[U]; r1 += a1.X * tr[U] - b1.X * ti[U]; q1 += a1.X * ti[U] + b1.X * tr[U]; \
+          r2 += a2.X * tr[U] - b2.X * ti[U]; q2 += a2.X * ti[U] + b2.X * tr[U]; r3 += a3.X * tr[U] - b3.X * ti[U]; q3 += a3.X * ti[U] + b3.X * tr[U]; } while (0)
+        PQA_CXS(0, x); PQA_CXS(1, y); PQA_CXS(2, z); PQA_CXS(3, w);
+#undef PQA_CXS
+      }
     } else {
 #pragma unroll 4
       for (int j = jb; j < je; ++j) {
@@ -1143,6 +1159,46 @@ __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwStat
           r[c] += lo.x * t[0]; r[c] += lo.y * t[1]; r[c] += lo.z * t[2]; r[c] += lo.w * t[3];
           r[c] += hi.x * t[4]; r[c] += hi.y * t[5]; r[c] += hi.z * t[6]; r[c] += hi.w * t[7];
         }
+      }
+    } else
+    if (CX && S.occ_ident[s] && ((n | nh) & 7) == 0) {
+      // complex rows, ground-state occupation: whole 64-byte lines of the lane's own row — per component the real and the
+      // imaginary block of 8 slots are one line each (two adjacent 32-byte loads).  Element by element every 8-byte load of the
+      // wave touched 64 different lines: 12 k line requests per wave, and the kernel was bound by them (0.72 ms per evaluation of
+      // the twisted 32-electron cell at 8 192 walkers against 0.30 for the real 64-electron cell with as many threads).
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        double tr[8], ti[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { tr[u] = Ti[(size_t)(2 * (j0 + u)) * W]; ti[u] = Ti[(size_t)(2 * (j0 + u) + 1) * W]; }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const double4 al = *reinterpret_cast<const double4*>(row + c * nmo + j0), ah = *reinterpret_cast<const double4*>(row + c * nmo + j0 + 4);
+          const double4 bl = *reinterpret_cast<const double4*>(row + c * nmo + nh + j0), bh = *reinterpret_cast<const double4*>(row + c * nmo + nh + j0 + 4);
+          const double a[8] = {al.x, al.y, al.z, al.w, ah.x, ah.y, ah.z, ah.w}, b[8] = {bl.x, bl.y, bl.z, bl.w, bh.x, bh.y, bh.z, bh.w};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { r[c] += a[u] * tr[u] - b[u] * ti[u]; q[c] += a[u] * ti[u] + b[u] * tr[u]; }
+        }
+      }
+    } else
+    if (CX) {
+      // four slots' worth of loads (2 inverse planes + 10 row elements each) in flight before the first product: one slot at a time
+      // every iteration waited for its own loads — 0.76 ms per evaluation of the twisted 32-electron cell at 8 192 walkers
+      for (int j0 = 0; j0 < n; j0 += 4) {
+        double tr[4], ti[4], a[4][5], b[4][5];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = (j0 + u < n) ? j0 + u : n - 1;
+          const double* cj = row + occ[j];
+          tr[u] = Ti[(size_t)(2 * j) * W]; ti[u] = Ti[(size_t)(2 * j + 1) * W];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) { a[u][c] = cj[c * nmo]; b[u][c] = cj[c * nmo + nh]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u < n) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) { r[c] += a[u][c] * tr[u] - b[u][c] * ti[u]; q[c] += a[u][c] * ti[u] + b[u][c] * tr[u]; }
+          }
       }
     } else
     for (int j = 0; j < n; ++j) {

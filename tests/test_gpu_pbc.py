@@ -750,3 +750,26 @@ def test_event_brackets_do_not_change_the_sweep(periodic, monkeypatch):
             dev.profile_enable(False)
         out[prof] = (np.array(acc), np.array(en))
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+
+
+@pytest.mark.gpu
+def test_complex_ecp_points_agree_with_the_wave_per_walker_accumulation(monkeypatch):
+    """Twisted cell, fused sweep energies: the thread-per-point ECP kernel on the complex planes (k_ecp_point_lw<.., CX>, default)
+    against the wave-per-walker accumulation it replaces there (PQA_ECP_POINT_LW=0): same points, complex sums in another order."""
+    import pyqmc_amd as pa
+    from pyqmc_amd import pbc, systems
+
+    sup = pbc.get_supercell(systems.diamond_primitive(), np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
+    mf = pbc.random_kmf(sup, complex_coeff=True, twist=(0.25, 0.1, -0.3))
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PQA_ECP_POINT_LW", flag)
+        wf = pa.generate_wf(sup, mf)
+        wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = helpers.pbc_jastrow_coeffs(sup)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(sup, 500, rng=np.random.default_rng(2)))
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=19, energy=True)
+        out.append((dev.configs(), np.asarray(en)))
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.max(np.abs(out[0][1][:, 3])) > 0 and np.max(np.abs(out[0][1].imag)) > 0  # there is an ECP term, with an imaginary part
+    assert note("complex_ecp_point_vs_accum", np.max(np.abs(out[0][1] - out[1][1]) / np.maximum(1.0, np.abs(out[1][1])))) < 1e-12
