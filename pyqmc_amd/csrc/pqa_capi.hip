@@ -2549,16 +2549,23 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
           }
         // ratios of all candidates against the state before the first T-move: one thread per candidate (k_tm_ratio)
         const bool pre = h->ndet == 1 && !h->has_j3 && !h->cplx && h->tm_pre;
+        // U_e of every electron at its current position: from the second step of a call on, the energy evaluation that closed the
+        // previous step left exactly that ([N][W], k_kinetic_lw) — the walkers have not moved since
+        const double* d_uold = nullptr;
         if (pre && h->has_jastrow) {
-          TRY(ensure(h, h->b_tmuold, (size_t)NW * sizeof(double)));
-          hipLaunchKernelGGL(k_tm_uold, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
+          if (lw && step > 0 && h->has_j2 && !h->has_j3) d_uold = (const double*)h->b_kpart.p + (size_t)4 * NW;
+          else {
+            TRY(ensure(h, h->b_tmuold, (size_t)NW * sizeof(double)));
+            hipLaunchKernelGGL(k_tm_uold, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
+            d_uold = (const double*)h->b_tmuold.p;
+          }
         }
         if (pre)
           for (int s = 0; s < 2; ++s) {
             if (cnt_s[s] == 0) continue;
             const dim3 g((unsigned)((cnt_s[s] + 255) / 256));
             hipLaunchKernelGGL(k_tm_ratio, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater, (int)h->has_jastrow,
-                               (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, (const double*)h->b_tmuold.p);
+                               (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, d_uold);
           }
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
         if (h->cplx) hipLaunchKernelGGL(k_tm_walker<true>, dim3((unsigned)W), dim3(64), 2 * lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
