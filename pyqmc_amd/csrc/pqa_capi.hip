@@ -87,6 +87,7 @@ struct pqa_handle {
   long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
   int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
   int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
+  int jas_fold_allowed = 1;  // PQA_JAS_FOLD=0: Voronoi reduction in every periodic Jastrow pair (A/B, bitwise check)
   int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
   int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
@@ -517,6 +518,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* es = getenv("PQA_ECP_SOA_T")) h->ecp_soa_t = atoi(es);
   if (const char* ep = getenv("PQA_ECP_POINT_LW")) h->ecp_point_lw = atoi(ep);
   if (const char* el = getenv("PQA_ECP_LDS")) h->ecp_lds = atoi(el);
+  if (const char* jf = getenv("PQA_JAS_FOLD")) h->jas_fold_allowed = atoi(jf);
   if (const char* ea = getenv("PQA_ECP_ACC_WAVES")) h->ecp_acc_waves = atoi(ea);
   if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
   if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
@@ -555,6 +557,15 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     P.linv[0] = (a[4] * a[8] - a[5] * a[7]) * id; P.linv[1] = (a[2] * a[7] - a[1] * a[8]) * id; P.linv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
     P.linv[3] = (a[5] * a[6] - a[3] * a[8]) * id; P.linv[4] = (a[0] * a[8] - a[2] * a[6]) * id; P.linv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
     P.linv[6] = (a[3] * a[7] - a[4] * a[6]) * id; P.linv[7] = (a[1] * a[6] - a[0] * a[7]) * id; P.linv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    {  // inradius of {frac in [-1/2, 1/2)^3}: the face frac_c = 1/2 is 1 / (2 |column c of linv|) away from the origin
+      double rho = 1e300;
+      for (int c = 0; c < 3; ++c) rho = std::min(rho, 0.5 / sqrt(P.linv[c] * P.linv[c] + P.linv[3 + c] * P.linv[3 + c] + P.linv[6 + c] * P.linv[6 + c]));
+      double rmax = 0.0;
+      if (sys->na > 0) rmax = std::max(rmax, sys->rcut_a);
+      if (sys->nb > 0) rmax = std::max(rmax, sys->rcut_b);
+      if (sys->na3 > 0 && sys->nb3 > 0) rmax = std::max(rmax, std::max(sys->rcut_a3, sys->rcut_b3));
+      P.jas_fold = (h->jas_fold_allowed && rmax <= rho * (1.0 + 1e-12)) ? 1 : 0;
+    }
   }
   double* tmp_d; int* tmp_i;
   TRY(upload_table(h, sys->atom_xyz, (size_t)h->natom * 3, &tmp_d)); S.atom_xyz = tmp_d;

@@ -18,6 +18,9 @@ struct PbcDev {
   // general cells: the Voronoi-relevant lattice vectors (one of each +- pair, at most 7 in three dimensions) and |v|^2 / 2
   int nvor;
   double vor[7][3], vorh[7];
+  // 1: every Jastrow cut-off is at most the inradius of the cell-centred parallelepiped {frac in [-1/2, 1/2)^3}: a Jastrow pair then
+  // never needs the reduction above — inside the cut-off the folded vector IS the minimal image (see min_image_j)
+  int jas_fold;
   // periodic Gamma-point orbitals (numba/pbcgto.py:99-653): AO = sum over the cell translations Ls[j], j < num_Ls[atom],
   // skipping images with r^2 > atom_cut[atom] or r^2 > shell_cut[shell]
   const double* Ls;
@@ -112,7 +115,8 @@ struct SysDev {
 // sweeps over the host-made list (create: voronoi_vectors) and one that changes nothing, ~150 instructions where the
 // 27-candidate search took ~500 in every periodic Jastrow / ECP / Ewald pair.  Same distances (both are exact minima; at a
 // tie on the cell boundary the representative may differ).
-__device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& dy, double& dz) {
+template <bool JAS>
+__device__ __forceinline__ void min_image_impl(const SysDev& S, double& dx, double& dy, double& dz) {
   if (S.pbc == 0) return;
   double f0 = dx * S.pb->linv[0] + dy * S.pb->linv[3] + dz * S.pb->linv[6];
   double f1 = dx * S.pb->linv[1] + dy * S.pb->linv[4] + dz * S.pb->linv[7];
@@ -121,7 +125,7 @@ __device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& d
   dx = f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6];
   dy = f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7];
   dz = f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8];
-  if (S.pbc == 2) {
+  if (S.pbc == 2 && !(JAS && S.pb->jas_fold)) {
     // table once into (scalar) registers: unused entries are zero vectors with h = 1, which never trigger
     double vx[7], vy[7], vz[7], hh[7];
 #pragma unroll
@@ -150,6 +154,15 @@ __device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& d
     }
   }
 }
+
+__device__ __forceinline__ void min_image(const SysDev& S, double& dx, double& dy, double& dz) { min_image_impl<false>(S, dx, dy, dz); }
+// For the pair functions of the Jastrow factor, which vanish from their cut-off r_c on.  Where r_c <= rho, the inradius of the
+// parallelepiped the fold maps into (pyqmc's periodic default is r_c = rho: wftools.py generate_jastrow), the Voronoi
+// reduction is never needed: a minimal image shorter than rho lies inside the parallelepiped, so the fold — the unique
+// representative in there — is that image, unchanged by the reduction (bitwise the same vector); and a folded vector of
+// length >= r_c means the minimal image is >= r_c as well (were it shorter it would be the folded vector), so the pair is
+// skipped either way.  ~150 of the ~250 instructions of every periodic Jastrow pair in the general (fcc-type) cells.
+__device__ __forceinline__ void min_image_j(const SysDev& S, double& dx, double& dy, double& dz) { min_image_impl<true>(S, dx, dy, dz); }
 
 // Position -> inside the cell (enforce_pbc, pbc/pbc.py:37-48: fractional coordinates split by divmod(., 1)); dw receives
 // the integer wrap that was removed.

@@ -213,7 +213,7 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
     const int edown = e >= S.nup;
     const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
     auto norm = [&](double dx, double dy, double dz) {
-      min_image(S, dx, dy, dz);
+      min_image_j(S, dx, dy, dz);
       return sqrt(dx * dx + dy * dy + dz * dz);
     };
     auto u_b = [&](double rn, int col) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBu
   for (int j = 0; j < S.nelec; ++j) {
     if (j == e) continue;
     double dx = ox - xw[3 * j], dy = oy - xw[3 * j + 1], dz = oz - xw[3 * j + 2];
-    min_image(S, dx, dy, dz);
+    min_image_j(S, dx, dy, dz);
     const double rn = sqrt(dx * dx + dy * dy + dz * dz);
     if (rn < S.rcut_b) {
       const RadShared sh = rad_shared<0>(rn, irb);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBu
   }
   for (int I = 0; I < S.natom; ++I) {
     double dx = ox - S.atom_xyz[3 * I], dy = oy - S.atom_xyz[3 * I + 1], dz = oz - S.atom_xyz[3 * I + 2];
-    min_image(S, dx, dy, dz);
+    min_image_j(S, dx, dy, dz);
     const double rn = sqrt(dx * dx + dy * dy + dz * dz);
     if (rn < S.rcut_a) {
       const RadShared sh = rad_shared<0>(rn, ira);

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, Jas
     const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
     double du = 0.0;
     auto norm = [&](double dx, double dy, double dz) {
-      if (PBC) min_image(S, dx, dy, dz);
+      if (PBC) min_image_j(S, dx, dy, dz);
       return sqrt(dx * dx + dy * dy + dz * dz);
     };
     for (int j = 0; j < S.nelec; ++j) {

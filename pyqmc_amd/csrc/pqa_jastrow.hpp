@@ -114,7 +114,7 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
     // coefficients with independent loads.  Same sums in the same order.
     const int I0 = lane < S.natom ? lane : 0;
     double dx = rx - S.atom_xyz[3 * I0], dy = ry - S.atom_xyz[3 * I0 + 1], dz = rz - S.atom_xyz[3 * I0 + 2];
-    min_image(S, dx, dy, dz);
+    min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (lane < S.natom) { double* row = scr + (size_t)lane * str; row[0] = dx; row[1] = dy; row[2] = dz; }
     double av[PQA_MAXBAS3], ag[PQA_MAXBAS3], al[PQA_MAXBAS3];
@@ -149,7 +149,7 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
   } else
   for (int I = lane; I < S.natom; I += 64) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
-    min_image(S, dx, dy, dz);
+    min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     double* row = scr + (size_t)I * str;
     row[0] = dx; row[1] = dy; row[2] = dz;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void jas3_eval(const SysDev& S, const double* __restr
     if (j == e) continue;
     const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
     double dx = rx - jx, dy = ry - jy, dz = rz - jz;
-    min_image(S, dx, dy, dz);
+    min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (!(r < S.rcut_b3)) continue;
     double bv[PQA_MAXBAS3], bg[PQA_MAXBAS3], bl[PQA_MAXBAS3];
@@ -243,7 +243,7 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
   for (int j = lane; j < S.nelec; j += 64) {
     if (j == e) continue;
     double dx = rx - xw[3 * j], dy = ry - xw[3 * j + 1], dz = rz - xw[3 * j + 2];
-    if (PBC) min_image(S, dx, dy, dz);
+    if (PBC) min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_b) {
       const RadShared sh = rad_shared<MODE>(r, irb);
@@ -262,7 +262,7 @@ __device__ __forceinline__ void jas_eval(const SysDev& S, const double* __restri
   }
   for (int I = lane; I < S.natom; I += 64) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
-    if (PBC) min_image(S, dx, dy, dz);
+    if (PBC) min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (r < S.rcut_a) {
       const RadShared sh = rad_shared<MODE>(r, ira);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
       double sum[2] = {0.0, 0.0};
       for (int e = 0; e < S.nelec; ++e) {
         double dx = xw[3 * e] - ax, dy = xw[3 * e + 1] - ay, dz = xw[3 * e + 2] - az;
-        min_image(S, dx, dy, dz);
+        min_image_j(S, dx, dy, dz);
         const double r = sqrt(dx * dx + dy * dy + dz * dz);
         if (r < S.rcut_a) sum[e >= S.nup] += jas_value1(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, r);
       }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
     const double ix = xw[3 * i], iy = xw[3 * i + 1], iz = xw[3 * i + 2];
     for (int j = i + 1 + lane; j < S.nelec; j += 64) {
       double dx = ix - xw[3 * j], dy = iy - xw[3 * j + 1], dz = iz - xw[3 * j + 2];
-      min_image(S, dx, dy, dz);
+      min_image_j(S, dx, dy, dz);
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
       if (r < S.rcut_b) {
         const int t = (i >= S.nup) + (j >= S.nup);  // 0 upup, 1 updown, 2 downdown

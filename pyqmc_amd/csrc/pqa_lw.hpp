@@ -121,7 +121,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
       const int j = jb + u * dj;
       if (j >= S.nelec || j == e) continue;
       double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
-      if (PBC) min_image(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
+      if (PBC) min_image_j(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
       if (MODE == 2 && j > e) see += fast_rcp(r);
       if (has_jastrow && r < S.rcut_b) {
@@ -162,7 +162,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 #pragma unroll
       for (int k = 0; k < NF; ++k) ac[k] = (has_jastrow && k < S.na) ? S.acoeff[(I * S.na + k) * 2 + edown] : 0.0;
     }
-    if (PBC) min_image(S, dx, dy, dz);
+    if (PBC) min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (MODE == 2) sei -= S.atom_charge[I] * fast_rcp(r);
     if (has_jastrow && r < S.rcut_a) {
@@ -708,7 +708,7 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
     const int j = g + m * G;
     if (j >= S.nelec || j == e) continue;
     double dx = rx - pcx[m], dy = ry - pcy[m], dz = rz - pcz[m];
-    if (PBC) min_image(S, dx, dy, dz);
+    if (PBC) min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (has_jastrow && r < S.rcut_b) {
       const RadShared sh = rad_shared<1>(r, irb);
@@ -732,7 +732,7 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
     const int I = g + m * G;
     if (I >= S.natom) continue;
     double dx = rx - atx[m], dy = ry - aty[m], dz = rz - atz[m];
-    if (PBC) min_image(S, dx, dy, dz);
+    if (PBC) min_image_j(S, dx, dy, dz);
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
     if (has_jastrow && r < S.rcut_a) {
       const RadShared sh = rad_shared<1>(r, ira);

@@ -773,3 +773,30 @@ def test_complex_ecp_points_agree_with_the_wave_per_walker_accumulation(monkeypa
     assert np.array_equal(out[0][0], out[1][0])
     assert np.max(np.abs(out[0][1][:, 3])) > 0 and np.max(np.abs(out[0][1].imag)) > 0  # there is an ECP term, with an imaginary part
     assert note("complex_ecp_point_vs_accum", np.max(np.abs(out[0][1] - out[1][1]) / np.maximum(1.0, np.abs(out[1][1])))) < 1e-12
+
+
+@pytest.mark.gpu
+def test_fold_only_minimal_image_in_the_jastrow_pairs_is_bitwise_the_full_reduction(monkeypatch):
+    """General (fcc-type) cell with the Jastrow cut-offs at the inradius of the fold's parallelepiped (pyqmc's periodic default):
+    the pair loops skip the Voronoi reduction (min_image_j).  Inside the cut-off the folded vector is the minimal image and
+    outside it the pair does not contribute either way, so walkers, log-values, energies and DMC weights must equal the
+    PQA_JAS_FOLD=0 run bit for bit."""
+    import pyqmc_amd as pa
+    from pyqmc_amd import pbc, systems
+
+    sup = pbc.get_supercell(systems.diamond_primitive(), 2.0 * np.eye(3))
+    mf = pbc.random_kmf(sup)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("PQA_JAS_FOLD", flag)
+        wf = pa.generate_wf(sup, mf)
+        wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = helpers.pbc_jastrow_coeffs(sup)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(sup, 600, rng=np.random.default_rng(12)))
+        acc, en, _ = dev.vmc_sweeps(0.3, 2, seed=23, energy=True)
+        w = np.ones(600)
+        et = float(np.real(en[-1][5]))
+        avg, dacc = dev.dmc_steps(0.02, 2, w, 10.0, et, et, seed=5)
+        out.append((dev.configs(), dev.value()[1], np.asarray(en), avg.copy(), dacc.copy(), w.copy()))
+    for p, q in zip(*out):
+        assert np.array_equal(p, q)
