@@ -22,7 +22,10 @@
 // is per lane and the exp sequence is only saved when EVERY lane of the wave skips.
 //  * open systems (-DPQA_PRIM_SCREEN=1, off): the 64 points of a wave are 64 different walkers, some lane is nearly always
 //    close, and the compare + branch cost more than the rare skip saves (round 2, tools/scratch/ab_screen.sh: k_orb<5>
-//    136.7 -> 141.4 us per 65536 points).
+//    136.7 -> 141.4 us per 65536 points).  Round 3 tried it on the values-only launches with the ECP points listed atom by atom
+//    (every tile within a few bohr of one atom, so distant atoms' tight primitives drop out for the whole wave): 826 -> 968 us
+//    per launch of 1.2 M points — the branch per primitive breaks up the interleaved exp sequences of neighbouring primitives,
+//    which costs more than the skipped ones save (walker-major points with the test: 1 035 us).
 //  * periodic cells (always on, SCREEN template argument): every lane walks the images of an atom NEAREST FIRST, so from the
 //    second image on all lanes sit at r^2 >~ (half the cell)^2 and the tight primitives of a contracted shell drop out for
 //    the whole wave.

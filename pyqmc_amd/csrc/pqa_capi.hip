@@ -88,6 +88,7 @@ struct pqa_handle {
   int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
   int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
   int jas_fold_allowed = 1;  // PQA_JAS_FOLD=0: Voronoi reduction in every periodic Jastrow pair (A/B, bitwise check)
+  int ecp_atom_major = 1;  // PQA_ECP_ATOM_MAJOR=0: walker-major ECP point lists in periodic cells too (A/B)
   int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
   int ecp_nchan = 0, ecp_nterm = 0;
   long wrap_W = 0;
@@ -519,6 +520,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* ep = getenv("PQA_ECP_POINT_LW")) h->ecp_point_lw = atoi(ep);
   if (const char* el = getenv("PQA_ECP_LDS")) h->ecp_lds = atoi(el);
   if (const char* jf = getenv("PQA_JAS_FOLD")) h->jas_fold_allowed = atoi(jf);
+  if (const char* am = getenv("PQA_ECP_ATOM_MAJOR")) h->ecp_atom_major = atoi(am);
   if (const char* ea = getenv("PQA_ECP_ACC_WAVES")) h->ecp_acc_waves = atoi(ea);
   if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
   if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
@@ -1846,17 +1848,21 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     }
     B.quad = h->d_quad; B.seed = seed; B.step = step; B.threshold = threshold;
     TRY(ensure(h, h->b_elocal, W * sizeof(double)));
-    TRY(ensure(h, h->b_ecnt, 2 * W * sizeof(int)));
-    TRY(ensure(h, h->b_eoff, 2 * (W + 1) * sizeof(long)));
+    // second-generation list passes (pqa_ecp.hpp): tables in LDS, four walkers per block, ATOM-major point lists
+    const size_t tab_b = ecp_tab_bytes(h->necp, h->ecp_nchan, h->ecp_nterm);
+    const bool ecp_t = h->ecp_lds && h->necp <= 64 && (long)h->necp * ((h->N + 63) / 64) <= 64 && tab_b <= 32768;
+    // (atom-major lists where the orbital kernel gains from them: periodic cells, whose per-lane image walks then have similar
+    // lengths within a tile — 2x2x2 diamond VMC +3 % at 32768 walkers; open systems gain nothing and pay a longer scan and sum)
+    const long nseg = (ecp_t && h->ecp_atom_major && h->S.pbc) ? h->necp : 1, nsw = nseg * W;
+    B.nseg = (int)nseg;
+    TRY(ensure(h, h->b_ecnt, 2 * nsw * sizeof(int)));
+    TRY(ensure(h, h->b_eoff, 2 * (nsw + 1) * sizeof(long)));
     TRY(ensure(h, h->b_ecp, (h->cplx ? 2 : 1) * W * sizeof(double)));
     TRY(ensure(h, h->b_epass, (size_t)W * h->necp * ((h->N + 63) / 64) * sizeof(unsigned long long)));
     B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
     B.passbits = (unsigned long long*)h->b_epass.p;
     B.has_j2 = h->has_j2 ? 1 : 0;
     B.ue = (soa_current && h->has_j2) ? (const double*)h->b_kpart.p + (size_t)4 * h->N * W : nullptr;  // k_kinetic_lw left U_e there
-    // second-generation list passes (pqa_ecp.hpp): tables in LDS, four walkers per block
-    const size_t tab_b = ecp_tab_bytes(h->necp, h->ecp_nchan, h->ecp_nterm);
-    const bool ecp_t = h->ecp_lds && h->necp <= 64 && (long)h->necp * ((h->N + 63) / 64) <= 64 && tab_b <= 32768;
     const dim3 g_t((unsigned)((W + PQA_ECP_WB - 1) / PQA_ECP_WB)), b_t(64 * PQA_ECP_WB);
     if (ecp_t) {
       if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count_t<true>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
@@ -1866,12 +1872,12 @@ static int energy_dev(pqa_handle* h, double threshold, const double* rot, const 
     else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers)
     TRY(ensure(h, h->b_tmmarks, 4 * sizeof(long)));
-    TRY(scan_ints(h, (const int*)B.cnt, B.off, W, W, (long*)h->b_tmmarks.p));
-    TRY(scan_ints(h, (const int*)B.cnt + W, B.off + (W + 1), W, W, (long*)h->b_tmmarks.p + 2));
+    TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
+    TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
     TRY(check_launch(h, "k_ecp_count/k_scan2"));
     long tot[2];
-    TRY(copy_in(h, &tot[0], B.off + W, sizeof(long)));
-    TRY(copy_out(h, &tot[1], B.off + (W + 1) + W, sizeof(long)));
+    TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
+    TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
     h->last_ecp_points = tot[0] + tot[1];
     for (int s = 0; s < 2; ++s) {
       const size_t n = (size_t)std::max<long>(tot[s], 1);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, Jastr
   if (lane < S.necp) pb[lane] = 0ull;
   __syncthreads();
   double loc = 0.0;
-  int c_up = 0, c_dn = 0;
+  int c_up = 0, c_dn = 0, k_up = 0, k_dn = 0;  // k_*: entries of ECP atom `lane` (atom-major lists)
   for (int eb = 0; eb < neb; ++eb) {
     const int e = eb * 64 + lane;
     const bool live = e < S.nelec;
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, Jastr
     }
     __syncthreads();
     if (lane < S.necp) {
-      if (wlive) B.passbits[((size_t)w * S.necp + lane) * neb + eb] = pb[lane];
+      const unsigned long long mk = pb[lane];
+      if (wlive) B.passbits[((size_t)w * S.necp + lane) * neb + eb] = mk;
+      const int nu = S.nup - eb * 64;  // bits below it are spin-up electrons
+      const unsigned long long um = (nu >= 64) ? ~0ull : ((nu <= 0) ? 0ull : ((1ull << nu) - 1ull));
+      k_up += __popcll(mk & um); k_dn += __popcll(mk & ~um);
       pb[lane] = 0ull;
     }
     __syncthreads();
@@ -155,7 +159,14 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, Jastr
   loc = wave_sum(loc);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { c_up += __shfl_xor(c_up, off, 64); c_dn += __shfl_xor(c_dn, off, 64); }
-  if (lane == 0 && wlive) { B.local[w] = loc; B.cnt[w] = c_up; B.cnt[W + w] = c_dn; }
+  if (lane == 0 && wlive) B.local[w] = loc;
+  if (B.nseg > 1) {  // atom-major: points of (atom lane, walker w), spin up and spin down
+    if (lane < S.necp && wlive) {
+      const int naip = (T.ecp_chan_off[lane + 1] - T.ecp_chan_off[lane] <= 2) ? 6 : 12;
+      B.cnt[(size_t)lane * W + w] = naip * k_up;
+      B.cnt[(size_t)B.nseg * W + (size_t)lane * W + w] = naip * k_dn;
+    }
+  } else if (lane == 0 && wlive) { B.cnt[w] = c_up; B.cnt[W + w] = c_dn; }
 }
 
 // pass B: k_ecp_fill for necp * ceil(N / 64) <= 64.  Same launch shape as k_ecp_count_t.
@@ -174,7 +185,6 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, Jastro
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   const int neb = (S.nelec + 63) / 64, nq = S.necp * neb;
   unsigned long long m = (wlive && lane < nq) ? B.passbits[(size_t)w * nq + lane] : 0ull;  // the mask k_ecp_count drew
-  const long run0 = B.off[w], run1 = B.off[(W + 1) + w];
   const EcpTab T = ecp_stage(S, nchan, nterm, lds, (int)threadIdx.x, 64 * PQA_ECP_WB);
   __syncthreads();
   int* el = el_[wv];
@@ -188,8 +198,19 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, Jastro
   const int cu = __popcll(m & upmask), cd = __popcll(m & ~upmask);
   int nent, tu, td;
   const int ebase = wave_excl_scan(cu + cd, lane, nent);
-  const long ubase = run0 + wave_excl_scan(cu * naipq, lane, tu);
-  const long dbase = run1 + wave_excl_scan(cd * naipq, lane, td);
+  // first slot of this lane's (atom, electron block) word in the two spins' lists: walker-major — after the walker's earlier
+  // words; atom-major — segment (atom, walker), after the atom's earlier electron blocks
+  const int urel = wave_excl_scan(cu * naipq, lane, tu), drel = wave_excl_scan(cd * naipq, lane, td);
+  const size_t SS = (size_t)B.nseg * W + 1;
+  long ubase, dbase;
+  if (B.nseg > 1) {
+    const int first = kq * neb;  // the atom's first word
+    ubase = B.off[(size_t)kq * W + w] + (urel - __shfl(urel, first, 64));
+    dbase = B.off[SS + (size_t)kq * W + w] + (drel - __shfl(drel, first, 64));
+  } else {
+    ubase = B.off[w] + urel;
+    dbase = B.off[SS + w] + drel;
+  }
   for (int base = 0; base < nent; base += 64) {
     {
       unsigned long long mm = m;

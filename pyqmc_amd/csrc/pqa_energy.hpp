@@ -261,8 +261,12 @@ struct EcpBuf {
   uint32_t step;
   double threshold;
   double* local;         // [W] sum of local channels
-  int* cnt;              // [2][W] aux points per walker per spin
-  long* off;             // [2][W+1] exclusive scan of cnt
+  int* cnt;              // [2][nseg W] aux points per (segment, walker) per spin
+  long* off;             // [2][nseg W + 1] exclusive scan of cnt
+  int nseg;              // 1: the points of a walker are contiguous; necp: ATOM-major — segment k holds the points around ECP atom k of
+                         // all walkers, walker by walker, so that a tile of the orbital kernel sits within a few bohr of ONE atom: in a
+                         // periodic cell the lanes' image walks (shell_eval_pbc: iterations = the longest list in the wave) then have
+                         // similar lengths.  A walker's sum still runs atom by atom, i.e. in the same order.
   double* pts[2];        // [npts_s][3]
   double* wgt[2];        // [npts_s]  sum_l (v_l/prob)(2l+1)P_l(cos) w_i
   int* pte[2];           // [npts_s]  electron index of the point
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
   loc = wave_sum(loc);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { c_up += __shfl_xor(c_up, off, 64); c_dn += __shfl_xor(c_dn, off, 64); }
-  if (lane == 0) { B.local[w] = loc; B.cnt[w] = c_up; B.cnt[W + w] = c_dn; }
+  if (lane == 0) { B.local[w] = loc; B.cnt[w] = c_up; B.cnt[W + w] = c_dn; }  // (walker-major: nseg = 1)
 }
 
 // exclusive scan of cnt[2][W] -> off[2][W+1]; one block of 1024 threads
@@ -506,7 +510,9 @@ __global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st
     const int nmo = S.nmo[s];
     int last_e = -1;
     double U0 = 0.0;
-    const long p0 = B.off[(size_t)s * (W + 1) + w], p1 = B.off[(size_t)s * (W + 1) + w + 1];
+    for (int seg = 0; seg < B.nseg; ++seg) {
+    const size_t so = (size_t)s * ((size_t)B.nseg * W + 1) + (size_t)seg * W + w;
+    const long p0 = B.off[so], p1 = B.off[so + 1];
     for (long pb = p0; pb < p1; pb += NWV) {
       const bool valid = pb + wv < p1;
       const long p = valid ? pb + wv : p1 - 1;
@@ -535,6 +541,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st
         tot += ratio * B.wgt[s][p];
         if (CX) tot_im += ratio_im * B.wgt[s][p];
       }
+    }
     }
   }
   if (NWV > 1) {
@@ -678,8 +685,11 @@ __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restr
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
   double tot = 0.0, tim = 0.0;
-  for (long p = B.off[w]; p < B.off[w + 1]; ++p) { tot += c_up[p]; if (n_up > 0) tim += c_up[n_up + p]; }
-  for (long p = B.off[(W + 1) + w]; p < B.off[(W + 1) + w + 1]; ++p) { tot += c_dn[p]; if (n_dn > 0) tim += c_dn[n_dn + p]; }
+  const size_t SS = (size_t)B.nseg * W + 1;
+  for (int seg = 0; seg < B.nseg; ++seg)
+    for (long p = B.off[(size_t)seg * W + w]; p < B.off[(size_t)seg * W + w + 1]; ++p) { tot += c_up[p]; if (n_up > 0) tim += c_up[n_up + p]; }
+  for (int seg = 0; seg < B.nseg; ++seg)
+    for (long p = B.off[SS + (size_t)seg * W + w]; p < B.off[SS + (size_t)seg * W + w + 1]; ++p) { tot += c_dn[p]; if (n_dn > 0) tim += c_dn[n_dn + p]; }
   ecp[w] = B.local[w] + tot;
   if (n_up > 0 || n_dn > 0) ecp[W + w] = tim;
 }
