@@ -2086,7 +2086,9 @@ static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   c.nmax = std::max(h->nup, h->ndn);
   // block size of the delayed Sherman-Morrison update: 4 from 16 electrons per spin (8 flushes at 32), 5 from 24 (7 flushes at 32:
   // 35.60 -> 35.32 ms per step of the 64-electron benchmark; 6 is slower again — the per-move commit touches KB rows)
-  const int kb = h->lw_kb < 0 ? (c.nmax >= 24 ? 5 : (c.nmax >= 16 ? 4 : 0)) : h->lw_kb;
+  // small shards (every launch a latency chain, one block row per thread group): 8 — fewer flush launches and split step launches
+  // ((H2O)8 at 4096 walkers: 4.08 ms per step with 5, 3.97 with 8, 3.94 with 11, 4.01 with 16; 8192: 5.97 / 5.80 / 5.90 / 6.00)
+  const int kb = h->lw_kb < 0 ? (c.nmax >= 24 ? (W <= 8192 ? 8 : 5) : (c.nmax >= 16 ? 4 : 0)) : h->lw_kb;
   c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
   if (!lw) TRY(sync_aos(h));
   if (lw) {
