@@ -344,11 +344,23 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   double* shR = sh + (size_t)nq * L_ * WB;
   const int wl = threadIdx.x & (WB - 1), g = threadIdx.x / WB;
   const long w0 = (long)blockIdx.x * WB;
-  for (int idx = threadIdx.x; idx < nq * L_ * WB; idx += 256) {
-    const long ws = (w0 + (idx & (WB - 1)) < W) ? w0 + (idx & (WB - 1)) : W - 1;
-    const size_t src = (size_t)(idx / WB) * W + ws;  // idx / WB = q * L_ + k
-    shV[idx] = Vb[src];
-    shR[idx] = Rb[src];
+  // eight elements of each vector per pass, all sixteen loads in flight before the first LDS store (one element per iteration was
+  // a round trip per iteration: 8-10 of them at the head of a ~30-us launch for small shards)
+  for (int base = threadIdx.x; base < nq * L_ * WB; base += 8 * 256) {
+    double v8[8], r8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256;
+      const int ic = (idx < nq * L_ * WB) ? idx : base;
+      const long ws = (w0 + (ic & (WB - 1)) < W) ? w0 + (ic & (WB - 1)) : W - 1;
+      const size_t src = (size_t)(ic / WB) * W + ws;  // idx / WB = q * L_ + k
+      v8[u] = Vb[src]; r8[u] = Rb[src];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256;
+      if (idx < nq * L_ * WB) { shV[idx] = v8[u]; shR[idx] = r8[u]; }
+    }
   }
   __syncthreads();
   const long w = w0 + wl;
