@@ -18,6 +18,37 @@
 #ifndef PQA_PRIM_UNROLL
 #define PQA_PRIM_UNROLL 1
 #endif
+// exp of a non-positive argument (the Gaussians' -alpha r^2): round(x log2 e) and a two-term Cody-Waite reduction, a degree-11
+// polynomial on |r| <= ln 2 / 2 (near-minimax fit of (e^r - 1 - r) / r^2, so e^0 = 1 exactly), ldexp.  20 instructions where the
+// library routine takes 24 (it also serves positive arguments: two compare-and-select pairs for overflow / underflow); max error
+// 1.3 ulp over [-745, 0] against long-double expl (host check with the same constants and fma order, 4e7 arguments).
+__device__ __forceinline__ double exp_neg(double x) {
+  x = fmax(x, -800.0);
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = fma(-k, 6.93147180369123816490e-01, x);
+  r = fma(-k, 1.90821492927058770002e-10, r);
+  double p = 2.519062899249436e-08;
+  p = fma(p, r, 2.761249479944321e-07);
+  p = fma(p, r, 2.7557019442003614e-06);
+  p = fma(p, r, 2.480153911822949e-05);
+  p = fma(p, r, 0.0001984127010654779);
+  p = fma(p, r, 0.0013888888904182626);
+  p = fma(p, r, 0.008333333333235474);
+  p = fma(p, r, 0.04166666666665442);
+  p = fma(p, r, 0.1666666666666677);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+#ifndef PQA_EXP_NEG
+#define PQA_EXP_NEG 1  // 0: library exp (A/B: k_orb<5> 129.2 -> 127.3 us, k_orb<1> 821 -> 790, periodic k_orb_wide 193 -> 187)
+#endif
+#if PQA_EXP_NEG
+#define PQA_EXP(x) exp_neg(x)
+#else
+#define PQA_EXP(x) exp(x)
+#endif
 // Primitive screening: skip a primitive with alpha r^2 > PQA_PRIM_CUT (it contributes < 2e-22 of its coefficient).  The test
 // is per lane and the exp sequence is only saved when EVERY lane of the wave skips.
 //  * open systems (-DPQA_PRIM_SCREEN=1, off): the 64 points of a wave are 64 different walkers, some lane is nearly always
@@ -100,7 +131,7 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
 #ifdef PQA_ABL_NOEXP  // ablation builds only (tools/scratch/abl_pbc.sh): wrong values, kernel timing only
     const double t = pcoef[p] * (1.0 - 1e-3 * a * r2);
 #else
-    const double t = pcoef[p] * exp(-a * r2);
+    const double t = pcoef[p] * PQA_EXP(-a * r2);
 #endif
     R += t;
     if (NCOMP > 1) dRs += a * t;
