@@ -501,7 +501,12 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled,
   //   PQA_PBC_NW n words (4 image indices each) per (point, atom) image list of the periodic pre-pass (default from the cell;
   //   1 forces the direct-test fallback: tests), PQA_WIDE_NTH 512 k_orb_wide with 512 threads in untwisted periodic cells,
-  //   PQA_TM_PRE 0 T-move ratios by the wave-per-walker loop only.
+  //   PQA_TM_PRE 0 T-move ratios by the wave-per-walker loop only;
+  //   round 3 (each documented at its field above): PQA_STEP_PRE 0 k_step_lw for small shards too, PQA_DRAWS_MAX n walker count up to
+  //   which a sweep's random numbers are drawn ahead, PQA_FLUSH_WB8_MAX n 8-walker flush blocks up to n walkers, PQA_ECP_LDS 0 /
+  //   PQA_ECP_POINT_LW 0 first-generation ECP list passes / point kernel, PQA_ECP_ACC_WAVES 1|4 waves per walker in the
+  //   wave-per-walker energy kernels, PQA_ECP_ATOM_MAJOR 0 walker-major ECP lists in periodic cells, PQA_JAS_FOLD 0 Voronoi
+  //   reduction in every periodic Jastrow pair.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
