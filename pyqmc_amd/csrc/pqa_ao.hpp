@@ -369,7 +369,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // recomputed n^2 distances — both 2.4 x slower than this.
 #define PQA_PRE_NWMAX 8   // list words the pre-pass can assemble in LDS (32 entries: PQA_PRE_CAP)
 #define PQA_PRE_MEMB 2048 // bytes of one atom class of the membership table staged in LDS (side^3; 729 for M = 4)
-__global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
+static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
                                                      unsigned long long* __restrict__ lst, double* __restrict__ theta) {
   // The candidates' lattice vectors, their membership offsets and the atom class's membership bytes are staged in LDS: as
   // per-candidate scalar / gather loads (load, wait, test) they were 79 + 4 x 13 dependent round trips per thread in the
@@ -525,13 +525,13 @@ __device__ __forceinline__ void pbc_ctx_load(const SysDev& S, const Tab& T, PbcC
 
 // Twisted cells: multiply every orbital row [ncomp][2 nmo] (re block | im block) by the point's wrap phase.
 // rows of a two-slot output cleared before a K-split launch accumulates into them.  grid = (P, ceil(row / 256)), block = 256
-__global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ out, int row, const unsigned char* __restrict__ sel, long slot_stride) {
+static __global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ out, int row, const unsigned char* __restrict__ sel, long slot_stride) {
   const long p = blockIdx.x;
   const int k = blockIdx.y * 256 + threadIdx.x;
   if (k < row) out[(size_t)(sel[p] ^ 1) * slot_stride + (size_t)p * row + k] = 0.0;
 }
 // sel / slot_stride: the two-slot output of ChunkTab (nullptr: plain rows)
-__global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta,
+static __global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta,
                             const unsigned char* __restrict__ sel, long slot_stride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nmo = nmo2 / 2;
@@ -547,7 +547,7 @@ __global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo
 // ---------------------------------------------------------------- AO only (test / A-B entry)
 // out (NCOMP, P, nao); one thread per point.
 template <int NCOMP>
-__global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
+static __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
@@ -580,7 +580,7 @@ __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* _
 }
 
 // plain contraction out[c][p][j] = sum_a ao[c][p][a] C[a][j]  (A/B check of the MFMA kernel only)
-__global__ void k_mo_valu(const double* __restrict__ ao, const double* __restrict__ C, long rows, int nao, int nmo,
+static __global__ void k_mo_valu(const double* __restrict__ ao, const double* __restrict__ C, long rows, int nao, int nmo,
                           double* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * nmo) return;
@@ -632,7 +632,7 @@ __device__ __forceinline__ double* orb_out(const ChunkTab& T, double* out, long 
 //          D[point][orb] += A[point][k] B[k][orb] with v_mfma_f64_16x16x4_f64; B straight from L2.
 // PBC: 0 open system, 1 periodic (real lattice sums), 2 periodic with a twist (complex lattice sums: real and imaginary tile rows per shell)
 template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, int PBC = 0>
-__global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
+static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
   constexpr int G = 256 / TP;                         // lane groups in phase 1
   constexpr int NU = (TP == 64) ? NT : ((TP == 32) ? (NT + 1) / 2 : (NT + 3) / 4);  // orbital tiles per wave in phase 2
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, Poi
 // so the VALU/transcendental pipe and the matrix pipe run concurrently inside ONE block — which is
 // what a launch of only W/64 = 256 blocks (one per CU) needs.
 template <int NCOMP, int NT, int KC>
-__global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
+static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                                 double* __restrict__ out) {
   constexpr int KS = KC / 4;
   __shared__ double tile[2][NCOMP][KC][64];
@@ -982,7 +982,7 @@ __host__ __device__ inline size_t wide_lds_bytes(int ncomp, int rows_pad, int ns
 // NTH threads: 1024 for open systems (94 VGPRs); periodic lattice sums need > 128 registers (at 1024 threads they spilled
 // 384 B, twisted 1024 B per lane, and lost to k_orb), so periodic launches take 512 threads = 32 lane groups.
 template <int NCOMP, int NT, int PBC, int NTH>
-__global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab Wt, int spin, PointAddr pa, long P, double* __restrict__ out) {
+static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab Wt, int spin, PointAddr pa, long P, double* __restrict__ out) {
   extern __shared__ double wl[];
   const int K = Wt.rows_pad;
   double* tile = wl;                                  // [NCOMP][K][16]

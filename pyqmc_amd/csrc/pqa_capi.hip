@@ -1,229 +1,9 @@
 // pyqmc_amd C ABI implementation (host side).  See include/pyqmc_amd.h for the contract.
 // Single translation unit: the device code lives in the headers included below.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "../../include/pyqmc_amd.h"
-#include "pqa_ao.hpp"
-#include "pqa_common.hpp"
-#include "pqa_cslater.hpp"
-#include "pqa_dmc.hpp"
-#include "pqa_energy.hpp"
-#include "pqa_ecp.hpp"
-#include "pqa_jastrow.hpp"
-#include "pqa_lw.hpp"
-#include "pqa_slater.hpp"
-#include "pqa_tile.hpp"
-#include "pqa_dm.hpp"
-#include "pqa_vmc.hpp"
+#include "pqa_internal.hpp"
 
 static thread_local std::string g_create_error;
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-};
-
-struct ChunkHost {
-  std::vector<int> nk, row0;
-  std::vector<int> shell_kb, shell_chunk;  // per shell: first tile row inside its chunk, chunk index
-  std::vector<int> cw_off[3], cw_shell[3];  // shell lists per (chunk, lane group) for 4, 8 and 16 groups
-  int rows_pad = 0;
-};
-
-struct pqa_handle {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  std::vector<void*> owned;  // table allocations freed at destroy
-  // host copies needed after create
-  int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
-  int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
-  int na = 0, nb = 0, necp = 0;
-  bool tm_pre = true;   // T-move ratios of all candidates in one thread-per-candidate launch (PQA_TM_PRE=0: wave-per-walker loop only)
-  bool aos_stale = false;  // the lane-per-walker planes hold the live state; the walker-major arrays are converted back on demand (sync_aos)
-  int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
-  int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
-  bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
-  bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
-  bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
-  bool has_j2 = false, has_j3 = false;
-  int na3 = 0, nb3 = 0;
-  double* d_c3 = nullptr;
-  DevBuf b_j3u;
-  double ii_energy = 0.0;
-  EwaldDev ew{};  // periodic Coulomb tables (pqa_set_ewald)
-  bool ew_set = false;
-  std::vector<int> shell_l, shell_np, shell_ao;
-  std::vector<int> shell_cost;  // phase-1 cost model of a shell (shell_costs): balances the lane groups of the orbital kernels
-  SysDev S{};
-  ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
-  ChunkTab tab[2]{};
-  const unsigned char* out_sel = nullptr;  // two-slot output of the NEXT orbital launch (ChunkTab::out_sel; set by launch_orb)
-  long out_slot_stride = 0;
-  double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
-  double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
-  double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
-  // walker state
-  long W = 0;
-  SlaterState st{};
-  JastrowState js{};
-  DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
-  DevBuf b_alt_x, b_alt_T[2], b_alt_dsign[2], b_alt_dlog[2], b_alt_cache[2], b_alt_aval, b_alt_bval, b_alt_j3u, b_rsidx;  // pqa_resample's other halves
-  // scratch
-  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth, b_tmuold;
-  int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
-  int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
-  int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
-  int ecp_point_lw = 1;  // PQA_ECP_POINT_LW=0: k_ecp_point on the planes instead of k_ecp_point_lw (A/B)
-  long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
-  long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
-  int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
-  int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
-  int jas_fold_allowed = 1;  // PQA_JAS_FOLD=0: Voronoi reduction in every periodic Jastrow pair (A/B, bitwise check)
-  int ecp_atom_major = 1;  // PQA_ECP_ATOM_MAJOR=0: walker-major ECP point lists in periodic cells too (A/B)
-  int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
-  int ecp_nchan = 0, ecp_nterm = 0;
-  long wrap_W = 0;
-  DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
-  DevBuf b_tpos, b_twgt, b_tlive, b_trat;
-  DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_tmtile, b_tmaoff, b_tmptw, b_tmmarks, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
-  int tm_P = 0;
-  int *d_ptk = nullptr, *d_pti = nullptr;
-  DevBuf b_xt, b_Tt[2], b_rc[2], b_sel[2], b_auxt, b_kpart, b_rbuf, b_vbuf, b_act;
-  // electrons per Sherman-Morrison block (PQA_LW_KB): -1 automatic (4 for >= 16 electrons per spin), 0 = update every row on
-  // every move.  Blocking is bitwise identical and cuts the inverse's HBM traffic ~3x; it pays since k_flush_lw stages the
-  // block's update vectors in LDS (1.26 -> 0.27 ms per flush at 65536 walkers): commit + flush 15.5 -> 8.4 ms per step.
-  int lw_kb = -1;
-  int lw_nw = 0;  // PQA_LW_NW: walkers per block of k_step_lw (16, 32, 64; 0 = automatic)
-  int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
-  DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
-  int orb_tp = 0;  // 0 = automatic
-  int orb_nosplit = 0;  // PQA_ORB_NOSPLIT=1: never split the chunk loop of small periodic launches (A/B)
-  long orb_split_max = 8192;  // largest periodic launch whose chunk loop is split over two blocks (PQA_ORB_SPLIT_MAX)
-  // AO rows per chunk of the PERIODIC 5-component launch: 32 halves the number of (phase 1, barrier, MFMA, barrier)
-  // rounds of a block's latency chain — 2x2x2 diamond supercell +4.5-10 % at every walker count, 8-atom cell +11 % at 8192
-  // walkers, -4 % at 32768 (PQA_ORB_KC5=16 restores the 16-row chunks; the open-system kernel keeps 16: 0.36 vs 0.29 of peak)
-  int orb_kc5 = 32;
-  struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
-  TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
-  WideTab wide[2]{};  // lane-group shell lists of the whole-K small-launch kernel (k_orb_wide), per chunk table (64 groups; periodic: 32)
-  int orb_wide = -1;  // PQA_ORB_WIDE: -1 automatic (5-component launches of <= orb_wide_max points), 0 never, 1 whenever the tile fits LDS
-  long orb_wide_max = 8192;  // PQA_ORB_WIDE_MAX
-  std::vector<const void*> wide_attr;  // kernels whose dynamic-LDS limit has been raised
-  int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
-  int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
-  int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
-  // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
-  // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
-  struct DmSlot { DevBuf pos, row, f, newpos, keep_pos, keep_row, keep_f, cfg; long n = 0, ncfg = 0; int nkeep = 0, spin = 0; };
-  DmSlot dm[2];
-  DevBuf dm_val, dm_norm[2], dm_tmp, dm_ijkl, dm_assign[2], dm_ratio, dm_acc;
-  long dm_nconf = 0, dm_nval = 0;
-  int dm_cx = 0;
-  bool tile_attr_set = false;
-  bool saved_valid = false;
-  bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
-  int saved_e = -1;
-  long last_ecp_points = 0;
-  // measurement
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_events;  // Sherman-Morrison commit launches of the fused sweep
-  size_t prof2_used = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof3_events;  // partial-sum launches (k_move_part_lw) of the fused sweep
-  size_t prof3_used = 0;
-  long prof3_launches = 0;
-  double prof3_ms = 0.0;
-  long prof2_launches = 0;
-  double prof2_ms = 0.0;
-  size_t prof_used = 0;
-  unsigned prof_tick = 0, prof2_tick = 0;  // the event pairs bracket every 4th eligible launch (PQA_PROF_STRIDE)
-  unsigned prof_stride = 4;
-  long prof_launches = 0;
-  double prof_ms = 0.0, prof_pc = 0.0;
-};
-
-#define HIPCHK(call)                                                                                     \
-  do {                                                                                                   \
-    hipError_t e_ = (call);                                                                              \
-    if (e_ != hipSuccess) {                                                                              \
-      char buf_[512];                                                                                    \
-      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-      h->err = buf_;                                                                                     \
-      return -1;                                                                                         \
-    }                                                                                                    \
-  } while (0)
-#define FAIL(msg)      \
-  do {                 \
-    h->err = (msg);    \
-    return -2;         \
-  } while (0)
-#define TRY(x)          \
-  do {                  \
-    int rc_ = (x);      \
-    if (rc_) return rc_; \
-  } while (0)
-
-struct pqa_handle;
-static int sync_aos(pqa_handle* h);
-static int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks);
-
-static int ensure(pqa_handle* h, DevBuf& b, size_t bytes) {
-  if (bytes <= b.cap && b.p) return 0;
-  // A buffer that has to GROW holds data-dependent sizes (ECP / T-move point lists: ~38 points per walker +- sqrt(N)
-  // from step to step).  Exact-size regrowth made every new maximum a hipFree + hipMalloc pair, i.e. a device
-  // synchronisation and milliseconds of driver time in the first dozens of steps (the first timed steps on a fresh box
-  // ran 15 % slow); 25 % headroom on regrowth ends that after the second step.  First allocations stay exact.
-  const bool regrow = b.p != nullptr;
-  if (b.p) HIPCHK(hipFree(b.p));
-  b.p = nullptr;
-  b.cap = 0;
-  size_t want = std::max<size_t>(regrow ? bytes + bytes / 4 : bytes, 256);
-  HIPCHK(hipMalloc(&b.p, want));
-  b.cap = want;
-  return 0;
-}
-
-template <class T>
-static int upload_table(pqa_handle* h, const T* src, size_t n, T** dst) {
-  *dst = nullptr;
-  if (n == 0) n = 1;
-  void* p = nullptr;
-  HIPCHK(hipMalloc(&p, n * sizeof(T)));
-  h->owned.push_back(p);
-  if (src) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
-  else HIPCHK(hipMemset(p, 0, n * sizeof(T)));
-  *dst = (T*)p;
-  return 0;
-}
-
-static int copy_in(pqa_handle* h, void* dst, const void* src, size_t bytes) {
-  if (bytes == 0) return 0;
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
-  return 0;
-}
-static int copy_out(pqa_handle* h, void* dst, const void* src, size_t bytes) {
-  if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
-}
-static int check_launch(pqa_handle* h, const char* what) {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    h->err = std::string(what) + " launch failed: " + hipGetErrorString(e);
-    return -1;
-  }
-  return 0;
-}
 
 // ---------------------------------------------------------------- membership masks (k_pbc_prepass)
 // The reference's image-membership rule asks, for candidate image j of an atom, whether member[class][b + img_n[j]] is set,
@@ -530,6 +310,13 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
   if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
   if (const char* fw = getenv("PQA_FLUSH_WB8_MAX")) h->flush_wb8_max = atol(fw);
+  if (const char* sp = getenv("PQA_SPLIT")) h->split_mode = std::max(0, std::min(3, atoi(sp)));
+  if (const char* sp = getenv("PQA_SPLIT_MIN")) h->split_min = std::max(512L, atol(sp));
+  if (const char* sp = getenv("PQA_SPLIT_CUS")) h->split_cus = atoi(sp);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->cu_count = prop.multiProcessorCount;
+  }
   h->natom = sys->natom; h->nup = sys->nelec_up; h->ndn = sys->nelec_dn; h->N = h->nup + h->ndn;
   h->nao = sys->nao; h->nshell = sys->nshell;
   h->has_slater = sys->has_slater != 0;
@@ -884,6 +671,9 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (auto& pr : h->prof3_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->pipe_events) (void)hipEventDestroy(e);
+  for (hipStream_t s : h->pipe_stream)
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -937,226 +727,6 @@ extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int
   return 0;
 }
 
-// ---------------------------------------------------------------- orbital kernel launch
-static ChunkTab tabx(const pqa_handle* h, int tabi) {  // the chunk table + where this launch's rows go
-  ChunkTab T = h->tab[tabi];
-  T.out_sel = h->out_sel;
-  T.out_slot_stride = h->out_slot_stride;
-  return T;
-}
-template <int NCOMP, int KC>
-static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  const dim3 grid((unsigned)((P + 63) / 64)), block(512);
-  switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb_ws<NCOMP, 1, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb_ws<NCOMP, 2, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb_ws<NCOMP, 4, KC>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-  }
-}
-
-template <int NCOMP, int KC, int TP, bool LT>
-static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
-  switch (h->nt[spin]) {
-    case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-    case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-    default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
-  }
-}
-// whole-K kernel for small 5-component launches (k_orb_wide, pqa_ao.hpp)
-static bool wide_wanted(const pqa_handle* h, int tabi, long P, int ncomp) {
-  if (ncomp != 5 || h->orb_wide == 0 || h->wide[tabi].rows_pad <= 0) return false;
-  if (wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim, (h->S.pbc && h->S.nL <= PQA_LS_MAX) ? 5 * h->S.nL : 0) > (size_t)160 * 1024 - 256) return false;
-  if (h->orb_wide == 1) return true;
-  // measured (tools/scratch/ab_wide*.sh, 1 MI355X): (H2O)8 step 6.65 -> 4.73 ms at 1024 walkers, 7.64 -> 5.86 at 4096, 9.08 -> 7.84
-  // at 8192, even at 16384, slower at 32768 (one 1024-thread block per CU cannot overlap AO and MFMA phases of different
-  // tiles); periodic cells (512 threads, two lane-group chains per point like the K-split k_orb): 2x2x2 diamond +5 / +8 / +2.5 %
-  // at 1024 / 4096 / 8192 walkers, but the 8-atom cell (40 shells on 32 groups) and twisted cells (528 B of spills) lose
-  // after the image lists / in-tile accumulation (no spills any more): twisted 8-atom cell 451k -> 580k walker-steps/s at 4096
-  // walkers, 708k -> 756k at 8192; untwisted 8-atom cell even
-  // ... and with the image walk / accumulation as they are now it wins up to 32768 points (C3 +18 % at 24576 walkers, +7 % at
-  // 16384 and 32768; C5 +6 % at 12288, +1-2 % at 16384 and 32768): periodic threshold 4 x orb_wide_max
-  if (h->S.pbc) return (h->twist || h->nshell >= 64) && P <= 4 * h->orb_wide_max;
-  return P <= h->orb_wide_max + h->orb_wide_max / 2;
-}
-template <int PBCV, int NTH>
-static int launch_orb_wide(pqa_handle* h, const ChunkTab& T, int tabi, int spin, PointAddr pa, long P, double* out) {
-  const size_t lds = wide_lds_bytes(5, h->wide[tabi].rows_pad, h->nshell, (int)h->S.nprim, (h->S.pbc && h->S.nL <= PQA_LS_MAX) ? 5 * h->S.nL : 0);
-  const dim3 grid((unsigned)((P + 15) / 16)), block(NTH);
-#define PQA_WIDE(NT) do { const void* fn = (const void*)k_orb_wide<5, NT, PBCV, NTH>; \
-    if (std::find(h->wide_attr.begin(), h->wide_attr.end(), fn) == h->wide_attr.end()) { \
-      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); h->wide_attr.push_back(fn); } \
-    hipLaunchKernelGGL((k_orb_wide<5, NT, PBCV, NTH>), grid, block, lds, h->stream, h->S, T, h->wide[tabi], spin, pa, P, out); } while (0)
-  switch (h->nt[spin]) {
-    case 1: PQA_WIDE(1); break;
-    case 2: PQA_WIDE(2); break;
-    default: PQA_WIDE(4); break;
-  }
-#undef PQA_WIDE
-  return 0;
-}
-
-// periodic orbitals: lattice-summed shells, 64-point tiles, tables through the scalar cache
-template <int NCOMP, int KC>
-static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  TRY(ensure(h, h->b_pbcd0, (size_t)h->natom * (h->twist ? 5 : 3) * P * sizeof(double)));
-  const int NW = h->pbc_nw;
-  TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * NW * P * sizeof(unsigned long long)));
-  if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
-  hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
-                     (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
-  ChunkTab T = tabx(h, tabi);
-  T.pbc_d0 = (const double*)h->b_pbcd0.p;
-  T.pbc_list = (const unsigned long long*)h->b_pbcmask.p;
-  T.pbc_nw = NW;
-  if (wide_wanted(h, tabi, P, NCOMP)) {  // small launch: one 1024-thread block per 16-point tile, the whole basis in LDS
-    if (h->twist) TRY((launch_orb_wide<2, 512>(h, T, tabi, spin, pa, P, out)));
-    else if (h->wide_nth == 1024) TRY((launch_orb_wide<1, 1024>(h, T, tabi, spin, pa, P, out)));
-    else TRY((launch_orb_wide<1, 512>(h, T, tabi, spin, pa, P, out)));
-    if (h->twist) {
-      const long nel = P * NCOMP * (h->nmo[spin] / 2);
-      hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
-                         (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
-    }
-    return 0;
-  }
-  // Tile width.  32-point tiles: twice the blocks, and the 8 lane groups halve each thread's share of a chunk's lattice
-  // sums; 64-point tiles: half the B-operand and table traffic per point.  Which wins depends on cell and launch size
-  // (2x2x2 diamond supercell, 16 atoms: 32 wins at every size, 28.5 -> 21.9 ms/step at 1024 walkers, 107.5 -> 100.0 at
-  // 32768; 8-atom cubic cell: 32 wins up to 16384 points, 64 wins by 14 % at 32768), both give bit-identical rows, so
-  // large launches time each twice per size class (four stream synchronisations in the handle's lifetime per class) and
-  // keep the faster; small ones take 32.  PQA_ORB_TP pins it.
-  // small launches: 16-point tiles (2x2x2 diamond: 19.8 -> 15.6 ms/step at 1024 walkers, 25.5 -> 21.9 at 4096, +3.5 % at 8192;
-  // the twisted 8-atom cell loses 13 % at 8192, hence the threshold)
-  int tp = (P <= 4096) ? 16 : 32;
-  pqa_handle::TpTune* tune = nullptr;
-  int tune_slot = -1;
-  hipEvent_t te0 = nullptr, te1 = nullptr;
-  if (h->orb_tp == 16 || h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
-  else if (P >= 16384) {
-    int b = 0;
-    while ((2L << b) <= P && b < 46) ++b;
-    tune = &h->tp_tune[tabi & 1][b];
-    if (tune->choice) tp = tune->choice;
-    else {
-      tune_slot = tune->n[0] <= tune->n[1] ? 0 : 1;  // alternate; best of two samples each
-      tp = tune_slot ? 64 : 32;
-      HIPCHK(hipEventCreate(&te0));
-      HIPCHK(hipEventCreate(&te1));
-      HIPCHK(hipEventRecord(te0, h->stream));
-    }
-  }
-  // small launches: split the chunk loop over two blocks per point tile (k_orb: gridDim.y), output accumulated atomically
-  const int nsplit = (P <= h->orb_split_max && T.nchunk >= 4 && !h->orb_nosplit) ? 2 : 1;
-  if (nsplit > 1) {
-    if (h->out_sel) hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)P, (unsigned)((NCOMP * h->nmo[spin] + 255) / 256)), dim3(256), 0, h->stream, out,
-                                       NCOMP * h->nmo[spin], h->out_sel, h->out_slot_stride);
-    else HIPCHK(hipMemsetAsync(out, 0, (size_t)P * NCOMP * h->nmo[spin] * sizeof(double), h->stream));
-  }
-  const dim3 grid((unsigned)((P + tp - 1) / tp), (unsigned)nsplit), block(256);
-  // basis tables in LDS when they fit: besides the faster table reads, the larger LDS footprint makes the compiler
-  // budget registers for 2 blocks per CU instead of 4 (128 registers + 800 B of scratch spills otherwise)
-  const bool lt = h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab;
-#define PQA_ORB_PBC2(NT, LT, TPV) do { if (h->twist) hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, TPV, LT, 2>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); \
-                                       else hipLaunchKernelGGL((k_orb<NCOMP, NT, KC, TPV, LT, 1>), grid, block, 0, h->stream, h->S, T, spin, pa, P, out); } while (0)
-#define PQA_ORB_PBC(NT, LT) do { if (tp == 64) PQA_ORB_PBC2(NT, LT, 64); else if (tp == 16) PQA_ORB_PBC2(NT, LT, 16); else PQA_ORB_PBC2(NT, LT, 32); } while (0)
-  switch (h->nt[spin]) {
-    case 1: if (lt) PQA_ORB_PBC(1, true); else PQA_ORB_PBC(1, false); break;
-    case 2: if (lt) PQA_ORB_PBC(2, true); else PQA_ORB_PBC(2, false); break;
-    default: if (lt) PQA_ORB_PBC(4, true); else PQA_ORB_PBC(4, false); break;
-  }
-#undef PQA_ORB_PBC2
-  if (tune_slot >= 0) {
-    HIPCHK(hipEventRecord(te1, h->stream));
-    HIPCHK(hipEventSynchronize(te1));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, te0, te1));
-    HIPCHK(hipEventDestroy(te0));
-    HIPCHK(hipEventDestroy(te1));
-    tune->ms[tune_slot] = std::min(tune->ms[tune_slot], ms);
-    if (++tune->n[tune_slot] >= 2 && tune->n[1 - tune_slot] >= 2) tune->choice = tune->ms[1] < tune->ms[0] ? 64 : 32;
-  }
-#undef PQA_ORB_PBC
-  if (h->twist) {
-    const long nel = P * NCOMP * (h->nmo[spin] / 2);
-    hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
-                       (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
-  }
-  return 0;
-}
-template <int NCOMP, int KC, int TP>
-static void launch_orb_t(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
-  if (h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP && !h->orb_notab) launch_orb_t2<NCOMP, KC, TP, true>(h, tabi, spin, pa, P, out);
-  else launch_orb_t2<NCOMP, KC, TP, false>(h, tabi, spin, pa, P, out);
-}
-
-// out[p][ncomp][nmo_spin]
-// out_sel / slot_stride: two-slot output (ChunkTab::out_sel), else plain rows
-static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out);
-static int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out, const unsigned char* out_sel = nullptr,
-                      long slot_stride = 0) {
-  h->out_sel = out_sel; h->out_slot_stride = slot_stride;
-  const int rc = launch_orb_impl(h, spin, pa, P, ncomp, out);
-  h->out_sel = nullptr; h->out_slot_stride = 0;
-  return rc;
-}
-static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out) {
-  if (P <= 0 || h->nmo[spin] == 0) return 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  // account the dominant (move) launches only, and only a 1-in-prof_stride sample of them: an event pair costs ~2 us of
-  // stream time, 512 pairs per step were 1.2 ms of a 27 ms step
-  const bool prof = h->profile && ncomp == 5 && (h->prof_tick++ % h->prof_stride) == 0;
-  if (prof) {
-    if (h->prof_used == h->prof_events.size()) {
-      hipEvent_t a, b;
-      HIPCHK(hipEventCreate(&a));
-      HIPCHK(hipEventCreate(&b));
-      h->prof_events.emplace_back(a, b);
-    }
-    e0 = h->prof_events[h->prof_used].first;
-    e1 = h->prof_events[h->prof_used].second;
-    ++h->prof_used;
-    HIPCHK(hipEventRecord(e0, h->stream));
-  }
-  // 64-point tiles need >= ~4 blocks per CU to overlap their exp and MFMA phases across blocks; below
-  // that, 32-point tiles double the number of resident blocks (PQA_ORB_TP overrides for A/B runs)
-  int tp = (P >= (long)64 * 512) ? 64 : 32;
-  if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
-  // measured on MI355X: below ~2 blocks per CU the wave-specialised schedule wins (its
-  // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
-  const bool want_ws = h->orb_ws < 0 ? (P < (long)64 * 512) : (h->orb_ws != 0);
-  if (h->S.nL > 0) {
-    if (ncomp == 5) { if (h->orb_kc5 == 32) TRY((launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out))); else TRY((launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out))); }
-    else if (ncomp == 1) TRY((launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out)));
-    else FAIL("orbital kernel supports ncomp 1 or 5");
-  } else
-  if (wide_wanted(h, 0, P, ncomp)) {
-    TRY((launch_orb_wide<0, 1024>(h, tabx(h, 0), 0, spin, pa, P, out)));
-  } else
-  if (want_ws && h->nshell <= PQA_WS_MAXSH && (int)h->S.nprim <= PQA_WS_MAXP) {
-    if (ncomp == 5) launch_orb_ws<5, 16>(h, 0, spin, pa, P, out);
-    else if (ncomp == 1) launch_orb_ws<1, 32>(h, 1, spin, pa, P, out);
-    else FAIL("orbital kernel supports ncomp 1 or 5");
-  } else
-  if (ncomp == 5) { if (tp == 64) launch_orb_t<5, 16, 64>(h, 0, spin, pa, P, out); else launch_orb_t<5, 16, 32>(h, 0, spin, pa, P, out); }
-  else if (ncomp == 1) { if (tp == 64) launch_orb_t<1, 32, 64>(h, 1, spin, pa, P, out); else launch_orb_t<1, 32, 32>(h, 1, spin, pa, P, out); }
-  else FAIL("orbital kernel supports ncomp 1 or 5");
-  TRY(check_launch(h, "k_orb"));
-  if (prof) {
-    HIPCHK(hipEventRecord(e1, h->stream));
-    h->prof_launches += 1;
-    h->prof_pc += (double)P * ncomp;
-  }
-  return 0;
-}
-
-static PointAddr plain_points(const double* base, long P) {
-  PointAddr pa;
-  pa.base = base;
-  pa.group = (int)std::max<long>(P, 1);
-  pa.group_stride = 0;
-  return pa;
-}
 
 extern "C" int pqa_eval_ao(pqa_handle_t* h, const double* pts, int64_t npts, int ncomp, double* out) {
   HIPCHK(hipSetDevice(h->device));
@@ -1257,16 +827,6 @@ static int jas_refresh(pqa_handle* h) {
   return 0;
 }
 
-static size_t lds_j3(const pqa_handle* h) {  // bytes needed by kernels that call jas_eval with the three-body term
-  return h->has_j3 ? ((size_t)h->S.j3_off + (size_t)h->natom * (3 + 6 * h->na3 * h->nb3)) * sizeof(double) : 0;
-}
-static size_t lds_sm(const pqa_handle* h) {
-  const size_t n = std::max(h->nup, h->ndn);
-  return std::max((n * (n + 1) + 2 * n + 64 + n) * sizeof(double), lds_j3(h));
-}
-static size_t lds_det(const pqa_handle* h, int ncomp) {
-  return std::max((size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double), lds_j3(h));
-}
 
 static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants from js.x
   const int nel[2] = {h->nup, h->ndn};
@@ -1720,601 +1280,6 @@ extern "C" int pqa_wf_value(pqa_handle_t* h, double* sign, double* logabs) {
 
 extern "C" int pqa_get_configs(pqa_handle_t* h, double* configs) { return pqa_jastrow_get_state(h, nullptr, nullptr, configs); }
 
-// energy of the resident walkers into device buffer b_en (6,W)
-static void transpose(pqa_handle* h, const double* in, double* out, long R, long C) {  // in [R][C] -> out [C][R]
-  if (R <= 0 || C <= 0) return;
-  hipLaunchKernelGGL(k_transpose, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, h->stream, in, out, R, C);
-}
-
-static LwState lw_state(pqa_handle* h) {
-  LwState L{};
-  L.xt = (double*)h->b_xt.p;
-  for (int s = 0; s < 2; ++s) {
-    L.Tt[s] = (double*)h->b_Tt[s].p; L.rc[s] = (double*)h->b_rc[s].p; L.sel[s] = (uint8_t*)h->b_sel[s].p;
-    L.dsign[s] = h->st.dsign[s]; L.dlog[s] = h->st.dlog[s];
-  }
-  L.auxt = (double*)h->b_auxt.p;
-  return L;
-}
-
-// AoS (canonical, wave-per-walker kernels) -> SoA mirrors for the lane-per-walker kernels
-static int lw_from_aos(pqa_handle* h, bool with_cache = true) {
-  const long W = h->W;
-  const int nel[2] = {h->nup, h->ndn};
-  TRY(ensure(h, h->b_xt, (size_t)W * h->N * 3 * sizeof(double)));
-  TRY(ensure(h, h->b_auxt, (size_t)W * 8 * sizeof(double)));
-  TRY(ensure(h, h->b_kpart, (size_t)W * h->N * 5 * sizeof(double)));
-  transpose(h, h->js.x, (double*)h->b_xt.p, W, (long)h->N * 3);
-  for (int s = 0; s < 2; ++s) {
-    const size_t n = nel[s], cf = h->cplx ? 2 : 1;
-    TRY(ensure(h, h->b_Tt[s], cf * W * n * n * sizeof(double)));
-    const int row = 5 * h->nmo[s];
-    TRY(ensure(h, h->b_rc[s], (size_t)2 * W * n * row * sizeof(double)));  // two slots per electron (pqa_lw.hpp)
-    TRY(ensure(h, h->b_sel[s], (size_t)W * n));
-    transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(cf * n * n));
-    if (n > 0 && row > 0) {
-      // (without the cache: the caller knows the row cache and its selectors are live — the T-move phase of the DMC step)
-      if (with_cache) hipLaunchKernelGGL(k_cache_to_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
-                                         (const double*)h->st.cache[s], (double*)h->b_rc[s].p, (uint8_t*)h->b_sel[s].p, (int)n, row, W);
-    }
-  }
-  return check_launch(h, "k_transpose");
-}
-// SoA -> AoS: coordinates and inverses (what the ECP kernels read); with_cache also the orbital cache
-static int lw_to_aos(pqa_handle* h, bool with_cache) {
-  const long W = h->W;
-  const int nel[2] = {h->nup, h->ndn};
-  transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W);
-  for (int s = 0; s < 2; ++s) {
-    const long n = nel[s];
-    transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], (h->cplx ? 2 : 1) * n * n, W);
-    const int row = 5 * h->nmo[s];
-    if (with_cache && n > 0 && row > 0)
-      hipLaunchKernelGGL(k_cache_from_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
-                         (const double*)h->b_rc[s].p, (const uint8_t*)h->b_sel[s].p, h->st.cache[s], (int)n, row, W);
-  }
-  return check_launch(h, "k_transpose");
-}
-
-// A fused call on the lane-per-walker kernels leaves the live state in the SoA planes and only marks the walker-major arrays
-// stale: back-to-back fused calls (the blocks of a VMC run) then skip both layout conversions (~13 GB of traffic per call at
-// 65536 walkers of the 64-electron system, 7 ms), and whoever needs the walker-major state — every protocol entry, the
-// energy entry, branching — converts it back first.
-static int sync_aos(pqa_handle* h) {
-  if (!h || !h->aos_stale) return 0;
-  HIPCHK(hipSetDevice(h->device));
-  h->aos_stale = false;
-  return lw_to_aos(h, true);
-}
-
-static int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-                      bool soa_current = false, bool aos_T_needed = true) {
-  const long W = h->W;
-  bool soa_T = false;
-  TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
-  TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
-  if (soa_current) {
-    const dim3 gk((unsigned)((((W + 63) / 64 + 7) / 8) * 8 * ((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB))), bk(64, PQA_KIN_EB);  // see k_kinetic_lw
-    if (h->cplx) {
-      if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-      else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-    } else if (h->S.pbc)
-      hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-    else
-      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-    hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
-                       h->N, W, (double*)h->b_kc.p);
-    TRY(check_launch(h, "k_kinetic_lw"));
-    // the ECP kernels read walker-major coordinates; the inverse only when the wave-per-walker accumulation runs (or the
-    // caller works on the walker-major state next: the DMC step's T-moves) — the thread-per-point kernel takes the planes
-    soa_T = !aos_T_needed && (!h->cplx || h->ecp_point_lw) && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_soa_t;
-    if (h->necp > 0) {
-      if (soa_T) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }
-      else TRY(lw_to_aos(h, false));
-    }
-  } else {
-    {  // four waves per walker while the launch is too small to fill the chip with one
-      const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
-      const size_t st_ = (size_t)(h->cplx ? 2 : 1) * lds_det(h, 5);
-      const int str_ = (int)(st_ / sizeof(double));
-#define PQA_KC(CXF, NV) hipLaunchKernelGGL((k_kinetic_coulomb<CXF, NV>), dim3((unsigned)W), dim3(64 * NV), NV * st_, h->stream, h->S, h->st, h->js, \
-                                           (int)h->has_slater, (int)h->has_jastrow, W, (double*)h->b_kc.p, str_)
-      if (h->cplx) { if (kc4) PQA_KC(true, 4); else PQA_KC(true, 1); }
-      else { if (kc4) PQA_KC(false, 4); else PQA_KC(false, 1); }
-#undef PQA_KC
-    }
-    TRY(check_launch(h, "k_kinetic_coulomb"));
-  }
-  if (h->S.pbc) {
-    if (!h->ew_set) FAIL("periodic Coulomb energy needs the Ewald tables (pqa_set_ewald)");
-    const bool soa = soa_current && h->necp == 0;  // with ECPs the coordinates were just transposed back
-    const double* x = soa ? (const double*)h->b_xt.p : h->js.x;
-    const size_t lds_ew = ((size_t)h->N * 3 + (h->ew.gn ? (size_t)h->N * 3 * (h->ew.nmax + 1) * 2 : 0)) * sizeof(double);
-    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(PQA_EWALD_T), lds_ew, h->stream, h->S, h->ew, x,
-                       soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
-    TRY(check_launch(h, "k_ewald"));
-  }
-  const double* d_ecp = nullptr;
-  h->last_ecp_points = 0;
-  if (h->necp > 0) {
-    const size_t nrot = (size_t)h->N * h->necp;
-    TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
-    if (rot) TRY(copy_in(h, h->b_rot.p, rot, nrot * 9 * sizeof(double)));
-    else {
-      hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed, step, (double*)h->b_rot.p);
-      TRY(check_launch(h, "k_gen_rot"));
-    }
-    EcpBuf B{};
-    B.rot = (const double*)h->b_rot.p;
-    if (unif) {
-      TRY(ensure(h, h->b_eunif, nrot * W * sizeof(double)));
-      TRY(copy_in(h, h->b_eunif.p, unif, nrot * W * sizeof(double)));
-      B.unif = (const double*)h->b_eunif.p;
-    }
-    B.quad = h->d_quad; B.seed = seed; B.step = step; B.threshold = threshold;
-    TRY(ensure(h, h->b_elocal, W * sizeof(double)));
-    // second-generation list passes (pqa_ecp.hpp): tables in LDS, four walkers per block, ATOM-major point lists
-    const size_t tab_b = ecp_tab_bytes(h->necp, h->ecp_nchan, h->ecp_nterm);
-    const bool ecp_t = h->ecp_lds && h->necp <= 64 && (long)h->necp * ((h->N + 63) / 64) <= 64 && tab_b <= 32768;
-    // (atom-major lists where the orbital kernel gains from them: periodic cells, whose per-lane image walks then have similar
-    // lengths within a tile — 2x2x2 diamond VMC +3 % at 32768 walkers; open systems gain nothing and pay a longer scan and sum)
-    const long nseg = (ecp_t && h->ecp_atom_major && h->S.pbc) ? h->necp : 1, nsw = nseg * W;
-    B.nseg = (int)nseg;
-    TRY(ensure(h, h->b_ecnt, 2 * nsw * sizeof(int)));
-    TRY(ensure(h, h->b_eoff, 2 * (nsw + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_ecp, (h->cplx ? 2 : 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_epass, (size_t)W * h->necp * ((h->N + 63) / 64) * sizeof(unsigned long long)));
-    B.local = (double*)h->b_elocal.p; B.cnt = (int*)h->b_ecnt.p; B.off = (long*)h->b_eoff.p;
-    B.passbits = (unsigned long long*)h->b_epass.p;
-    B.has_j2 = h->has_j2 ? 1 : 0;
-    B.ue = (soa_current && h->has_j2) ? (const double*)h->b_kpart.p + (size_t)4 * h->N * W : nullptr;  // k_kinetic_lw left U_e there
-    const dim3 g_t((unsigned)((W + PQA_ECP_WB - 1) / PQA_ECP_WB)), b_t(64 * PQA_ECP_WB);
-    if (ecp_t) {
-      if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count_t<true>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-      else hipLaunchKernelGGL(k_ecp_count_t<false>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-    } else
-    if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
-    else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
-    // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers)
-    TRY(ensure(h, h->b_tmmarks, 4 * sizeof(long)));
-    TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
-    TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
-    TRY(check_launch(h, "k_ecp_count/k_scan2"));
-    long tot[2];
-    TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
-    TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
-    h->last_ecp_points = tot[0] + tot[1];
-    for (int s = 0; s < 2; ++s) {
-      const size_t n = (size_t)std::max<long>(tot[s], 1);
-      TRY(ensure(h, h->b_epts[s], n * 3 * sizeof(double)));
-      TRY(ensure(h, h->b_ewgt[s], n * sizeof(double)));
-      TRY(ensure(h, h->b_epte[s], n * sizeof(int)));
-      TRY(ensure(h, h->b_eptw[s], n * sizeof(int)));
-      TRY(ensure(h, h->b_econ[s], (h->cplx ? 2 : 1) * n * sizeof(double)));
-      TRY(ensure(h, h->b_eu0[s], n * sizeof(double)));
-      B.ptw[s] = (int*)h->b_eptw[s].p;
-      B.u0[s] = (double*)h->b_eu0[s].p;
-      TRY(ensure(h, h->b_emo[s], n * std::max(h->nmo[s], 1) * sizeof(double)));
-      B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
-    }
-    if (tot[0] + tot[1] > 0) {
-      if (ecp_t) {
-        if (B.ue) {
-          if (h->S.pbc) hipLaunchKernelGGL((k_ecp_fill_t<true, true>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-          else hipLaunchKernelGGL((k_ecp_fill_t<false, true>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-        } else {
-          if (h->S.pbc) hipLaunchKernelGGL((k_ecp_fill_t<true, false>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-          else hipLaunchKernelGGL((k_ecp_fill_t<false, false>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
-        }
-      } else
-      if (h->S.pbc) hipLaunchKernelGGL(k_ecp_fill<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
-      else hipLaunchKernelGGL(k_ecp_fill<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
-      TRY(check_launch(h, "k_ecp_fill"));
-      if (h->has_slater)
-        for (int s = 0; s < 2; ++s)
-          TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
-    }
-    // wave-per-walker accumulation (complex determinants, several determinants, three-body factor): four waves share a walker's
-    // points while the launch is too small to fill the chip with one (measured after the three-body / determinant-pass fixes: C4
-    // +7 % at 2048 walkers, even at 4096, -7 % at 8192; the 32-electron twisted cell +1 % at 1024, -1.5 % at 2048, -6 % at 8192)
-    const bool acc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
-#define PQA_ECP_ACC(PB, CXF, SC) do { const size_t st_ = (size_t)(SC) * lds_det(h, 1); const int str_ = (int)(st_ / sizeof(double)); \
-      if (acc4) hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 4>), dim3((unsigned)W), dim3(256), 4 * st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
-                                   (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); \
-      else hipLaunchKernelGGL((k_ecp_accum<PB, CXF, 1>), dim3((unsigned)W), dim3(64), st_, h->stream, h->S, h->st, h->js, B, (int)h->has_slater, \
-                              (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, W, (double*)h->b_ecp.p, str_); } while (0)
-    const bool cx_points = h->cplx && soa_current && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_point_lw;  // thread per point on the complex planes
-    if (h->cplx && !cx_points) {  // complex determinants: wave-per-walker accumulation in complex arithmetic
-      if (h->S.pbc) PQA_ECP_ACC(true, true, 2); else PQA_ECP_ACC(false, true, 2);
-    } else
-    if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
-      for (int s = 0; s < 2; ++s) {
-        if (tot[s] <= 0) continue;
-        const dim3 g((unsigned)((tot[s] + 255) / 256));
-        const long n_s = s ? h->ndn : h->nup;
-        const double* Tb = soa_T ? (const double*)h->b_Tt[s].p : (const double*)h->st.T[s];
-        const long sw = soa_T ? 1 : n_s * n_s, si = soa_T ? n_s * W : n_s, sk = soa_T ? W : 1;
-        // (the planes are the live state whenever this evaluation follows a lane-per-walker sweep, also where the walker-major copy
-        // was refreshed for the caller's next step — the DMC loop's T-moves)
-        if (cx_points) {
-          if (h->S.pbc)
-            hipLaunchKernelGGL((k_ecp_point_lw<true, true>), g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
-                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
-          else
-            hipLaunchKernelGGL((k_ecp_point_lw<false, true>), g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
-                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
-        } else
-        if (soa_current && !h->cplx && h->ecp_point_lw) {
-          if (h->S.pbc)
-            hipLaunchKernelGGL(k_ecp_point_lw<true>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
-                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
-          else
-            hipLaunchKernelGGL(k_ecp_point_lw<false>, g, dim3(256), 0, h->stream, h->S, lw_state(h), B, s, (int)h->has_slater,
-                               (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], W, (double*)h->b_econ[s].p);
-        } else
-        if (h->S.pbc)
-          hipLaunchKernelGGL(k_ecp_point<true>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
-        else
-          hipLaunchKernelGGL(k_ecp_point<false>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
-                             (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
-      }
-      hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
-                         (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p, cx_points ? std::max<long>(tot[0], 1) : 0L,
-                         cx_points ? std::max<long>(tot[1], 1) : 0L);
-    } else {
-      if (h->S.pbc) PQA_ECP_ACC(true, false, 1); else PQA_ECP_ACC(false, false, 1);
-    }
-#undef PQA_ECP_ACC
-    TRY(check_launch(h, "k_ecp_accum"));
-    d_ecp = (const double*)h->b_ecp.p;
-  }
-  hipLaunchKernelGGL(k_energy_assemble, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
-                     h->ii_energy, W, (double*)h->b_en.p, (int)h->cplx);
-  return check_launch(h, "k_energy_assemble");
-}
-
-extern "C" int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,
-                             const double* ion_cos, const double* ion_sin, double ee_const, double ei_const, double ii,
-                             const int32_t* gidx, const double* recip) {
-  HIPCHK(hipSetDevice(h->device));
-  if (!h->S.pbc) FAIL("Ewald tables on an open-boundary handle");
-  if (ng < 0 || !(alpha > 0.0)) FAIL("bad Ewald parameters");
-  HIPCHK(hipStreamSynchronize(h->stream));
-  double* d;
-  TRY(upload_table(h, gpoints, (size_t)ng * 3, &d)); h->ew.g = d;
-  TRY(upload_table(h, gweight, (size_t)ng, &d)); h->ew.gweight = d;
-  TRY(upload_table(h, ion_cos, (size_t)ng, &d)); h->ew.ion_cos = d;
-  TRY(upload_table(h, ion_sin, (size_t)ng, &d)); h->ew.ion_sin = d;
-  h->ew.ng = ng; h->ew.alpha = alpha; h->ew.ee_const = ee_const; h->ew.ei_const = ei_const;
-  h->ew.gn = nullptr; h->ew.nmax = 0;
-  if (gidx && recip && ng > 0) {
-    std::vector<int> gi((size_t)ng * 3);
-    HIPCHK(hipMemcpy(gi.data(), gidx, gi.size() * sizeof(int), hipMemcpyDefault));
-    int nmax = 0;
-    for (int v : gi) nmax = std::max(nmax, std::abs(v));
-    const size_t lds = ((size_t)h->N * 3 + (size_t)h->N * 3 * (nmax + 1) * 2) * sizeof(double);
-    if (lds <= 64 * 1024) {  // otherwise stay with the direct sincos form
-      int* dgi;
-      TRY(upload_table(h, gi.data(), gi.size(), &dgi));
-      h->ew.gn = dgi; h->ew.nmax = nmax;
-      HIPCHK(hipMemcpy(h->ew.recip, recip, 9 * sizeof(double), hipMemcpyDefault));
-    }
-  }
-  h->ii_energy = ii;
-  h->ew_set = true;
-  return 0;
-}
-
-extern "C" int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap) {
-  HIPCHK(hipSetDevice(h->device));
-  if (!h->S.pbc) FAIL("open-boundary handle has no wrap counters");
-  if (h->wrap_W != h->W || h->W == 0) FAIL("no fused sweep has run on the resident walkers");
-  return copy_out(h, wrap, h->b_wrap.p, (size_t)h->W * h->N * 3 * sizeof(int));
-}
-
-extern "C" int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out) {
-  TRY(sync_aos(h));
-  HIPCHK(hipSetDevice(h->device));
-  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
-  h->saved_valid = false;
-  TRY(energy_dev(h, threshold, rot, unif, seed, 0u));
-  return copy_out(h, out, h->b_en.p, (size_t)(h->cplx ? 7 : 6) * h->W * sizeof(double));
-}
-
-// ---------------------------------------------------------------- walker-tile sweep (pqa_tile.hpp)
-static bool tile_eligible(const pqa_handle* h) {
-  if (h->lw_mode != 2 || !h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc) return false;
-  if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32) return false;
-  for (int l : h->shell_l)
-    if (l > 3) return false;
-  const int nmo_pad = 16 * std::max(h->nt[0], h->nt[1]);
-  return tile_lds_bytes(h->N, nmo_pad, h->nshell, (int)h->S.nprim, h->chunks[0].rows_pad) <= 160 * 1024 - 512;
-}
-// One sweep over all electrons for every walker, in one launch.  mb carries the step's tapes / seeds as for the other paths.
-static int sweep_tile(pqa_handle* h, const MoveBuf& mb_in) {
-  MoveBuf mb = mb_in;
-  if (!mb.gauss || !mb.unif) {  // no replay tapes: draw this sweep's numbers from the Philox streams first
-    const size_t NW = (size_t)h->N * h->W;
-    TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
-    TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, h->W,
-                       (double*)h->b_gauss.p, (double*)h->b_unif.p);
-    mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
-  }
-  const ChunkHost& c = h->chunks[0];
-  TileTab TT{};
-  TT.nmo_pad = 16 * std::max(h->nt[0], h->nt[1]);
-  TT.rows_pad = c.rows_pad;
-  TT.pass_chunk[0] = 0;
-  const int nch = (int)c.nk.size();
-  int ch = 0;
-  while (ch < nch) {  // greedy: consecutive chunks while their padded rows fit the LDS tile
-    if (TT.npass == PQA_TILE_MAXPASS) FAIL("walker-tile sweep: too many AO passes for this basis");
-    const int base = c.row0[ch];
-    int end = ch;
-    while (end < nch && c.row0[end] + ((c.nk[end] + 3) & ~3) - base <= PQA_TILE_KT) ++end;
-    if (end == ch) FAIL("walker-tile sweep: a chunk does not fit the AO tile");
-    ch = end;
-    TT.pass_chunk[++TT.npass] = ch;
-  }
-  const size_t lds = tile_lds_bytes(h->N, TT.nmo_pad, h->nshell, (int)h->S.nprim, TT.rows_pad);
-  const dim3 grid((unsigned)((h->W + PQA_TILE_NW - 1) / PQA_TILE_NW)), block(PQA_TILE_NT);
-  int lmax = 0;
-  for (int sh = 0; sh < h->nshell; ++sh) lmax = std::max(lmax, h->shell_l[sh]);
-  if (!h->tile_attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_sweep_tile<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    h->tile_attr_set = true;
-  }
-#define PQA_TILE_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_tile<D, LM>), grid, block, lds, h->stream, h->S, h->st, h->js, mb, h->tab[0], TT, (int)h->has_jastrow, h->W)
-  if (mb.dmc) { if (lmax <= 2) PQA_TILE_LAUNCH(true, 2); else PQA_TILE_LAUNCH(true, 3); }
-  else { if (lmax <= 2) PQA_TILE_LAUNCH(false, 2); else PQA_TILE_LAUNCH(false, 3); }
-#undef PQA_TILE_LAUNCH
-  return check_launch(h, "k_sweep_tile");
-}
-
-// ---------------------------------------------------------------- one sweep over the electrons (shared by VMC and DMC)
-struct LwCtx {
-  int Gm = 1, KB = 1, nmax = 1;
-};
-// Geometry of the lane-per-walker kernels and, when `lw`, the SoA copy of the state and its scratch.
-static int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
-  const long W = h->W;
-  // thread groups per walker in k_step_lw.  Measured (tools/scratch/r3_step_abl*.sh, (H2O)8 step in ms at 4 / 8 / 16 groups):
-  // 4096 walkers 6.38 / 5.15 / 4.67, 8192: 7.71 / 6.54 / 6.39, 16384: 10.7 / 9.8 / 11.1, 32768: 16.5 / 17.3 / 18.8, 65536: 30.8 / 32.7 / 37.3
-  c.Gm = 4;
-  while (c.Gm < 16 && (long)c.Gm * W < 2048L * 64) c.Gm *= 2;
-  if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 16);
-  c.nmax = std::max(h->nup, h->ndn);
-  // block size of the delayed Sherman-Morrison update: 4 from 16 electrons per spin (8 flushes at 32), 5 from 24 (7 flushes at 32:
-  // 35.60 -> 35.32 ms per step of the 64-electron benchmark; 6 is slower again — the per-move commit touches KB rows)
-  // small shards (every launch a latency chain, one block row per thread group): 8 — fewer flush launches and split step launches
-  // ((H2O)8 at 4096 walkers: 4.08 ms per step with 5, 3.97 with 8, 3.94 with 11, 4.01 with 16; 8192: 5.97 / 5.80 / 5.90 / 6.00)
-  const int kb = h->lw_kb < 0 ? (c.nmax >= 24 ? (W <= 8192 ? 8 : 5) : (c.nmax >= 16 ? 4 : 0)) : h->lw_kb;
-  c.KB = (kb > 0) ? std::min(kb, std::max(c.nmax, 1)) : std::max(c.nmax, 1);  // KB = n: plain per-move update
-  if (!lw) TRY(sync_aos(h));
-  if (lw) {
-    if (!h->aos_stale) TRY(lw_from_aos(h));  // (stale walker-major arrays: the planes ARE the state)
-    const size_t cf = h->cplx ? 2 : 1;
-    TRY(ensure(h, h->b_rbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_vbuf, cf * c.KB * std::max(c.nmax, 1) * W * sizeof(double)));
-    TRY(ensure(h, h->b_act, (size_t)c.KB * W));
-  }
-  return 0;
-}
-// Lane-per-walker sweep, two launches per move: k_orb at the proposal, then k_step_lw = decide electron e + propose electron
-// e + 1 (pqa_lw.hpp).  The two halves are launched apart where the blocked Sherman-Morrison update has to flush in between
-// (e + 1 opens a new electron block of the same spin: its inverse row is only current after k_flush_lw).
-template <bool PBC, bool CX>
-static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen) {
-  const dim3 grid((unsigned)((a.W + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
-  // small shards: the variant with every load issued at entry (k_step_pre, pqa_lw.hpp) where its scope covers the system
-  // (one block per CU at most: the kernel holds ~360 registers per lane, one wave per SIMD)
-  if (!CX && h->step_pre && a.NW < 64 && a.G >= 8 && grid.x <= 256 && h->S.occ_ident[0] && h->S.occ_ident[1] && h->S.nb <= PQA_JAS_NF && h->S.na <= PQA_JAS_NF &&
-      h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G) && rowlen <= 64) {
-#define PQA_STEP_P(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM) * a.NW * sizeof(double); \
-      hipLaunchKernelGGL((k_step_pre<PBC, NM>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
-    if (rowlen <= 8) PQA_STEP_P(8); else if (rowlen <= 16) PQA_STEP_P(16); else if (rowlen <= 32) PQA_STEP_P(32); else PQA_STEP_P(64);
-#undef PQA_STEP_P
-    return;
-  }
-  const size_t lds = (size_t)std::max(PQA_LW_PART_ROWS(CX) * a.G, 2 * rowlen) * a.NW * sizeof(double);
-#define PQA_STEP(NM) do { if (a.NW == 64) hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, true>), grid, block, lds, h->stream, h->S, L, mb, a); \
-                          else hipLaunchKernelGGL((k_step_lw<PBC, CX, NM, false>), grid, block, lds, h->stream, h->S, L, mb, a); } while (0)
-  if (rowlen <= 8) PQA_STEP(8); else if (rowlen <= 16) PQA_STEP(16); else if (rowlen <= 32) PQA_STEP(32); else PQA_STEP(64);
-#undef PQA_STEP
-}
-static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCtx& lc) {
-  const long W = h->W;
-  MoveBuf mb = mb_in;
-  if (!mb.gauss && !mb.unif && W <= h->draws_max) {
-    // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
-    // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD
-    const size_t NW = (size_t)h->N * W;
-    TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
-    TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W,
-                       (double*)h->b_gauss.p, (double*)h->b_unif.p);
-    mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
-  }
-  const int N = h->N, KB = lc.KB, nmax = lc.nmax;
-  const LwState L = lw_state(h);
-  const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
-  // thread groups per walker (lc.Gm: ~4 waves per SIMD's worth of threads) and walkers per block: 256 threads at most, so more
-  // than 4 groups narrow the block to 32 or 16 walkers — which is also what spreads a small shard over the chip
-  const int G = std::min(lc.Gm, 16);
-  int NW = (G <= 4) ? 64 : 256 / G;
-  if (h->lw_nw > 0 && h->lw_nw * G <= 256) NW = h->lw_nw;
-  auto step = [&](int e_acc, int e_prop) {
-    StepArgs a{};
-    a.e_acc = e_acc; a.e_prop = e_prop; a.has_jastrow = (int)h->has_jastrow; a.G = G; a.NW = NW; a.W = W;
-    if (e_acc >= 0) {
-      const int s = e_acc >= h->nup, n_s = s ? h->ndn : h->nup, i_s = e_acc - (s ? h->nup : 0);
-      const int q = i_s % KB;
-      a.j_lo = i_s - q; a.j_hi = std::min(a.j_lo + KB, n_s);
-      a.Rbuf = (double*)h->b_rbuf.p + (size_t)q * cfi * n_s * W;
-      a.Vbuf = (double*)h->b_vbuf.p + (size_t)q * cfi * n_s * W;
-      a.act = (uint8_t*)h->b_act.p + (size_t)q * W;
-    }
-    if (h->cplx) { if (h->S.pbc) launch_step_lw<true, true>(h, L, mb, a, rowlen); else launch_step_lw<false, true>(h, L, mb, a, rowlen); }
-    else { if (h->S.pbc) launch_step_lw<true, false>(h, L, mb, a, rowlen); else launch_step_lw<false, false>(h, L, mb, a, rowlen); }
-  };
-  step(-1, 0);
-  for (int e = 0; e < N; ++e) {
-    const int s = e >= h->nup, n_s = s ? h->ndn : h->nup, i_s = e - (s ? h->nup : 0);
-    const int q = i_s % KB, j_lo = i_s - q, j_hi = std::min(j_lo + KB, n_s);
-    // the proposal's rows go straight into the slot of electron i_s the walker is not using (accepting flips the selector)
-    TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_rc[s].p + (size_t)i_s * 2 * W * 5 * h->nmo[s],
-                   (const unsigned char*)h->b_sel[s].p + (size_t)i_s * W, (long)W * 5 * h->nmo[s]));
-    const bool block_done = (i_s == j_hi - 1);
-    const bool need_flush = block_done && (j_hi - j_lo < n_s);
-    // the next electron's inverse row is current after this move's commit unless it opens a new block of the SAME spin
-    const bool fuse_next = (e + 1 < N) && !(need_flush && i_s + 1 < n_s);
-    hipEvent_t pe1 = nullptr;
-    if (h->profile && (e % (4 * (int)h->prof_stride)) == 1) {  // sparsely sampled full (decide + propose) launches: an event pair costs ~2 us of stream time
-      if (h->prof3_used == h->prof3_events.size()) {
-        hipEvent_t a, b;
-        HIPCHK(hipEventCreate(&a));
-        HIPCHK(hipEventCreate(&b));
-        h->prof3_events.emplace_back(a, b);
-      }
-      if (fuse_next) {
-        HIPCHK(hipEventRecord(h->prof3_events[h->prof3_used].first, h->stream));
-        pe1 = h->prof3_events[h->prof3_used].second;
-        ++h->prof3_used;
-      }
-    }
-    step(e, fuse_next ? e + 1 : -1);
-    if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
-    if (need_flush) {  // block finished: bring every other row of this spin up to date
-      const int nq = j_hi - j_lo;
-      hipEvent_t ce1 = nullptr;
-      if (h->profile && ((j_lo / std::max(KB, 1)) % 4) == 0) {  // every 4th flush of a spin
-        if (h->prof2_used == h->prof2_events.size()) {
-          hipEvent_t a, b;
-          HIPCHK(hipEventCreate(&a));
-          HIPCHK(hipEventCreate(&b));
-          h->prof2_events.emplace_back(a, b);
-        }
-        HIPCHK(hipEventRecord(h->prof2_events[h->prof2_used].first, h->stream));
-        ce1 = h->prof2_events[h->prof2_used].second;
-        ++h->prof2_used;
-      }
-#define PQA_FLUSH_W(NM, WB_) do { const size_t lds_f = (size_t)2 * nq * cfi * n_s * WB_ * sizeof(double); const dim3 gf((unsigned)((W + WB_ - 1) / WB_)); \
-      if (h->cplx) hipLaunchKernelGGL((k_flush_lw<NM, true, WB_>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); \
-      else hipLaunchKernelGGL((k_flush_lw<NM, false, WB_>), gf, dim3(256), lds_f, h->stream, h->S, L, s, (const double*)h->b_vbuf.p, (const double*)h->b_rbuf.p, (const uint8_t*)h->b_act.p, W, j_lo, j_hi, nq); } while (0)
-#define PQA_FLUSH(NM) do { if (W <= h->flush_wb8_max) PQA_FLUSH_W(NM, 8); else PQA_FLUSH_W(NM, PQA_FLUSH_WB); } while (0)
-      if (rowlen <= 8) PQA_FLUSH(8); else if (rowlen <= 16) PQA_FLUSH(16); else if (rowlen <= 32) PQA_FLUSH(32); else PQA_FLUSH(64);
-#undef PQA_FLUSH_W
-#undef PQA_FLUSH
-      if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
-    }
-    if (!fuse_next && e + 1 < N) step(-1, e + 1);
-  }
-  return 0;
-}
-
-// One proposal per electron, in index order, on the SoA state (lw: two launches per move, above) or the AoS state with the
-// wave-per-walker kernels (multi-determinant, three-body, large complex determinants); mb.dmc selects the DMC variant.
-static int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) {
-  if (lw) return sweep_electrons_fused(h, mb, lc);
-  const long W = h->W;
-  const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
-  for (int e = 0; e < h->N; ++e) {
-    const int s = e >= h->nup;
-    const double* mo = (const double*)h->b_motmp.p;
-    if (h->cplx) {
-      hipLaunchKernelGGL(k_propose<true>, dim3((unsigned)W), dim3(64), 2 * lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
-                         (int)h->has_slater, (int)h->has_jastrow, W);
-      if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-      hipLaunchKernelGGL(k_accept<true>, dim3((unsigned)W), dim3(64), 2 * lds_acc, h->stream, h->S, h->st, h->js, mb, e,
-                         (int)h->has_slater, (int)h->has_jastrow, mo, W);
-      continue;
-    }
-    hipLaunchKernelGGL(k_propose<false>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, h->js, mb, e,
-                       (int)h->has_slater, (int)h->has_jastrow, W);
-    if (h->has_slater) TRY(launch_orb(h, s, plain_points(mb.newpos, W), W, 5, (double*)h->b_motmp.p));
-    hipLaunchKernelGGL(k_accept<false>, dim3((unsigned)W), dim3(64), lds_acc, h->stream, h->S, h->st, h->js, mb, e, (int)h->has_slater,
-                       (int)h->has_jastrow, mo, W);
-  }
-  return 0;
-}
-
-extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif, double threshold,
-                              const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
-                              double* energy_mean, uint8_t* accept_rec) {
-  HIPCHK(hipSetDevice(h->device));
-  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
-  if (nsteps <= 0) return 0;
-  const long W = h->W;
-  const int N = h->N;
-  h->saved_valid = false;
-  const int nmo_max = std::max(h->nmo[0], h->nmo[1]);
-  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
-  TRY(ensure(h, h->b_aux, (size_t)W * 8 * sizeof(double)));
-  TRY(ensure(h, h->b_accept, (size_t)W));
-  TRY(ensure(h, h->b_acccnt, (size_t)nsteps * sizeof(int)));
-  TRY(ensure(h, h->b_motmp, (size_t)W * 5 * std::max(nmo_max, 1) * sizeof(double)));
-  const int nen = h->cplx ? 7 : 6;  // energy rows: complex determinants add Im(ecp) = Im(total)
-  TRY(ensure(h, h->b_means, (size_t)nsteps * nen * sizeof(double)));
-  TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
-  HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * sizeof(int), h->stream));
-  HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
-  if (h->S.pbc) {  // wrap counters of this call's accepted moves (pqa_get_wrap)
-    TRY(ensure(h, h->b_dwrap, (size_t)W * 3 * sizeof(int)));
-    TRY(ensure(h, h->b_wrap, (size_t)W * N * 3 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->b_wrap.p, 0, (size_t)W * N * 3 * sizeof(int), h->stream));
-    h->wrap_W = W;
-  }
-  if (gauss) TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
-  if (unif) TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
-  if (accept_rec) TRY(ensure(h, h->b_accrec, (size_t)N * W));
-  const size_t nrot = (size_t)N * std::max(h->necp, 1);
-  const bool tile = tile_eligible(h);
-  const bool lw = !tile && h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && (!h->cplx || std::max(h->nup, h->ndn) <= 32);
-  LwCtx lc;
-  TRY(lw_setup(h, lw, lc));
-  for (int step = 0; step < nsteps; ++step) {
-    MoveBuf mb{};
-    mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
-    mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
-    if (h->S.pbc && !h->twist) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }  // twisted handles keep the walkers unfolded
-    if (gauss) {
-      TRY(copy_in(h, h->b_gauss.p, gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
-      mb.gauss = (const double*)h->b_gauss.p;
-    }
-    if (unif) {
-      TRY(copy_in(h, h->b_unif.p, unif + (size_t)step * N * W, (size_t)N * W * sizeof(double)));
-      mb.unif = (const double*)h->b_unif.p;
-    }
-    if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
-    if (tile) TRY(sweep_tile(h, mb));
-    else TRY(sweep_electrons(h, mb, lw, lc));
-    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
-    TRY(check_launch(h, "k_propose/k_accept"));
-    if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
-    if (energy_mean) {
-      TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
-                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false));
-      hipLaunchKernelGGL(k_row_means, dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
-      TRY(check_launch(h, "k_row_means"));
-    }
-  }
-  h->aos_stale = lw;  // converted back on demand (sync_aos)
-  h->jas_stale = h->has_j2;
-  std::vector<int> cnt(nsteps);
-  TRY(copy_out(h, cnt.data(), h->b_acccnt.p, (size_t)nsteps * sizeof(int)));
-  if (acceptance) {
-    std::vector<double> acc(nsteps);
-    for (int i = 0; i < nsteps; ++i) acc[i] = (double)cnt[i] / ((double)W * N);
-    HIPCHK(hipMemcpy(acceptance, acc.data(), nsteps * sizeof(double), hipMemcpyDefault));
-  }
-  if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * nen * sizeof(double), hipMemcpyDefault));
-  return 0;
-}
 
 // ---------------------------------------------------------------- branching on the device
 // dst row w <- src row idx[w]; rows of `row` doubles.  grid = (W, ceil(row / 1024)), block = 256 (4 doubles per thread)
@@ -2443,254 +1408,6 @@ extern "C" int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int
 }
 
 // device-wide exclusive scan c[n] -> o[n+1]; marks[k] = o[k*Wm] for k = 0..n/Wm (pqa_dmc.hpp)
-static int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks) {
-  const long nt = (n + 1023) / 1024;
-  TRY(ensure(h, h->b_tmtile, (size_t)(nt + 1) * sizeof(long)));
-  long* tile = (long*)h->b_tmtile.p;
-  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nt), dim3(1024), 0, h->stream, c, o, n, tile);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, tile, nt);
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nt), dim3(1024), 0, h->stream, o, n, (const long*)tile, nt, Wm, marks);
-  return check_launch(h, "k_scan_local/tiles/add");
-}
-
-// ---------------------------------------------------------------- fused DMC propagation
-// nsteps steps of dmc_propagate (pyqmc/method/dmc.py:123-221) without leaving the device: T-moves, drift-diffusion with
-// fixed-node rejection, local energy, weight update, weighted step averages.  Walker-per-wave kernels (the AoS state).
-extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double branchcut, double e_trial, double e_est, double threshold,
-                             double* weights, const pqa_dmc_tapes_t* tp, uint64_t seed, double* step_avg, double* step_acc) {
-  TRY(sync_aos(h));  // (the starting energy and the first T-moves read the walker-major state)
-  HIPCHK(hipSetDevice(h->device));
-  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
-  if (nsteps <= 0) return 0;
-  if (!weights || !step_avg || !step_acc) FAIL("pqa_dmc_steps: weights / step_avg / step_acc must not be NULL");
-  const int navg = h->cplx ? 8 : 7;  // numbers per step in step_avg (complex: + the weighted mean of Im ecp = Im total)
-  const long W = h->W;
-  const int N = h->N, necp = h->necp, P = h->tm_P;
-  const bool tmoves = necp > 0 && P > 0;
-  if (tp && (!tp->gauss || !tp->unif)) FAIL("pqa_dmc_steps: a tape set needs gauss and unif");
-  if (tp && necp > 0 && (!tp->ecp_rot || !tp->ecp_unif)) FAIL("pqa_dmc_steps: a tape set needs ecp_rot and ecp_unif for ECP systems");
-  if (tp && tmoves && (!tp->tm_rot || !tp->tm_unif || !tp->tm_u1 || !tp->tm_u2)) FAIL("pqa_dmc_steps: a tape set needs the four T-move tapes");
-  h->saved_valid = false;
-  const int nmo_max = std::max(std::max(h->nmo[0], h->nmo[1]), 1);
-  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
-  TRY(ensure(h, h->b_aux, (size_t)W * 8 * sizeof(double)));
-  TRY(ensure(h, h->b_accept, (size_t)W));
-  TRY(ensure(h, h->b_acccnt, (size_t)nsteps * 2 * sizeof(int)));
-  TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo_max * sizeof(double)));
-  TRY(ensure(h, h->b_accw, (size_t)W * sizeof(int)));
-  TRY(ensure(h, h->b_dmcw, (size_t)W * sizeof(double)));
-  TRY(ensure(h, h->b_dmcold, (size_t)2 * W * sizeof(double)));
-  TRY(ensure(h, h->b_dmcr2, (size_t)2 * W * sizeof(double)));
-  TRY(ensure(h, h->b_dmcout, (size_t)nsteps * navg * sizeof(double)));
-  HIPCHK(hipMemsetAsync(h->b_acccnt.p, 0, (size_t)nsteps * 2 * sizeof(int), h->stream));
-  HIPCHK(hipMemsetAsync(h->b_accw.p, 0, (size_t)W * sizeof(int), h->stream));
-  HIPCHK(hipMemsetAsync(h->b_dmcr2.p, 0, (size_t)2 * W * sizeof(double), h->stream));
-  TRY(copy_in(h, h->b_dmcw.p, weights, (size_t)W * sizeof(double)));
-  if (h->S.pbc) {
-    TRY(ensure(h, h->b_dwrap, (size_t)W * 3 * sizeof(int)));
-    TRY(ensure(h, h->b_wrap, (size_t)W * N * 3 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->b_wrap.p, 0, (size_t)W * N * 3 * sizeof(int), h->stream));
-    h->wrap_W = W;
-  }
-  if (tp) {
-    TRY(ensure(h, h->b_gauss, (size_t)N * W * 3 * sizeof(double)));
-    TRY(ensure(h, h->b_unif, (size_t)N * W * sizeof(double)));
-  }
-  const size_t nrot = (size_t)N * std::max(necp, 1);
-  const int nkw = (std::max(necp, 1) + 63) / 64;
-  if (tmoves) {
-    const size_t NW = (size_t)N * W;
-    TRY(ensure(h, h->b_tmcnt, NW * sizeof(int)));
-    TRY(ensure(h, h->b_tmoff, (NW + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_tmpass, NW * nkw * sizeof(unsigned long long)));
-    TRY(ensure(h, h->b_tmacc, NW * sizeof(int)));
-    TRY(ensure(h, h->b_tmaoff, (NW + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_tmmarks, (size_t)(N + 1) * sizeof(long)));
-    TRY(ensure(h, h->b_tmidx, NW * sizeof(int)));
-    TRY(ensure(h, h->b_tmapos, NW * 3 * sizeof(double)));
-    if (tp) TRY(ensure(h, h->b_tmu, (size_t)(2 + necp) * NW * sizeof(double)));
-    TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
-  }
-  const bool lw = h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && (!h->cplx || std::max(h->nup, h->ndn) <= 32);
-  LwCtx lc;
-  TRY(lw_setup(h, lw, lc));
-  const dim3 gw256((unsigned)((W + 255) / 256));
-  double* eold = (double*)h->b_dmcold.p;
-  double* r2 = (double*)h->b_dmcr2.p;
-  std::vector<long> tm_accepted((size_t)nsteps, 0);
-  // energy of the starting configuration (dmc.py:146-149)
-  TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
-  hipLaunchKernelGGL(k_dmc_keep, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
-  for (int step = 0; step < nsteps; ++step) {
-    MoveBuf mb{};
-    mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
-    mb.acc_w = (int*)h->b_accw.p; mb.seed = seed; mb.step = (uint32_t)step; mb.tstep = tstep;
-    mb.dmc = 1; mb.r2_acc = r2; mb.r2_prop = r2 + W;
-    if (h->S.pbc && !h->twist) { mb.dwrap = (int*)h->b_dwrap.p; mb.wrap = (int*)h->b_wrap.p; }  // twisted handles keep the walkers unfolded
-    if (tmoves) {
-      const size_t NW = (size_t)N * W;
-      TmBuf B{};
-      B.quad = h->d_quad; B.seed = seed; B.step = (uint32_t)step; B.tau = tstep; B.threshold = threshold; B.nofold = h->twist ? 1 : 0;
-      B.cnt = (int*)h->b_tmcnt.p; B.off = (long*)h->b_tmoff.p; B.pass = (unsigned long long*)h->b_tmpass.p;
-      long* d_marks = (long*)h->b_tmmarks.p;
-      B.acc = (int*)h->b_tmacc.p; B.acc_off = (long*)h->b_tmaoff.p;
-      B.acc_idx = (int*)h->b_tmidx.p; B.acc_pos = (double*)h->b_tmapos.p;
-      if (tp) {
-        double* u = (double*)h->b_tmu.p;
-        TRY(copy_in(h, h->b_rot.p, tp->tm_rot + (size_t)step * nrot * 9, nrot * 9 * sizeof(double)));
-        TRY(copy_in(h, u, tp->tm_u1 + (size_t)step * NW, NW * sizeof(double)));
-        TRY(copy_in(h, u + NW, tp->tm_u2 + (size_t)step * NW, NW * sizeof(double)));
-        TRY(copy_in(h, u + 2 * NW, tp->tm_unif + (size_t)step * NW * necp, NW * necp * sizeof(double)));
-        B.u1 = u; B.u2 = u + NW; B.unif = u + 2 * NW;
-      } else {
-        hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed ^ 0x9E3779B97F4A7C15ull,
-                           (uint32_t)step, (double*)h->b_rot.p);
-        TRY(check_launch(h, "k_gen_rot"));
-      }
-      B.rot = (const double*)h->b_rot.p;
-      HIPCHK(hipMemsetAsync(B.acc, 0, NW * sizeof(int), h->stream));
-      hipLaunchKernelGGL(k_tm_count, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W);
-      TRY(check_launch(h, "k_tm_count"));
-      TRY(scan_ints(h, (const int*)B.cnt, B.off, (long)NW, W, d_marks));
-      std::vector<long> eoff((size_t)N + 1);  // first candidate of every electron
-      TRY(copy_out(h, eoff.data(), d_marks, eoff.size() * sizeof(long)));
-      const long tot = eoff[N], tot_up = eoff[h->nup];
-      if (tot > 0) {
-        TRY(ensure(h, h->b_tpos, (size_t)tot * 3 * sizeof(double)));
-        TRY(ensure(h, h->b_twgt, (size_t)tot * sizeof(double)));
-        TRY(ensure(h, h->b_tmamp, (size_t)tot * 2 * sizeof(double)));
-        TRY(ensure(h, h->b_tmptw, (size_t)tot * sizeof(int)));
-        B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot;
-        B.ptw = (int*)h->b_tmptw.p;
-        hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W, (unsigned)N), dim3(64), 0, h->stream, h->S, h->js, B, W);
-        TRY(check_launch(h, "k_tm_fill"));
-        const long cnt_s[2] = {tot_up, tot - tot_up}, base_s[2] = {0, tot_up};
-        if (h->has_slater)
-          for (int s = 0; s < 2; ++s) {
-            if (cnt_s[s] == 0) continue;
-            TRY(ensure(h, h->b_emo[s], (size_t)cnt_s[s] * nmo_max * sizeof(double)));
-            TRY(launch_orb(h, s, plain_points(B.pts + 3 * base_s[s], cnt_s[s]), cnt_s[s], 1, (double*)h->b_emo[s].p));
-          }
-        // ratios of all candidates against the state before the first T-move: one thread per candidate (k_tm_ratio)
-        const bool pre = h->ndet == 1 && !h->has_j3 && !h->cplx && h->tm_pre;
-        // U_e of every electron at its current position: from the second step of a call on, the energy evaluation that closed the
-        // previous step left exactly that ([N][W], k_kinetic_lw) — the walkers have not moved since
-        const double* d_uold = nullptr;
-        if (pre && h->has_jastrow) {
-          if (lw && step > 0 && h->has_j2 && !h->has_j3) d_uold = (const double*)h->b_kpart.p + (size_t)4 * NW;
-          else {
-            TRY(ensure(h, h->b_tmuold, (size_t)NW * sizeof(double)));
-            hipLaunchKernelGGL(k_tm_uold, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
-            d_uold = (const double*)h->b_tmuold.p;
-          }
-        }
-        if (pre)
-          for (int s = 0; s < 2; ++s) {
-            if (cnt_s[s] == 0) continue;
-            const dim3 g((unsigned)((cnt_s[s] + 255) / 256));
-            hipLaunchKernelGGL(k_tm_ratio, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater, (int)h->has_jastrow,
-                               (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, d_uold);
-          }
-        const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
-        if (h->cplx) hipLaunchKernelGGL(k_tm_walker<true>, dim3((unsigned)W), dim3(64), 2 * lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                                        (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, 0);
-        else hipLaunchKernelGGL(k_tm_walker<false>, dim3((unsigned)W), dim3(64), lds_tm, h->stream, h->S, h->st, h->js, B, (int)h->has_slater,
-                                (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, pre ? 1 : 0);
-        TRY(check_launch(h, "k_tm_walker"));
-        TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
-        hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
-        TRY(check_launch(h, "k_tm_gather"));
-        TRY(copy_out(h, eoff.data(), d_marks, eoff.size() * sizeof(long)));
-        const long nacc[2] = {eoff[N], eoff[h->nup]};
-        tm_accepted[step] = nacc[0];
-        if (h->has_slater) {  // gradient / Laplacian rows of the moved electrons, one launch per spin
-          const long na_s[2] = {nacc[1], nacc[0] - nacc[1]}, a0_s[2] = {0, nacc[1]};
-          for (int s = 0; s < 2; ++s) {
-            if (na_s[s] == 0) continue;
-            TRY(ensure(h, h->b_emo[s], (size_t)na_s[s] * 5 * nmo_max * sizeof(double)));
-            TRY(launch_orb(h, s, plain_points(B.acc_pos + 3 * a0_s[s], na_s[s]), na_s[s], 5, (double*)h->b_emo[s].p));
-            hipLaunchKernelGGL(k_tm_cache, dim3((unsigned)na_s[s]), dim3(64), 0, h->stream, h->S, h->st, (const int*)(B.acc_idx + a0_s[s]),
-                               (const double*)h->b_emo[s].p, s, W, lw ? (double*)h->b_rc[s].p : (double*)nullptr, lw ? (const uint8_t*)h->b_sel[s].p : (const uint8_t*)nullptr);
-          }
-          TRY(check_launch(h, "k_tm_cache"));
-        }
-      }
-    }
-    if (tp) {
-      TRY(copy_in(h, h->b_gauss.p, tp->gauss + (size_t)step * N * W * 3, (size_t)N * W * 3 * sizeof(double)));
-      TRY(copy_in(h, h->b_unif.p, tp->unif + (size_t)step * N * W, (size_t)N * W * sizeof(double)));
-      mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
-    }
-    if (lw && tmoves) TRY(lw_from_aos(h, false));  // the T-moves worked on the AoS coordinates and inverses
-    TRY(sweep_electrons(h, mb, lw, lc));
-    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + 2 * step);
-    TRY(check_launch(h, "k_propose/k_accept (dmc)"));
-    TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot + (size_t)(step + 1) * nrot * 9 : nullptr,
-                   (tp && necp) ? tp->ecp_unif + (size_t)(step + 1) * nrot * W : nullptr, seed, (uint32_t)(step + 1), lw));
-    hipLaunchKernelGGL(k_dmc_weights, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
-                       (double*)h->b_dmcw.p, tstep, branchcut, e_trial, e_est, N, W);
-    hipLaunchKernelGGL(k_dmc_averages, dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
-                       (double*)h->b_dmcout.p + (size_t)step * navg, h->cplx ? 7 : 6);
-    TRY(check_launch(h, "k_dmc_weights/k_dmc_averages"));
-  }
-  if (lw) TRY(lw_to_aos(h, true));
-  h->jas_stale = h->has_j2;
-  std::vector<int> cnt((size_t)nsteps * 2);
-  TRY(copy_in(h, step_avg, h->b_dmcout.p, (size_t)nsteps * navg * sizeof(double)));
-  TRY(copy_in(h, weights, h->b_dmcw.p, (size_t)W * sizeof(double)));
-  TRY(copy_out(h, cnt.data(), h->b_acccnt.p, cnt.size() * sizeof(int)));
-  for (int i = 0; i < nsteps; ++i) {
-    step_acc[2 * i] = (double)cnt[2 * i] / ((double)W * N);
-    step_acc[2 * i + 1] = (double)tm_accepted[i] / ((double)W * N);
-  }
-  return 0;
-}
-
-extern "C" int pqa_tmove_npoints(pqa_handle_t* h) { return h->tm_P; }
-
-extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif,
-                          double* ratio, double* weight, double* pos) {
-  TRY(sync_aos(h));
-  HIPCHK(hipSetDevice(h->device));
-  if (h->cplx && ratio) FAIL("pqa_tmoves: complex orbitals — pass ratio = NULL (positions and weights only) and take the ratios from pqa_wf_testvalue");
-  if (h->W == 0) FAIL("state not initialised (call recompute)");
-  if (e < 0 || e >= h->N) FAIL("electron index out of range");
-  const long W = h->W;
-  const int P = h->tm_P, s = e >= h->nup;
-  if (P == 0) return 0;
-  if (!rot || !unif) FAIL("pqa_tmoves needs the rotation and mask-uniform tapes");
-  h->saved_valid = false;
-  const size_t np = (size_t)W * P;
-  TRY(ensure(h, h->b_rot, (size_t)h->necp * 9 * sizeof(double)));
-  TRY(ensure(h, h->b_eunif, (size_t)h->necp * W * sizeof(double)));
-  TRY(ensure(h, h->b_tpos, np * 3 * sizeof(double)));
-  TRY(ensure(h, h->b_twgt, np * sizeof(double)));
-  TRY(ensure(h, h->b_tlive, np));
-  TRY(ensure(h, h->b_trat, np * sizeof(double)));
-  TRY(copy_in(h, h->b_rot.p, rot, (size_t)h->necp * 9 * sizeof(double)));
-  TRY(copy_in(h, h->b_eunif.p, unif, (size_t)h->necp * W * sizeof(double)));
-  hipLaunchKernelGGL(k_tmove_points, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, tau, threshold,
-                     (const double*)h->b_rot.p, (const double*)h->b_eunif.p, (const double*)h->d_quad, (const int*)h->d_ptk,
-                     (const int*)h->d_pti, P, W, (double*)h->b_tpos.p, (double*)h->b_twgt.p, (uint8_t*)h->b_tlive.p);
-  TRY(check_launch(h, "k_tmove_points"));
-  if (!ratio) {  // candidate positions and weights only (dead candidates carry weight 0)
-    TRY(copy_in(h, weight, h->b_twgt.p, np * sizeof(double)));
-    return copy_out(h, pos, h->b_tpos.p, np * 3 * sizeof(double));
-  }
-  if (h->has_slater) {
-    TRY(ensure(h, h->b_motmp, np * std::max(h->nmo[s], 1) * sizeof(double)));
-    TRY(launch_orb(h, s, plain_points((const double*)h->b_tpos.p, (long)np), (long)np, 1, (double*)h->b_motmp.p));
-  }
-  hipLaunchKernelGGL(k_tmove_ratio, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, e, (int)h->has_slater,
-                     (int)h->has_jastrow, (const double*)h->b_motmp.p, (const double*)h->b_tpos.p, (const uint8_t*)h->b_tlive.p, P,
-                     (double*)h->b_trat.p);
-  TRY(check_launch(h, "k_tmove_ratio"));
-  TRY(copy_in(h, ratio, h->b_trat.p, np * sizeof(double)));
-  TRY(copy_in(h, weight, h->b_twgt.p, np * sizeof(double)));
-  return copy_out(h, pos, h->b_tpos.p, np * 3 * sizeof(double));
-}
-
-// ---------------------------------------------------------------- measurement
 // ---------------------------------------------------------------- density-matrix sampling (pqa_dm.hpp)
 extern "C" int pqa_dm_walk(pqa_handle_t* h, int slot, int spin, int64_t n, int nsamples, double tstep, double* pos, const double* gauss,
                            const double* unif, uint64_t seed, int nkeep, double* keep_pos, double* accept) {

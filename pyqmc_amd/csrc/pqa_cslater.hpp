@@ -31,7 +31,7 @@ __device__ __forceinline__ cx wave_sum_cx(cx a) { return {wave_sum(a.r), wave_su
 
 // ---------------------------------------------------------------- build + invert
 // grid = W * ndet_s blocks of 64 threads; dynamic LDS: 2 * n * (n+1) doubles + n ints.
-__global__ __launch_bounds__(64) void k_build_invert_c(SysDev S, SlaterState st, int s, long W) {
+static __global__ __launch_bounds__(64) void k_build_invert_c(SysDev S, SlaterState st, int s, long W) {
   extern __shared__ double lds[];
   const int n = s ? S.ndn : S.nup, nmo2 = S.nmo[s], nmo = nmo2 / 2, D = S.ndet_s[s];
   if (n == 0) return;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void slater_value_wave_c(const SysDev& S, const Slate
   logv = clamp_nan_to_num(log(m) + ref);
 }
 
-__global__ __launch_bounds__(64) void k_slater_value_c(SysDev S, SlaterState st, double* sign, double* logv) {
+static __global__ __launch_bounds__(64) void k_slater_value_c(SysDev S, SlaterState st, double* sign, double* logv) {
   const long w = blockIdx.x;
   cx ph;
   double lv;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void slater_ratios_c(const SysDev& S, const SlaterSta
 
 // out (NCOMP, nrow*npt) complex (interleaved); mo rows [(r*npt+q)][NCOMP][2 nmo]; LDS: max(ndet_s)*NCOMP*2 doubles
 template <int NCOMP>
-__global__ __launch_bounds__(64) void k_slater_eval_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, long nrow,
+static __global__ __launch_bounds__(64) void k_slater_eval_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, long nrow,
                                                       int npt, const int* __restrict__ widx, double* __restrict__ out) {
   extern __shared__ double lds[];
   const long r = blockIdx.x;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void sm_update_wave_c(const SysDev& S, const SlaterSt
   }
 }
 
-__global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, int row_stride,
+static __global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, int row_stride,
                                                     const uint8_t* __restrict__ mask, int to_cache) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;

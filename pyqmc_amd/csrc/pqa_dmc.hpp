@@ -48,7 +48,7 @@ struct TmBuf {
 // when its turn comes, and the mask / rotation draws do not depend on the state, so positions, weights and orbital
 // values are those the reference computes one electron at a time (dmc.py:160-168); only the ratios need the loop.
 // grid = (ceil(W/256), N), block = 256.
-__global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, long W) {
+static __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.y;
   if (w >= W) return;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmB
 // ~2 ms; this is ~20 us): k_scan_local scans 1024-element tiles and emits tile totals, k_scan_tiles scans those (one block),
 // k_scan_add adds the tile offsets and copies o[k*W] (k = 0..n/W) to marks[] — the per-electron totals the host reads back
 // in one small copy to size the launches.
-__global__ __launch_bounds__(1024) void k_scan_local(const int* __restrict__ c, long* __restrict__ o, long n, long* __restrict__ tile_sum) {
+static __global__ __launch_bounds__(1024) void k_scan_local(const int* __restrict__ c, long* __restrict__ o, long n, long* __restrict__ tile_sum) {
   __shared__ long wsum[16];
   const long i = (long)blockIdx.x * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(1024) void k_scan_local(const int* __restrict__ c, 
   __syncthreads();
   if (i < n) o[i] = wsum[wv] + x - v;
 }
-__global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long nt) {  // in place, t[nt] = total
+static __global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long nt) {  // in place, t[nt] = total
   __shared__ long part[1024];
   const long per = (nt + 1023) / 1024;
   const long b = (long)threadIdx.x * per, e = (b + per < nt) ? b + per : nt;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long 
   long run = part[threadIdx.x];
   for (long i = b; i < e; ++i) { const long v = t[i]; t[i] = run; run += v; }
 }
-__global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, long n, const long* __restrict__ tile_off, long nt, long W,
+static __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, long n, const long* __restrict__ tile_off, long nt, long W,
                                                    long* __restrict__ marks) {
   const long i = (long)blockIdx.x * 1024 + threadIdx.x;
   if (i < n) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, long n,
 
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
 // grid = (W, N), block = 64.
-__global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, long W) {
+static __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = blockIdx.x;
   const int e = blockIdx.y;
   const int lane = threadIdx.x;
@@ -260,7 +260,7 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
 
 // U_e at the CURRENT position of every (electron, walker) that has candidates: -log of the denominator all of its candidates
 // share (computed once here instead of once per candidate).  uold: [N][W].  grid = (ceil(W/256), N), block = 256.
-__global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBuf B, long W, double* __restrict__ uold) {
+static __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBuf B, long W, double* __restrict__ uold) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.y;
   if (w >= W || B.cnt[(size_t)e * W + w] == 0) return;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBu
   uold[(size_t)e * W + w] = uo;
 }
 
-__global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int s, int has_slater, int has_jastrow,
+static __global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int s, int has_slater, int has_jastrow,
                                                   const double* __restrict__ mo, long p_base, long npts, long W, const double* __restrict__ uold) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
   if (q >= npts) return;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, Jast
 // from the reference with the real part of the ratios handed to those very lines — is amplitudes from Re[Psi(R')/Psi(R)]:
 // `rat` below is that real part, the commit is the full complex Sherman-Morrison update.
 template <bool CX>
-__global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, JastrowState js, TmBuf B, int has_slater, int has_jastrow,
+static __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, JastrowState js, TmBuf B, int has_slater, int has_jastrow,
                                                   const double* __restrict__ mo_up, const double* __restrict__ mo_dn, long tot_up, long W, int precomputed) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState st, Jast
 
 // ascending list of the (electron, walker) pairs whose T-move was accepted in this step, with their (new) positions:
 // entry acc_off[i] of the list for every flagged i = e*W + w.  grid = ceil(N*W/256), block = 256.
-__global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __restrict__ x, int nelec, long W) {
+static __global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __restrict__ x, int nelec, long W) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nelec * W || !B.acc[i]) return;
   const long el = i / W, w = i - el * W, a = B.acc_off[i];
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __rest
 // orbital-row cache (value, gradient, Laplacian) of the accepted T-moves of one spin.  mo5: [count][5][nmo_s] rows at the
 // new positions, idx: the matching (e*W + w) entries.  rc / sel: the two-slot row cache of the lane-per-walker sweep when that
 // holds the live cache (the row replaces the CURRENT slot's), else NULL (st.cache).  grid = count, block = 64.
-__global__ __launch_bounds__(64) void k_tm_cache(SysDev S, SlaterState st, const int* __restrict__ idx, const double* __restrict__ mo5,
+static __global__ __launch_bounds__(64) void k_tm_cache(SysDev S, SlaterState st, const int* __restrict__ idx, const double* __restrict__ mo5,
                                                  int s, long W, double* __restrict__ rc, const uint8_t* __restrict__ sel) {
   const long a = blockIdx.x;
   const long i = idx[a];
@@ -509,7 +509,7 @@ __device__ __forceinline__ double dmc_S(double e_trial, double e_est, double bra
 
 // weights *= exp(tau (r2_acc / r2_prop) (S_new + S_old)/2); the new energy becomes the old one; statistics reset.
 // en: rows ke, ee, ei, ecp, grad2, total of the NEW configuration.  eold/v2old: [W].
-__global__ __launch_bounds__(256) void k_dmc_weights(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old,
+static __global__ __launch_bounds__(256) void k_dmc_weights(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old,
                                                      double* __restrict__ r2_acc, double* __restrict__ r2_prop,
                                                      double* __restrict__ weights, double tau, double branchcut, double e_trial,
                                                      double e_est, int nelec, long W) {
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void k_dmc_weights(const double* __restrict__ 
   r2_acc[w] = 0.0; r2_prop[w] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old, long W) {
+static __global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old, long W) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
   eold[w] = en[5 * W + w]; v2old[w] = en[4 * W + w];
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en,
 // out[0..5] = sum_w weights[w] en[k][w] / sum_w weights[w] (the reference's dot(weights, v)/(W wavg), dmc.py:205-209),
 // out[6] = mean weight; complex wave functions (nrow = 7: the energy buffer's row 6 is Im ecp = Im total) also out[7] = the
 // weighted mean of that row.  One block of 1024 threads, deterministic.
-__global__ __launch_bounds__(1024) void k_dmc_averages(const double* __restrict__ en, const double* __restrict__ weights, long W,
+static __global__ __launch_bounds__(1024) void k_dmc_averages(const double* __restrict__ en, const double* __restrict__ weights, long W,
                                                        double* __restrict__ out, int nrow) {
   __shared__ double part[8][1024];
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};

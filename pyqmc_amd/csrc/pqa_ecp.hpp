@@ -99,7 +99,7 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int& total) {
 
 // pass A: k_ecp_count for necp <= 64 with the tables in LDS.  grid = ceil(W / PQA_ECP_WB), block = 64 * PQA_ECP_WB, dynamic LDS = ecp_tab_bytes.
 template <bool PBC>
-__global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, JastrowState js, EcpBuf B, int nchan, int nterm, long W) {
+static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, JastrowState js, EcpBuf B, int nchan, int nterm, long W) {
   extern __shared__ double lds[];
   __shared__ unsigned long long pb_[PQA_ECP_WB][64];  // electrons of the current block that passed the mask at atom k
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S, Jastr
 // UE: the old-position Jastrow exponents come from B.ue (k_kinetic_lw evaluates U_e of every electron anyway and ran just before);
 // otherwise the 16 lanes of a group sum the entry's exponent themselves.
 template <bool PBC, bool UE>
-__global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, JastrowState js, EcpBuf B, int nchan, int nterm, long W) {
+static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, JastrowState js, EcpBuf B, int nchan, int nterm, long W) {
   extern __shared__ double lds[];
   __shared__ int el_[PQA_ECP_WB][64];   // entries of the current window: atom << 16 | electron
   __shared__ long eo_[PQA_ECP_WB][64];  // their first slot in the spin's point list
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S, Jastro
 // contributions go to contrib[npts + p].  (k_ecp_accum walked a walker's points one after the other on one wave, 16 of its lanes
 // busy in the 16-electron dots: 0.99 ms per evaluation of the twisted 32-electron cell at 8 192 walkers, 11 % of its step.)
 template <bool PBC, bool CX = false>
-__global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBuf B, int s, int has_slater, int has_jastrow,
+static __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBuf B, int s, int has_slater, int has_jastrow,
                                                       const double* __restrict__ mo, long npts, long W, double* __restrict__ contrib) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= npts) return;

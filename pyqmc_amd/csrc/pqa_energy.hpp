@@ -19,7 +19,7 @@
 // rows i = v, v + NWV, ... of the Coulomb sums; the block adds the waves' sums in wave order.  All waves run the same number of
 // rounds (the helpers use block barriers): a surplus round repeats the last electron and adds nothing.
 template <bool CX, int NWV = 1>
-__global__ __launch_bounds__(64 * NWV) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
+static __global__ __launch_bounds__(64 * NWV) void k_kinetic_coulomb(SysDev S, SlaterState st, JastrowState js, int has_slater,
                                                               int has_jastrow, long W, double* __restrict__ out, int lds_stride) {
   extern __shared__ double lds_all[];
   __shared__ double wsum[4][NWV];
@@ -104,7 +104,7 @@ struct EwaldDev {
   int nmax;               // max |gn| component
 };
 #define PQA_EWALD_T 256  // threads per walker: the phase tables cost ~20 KB of LDS per block, so one wave per block left 1-2 waves per SIMD
-__global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
+static __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
                                               long W, double* __restrict__ out) {
   extern __shared__ double lds[];  // [N][3] coordinates of this walker
   // erfc(x) = erfcx(x) exp(-x^2), erfcx from the generated piecewise polynomials (tools/gen_erfc_table.py: 52 intervals, degree 9,
@@ -331,7 +331,7 @@ __device__ __forceinline__ bool ecp_pass(const SysDev& S, const EcpBuf& B, long 
 // passbits[w][k][e-block]: which electrons passed the stochastic mask at atom k (k_ecp_fill walks them atom-major).
 // PBC = false compiles the minimal-image code out: its register demand cost the open-system launches a wave per SIMD.
 template <bool PBC>
-__global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, EcpBuf B, long W) {
+static __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, EcpBuf B, long W) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState js, Ecp
 }
 
 // exclusive scan of cnt[2][W] -> off[2][W+1]; one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, long* __restrict__ off, long W) {
+static __global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, long* __restrict__ off, long W) {
   __shared__ long part[1024];
   for (int s = 0; s < 2; ++s) {
     const int* c = cnt + (size_t)s * W;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, lon
 
 // pass B: emit auxiliary points, per-point weights and electron index.  grid = W, block = 64.
 template <bool PBC>
-__global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpBuf B, long W) {
+static __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpBuf B, long W) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState js, EcpB
 // ANY wave meets a new electron.
 // CX: complex determinants; the imaginary part of the walker's sum goes to ecp[W + w].
 template <bool PBC, bool CX = false, int NWV = 1>
-__global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
+static __global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int has_slater,
                                                         int has_jastrow, const double* __restrict__ mo_up,
                                                         const double* __restrict__ mo_dn, long W, double* __restrict__ ecp,
                                                         int lds_stride) {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterState st
 }
 
 // uniformly random rotations from a normalised Gaussian quaternion (one per (electron, ECP atom))
-__global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __restrict__ rot) {
+static __global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __restrict__ rot) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= count) return;
   double q0, q1, q2, q3;
@@ -575,7 +575,7 @@ __global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __res
 
 // total = ke + ee + ei + ecp + ii ; rows of out: ke, ee, ei, ecp, grad2, total  (accumulators.py:68-75)
 // complex determinants: a 7th row holds Im(ecp) = Im(total) (eval_ecp.py:89, accumulators.py:74).
-__global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2*/, const double* __restrict__ ecp,
+static __global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2*/, const double* __restrict__ ecp,
                                   double ii, long W, double* __restrict__ out, int cplx) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
@@ -586,7 +586,7 @@ __global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2
 }
 
 // deterministic column means of a (nrow, W) array: one block of 256 threads per row
-__global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a, long W, double* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a, long W, double* __restrict__ out) {
   __shared__ double part[256];
   const double* row = a + (size_t)blockIdx.x * W;
   double s = 0.0;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a,
 // one loop over the other electrons and the ions for U(new) - U(old).  k_ecp_sum then adds a walker's points in slot
 // order, so the result does not depend on scheduling.
 template <bool PBC>
-__global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int s, int has_slater,
+static __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, JastrowState js, EcpBuf B, int s, int has_slater,
                                                    int has_jastrow, const double* __restrict__ mo, long npts,
                                                    double* __restrict__ contrib, const double* __restrict__ Tbase, long sw, long si, long sk) {
   // Tbase / sw / si / sk: element (walker, electron row, column) of the inverse at Tbase[w sw + i si + k sk] — the
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState st, Jas
 
 // ecp[w] = local + sum of the walker's point contributions, spin up then spin down, in slot order
 // n_up / n_dn > 0: complex contributions, imaginary parts at c[n + p]; their sum goes to ecp[W + w]
-__global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restrict__ c_up, const double* __restrict__ c_dn, long W,
+static __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restrict__ c_up, const double* __restrict__ c_dn, long W,
                                                  double* __restrict__ ecp, long n_up = 0, long n_dn = 0) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restr
 //   weight    sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i   (0 where masked out)
 //   live      1 where the walker passed the mask for that atom
 // rot [necp][3][3], unif [necp][W].  grid = W, block = 64.
-__global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, int e, double tau, double threshold,
+static __global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, int e, double tau, double threshold,
                                                      const double* __restrict__ rot, const double* __restrict__ unif,
                                                      const double* __restrict__ quad, const int* __restrict__ pt_k,
                                                      const int* __restrict__ pt_i, int P, long W, double* __restrict__ pos,
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, 
 }
 
 // ratio[w][q] = Psi(candidate)/Psi for live candidates, 1 otherwise.  mo: [W*P][nmo_s].  LDS: max(ndet_s) doubles.
-__global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, JastrowState js, int e, int has_slater,
+static __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, JastrowState js, int e, int has_slater,
                                                     int has_jastrow, const double* __restrict__ mo,
                                                     const double* __restrict__ pos, const uint8_t* __restrict__ live, int P,
                                                     double* __restrict__ ratio) {
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, Ja
 // three_body_jastrow.py:343-372, product multiplywf.py:112-114).  factors: bit 0 Slater, bit 1 two-body, bit 2 three-body.
 // mo_up / mo_dn: [nrow][nmo_s] orbital values at the auxiliary positions.  Block = one wave per row.
 template <bool CX>
-__global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st, JastrowState js, const int* __restrict__ es, int ne,
+static __global__ __launch_bounds__(64) void k_testvalue_many(SysDev S, SlaterState st, JastrowState js, const int* __restrict__ es, int ne,
                                                        const double* __restrict__ pts, const double* __restrict__ mo_up,
                                                        const double* __restrict__ mo_dn, long nrow,
                                                        const int* __restrict__ widx, int factors, double* __restrict__ out) {

@@ -1,0 +1,273 @@
+// Host-side internals shared by the translation units of libpyqmc_amd.so (pqa_capi.hip, pqa_orb.hip, pqa_sweep.hip,
+// pqa_energy.hip, pqa_dmcsteps.hip): the handle, the error macros, buffer helpers and the functions one unit calls in another.
+// The device code lives in the kernel headers; every kernel has internal linkage, so a unit only compiles what it launches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pyqmc_amd.h"
+#include "pqa_ao.hpp"
+#include "pqa_common.hpp"
+#include "pqa_cslater.hpp"
+#include "pqa_dmc.hpp"
+#include "pqa_energy.hpp"
+#include "pqa_ecp.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_lw.hpp"
+#include "pqa_slater.hpp"
+#include "pqa_tile.hpp"
+#include "pqa_dm.hpp"
+#include "pqa_vmc.hpp"
+
+
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ChunkHost {
+  std::vector<int> nk, row0;
+  std::vector<int> shell_kb, shell_chunk;  // per shell: first tile row inside its chunk, chunk index
+  std::vector<int> cw_off[3], cw_shell[3];  // shell lists per (chunk, lane group) for 4, 8 and 16 groups
+  int rows_pad = 0;
+};
+
+struct pqa_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<void*> owned;  // table allocations freed at destroy
+  // host copies needed after create
+  int natom = 0, nup = 0, ndn = 0, N = 0, nao = 0, nshell = 0;
+  int nmo[2] = {0, 0}, nt[2] = {1, 1}, ndet = 1, ndet_s[2] = {1, 1};
+  int na = 0, nb = 0, necp = 0;
+  bool tm_pre = true;   // T-move ratios of all candidates in one thread-per-candidate launch (PQA_TM_PRE=0: wave-per-walker loop only)
+  bool aos_stale = false;  // the lane-per-walker planes hold the live state; the walker-major arrays are converted back on demand (sync_aos)
+  int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
+  int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
+  bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
+  bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
+  bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
+  bool has_j2 = false, has_j3 = false;
+  int na3 = 0, nb3 = 0;
+  double* d_c3 = nullptr;
+  DevBuf b_j3u;
+  double ii_energy = 0.0;
+  EwaldDev ew{};  // periodic Coulomb tables (pqa_set_ewald)
+  bool ew_set = false;
+  std::vector<int> shell_l, shell_np, shell_ao;
+  std::vector<int> shell_cost;  // phase-1 cost model of a shell (shell_costs): balances the lane groups of the orbital kernels
+  SysDev S{};
+  ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)
+  ChunkTab tab[2]{};
+  const unsigned char* out_sel = nullptr;  // two-slot output of the NEXT orbital launch (ChunkTab::out_sel; set by launch_orb)
+  long out_slot_stride = 0;
+  double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
+  double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
+  double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
+  // walker state
+  long W = 0;
+  SlaterState st{};
+  JastrowState js{};
+  DevBuf b_x, b_T[2], b_dsign[2], b_dlog[2], b_cache[2], b_aval, b_bval;
+  DevBuf b_alt_x, b_alt_T[2], b_alt_dsign[2], b_alt_dlog[2], b_alt_cache[2], b_alt_aval, b_alt_bval, b_alt_j3u, b_rsidx;  // pqa_resample's other halves
+  // scratch
+  DevBuf b_pts, b_motmp, b_out, b_widx, b_mask, b_ao, b_flag, b_newpos, b_aux, b_accept, b_accrec, b_acccnt, b_accw, b_dwrap, b_wrap, b_epass, b_eptw[2], b_econ[2], b_eu0[2], b_tves, b_pgdet, b_pbcd0, b_pbcmask, b_pbcth, b_tmuold;
+  int* d_colmap[2] = {nullptr, nullptr};  // [ndet_s][nmo_s] column of an orbital in a unique determinant, or -1
+  int ecp_wave = 0;  // PQA_ECP_WAVE=1: wave-per-walker ECP accumulation (A/B)
+  int ecp_soa_t = 1;  // PQA_ECP_SOA_T=0: transpose the inverse back for the ECP point kernel (A/B)
+  int ecp_point_lw = 1;  // PQA_ECP_POINT_LW=0: k_ecp_point on the planes instead of k_ecp_point_lw (A/B)
+  long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
+  long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
+  int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
+  int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
+  int jas_fold_allowed = 1;  // PQA_JAS_FOLD=0: Voronoi reduction in every periodic Jastrow pair (A/B, bitwise check)
+  int ecp_atom_major = 1;  // PQA_ECP_ATOM_MAJOR=0: walker-major ECP point lists in periodic cells too (A/B)
+  int ecp_lds = 1;       // PQA_ECP_LDS=0: first-generation k_ecp_count / k_ecp_fill (A/B)
+  int ecp_nchan = 0, ecp_nterm = 0;
+  long wrap_W = 0;
+  DevBuf b_gauss, b_unif, b_kc, b_en, b_means, b_sign, b_log, b_ju;
+  DevBuf b_tpos, b_twgt, b_tlive, b_trat;
+  DevBuf b_tmcnt, b_tmoff, b_tmpass, b_tmamp, b_tmacc, b_tmidx, b_tmapos, b_tmu, b_tmtile, b_tmaoff, b_tmptw, b_tmmarks, b_dmcw, b_dmcold, b_dmcr2, b_dmcout;
+  int tm_P = 0;
+  int *d_ptk = nullptr, *d_pti = nullptr;
+  DevBuf b_xt, b_Tt[2], b_rc[2], b_sel[2], b_auxt, b_kpart, b_rbuf, b_vbuf, b_act;
+  // electrons per Sherman-Morrison block (PQA_LW_KB): -1 automatic (4 for >= 16 electrons per spin), 0 = update every row on
+  // every move.  Blocking is bitwise identical and cuts the inverse's HBM traffic ~3x; it pays since k_flush_lw stages the
+  // block's update vectors in LDS (1.26 -> 0.27 ms per flush at 65536 walkers): commit + flush 15.5 -> 8.4 ms per step.
+  int lw_kb = -1;
+  int lw_nw = 0;  // PQA_LW_NW: walkers per block of k_step_lw (16, 32, 64; 0 = automatic)
+  int lw_gm = 0;  // thread groups of the move kernels (PQA_LW_GM; 0 = automatic)  // lane-per-walker SoA mirrors (pqa_lw.hpp)
+  DevBuf b_rot, b_eunif, b_elocal, b_ecnt, b_eoff, b_epts[2], b_ewgt[2], b_epte[2], b_emo[2], b_ecp;
+  int orb_tp = 0;  // 0 = automatic
+  int orb_nosplit = 0;  // PQA_ORB_NOSPLIT=1: never split the chunk loop of small periodic launches (A/B)
+  long orb_split_max = 8192;  // largest periodic launch whose chunk loop is split over two blocks (PQA_ORB_SPLIT_MAX)
+  // AO rows per chunk of the PERIODIC 5-component launch: 32 halves the number of (phase 1, barrier, MFMA, barrier)
+  // rounds of a block's latency chain — 2x2x2 diamond supercell +4.5-10 % at every walker count, 8-atom cell +11 % at 8192
+  // walkers, -4 % at 32768 (PQA_ORB_KC5=16 restores the 16-row chunks; the open-system kernel keeps 16: 0.36 vs 0.29 of peak)
+  int orb_kc5 = 32;
+  struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
+  TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
+  WideTab wide[2]{};  // lane-group shell lists of the whole-K small-launch kernel (k_orb_wide), per chunk table (64 groups; periodic: 32)
+  int orb_wide = -1;  // PQA_ORB_WIDE: -1 automatic (5-component launches of <= orb_wide_max points), 0 never, 1 whenever the tile fits LDS
+  long orb_wide_max = 8192;  // PQA_ORB_WIDE_MAX
+  std::vector<const void*> wide_attr;  // kernels whose dynamic-LDS limit has been raised
+  int orb_ws = -1;  // -1 automatic; 1 wave-specialised orbital kernel; 0 phase-alternating k_orb (PQA_ORB_WS)
+  int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
+  // pipelined half-ensembles of the lane-per-walker sweep (pqa_sweep.hip): mode (PQA_SPLIT), smallest shard that is cut
+  // (PQA_SPLIT_MIN), CUs of the orbital stream in mode 3 (PQA_SPLIT_CUS, 0 = no masks)
+  int split_mode = 0, split_cus = 0, cu_count = 256;
+  long split_min = 32768;
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> pipe_events;
+  size_t pipe_next = 0;
+  int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
+  // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
+  // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
+  struct DmSlot { DevBuf pos, row, f, newpos, keep_pos, keep_row, keep_f, cfg; long n = 0, ncfg = 0; int nkeep = 0, spin = 0; };
+  DmSlot dm[2];
+  DevBuf dm_val, dm_norm[2], dm_tmp, dm_ijkl, dm_assign[2], dm_ratio, dm_acc;
+  long dm_nconf = 0, dm_nval = 0;
+  int dm_cx = 0;
+  bool tile_attr_set = false;
+  bool saved_valid = false;
+  bool jas_stale = false;  // fused sweeps move x without patching avalues/bvalues
+  int saved_e = -1;
+  long last_ecp_points = 0;
+  // measurement
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_events;  // Sherman-Morrison commit launches of the fused sweep
+  size_t prof2_used = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof3_events;  // partial-sum launches (k_move_part_lw) of the fused sweep
+  size_t prof3_used = 0;
+  long prof3_launches = 0;
+  double prof3_ms = 0.0;
+  long prof2_launches = 0;
+  double prof2_ms = 0.0;
+  size_t prof_used = 0;
+  unsigned prof_tick = 0, prof2_tick = 0;  // the event pairs bracket every 4th eligible launch (PQA_PROF_STRIDE)
+  unsigned prof_stride = 4;
+  long prof_launches = 0;
+  double prof_ms = 0.0, prof_pc = 0.0;
+};
+
+#define HIPCHK(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      char buf_[512];                                                                                    \
+      snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      h->err = buf_;                                                                                     \
+      return -1;                                                                                         \
+    }                                                                                                    \
+  } while (0)
+#define FAIL(msg)      \
+  do {                 \
+    h->err = (msg);    \
+    return -2;         \
+  } while (0)
+#define TRY(x)          \
+  do {                  \
+    int rc_ = (x);      \
+    if (rc_) return rc_; \
+  } while (0)
+
+
+static inline int ensure(pqa_handle* h, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return 0;
+  // A buffer that has to GROW holds data-dependent sizes (ECP / T-move point lists: ~38 points per walker +- sqrt(N)
+  // from step to step).  Exact-size regrowth made every new maximum a hipFree + hipMalloc pair, i.e. a device
+  // synchronisation and milliseconds of driver time in the first dozens of steps (the first timed steps on a fresh box
+  // ran 15 % slow); 25 % headroom on regrowth ends that after the second step.  First allocations stay exact.
+  const bool regrow = b.p != nullptr;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = std::max<size_t>(regrow ? bytes + bytes / 4 : bytes, 256);
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return 0;
+}
+
+template <class T>
+static int upload_table(pqa_handle* h, const T* src, size_t n, T** dst) {
+  *dst = nullptr;
+  if (n == 0) n = 1;
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, n * sizeof(T)));
+  h->owned.push_back(p);
+  if (src) HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  else HIPCHK(hipMemset(p, 0, n * sizeof(T)));
+  *dst = (T*)p;
+  return 0;
+}
+
+static inline int copy_in(pqa_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return 0;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+  return 0;
+}
+static inline int copy_out(pqa_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static inline int check_launch(pqa_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    h->err = std::string(what) + " launch failed: " + hipGetErrorString(e);
+    return -1;
+  }
+  return 0;
+}
+
+static inline size_t lds_j3(const pqa_handle* h) {  // bytes needed by kernels that call jas_eval with the three-body term
+  return h->has_j3 ? ((size_t)h->S.j3_off + (size_t)h->natom * (3 + 6 * h->na3 * h->nb3)) * sizeof(double) : 0;
+}
+static inline size_t lds_sm(const pqa_handle* h) {
+  const size_t n = std::max(h->nup, h->ndn);
+  return std::max((n * (n + 1) + 2 * n + 64 + n) * sizeof(double), lds_j3(h));
+}
+static inline size_t lds_det(const pqa_handle* h, int ncomp) {
+  return std::max((size_t)std::max(h->ndet_s[0], h->ndet_s[1]) * ncomp * sizeof(double), lds_j3(h));
+}
+
+struct LwCtx {
+  int Gm = 1, KB = 1, nmax = 1;
+};
+
+// ---- functions defined in one unit and called from others
+// pqa_orb.hip: out[p][ncomp][nmo_spin]; out_sel / slot_stride: two-slot output (ChunkTab::out_sel), else plain rows
+int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out, const unsigned char* out_sel = nullptr, long slot_stride = 0);
+PointAddr plain_points(const double* base, long P);
+// pqa_sweep.hip
+void transpose(pqa_handle* h, const double* in, double* out, long R, long C);  // in [R][C] -> out [C][R]
+LwState lw_state(pqa_handle* h);
+int lw_from_aos(pqa_handle* h, bool with_cache = true);
+int lw_to_aos(pqa_handle* h, bool with_cache);
+int sync_aos(pqa_handle* h);
+int lw_setup(pqa_handle* h, bool lw, LwCtx& c);
+int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc);
+void launch_step_real(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen);
+void launch_flush_real(pqa_handle* h, const LwState& L, int s, long W, long w0, long w1, int j_lo, int j_hi, int nq, int rowlen, int n_s);
+// pqa_sweep_cx.hip
+void launch_step_cx(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen);
+void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, long w1, int j_lo, int j_hi, int nq, int rowlen, int n_s);
+// pqa_tile.hip
+bool tile_eligible(const pqa_handle* h);
+int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);
+// pqa_energy.hip
+int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
+               bool soa_current = false, bool aos_T_needed = true);
+// pqa_dmcsteps.hip
+int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks);

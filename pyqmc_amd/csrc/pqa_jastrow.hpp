@@ -351,13 +351,13 @@ __device__ __forceinline__ double jas_value_wave(const SysDev& S, const JastrowS
   return wave_sum(u);
 }
 
-__global__ __launch_bounds__(64) void k_jastrow_value(SysDev S, JastrowState js, double* out) {
+static __global__ __launch_bounds__(64) void k_jastrow_value(SysDev S, JastrowState js, double* out) {
   const double u = jas_value_wave(S, js, blockIdx.x);
   if (threadIdx.x == 0) out[blockIdx.x] = u;
 }
 
 // _avalues / _bvalues from scratch for walker w (jastrowspin.py:80-105)
-__global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState js) {
+static __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState js) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState
 // mode 0: out[r*npt+q] = exp(U_e(pt) - U_e(x_e))                       (testvalue)
 // mode 1: out (4,nrow): grad U_e(pt), exp(U_e(pt) - U_e(x_e))          (gradient_value)
 // mode 2: out (4,nrow): grad U_e(pt), lap U_e + |grad U_e|^2           (gradient_laplacian)
-__global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowState js, int e, const double* __restrict__ pts,
+static __global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowState js, int e, const double* __restrict__ pts,
                                                      long nrow, int npt, const int* __restrict__ widx, int mode,
                                                      int parts, double* __restrict__ out) {
   extern __shared__ double lds[];
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowState js, 
   }
 }
 
-__global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowState js, int e, const double* __restrict__ epos,
+static __global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowState js, int e, const double* __restrict__ epos,
                                                        const uint8_t* __restrict__ mask) {
   const long w = blockIdx.x;
   if (mask && !mask[w]) return;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowState js
 }
 
 // three-body log value U3 = 1/2 sum_e P_e(x_e)  (three_body_jastrow.py:98-101)
-__global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState js, double* __restrict__ out) {
+static __global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState js, double* __restrict__ out) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const double* xw = js.x + (size_t)w * S.nelec * 3;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState js, doub
 }
 
 // move the stored coordinate of electron e for the masked walkers (handles without a two-body factor)
-__global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict__ epos, const uint8_t* __restrict__ mask, long W) {
+static __global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict__ epos, const uint8_t* __restrict__ mask, long W) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W || (mask && !mask[w])) return;
   double* x = js.x + ((size_t)w * N + e) * 3;
@@ -473,7 +473,7 @@ __global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict
 //   a_k(r_iI) a_l(r_jI) b_m(r_ij):  sp 0 = up-up (i<j), 1 = up (i) - down (j), 2 = down-down (i<j)
 // (ThreeBodyJastrow.pgradient, three_body_jastrow.py:657-719).  One wave per walker; LDS: a-values of every electron
 // [N][natom][na] followed by b-values of every pair [N(N-1)/2][nb] (row-major upper triangle); out (W, natom, na, na, nb, 3).
-__global__ __launch_bounds__(64) void k_j3_pgrad(SysDev S, JastrowState js, double* __restrict__ out) {
+static __global__ __launch_bounds__(64) void k_j3_pgrad(SysDev S, JastrowState js, double* __restrict__ out) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
   const int lane = threadIdx.x, N = S.nelec, A = S.natom, na = S.na3, nb = S.nb3;

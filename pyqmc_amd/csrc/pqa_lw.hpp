@@ -46,7 +46,7 @@ __device__ __forceinline__ double* lw_row(const LwState& L, int s, int i, int sl
 
 // ---------------------------------------------------------------- layout transposes
 // in [R][C] -> out [C][R] through a 32x33 LDS tile; block (32,8)
-__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in, double* __restrict__ out, long R, long C) {
+static __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in, double* __restrict__ out, long R, long C) {
   __shared__ double tile[32][33];
   const long c0 = (long)blockIdx.x * 32, r0 = (long)blockIdx.y * 32;
   for (int j = threadIdx.y; j < 32; j += 8) {
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in
 
 // walker-major orbital cache [W][n][5 nmo] <-> the two-slot row cache.  to_rc: everything lands in slot 0 (selectors cleared);
 // from_rc: every electron's CURRENT slot.  grid = (W, n, ceil(row / 256)), block = 256.
-__global__ __launch_bounds__(256) void k_cache_to_rc(const double* __restrict__ aos, double* __restrict__ rc, uint8_t* __restrict__ sel, int n,
+static __global__ __launch_bounds__(256) void k_cache_to_rc(const double* __restrict__ aos, double* __restrict__ rc, uint8_t* __restrict__ sel, int n,
                                                      int row, long W) {
   const long w = blockIdx.x;
   const int i = blockIdx.y, k = blockIdx.z * 256 + threadIdx.x;
   if (k == 0) sel[(size_t)i * W + w] = 0;
   if (k < row) rc[(((size_t)i * 2) * W + w) * row + k] = aos[((size_t)w * n + i) * row + k];
 }
-__global__ __launch_bounds__(256) void k_cache_from_rc(const double* __restrict__ rc, const uint8_t* __restrict__ sel, double* __restrict__ aos,
+static __global__ __launch_bounds__(256) void k_cache_from_rc(const double* __restrict__ rc, const uint8_t* __restrict__ sel, double* __restrict__ aos,
                                                        int n, int row, long W) {
   const long w = blockIdx.x;
   const int i = blockIdx.y, k = blockIdx.z * 256 + threadIdx.x;
@@ -334,16 +334,16 @@ __device__ __forceinline__ void lw_slater_terms(const double (&v)[PR], double& g
 // WB: walkers per block (16 rows groups at 16, 32 at 8: small walker counts get twice the blocks and one row per thread —
 // at 4 096 walkers a flush was 256 blocks of two-row threads, 40 us for 17 us of traffic)
 template <int NMAX, bool CX = false, int WB = PQA_FLUSH_WB>
-__global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
+static __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, const double* __restrict__ Vb,
                                                   const double* __restrict__ Rb, const uint8_t* __restrict__ act, long W,
-                                                  int j_lo, int j_hi, int nq) {
+                                                  long wlo, long whi, int j_lo, int j_hi, int nq) {
   extern __shared__ double sh[];
   const int n = s ? S.ndn : S.nup;
   const int L_ = CX ? 2 * n : n;  // doubles per row
   double* shV = sh;
   double* shR = sh + (size_t)nq * L_ * WB;
   const int wl = threadIdx.x & (WB - 1), g = threadIdx.x / WB;
-  const long w0 = (long)blockIdx.x * WB;
+  const long w0 = wlo + (long)blockIdx.x * WB;  // walkers [wlo, whi) of the shard; W is the plane stride
   // eight elements of each vector per pass, all sixteen loads in flight before the first LDS store (one element per iteration was
   // a round trip per iteration: 8-10 of them at the head of a ~30-us launch for small shards)
   for (int base = threadIdx.x; base < nq * L_ * WB; base += 8 * 256) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
     for (int u = 0; u < 8; ++u) {
       const int idx = base + u * 256;
       const int ic = (idx < nq * L_ * WB) ? idx : base;
-      const long ws = (w0 + (ic & (WB - 1)) < W) ? w0 + (ic & (WB - 1)) : W - 1;
+      const long ws = (w0 + (ic & (WB - 1)) < whi) ? w0 + (ic & (WB - 1)) : whi - 1;
       const size_t src = (size_t)(ic / WB) * W + ws;  // idx / WB = q * L_ + k
       v8[u] = Vb[src]; r8[u] = Rb[src];
     }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, int s, co
   }
   __syncthreads();
   const long w = w0 + wl;
-  if (w >= W) return;
+  if (w >= whi) return;
   unsigned mask = 0;
   for (int q = 0; q < nq; ++q) mask |= act[(size_t)q * W + w] ? (1u << q) : 0u;
   if (!mask) return;
@@ -428,7 +428,8 @@ struct StepArgs {
   int e_acc, e_prop;   // electron to decide / to propose (-1: skip that half)
   int has_jastrow, G, NW;  // thread groups per walker, walkers per block (NW * G <= 256)
   int j_lo, j_hi;      // Sherman-Morrison block of e_acc (rows of its spin)
-  long W;
+  long W;              // walkers of the shard = stride of every plane
+  long w0, w1;         // this launch covers walkers [w0, w1) (the whole shard, or one half-ensemble of the pipelined sweep)
   double* Rbuf;        // block buffers, slot of e_acc: [L_][W]
   double* Vbuf;
   uint8_t* act;        // [W]
@@ -446,7 +447,7 @@ struct StepArgs {
 #define PQA_STEP_BOUNDS __launch_bounds__(256)
 #endif
 template <bool PBC, bool CX, int NMAX, bool WIDE>
-__global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
   extern __shared__ double sh[];
   constexpr int PR = PQA_LW_PART_ROWS(CX), JU = CX ? 8 : 4, CF = CX ? 2 : 1;
   const int NW = WIDE ? 64 : a.NW;
@@ -454,9 +455,9 @@ __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb, StepA
   const int g = WIDE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)threadIdx.x / NW;
   const int G = a.G;
   const long W = a.W;
-  const long wr = (long)blockIdx.x * NW + lane;
-  const bool live = wr < W;
-  const long w = live ? wr : W - 1;  // lanes past the end shadow the last walker and store nothing
+  const long wr = a.w0 + (long)blockIdx.x * NW + lane;
+  const bool live = wr < a.w1;
+  const long w = live ? wr : a.w1 - 1;  // lanes past the end shadow the last walker and store nothing
   const bool lead = live && g == 0;
   if (a.e_acc >= 0) {
     const int e = a.e_acc;
@@ -765,15 +766,15 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
 }
 
 template <bool PBC, int NMAX>
-__global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
   extern __shared__ double sh[];
   constexpr int PR = 8, JU = 4, NS = (NMAX + 7) / 8, NF = PQA_JAS_NF, NP = PQA_PRE_NP, NA = PQA_PRE_NA;
   const int NW = a.NW, G = a.G;
   const int lane = (int)threadIdx.x % NW, g = (int)threadIdx.x / NW;
   const long W = a.W;
-  const long wr = (long)blockIdx.x * NW + lane;
-  const bool live = wr < W;
-  const long w = live ? wr : W - 1;  // lanes past the end shadow the last walker and store nothing
+  const long wr = a.w0 + (long)blockIdx.x * NW + lane;
+  const bool live = wr < a.w1;
+  const long w = live ? wr : a.w1 - 1;  // lanes past the end shadow the last walker and store nothing
   const bool lead = live && g == 0;
   double* shP = sh;                           // [PR][G][NW] partial sums
   double* shV = sh + (size_t)PR * G * NW;     // [NMAX][NW] update vectors
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, MoveBuf m
 #define PQA_KIN_V 1
 #endif
 template <bool PBC, bool CX = false>
-__global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
+static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   // Block b -> (walker group, electron block): the electron blocks of ONE walker group sit 8 apart in the linear block order, so
   // they land on the same XCD (blocks go to the XCDs round-robin) and run at about the same time: the group's coordinates, which
   // every one of them walks, come out of that XCD's L2 after the first.  (With the electron on grid.y the 64 blocks of a group were
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwStat
 }
 
 // out rows ke, ee, ei, grad2 (layout of k_kinetic_coulomb) = sums over electrons of part
-__global__ void k_kinetic_reduce(const double* __restrict__ part, int N, long W, double* __restrict__ out) {
+static __global__ void k_kinetic_reduce(const double* __restrict__ part, int N, long W, double* __restrict__ out) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   const size_t NW = (size_t)N * W;

@@ -72,7 +72,7 @@ __device__ __forceinline__ void slater_move_terms(const SysDev& S, const SlaterS
 }
 
 template <bool CX>
-__global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
+static __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
                                                 int has_slater, int has_jastrow, long W) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, Jastro
 
 // motmp: [W][5][nmo_s] orbitals at the proposed position.  LDS: n(n+1)+2n doubles (+ multi-det scratch).
 template <bool CX>
-__global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
+static __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
                                                int has_slater, int has_jastrow, const double* __restrict__ motmp, long W) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, Jastrow
 }
 
 // accepted-move count of one sweep: sum acc_w[0..W) -> *out, and reset acc_w.  One block, deterministic.
-__global__ __launch_bounds__(1024) void k_sum_reset_int(int* __restrict__ acc_w, long W, int* __restrict__ out) {
+static __global__ __launch_bounds__(1024) void k_sum_reset_int(int* __restrict__ acc_w, long W, int* __restrict__ out) {
   __shared__ int part[1024];
   int s = 0;
   for (long i = threadIdx.x; i < W; i += 1024) { s += acc_w[i]; acc_w[i] = 0; }
