@@ -26,7 +26,10 @@ PYSCF_BOHR = 0.52917721092  # pyscf.data.nist.BOHR (angstrom): the constant PySC
 
 
 def _scan_json(raw, start_key=b'{"atom"'):
-    """First balanced JSON object starting with ``start_key`` in ``raw`` (bytes), string-aware brace matching."""
+    """The balanced JSON object starting with ``start_key`` in ``raw`` (bytes), string-aware brace matching.  A chkfile an SCF was
+    re-run into can still hold an older ``mol`` string in freed space: several DIFFERENT objects are an error (use h5py or
+    ``hdf5lite``, which follow the file's own pointers); identical copies are one."""
+    found = []
     pos = raw.find(start_key)
     while pos >= 0:
         depth, i, in_str, esc = 0, pos, False, False
@@ -47,17 +50,27 @@ def _scan_json(raw, start_key=b'{"atom"'):
                 depth -= 1
                 if depth == 0:
                     try:
-                        return json.loads(raw[pos : i + 1].decode("utf-8"))
+                        found.append(json.loads(raw[pos : i + 1].decode("utf-8")))
                     except (UnicodeDecodeError, json.JSONDecodeError):
-                        break
+                        pass
+                    break
             i += 1
         pos = raw.find(start_key, pos + 1)
-    raise ValueError("no PySCF mol JSON found in the file")
+    if not found:
+        raise ValueError("no PySCF mol JSON found in the file")
+    if any(o != found[-1] for o in found):
+        raise ValueError(f"{len(found)} different mol JSON objects in the file (a rewritten chkfile): read it with backend='lite' or h5py")
+    return found[-1]
 
 
 def read_mol_json(path, backend=None):
-    """The ``mol`` JSON of a PySCF chkfile as a dict.  ``backend``: "h5py", "scan" or None (h5py when importable)."""
-    backend = backend or ("h5py" if h5py is not None else "scan")
+    """The ``mol`` JSON of a PySCF chkfile as a dict.  ``backend``: "h5py", "lite" (``pyqmc_amd.hdf5lite``: follows the file's
+    group and heap pointers), "scan" (byte scan for the object) or None (h5py when importable, else lite)."""
+    backend = backend or ("h5py" if h5py is not None else "lite")
+    if backend == "lite":
+        from .hdf5lite import File
+
+        return json.loads(File(path)["mol"])
     if backend == "h5py":
         if h5py is None:
             raise RuntimeError("h5py is not installed: use backend='scan'")
@@ -75,11 +88,13 @@ def mol_from_json(d):
     symbols = [a[0] for a in d["_atom"]]
     coords = np.array([a[1] for a in d["_atom"]], dtype=float)  # bohr (Mole.build converts; format_atom, pyscf/gto/mole.py)
     pure = ["".join(ch for ch in s if ch.isalpha()) for s in symbols]  # atom_pure_symbol: 'C1' -> 'C'
-    basis = {k: [[int(sh[0])] + [[float(x) for x in p] for p in sh[1:]] for sh in v] for k, v in d["_basis"].items()}
-    for sym, shells in basis.items():
+    for sym, shells in d["_basis"].items():
         for sh in shells:
+            if len(sh) > 1 and not hasattr(sh[1], "__len__"):  # [l, kappa, [exp, c], ...]
+                raise NotImplementedError(f"{sym}: shells with a kappa entry (spinor basis) are not supported")
             if not all(len(p) == 2 for p in sh[1:]):
-                raise NotImplementedError(f"{sym}: general contractions (several coefficient columns, or a kappa entry) are not supported")
+                raise NotImplementedError(f"{sym}: general contractions (several coefficient columns) are not supported")
+    basis = {k: [[int(sh[0])] + [[float(x) for x in p] for p in sh[1:]] for sh in v] for k, v in d["_basis"].items()}
     ecp = {k: (int(v[0]), [[int(ch[0]), [[[float(t[0]), float(t[1])] for t in terms] for terms in ch[1]]] for ch in v[1]]) for k, v in (d.get("_ecp") or {}).items()}
     # effective nuclear charges: _atm[:, 0] (CHARGE_OF) already has the ECP core removed
     if d.get("_atm"):
@@ -91,15 +106,23 @@ def mol_from_json(d):
     if (ntot + spin) % 2:
         raise ValueError(f"{ntot} electrons cannot have spin {spin}")
     nelec = ((ntot + spin) // 2, (ntot - spin) // 2)
-    kw = dict(nelec=nelec, basis={s: basis[s] for s in dict.fromkeys(pure)}, ecp=ecp, charges=charges)
+    # PySCF keys _basis / _ecp by the atom label as given ('C1', 'ghost-H') and falls back to the pure symbol
+    by_label = lambda table, lab, p: table[lab] if lab in table else table[p]
+    labels = list(dict.fromkeys(zip(symbols, pure)))
+    if any(lab != p and (lab in basis or lab in ecp) for lab, p in labels):  # labelled species: each label is its own kind
+        names = symbols
+        kw = dict(nelec=nelec, basis={lab: by_label(basis, lab, p) for lab, p in labels}, ecp={lab: by_label(ecp, lab, p) for lab, p in labels if lab in ecp or p in ecp}, charges=charges)
+    else:
+        names = pure
+        kw = dict(nelec=nelec, basis={s: basis[s] for s in dict.fromkeys(pure)}, ecp=ecp, charges=charges)
     if d.get("a") is None:
-        m = Mol(pure, coords, **kw)
+        m = Mol(names, coords, **kw)
     else:
         unit = str(d.get("unit", "angstrom") or "angstrom").lower()
         a = np.array(d["a"], dtype=float).reshape(3, 3)
         if not unit.startswith(("b", "au")):  # Cell.lattice_vectors(): a / BOHR unless the input unit was bohr
             a = a / PYSCF_BOHR
-        m = Cell(pure, coords, a, **kw)
+        m = Cell(names, coords, a, **kw)
     m.exp_to_discard = d.get("exp_to_discard")
     m.precision = d.get("precision")
     m.basis_name, m.ecp_name = d.get("basis"), d.get("ecp")
@@ -111,25 +134,47 @@ def load_mol(path, backend=None):
     return mol_from_json(read_mol_json(path, backend))
 
 
-def load_scf(path):
-    """``(mol, MeanField)`` with the chkfile's ``scf/mo_coeff`` and ``scf/mo_occ`` (needs h5py: binary datasets).  Restricted
-    results are duplicated to the two spin channels like ``mf.to_uhf()`` (pyscftools.py:139-146); k-point lists stay lists."""
-    if h5py is None:
-        raise RuntimeError("reading MO coefficients from a chkfile needs h5py (binary HDF5 datasets); the mol JSON does not")
+def _open(path, backend):
+    """(file object with ``f[path]``, ``path in f`` and ``keys``, close function) through h5py or the built-in parser."""
+    backend = backend or ("h5py" if h5py is not None else "lite")
+    if backend == "h5py":
+        if h5py is None:
+            raise RuntimeError("h5py is not installed: use backend='lite'")
+        f = h5py.File(path, "r")
+        return f, (lambda name: np.array(f[name])), (lambda name: sorted(f[name])), f.close
+    from .hdf5lite import File
+
+    f = File(path)
+    return f, (lambda name: np.asarray(f[name])), f.keys, (lambda: None)
+
+
+def load_scf(path, backend=None):
+    """``(mol, mean field)`` with the chkfile's ``scf/mo_coeff`` / ``scf/mo_occ`` (``pyscftools.recover_pyscf`` +
+    ``orbital_evaluator_from_pyscf``, pyscftools.py:105-191).  Restricted results are duplicated to the two spin channels like
+    ``mf.to_uhf()`` (:139-146: occupations ``occ > 0`` and ``occ > 1``); a k-point SCF (``mo_coeff__from_list__/000000`` ...)
+    becomes a ``pbc.KMeanField`` with ``kpts`` — what ``generate_wf(get_supercell(cell, S), mf)`` takes.
+    ``backend``: "h5py", "lite" (``pyqmc_amd.hdf5lite``, no HDF5 library needed) or None = h5py when importable."""
+    from .pbc import KMeanField
     from .systems import MeanField
 
-    mol = load_mol(path, "h5py")
-    with h5py.File(path, "r") as f:
-        g = f["scf"]
-        if "mo_coeff" in g:
-            mo, occ = np.array(g["mo_coeff"]), np.array(g["mo_occ"])
-            if mo.ndim == 2:  # RHF / ROHF: (nao, nmo), occupations 0 / 1 / 2
-                mo = np.stack([mo, mo])
-                occ = np.stack([(occ > 0).astype(float), (occ > 1).astype(float)])
-            mf = MeanField(mo, occ)
-        else:  # k-point SCF: lists stored as mo_coeff__from_list__/000000 ...
-            key = lambda name: [np.array(g[name][k]) for k in sorted(g[name])]
-            mf = MeanField.__new__(MeanField)
-            mf.mo_coeff, mf.mo_occ = key("mo_coeff__from_list__"), key("mo_occ__from_list__")
-            mf.kpts = np.array(g["kpts"]) if "kpts" in g else None
+    mol = load_mol(path, backend)
+    f, arr, keys, close = _open(path, backend)
+    try:
+        def uhf(mo, occ):
+            mo, occ = np.asarray(mo), np.asarray(occ)
+            if occ.ndim == 1:  # RHF / ROHF: one set of orbitals, occupations 0 / 1 / 2
+                return [mo, mo], [(occ > 0).astype(float), (occ > 1).astype(float)]
+            return [mo[0], mo[1]], [occ[0], occ[1]]
+
+        if "scf/mo_coeff" in f:
+            mo, occ = uhf(arr("scf/mo_coeff"), arr("scf/mo_occ"))
+            mf = MeanField(np.stack(mo), np.stack(occ))
+        else:
+            names = keys("scf/mo_coeff__from_list__")
+            per_k = [uhf(arr(f"scf/mo_coeff__from_list__/{k}"), arr(f"scf/mo_occ__from_list__/{k}")) for k in names]
+            mf = KMeanField(arr("scf/kpts"), [[pk[0][s] for pk in per_k] for s in (0, 1)], [[pk[1][s] for pk in per_k] for s in (0, 1)])
+            mf.mo_energy = [arr(f"scf/mo_energy__from_list__/{k}") for k in names] if "scf/mo_energy__from_list__" in f else None
+        mf.e_tot = float(arr("scf/e_tot")) if "scf/e_tot" in f else None
+    finally:
+        close()
     return mol, mf

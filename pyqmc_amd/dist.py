@@ -38,12 +38,17 @@ def allreduce_block(local_sums, local_count, device=None):
     if device is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
 
-    t = torch.tensor(np.concatenate([np.asarray(local_sums, dtype=np.float64).ravel(), [float(local_count)]]),
-                     dtype=torch.float64, device=device)
+    sums = np.asarray(local_sums).ravel()
+    cplx = np.iscomplexobj(sums)  # complex wave functions: <acc>ecp and <acc>total are complex (eval_ecp.py:89); RCCL reduces reals
+    flat = np.concatenate([sums.real, sums.imag]) if cplx else sums
+    t = torch.tensor(np.concatenate([np.asarray(flat, dtype=np.float64), [float(local_count)]]), dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t)
     t = t.cpu().numpy()
-    return t[:-1] / t[-1], t[-1]
+    means = t[:-1] / t[-1]
+    if cplx:
+        means = means[: len(sums)] + 1j * means[len(sums):]
+    return means, t[-1]
 
 
 def combine_blocks(block_avgs, counts):

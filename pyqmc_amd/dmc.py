@@ -79,12 +79,54 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     return out, configs, weights
 
 
-def fused_dmc_supported(wf, accumulators, ekey):
-    """The device step loop covers wave functions on one handle (real or complex) with the energy accumulator as the only one."""
-    from .energy import EnergyAccumulator
+def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, accumulators, ekey, state_current=False):
+    """``dmc_propagate`` with further accumulators (density matrices, ...) next to the energy: every step is one device call
+    (``pqa_dmc_steps`` with ``nsteps = 1``), after which the walkers come back and the other accumulators run on the host over
+    the protocol entry points, weight-averaged as in dmc.py:205-221.  The device evaluates the energy of the step's starting
+    configuration itself, where the reference carries the previous step's: the same numbers unless the ECP evaluation is
+    stochastic (then an independent unbiased sample of the same energy)."""
+    from .energy import KEYS
+    from .vmc import _fetch
 
-    dev = wf.fused_device() if hasattr(wf, "fused_device") else getattr(wf, "_dev", None)
-    if dev is None or set(accumulators) != {ekey[0]} or ekey[1] != "total":
+    acc, name = accumulators[ekey[0]], ekey[0]
+    W = configs.configs.shape[0]
+    if not state_current:
+        wf.recompute(configs)
+    if dev.pbc:
+        dev.set_ewald(**acc._ewald_kws)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    df = []
+    for _ in range(nsteps):
+        avg, stat = dev.dmc_steps(tstep, 1, w, branchcut, e_trial, e_est, threshold=acc.threshold, seed=int(np.random.randint(0, 2**31 - 1)))
+        _fetch(dev, configs)
+        wavg = float(avg[0, 6])
+        d = {name + k: avg[0, i] for i, k in enumerate(KEYS[:6])}
+        if avg.shape[1] > 7:
+            for k in ("ecp", "total"):
+                d[name + k] = complex(d[name + k], avg[0, 7])
+        for k, other in accumulators.items():
+            if k == name:
+                continue
+            for m, res in other(configs, wf).items():
+                d[k + m] = np.einsum("...i,i...->...", w, res) / (W * wavg)
+        d["weight"], d["acceptance"], d["tmove_acceptance"] = wavg, stat[0, 0], stat[0, 1]
+        df.append(d)
+    weights[:] = w
+    wts = np.asarray([d["weight"] for d in df])
+    rel = wts / wts.mean()
+    out = {k: np.mean([d[k] * r for d, r in zip(df, rel)], axis=0) for k in df[0]}
+    out["weight"] = wts.mean()
+    return out, configs, weights
+
+
+def fused_dmc_supported(wf, accumulators, ekey):
+    """The device step loop covers wave functions on one handle (real or complex) whose energy accumulator is ours; further
+    accumulators run on the host between device steps (``_propagate_host_accumulators``)."""
+    from .energy import EnergyAccumulator
+    from .vmc import device_of
+
+    dev = device_of(wf)
+    if dev is None or ekey[0] not in accumulators or ekey[1] != "total":
         return None
     return dev if isinstance(accumulators[ekey[0]], EnergyAccumulator) else None
 
@@ -96,16 +138,21 @@ def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, 
 
     The whole step loop of dmc.py:123-221 runs on the device (``pqa_dmc_steps``): wave functions on one handle — real, or
     complex (no node constraint, weights from Re E_L, T-move amplitudes from Re[Psi(R')/Psi(R)]: golden g30) — with the
-    energy accumulator as the only accumulator.  ``rng`` replays the reference's draws (tests); ``state_current=True``
+    energy accumulator; further accumulators (OBDM, TBDM, ...) are evaluated on the host between device steps and
+    weight-averaged as dmc.py:205-212 does.  ``rng`` replays the reference's draws (tests, energy only); ``state_current=True``
     promises that the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on
-    the device (``DeviceWF.resample``) — and skips the initial recompute.  Further accumulators inside the DMC loop are
-    not built here: the reference's own ``pyqmc.method.dmc.dmc_propagate`` runs over
-    these wave-function objects unmodified (``tests/helpers.protocol_dmc_propagate`` is that route)."""
+    the device (``DeviceWF.resample``) — and skips the initial recompute.  (``tests/helpers.protocol_dmc_propagate`` is the
+    protocol-route harness the parity tests use.)"""
     assert accumulators is not None, "Need an energy accumulator for DMC"
     dev = fused_dmc_supported(wf, accumulators, ekey)
     if dev is None:
-        raise NotImplementedError("pyqmc_amd.dmc_propagate runs wave functions on one device handle with the EnergyAccumulator as the "
-                                  "only accumulator; drive pyqmc.method.dmc.dmc_propagate over the protocol objects for anything else")
+        raise NotImplementedError("pyqmc_amd.dmc_propagate runs wave functions on one device handle whose energy comes from "
+                                  "pyqmc_amd.EnergyAccumulator; drive pyqmc.method.dmc.dmc_propagate over the protocol objects for anything else")
+    if set(accumulators) != {ekey[0]}:
+        if rng is not None:
+            raise NotImplementedError("replayed draws (rng=) cover the energy-only step loop")
+        return _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators, ekey,
+                                            state_current=state_current)
     return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators[ekey[0]], ekey[0], rng,
                             state_current=state_current)
 
@@ -213,9 +260,16 @@ def rundmc(wf, configs, weights=None, tstep=0.01, nblocks=10, nsteps_per_block=N
                                                   state_current=current and block % max(int(recompute_every), 1) != 0)
         if distributed:  # weighted recombination of the per-rank block averages (dmc.py:238-304)
             keys = sorted(k for k in blk if k != "weight")
-            sums, _ = pdist.allreduce_block([blk[k] * blk["weight"] * W for k in keys] + [blk["weight"] * W, W], 1)
-            wsum, wtot_n = sums[-2], sums[-1]
-            blk = {k: s / wsum for k, s in zip(keys, sums[:-2])}
+            parts = [np.asarray(blk[k] * blk["weight"] * W).ravel() for k in keys]  # (array-valued accumulators, complex energies)
+            sums, _ = pdist.allreduce_block(np.concatenate(parts + [[blk["weight"] * W, W]]), 1)
+            wsum, wtot_n = np.real(sums[-2]), np.real(sums[-1])
+            offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
+            new = {}
+            for k, a, b in zip(keys, offs[:-1], offs[1:]):
+                v = (sums[a:b] / wsum).reshape(np.shape(blk[k]))
+                new[k] = v if np.iscomplexobj(blk[k]) else np.real(v)
+                new[k] = new[k][()] if np.ndim(new[k]) == 0 else new[k]
+            blk = new
             blk["weight"] = wsum / wtot_n
             # weights all-gathered, identical comb on every rank, only re-assigned walkers exchanged (device buffers under
             # RCCL); the state of walkers that stay is gathered on the device, arrivals alone are recomputed

@@ -23,6 +23,13 @@ import numpy as np
 from .energy import KEYS, EnergyAccumulator
 
 
+def device_of(wf):
+    """The device handle a wave function lives on: the shared one of a ``MultiplyWF``, or a bare factor's own
+    (``Slater`` / ``JastrowSpin`` / ``ThreeBodyJastrow`` built by ``generate_wf`` / ``generate_jastrow``); None otherwise."""
+    dev = wf.fused_device() if hasattr(wf, "fused_device") else getattr(wf, "_dev", None)
+    return dev if hasattr(dev, "vmc_sweeps") else None
+
+
 def _fetch(dev, configs):
     """Walkers of the device handle into the host container (periodic: folded positions + wrap counters)."""
     if getattr(dev, "twisted", False):  # the handle keeps true (unfolded) coordinates: fold them back into the container
@@ -40,6 +47,8 @@ def _vmc_worker_host_accumulators(dev, wf, configs, tstep, nsteps, accumulators,
     accumulator's ``avg(configs, wf)`` runs as in mc.py:142-148 — through the protocol entry points, on the state the sweep left."""
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
+    # one Philox key per sweep, seed * nsteps + step: `vmc` hands block b the seed s + b, and keys s + b + step would give sweep
+    # k + 1 of block b the draws of sweep k of block b + 1
     if not state_current:
         wf.recompute(configs)
     block_avg = {}
@@ -49,7 +58,7 @@ def _vmc_worker_host_accumulators(dev, wf, configs, tstep, nsteps, accumulators,
         t0 = time.perf_counter()
         g, u = tapes.get("gauss"), tapes.get("unif")
         acc, _, rec = dev.vmc_sweeps(tstep, 1, gauss=None if g is None else g[step : step + 1], unif=None if u is None else u[step : step + 1],
-                                     seed=seed + step, energy=False, record="record" in tapes)
+                                     seed=seed * nsteps + step, energy=False, record="record" in tapes)
         if "record" in tapes:
             tapes["record"].append(rec)
         _fetch(dev, configs)
@@ -73,7 +82,7 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, tapes=None, seed=None, 
     that knows the device already holds the state of ``configs`` (it ran the previous block and touched nothing since) passes
     ``state_current=True``; one that does not need the walkers on the host after this block passes ``fetch_configs=False``
     (open systems only: periodic containers also carry the block's wrap counters)."""
-    dev = wf.fused_device() if hasattr(wf, "fused_device") else None
+    dev = device_of(wf)
     if dev is None:
         raise TypeError("pyqmc_amd.vmc_worker drives a wave function that lives on one device handle (generate_wf); for anything else "
                         "run the reference's own pyqmc.method.mc.vmc_worker over the protocol objects (INTEGRATION.md)")
@@ -132,7 +141,7 @@ def vmc(wf, configs, nblocks=10, nsteps_per_block=10, tstep=0.5, accumulators=No
         first = source.last_block() + 1
         source.load_walkers(configs)
     df = {}
-    dev = wf.fused_device() if worker is None and hasattr(wf, "fused_device") and all(isinstance(a, EnergyAccumulator) for a in accumulators.values()) else None
+    dev = device_of(wf) if worker is None and all(isinstance(a, EnergyAccumulator) for a in accumulators.values()) else None
     current = False  # the device holds the wave-function state of the walkers it moved in the previous block
     for block in range(first, nblocks):
         # fused path: the walkers stay on the device from block to block; the state is rebuilt from the (fetched) walkers every

@@ -4,6 +4,7 @@ builds from the same files (tests/golden/g28_chk_mol.npz, make_golden.py::g_chk_
 channel functions, coordinates, charges, lattice.  The image has no HDF5 library, so the byte-scan path is what runs here; the
 h5py path is covered where h5py exists."""
 
+import json
 import os
 
 import numpy as np
@@ -52,7 +53,8 @@ def test_scan_and_h5py_backends_agree_and_errors_are_loud(tmp_path):
         with pytest.raises(RuntimeError, match="h5py"):
             chkfile.read_mol_json(path, backend="h5py")
         with pytest.raises(RuntimeError, match="h5py"):
-            chkfile.load_scf(path)
+            chkfile.load_scf(path, backend="h5py")
+        assert chkfile.load_scf(path)[1].kpts.shape == (8, 3)  # default without h5py: the built-in parser
     else:
         assert chkfile.read_mol_json(path, backend="h5py") == d
         mol, mf = chkfile.load_scf(path)
@@ -61,3 +63,75 @@ def test_scan_and_h5py_backends_agree_and_errors_are_loud(tmp_path):
     junk.write_bytes(b"\x89HDF" + b'{"atom": broken' + bytes(100))
     with pytest.raises(ValueError, match="no PySCF mol JSON"):
         chkfile.read_mol_json(str(junk), backend="scan")
+
+
+@pytest.mark.parametrize("name", ["diamond_primitive", "li_cubic_ccecp"])
+def test_hdf5lite_reads_the_reference_checkpoints(name):
+    """pyqmc_amd.hdf5lite (no HDF5 library in the images) on the reference's own PySCF checkpoint files: the group tree, the
+    variable-length ``mol`` string out of the global heap (equal to what the byte scan finds), real, complex ({r, i} compound)
+    and scalar datasets with the shapes a 2x2x2 k-point SCF has."""
+    from pyqmc_amd import hdf5lite
+
+    path = os.path.join(FILES, name + ".hdf5")
+    f = hdf5lite.File(path)
+    assert f.keys() == ["mol", "scf"] and f.is_group("scf") and not f.is_group("mol")
+    assert f.keys("scf") == ["e_tot", "kpts", "mo_coeff__from_list__", "mo_energy__from_list__", "mo_occ__from_list__"]
+    assert json.loads(f["mol"]) == chkfile.read_mol_json(path, "scan") == chkfile.read_mol_json(path, "lite")
+    assert f["scf/kpts"].shape == (8, 3) and f["scf/kpts"].dtype == np.float64 and np.all(f["scf/kpts"][0] == 0.0)
+    assert isinstance(float(f["scf/e_tot"]), float) and f["scf/e_tot"] < 0
+    nao = {"diamond_primitive": 18, "li_cubic_ccecp": 20}[name]
+    assert f.keys("scf/mo_coeff__from_list__") == [f"{k:06d}" for k in range(8)]
+    for k in range(8):
+        c, o, e = f[f"scf/mo_coeff__from_list__/{k:06d}"], f[f"scf/mo_occ__from_list__/{k:06d}"], f[f"scf/mo_energy__from_list__/{k:06d}"]
+        assert c.shape == (nao, nao) and c.dtype == np.complex128 and o.shape == e.shape == (nao,)
+        assert np.all(np.diff(e) > -1e-9) and set(np.unique(o)) <= {0.0, 1.0, 2.0}
+    assert "scf/mo_coeff" not in f and "scf/e_tot" in f and len(f.walk("/")) == 3 + 3 * 8
+    with pytest.raises(KeyError):
+        f["scf/nothing"]
+
+
+def test_load_scf_gives_orbitals_orthonormal_in_our_ao_metric():
+    """``chkfile.load_scf`` on the diamond checkpoint: a ``KMeanField`` in the layout ``generate_wf`` takes (spin-duplicated
+    KRKS orbitals, occupations occ > 0 / occ > 1 as ``mf.to_uhf()`` gives, pyscftools.py:139-146) whose k-points are exactly the
+    Gamma-folding k-points of the 2x2x2 supercell — and, the point of the exercise, orbitals that are ORTHONORMAL under the
+    overlap of the oracle's lattice-summed AOs, C_k^H S_k C_k = 1: PySCF's AO convention (normalisation, m-ordering, Bloch
+    phase) is the one the reference's in-repo evaluator and this code follow.  (S_k by midpoint quadrature over the cell.)"""
+    from oracle import pbc as opbc
+    from pyqmc_amd import pbc
+
+    cell, mf = chkfile.load_scf(os.path.join(FILES, "diamond_primitive.hdf5"), backend="lite")
+    assert type(mf).__name__ == "KMeanField" and cell.nelec == (4, 4) and abs(mf.e_tot + 10.507476186847358) < 1e-12
+    assert all(np.array_equal(mf.mo_occ[s][k], np.r_[np.ones(4), np.zeros(14)]) for s in (0, 1) for k in range(8))
+    sup = pbc.get_supercell(cell, 2.0 * np.eye(3))
+    want = pbc.get_supercell_kpts(sup)
+    frac = (mf.kpts[:, None, :] - want[None, :, :]) @ np.linalg.inv(cell.reciprocal_vectors())
+    assert np.all(np.min(np.abs(frac - np.round(frac)).max(axis=2), axis=1) < 1e-8)  # every file k-point folds onto Gamma of the supercell
+    lat = cell.lattice_vectors()
+    n = 18
+    g = (np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) / n
+    pt = opbc.PeriodicAOTable(cell, mf.kpts, pbc.lattice_points_within(lat, 30.0), precision=1e-8)
+    ao = opbc.eval_ao_pbc(pt, g @ lat, 1)[:, 0]
+    w = abs(np.linalg.det(lat)) / len(g)
+    for k in range(8):
+        C = mf.mo_coeff[0][k]
+        assert np.abs(C.conj().T @ (w * ao[k].conj().T @ ao[k]) @ C - np.eye(18)).max() < 1e-5, k
+
+
+def test_chkfile_reader_handles_labelled_atoms_kappa_and_stale_json():
+    """`_basis` / `_ecp` keyed by the atom label as given; a kappa entry refused with the intended message; a file
+    holding two different mol strings refused by the byte scan."""
+    d = chkfile.read_mol_json(os.path.join(FILES, "diamond_primitive.hdf5"), "lite")
+    lab = json.loads(json.dumps(d))
+    lab["_atom"] = [["C1", lab["_atom"][0][1]], ["C", lab["_atom"][1][1]]]
+    lab["_basis"] = {"C1": d["_basis"]["C"][:2], "C": d["_basis"]["C"]}
+    m = chkfile.mol_from_json(lab)
+    assert [m.atom_symbol(i) for i in range(2)] == ["C1", "C"] and len(m._basis["C1"]) == 2 and len(m._basis["C"]) == 3
+    kap = json.loads(json.dumps(d))
+    kap["_basis"]["C"][0] = [0, -1] + kap["_basis"]["C"][0][1:]
+    with pytest.raises(NotImplementedError, match="kappa"):
+        chkfile.mol_from_json(kap)
+    raw = open(os.path.join(FILES, "diamond_primitive.hdf5"), "rb").read()
+    other = json.dumps({"atom": "x", "_atom": []}).encode()
+    assert chkfile._scan_json(raw + b"\0" + raw) == d
+    with pytest.raises(ValueError, match="different mol JSON"):
+        chkfile._scan_json(other + b"\0" * 8 + raw)

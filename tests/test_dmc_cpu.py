@@ -367,3 +367,63 @@ def test_sharded_rundmc_writes_one_block_file_per_rank():
         # the block record is the all-reduced one: identical in both files; the shards are not
         assert np.array_equal(stores[0].datasets()["energytotal"], stores[1].datasets()["energytotal"])
         assert not np.array_equal(res[0][3], res[1][3])
+
+
+def _fake_propagate(rank):
+    def propagate(wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps=1, accumulators=None, ekey=None):
+        blk = {"energytotal": complex(-17.0 - rank, 0.25 + 0.5 * rank), "energyke": 3.0 + rank, "obdmvalue": (rank + 1.0) * np.arange(6.0).reshape(2, 3),
+               "weight": 1.0 + 0.5 * rank, "acceptance": 0.5, "tmove_acceptance": 0.0}
+        return blk, configs, weights
+    return propagate
+
+
+def _complex_block_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    import pyqmc_amd as pa
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        means, n = pdist.allreduce_block(np.array([1.0 + 2.0j * (rank + 1), 3.0 * (rank + 1)]), 2 + rank)
+        mol = systems.water()
+        wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+        np.random.seed(rank)
+        cfg = pa.initial_guess(mol, 4 + rank, rng=np.random.default_rng(rank))
+        df, _, _ = dmc.rundmc(wf, cfg, tstep=0.05, nblocks=1, nsteps_per_block=1, vmc_warmup=1, distributed=True,
+                              accumulators={"energy": OracleAccumulator(mol)}, propagate=_fake_propagate(rank), vmc_worker=helpers.protocol_vmc_worker)
+        q.put((rank, means, n, {k: np.asarray(v) for k, v in df.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rundmc_recombines_complex_and_array_valued_blocks():
+    """a complex (twisted) wave function's block carries complex <acc>ecp / <acc>total, and host accumulators
+    (density matrices) carry arrays: the sharded recombination reduces real and imaginary parts (RCCL has no complex type) and
+    keeps shapes — weight-averaged over the ranks' shards exactly as dmc.py:238-304 combines worker blocks."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_complex_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, means, n, df in res:
+        assert n == 5 and np.iscomplexobj(means)
+        assert np.allclose(means, [(2.0 + 6.0j) / 5, 9.0 / 5])
+        # ranks hold 4 and 5 walkers with block weights 1.0 and 1.5: weight of a rank in the block average = weight * walkers
+        wr = np.array([1.0 * 4, 1.5 * 5])
+        wr = wr / wr.sum()
+        assert np.allclose(df["energytotal"][0], wr[0] * complex(-17.0, 0.25) + wr[1] * complex(-18.0, 0.75))
+        assert df["energytotal"].dtype.kind == "c" and df["energyke"].dtype.kind == "f"
+        assert np.allclose(df["energyke"][0], wr[0] * 3.0 + wr[1] * 4.0)
+        assert df["obdmvalue"].shape == (1, 2, 3) and np.allclose(df["obdmvalue"][0], (wr[0] + 2.0 * wr[1]) * np.arange(6.0).reshape(2, 3))
+        assert np.allclose(df["weight"][0], (1.0 * 4 + 1.5 * 5) / 9)

@@ -359,3 +359,82 @@ def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
     for k in a:
         if k not in ("rec", "acc", "dacc"):
             assert note(f"{cfg}_{W}_pre_vs_general_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-11
+
+
+def _scf_kinetic_energy(cell, mf, n=20):
+    """2 sum_k sum_occ 1/2 int_cell |grad psi_kn|^2 — the supercell's kinetic energy of the SCF determinant — by midpoint quadrature
+    of the oracle's lattice-summed AOs over the primitive cell (periodic integrands: spectrally accurate; the role of
+    ``cell.pbc_intor('int1e_kin')`` in the reference's tests/integration/test_periodic.py:33-44).  Also returns the largest
+    deviation of C_k^H S_k C_k from the identity."""
+    from oracle import pbc as opbc
+
+    lat = cell.lattice_vectors()
+    pt = opbc.PeriodicAOTable(cell, mf.kpts, pbc.lattice_points_within(lat, 30.0), precision=1e-8)
+    g = (np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) / n
+    ao = opbc.eval_ao_pbc(pt, g @ lat, 4)
+    w = abs(np.linalg.det(lat)) / len(g)
+    ke, dev = 0.0, 0.0
+    for k in range(len(mf.kpts)):
+        for s in (0, 1):
+            C = mf.mo_coeff[s][k][:, mf.mo_occ[s][k] > 0.5]
+            dev = max(dev, np.abs(C.conj().T @ (w * ao[k, 0].conj().T @ ao[k, 0]) @ C - np.eye(C.shape[1])).max())
+            ke += sum(0.5 * w * np.sum(np.abs(ao[k, c] @ C) ** 2) for c in (1, 2, 3))
+    return ke, dev
+
+
+def test_device_path_on_an_ingested_pyscf_checkpoint():
+    """a REAL SCF result instead of the synthetic tables.  The reference's own checkpoint file
+    tests/files/diamond_primitive.hdf5 (KRKS/LDA diamond, ccECP cc-pVDZ, 2x2x2 k-points) is read without an HDF5 library
+    (``chkfile.load_scf`` -> ``hdf5lite``), its 2x2x2 supercell (BASELINE config C5's cell: 16 atoms, 64 electrons, 8 k-points)
+    goes through ``generate_wf`` like ``pyqmc.recipes`` would, and the device is checked (a) against the oracle on the same
+    ingested tables — orbitals at points inside and outside the cell, one VMC sweep of 8 walkers on the device's own draws —
+    and (b) against physics the file itself fixes, as the reference's tests/integration/test_periodic.py does: the VMC
+    kinetic energy of the Slater determinant equals the kinetic-energy integral of the stored orbitals."""
+    import os
+
+    import pyqmc_amd as pa
+    from oracle import vmc as ovmc
+    from pyqmc_amd import chkfile
+
+    cell, mf = chkfile.load_scf(os.path.join(helpers.ROOT, "tests", "golden", "files", "diamond_primitive.hdf5"), backend="lite")
+    assert cell.nelec == (4, 4) and len(mf.kpts) == 8 and mf.mo_coeff[0][0].shape == (18, 18) and np.iscomplexobj(mf.mo_coeff[0][0])
+    sup = pbc.get_supercell(cell, 2.0 * np.eye(3))
+    wf = _gpu_pbc(sup, mf)
+    dev = wf.fused_device()
+    assert dev.N == 64 and sup.natm == 16
+    # the oracle takes the occupied columns per k (its default determinant is the first n columns of the k-concatenated list)
+    occ_mf = pbc.KMeanField(mf.kpts, [[mf.mo_coeff[s][k][:, mf.mo_occ[s][k] > 0.5] for k in range(8)] for s in (0, 1)],
+                            [[np.ones(4) for _ in range(8)] for _ in (0, 1)])
+    owf = _oracle_pbc(sup, occ_mf)
+    # (a1) orbitals
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-1.5, 2.5, size=(96, 3)) @ sup.lattice_vectors()
+    ref = owf.wf_factors[0]._orb  # oracle PeriodicOrbitals
+    ao = ref.aos(pts, 5)
+    for s in (0, 1):
+        got = dev.eval_mo(s, pts, 5)
+        assert note("chk_mo_relerr", relerr(got, ref.mos(ao, s))) < 1e-10
+    # (a2) one sweep of the first walkers against the oracle on the device's draws
+    W = 256
+    start = pa.initial_guess(sup, W, rng=np.random.default_rng(23))
+    wf.recompute(start.copy())
+    acc, en, rec = dev.vmc_sweeps(0.3, 1, seed=99, energy=True, record=True)
+    x = dev.configs()
+    gauss, unif = dev.philox_tapes(99, 1, NCHECK)
+    ocfg = PeriodicConfigs(start.configs[:NCHECK].copy(), sup.lattice_vectors(), wrap=start.wrap[:NCHECK].copy())
+    record = []
+    _, ocfg = ovmc.vmc_worker(sup, owf, ocfg, 0.3, gauss, unif, with_energy=False, record=record)
+    assert np.array_equal(np.asarray(record).reshape(1, -1, NCHECK), rec[:, :, :NCHECK])
+    assert note("chk_sweep_dx", np.max(np.abs(x[:NCHECK] - ocfg.configs))) < 1e-9
+    # (b) kinetic energy of the bare determinant: VMC on the device vs the integral over the stored orbitals
+    ke_int, ortho = _scf_kinetic_energy(cell, mf)
+    assert note("chk_orthonormality", ortho) < 1e-6  # the file's orbitals are orthonormal in OUR lattice-summed AO metric
+    sl = pa.Slater(sup, mf)
+    cfg = pa.initial_guess(sup, 4096, rng=np.random.default_rng(1))
+    df, cfg = pa.vmc(sl, cfg, nblocks=14, nsteps_per_block=10, tstep=0.3, accumulators={"energy": pa.EnergyAccumulator(sup)}, seed=5)
+    ke = np.real(df["energyke"])[4:]
+    err = ke.std(ddof=1) / np.sqrt(len(ke))
+    note("chk_ke_vmc", ke.mean()); note("chk_ke_integral", ke_int); note("chk_ke_err", err)
+    assert abs(ke.mean() - ke_int) < 5 * err + 2e-3, (ke.mean(), ke_int, err)
+    g2 = np.real(df["energygrad2"])[4:] / 2  # <|grad log Psi|^2>/2 is the same integral (test_periodic.py:60-61)
+    assert abs(g2.mean() - ke_int) < 5 * g2.std(ddof=1) / np.sqrt(len(g2)) + 2e-3

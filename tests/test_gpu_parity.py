@@ -847,3 +847,71 @@ def test_two_body_jastrow_with_more_than_eight_basis_functions():
     _, ocfg = ovmc.vmc_worker(mol, ow, OpenConfigs(start.copy()), 0.3, gauss, unif, with_energy=False, record=record)
     assert np.array_equal(rec[0], np.asarray(record))
     assert note("jastrow13_fused_sweep", np.max(np.abs(dev.configs() - ocfg.configs))) < 1e-10
+
+
+def test_vmc_and_rundmc_on_a_single_factor_wave_function():
+    """a bare Slater (its own device handle, no MultiplyWF around it) runs the device sweep and the DMC block loop —
+    the drivers find the handle through ``vmc.device_of`` — and its sweep agrees with the oracle's Slater on the device's draws."""
+    import pyqmc_amd as pa
+    from oracle import vmc as ovmc
+    from oracle import wf as owf
+
+    np.random.seed(11)
+    mol = systems.water()
+    mf = systems.random_mf(mol)
+    sl = pa.Slater(mol, mf)
+    from pyqmc_amd.vmc import device_of
+
+    assert device_of(sl) is sl._dev and not hasattr(sl, "fused_device")
+    W = 64
+    start = pa.initial_guess(mol, W, rng=np.random.default_rng(5))
+    blk, cfg = pa.vmc_worker(sl, pa.OpenConfigs(start.configs.copy()), 0.3, 2, {"energy": pa.EnergyAccumulator(mol)}, seed=77)
+    assert np.isfinite(blk["energytotal"]) and 0.3 < blk["acceptance"] < 1.0
+    gauss, unif = sl._dev.philox_tapes(77, 2, W)
+    ref = owf.Slater(mol, mf.mo_coeff, None)
+    ocfg = pa.OpenConfigs(start.configs.copy())
+    ref.recompute(ocfg)
+    for s in range(2):
+        for e in range(8):
+            g, _, _ = ref.gradient_value(e, ocfg.electron(e))
+            grad = ovmc.limdrift(np.real(g.T))
+            new = ocfg.configs[:, e, :] + np.sqrt(0.3) * gauss[s, e] + 0.3 * grad
+            newpos = ocfg.make_irreducible(e, new)
+            g2, val, saved = ref.gradient_value(e, newpos)
+            fwd = np.sum((np.sqrt(0.3) * gauss[s, e]) ** 2, axis=1)
+            bwd = np.sum((np.sqrt(0.3) * gauss[s, e] + 0.3 * (grad + ovmc.limdrift(np.real(g2.T)))) ** 2, axis=1)
+            accept = np.abs(val) ** 2 * np.exp((fwd - bwd) / (2 * 0.3)) > unif[s, e]
+            ocfg.move(e, newpos, accept)
+            ref.updateinternals(e, newpos, ocfg, mask=accept, saved_values=saved)
+    assert note("bare_slater_sweep_dx", float(np.max(np.abs(cfg.configs - ocfg.configs)))) < 1e-9
+    df, cfg2, w = pa.rundmc(sl, pa.OpenConfigs(start.configs.copy()), tstep=0.02, nblocks=2, nsteps_per_block=2, vmc_warmup=2,
+                            accumulators={"energy": pa.EnergyAccumulator(mol)})
+    assert df["energytotal"].shape == (2,) and np.all(np.isfinite(df["energytotal"])) and np.allclose(w, w[0])
+
+
+def test_dmc_propagate_with_a_second_accumulator():
+    """ADVICE r3 / dmc.py:205-212: accumulators next to the energy are evaluated on the host between device steps and
+    weight-averaged like the energy.  A second energy accumulator under another key must reproduce the device's own weighted
+    step averages (exactly for the kinetic and Coulomb terms, to quadrature noise for the ECP term); the one-body density matrix comes back with its shape and a sane trace."""
+    import pyqmc_amd as pa
+
+    np.random.seed(5)
+    mol = systems.water()
+    mf = systems.random_mf(mol, nvirt=2)
+    wf = helpers.gpu_wf(mol, mf)
+    W = 128
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(8))
+    orb = np.asarray(mf.mo_coeff)
+    orb = (orb[0] if orb.ndim == 3 else orb)[:, :5]
+    accs = {"energy": pa.EnergyAccumulator(mol), "second": pa.EnergyAccumulator(mol),
+            "obdm": pa.obdm.OBDMAccumulator(mol, orb, nsweeps=2, tstep=0.4, warmup=4, spin=0)}
+    blk, cfg, w = pa.dmc_propagate(wf, cfg, np.ones(W), 0.02, 50.0, -17.0, -17.0, nsteps=3, accumulators=accs)
+    for k in ("ke", "ee", "ei", "ecp", "total"):  # (ecp: each evaluation draws its own quadrature rotations, eval_ecp.py:187-201)
+        tol = 1e-9 if k in ("ke", "ee", "ei") else 5e-3
+        assert note("dmc_second_acc_" + k, abs(blk["second" + k] - blk["energy" + k]) / (abs(blk["energy" + k]) + 1e-3)) < tol, k
+    assert blk["obdmvalue"].shape == (5, 5) and blk["obdmnorm"].shape == (5,)
+    occ = np.trace(blk["obdmvalue"] / np.sqrt(np.outer(blk["obdmnorm"], blk["obdmnorm"])))
+    assert 1.0 < occ < 5.0  # 4 spin-up electrons, most of them inside the five lowest orbitals
+    assert np.all(np.isfinite(w)) and 0.5 < blk["acceptance"] <= 1.0 and blk["weight"] > 0
+    df, _, _ = pa.rundmc(wf, cfg, tstep=0.02, nblocks=2, nsteps_per_block=2, vmc_warmup=1, accumulators=accs)
+    assert df["obdmvalue"].shape == (2, 5, 5) and np.all(np.isfinite(df["energytotal"]))
