@@ -5,6 +5,7 @@ is what runs here; the GPU twin (tests/test_gpu_parity.py::test_vmc_and_dmc_writ
 real vmc / rundmc loops."""
 
 import json
+import os
 
 import numpy as np
 import pytest
@@ -70,32 +71,104 @@ def test_periodic_walkers_keep_wrap_counters_and_h5py_absence_is_loud(tmp_path):
             blockfile.to_hdf5(str(tmp_path / "p"), str(tmp_path / "p.h5"))
 
 
-def test_h5py_backend_round_trip_matches_the_npz_store(tmp_path):
-    """Runs wherever h5py exists (NOT in this image: the HDF5 branch of blockfile.py has never executed here — INTEGRATION.md
-    says so).  The same blocks through both back ends give the same datasets, attributes and restart state; the converter
-    reproduces the direct file; and the file has the reference's extendable-dataset layout (hdftools.py:19-53)."""
-    h5py = pytest.importorskip("h5py")
+@pytest.fixture(params=["h5py", "stand-in"])
+def h5(request, monkeypatch):
+    """The HDF5 back end under test: the real h5py where it exists, and ALWAYS the in-memory stand-in (tests/fake_h5py.py),
+    which is how the h5py branches of blockfile.py execute in images without an HDF5 library."""
+    if request.param == "h5py":
+        return pytest.importorskip("h5py")
+    import fake_h5py
+
+    monkeypatch.setattr(blockfile, "h5py", fake_h5py)
+    yield fake_h5py
+    fake_h5py.forget()
+
+
+def test_h5py_backend_round_trip_matches_the_npz_store(tmp_path, h5):
+    """The same blocks through both back ends give the same datasets, attributes and restart state; the converter reproduces
+    the direct file; and the file has the reference's extendable-dataset layout (hdftools.py:19-53)."""
     lay = ref_layout()["dmc"]
     rng = np.random.default_rng(0)
     cfg = OpenConfigs(rng.standard_normal(lay["configs"][0]))
     w = rng.random(lay["configs"][0][0])
     a = blockfile.BlockFile(str(tmp_path / "a.hdf5"), backend="h5py")
     b = blockfile.BlockFile(str(tmp_path / "b"), backend="npz")
+    assert not a.exists() and a.last_block() is None
     for i in range(4):
         blk = fake_block(lay, i, rng)
         cfg.configs += 0.1
         for f in (a, b):
             f.append(blk, {"tstep": 0.02}, cfg, w)
     da, db = a.datasets(with_state=True), b.datasets(with_state=True)
-    assert sorted(da) == sorted(db)
+    assert sorted(da) == sorted(db) and a.listing() == b.listing()
     for k in da:
         assert np.array_equal(da[k], db[k]), k
-    assert a.last_block() == b.last_block() == 3 and dict(a.attrs()).keys() == dict(b.attrs()).keys()
-    with h5py.File(str(tmp_path / "a.hdf5"), "r") as f:
+    assert a.exists() and a.last_block() == b.last_block() == 3 and dict(a.attrs()).keys() == dict(b.attrs()).keys()
+    with h5.File(str(tmp_path / "a.hdf5"), "r") as f:
         assert f["energytotal"].maxshape[0] is None and f["energytotal"].shape == (4,)
+        assert f["configs"].maxshape[0] is None and f["configs"].shape == tuple(lay["configs"][0])
+    # restart state: the walkers of the LAST block, weights included (mc.py:235-243, dmc.py:466-500)
+    back = OpenConfigs(np.zeros((1, 1, 3)))
+    wb = a.load_walkers(back)
+    assert np.array_equal(back.configs, cfg.configs) and np.array_equal(wb, w)
+    # a walker count that changes between blocks (a DMC restart with another population) resizes the state datasets
+    cfg2 = OpenConfigs(rng.standard_normal((lay["configs"][0][0] + 3,) + tuple(lay["configs"][0][1:])))
+    a.append(fake_block(lay, 4, rng), {"tstep": 0.02}, cfg2, np.ones(len(cfg2.configs)))
+    assert a._state()["configs"].shape == cfg2.configs.shape and a.last_block() == 4
     blockfile.to_hdf5(str(tmp_path / "b"), str(tmp_path / "c.hdf5"))
     dc = blockfile.BlockFile(str(tmp_path / "c.hdf5"), backend="h5py").datasets(with_state=True)
-    for k in da:
-        assert np.array_equal(da[k], dc[k]), k
-    out_a, out_b = blockfile.read_mc_output(str(tmp_path / "a.hdf5")), blockfile.read_mc_output(str(tmp_path / "b"))
-    assert out_a["energytotal"] == out_b["energytotal"]
+    for k in db:
+        assert np.array_equal(db[k], dc[k]), k
+    out_a, out_b = blockfile.read_mc_output(str(tmp_path / "c.hdf5")), blockfile.read_mc_output(str(tmp_path / "b"))
+    assert out_a["energytotal"] == out_b["energytotal"] and out_a["energytotal_err"] == out_b["energytotal_err"]
+
+
+def test_vmc_and_rundmc_write_through_the_h5py_backend(tmp_path, h5):
+    """The drivers' own file handling on the HDF5 back end: vmc(hdf_file=) appends one record per block and restarts from
+    block[-1] + 1; rundmc(hdf_file=) stores weights and the per-block e_trial / e_est and continues from them — the same
+    checks test_dmc_cpu makes on the npz store.  (Oracle wave function, protocol-route workers: no GPU.)"""
+    import helpers
+    import pyqmc_amd as pa
+    from pyqmc_amd import dmc, systems
+    from test_dmc_cpu import OracleAccumulator
+
+    mol = systems.water()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    np.random.seed(1)
+    cfg = pa.initial_guess(mol, 5, rng=np.random.default_rng(1))
+    path = str(tmp_path / "v.hdf5")
+    acc = {"energy": OracleAccumulator(mol)}
+    df, cfg = pa.vmc(wf, cfg, nblocks=2, nsteps_per_block=1, tstep=0.3, accumulators=acc, hdf_file=path, worker=helpers.protocol_vmc_worker)
+    st = blockfile.BlockFile(path)
+    assert st.backend == "h5py" and st.datasets()["block"].tolist() == [0, 1] and float(st.attrs()["tstep"]) == 0.3
+    df2, cfg2 = pa.vmc(wf, pa.initial_guess(mol, 5, rng=np.random.default_rng(9)), nblocks=3, nsteps_per_block=1, tstep=0.3, accumulators=acc,
+                       hdf_file=path, worker=helpers.protocol_vmc_worker)
+    assert df2["block"].tolist() == [2] and st.datasets()["block"].tolist() == [0, 1, 2]
+    assert np.array_equal(st._state()["configs"], cfg2.configs)
+    lay = ref_layout()["vmc"]
+    assert {k: v[1] for k, v in st.listing().items()} == {k: v[1] for k, v in lay.items()}  # the reference's dataset names and dtype kinds
+    dpath = str(tmp_path / "d.hdf5")
+    kw = dict(tstep=0.05, nsteps_per_block=1, vmc_warmup=1, accumulators=acc, hdf_file=dpath, propagate=helpers.protocol_dmc_propagate,
+              vmc_worker=helpers.protocol_vmc_worker)
+    d1, c1, w1 = dmc.rundmc(wf, pa.initial_guess(mol, 5, rng=np.random.default_rng(2)), nblocks=2, **kw)
+    d2, c2, w2 = dmc.rundmc(wf, pa.initial_guess(mol, 5, rng=np.random.default_rng(3)), nblocks=3, **kw)
+    ds = blockfile.BlockFile(dpath)
+    assert ds.datasets()["block"].tolist() == [0, 1, 2] and d2["block"].tolist() == [2] and d2["e_trial"][0] == d1["e_trial"][-1]
+    assert np.array_equal(ds._state()["weights"], w2) and np.array_equal(ds._state()["configs"], c2.configs)
+    assert sorted(ds.listing()) == sorted(ref_layout()["dmc"])
+
+
+def test_chkfile_h5py_branch_on_the_reference_checkpoint(monkeypatch):
+    """chkfile.py's h5py code path (f["mol"][()], f["scf"] group access, k-point lists) executed through the stand-in serving the
+    reference's real file, against the built-in parser's result."""
+    import fake_h5py
+    from pyqmc_amd import chkfile
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "files", "diamond_primitive.hdf5")
+    monkeypatch.setattr(chkfile, "h5py", fake_h5py)
+    assert chkfile.read_mol_json(path, "h5py") == chkfile.read_mol_json(path, "lite")
+    (m1, f1), (m2, f2) = chkfile.load_scf(path, backend="h5py"), chkfile.load_scf(path, backend="lite")
+    assert np.array_equal(f1.kpts, f2.kpts) and f1.e_tot == f2.e_tot and m1.nelec == m2.nelec
+    for s in (0, 1):
+        for k in range(8):
+            assert np.array_equal(f1.mo_coeff[s][k], f2.mo_coeff[s][k]) and np.array_equal(f1.mo_occ[s][k], f2.mo_occ[s][k])

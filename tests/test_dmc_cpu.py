@@ -43,6 +43,9 @@ class OracleAccumulator:
             rot = np.array([[rng.rot() for _ in range(necp)] for _ in range(N)])
         return oenergy.energy(self.mol, configs, wf, self.threshold, rot, unif, ewald_kws=self.ewald_kws)
 
+    def avg(self, configs, wf):  # accumulators.py:77-84
+        return {k: np.mean(v, axis=0) for k, v in self(configs, wf).items()}
+
     def has_nonlocal_moves(self):
         return bool(self.mol._ecp)
 
