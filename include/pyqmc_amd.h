@@ -355,6 +355,12 @@ int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* A, const do
    (seed; walker, electron, stream, step).  Test entry: lets the CPU oracle replay a device-RNG trajectory (the role
    np.random.seed plays for the reference's vmc_worker, mc.py:119,131). */
 int pqa_philox_tapes(pqa_handle_t* h, uint64_t seed, int step, int64_t W, double* gauss, double* unif);
+/* The same for pqa_dmc_steps without tapes: every array of pqa_dmc_tapes_t for `nsteps` steps of `seed`, restricted to walkers
+   0..W-1, in the tape layouts above (the members of `out` point to caller-allocated HOST arrays of those shapes; tm_* may be
+   NULL for systems without ECPs) — T-move grid rotations, mask uniforms, selection / acceptance uniforms, drift-diffusion
+   normals and uniforms, and the energy evaluations' quadrature rotations and mask uniforms (index 0 = starting energy).
+   Test entry: the CPU oracle's dmc_propagate (pyqmc/method/dmc.py:123-221) replays a device-RNG block walker by walker. */
+int pqa_philox_dmc_tapes(pqa_handle_t* h, uint64_t seed, int nsteps, int64_t W, pqa_dmc_tapes_t* out);
 
 /* ---- measurement -------------------------------------------------------------------- */
 /* HIP-event timing on the handle's own stream (torch.cuda.Event only sees torch's stream). */

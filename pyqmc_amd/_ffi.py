@@ -107,6 +107,7 @@ _PROTOTYPES = {
     "pqa_dm_fetch": (C.c_int, [_H, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]),
     "pqa_gram": (C.c_int, [_H, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pqa_philox_tapes": (C.c_int, [_H, C.c_uint64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pqa_philox_dmc_tapes": (C.c_int, [_H, C.c_uint64, C.c_int, C.c_int64, C.c_void_p]),
     "pqa_timer_start": (C.c_int, [_H]),
     "pqa_timer_stop": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "pqa_sync": (C.c_int, [_H]),

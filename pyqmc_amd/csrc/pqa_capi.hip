@@ -1595,6 +1595,56 @@ extern "C" int pqa_philox_tapes(pqa_handle_t* h, uint64_t seed, int step, int64_
   return copy_out(h, unif, h->b_unif.p, NW * sizeof(double));
 }
 
+// out[c][w] = the uniform of Philox(seed; walker w, counter c, stream, step) — what ecp_pass / k_tm_count / k_tm_walker draw
+static __global__ __launch_bounds__(256) void k_uniform_plane(uint64_t seed, uint32_t stream, uint32_t step, long ncount, long W, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= ncount * W) return;
+  const long c = idx / W, w = idx - c * W;
+  const Philox p = philox(seed, (uint32_t)w, (uint32_t)c, stream, step);
+  out[idx] = u01(p.c[0], p.c[1]);
+}
+extern "C" int pqa_philox_dmc_tapes(pqa_handle_t* h, uint64_t seed, int nsteps, int64_t W, pqa_dmc_tapes_t* out) {
+  HIPCHK(hipSetDevice(h->device));
+  if (W <= 0 || nsteps <= 0 || !out || !out->gauss || !out->unif) FAIL("pqa_philox_dmc_tapes: bad arguments");
+  const int N = h->N, necp = h->necp;
+  const size_t NW = (size_t)N * W, nrot = (size_t)N * std::max(necp, 1);
+  if (necp > 0 && (!out->ecp_rot || !out->ecp_unif)) FAIL("pqa_philox_dmc_tapes: ECP systems need ecp_rot and ecp_unif");
+  const bool tm = necp > 0 && out->tm_rot && out->tm_unif && out->tm_u1 && out->tm_u2;
+  TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_unif, std::max(NW, nrot * (size_t)W) * sizeof(double)));
+  TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
+  auto plane = [&](uint32_t stream, uint32_t step, size_t ncount, const double* dst) -> int {
+    hipLaunchKernelGGL(k_uniform_plane, dim3((unsigned)((ncount * W + 255) / 256)), dim3(256), 0, h->stream, seed, stream, step, (long)ncount, (long)W,
+                       (double*)h->b_unif.p);
+    TRY(check_launch(h, "k_uniform_plane"));
+    return copy_out(h, const_cast<double*>(dst), h->b_unif.p, ncount * W * sizeof(double));
+  };
+  auto rots = [&](uint64_t sd, uint32_t step, const double* dst) -> int {
+    hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, sd, step, (double*)h->b_rot.p);
+    TRY(check_launch(h, "k_gen_rot"));
+    return copy_out(h, const_cast<double*>(dst), h->b_rot.p, nrot * 9 * sizeof(double));
+  };
+  for (int i = 0; i <= nsteps; ++i) {
+    if (necp > 0) {  // energy evaluation i (0: the starting configuration; energy_dev's draws)
+      TRY(rots(seed, (uint32_t)i, out->ecp_rot + (size_t)i * nrot * 9));
+      TRY(plane(PQA_STREAM_ECPMASK, (uint32_t)i, nrot, out->ecp_unif + (size_t)i * nrot * W));
+    }
+    if (i == nsteps) break;
+    if (tm) {
+      TRY(rots(seed ^ 0x9E3779B97F4A7C15ull, (uint32_t)i, out->tm_rot + (size_t)i * nrot * 9));
+      TRY(plane(PQA_STREAM_TMMASK, (uint32_t)i, nrot, out->tm_unif + (size_t)i * nrot * W));
+      TRY(plane(PQA_STREAM_TM_U1, (uint32_t)i, (size_t)N, out->tm_u1 + (size_t)i * NW));
+      TRY(plane(PQA_STREAM_TM_U2, (uint32_t)i, (size_t)N, out->tm_u2 + (size_t)i * NW));
+    }
+    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)i, N, (long)W,
+                       (double*)h->b_gauss.p, (double*)h->b_unif.p);
+    TRY(check_launch(h, "k_tile_draws"));
+    TRY(copy_in(h, const_cast<double*>(out->gauss) + (size_t)i * NW * 3, h->b_gauss.p, NW * 3 * sizeof(double)));
+    TRY(copy_out(h, const_cast<double*>(out->unif) + (size_t)i * NW, h->b_unif.p, NW * sizeof(double)));
+  }
+  return 0;
+}
+
 extern "C" int pqa_sync(pqa_handle_t* h) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));

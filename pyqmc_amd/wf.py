@@ -290,6 +290,23 @@ class DeviceWF:
             self.call("pqa_philox_tapes", int(seed), s, int(W), _ffi.ptr(gauss[s]), _ffi.ptr(unif[s]))
         return gauss, unif
 
+    def philox_dmc_tapes(self, seed, nsteps, W, tmoves=True):
+        """The draws ``dmc_steps(..., tapes=None, seed=seed)`` makes for walkers 0..W-1, as the tape dictionary ``dmc_steps`` takes
+        (``pqa_philox_dmc_tapes``): lets the CPU oracle replay a device-RNG DMC block."""
+        N, necp = self.N, getattr(self, "necp", 0)
+        t = {"gauss": np.empty((nsteps, N, W, 3)), "unif": np.empty((nsteps, N, W))}
+        if necp:
+            t["ecp_rot"], t["ecp_unif"] = np.empty((nsteps + 1, N, necp, 3, 3)), np.empty((nsteps + 1, N, necp, W))
+            if tmoves:
+                t["tm_rot"], t["tm_unif"] = np.empty((nsteps, N, necp, 3, 3)), np.empty((nsteps, N, necp, W))
+                t["tm_u1"], t["tm_u2"] = np.empty((nsteps, N, W)), np.empty((nsteps, N, W))
+        tp = _ffi.DmcTapes()
+        for name, _ in _ffi.DmcTapes._fields_:
+            if name in t:
+                setattr(tp, name, t[name].ctypes.data)
+        self.call("pqa_philox_dmc_tapes", int(seed), int(nsteps), int(W), C.addressof(tp))
+        return t
+
     def resample(self, newinds):
         """``pqa_resample``: walker w of the resident state becomes a copy of walker ``newinds[w]``."""
         idx = np.ascontiguousarray(newinds, dtype=np.int32)

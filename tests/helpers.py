@@ -157,6 +157,52 @@ class ReplayTape:
         return next(self._rnd)
 
 
+class DeviceDmcTape:
+    """Serves the draws of a device-RNG DMC block (``DeviceWF.philox_dmc_tapes``: the arrays of ``pqa_dmc_tapes_t`` for walkers
+    0..W-1) to ``oracle.dmc.dmc_propagate`` in the order the reference consumes them (dmc.py:146-196) — the inverse of
+    ``pyqmc_amd.dmc._record_tapes``."""
+
+    def __init__(self, t, N, necp, tmoves):
+        self.q = {k: [] for k in ("normal", "rand", "rand1", "rot", "random")}
+        nsteps = t["gauss"].shape[0]
+
+        def energy(i):
+            for e in range(N):
+                for k in range(necp):
+                    self.q["random"].append(t["ecp_unif"][i, e, k])
+                    self.q["rot"].append(t["ecp_rot"][i, e, k])
+
+        energy(0)
+        for i in range(nsteps):
+            if tmoves:
+                for e in range(N):
+                    for k in range(necp):
+                        self.q["random"].append(t["tm_unif"][i, e, k])
+                        self.q["rot"].append(t["tm_rot"][i, e, k])
+                    self.q["rand1"].extend(float(u) for u in t["tm_u1"][i, e])
+                    self.q["rand"].append(t["tm_u2"][i, e])
+            for e in range(N):
+                self.q["normal"].append(t["gauss"][i, e])
+                self.q["rand"].append(t["unif"][i, e])
+            energy(i + 1)
+        self.it = {k: iter(v) for k, v in self.q.items()}
+
+    def normal(self, W):
+        return next(self.it["normal"])
+
+    def rand(self, W):
+        return next(self.it["rand"])
+
+    def rand1(self):
+        return next(self.it["rand1"])
+
+    def rot(self):
+        return next(self.it["rot"])
+
+    def random(self, W):
+        return next(self.it["random"])
+
+
 def ccoeff_params(mol, na=4, nb=4, seed=12):
     return 0.1 * np.random.default_rng(seed).standard_normal((mol.natm, na, na, nb, 3))
 

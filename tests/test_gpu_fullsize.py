@@ -172,6 +172,27 @@ def test_dmc_steps_at_baseline_size():
     frac = x @ np.linalg.inv(sup.lattice_vectors())
     assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12
     assert note("C5_dmc_update_vs_recompute", np.max(np.abs(dev.recompute(x)[1] - logv))) < 1e-9
+    # the first walkers of the 4096, replayed by the oracle's dmc_propagate (dmc.py:123-221) on the device's own draws
+    # (pqa_philox_dmc_tapes): every T-move and drift-diffusion decision, the walkers, and the weights
+    from oracle import dmc as odmc
+
+    nchk, nst = 4, 2
+    wf.recompute(_container(sup, x0))
+    w = np.ones(W)
+    bc = 10.0 * float(np.std(en0[5]))
+    dev.dmc_steps(0.02, nst, w, bc, etrial, etrial, seed=77)
+    xd = dev.configs()
+    tape = dev.philox_dmc_tapes(77, nst, nchk)
+    owf = build("C5")[2]()
+    ocfg = _container(sup, x0[:nchk].copy(), np.zeros((nchk, 64, 3)))
+    record = []
+    _, ocfg, ow = odmc.dmc_propagate(sup, owf, ocfg, np.ones(nchk), 0.02, bc, etrial, etrial, nst, helpers.DeviceDmcTape(tape, 64, dev.necp, True),
+                                     record=record)
+    n_t = sum(int(r[2].sum()) for r in record if r[0] == "t")
+    n_d = sum(int((~r[2]).sum()) for r in record if r[0] == "d")
+    note("C5_dmc_oracle_tmoves_accepted", n_t); note("C5_dmc_oracle_diffusion_rejected", n_d)
+    assert note("C5_dmc_vs_oracle_configs", np.max(np.abs(xd[:nchk] - ocfg.configs))) < 1e-9
+    assert note("C5_dmc_vs_oracle_weights", np.max(np.abs(w[:nchk] - ow) / ow)) < 1e-8
 
 
 def test_vmc_philox_energy_statistics():
