@@ -133,7 +133,7 @@ def cpu_baseline(walkers_per_core, tstep, nsteps=2, max_procs=0):
                 "walker_steps": sum(r[3] for r in res), "seconds": t_end - t_begin, "late": max(r[1] for r in res) - start_at}
 
     c_leg, np_leg = leg("c"), leg("numpy")
-    return {"value": c_leg["value"], "unit": "walker-steps/s", "cores": P, "kind": "port", "ao_backend": "c++ (oracle/ao_eval.c, gcc -O3 -ffast-math, single thread per process)",
+    return {"value": c_leg["value"], "unit": "walker-steps/s", "cores": P, "kind": "port", "ao_backend": "c (oracle/ao_eval.c, gcc -O3, single thread per process)",
             "per_core": c_leg["per_core"], "ao_share_of_wall_time": c_leg["ao_share_of_wall_time"],
             "cpu_model": model, "socket_physical_cores": socket, "cgroup_cpu_quota": quota,
             "socket_extrapolated": c_leg["per_core"] * socket,

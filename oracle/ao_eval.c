@@ -68,7 +68,8 @@ static void solid_harmonics(const double* v, int lmax, int deriv, double* S, dou
 /* shells must be grouped by atom (as AOTable builds them).  Returns 0, or -1 if a shell has l > 3.
  * Loop structure of the reference: per atom the displacement / r^2 arrays of all points, per shell the radial sums with the
  * POINT loop innermost (radial_gto*: `for c in coeffs: for a in range(npts)`), which is what lets the compiler vectorise the
- * exponential (numba compiles these loops with fastmath=True; here -O3 -ffast-math + libmvec).  Points go in blocks that fit L1. */
+ * exponential (numba compiles these loops with fastmath=True; gcc -O3 here — -ffast-math was measured and changes nothing: oracle/Makefile).
+ * Points go in blocks that fit L1. */
 #define BLK 128
 int ao_eval(int ncomp, long npts, const double* pts, int nshell, const int* shell_atom, const int* shell_l, const int* prim_off,
             const double* exps, const double* coefs, const int* ao_off, const double* atom_xyz, int nao, double* out) {
@@ -112,6 +113,97 @@ int ao_eval(int ncomp, long npts, const double* pts, int nshell, const int* shel
               for (int i = 0; i < 3; ++i) o[(size_t)(1 + i) * plane + m] = dS[p][sl + m][i] * R[p] + S[p][sl + m] * d * v[i];
             if (ncomp == 5)
               o[4 * plane + m] = S[p][sl + m] * lapR[p] + 2.0 * d * (dS[p][sl + m][0] * v[0] + dS[p][sl + m][1] * v[1] + dS[p][sl + m][2] * v[2]);
+          }
+        }
+      }
+      s0 = s1;
+    }
+  }
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Periodic (lattice-summed, Bloch-phased) AOs: pyqmc/wf/numba/pbcgto.py:99-506 restated like the molecular routine above —
+ *   pbc_eval_gto / _grad / _lap   pbcgto.py:205-225, 300-330, 400-440: per atom, per translation j < num_Ls[atom] of the
+ *   norm-sorted list Ls, v = r - R_atom - Ls[j]; points with r^2 > atom_cut[atom] are skipped (:217); per shell points pass
+ *   r^2 < shell_cut (values, :254) / not r^2 > shell_cut (derivatives, :356); the shell's functions are added to every
+ *   k-point's output weighted by the Bloch phase e^{i k.Ls[j]} (:222-224, phases precomputed :620-621).
+ * The same tests, the same image order, the same sums as oracle/pbc.py:eval_ao_pbc (the NumPy restatement this is checked
+ * against to 1e-12).  phases: [nL][nk] real (cplx = 0) or [nL][nk][2] (re, im); out: [nk][ncomp][npts][nao] doubles, or
+ * interleaved (re, im) pairs when cplx.  pts must already be folded into the primitive cell (as PeriodicOrbitals.aos does). */
+int ao_eval_pbc(int ncomp, long npts, const double* pts, int nshell, const int* shell_atom, const int* shell_l, const int* prim_off,
+                const double* exps, const double* coefs, const int* ao_off, const double* atom_xyz, int nao,
+                int nk, const double* Ls, const int* num_Ls, const double* atom_cut, const double* shell_cut, const double* phases, int cplx,
+                double* out) {
+  const int deriv = ncomp > 1, cf = cplx ? 2 : 1;
+  const size_t plane = (size_t)npts * nao * cf, kplane = plane * ncomp;
+  for (int s = 0; s < nshell; ++s)
+    if (shell_l[s] > 3) return -1;
+  for (size_t i = 0; i < kplane * nk; ++i) out[i] = 0.0;
+  double vx[BLK], vy[BLK], vz[BLK], r2[BLK], R[BLK], dRs[BLK], lapR[BLK];
+  double S[BLK][16], dS[BLK][16][3];
+  int idx[BLK], sidx[BLK];
+  double val[5][7];
+  for (long p0 = 0; p0 < npts; p0 += BLK) {
+    const int nb_ = (int)((npts - p0 < BLK) ? npts - p0 : BLK);
+    for (int s0 = 0; s0 < nshell;) {
+      const int ia = shell_atom[s0];
+      int s1 = s0, lmax = 0;
+      while (s1 < nshell && shell_atom[s1] == ia) { if (shell_l[s1] > lmax) lmax = shell_l[s1]; ++s1; }
+      for (int j = 0; j < num_Ls[ia]; ++j) {
+        int n = 0;
+        for (int p = 0; p < nb_; ++p) {  /* points inside the atom's cut-off for this image */
+          const double x = pts[3 * (p0 + p)] - atom_xyz[3 * ia] - Ls[3 * j], y = pts[3 * (p0 + p) + 1] - atom_xyz[3 * ia + 1] - Ls[3 * j + 1],
+                       z = pts[3 * (p0 + p) + 2] - atom_xyz[3 * ia + 2] - Ls[3 * j + 2];
+          const double rr = x * x + y * y + z * z;
+          if (rr > atom_cut[ia]) continue;
+          vx[n] = x; vy[n] = y; vz[n] = z; r2[n] = rr; idx[n] = p;
+          ++n;
+        }
+        if (n == 0) continue;
+        for (int q = 0; q < n; ++q) {
+          const double v[3] = {vx[q], vy[q], vz[q]};
+          solid_harmonics(v, lmax, deriv, S[q], dS[q]);
+        }
+        for (int s = s0; s < s1; ++s) {
+          const int l = shell_l[s], nb = 2 * l + 1, off = ao_off[s], sl = l * l;
+          int m_ = 0;
+          for (int q = 0; q < n; ++q)
+            if (ncomp == 1 ? (r2[q] < shell_cut[s]) : !(r2[q] > shell_cut[s])) sidx[m_++] = q;
+          if (m_ == 0) continue;
+          for (int t = 0; t < m_; ++t) R[t] = dRs[t] = lapR[t] = 0.0;
+          for (int pq = prim_off[s]; pq < prim_off[s + 1]; ++pq) {
+            const double a = exps[pq], c = coefs[pq];
+            if (ncomp == 5) {
+              for (int t = 0; t < m_; ++t) { const double rr = r2[sidx[t]], e = c * exp(-rr * a); R[t] += e; dRs[t] += a * e; lapR[t] += e * (2.0 * a) * (2.0 * a * rr - 3.0); }
+            } else if (deriv) {
+              for (int t = 0; t < m_; ++t) { const double e = c * exp(-r2[sidx[t]] * a); R[t] += e; dRs[t] += a * e; }
+            } else {
+              for (int t = 0; t < m_; ++t) R[t] += c * exp(-r2[sidx[t]] * a);
+            }
+          }
+          for (int t = 0; t < m_; ++t) {
+            const int q = sidx[t];
+            const double v[3] = {vx[q], vy[q], vz[q]}, d = -2.0 * dRs[t];
+            for (int m = 0; m < nb; ++m) {
+              val[0][m] = S[q][sl + m] * R[t];
+              if (deriv)
+                for (int i = 0; i < 3; ++i) val[1 + i][m] = dS[q][sl + m][i] * R[t] + S[q][sl + m] * d * v[i];
+              if (ncomp == 5)
+                val[4][m] = S[q][sl + m] * lapR[t] + 2.0 * d * (dS[q][sl + m][0] * v[0] + dS[q][sl + m][1] * v[1] + dS[q][sl + m][2] * v[2]);
+            }
+            for (int k = 0; k < nk; ++k) {
+              double* o = out + (size_t)k * kplane + ((size_t)(p0 + idx[q]) * nao + off) * cf;
+              if (cplx) {
+                const double pr = phases[((size_t)j * nk + k) * 2], pi = phases[((size_t)j * nk + k) * 2 + 1];
+                for (int c = 0; c < ncomp; ++c)
+                  for (int m = 0; m < nb; ++m) { o[c * plane + 2 * m] += pr * val[c][m]; o[c * plane + 2 * m + 1] += pi * val[c][m]; }
+              } else {
+                const double pr = phases[(size_t)j * nk + k];
+                for (int c = 0; c < ncomp; ++c)
+                  for (int m = 0; m < nb; ++m) o[c * plane + m] += pr * val[c][m];
+              }
+            }
           }
         }
       }

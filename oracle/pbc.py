@@ -104,12 +104,38 @@ class PeriodicAOTable:
         self.phases = ph.real if np.abs(ph.imag).max() < 1e-9 else ph  # np.real_if_close, pbcgto.py:620-621
 
 
+def _eval_ao_pbc_c(pt, pts, ncomp):
+    """oracle/ao_eval.c:ao_eval_pbc — the compiled twin of the routine below (same tests, same image order, same sums)."""
+    import ctypes
+
+    from . import gto
+
+    f = gto._flat_tables(pt.table)
+    cplx = np.iscomplexobj(pt.phases)
+    nk = len(pt.kpts)
+    out = np.zeros((nk, ncomp, len(pts), pt.table.nao), dtype=complex if cplx else float)
+    ph = np.ascontiguousarray(pt.phases)
+    dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+    c = lambda a, ty: np.ascontiguousarray(a, dtype=ty)
+    Ls, numL, acut, scut = c(pt.Ls, float), c(pt.num_Ls, np.int32), c(pt.atom_cut, float), c(pt.shell_cut, float)
+    rc = gto._ao_lib().ao_eval_pbc(ncomp, len(pts), pts.ctypes.data_as(dp), len(f["l"]), f["atom"].ctypes.data_as(ip), f["l"].ctypes.data_as(ip),
+                                   f["prim_off"].ctypes.data_as(ip), f["exps"].ctypes.data_as(dp), f["coefs"].ctypes.data_as(dp),
+                                   f["ao_off"].ctypes.data_as(ip), f["xyz"].ctypes.data_as(dp), pt.table.nao, nk, Ls.ctypes.data_as(dp),
+                                   numL.ctypes.data_as(ip), acut.ctypes.data_as(dp), scut.ctypes.data_as(dp),
+                                   ph.view(float).ctypes.data_as(dp) if cplx else ph.ctypes.data_as(dp), int(cplx), out.view(float).ctypes.data_as(dp))
+    return out if rc == 0 else None
+
+
 def eval_ao_pbc(pt, pts, ncomp):
     """(nk, ncomp, npts, nao) lattice-summed AOs at points inside the primitive cell."""
     from . import gto
 
     t = pt.table
-    pts = np.asarray(pts, dtype=float).reshape(-1, 3)
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=float).reshape(-1, 3))
+    if gto._AO_BACKEND == "c" and ncomp in (1, 4, 5) and len(pts):
+        out = _eval_ao_pbc_c(pt, pts, ncomp)  # None: a shell with l > 3
+        if out is not None:
+            return out
     out = np.zeros((len(pt.kpts), ncomp, len(pts), t.nao), dtype=pt.phases.dtype)
     deriv = ncomp > 1
     for ia in range(len(t.coords)):

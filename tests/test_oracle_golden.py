@@ -224,7 +224,7 @@ def test_testvalue_many_matches_reference():
 
 
 def test_compiled_ao_backend_of_the_oracle_matches_the_numpy_routine():
-    """oracle/ao_eval.c (the CPU baseline's AO evaluator: the same loops compiled, -ffast-math) against oracle/gto.py's NumPy
+    """oracle/ao_eval.c (the CPU baseline's AO evaluator: the same loops compiled) against oracle/gto.py's NumPy
     routine — itself pinned to the reference by g2 — on the metric system and on H2O: value, gradient, Laplacian."""
     from oracle import gto
 

@@ -389,3 +389,33 @@ def test_oracle_complex_testvalue_many_matches_reference():
     epos = cfg.make_irreducible(0, g["cplx_aux"])
     for nm, w in (("slater", wf.wf_factors[0]), ("j2", wf.wf_factors[1]), ("wf", wf)):
         assert relerr(w.testvalue_many(g["cplx_es"], epos), g[f"cplx_{nm}"]) < 1e-9, nm
+
+
+@pytest.mark.parametrize("tag", ["real_k222", "complex_twist"])
+def test_compiled_periodic_ao_evaluator_equals_the_numpy_restatement(tag):
+    """oracle/ao_eval.c:ao_eval_pbc (the CPU baseline's periodic AO back end: pbcgto.py:99-506 compiled, as the reference's
+    default periodic evaluator is compiled code, orbitals.py:103-115) against oracle/pbc.py:eval_ao_pbc — the routine the
+    golden vectors g15 / g19 / g20 pin — for values, gradients and Laplacians, real (2x2x2 Gamma-folding k-points) and complex
+    (twisted) Bloch phases, every k-point."""
+    from oracle import gto, pbc as opbc
+    from pyqmc_amd import pbc, systems
+
+    cell = systems.diamond_primitive()
+    sup = pbc.get_supercell(cell, 2.0 * np.eye(3))
+    kpts = pbc.get_supercell_kpts(sup)
+    if tag == "complex_twist":
+        kpts = kpts + np.array([0.25, 0.1, -0.3]) @ sup.reciprocal_vectors()
+    lat = cell.lattice_vectors()
+    pt = opbc.PeriodicAOTable(cell, kpts, pbc.lattice_points_within(lat, 30.0))
+    assert np.iscomplexobj(pt.phases) == (tag == "complex_twist")
+    pts = np.random.default_rng(4).random((150, 3)) @ lat
+    try:
+        for ncomp in (1, 4, 5):
+            gto.set_ao_backend("numpy")
+            ref = opbc.eval_ao_pbc(pt, pts, ncomp)
+            gto.set_ao_backend("c")
+            got = opbc.eval_ao_pbc(pt, pts, ncomp)
+            assert got.shape == ref.shape == (len(kpts), ncomp, 150, cell.nao()) and got.dtype == ref.dtype
+            assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 1e-12, ncomp
+    finally:
+        gto.set_ao_backend("numpy")

@@ -4,10 +4,10 @@
 
 Same model as bench.py's `cpu_baseline`: P concurrent single-thread processes (P = the CPUs the container may use, at most the
 physical cores of one socket), each running the NumPy ORACLE — reference algorithm and structure — on its own walkers; all start
-together; rate = total walker-steps / (last end - first start).  Molecular AOs come from the compiled routine (oracle/ao_eval.c);
-the periodic configurations (c3, c5) evaluate their lattice-summed AOs in NumPy (the oracle has no compiled periodic evaluator), which
-dominates their time: `ao_share_of_wall_time` says how much, and `non_ao_rate` gives the rate with the AO time taken out — the
-reference's default periodic AO back end (pyscf's compiled eval_gto) sits between the two.  Prints one JSON line per configuration."""
+together; rate = total walker-steps / (last end - first start).  AOs come from the compiled routines of oracle/ao_eval.c — molecular
+(`ao_eval`) and, since round 4, periodic lattice sums (`ao_eval_pbc`: pbcgto.py:99-506 compiled, as the reference's default
+periodic back end is compiled code) — `ao_share_of_wall_time` says how much of the time they are, `non_ao_rate_per_core` gives
+the rate with the AO time taken out (`--ao numpy` reproduces the round-3 lines with NumPy lattice sums).  One JSON line per configuration."""
 import argparse
 import json
 import multiprocessing as mp
@@ -18,11 +18,11 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SIZES = {"c2": (2048, 4), "c3": (24, 1), "c4": (256, 4), "c5": (8, 1)}  # (walkers per process, steps): a few seconds of work each
+SIZES = {"c2": (2048, 4), "c3": (256, 2), "c4": (256, 4), "c5": (64, 1)}  # (walkers per process, steps): a few seconds of work each
 
 
 def worker(args):
-    name, idx, cpu, start_at = args
+    name, idx, cpu, start_at, ao = args
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ[v] = "1"
     if cpu is not None:
@@ -41,7 +41,7 @@ def worker(args):
     from pyqmc_amd import pbc, systems
     from helpers import NumpyRNG as _NumpyRNG
 
-    ogto.set_ao_backend("c")
+    ogto.set_ao_backend(ao)
     W, nsteps = SIZES[name]
     rng = np.random.default_rng(5 + idx)
     np.random.seed(5 + idx)
@@ -89,6 +89,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["c2", "c3", "c4", "c5"])
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--ao", default="c", choices=["c", "numpy"])
     a = ap.parse_args()
     cpus, model = bench.socket_cores()
     socket = len(cpus)
@@ -102,12 +103,12 @@ def main():
     for name in a.configs:
         start_at = time.time() + 25.0 + 0.05 * P
         with ctx.Pool(P) as pool:
-            res = pool.map(worker, [(name, i, cpus[i], start_at) for i in range(P)], chunksize=1)
+            res = pool.map(worker, [(name, i, cpus[i], start_at, a.ao) for i in range(P)], chunksize=1)
         t_begin, t_end = min(r[1] for r in res), max(r[2] for r in res)
         per_core = sum(r[3] / (r[2] - r[1]) for r in res) / P
         print(json.dumps({"config": name, "value": sum(r[3] for r in res) / (t_end - t_begin), "unit": "walker-steps/s", "cores": P, "per_core": per_core,
                           "socket_extrapolated": per_core * socket, "socket_physical_cores": socket, "cpu_model": model, "kind": "port",
-                          "ao_backend": "c (oracle/ao_eval.c)" if name in ("c2", "c4") else "numpy (periodic lattice sums: no compiled evaluator in the oracle)",
+                          "ao_backend": ("c (oracle/ao_eval.c: " + ("ao_eval" if name in ("c2", "c4") else "ao_eval_pbc") + ", gcc -O3)") if a.ao == "c" else "numpy",
                           "ao_share_of_wall_time": sum(r[4] for r in res) / sum(r[2] - r[1] for r in res),
                           "non_ao_rate_per_core": sum(r[3] / max(r[2] - r[1] - r[4], 1e-9) for r in res) / P,
                           "sample": f"{P} processes x {SIZES[name][0]} walkers x {SIZES[name][1]} steps in {t_end - t_begin:.1f} s; "

@@ -1,6 +1,6 @@
 """VMC energy of a physically shaped H2O trial function from the CPU ORACLE, to a ~1 mHa error bar -> tests/golden/g29_energy_stats.npz
 
-    python tools/make_energy_stats.py [--procs 8] [--walkers 1000] [--samples 170]
+    python tools/make_energy_stats.py [--procs 8] [--walkers 1000] [--samples 1100]      (440 s on 8 cores: -16.682816 +- 0.000626 Ha)
 
 north_star asks for energies "within 1 mHa statistical error of reference".  With random orbitals sigma(E_L) ~ 5 Ha and such a
 statement cannot fail; here the orbitals are the eigenvectors of a model one-electron Hamiltonian (pyqmc_amd.systems.model_mf,
@@ -9,7 +9,7 @@ P independent single-thread chains (own seeds, own ECP rotations / masks) here i
 equilibration sweeps, then an energy sample every 3rd sweep.  Stored: the wave-function parameters (so the device test evaluates
 EXACTLY this function), the mean, and its standard error from the per-walker means (independent Markov chains: no
 autocorrelation estimate needed).  The GPU test (tests/test_gpu_fullsize.py::test_energy_statistics_against_the_oracle) runs the
-same function with the device's own Philox streams and asserts |dE| < 3 sigma_combined with sigma_combined <= 2 mHa."""
+same function with the device's own Philox streams and asserts |dE| < 3 sigma_combined with sigma_combined <= 1 mHa."""
 import argparse
 import multiprocessing as mp
 import os
@@ -87,7 +87,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=8)
     ap.add_argument("--walkers", type=int, default=1000)
-    ap.add_argument("--samples", type=int, default=170)
+    ap.add_argument("--samples", type=int, default=1100)
     a = ap.parse_args()
     mol, mo, acoeff, bcoeff = trial_function()
     t0 = time.time()
