@@ -915,3 +915,42 @@ def test_dmc_propagate_with_a_second_accumulator():
     assert np.all(np.isfinite(w)) and 0.5 < blk["acceptance"] <= 1.0 and blk["weight"] > 0
     df, _, _ = pa.rundmc(wf, cfg, tstep=0.02, nblocks=2, nsteps_per_block=2, vmc_warmup=1, accumulators=accs)
     assert df["obdmvalue"].shape == (2, 5, 5) and np.all(np.isfinite(df["energytotal"]))
+
+
+def test_func3d_golden_through_a_one_electron_jastrow():
+    """SURVEY a9 directly on the device: the radial functions of pyqmc/wf/func3d.py — PolyPadeFunction
+    :52-108, CutoffCuspFunction :112-199 — against the reference's own values (tests/golden/g4_func3d.npz) through a Jastrow
+    factor that IS one function: one ion at the origin, one electron, acoeff = 1 for a single basis function, so
+    log Psi(r) = f(|r|), grad log Psi = grad f, lap log Psi + |grad log Psi|^2 = (lap e^f) / e^f.  Inside the cut-off the golden's
+    numbers, at r = rcut and beyond exactly zero (func3d.py:97-98, :150-152)."""
+    import pyqmc_amd as pa
+    from pyqmc_amd.func3d import CutoffCuspFunction, PolyPadeFunction
+
+    g = golden("g4_func3d")
+    r, rvec = g["r"], g["rvec"]
+    assert np.any(r == 1.5) and np.any(r == 7.5) and np.any(r > 7.5) and np.any(r < 0.1)  # the grid holds both cut-offs themselves and both sides
+    mol = systems.Mol(["H"], np.zeros((1, 3)), nelec=(1, 0), basis={"H": [[0, [1.0, 1.0]]]}, ecp={}, charges=[1.0])
+    cases = {"pade_2.0_1.5": (PolyPadeFunction(2.0, 1.5), 1.5), "cusp_2.0_1.5": (CutoffCuspFunction(2.0, 1.5), 1.5),
+             "pade_0.2_7.5": (PolyPadeFunction(0.2, 7.5), 7.5), "cusp_24_7.5": (CutoffCuspFunction(24.0, 7.5), 7.5)}
+    cfg = pa.OpenConfigs(rvec.reshape(-1, 1, 3).copy())
+    far = pa.OpenConfigs(np.full((len(r), 1, 3), 100.0))
+    for key, (fn, rcut) in cases.items():
+        ja = pa.JastrowSpin(mol, [fn], [CutoffCuspFunction(24.0, rcut)])
+        a = np.zeros((1, 1, 2))
+        a[0, 0, :] = 1.0
+        ja.parameters["acoeff"] = a
+        inside = r < rcut
+        _, u = ja.recompute(cfg)
+        assert note(f"func3d_{key}_value", np.max(np.abs(u[inside] - g[key + "_value"][inside]))) < 1e-14
+        assert np.all(u[~inside] == 0.0)
+        ja.recompute(far)  # every walker parked far outside: U = 0, so the ratio at a test position is e^{f(r)}
+        grad, val, _ = ja.gradient_value(0, pa.OpenElectron(rvec.copy()))
+        assert np.max(np.abs(np.log(val[inside]) - g[key + "_value"][inside])) < 1e-13 and np.all(val[~inside] == 1.0)
+        assert note(f"func3d_{key}_grad", np.max(np.abs(grad.T[inside] - g[key + "_grad"][inside]))) < 1e-13
+        assert np.all(grad.T[~inside] == 0.0)
+        gl, lap = ja.gradient_laplacian(0, pa.OpenElectron(rvec.copy()))
+        ok = inside & np.isfinite(g[key + "_lap"])
+        bare = lap - np.sum(gl * gl, axis=0)  # jastrowspin.py:360-385 returns lap Psi / Psi = lap f + |grad f|^2
+        scale = 1.0 + np.abs(g[key + "_lap"][ok])
+        assert note(f"func3d_{key}_lap", np.max(np.abs(bare[ok] - g[key + "_lap"][ok]) / scale)) < 1e-12
+        assert np.all(lap[~inside] == 0.0)
