@@ -176,12 +176,15 @@ def extra_measurements(pa, wf, dev, mol, W, args):
 def rank_table(torch, dist, rank, local_rank, world):
     """One line per rank for the JSON: which device each process of the job really sits on, and the communicator's size as the
     process group reports it (so an 8-GPU record shows 8 distinct devices over RCCL, not 8 processes on one)."""
-    p = torch.cuda.get_device_properties(local_rank)
-    bus = None
-    if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
-        bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
-    me = {"rank": rank, "local_rank": local_rank, "device": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "pci_bus_id": bus,
-          "hbm_gb": round(p.total_memory / 2**30, 1), "compute_units": p.multi_processor_count}
+    if torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(local_rank)
+        bus = None
+        if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            bus = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+        me = {"rank": rank, "local_rank": local_rank, "device": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "pci_bus_id": bus,
+              "hbm_gb": round(p.total_memory / 2**30, 1), "compute_units": p.multi_processor_count}
+    else:  # (control-flow tests of the multi-rank bookkeeping on a CPU box)
+        me = {"rank": rank, "local_rank": local_rank, "device": "cpu", "gcn_arch": None, "pci_bus_id": None, "hbm_gb": 0.0, "compute_units": 0}
     if dist is None:
         return {"rccl_ranks": 1, "backend": None, "ranks": [me]}
     table = [None] * world
@@ -269,19 +272,23 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     eref, esig = float(m1), float(np.sqrt(max(m2 - m1 * m1, 0.0)))
     weights = np.ones(W)
     nsb = 5
-    stats = {"moved": 0, "bytes": 0, "blocks": 0}
+    stats = {"moved": 0, "bytes": 0, "blocks": 0, "gather_s": 0.0, "exchange_s": 0.0, "state_s": 0.0}
+    wrng = np.random.default_rng(4242 + rank)
 
     def block(current):
         nonlocal cfg, weights
         blk, cfg, weights = dmc_propagate(wf, cfg, weights, 0.02, 10 * esig, eref, eref, nsteps=nsb, accumulators=acc, state_current=current)
         pdist.allreduce_block([blk["energytotal"] * blk["weight"] * W, blk["weight"] * W], W, device=red_dev)
-        cfg, weights, info, _ = pdist.branch_distributed(cfg, weights, dev=dev)
+        if args.unbalance > 0:  # rehearsal: the shards' total weights pushed apart so that the comb re-assigns walkers across ranks
+            weights = weights * (1.0 + args.unbalance * (rank % 2)) * np.exp(0.3 * wrng.standard_normal(len(weights)))
+        cfg, weights, info, _ = pdist.branch_distributed(cfg, weights, dev=dev, device_buffers=True if args.device_buffers else None)
         stats["moved"] += info["walkers moved"]; stats["bytes"] += info["bytes exchanged"]; stats["blocks"] += 1
+        stats["gather_s"] += info["gather seconds"]; stats["exchange_s"] += info["exchange seconds"]; stats["state_s"] += info["state seconds"]
         return blk
 
     for i in range(max(args.warmup, 1)):
         block(i > 0)
-    stats.update(moved=0, bytes=0, blocks=0)
+    stats.update(moved=0, bytes=0, blocks=0, gather_s=0.0, exchange_s=0.0, state_s=0.0)
     nblocks = max((args.steps + nsb - 1) // nsb, 1)
     fence()
     t0 = time.perf_counter()
@@ -293,6 +300,9 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+    tbytes = torch.tensor([float(stats["bytes"])], dtype=torch.float64, device=red_dev)
+    if dist is not None:
+        dist.all_reduce(tbytes)
     info = rank_table(torch, dist, rank, local_rank, world)
     if rank == 0:
         steps = nblocks * nsb
@@ -306,6 +316,11 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
             **info, "energy_total": float(blk["energytotal"]), "acceptance": float(blk["acceptance"]), "tmove_acceptance": float(blk["tmove_acceptance"]),
             "branching": {"blocks": stats["blocks"], "walkers_moved_per_block": stats["moved"] / max(stats["blocks"], 1),
                           "bytes_sent_per_block_rank0": stats["bytes"] / max(stats["blocks"], 1),
+                          "bytes_sent_per_block_all_ranks": float(tbytes.item()) / max(stats["blocks"], 1),
+                          "ms_per_block_rank0": {"weights_all_gather_and_comb": 1e3 * stats["gather_s"] / max(stats["blocks"], 1),
+                                                 "pack_and_point_to_point": 1e3 * stats["exchange_s"] / max(stats["blocks"], 1),
+                                                 "state_gather_and_recompute_of_arrivals": 1e3 * stats["state_s"] / max(stats["blocks"], 1)},
+                          "unbalance": args.unbalance, "device_buffers": bool(args.device_buffers) or args.backend == "nccl",
                           "exchange": "all-gather of weights + point-to-point coordinates of re-assigned walkers only (RCCL)"}}), flush=True)
 
 
@@ -328,6 +343,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the orbital kernel with HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for control-flow tests)")
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: all ranks use GPU 0 (needs --backend gloo)")
+    ap.add_argument("--unbalance", type=float, default=0.0, help="--mode dmc rehearsal: odd ranks' weights scaled by 1 + this before every comb (and all "
+                    "weights spread log-normally), so that walkers cross ranks in every block")
+    ap.add_argument("--device-buffers", action="store_true", help="--mode dmc under gloo: pack / unpack the exchanged walkers in GPU tensors and hand the "
+                    "library device pointers (the RCCL code path with gloo as the transport only)")
     args = ap.parse_args()
 
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):

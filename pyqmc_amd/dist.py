@@ -100,7 +100,11 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
 
     The new local order is: walkers that stayed (comb order), then arrivals by source rank (comb order) — walkers are
     exchangeable and carry equal weights after the comb.  Returns (configs, weights, info, global weight std); ``info`` also
-    reports ``walkers moved`` (global) and ``bytes exchanged`` (sent by this rank)."""
+    reports ``walkers moved`` (global), ``bytes exchanged`` (sent by this rank) and the wall time of the three stages on this
+    rank: ``gather seconds`` (weights all-gather + comb), ``exchange seconds`` (packing + point-to-point transfers) and
+    ``state seconds`` (gather of the kept walkers' state + recompute of the arrivals)."""
+    import time
+
     import torch
     import torch.distributed as dist
 
@@ -111,7 +115,8 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
 
         wstd = float(np.std(weights))
         cfg, w, info = branch(configs, weights, base_u, on_resample=None if dev is None else dev.resample)
-        return cfg, w, {**info, "walkers moved": 0, "bytes exchanged": 0}, wstd
+        return cfg, w, {**info, "walkers moved": 0, "bytes exchanged": 0, "gather seconds": 0.0, "exchange seconds": 0.0, "state seconds": 0.0}, wstd
+    t_start = time.perf_counter()
     world, rank = dist.get_world_size(), dist.get_rank()
     nccl = dist.get_backend() == "nccl"
     tdev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")  # what the transport moves
@@ -136,6 +141,7 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
     # next to the rank that holds the source.
     newinds = np.sort(newinds)
     keep, recv, send = exchange_plan(newinds, counts, rank)
+    t_plan = time.perf_counter()
     x = configs.configs
     nx = int(np.prod(x.shape[1:]))
     periodic = hasattr(configs, "wrap")  # PeriodicConfigs: the wrap counters travel with the coordinates (coord.py:191-198)
@@ -168,6 +174,7 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
     nrecv = sum(recv.values())
     got = torch.cat([inbox[q] for q in sorted(inbox)], dim=0) if nrecv else torch.empty((0, row), dtype=torch.float64, device=tdev)
     got_host = got.cpu().numpy()
+    t_xchg = time.perf_counter()
     if dev is not None:  # state follows the walkers that stay; arrivals are recomputed (device pointer when packed on the GPU)
         gx = got[:, :nx].to(bdev).contiguous()
         if on_gpu:
@@ -182,5 +189,6 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
     moved = int(np.sum(np.searchsorted(np.concatenate([[0], np.cumsum(counts)]), newinds, side="right") - 1
                        != np.repeat(np.arange(world), counts)))
     info = {"max branches": int(cnt.max()), "Number of walkers killed": int(len(gw) - len(unique)), "walkers moved": moved,
-            "bytes exchanged": int(sent_bytes), "device_buffers": bool(on_gpu)}
+            "bytes exchanged": int(sent_bytes), "device_buffers": bool(on_gpu), "gather seconds": t_plan - t_start,
+            "exchange seconds": t_xchg - t_plan, "state seconds": time.perf_counter() - t_xchg}
     return configs, new_w, info, float(np.std(gw))

@@ -142,3 +142,58 @@ def test_distributed_branch_eight_ranks_c5_like_weights():
         # most of a rank's new walkers were already its own: arrivals are a small minority on every rank
         own = np.sum((r[1][:, 0, 0] / 6 >= lo) & (r[1][:, 0, 0] / 6 < hi))
         assert own > 0.97 * (hi - lo)
+
+
+def _bench_logic_worker(rank, world, port, q):
+    import argparse
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, helpers.ROOT)
+        import bench
+
+        weak = bench.local_walkers(argparse.Namespace(scaling="weak", walkers=0), rank, world, 4096, 32768)
+        weak_set = bench.local_walkers(argparse.Namespace(scaling="weak", walkers=1000), rank, world, 4096, 32768)
+        strong = bench.local_walkers(argparse.Namespace(scaling="strong", walkers=0), rank, world, 4096, 32769)
+        table = bench.rank_table(torch, dist, rank, 0, world)
+        # the block reduction bench.py's timed region ends with: per-rank energy sums -> global walker-weighted means
+        en = np.full((3, 6), 1.0 + rank)  # (steps, energy rows) of this rank's shard
+        W = strong[0]
+        means, count = pdist.allreduce_block(en.sum(axis=0) * W, en.shape[0] * W, device="cpu")
+        tmax = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        q.put((rank, weak, weak_set, strong, table, means, count, float(tmax.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multi_rank_bookkeeping_two_ranks_gloo():
+    """The parts of bench.py an N > 1 run adds to the N = 1 one — walkers per rank for weak / strong scaling (`local_walkers`),
+    the per-rank device table and communicator size (`rank_table`), the block reduction and the max-over-ranks clock — driven
+    at world size 2 over gloo (no GPU): what `SCALE_rNN.json` will be computed from is exercised before the first 8-GPU run."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_logic_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [(4096, 8192), (4096, 8192)]  # weak: the per-GPU default on every rank, total = per-GPU x ranks
+    assert [r[2] for r in res] == [(1000, 2000), (1000, 2000)]
+    assert [r[3] for r in res] == [(16385, 32769), (16384, 32769)]  # strong: the config's total split like configs.split (coord.py:72-80)
+    for r in res:
+        t = r[4]
+        assert t["rccl_ranks"] == 2 and t["backend"] == "gloo" and [e["rank"] for e in t["ranks"]] == [0, 1]
+        assert np.allclose(r[5], (1.0 * 16385 + 2.0 * 16384) / 32769) and r[6] == 3 * 32769 and r[7] == 2.0
