@@ -209,7 +209,10 @@ int pqa_get_configs(pqa_handle_t* h, double* configs);
 
 /* Slater.pgradient (slater.py:462-542): d Psi / Psi with respect to the determinant coefficients, d_det (W, ndet)
    (:495-505), and to the orbital coefficients of each spin, d_mo_* (W, nao, nmo_s) (:507-533, _testcol :382-388),
-   from the resident state (call after recompute / updateinternals).  Any output may be NULL. */
+   from the resident state (call after recompute / updateinternals).  Any output may be NULL.  Complex handles (complex
+   orbitals / twisted cells): every output is complex, (re, im) interleaved, nmo_s counting orbitals — the holomorphic
+   derivative the reference forms in complex arithmetic; twisted cells take the (complex) AO values of the unfolded
+   walkers with their wrap phases. */
 int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn);
 
 /* ThreeBodyJastrow.pgradient (three_body_jastrow.py:657-719): dU/dccoeff, d_ccoeff (W, natom, na3, na3, nb3, 3), from the

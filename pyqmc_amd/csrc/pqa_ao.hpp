@@ -579,6 +579,41 @@ static __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, do
   }
 }
 
+// AO values of a TWISTED cell at arbitrary (unfolded) points: sum_L e^{i k_t.L} phi(r - R - L) times the wrap phase of the fold
+// (orbitals.py:203-213).  out: real plane [P][nao] followed by the imaginary plane.  One thread per point, direct image tests.
+// Used by the parameter gradient of complex determinants (pqa_slater_pgradient).
+static __global__ void k_ao_tw(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  int dw[3];
+  fold_cell(S, px, py, pz, dw);
+  double wsn, wcs;
+  sincos(dw[0] * S.pb->ktl[0] + dw[1] * S.pb->ktl[1] + dw[2] * S.pb->ktl[2], &wsn, &wcs);
+  PbcCtx ctx;
+  const PrimWrap pw = prim_wrap(S, px, py, pz);
+  double* ore = out + p * S.nao;
+  double* oim = out + (P + p) * (long)S.nao;
+  for (int sh = 0; sh < S.nshell; ++sh) {
+    const int ia = S.shell_atom[sh], p0 = S.shell_prim_off[sh], ao0 = S.shell_ao_off[sh];
+    const double x = px - S.atom_xyz[3 * ia], y = py - S.atom_xyz[3 * ia + 1], z = pz - S.atom_xyz[3 * ia + 2];
+    bool accum = false;
+    auto st_re = [&](int m, double v, double, double, double, double) { if (accum) ore[ao0 + m] += v; else ore[ao0 + m] = v; };
+    auto st_im = [&](int m, double v, double, double, double, double) { if (accum) oim[ao0 + m] += v; else oim[ao0 + m] = v; };
+    pbc_ctx_update(S, ctx, ia, x, y, z, pw);
+    shell_eval_pbc<1, true>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, st_re, st_im, accum,
+                            [&](int j, double& lx, double& ly, double& lz, double& cj, double& sj) {
+                              lx = S.pb->Ls[3 * j]; ly = S.pb->Ls[3 * j + 1]; lz = S.pb->Ls[3 * j + 2];
+                              cj = S.pb->img_phase[2 * j]; sj = S.pb->img_phase[2 * j + 1];
+                            });
+    for (int m = 0; m < 2 * S.shell_l[sh] + 1; ++m) {  // wrap phase of the point
+      const double re = ore[ao0 + m], im = oim[ao0 + m];
+      ore[ao0 + m] = re * wcs - im * wsn;
+      oim[ao0 + m] = re * wsn + im * wcs;
+    }
+  }
+}
+
 // plain contraction out[c][p][j] = sum_a ao[c][p][a] C[a][j]  (A/B check of the MFMA kernel only)
 static __global__ void k_mo_valu(const double* __restrict__ ao, const double* __restrict__ C, long rows, int nao, int nmo,
                           double* __restrict__ out) {

@@ -974,31 +974,41 @@ extern "C" int pqa_testvalue_many(pqa_handle_t* h, const int32_t* es, int ne, co
 
 extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo_up, double* d_mo_dn) {
   TRY(sync_aos(h));
-  if (h->cplx) FAIL("complex orbitals: only the wave-function protocol entry points are implemented so far");
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
   const long W = h->W;
-  TRY(slater_value_dev(h));  // sign / log of the determinant expansion -> b_sign, b_log
-  TRY(ensure(h, h->b_pgdet, (size_t)W * h->ndet * sizeof(double)));
-  hipLaunchKernelGGL(k_pgrad_det, dim3((unsigned)((W * h->ndet + 255) / 256)), dim3(256), 0, h->stream, h->S, h->st,
-                     (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
+  const size_t cf = h->cplx ? 2 : 1;  // complex handles: every output is complex, (re, im) interleaved; nmo below counts orbitals
+  TRY(slater_value_dev(h));  // sign (complex: phase) / log of the determinant expansion -> b_sign, b_log
+  TRY(ensure(h, h->b_pgdet, cf * W * h->ndet * sizeof(double)));
+  const dim3 gd((unsigned)((W * h->ndet + 255) / 256));
+  if (h->cplx) hipLaunchKernelGGL(k_pgrad_det_c, gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
+  else hipLaunchKernelGGL(k_pgrad_det, gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
   TRY(check_launch(h, "k_pgrad_det"));
-  if (d_det) TRY(copy_out(h, d_det, h->b_pgdet.p, (size_t)W * h->ndet * sizeof(double)));
+  if (d_det) TRY(copy_out(h, d_det, h->b_pgdet.p, cf * W * h->ndet * sizeof(double)));
   double* outs[2] = {d_mo_up, d_mo_dn};
   if (!d_mo_up && !d_mo_dn) return 0;
-  const size_t nao_all = (size_t)W * h->N * h->nao;
+  // AO values of every electron at its position: real, or for a twisted cell complex (two planes; the walkers of a twisted
+  // handle are unfolded: k_ao_tw folds every point and gives it its wrap phase)
+  const long ao_plane = W * h->N * (long)h->nao;
+  const size_t nao_all = (size_t)ao_plane * (h->twist ? 2 : 1);
   if (nao_all * sizeof(double) > ((size_t)16 << 30)) FAIL("orbital-coefficient gradients need the AO values of all electrons: too many walkers for one call");
   TRY(ensure(h, h->b_ao, nao_all * sizeof(double)));
-  hipLaunchKernelGGL(k_ao<1>, dim3((unsigned)((W * h->N + 63) / 64)), dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N,
-                     (double*)h->b_ao.p);
+  const dim3 ga((unsigned)((W * h->N + 63) / 64));
+  if (h->twist) hipLaunchKernelGGL(k_ao_tw, ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
+  else hipLaunchKernelGGL(k_ao<1>, ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
   TRY(check_launch(h, "k_ao"));
   for (int s = 0; s < 2; ++s) {
     const int n = s ? h->ndn : h->nup;
     if (!outs[s] || n == 0 || h->nmo[s] == 0) continue;
-    const size_t nout = (size_t)W * h->nao * h->nmo[s];
+    const size_t nout = (size_t)W * h->nao * h->nmo[s];  // (complex: nmo[s] = 2 x orbitals, i.e. already the doubles of the complex result)
     TRY(ensure(h, h->b_out, nout * sizeof(double)));
-    hipLaunchKernelGGL(k_pgrad_mo, dim3((unsigned)W), dim3(256), (size_t)h->ndet_s[s] * sizeof(double), h->stream, h->S, h->st, s,
-                       (const double*)h->b_ao.p, (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
+    const size_t lds = cf * (size_t)h->ndet_s[s] * sizeof(double);
+    if (!h->cplx) hipLaunchKernelGGL(k_pgrad_mo, dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s,
+                                     (const double*)h->b_ao.p, (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
+    else if (h->twist) hipLaunchKernelGGL(k_pgrad_mo_c<true>, dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s, (const double*)h->b_ao.p, ao_plane,
+                                          (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
+    else hipLaunchKernelGGL(k_pgrad_mo_c<false>, dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s, (const double*)h->b_ao.p, ao_plane,
+                            (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
     TRY(check_launch(h, "k_pgrad_mo"));
     TRY(copy_out(h, outs[s], h->b_out.p, nout * sizeof(double)));
   }

@@ -277,3 +277,65 @@ static __global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState
     for (int k = threadIdx.x; k < 5 * nmo2; k += 64) c[k] = row[k];
   }
 }
+
+// ---------------------------------------------------------------- parameter gradients of complex determinants (slater.py:462-542)
+// d_det[w][di] = D_up D_dn / Psi (complex, interleaved): phase_up phase_dn e^{log_up + log_dn - log|Psi|} / phase(Psi).
+static __global__ void k_pgrad_det_c(SysDev S, SlaterState st, const double* __restrict__ psi_phase, const double* __restrict__ psi_log,
+                                     long W, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W * S.ndet) return;
+  const long w = idx / S.ndet;
+  const int di = (int)(idx % S.ndet), u0 = S.det_map[di], u1 = S.det_map[S.ndet + di];
+  const cx pp = {psi_phase[2 * w], psi_phase[2 * w + 1]};
+  cx v = {0.0, 0.0};
+  if (pp.r != 0.0 || pp.i != 0.0) {
+    cx ph = {1.0, 0.0};
+    double lg = 0.0;
+    if (S.nup > 0) { const double* q = st.dsign[0] + 2 * (w * S.ndet_s[0] + u0); ph = cmul(ph, cx{q[0], q[1]}); lg += st.dlog[0][w * S.ndet_s[0] + u0]; }
+    if (S.ndn > 0) { const double* q = st.dsign[1] + 2 * (w * S.ndet_s[1] + u1); ph = cmul(ph, cx{q[0], q[1]}); lg += st.dlog[1][w * S.ndet_s[1] + u1]; }
+    v = cdiv(cscale(ph, exp(lg - psi_log[w])), pp);
+  }
+  out[2 * idx] = v.r; out[2 * idx + 1] = v.i;
+}
+
+// d_mo[w][a][m] = sum_di coeff[di] d_det[w][di] * sum_e ao[w][e][a] inverse_u[col(m)][e]  (holomorphic: no conjugation; _testcol
+// slater.py:382-388 in complex arithmetic).  ao: [W*N][nao] real AOs, or with AOCX (twisted cells) the real plane followed by
+// the imaginary plane, each [W*N][nao].  out: [W][nao][nmo] complex interleaved, nmo = orbitals.  grid = W, block = 256.
+template <bool AOCX>
+static __global__ __launch_bounds__(256) void k_pgrad_mo_c(SysDev S, SlaterState st, int s, const double* __restrict__ ao, long ao_plane,
+                                                           const double* __restrict__ d_det, const int* __restrict__ colmap,
+                                                           double* __restrict__ out) {
+  extern __shared__ double wu[];  // [ndet_s][2]
+  const long w = blockIdx.x;
+  const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], nmo2 = S.nmo[s], nmo = nmo2 / 2, nao = S.nao;
+  for (int u = threadIdx.x; u < D; u += blockDim.x) {
+    cx acc = {0.0, 0.0};
+    for (int di = 0; di < S.ndet; ++di)
+      if (S.det_map[s * S.ndet + di] == u) {
+        const double* q = d_det + 2 * (w * S.ndet + di);
+        acc = cadd(acc, cscale(cx{q[0], q[1]}, S.det_coeff[di]));
+      }
+    wu[2 * u] = acc.r; wu[2 * u + 1] = acc.i;
+  }
+  __syncthreads();
+  const double* aow = ao + ((size_t)w * S.nelec + (size_t)s * S.nup) * nao;
+  const double* Tw = st.T[s] + (size_t)w * D * n * n * 2;
+  for (int idx = threadIdx.x; idx < nao * nmo; idx += blockDim.x) {
+    const int a = idx / nmo, m = idx % nmo;
+    cx acc = {0.0, 0.0};
+    for (int u = 0; u < D; ++u) {
+      const int col = colmap[u * nmo2 + m];
+      if (col < 0) continue;
+      const double* Tu = Tw + (size_t)u * n * n * 2;
+      cx t = {0.0, 0.0};
+      for (int e = 0; e < n; ++e) {
+        const cx tv = {Tu[2 * (e * n + col)], Tu[2 * (e * n + col) + 1]};
+        const cx av = {aow[(size_t)e * nao + a], AOCX ? aow[ao_plane + (size_t)e * nao + a] : 0.0};
+        t = cadd(t, cmul(av, tv));
+      }
+      acc = cadd(acc, cmul(cx{wu[2 * u], wu[2 * u + 1]}, t));
+    }
+    out[2 * (((size_t)w * nao + a) * nmo + m)] = acc.r;
+    out[2 * (((size_t)w * nao + a) * nmo + m) + 1] = acc.i;
+  }
+}

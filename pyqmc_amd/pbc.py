@@ -199,21 +199,21 @@ def fold_mo_coeff(supercell, kpts, mo_coeff):
 
 
 def unfold_mo_gradient(supercell, kpts, d_super, nmo_k):
-    """Chain rule of ``fold_mo_coeff`` for real phases: derivatives w.r.t. the folded supercell coefficients
+    """Chain rule of ``fold_mo_coeff``: derivatives w.r.t. the folded supercell coefficients
     ``d_super`` (..., nao_super, sum_k nmo_k) -> derivatives w.r.t. the per-k blocks, concatenated over k like the
     reference's ``mo_coeff_alpha`` parameter (..., nao_prim, sum_k nmo_k) (orbitals.py:154-160, slater.py:511-527):
-    d/dC_k[(a,m), n] = sum_c cos(k . T_c) d/dC_super[(a,c,m), (k,n)]."""
+    d/dC_k[(a,m), n] = sum_c e^{i k . T_c} d/dC_super[(a,c,m), (k,n)] (C_super = e^{i k . T_c} C_k is holomorphic in C_k;
+    real phases and derivatives stay real)."""
     prim = supercell.original_cell
     kpts = np.asarray(kpts, dtype=float).reshape(-1, 3)
     copies = get_supercell_copies(prim.lattice_vectors(), supercell.S)
     phase = np.exp(1j * copies @ kpts.T)
-    if np.abs(phase.imag).max() > 1e-9:
-        raise NotImplementedError("orbital-coefficient gradients with complex Bloch phases")
-    phase = phase.real
+    if np.abs(phase.imag).max() <= 1e-9 and not np.iscomplexobj(d_super):
+        phase = phase.real
     nao_atom = [sum(2 * sh[0] + 1 for sh in prim._basis[n]) for n in prim._names]
     ncopy = len(copies)
     lead = d_super.shape[:-2]
-    out = np.zeros(lead + (sum(nao_atom), d_super.shape[-1]))
+    out = np.zeros(lead + (sum(nao_atom), d_super.shape[-1]), dtype=np.result_type(phase.dtype, d_super.dtype))
     col = np.concatenate([[0], np.cumsum(nmo_k)])
     row = prow = 0
     for na in nao_atom:

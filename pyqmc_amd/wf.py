@@ -575,11 +575,11 @@ class Slater(_DeviceFactor):
         self._mol = mol
         self._nelec = tuple(mol.nelec)
         self._dev = _dev
-        self._fold = _fold if (_fold is not None and not _dev.cplx) else None
+        self._fold = _fold
         items = {"det_coeff": _dev.det_coeff.copy(), "mo_coeff_alpha": _dev.mo_coeff[0].copy(), "mo_coeff_beta": _dev.mo_coeff[1].copy()}
         if self._fold is not None:
             for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
-                items[key] = np.concatenate([np.real(b) for b in self._fold["blocks"][sp]], axis=1)
+                items[key] = np.concatenate([np.asarray(b) if _dev.cplx else np.real(b) for b in self._fold["blocks"][sp]], axis=1)
         self._bind_parameters(items)
         self._det_occup = [o.tolist() for o in _dev.det_occup]
         self._det_map = _dev.det_map
@@ -589,13 +589,14 @@ class Slater(_DeviceFactor):
     def _bind_parameters(self, items):
         to_device = {}
         if self._fold is not None:
-            # periodic (real) determinants: the parameters have the reference's layout — per-k blocks (nao_prim, nmo_k)
+            # periodic determinants (real or complex): the parameters have the reference's layout — per-k blocks (nao_prim, nmo_k)
             # concatenated over k (orbitals.py:154-160) — and are folded into supercell coefficients when pushed
             from . import pbc as _pbc
 
+            cplx = self._dev.cplx
             for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):
                 split = np.cumsum(self._fold["nmo_k"][sp])[:-1]
-                to_device[key] = (lambda v, split=split: np.real(_pbc.fold_mo_coeff(
+                to_device[key] = (lambda v, split=split: (np.asarray if cplx else np.real)(_pbc.fold_mo_coeff(
                     self._mol, self._fold["kpts"], [np.split(np.asarray(v), split, axis=1)] * 2)[0]))
         self.parameters = _DeviceParams(self._dev, items, to_device)
 
@@ -658,17 +659,17 @@ class Slater(_DeviceFactor):
 
     def pgradient(self):
         """slater.py:462-542: d Psi / Psi w.r.t. ``det_coeff`` (nconf, ndet) and the orbital coefficients
-        (nconf, nao, nmo_s); zero-sized entries are dropped like the reference does (:537-541)."""
+        (nconf, nao, nmo_s); zero-sized entries are dropped like the reference does (:537-541).  Complex determinants
+        (complex Bloch phases or coefficients, twisted cells) give complex, holomorphic derivatives."""
         d = self._dev
-        if d.pbc and self._fold is None:
-            raise NotImplementedError("orbital-coefficient gradients of complex periodic Slater determinants are not implemented")
         W = d.W
-        out = {"det_coeff": np.empty((W, d.ndet)), "mo_coeff_alpha": np.empty((W, d.nao, d.nmo[0])),
-               "mo_coeff_beta": np.empty((W, d.nao, d.nmo[1]))}
+        dt = complex if d.cplx else float
+        out = {"det_coeff": np.empty((W, d.ndet), dtype=dt), "mo_coeff_alpha": np.empty((W, d.nao, d.nmo[0]), dtype=dt),
+               "mo_coeff_beta": np.empty((W, d.nao, d.nmo[1]), dtype=dt)}
         d.call("pqa_slater_pgradient", _ffi.ptr(out["det_coeff"]),
                _ffi.ptr(out["mo_coeff_alpha"]) if out["mo_coeff_alpha"].size else None,
                _ffi.ptr(out["mo_coeff_beta"]) if out["mo_coeff_beta"].size else None)
-        if self._fold is not None:  # periodic: chain rule back to the per-k blocks of the parameter (slater.py:511-527)
+        if d.pbc and self._fold is not None:  # periodic: chain rule back to the per-k blocks of the parameter (slater.py:511-527)
             from . import pbc as _pbc
 
             for sp, key in enumerate(("mo_coeff_alpha", "mo_coeff_beta")):

@@ -1272,6 +1272,37 @@ def g_complex_testvalue_many():
     save("g25_complex_testvalue_many", **out)
 
 
+# ------------------------------------------------------------------ G31 pgradient of complex determinants
+def g_complex_pgrad():
+    """wf.pgradient() (slater.py:462-542, PBCOrbitalEvaluatorKpoints.pgradient orbitals.py:239-254) for complex Bloch orbitals:
+    the 3x1x1 supercell at k = 0, 1/3, 2/3 b1 (complex phases e^{ik.L}, complex coefficients) and the twisted cells of g20, walkers
+    partly OUTSIDE the cell (wrap counters != 0: the derivative carries the wrap phase of every electron).  The orbital parameters
+    are the per-k blocks (nao_prim, nmo_k) concatenated over k; their derivatives are complex and holomorphic (no conjugation)."""
+    from pyqmc.configurations.coord import PeriodicConfigs
+
+    out = {}
+    sup, mf, Ls, oe, sl, j2, wf = ref_pbc_wf_complex()
+    cases = {"cplx": (sup, sl, wf, 3)}
+    for tag in TWIST_CASES:
+        sup2, mf2, Ls2, oe2, sl2, j22, wf2, W2, el2 = ref_twisted_wf(tag)
+        cases["twist_" + tag] = (sup2, sl2, wf2, 3)
+    for tag, (cell, slater, full, W) in cases.items():
+        rng = np.random.default_rng(310 + len(out))
+        true_x = systems.initial_guess(cell, W, rng=rng).configs + (rng.integers(-1, 2, size=(W, sum(cell.nelec), 3)) @ cell.lattice_vectors())
+        cfg = PeriodicConfigs(true_x.copy(), cell.lattice_vectors())  # folds the walkers and sets their wrap counters
+        out[tag + "_configs"], out[tag + "_wrap"] = cfg.configs.copy(), cfg.wrap.copy()
+        assert np.abs(cfg.wrap).max() > 0
+        full.recompute(cfg)
+        for nm, w in (("slater", slater), ("wf", full)):
+            pg = w.pgradient()
+            out[f"{tag}_{nm}_keys"] = np.asarray(sorted(pg.keys()))
+            for k, v in pg.items():
+                out[f"{tag}_{nm}_pgrad_{k}"] = np.asarray(v)
+        for k, v in slater.parameters.items():
+            out[f"{tag}_param_{k}"] = np.asarray(v)
+    save("g31_complex_pgrad", **out)
+
+
 # ------------------------------------------------------------------ G27 on-disk layout (hdftools)
 class _FakeDataset:
     def __init__(self, shape, dtype):
@@ -1524,3 +1555,4 @@ if __name__ == "__main__":
     g_hdf_layout()
     g_chk_mol()
     g_pbc_complex_dmc()
+    g_complex_pgrad()

@@ -800,3 +800,51 @@ def test_fold_only_minimal_image_in_the_jastrow_pairs_is_bitwise_the_full_reduct
         out.append((dev.configs(), dev.value()[1], np.asarray(en), avg.copy(), dacc.copy(), w.copy()))
     for p, q in zip(*out):
         assert np.array_equal(p, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["cplx", "twist_prim", "twist_s211"])
+def test_complex_pgradient_matches_reference(tag):
+    """Slater.pgradient for COMPLEX determinants (slater.py:462-542 in complex arithmetic): complex Bloch phases
+    and coefficients on the 3x1x1 supercell, and twisted cells whose AOs are complex lattice sums (k_ao_tw) — walkers partly
+    outside the cell, so every electron's wrap phase enters.  The derivatives w.r.t. the determinant coefficients and the
+    per-k orbital blocks (the reference's parameter layout: complex (nao_prim, sum_k nmo_k)) against the reference's
+    (tests/golden/g31_complex_pgrad.npz), for the bare Slater factor and inside the product; plus a complex finite difference
+    along one coefficient (holomorphic: the same derivative along the real and the imaginary direction)."""
+    import pyqmc_amd as pa
+    from helpers import pbc_complex_case, twist_case
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g31_complex_pgrad")
+    sup, mf = pbc_complex_case() if tag == "cplx" else twist_case(tag[6:])
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    sl = wf.wf_factors[0]
+    for k in ("det_coeff", "mo_coeff_alpha", "mo_coeff_beta"):  # the parameters themselves, in the reference's per-k layout
+        ref = g[f"{tag}_param_{k}"]
+        assert np.shape(sl.parameters[k]) == ref.shape and helpers.relerr(sl.parameters[k], ref) < 1e-13, k
+    cfg = PeriodicConfigs(g[tag + "_configs"].copy(), sup.lattice_vectors(), wrap=g[tag + "_wrap"].copy())
+    s0, l0 = wf.recompute(cfg)
+    for nm, w, pre in (("slater", sl, ""), ("wf", wf, "wf1")):
+        pg = w.pgradient()
+        assert sorted(pg.keys()) == g[f"{tag}_{nm}_keys"].tolist()
+        for k, v in pg.items():
+            ref = g[f"{tag}_{nm}_pgrad_{k}"]
+            assert v.shape == ref.shape and v.dtype == ref.dtype, k
+            assert note(f"cpgrad_{tag}_{nm}_{k}", helpers.relerr(v, ref)) < 1e-8, k
+    pg = sl.pgradient()
+    C = np.array(sl.parameters["mo_coeff_beta"])
+    mu, col, h = 7, C.shape[1] - 1, 1e-5
+    for direction in (1.0, 1.0j):
+        vals = []
+        for sgn in (1, -1):
+            Cp = C.copy()
+            Cp[mu, col] += sgn * h * direction
+            sl.parameters["mo_coeff_beta"] = Cp
+            ph, lg = sl.recompute(cfg)
+            vals.append(np.log(ph) + lg)
+        fd = (vals[0] - vals[1]) / (2 * h * direction)
+        fd = fd.real + 1j * ((fd.imag + np.pi) % (2 * np.pi) - np.pi)
+        assert np.allclose(fd, pg["mo_coeff_beta"][:, mu, col], rtol=5e-5, atol=2e-6), direction
+    sl.parameters["mo_coeff_beta"] = C
