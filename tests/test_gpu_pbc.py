@@ -6,7 +6,7 @@ import pytest
 
 import helpers
 from helpers import PBC_JASTROW_CASES, golden, pbc_jastrow_coeffs, run_protocol_pbc
-from pyqmc_amd import systems
+from pyqmc_amd import pbc, systems
 
 pytestmark = pytest.mark.gpu
 
@@ -848,3 +848,50 @@ def test_complex_pgradient_matches_reference(tag):
         fd = fd.real + 1j * ((fd.imag + np.pi) % (2 * np.pi) - np.pi)
         assert np.allclose(fd, pg["mo_coeff_beta"][:, mu, col], rtol=5e-5, atol=2e-6), direction
     sl.parameters["mo_coeff_beta"] = C
+
+
+@pytest.mark.gpu
+def test_stochastic_reconfiguration_on_a_twisted_cell():
+    """BASELINE config C3's wave function (8-atom diamond cell, k-point twist: complex determinants) through
+    LinearTransform + StochasticReconfiguration: complex per-k orbital blocks serialise to real + imaginary parameters
+    (accumulators.py:134-150), the moments <dp f dp^T>, <E f dp>, <f dp> come from the device product (pqa_gram on the real and
+    imaginary parts) and equal the reference's einsum formulas on the same derivatives; an SR step is finite."""
+    import pyqmc_amd as pa
+
+    sup = pbc.get_supercell(systems.diamond_primitive(), np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
+    mf = pbc.random_kmf(sup, complex_coeff=True, twist=(0.25, 0.1, -0.3), nvirt=1)
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    assert wf.fused_device().twisted and np.iscomplexobj(wf.parameters["wf1mo_coeff_alpha"])
+    rng = np.random.default_rng(3)
+    to_opt = {"wf1mo_coeff_alpha": rng.random(np.shape(wf.parameters["wf1mo_coeff_alpha"])) < 0.05, "wf2bcoeff": np.ones((4, 3), dtype=bool)}
+    to_opt["wf2bcoeff"][0] = False
+    tr = pa.LinearTransform(wf.parameters, to_opt)
+    nre = int(to_opt["wf1mo_coeff_alpha"].sum()) + 9
+    assert tr.nparams == nre and len(tr.serialize_parameters(wf.parameters)) == nre + int(to_opt["wf1mo_coeff_alpha"].sum())
+    class OneEnergy:  # the ECP quadrature draws fresh rotations per evaluation: both routes below must see the same energies
+        def __init__(self, acc):
+            self.acc, self.last = acc, None
+
+        def __call__(self, configs, wf_):
+            if self.last is None:
+                self.last = self.acc(configs, wf_)
+            return {k: v.copy() for k, v in self.last.items()}
+
+    sr = pa.StochasticReconfiguration(OneEnergy(pa.EnergyAccumulator(sup, ewald_gmax=10)), tr)
+    cfg = pa.initial_guess(sup, 64, rng=np.random.default_rng(5))
+    wf.recompute(cfg)
+    d = sr.avg(cfg, wf)
+    dp, en, fdp = sr._derivatives(cfg, wf, 1e-3)
+    w = np.full(64, 1.0 / 64)
+    assert np.iscomplexobj(dp) and dp.shape == (64, len(tr.serialize_parameters(wf.parameters)))
+    assert helpers.relerr(d["dpidpj"], np.einsum("ij,ik->jk", dp, w[:, None] * fdp)) < 1e-12
+    assert helpers.relerr(d["dpH"], np.einsum("i,ij->j", en["total"], w[:, None] * fdp)) < 1e-12
+    assert helpers.relerr(d["dppsi"], np.average(fdp, weights=w, axis=0)) < 1e-12
+    steps, rep = sr.delta_p([0.1], d)
+    assert np.all(np.isfinite(steps[0])) and steps[0].shape == (len(tr.serialize_parameters(wf.parameters)),)
+    new = tr.deserialize(wf, tr.serialize_parameters(wf.parameters) + steps[0])
+    for k, v in new.items():
+        wf.parameters[k] = v
+    assert np.all(np.isfinite(wf.recompute(cfg)[1]))
