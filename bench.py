@@ -30,7 +30,7 @@ HBM_ACHIEVABLE_GBS = 6300.0
 FP64_MFMA_ACHIEVABLE_TFLOPS = 72.0
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
 
 
 def pmc_kernel(key, walkers):
