@@ -313,6 +313,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* sp = getenv("PQA_SPLIT")) h->split_mode = std::max(0, std::min(3, atoi(sp)));
   if (const char* sp = getenv("PQA_SPLIT_MIN")) h->split_min = std::max(512L, atol(sp));
   if (const char* sp = getenv("PQA_SPLIT_CUS")) h->split_cus = atoi(sp);
+  if (const char* sp = getenv("PQA_JPRE")) h->jpre = atoi(sp);
+  if (const char* sp = getenv("PQA_JPRE_MIN")) h->jpre_min = std::max(64L, atol(sp));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->cu_count = prop.multiProcessorCount;
@@ -674,6 +676,9 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (hipEvent_t e : h->pipe_events) (void)hipEventDestroy(e);
   for (hipStream_t s : h->pipe_stream)
     if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  for (hipStream_t s : h->jas_stream)
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  if (h->b_jpre.p) (void)hipFree(h->b_jpre.p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

@@ -127,6 +127,12 @@ struct pqa_handle {
   int split_mode = 0, split_cus = 0, cu_count = 256;
   long split_min = 32768;
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  // Jastrow sums of a move summed ahead on a side stream next to the orbital kernel (k_jas_pre, pqa_lw.hpp): PQA_JPRE (-1 automatic:
+  // shards of at least jpre_min walkers, PQA_JPRE_MIN), one side stream per half-ensemble, partials [2 halves of a move][G][4][W]
+  int jpre = -1;
+  long jpre_min = 32768;
+  hipStream_t jas_stream[2] = {nullptr, nullptr};
+  DevBuf b_jpre;
   std::vector<hipEvent_t> pipe_events;
   size_t pipe_next = 0;
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
@@ -259,6 +265,7 @@ int sync_aos(pqa_handle* h);
 int lw_setup(pqa_handle* h, bool lw, LwCtx& c);
 int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc);
 void launch_step_real(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen);
+void launch_jas_pre(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, double* jnew, double* jold);
 void launch_flush_real(pqa_handle* h, const LwState& L, int s, long W, long w0, long w1, int j_lo, int j_hi, int nq, int rowlen, int n_s);
 // pqa_sweep_cx.hip
 void launch_step_cx(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen);

@@ -91,7 +91,7 @@ static __global__ __launch_bounds__(256) void k_cache_from_rc(const double* __re
 template <int MODE, bool PBC, bool FAST>
 __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
-                                                double (&g)[3], double& lapU, double& ee, double& ei) {
+                                                double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
   constexpr int NF = PQA_JAS_NF;
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
@@ -119,7 +119,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 #pragma unroll
     for (int u = 0; u < PQA_JAS_PF; ++u) {
       const int j = jb + u * dj;
-      if (j >= S.nelec || j == e) continue;
+      if (j >= S.nelec || j == e || j == skip) continue;
       double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
       if (PBC) min_image_j(S, dx, dy, dz);  // compiled out of the open-boundary instantiation (the hot path of the headline bench)
       const double r = sqrt(dx * dx + dy * dy + dz * dz);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
       }
     }
   }
-  for (int I = j0; I < S.natom; I += dj) {
+  for (int I = ions ? j0 : S.natom; I < S.natom; I += dj) {
     double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
     double ac[NF];
     if (FAST) {
@@ -197,9 +197,27 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 template <int MODE, bool PBC>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
-                                              double (&g)[3], double& lapU, double& ee, double& ei) {
-  if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei);
-  else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei);
+                                              double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
+  if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+}
+// Jastrow part of group g's partial sums of electron e at (px, py, pz): value and gradient over the partners j = g, g + G, ...
+// and the ions I = g, g + G, ...  `skip` (>= 0): the pair with electron `skip` is left out of the strided sum and ADDED LAST by
+// the group that owns it (skip mod G) — the old-position sums of the next electron to be proposed leave out the electron that
+// has just been decided, the one partner whose position is not known before that decision: everything else can be (and, for
+// large shards, is) summed ahead by k_jas_pre while the orbital kernel runs.  `pre` (non-null): that partial, [G][4][W].
+template <bool PBC>
+__device__ __forceinline__ void lw_jastrow_part(const SysDev& S, const LwState& L, int e, int has_jastrow, double px, double py, double pz, long W, long w,
+                                                int g, int G, int skip, const double* __restrict__ pre, double& U, double (&gg)[3]) {
+  double lp, ee, ei;
+  if (pre) {
+    U = pre[((size_t)g * 4 + 0) * W + w]; gg[0] = pre[((size_t)g * 4 + 1) * W + w]; gg[1] = pre[((size_t)g * 4 + 2) * W + w]; gg[2] = pre[((size_t)g * 4 + 3) * W + w];
+  } else jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei, skip);
+  if (skip >= 0 && skip % G == g) {  // the one pair, at the partner's settled position
+    double u1, g1[3];
+    jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, skip, S.nelec, u1, g1, lp, ee, ei, -1, false);
+    U += u1; gg[0] += g1[0]; gg[1] += g1[1]; gg[2] += g1[2];
+  }
 }
 
 // ---------------------------------------------------------------- move kernels
@@ -220,7 +238,7 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt,
 template <bool PBC, bool CX>
 __device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, int e, int has_jastrow, double px, double py, double pz,
                                              const double* row, long W, long w, int g, int G,
-                                             double (&p)[PQA_LW_PART_ROWS(CX)]) {
+                                             double (&p)[PQA_LW_PART_ROWS(CX)], int jskip = -1, const double* __restrict__ jpre = nullptr) {
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
   double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;  // q: imaginary parts (CX)
@@ -290,9 +308,9 @@ __device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, 
     }
   }
 #endif
-  double U = 0.0, gg[3] = {0.0, 0.0, 0.0}, lp, ee, ei;
+  double U = 0.0, gg[3] = {0.0, 0.0, 0.0};
 #ifndef PQA_MP_NOJAS
-  jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei);
+  lw_jastrow_part<PBC>(S, L, e, has_jastrow, px, py, pz, W, w, g, G, jskip, jpre, U, gg);
 #endif
   if (CX) {  // rows: Re r0, Im r0, Re r1, Im r1, ..., then U, grad U
     p[0] = r0; p[1] = q0; p[2] = r1; p[3] = q1; p[4] = r2; p[5] = q2; p[6] = r3; p[7] = q3;
@@ -430,6 +448,9 @@ struct StepArgs {
   int j_lo, j_hi;      // Sherman-Morrison block of e_acc (rows of its spin)
   long W;              // walkers of the shard = stride of every plane
   long w0, w1;         // this launch covers walkers [w0, w1) (the whole shard, or one half-ensemble of the pipelined sweep)
+  int j_skip;          // propose half: electron decided just before e_prop (its pair is summed last, lw_jastrow_part), or -1
+  const double* jnew;  // Jastrow partial sums summed ahead by k_jas_pre, [G][4][W]: at the proposal of e_acc / at the current
+  const double* jold;  //   position of e_prop without the pair j_skip (nullptr: summed here)
   double* Rbuf;        // block buffers, slot of e_acc: [L_][W]
   double* Vbuf;
   uint8_t* act;        // [W]
@@ -469,7 +490,7 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
     double v[PR];
     {
       double p[PR];
-      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], row, W, w, g, G, p);
+      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], row, W, w, g, G, p, -1, a.jnew);
 #pragma unroll
       for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
     }
@@ -641,7 +662,7 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
       const int s = e >= S.nup, i = e - s * S.nup;
       const double* xe = L.xt + (size_t)e * 3 * W + w;
       const double* row = lw_row(L, s, i, L.sel[s][(size_t)i * W + w], w, W, S.nmo[s]);  // cached row of the current position
-      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, xe[0], xe[W], xe[2 * W], row, W, w, g, G, p);
+      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, xe[0], xe[W], xe[2 * W], row, W, w, g, G, p, a.j_skip, a.jold);
 #pragma unroll
       for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
     }
@@ -677,6 +698,33 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
     if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
     double* ao = L.auxt + w;
     ao[0] = z0; ao[W] = z1; ao[2 * W] = z2; ao[3 * W] = gx; ao[4 * W] = gy; ao[5 * W] = gz; ao[6 * W] = v[JU];
+  }
+}
+
+// ---------------------------------------------------------------- Jastrow sums of a move, ahead of its orbitals (round 4)
+// Of k_step_lw's 117 us per move at 65536 walkers ~48 are the two Jastrow pair loops (value + gradient at the proposal of
+// e_acc, and at the current position of e_prop) — fp64 VALU work on 1.5 KB of coordinates per walker that needs nothing from
+// the orbital kernel: the proposal is known when the previous step launch ends, and of e_prop's partners only e_acc can still
+// move.  k_jas_pre forms exactly the partial sums k_step_lw would (same block geometry, same strided partner lists, the pair
+// (e_prop, e_acc) left to k_step_lw: lw_jastrow_part) and is launched on a side stream NEXT TO k_orb, whose waves leave the
+// SIMDs' fp64 pipe idle a quarter of the time and 96 registers per SIMD free: the sums cost the move nothing, k_step_lw
+// loads 2 x 4 doubles per thread instead.  Bitwise the same sums as the in-kernel route (tests: PQA_JPRE=0 / 1).
+template <bool PBC>
+static __global__ __launch_bounds__(256) void k_jas_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a, double* __restrict__ jnew, double* __restrict__ jold) {
+  const int NW = a.NW, G = a.G;
+  const int lane = (int)threadIdx.x % NW, g = (int)threadIdx.x / NW;
+  const long W = a.W;
+  const long w = a.w0 + (long)blockIdx.x * NW + lane;
+  if (w >= a.w1) return;
+  double U, gg[3], lp, ee, ei;
+  if (a.e_acc >= 0) {
+    jas_eval_lane<1, PBC>(S, L.xt, W, w, a.e_acc, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], a.has_jastrow, g, G, U, gg, lp, ee, ei);
+    jnew[((size_t)g * 4 + 0) * W + w] = U; jnew[((size_t)g * 4 + 1) * W + w] = gg[0]; jnew[((size_t)g * 4 + 2) * W + w] = gg[1]; jnew[((size_t)g * 4 + 3) * W + w] = gg[2];
+  }
+  if (a.e_prop >= 0) {
+    const double* xe = L.xt + (size_t)a.e_prop * 3 * W + w;
+    jas_eval_lane<1, PBC>(S, L.xt, W, w, a.e_prop, xe[0], xe[W], xe[2 * W], a.has_jastrow, g, G, U, gg, lp, ee, ei, a.j_skip);
+    jold[((size_t)g * 4 + 0) * W + w] = U; jold[((size_t)g * 4 + 1) * W + w] = gg[0]; jold[((size_t)g * 4 + 2) * W + w] = gg[1]; jold[((size_t)g * 4 + 3) * W + w] = gg[2];
   }
 }
 

@@ -5,6 +5,11 @@
 void launch_step_real(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen) {
   if (h->S.pbc) launch_step_lw<true, false>(h, L, mb, a, rowlen); else launch_step_lw<false, false>(h, L, mb, a, rowlen);
 }
+void launch_jas_pre(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, double* jnew, double* jold) {
+  const dim3 grid((unsigned)((a.w1 - a.w0 + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
+  if (h->S.pbc) hipLaunchKernelGGL(k_jas_pre<true>, grid, block, 0, h->stream, h->S, L, mb, a, jnew, jold);
+  else hipLaunchKernelGGL(k_jas_pre<false>, grid, block, 0, h->stream, h->S, L, mb, a, jnew, jold);
+}
 void launch_flush_real(pqa_handle* h, const LwState& L, int s, long W, long w0, long w1, int j_lo, int j_hi, int nq, int rowlen, int n_s) {
   launch_flush_lw<false>(h, L, s, W, w0, w1, j_lo, j_hi, nq, rowlen, n_s);
 }
@@ -182,13 +187,25 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
     HIPCHK(hipStreamWaitEvent(P.s[0], fork, 0));
     HIPCHK(hipStreamWaitEvent(P.s[1], fork, 0));
   }
+  // Jastrow sums ahead of the orbitals (k_jas_pre): on for the k_step_lw launches of large shards with a Jastrow factor
+  const bool jpre = h->has_jastrow && (h->jpre < 0 ? W >= h->jpre_min : h->jpre != 0) && !(NW < 64 && h->step_pre && W <= 4096);
+  double* jbuf = nullptr;
+  hipEvent_t jas_done[2] = {nullptr, nullptr}, steps_done[2] = {nullptr, nullptr};
+  if (jpre) {
+    TRY(ensure(h, h->b_jpre, (size_t)2 * G * 4 * W * sizeof(double)));
+    jbuf = (double*)h->b_jpre.p;
+    for (int k = 0; k < nh; ++k)
+      if (!h->jas_stream[k]) HIPCHK(hipStreamCreateWithFlags(&h->jas_stream[k], hipStreamNonBlocking));
+  }
   struct Guard { pqa_handle* h; hipStream_t s; ~Guard() { h->stream = s; } } guard{h, P.main};  // launches go to h->stream: restored on every exit
   const long wlo[2] = {0, P.wm}, whi[2] = {P.wm, W};
   // stream of a launch: half hh, family 0 = orbitals, 1 = state streaming
   auto on = [&](int hh, int fam) { h->stream = !P.mode ? P.main : (P.mode == 3 ? P.s[fam] : P.s[hh]); };
-  auto step = [&](int hh, int e_acc, int e_prop) {
+  auto step = [&](int hh, int e_acc, int e_prop, bool use_pre = false) {
     StepArgs a{};
     a.e_acc = e_acc; a.e_prop = e_prop; a.has_jastrow = (int)h->has_jastrow; a.G = G; a.NW = NW; a.W = W; a.w0 = wlo[hh]; a.w1 = whi[hh];
+    a.j_skip = e_prop > 0 ? e_prop - 1 : -1;
+    if (use_pre) { a.jnew = e_acc >= 0 ? jbuf : nullptr; a.jold = e_prop >= 0 ? jbuf + (size_t)G * 4 * W : nullptr; }
     if (e_acc >= 0) {
       const int s = e_acc >= h->nup, n_s = s ? h->ndn : h->nup, i_s = e_acc - (s ? h->nup : 0);
       const int q = i_s % KB;
@@ -219,6 +236,20 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
     for (int hh = 0; hh < nh; ++hh) {
       const long w0 = wlo[hh], Wn = whi[hh] - wlo[hh];
       if (Wn <= 0) continue;
+      // ---- Jastrow sums of this move on the side stream: they need the proposal (previous step launch) and nothing of the orbitals
+      if (jpre) {
+        hipStream_t st_steps = !P.mode ? P.main : (P.mode == 3 ? P.s[1] : P.s[hh]);
+        TRY(pipe_event(h, &steps_done[hh]));
+        HIPCHK(hipEventRecord(steps_done[hh], st_steps));
+        HIPCHK(hipStreamWaitEvent(h->jas_stream[hh], steps_done[hh], 0));
+        StepArgs ja{};
+        ja.e_acc = e; ja.e_prop = (e + 1 < N) ? e + 1 : -1; ja.has_jastrow = 1; ja.G = G; ja.NW = NW; ja.W = W; ja.w0 = w0; ja.w1 = whi[hh];
+        ja.j_skip = e;
+        h->stream = h->jas_stream[hh];
+        launch_jas_pre(h, L, mb, ja, jbuf, jbuf + (size_t)G * 4 * W);
+        TRY(pipe_event(h, &jas_done[hh]));
+        HIPCHK(hipEventRecord(jas_done[hh], h->stream));
+      }
       // ---- orbitals at the proposals: the rows go straight into the slot of electron i_s the walker is not using (accepting
       // flips the selector)
       on(hh, 0);
@@ -230,6 +261,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
       // ---- decide e, commit, propose e + 1
       on(hh, 1);
       if (P.mode == 3) HIPCHK(hipStreamWaitEvent(h->stream, P.orb_done[hh], 0));
+      if (jpre) HIPCHK(hipStreamWaitEvent(h->stream, jas_done[hh], 0));
       hipEvent_t pe1 = nullptr;
       if (h->profile && hh == 0 && (e % (4 * (int)h->prof_stride)) == 1) {  // sparsely sampled full (decide + propose) launches: an event pair costs ~2 us of stream time
         if (h->prof3_used == h->prof3_events.size()) {
@@ -244,7 +276,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
           ++h->prof3_used;
         }
       }
-      step(hh, e, fuse_next ? e + 1 : -1);
+      step(hh, e, fuse_next ? e + 1 : -1, jpre);
       if (pe1) { HIPCHK(hipEventRecord(pe1, h->stream)); h->prof3_launches += 1; }
       if (need_flush) {  // block finished: bring every other row of this spin up to date
         const int nq = j_hi - j_lo;
@@ -264,7 +296,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
         else launch_flush_real(h, L, s, W, w0, whi[hh], j_lo, j_hi, nq, rowlen, n_s);
         if (ce1) { HIPCHK(hipEventRecord(ce1, h->stream)); h->prof2_launches += 1; }
       }
-      if (!fuse_next && e + 1 < N) step(hh, -1, e + 1);
+      if (!fuse_next && e + 1 < N) step(hh, -1, e + 1, jpre);
       TRY(after_steps(hh));
     }
   }

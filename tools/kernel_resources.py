@@ -5,11 +5,18 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.environ.get("PQA_LIB", os.path.join(ROOT, "pyqmc_amd", "lib", "libpyqmc_amd.so"))
 with tempfile.TemporaryDirectory() as d:
-    fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+    fat = os.path.join(d, "fat.bin")
     subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-    subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
-                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+    raw = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(magic, raw)]  # one bundle per translation unit of the library
+    notes = ""
+    for i, s in enumerate(starts):
+        one, co = os.path.join(d, f"b{i}.bin"), os.path.join(d, f"dev{i}.co")
+        open(one, "wb").write(raw[s : starts[i + 1] if i + 1 < len(starts) else len(raw)])
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={one}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        notes += subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
 rows = []
 for k in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
     k = ".agpr_count:" + k
