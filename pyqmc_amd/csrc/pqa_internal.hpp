@@ -124,12 +124,17 @@ struct pqa_handle {
   int orb_notab = 0;  // PQA_ORB_NOTAB=1: basis tables from global memory (A/B)
   // pipelined half-ensembles of the lane-per-walker sweep (pqa_sweep.hip): mode (PQA_SPLIT), smallest shard that is cut
   // (PQA_SPLIT_MIN), CUs of the orbital stream in mode 3 (PQA_SPLIT_CUS, 0 = no masks)
+  // OFF by default: two free-running half-ensembles (PQA_SPLIT=1) give +3.3-3.7 % at 65536 walkers in same-box A/B runs (bit-identical;
+  // -8 % at 32768), but the kernels of the two halves then share the chip and every launch takes about twice as long for the same
+  // work — the per-kernel roofline bench.py reports from launch durations stops meaning what it says (0.40 -> 0.23 for k_orb)
   int split_mode = 0, split_cus = 0, cu_count = 256;
-  long split_min = 32768;
+  long split_min = 65536;
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
-  // Jastrow sums of a move summed ahead on a side stream next to the orbital kernel (k_jas_pre, pqa_lw.hpp): PQA_JPRE (-1 automatic:
-  // shards of at least jpre_min walkers, PQA_JPRE_MIN), one side stream per half-ensemble, partials [2 halves of a move][G][4][W]
-  int jpre = -1;
+  // Jastrow sums of a move summed ahead on a side stream next to the orbital kernel (k_jas_pre, pqa_lw.hpp): PQA_JPRE=1 (or -1:
+  // shards of at least jpre_min walkers, PQA_JPRE_MIN), one side stream per half-ensemble, partials [2 halves of a move][G][4][W].
+  // OFF by default — measured: k_step_lw 117 -> 81 us per move, but k_orb next to k_jas_pre 122 -> 196 us (25.9 -> 27.0 ms per step
+  // at 65536 walkers; 2x2x2 periodic cell +2 %): the fp64 pipe the two share is the step's bottleneck, not idle
+  int jpre = 0;
   long jpre_min = 32768;
   hipStream_t jas_stream[2] = {nullptr, nullptr};
   DevBuf b_jpre;

@@ -27,9 +27,17 @@ def build():
 
 
 def run(mode):
-    m, _, cus = mode.partition(":")
+    """mode: "<split mode>[:<orbital-stream CUs>][,KEY=VALUE ...]" (further PQA_* switches, e.g. 0,PQA_JPRE=1)"""
+    head, *extra = mode.split(",")
+    m, _, cus = head.partition(":")
+    for k in [k for k in os.environ if k.startswith("PQA_")]:
+        del os.environ[k]
     os.environ["PQA_SPLIT"] = m
     os.environ["PQA_SPLIT_CUS"] = cus or "0"
+    os.environ["PQA_JPRE"] = "0"
+    for kv in extra:
+        k, _, v = kv.partition("=")
+        os.environ[k] = v
     mol, wf = build()
     dev = wf.fused_device()
     wf.recompute(pa.initial_guess(mol, args.walkers, rng=np.random.default_rng(5)))
