@@ -369,6 +369,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // recomputed n^2 distances — both 2.4 x slower than this.
 #define PQA_PRE_NWMAX 8   // list words the pre-pass can assemble in LDS (32 entries: PQA_PRE_CAP)
 #define PQA_PRE_MEMB 2048 // bytes of one atom class of the membership table staged in LDS (side^3; 729 for M = 4)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
                                                      unsigned long long* __restrict__ lst, double* __restrict__ theta) {
   // The candidates' lattice vectors, their membership offsets and the atom class's membership bytes are staged in LDS: as
@@ -525,12 +526,14 @@ __device__ __forceinline__ void pbc_ctx_load(const SysDev& S, const Tab& T, PbcC
 
 // Twisted cells: multiply every orbital row [ncomp][2 nmo] (re block | im block) by the point's wrap phase.
 // rows of a two-slot output cleared before a K-split launch accumulates into them.  grid = (P, ceil(row / 256)), block = 256
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_zero_rows(double* __restrict__ out, int row, const unsigned char* __restrict__ sel, long slot_stride) {
   const long p = blockIdx.x;
   const int k = blockIdx.y * 256 + threadIdx.x;
   if (k < row) out[(size_t)(sel[p] ^ 1) * slot_stride + (size_t)p * row + k] = 0.0;
 }
 // sel / slot_stride: the two-slot output of ChunkTab (nullptr: plain rows)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, int nmo2, const double* __restrict__ theta,
                             const unsigned char* __restrict__ sel, long slot_stride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -582,6 +585,7 @@ static __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, do
 // AO values of a TWISTED cell at arbitrary (unfolded) points: sum_L e^{i k_t.L} phi(r - R - L) times the wrap phase of the fold
 // (orbitals.py:203-213).  out: real plane [P][nao] followed by the imaginary plane.  One thread per point, direct image tests.
 // Used by the parameter gradient of complex determinants (pqa_slater_pgradient).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_ao_tw(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
@@ -615,6 +619,7 @@ static __global__ void k_ao_tw(SysDev S, const double* __restrict__ pts, long P,
 }
 
 // plain contraction out[c][p][j] = sum_a ao[c][p][a] C[a][j]  (A/B check of the MFMA kernel only)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_mo_valu(const double* __restrict__ ao, const double* __restrict__ C, long rows, int nao, int nmo,
                           double* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

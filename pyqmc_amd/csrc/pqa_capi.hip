@@ -781,7 +781,7 @@ extern "C" int pqa_eval_mo(pqa_handle_t* h, int spin, const double* pts, int64_t
   if (ncomp == 1) hipLaunchKernelGGL(k_ao<1>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
   else hipLaunchKernelGGL(k_ao<5>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
   const long rows = (long)ncomp * npts;
-  hipLaunchKernelGGL(k_mo_valu, dim3((unsigned)((rows * nmo + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p,
+  hipLaunchKernelGGL((k_mo_valu<>), dim3((unsigned)((rows * nmo + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p,
                      (const double*)h->d_mo[spin], rows, h->nao, nmo, (double*)h->b_out.p);
   TRY(check_launch(h, "k_mo_valu"));
   return copy_out(h, out, h->b_out.p, nout * sizeof(double));
@@ -825,7 +825,7 @@ static int ensure_walkers(pqa_handle* h, long W) {
 
 static int jas_refresh(pqa_handle* h) {
   if (h->has_j2 && h->jas_stale && h->W > 0) {
-    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js);
+    hipLaunchKernelGGL((k_jastrow_recompute<>), dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js);
     TRY(check_launch(h, "k_jastrow_recompute"));
   }
   h->jas_stale = false;
@@ -843,16 +843,16 @@ static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants fr
     pa.group_stride = (long)h->N * 3;
     TRY(launch_orb(h, s, pa, h->W * nel[s], 5, h->st.cache[s]));
     const size_t lds = (h->cplx ? 2 : 1) * ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
-    if (h->cplx) hipLaunchKernelGGL(k_build_invert_c, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
-    else hipLaunchKernelGGL(k_build_invert, dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
+    if (h->cplx) hipLaunchKernelGGL((k_build_invert_c<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
+    else hipLaunchKernelGGL((k_build_invert<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     TRY(check_launch(h, "k_build_invert"));
   }
   return 0;
 }
 
 static int slater_value_dev(pqa_handle* h) {
-  if (h->cplx) hipLaunchKernelGGL(k_slater_value_c, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
-  else hipLaunchKernelGGL(k_slater_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
+  if (h->cplx) hipLaunchKernelGGL((k_slater_value_c<>), dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
+  else hipLaunchKernelGGL((k_slater_value<>), dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->st, (double*)h->b_sign.p, (double*)h->b_log.p);
   return check_launch(h, "k_slater_value");
 }
 
@@ -986,8 +986,8 @@ extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo
   TRY(slater_value_dev(h));  // sign (complex: phase) / log of the determinant expansion -> b_sign, b_log
   TRY(ensure(h, h->b_pgdet, cf * W * h->ndet * sizeof(double)));
   const dim3 gd((unsigned)((W * h->ndet + 255) / 256));
-  if (h->cplx) hipLaunchKernelGGL(k_pgrad_det_c, gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
-  else hipLaunchKernelGGL(k_pgrad_det, gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
+  if (h->cplx) hipLaunchKernelGGL((k_pgrad_det_c<>), gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
+  else hipLaunchKernelGGL((k_pgrad_det<>), gd, dim3(256), 0, h->stream, h->S, h->st, (const double*)h->b_sign.p, (const double*)h->b_log.p, W, (double*)h->b_pgdet.p);
   TRY(check_launch(h, "k_pgrad_det"));
   if (d_det) TRY(copy_out(h, d_det, h->b_pgdet.p, cf * W * h->ndet * sizeof(double)));
   double* outs[2] = {d_mo_up, d_mo_dn};
@@ -999,7 +999,7 @@ extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo
   if (nao_all * sizeof(double) > ((size_t)16 << 30)) FAIL("orbital-coefficient gradients need the AO values of all electrons: too many walkers for one call");
   TRY(ensure(h, h->b_ao, nao_all * sizeof(double)));
   const dim3 ga((unsigned)((W * h->N + 63) / 64));
-  if (h->twist) hipLaunchKernelGGL(k_ao_tw, ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
+  if (h->twist) hipLaunchKernelGGL((k_ao_tw<>), ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
   else hipLaunchKernelGGL(k_ao<1>, ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
   TRY(check_launch(h, "k_ao"));
   for (int s = 0; s < 2; ++s) {
@@ -1008,7 +1008,7 @@ extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo
     const size_t nout = (size_t)W * h->nao * h->nmo[s];  // (complex: nmo[s] = 2 x orbitals, i.e. already the doubles of the complex result)
     TRY(ensure(h, h->b_out, nout * sizeof(double)));
     const size_t lds = cf * (size_t)h->ndet_s[s] * sizeof(double);
-    if (!h->cplx) hipLaunchKernelGGL(k_pgrad_mo, dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s,
+    if (!h->cplx) hipLaunchKernelGGL((k_pgrad_mo<>), dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s,
                                      (const double*)h->b_ao.p, (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
     else if (h->twist) hipLaunchKernelGGL(k_pgrad_mo_c<true>, dim3((unsigned)W), dim3(256), lds, h->stream, h->S, h->st, s, (const double*)h->b_ao.p, ao_plane,
                                           (const double*)h->b_pgdet.p, (const int*)h->d_colmap[s], (double*)h->b_out.p);
@@ -1027,7 +1027,7 @@ extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
   TRY(ensure(h, h->b_flag, sizeof(int)));
   HIPCHK(hipMemsetAsync(h->b_flag.p, 0, sizeof(int), h->stream));
   const long count = h->W * h->ndet_s[spin];
-  hipLaunchKernelGGL(k_has_zero, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->st.dlog[spin], count, (int*)h->b_flag.p);
+  hipLaunchKernelGGL((k_has_zero<>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->st.dlog[spin], count, (int*)h->b_flag.p);
   TRY(check_launch(h, "k_has_zero"));
   return copy_out(h, flag, h->b_flag.p, sizeof(int));
 }
@@ -1051,9 +1051,9 @@ extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, con
     TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
     dm = (const uint8_t*)h->b_mask.p;
   }
-  if (h->cplx) hipLaunchKernelGGL(k_sm_update_c, dim3((unsigned)W), dim3(64), 2 * lds_sm(h), h->stream, h->S, h->st, e,
+  if (h->cplx) hipLaunchKernelGGL((k_sm_update_c<>), dim3((unsigned)W), dim3(64), 2 * lds_sm(h), h->stream, h->S, h->st, e,
                                   (const double*)h->b_motmp.p, 5 * nmo, dm, 1);
-  else hipLaunchKernelGGL(k_sm_update, dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
+  else hipLaunchKernelGGL((k_sm_update<>), dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p,
                           5 * nmo, dm, 1);
   TRY(check_launch(h, "k_sm_update"));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1093,7 +1093,7 @@ extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int
   if (h->W != W) TRY(ensure_walkers(h, W));
   h->jas_stale = false;
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
-  hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
+  hipLaunchKernelGGL((k_jastrow_recompute<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
   TRY(check_launch(h, "k_jastrow_recompute"));
   return pqa_jastrow_value(h, logval);
 }
@@ -1103,7 +1103,7 @@ extern "C" int pqa_jastrow_value(pqa_handle_t* h, double* logval) {
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
   TRY(jas_refresh(h));
-  hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
+  hipLaunchKernelGGL((k_jastrow_value<>), dim3((unsigned)h->W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
   TRY(check_launch(h, "k_jastrow_value"));
   return copy_out(h, logval, h->b_ju.p, h->W * sizeof(double));
 }
@@ -1127,7 +1127,7 @@ static int jastrow_eval_parts(pqa_handle_t* h, int parts, int e, const double* p
     TRY(copy_in(h, h->b_widx.p, widx, (size_t)nrow * sizeof(int)));
     dw = (const int*)h->b_widx.p;
   }
-  hipLaunchKernelGGL(k_jastrow_eval, dim3((unsigned)nrow), dim3(64), lds_j3(h), h->stream, h->S, h->js, e, (const double*)h->b_pts.p,
+  hipLaunchKernelGGL((k_jastrow_eval<>), dim3((unsigned)nrow), dim3(64), lds_j3(h), h->stream, h->S, h->js, e, (const double*)h->b_pts.p,
                      (long)nrow, npt, dw, mode, parts, (double*)h->b_out.p);
   TRY(check_launch(h, "k_jastrow_eval"));
   return copy_out(h, out, h->b_out.p, nout * sizeof(double));
@@ -1146,7 +1146,7 @@ extern "C" int pqa_j3_eval(pqa_handle_t* h, int e, const double* pts, int64_t nr
 }
 
 static int j3_value_dev(pqa_handle* h) {
-  hipLaunchKernelGGL(k_j3_value, dim3((unsigned)h->W), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p);
+  hipLaunchKernelGGL((k_j3_value<>), dim3((unsigned)h->W), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p);
   return check_launch(h, "k_j3_value");
 }
 
@@ -1167,8 +1167,8 @@ extern "C" int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff) {
   const size_t lds = ((size_t)h->N * h->natom * h->na3 + (size_t)h->N * (h->N - 1) / 2 * h->nb3) * sizeof(double);
   if (lds > 150 * 1024) FAIL("three-body parameter gradient: the a/b value tables of one walker do not fit LDS");
   TRY(ensure(h, h->b_out, (size_t)W * E * sizeof(double)));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_j3_pgrad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_j3_pgrad, dim3((unsigned)W), dim3(64), lds, h->stream, h->S, h->js, (double*)h->b_out.p);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_j3_pgrad<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_j3_pgrad<>), dim3((unsigned)W), dim3(64), lds, h->stream, h->S, h->js, (double*)h->b_out.p);
   TRY(check_launch(h, "k_j3_pgrad"));
   return copy_out(h, d_ccoeff, h->b_out.p, (size_t)W * E * sizeof(double));
 }
@@ -1206,7 +1206,7 @@ extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const u
     TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
     dm = (const uint8_t*)h->b_mask.p;
   }
-  hipLaunchKernelGGL(k_move_x, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, h->js, h->N, e, (const double*)h->b_newpos.p, dm, W);
+  hipLaunchKernelGGL((k_move_x<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, h->js, h->N, e, (const double*)h->b_newpos.p, dm, W);
   TRY(check_launch(h, "k_move_x"));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -1226,7 +1226,7 @@ extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, co
     TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
     dm = (const uint8_t*)h->b_mask.p;
   }
-  hipLaunchKernelGGL(k_jastrow_update, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_newpos.p, dm);
+  hipLaunchKernelGGL((k_jastrow_update<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_newpos.p, dm);
   TRY(check_launch(h, "k_jastrow_update"));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -1257,7 +1257,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
   std::vector<double> j3u(W, 0.0);
   if (h->has_j2) {
     TRY(jas_refresh(h));
-    hipLaunchKernelGGL(k_jastrow_value, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
+    hipLaunchKernelGGL((k_jastrow_value<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, (double*)h->b_ju.p);
     TRY(check_launch(h, "k_jastrow_value"));
     TRY(copy_in(h, ju.data(), h->b_ju.p, W * sizeof(double)));
   }
@@ -1280,7 +1280,7 @@ extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t 
   TRY(copy_in(h, h->js.x, configs, (size_t)W * h->N * 3 * sizeof(double)));
   if (h->has_slater) TRY(slater_rebuild(h));
   if (h->has_j2) {
-    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
+    hipLaunchKernelGGL((k_jastrow_recompute<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js);
     TRY(check_launch(h, "k_jastrow_recompute"));
   }
   return wf_value_host(h, sign, logabs);
@@ -1395,11 +1395,11 @@ static int recompute_range(pqa_handle* h, long w0, long n) {
   int rc = 0;
   if (h->has_slater) rc = slater_rebuild(h);
   if (!rc && h->has_j2 && !h->jas_stale) {
-    hipLaunchKernelGGL(k_jastrow_recompute, dim3((unsigned)n), dim3(64), 0, h->stream, h->S, h->js);
+    hipLaunchKernelGGL((k_jastrow_recompute<>), dim3((unsigned)n), dim3(64), 0, h->stream, h->S, h->js);
     rc = check_launch(h, "k_jastrow_recompute");
   }
   if (!rc && h->has_j3) {
-    hipLaunchKernelGGL(k_j3_value, dim3((unsigned)n), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p + w0);
+    hipLaunchKernelGGL((k_j3_value<>), dim3((unsigned)n), dim3(64), lds_j3(h), h->stream, h->S, h->js, (double*)h->b_j3u.p + w0);
     rc = check_launch(h, "k_j3_value");
   }
   h->js = js0; h->st = st0; h->W = W0;
@@ -1453,7 +1453,7 @@ extern "C" int pqa_dm_walk(pqa_handle_t* h, int slot, int spin, int64_t n, int n
   TRY(copy_in(h, d.pos.p, pos, (size_t)n * 3 * sizeof(double)));
   const dim3 g256((unsigned)((n + 255) / 256));
   TRY(launch_orb(h, spin, plain_points((const double*)d.pos.p, n), n, 1, (double*)d.row.p));
-  hipLaunchKernelGGL(k_dm_density, g256, dim3(256), 0, h->stream, (const double*)d.row.p, (long)n, nmo2, (double*)d.f.p);
+  hipLaunchKernelGGL((k_dm_density<>), g256, dim3(256), 0, h->stream, (const double*)d.row.p, (long)n, nmo2, (double*)d.f.p);
   TRY(check_launch(h, "k_dm_density"));
   const double sq = sqrt(tstep);
   for (int s0 = 0; s0 < nsamples; s0 += CH) {
@@ -1464,11 +1464,11 @@ extern "C" int pqa_dm_walk(pqa_handle_t* h, int slot, int spin, int64_t n, int n
     }
     for (int k = 0; k < ns; ++k) {
       const int s = s0 + k, kk = s - (nsamples - nkeep);
-      hipLaunchKernelGGL(k_dm_propose, g256, dim3(256), 0, h->stream, (const double*)d.pos.p,
+      hipLaunchKernelGGL((k_dm_propose<>), g256, dim3(256), 0, h->stream, (const double*)d.pos.p,
                          gauss ? (const double*)h->b_gauss.p + (size_t)k * n * 3 : (const double*)nullptr, seed, (uint32_t)s, sq, (long)n,
                          (double*)d.newpos.p);
       TRY(launch_orb(h, spin, plain_points((const double*)d.newpos.p, n), n, 1, (double*)h->b_motmp.p));
-      hipLaunchKernelGGL(k_dm_accept, dim3((unsigned)n), dim3(64), 0, h->stream, (double*)d.pos.p, (double*)d.row.p, (double*)d.f.p,
+      hipLaunchKernelGGL((k_dm_accept<>), dim3((unsigned)n), dim3(64), 0, h->stream, (double*)d.pos.p, (double*)d.row.p, (double*)d.f.p,
                          (const double*)d.newpos.p, (const double*)h->b_motmp.p,
                          unif ? (const double*)h->b_unif.p + (size_t)k * n : (const double*)nullptr, seed, (uint32_t)s, (long)n, nmo2,
                          accept ? (double*)h->dm_acc.p + (size_t)k * n : (double*)nullptr,
@@ -1520,7 +1520,7 @@ extern "C" int pqa_obdm_accumulate(pqa_handle_t* h, int slot, int k, int64_t nco
   TRY(ensure(h, h->dm_ratio, (size_t)nconf * nelec * (rc ? 2 : 1) * sizeof(double)));
   TRY(copy_in(h, h->dm_assign[0].p, assign, (size_t)nconf * sizeof(int)));
   TRY(copy_in(h, h->dm_ratio.p, ratio, (size_t)nconf * nelec * (rc ? 2 : 1) * sizeof(double)));
-  hipLaunchKernelGGL(k_obdm_acc, dim3((unsigned)nconf), dim3(256), (size_t)2 * norb * sizeof(double), h->stream,
+  hipLaunchKernelGGL((k_obdm_acc<>), dim3((unsigned)nconf), dim3(256), (size_t)2 * norb * sizeof(double), h->stream,
                      (const double*)d.keep_row.p + (size_t)k * d.n * nmo2, (const double*)d.keep_f.p + (size_t)k * d.n,
                      (const int*)h->dm_assign[0].p, (const double*)d.cfg.p, (const double*)h->dm_ratio.p, rc, oc, nelec, norb, first,
                      (double*)h->dm_val.p, (double*)h->dm_norm[0].p);
@@ -1547,7 +1547,7 @@ extern "C" int pqa_tbdm_accumulate(pqa_handle_t* h, int k, int64_t nconf, int ne
   TRY(copy_in(h, h->dm_assign[1].p, assign_b, (size_t)nconf * sizeof(int)));
   TRY(copy_in(h, h->dm_ratio.p, ratio, (size_t)nconf * nea * neb * (rc ? 2 : 1) * sizeof(double)));
   TRY(copy_in(h, h->dm_ijkl.p, ijkl, (size_t)4 * ntuple * sizeof(int)));
-  hipLaunchKernelGGL(k_tbdm_acc, dim3((unsigned)nconf), dim3(256), lds, h->stream,
+  hipLaunchKernelGGL((k_tbdm_acc<>), dim3((unsigned)nconf), dim3(256), lds, h->stream,
                      (const double*)da.keep_row.p + (size_t)k * da.n * na2, (const double*)da.keep_f.p + (size_t)k * da.n,
                      (const double*)db.keep_row.p + (size_t)k * db.n * nb2, (const double*)db.keep_f.p + (size_t)k * db.n,
                      (const int*)h->dm_assign[0].p, (const int*)h->dm_assign[1].p, (const double*)da.cfg.p, (const double*)db.cfg.p,
@@ -1569,8 +1569,8 @@ extern "C" int pqa_dm_fetch(pqa_handle_t* h, int which, int ncol, double scale, 
   if (which == 0 && ncol != cols) FAIL("pqa_dm_fetch: ncol does not match the accumulated value");
   const long nout = mean ? cols : h->dm_nconf * cols;
   TRY(ensure(h, h->dm_tmp, (size_t)nout * sizeof(double)));
-  if (mean) hipLaunchKernelGGL(k_col_means, dim3((unsigned)cols), dim3(256), 0, h->stream, src, h->dm_nconf, cols, scale, (double*)h->dm_tmp.p);
-  else hipLaunchKernelGGL(k_scale_copy, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, src, nout, scale, (double*)h->dm_tmp.p);
+  if (mean) hipLaunchKernelGGL((k_col_means<>), dim3((unsigned)cols), dim3(256), 0, h->stream, src, h->dm_nconf, cols, scale, (double*)h->dm_tmp.p);
+  else hipLaunchKernelGGL((k_scale_copy<>), dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, h->stream, src, nout, scale, (double*)h->dm_tmp.p);
   TRY(check_launch(h, "pqa_dm_fetch"));
   return copy_out(h, out, h->dm_tmp.p, (size_t)nout * sizeof(double));
 }
@@ -1587,9 +1587,9 @@ extern "C" int pqa_gram(pqa_handle_t* h, int64_t n, int P, int Q, const double* 
   TRY(ensure(h, c, (size_t)P * Q * sizeof(double)));
   TRY(copy_in(h, a.p, A, (size_t)n * P * sizeof(double)));
   TRY(copy_in(h, b.p, B, (size_t)n * Q * sizeof(double)));
-  hipLaunchKernelGGL(k_gram_mfma, dim3((unsigned)((P + 15) / 16), (unsigned)((Q + 15) / 16), (unsigned)nslice), dim3(64), 0, h->stream,
+  hipLaunchKernelGGL((k_gram_mfma<>), dim3((unsigned)((P + 15) / 16), (unsigned)((Q + 15) / 16), (unsigned)nslice), dim3(64), 0, h->stream,
                      (const double*)a.p, (const double*)b.p, (long)n, P, Q, nslice, (double*)part.p);
-  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)(((long)P * Q + 255) / 256)), dim3(256), 0, h->stream, (const double*)part.p, (long)P * Q,
+  hipLaunchKernelGGL((k_gram_reduce<>), dim3((unsigned)(((long)P * Q + 255) / 256)), dim3(256), 0, h->stream, (const double*)part.p, (long)P * Q,
                      nslice, (double*)c.p);
   TRY(check_launch(h, "k_gram_mfma"));
   return copy_out(h, C, c.p, (size_t)P * Q * sizeof(double));
@@ -1603,7 +1603,7 @@ extern "C" int pqa_philox_tapes(pqa_handle_t* h, uint64_t seed, int step, int64_
   const size_t NW = (size_t)h->N * W;
   TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
   TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-  hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)step, h->N, (long)W,
+  hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)step, h->N, (long)W,
                      (double*)h->b_gauss.p, (double*)h->b_unif.p);
   TRY(check_launch(h, "k_tile_draws"));
   TRY(copy_in(h, gauss, h->b_gauss.p, NW * 3 * sizeof(double)));
@@ -1635,7 +1635,7 @@ extern "C" int pqa_philox_dmc_tapes(pqa_handle_t* h, uint64_t seed, int nsteps, 
     return copy_out(h, const_cast<double*>(dst), h->b_unif.p, ncount * W * sizeof(double));
   };
   auto rots = [&](uint64_t sd, uint32_t step, const double* dst) -> int {
-    hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, sd, step, (double*)h->b_rot.p);
+    hipLaunchKernelGGL((k_gen_rot<>), dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, sd, step, (double*)h->b_rot.p);
     TRY(check_launch(h, "k_gen_rot"));
     return copy_out(h, const_cast<double*>(dst), h->b_rot.p, nrot * 9 * sizeof(double));
   };
@@ -1651,7 +1651,7 @@ extern "C" int pqa_philox_dmc_tapes(pqa_handle_t* h, uint64_t seed, int nsteps, 
       TRY(plane(PQA_STREAM_TM_U1, (uint32_t)i, (size_t)N, out->tm_u1 + (size_t)i * NW));
       TRY(plane(PQA_STREAM_TM_U2, (uint32_t)i, (size_t)N, out->tm_u2 + (size_t)i * NW));
     }
-    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)i, N, (long)W,
+    hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, seed, (uint32_t)i, N, (long)W,
                        (double*)h->b_gauss.p, (double*)h->b_unif.p);
     TRY(check_launch(h, "k_tile_draws"));
     TRY(copy_in(h, const_cast<double*>(out->gauss) + (size_t)i * NW * 3, h->b_gauss.p, NW * 3 * sizeof(double)));

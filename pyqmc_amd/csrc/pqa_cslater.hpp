@@ -31,6 +31,7 @@ __device__ __forceinline__ cx wave_sum_cx(cx a) { return {wave_sum(a.r), wave_su
 
 // ---------------------------------------------------------------- build + invert
 // grid = W * ndet_s blocks of 64 threads; dynamic LDS: 2 * n * (n+1) doubles + n ints.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_build_invert_c(SysDev S, SlaterState st, int s, long W) {
   extern __shared__ double lds[];
   const int n = s ? S.ndn : S.nup, nmo2 = S.nmo[s], nmo = nmo2 / 2, D = S.ndet_s[s];
@@ -134,6 +135,7 @@ __device__ __forceinline__ void slater_value_wave_c(const SysDev& S, const Slate
   logv = clamp_nan_to_num(log(m) + ref);
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_slater_value_c(SysDev S, SlaterState st, double* sign, double* logv) {
   const long w = blockIdx.x;
   cx ph;
@@ -264,6 +266,7 @@ __device__ __forceinline__ void sm_update_wave_c(const SysDev& S, const SlaterSt
   }
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState st, int e, const double* __restrict__ mo, int row_stride,
                                                     const uint8_t* __restrict__ mask, int to_cache) {
   extern __shared__ double lds[];
@@ -280,6 +283,7 @@ static __global__ __launch_bounds__(64) void k_sm_update_c(SysDev S, SlaterState
 
 // ---------------------------------------------------------------- parameter gradients of complex determinants (slater.py:462-542)
 // d_det[w][di] = D_up D_dn / Psi (complex, interleaved): phase_up phase_dn e^{log_up + log_dn - log|Psi|} / phase(Psi).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_pgrad_det_c(SysDev S, SlaterState st, const double* __restrict__ psi_phase, const double* __restrict__ psi_log,
                                      long W, double* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,6 +21,7 @@ __device__ __forceinline__ cplx2 dm_row(const double* __restrict__ row, int j, i
 __device__ __forceinline__ cplx2 dm_rat(const double* __restrict__ a, size_t idx, int rc) { return rc ? cplx2{a[2 * idx], a[2 * idx + 1]} : cplx2{a[idx], 0.0}; }
 
 // f[p] = sum_j |row[p][j]|^2
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_dm_density(const double* __restrict__ rows, long n, int nmo2, double* __restrict__ f) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
@@ -32,6 +33,7 @@ static __global__ __launch_bounds__(256) void k_dm_density(const double* __restr
 
 // proposal of sample s: r' = r + sqrt(tstep) z (obdm.py:232-237; the walkers are kept in unfolded coordinates — the orbital
 // kernel folds every point itself, which also gives a twisted cell its wrap phase)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_dm_propose(const double* __restrict__ pos, const double* __restrict__ gauss, uint64_t seed, uint32_t s,
                                                     double sq, long n, double* __restrict__ newpos) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
@@ -47,6 +49,7 @@ static __global__ __launch_bounds__(256) void k_dm_propose(const double* __restr
 
 // accept with probability f(r')/f(r) (obdm.py:240-246); accepted walkers take the new position, orbital row and density.
 // keep_*: where this sample's walkers are recorded (NULL: not kept).  One wave per walker, lanes over the row.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_dm_accept(double* __restrict__ pos, double* __restrict__ rows, double* __restrict__ f,
                                                   const double* __restrict__ newpos, const double* __restrict__ newrows,
                                                   const double* __restrict__ unif, uint64_t seed, uint32_t s, long n, int nmo2,
@@ -83,6 +86,7 @@ static __global__ __launch_bounds__(64) void k_dm_accept(double* __restrict__ po
 //   value[n][j][k] (+)= (phi_j(r')/F) conj( sum_e ratio[n][e] phi_k(r_e) ),  norm[n][j] (+)= |phi_j(r')|^2 / F,  F = f(r') / norb
 // with r' the auxiliary walker assign[n] of the kept sample.  cfg: [nconf][nelec][nmo2] orbitals at the electrons.
 // LDS: 2 norb doubles.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_obdm_acc(const double* __restrict__ aux_rows, const double* __restrict__ aux_f,
                                                   const int* __restrict__ assign, const double* __restrict__ cfg,
                                                   const double* __restrict__ ratio, int rc, int oc, int nelec, int norb, int first,
@@ -124,6 +128,7 @@ static __global__ __launch_bounds__(256) void k_obdm_acc(const double* __restric
 // Two-body estimator, one block per configuration (tbdm.py:232-277).  ratio[n][a][b] = Psi(r_a -> r1', r_b -> r2') / Psi
 // (0 for a pair that would move the same electron twice); cfg_a [nconf][nea][nmo2a], cfg_b [nconf][neb][nmo2b];
 // ijkl [4][ntuple].  LDS: 2 (nea nb + na nb) doubles.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tbdm_acc(const double* __restrict__ auxa_rows, const double* __restrict__ auxa_f,
                                                   const double* __restrict__ auxb_rows, const double* __restrict__ auxb_f,
                                                   const int* __restrict__ assign_a, const int* __restrict__ assign_b,
@@ -183,6 +188,7 @@ static __global__ __launch_bounds__(256) void k_tbdm_acc(const double* __restric
 }
 
 // out[c] = scale * mean over rows of in[rows][cols] (deterministic: one block per column, fixed tree)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_col_means(const double* __restrict__ in, long rows, long cols, double scale, double* __restrict__ out) {
   __shared__ double sh[256];
   const long c = blockIdx.x;
@@ -196,6 +202,7 @@ static __global__ __launch_bounds__(256) void k_col_means(const double* __restri
   }
   if (threadIdx.x == 0) out[c] = scale * sh[0] / (double)rows;
 }
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_scale_copy(const double* __restrict__ in, long n, double scale, double* __restrict__ out) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = scale * in[i];
@@ -206,6 +213,7 @@ static __global__ __launch_bounds__(256) void k_scale_copy(const double* __restr
 // stochastic_reconfiguration.py:106-114: A = dp, B = weights * f * dp).  One wave per 16x16 tile of C and slice of n,
 // v_mfma_f64_16x16x4_f64 over 4 configurations at a time; the slices' partial tiles are summed by k_gram_reduce in slice
 // order (deterministic).  A, B row-major [n][p], [n][q]: a lane's operand A[n0 + kq][p0 + i16] is contiguous over i16.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_gram_mfma(const double* __restrict__ A, const double* __restrict__ B, long n, int P, int Q,
                                                   int nslice, double* __restrict__ part) {
   const int lane = threadIdx.x, i16 = lane & 15, kq = lane >> 4;
@@ -227,6 +235,7 @@ static __global__ __launch_bounds__(64) void k_gram_mfma(const double* __restric
     if (p < P && q < Q) part[((size_t)sl * P + p) * Q + q] = acc[r];
   }
 }
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ part, long PQ, int nslice, double* __restrict__ C) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= PQ) return;

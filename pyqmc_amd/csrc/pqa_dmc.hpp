@@ -48,6 +48,7 @@ struct TmBuf {
 // when its turn comes, and the mask / rotation draws do not depend on the state, so positions, weights and orbital
 // values are those the reference computes one electron at a time (dmc.py:160-168); only the ratios need the loop.
 // grid = (ceil(W/256), N), block = 256.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.y;
@@ -86,6 +87,7 @@ static __global__ __launch_bounds__(256) void k_tm_count(SysDev S, JastrowState 
 // ~2 ms; this is ~20 us): k_scan_local scans 1024-element tiles and emits tile totals, k_scan_tiles scans those (one block),
 // k_scan_add adds the tile offsets and copies o[k*W] (k = 0..n/W) to marks[] — the per-electron totals the host reads back
 // in one small copy to size the launches.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_scan_local(const int* __restrict__ c, long* __restrict__ o, long n, long* __restrict__ tile_sum) {
   __shared__ long wsum[16];
   const long i = (long)blockIdx.x * 1024 + threadIdx.x;
@@ -107,6 +109,7 @@ static __global__ __launch_bounds__(1024) void k_scan_local(const int* __restric
   __syncthreads();
   if (i < n) o[i] = wsum[wv] + x - v;
 }
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long nt) {  // in place, t[nt] = total
   __shared__ long part[1024];
   const long per = (nt + 1023) / 1024;
@@ -124,6 +127,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t
   long run = part[threadIdx.x];
   for (long i = b; i < e; ++i) { const long v = t[i]; t[i] = run; run += v; }
 }
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, long n, const long* __restrict__ tile_off, long nt, long W,
                                                    long* __restrict__ marks) {
   const long i = (long)blockIdx.x * 1024 + threadIdx.x;
@@ -137,6 +141,7 @@ static __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, 
 
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
 // grid = (W, N), block = 64.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_tm_fill(SysDev S, JastrowState js, TmBuf B, long W) {
   const long w = blockIdx.x;
   const int e = blockIdx.y;
@@ -260,6 +265,7 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
 
 // U_e at the CURRENT position of every (electron, walker) that has candidates: -log of the denominator all of its candidates
 // share (computed once here instead of once per candidate).  uold: [N][W].  grid = (ceil(W/256), N), block = 256.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState js, TmBuf B, long W, double* __restrict__ uold) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   const int e = blockIdx.y;
@@ -304,6 +310,7 @@ static __global__ __launch_bounds__(256) void k_tm_uold(SysDev S, JastrowState j
   uold[(size_t)e * W + w] = uo;
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tm_ratio(SysDev S, SlaterState st, JastrowState js, TmBuf B, int s, int has_slater, int has_jastrow,
                                                   const double* __restrict__ mo, long p_base, long npts, long W, const double* __restrict__ uold) {
   const long q = (long)blockIdx.x * 256 + threadIdx.x;
@@ -475,6 +482,7 @@ static __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState s
 
 // ascending list of the (electron, walker) pairs whose T-move was accepted in this step, with their (new) positions:
 // entry acc_off[i] of the list for every flagged i = e*W + w.  grid = ceil(N*W/256), block = 256.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double* __restrict__ x, int nelec, long W) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)nelec * W || !B.acc[i]) return;
@@ -487,6 +495,7 @@ static __global__ __launch_bounds__(256) void k_tm_gather(TmBuf B, const double*
 // orbital-row cache (value, gradient, Laplacian) of the accepted T-moves of one spin.  mo5: [count][5][nmo_s] rows at the
 // new positions, idx: the matching (e*W + w) entries.  rc / sel: the two-slot row cache of the lane-per-walker sweep when that
 // holds the live cache (the row replaces the CURRENT slot's), else NULL (st.cache).  grid = count, block = 64.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_tm_cache(SysDev S, SlaterState st, const int* __restrict__ idx, const double* __restrict__ mo5,
                                                  int s, long W, double* __restrict__ rc, const uint8_t* __restrict__ sel) {
   const long a = blockIdx.x;
@@ -509,6 +518,7 @@ __device__ __forceinline__ double dmc_S(double e_trial, double e_est, double bra
 
 // weights *= exp(tau (r2_acc / r2_prop) (S_new + S_old)/2); the new energy becomes the old one; statistics reset.
 // en: rows ke, ee, ei, ecp, grad2, total of the NEW configuration.  eold/v2old: [W].
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_dmc_weights(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old,
                                                      double* __restrict__ r2_acc, double* __restrict__ r2_prop,
                                                      double* __restrict__ weights, double tau, double branchcut, double e_trial,
@@ -523,6 +533,7 @@ static __global__ __launch_bounds__(256) void k_dmc_weights(const double* __rest
   r2_acc[w] = 0.0; r2_prop[w] = 0.0;
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_dmc_keep(const double* __restrict__ en, double* __restrict__ eold, double* __restrict__ v2old, long W) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
   if (w >= W) return;
@@ -532,6 +543,7 @@ static __global__ __launch_bounds__(256) void k_dmc_keep(const double* __restric
 // out[0..5] = sum_w weights[w] en[k][w] / sum_w weights[w] (the reference's dot(weights, v)/(W wavg), dmc.py:205-209),
 // out[6] = mean weight; complex wave functions (nrow = 7: the energy buffer's row 6 is Im ecp = Im total) also out[7] = the
 // weighted mean of that row.  One block of 1024 threads, deterministic.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_dmc_averages(const double* __restrict__ en, const double* __restrict__ weights, long W,
                                                        double* __restrict__ out, int nrow) {
   __shared__ double part[8][1024];

@@ -5,9 +5,9 @@ int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks
   const long nt = (n + 1023) / 1024;
   TRY(ensure(h, h->b_tmtile, (size_t)(nt + 1) * sizeof(long)));
   long* tile = (long*)h->b_tmtile.p;
-  hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nt), dim3(1024), 0, h->stream, c, o, n, tile);
-  hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, h->stream, tile, nt);
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nt), dim3(1024), 0, h->stream, o, n, (const long*)tile, nt, Wm, marks);
+  hipLaunchKernelGGL((k_scan_local<>), dim3((unsigned)nt), dim3(1024), 0, h->stream, c, o, n, tile);
+  hipLaunchKernelGGL((k_scan_tiles<>), dim3(1), dim3(1024), 0, h->stream, tile, nt);
+  hipLaunchKernelGGL((k_scan_add<>), dim3((unsigned)nt), dim3(1024), 0, h->stream, o, n, (const long*)tile, nt, Wm, marks);
   return check_launch(h, "k_scan_local/tiles/add");
 }
 
@@ -78,7 +78,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   std::vector<long> tm_accepted((size_t)nsteps, 0);
   // energy of the starting configuration (dmc.py:146-149)
   TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
-  hipLaunchKernelGGL(k_dmc_keep, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
+  hipLaunchKernelGGL((k_dmc_keep<>), gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
@@ -101,13 +101,13 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
         TRY(copy_in(h, u + 2 * NW, tp->tm_unif + (size_t)step * NW * necp, NW * necp * sizeof(double)));
         B.u1 = u; B.u2 = u + NW; B.unif = u + 2 * NW;
       } else {
-        hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed ^ 0x9E3779B97F4A7C15ull,
+        hipLaunchKernelGGL((k_gen_rot<>), dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed ^ 0x9E3779B97F4A7C15ull,
                            (uint32_t)step, (double*)h->b_rot.p);
         TRY(check_launch(h, "k_gen_rot"));
       }
       B.rot = (const double*)h->b_rot.p;
       HIPCHK(hipMemsetAsync(B.acc, 0, NW * sizeof(int), h->stream));
-      hipLaunchKernelGGL(k_tm_count, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W);
+      hipLaunchKernelGGL((k_tm_count<>), dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W);
       TRY(check_launch(h, "k_tm_count"));
       TRY(scan_ints(h, (const int*)B.cnt, B.off, (long)NW, W, d_marks));
       std::vector<long> eoff((size_t)N + 1);  // first candidate of every electron
@@ -120,7 +120,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
         TRY(ensure(h, h->b_tmptw, (size_t)tot * sizeof(int)));
         B.pts = (double*)h->b_tpos.p; B.wgt = (double*)h->b_twgt.p; B.amp = (double*)h->b_tmamp.p; B.rat = B.amp + tot;
         B.ptw = (int*)h->b_tmptw.p;
-        hipLaunchKernelGGL(k_tm_fill, dim3((unsigned)W, (unsigned)N), dim3(64), 0, h->stream, h->S, h->js, B, W);
+        hipLaunchKernelGGL((k_tm_fill<>), dim3((unsigned)W, (unsigned)N), dim3(64), 0, h->stream, h->S, h->js, B, W);
         TRY(check_launch(h, "k_tm_fill"));
         const long cnt_s[2] = {tot_up, tot - tot_up}, base_s[2] = {0, tot_up};
         if (h->has_slater)
@@ -138,7 +138,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
           if (lw && step > 0 && h->has_j2 && !h->has_j3) d_uold = (const double*)h->b_kpart.p + (size_t)4 * NW;
           else {
             TRY(ensure(h, h->b_tmuold, (size_t)NW * sizeof(double)));
-            hipLaunchKernelGGL(k_tm_uold, dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
+            hipLaunchKernelGGL((k_tm_uold<>), dim3(gw256.x, (unsigned)N), dim3(256), 0, h->stream, h->S, h->js, B, W, (double*)h->b_tmuold.p);
             d_uold = (const double*)h->b_tmuold.p;
           }
         }
@@ -146,7 +146,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
           for (int s = 0; s < 2; ++s) {
             if (cnt_s[s] == 0) continue;
             const dim3 g((unsigned)((cnt_s[s] + 255) / 256));
-            hipLaunchKernelGGL(k_tm_ratio, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater, (int)h->has_jastrow,
+            hipLaunchKernelGGL((k_tm_ratio<>), g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater, (int)h->has_jastrow,
                                (const double*)h->b_emo[s].p, base_s[s], cnt_s[s], W, d_uold);
           }
         const size_t lds_tm = std::max(lds_sm(h), lds_det(h, 1));
@@ -156,7 +156,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
                                 (int)h->has_jastrow, (const double*)h->b_emo[0].p, (const double*)h->b_emo[1].p, tot_up, W, pre ? 1 : 0);
         TRY(check_launch(h, "k_tm_walker"));
         TRY(scan_ints(h, (const int*)B.acc, B.acc_off, (long)NW, W, d_marks));
-        hipLaunchKernelGGL(k_tm_gather, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
+        hipLaunchKernelGGL((k_tm_gather<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->js.x, N, W);
         TRY(check_launch(h, "k_tm_gather"));
         TRY(copy_out(h, eoff.data(), d_marks, eoff.size() * sizeof(long)));
         const long nacc[2] = {eoff[N], eoff[h->nup]};
@@ -167,7 +167,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
             if (na_s[s] == 0) continue;
             TRY(ensure(h, h->b_emo[s], (size_t)na_s[s] * 5 * nmo_max * sizeof(double)));
             TRY(launch_orb(h, s, plain_points(B.acc_pos + 3 * a0_s[s], na_s[s]), na_s[s], 5, (double*)h->b_emo[s].p));
-            hipLaunchKernelGGL(k_tm_cache, dim3((unsigned)na_s[s]), dim3(64), 0, h->stream, h->S, h->st, (const int*)(B.acc_idx + a0_s[s]),
+            hipLaunchKernelGGL((k_tm_cache<>), dim3((unsigned)na_s[s]), dim3(64), 0, h->stream, h->S, h->st, (const int*)(B.acc_idx + a0_s[s]),
                                (const double*)h->b_emo[s].p, s, W, lw ? (double*)h->b_rc[s].p : (double*)nullptr, lw ? (const uint8_t*)h->b_sel[s].p : (const uint8_t*)nullptr);
           }
           TRY(check_launch(h, "k_tm_cache"));
@@ -181,13 +181,13 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     }
     if (lw && tmoves) TRY(lw_from_aos(h, false));  // the T-moves worked on the AoS coordinates and inverses
     TRY(sweep_electrons(h, mb, lw, lc));
-    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + 2 * step);
+    hipLaunchKernelGGL((k_sum_reset_int<>), dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + 2 * step);
     TRY(check_launch(h, "k_propose/k_accept (dmc)"));
     TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot + (size_t)(step + 1) * nrot * 9 : nullptr,
                    (tp && necp) ? tp->ecp_unif + (size_t)(step + 1) * nrot * W : nullptr, seed, (uint32_t)(step + 1), lw));
-    hipLaunchKernelGGL(k_dmc_weights, gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
+    hipLaunchKernelGGL((k_dmc_weights<>), gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, r2, r2 + W,
                        (double*)h->b_dmcw.p, tstep, branchcut, e_trial, e_est, N, W);
-    hipLaunchKernelGGL(k_dmc_averages, dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
+    hipLaunchKernelGGL((k_dmc_averages<>), dim3(1), dim3(1024), 0, h->stream, (const double*)h->b_en.p, (const double*)h->b_dmcw.p, W,
                        (double*)h->b_dmcout.p + (size_t)step * navg, h->cplx ? 7 : 6);
     TRY(check_launch(h, "k_dmc_weights/k_dmc_averages"));
   }
@@ -227,7 +227,7 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
   TRY(ensure(h, h->b_trat, np * sizeof(double)));
   TRY(copy_in(h, h->b_rot.p, rot, (size_t)h->necp * 9 * sizeof(double)));
   TRY(copy_in(h, h->b_eunif.p, unif, (size_t)h->necp * W * sizeof(double)));
-  hipLaunchKernelGGL(k_tmove_points, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, tau, threshold,
+  hipLaunchKernelGGL((k_tmove_points<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, tau, threshold,
                      (const double*)h->b_rot.p, (const double*)h->b_eunif.p, (const double*)h->d_quad, (const int*)h->d_ptk,
                      (const int*)h->d_pti, P, W, (double*)h->b_tpos.p, (double*)h->b_twgt.p, (uint8_t*)h->b_tlive.p);
   TRY(check_launch(h, "k_tmove_points"));
@@ -239,7 +239,7 @@ extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, 
     TRY(ensure(h, h->b_motmp, np * std::max(h->nmo[s], 1) * sizeof(double)));
     TRY(launch_orb(h, s, plain_points((const double*)h->b_tpos.p, (long)np), (long)np, 1, (double*)h->b_motmp.p));
   }
-  hipLaunchKernelGGL(k_tmove_ratio, dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, e, (int)h->has_slater,
+  hipLaunchKernelGGL((k_tmove_ratio<>), dim3((unsigned)W), dim3(64), lds_det(h, 1), h->stream, h->S, h->st, h->js, e, (int)h->has_slater,
                      (int)h->has_jastrow, (const double*)h->b_motmp.p, (const double*)h->b_tpos.p, (const uint8_t*)h->b_tlive.p, P,
                      (double*)h->b_trat.p);
   TRY(check_launch(h, "k_tmove_ratio"));

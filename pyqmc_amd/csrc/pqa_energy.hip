@@ -17,7 +17,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     else
       hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
-    hipLaunchKernelGGL(k_kinetic_reduce, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
+    hipLaunchKernelGGL((k_kinetic_reduce<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));
     // the ECP kernels read walker-major coordinates; the inverse only when the wave-per-walker accumulation runs (or the
@@ -45,7 +45,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     const bool soa = soa_current && h->necp == 0;  // with ECPs the coordinates were just transposed back
     const double* x = soa ? (const double*)h->b_xt.p : h->js.x;
     const size_t lds_ew = ((size_t)h->N * 3 + (h->ew.gn ? (size_t)h->N * 3 * (h->ew.nmax + 1) * 2 : 0)) * sizeof(double);
-    hipLaunchKernelGGL(k_ewald, dim3((unsigned)W), dim3(PQA_EWALD_T), lds_ew, h->stream, h->S, h->ew, x,
+    hipLaunchKernelGGL((k_ewald<>), dim3((unsigned)W), dim3(PQA_EWALD_T), lds_ew, h->stream, h->S, h->ew, x,
                        soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_ewald"));
   }
@@ -56,7 +56,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
     if (rot) TRY(copy_in(h, h->b_rot.p, rot, nrot * 9 * sizeof(double)));
     else {
-      hipLaunchKernelGGL(k_gen_rot, dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed, step, (double*)h->b_rot.p);
+      hipLaunchKernelGGL((k_gen_rot<>), dim3((unsigned)((nrot + 63) / 64)), dim3(64), 0, h->stream, (int)nrot, seed, step, (double*)h->b_rot.p);
       TRY(check_launch(h, "k_gen_rot"));
     }
     EcpBuf B{};
@@ -174,7 +174,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
           hipLaunchKernelGGL(k_ecp_point<false>, g, dim3(256), 0, h->stream, h->S, h->st, h->js, B, s, (int)h->has_slater,
                              (int)h->has_jastrow, (const double*)h->b_emo[s].p, tot[s], (double*)h->b_econ[s].p, Tb, sw, si, sk);
       }
-      hipLaunchKernelGGL(k_ecp_sum, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
+      hipLaunchKernelGGL((k_ecp_sum<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, B, (const double*)h->b_econ[0].p,
                          (const double*)h->b_econ[1].p, W, (double*)h->b_ecp.p, cx_points ? std::max<long>(tot[0], 1) : 0L,
                          cx_points ? std::max<long>(tot[1], 1) : 0L);
     } else {
@@ -184,7 +184,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     TRY(check_launch(h, "k_ecp_accum"));
     d_ecp = (const double*)h->b_ecp.p;
   }
-  hipLaunchKernelGGL(k_energy_assemble, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
+  hipLaunchKernelGGL((k_energy_assemble<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
                      h->ii_energy, W, (double*)h->b_en.p, (int)h->cplx);
   return check_launch(h, "k_energy_assemble");
 }

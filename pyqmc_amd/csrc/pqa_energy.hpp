@@ -104,6 +104,7 @@ struct EwaldDev {
   int nmax;               // max |gn| component
 };
 #define PQA_EWALD_T 256  // threads per walker: the phase tables cost ~20 KB of LDS per block, so one wave per block left 1-2 waves per SIMD
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev E, const double* __restrict__ x, long sw, long se, long sc,
                                               long W, double* __restrict__ out) {
   extern __shared__ double lds[];  // [N][3] coordinates of this walker
@@ -409,6 +410,7 @@ static __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState 
 }
 
 // exclusive scan of cnt[2][W] -> off[2][W+1]; one block of 1024 threads
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_scan2(const int* __restrict__ cnt, long* __restrict__ off, long W) {
   __shared__ long part[1024];
   for (int s = 0; s < 2; ++s) {
@@ -559,6 +561,7 @@ static __global__ __launch_bounds__(64 * NWV) void k_ecp_accum(SysDev S, SlaterS
 }
 
 // uniformly random rotations from a normalised Gaussian quaternion (one per (electron, ECP atom))
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double* __restrict__ rot) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= count) return;
@@ -575,6 +578,7 @@ static __global__ void k_gen_rot(int count, uint64_t seed, uint32_t step, double
 
 // total = ke + ee + ei + ecp + ii ; rows of out: ke, ee, ei, ecp, grad2, total  (accumulators.py:68-75)
 // complex determinants: a 7th row holds Im(ecp) = Im(total) (eval_ecp.py:89, accumulators.py:74).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,ei,grad2*/, const double* __restrict__ ecp,
                                   double ii, long W, double* __restrict__ out, int cplx) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,6 +590,7 @@ static __global__ void k_energy_assemble(const double* __restrict__ kc /*ke,ee,e
 }
 
 // deterministic column means of a (nrow, W) array: one block of 256 threads per row
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ a, long W, double* __restrict__ out) {
   __shared__ double part[256];
   const double* row = a + (size_t)blockIdx.x * W;
@@ -680,6 +685,7 @@ static __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState 
 
 // ecp[w] = local + sum of the walker's point contributions, spin up then spin down, in slot order
 // n_up / n_dn > 0: complex contributions, imaginary parts at c[n + p]; their sum goes to ecp[W + w]
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* __restrict__ c_up, const double* __restrict__ c_dn, long W,
                                                  double* __restrict__ ecp, long n_up = 0, long n_dn = 0) {
   const long w = (long)blockIdx.x * 256 + threadIdx.x;
@@ -701,6 +707,7 @@ static __global__ __launch_bounds__(256) void k_ecp_sum(EcpBuf B, const double* 
 //   weight    sum_l (exp(-tau v_l/prob) - 1)(2l+1) P_l(cos) w_i   (0 where masked out)
 //   live      1 where the walker passed the mask for that atom
 // rot [necp][3][3], unif [necp][W].  grid = W, block = 64.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowState js, int e, double tau, double threshold,
                                                      const double* __restrict__ rot, const double* __restrict__ unif,
                                                      const double* __restrict__ quad, const int* __restrict__ pt_k,
@@ -740,6 +747,7 @@ static __global__ __launch_bounds__(64) void k_tmove_points(SysDev S, JastrowSta
 }
 
 // ratio[w][q] = Psi(candidate)/Psi for live candidates, 1 otherwise.  mo: [W*P][nmo_s].  LDS: max(ndet_s) doubles.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_tmove_ratio(SysDev S, SlaterState st, JastrowState js, int e, int has_slater,
                                                     int has_jastrow, const double* __restrict__ mo,
                                                     const double* __restrict__ pos, const uint8_t* __restrict__ live, int P,

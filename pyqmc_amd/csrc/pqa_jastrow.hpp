@@ -351,12 +351,14 @@ __device__ __forceinline__ double jas_value_wave(const SysDev& S, const JastrowS
   return wave_sum(u);
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_jastrow_value(SysDev S, JastrowState js, double* out) {
   const double u = jas_value_wave(S, js, blockIdx.x);
   if (threadIdx.x == 0) out[blockIdx.x] = u;
 }
 
 // _avalues / _bvalues from scratch for walker w (jastrowspin.py:80-105)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, JastrowState js) {
   const long w = blockIdx.x;
   const int lane = threadIdx.x;
@@ -411,6 +413,7 @@ static __global__ __launch_bounds__(64) void k_jastrow_recompute(SysDev S, Jastr
 // mode 0: out[r*npt+q] = exp(U_e(pt) - U_e(x_e))                       (testvalue)
 // mode 1: out (4,nrow): grad U_e(pt), exp(U_e(pt) - U_e(x_e))          (gradient_value)
 // mode 2: out (4,nrow): grad U_e(pt), lap U_e + |grad U_e|^2           (gradient_laplacian)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowState js, int e, const double* __restrict__ pts,
                                                      long nrow, int npt, const int* __restrict__ widx, int mode,
                                                      int parts, double* __restrict__ out) {
@@ -439,6 +442,7 @@ static __global__ __launch_bounds__(64) void k_jastrow_eval(SysDev S, JastrowSta
   }
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowState js, int e, const double* __restrict__ epos,
                                                        const uint8_t* __restrict__ mask) {
   const long w = blockIdx.x;
@@ -447,6 +451,7 @@ static __global__ __launch_bounds__(64) void k_jastrow_update(SysDev S, JastrowS
 }
 
 // three-body log value U3 = 1/2 sum_e P_e(x_e)  (three_body_jastrow.py:98-101)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState js, double* __restrict__ out) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;
@@ -461,6 +466,7 @@ static __global__ __launch_bounds__(64) void k_j3_value(SysDev S, JastrowState j
 }
 
 // move the stored coordinate of electron e for the masked walkers (handles without a two-body factor)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_move_x(JastrowState js, int N, int e, const double* __restrict__ epos, const uint8_t* __restrict__ mask, long W) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W || (mask && !mask[w])) return;
@@ -473,6 +479,7 @@ static __global__ void k_move_x(JastrowState js, int N, int e, const double* __r
 //   a_k(r_iI) a_l(r_jI) b_m(r_ij):  sp 0 = up-up (i<j), 1 = up (i) - down (j), 2 = down-down (i<j)
 // (ThreeBodyJastrow.pgradient, three_body_jastrow.py:657-719).  One wave per walker; LDS: a-values of every electron
 // [N][natom][na] followed by b-values of every pair [N(N-1)/2][nb] (row-major upper triangle); out (W, natom, na, na, nb, 3).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_j3_pgrad(SysDev S, JastrowState js, double* __restrict__ out) {
   extern __shared__ double lds[];
   const long w = blockIdx.x;

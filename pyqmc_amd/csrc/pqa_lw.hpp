@@ -46,6 +46,7 @@ __device__ __forceinline__ double* lw_row(const LwState& L, int s, int i, int sl
 
 // ---------------------------------------------------------------- layout transposes
 // in [R][C] -> out [C][R] through a 32x33 LDS tile; block (32,8)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ in, double* __restrict__ out, long R, long C) {
   __shared__ double tile[32][33];
   const long c0 = (long)blockIdx.x * 32, r0 = (long)blockIdx.y * 32;
@@ -62,6 +63,7 @@ static __global__ __launch_bounds__(256) void k_transpose(const double* __restri
 
 // walker-major orbital cache [W][n][5 nmo] <-> the two-slot row cache.  to_rc: everything lands in slot 0 (selectors cleared);
 // from_rc: every electron's CURRENT slot.  grid = (W, n, ceil(row / 256)), block = 256.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_cache_to_rc(const double* __restrict__ aos, double* __restrict__ rc, uint8_t* __restrict__ sel, int n,
                                                      int row, long W) {
   const long w = blockIdx.x;
@@ -69,6 +71,7 @@ static __global__ __launch_bounds__(256) void k_cache_to_rc(const double* __rest
   if (k == 0) sel[(size_t)i * W + w] = 0;
   if (k < row) rc[(((size_t)i * 2) * W + w) * row + k] = aos[((size_t)w * n + i) * row + k];
 }
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_cache_from_rc(const double* __restrict__ rc, const uint8_t* __restrict__ sel, double* __restrict__ aos,
                                                        int n, int row, long W) {
   const long w = blockIdx.x;
@@ -1303,6 +1306,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
 }
 
 // out rows ke, ee, ei, grad2 (layout of k_kinetic_coulomb) = sums over electrons of part
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_kinetic_reduce(const double* __restrict__ part, int N, long W, double* __restrict__ out) {
   const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;

@@ -8,7 +8,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   const int NW = h->pbc_nw;
   TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * NW * P * sizeof(unsigned long long)));
   if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
-  hipLaunchKernelGGL(k_pbc_prepass, dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
+  hipLaunchKernelGGL((k_pbc_prepass<>), dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
                      (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
   ChunkTab T = tabx(h, tabi);
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
@@ -20,7 +20,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
     else TRY((launch_orb_wide<1, 512>(h, T, tabi, spin, pa, P, out)));
     if (h->twist) {
       const long nel = P * NCOMP * (h->nmo[spin] / 2);
-      hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
+      hipLaunchKernelGGL((k_row_phase<>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
                          (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
     }
     return 0;
@@ -54,7 +54,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   // small launches: split the chunk loop over two blocks per point tile (k_orb: gridDim.y), output accumulated atomically
   const int nsplit = (P <= h->orb_split_max && T.nchunk >= 4 && !h->orb_nosplit) ? 2 : 1;
   if (nsplit > 1) {
-    if (h->out_sel) hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)P, (unsigned)((NCOMP * h->nmo[spin] + 255) / 256)), dim3(256), 0, h->stream, out,
+    if (h->out_sel) hipLaunchKernelGGL((k_zero_rows<>), dim3((unsigned)P, (unsigned)((NCOMP * h->nmo[spin] + 255) / 256)), dim3(256), 0, h->stream, out,
                                        NCOMP * h->nmo[spin], h->out_sel, h->out_slot_stride);
     else HIPCHK(hipMemsetAsync(out, 0, (size_t)P * NCOMP * h->nmo[spin] * sizeof(double), h->stream));
   }
@@ -84,7 +84,7 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
 #undef PQA_ORB_PBC
   if (h->twist) {
     const long nel = P * NCOMP * (h->nmo[spin] / 2);
-    hipLaunchKernelGGL(k_row_phase, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
+    hipLaunchKernelGGL((k_row_phase<>), dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, h->stream, out, P, NCOMP, h->nmo[spin],
                        (const double*)h->b_pbcth.p, h->out_sel, h->out_slot_stride);
   }
   return 0;

@@ -30,6 +30,7 @@ __device__ __forceinline__ double clamp_nan_to_num(double v) {
 // ---------------------------------------------------------------- build + invert (recompute)
 // grid = W * ndet_s blocks of 64 threads; dynamic LDS: n*(n+1) doubles + n ints.
 // B[j][i] = mo(electron i, orbital occ[d][j]); T = B^{-1}, det(B) = det(reference matrix).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterState st, int s, long W) {
   extern __shared__ double lds[];
   const int n = s ? S.ndn : S.nup, nmo = S.nmo[s], D = S.ndet_s[s];
@@ -134,6 +135,7 @@ __device__ __forceinline__ void slater_value_wave(const SysDev& S, const SlaterS
   logv = clamp_nan_to_num(log(fabs(t)) + ref);
 }
 
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_slater_value(SysDev S, SlaterState st, double* sign, double* logv) {
   const long w = blockIdx.x;
   double sg, lv;
@@ -354,6 +356,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
 }
 
 // grid = W; mo rows [w][NCOMP_STRIDE][nmo] (value component first); mask (W) bytes
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(64) void k_sm_update(SysDev S, SlaterState st, int e, const double* __restrict__ mo,
                                                   int row_stride, const uint8_t* __restrict__ mask, int to_cache) {
   extern __shared__ double lds[];
@@ -369,6 +372,7 @@ static __global__ __launch_bounds__(64) void k_sm_update(SysDev S, SlaterState s
 }
 
 // any non-finite log-determinant? (slater.py:269-275 trigger for a full recompute)
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_has_zero(const double* dlog, long count, int* flag) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < count) {
@@ -379,6 +383,7 @@ static __global__ void k_has_zero(const double* dlog, long count, int* flag) {
 
 // ---------------------------------------------------------------- parameter gradients (Slater.pgradient, slater.py:462-542)
 // d_det[w][di] = D_up D_dn / Psi for determinant di (:495-505).
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ void k_pgrad_det(SysDev S, SlaterState st, const double* __restrict__ psi_sign, const double* __restrict__ psi_log,
                             long W, double* __restrict__ out) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,6 +404,7 @@ static __global__ void k_pgrad_det(SysDev S, SlaterState st, const double* __res
 // d_mo[w][a][m] = sum_di coeff[di] d_det[w][di] * sum_e ao[w][e][a] inverse_det[col(m)][e]   for m occupied in the
 // determinant (:507-533; _testcol :382-388).  ao: [W*N][nao] values of all electrons (walker-major, electron order of x);
 // colmap: [ndet_s][nmo_s] column of orbital m in unique determinant u or -1.  grid = (W), block = 256.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_pgrad_mo(SysDev S, SlaterState st, int s, const double* __restrict__ ao,
                                                   const double* __restrict__ d_det, const int* __restrict__ colmap,
                                                   double* __restrict__ out) {

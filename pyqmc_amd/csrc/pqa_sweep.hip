@@ -17,7 +17,7 @@ void launch_flush_real(pqa_handle* h, const LwState& L, int s, long W, long w0, 
 // energy of the resident walkers into device buffer b_en (6,W)
 void transpose(pqa_handle* h, const double* in, double* out, long R, long C) {  // in [R][C] -> out [C][R]
   if (R <= 0 || C <= 0) return;
-  hipLaunchKernelGGL(k_transpose, dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, h->stream, in, out, R, C);
+  hipLaunchKernelGGL((k_transpose<>), dim3((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32)), dim3(32, 8), 0, h->stream, in, out, R, C);
 }
 
 LwState lw_state(pqa_handle* h) {
@@ -48,7 +48,7 @@ int lw_from_aos(pqa_handle* h, bool with_cache) {
     transpose(h, h->st.T[s], (double*)h->b_Tt[s].p, W, (long)(cf * n * n));
     if (n > 0 && row > 0) {
       // (without the cache: the caller knows the row cache and its selectors are live — the T-move phase of the DMC step)
-      if (with_cache) hipLaunchKernelGGL(k_cache_to_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
+      if (with_cache) hipLaunchKernelGGL((k_cache_to_rc<>), dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
                                          (const double*)h->st.cache[s], (double*)h->b_rc[s].p, (uint8_t*)h->b_sel[s].p, (int)n, row, W);
     }
   }
@@ -64,7 +64,7 @@ int lw_to_aos(pqa_handle* h, bool with_cache) {
     transpose(h, (const double*)h->b_Tt[s].p, h->st.T[s], (h->cplx ? 2 : 1) * n * n, W);
     const int row = 5 * h->nmo[s];
     if (with_cache && n > 0 && row > 0)
-      hipLaunchKernelGGL(k_cache_from_rc, dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
+      hipLaunchKernelGGL((k_cache_from_rc<>), dim3((unsigned)W, (unsigned)n, (unsigned)((row + 255) / 256)), dim3(256), 0, h->stream,
                          (const double*)h->b_rc[s].p, (const uint8_t*)h->b_sel[s].p, h->st.cache[s], (int)n, row, W);
   }
   return check_launch(h, "k_transpose");
@@ -160,7 +160,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
     const size_t NW = (size_t)h->N * W;
     TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
     TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W,
+    hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W,
                        (double*)h->b_gauss.p, (double*)h->b_unif.p);
     mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
   }
@@ -387,13 +387,13 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
     if (tile) TRY(sweep_tile(h, mb));
     else TRY(sweep_electrons(h, mb, lw, lc));
-    hipLaunchKernelGGL(k_sum_reset_int, dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
+    hipLaunchKernelGGL((k_sum_reset_int<>), dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
                      ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false));
-      hipLaunchKernelGGL(k_row_means, dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
+      hipLaunchKernelGGL((k_row_means<>), dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
       TRY(check_launch(h, "k_row_means"));
     }
   }

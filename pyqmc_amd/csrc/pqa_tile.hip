@@ -1,6 +1,12 @@
 // pyqmc_amd C ABI implementation (host side): the walker-tile sweep (opt-in, PQA_LW=2; pqa_tile.hpp).
+// An experiment kept for A/B runs (on par with the lane-per-walker sweep up to ~3000 walkers, behind it
+// above): compiled only into -DPQA_AB builds (python __graft_entry__.py --ab), the default library carries neither the
+// kernel nor its launch code.
 #include "pqa_internal.hpp"
-
+#ifndef PQA_AB
+bool tile_eligible(const pqa_handle*) { return false; }
+int sweep_tile(pqa_handle* h, const MoveBuf&) { FAIL("the walker-tile sweep is only part of -DPQA_AB builds"); }
+#else
 bool tile_eligible(const pqa_handle* h) {
   if (h->lw_mode != 2 || !h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc) return false;
   if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32) return false;
@@ -16,7 +22,7 @@ int sweep_tile(pqa_handle* h, const MoveBuf& mb_in) {
     const size_t NW = (size_t)h->N * h->W;
     TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
     TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-    hipLaunchKernelGGL(k_tile_draws, dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, h->W,
+    hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, h->W,
                        (double*)h->b_gauss.p, (double*)h->b_unif.p);
     mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
   }
@@ -53,3 +59,4 @@ int sweep_tile(pqa_handle* h, const MoveBuf& mb_in) {
 #undef PQA_TILE_LAUNCH
   return check_launch(h, "k_sweep_tile");
 }
+#endif

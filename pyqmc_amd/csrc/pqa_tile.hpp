@@ -76,6 +76,7 @@ __device__ __forceinline__ void tile_rowdots4(const double* __restrict__ rows, i
 // The sweep's random numbers, drawn ahead of it from the same Philox streams the other sweep kernels use (so the three
 // paths make the same decisions): gauss [N][W][3] standard normals, unif [N][W].  Keeping Box-Muller (sincos, log) out of
 // k_sweep_tile matters: its argument reduction alone costs that kernel dozens of spilled registers.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(256) void k_tile_draws(uint64_t seed, uint32_t step, int N, long W, double* __restrict__ gauss, double* __restrict__ unif) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)N * W) return;

@@ -185,6 +185,7 @@ static __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, 
 }
 
 // accepted-move count of one sweep: sum acc_w[0..W) -> *out, and reset acc_w.  One block, deterministic.
+template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_sum_reset_int(int* __restrict__ acc_w, long W, int* __restrict__ out) {
   __shared__ int part[1024];
   int s = 0;
