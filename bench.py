@@ -327,7 +327,7 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--walkers", type=int, default=0, help="walkers per GPU (weak scaling; default 65536 for the headline, the measured throughput "
                     "optimum; 4096 / 2048 for --mode dmc / c4) or in total (--scaling strong; default 32768 / 16384 for dmc / c4)")

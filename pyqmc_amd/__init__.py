@@ -19,3 +19,4 @@ from .obdm import OBDMAccumulator  # noqa: F401
 from .tbdm import TBDMAccumulator  # noqa: F401
 
 __version__ = "0.1.0"
+from . import chkfile, hdf5lite  # noqa: F401,E402  (PySCF checkpoint ingest without an HDF5 library)

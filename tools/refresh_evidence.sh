@@ -19,12 +19,14 @@ python $R/bench.py --mode dmc --steps 20 --warmup 2 > $O/bench_dmc.json 2>> $O/b
 python $R/bench.py --mode c4 --steps 20 --warmup 2 > $O/bench_c4.json 2>> $O/bench.err < /dev/null
 rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --walkers $W --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2>&1 < /dev/null
 python $R/tools/prof_stats.py /tmp/pb/b_results.db $O/bench_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do  # counter passes of the periodic case (separate runs, no trace options); calibration as above
-  rocprofv3 --pmc $c -d /tmp/pkm_$c -o t -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 1 --warmup 1 > /dev/null 2>&1 < /dev/null
-  python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_k222_pmc_$c.csv
+for case in k222 cubic; do  # counter passes of the periodic cases (separate runs, no trace options); calibration as above
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pkm_$c; rocprofv3 --pmc $c -d /tmp/pkm_$c -o t -- python $R/tools/pbc_bench.py --case $case --walkers 32768 --steps 1 --warmup 1 > /dev/null 2>&1 < /dev/null
+    python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_${case}_pmc_$c.csv
+  done
+  python $R/tools/pmc_summary.py /tmp/pkm_FETCH_SIZE/t_results.db /tmp/pkm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db 32768 $O/pbc_${case}_pmc_summary.json > /dev/null 2>&1
+  cp $O/pbc_${case}_pmc_summary.json $R/profiles/r04_pbc_${case}_pmc_summary.json
 done
-python $R/tools/pmc_summary.py /tmp/pkm_FETCH_SIZE/t_results.db /tmp/pkm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db 32768 $O/pbc_k222_pmc_summary.json > /dev/null 2>&1
-cp $O/pbc_k222_pmc_summary.json $R/profiles/r04_pbc_k222_pmc_summary.json
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
 python $R/tools/prof_stats.py /tmp/pk/k_results.db $O/pbc_k222_kernel_stats.csv
