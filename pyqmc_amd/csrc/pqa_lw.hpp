@@ -758,17 +758,17 @@ struct JasTabs {  // wave-uniform function tables (scalar registers)
 };
 // jas_eval_lane_t<1, PBC, true> for the partners j = g, g + G, ... and ions I = g, g + G, ... on coordinates and ion
 // coefficients that are already in registers
-template <bool PBC>
+template <bool PBC, int NP, int NA>
 __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e, double rx, double ry, double rz, int has_jastrow, int g,
-                                        int G, const double (&pcx)[PQA_PRE_NP], const double (&pcy)[PQA_PRE_NP],
-                                        const double (&pcz)[PQA_PRE_NP], const double (&atx)[PQA_PRE_NA], const double (&aty)[PQA_PRE_NA],
-                                        const double (&atz)[PQA_PRE_NA], const double (&bc0)[PQA_JAS_NF], const double (&bc1)[PQA_JAS_NF],
-                                        const double (&ac)[PQA_PRE_NA][PQA_JAS_NF], double& U, double (&gr)[3]) {
+                                        int G, const double (&pcx)[NP], const double (&pcy)[NP],
+                                        const double (&pcz)[NP], const double (&atx)[NA], const double (&aty)[NA],
+                                        const double (&atz)[NA], const double (&bc0)[PQA_JAS_NF], const double (&bc1)[PQA_JAS_NF],
+                                        const double (&ac)[NA][PQA_JAS_NF], double& U, double (&gr)[3]) {
   constexpr int NF = PQA_JAS_NF;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
 #pragma unroll
-  for (int m = 0; m < PQA_PRE_NP; ++m) {
+  for (int m = 0; m < NP; ++m) {
     const int j = g + m * G;
     if (j >= S.nelec || j == e) continue;
     double dx = rx - pcx[m], dy = ry - pcy[m], dz = rz - pcz[m];
@@ -792,7 +792,7 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
     }
   }
 #pragma unroll
-  for (int m = 0; m < PQA_PRE_NA; ++m) {
+  for (int m = 0; m < NA; ++m) {
     const int I = g + m * G;
     if (I >= S.natom) continue;
     double dx = rx - atx[m], dy = ry - aty[m], dz = rz - atz[m];
@@ -816,10 +816,15 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
   U = u_; gr[0] = gx; gr[1] = gy; gr[2] = gz;
 }
 
-template <bool PBC, int NMAX>
-static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
+// GW = 16: the kernel as described (256 threads: NW walkers x G >= 8 groups, up to 8 partners and 4 ions per thread).
+// GW = 32 / 64 (round 4): 16 walkers x GW groups = 512 / 1024 threads — two / ONE partner electron and ion per thread, so the two
+// Jastrow pair loops that made up most of the ~3000-instruction dependent chain of a launch become one or two pair evaluations;
+// the groups' partial sums are totalled by eight threads per walker (one per row of the sums, group order) instead of by every thread.
+template <bool PBC, int NMAX, int GW = 16>
+static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
   extern __shared__ double sh[];
-  constexpr int PR = 8, JU = 4, NS = (NMAX + 7) / 8, NF = PQA_JAS_NF, NP = PQA_PRE_NP, NA = PQA_PRE_NA;
+  constexpr int PR = 8, JU = 4, NF = PQA_JAS_NF;
+  constexpr int NS = GW == 16 ? (NMAX + 7) / 8 : (NMAX + GW - 1) / GW, NP = GW == 16 ? PQA_PRE_NP : 64 / GW, NA = GW == 16 ? PQA_PRE_NA : 64 / GW;
   const int NW = a.NW, G = a.G;
   const int lane = (int)threadIdx.x % NW, g = (int)threadIdx.x / NW;
   const long W = a.W;
@@ -831,6 +836,7 @@ static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, Mo
   double* shV = sh + (size_t)PR * G * NW;     // [NMAX][NW] update vectors
   double* shR = shV + (size_t)NMAX * NW;
   double* shT = shR + (size_t)NMAX * NW;      // [NMAX][NW] inverse row of the next electron after the commit
+  double* shTot = shT + (size_t)NMAX * NW;    // [PR][NW] (GW > 16) the totals of the groups' partial sums
   const int ea = a.e_acc, ep = a.e_prop;
   const bool has_a = ea >= 0, has_p = ep >= 0;
   const int s = has_a ? (ea >= S.nup) : 0, i = ea - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
@@ -931,7 +937,7 @@ static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, Mo
       for (int u = 0; u < NS; ++u)
         if (jb + u < je) { const double t = tinv[u]; r0 += rv[0][u] * t; r1 += rv[1][u] * t; r2 += rv[2][u] * t; r3 += rv[3][u] * t; }
       double U, gg[3];
-      jas_pre<PBC>(S, J, e, npx, npy, npz, a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcA0, bcA1, acA, U, gg);
+      jas_pre<PBC, NP, NA>(S, J, e, npx, npy, npz, a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcA0, bcA1, acA, U, gg);
 #if PQA_PRE_DBG & 1
       double p[PR];
       lw_move_sums<PBC, false>(S, L, e, a.has_jastrow, npx, npy, npz, lw_row(L, s, i, cur ^ 1, w, W, nmo), W, w, g, G, p);
@@ -947,11 +953,22 @@ static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, Mo
     }
     __syncthreads();
     double v[PR];
+    if (GW > 16) {
+      if (g < PR) {
+        double tsum = 0.0;
+        for (int gg = 0; gg < G; ++gg) tsum += shP[(g * G + gg) * NW + lane];
+        shTot[g * NW + lane] = tsum;
+      }
+      __syncthreads();
 #pragma unroll
-    for (int c = 0; c < PR; ++c) v[c] = 0.0;
-    for (int gg = 0; gg < G; ++gg) {
+      for (int c = 0; c < PR; ++c) v[c] = shTot[c * NW + lane];
+    } else {
 #pragma unroll
-      for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+      for (int c = 0; c < PR; ++c) v[c] = 0.0;
+      for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+        for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+      }
     }
     // ---- Metropolis decision (mc.py:124-132; dmc.py:57-70), every group the same numbers: k_step_lw's lines
     double gx, gy, gz, dr, di;
@@ -1083,7 +1100,7 @@ static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, Mo
       for (int u = 0; u < NS; ++u)
         if (jb2 + u < je2) { const double t = tinv2[u]; r0 += rv2[0][u] * t; r1 += rv2[1][u] * t; r2 += rv2[2][u] * t; r3 += rv2[3][u] * t; }
       double U, gg[3];
-      jas_pre<PBC>(S, J, e, xe2[0], xe2[1], xe2[2], a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcP0, bcP1, acP, U, gg);
+      jas_pre<PBC, NP, NA>(S, J, e, xe2[0], xe2[1], xe2[2], a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcP0, bcP1, acP, U, gg);
 #if PQA_PRE_DBG & 32
       {
         double U2, g2[3], lp_, ee_, ei_;
@@ -1106,20 +1123,26 @@ static __global__ __launch_bounds__(256) void k_step_pre(SysDev S, LwState L, Mo
       for (int c = 0; c < PR; ++c) shP[(c * G + g) * NW + lane] = p[c];
     }
     __syncthreads();
-    if (!lead) return;
-#if PQA_PRE_DBG & 32
-    if (mb.accept_rec) {
-      int code = 0;
-      for (int gg = 0; gg < G; ++gg) { const int c = (int)shV[gg * NW + lane]; if (c && !code) code = c; }
-      mb.accept_rec[(size_t)e * W + w] = (uint8_t)code;
+    if (GW > 16) {
+      if (g < PR) {
+        double tsum = 0.0;
+        for (int gg = 0; gg < G; ++gg) tsum += shP[(g * G + gg) * NW + lane];
+        shTot[g * NW + lane] = tsum;
+      }
+      __syncthreads();
     }
-#endif
+    if (!lead) return;
     double v[PR];
+    if (GW > 16) {
 #pragma unroll
-    for (int c = 0; c < PR; ++c) v[c] = 0.0;
-    for (int gg = 0; gg < G; ++gg) {
+      for (int c = 0; c < PR; ++c) v[c] = shTot[c * NW + lane];
+    } else {
 #pragma unroll
-      for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+      for (int c = 0; c < PR; ++c) v[c] = 0.0;
+      for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+        for (int c = 0; c < PR; ++c) v[c] += shP[(c * G + gg) * NW + lane];
+      }
     }
     double gx, gy, gz, dr, di;
     lw_slater_terms<false, PR>(v, gx, gy, gz, dr, di);

@@ -151,6 +151,7 @@ static int pipe_streams(pqa_handle* h) {
   return 0;
 }
 
+static bool N_ok(const pqa_handle* h) { return h->N <= 64 && h->natom <= 64 && std::max(h->nup, h->ndn) <= 64; }
 static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCtx& lc) {
   const long W = h->W;
   MoveBuf mb = mb_in;
@@ -169,9 +170,16 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
   const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
   // thread groups per walker (lc.Gm: ~4 waves per SIMD's worth of threads) and walkers per block: 256 threads at most, so more
   // than 4 groups narrow the block to 32 or 16 walkers — which is also what spreads a small shard over the chip
-  const int G = std::min(lc.Gm, 16);
+  int G = std::min(lc.Gm, 16);
   int NW = (G <= 4) ? 64 : 256 / G;
   if (h->lw_nw > 0 && h->lw_nw * G <= 256) NW = h->lw_nw;
+  // small shards (one 16-walker block per CU at most): 32 thread groups per walker — k_step_pre<.., 32>, 512 threads, two Jastrow
+  // partners per thread: (H2O)8 step 3.93 -> 3.40 ms at 4096 walkers, 3.38 -> 2.88 at 1024; 64 groups (one partner per thread, 1024
+  // threads) spill at the 128-register limit: 4.47 / 3.53 ms.  PQA_STEP_GW = 16 / 32 / 64 pins it.
+  {
+    const int gw = h->step_gw ? h->step_gw : 32;
+    if ((gw == 32 || gw == 64) && W <= 4096 && N_ok(h) && step_pre_system_ok(h, rowlen) && KB <= gw) { G = gw; NW = 16; }
+  }
 
   HalfPipe P;
   P.main = h->stream;

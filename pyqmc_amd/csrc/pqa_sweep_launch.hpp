@@ -6,14 +6,26 @@
 // Lane-per-walker sweep, two launches per move: k_orb at the proposal, then k_step_lw = decide electron e + propose electron
 // e + 1 (pqa_lw.hpp).  The two halves are launched apart where the blocked Sherman-Morrison update has to flush in between
 // (e + 1 opens a new electron block of the same spin: its inverse row is only current after k_flush_lw).
+// what k_step_pre's scope asks of the system whatever its group count (pqa_lw.hpp)
+static inline bool step_pre_system_ok(const pqa_handle* h, int rowlen) {
+  return !h->cplx && h->step_pre && h->S.occ_ident[0] && h->S.occ_ident[1] && h->S.nb <= PQA_JAS_NF && h->S.na <= PQA_JAS_NF && rowlen <= 64;
+}
 template <bool PBC, bool CX>
 static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen) {
   const dim3 grid((unsigned)((a.w1 - a.w0 + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
   // small shards: the variant with every load issued at entry (k_step_pre, pqa_lw.hpp) where its scope covers the system
   // (one block per CU at most: the kernel holds ~360 registers per lane, one wave per SIMD)
-  if (!CX && h->step_pre && a.NW < 64 && a.G >= 8 && grid.x <= 256 && h->S.occ_ident[0] && h->S.occ_ident[1] && h->S.nb <= PQA_JAS_NF && h->S.na <= PQA_JAS_NF &&
-      h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G) && rowlen <= 64) {
-#define PQA_STEP_P(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM) * a.NW * sizeof(double); \
+  const bool pre_ok = !CX && step_pre_system_ok(h, rowlen) && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G);
+  if (pre_ok && a.NW == 16 && (a.G == 32 || a.G == 64) && grid.x <= 256 && h->N <= 64 && h->S.natom <= 64) {  // 512 / 1024 threads per 16 walkers
+#define PQA_STEP_W(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM + 8) * a.NW * sizeof(double); \
+      if (a.G == 64) hipLaunchKernelGGL((k_step_pre<PBC, NM, 64>), grid, block, lds_p, h->stream, h->S, L, mb, a); \
+      else hipLaunchKernelGGL((k_step_pre<PBC, NM, 32>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
+    if (rowlen <= 8) PQA_STEP_W(8); else if (rowlen <= 16) PQA_STEP_W(16); else if (rowlen <= 32) PQA_STEP_W(32); else PQA_STEP_W(64);
+#undef PQA_STEP_W
+    return;
+  }
+  if (pre_ok && a.NW < 64 && a.G >= 8 && a.G <= 16 && grid.x <= 256 && h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G) {
+#define PQA_STEP_P(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM + 8) * a.NW * sizeof(double); \
       hipLaunchKernelGGL((k_step_pre<PBC, NM>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
     if (rowlen <= 8) PQA_STEP_P(8); else if (rowlen <= 16) PQA_STEP_P(16); else if (rowlen <= 32) PQA_STEP_P(32); else PQA_STEP_P(64);
 #undef PQA_STEP_P
