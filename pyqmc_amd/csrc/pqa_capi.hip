@@ -309,6 +309,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* ea = getenv("PQA_ECP_ACC_WAVES")) h->ecp_acc_waves = atoi(ea);
   if (const char* sp = getenv("PQA_STEP_PRE")) h->step_pre = atoi(sp);
   if (const char* sp = getenv("PQA_STEP_GW")) h->step_gw = atoi(sp);
+  if (const char* sp = getenv("PQA_STEP_PRE_MAX")) h->step_pre_max = atol(sp);
   if (const char* dm = getenv("PQA_DRAWS_MAX")) h->draws_max = atol(dm);
   if (const char* fw = getenv("PQA_FLUSH_WB8_MAX")) h->flush_wb8_max = atol(fw);
   if (const char* sp = getenv("PQA_SPLIT")) h->split_mode = std::max(0, std::min(3, atoi(sp)));

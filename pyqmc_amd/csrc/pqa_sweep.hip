@@ -178,7 +178,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
   // threads) spill at the 128-register limit: 4.47 / 3.53 ms.  PQA_STEP_GW = 16 / 32 / 64 pins it.
   {
     const int gw = h->step_gw ? h->step_gw : 32;
-    if ((gw == 32 || gw == 64) && W <= 4096 && N_ok(h) && step_pre_system_ok(h, rowlen) && KB <= gw) { G = gw; NW = 16; }
+    if ((gw == 32 || gw == 64) && W <= h->step_pre_max && N_ok(h) && step_pre_system_ok(h, rowlen) && KB <= gw) { G = gw; NW = 16; }
   }
 
   HalfPipe P;
@@ -196,7 +196,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
     HIPCHK(hipStreamWaitEvent(P.s[1], fork, 0));
   }
   // Jastrow sums ahead of the orbitals (k_jas_pre): on for the k_step_lw launches of large shards with a Jastrow factor
-  const bool jpre = h->has_jastrow && (h->jpre < 0 ? W >= h->jpre_min : h->jpre != 0) && !(NW < 64 && h->step_pre && W <= 4096);
+  const bool jpre = h->has_jastrow && (h->jpre < 0 ? W >= h->jpre_min : h->jpre != 0) && !(NW < 64 && h->step_pre && W <= h->step_pre_max);
   double* jbuf = nullptr;
   hipEvent_t jas_done[2] = {nullptr, nullptr}, steps_done[2] = {nullptr, nullptr};
   if (jpre) {

@@ -16,7 +16,7 @@ static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, c
   // small shards: the variant with every load issued at entry (k_step_pre, pqa_lw.hpp) where its scope covers the system
   // (one block per CU at most: the kernel holds ~360 registers per lane, one wave per SIMD)
   const bool pre_ok = !CX && step_pre_system_ok(h, rowlen) && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G);
-  if (pre_ok && a.NW == 16 && (a.G == 32 || a.G == 64) && grid.x <= 256 && h->N <= 64 && h->S.natom <= 64) {  // 512 / 1024 threads per 16 walkers
+  if (pre_ok && a.NW == 16 && (a.G == 32 || a.G == 64) && a.W <= h->step_pre_max && h->N <= 64 && h->S.natom <= 64) {  // 512 / 1024 threads per 16 walkers
 #define PQA_STEP_W(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM + 8) * a.NW * sizeof(double); \
       if (a.G == 64) hipLaunchKernelGGL((k_step_pre<PBC, NM, 64>), grid, block, lds_p, h->stream, h->S, L, mb, a); \
       else hipLaunchKernelGGL((k_step_pre<PBC, NM, 32>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
@@ -24,7 +24,7 @@ static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, c
 #undef PQA_STEP_W
     return;
   }
-  if (pre_ok && a.NW < 64 && a.G >= 8 && a.G <= 16 && grid.x <= 256 && h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G) {
+  if (pre_ok && a.NW < 64 && a.G >= 8 && a.G <= 16 && a.W <= h->step_pre_max && h->N <= PQA_PRE_NP * a.G && h->S.natom <= PQA_PRE_NA * a.G) {
 #define PQA_STEP_P(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM + 8) * a.NW * sizeof(double); \
       hipLaunchKernelGGL((k_step_pre<PBC, NM>), grid, block, lds_p, h->stream, h->S, L, mb, a); } while (0)
     if (rowlen <= 8) PQA_STEP_P(8); else if (rowlen <= 16) PQA_STEP_P(16); else if (rowlen <= 32) PQA_STEP_P(32); else PQA_STEP_P(64);
