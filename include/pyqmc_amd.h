@@ -37,7 +37,7 @@ typedef struct {
      normalised (gto.py:375-405) */
   int32_t nshell, nprim, nao;
   const int32_t* shell_atom;     /* nshell */
-  const int32_t* shell_l;        /* nshell, l <= 3 */
+  const int32_t* shell_l;        /* nshell, l <= 5 (twisted cells: l <= 3) */
   const int32_t* shell_prim_off; /* nshell+1 */
   const int32_t* shell_ao_off;   /* nshell */
   const double* prim_exp;        /* nprim */

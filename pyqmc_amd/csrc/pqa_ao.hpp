@@ -270,7 +270,7 @@ __device__ __forceinline__ void pbc_ctx_update(const SysDev& S, PbcCtx& c, int i
 // ls(j, lx, ly, lz, ph): lattice vector (and, twisted, the (cos, sin) phase) of image j — from the kernel's LDS copy where it has one:
 // the image walk alone (list decode, a per-lane gather of the vector, r^2, the range test) was a third of k_orb<5> and two thirds
 // of k_orb<1> in a periodic cell with the vectors gathered from global memory (compile-time ablation, tools/scratch/abl_pbc.sh).
-template <int NCOMP, bool TW = false, class Sink, class SinkIm, class LsGet>
+template <int NCOMP, bool TW = false, int LMAX = 3, class Sink, class SinkIm, class LsGet>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
                                                const double* __restrict__ pcoef, int np, Sink&& sink, SinkIm&& sink_im, bool& accumulate,
                                                LsGet&& ls) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   accumulate = false;
 #ifndef PQA_ABL_NOZERO
 #pragma unroll
-  for (int m = 0; m < 7; ++m)
+  for (int m = 0; m < 2 * LMAX + 1; ++m)
     if (m < 2 * l + 1) {
       sink(m, 0.0, 0.0, 0.0, 0.0, 0.0);
       if (TW) sink_im(m, 0.0, 0.0, 0.0, 0.0, 0.0);
@@ -295,7 +295,7 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
       pr = c.cf * cj - c.sf * sj;
       pi = c.sf * cj + c.cf * sj;
     }
-    shell_eval<NCOMP, 3, true>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
+    shell_eval<NCOMP, LMAX, true>(l, xj, yj, zj, pexp, pcoef, np, [&](int m, double v, double gx, double gy, double gz, double lp) {
       if (TW) {
         sink_im(m, pi * v, pi * gx, pi * gy, pi * gz, pi * lp);
         v *= pr; gx *= pr; gy *= pr; gz *= pr; lp *= pr;
@@ -346,10 +346,10 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
   }
   accumulate = false;
 }
-template <int NCOMP, class Sink>
+template <int NCOMP, int LMAX = 3, class Sink>
 __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c, int sh, int l, const double* __restrict__ pexp,
                                                const double* __restrict__ pcoef, int np, Sink&& sink, bool& accumulate) {
-  shell_eval_pbc<NCOMP, false>(S, c, sh, l, pexp, pcoef, np, sink, sink, accumulate,
+  shell_eval_pbc<NCOMP, false, LMAX>(S, c, sh, l, pexp, pcoef, np, sink, sink, accumulate,
                                [&](int j, double& lx, double& ly, double& lz, double&, double&) { lx = S.pb->Ls[3 * j]; ly = S.pb->Ls[3 * j + 1]; lz = S.pb->Ls[3 * j + 2]; });
 }
 
@@ -549,11 +549,13 @@ static __global__ void k_row_phase(double* __restrict__ out, long P, int ncomp, 
 
 // ---------------------------------------------------------------- AO only (test / A-B entry)
 // out (NCOMP, P, nao); one thread per point.
-template <int NCOMP>
-static __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, double* __restrict__ out) {
+// PLMAX: largest l of the lattice-summed shells (3: the instantiation every periodic handle without g / h shells uses)
+template <int NCOMP, int PLMAX = 3>
+static __global__ void k_ao(SysDev S, PointAddr pa, long P, double* __restrict__ out) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  double px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+  double px, py, pz;
+  load_point(pa, p, px, py, pz);
   if (S.nL > 0) fold_cell(S, px, py, pz);  // periodic orbitals are tabulated for points inside the cell
   PbcCtx ctx;
   const PrimWrap pw = S.nL > 0 ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};  // S.pb is null for open systems
@@ -576,7 +578,7 @@ static __global__ void k_ao(SysDev S, const double* __restrict__ pts, long P, do
     };
     if (S.nL > 0) {
       pbc_ctx_update(S, ctx, ia, x, y, z, pw);
-      shell_eval_pbc<NCOMP>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store, accum);
+      shell_eval_pbc<NCOMP, PLMAX>(S, ctx, sh, S.shell_l[sh], S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store, accum);
     } else
       shell_eval<NCOMP>(S.shell_l[sh], x, y, z, S.prim_exp + p0, S.prim_coef + p0, S.shell_prim_off[sh + 1] - p0, store);
   }
@@ -616,6 +618,22 @@ static __global__ void k_ao_tw(SysDev S, const double* __restrict__ pts, long P,
       oim[ao0 + m] = re * wsn + im * wcs;
     }
   }
+}
+
+// Contraction of AO planes [ncomp][P][nao] (k_ao) with C [nao][nmo] into the orbital kernels' row layout out[p][ncomp][nmo]
+// (two-slot output like ChunkTab::out_sel when sel != nullptr).  The general path of periodic cells with g / h shells — the MFMA
+// kernels' lattice-sum phase is built for l <= 3 (registers); correctness first, one thread per output value.
+template <int PQA_UNIT = 0>
+static __global__ void k_mo_rows(const double* __restrict__ ao, const double* __restrict__ C, long P, int ncomp, int nao, int nmo,
+                                 double* __restrict__ out, const unsigned char* __restrict__ sel, long slot_stride) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * ncomp * nmo) return;
+  const long p = idx / ((long)ncomp * nmo);
+  const int c = (int)((idx / nmo) % ncomp), j = (int)(idx % nmo);
+  const double* a = ao + ((size_t)c * P + p) * nao;
+  double s = 0.0;
+  for (int k = 0; k < nao; ++k) s += a[k] * C[(size_t)k * nmo + j];
+  out[(sel ? (size_t)(sel[p] ^ 1) * slot_stride : (size_t)0) + ((size_t)p * ncomp + c) * nmo + j] = s;
 }
 
 // plain contraction out[c][p][j] = sum_a ao[c][p][a] C[a][j]  (A/B check of the MFMA kernel only)

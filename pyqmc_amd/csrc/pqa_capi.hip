@@ -378,7 +378,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     S.nshell = sys->nshell; S.nprim = sys->nprim; S.nao = sys->nao;
     for (int s = 0; s < sys->nshell; ++s) {
       if (sys->shell_l[s] < 0 || sys->shell_l[s] > 5) FAIL("shells up to h (l <= 5, as numba/gto.py:107-118) are implemented");
-      if (sys->nL > 0 && sys->shell_l[s] > 3) FAIL("periodic orbitals: shells up to f (l <= 3); g and h shells are implemented for open systems only");
+      if (sys->nL > 0 && sys->shell_l[s] > 3) {
+        if (h->twist) FAIL("twisted cells: shells up to f (l <= 3); g and h shells are implemented for open systems and untwisted cells");
+        h->pbc_high_l = true;  // the general (thread-per-point) orbital path, pqa_orb_pbc.hip
+      }
       h->shell_l.push_back(sys->shell_l[s]);
       h->shell_np.push_back(sys->shell_prim_off[s + 1] - sys->shell_prim_off[s]);
       h->shell_ao.push_back(sys->shell_ao_off[s]);
@@ -746,9 +749,7 @@ extern "C" int pqa_eval_ao(pqa_handle_t* h, const double* pts, int64_t npts, int
   TRY(ensure(h, h->b_ao, nout * sizeof(double)));
   TRY(copy_in(h, h->b_pts.p, pts, (size_t)npts * 3 * sizeof(double)));
   const dim3 grid((unsigned)((npts + 63) / 64)), block(64);
-  if (ncomp == 1) hipLaunchKernelGGL(k_ao<1>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
-  else if (ncomp == 4) hipLaunchKernelGGL(k_ao<4>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
-  else hipLaunchKernelGGL(k_ao<5>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  TRY(launch_ao(h, plain_points((const double*)h->b_pts.p, npts), npts, ncomp, (double*)h->b_ao.p));
   TRY(check_launch(h, "k_ao"));
   return copy_out(h, out, h->b_ao.p, nout * sizeof(double));
 }
@@ -780,8 +781,7 @@ extern "C" int pqa_eval_mo(pqa_handle_t* h, int spin, const double* pts, int64_t
   const size_t nao_out = (size_t)ncomp * npts * h->nao;
   TRY(ensure(h, h->b_ao, nao_out * sizeof(double)));
   const dim3 grid((unsigned)((npts + 63) / 64)), block(64);
-  if (ncomp == 1) hipLaunchKernelGGL(k_ao<1>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
-  else hipLaunchKernelGGL(k_ao<5>, grid, block, 0, h->stream, h->S, (const double*)h->b_pts.p, (long)npts, (double*)h->b_ao.p);
+  TRY(launch_ao(h, plain_points((const double*)h->b_pts.p, npts), npts, ncomp, (double*)h->b_ao.p));
   const long rows = (long)ncomp * npts;
   hipLaunchKernelGGL((k_mo_valu<>), dim3((unsigned)((rows * nmo + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p,
                      (const double*)h->d_mo[spin], rows, h->nao, nmo, (double*)h->b_out.p);
@@ -1002,7 +1002,7 @@ extern "C" int pqa_slater_pgradient(pqa_handle_t* h, double* d_det, double* d_mo
   TRY(ensure(h, h->b_ao, nao_all * sizeof(double)));
   const dim3 ga((unsigned)((W * h->N + 63) / 64));
   if (h->twist) hipLaunchKernelGGL((k_ao_tw<>), ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
-  else hipLaunchKernelGGL(k_ao<1>, ga, dim3(64), 0, h->stream, h->S, (const double*)h->js.x, W * h->N, (double*)h->b_ao.p);
+  else TRY(launch_ao(h, plain_points((const double*)h->js.x, W * h->N), W * h->N, 1, (double*)h->b_ao.p));
   TRY(check_launch(h, "k_ao"));
   for (int s = 0; s < 2; ++s) {
     const int n = s ? h->ndn : h->nup;

@@ -53,6 +53,7 @@ struct pqa_handle {
   bool aos_stale = false;  // the lane-per-walker planes hold the live state; the walker-major arrays are converted back on demand (sync_aos)
   int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
+  bool pbc_high_l = false;  // a periodic cell with g / h shells: orbitals through k_ao<.., 5> + k_mo_rows (pqa_orb_pbc.hip)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
   bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
   bool has_slater = false, has_jastrow = false;  // has_jastrow: any Jastrow factor (two- and/or three-body)
@@ -263,6 +264,9 @@ struct LwCtx {
 // pqa_orb.hip: out[p][ncomp][nmo_spin]; out_sel / slot_stride: two-slot output (ChunkTab::out_sel), else plain rows
 int launch_orb(pqa_handle* h, int spin, PointAddr pa, long P, int ncomp, double* out, const unsigned char* out_sel = nullptr, long slot_stride = 0);
 PointAddr plain_points(const double* base, long P);
+// pqa_orb_pbc.hip: AO planes out[ncomp][P][nao] at arbitrary points, thread per point (test entry, parameter gradients, the general
+// periodic path); ncomp 1, 4 or 5
+int launch_ao(pqa_handle* h, PointAddr pa, long P, int ncomp, double* out);
 // pqa_sweep.hip
 void transpose(pqa_handle* h, const double* in, double* out, long R, long C);  // in [R][C] -> out [C][R]
 LwState lw_state(pqa_handle* h);

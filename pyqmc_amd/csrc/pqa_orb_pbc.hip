@@ -89,7 +89,35 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   }
   return 0;
 }
+int launch_ao(pqa_handle* h, PointAddr pa, long P, int ncomp, double* out) {
+  const dim3 grid((unsigned)((P + 63) / 64)), block(64);
+#define PQA_AO(NC) do { if (h->pbc_high_l) hipLaunchKernelGGL((k_ao<NC, 5>), grid, block, 0, h->stream, h->S, pa, P, out); \
+                        else hipLaunchKernelGGL((k_ao<NC, 3>), grid, block, 0, h->stream, h->S, pa, P, out); } while (0)
+  if (ncomp == 1) PQA_AO(1); else if (ncomp == 4) PQA_AO(4); else if (ncomp == 5) PQA_AO(5); else FAIL("AO evaluation: ncomp must be 1, 4 or 5");
+#undef PQA_AO
+  return check_launch(h, "k_ao");
+}
+// periodic cells with g / h shells: AO planes by the thread-per-point evaluator (direct image tests, the reference's cut-offs and
+// membership rule like every other path), contracted by k_mo_rows into the row layout the callers expect
+static int launch_orb_pbc_general(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
+  const long chunk = std::max<long>(1, ((long)1 << 28) / ((long)ncomp * h->nao));  // <= 2 GiB of AO planes per pass
+  if (pa.group_stride != 0 && P > chunk) FAIL("general periodic orbital path: grouped point lists longer than one pass are not supported");
+  for (long p0 = 0; p0 < P; p0 += chunk) {
+    const long n = std::min(chunk, P - p0);
+    TRY(ensure(h, h->b_ao, (size_t)n * ncomp * h->nao * sizeof(double)));
+    PointAddr pp = pa;
+    if (p0) pp.base = pa.base + 3 * p0;  // (plain lists: group = P, stride 0)
+    if (p0) pp.group = (int)n;
+    TRY(launch_ao(h, pp, n, ncomp, (double*)h->b_ao.p));
+    const long tot = n * ncomp * h->nmo[spin];
+    hipLaunchKernelGGL((k_mo_rows<>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p, (const double*)h->d_mo[spin], n,
+                       ncomp, h->nao, h->nmo[spin], out + (size_t)p0 * ncomp * h->nmo[spin], h->out_sel ? h->out_sel + p0 : nullptr, h->out_slot_stride);
+    TRY(check_launch(h, "k_mo_rows"));
+  }
+  return 0;
+}
 int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
+  if (h->pbc_high_l) return launch_orb_pbc_general(h, ncomp, spin, pa, P, out);
   if (ncomp == 5) return (h->orb_kc5 == 32) ? launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out) : launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
   if (ncomp == 1) return launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
   FAIL("orbital kernel supports ncomp 1 or 5");

@@ -204,6 +204,15 @@ def diamond_primitive():
     return Cell(["C", "C"], [(0, 0, 0), (a / 4, a / 4, a / 4)], lat)
 
 
+def diamond_primitive_high_l():
+    """The diamond primitive cell with a g and an h shell added to the carbon table: lattice-summed shells beyond f — the range
+    of the reference's periodic evaluator (numba/pbcgto.py:52-96 wraps SPH0..SPH5)."""
+    a = _DIAMOND_A
+    lat = 0.5 * a * np.array([[0., 1., 1.], [1., 0., 1.], [1., 1., 0.]])
+    extra = [[4, [1.9, 0.6], [0.8, 0.5]], [5, [1.2, 1.0]]]
+    return Cell(["C", "C"], [(0, 0, 0), (a / 4, a / 4, a / 4)], lat, basis={"C": _C_BASIS + extra})
+
+
 def random_mf(mol, seed=20260928, nvirt=0, scale_virtual=1.0):
     """Seeded MO coefficients: first columns of qr(randn(nao,nao)); occupied = lowest n_s.
 

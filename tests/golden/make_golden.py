@@ -1303,6 +1303,43 @@ def g_complex_pgrad():
     save("g31_complex_pgrad", **out)
 
 
+# ------------------------------------------------------------------ G32 periodic g / h shells
+def g_pbc_high_l():
+    """Lattice-summed shells with l = 4, 5 (pbcgto.py:52-96: SPH4 / SPH5 wrappers): the diamond primitive cell with a g and an h
+    shell on carbon, as a Gamma cell and as the fcc -> cubic 4-fold supercell (4 k-points, real phases): AOs and MOs (value,
+    gradient, Laplacian) at points inside and outside the cell, and the Slater / Jastrow / product protocol with moves."""
+    import pyqmc.wftools as wftools
+    from pyqmc.configurations.coord import PeriodicConfigs
+    from pyqmc.wf.multiplywf import MultiplyWF
+    from pyqmc_amd import pbc as mypbc
+
+    prim = systems.diamond_primitive_high_l()
+    out = {}
+    for tag in ("gamma", "fcc2cubic"):
+        S, W, electrons = PBC_SLATER_CASES[tag]
+        sup = mypbc.get_supercell(prim, S)
+        mf = mypbc.random_kmf(sup)
+        Ls = mypbc.lattice_points_within(prim.lattice_vectors(), 30.0)
+        ev, oe, sl = ref_pbc_objects(sup, mf.kpts, mf.mo_coeff, Ls)
+        assert max(ev.max_l) == 5
+        rng = np.random.default_rng(321)
+        pts = PeriodicConfigs((rng.random((1, 10, 3)) * 3 - 1) @ sup.lattice_vectors(), sup.lattice_vectors())
+        out[f"{tag}_pts"], out[f"{tag}_pts_wrap"] = pts.configs.copy(), pts.wrap.copy()
+        for nm, es in (("val", "GTOval_sph"), ("grad", "GTOval_sph_deriv1"), ("lap", "GTOval_sph_deriv2")):
+            ao = oe.aos(es, pts)
+            out[f"{tag}_ao_{nm}"] = ao
+            out[f"{tag}_mo_{nm}"] = oe.mos(ao, 0)
+        j2, _ = wftools.generate_jastrow(sup)
+        jr = np.random.default_rng(17)
+        j2.parameters["acoeff"] = 0.05 * jr.standard_normal(j2.parameters["acoeff"].shape)
+        b = 0.05 * jr.standard_normal(j2.parameters["bcoeff"].shape)
+        b[0] = [-0.25, -0.5, -0.25]
+        j2.parameters["bcoeff"] = b
+        wf = MultiplyWF(sl, j2)
+        pbc_protocol(f"{tag}_", sup, {"slater": sl, "jastrow": j2, "wf": wf}, W, 51, electrons, out)
+    save("g32_pbc_high_l", **out)
+
+
 # ------------------------------------------------------------------ G27 on-disk layout (hdftools)
 class _FakeDataset:
     def __init__(self, shape, dtype):
@@ -1556,3 +1593,4 @@ if __name__ == "__main__":
     g_chk_mol()
     g_pbc_complex_dmc()
     g_complex_pgrad()
+    g_pbc_high_l()

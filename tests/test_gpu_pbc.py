@@ -895,3 +895,54 @@ def test_stochastic_reconfiguration_on_a_twisted_cell():
     for k, v in new.items():
         wf.parameters[k] = v
     assert np.all(np.isfinite(wf.recompute(cfg)[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_periodic_g_and_h_shells_match_reference(tag):
+    """Periodic cells with l = 4, 5 shells (the reference's pbcgto.py goes to SPH5): the MFMA orbital kernels' lattice-sum phase is
+    built for l <= 3, so such handles evaluate their orbitals on the general path — thread-per-point AOs with the same image
+    tests (k_ao<.., 5>), contracted by k_mo_rows.  AOs, MOs and the whole Slater-Jastrow protocol against the reference (g32),
+    then a fused VMC sweep + energy (ECP points and all go through the same path) against the oracle on the same tapes."""
+    import pyqmc_amd as pa
+    from helpers import PBC_SLATER_CASES, unfold_ao
+    from oracle import jastrow_basis, vmc as ovmc, wf as owf
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g32_pbc_high_l")
+    sup = pbc.get_supercell(systems.diamond_primitive_high_l(), PBC_SLATER_CASES[tag])
+    mf = pbc.random_kmf(sup)
+    wf = pa.generate_wf(sup, mf)
+    a, b = pbc_jastrow_coeffs(sup)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b
+    sl = wf.wf_factors[0]
+    pts = g[f"{tag}_pts"].reshape(-1, 3)
+    for nm, nc in (("val", 1), ("grad", 4), ("lap", 5)):
+        ao = sl._dev.eval_ao(pts, nc)
+        ref = g[f"{tag}_ao_{nm}"]
+        assert note(f"pbc_high_l_{tag}_ao_{nm}", helpers.relerr(unfold_ao(sup, mf.kpts, ao), ref.reshape((ref.shape[0], nc, -1, ref.shape[-1])))) < 1e-12
+    for nm, nc in (("val", 1), ("lap", 5)):
+        ref = g[f"{tag}_mo_{nm}"]
+        assert helpers.relerr(sl._dev.eval_mo(0, pts, nc), ref.reshape((nc, -1, ref.shape[-1]))) < 1e-12, nm
+    err = run_protocol_pbc({"slater": sl, "jastrow": wf.wf_factors[1], "wf": wf}, g, f"{tag}_", sup)
+    assert max(err.values()) < 2e-9, {k: v for k, v in err.items() if v > 1e-10}
+    # fused sweep + energy against the oracle, replayed tapes
+    W, N, necp = 6, int(sum(sup.nelec)), sup.natm
+    rng = np.random.default_rng(8)
+    start = pa.initial_guess(sup, W, rng=rng)
+    gauss, unif = rng.standard_normal((1, N, W, 3)), rng.random((1, N, W))
+    rot = np.broadcast_to(np.eye(3), (1, N, necp, 3, 3)).copy()
+    eunif = rng.random((1, N, necp, W))
+    blk, cfg = pa.vmc_worker(wf, PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()), 0.3, 1, {"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                             tapes=dict(gauss=gauss, unif=unif, ecp_rot=rot, ecp_unif=eunif))
+    Ls = pbc.lattice_points_within(sup.original_cell.lattice_vectors(), 30.0 + pbc.cell_diameter(sup.original_cell.lattice_vectors()))
+    osl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, Ls)
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    oja = owf.JastrowSpin(sup, ab, bb, rcut)
+    oja.parameters["acoeff"], oja.parameters["bcoeff"] = a, b
+    oblk, ocfg = ovmc.vmc_worker(sup, owf.MultiplyWF(osl, oja), PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()), 0.3, gauss, unif, rot, eunif,
+                                 ewald_kws={"ewald_gmax": 10})
+    assert abs(blk["acceptance"] - oblk["acceptance"]) < 1e-12
+    assert note(f"pbc_high_l_{tag}_sweep_dx", np.max(np.abs(cfg.configs - ocfg.configs))) < 1e-9
+    assert abs(blk["energytotal"] - oblk["energytotal"]) < 1e-8 * abs(oblk["energytotal"])

@@ -419,3 +419,31 @@ def test_compiled_periodic_ao_evaluator_equals_the_numpy_restatement(tag):
             assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 1e-12, ncomp
     finally:
         gto.set_ao_backend("numpy")
+
+
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_oracle_periodic_high_l_matches_reference(tag):
+    """g and h shells in a periodic cell (pbcgto.py:52-96: the SPH4 / SPH5 wrappers): the oracle's lattice-summed AOs / MOs and
+    the Slater-Jastrow protocol on the diamond cell with added l = 4, 5 shells against the reference (g32)."""
+    from helpers import PBC_SLATER_CASES
+    from oracle import jastrow_basis, pbc as opbc, wf as owf
+    from pyqmc_amd import pbc, systems
+
+    g = golden("g32_pbc_high_l")
+    sup = pbc.get_supercell(systems.diamond_primitive_high_l(), PBC_SLATER_CASES[tag])
+    mf = pbc.random_kmf(sup)
+    Ls = pbc.lattice_points_within(sup.original_cell.lattice_vectors(), 30.0)
+    orb = opbc.PeriodicOrbitals(sup, mf.kpts, mf.mo_coeff, Ls)
+    assert orb.aotab.table.max_l == 5
+    for nm, nc in (("val", 1), ("grad", 4), ("lap", 5)):
+        ao = orb.aos(g[f"{tag}_pts"].reshape(-1, 3), nc)
+        ref = g[f"{tag}_ao_{nm}"]
+        assert relerr(ao, ref.reshape((ref.shape[0], nc, -1, ref.shape[-1]))) < 1e-12, nm
+        assert relerr(orb.mos(ao, 0), g[f"{tag}_mo_{nm}"].reshape((nc, -1, g[f"{tag}_mo_{nm}"].shape[-1]))) < 1e-12
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, Ls)
+    rcut = float(np.amin(np.pi / np.linalg.norm(sup.reciprocal_vectors(), axis=1)))
+    ab, bb, rcut = jastrow_basis.default_basis(ion_cusp=False, rcut=rcut)
+    ja = owf.JastrowSpin(sup, ab, bb, rcut)
+    ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
+    err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": owf.MultiplyWF(sl, ja)}, g, f"{tag}_", sup)
+    assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
