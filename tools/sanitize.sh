@@ -3,7 +3,7 @@
 # with it.
 #   build only (no GPU needed):  bash tools/sanitize.sh build
 #   on the GPU box:              /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/sanitize.sh run'
-# What is instrumented: the host code of pqa_capi.hip (table packing, chunk building, buffer bookkeeping, argument checks)
+# What is instrumented: the host code of every translation unit (table packing, chunk building, buffer bookkeeping, argument checks)
 # with UndefinedBehaviorSanitizer (integer overflow, shifts, null/misaligned access, array bounds of fixed-size arrays) and
 # libstdc++'s container assertions (_GLIBCXX_ASSERTIONS: every std::vector index of build_chunks & co is bounds-checked).
 # Device code is left alone (-fno-gpu-sanitize).
@@ -16,10 +16,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 MODE=${MODE:-ubsan}
 OUT=$ROOT/pyqmc_amd/lib/libpyqmc_amd_$MODE.so
 CLANG=/opt/rocm/lib/llvm/bin/clang
-if [ "$MODE" = asan ]; then SAN="-fsanitize=address,undefined -shared-libsan"; else SAN="-fsanitize=undefined,bounds -fno-sanitize=vptr -fno-sanitize-recover=all -shared-libsan"; fi
 if [ "$1" = build ] || [ ! -f "$OUT" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -shared -fPIC $SAN -fno-gpu-sanitize -D_GLIBCXX_ASSERTIONS \
-      -fno-omit-frame-pointer "$ROOT/pyqmc_amd/csrc/pqa_capi.hip" -o "$OUT"
+  if [ "$MODE" != ubsan ]; then echo "only MODE=ubsan is built by __graft_entry__.py --sanitize (ASan: see the note above)"; exit 1; fi
+  (cd "$ROOT" && python __graft_entry__.py --sanitize)
   echo "[sanitize] built $OUT"
 fi
 [ "$1" = build ] && exit 0
