@@ -147,13 +147,19 @@ class Slater(_ManyMixin):
         for s, name in ((0, "mo_coeff_alpha"), (1, "mo_coeff_beta")):
             b, e = self._nelec[0] * s, self._nelec[0] + self._nelec[1] * s
             ao, _ = self._mo(self._x_last[:, b:e].reshape(-1, 3), s, 1)
-            ao = ao[0].reshape(W, e - b, -1)  # (W, n, nao)
-            nmo = self.parameters[name].shape[1]
-            g = np.zeros((W, ao.shape[-1], nmo))
+            if getattr(self, "_orb", None) is not None:  # periodic: per-k AO blocks (nk, 1, P, nao_prim) and per-k columns (orbitals.py:239-254)
+                aos = [ao[k][0].reshape(W, e - b, -1) for k in range(len(self._orb.kpts))]
+                split = np.cumsum([0] + [m.shape[1] for m in self._orb.mo[s]])
+            else:
+                aos = [ao[0].reshape(W, e - b, -1)]  # (W, n, nao)
+                split = np.array([0, self.parameters[name].shape[1]])
+            nmo = int(split[-1])
+            g = np.zeros((W, aos[0].shape[-1], nmo), dtype=np.result_type(ddet.dtype, aos[0].dtype, self._inverse[s].dtype))
             for di, coeff in enumerate(self.parameters["det_coeff"]):
                 u = self._det_map[s][di]
                 for col, m in enumerate(self._det_occup[s][u]):  # _testcol: sum_e ao[w,e,a] inverse[w,u,col,e]
-                    g[:, :, m] += coeff * ddet[:, di, None] * np.einsum("wea,we->wa", ao, self._inverse[s][:, u, col, :])
+                    k = int(np.searchsorted(split, m, side="right") - 1)
+                    g[:, :, m] += coeff * ddet[:, di, None] * np.einsum("wea,we->wa", aos[k], self._inverse[s][:, u, col, :])
             if g.size:
                 out[name] = g
         return out

@@ -166,14 +166,25 @@ def load_scf(path, backend=None):
                 return [mo, mo], [(occ > 0).astype(float), (occ > 1).astype(float)]
             return [mo[0], mo[1]], [occ[0], occ[1]]
 
+        periodic = hasattr(mol, "a") or hasattr(mol, "lattice_vectors")
         if "scf/mo_coeff" in f:
             mo, occ = uhf(arr("scf/mo_coeff"), arr("scf/mo_occ"))
-            mf = MeanField(np.stack(mo), np.stack(occ))
+            if periodic:  # a single-k-point SCF of a cell (pbc.scf.RHF / UHF with kpt): a one-entry k-point list
+                kpt = arr("scf/kpt") if "scf/kpt" in f else np.zeros(3)
+                mf = KMeanField(np.asarray(kpt, dtype=float).reshape(1, 3), [[mo[0]], [mo[1]]], [[occ[0]], [occ[1]]])
+            else:
+                mf = MeanField(np.stack(mo), np.stack(occ))
         else:
             names = keys("scf/mo_coeff__from_list__")
-            per_k = [uhf(arr(f"scf/mo_coeff__from_list__/{k}"), arr(f"scf/mo_occ__from_list__/{k}")) for k in names]
-            mf = KMeanField(arr("scf/kpts"), [[pk[0][s] for pk in per_k] for s in (0, 1)], [[pk[1][s] for pk in per_k] for s in (0, 1)])
-            mf.mo_energy = [arr(f"scf/mo_energy__from_list__/{k}") for k in names] if "scf/mo_energy__from_list__" in f else None
+            if names and names[0].endswith("__from_list__"):  # unrestricted k-point SCF: [spin][k] nested lists
+                ks = keys(f"scf/mo_coeff__from_list__/{names[0]}")
+                get = lambda what: [[arr(f"scf/{what}__from_list__/{sp}/{k}") for k in ks] for sp in names[:2]]
+                mf = KMeanField(arr("scf/kpts"), get("mo_coeff"), get("mo_occ"))
+                mf.mo_energy = get("mo_energy") if "scf/mo_energy__from_list__" in f else None
+            else:
+                per_k = [uhf(arr(f"scf/mo_coeff__from_list__/{k}"), arr(f"scf/mo_occ__from_list__/{k}")) for k in names]
+                mf = KMeanField(arr("scf/kpts"), [[pk[0][s] for pk in per_k] for s in (0, 1)], [[pk[1][s] for pk in per_k] for s in (0, 1)])
+                mf.mo_energy = [arr(f"scf/mo_energy__from_list__/{k}") for k in names] if "scf/mo_energy__from_list__" in f else None
         mf.e_tot = float(arr("scf/e_tot")) if "scf/e_tot" in f else None
     finally:
         close()

@@ -135,3 +135,25 @@ def test_chkfile_reader_handles_labelled_atoms_kappa_and_stale_json():
     assert chkfile._scan_json(raw + b"\0" + raw) == d
     with pytest.raises(ValueError, match="different mol JSON"):
         chkfile._scan_json(other + b"\0" * 8 + raw)
+
+
+@pytest.mark.parametrize("name,nelec,nao", [("h_pbc_casscf", (1, 1), 10), ("h_noncubic_sto3g_triplet", (2, 0), 2)])
+def test_load_scf_single_k_and_unrestricted_layouts(name, nelec, nao):
+    """The reference's two other checkpoint fixtures: a single-k-point restricted SCF of a cell (``scf/kpt`` + plain ``mo_coeff``)
+    and an unrestricted k-point SCF (``mo_coeff__from_list__/00000S__from_list__/00000K``, here a spin triplet with NO down
+    electron) — both come back as one-k-point ``KMeanField``s whose orbitals are orthonormal in the oracle's AO metric."""
+    from oracle import pbc as opbc
+    from pyqmc_amd import pbc
+
+    cell, mf = chkfile.load_scf(os.path.join(FILES, name + ".hdf5"), backend="lite")
+    assert type(mf).__name__ == "KMeanField" and cell.nelec == nelec and mf.kpts.shape == (1, 3) and np.all(mf.kpts == 0.0)
+    assert [m[0].shape for m in mf.mo_coeff] == [(nao, nao)] * 2 and [int(o[0].sum()) for o in mf.mo_occ] == list(nelec)
+    lat = cell.lattice_vectors()
+    n = 40
+    g = (np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) / n
+    pt = opbc.PeriodicAOTable(cell, mf.kpts, pbc.lattice_points_within(lat, 40.0), precision=1e-8)
+    ao = opbc.eval_ao_pbc(pt, g @ lat, 1)[0, 0]
+    S = abs(np.linalg.det(lat)) / len(g) * ao.T @ ao
+    for s in (0, 1):
+        C = mf.mo_coeff[s][0]
+        assert np.abs(C.conj().T @ S @ C - np.eye(nao)).max() < 5e-6, s  # (quadrature of the 13.01-exponent s function limits this)

@@ -460,3 +460,35 @@ def test_device_path_on_an_ingested_pyscf_checkpoint():
     assert abs(ke.mean() - ke_int) < 5 * err + 2e-3, (ke.mean(), ke_int, err)
     g2 = np.real(df["energygrad2"])[4:] / 2  # <|grad log Psi|^2>/2 is the same integral (test_periodic.py:60-61)
     assert abs(g2.mean() - ke_int) < 5 * g2.std(ddof=1) / np.sqrt(len(g2)) + 2e-3
+
+
+@pytest.mark.parametrize("name", ["h_pbc_casscf", "h_noncubic_sto3g_triplet"])
+def test_device_on_the_small_reference_checkpoints(name):
+    """The reference's two hydrogen checkpoint fixtures through the device: a cubic H2 cell (one electron per spin) and a
+    non-cubic spin-triplet H2 cell with NO down electron (an empty spin channel on every kernel).  Wave-function values, one
+    fused sweep + energy and the walkers against the oracle on the same ingested tables and tapes."""
+    import os
+
+    import pyqmc_amd as pa
+    from oracle import vmc as ovmc
+    from pyqmc_amd import chkfile
+
+    cell, mf = chkfile.load_scf(os.path.join(helpers.ROOT, "tests", "golden", "files", name + ".hdf5"), backend="lite")
+    occ_mf = pbc.KMeanField(mf.kpts, [[mf.mo_coeff[s][0][:, mf.mo_occ[s][0] > 0.5]] for s in (0, 1)], [[np.ones(int(mf.mo_occ[s][0].sum()))] for s in (0, 1)])
+    sup = pbc.get_supercell(cell, np.eye(3))
+    wf = _gpu_pbc(sup, mf)
+    owf = _oracle_pbc(sup, occ_mf)
+    W, N = 32, int(sum(sup.nelec))
+    rng = np.random.default_rng(4)
+    start = pa.initial_guess(sup, W, rng=rng)
+    s_d, l_d = wf.recompute(PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()))
+    s_o, l_o = owf.recompute(PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()))
+    assert np.array_equal(np.real(s_d), np.real(s_o)) and note(f"chk_{name}_log", np.max(np.abs(l_d - l_o))) < 1e-10
+    gauss, unif = rng.standard_normal((2, N, W, 3)), rng.random((2, N, W))
+    blk, cfg = pa.vmc_worker(wf, PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()), 0.3, 2, {"energy": pa.EnergyAccumulator(sup, ewald_gmax=10)},
+                             tapes=dict(gauss=gauss, unif=unif))
+    oblk, ocfg = ovmc.vmc_worker(sup, owf, PeriodicConfigs(start.configs.copy(), sup.lattice_vectors()), 0.3, gauss, unif, ewald_kws={"ewald_gmax": 10})
+    assert abs(blk["acceptance"] - oblk["acceptance"]) < 1e-12
+    assert note(f"chk_{name}_dx", np.max(np.abs(cfg.configs - ocfg.configs))) < 1e-9 and np.array_equal(cfg.wrap, ocfg.wrap)
+    for k in ("energyke", "energyee", "energyei", "energytotal"):
+        assert abs(blk[k] - oblk[k]) < 1e-8 * (1.0 + abs(oblk[k])), k

@@ -447,3 +447,28 @@ def test_oracle_periodic_high_l_matches_reference(tag):
     ja.parameters["acoeff"], ja.parameters["bcoeff"] = pbc_jastrow_coeffs(sup)
     err = run_protocol_pbc({"slater": sl, "jastrow": ja, "wf": owf.MultiplyWF(sl, ja)}, g, f"{tag}_", sup)
     assert max(err.values()) < 5e-10, {k: v for k, v in err.items() if v > 1e-10}
+
+
+@pytest.mark.parametrize("fixture,tag", [("g24_pbc_pgrad", "gamma"), ("g24_pbc_pgrad", "fcc2cubic"), ("g31_complex_pgrad", "cplx"),
+                                         ("g31_complex_pgrad", "twist_prim"), ("g31_complex_pgrad", "twist_s211")])
+def test_oracle_periodic_pgradient_matches_reference(fixture, tag):
+    """Slater.pgradient of periodic determinants in the oracle (slater.py:462-542 with orbitals.py:239-254: per-k AO blocks and
+    parameter columns), real phases (g24) and complex ones incl. twisted cells with walkers outside the cell (g31)."""
+    from helpers import pbc_complex_case, pbc_slater_case, twist_case
+    from oracle import wf as owf
+    from pyqmc_amd import pbc
+
+    g = golden(fixture)
+    if fixture == "g24_pbc_pgrad":
+        sup, mf = pbc_slater_case(tag)
+        key = lambda k: f"{tag}_pgrad_wf1{k}"
+    else:
+        sup, mf = pbc_complex_case() if tag == "cplx" else twist_case(tag[6:])
+        key = lambda k: f"{tag}_slater_pgrad_{k}"
+    sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, pbc.lattice_points_within(sup.original_cell.lattice_vectors(), 30.0))
+    wrap = g[tag + "_wrap"] if (tag + "_wrap") in g.files else None
+    sl.recompute(pc.PeriodicConfigs(g[tag + "_configs"].copy(), sup.lattice_vectors(), wrap=None if wrap is None else wrap.copy()))
+    pg = sl.pgradient()
+    for k in ("det_coeff", "mo_coeff_alpha", "mo_coeff_beta"):
+        ref = g[key(k)]
+        assert pg[k].shape == ref.shape and relerr(pg[k], ref) < 1e-9, k
