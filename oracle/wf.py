@@ -113,7 +113,7 @@ class Slater(_ManyMixin):
         for s in (0, 1):
             b, e = self._nelec[0] * s, self._nelec[0] + self._nelec[1] * s
             _, mo = self._mo(x[:, b:e].reshape(-1, 3), s, 1)
-            mo = mo[0].reshape(nconf, e - b, -1)
+            mo = mo[0].reshape(nconf, e - b, mo.shape[-1])
             mats = np.stack([mo[:, :, occ] for occ in self._det_occup[s]], axis=1)  # (W,D,n,n) [elec,orb]
             sign, logdet = np.linalg.slogdet(mats)
             self._dets.append(np.array([sign, logdet]))

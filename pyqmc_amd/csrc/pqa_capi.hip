@@ -236,6 +236,7 @@ static int upload_cpad(pqa_handle* h, int t, int s, const double* mo_host) {
 }
 
 static int set_mo(pqa_handle* h, int s, const double* mo_host) {
+  if (h->nmo[s] == 0 || !mo_host) return 0;  // an empty spin channel (fully polarised systems): nothing to upload
   HIPCHK(hipMemcpy(h->d_mo[s], mo_host, (size_t)h->nao * std::max(h->nmo[s], 1) * sizeof(double), hipMemcpyHostToDevice));
   for (int t = 0; t < 2; ++t) TRY(upload_cpad(h, t, s, mo_host));
   return 0;
@@ -838,7 +839,15 @@ static int jas_refresh(pqa_handle* h) {
 static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants from js.x
   const int nel[2] = {h->nup, h->ndn};
   for (int s = 0; s < 2; ++s) {
-    if (nel[s] == 0) continue;
+    if (nel[s] == 0) {  // an empty spin channel (fully polarised system): the determinant of the 0 x 0 matrix is 1
+      const size_t nd = (size_t)h->W * std::max(h->ndet_s[s], 1);
+      std::vector<double> one((h->cplx ? 2 : 1) * nd, 0.0);
+      for (size_t k = 0; k < nd; ++k) one[(h->cplx ? 2 : 1) * k] = 1.0;
+      HIPCHK(hipStreamSynchronize(h->stream));
+      HIPCHK(hipMemcpy(h->st.dsign[s], one.data(), one.size() * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemset(h->st.dlog[s], 0, nd * sizeof(double)));
+      continue;
+    }
     PointAddr pa;
     pa.base = h->js.x + (size_t)(s ? h->nup : 0) * 3;
     pa.group = nel[s];

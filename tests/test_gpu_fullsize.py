@@ -476,7 +476,8 @@ def test_device_on_the_small_reference_checkpoints(name):
     cell, mf = chkfile.load_scf(os.path.join(helpers.ROOT, "tests", "golden", "files", name + ".hdf5"), backend="lite")
     occ_mf = pbc.KMeanField(mf.kpts, [[mf.mo_coeff[s][0][:, mf.mo_occ[s][0] > 0.5]] for s in (0, 1)], [[np.ones(int(mf.mo_occ[s][0].sum()))] for s in (0, 1)])
     sup = pbc.get_supercell(cell, np.eye(3))
-    wf = _gpu_pbc(sup, mf)
+    wf = pa.generate_wf(sup, mf, jastrow_kws={"ion_cusp": False})  # (all-electron hydrogen: the default would add the ion-cusp function)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = helpers.pbc_jastrow_coeffs(sup)
     owf = _oracle_pbc(sup, occ_mf)
     W, N = 32, int(sum(sup.nelec))
     rng = np.random.default_rng(4)
