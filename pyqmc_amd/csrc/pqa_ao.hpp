@@ -369,7 +369,11 @@ __device__ __forceinline__ void shell_eval_pbc(const SysDev& S, const PbcCtx& c,
 // recomputed n^2 distances — both 2.4 x slower than this.
 #define PQA_PRE_NWMAX 8   // list words the pre-pass can assemble in LDS (32 entries: PQA_PRE_CAP)
 #define PQA_PRE_MEMB 2048 // bytes of one atom class of the membership table staged in LDS (side^3; 729 for M = 4)
-template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
+template <int NCUT> struct PreFields { typedef unsigned long long type; };
+template <> struct PreFields<5> { typedef unsigned type; };
+// NCUT: distinct shell cut-offs per atom the instantiation handles (5: the usual basis sets; PQA_PRE_NCUT otherwise).
+// Dynamic LDS: 2 x (4 NW) x PQA_PRE_NT 16-bit entries (records in arrival order, entries in list order).
+template <int NCUT = PQA_PRE_NCUT, int PQA_UNIT = 0>
 static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, PointAddr pa, long P, int NW, double* __restrict__ d0,
                                                      unsigned long long* __restrict__ lst, double* __restrict__ theta) {
   // The candidates' lattice vectors, their membership offsets and the atom class's membership bytes are staged in LDS: as
@@ -379,7 +383,7 @@ static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, Poi
   __shared__ int s_imgn[128][3];
   __shared__ unsigned char s_memb[PQA_PRE_MEMB];
   __shared__ double s_cut[PQA_MAXCLS + 1];
-  __shared__ unsigned long long s_w[PQA_PRE_NWMAX][PQA_PRE_NT];   // the list being assembled, one column per thread
+  extern __shared__ unsigned short s_pre[];   // records / entries of the list being assembled, one column per thread each
   const int ia = blockIdx.y, tid = threadIdx.x;
   const int ncls = S.pb->ncls[ia];
   const bool has_member = S.pb->member != nullptr;
@@ -388,11 +392,12 @@ static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, Poi
   const unsigned char* gmemb = has_member ? S.pb->member + (size_t)S.pb->member_class[ia] * side3 : nullptr;
   {
     const int nl = min(S.pb->num_Ls[ia], 128);
+    const bool by_candidate = has_member && !S.pb->memb_mask;  // (only the table-less membership tests read these two)
     for (int q = tid; q < 3 * nl; q += PQA_PRE_NT) {
       s_Ls[q / 3][q % 3] = S.pb->Ls[q];
-      if (has_member) s_imgn[q / 3][q % 3] = S.pb->img_n[q];
+      if (by_candidate) s_imgn[q / 3][q % 3] = S.pb->img_n[q];
     }
-    if (memb_lds) for (int q = tid; q < side3; q += PQA_PRE_NT) s_memb[q] = gmemb[q];
+    if (memb_lds && by_candidate) for (int q = tid; q < side3; q += PQA_PRE_NT) s_memb[q] = gmemb[q];
     if (tid < PQA_MAXCLS) s_cut[tid] = tid < ncls ? S.pb->cls_cut[ia * PQA_MAXCLS + tid] : 0.0;
     __syncthreads();
   }
@@ -416,19 +421,24 @@ static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, Poi
   unsigned long long* out = lst + (size_t)ia * NW * P + p;  // word w at out[w * P]
   const int nimg = S.pb->num_Ls[ia];
   const int nw = min(NW, PQA_PRE_NWMAX), cap = min(4 * nw - 1, PQA_PRE_CAP);
-  if (nimg > 128 || ncls <= 0 || ncls > PQA_PRE_NCUT) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
-  // 1. distance test of every candidate
-  unsigned long long m0 = 0ull, m1 = 0ull;
-  {
-    const double acut = S.pb->atom_cut[ia];
-#pragma unroll 4
-    for (int j = 0; j < nimg; ++j) {
-      const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
-      if (xj * xj + yj * yj + zj * zj <= acut) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
-    }
+  unsigned short* s_rec = s_pre;
+  unsigned short* s_ent = s_pre + (size_t)4 * nw * PQA_PRE_NT;
+  if (nimg > 128 || ncls <= 0 || ncls > NCUT) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
+  // 1. candidates worth a distance test: the ones near this sub-cell of the folded displacement (create: near_masks) that the
+  //    membership rule admits (one look-up of the pre-tabulated mask of this (atom class, fold): member_masks)
+  unsigned long long m0 = nimg >= 64 ? ~0ull : (1ull << nimg) - 1ull;
+  unsigned long long m1 = nimg <= 64 ? 0ull : (nimg >= 128 ? ~0ull : (1ull << (nimg - 64)) - 1ull);
+  if (S.pb->near_mask) {
+    const int G = S.pb->near_G;
+    const double u0 = c.x0 * S.pb->linv[0] + c.y0 * S.pb->linv[3] + c.z0 * S.pb->linv[6];
+    const double u1 = c.x0 * S.pb->linv[1] + c.y0 * S.pb->linv[4] + c.z0 * S.pb->linv[7];
+    const double u2 = c.x0 * S.pb->linv[2] + c.y0 * S.pb->linv[5] + c.z0 * S.pb->linv[8];
+    const int g0 = min(G - 1, max(0, (int)((u0 + 0.5) * G))), g1 = min(G - 1, max(0, (int)((u1 + 0.5) * G))),
+              g2 = min(G - 1, max(0, (int)((u2 + 0.5) * G)));
+    const unsigned long long* nm = S.pb->near_mask + 2 * ((((size_t)ia * G + g0) * G + g1) * G + g2);
+    m0 &= nm[0]; m1 &= nm[1];
   }
-  // 2. membership rule: one look-up of the pre-tabulated candidate mask of this (atom class, fold) (create: member_masks), or
-  //    candidate by candidate where there is no table
+  const double acut = S.pb->atom_cut[ia];
   if (has_member) {
     if (S.pb->memb_mask) {
       const int E = S.pb->memb_E, T = side + 2 * E;
@@ -437,12 +447,14 @@ static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, Poi
         const unsigned long long* mm = S.pb->memb_mask + 2 * ((((size_t)S.pb->member_class[ia] * T + i0) * T + i1) * T + i2);
         m0 &= mm[0]; m1 &= mm[1];
       } else { m0 = 0ull; m1 = 0ull; }
-    } else {
+    } else {  // no table: candidate by candidate (distance first: the rule costs four dependent look-ups)
       unsigned long long k0 = 0ull, k1 = 0ull, b0_ = m0, b1_ = m1;
       while (b0_ | b1_) {
         int j;
         if (b0_) { j = __ffsll((long long)b0_) - 1; b0_ &= b0_ - 1; }
         else { j = 64 + __ffsll((long long)b1_) - 1; b1_ &= b1_ - 1; }
+        const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
+        if (xj * xj + yj * yj + zj * zj > acut) continue;
         const int n0 = c.b0 + s_imgn[j][0], n1 = c.b1 + s_imgn[j][1], n2 = c.b2 + s_imgn[j][2];
         if ((unsigned)n0 >= (unsigned)side || (unsigned)n1 >= (unsigned)side || (unsigned)n2 >= (unsigned)side) continue;
         const int mi = (n0 * side + n1) * side + n2;
@@ -452,56 +464,60 @@ static __global__ __launch_bounds__(PQA_PRE_NT) void k_pbc_prepass(SysDev S, Poi
       m0 = k0; m1 = k1;
     }
   }
-  // 3. the lane's own few admitted images: class (4 bits each, packed), nearest, class populations (6 bits each, packed)
-  double cut_r[PQA_PRE_NCUT];
+  // 2. distance test of those.  Every admitted image gets the class of the smallest shell cut-off that contains it; its record
+  //    (index, class) goes to the thread's LDS column in arrival order, the class populations are counted in 6-bit fields.
+  double cut_r[NCUT];
 #pragma unroll
-  for (int q = 0; q < PQA_PRE_NCUT; ++q) cut_r[q] = q < ncls ? s_cut[q] : -1.0;  // (r^2 > -1 always: classes past the last count as "outside")
-  unsigned long long a0 = 0ull, a1 = 0ull, cl0 = 0ull, cl1 = 0ull, cnt = 0ull;
-  int n = 0, jmin = -1, kmin = -1;
+  for (int q = 0; q < NCUT; ++q) cut_r[q] = q < ncls ? s_cut[q] : INFINITY;  // (classes past the last are never exceeded)
+  typedef typename PreFields<NCUT>::type fld_t;   // NCUT 6-bit fields: 32 bits for five classes, 64 for ten
+  fld_t cnt = 0;
+  int n = 0, kmin = -1;
   double rmin = 1e300;
   bool over = false;
-  while (m0 | m1) {
-    int j;
-    if (m0) { j = __ffsll((long long)m0) - 1; m0 &= m0 - 1; }
-    else { j = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1; }
-    const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
-    const double r2 = xj * xj + yj * yj + zj * zj;
-    int cls = 0;
 #pragma unroll
-    for (int q = 0; q < PQA_PRE_NCUT; ++q) cls += (q < ncls && r2 > cut_r[q]) ? 1 : 0;
-    if (cls >= ncls) continue;  // inside the atom's cut-off but outside every shell's
-    if (n >= cap) { over = true; break; }
-    if (j < 64) a0 |= 1ull << j; else a1 |= 1ull << (j - 64);
-    if (n < 16) cl0 |= (unsigned long long)cls << (4 * n); else cl1 |= (unsigned long long)cls << (4 * (n - 16));
-    cnt += 1ull << (6 * cls);
-    if (r2 < rmin) { rmin = r2; jmin = j; kmin = n; }
-    ++n;
-  }
-  if (over) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
-  // 4. nearest image first, then class by class (index order inside a class): counting scatter into the LDS column
-  const int nwords = n / 4 + 1;  // n entries + at least one terminator
-  for (int w = 0; w < nwords; ++w) s_w[w][tid] = ~0ull;  // PQA_IMG_END everywhere
-  if (n > 0) {
-    const int cmin = (int)((kmin < 16 ? cl0 >> (4 * kmin) : cl1 >> (4 * (kmin - 16))) & 15ull);
-    cnt -= 1ull << (6 * cmin);  // the nearest image leaves its class ...
-    unsigned long long off = 0ull;  // ... and takes position 0; off: next free position of every class, 6 bits each
-    int run = 1;
+  for (int half = 0; half < 2; ++half) {
+    unsigned long long m = over ? 0ull : (half ? m1 : m0);
+    while (m) {
+      const int j = 64 * half + __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const double xj = c.x0 - s_Ls[j][0], yj = c.y0 - s_Ls[j][1], zj = c.z0 - s_Ls[j][2];
+      const double r2 = xj * xj + yj * yj + zj * zj;
+      int cls = 0;
 #pragma unroll
-    for (int q = 0; q < PQA_PRE_NCUT; ++q) { off |= (unsigned long long)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63ull); }
-    int k = 0;
-    while (a0 | a1) {
-      int j;
-      if (a0) { j = __ffsll((long long)a0) - 1; a0 &= a0 - 1; }
-      else { j = 64 + __ffsll((long long)a1) - 1; a1 &= a1 - 1; }
-      const int cj = (int)((k < 16 ? cl0 >> (4 * k) : cl1 >> (4 * (k - 16))) & 15ull);
-      int pos = 0;
-      if (k != kmin) { pos = (int)((off >> (6 * cj)) & 63ull); off += 1ull << (6 * cj); }
-      ++k;
-      const int sh16 = 16 * (pos & 3);
-      s_w[pos >> 2][tid] = (s_w[pos >> 2][tid] & ~(0xFFFFull << sh16)) | ((unsigned long long)j << sh16);
+      for (int q = 0; q < NCUT; ++q) cls += r2 > cut_r[q] ? 1 : 0;
+      if (r2 > acut || cls >= ncls) continue;  // outside the atom's cut-off, or inside it but outside every shell's
+      if (n >= cap) { over = true; m = 0ull; continue; }
+      s_rec[n * PQA_PRE_NT + tid] = (unsigned short)(j | (cls << 8));
+      cnt += (fld_t)1 << (6 * cls);
+      if (r2 < rmin) { rmin = r2; kmin = n; }
+      ++n;
     }
   }
-  for (int w = 0; w < nwords; ++w) out[(size_t)w * P] = s_w[w][tid];
+  if (over) { out[0] = (unsigned long long)PQA_IMG_OVF; return; }
+  // 3. nearest image first, then class by class (index order inside a class): counting scatter of the records into the
+  //    thread's second LDS column, 16-bit entries (no read-modify-write of packed words)
+  const int nwords = n / 4 + 1;  // n entries + at least one terminator
+  if (n > 0) {
+    const int cmin = s_rec[kmin * PQA_PRE_NT + tid] >> 8;
+    cnt -= (fld_t)1 << (6 * cmin);  // the nearest image leaves its class ...
+    fld_t off = 0;                  // ... and takes position 0; off: next free position of every class
+    int run = 1;
+#pragma unroll
+    for (int q = 0; q < NCUT; ++q) { off |= (fld_t)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63); }
+    for (int k = 0; k < n; ++k) {
+      const int rec = s_rec[k * PQA_PRE_NT + tid];
+      const int sh = 6 * (rec >> 8);
+      int pos = 0;
+      if (k != kmin) { pos = (int)((off >> sh) & 63); off += (fld_t)1 << sh; }
+      s_ent[pos * PQA_PRE_NT + tid] = (unsigned short)(rec & 255);
+    }
+  }
+  for (int k = n; k < 4 * nwords; ++k) s_ent[k * PQA_PRE_NT + tid] = (unsigned short)PQA_IMG_END;
+  for (int w = 0; w < nwords; ++w) {
+    const unsigned e0 = s_ent[(4 * w) * PQA_PRE_NT + tid], e1 = s_ent[(4 * w + 1) * PQA_PRE_NT + tid],
+                   e2 = s_ent[(4 * w + 2) * PQA_PRE_NT + tid], e3 = s_ent[(4 * w + 3) * PQA_PRE_NT + tid];
+    out[(size_t)w * P] = (unsigned long long)(e0 | (e1 << 16)) | ((unsigned long long)(e2 | (e3 << 16)) << 32);
+  }
 }
 
 // per (point, atom) data of k_pbc_prepass -> context of the shells of atom ia (k_orb, k_orb_wide)

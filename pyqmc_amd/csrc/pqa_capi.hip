@@ -41,6 +41,55 @@ static int member_masks(pqa_handle* h, const pqa_system_t* sys, PbcDev& P) {
   return 0;
 }
 
+// ---------------------------------------------------------------- near-candidate masks (k_pbc_prepass)
+// The pre-pass folds point - atom into the cell-centred parallelepiped and then needs the lattice vectors L_j with
+// |d - L_j|^2 <= atom_cut.  The candidate list (num_Ls[atom] vectors, 79 in the 2x2x2 diamond cell) is what ANY point of the
+// cell may need; a given point needs about a sixth of it.  Tabulated here, for every sub-cell of a G^3 grid over the fractional
+// coordinates [-1/2, 1/2)^3, the candidates whose distance to the sub-cell's centre is at most sqrt(atom_cut) + the sub-cell's
+// half diagonal (padded): a superset of what any point inside it can admit.  16 bytes per (atom, sub-cell).
+static int near_masks(pqa_handle* h, const pqa_system_t* sys, const std::vector<int>& nl, const std::vector<double>& ac, PbcDev& P) {
+  P.near_mask = nullptr;
+  P.near_G = 0;
+  int G = (size_t)h->natom * 16 * 16 * 16 * 16 <= ((size_t)2 << 20) ? 16 : 8;  // (the table should stay in an XCD's L2)
+  if (const char* e = getenv("PQA_PRE_GRID")) G = std::max(0, std::min(16, atoi(e)));
+  while (G > 1 && (size_t)h->natom * G * G * G * 16 > ((size_t)64 << 20)) G /= 2;
+  if (G < 2) return 0;
+  const int nj = std::min(sys->nL, 128);
+  std::vector<double> ls((size_t)nj * 3);
+  HIPCHK(hipMemcpy(ls.data(), sys->Ls, ls.size() * sizeof(double), hipMemcpyDefault));
+  const double* a = sys->lattice;
+  const double hw = 0.5 / G + 1e-6;  // half width of a sub-cell in fractional coordinates, padded for the rounding of the fold
+  double rho = 0.0;
+  for (int sg = 0; sg < 4; ++sg) {   // half of the longest body diagonal
+    const double s1 = (sg & 1) ? -hw : hw, s2 = (sg & 2) ? -hw : hw;
+    double d2 = 0.0;
+    for (int c = 0; c < 3; ++c) { const double v = hw * a[c] + s1 * a[3 + c] + s2 * a[6 + c]; d2 += v * v; }
+    rho = std::max(rho, std::sqrt(d2));
+  }
+  std::vector<unsigned long long> mask((size_t)h->natom * G * G * G * 2, 0ull);
+  for (int ia = 0; ia < h->natom; ++ia) {
+    const double reach = std::sqrt(std::max(ac[ia], 0.0)) * (1.0 + 1e-9) + rho + 1e-9;
+    const int n = std::min(nl[ia], nj);
+    for (int g0 = 0; g0 < G; ++g0)
+      for (int g1 = 0; g1 < G; ++g1)
+        for (int g2 = 0; g2 < G; ++g2) {
+          const double f[3] = {(g0 + 0.5) / G - 0.5, (g1 + 0.5) / G - 0.5, (g2 + 0.5) / G - 0.5};
+          double ctr[3];
+          for (int c = 0; c < 3; ++c) ctr[c] = f[0] * a[c] + f[1] * a[3 + c] + f[2] * a[6 + c];
+          unsigned long long* m = &mask[2 * ((((size_t)ia * G + g0) * G + g1) * G + g2)];
+          for (int j = 0; j < n; ++j) {
+            const double dx = ctr[0] - ls[3 * j], dy = ctr[1] - ls[3 * j + 1], dz = ctr[2] - ls[3 * j + 2];
+            if (dx * dx + dy * dy + dz * dz <= reach * reach) m[j >> 6] |= 1ull << (j & 63);
+          }
+        }
+  }
+  unsigned long long* d = nullptr;
+  TRY(upload_table(h, mask.data(), mask.size(), &d));
+  P.near_mask = d;
+  P.near_G = G;
+  return 0;
+}
+
 // ---------------------------------------------------------------- Voronoi-relevant lattice vectors (min_image)
 // v is relevant iff v/2 is strictly closer to 0 (and v) than to every other lattice point.  Candidates: coefficients in
 // {-2..2}^3 (all relevant vectors of any cell that is not absurdly skewed), tested against the points with coefficients in
@@ -280,6 +329,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   Sherman-Morrison block (0: update every row per move; default 4), PQA_LW_GM g thread groups per walker and PQA_LW_NW
   //   walkers per block of k_step_lw, PQA_ECP_WAVE 1 wave-per-walker ECP accumulation,
   //   PQA_PROF_STRIDE n event brackets on every n-th orbital launch when profiling is enabled,
+  //   PQA_PRE_GRID g   sub-cells per axis of the near-candidate masks of the periodic pre-pass (default 16, 8 beyond 32 atoms; 0: every candidate tested)
+  //   PQA_PRE_NCUT n   at least n shell cut-off classes in the pre-pass instantiation (5 or 10 are compiled; tests)
   //   PQA_PBC_NW n words (4 image indices each) per (point, atom) image list of the periodic pre-pass (default from the cell;
   //   1 forces the direct-test fallback: tests), PQA_WIDE_NTH 512 k_orb_wide with 512 threads in untwisted periodic cells,
   //   PQA_TM_PRE 0 T-move ratios by the wave-per-walker loop only;
@@ -422,6 +473,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         }
         TRY(upload_table(h, cc.data(), cc.size(), &tmp_d)); P.cls_cut = tmp_d;
         TRY(upload_table(h, nc.data(), nc.size(), &tmp_i)); P.ncls = tmp_i;
+        h->pbc_maxcls = *std::max_element(nc.begin(), nc.end());
+        if (const char* e = getenv("PQA_PRE_NCUT")) h->pbc_maxcls = std::max(h->pbc_maxcls, atoi(e));  // (tests: the ten-class instantiation)
       }
       {  // capacity of the per-(atom, point) image lists: the lattice points inside a sphere of the largest atom cut-off number
          // V_sphere / V_cell on average; 1.5 x that + 8 with room for a terminator (lanes beyond it test images directly)
@@ -434,6 +487,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         const int cap = (int)std::min(127.0, std::ceil(1.5 * mean + 8.0));
         h->pbc_nw = cap / 4 + 1;
         if (const char* e = getenv("PQA_PBC_NW")) h->pbc_nw = std::max(1, std::min(32, atoi(e)));
+        TRY(near_masks(h, sys, nl, ac, P));
       }
       P.twist = h->twist ? 1 : 0;
       if (h->twist) {

@@ -36,6 +36,11 @@ struct PbcDev {
   // (side + 2 E)^3 grid of bases (create: member_masks); nullptr: no table, test candidate by candidate
   const unsigned long long* memb_mask;
   int memb_E;
+  // candidates that can lie inside atom_cut of SOME point of a sub-cell of the cell-centred parallelepiped the folded
+  // displacement point - atom lives in: near_mask[atom][g0][g1][g2][2] over a near_G^3 grid of fractional coordinates
+  // (create: near_masks; conservative, so the exact tests downstream decide).  nullptr: every candidate is looked at
+  const unsigned long long* near_mask;
+  int near_G;
   const int* member_class;
   const int* img_n;
   const int* atom_n;

@@ -52,6 +52,7 @@ struct pqa_handle {
   bool tm_pre = true;   // T-move ratios of all candidates in one thread-per-candidate launch (PQA_TM_PRE=0: wave-per-walker loop only)
   bool aos_stale = false;  // the lane-per-walker planes hold the live state; the walker-major arrays are converted back on demand (sync_aos)
   int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
+  int pbc_maxcls = PQA_PRE_NCUT;  // most distinct shell cut-offs any atom has (picks the pre-pass instantiation)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool pbc_high_l = false;  // a periodic cell with g / h shells: orbitals through k_ao<.., 5> + k_mo_rows (pqa_orb_pbc.hip)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)

@@ -8,8 +8,16 @@ static int launch_orb_pbc(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
   const int NW = h->pbc_nw;
   TRY(ensure(h, h->b_pbcmask, (size_t)h->natom * NW * P * sizeof(unsigned long long)));
   if (h->twist) TRY(ensure(h, h->b_pbcth, (size_t)2 * P * sizeof(double)));
-  hipLaunchKernelGGL((k_pbc_prepass<>), dim3((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom), dim3(PQA_PRE_NT), 0, h->stream, h->S, pa, P, NW,
-                     (double*)h->b_pbcd0.p, (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
+  {
+    const dim3 grid((unsigned)((P + PQA_PRE_NT - 1) / PQA_PRE_NT), (unsigned)h->natom);
+    const size_t lds = (size_t)2 * 4 * std::min(NW, PQA_PRE_NWMAX) * PQA_PRE_NT * sizeof(unsigned short);
+    if (h->pbc_maxcls <= 5)
+      hipLaunchKernelGGL((k_pbc_prepass<5>), grid, dim3(PQA_PRE_NT), lds, h->stream, h->S, pa, P, NW, (double*)h->b_pbcd0.p,
+                         (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
+    else
+      hipLaunchKernelGGL((k_pbc_prepass<PQA_PRE_NCUT>), grid, dim3(PQA_PRE_NT), lds, h->stream, h->S, pa, P, NW, (double*)h->b_pbcd0.p,
+                         (unsigned long long*)h->b_pbcmask.p, (double*)h->b_pbcth.p);
+  }
   ChunkTab T = tabx(h, tabi);
   T.pbc_d0 = (const double*)h->b_pbcd0.p;
   T.pbc_list = (const unsigned long long*)h->b_pbcmask.p;

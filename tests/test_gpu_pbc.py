@@ -655,6 +655,40 @@ def test_periodic_image_lists_and_direct_tests_agree(tag, monkeypatch):
         assert helpers.relerr(rows[""][1], rows[""][2]) < 1e-13
 
 
+@pytest.mark.parametrize("tag", ["fcc2cubic", "k222", "twist_s211", "general"])
+def test_near_candidate_masks_do_not_change_a_bit(tag, monkeypatch):
+    """The pre-pass only distance-tests the candidate images a table marks as reachable from the sub-cell the folded displacement
+    point - atom falls in (create: near_masks; PQA_PRE_GRID sub-cells per axis, 0 = test every candidate).  The table is a superset
+    of what the exact tests admit, so the image lists — and with them every orbital value — must be the SAME BITS with it,
+    without it and with a coarse grid; points on sub-cell faces, on cell faces and far outside the cell included."""
+    import pyqmc_amd as pa
+
+    if tag == "general":  # a sheared cell: the sub-cells are parallelepipeds whose half diagonal is not a coordinate axis
+        sup, mf = helpers.pbc_slater_case("gamma")
+    else:
+        sup, mf = helpers.twist_case("s211") if tag == "twist_s211" else helpers.pbc_slater_case(tag)
+    lat = sup.lattice_vectors()
+    rng = np.random.default_rng(12)
+    frac = rng.random((3000, 3)) * 5 - 2
+    frac[:600] = np.rint(frac[:600] * 16) / 16          # exactly on the faces of the 8^3 and 16^3 grids (and on cell faces)
+    frac[600:900, 0] = 0.5; frac[900:1200, 1] = -0.5     # the fold's own boundary
+    pts = frac @ lat
+    atoms = np.asarray(sup.atom_coords())
+    pts[1200:1200 + len(atoms)] = atoms                 # on the nuclei: folded displacement exactly 0
+    rows = {}
+    for g in ("", "0", "3", "16", "ncut10"):
+        if g == "ncut10":  # the pre-pass instantiation for atoms with more than five distinct shell cut-offs
+            monkeypatch.delenv("PQA_PRE_GRID")
+            monkeypatch.setenv("PQA_PRE_NCUT", "10")
+        elif g:
+            monkeypatch.setenv("PQA_PRE_GRID", g)
+        dev = pa.generate_wf(sup, mf).fused_device()
+        rows[g] = [dev.eval_mo(0, pts, nc) for nc in (1, 5)]
+    for g in ("0", "3", "16", "ncut10"):
+        for a, b in zip(rows[""], rows[g]):
+            assert np.array_equal(a, b), g
+
+
 @pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
 def test_periodic_pgradient_matches_reference(tag):
     """pgradient() of a periodic Slater-Jastrow (slater.py:462-542, orbitals.py:239-254): the orbital coefficients are
