@@ -1042,6 +1042,12 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
 // (up to ~150 KB: one block per CU), and after a single barrier the waves contract (component, orbital tile) pairs over the
 // full K with v_mfma_f64_16x16x4_f64.  Same shell routines, same coefficient layout (the chunk table's padded row order), so
 // rows are identical to k_orb's up to the MFMA accumulation order (one K loop instead of per-chunk partial sums).
+#ifdef PQA_WIDE_CLK  // timing build only (tools/scratch/wide_clk.py): 100 MHz stamps of the phases of the first blocks
+static __device__ unsigned long long pqa_wide_clk[1024 * 8];
+#define PQA_CLK(k) do { if (blockIdx.x < 1024 && threadIdx.x == 0) pqa_wide_clk[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PQA_CLK(k) do { } while (0)
+#endif
 struct WideTab {
   const int* off;     // [65] shells of lane group g: shell[off[g] .. off[g+1]); 64 groups (1024 threads) or 32 (512 threads)
   const int* shell;
@@ -1058,6 +1064,7 @@ __host__ __device__ inline size_t wide_lds_bytes(int ncomp, int rows_pad, int ns
 template <int NCOMP, int NT, int PBC, int NTH>
 static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, WideTab Wt, int spin, PointAddr pa, long P, double* __restrict__ out) {
   extern __shared__ double wl[];
+  PQA_CLK(0);
   const int K = Wt.rows_pad;
   double* tile = wl;                                  // [NCOMP][K][16]
   double* sh_xyz = tile + (size_t)NCOMP * K * 16;     // [nshell][3]
@@ -1093,6 +1100,7 @@ static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, W
   for (int p = tid; p < S.nprim; p += NTH) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   for (int k = tid; k < NCOMP * K * 16; k += NTH) tile[k] = 0.0;  // (the K padding rows stay zero)
   __syncthreads();
+  PQA_CLK(1);
   const int pl = tid & 15, grp = tid >> 4;
   const long p0 = (long)blockIdx.x * 16;
   const long pmine = (p0 + pl < P) ? p0 + pl : P - 1;
@@ -1140,7 +1148,12 @@ static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, W
       } else shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_get);
     } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
   }
+  PQA_CLK(2);
+#ifdef PQA_WIDE_CLK
+  if (blockIdx.x < 1024 && threadIdx.x == NTH - 64) pqa_wide_clk[blockIdx.x * 8 + 6] = wall_clock64();  // (last wave's phase 1)
+#endif
   __syncthreads();
+  PQA_CLK(3);
   // contraction: wave <-> (component c, orbital tile ut); D[point][orbital] += A[point][k] B[k][orbital], B straight from L2
   const double* __restrict__ C = T.cpad[spin];
   const int ldc = T.ldc[spin], nmo = S.nmo[spin];
@@ -1165,6 +1178,7 @@ static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, W
       for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
     for (; ks < K / 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[(size_t)ks * 64], b_[(size_t)ks * 4 * ldc], acc, 0, 0, 0);
+    PQA_CLK(4);
     const int j = 16 * ut + i16;
     if (j < nmo) {
 #pragma unroll
@@ -1172,4 +1186,5 @@ static __global__ __launch_bounds__(NTH) void k_orb_wide(SysDev S, ChunkTab T, W
         if (orow[r]) orow[r][c * nmo + j] = acc[r];
     }
   }
+  PQA_CLK(5);
 }

@@ -130,3 +130,9 @@ int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P,
   if (ncomp == 1) return launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
   FAIL("orbital kernel supports ncomp 1 or 5");
 }
+
+#ifdef PQA_WIDE_CLK  // timing build only (tools/scratch/wide_clk.py)
+extern "C" int pqa_debug_wide_clk(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_wide_clk), (size_t)n * sizeof(unsigned long long));
+}
+#endif
