@@ -5,7 +5,9 @@
 
 #define PQA_WAVE 64
 #define PQA_MAXBAS 16     // max two-body Jastrow basis functions per kind (hot kernels loop to na / nb; only the protocol kernels' register arrays have this length)
+#ifndef PQA_MAXBAS3
 #define PQA_MAXBAS3 8     // max three-body basis functions per kind (fully unrolled register arrays in jas3_eval)
+#endif
 #define PQA_MAXN 64       // max electrons per spin handled by one wave (LU / Sherman-Morrison tile)
 #define PQA_MAXCHAN 5     // ECP channels per atom incl. local
 #define PQA_MAXAIP 12
