@@ -417,3 +417,9 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   if (energy_mean) HIPCHK(hipMemcpy(energy_mean, h->b_means.p, (size_t)nsteps * nen * sizeof(double), hipMemcpyDefault));
   return 0;
 }
+
+#ifdef PQA_WW_CLK  // timing build only (tools/scratch/ww_clk.py)
+extern "C" int pqa_debug_ww_clk(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_ww_clk), (size_t)n * sizeof(unsigned long long));
+}
+#endif

@@ -71,6 +71,12 @@ __device__ __forceinline__ void slater_move_terms(const SysDev& S, const SlaterS
   }
 }
 
+#ifdef PQA_WW_CLK  // timing build only (tools/scratch/ww_clk.py): 100 MHz stamps inside k_propose (0-3) and k_accept (4-7)
+static __device__ unsigned long long pqa_ww_clk[1024 * 8];
+#define PQA_WCLK(k) do { if (blockIdx.x < 1024 && threadIdx.x == 0) pqa_ww_clk[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PQA_WCLK(k) do { } while (0)
+#endif
 template <bool CX>
 static __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st, JastrowState js, MoveBuf mb, int e,
                                                 int has_slater, int has_jastrow, long W) {
@@ -79,16 +85,25 @@ static __global__ __launch_bounds__(64) void k_propose(SysDev S, SlaterState st,
   const double* xw = js.x + (size_t)w * S.nelec * 3;
   const double ex = xw[3 * e], ey = xw[3 * e + 1], ez = xw[3 * e + 2];
   double gx = 0.0, gy = 0.0, gz = 0.0, U0 = 0.0;
+  PQA_WCLK(0);
   if (has_slater) {
     const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
     double v2;
     slater_move_terms<CX>(S, st, s, i, w, st.cache[s] + ((size_t)w * n + i) * 5 * nmo, lds, gx, gy, gz, v2);
   }
+  PQA_WCLK(1);
   if (has_jastrow) {
     double g[3], lp;
+#ifdef PQA_WW_CLK
+    jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp, 1, lds + S.j3_off);
+    PQA_WCLK(2);
+    { double u3 = 0.0, g3[3] = {0.0, 0.0, 0.0}; jas_eval<1>(S, xw, e, ex, ey, ez, u3, g3, lp, 2, lds + S.j3_off); U0 += u3; g[0] += g3[0]; g[1] += g3[1]; g[2] += g3[2]; }
+#else
     jas_eval<1>(S, xw, e, ex, ey, ez, U0, g, lp, 3, lds + S.j3_off);
+#endif
     gx += g[0]; gy += g[1]; gz += g[2];
   }
+  PQA_WCLK(3);
   if (mb.dmc) limdrift_dmc(gx, gy, gz, mb.tstep);  // the drift vector itself (already times tau_eff)
   else limdrift3(gx, gy, gz);
   if (threadIdx.x == 0) {
@@ -127,7 +142,9 @@ static __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, 
   double val2 = 1.0, gx = 0.0, gy = 0.0, gz = 0.0;  // val2 = |Psi(new)/Psi|^2 (mc.py:131)
   const double* row = motmp + (size_t)w * 5 * nmo;
   double sgn = 1.0;
+  PQA_WCLK(4);
   if (has_slater) slater_move_terms<CX>(S, st, s, i, w, row, lds, gx, gy, gz, val2, &sgn);
+  PQA_WCLK(5);
   if (has_jastrow) {
     double g[3], lp, U;
     jas_eval<1>(S, xw, e, nx, ny, nz, U, g, lp, 3, lds + S.j3_off);
@@ -155,6 +172,7 @@ static __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, 
     u = u01(p.c[0], p.c[1]);
   }
   const bool acc = ratio > u;
+  PQA_WCLK(6);
   if (mb.dmc && lane == 0) {  // dmc.py:68 r2 = |gauss + drift|^2
     const double r2 = (a[0] + a[3]) * (a[0] + a[3]) + (a[1] + a[4]) * (a[1] + a[4]) + (a[2] + a[5]) * (a[2] + a[5]);
     mb.r2_prop[w] += r2;
@@ -182,6 +200,7 @@ static __global__ __launch_bounds__(64) void k_accept(SysDev S, SlaterState st, 
       wr[0] += mb.dwrap[3 * w]; wr[1] += mb.dwrap[3 * w + 1]; wr[2] += mb.dwrap[3 * w + 2];
     }
   }
+  PQA_WCLK(7);
 }
 
 // accepted-move count of one sweep: sum acc_w[0..W) -> *out, and reset acc_w.  One block, deterministic.
