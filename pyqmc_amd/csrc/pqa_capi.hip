@@ -300,6 +300,7 @@ extern "C" int pqa_device_count(void) {
 
 extern "C" const char* pqa_last_error(const pqa_handle_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+static int jas_merge_tables(pqa_handle* h);
 // ccoeff (natom,na3,na3,nb3,3) -> C = (c + c^T_kl)/2 (three_body_jastrow.py:94-96)
 static int set_c3(pqa_handle* h, const double* c) {
   const int A = h->natom, na = h->na3, nb = h->nb3;
@@ -368,6 +369,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* sp = getenv("PQA_SPLIT_MIN")) h->split_min = std::max(512L, atol(sp));
   if (const char* sp = getenv("PQA_SPLIT_CUS")) h->split_cus = atoi(sp);
   if (const char* sp = getenv("PQA_JPRE")) h->jpre = atoi(sp);
+  if (const char* sp = getenv("PQA_JAS_MERGE")) h->jas_merge = atoi(sp);
   if (const char* sp = getenv("PQA_JPRE_MIN")) h->jpre_min = std::max(64L, atol(sp));
   {
     hipDeviceProp_t prop;
@@ -618,6 +620,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   }
   TRY(upload_table(h, sys->acoeff, (size_t)h->natom * h->na * 2, &h->d_acoeff)); S.acoeff = h->d_acoeff;
   TRY(upload_table(h, sys->bcoeff, (size_t)h->nb * 3, &h->d_bcoeff)); S.bcoeff = h->d_bcoeff;
+  TRY(jas_merge_tables(h));
   S.na3 = h->na3; S.nb3 = h->nb3; S.rcut_a3 = sys->rcut_a3; S.rcut_b3 = sys->rcut_b3;
   for (int k = 0; k < h->na3; ++k) { S.a3_kind[k] = sys->a3_kind[k]; S.a3_param[k] = sys->a3_param[k]; S.a3_aux[k] = 1.0 / (3.0 + sys->a3_param[k]); }
   for (int k = 0; k < h->nb3; ++k) { S.b3_kind[k] = sys->b3_kind[k]; S.b3_param[k] = sys->b3_param[k]; S.b3_aux[k] = 1.0 / (3.0 + sys->b3_param[k]); }
@@ -743,6 +746,81 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   delete h;
 }
 
+// ---------------------------------------------------------------- merged Pade numerators
+// Tables for pade_merged (pqa_jastrow.hpp): with D_k = 1 + beta_k p over the PolyPade functions k of a basis and a coefficient set c,
+//   N1 = sum_k c_k prod_{j != k} D_j,  N2 = sum_k c_k (1 + beta_k) prod_{j != k} D_j^2,  N3 = sum_k c_k beta_k (1 + beta_k) prod_{j != k} D_j^3
+// as ascending coefficients at offsets 0 / 4 / 11 of a PQA_JQ-double record, one record per (atom, spin of the electron) and per
+// electron-electron spin channel; D = prod_k D_k in S.a_D / S.b_D.  Products in long double, rounded once.  Called at create and
+// after every change of acoeff / bcoeff.  Route available (S.jq_on) when every non-empty basis is [cusp]? + 1..4 Pade functions.
+typedef std::vector<long double> Poly;
+static Poly poly_mul(const Poly& a, const Poly& b) {
+  Poly c(a.size() + b.size() - 1, 0.0L);
+  for (size_t i = 0; i < a.size(); ++i)
+    for (size_t j = 0; j < b.size(); ++j) c[i + j] += a[i] * b[j];
+  return c;
+}
+static void jas_merge_record(const std::vector<double>& beta, const double* c, size_t cstride, double* rec) {
+  const int K = (int)beta.size();
+  Poly n1(1, 0.0L), n2(1, 0.0L), n3(1, 0.0L);
+  auto add = [](Poly& acc, const Poly& t, long double f) {
+    if (acc.size() < t.size()) acc.resize(t.size(), 0.0L);
+    for (size_t i = 0; i < t.size(); ++i) acc[i] += f * t[i];
+  };
+  for (int k = 0; k < K; ++k) {
+    Poly o(1, 1.0L);
+    for (int j = 0; j < K; ++j)
+      if (j != k) o = poly_mul(o, Poly{1.0L, (long double)beta[j]});
+    const Poly o2 = poly_mul(o, o), o3 = poly_mul(o2, o);
+    const long double ck = c[(size_t)k * cstride], bk = beta[k];
+    add(n1, o, ck); add(n2, o2, ck * (1.0L + bk)); add(n3, o3, ck * bk * (1.0L + bk));
+  }
+  for (int i = 0; i < PQA_JQ; ++i) rec[i] = 0.0;
+  for (size_t i = 0; i < n1.size() && i < 4; ++i) rec[i] = (double)n1[i];
+  for (size_t i = 0; i < n2.size() && i < 7; ++i) rec[4 + i] = (double)n2[i];
+  for (size_t i = 0; i < n3.size() && i < 10; ++i) rec[11 + i] = (double)n3[i];
+}
+static int jas_merge_tables(pqa_handle* h) {
+  SysDev& S = h->S;
+  S.jq_on = S.jq_a = S.jq_b = 0;
+  if (!h->jas_merge || !h->has_j2 || (h->na == 0 && h->nb == 0)) return 0;
+  auto pades = [](int n, const int* kind, const double* par, std::vector<double>& beta, int& first) {
+    first = (n > 0 && kind[0] == 1) ? 1 : 0;
+    beta.clear();
+    for (int k = first; k < n; ++k) {
+      if (kind[k] != 0 || !(par[k] > -1.0)) return false;
+      beta.push_back(par[k]);
+    }
+    return n == 0 || (beta.size() >= 1 && beta.size() <= 4);
+  };
+  std::vector<double> ba, bb;
+  int fa = 0, fb = 0;
+  if (!pades(h->na, S.a_kind, S.a_param, ba, fa) || !pades(h->nb, S.b_kind, S.b_param, bb, fb)) return 0;
+  auto denom = [](const std::vector<double>& beta, double* D) {
+    Poly d(1, 1.0L);
+    for (double b : beta) d = poly_mul(d, Poly{1.0L, (long double)b});
+    for (int i = 0; i < 5; ++i) D[i] = i < (int)d.size() ? (double)d[i] : 0.0;
+  };
+  denom(ba, S.a_D); denom(bb, S.b_D);
+  std::vector<double> ac((size_t)h->natom * h->na * 2 + 1), bc((size_t)h->nb * 3 + 1);
+  HIPCHK(hipMemcpy(ac.data(), h->d_acoeff, (size_t)h->natom * h->na * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(bc.data(), h->d_bcoeff, (size_t)h->nb * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<double> aq((size_t)h->natom * 2 * PQA_JQ + PQA_JQ, 0.0), bq((size_t)3 * PQA_JQ, 0.0);
+  if (h->na > 0)
+    for (int I = 0; I < h->natom; ++I)
+      for (int sp = 0; sp < 2; ++sp) jas_merge_record(ba, ac.data() + ((size_t)I * h->na + fa) * 2 + sp, 2, aq.data() + ((size_t)I * 2 + sp) * PQA_JQ);
+  if (h->nb > 0)
+    for (int ch = 0; ch < 3; ++ch) jas_merge_record(bb, bc.data() + (size_t)fb * 3 + ch, 3, bq.data() + (size_t)ch * PQA_JQ);
+  if (!h->d_aq) {
+    TRY(upload_table<double>(h, nullptr, aq.size(), &h->d_aq));
+    TRY(upload_table<double>(h, nullptr, bq.size(), &h->d_bq));
+  }
+  HIPCHK(hipMemcpy(h->d_aq, aq.data(), aq.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_bq, bq.data(), bq.size() * sizeof(double), hipMemcpyHostToDevice));
+  S.aq = h->d_aq; S.bq = h->d_bq;
+  S.jq_a = (int)ba.size(); S.jq_b = (int)bb.size(); S.jq_on = 1;
+  return 0;
+}
+
 // ---------------------------------------------------------------- parameters
 extern "C" int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n) {
   HIPCHK(hipSetDevice(h->device));
@@ -752,9 +830,11 @@ extern "C" int pqa_set_param(pqa_handle_t* h, const char* name, const double* da
   if (k == "acoeff") {
     if (!expect((int64_t)h->natom * h->na * 2)) FAIL("acoeff size mismatch");
     HIPCHK(hipMemcpy(h->d_acoeff, data, n * sizeof(double), hipMemcpyDefault));
+    TRY(jas_merge_tables(h));
   } else if (k == "bcoeff") {
     if (!expect((int64_t)h->nb * 3)) FAIL("bcoeff size mismatch");
     HIPCHK(hipMemcpy(h->d_bcoeff, data, n * sizeof(double), hipMemcpyDefault));
+    TRY(jas_merge_tables(h));
   } else if (k == "ccoeff") {
     if (!h->has_j3 || !expect((int64_t)h->natom * h->na3 * h->na3 * h->nb3 * 3)) FAIL("ccoeff size mismatch");
     std::vector<double> host((size_t)n);

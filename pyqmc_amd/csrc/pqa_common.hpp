@@ -8,6 +8,7 @@
 #ifndef PQA_MAXBAS3
 #define PQA_MAXBAS3 8     // max three-body basis functions per kind (fully unrolled register arrays in jas3_eval)
 #endif
+#define PQA_JQ 24         // doubles per merged-numerator record (N1[4], N2[7], N3[10], padding)
 #define PQA_MAXN 64       // max electrons per spin handled by one wave (LU / Sherman-Morrison tile)
 #define PQA_MAXCHAN 5     // ECP channels per atom incl. local
 #define PQA_MAXAIP 12
@@ -84,6 +85,14 @@ struct SysDev {
   double rcut_a, rcut_b;
   const double* acoeff;  // [natom][na][2]
   const double* bcoeff;  // [nb][3]
+  // merged Pade functions (pqa_jastrow.hpp: pade_merged): jq_on -> every non-empty basis consists of an optional cusp function at index 0
+  // followed by 2..4 PolyPade functions, whose coefficient-weighted sums are evaluated as ONE rational function of p per pair:
+  // denominators a_D / b_D (ascending powers of p, zero padded), numerators per coefficient set in aq [natom][2][PQA_JQ] and
+  // bq [3][PQA_JQ] (N1 at 0, N2 at 4, N3 at 11; host: jas_merge_tables).  0: function by function (rad_fn)
+  int jq_on, jq_a, jq_b;  // jq_on: merged route available; jq_a / jq_b: Pade functions of the basis (0: the basis is empty)
+  double a_D[5], b_D[5];
+  const double* aq;
+  const double* bq;
   // three-body Jastrow (three_body_jastrow.py:19-63): own a/b bases, C = (c + c^T_kl)/2 as [natom][na3][na3][nb3][3]
   int na3, nb3;
   int a3_kind[PQA_MAXBAS3];

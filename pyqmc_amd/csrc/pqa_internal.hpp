@@ -75,6 +75,8 @@ struct pqa_handle {
   double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
   double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
   double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
+  double *d_aq = nullptr, *d_bq = nullptr;  // merged Pade numerators (jas_merge_tables); jas_merge: PQA_JAS_MERGE=0 keeps the function-by-function route (A/B)
+  int jas_merge = 1;
   // walker state
   long W = 0;
   SlaterState st{};

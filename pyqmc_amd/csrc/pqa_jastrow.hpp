@@ -81,6 +81,94 @@ __device__ __forceinline__ void rad_fn(int kind, double par, double aux, double 
   }
 }
 
+// ---------------------------------------------------------------- merged Pade functions (round 4)
+// The K PolyPade functions of a basis share p(r), so their coefficient-weighted sums are rational functions of p with the common
+// denominator D(p) = prod_k (1 + beta_k p):
+//   S1 = sum_k c_k / (1 + beta_k p)                        = N1(p) / D(p)      value      = (1 - p) S1
+//   S2 = sum_k c_k (1 + beta_k) / (1 + beta_k p)^2         = N2(p) / D(p)^2    (dU/dr)/r  = c0 S2
+//   S3 = sum_k c_k beta_k (1 + beta_k) / (1 + beta_k p)^3  = N3(p) / D(p)^3    lap        = c0 (t5 S2 - q S3)
+// (c0, t5, q of RadShared; rad_fn's formulas summed over k).  ONE reciprocal and 3K .. 6K - 3 multiply-adds per pair instead of K
+// reciprocals with two Newton steps each: the lane-per-walker pair loops are instruction bound and the reciprocals were a third of
+// them.  The numerator polynomials depend on the coefficient set (spin channel; atom and spin) and are tabulated by the host
+// whenever coefficients change (pqa_capi.hip: jas_merge_tables, long-double products rounded once).  All beta_k > -1 and
+// 0 <= p <= 1: D has no zero, its coefficients are positive for the usual positive beta; the numerators carry the same
+// cancellation between functions as the function-by-function sums, so the results agree to rounding (a few 1e-16 of the sum of
+// magnitudes: tests/test_gpu_jastrow_merge.py).  KD = 3: K <= 3 (zero-padded), KD = 4: K = 4.
+// The numerator record is WAVE-UNIFORM at every call site (scalar loads).  A Horner step acc * p + c with c in scalar registers is
+// one v_fma_f64 with a scalar addend; left to itself the compiler copies each freshly loaded coefficient into a vector register
+// pair first (its two-address v_fmac form wants the addend in the destination): three instructions per step instead of one — which
+// ate most of what the merge saves.  horner_s pins the three-address form.
+__device__ __forceinline__ double horner_s(double acc, double p, double c_uniform) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(acc), "v"(p), "s"(c_uniform));
+  return d;
+}
+struct MergedSums { double S1, S2, S3; };
+template <int MODE, int KD>
+__device__ __forceinline__ MergedSums pade_merged(const double (&Dc)[5], const double* __restrict__ q, double p) {
+  double D = Dc[KD], n1 = q[KD - 1];
+#pragma unroll
+  for (int i = KD - 1; i >= 0; --i) D = fma(D, p, Dc[i]);
+#pragma unroll
+  for (int i = KD - 2; i >= 0; --i) n1 = horner_s(n1, p, q[i]);
+  const double id = fast_rcp(D);
+  MergedSums m;
+  m.S1 = n1 * id; m.S2 = 0.0; m.S3 = 0.0;
+  if (MODE >= 1) {
+    double n2 = q[4 + 2 * KD - 2];
+#pragma unroll
+    for (int i = 2 * KD - 3; i >= 0; --i) n2 = horner_s(n2, p, q[4 + i]);
+    const double id2 = id * id;
+    m.S2 = n2 * id2;
+    if (MODE == 2) {
+      double n3 = q[11 + 3 * KD - 3];
+#pragma unroll
+      for (int i = 3 * KD - 4; i >= 0; --i) n3 = horner_s(n3, p, q[11 + i]);
+      m.S3 = n3 * (id2 * id);
+    }
+  }
+  return m;
+}
+
+// r = sqrt(x) by the compiler's own sequence for v_rsq_f64 (one coupled Goldschmidt step, two corrections: bitwise the library
+// result for normal x) without its scaling of arguments below 2^-767 and its zero / infinity fix-up, and 1 / r from the
+// half-reciprocal the sequence carries (one Newton step: relative error ~1e-16) instead of v_rcp_f64 + two steps.  x = 0 (two
+// particles on one point) gives r = 0, 1 / r = +inf as sqrt + fast_rcp do.
+__device__ __forceinline__ void sqrt_rinv(double x, double& r, double& rinv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g); h = fma(h, e, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  d = fma(-g, g, x);
+  g = fma(d, h, g);
+  const double t = h + h;
+  double ri = fma(t, fma(-g, t, 1.0), t);
+  if (x == 0.0) { g = 0.0; ri = INFINITY; }
+  r = g; rinv = ri;
+}
+// rad_shared with 1 / r handed in
+template <int MODE>
+__device__ __forceinline__ RadShared rad_shared_ri(double r, double inv_r, double inv_rcut) {
+  RadShared s;
+  s.r = r;
+  s.y = r * inv_rcut;
+  s.z1 = s.y - 1.0;
+  s.z12 = s.z1 * s.z1;
+  s.p = (3.0 * s.z12 + 4.0 * s.z1) * s.z12 + 1.0;
+  s.omp = 1.0 - s.p;
+  s.c0 = -12.0 * inv_rcut * inv_rcut * s.z12;
+  s.b = (s.z12 * s.z1 + 1.0) * (1.0 / 3.0);
+  s.inv_r = inv_r;
+  s.t5 = 0.0; s.q = 0.0;
+  if (MODE == 2) {
+    s.t5 = 5.0 + 2.0 * fast_rcp(s.z1);
+    s.q = 24.0 * s.y * s.y * s.z12;
+  }
+  return s;
+}
+
 // value of one radial function for r < rcut (sums maintenance: recompute / protocol update)
 __device__ __forceinline__ double jas_value1(int kind, double par, double aux, double rcut, double r) {
   const RadShared s = rad_shared<0>(r, 1.0 / rcut);

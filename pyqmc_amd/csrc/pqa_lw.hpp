@@ -197,11 +197,97 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
   }
   U = u_; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
 }
+// MERGED (S.jq_on; callers whose electron AND partner index are wave-uniform, UJ): the Pade functions of a basis as one rational function of p
+// per pair (pade_merged), the numerator record picked by the pair's spin channel / the ion with scalar selects and loads; a cusp
+// function at index 0 is evaluated as before.  r and 1 / r from one v_rsq_f64 (sqrt_rinv).  Same sums as the FAST route up to
+// rounding (the reciprocals are not the same operations), a third fewer instructions per pair.
 template <int MODE, bool PBC>
+__device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* xt, long W, long w, int e,
+                                                double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
+                                                double (&g)[3], double& lapU, double& ee, double& ei, int skip, bool ions) {
+  j0 = __builtin_amdgcn_readfirstlane(j0); dj = __builtin_amdgcn_readfirstlane(dj); skip = __builtin_amdgcn_readfirstlane(skip);
+  e = __builtin_amdgcn_readfirstlane(e);  // UJ callers: the electron is wave-uniform too (kernel argument / block index)
+  const int edown = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
+  const bool jb_on = has_jastrow && S.nb > 0, ja_on = has_jastrow && S.na > 0;
+  const bool bcusp = S.b_kind[0] == 1, acusp = S.a_kind[0] == 1;
+  const double bcp = S.b_param[0], bca = S.b_aux[0], acp = S.a_param[0], aca = S.a_aux[0];
+  const double bcc0 = (jb_on && bcusp) ? S.bcoeff[edown] : 0.0, bcc1 = (jb_on && bcusp) ? S.bcoeff[edown + 1] : 0.0;
+  const double* qb0 = S.bq + edown * PQA_JQ;
+  double Db[5], Da[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { Db[i] = S.b_D[i]; Da[i] = S.a_D[i]; }
+  const bool kb4 = S.jq_b > 3, ka4 = S.jq_a > 3;
+  for (int jb = j0; jb < S.nelec; jb += PQA_JAS_PF * dj) {
+    double cx[PQA_JAS_PF], cy[PQA_JAS_PF], cz[PQA_JAS_PF];
+#pragma unroll
+    for (int u = 0; u < PQA_JAS_PF; ++u) {
+      const int j = jb + u * dj;
+      const double* xj = xt + (size_t)(j < S.nelec ? j : e) * 3 * W + w;
+      cx[u] = xj[0]; cy[u] = xj[W]; cz[u] = xj[2 * W];
+    }
+#pragma unroll
+    for (int u = 0; u < PQA_JAS_PF; ++u) {
+      const int j = jb + u * dj;
+      if (j >= S.nelec || j == e || j == skip) continue;
+      double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
+      if (PBC) min_image_j(S, dx, dy, dz);
+      double r, ri;
+      sqrt_rinv(dx * dx + dy * dy + dz * dz, r, ri);
+      if (MODE == 2 && j > e) see += ri;
+      if (jb_on && r < S.rcut_b) {
+        const RadShared sh = rad_shared_ri<MODE>(r, ri, irb);
+        const bool hi = j >= S.nup;
+        const double* q = qb0 + (hi ? PQA_JQ : 0);
+        const MergedSums m = kb4 ? pade_merged<MODE, 4>(Db, q, sh.p) : pade_merged<MODE, 3>(Db, q, sh.p);
+        u_ += sh.omp * m.S1;
+        double sg = sh.c0 * m.S2;
+        if (MODE == 2) lp += sh.c0 * (sh.t5 * m.S2 - sh.q * m.S3);
+        if (bcusp) {
+          double v, gf, lpl;
+          rad_fn<MODE>(1, bcp, bca, S.rcut_b, sh, v, gf, lpl);
+          const double c = hi ? bcc1 : bcc0;
+          u_ += c * v;
+          if (MODE >= 1) sg += c * gf;
+          if (MODE == 2) lp += c * lpl;
+        }
+        if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
+      }
+    }
+  }
+  for (int I = ions ? j0 : S.natom; I < S.natom; I += dj) {
+    double dx = rx - S.atom_xyz[3 * I], dy = ry - S.atom_xyz[3 * I + 1], dz = rz - S.atom_xyz[3 * I + 2];
+    const double* q = S.aq + (size_t)(I * 2 + edown) * PQA_JQ;
+    const double acc = (ja_on && acusp) ? S.acoeff[(I * S.na) * 2 + edown] : 0.0;
+    if (PBC) min_image_j(S, dx, dy, dz);
+    double r, ri;
+    sqrt_rinv(dx * dx + dy * dy + dz * dz, r, ri);
+    if (MODE == 2) sei -= S.atom_charge[I] * ri;
+    if (ja_on && r < S.rcut_a) {
+      const RadShared sh = rad_shared_ri<MODE>(r, ri, ira);
+      const MergedSums m = ka4 ? pade_merged<MODE, 4>(Da, q, sh.p) : pade_merged<MODE, 3>(Da, q, sh.p);
+      u_ += sh.omp * m.S1;
+      double sg = sh.c0 * m.S2;
+      if (MODE == 2) lp += sh.c0 * (sh.t5 * m.S2 - sh.q * m.S3);
+      if (acusp) {
+        double v, gf, lpl;
+        rad_fn<MODE>(1, acp, aca, S.rcut_a, sh, v, gf, lpl);
+        u_ += acc * v;
+        if (MODE >= 1) sg += acc * gf;
+        if (MODE == 2) lp += acc * lpl;
+      }
+      if (MODE >= 1) { gx += sg * dx; gy += sg * dy; gz += sg * dz; }
+    }
+  }
+  U = u_; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
+}
+template <int MODE, bool PBC, bool UJ = false>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
-  if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  if (UJ && S.jq_on) jas_eval_lane_m<MODE, PBC>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
   else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
 }
 // Jastrow part of group g's partial sums of electron e at (px, py, pz): value and gradient over the partners j = g, g + G, ...
@@ -209,16 +295,16 @@ __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt,
 // the group that owns it (skip mod G) — the old-position sums of the next electron to be proposed leave out the electron that
 // has just been decided, the one partner whose position is not known before that decision: everything else can be (and, for
 // large shards, is) summed ahead by k_jas_pre while the orbital kernel runs.  `pre` (non-null): that partial, [G][4][W].
-template <bool PBC>
+template <bool PBC, bool UJ = false>
 __device__ __forceinline__ void lw_jastrow_part(const SysDev& S, const LwState& L, int e, int has_jastrow, double px, double py, double pz, long W, long w,
                                                 int g, int G, int skip, const double* __restrict__ pre, double& U, double (&gg)[3]) {
   double lp, ee, ei;
   if (pre) {
     U = pre[((size_t)g * 4 + 0) * W + w]; gg[0] = pre[((size_t)g * 4 + 1) * W + w]; gg[1] = pre[((size_t)g * 4 + 2) * W + w]; gg[2] = pre[((size_t)g * 4 + 3) * W + w];
-  } else jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei, skip);
+  } else jas_eval_lane<1, PBC, UJ>(S, L.xt, W, w, e, px, py, pz, has_jastrow, g, G, U, gg, lp, ee, ei, skip);
   if (skip >= 0 && skip % G == g) {  // the one pair, at the partner's settled position
     double u1, g1[3];
-    jas_eval_lane<1, PBC>(S, L.xt, W, w, e, px, py, pz, has_jastrow, skip, S.nelec, u1, g1, lp, ee, ei, -1, false);
+    jas_eval_lane<1, PBC, UJ>(S, L.xt, W, w, e, px, py, pz, has_jastrow, skip, S.nelec, u1, g1, lp, ee, ei, -1, false);
     U += u1; gg[0] += g1[0]; gg[1] += g1[1]; gg[2] += g1[2];
   }
 }
@@ -238,7 +324,7 @@ __device__ __forceinline__ void lw_jastrow_part(const SysDev& S, const LwState& 
 // Share of thread group g (of G) in the sums of electron e of walker w at (px, py, pz): Slater sums of the orbital row
 // `row` ([5][nmo], point-major: the proposal's row or the cached one) against the inverse row, Jastrow sums against the
 // walker's coordinates; p[] in the row order above.
-template <bool PBC, bool CX>
+template <bool PBC, bool CX, bool UJ = false>
 __device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, int e, int has_jastrow, double px, double py, double pz,
                                              const double* row, long W, long w, int g, int G,
                                              double (&p)[PQA_LW_PART_ROWS(CX)], int jskip = -1, const double* __restrict__ jpre = nullptr) {
@@ -313,7 +399,7 @@ __device__ __forceinline__ void lw_move_sums(const SysDev& S, const LwState& L, 
 #endif
   double U = 0.0, gg[3] = {0.0, 0.0, 0.0};
 #ifndef PQA_MP_NOJAS
-  lw_jastrow_part<PBC>(S, L, e, has_jastrow, px, py, pz, W, w, g, G, jskip, jpre, U, gg);
+  lw_jastrow_part<PBC, UJ>(S, L, e, has_jastrow, px, py, pz, W, w, g, G, jskip, jpre, U, gg);
 #endif
   if (CX) {  // rows: Re r0, Im r0, Re r1, Im r1, ..., then U, grad U
     p[0] = r0; p[1] = q0; p[2] = r1; p[3] = q1; p[4] = r2; p[5] = q2; p[6] = r3; p[7] = q3;
@@ -493,7 +579,7 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
     double v[PR];
     {
       double p[PR];
-      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], row, W, w, g, G, p, -1, a.jnew);
+      lw_move_sums<PBC, CX, WIDE>(S, L, e, a.has_jastrow, mb.newpos[3 * w], mb.newpos[3 * w + 1], mb.newpos[3 * w + 2], row, W, w, g, G, p, -1, a.jnew);
 #pragma unroll
       for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
     }
@@ -665,7 +751,7 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
       const int s = e >= S.nup, i = e - s * S.nup;
       const double* xe = L.xt + (size_t)e * 3 * W + w;
       const double* row = lw_row(L, s, i, L.sel[s][(size_t)i * W + w], w, W, S.nmo[s]);  // cached row of the current position
-      lw_move_sums<PBC, CX>(S, L, e, a.has_jastrow, xe[0], xe[W], xe[2 * W], row, W, w, g, G, p, a.j_skip, a.jold);
+      lw_move_sums<PBC, CX, WIDE>(S, L, e, a.has_jastrow, xe[0], xe[W], xe[2 * W], row, W, w, g, G, p, a.j_skip, a.jold);
 #pragma unroll
       for (int c = 0; c < PR; ++c) sh[(c * G + g) * NW + lane] = p[c];
     }
@@ -1316,7 +1402,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
   }
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double U, gj[3], lj, ee, ei;
-  jas_eval_lane<2, PBC>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
+  jas_eval_lane<2, PBC, true>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
   lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
   const double gx = gs0 + gj[0], gy = gs1 + gj[1], gz = gs2 + gj[2];
   const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);
