@@ -7,10 +7,15 @@
 * the CURRENT walkers: ``configs`` (nconf, nelec, 3), periodic runs also ``wrap``, DMC also ``weights`` — overwritten every
   block (the restart state: a run continues from ``block[-1] + 1``, mc.py:235-243).
 
-Two back ends behind one interface.  With ``h5py`` importable the file IS that HDF5 file (``read_mc_output`` of the reference
-reads it).  This image ships no HDF5 library, so otherwise the same layout goes into two NumPy archives — ``<name>.blocks.npz``
-(an append-only zip: member ``<dataset>/<block index>.npy``) and ``<name>.state.npz`` (configs / wrap / weights, replaced
-atomically) — and ``to_hdf5`` converts them wherever h5py exists.  ``read_mc_output`` here reads either form.
+Two back ends behind one interface.  With ``h5py`` importable the file IS that HDF5 file — the reference's
+``read_mc_output`` / ``Configs.load_hdf`` read it and files written by the reference's ``hdftools`` are read and continued here
+(``tools/verify_hdf5_with_reference.py``, real h5py 3.3.0 / HDF5 1.10.6: ``profiles/r04_f4_reference_hdf5.txt``).  The interpreter
+the GPU stack runs under has no h5py, so otherwise the same layout goes into two NumPy archives — ``<name>.blocks.npz`` (an
+append-only zip: member ``<dataset>/<block index>.npy``) and ``<name>.state.npz`` (configs / wrap / weights, replaced
+atomically) — and ``to_hdf5`` converts them: in-process where h5py exists, else through any interpreter that has it
+(``PQA_H5PY_PYTHON``; this image: ``/opt/conda/bin/python3.9``).  ``read_mc_output`` here reads either form.  One deliberate
+difference from the reference's file: the walkers are stored as float64 (the reference's ``initialize_hdf`` names no dtype and
+h5py then keeps float32: its restarts round the walkers; ``load_hdf`` accepts either).
 """
 
 import io
@@ -152,10 +157,33 @@ class BlockFile:
         return {k: (tuple(v.shape), v.dtype.kind) for k, v in self.datasets(with_state=True).items()}
 
 
+def h5py_interpreter():
+    """An interpreter with h5py + numpy for ``to_hdf5`` where this one has none: ``$PQA_H5PY_PYTHON``, else the image's Anaconda
+    python; None if neither works."""
+    import subprocess
+
+    for cand in (os.environ.get("PQA_H5PY_PYTHON"), "/opt/conda/bin/python3.9"):
+        if cand and os.path.exists(cand):
+            if subprocess.run([cand, "-c", "import h5py, numpy"], capture_output=True).returncode == 0:
+                return cand
+    return None
+
+
 def to_hdf5(src, dst):
-    """Convert an npz block store into the reference's HDF5 file (needs h5py; run it where that exists)."""
+    """Convert an npz block store into the reference's HDF5 file: with h5py in-process, else by running this module's converter
+    under an interpreter that has h5py (``h5py_interpreter``); RuntimeError if there is none."""
     if h5py is None:
-        raise RuntimeError("to_hdf5 needs h5py")
+        import subprocess
+
+        py = h5py_interpreter()
+        if py is None:
+            raise RuntimeError("to_hdf5 needs h5py (none importable here, no interpreter with h5py found: set PQA_H5PY_PYTHON)")
+        code = ("import importlib.util, sys; sp = importlib.util.spec_from_file_location('pqa_blockfile', sys.argv[1]); "
+                "m = importlib.util.module_from_spec(sp); sp.loader.exec_module(m); m.to_hdf5(sys.argv[2], sys.argv[3])")
+        r = subprocess.run([py, "-W", "ignore", "-c", code, os.path.abspath(__file__), src, dst], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("to_hdf5 under " + py + " failed: " + r.stderr[-500:])
+        return
     store = BlockFile(src, backend="npz")
     with h5py.File(dst, "w") as f:
         for k, v in store.datasets().items():

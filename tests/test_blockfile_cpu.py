@@ -67,8 +67,21 @@ def test_periodic_walkers_keep_wrap_counters_and_h5py_absence_is_loud(tmp_path):
     if blockfile.h5py is None:
         with pytest.raises(RuntimeError, match="h5py"):
             blockfile.BlockFile(str(tmp_path / "q"), backend="h5py")
-        with pytest.raises(RuntimeError, match="h5py"):
+        py = blockfile.h5py_interpreter()
+        if py is None:
+            with pytest.raises(RuntimeError, match="h5py"):
+                blockfile.to_hdf5(str(tmp_path / "p"), str(tmp_path / "p.h5"))
+        else:  # the converter runs under the interpreter that has h5py: a real HDF5 file with the same datasets and walkers
+            import subprocess
+
             blockfile.to_hdf5(str(tmp_path / "p"), str(tmp_path / "p.h5"))
+            assert open(tmp_path / "p.h5", "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+            code = ("import h5py, json, sys; f = h5py.File(sys.argv[1], 'r'); "
+                    "print(json.dumps({k: [list(f[k].shape), f[k].dtype.kind, f[k][()].tolist(), f[k].maxshape[0] is None] for k in f}))")
+            got = json.loads(subprocess.run([py, "-W", "ignore", "-c", code, str(tmp_path / "p.h5")], capture_output=True, text=True, check=True).stdout)
+            assert sorted(got) == ["block", "configs", "energytotal", "wrap"] and all(v[3] for v in got.values())
+            assert np.array_equal(np.array(got["configs"][2]), cfg.configs) and np.array_equal(np.array(got["wrap"][2]), cfg.wrap)
+            assert got["energytotal"][:3] == [[1], "f", [1.0]] and got["block"][:3] == [[1], "i", [0]]
 
 
 @pytest.fixture(params=["h5py", "stand-in"])
@@ -76,7 +89,8 @@ def h5(request, monkeypatch):
     """The HDF5 back end under test: the real h5py where it exists, and ALWAYS the in-memory stand-in (tests/fake_h5py.py),
     which is how the h5py branches of blockfile.py execute in images without an HDF5 library."""
     if request.param == "h5py":
-        return pytest.importorskip("h5py")
+        yield pytest.importorskip("h5py")
+        return
     import fake_h5py
 
     monkeypatch.setattr(blockfile, "h5py", fake_h5py)
@@ -172,3 +186,38 @@ def test_chkfile_h5py_branch_on_the_reference_checkpoint(monkeypatch):
     for s in (0, 1):
         for k in range(8):
             assert np.array_equal(f1.mo_coeff[s][k], f2.mo_coeff[s][k]) and np.array_equal(f1.mo_occ[s][k], f2.mo_occ[s][k])
+
+
+def h5py_interpreter():
+    """An interpreter that has h5py, numpy and pytest (this image: the Anaconda python under /opt/conda; PQA_H5PY_PYTHON names another)."""
+    import shutil
+    import subprocess
+
+    for cand in (os.environ.get("PQA_H5PY_PYTHON"), "/opt/conda/bin/python3.9", shutil.which("python3.9")):
+        if cand and os.path.exists(cand):
+            r = subprocess.run([cand, "-c", "import h5py, numpy, pytest, scipy"], capture_output=True)
+            if r.returncode == 0:
+                return cand
+    return None
+
+
+@pytest.mark.skipif(blockfile.h5py is not None, reason="h5py is importable here: the [h5py] cases above already ran")
+def test_h5py_branches_against_a_real_hdf5_library_in_another_interpreter():
+    """This interpreter has no h5py, the image's Anaconda python has (h5py 3.3.0 / HDF5 1.10.6): the [h5py] cases of this file
+    (block round trip, restart, resize, converter, read_mc_output, vmc / rundmc writing and continuing their files) and the
+    chkfile tests (h5py back end and the built-in parser against the real library on the reference's checkpoints) run THERE.
+    tools/verify_hdf5_with_reference.py (profiles/r04_f4_reference_hdf5.txt) is the same against the reference's own
+    read_mc_output / hdftools / Configs.to_hdf."""
+    import subprocess
+
+    py = h5py_interpreter()
+    if py is None:
+        pytest.skip("no interpreter with h5py in this image")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([py, "-m", "pytest", "-q", "-p", "no:cacheprovider", "-rA", "-W", "ignore", os.path.join(here, "test_blockfile_cpu.py"),
+                        os.path.join(here, "test_chkfile_cpu.py"), "-k", "h5py"], capture_output=True, text=True, cwd=os.path.dirname(here), timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    for name in ("test_h5py_backend_round_trip_matches_the_npz_store[h5py]", "test_vmc_and_rundmc_write_through_the_h5py_backend[h5py]",
+                 "test_scan_and_h5py_backends_agree_and_errors_are_loud"):
+        assert f"PASSED tests/test_blockfile_cpu.py::{name}" in out or f"PASSED tests/test_chkfile_cpu.py::{name}" in out, out[-3000:]

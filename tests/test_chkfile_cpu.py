@@ -59,6 +59,14 @@ def test_scan_and_h5py_backends_agree_and_errors_are_loud(tmp_path):
         assert chkfile.read_mol_json(path, backend="h5py") == d
         mol, mf = chkfile.load_scf(path)
         assert len(mf.mo_coeff) > 0
+        # the built-in parser (hdf5lite) against the real HDF5 library on both of the reference's files: every SCF dataset equal
+        for name in ("diamond_primitive", "li_cubic_ccecp"):
+            p2 = os.path.join(FILES, name + ".hdf5")
+            (m1, f1), (m2, f2) = chkfile.load_scf(p2, backend="h5py"), chkfile.load_scf(p2, backend="lite")
+            assert np.array_equal(f1.kpts, f2.kpts) and f1.e_tot == f2.e_tot and m1.nelec == m2.nelec
+            c1, c2 = np.asarray(f1.mo_coeff), np.asarray(f2.mo_coeff)
+            o1, o2 = np.asarray(f1.mo_occ), np.asarray(f2.mo_occ)
+            assert c1.shape == c2.shape and c1.dtype == c2.dtype and np.array_equal(c1, c2) and np.array_equal(o1, o2)
     junk = tmp_path / "junk.bin"
     junk.write_bytes(b"\x89HDF" + b'{"atom": broken' + bytes(100))
     with pytest.raises(ValueError, match="no PySCF mol JSON"):
