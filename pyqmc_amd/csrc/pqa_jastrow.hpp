@@ -104,26 +104,28 @@ __device__ __forceinline__ double horner_s(double acc, double p, double c_unifor
   return d;
 }
 struct MergedSums { double S1, S2, S3; };
-template <int MODE, int KD>
+// UNI: the record pointer is wave-uniform (scalar loads, horner_s); otherwise it may differ between lanes (vector loads, plain fma)
+template <int MODE, int KD, bool UNI = true>
 __device__ __forceinline__ MergedSums pade_merged(const double (&Dc)[5], const double* __restrict__ q, double p) {
+  auto step = [&](double acc, double c) { return UNI ? horner_s(acc, p, c) : fma(acc, p, c); };
   double D = Dc[KD], n1 = q[KD - 1];
 #pragma unroll
   for (int i = KD - 1; i >= 0; --i) D = fma(D, p, Dc[i]);
 #pragma unroll
-  for (int i = KD - 2; i >= 0; --i) n1 = horner_s(n1, p, q[i]);
+  for (int i = KD - 2; i >= 0; --i) n1 = step(n1, q[i]);
   const double id = fast_rcp(D);
   MergedSums m;
   m.S1 = n1 * id; m.S2 = 0.0; m.S3 = 0.0;
   if (MODE >= 1) {
     double n2 = q[4 + 2 * KD - 2];
 #pragma unroll
-    for (int i = 2 * KD - 3; i >= 0; --i) n2 = horner_s(n2, p, q[4 + i]);
+    for (int i = 2 * KD - 3; i >= 0; --i) n2 = step(n2, q[4 + i]);
     const double id2 = id * id;
     m.S2 = n2 * id2;
     if (MODE == 2) {
       double n3 = q[11 + 3 * KD - 3];
 #pragma unroll
-      for (int i = 3 * KD - 4; i >= 0; --i) n3 = horner_s(n3, p, q[11 + i]);
+      for (int i = 3 * KD - 4; i >= 0; --i) n3 = step(n3, q[11 + i]);
       m.S3 = n3 * (id2 * id);
     }
   }

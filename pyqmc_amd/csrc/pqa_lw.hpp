@@ -201,12 +201,17 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 // per pair (pade_merged), the numerator record picked by the pair's spin channel / the ion with scalar selects and loads; a cusp
 // function at index 0 is evaluated as before.  r and 1 / r from one v_rsq_f64 (sqrt_rinv).  Same sums as the FAST route up to
 // rounding (the reciprocals are not the same operations), a third fewer instructions per pair.
-template <int MODE, bool PBC>
+// UNI = false: electron and partner index may differ between lanes (the narrow step kernel, the ECP passes): the same code with
+// per-lane table reads — taken only where the FAST route does not apply (more than PQA_JAS_NF functions in a basis, i.e. the
+// ion-cusp function of all-electron atoms next to four Pade functions), instead of the table walk in the innermost loop.
+template <int MODE, bool PBC, bool UNI = true>
 __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                                 double (&g)[3], double& lapU, double& ee, double& ei, int skip, bool ions) {
-  j0 = __builtin_amdgcn_readfirstlane(j0); dj = __builtin_amdgcn_readfirstlane(dj); skip = __builtin_amdgcn_readfirstlane(skip);
-  e = __builtin_amdgcn_readfirstlane(e);  // UJ callers: the electron is wave-uniform too (kernel argument / block index)
+  if (UNI) {
+    j0 = __builtin_amdgcn_readfirstlane(j0); dj = __builtin_amdgcn_readfirstlane(dj); skip = __builtin_amdgcn_readfirstlane(skip);
+    e = __builtin_amdgcn_readfirstlane(e);  // UJ callers: the electron is wave-uniform too (kernel argument / block index)
+  }
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
@@ -240,7 +245,7 @@ __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* x
         const RadShared sh = rad_shared_ri<MODE>(r, ri, irb);
         const bool hi = j >= S.nup;
         const double* q = qb0 + (hi ? PQA_JQ : 0);
-        const MergedSums m = kb4 ? pade_merged<MODE, 4>(Db, q, sh.p) : pade_merged<MODE, 3>(Db, q, sh.p);
+        const MergedSums m = kb4 ? pade_merged<MODE, 4, UNI>(Db, q, sh.p) : pade_merged<MODE, 3, UNI>(Db, q, sh.p);
         u_ += sh.omp * m.S1;
         double sg = sh.c0 * m.S2;
         if (MODE == 2) lp += sh.c0 * (sh.t5 * m.S2 - sh.q * m.S3);
@@ -266,7 +271,7 @@ __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* x
     if (MODE == 2) sei -= S.atom_charge[I] * ri;
     if (ja_on && r < S.rcut_a) {
       const RadShared sh = rad_shared_ri<MODE>(r, ri, ira);
-      const MergedSums m = ka4 ? pade_merged<MODE, 4>(Da, q, sh.p) : pade_merged<MODE, 3>(Da, q, sh.p);
+      const MergedSums m = ka4 ? pade_merged<MODE, 4, UNI>(Da, q, sh.p) : pade_merged<MODE, 3, UNI>(Da, q, sh.p);
       u_ += sh.omp * m.S1;
       double sg = sh.c0 * m.S2;
       if (MODE == 2) lp += sh.c0 * (sh.t5 * m.S2 - sh.q * m.S3);
@@ -286,8 +291,10 @@ template <int MODE, bool PBC, bool UJ = false>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
-  if (UJ && S.jq_on) jas_eval_lane_m<MODE, PBC>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
-  else if (S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  const bool fast = S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF;
+  if (UJ && S.jq_on) jas_eval_lane_m<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else if (!UJ && S.jq_on && !fast) jas_eval_lane_m<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else if (fast) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
   else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
 }
 // Jastrow part of group g's partial sums of electron e at (px, py, pz): value and gradient over the partners j = g, g + G, ...

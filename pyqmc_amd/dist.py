@@ -42,13 +42,22 @@ def allreduce_block(local_sums, local_count, device=None):
     cplx = np.iscomplexobj(sums)  # complex wave functions: <acc>ecp and <acc>total are complex (eval_ecp.py:89); RCCL reduces reals
     flat = np.concatenate([sums.real, sums.imag]) if cplx else sums
     t = torch.tensor(np.concatenate([np.asarray(flat, dtype=np.float64), [float(local_count)]]), dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _world_one_collectives()):
         dist.all_reduce(t)
     t = t.cpu().numpy()
     means = t[:-1] / t[-1]
     if cplx:
         means = means[: len(sums)] + 1j * means[len(sums):]
     return means, t[-1]
+
+
+def _world_one_collectives():
+    """``PQA_DIST_WORLD1=1``: with a process group of ONE rank still take the collective routes (all-reduce, all-gather,
+    broadcast on the communicator; the exchange plan then keeps every walker) — how a single-GPU box executes the RCCL
+    (``backend="nccl"``) branches of this module: tests/test_gpu_fullsize.py::test_rccl_single_rank_communicator_...."""
+    import os
+
+    return os.environ.get("PQA_DIST_WORLD1", "0") == "1"
 
 
 def combine_blocks(block_avgs, counts):
@@ -110,7 +119,7 @@ def branch_distributed(configs, weights, base_u=None, dev=None, device_buffers=N
 
     from .dmc import comb_indices
 
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _world_one_collectives())):
         from .dmc import branch
 
         wstd = float(np.std(weights))

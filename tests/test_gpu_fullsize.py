@@ -316,6 +316,74 @@ def test_distributed_branching_exchanges_walkers_between_device_handles(periodic
         assert note(f"exchange_state_vs_recompute_{int(periodic)}_{int(bool(device_buffers))}_{r[0]}", np.max(np.abs(r[7] - r[8]))) < 1e-9
 
 
+def _rccl_single_rank_worker(port, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PQA_DIST_WORLD1="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import pyqmc_amd as pa
+        from pyqmc_amd import dist as pdist
+        from pyqmc_amd import dmc
+
+        assert dist.get_backend() == "nccl"
+        dist.barrier()
+        means, cnt = pdist.allreduce_block(np.array([3.0, 4.5 + 2.0j, -1.0]), 4)  # complex block entries: real / imaginary parts reduced apart
+        tmax = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks clock
+        table = [None]
+        dist.all_gather_object(table, {"rank": 0})  # bench.py's rank table
+        mol, wf = helpers.gpu_pbc_wf("fcc2cubic")
+        dev = wf.fused_device()
+        W = 53
+        cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(10))
+        wf.recompute(cfg)
+        dev.vmc_sweeps(0.3, 1, seed=3, energy=False)
+        cfg.configs[...] = dev.configs()
+        cfg.wrap += dev.wrap_delta()
+        x0, wr0 = cfg.configs.copy(), cfg.wrap.copy()
+        weights = np.random.default_rng(50).random(W) ** 3
+        cfg, w, info, wstd = pdist.branch_distributed(cfg, weights.copy(), base_u=0.37, dev=dev)
+        newinds = np.sort(dmc.comb_indices(weights, 0.37)[0])
+        after = dev.value()[1].copy()  # the state that followed the walkers through the gather
+        fresh = wf.recompute(cfg)[1]
+        q.put(dict(means=means, cnt=cnt, tmax=float(tmax.item()), table=table, same=bool(np.array_equal(cfg.configs, x0[newinds]) and np.array_equal(cfg.wrap, wr0[newinds])),
+                   info=info, w=w, wsum=float(weights.sum()), state=float(np.max(np.abs(after - fresh))), backend=dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_single_rank_communicator_runs_the_collective_routes():
+    """The RCCL (backend "nccl") branches of pyqmc_amd.dist on this one GPU: a one-rank communicator, and PQA_DIST_WORLD1=1 makes
+    allreduce_block / branch_distributed take their collective routes anyway — device tensors through all-reduce (sum and max),
+    all-gather, broadcast, barrier, all_gather_object; device-side packing is chosen because the backend is nccl; the exchange
+    plan keeps every walker.  What it cannot show: the point-to-point transfers (they need a second GPU; the two-handle gloo test
+    above moves walkers between handles through the same packing code)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(port, q))
+    p.start()
+    r = q.get(timeout=500)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and r["backend"] == "nccl"
+    assert np.allclose(r["means"], np.array([3.0, 4.5 + 2.0j, -1.0]) / 4) and r["cnt"] == 4 and r["tmax"] == 1.25 and r["table"] == [{"rank": 0}]
+    assert r["same"] and r["info"]["walkers moved"] == 0 and r["info"]["device_buffers"] is True and r["state"] < 1e-9
+    assert np.allclose(r["w"], r["wsum"] / len(r["w"]))
+
+
 def test_energy_statistics_against_the_oracle():
     """north_star: "energies within 1 mHa statistical error of reference" — as a test that can fail.  Trial function: H2O with
     the orbitals of a model one-electron Hamiltonian (systems.model_mf) and the cusp-only default Jastrow, sigma(E_L) ~ 1.6 Ha

@@ -91,3 +91,26 @@ def test_merged_pade_sums_in_a_periodic_cell(monkeypatch):
         res[merge] = _sweep(wf, start.copy(), nsteps=1)
     _compare(res["1"], res["0"], tol_e=1e-8)
     assert not np.array_equal(res["1"]["x"], res["0"]["x"])
+
+
+def test_ion_cusp_basis_on_the_small_shard_and_ecp_routes(monkeypatch):
+    """Five functions in the electron-ion basis (the ion cusp of all-electron atoms + four Pade functions) are more than the
+    register-table route of the pair loops takes: where electron or partner index differs between lanes (the narrow step kernel
+    small shards fall back to, the ECP list pass) the merged tables are read per lane instead of walking the function tables in
+    the innermost loop.  Default kernel selection at 300 walkers, tables on / off."""
+    import pyqmc_amd as pa
+
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    start = pa.initial_guess(mol, 300, rng=np.random.default_rng(5)).configs
+    res = {}
+    for merge in ("1", "0"):
+        monkeypatch.setenv("PQA_JAS_MERGE", merge)
+        wf = pa.generate_wf(mol, mf, jastrow_kws=dict(ion_cusp=["O"]))
+        a0 = np.array(wf.parameters["wf2acoeff"])
+        a = 0.05 * np.random.default_rng(11).standard_normal(a0.shape)
+        a[:, 0, :] = a0[:, 0, :]
+        wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, helpers.jastrow_params(mol)[1]
+        res[merge] = _sweep(wf, OpenConfigs(start.copy()))
+    _compare(res["1"], res["0"])
+    assert not np.array_equal(res["1"]["x"], res["0"]["x"])

@@ -6,6 +6,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/evidence; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 W=${BENCH_WALKERS:-65536}
 lscpu > $O/host_lscpu.txt
+[ -x $R/tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/pmc_calib.hip -o $R/tools/pmc_calib 2>/dev/null  # (git-ignored binary: a fresh checkout has none)
 (cd $R && python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d /tmp/pm_$c -o t -- python $R/bench.py --walkers $W --steps 2 --warmup 1 --settle 2 --no-cpu-baseline --no-profile --no-extra > /dev/null 2>&1 < /dev/null
