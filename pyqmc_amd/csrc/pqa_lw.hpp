@@ -913,11 +913,18 @@ __device__ __forceinline__ void jas_pre(const SysDev& S, const JasTabs& J, int e
 // GW = 32 / 64 (round 4): 16 walkers x GW groups = 512 / 1024 threads — two / ONE partner electron and ion per thread, so the two
 // Jastrow pair loops that made up most of the ~3000-instruction dependent chain of a launch become one or two pair evaluations;
 // the groups' partial sums are totalled by eight threads per walker (one per row of the sums, group order) instead of by every thread.
+#ifdef PQA_PRE_CLK  // timing build only (tools/scratch/pre_clk.py): 100 MHz stamps of the phases of the first 256 blocks of the LAST launch
+static __device__ unsigned long long pqa_pre_clk[256 * 16];
+#define PQA_PCLK(k) do { if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PQA_PCLK(k) do { } while (0)
+#endif
 template <bool PBC, int NMAX, int GW = 16>
 static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a) {
   extern __shared__ double sh[];
   constexpr int PR = 8, JU = 4, NF = PQA_JAS_NF;
   constexpr int NS = GW == 16 ? (NMAX + 7) / 8 : (NMAX + GW - 1) / GW, NP = GW == 16 ? PQA_PRE_NP : 64 / GW, NA = GW == 16 ? PQA_PRE_NA : 64 / GW;
+  PQA_PCLK(0);
   const int NW = a.NW, G = a.G;
   const int lane = (int)threadIdx.x % NW, g = (int)threadIdx.x / NW;
   const long W = a.W;
@@ -1022,6 +1029,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       for (int u = 0; u < NS; ++u) rv2[c][u] = (jb2 + u < je2) ? row2[c * nmo2 + jb2 + u] : 0.0;
   }
   bool acc = false;
+  PQA_PCLK(1);
   if (has_a) {
     const int e = ea;
     {
@@ -1029,8 +1037,14 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 #pragma unroll
       for (int u = 0; u < NS; ++u)
         if (jb + u < je) { const double t = tinv[u]; r0 += rv[0][u] * t; r1 += rv[1][u] * t; r2 += rv[2][u] * t; r3 += rv[3][u] * t; }
+#ifdef PQA_PRE_CLK
+      if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 2] = wall_clock64() + (r0 == 1.2345e300 ? 1 : 0);  // the Slater sums (= every load of the first two round trips) done
+#endif
       double U, gg[3];
       jas_pre<PBC, NP, NA>(S, J, e, npx, npy, npz, a.has_jastrow, g, G, pcx, pcy, pcz, atx, aty, atz, bcA0, bcA1, acA, U, gg);
+#ifdef PQA_PRE_CLK
+      if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 3] = wall_clock64() + (U == 1.2345e300 ? 1 : 0);  // this thread's Jastrow pairs done
+#endif
 #if PQA_PRE_DBG & 1
       double p[PR];
       lw_move_sums<PBC, false>(S, L, e, a.has_jastrow, npx, npy, npz, lw_row(L, s, i, cur ^ 1, w, W, nmo), W, w, g, G, p);
@@ -1045,6 +1059,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       for (int c = 0; c < PR; ++c) shP[(c * G + g) * NW + lane] = p[c];
     }
     __syncthreads();
+    PQA_PCLK(4);
     double v[PR];
     if (GW > 16) {
       if (g < PR) {
@@ -1053,6 +1068,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
         shTot[g * NW + lane] = tsum;
       }
       __syncthreads();
+      PQA_PCLK(5);
 #pragma unroll
       for (int c = 0; c < PR; ++c) v[c] = shTot[c * NW + lane];
     } else {
@@ -1094,6 +1110,9 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       u = u01(ph.c[0], ph.c[1]);
     }
     acc = ratio > u;
+#ifdef PQA_PRE_CLK
+    if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 6] = wall_clock64() + (acc ? 0 : 0);  // decided
+#endif
     if (lead) {
       if (mb.dmc) {
         const double rx = a0 + d0, ry = a1 + d1, rz = a2 + d2;
@@ -1135,6 +1154,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       }
     }
     __syncthreads();
+    PQA_PCLK(7);
     // ---- this group's row of the electron block
     if (has_row) {
       double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
@@ -1150,14 +1170,21 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
           if (k < n) tmp += shV[k * NW + lane] * tb[k];
+#ifdef PQA_PRE_CLK
+        if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 12] = wall_clock64() + (tmp == 1.2345e300 ? 1 : 0);
+#endif
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
           if (k < n) tb[k] = acc ? tb[k] - shR[k * NW + lane] * tmp : tb[k];
+#ifdef PQA_PRE_CLK
+        if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 13] = wall_clock64() + (tb[0] == 1.2345e300 ? 1 : 0);
+#endif
         if (live && any) {
 #pragma unroll
           for (int k = 0; k < NMAX; ++k)
             if (k < n) Tj[(size_t)k * W] = tb[k];
         }
+        PQA_PCLK(14);
         if (handoff && jrow == i2) {
 #pragma unroll
           for (int k = 0; k < NMAX; ++k)
@@ -1166,6 +1193,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       }
     }
     __syncthreads();
+    PQA_PCLK(8);
     // the accepted proposal replaces the electron's coordinate in the register copy
 #if PQA_PRE_DBG & 16
 #pragma unroll
@@ -1216,6 +1244,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       for (int c = 0; c < PR; ++c) shP[(c * G + g) * NW + lane] = p[c];
     }
     __syncthreads();
+    PQA_PCLK(9);
     if (GW > 16) {
       if (g < PR) {
         double tsum = 0.0;
@@ -1224,6 +1253,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
       }
       __syncthreads();
     }
+    PQA_PCLK(10);
     if (!lead) return;
     double v[PR];
     if (GW > 16) {
@@ -1258,6 +1288,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
     if (mb.dwrap) fold_cell(S, np_[0], np_[1], np_[2], mb.dwrap + 3 * w);  // make_irreducible, mc.py:121
     double* ao = L.auxt + w;
     ao[0] = z0; ao[W] = z1; ao[2 * W] = z2; ao[3 * W] = gx; ao[4 * W] = gy; ao[5 * W] = gz; ao[6 * W] = v[JU];
+    PQA_PCLK(11);
   }
 }
 

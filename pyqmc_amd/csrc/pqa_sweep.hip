@@ -418,6 +418,11 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   return 0;
 }
 
+#ifdef PQA_PRE_CLK  // timing build only (tools/scratch/pre_clk.py)
+extern "C" int pqa_debug_pre_clk(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_pre_clk), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 #ifdef PQA_WW_CLK  // timing build only (tools/scratch/ww_clk.py)
 extern "C" int pqa_debug_ww_clk(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_ww_clk), (size_t)n * sizeof(unsigned long long));
