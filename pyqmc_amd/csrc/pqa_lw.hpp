@@ -445,6 +445,12 @@ __device__ __forceinline__ void lw_slater_terms(const double (&v)[PR], double& g
 #ifndef PQA_FLUSH_WB
 #define PQA_FLUSH_WB 16
 #endif
+// PQA_ROWDOT — the order of a row's dot product V . T[j] in EVERY lane-per-walker kernel that updates rows (k_flush_lw, the commit
+// halves of k_step_lw and k_step_pre): four partial sums over the quarters [q NMAX/4, (q + 1) NMAX/4) of the row's NMAX-padded
+// columns, each in ascending k, combined as ((p0 + p1) + p2) + p3 (complex rows: quarters of the complex columns, real and imaginary
+// part alike).  One convention everywhere keeps the inverse independent of the block size KB bit for bit, and it is what lets the
+// small-shard kernel give a block row to FOUR threads, a quarter each (k_step_pre, GW > 16), instead of one thread walking 32 columns
+// while 24 of the 32 thread groups wait.  (Until the last session of round 4 the dot was one running sum over k.)
 // WB: walkers per block (16 rows groups at 16, 32 at 8: small walker counts get twice the blocks and one row per thread —
 // at 4 096 walkers a flush was 256 blocks of two-row threads, 40 us for 17 us of traffic)
 template <int NMAX, bool CX = false, int WB = PQA_FLUSH_WB>
@@ -495,14 +501,15 @@ static __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, in
       const double* Vq = shV + (size_t)q * L_ * WB + wl;
       const double* Rq = shR + (size_t)q * L_ * WB + wl;
       if (CX) {
-        double tmp = 0.0, tmi = 0.0;
+        double pr[4] = {0.0, 0.0, 0.0, 0.0}, pi[4] = {0.0, 0.0, 0.0, 0.0};  // row dot in four partial sums: PQA_ROWDOT below
 #pragma unroll
         for (int k = 0; k < NMAX / 2; ++k)
           if (2 * k < L_) {
             const double vr = Vq[(2 * k) * WB], vi = Vq[(2 * k + 1) * WB];
-            tmp += vr * t[2 * k] - vi * t[2 * k + 1];
-            tmi += vr * t[2 * k + 1] + vi * t[2 * k];
+            pr[k / (NMAX / 8)] += vr * t[2 * k] - vi * t[2 * k + 1];
+            pi[k / (NMAX / 8)] += vr * t[2 * k + 1] + vi * t[2 * k];
           }
+        const double tmp = ((pr[0] + pr[1]) + pr[2]) + pr[3], tmi = ((pi[0] + pi[1]) + pi[2]) + pi[3];
 #pragma unroll
         for (int k = 0; k < NMAX / 2; ++k)
           if (2 * k < L_) {
@@ -511,10 +518,11 @@ static __global__ __launch_bounds__(256) void k_flush_lw(SysDev S, LwState L, in
             t[2 * k + 1] -= rr * tmi + ri * tmp;
           }
       } else {
-        double tmp = 0.0;
+        double p4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
-          if (k < L_) tmp += Vq[k * WB] * t[k];
+          if (k < L_) p4[k / (NMAX / 4)] += Vq[k * WB] * t[k];
+        const double tmp = ((p4[0] + p4[1]) + p4[2]) + p4[3];
 #pragma unroll
         for (int k = 0; k < NMAX; ++k)
           if (k < L_) t[k] = t[k] - Rq[k * WB] * tmp;
@@ -713,17 +721,18 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
           continue;
         }
         double t[NMAX];
-        double tmp = 0.0, tmi = 0.0;
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) t[k] = (k < L_) ? Tj[(size_t)k * W] : 0.0;
         if (CX) {
+          double pr[4] = {0.0, 0.0, 0.0, 0.0}, pi[4] = {0.0, 0.0, 0.0, 0.0};  // PQA_ROWDOT
 #pragma unroll
           for (int k = 0; k < NMAX / 2; ++k)
             if (2 * k < L_) {  // tmp = sum_k V_k t_k (complex, no conjugation)
               const double vr = shV[(2 * k) * NW + lane], vi = shV[(2 * k + 1) * NW + lane];
-              tmp += vr * t[2 * k] - vi * t[2 * k + 1];
-              tmi += vr * t[2 * k + 1] + vi * t[2 * k];
+              pr[k / (NMAX / 8)] += vr * t[2 * k] - vi * t[2 * k + 1];
+              pi[k / (NMAX / 8)] += vr * t[2 * k + 1] + vi * t[2 * k];
             }
+          const double tmp = ((pr[0] + pr[1]) + pr[2]) + pr[3], tmi = ((pi[0] + pi[1]) + pi[2]) + pi[3];
           if (live) {
 #pragma unroll
             for (int k = 0; k < NMAX / 2; ++k)
@@ -735,9 +744,11 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
               }
           }
         } else {
+          double p4[4] = {0.0, 0.0, 0.0, 0.0};  // PQA_ROWDOT
 #pragma unroll
           for (int k = 0; k < NMAX; ++k)
-            if (k < L_) tmp += shV[k * NW + lane] * t[k];
+            if (k < L_) p4[k / (NMAX / 4)] += shV[k * NW + lane] * t[k];
+          const double tmp = ((p4[0] + p4[1]) + p4[2]) + p4[3];
           if (live) {
 #pragma unroll
             for (int k = 0; k < NMAX; ++k)
@@ -982,8 +993,14 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
   }
   int cur = 0, cur2 = 0;
   double npx = 0.0, npy = 0.0, npz = 0.0, ax7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, uu = 0.0;
-  double tinv[NS], tb[NMAX], tinv2[NS], xe2[3] = {0.0, 0.0, 0.0}, zt[3] = {0.0, 0.0, 0.0};
-  const int jrow = a.j_lo + g;  // block row of this group (one per group: the host checks j_hi - j_lo <= G)
+  // Block rows.  GW = 16: one row per group (the host checks j_hi - j_lo <= G).  GW > 16: one row per QUARTET of groups, group
+  // g holding the quarter g % 4 of the row's NMAX-padded columns (j_hi - j_lo <= G / 4): the row's dot product is the four
+  // quarter sums combined in the PQA_ROWDOT order, so the inverse stays bitwise what k_step_lw / k_flush_lw make of it.
+  constexpr bool QUART = GW > 16;
+  constexpr int QL = NMAX / 4, TBN = QUART ? QL : NMAX;
+  const int qd = QUART ? (g & 3) : 0, kq0 = qd * QL;
+  double tinv[NS], tb[TBN], tinv2[NS], xe2[3] = {0.0, 0.0, 0.0}, zt[3] = {0.0, 0.0, 0.0};
+  const int jrow = a.j_lo + (QUART ? (g >> 2) : g);
   const bool has_row = has_a && jrow < a.j_hi;
   if (has_a) {
     cur = L.sel[s][(size_t)i * W + w];
@@ -998,7 +1015,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
     if (has_row) {
       const double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k) tb[k] = (k < n) ? Tj[(size_t)k * W] : 0.0;
+      for (int u = 0; u < TBN; ++u) tb[u] = (kq0 + u < n) ? Tj[(size_t)(kq0 + u) * W] : 0.0;
     }
   }
   if (has_p) {
@@ -1155,8 +1172,53 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
     }
     __syncthreads();
     PQA_PCLK(7);
-    // ---- this group's row of the electron block
-    if (has_row) {
+    // ---- the block rows
+    if (QUART) {
+      // quarter sums of V . T[jrow] -> LDS (the partial-sum planes are free: every group has read its totals), then every thread of
+      // the quartet combines the four in the PQA_ROWDOT order and updates its own quarter of the row
+      double pq = 0.0;
+      if (has_row && jrow != i) {
+#pragma unroll
+        for (int u = 0; u < TBN; ++u)
+          if (kq0 + u < n) pq += shV[(kq0 + u) * NW + lane] * tb[u];
+      }
+      shP[g * NW + lane] = pq;
+      __syncthreads();
+#ifdef PQA_PRE_CLK
+      if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 12] = wall_clock64();
+#endif
+      if (has_row) {
+        double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
+        const bool any = __any(acc);  // k_step_lw stores nothing where no lane of the wave accepted
+        if (jrow == i) {
+          if (acc && live) {
+#pragma unroll
+            for (int u = 0; u < TBN; ++u)
+              if (kq0 + u < n) Tj[(size_t)(kq0 + u) * W] = shR[(kq0 + u) * NW + lane];
+          }
+        } else {
+          const int gq = g & ~3;
+          const double tmp = ((shP[gq * NW + lane] + shP[(gq + 1) * NW + lane]) + shP[(gq + 2) * NW + lane]) + shP[(gq + 3) * NW + lane];
+#pragma unroll
+          for (int u = 0; u < TBN; ++u)
+            if (kq0 + u < n) tb[u] = acc ? tb[u] - shR[(kq0 + u) * NW + lane] * tmp : tb[u];
+#ifdef PQA_PRE_CLK
+          if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 13] = wall_clock64() + (tb[0] == 1.2345e300 ? 1 : 0);
+#endif
+          if (live && any) {
+#pragma unroll
+            for (int u = 0; u < TBN; ++u)
+              if (kq0 + u < n) Tj[(size_t)(kq0 + u) * W] = tb[u];
+          }
+          PQA_PCLK(14);
+          if (handoff && jrow == i2) {
+#pragma unroll
+            for (int u = 0; u < TBN; ++u)
+              if (kq0 + u < n) shT[(kq0 + u) * NW + lane] = tb[u];
+          }
+        }
+      }
+    } else if (has_row) {
       double* Tj = L.Tt[s] + (size_t)jrow * n * W + w;
       const bool any = __any(acc);  // k_step_lw stores nothing where no lane of the wave accepted
       if (jrow == i) {
@@ -1166,28 +1228,22 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
             if (k < n) Tj[(size_t)k * W] = shR[k * NW + lane];
         }
       } else {
-        double tmp = 0.0;
+        double p4[4] = {0.0, 0.0, 0.0, 0.0};  // PQA_ROWDOT
 #pragma unroll
-        for (int k = 0; k < NMAX; ++k)
-          if (k < n) tmp += shV[k * NW + lane] * tb[k];
-#ifdef PQA_PRE_CLK
-        if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 12] = wall_clock64() + (tmp == 1.2345e300 ? 1 : 0);
-#endif
+        for (int k = 0; k < TBN; ++k)
+          if (k < n) p4[k / (NMAX / 4)] += shV[k * NW + lane] * tb[k];
+        const double tmp = ((p4[0] + p4[1]) + p4[2]) + p4[3];
 #pragma unroll
-        for (int k = 0; k < NMAX; ++k)
+        for (int k = 0; k < TBN; ++k)
           if (k < n) tb[k] = acc ? tb[k] - shR[k * NW + lane] * tmp : tb[k];
-#ifdef PQA_PRE_CLK
-        if (blockIdx.x < 256 && threadIdx.x == 0) pqa_pre_clk[blockIdx.x * 16 + 13] = wall_clock64() + (tb[0] == 1.2345e300 ? 1 : 0);
-#endif
         if (live && any) {
 #pragma unroll
-          for (int k = 0; k < NMAX; ++k)
+          for (int k = 0; k < TBN; ++k)
             if (k < n) Tj[(size_t)k * W] = tb[k];
         }
-        PQA_PCLK(14);
         if (handoff && jrow == i2) {
 #pragma unroll
-          for (int k = 0; k < NMAX; ++k)
+          for (int k = 0; k < TBN; ++k)
             if (k < n) shT[k * NW + lane] = tb[k];
         }
       }

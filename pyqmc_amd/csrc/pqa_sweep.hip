@@ -178,7 +178,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
   // threads) spill at the 128-register limit: 4.47 / 3.53 ms.  PQA_STEP_GW = 16 / 32 / 64 pins it.
   {
     const int gw = h->step_gw ? h->step_gw : 32;
-    if ((gw == 32 || gw == 64) && W <= h->step_pre_max && N_ok(h) && step_pre_system_ok(h, rowlen) && KB <= gw) { G = gw; NW = 16; }
+    if ((gw == 32 || gw == 64) && W <= h->step_pre_max && N_ok(h) && step_pre_system_ok(h, rowlen) && KB <= gw / 4) { G = gw; NW = 16; }  // (a block row per quartet of groups)
   }
 
   HalfPipe P;

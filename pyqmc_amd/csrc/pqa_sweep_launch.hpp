@@ -15,7 +15,7 @@ static void launch_step_lw(pqa_handle* h, const LwState& L, const MoveBuf& mb, c
   const dim3 grid((unsigned)((a.w1 - a.w0 + a.NW - 1) / a.NW)), block((unsigned)(a.NW * a.G));
   // small shards: the variant with every load issued at entry (k_step_pre, pqa_lw.hpp) where its scope covers the system
   // (one block per CU at most: the kernel holds ~360 registers per lane, one wave per SIMD)
-  const bool pre_ok = !CX && step_pre_system_ok(h, rowlen) && (a.e_acc < 0 || a.j_hi - a.j_lo <= a.G);
+  const bool pre_ok = !CX && step_pre_system_ok(h, rowlen) && (a.e_acc < 0 || a.j_hi - a.j_lo <= (a.G >= 32 ? a.G / 4 : a.G));  // (32 / 64 groups: a block row per quartet of groups)
   if (pre_ok && a.NW == 16 && (a.G == 32 || a.G == 64) && a.W <= h->step_pre_max && h->N <= 64 && h->S.natom <= 64) {  // 512 / 1024 threads per 16 walkers
 #define PQA_STEP_W(NM) do { const size_t lds_p = ((size_t)8 * a.G + 3 * NM + 8) * a.NW * sizeof(double); \
       if (a.G == 64) hipLaunchKernelGGL((k_step_pre<PBC, NM, 64>), grid, block, lds_p, h->stream, h->S, L, mb, a); \
