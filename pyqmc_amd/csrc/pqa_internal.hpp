@@ -91,7 +91,7 @@ struct pqa_handle {
   int ecp_point_lw = 1;  // PQA_ECP_POINT_LW=0: k_ecp_point on the planes instead of k_ecp_point_lw (A/B)
   long flush_wb8_max = 8192;  // PQA_FLUSH_WB8_MAX: walker counts up to which k_flush_lw runs with 8 walkers per block
   long draws_max = 16384;  // PQA_DRAWS_MAX: walker counts up to which a fused sweep draws its random numbers ahead (k_tile_draws)
-  long step_pre_max = 4096;  // PQA_STEP_PRE_MAX: largest shard (walkers) that runs k_step_pre
+  long step_pre_max = 8192;  // PQA_STEP_PRE_MAX: largest shard (walkers) that runs k_step_pre (8192: 5.90 -> 5.57 ms per (H2O)8 step since the quartet commit; 16384 loses)
   int step_gw = 0;       // PQA_STEP_GW: thread groups per walker of k_step_pre for shards <= 4096 walkers (0 automatic: 64; 16 / 32 / 64)
   int step_pre = 1;      // PQA_STEP_PRE=0: k_step_lw for small shards too (A/B, bitwise check)
   int ecp_acc_waves = 0; // PQA_ECP_ACC_WAVES: 1 / 4 waves per walker in k_ecp_accum / k_kinetic_coulomb (0: 4 while walkers x electrons <= 32768)
