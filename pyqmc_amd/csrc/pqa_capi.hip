@@ -339,7 +339,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   which a sweep's random numbers are drawn ahead, PQA_FLUSH_WB8_MAX n 8-walker flush blocks up to n walkers, PQA_ECP_LDS 0 /
   //   PQA_ECP_POINT_LW 0 first-generation ECP list passes / point kernel, PQA_ECP_ACC_WAVES 1|4 waves per walker in the
   //   wave-per-walker energy kernels, PQA_ECP_ATOM_MAJOR 0 walker-major ECP lists in periodic cells, PQA_JAS_FOLD 0 Voronoi
-  //   reduction in every periodic Jastrow pair.
+  //   reduction in every periodic Jastrow pair;
+  //   round 4: PQA_STEP_GW 16|32|64 thread groups per walker of k_step_pre, PQA_STEP_PRE_MAX n largest shard that runs it (8192),
+  //   PQA_SPLIT 0..3 / PQA_SPLIT_MIN / PQA_SPLIT_CUS pipelined half-ensembles, PQA_JPRE 1 Jastrow sums ahead on a side stream,
+  //   PQA_JAS_MERGE 0 Pade functions one by one instead of the merged rational function (jas_merge_tables).
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
