@@ -126,7 +126,14 @@ static int launch_orb_pbc_general(pqa_handle* h, int ncomp, int spin, PointAddr 
 }
 int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
   if (h->pbc_high_l) return launch_orb_pbc_general(h, ncomp, spin, pa, P, out);
-  if (ncomp == 5) return (h->orb_kc5 == 32) ? launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out) : launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
+  if (ncomp == 5) {
+    // AO rows per chunk of the 5-component launch.  Automatic (PQA_ORB_KC5 unset): 16 for launches of at least 16384 points, 32 below —
+    // measured at the end of round 4: whole-ensemble launches (recompute, the DMC step's refresh of accepted T-moves: 131 k points per
+    // spin at 4096 walkers) run ~2x faster with 16-row chunks (C5 DMC 33.5 -> 31.4 ms per step at 16384 walkers, 62.8 -> 58.0 at 32768,
+    // 10.5 -> 10.05 at 4096; 8-atom cubic cell VMC 12.7 -> 11.9 at 32768), 8192-point move launches of that cell lose 16 % with them.
+    const int kc = (h->orb_kc5 == 16 || h->orb_kc5 == 32) ? h->orb_kc5 : (P >= 16384 ? 16 : 32);
+    return (kc == 32) ? launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out) : launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
+  }
   if (ncomp == 1) return launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
   FAIL("orbital kernel supports ncomp 1 or 5");
 }
