@@ -342,11 +342,13 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   reduction in every periodic Jastrow pair;
   //   round 4: PQA_STEP_GW 16|32|64 thread groups per walker of k_step_pre, PQA_STEP_PRE_MAX n largest shard that runs it (8192),
   //   PQA_SPLIT 0..3 / PQA_SPLIT_MIN / PQA_SPLIT_CUS pipelined half-ensembles, PQA_JPRE 1 Jastrow sums ahead on a side stream,
-  //   PQA_JAS_MERGE 0 Pade functions one by one instead of the merged rational function (jas_merge_tables).
+  //   PQA_JAS_MERGE 0 Pade functions one by one instead of the merged rational function (jas_merge_tables),
+  //   PQA_ORB_KC5 / PQA_ORB_KC1 16|32 AO rows per chunk of the periodic 5-component / value-only orbital launches.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
   if (const char* kc = getenv("PQA_ORB_KC5")) h->orb_kc5 = atoi(kc);
+  if (const char* kc = getenv("PQA_ORB_KC1")) h->orb_kc1 = atoi(kc);
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);

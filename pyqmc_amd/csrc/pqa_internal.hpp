@@ -120,6 +120,7 @@ struct pqa_handle {
   // rounds of a block's latency chain — 2x2x2 diamond supercell +4.5-10 % at every walker count, 8-atom cell +11 % at 8192
   // walkers, -4 % at 32768 (PQA_ORB_KC5=16 restores the 16-row chunks; the open-system kernel keeps 16: 0.36 vs 0.29 of peak)
   int orb_kc5 = 0;  // 0: by launch size (launch_orb_pbc_any); PQA_ORB_KC5 16|32 pins it
+  int orb_kc1 = 16;  // AO rows per chunk of the periodic value-only launch (PQA_ORB_KC1 16|32)
   struct TpTune { float ms[2] = {1e30f, 1e30f}; int n[2] = {0, 0}; int choice = 0; };  // periodic k_orb: [0] 32-point, [1] 64-point tiles
   TpTune tp_tune[2][48];  // per chunk table (5 / 1 components) and log2 bucket of the point count
   WideTab wide[2]{};  // lane-group shell lists of the whole-K small-launch kernel (k_orb_wide), per chunk table (64 groups; periodic: 32)

@@ -134,7 +134,10 @@ int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P,
     const int kc = (h->orb_kc5 == 16 || h->orb_kc5 == 32) ? h->orb_kc5 : (P >= 16384 ? 16 : 32);
     return (kc == 32) ? launch_orb_pbc<5, 32>(h, 1, spin, pa, P, out) : launch_orb_pbc<5, 16>(h, 0, spin, pa, P, out);
   }
-  if (ncomp == 1) return launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out);
+  // value-only launches (ECP quadrature points, T-move candidates): 16-row chunks on the 5-component launch's chunk table
+  // (C5 DMC 10.1 -> 9.8 ms per step at 4096 walkers, 31.2 -> 30.3 at 16384; C3 6.62 -> 6.47 at 8192; 2x2x2 VMC + 1.5-2 %; the 8-atom
+  // cubic cell loses 1 %); PQA_ORB_KC1=32 restores the 32-row chunks
+  if (ncomp == 1) return (h->orb_kc1 == 32) ? launch_orb_pbc<1, 32>(h, 1, spin, pa, P, out) : launch_orb_pbc<1, 16>(h, 0, spin, pa, P, out);
   FAIL("orbital kernel supports ncomp 1 or 5");
 }
 
