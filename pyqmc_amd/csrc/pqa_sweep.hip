@@ -88,8 +88,11 @@ int lw_setup(pqa_handle* h, bool lw, LwCtx& c) {
   const long W = h->W;
   // thread groups per walker in k_step_lw.  Measured (tools/scratch/r3_step_abl*.sh, (H2O)8 step in ms at 4 / 8 / 16 groups):
   // 4096 walkers 6.38 / 5.15 / 4.67, 8192: 7.71 / 6.54 / 6.39, 16384: 10.7 / 9.8 / 11.1, 32768: 16.5 / 17.3 / 18.8, 65536: 30.8 / 32.7 / 37.3
+  // 4 groups (a wave per group, k_step_lw's wide form) from 26624 walkers, 8 below, 16 below 16384 (re-measured at the end of round 4:
+  // at 28672 walkers the wide form takes 13.1 ms per (H2O)8 step against 14.6 with 8 groups; at 24576 8 groups win 11.6 vs 12.2)
   c.Gm = 4;
-  while (c.Gm < 16 && (long)c.Gm * W < 2048L * 64) c.Gm *= 2;
+  if ((long)4 * W < 1664L * 64) c.Gm = 8;
+  if (c.Gm == 8 && (long)8 * W < 2048L * 64) c.Gm = 16;
   if (h->lw_gm > 0) c.Gm = std::min(h->lw_gm, 16);
   c.nmax = std::max(h->nup, h->ndn);
   // block size of the delayed Sherman-Morrison update: 4 from 16 electrons per spin (8 flushes at 32), 5 from 24 (7 flushes at 32:
