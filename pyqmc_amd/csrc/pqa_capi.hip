@@ -351,6 +351,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* kc = getenv("PQA_ORB_KC1")) h->orb_kc1 = atoi(kc);
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
+  if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
+  if (const char* rs = getenv("PQA_RES_MIN")) h->res_min = atol(rs);
+  if (const char* rs = getenv("PQA_RES_MAX")) h->res_max = atol(rs);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
   if (const char* wd = getenv("PQA_ORB_WIDE")) h->orb_wide = atoi(wd);
   if (const char* wm = getenv("PQA_ORB_WIDE_MAX")) h->orb_wide_max = atol(wm);

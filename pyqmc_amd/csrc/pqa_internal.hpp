@@ -23,6 +23,7 @@
 #include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
 #include "pqa_tile.hpp"
+#include "pqa_res.hpp"
 #include "pqa_dm.hpp"
 #include "pqa_vmc.hpp"
 
@@ -147,6 +148,14 @@ struct pqa_handle {
   DevBuf b_jpre;
   std::vector<hipEvent_t> pipe_events;
   size_t pipe_next = 0;
+  // resident sweep (pqa_res.hpp / pqa_res.hip): the whole electron sweep of 16 walkers in one block, one launch per sweep.
+  // PQA_RES: -1 automatic (shards of res_min .. res_max walkers: PQA_RES_MIN / PQA_RES_MAX), 0 never, 1 whenever the system is in scope
+  int res_mode = -1;
+  long res_min = 1, res_max = 1L << 40;
+  bool res_ready = false, res_ok = false;
+  ResTab res_tab{};
+  size_t res_lds = 0;
+  int res_lmax = 0;
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
   // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
   // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
@@ -285,6 +294,9 @@ void launch_flush_real(pqa_handle* h, const LwState& L, int s, long W, long w0, 
 // pqa_sweep_cx.hip
 void launch_step_cx(pqa_handle* h, const LwState& L, const MoveBuf& mb, const StepArgs& a, int rowlen);
 void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, long w1, int j_lo, int j_hi, int nq, int rowlen, int n_s);
+// pqa_res.hip
+bool res_eligible(pqa_handle* h, long W);
+int sweep_res(pqa_handle* h, const MoveBuf& mb);
 // pqa_tile.hip
 bool tile_eligible(const pqa_handle* h);
 int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);

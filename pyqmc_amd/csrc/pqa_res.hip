@@ -1,0 +1,137 @@
+// pyqmc_amd C ABI implementation (host side): the resident electron sweep (pqa_res.hpp) — tables, eligibility, launch.
+// Called by sweep_electrons_fused (pqa_sweep.hip) in place of the per-move launches of the lane-per-walker sweep.
+#include "pqa_internal.hpp"
+
+// Passes over the padded coefficient rows of the 16-row chunk table (h->chunks[0]: the coefficient matrices cpad[0] are shared
+// with k_orb), shell lists per (pass, lane group), LDS budget.  Once per handle; leaves res_ok = false when the system is outside
+// the kernel's scope.
+static int res_setup(pqa_handle* h) {
+  h->res_ready = true;
+  h->res_ok = false;
+  if (h->res_mode == 0) return 0;
+  if (!h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc || h->twist) return 0;
+  if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32 || h->N > 64 || h->N < 1 || h->natom > 64) return 0;
+  int lmax = 0;
+  for (int l : h->shell_l) lmax = std::max(lmax, l);
+  if (lmax > 3) return 0;
+  h->res_lmax = lmax;
+  const ChunkHost& c = h->chunks[0];
+  const int nch = (int)c.nk.size();
+  if (nch == 0) return 0;
+  int rows_cap = 1 << 30;
+  size_t part_rn = 0;
+  for (int s = 0; s < 2; ++s) {
+    if ((s ? h->ndn : h->nup) == 0) continue;
+    const int nt = h->nt[s];
+    if (nt < 1 || nt > 2) return 0;
+    rows_cap = std::min(rows_cap, 4 * PQA_RES_MAXKS * (8 / nt));
+    part_rn = std::max(part_rn, (size_t)(8 / nt) * 16 * res_ps(nt) + (size_t)16 * PQA_RES_RS);
+  }
+  const size_t fixed = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS);
+  const size_t budget = 160 * 1024 - 256;
+  if (fixed + part_rn * sizeof(double) > budget) return 0;
+  const size_t avail = (budget - fixed) / sizeof(double);
+  // one pass if the whole basis fits (the partials then reuse the tile's memory); otherwise the tile shares the region with them
+  const int rows_all = c.rows_pad;
+  const bool one = rows_all <= rows_cap && (size_t)80 * rows_all <= avail;
+  const int kt_cap = one ? rows_all : std::min(rows_cap, (int)(((avail - part_rn) / 80) & ~(size_t)3));
+  if (kt_cap < 20) return 0;
+  ResTab RT{};
+  int ch = 0, kt = 0;
+  std::vector<int> pass_of_chunk((size_t)nch, 0);
+  while (ch < nch) {  // greedy: consecutive chunks while their padded rows fit the tile
+    if (RT.npass == PQA_RES_MAXPASS) return 0;
+    const int base = c.row0[ch];
+    int end = ch;
+    while (end < nch && c.row0[end] + ((c.nk[end] + 3) & ~3) - base <= kt_cap) ++end;
+    if (end == ch) return 0;
+    for (int q = ch; q < end; ++q) pass_of_chunk[q] = RT.npass;
+    RT.pass_row0[RT.npass] = base;
+    kt = std::max(kt, c.row0[end - 1] + ((c.nk[end - 1] + 3) & ~3) - base);
+    ch = end;
+    ++RT.npass;
+  }
+  RT.pass_row0[RT.npass] = c.rows_pad;
+  RT.kt = kt;
+  RT.part_off = (RT.npass == 1) ? 0 : 80 * kt;
+  RT.region = (RT.npass == 1) ? (int)std::max((size_t)80 * kt, part_rn) : (int)((size_t)80 * kt + part_rn);
+  // shell lists: per pass the shells by descending phase-1 cost, dealt to the 32 lane groups in snake order — neighbours in cost
+  // (the same kind of shell) land in neighbouring groups, i.e. in one wave, and the groups' totals stay balanced
+  std::vector<int> off(1, 0), list, srow((size_t)h->nshell, 0);
+  for (int sh = 0; sh < h->nshell; ++sh) srow[sh] = c.row0[c.shell_chunk[sh]] + c.shell_kb[sh];
+  for (int p = 0; p < RT.npass; ++p) {
+    std::vector<int> mem;
+    for (int sh = 0; sh < h->nshell; ++sh)
+      if (pass_of_chunk[c.shell_chunk[sh]] == p) mem.push_back(sh);
+    std::stable_sort(mem.begin(), mem.end(), [&](int a, int b) {
+      if (h->shell_cost[a] != h->shell_cost[b]) return h->shell_cost[a] > h->shell_cost[b];
+      return h->shell_l[a] > h->shell_l[b];
+    });
+    std::vector<std::vector<int>> grp(PQA_RES_G);
+    for (size_t k = 0; k < mem.size(); ++k) {
+      const int round = (int)(k / PQA_RES_G), pos = (int)(k % PQA_RES_G);
+      grp[(round & 1) ? PQA_RES_G - 1 - pos : pos].push_back(mem[k]);
+    }
+    for (int g = 0; g < PQA_RES_G; ++g) {
+      for (int sh : grp[g]) list.push_back(sh);
+      off.push_back((int)list.size());
+    }
+  }
+  RT.nlist = (int)list.size();
+  int* tmp_i = nullptr;
+  TRY(upload_table(h, off.data(), off.size(), &tmp_i)); RT.grp_off = tmp_i;
+  TRY(upload_table(h, list.data(), list.size(), &tmp_i)); RT.grp_shell = tmp_i;
+  TRY(upload_table(h, srow.data(), srow.size(), &tmp_i)); RT.shell_row = tmp_i;
+  h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, RT.nlist, RT.npass);
+  if (h->res_lds > 160 * 1024) return 0;
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  h->res_tab = RT;
+  h->res_ok = true;
+  return 0;
+}
+
+bool res_eligible(pqa_handle* h, long W) {
+  if (!h->res_ready) {
+    if (res_setup(h) != 0) { h->res_ok = false; h->err.clear(); }
+  }
+  if (!h->res_ok) return false;
+  if (h->res_mode > 0) return true;
+  return W >= h->res_min && W <= h->res_max;
+}
+
+// One sweep over all electrons of walkers [0, W): a single launch.  mb carries both tapes (the caller drew them if there were none).
+int sweep_res(pqa_handle* h, const MoveBuf& mb) {
+  if (!mb.gauss || !mb.unif) FAIL("resident sweep: the random-number tapes are missing");
+  const long W = h->W;
+  const LwState L = lw_state(h);
+  const dim3 grid((unsigned)((W + PQA_RES_NW - 1) / PQA_RES_NW)), block(PQA_RES_NT);
+  hipEvent_t e1 = nullptr;
+  if (h->profile) {  // every launch is bracketed (one launch per sweep)
+    if (h->prof_used == h->prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      h->prof_events.emplace_back(a, b);
+    }
+    HIPCHK(hipEventRecord(h->prof_events[h->prof_used].first, h->stream));
+    e1 = h->prof_events[h->prof_used].second;
+    ++h->prof_used;
+    h->prof_launches += 1;
+    h->prof_pc += (double)W * h->N * 5;  // point-components of this launch (as launch_orb counts them)
+  }
+#define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, h->tab[0], h->res_tab, (int)h->has_jastrow, W, 0L, W)
+  if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH(true, 2); else PQA_RES_LAUNCH(true, 3); }
+  else { if (h->res_lmax <= 2) PQA_RES_LAUNCH(false, 2); else PQA_RES_LAUNCH(false, 3); }
+#undef PQA_RES_LAUNCH
+  if (e1) HIPCHK(hipEventRecord(e1, h->stream));
+  return check_launch(h, "k_sweep_res");
+}
+
+#ifdef PQA_RES_CLK  // timing build only
+extern "C" int pqa_debug_res_clk(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk), (size_t)n * sizeof(unsigned long long));
+}
+#endif

@@ -1,0 +1,503 @@
+// pqa_res.hpp — the RESIDENT electron sweep: all N single-electron moves of a walker tile in ONE launch, state on chip.
+//
+// north_star's prescription ("one walker per wavefront with LDS-staged MO-inverse and electron-electron distance tiles") in the
+// form the measurements of rounds 2-4 point to.  The lane-per-walker sweep (pqa_lw.hpp) streams ~1 MB per walker-step through
+// HBM in ~155 dependent launches (k_orb -> k_step_lw per move, k_flush_lw per electron block); both kernel families are bound by
+// the wave slots they hold, and small shards are a 128-link chain of latency-bound launches.  Here a block of 512 threads owns
+// 16 walkers — exactly one 16-point fp64 MFMA tile — for the whole sweep:
+//   * the transposed inverse of the current spin lives in REGISTERS: thread (walker wl = tid / 32, row r = tid % 32) holds the
+//     32 columns of row r (64 VGPRs; a 512-thread block has 256 per thread), the walker's coordinates two electrons per thread;
+//     a walker is 32 consecutive lanes, so every per-walker sum is a DPP row reduction plus one 16-lane swizzle — no barrier;
+//   * per move the block evaluates the 16 proposals' atomic orbitals cooperatively (thread = (point, one of 32 lane groups),
+//     shell lists balanced by the phase-1 cost model) into ONE LDS tile holding the whole basis (5 x K x 16 doubles: 118 KB for
+//     the 184-AO (H2O)8 basis; several passes when it does not fit), contracts it on v_mfma_f64_16x16x4_f64 with the K dimension
+//     split over the waves (partials meet in LDS and are added in a fixed order), and decides / commits / proposes the next
+//     electron without leaving the CU: Slater ratio sums against the register inverse, Jastrow pair sums from register
+//     coordinates, Metropolis test, Sherman-Morrison update of the 32 register rows, cache row of accepted moves;
+//   * HBM is touched once per sweep for the inverse and the coordinates, once per move for the cached orbital row (1 KB read,
+//     1.3 KB written on acceptance) and the random-number tapes: ~150 KB per walker-step instead of ~1 MB, one launch instead of
+//     ~155.
+// Arithmetic per walker is the reference's (vmc_worker body mc.py:112-137, limdrift :76-89; dmc.py:38-70 in DMC mode; Slater
+// ratios slater.py:342-418, Sherman-Morrison slater.py:88-94, Jastrow jastrowspin.py:296-385 with func3d.py radial functions).
+// Sums run in a different order than in the lane-per-walker kernels: trajectories agree to rounding, decisions are identical off
+// measure-zero ties; the random numbers are the same Philox streams (drawn ahead by k_tile_draws), so the oracle replays apply.
+// State in and out: the lane-per-walker SoA planes (xt, Tt, two-slot row cache + selectors, dsign / dlog) — the energy kernels
+// run on them unchanged.
+// Scope: open boundary conditions, real single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin,
+// optional two-body Jastrow factor, l <= 3.  Everything else keeps the lane-per-walker sweep.
+#pragma once
+#include "pqa_ao.hpp"
+#include "pqa_jastrow.hpp"
+#include "pqa_lw.hpp"
+#include "pqa_vmc.hpp"
+
+#define PQA_RES_NT 512     // threads per block
+#define PQA_RES_NW 16      // walkers per block = points of the MFMA tile
+#define PQA_RES_G 32       // lane groups of the AO phase
+#define PQA_RES_MAXKS 16   // k-steps (4 AO rows each) of one pass a wave contracts at most
+#define PQA_RES_MAXPASS 8
+#define PQA_RES_RS 176     // doubles per walker of the combined orbital rows [5][32] (+16: walkers of a wave on disjoint LDS banks)
+
+struct ResTab {
+  int npass;                               // AO passes per move (1 when the whole basis fits the LDS tile)
+  int kt;                                  // rows of the LDS tile (largest pass), multiple of 4
+  int pass_row0[PQA_RES_MAXPASS + 1];      // padded coefficient rows [pass_row0[p], pass_row0[p + 1]) form pass p
+  const int* grp_off;                      // [npass * 32 + 1]
+  const int* grp_shell;                    // shells of (pass, lane group)
+  const int* shell_row;                    // [nshell] padded coefficient row of the shell's first function
+  int nlist;                               // entries of grp_shell
+  int region;                              // doubles of the tile / partial-sum / orbital-row region
+  int part_off;                            // offset of the K-partials in the region: 0 (one pass: they reuse the tile) or 80 kt
+};
+// doubles per point of a K-partial [5][16 nt] (+ padding: the four point quartets of a wave on different banks)
+__host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
+__host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
+  const size_t d = 16 * 32 + 16 * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1);
+  const size_t i = 4 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
+  return d * sizeof(double) + i * sizeof(int);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double res_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 32 lanes of a walker (half a wave), the SAME bits in every lane: four rotate-and-add steps inside each DPP row of
+// 16 lanes (after the step by d the values have period d along the row, and x + y = y + x), then the two rows are exchanged with
+// ds_swizzle (xor 16; no LDS memory access).  15 instructions per sum.
+__device__ __forceinline__ double res_sum32(double v) {
+  v += res_dpp<0x128>(v);  // row_ror:8
+  v += res_dpp<0x124>(v);  // row_ror:4
+  v += res_dpp<0x122>(v);  // row_ror:2
+  v += res_dpp<0x121>(v);  // row_ror:1
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F);  // bit mode: and 0x1f, or 0, xor 0x10
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+  return v + __hiloint2double(hi, lo);
+}
+// LDS written by other lanes of the SAME wave: the hardware executes a wave's DS instructions in order; this keeps the compiler
+// from moving accesses across the point.
+__device__ __forceinline__ void res_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// This thread's share of U_e, grad U_e at (rx, ry, rz): partners j = r, r + 32 (coordinates in registers) and ions I = r, r + 32.
+// Function by function like jas_eval_lane_t (the partner's spin differs between lanes).
+__device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, double rx, double ry, double rz, const double (&cx)[2],
+                                             const double (&cy)[2], const double (&cz)[2], const double* __restrict__ at_xyz,
+                                             const double* __restrict__ acoef, double& U, double (&g)[3]) {
+  const int edown = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#pragma unroll 1
+  for (int q = 0; q < 2; ++q) {
+    const int j = r + 32 * q;
+    if (j < S.nelec && j != e && S.nb > 0) {
+      const double dx = rx - (q ? cx[1] : cx[0]), dy = ry - (q ? cy[1] : cy[0]), dz = rz - (q ? cz[1] : cz[0]);
+      const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+      if (rr < S.rcut_b) {
+        const RadShared sh = rad_shared<1>(rr, irb);
+        const int col = edown + (j >= S.nup ? 1 : 0);
+        double sg = 0.0;
+#pragma unroll 1
+        for (int l = 0; l < S.nb; ++l) {
+          double v, gf, lpl;
+          rad_fn<1>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
+          const double c = S.bcoeff[l * 3 + col];
+          u_ += c * v;
+          sg += c * gf;
+        }
+        gx += sg * dx; gy += sg * dy; gz += sg * dz;
+      }
+    }
+  }
+#pragma unroll 1
+  for (int q = 0; q < 2; ++q) {
+    const int I = r + 32 * q;
+    if (I < S.natom && S.na > 0) {
+      const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+      const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+      if (rr < S.rcut_a) {
+        const RadShared sh = rad_shared<1>(rr, ira);
+        double sg = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < S.na; ++k) {
+          double v, gf, lpl;
+          rad_fn<1>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
+          const double c = acoef[(I * S.na + k) * 2 + edown];
+          u_ += c * v;
+          sg += c * gf;
+        }
+        gx += sg * dx; gy += sg * dy; gz += sg * dz;
+      }
+    }
+  }
+  U = u_; g[0] = gx; g[1] = gy; g[2] = gz;
+}
+
+#ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
+static __device__ unsigned long long pqa_res_clk[64 * 16];
+#define PQA_RCLK(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define PQA_RCLK(k) do { } while (0)
+#endif
+
+// grid = ceil((w_hi - w_lo) / 16) blocks of 512 threads; dynamic LDS = RT.region doubles + res_lds_fixed(...).
+// mb.gauss [N][W][3] and mb.unif [N][W] must be set (the caller draws them ahead from the Philox streams when there is no tape).
+// Register budget: 256 per thread (two waves per SIMD).  What is carried across the orbital phase is the inverse row (64), the
+// two coordinates (12) and a few indices; everything a proposal hands to its decision waits in LDS (wsc), the accumulators live
+// only across the MFMA loop, and the loads a decision / the next proposal need are issued after the AO phase.
+template <bool DMC, int LMAX>
+static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwState L, MoveBuf mb, ChunkTab T, ResTab RT, int has_jastrow,
+                                                                  long W, long w_lo, long w_hi) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: scalar)
+  const int wl = tid >> 5, r = tid & 31;      // step phases: walker of the block, inverse row / partner slot
+  const int pl = tid & 15, grp = tid >> 4;    // AO phase: point, lane group
+  const int i16 = lane & 15, kq = lane >> 4;  // MFMA phase
+  const int N = S.nelec, KT = RT.kt;
+  double* region = lds;
+  double* rowE = region + RT.region;           // [16][32] inverse row of the electron being moved
+  double* wsc = rowE + 16 * 32;                // [16][16] per walker: 0..2 proposal, 3..5 scaled gaussians, 6..8 drift, 9 U at the old position
+  double* sh_xyz = wsc + 16 * 16;
+  double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
+  double* pr_coef = pr_exp + S.nprim;
+  double* at_xyz = pr_coef + S.nprim;
+  double* acoef = at_xyz + 3 * (size_t)S.natom;
+  int* sh_meta = (int*)(acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1));  // l, primitives, first primitive, padded row
+  int* glist = sh_meta + 4 * (size_t)S.nshell;
+  int* goff = glist + RT.nlist;
+  int* occ = goff + RT.npass * 32 + 1;
+  double* ws = wsc + wl * 16;
+
+  const long wraw = w_lo + (long)blockIdx.x * PQA_RES_NW + wl;
+  const bool live = wraw < w_hi;
+  const long wg = live ? wraw : w_hi - 1;  // walkers past the end shadow the last one and store nothing
+
+  // ---- tables and the walker's coordinates
+  for (int sh = tid; sh < S.nshell; sh += PQA_RES_NT) {
+    const int ia = S.shell_atom[sh];
+    sh_xyz[3 * sh] = S.atom_xyz[3 * ia]; sh_xyz[3 * sh + 1] = S.atom_xyz[3 * ia + 1]; sh_xyz[3 * sh + 2] = S.atom_xyz[3 * ia + 2];
+    sh_meta[4 * sh] = S.shell_l[sh];
+    sh_meta[4 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
+    sh_meta[4 * sh + 2] = S.shell_prim_off[sh];
+    sh_meta[4 * sh + 3] = RT.shell_row[sh];
+  }
+  for (int p = tid; p < S.nprim; p += PQA_RES_NT) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
+  for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
+  for (int k = tid; k < 2 * S.natom * S.na; k += PQA_RES_NT) acoef[k] = has_jastrow ? S.acoeff[k] : 0.0;
+  for (int k = tid; k < RT.nlist; k += PQA_RES_NT) glist[k] = RT.grp_shell[k];
+  for (int k = tid; k < RT.npass * 32 + 1; k += PQA_RES_NT) goff[k] = RT.grp_off[k];
+  for (int k = tid; k < 64; k += PQA_RES_NT) {
+    const int s = k >> 5, q = k & 31, n = s ? S.ndn : S.nup;
+    occ[k] = q < n ? (s ? S.det_occ[1][q] : S.det_occ[0][q]) : 0;
+  }
+  for (int k = tid; k < RT.region; k += PQA_RES_NT) region[k] = 0.0;  // (K-padding rows of the tile stay finite)
+  double cx[2], cy[2], cz[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = r + 32 * q;
+    const double* xj = L.xt + (size_t)(j < N ? j : 0) * 3 * W + wg;
+    cx[q] = xj[0]; cy[q] = xj[W]; cz[q] = xj[2 * W];
+  }
+  int n_acc = 0;
+  double r2p = 0.0, r2a = 0.0;
+  const double sq = sqrt(mb.tstep), df = DMC ? 1.0 : mb.tstep;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int s = 0; s < 2; ++s) {
+    const int n = s ? S.ndn : S.nup;
+    if (n == 0) continue;
+    const int nmo = s ? S.nmo[1] : S.nmo[0], ldc = s ? T.ldc[1] : T.ldc[0], nt = ldc >> 4, e0 = s ? S.nup : 0;
+    const double* __restrict__ cpad = s ? T.cpad[1] : T.cpad[0];
+    double* Tg = (s ? L.Tt[1] : L.Tt[0]) + wg;
+    double* rcs = s ? L.rc[1] : L.rc[0];
+    uint8_t* sels = s ? L.sel[1] : L.sel[0];
+    const int KW = 8 / nt, u = wv % nt, kw = wv / nt;  // MFMA roles: orbital tile u, K-split part kw of KW
+    const int PS = res_ps(nt);
+    double* part = region + RT.part_off;        // [KW][16][PS]
+    double* rn = part + (size_t)KW * 16 * PS + (size_t)wl * PQA_RES_RS;  // this walker's combined rows [5][32]
+    const int* occs = occ + 32 * s;
+    const bool ident = (s ? S.occ_ident[1] : S.occ_ident[0]) != 0;
+    const int oc = occs[r];
+    // ---- the transposed inverse of this spin: row r of walker wl
+    double t[32];
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8) {
+#pragma unroll
+      for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {  // (unconditional loads of clamped addresses: a branch per element otherwise)
+        double v = Tg[((size_t)(r < n ? r : 0) * n + (k < n ? k : 0)) * W];
+        asm volatile("" : "+v"(v));
+        t[k] = (r < n && k < n) ? v : 0.0;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int selr = (r < n) ? (int)sels[(size_t)r * W + wg] : 0;  // slot of electron r's cached row
+    double dsg = (s ? L.dsign[1] : L.dsign[0])[wg], dlg = (s ? L.dlog[1] : L.dlog[0])[wg];
+
+#pragma unroll 1
+    for (int i = -1; i < n; ++i) {  // iteration i: [orbitals at the proposals of electron i, decide i], then propose i + 1
+      const int e = e0 + i;
+      double ro[4] = {0.0, 0.0, 0.0, 0.0}, uacc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      // loads the decision / the next proposal need (cached row of electron i + 1, tape entries): issued behind the AO phase, used
+      // after the contraction
+      auto prefetch = [&]() {
+        if (i + 1 < n) {
+          const int slot = __shfl(selr, (lane & 32) | (i + 1), 64);
+          const double* row = rcs + (((size_t)(i + 1) * 2 + slot) * W + wg) * 5 * nmo;
+          if (r < n) { ro[0] = row[oc]; ro[1] = row[nmo + oc]; ro[2] = row[2 * nmo + oc]; ro[3] = row[3 * nmo + oc]; }
+          const double* zt = mb.gauss + ((size_t)(e + 1) * W + wg) * 3;
+          g0 = zt[0]; g1 = zt[1]; g2 = zt[2];
+        }
+        if (i >= 0) uacc = mb.unif[(size_t)e * W + wg];
+      };
+      if (i < 0) prefetch();
+      if (i >= 0) {
+        PQA_RCLK(0);
+        __syncthreads();  // proposals of all 16 walkers are in wsc; the previous move's reads of the region are done
+        // ================= orbital rows at the 16 proposals
+        // (opaque copies: the addresses of the unrolled contraction below depend on them, so the compiler cannot hoist the ~100
+        // loop-invariant address values out of the electron loop — it did, and spilled them and a third of the inverse row)
+        int kwv = kw, ktv = KT;
+        asm volatile("" : "+s"(kwv), "+s"(ktv));
+        for (int ps = 0; ps < RT.npass; ++ps) {
+          const int row_base = RT.pass_row0[ps], nks = (RT.pass_row0[ps + 1] - row_base) >> 2;
+          if (ps > 0) __syncthreads();  // the previous pass's MFMA reads of the tile are done
+          {
+            const double px = wsc[pl * 16], py = wsc[pl * 16 + 1], pz = wsc[pl * 16 + 2];
+#ifndef PQA_RES_ABL_NOAO
+            for (int it = goff[ps * 32 + grp]; it < goff[ps * 32 + grp + 1]; ++it) {
+              const int sh = glist[it];
+              const int l_ = sh_meta[4 * sh], np_ = sh_meta[4 * sh + 1], q0 = sh_meta[4 * sh + 2], krow = sh_meta[4 * sh + 3] - row_base;
+              shell_eval<5, LMAX>(l_, px - sh_xyz[3 * sh], py - sh_xyz[3 * sh + 1], pz - sh_xyz[3 * sh + 2], pr_exp + q0, pr_coef + q0, np_,
+                                  [&](int m, double v, double ax, double ay, double az, double lp) {
+                                    double* tl = region + (size_t)(krow + m) * 16 + pl;
+                                    tl[0] = v; tl[(size_t)KT * 16] = ax; tl[(size_t)2 * KT * 16] = ay; tl[(size_t)3 * KT * 16] = az;
+                                    tl[(size_t)4 * KT * 16] = lp;
+                                  });
+            }
+#endif
+          }
+          // B operand of this wave's k-steps (L2-resident coefficient rows): a ring of four, the first three requested behind the AO
+          // phase — in flight while the waves meet at the barrier — and k-step q + 3 while k-step q is contracted (all of them at
+          // once would be 32 registers across the contraction)
+          const double* cb = cpad + (size_t)(row_base + kq) * ldc + 16 * u + i16;
+          double bq[4];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bq[q] = (kwv + q * KW < nks) ? cb[(size_t)(kwv + q * KW) * 4 * ldc] : 0.0;
+          bq[3] = 0.0;
+          if (ps == RT.npass - 1) prefetch();
+          PQA_RCLK(1);
+          __syncthreads();
+          d4 acc[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
+#ifndef PQA_RES_ABL_NOMFMA
+          {
+            const double* a_ = region + (size_t)kq * 16 + i16;
+#pragma unroll
+            for (int q = 0; q < PQA_RES_MAXKS; ++q) {
+              const int ks = kwv + q * KW;
+              if (q + 3 < PQA_RES_MAXKS && ks + 3 * KW < nks) bq[(q + 3) & 3] = cb[(size_t)(ks + 3 * KW) * 4 * ldc];
+              if (ks < nks) {
+                double ac[5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) ac[c] = a_[((size_t)c * ktv + 4 * ks) * 16];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[c], bq[q & 3], acc[c], 0, 0, 0);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#endif
+          PQA_RCLK(2);
+          // K-partials of this wave: lane holds D[point = kq + 4 rr][orbital = 16 u + i16].  One pass: they take the tile's place
+          // (every wave has to be done reading it); several passes: own memory behind the tile, accumulated pass by pass by the
+          // same lane
+          if (RT.part_off == 0) __syncthreads();
+          {
+            double* pw = part + ((size_t)kw * 16 + kq) * PS + 16 * u + i16;
+            if (ps == 0) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) pw[(size_t)4 * rr * PS + c * 16 * nt] = acc[c][rr];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) pw[(size_t)4 * rr * PS + c * 16 * nt] += acc[c][rr];
+            }
+          }
+        }
+        __syncthreads();
+        PQA_RCLK(3);
+        // ---- this walker's rows: the KW partials added in a fixed order (thread r: orbital r, five components)
+        if (r < 16 * nt) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c) {
+            double sum = part[(size_t)wl * PS + c * 16 * nt + r];
+            for (int k2 = 1; k2 < KW; ++k2) sum += part[((size_t)k2 * 16 + wl) * PS + c * 16 * nt + r];
+            rn[c * 32 + r] = sum;
+          }
+        }
+        res_wave_sync();
+        // ================= decide electron i (mc.py:124-132; dmc.py:57-70): the same numbers in all lanes of the walker
+        const double te = rowE[wl * 32 + r];  // T[i][r] (zero beyond n)
+        double p0 = rn[oc] * te, p1 = rn[32 + oc] * te, p2 = rn[64 + oc] * te, p3 = rn[96 + oc] * te;
+        p0 = res_sum32(p0); p1 = res_sum32(p1); p2 = res_sum32(p2); p3 = res_sum32(p3);
+        double hx = finite_or(p1 / p0, 0.0), hy = finite_or(p2 / p0, 0.0), hz = finite_or(p3 / p0, 0.0);
+        const double dr = p0;
+        const double val = finite_or(dr, 1.0);
+        double val2 = val * val;
+        const double npx = ws[0], npy = ws[1], npz = ws[2];
+#ifndef PQA_RES_ABL_NOJAS
+        if (has_jastrow) {
+          double ju, jg[3];
+          res_jas_part(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, ju, jg);
+          ju = res_sum32(ju); jg[0] = res_sum32(jg[0]); jg[1] = res_sum32(jg[1]); jg[2] = res_sum32(jg[2]);
+          hx += jg[0]; hy += jg[1]; hz += jg[2];
+          const double ej = exp(ju - ws[9]);
+          val2 *= ej * ej;
+        }
+#endif
+        bool accd;
+        {
+          const double z0 = ws[3], z1 = ws[4], z2 = ws[5], d0 = ws[6], d1 = ws[7], d2 = ws[8];
+          const double fwd = z0 * z0 + z1 * z1 + z2 * z2;
+          double bx, by, bz;
+          if (DMC) {
+            limdrift_dmc(hx, hy, hz, mb.tstep);
+            bx = z0 + d0 + hx; by = z1 + d1 + hy; bz = z2 + d2 + hz;
+          } else {
+            limdrift3(hx, hy, hz);
+            bx = z0 + mb.tstep * (d0 + hx); by = z1 + mb.tstep * (d1 + hy); bz = z2 + mb.tstep * (d2 + hz);
+          }
+          const double bwd = bx * bx + by * by + bz * bz;
+          double ratio = val2 * exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
+          if (DMC) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
+          accd = ratio > uacc;
+          if (DMC) {
+            const double rx = z0 + d0, ry = z1 + d1, rz = z2 + d2, r2 = rx * rx + ry * ry + rz * rz;
+            r2p += r2;
+            if (accd) r2a += r2;
+          }
+        }
+        if (live && r == 0 && mb.accept_rec) mb.accept_rec[(size_t)e * W + wg] = accd;
+        PQA_RCLK(4);
+        if (accd) {
+          ++n_acc;
+          // Sherman-Morrison on the register rows (slater.py:88-94): R = T_old[i] / ratio, T[j] -= R (V . T[j]), T[i] = R;
+          // the row's dot product in the PQA_ROWDOT order of the lane-per-walker kernels.  Eight columns at a time (the
+          // scheduling fences keep the compiler from requesting all 64 LDS operands at once)
+#ifndef PQA_RES_ABL_NOSM
+          const double inv = 1.0 / dr;
+          double p4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int k8 = 0; k8 < 4; ++k8) {
+            if (ident) {
+#pragma unroll
+              for (int k = 8 * k8; k < 8 * k8 + 8; ++k) p4[k8] += rn[k] * t[k];
+            } else {
+#pragma unroll
+              for (int k = 8 * k8; k < 8 * k8 + 8; ++k) p4[k8] += rn[occs[k]] * t[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const double tmp = ((p4[0] + p4[1]) + p4[2]) + p4[3];
+          const double* Re = rowE + wl * 32;
+#pragma unroll
+          for (int k8 = 0; k8 < 4; ++k8) {
+#pragma unroll
+            for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {
+              const double R = Re[k] * inv;
+              t[k] = (r == i) ? R : t[k] - R * tmp;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
+          dsg *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+          dlg += log(fabs(dr));
+          if (r == (e & 31)) {
+            if (e >> 5) { cx[1] = npx; cy[1] = npy; cz[1] = npz; } else { cx[0] = npx; cy[0] = npy; cz[0] = npz; }
+          }
+          // the proposal's rows become the cached rows of electron i: into the walker's other slot, selector flipped
+          const int cur = __shfl(selr, (lane & 32) | i, 64);
+          if (live && r < nmo) {
+            double* out = rcs + (((size_t)i * 2 + (cur ^ 1)) * W + wg) * 5 * nmo;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) out[c * nmo + r] = rn[c * 32 + r];
+          }
+          if (r == i) {
+            selr = cur ^ 1;
+            if (live) sels[(size_t)i * W + wg] = (uint8_t)selr;
+          }
+        }
+        PQA_RCLK(5);
+      }
+      // ================= propose electron i + 1 (mc.py:117-121): drift at its current position
+      if (i + 1 < n) {
+        const int ip = i + 1, ep = e0 + ip;
+        res_wave_sync();  // (the decision's reads of rowE and wsc are done)
+        if (r == ip) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) rowE[wl * 32 + k] = t[k];
+        }
+        res_wave_sync();
+        const double te = rowE[wl * 32 + r];
+        double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
+        q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
+        double gx = finite_or(q1 / q0, 0.0), gy = finite_or(q2 / q0, 0.0), gz = finite_or(q3 / q0, 0.0);
+        const int src = (lane & 32) | (ep & 31);
+        const double ex = __shfl((ep >> 5) ? cx[1] : cx[0], src, 64), ey = __shfl((ep >> 5) ? cy[1] : cy[0], src, 64),
+                     ez = __shfl((ep >> 5) ? cz[1] : cz[0], src, 64);
+        double U0 = 0.0;
+#ifndef PQA_RES_ABL_NOJAS
+        if (has_jastrow) {
+          double jg[3];
+          res_jas_part(S, ep, r, ex, ey, ez, cx, cy, cz, at_xyz, acoef, U0, jg);
+          U0 = res_sum32(U0); jg[0] = res_sum32(jg[0]); jg[1] = res_sum32(jg[1]); jg[2] = res_sum32(jg[2]);
+          gx += jg[0]; gy += jg[1]; gz += jg[2];
+        }
+#endif
+        if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else limdrift3(gx, gy, gz);
+        const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
+        if (r == 0) {
+          ws[0] = ex + z0 + gx * df; ws[1] = ey + z1 + gy * df; ws[2] = ez + z2 + gz * df;
+          ws[3] = z0; ws[4] = z1; ws[5] = z2; ws[6] = gx; ws[7] = gy; ws[8] = gz; ws[9] = U0;
+        }
+        res_wave_sync();
+        PQA_RCLK(6);
+      }
+    }
+    // ---- this spin's state back to the planes
+    if (live && r < n) {
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+#pragma unroll
+        for (int k = 8 * k8; k < 8 * k8 + 8; ++k)
+          if (k < n) Tg[((size_t)r * n + k) * W] = t[k];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (live && r == 0) { (s ? L.dsign[1] : L.dsign[0])[wg] = dsg; (s ? L.dlog[1] : L.dlog[0])[wg] = dlg; }
+    __syncthreads();  // (rowE / region reads of this spin's last decision before the next spin's first proposal)
+  }
+  if (live) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = r + 32 * q;
+      if (j < N) {
+        double* xj = L.xt + (size_t)j * 3 * W + wg;
+        xj[0] = cx[q]; xj[W] = cy[q]; xj[2 * W] = cz[q];
+      }
+    }
+    if (r == 0) {
+      mb.acc_w[wg] += n_acc;
+      if (DMC) { mb.r2_prop[wg] += r2p; mb.r2_acc[wg] += r2a; }
+    }
+  }
+}

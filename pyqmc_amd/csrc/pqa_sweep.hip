@@ -158,7 +158,9 @@ static bool N_ok(const pqa_handle* h) { return h->N <= 64 && h->natom <= 64 && s
 static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCtx& lc) {
   const long W = h->W;
   MoveBuf mb = mb_in;
-  if (!mb.gauss && !mb.unif && W <= h->draws_max) {
+  // the resident sweep (pqa_res.hpp: one launch per sweep, state on chip) where the system is in its scope; it reads both tapes
+  const bool res = ((mb.gauss != nullptr) == (mb.unif != nullptr)) && res_eligible(h, W);
+  if (!mb.gauss && !mb.unif && (res || W <= h->draws_max)) {
     // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
     // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD
     const size_t NW = (size_t)h->N * W;
@@ -168,6 +170,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
                        (double*)h->b_gauss.p, (double*)h->b_unif.p);
     mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
   }
+  if (res) return sweep_res(h, mb);
   const int N = h->N, KB = lc.KB, nmax = lc.nmax;
   const LwState L = lw_state(h);
   const int cfi = h->cplx ? 2 : 1, rowlen = cfi * nmax;  // doubles per inverse row
