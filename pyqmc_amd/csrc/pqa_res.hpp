@@ -52,7 +52,8 @@ struct ResTab {
 // doubles per point of a K-partial [5][16 nt] (+ padding: the four point quartets of a wave on different banks)
 __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
-  const size_t d = 16 * 32 + 16 * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1);
+  const size_t d = 16 * 32 + 16 * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
+                   2 * (size_t)natom * PQA_JQ;
   const size_t i = 4 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
   return d * sizeof(double) + i * sizeof(int);
 }
@@ -82,58 +83,191 @@ __device__ __forceinline__ void res_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// This thread's share of U_e, grad U_e at (rx, ry, rz): partners j = r, r + 32 (coordinates in registers) and ions I = r, r + 32.
-// Function by function like jas_eval_lane_t (the partner's spin differs between lanes).
+// This thread's share of U_e, grad U_e at (rx, ry, rz).  Partner slots of thread r: the up electron r, the down electron nup + r
+// (coordinates in registers) and the ions r, r + 32 — so the partner's spin, and with it the coefficient set, is wave-uniform.
+// Merged route (S.jq_on, pqa_jastrow.hpp: the Pade functions of a basis as one rational function per pair; electron-electron
+// numerators through scalar registers, the per-ion numerators from the block's LDS copy) or function by function (any basis).
 __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, double rx, double ry, double rz, const double (&cx)[2],
                                              const double (&cy)[2], const double (&cz)[2], const double* __restrict__ at_xyz,
-                                             const double* __restrict__ acoef, double& U, double (&g)[3]) {
+                                             const double* __restrict__ acoef, const double* __restrict__ aq, double& U, double (&g)[3], int excl = -1) {
   const int edown = e >= S.nup;
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-#pragma unroll 1
-  for (int q = 0; q < 2; ++q) {
-    const int j = r + 32 * q;
-    if (j < S.nelec && j != e && S.nb > 0) {
-      const double dx = rx - (q ? cx[1] : cx[0]), dy = ry - (q ? cy[1] : cy[0]), dz = rz - (q ? cz[1] : cz[0]);
-      const double rr = sqrt(dx * dx + dy * dy + dz * dz);
-      if (rr < S.rcut_b) {
-        const RadShared sh = rad_shared<1>(rr, irb);
-        const int col = edown + (j >= S.nup ? 1 : 0);
-        double sg = 0.0;
-#pragma unroll 1
-        for (int l = 0; l < S.nb; ++l) {
-          double v, gf, lpl;
-          rad_fn<1>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
-          const double c = S.bcoeff[l * 3 + col];
-          u_ += c * v;
-          sg += c * gf;
+  if (S.jq_on) {
+    const bool bcusp = S.b_kind[0] == 1, acusp = S.a_kind[0] == 1, kb4 = S.jq_b > 3, ka4 = S.jq_a > 3;
+    const double bcp = S.b_param[0], bca = S.b_aux[0], acp = S.a_param[0], aca = S.a_aux[0];
+    double Db[5], Da[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { Db[i] = S.b_D[i]; Da[i] = S.a_D[i]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = (q ? S.nup : 0) + r;
+      if (S.nb > 0 && r < (q ? S.ndn : S.nup) && j != e && j != excl) {
+        const double dx = rx - cx[q], dy = ry - cy[q], dz = rz - cz[q];
+        double rr, ri;
+        sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
+        if (rr < S.rcut_b) {
+          const RadShared sh = rad_shared_ri<1>(rr, ri, irb);
+          const double* qq = S.bq + (edown + q) * PQA_JQ;
+          const MergedSums m = kb4 ? pade_merged<1, 4, true>(Db, qq, sh.p) : pade_merged<1, 3, true>(Db, qq, sh.p);
+          u_ += sh.omp * m.S1;
+          double sg = sh.c0 * m.S2;
+          if (bcusp) {
+            double v, gf, lpl;
+            rad_fn<1>(1, bcp, bca, S.rcut_b, sh, v, gf, lpl);
+            const double c = S.bcoeff[edown + q];
+            u_ += c * v;
+            sg += c * gf;
+          }
+          gx += sg * dx; gy += sg * dy; gz += sg * dz;
         }
-        gx += sg * dx; gy += sg * dy; gz += sg * dz;
       }
     }
-  }
-#pragma unroll 1
-  for (int q = 0; q < 2; ++q) {
-    const int I = r + 32 * q;
-    if (I < S.natom && S.na > 0) {
-      const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
-      const double rr = sqrt(dx * dx + dy * dy + dz * dz);
-      if (rr < S.rcut_a) {
-        const RadShared sh = rad_shared<1>(rr, ira);
-        double sg = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < S.na; ++k) {
-          double v, gf, lpl;
-          rad_fn<1>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
-          const double c = acoef[(I * S.na + k) * 2 + edown];
-          u_ += c * v;
-          sg += c * gf;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int I = r + 32 * q;
+      if (q == 1 && S.natom <= 32) break;
+      if (S.na > 0 && I < S.natom) {
+        const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        double rr, ri;
+        sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
+        if (rr < S.rcut_a) {
+          const RadShared sh = rad_shared_ri<1>(rr, ri, ira);
+          const double* qq = aq + (size_t)(I * 2 + edown) * PQA_JQ;
+          const MergedSums m = ka4 ? pade_merged<1, 4, false>(Da, qq, sh.p) : pade_merged<1, 3, false>(Da, qq, sh.p);
+          u_ += sh.omp * m.S1;
+          double sg = sh.c0 * m.S2;
+          if (acusp) {
+            double v, gf, lpl;
+            rad_fn<1>(1, acp, aca, S.rcut_a, sh, v, gf, lpl);
+            const double c = acoef[(I * S.na) * 2 + edown];
+            u_ += c * v;
+            sg += c * gf;
+          }
+          gx += sg * dx; gy += sg * dy; gz += sg * dz;
         }
-        gx += sg * dx; gy += sg * dy; gz += sg * dz;
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+      const int j = (q ? S.nup : 0) + r;
+      if (S.nb > 0 && r < (q ? S.ndn : S.nup) && j != e && j != excl) {
+        const double dx = rx - (q ? cx[1] : cx[0]), dy = ry - (q ? cy[1] : cy[0]), dz = rz - (q ? cz[1] : cz[0]);
+        const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+        if (rr < S.rcut_b) {
+          const RadShared sh = rad_shared<1>(rr, irb);
+          double sg = 0.0;
+#pragma unroll 1
+          for (int l = 0; l < S.nb; ++l) {
+            double v, gf, lpl;
+            rad_fn<1>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, gf, lpl);
+            const double c = S.bcoeff[l * 3 + edown + q];
+            u_ += c * v;
+            sg += c * gf;
+          }
+          gx += sg * dx; gy += sg * dy; gz += sg * dz;
+        }
+      }
+    }
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+      const int I = r + 32 * q;
+      if (S.na > 0 && I < S.natom) {
+        const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+        if (rr < S.rcut_a) {
+          const RadShared sh = rad_shared<1>(rr, ira);
+          double sg = 0.0;
+#pragma unroll 1
+          for (int k = 0; k < S.na; ++k) {
+            double v, gf, lpl;
+            rad_fn<1>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, gf, lpl);
+            const double c = acoef[(I * S.na + k) * 2 + edown];
+            u_ += c * v;
+            sg += c * gf;
+          }
+          gx += sg * dx; gy += sg * dy; gz += sg * dz;
+        }
       }
     }
   }
   U = u_; g[0] = gx; g[1] = gy; g[2] = gz;
+}
+
+// ---- merged route, branch-free: the kernel runs two waves per SIMD, so a chain of dependent fp64 instructions runs at a quarter of
+// the pipe's rate; what hides the latency is independent chains in ONE thread.  res_pair_m has no branch (masked pairs are evaluated
+// at a harmless distance and discarded by a select), so the compiler interleaves the eight pairs res_jas_dual_m evaluates.
+// K <= 4 Pade functions through the KD = 4 polynomials (records and denominators are zero padded); a basis without cusp function
+// passes cusp parameter and coefficient 0.
+#ifndef PQA_RES_JCHAIN
+#define PQA_RES_JCHAIN 4
+#endif
+struct ResJ { double u, x, y, z; };
+template <bool UNI>
+__device__ __forceinline__ void res_pair_m(bool valid, double dx, double dy, double dz, double rcut, double ircut, const double (&D)[5],
+                                           const double* __restrict__ q, double cpar, double caux, double ccoef, ResJ& a) {
+  double rr, ri;
+  sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
+  const bool in = valid && rr < rcut;
+  rr = in ? rr : 0.5 * rcut; ri = in ? ri : 2.0 * ircut;
+  const RadShared sh = rad_shared_ri<1>(rr, ri, ircut);
+  const MergedSums m = pade_merged<1, 4, UNI>(D, q, sh.p);
+  double du = sh.omp * m.S1, sg = sh.c0 * m.S2;
+  {
+    double v, gf, lpl;
+    rad_fn<1>(1, cpar, caux, rcut, sh, v, gf, lpl);
+    du += ccoef * v;
+    sg += ccoef * gf;
+  }
+  du = in ? du : 0.0; sg = in ? sg : 0.0;
+  a.u += du; a.x += sg * dx; a.y += sg * dy; a.z += sg * dz;
+}
+// This thread's share of U, grad U of electron e at (px, py, pz), merged route: the two electron partners interleaved, then the ion(s).
+__device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (&cx)[2], const double (&cy)[2], const double (&cz)[2],
+                                          const double* __restrict__ at_xyz, const double* __restrict__ acoef, const double* __restrict__ aq,
+                                          int e, double px, double py, double pz, ResJ& j) {
+  const int se = e >= S.nup;
+  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  const bool bcusp = S.nb > 0 && S.b_kind[0] == 1, acusp = S.na > 0 && S.a_kind[0] == 1;
+  const double bcp = bcusp ? S.b_param[0] : 0.0, bca = bcusp ? S.b_aux[0] : 0.0, acp = acusp ? S.a_param[0] : 0.0, aca = acusp ? S.a_aux[0] : 0.0;
+  {
+    double Db[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) Db[i] = S.b_D[i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // partner slot q: spin q
+      const int jj = (q ? S.nup : 0) + r;
+      res_pair_m<true>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, px - cx[q], py - cy[q], pz - cz[q], S.rcut_b, irb, Db,
+                       S.bq + (se + q) * PQA_JQ, bcp, bca, bcusp ? S.bcoeff[se + q] : 0.0, j);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (three pairs interleaved need more registers than the kernel has to spare)
+  {
+    double Da[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) Da[i] = S.a_D[i];
+    for (int q = 0; q < (S.natom > 32 ? 2 : 1); ++q) {
+      const int I = r + 32 * q, Ic = I < S.natom ? I : 0;
+      res_pair_m<false>(S.na > 0 && I < S.natom, px - at_xyz[3 * Ic], py - at_xyz[3 * Ic + 1], pz - at_xyz[3 * Ic + 2], S.rcut_a, ira, Da,
+                        aq + (size_t)(Ic * 2 + se) * PQA_JQ, acp, aca, acusp ? acoef[(Ic * S.na) * 2 + se] : 0.0, j);
+    }
+  }
+}
+template <int KWC>
+__device__ __forceinline__ void res_combine(const double* __restrict__ pb, int PS, int cstride, double* __restrict__ rn_r) {
+  double v[5][KWC];
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int k = 0; k < KWC; ++k) v[c][k] = pb[(size_t)k * 16 * PS + c * cstride];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    double sum = v[c][0];
+#pragma unroll
+    for (int k = 1; k < KWC; ++k) sum += v[c][k];
+    rn_r[c * 32] = sum;
+  }
 }
 
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
@@ -148,8 +282,11 @@ static __device__ unsigned long long pqa_res_clk[64 * 16];
 // Register budget: 256 per thread (two waves per SIMD).  What is carried across the orbital phase is the inverse row (64), the
 // two coordinates (12) and a few indices; everything a proposal hands to its decision waits in LDS (wsc), the accumulators live
 // only across the MFMA loop, and the loads a decision / the next proposal need are issued after the AO phase.
+#ifndef PQA_RES_LB
+#define PQA_RES_LB PQA_RES_NT
+#endif
 template <bool DMC, int LMAX>
-static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwState L, MoveBuf mb, ChunkTab T, ResTab RT, int has_jastrow,
+static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwState L, MoveBuf mb, ChunkTab T, ResTab RT, int has_jastrow,
                                                                   long W, long w_lo, long w_hi) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: scalar)
@@ -159,13 +296,15 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
   const int N = S.nelec, KT = RT.kt;
   double* region = lds;
   double* rowE = region + RT.region;           // [16][32] inverse row of the electron being moved
-  double* wsc = rowE + 16 * 32;                // [16][16] per walker: 0..2 proposal, 3..5 scaled gaussians, 6..8 drift, 9 U at the old position
+  double* wsc = rowE + 16 * 32;                // [16][16] per walker: 0..2 proposal, 3..5 scaled gaussians, 6..8 drift, 9 U at the old position,
+                                               // 10..12 determinant sign / log / running |ratio| product, 13..14 r^2 sums (DMC), 15 accepted moves
   double* sh_xyz = wsc + 16 * 16;
   double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
   double* pr_coef = pr_exp + S.nprim;
   double* at_xyz = pr_coef + S.nprim;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
-  int* sh_meta = (int*)(acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1));  // l, primitives, first primitive, padded row
+  double* aql = acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1);          // merged Pade numerators per (ion, spin)
+  int* sh_meta = (int*)(aql + 2 * (size_t)S.natom * PQA_JQ);  // l, primitives, first primitive, padded row
   int* glist = sh_meta + 4 * (size_t)S.nshell;
   int* goff = glist + RT.nlist;
   int* occ = goff + RT.npass * 32 + 1;
@@ -187,6 +326,7 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
   for (int p = tid; p < S.nprim; p += PQA_RES_NT) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
   for (int k = tid; k < 2 * S.natom * S.na; k += PQA_RES_NT) acoef[k] = has_jastrow ? S.acoeff[k] : 0.0;
+  for (int k = tid; k < 2 * S.natom * PQA_JQ; k += PQA_RES_NT) aql[k] = (has_jastrow && S.jq_on && S.na > 0) ? S.aq[k] : 0.0;
   for (int k = tid; k < RT.nlist; k += PQA_RES_NT) glist[k] = RT.grp_shell[k];
   for (int k = tid; k < RT.npass * 32 + 1; k += PQA_RES_NT) goff[k] = RT.grp_off[k];
   for (int k = tid; k < 64; k += PQA_RES_NT) {
@@ -196,13 +336,12 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
   for (int k = tid; k < RT.region; k += PQA_RES_NT) region[k] = 0.0;  // (K-padding rows of the tile stay finite)
   double cx[2], cy[2], cz[2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int j = r + 32 * q;
-    const double* xj = L.xt + (size_t)(j < N ? j : 0) * 3 * W + wg;
+  for (int q = 0; q < 2; ++q) {  // slot 0: up electron r, slot 1: down electron nup + r
+    const int j = (q ? S.nup : 0) + r;
+    const double* xj = L.xt + (size_t)((r < (q ? S.ndn : S.nup)) ? j : 0) * 3 * W + wg;
     cx[q] = xj[0]; cy[q] = xj[W]; cz[q] = xj[2 * W];
   }
-  int n_acc = 0;
-  double r2p = 0.0, r2a = 0.0;
+  if (r == 0) { ws[13] = 0.0; ws[14] = 0.0; ws[15] = 0.0; }  // r^2 sums of the proposals / the accepted ones (DMC), accepted moves
   const double sq = sqrt(mb.tstep), df = DMC ? 1.0 : mb.tstep;
   __syncthreads();
 
@@ -236,12 +375,27 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
       __builtin_amdgcn_sched_barrier(0);
     }
     int selr = (r < n) ? (int)sels[(size_t)r * W + wg] : 0;  // slot of electron r's cached row
-    double dsg = (s ? L.dsign[1] : L.dsign[0])[wg], dlg = (s ? L.dlog[1] : L.dlog[0])[wg];
+    if (r == 0) {  // per-walker scalars of this spin's sweep live in LDS (wsc 10..12: sign, log, running product of |ratio|)
+      ws[10] = (s ? L.dsign[1] : L.dsign[0])[wg]; ws[11] = (s ? L.dlog[1] : L.dlog[0])[wg]; ws[12] = 1.0;
+    }
 
 #pragma unroll 1
     for (int i = -1; i < n; ++i) {  // iteration i: [orbitals at the proposals of electron i, decide i], then propose i + 1
       const int e = e0 + i;
+      // Everything derived from the thread index is re-derived here from an OPAQUE copy: the loop body is ~10 000 instructions, and
+      // whatever the compiler proves loop-invariant (hundreds of address and mask values) it hoists in front of the loop, keeps live
+      // across it and spills — together with a good part of the inverse row.  A dozen integer instructions per move instead.
+      int tido = tid;
+      asm volatile("" : "+v"(tido));
+      const int lane = tido & 63, wl = tido >> 5, r = tido & 31, pl = tido & 15, grp = tido >> 4, i16 = lane & 15, kq = lane >> 4;
+      const long wraw = w_lo + (long)blockIdx.x * PQA_RES_NW + wl;
+      const bool live = wraw < w_hi;
+      const long wg = live ? wraw : w_hi - 1;
+      double* ws = wsc + wl * 16;
+      double* rn = part + (size_t)KW * 16 * PS + (size_t)wl * PQA_RES_RS;
+      const int oc = occs[r];
       double ro[4] = {0.0, 0.0, 0.0, 0.0}, uacc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      double p0 = 1.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;  // Slater sums at the proposal of electron i
       // loads the decision / the next proposal need (cached row of electron i + 1, tape entries): issued behind the AO phase, used
       // after the contraction
       auto prefetch = [&]() {
@@ -337,34 +491,42 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
         PQA_RCLK(3);
         // ---- this walker's rows: the KW partials added in a fixed order (thread r: orbital r, five components)
         if (r < 16 * nt) {
-#pragma unroll
-          for (int c = 0; c < 5; ++c) {
-            double sum = part[(size_t)wl * PS + c * 16 * nt + r];
-            for (int k2 = 1; k2 < KW; ++k2) sum += part[((size_t)k2 * 16 + wl) * PS + c * 16 * nt + r];
-            rn[c * 32 + r] = sum;
-          }
+          if (KW == 4) res_combine<4>(part + (size_t)wl * PS + r, PS, 16 * nt, rn + r);
+          else res_combine<8>(part + (size_t)wl * PS + r, PS, 16 * nt, rn + r);
         }
         res_wave_sync();
-        // ================= decide electron i (mc.py:124-132; dmc.py:57-70): the same numbers in all lanes of the walker
-        const double te = rowE[wl * 32 + r];  // T[i][r] (zero beyond n)
-        double p0 = rn[oc] * te, p1 = rn[32 + oc] * te, p2 = rn[64 + oc] * te, p3 = rn[96 + oc] * te;
+        PQA_RCLK(7);
+        // Slater sums at the proposal: ratio and gradient rows against T[i] (zero beyond n)
+        const double te = rowE[wl * 32 + r];
+        p0 = rn[oc] * te; p1 = rn[32 + oc] * te; p2 = rn[64 + oc] * te; p3 = rn[96 + oc] * te;
         p0 = res_sum32(p0); p1 = res_sum32(p1); p2 = res_sum32(p2); p3 = res_sum32(p3);
+        PQA_RCLK(8);
+      }
+      const bool have_dec = i >= 0, have_prop = i + 1 < n;
+      bool accd = false;
+      if (have_dec) {
+        // ================= decide electron i (mc.py:124-132; dmc.py:57-70): the same numbers in all lanes of the walker
+        const double npx = ws[0], npy = ws[1], npz = ws[2];
         double hx = finite_or(p1 / p0, 0.0), hy = finite_or(p2 / p0, 0.0), hz = finite_or(p3 / p0, 0.0);
         const double dr = p0;
         const double val = finite_or(dr, 1.0);
         double val2 = val * val;
-        const double npx = ws[0], npy = ws[1], npz = ws[2];
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
-          double ju, jg[3];
-          res_jas_part(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, ju, jg);
-          ju = res_sum32(ju); jg[0] = res_sum32(jg[0]); jg[1] = res_sum32(jg[1]); jg[2] = res_sum32(jg[2]);
-          hx += jg[0]; hy += jg[1]; hz += jg[2];
-          const double ej = exp(ju - ws[9]);
+          ResJ jn{0.0, 0.0, 0.0, 0.0};
+          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, e, npx, npy, npz, jn);
+          else {
+            double g3[3];
+            res_jas_part(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, aql, jn.u, g3);
+            jn.x = g3[0]; jn.y = g3[1]; jn.z = g3[2];
+          }
+          jn.u = res_sum32(jn.u); jn.x = res_sum32(jn.x); jn.y = res_sum32(jn.y); jn.z = res_sum32(jn.z);
+          hx += jn.x; hy += jn.y; hz += jn.z;
+          const double ej = exp(jn.u - ws[9]);
           val2 *= ej * ej;
         }
 #endif
-        bool accd;
+        PQA_RCLK(9);
         {
           const double z0 = ws[3], z1 = ws[4], z2 = ws[5], d0 = ws[6], d1 = ws[7], d2 = ws[8];
           const double fwd = z0 * z0 + z1 * z1 + z2 * z2;
@@ -380,16 +542,15 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
           double ratio = val2 * exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
           if (DMC) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
           accd = ratio > uacc;
-          if (DMC) {
+          if (DMC && r == 0) {
             const double rx = z0 + d0, ry = z1 + d1, rz = z2 + d2, r2 = rx * rx + ry * ry + rz * rz;
-            r2p += r2;
-            if (accd) r2a += r2;
+            ws[13] += r2;
+            if (accd) ws[14] += r2;
           }
         }
         if (live && r == 0 && mb.accept_rec) mb.accept_rec[(size_t)e * W + wg] = accd;
         PQA_RCLK(4);
         if (accd) {
-          ++n_acc;
           // Sherman-Morrison on the register rows (slater.py:88-94): R = T_old[i] / ratio, T[j] -= R (V . T[j]), T[i] = R;
           // the row's dot product in the PQA_ROWDOT order of the lane-per-walker kernels.  Eight columns at a time (the
           // scheduling fences keep the compiler from requesting all 64 LDS operands at once)
@@ -400,7 +561,11 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
           for (int k8 = 0; k8 < 4; ++k8) {
             if (ident) {
 #pragma unroll
-              for (int k = 8 * k8; k < 8 * k8 + 8; ++k) p4[k8] += rn[k] * t[k];
+              for (int k = 8 * k8; k < 8 * k8 + 8; k += 2) {
+                const double2 v2 = *reinterpret_cast<const double2*>(rn + k);
+                p4[k8] += v2.x * t[k];
+                p4[k8] += v2.y * t[k + 1];
+              }
             } else {
 #pragma unroll
               for (int k = 8 * k8; k < 8 * k8 + 8; ++k) p4[k8] += rn[occs[k]] * t[k];
@@ -412,17 +577,28 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
 #pragma unroll
           for (int k8 = 0; k8 < 4; ++k8) {
 #pragma unroll
-            for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {
-              const double R = Re[k] * inv;
-              t[k] = (r == i) ? R : t[k] - R * tmp;
+            for (int k = 8 * k8; k < 8 * k8 + 8; k += 2) {
+              const double2 r2 = *reinterpret_cast<const double2*>(Re + k);
+              const double R0 = r2.x * inv, R1 = r2.y * inv;
+              t[k] = (r == i) ? R0 : t[k] - R0 * tmp;
+              t[k + 1] = (r == i) ? R1 : t[k + 1] - R1 * tmp;
             }
             __builtin_amdgcn_sched_barrier(0);
           }
 #endif
-          dsg *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
-          dlg += log(fabs(dr));
-          if (r == (e & 31)) {
-            if (e >> 5) { cx[1] = npx; cy[1] = npy; cz[1] = npz; } else { cx[0] = npx; cy[0] = npy; cz[0] = npz; }
+          PQA_RCLK(13);
+          // sign and log of the determinant (per walker, in LDS; lane 0): the ratios' magnitudes as a running product, its
+          // logarithm taken when it leaves [1e-60, 1e60] and at the end of the spin's sweep (log of a product = sum of logs to
+          // rounding; one log per move was ~1 us)
+          if (r == 0) {
+            ws[10] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+            double lpr = ws[12] * fabs(dr);
+            if (!(lpr > 1e-60 && lpr < 1e60)) { ws[11] += log(lpr); lpr = 1.0; }
+            ws[12] = lpr;
+            ws[15] += 1.0;
+          }
+          if (r == i) {
+            if (s) { cx[1] = npx; cy[1] = npy; cz[1] = npz; } else { cx[0] = npx; cy[0] = npy; cz[0] = npz; }
           }
           // the proposal's rows become the cached rows of electron i: into the walker's other slot, selector flipped
           const int cur = __shfl(selr, (lane & 32) | i, 64);
@@ -439,7 +615,7 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
         PQA_RCLK(5);
       }
       // ================= propose electron i + 1 (mc.py:117-121): drift at its current position
-      if (i + 1 < n) {
+      if (have_prop) {
         const int ip = i + 1, ep = e0 + ip;
         res_wave_sync();  // (the decision's reads of rowE and wsc are done)
         if (r == ip) {
@@ -447,26 +623,33 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
           for (int k = 0; k < 32; ++k) rowE[wl * 32 + k] = t[k];
         }
         res_wave_sync();
+        PQA_RCLK(10);
         const double te = rowE[wl * 32 + r];
         double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
         q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
         double gx = finite_or(q1 / q0, 0.0), gy = finite_or(q2 / q0, 0.0), gz = finite_or(q3 / q0, 0.0);
-        const int src = (lane & 32) | (ep & 31);
-        const double ex = __shfl((ep >> 5) ? cx[1] : cx[0], src, 64), ey = __shfl((ep >> 5) ? cy[1] : cy[0], src, 64),
-                     ez = __shfl((ep >> 5) ? cz[1] : cz[0], src, 64);
+        const int src = (lane & 32) | ip;
+        const double pox = __shfl(s ? cx[1] : cx[0], src, 64), poy = __shfl(s ? cy[1] : cy[0], src, 64), poz = __shfl(s ? cz[1] : cz[0], src, 64);
         double U0 = 0.0;
+        PQA_RCLK(11);
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
-          double jg[3];
-          res_jas_part(S, ep, r, ex, ey, ez, cx, cy, cz, at_xyz, acoef, U0, jg);
-          U0 = res_sum32(U0); jg[0] = res_sum32(jg[0]); jg[1] = res_sum32(jg[1]); jg[2] = res_sum32(jg[2]);
-          gx += jg[0]; gy += jg[1]; gz += jg[2];
+          ResJ jo{0.0, 0.0, 0.0, 0.0};
+          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, ep, pox, poy, poz, jo);
+          else {
+            double g3[3];
+            res_jas_part(S, ep, r, pox, poy, poz, cx, cy, cz, at_xyz, acoef, aql, jo.u, g3);
+            jo.x = g3[0]; jo.y = g3[1]; jo.z = g3[2];
+          }
+          jo.u = res_sum32(jo.u); jo.x = res_sum32(jo.x); jo.y = res_sum32(jo.y); jo.z = res_sum32(jo.z);
+          U0 = jo.u; gx += jo.x; gy += jo.y; gz += jo.z;
         }
 #endif
+        PQA_RCLK(12);
         if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else limdrift3(gx, gy, gz);
         const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
         if (r == 0) {
-          ws[0] = ex + z0 + gx * df; ws[1] = ey + z1 + gy * df; ws[2] = ez + z2 + gz * df;
+          ws[0] = pox + z0 + gx * df; ws[1] = poy + z1 + gy * df; ws[2] = poz + z2 + gz * df;
           ws[3] = z0; ws[4] = z1; ws[5] = z2; ws[6] = gx; ws[7] = gy; ws[8] = gz; ws[9] = U0;
         }
         res_wave_sync();
@@ -483,21 +666,21 @@ static __global__ __launch_bounds__(PQA_RES_NT) void k_sweep_res(SysDev S, LwSta
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (live && r == 0) { (s ? L.dsign[1] : L.dsign[0])[wg] = dsg; (s ? L.dlog[1] : L.dlog[0])[wg] = dlg; }
+    if (live && r == 0) { (s ? L.dsign[1] : L.dsign[0])[wg] = ws[10]; (s ? L.dlog[1] : L.dlog[0])[wg] = ws[11] + log(ws[12]); }
     __syncthreads();  // (rowE / region reads of this spin's last decision before the next spin's first proposal)
   }
   if (live) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int j = r + 32 * q;
-      if (j < N) {
+      const int j = (q ? S.nup : 0) + r;
+      if (r < (q ? S.ndn : S.nup)) {
         double* xj = L.xt + (size_t)j * 3 * W + wg;
         xj[0] = cx[q]; xj[W] = cy[q]; xj[2 * W] = cz[q];
       }
     }
     if (r == 0) {
-      mb.acc_w[wg] += n_acc;
-      if (DMC) { mb.r2_prop[wg] += r2p; mb.r2_acc[wg] += r2a; }
+      mb.acc_w[wg] += (int)ws[15];
+      if (DMC) { mb.r2_prop[wg] += ws[13]; mb.r2_acc[wg] += ws[14]; }
     }
   }
 }
