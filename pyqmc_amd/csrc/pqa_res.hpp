@@ -53,7 +53,7 @@ struct ResTab {
 __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
   const size_t d = 16 * 32 + 16 * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
-                   2 * (size_t)natom * PQA_JQ;
+                   2 * (size_t)natom * PQA_JQ + (3 * PQA_JQ + 24);
   const size_t i = 4 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
   return d * sizeof(double) + i * sizeof(int);
 }
@@ -76,6 +76,11 @@ __device__ __forceinline__ double res_sum32(double v) {
   const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
   return v + __hiloint2double(hi, lo);
 }
+// Block barrier for LDS hand-overs: __syncthreads() carries a fence that waits for vmcnt(0) — every cached-row / tape prefetch and
+// every cache-row store in flight (HBM round trips) at each of the four barriers of a move.  Nothing a barrier of this kernel
+// orders goes through global memory (a thread only re-reads global data written by earlier launches), so: this wave's LDS
+// operations done, then the barrier.
+__device__ __forceinline__ void res_block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // LDS written by other lanes of the SAME wave: the hardware executes a wave's DS instructions in order; this keeps the compiler
 // from moving accesses across the point.
 __device__ __forceinline__ void res_wave_sync() {
@@ -224,29 +229,33 @@ __device__ __forceinline__ void res_pair_m(bool valid, double dx, double dy, dou
   a.u += du; a.x += sg * dx; a.y += sg * dy; a.z += sg * dz;
 }
 // This thread's share of U, grad U of electron e at (px, py, pz), merged route: the two electron partners interleaved, then the ion(s).
+// Every table comes from the block's LDS copy jt (electron-electron numerators [3][PQA_JQ], denominators b_D, a_D, cusp coefficients
+// bcoeff[0][0..2]) and aq: a vector load from global memory in here makes the compiler wait for vmcnt(0), i.e. for the row / tape
+// prefetches and the cache-row stores still in flight (3.7 us per evaluation instead of ~1).
+#define PQA_RES_JT (3 * PQA_JQ + 24)
 __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (&cx)[2], const double (&cy)[2], const double (&cz)[2],
                                           const double* __restrict__ at_xyz, const double* __restrict__ acoef, const double* __restrict__ aq,
-                                          int e, double px, double py, double pz, ResJ& j) {
+                                          const double* __restrict__ jt, int e, double px, double py, double pz, ResJ& j) {
   const int se = e >= S.nup;
-  const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
+  const double irb = jt[3 * PQA_JQ + 13], ira = jt[3 * PQA_JQ + 14];  // (loop-invariant VALU results would be hoisted and spilled)
   const bool bcusp = S.nb > 0 && S.b_kind[0] == 1, acusp = S.na > 0 && S.a_kind[0] == 1;
   const double bcp = bcusp ? S.b_param[0] : 0.0, bca = bcusp ? S.b_aux[0] : 0.0, acp = acusp ? S.a_param[0] : 0.0, aca = acusp ? S.a_aux[0] : 0.0;
   {
     double Db[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) Db[i] = S.b_D[i];
+    for (int i = 0; i < 5; ++i) Db[i] = jt[3 * PQA_JQ + i];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {  // partner slot q: spin q
       const int jj = (q ? S.nup : 0) + r;
-      res_pair_m<true>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, px - cx[q], py - cy[q], pz - cz[q], S.rcut_b, irb, Db,
-                       S.bq + (se + q) * PQA_JQ, bcp, bca, bcusp ? S.bcoeff[se + q] : 0.0, j);
+      res_pair_m<false>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, px - cx[q], py - cy[q], pz - cz[q], S.rcut_b, irb, Db,
+                        jt + (se + q) * PQA_JQ, bcp, bca, jt[3 * PQA_JQ + 10 + se + q], j);
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // (three pairs interleaved need more registers than the kernel has to spare)
   {
     double Da[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) Da[i] = S.a_D[i];
+    for (int i = 0; i < 5; ++i) Da[i] = jt[3 * PQA_JQ + 5 + i];
     for (int q = 0; q < (S.natom > 32 ? 2 : 1); ++q) {
       const int I = r + 32 * q, Ic = I < S.natom ? I : 0;
       res_pair_m<false>(S.na > 0 && I < S.natom, px - at_xyz[3 * Ic], py - at_xyz[3 * Ic + 1], pz - at_xyz[3 * Ic + 2], S.rcut_a, ira, Da,
@@ -304,7 +313,8 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   double* at_xyz = pr_coef + S.nprim;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
   double* aql = acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1);          // merged Pade numerators per (ion, spin)
-  int* sh_meta = (int*)(aql + 2 * (size_t)S.natom * PQA_JQ);  // l, primitives, first primitive, padded row
+  double* jt = aql + 2 * (size_t)S.natom * PQA_JQ;                             // electron-electron Jastrow tables (res_jas_m)
+  int* sh_meta = (int*)(jt + PQA_RES_JT);  // l, primitives, first primitive, padded row
   int* glist = sh_meta + 4 * (size_t)S.nshell;
   int* goff = glist + RT.nlist;
   int* occ = goff + RT.npass * 32 + 1;
@@ -327,6 +337,20 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
   for (int k = tid; k < 2 * S.natom * S.na; k += PQA_RES_NT) acoef[k] = has_jastrow ? S.acoeff[k] : 0.0;
   for (int k = tid; k < 2 * S.natom * PQA_JQ; k += PQA_RES_NT) aql[k] = (has_jastrow && S.jq_on && S.na > 0) ? S.aq[k] : 0.0;
+  for (int k = tid; k < PQA_RES_JT; k += PQA_RES_NT) {
+    double v = 0.0;
+    if (has_jastrow && S.jq_on) {
+      if (k < 3 * PQA_JQ) v = S.nb > 0 ? S.bq[k] : 0.0;
+      else if (k < 3 * PQA_JQ + 5) v = S.b_D[k - 3 * PQA_JQ];
+      else if (k < 3 * PQA_JQ + 10) v = S.a_D[k - 3 * PQA_JQ - 5];
+      else if (k < 3 * PQA_JQ + 13) v = (S.nb > 0 && S.b_kind[0] == 1) ? S.bcoeff[k - 3 * PQA_JQ - 10] : 0.0;
+    }
+    if (k == 3 * PQA_JQ + 13) v = 1.0 / S.rcut_b;
+    if (k == 3 * PQA_JQ + 14) v = 1.0 / S.rcut_a;
+    if (k == 3 * PQA_JQ + 15) v = sqrt(mb.tstep);
+    if (k == 3 * PQA_JQ + 16) v = 1.0 / (2.0 * mb.tstep);
+    jt[k] = v;
+  }
   for (int k = tid; k < RT.nlist; k += PQA_RES_NT) glist[k] = RT.grp_shell[k];
   for (int k = tid; k < RT.npass * 32 + 1; k += PQA_RES_NT) goff[k] = RT.grp_off[k];
   for (int k = tid; k < 64; k += PQA_RES_NT) {
@@ -342,7 +366,6 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     cx[q] = xj[0]; cy[q] = xj[W]; cz[q] = xj[2 * W];
   }
   if (r == 0) { ws[13] = 0.0; ws[14] = 0.0; ws[15] = 0.0; }  // r^2 sums of the proposals / the accepted ones (DMC), accepted moves
-  const double sq = sqrt(mb.tstep), df = DMC ? 1.0 : mb.tstep;
   __syncthreads();
 
 #pragma unroll 1
@@ -411,7 +434,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       if (i < 0) prefetch();
       if (i >= 0) {
         PQA_RCLK(0);
-        __syncthreads();  // proposals of all 16 walkers are in wsc; the previous move's reads of the region are done
+        res_block_sync();  // proposals of all 16 walkers are in wsc; the previous move's reads of the region are done
         // ================= orbital rows at the 16 proposals
         // (opaque copies: the addresses of the unrolled contraction below depend on them, so the compiler cannot hoist the ~100
         // loop-invariant address values out of the electron loop — it did, and spilled them and a third of the inverse row)
@@ -419,7 +442,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         asm volatile("" : "+s"(kwv), "+s"(ktv));
         for (int ps = 0; ps < RT.npass; ++ps) {
           const int row_base = RT.pass_row0[ps], nks = (RT.pass_row0[ps + 1] - row_base) >> 2;
-          if (ps > 0) __syncthreads();  // the previous pass's MFMA reads of the tile are done
+          if (ps > 0) res_block_sync();  // the previous pass's MFMA reads of the tile are done
           {
             const double px = wsc[pl * 16], py = wsc[pl * 16 + 1], pz = wsc[pl * 16 + 2];
 #ifndef PQA_RES_ABL_NOAO
@@ -443,35 +466,39 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #pragma unroll
           for (int q = 0; q < 3; ++q) bq[q] = (kwv + q * KW < nks) ? cb[(size_t)(kwv + q * KW) * 4 * ldc] : 0.0;
           bq[3] = 0.0;
-          if (ps == RT.npass - 1) prefetch();
           PQA_RCLK(1);
-          __syncthreads();
+          res_block_sync();
           d4 acc[5];
 #pragma unroll
           for (int c = 0; c < 5; ++c) acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
 #ifndef PQA_RES_ABL_NOMFMA
           {
             const double* a_ = region + (size_t)kq * 16 + i16;
+#pragma unroll 1
+            for (int q4 = 0; q4 < PQA_RES_MAXKS; q4 += 4) {  // four k-steps per trip (the ring's static indices)
+              if (kwv + q4 * KW >= nks) break;
 #pragma unroll
-            for (int q = 0; q < PQA_RES_MAXKS; ++q) {
-              const int ks = kwv + q * KW;
-              if (q + 3 < PQA_RES_MAXKS && ks + 3 * KW < nks) bq[(q + 3) & 3] = cb[(size_t)(ks + 3 * KW) * 4 * ldc];
-              if (ks < nks) {
-                double ac[5];
+              for (int qq = 0; qq < 4; ++qq) {
+                const int ks = kwv + (q4 + qq) * KW;
+                if (ks + 3 * KW < nks) bq[(qq + 3) & 3] = cb[(size_t)(ks + 3 * KW) * 4 * ldc];
+                if (ks < nks) {
+                  double ac[5];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) ac[c] = a_[((size_t)c * ktv + 4 * ks) * 16];
+                  for (int c = 0; c < 5; ++c) ac[c] = a_[((size_t)c * ktv + 4 * ks) * 16];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[c], bq[q & 3], acc[c], 0, 0, 0);
+                  for (int c = 0; c < 5; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[c], bq[qq], acc[c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
               }
-              __builtin_amdgcn_sched_barrier(0);
             }
           }
 #endif
+          if (ps == RT.npass - 1) prefetch();
           PQA_RCLK(2);
           // K-partials of this wave: lane holds D[point = kq + 4 rr][orbital = 16 u + i16].  One pass: they take the tile's place
           // (every wave has to be done reading it); several passes: own memory behind the tile, accumulated pass by pass by the
           // same lane
-          if (RT.part_off == 0) __syncthreads();
+          if (RT.part_off == 0) res_block_sync();
           {
             double* pw = part + ((size_t)kw * 16 + kq) * PS + 16 * u + i16;
             if (ps == 0) {
@@ -487,7 +514,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
             }
           }
         }
-        __syncthreads();
+        res_block_sync();
         PQA_RCLK(3);
         // ---- this walker's rows: the KW partials added in a fixed order (thread r: orbital r, five components)
         if (r < 16 * nt) {
@@ -514,7 +541,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jn{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, e, npx, npy, npz, jn);
+          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, e, npx, npy, npz, jn);
           else {
             double g3[3];
             res_jas_part(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, aql, jn.u, g3);
@@ -539,7 +566,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
             bx = z0 + mb.tstep * (d0 + hx); by = z1 + mb.tstep * (d1 + hy); bz = z2 + mb.tstep * (d2 + hz);
           }
           const double bwd = bx * bx + by * by + bz * bz;
-          double ratio = val2 * exp(1.0 / (2.0 * mb.tstep) * (fwd - bwd));
+          double ratio = val2 * exp(jt[3 * PQA_JQ + 16] * (fwd - bwd));
           if (DMC) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
           accd = ratio > uacc;
           if (DMC && r == 0) {
@@ -635,7 +662,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jo{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, ep, pox, poy, poz, jo);
+          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, ep, pox, poy, poz, jo);
           else {
             double g3[3];
             res_jas_part(S, ep, r, pox, poy, poz, cx, cy, cz, at_xyz, acoef, aql, jo.u, g3);
@@ -647,6 +674,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #endif
         PQA_RCLK(12);
         if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else limdrift3(gx, gy, gz);
+        const double sq = jt[3 * PQA_JQ + 15], df = DMC ? 1.0 : mb.tstep;
         const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
         if (r == 0) {
           ws[0] = pox + z0 + gx * df; ws[1] = poy + z1 + gy * df; ws[2] = poz + z2 + gz * df;
