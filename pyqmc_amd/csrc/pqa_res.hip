@@ -99,7 +99,11 @@ bool res_eligible(pqa_handle* h, long W) {
   }
   if (!h->res_ok) return false;
   if (h->res_mode > 0) return true;
-  return W >= h->res_min && W <= h->res_max;
+  // automatic: measured against the launch-per-move sweep (gpurun_out/res_scan.jsonl, round 5; sweep only): (H2O)8 1.66x at 512
+  // walkers, 1.88x at 4096, 1.38x at 16384, 1.06x at 32768, 1.02x at 49152, 0.97x at 65536; H2O (8 electrons: a walker's 32 lanes
+  // are mostly idle) 1.2x up to 4096 walkers, 0.49x at 16384.  One round of blocks (16 walkers per CU) always wins.
+  if (W < h->res_min || W > h->res_max) return false;
+  return W <= 4096 || (std::max(h->nup, h->ndn) >= 16 && W <= 49152);
 }
 
 // One sweep over all electrons of walkers [0, W): a single launch.  mb carries both tapes (the caller drew them if there were none).

@@ -206,7 +206,7 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
 // K <= 4 Pade functions through the KD = 4 polynomials (records and denominators are zero padded); a basis without cusp function
 // passes cusp parameter and coefficient 0.
 #ifndef PQA_RES_JCHAIN
-#define PQA_RES_JCHAIN 4
+#define PQA_RES_JCHAIN 2
 #endif
 struct ResJ { double u, x, y, z; };
 template <bool UNI>
@@ -251,7 +251,9 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
                         jt + (se + q) * PQA_JQ, bcp, bca, jt[3 * PQA_JQ + 10 + se + q], j);
     }
   }
+#if PQA_RES_JCHAIN < 3
   __builtin_amdgcn_sched_barrier(0);  // (three pairs interleaved need more registers than the kernel has to spare)
+#endif
   {
     double Da[5];
 #pragma unroll

@@ -451,6 +451,39 @@ def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
             assert note(f"{cfg}_{W}_pre_vs_general_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-11
 
 
+@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C2", 530)])
+def test_resident_sweep_against_the_launch_per_move_sweep(cfg, W, monkeypatch):
+    """The resident sweep (k_sweep_res: the whole electron sweep of 16 walkers in one block — inverse rows in registers, AO tile +
+    MFMA contraction + decision + Sherman-Morrison on chip, one launch per sweep) against the launch-per-move sweep (k_orb +
+    k_step_lw / k_step_pre per move): the same Philox streams, sums in a different order.  Every Metropolis decision equal, walkers,
+    log-values and energies equal to rounding, the updated state equal to a fresh recompute; W = 1000 leaves a partly filled block
+    and 530 walkers of the 8-electron molecule exercise one orbital tile per spin (8-way K split) and idle lanes.  Open-system DMC
+    steps (drift limiter, fixed-node rejection, r^2 sums, T-moves between the sweeps) go through the same kernel in DMC mode."""
+    import pyqmc_amd as pa
+
+    outs = []
+    for res in ("0", "1"):
+        monkeypatch.setenv("PQA_RES", res)  # read when the handle is created
+        mol, wf, _, _ = build(cfg)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(11)))
+        acc, en, rec = dev.vmc_sweeps(0.3, 3, seed=21, energy=True, record=True)
+        x = dev.configs()
+        out = {"rec": rec, "x": x, "logv": dev.value()[1], "en": np.asarray(en), "acc": np.asarray(acc)}
+        out["upd"] = float(np.max(np.abs(dev.recompute(x)[1] - out["logv"])))
+        w = np.ones(W)
+        et = float(np.real(en[-1][5]))
+        avg, dacc = dev.dmc_steps(0.02, 2, w, 10.0, et, et, seed=5)
+        out.update(x2=dev.configs(), avg=avg.copy(), dacc=dacc.copy(), w=w.copy())
+        outs.append(out)
+    a, b = outs
+    assert np.array_equal(a["rec"], b["rec"]) and np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["dacc"], b["dacc"])
+    assert note(f"{cfg}_{W}_resident_update_vs_recompute", b["upd"]) < 1e-9
+    for k in a:
+        if k not in ("rec", "acc", "dacc", "upd"):
+            assert note(f"{cfg}_{W}_resident_vs_launches_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-10
+
+
 def _scf_kinetic_energy(cell, mf, n=20):
     """2 sum_k sum_occ 1/2 int_cell |grad psi_kn|^2 — the supercell's kinetic energy of the SCF determinant — by midpoint quadrature
     of the oracle's lattice-summed AOs over the primitive cell (periodic integrands: spectrally accurate; the role of

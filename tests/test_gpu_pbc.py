@@ -754,8 +754,8 @@ def test_complex_testvalue_many_matches_reference(tag):
     assert np.array_equal(wf.testvalue_many(es, epos, mask=mask), wf.testvalue_many(es, epos)[mask])
 
 
-@pytest.mark.parametrize("periodic", [False, True])
-def test_event_brackets_do_not_change_the_sweep(periodic, monkeypatch):
+@pytest.mark.parametrize("periodic,resident", [(False, False), (False, True), (True, False)])
+def test_event_brackets_do_not_change_the_sweep(periodic, resident, monkeypatch):
     """The measurement entry points (pqa_profile_enable / pqa_profile_query*: HIP events around a sample of the orbital,
     partial-sum and flush launches, read by bench.py and tools/pbc_bench.py) must leave the numbers alone: the same seeded
     sweep with and without them gives identical acceptances and energies, and the queries report bracketed launches with a
@@ -763,6 +763,7 @@ def test_event_brackets_do_not_change_the_sweep(periodic, monkeypatch):
     import pyqmc_amd as pa
 
     monkeypatch.delenv("PQA_LW", raising=False)  # the partial-sum brackets belong to the (default) lane-per-walker sweep
+    monkeypatch.setenv("PQA_RES", "1" if resident else "0")  # resident sweep: ONE bracketed launch per sweep (W x N x 5 point-components)
     if periodic:
         sup, mf = helpers.pbc_slater_case("fcc2cubic")
     else:
@@ -778,9 +779,12 @@ def test_event_brackets_do_not_change_the_sweep(periodic, monkeypatch):
         dev.sync()
         if prof:
             launches, ms, point_comps = dev.profile_query()
-            assert launches > 0 and ms > 0.0 and point_comps == launches * 256 * 5
-            p_launches, p_ms, groups = dev.profile_query_part()
-            assert p_launches > 0 and p_ms > 0.0 and groups >= 1
+            if resident:
+                assert launches == 2 and ms > 0.0 and point_comps == launches * 256 * dev.N * 5
+            else:
+                assert launches > 0 and ms > 0.0 and point_comps == launches * 256 * 5
+                p_launches, p_ms, groups = dev.profile_query_part()
+                assert p_launches > 0 and p_ms > 0.0 and groups >= 1
             dev.profile_enable(False)
         out[prof] = (np.array(acc), np.array(en))
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
