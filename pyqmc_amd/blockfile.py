@@ -158,11 +158,14 @@ class BlockFile:
 
 
 def h5py_interpreter():
-    """An interpreter with h5py + numpy for ``to_hdf5`` where this one has none: ``$PQA_H5PY_PYTHON``, else the image's Anaconda
-    python; None if neither works."""
+    """An interpreter with h5py + numpy for ``to_hdf5`` where this one has none: ``$PQA_H5PY_PYTHON``, else the first ``python3`` /
+    ``python`` on PATH (and conda's usual prefix) that imports both; None if none does."""
+    import shutil
     import subprocess
 
-    for cand in (os.environ.get("PQA_H5PY_PYTHON"), "/opt/conda/bin/python3.9"):
+    cands = [os.environ.get("PQA_H5PY_PYTHON")] + [shutil.which(n) for n in ("python3", "python")] + \
+            [os.path.join(os.environ.get("CONDA_PREFIX", "/opt/conda"), "bin", "python")]
+    for cand in cands:
         if cand and os.path.exists(cand):
             if subprocess.run([cand, "-c", "import h5py, numpy"], capture_output=True).returncode == 0:
                 return cand

@@ -167,7 +167,21 @@ def load_scf(path, backend=None):
             return [mo[0], mo[1]], [occ[0], occ[1]]
 
         periodic = hasattr(mol, "a") or hasattr(mol, "lattice_vectors")
-        if "scf/mo_coeff" in f:
+        if "scf/mo_coeff" in f and periodic and "scf/kpts" in f:
+            # a k-point SCF whose orbitals were stored as ARRAYS (equal orbital counts at every k): KRHF mo_coeff (nk, nao, nmo),
+            # mo_occ (nk, nmo); KUHF (2, nk, nao, nmo) / (2, nk, nmo) — split along k into the [spin][k] lists, as pyscf's
+            # mf.mo_coeff[k] indexing does for lists and arrays alike.  Never read as one k-point.
+            mo_a, occ_a, kpts = np.asarray(arr("scf/mo_coeff")), np.asarray(arr("scf/mo_occ")), np.asarray(arr("scf/kpts"), dtype=float).reshape(-1, 3)
+            nk = len(kpts)
+            if occ_a.ndim == 2 and mo_a.ndim == 3 and len(mo_a) == nk and len(occ_a) == nk:
+                per_k = [uhf(mo_a[k], occ_a[k]) for k in range(nk)]
+                mf = KMeanField(kpts, [[pk[0][sp] for pk in per_k] for sp in (0, 1)], [[pk[1][sp] for pk in per_k] for sp in (0, 1)])
+            elif occ_a.ndim == 3 and mo_a.ndim == 4 and mo_a.shape[:2] == (2, nk) and occ_a.shape[:2] == (2, nk):
+                mf = KMeanField(kpts, [[mo_a[sp, k] for k in range(nk)] for sp in (0, 1)], [[occ_a[sp, k] for k in range(nk)] for sp in (0, 1)])
+            else:
+                raise NotImplementedError(f"k-point SCF with mo_coeff {mo_a.shape} / mo_occ {occ_a.shape} for {nk} k-points")
+            mf.mo_energy = None
+        elif "scf/mo_coeff" in f:
             mo, occ = uhf(arr("scf/mo_coeff"), arr("scf/mo_occ"))
             if periodic:  # a single-k-point SCF of a cell (pbc.scf.RHF / UHF with kpt): a one-entry k-point list
                 kpt = arr("scf/kpt") if "scf/kpt" in f else np.zeros(3)

@@ -815,7 +815,8 @@ static __global__ PQA_STEP_BOUNDS void k_step_lw(SysDev S, LwState L, MoveBuf mb
 // move.  k_jas_pre forms exactly the partial sums k_step_lw would (same block geometry, same strided partner lists, the pair
 // (e_prop, e_acc) left to k_step_lw: lw_jastrow_part) and is launched on a side stream NEXT TO k_orb, whose waves leave the
 // SIMDs' fp64 pipe idle a quarter of the time and 96 registers per SIMD free: the sums cost the move nothing, k_step_lw
-// loads 2 x 4 doubles per thread instead.  Bitwise the same sums as the in-kernel route (tests: PQA_JPRE=0 / 1).
+// loads 2 x 4 doubles per thread instead.  OPT-IN experiment (PQA_JPRE=1, off by default, DESIGN.md section 4: it lost): the sums here go
+// function by function, the wide k_step_lw's own go through the merged Pade route, so the two routes agree to rounding, not bitwise.
 template <bool PBC>
 static __global__ __launch_bounds__(256) void k_jas_pre(SysDev S, LwState L, MoveBuf mb, StepArgs a, double* __restrict__ jnew, double* __restrict__ jold) {
   const int NW = a.NW, G = a.G;

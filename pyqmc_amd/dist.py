@@ -40,15 +40,18 @@ def allreduce_block(local_sums, local_count, device=None):
 
     sums = np.asarray(local_sums).ravel()
     cplx = np.iscomplexobj(sums)  # complex wave functions: <acc>ecp and <acc>total are complex (eval_ecp.py:89); RCCL reduces reals
-    flat = np.concatenate([sums.real, sums.imag]) if cplx else sums
+    # real and imaginary parts are ALWAYS packed: the tensor length must not depend on a rank's local dtype (one rank's block real,
+    # another's complex — own propagate functions, accumulators returning reals — would all-reduce tensors of different lengths)
+    flat = np.concatenate([sums.real, sums.imag if cplx else np.zeros(len(sums))])
     t = torch.tensor(np.concatenate([np.asarray(flat, dtype=np.float64), [float(local_count)]]), dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _world_one_collectives()):
         dist.all_reduce(t)
     t = t.cpu().numpy()
     means = t[:-1] / t[-1]
-    if cplx:
-        means = means[: len(sums)] + 1j * means[len(sums):]
-    return means, t[-1]
+    re, im = means[: len(sums)], means[len(sums):]
+    if cplx or np.any(im != 0.0):  # (some rank's block was complex)
+        return re + 1j * im, t[-1]
+    return re, t[-1]
 
 
 def _world_one_collectives():

@@ -165,3 +165,33 @@ def test_load_scf_single_k_and_unrestricted_layouts(name, nelec, nao):
     for s in (0, 1):
         C = mf.mo_coeff[s][0]
         assert np.abs(C.conj().T @ S @ C - np.eye(nao)).max() < 5e-6, s  # (quadrature of the 13.01-exponent s function limits this)
+
+
+@pytest.mark.parametrize("unrestricted", [False, True])
+def test_load_scf_k_point_orbitals_stored_as_arrays(unrestricted, monkeypatch):
+    """A k-point SCF whose orbitals PySCF stored as arrays (``scf/mo_coeff`` (nk, nao, nmo) / ``scf/mo_occ`` (nk, nmo); unrestricted
+    (2, nk, ...)) next to ``scf/kpts`` — equal orbital counts at every k — must come back as the same [spin][k] lists as the
+    ``__from_list__`` layout of the reference's diamond checkpoint, never as the single-k-point branch with k = 0 and k = 1 taken for
+    the two spin channels.  Shapes that fit neither layout raise."""
+    path = os.path.join(FILES, "diamond_primitive.hdf5")
+    cell, ref = chkfile.load_scf(path, backend="lite")
+    nk = len(ref.kpts)
+    mo = np.stack([ref.mo_coeff[0][k] for k in range(nk)])
+    occ2 = np.stack([ref.mo_occ[0][k] + ref.mo_occ[1][k] for k in range(nk)])  # restricted occupations 0 / 2
+    data = {"scf/kpts": np.asarray(ref.kpts), "scf/e_tot": np.float64(-1.0)}
+    if unrestricted:
+        data["scf/mo_coeff"] = np.stack([mo, mo])
+        data["scf/mo_occ"] = np.stack([np.stack(ref.mo_occ[0]), np.stack(ref.mo_occ[1])])
+    else:
+        data["scf/mo_coeff"], data["scf/mo_occ"] = mo, occ2
+    monkeypatch.setattr(chkfile, "load_mol", lambda p, b=None: cell)
+    monkeypatch.setattr(chkfile, "_open", lambda p, b=None: (data, lambda n: data[n], lambda n: [], lambda: None))
+    _, mf = chkfile.load_scf("unused", backend="lite")
+    assert type(mf).__name__ == "KMeanField" and np.array_equal(mf.kpts, ref.kpts)
+    for s in (0, 1):
+        assert len(mf.mo_coeff[s]) == nk
+        for k in range(nk):
+            assert np.array_equal(mf.mo_coeff[s][k], ref.mo_coeff[s][k]) and np.array_equal(mf.mo_occ[s][k], ref.mo_occ[s][k])
+    data["scf/mo_occ"] = np.asarray(data["scf/mo_occ"]).reshape(-1)  # neither layout
+    with pytest.raises(NotImplementedError):
+        chkfile.load_scf("unused", backend="lite")
