@@ -303,6 +303,13 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     tbytes = torch.tensor([float(stats["bytes"])], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(tbytes)
+    state_err = None
+    if args.check_state:  # after the exchanges: the resident state (kept walkers gathered, arrivals recomputed) against a fresh recompute
+        logv = dev.value()[1]
+        chk = torch.tensor([float(np.max(np.abs(dev.recompute(dev.configs())[1] - logv)))], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        state_err = float(chk.item())
     info = rank_table(torch, dist, rank, local_rank, world)
     if rank == 0:
         steps = nblocks * nsb
@@ -314,6 +321,7 @@ def dmc_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
                                    "tstep 0.02 with T-moves and Ewald energies; blocks of 5 steps + block reduction + distributed stochastic comb",
                        "walkers_per_gpu": W, "global_walkers": total, "parallelism": f"walker-sharded x{world}"},
             **info, "energy_total": float(blk["energytotal"]), "acceptance": float(blk["acceptance"]), "tmove_acceptance": float(blk["tmove_acceptance"]),
+            "state_vs_recompute": state_err,
             "branching": {"blocks": stats["blocks"], "walkers_moved_per_block": stats["moved"] / max(stats["blocks"], 1),
                           "bytes_sent_per_block_rank0": stats["bytes"] / max(stats["blocks"], 1),
                           "bytes_sent_per_block_all_ranks": float(tbytes.item()) / max(stats["blocks"], 1),
@@ -345,6 +353,8 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="TEST ONLY: all ranks use GPU 0 (needs --backend gloo)")
     ap.add_argument("--unbalance", type=float, default=0.0, help="--mode dmc rehearsal: odd ranks' weights scaled by 1 + this before every comb (and all "
                     "weights spread log-normally), so that walkers cross ranks in every block")
+    ap.add_argument("--check-state", action="store_true", help="--mode dmc: after the timed blocks compare every rank's resident state with a fresh "
+                    "recompute (max |log Psi| difference over all ranks -> state_vs_recompute)")
     ap.add_argument("--device-buffers", action="store_true", help="--mode dmc under gloo: pack / unpack the exchanged walkers in GPU tensors and hand the "
                     "library device pointers (the RCCL code path with gloo as the transport only)")
     args = ap.parse_args()

@@ -384,6 +384,35 @@ def test_rccl_single_rank_communicator_runs_the_collective_routes():
     assert np.allclose(r["w"], r["wsum"] / len(r["w"]))
 
 
+def test_two_gpu_dmc_bench_over_rccl():
+    """The first execution of the multi-GPU data path on real hardware must not be the driver's scaling run: with two visible GPUs,
+    ``bench.py --gpus 2 --mode dmc --unbalance 0.5`` under RCCL (one rank per GPU, torch.distributed.run) — the weights all-gather,
+    the comb, ``batch_isend_irecv`` of device tensors between the two GPUs, the state gather and the recompute of arrivals
+    (dmc.py:279-304, 342-376).  Asserted: two RCCL ranks on two different PCI devices, walkers really crossed ranks, and after the
+    exchanges every rank's resident state equals a fresh recompute.  Skipped on a single-GPU box (every driver box so far)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29741",
+           os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--mode", "dmc", "--unbalance", "0.5", "--walkers", "1024", "--steps", "10", "--warmup", "1",
+           "--check-state", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=helpers.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "nccl"
+    buses = [rk["pci_bus_id"] for rk in line["ranks"]]
+    assert len(set(buses)) == 2 and None not in buses, buses
+    assert line["branching"]["walkers_moved_per_block"] > 0 and line["branching"]["device_buffers"]
+    assert note("two_gpu_dmc_state_vs_recompute", line["state_vs_recompute"]) <= 1e-9
+
+
 def test_energy_statistics_against_the_oracle():
     """north_star: "energies within 1 mHa statistical error of reference" — as a test that can fail.  Trial function: H2O with
     the orbitals of a model one-electron Hamiltonian (systems.model_mf) and the cusp-only default Jastrow, sigma(E_L) ~ 1.6 Ha
