@@ -30,7 +30,16 @@ HBM_ACHIEVABLE_GBS = 6300.0
 FP64_MFMA_ACHIEVABLE_TFLOPS = 72.0
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
+def _newest(pattern):
+    """profiles/rNN_<pattern> of the latest round that has it (tools/refresh_evidence.sh writes them)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r05_" + pattern)
+
+
+PMC_SUMMARY = _newest("pmc_summary.json")  # tools/refresh_evidence.sh -> tools/pmc_summary.py
+KERNEL_STATS = _newest("bench_kernel_stats.csv")  # rocprofv3 --kernel-trace --stats of this command (tools/prof_stats.py)
 
 
 def pmc_kernel(key, walkers):
@@ -46,6 +55,21 @@ def pmc_kernel(key, walkers):
     per_walker = k["bytes_per_launch"] / d["walkers"]
     return {"bytes_per_launch": per_walker * walkers, "bytes_per_walker": per_walker, "fetch_calibration": d["calibration"]["applied_fetch_factor"],
             "write_calibration": d["calibration"]["applied_write_factor"], "measured_at_walkers": d["walkers"], "source": "profiles/" + os.path.basename(PMC_SUMMARY)}
+
+
+def kernel_stats():
+    """Average launch durations (us) of the kernel classes named in the committed rocprofv3 --stats summary of this command."""
+    out = {}
+    if not os.path.exists(KERNEL_STATS):
+        return out
+    import csv
+
+    for row in csv.DictReader(open(KERNEL_STATS)):
+        name = row.get("kernel", "")
+        for key, pat in (("k_orb1", "k_orb<1,"), ("k_orb5", "k_orb<5,"), ("k_step_lw", "k_step_lw<"), ("k_flush_lw", "k_flush_lw<"), ("k_sweep_res", "k_sweep_res<")):
+            if pat in name and key not in out:
+                out[key] = float(row["avg_us"])
+    return out
 
 
 def build_wf(device):
@@ -161,15 +185,32 @@ def extra_measurements(pa, wf, dev, mol, W, args):
             dev.vmc_sweeps(args.tstep, 4, seed=next(seeds), energy=energy)  # leave the initial guess behind
         dev.vmc_sweeps(args.tstep, 1, seed=next(seeds), energy=energy)
         dev.sync()
+        if not args.no_profile:
+            dev.profile_enable(True)
         t0 = time.perf_counter()
         dev.vmc_sweeps(args.tstep, steps, seed=next(seeds), energy=energy)
         dev.sync()
         dt = time.perf_counter() - t0
-        return {"walker_steps_per_s": walkers * steps / dt, "ms_per_step": 1e3 * dt / steps}
+        res = {"walker_steps_per_s": walkers * steps / dt, "ms_per_step": 1e3 * dt / steps}
+        if not args.no_profile:
+            launches, ms, pc = dev.profile_query()
+            dev.profile_enable(False)
+            if launches == steps and pc == launches * walkers * dev.N * 5:
+                # the resident sweep (k_sweep_res: one launch per sweep, every launch bracketed): the whole sweep's MFMA-eligible and
+                # AO-phase flops over the kernel's own duration, against the fp64 pipe both share
+                tf = pc * 2.0 * 184 * 32 / (ms * 1e-3) / 1e12
+                tv = (pc / 5.0) * (30 * 328 + 4 * 5 * 184) / (ms * 1e-3) / 1e12
+                res.update(sweep="resident (k_sweep_res, one launch per sweep)", sweep_kernel_ms=ms / launches,
+                           sweep_kernel_mfma_tflops=tf, sweep_kernel_mfma_frac=tf / FP64_MFMA_PEAK_TFLOPS,
+                           sweep_kernel_ao_valu_frac=tv / FP64_MFMA_PEAK_TFLOPS, us_per_move_of_a_16_walker_block=1e3 * ms / launches / dev.N / max(1.0, walkers / 4096.0))
+            else:
+                res.update(sweep="one k_orb + k_step launch per move")
+        return res
 
-    out = {"sweep_only": rate(W, False), "sweep_plus_energy": rate(W, True), "by_walkers_per_gpu": {}}
-    for w in (4096, 16384, 65536):
+    out = {"sweep_only": rate(W, False), "sweep_plus_energy": rate(W, True), "by_walkers_per_gpu": {}, "sweep_only_by_walkers_per_gpu": {}}
+    for w in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
         out["by_walkers_per_gpu"][str(w)] = out["sweep_plus_energy"] if w == W else rate(w, True)
+        out["sweep_only_by_walkers_per_gpu"][str(w)] = out["sweep_only"] if w == W else rate(w, False)
     return out
 
 
@@ -517,6 +558,52 @@ def main():
                                          "traffic": pmc_kernel("k_flush_lw", W), "launches": c_launches, "avg_launch_ms": c_ms / c_launches,
                                          "kernel_share_of_step": (c_ms / c_launches) * flushes_per_step * args.steps / (1e3 * elapsed),
                                          "algorithmic_bytes_per_walker": alg, "block_KB": kb}
+        # ---- the AO phase of the same k_orb launches against the fp64 VECTOR peak (one pipe with the matrix
+        # path on this part: the two fractions add up to the pipe's utilisation by useful flops).  F_ao = 30 P + 4 ncomp M per point
+        # with P = 328 primitives (one exp each), M = 184 functions, ncomp = 5.
+        nprim = 328
+        f_ao5, f_ao1 = 30 * nprim + 4 * 5 * nao, 30 * nprim + 4 * 1 * nao
+        if not args.no_profile and launches and "roofline" in out:
+            pts = point_comps / 5.0
+            ach = pts * f_ao5 / (orb_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"bound": "valu", "kernel": "k_orb, AO phase (GTO value / gradient / Laplacian of 184 functions, 328 exp per point)",
+                                    "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                    "flops_per_point": f_ao5, "exp_per_point": nprim,
+                                    "pipe_frac_mfma_plus_valu": (ach + out["roofline"]["achieved"]) / FP64_MFMA_PEAK_TFLOPS,
+                                    "note": "same launches and event times as `roofline`; SURVEY 8(d) formula F_ao = 30 P + 4 ncomp M"}
+        stats_k = kernel_stats()
+        if stats_k.get("k_orb1") and ecp_pts:
+            pts1 = ecp_pts / 2.0  # one value-only launch per spin and energy evaluation
+            us = stats_k["k_orb1"]
+            out["roofline_orb1"] = {"bound": "mfma", "kernel": "k_orb<1> (orbital values at the ECP quadrature points, one launch per spin)",
+                                    "achieved": pts1 * 2.0 * nao * nmo / (us * 1e-6) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": pts1 * 2.0 * nao * nmo / (us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                    "valu_frac": pts1 * f_ao1 / (us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                    "avg_launch_us": us, "points_per_launch": pts1,
+                                    "source": "launch duration from profiles/" + os.path.basename(KERNEL_STATS) + " (rocprofv3 of this command), points of THIS run"}
+        # ---- the whole step: useful flops per walker-step from the formula sheet (minimal count: one AO / MO evaluation per move, the
+        # cached rows serve the old position and the kinetic energy) and counter bytes per walker-step, both over ms_per_step
+        acc_rate = float(np.mean(acc))
+        f_j2 = 9500.0  # Jastrow value + gradient of one electron (F_j2), twice per move; with the Laplacian once per electron in the energy
+        f_move = f_ao5 + 2 * 5 * nao * n_s + 2 * (2 * 4 * n_s) + 2 * f_j2 + acc_rate * 4 * n_s * n_s
+        f_kin = N * (2 * 5 * n_s + 1.3 * f_j2)
+        f_ecp = (ecp_pts / W) * (f_ao1 + 2 * nao * n_s + 2 * n_s + 0.5 * f_j2)
+        f_step = N * f_move + f_kin + f_ecp
+        per_step = {"k_step_lw": 77, "k_flush_lw": 14, "k_kinetic_lw": 1, "k_orb5": 64, "k_orb1": 2, "k_ecp_point": 2, "k_ecp_count": 1, "k_ecp_fill": 1}
+        b_step = None
+        if os.path.exists(PMC_SUMMARY):
+            dpm = json.load(open(PMC_SUMMARY))
+            if all(k in dpm.get("kernels", {}) for k in per_step):
+                b_step = sum(n * dpm["kernels"][k]["bytes_per_launch"] / dpm["walkers"] for k, n in per_step.items())
+        ms = 1e3 * elapsed / args.steps
+        out["roofline_step"] = {"useful_flop_per_walker_step": f_step, "mfma_eligible_flop_per_walker_step": N * 2 * 5 * nao * n_s + (ecp_pts / W) * 2 * nao * n_s,
+                                "achieved_tflops": f_step * W / (ms * 1e-3) / 1e12, "frac_of_fp64_peak": f_step * W / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                "counter_bytes_per_walker_step": b_step,
+                                "achieved_gbs": None if b_step is None else b_step * W / (ms * 1e-3) / 1e9,
+                                "frac_of_hbm_peak": None if b_step is None else b_step * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "survey_B_sweep_bytes": 2 * 8 * (3 * N + 2 * n_s * n_s) + N * 2 * 8 * (24 * 4 + 2 * 4),
+                                "formula": "N (F_ao(5) + 2*5*M*n + 16 n + 2 F_j2 + acc*4 n^2) + N (10 n + 1.3 F_j2) + ecp_points (F_ao(1) + 2 M n + 2 n + F_j2/2); "
+                                           "bytes: launches per step x calibrated counter bytes per launch (k_step_lw 77, k_flush_lw 14, k_orb 64 + 2, kinetic, ECP passes)"}
         if world == 1 and not args.no_extra:
             out["extra"] = extra_measurements(pa, wf, dev, mol, W, args)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)
