@@ -252,6 +252,14 @@ int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap);
    unif (N, necp, W) replay the reference's random draws; NULL -> device Philox stream `seed`. */
 int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const double* unif, uint64_t seed, double* out);
 
+/* EnergyAccumulator(naip=...) (accumulators.py:48-51 -> eval_ecp.ecp(..., naip), eval_ecp.py:21, :228-252 get_P_l): the
+   quadrature rule of the ECP integrator of pqa_energy / the energy pass of pqa_vmc_sweeps / pqa_dmc_steps.  naip one of 6, 12,
+   18, 26, 32, 50 — the grids of Mitas, Shirley & Ceperley the reference tabulates (eval_ecp.py:278-336) — for every ECP atom;
+   0 restores the reference's default (naip=None: 6 points for atoms with at most one non-local channel, 12 otherwise,
+   eval_ecp.py:239-240).  Any other value is refused, as get_rot does (eval_ecp.py:266-267).  The T-move candidates
+   (pqa_tmoves, pqa_dmc_steps) keep the default rule: the reference's nonlocal_tmoves does not pass naip (accumulators.py:82-84). */
+int pqa_set_ecp_naip(pqa_handle_t* h, int32_t naip);
+
 /* EnergyAccumulator.nonlocal_tmoves -> eval_ecp.compute_tmoves (eval_ecp.py:43-80) for electron e of the resident
    walkers: the candidate T-moves over every ECP atom's quadrature points (P = pqa_tmove_npoints() per walker).
    rot (necp,3,3), unif (necp,W): the reference's per-atom random rotation / mask uniforms.  Outputs: ratio (W,P)

@@ -4,8 +4,8 @@ Kinetic + open-boundary Coulomb: ``pyqmc/observables/energy.py:19-65``.
 ECP (semi-local pseudopotential) integrator: ``pyqmc/observables/eval_ecp.py``
 — ``ecp`` :21-40, ``ecp_ea`` :83-132, ``ecp_mask`` :135-146, radial ``rnExp`` :182-200,
 Legendre ``P_l`` :203-225, quadrature weights/points ``get_P_l`` :228-252,
-``get_rot`` :255-275, grids :278-336 (octahedral 6-point "OA" and icosahedral
-12-point "IAB" rules of Mitas, Shirley & Ceperley, JCP 95, 3467 (1991)).
+``get_rot`` :255-275, grids :278-336 (the 6/18/26/50-point octahedral and 12/32-point
+icosahedral rules of Mitas, Shirley & Ceperley, JCP 95, 3467 (1991)).
 Harness: ``EnergyAccumulator.__call__`` ``pyqmc/observables/accumulators.py:60-75``.
 
 Randomness is injected, never drawn here: ``rot`` is one 3x3 rotation per
@@ -78,18 +78,31 @@ def legendre(x, l):
 
 
 def quadrature(naip):
-    """eval_ecp.py:278-336, the two rules the default path uses (naip = 6 or 12)."""
-    if naip == 6:
-        pts = np.array([[-1, 0, 0], [0, -1, 0], [0, 0, -1], [0, 0, 1], [0, 1, 0], [1, 0, 0]], dtype=float)
-        return pts, np.full(6, 1.0 / 6.0)
-    if naip == 12:
-        b1 = np.arctan(2.0)
-        k = np.arange(10)
-        th = np.concatenate([[0.0, np.pi], np.tile([b1, np.pi - b1], 5)])
-        ph = np.concatenate([[0.0, 0.0], k * np.pi / 5])
-        pts = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1)
-        return pts, np.full(12, 1.0 / 12.0)
-    raise NotImplementedError(naip)
+    """eval_ecp.py:278-336: the six rules of Mitas, Shirley & Ceperley, JCP 95, 3467 (1991), points in the reference's order.
+    Octahedral families: the 26 non-zero points of {-1,0,1}^3 (x slowest) split by how many coordinates are non-zero and
+    normalised (A: 6 axes, B: 12 edge midpoints, C: 8 corners), D: the 24 points (+-1,+-1,+-3)/sqrt(11) as three cyclic column
+    shifts.  Icosahedral families by polar angle: A poles, B at atan 2, C at the two angles c_1, c_2."""
+    cube = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)], dtype=float)
+    nnz = np.count_nonzero(cube, axis=1)
+    oct_ = [cube[nnz == k] / np.sqrt(k) for k in (1, 2, 3)]
+    d1 = oct_[2] * np.sqrt(3.0 / 11.0) * np.array([1.0, 1.0, 3.0])
+    oct_.append(np.concatenate([np.roll(d1, i, axis=1) for i in range(3)]))
+    k = np.arange(10)
+    s5 = np.sqrt(5.0)
+    b1, c1, c2 = np.arctan(2.0), np.arccos((2 + s5) / np.sqrt(15 + 6 * s5)), np.arccos(1 / np.sqrt(15 + 6 * s5))
+
+    def sph(th, ph):
+        return np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=1)
+
+    ico = [sph(np.array([0.0, np.pi]), np.zeros(2)), sph(np.tile([b1, np.pi - b1], 5), k * np.pi / 5),
+           sph(np.concatenate([np.tile([np.pi - c1, c1], 5), np.tile([np.pi - c2, c2], 5)]), np.tile(k * np.pi / 5, 2))]
+    rules = {6: (oct_[:1], [1 / 6]), 18: (oct_[:2], [1 / 30, 1 / 15]), 26: (oct_[:3], [1 / 21, 4 / 105, 27 / 840]),
+             50: (oct_[:4], [4 / 315, 64 / 2835, 27 / 1280, 14641 / 725760]),
+             12: (ico[:2], [1 / 12, 1 / 12]), 32: (ico[:3], [5 / 168, 5 / 168, 27 / 840])}
+    if naip not in rules:
+        raise ValueError(f"Possible AIPs are one of {sorted(rules)}")  # eval_ecp.py:266-267
+    fams, w = rules[naip]
+    return np.concatenate(fams), np.concatenate([np.full(len(f), wi) for f, wi in zip(fams, w)])
 
 
 def ecp_ea(mol, configs, wf, e, atom_index, threshold, rot, unif, naip=None):

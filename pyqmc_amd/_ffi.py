@@ -116,6 +116,7 @@ _PROTOTYPES = {
     "pqa_profile_query_commit": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "pqa_profile_query_part": (C.c_int, [_H, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pqa_last_ecp_points": (C.c_int, [_H, C.POINTER(C.c_int64)]),
+    "pqa_set_ecp_naip": (C.c_int, [_H, C.c_int32]),
 }
 
 

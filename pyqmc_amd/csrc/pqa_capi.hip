@@ -316,6 +316,52 @@ static int set_c3(pqa_handle* h, const double* c) {
   return 0;
 }
 
+// The reference's quadrature grids (eval_ecp.py:278-336, generate_quadrature_grids), every rule in the reference's point order.
+// Octahedral families from the 27 points of {-1,0,1}^3 (x slowest, z fastest: numpy's mgrid order) by their count of non-zero
+// coordinates: OA (1, the axes), OB (2, / sqrt 2), OC (3, / sqrt 3), OD = the three cyclic column rolls of (+-1, +-1, +-3) / sqrt 11.
+// Icosahedral families from polar angles: A the poles, B the ten points at atan 2 / pi - atan 2, C the twenty at c_1, c_2.
+static int ecp_quadrature_offset(int naip) {
+  switch (naip) { case 6: return 0; case 12: return 6; case 18: return 18; case 26: return 36; case 32: return 62; case 50: return 94; default: return -1; }
+}
+static void ecp_quadrature_tables(std::vector<double>& quad, std::vector<double>& quadw) {
+  std::vector<std::array<double, 3>> O[4], I[3];
+  for (int x = -1; x <= 1; ++x)
+    for (int y = -1; y <= 1; ++y)
+      for (int z = -1; z <= 1; ++z) {
+        const int nz = (x != 0) + (y != 0) + (z != 0);
+        if (nz == 0) continue;
+        const double sc = nz == 1 ? 1.0 : std::sqrt((double)nz);
+        O[nz - 1].push_back({x / sc, y / sc, z / sc});
+      }
+  {
+    const double f = std::sqrt(3.0 / 11.0);
+    std::vector<std::array<double, 3>> d1;
+    for (auto& p : O[2]) d1.push_back({p[0] * f, p[1] * f, p[2] * f * 3.0});
+    for (int roll = 0; roll < 3; ++roll)  // np.roll(d1, roll, axis=1): column j moves to column (j + roll) % 3
+      for (auto& p : d1) {
+        std::array<double, 3> q;
+        for (int j = 0; j < 3; ++j) q[(j + roll) % 3] = p[j];
+        O[3].push_back(q);
+      }
+  }
+  {
+    const double pi = std::acos(-1.0), b1 = std::atan(2.0), s5 = std::sqrt(5.0);
+    const double c1 = std::acos((2.0 + s5) / std::sqrt(15.0 + 6.0 * s5)), c2 = std::acos(1.0 / std::sqrt(15.0 + 6.0 * s5));
+    auto sph = [](double t, double p) { return std::array<double, 3>{std::sin(t) * std::cos(p), std::sin(t) * std::sin(p), std::cos(t)}; };
+    I[0].push_back(sph(0.0, 0.0)); I[0].push_back(sph(pi, 0.0));
+    for (int k = 0; k < 10; ++k) I[1].push_back(sph(k % 2 == 0 ? b1 : pi - b1, k * pi / 5.0));
+    for (int k = 0; k < 10; ++k) I[2].push_back(sph(k % 2 == 0 ? pi - c1 : c1, k * pi / 5.0));
+    for (int k = 0; k < 10; ++k) I[2].push_back(sph(k % 2 == 0 ? pi - c2 : c2, k * pi / 5.0));
+  }
+  auto emit = [&](const std::vector<std::array<double, 3>>* fam, int nfam, const double* w) {
+    for (int f = 0; f < nfam; ++f)
+      for (auto& p : fam[f]) { quad.insert(quad.end(), p.begin(), p.end()); quadw.push_back(w[f]); }
+  };
+  const double w6[] = {1.0 / 6}, w12[] = {1.0 / 12, 1.0 / 12}, w18[] = {1.0 / 30, 1.0 / 15}, w26[] = {1.0 / 21, 4.0 / 105, 27.0 / 840};
+  const double w32[] = {5.0 / 168, 5.0 / 168, 27.0 / 840}, w50[] = {4.0 / 315, 64.0 / 2835, 27.0 / 1280, 14641.0 / 725760};
+  emit(O, 1, w6); emit(I, 2, w12); emit(O, 2, w18); emit(O, 3, w26); emit(I, 3, w32); emit(O, 4, w50);
+}
+
 static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -678,21 +724,24 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
       TRY(upload_table(h, rc2.data(), rc2.size(), &tmp_d)); S.ecp_rc2 = tmp_d;
     }
   }
-  // quadrature directions (eval_ecp.py:278-336): octahedral 6, icosahedral 12
-  std::vector<double> quad;
-  const double oa[6][3] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}};
-  for (auto& p : oa) quad.insert(quad.end(), p, p + 3);
+  // quadrature grids (eval_ecp.py:278-336): all six rules of Mitas, Shirley & Ceperley in one table — rows 0-5 OA (6), 6-17 IAB (12),
+  // 18-35 OAB (18), 36-61 OABC (26), 62-93 IABC (32), 94-143 OABCD (50) — in the reference's point order, with their weights
   {
-    const double b1 = std::atan(2.0), pi = std::acos(-1.0);
-    std::vector<double> th = {0.0, pi}, ph = {0.0, 0.0};
-    for (int k = 0; k < 10; ++k) { th.push_back(k % 2 == 0 ? b1 : pi - b1); ph.push_back(k * pi / 5.0); }
-    for (int i = 0; i < 12; ++i) {
-      quad.push_back(std::sin(th[i]) * std::cos(ph[i]));
-      quad.push_back(std::sin(th[i]) * std::sin(ph[i]));
-      quad.push_back(std::cos(th[i]));
+    std::vector<double> quad, quadw;
+    ecp_quadrature_tables(quad, quadw);
+    TRY(upload_table(h, quad.data(), quad.size(), &h->d_quad));
+    TRY(upload_table(h, quadw.data(), quadw.size(), &h->d_quadw));
+    std::vector<int> na((size_t)std::max(h->necp, 1), 0), qo((size_t)std::max(h->necp, 1), 0);
+    h->ecp_nch.assign((size_t)h->necp, 0);
+    for (int k = 0; k < h->necp; ++k) {
+      h->ecp_nch[k] = sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k];
+      na[k] = h->ecp_nch[k] <= 2 ? 6 : 12;  // eval_ecp.py:239-240
+      qo[k] = ecp_quadrature_offset(na[k]);
     }
+    TRY(upload_table(h, na.data(), na.size(), &h->d_ecp_naip));
+    TRY(upload_table(h, qo.data(), qo.size(), &h->d_ecp_qoff));
+    S.ecp_naip = h->d_ecp_naip; S.ecp_qoff = h->d_ecp_qoff;
   }
-  TRY(upload_table(h, quad.data(), quad.size(), &h->d_quad));
   {  // flat (atom, quadrature index) list of the T-move candidates of one electron
     std::vector<int> ptk, pti;
     for (int k = 0; k < h->necp; ++k) {
@@ -1884,6 +1933,21 @@ extern "C" int pqa_profile_query_part(pqa_handle_t* h, int64_t* launches, double
     TRY(lw_setup(h, false, lc));
     *groups = lc.Gm;
   }
+  return 0;
+}
+extern "C" int pqa_set_ecp_naip(pqa_handle_t* h, int32_t naip) {
+  HIPCHK(hipSetDevice(h->device));
+  if (naip != 0 && ecp_quadrature_offset(naip) < 0) FAIL("naip must be one of 6, 12, 18, 26, 32, 50 (eval_ecp.py:266-267), or 0 for the per-atom default");
+  if (h->necp == 0) { h->ecp_naip = naip; return 0; }
+  std::vector<int> na((size_t)h->necp), qo((size_t)h->necp);
+  for (int k = 0; k < h->necp; ++k) {
+    na[k] = naip ? naip : (h->ecp_nch[k] <= 2 ? 6 : 12);
+    qo[k] = ecp_quadrature_offset(na[k]);
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->d_ecp_naip, na.data(), na.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_ecp_qoff, qo.data(), qo.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->ecp_naip = naip;
   return 0;
 }
 extern "C" int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints) {

@@ -119,6 +119,10 @@ struct SysDev {
   const double* ecp_term_exp;
   const double* ecp_term_coef;
   const double* ecp_rc2;  // [necp] r^2 beyond which every term of the atom's ECP is below 1e-22 in magnitude (create: ecp_ranges)
+  // quadrature rule of every ECP atom (eval_ecp.py:228-252 get_P_l, :278-336 the Mitas-Shirley-Ceperley grids): naip points starting at
+  // row ecp_qoff[k] of the direction / weight tables (EcpBuf::quad, quadw).  pqa_set_ecp_naip; default 6 (<= 2 channels) or 12.
+  const int* ecp_naip;
+  const int* ecp_qoff;
   int ecp_naip_max;
 };
 

@@ -32,10 +32,12 @@ struct EcpTab {  // same member names as the SysDev tables: ecp_radial_t works o
   const double* ecp_term_exp;
   const double* ecp_term_coef;
   const double* atom;  // [necp][4]: x, y, z of the ECP atom, r^2 range
+  const int* naip;     // [necp] quadrature points of the atom's rule, and the rule's first row in the direction / weight tables
+  const int* qoff;
 };
 
 __host__ __device__ inline size_t ecp_tab_bytes(int necp, int nchan, int nterm) {
-  const size_t d = (size_t)4 * necp + 2 * (size_t)nterm, i = (size_t)(necp + 1) + (nchan + 1) + nterm;
+  const size_t d = (size_t)4 * necp + 2 * (size_t)nterm, i = (size_t)(necp + 1) + (nchan + 1) + nterm + 2 * (size_t)necp;
   return d * sizeof(double) + ((i + 1) / 2) * 2 * sizeof(int);
 }
 
@@ -47,16 +49,19 @@ __device__ __forceinline__ EcpTab ecp_stage(const SysDev& S, int nchan, int nter
   int* ci = reinterpret_cast<int*>(co + nterm);
   int* to = ci + (S.necp + 1);
   int* tn = to + (nchan + 1);
+  int* na = tn + nterm;
+  int* qo = na + S.necp;
   for (int k = tid; k < S.necp; k += nthreads) {
     const int ia = S.ecp_atom[k];
     atom[4 * k] = S.atom_xyz[3 * ia]; atom[4 * k + 1] = S.atom_xyz[3 * ia + 1]; atom[4 * k + 2] = S.atom_xyz[3 * ia + 2];
     atom[4 * k + 3] = S.ecp_rc2[k];
+    na[k] = S.ecp_naip[k]; qo[k] = S.ecp_qoff[k];
   }
   for (int t = tid; t < nterm; t += nthreads) { ex[t] = S.ecp_term_exp[t]; co[t] = S.ecp_term_coef[t]; tn[t] = S.ecp_term_n[t]; }
   for (int k = tid; k <= S.necp; k += nthreads) ci[k] = S.ecp_chan_off[k];
   for (int c = tid; c <= nchan; c += nthreads) to[c] = S.ecp_term_off[c];
   EcpTab T;
-  T.ecp_chan_off = ci; T.ecp_term_off = to; T.ecp_term_n = tn; T.ecp_term_exp = ex; T.ecp_term_coef = co; T.atom = atom;
+  T.ecp_chan_off = ci; T.ecp_term_off = to; T.ecp_term_n = tn; T.ecp_term_exp = ex; T.ecp_term_coef = co; T.atom = atom; T.naip = na; T.qoff = qo;
   return T;
 }
 
@@ -139,7 +144,7 @@ static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S
         ecp_radial_t(T, k, r, B.threshold, v, nch, prob);
         loc += v[nch - 1];
         if (nch > 1 && ecp_pass(S, B, w, W, e, k, prob)) {
-          const int naip = (nch <= 2) ? 6 : 12;
+          const int naip = T.naip[k];
           if (e < S.nup) c_up += naip; else c_dn += naip;
           atomicOr(&pb[k], 1ull << lane);
         }
@@ -162,7 +167,7 @@ static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_count_t(SysDev S
   if (lane == 0 && wlive) B.local[w] = loc;
   if (B.nseg > 1) {  // atom-major: points of (atom lane, walker w), spin up and spin down
     if (lane < S.necp && wlive) {
-      const int naip = (T.ecp_chan_off[lane + 1] - T.ecp_chan_off[lane] <= 2) ? 6 : 12;
+      const int naip = T.naip[lane];
       B.cnt[(size_t)lane * W + w] = naip * k_up;
       B.cnt[(size_t)B.nseg * W + (size_t)lane * W + w] = naip * k_dn;
     }
@@ -191,8 +196,7 @@ static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S,
   long* eo = eo_[wv];
   // lane q = (atom k, electron block eb): its entries, atom-major, electrons ascending
   const int kq = (lane < nq) ? lane / neb : 0, ebq = (lane < nq) ? lane % neb : 0;
-  const int nchq = T.ecp_chan_off[kq + 1] - T.ecp_chan_off[kq];
-  const int naipq = (nchq <= 2) ? 6 : 12;
+  const int naipq = T.naip[kq];
   const int nup_here = S.nup - ebq * 64;  // bits below it are spin-up electrons
   const unsigned long long upmask = (nup_here >= 64) ? ~0ull : ((nup_here <= 0) ? 0ull : ((1ull << nup_here) - 1ull));
   const int cu = __popcll(m & upmask), cd = __popcll(m & ~upmask);
@@ -253,28 +257,29 @@ static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S,
       double v[PQA_MAXCHAN], prob;
       int nch;
       ecp_radial_t(T, k, r, B.threshold, v, nch, prob);
-      const int naip = (nch <= 2) ? 6 : 12;
+      const int naip = T.naip[k], qoff = T.qoff[k];
       double Rm[9];
 #pragma unroll
       for (int q = 0; q < 9; ++q) Rm[q] = __shfl(Rl, (lane & 48) + q, 64);
-      if (act && wlive && l16 < naip) {
-        const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * l16;
-        const double vx = Rm[0] * qd[0] + Rm[1] * qd[1] + Rm[2] * qd[2];
-        const double vy = Rm[3] * qd[0] + Rm[4] * qd[1] + Rm[5] * qd[2];
-        const double vz = Rm[6] * qd[0] + Rm[7] * qd[1] + Rm[8] * qd[2];
-        const double rix = r * vx, riy = r * vy, riz = r * vz;  // eval_ecp.py:242
-        const double cosv = (dx * rix + dy * riy + dz * riz) / (r * sqrt(rix * rix + riy * riy + riz * riz));
-        double wsum = 0.0;
-        for (int c = 0; c < nch - 1; ++c) wsum += (v[c] / prob) * (2 * c + 1) * legendre_l(c, cosv);
-        const long slot = off + l16;
-        B.pts[s][3 * slot] = (x0 - dx) + rix;  // eval_ecp.py:110
-        B.pts[s][3 * slot + 1] = (y0 - dy) + riy;
-        B.pts[s][3 * slot + 2] = (z0 - dz) + riz;
-        B.wgt[s][slot] = wsum * (1.0 / naip);
-        B.pte[s][slot] = e;
-        B.ptw[s][slot] = (int)w;
-        B.u0[s][slot] = U0;
-      }
+      if (act && wlive)
+        for (int ip = l16; ip < naip; ip += 16) {  // (6 or 12 points: one trip; the 18- to 50-point rules: up to four)
+          const double* qd = B.quad + 3 * (qoff + ip);
+          const double vx = Rm[0] * qd[0] + Rm[1] * qd[1] + Rm[2] * qd[2];
+          const double vy = Rm[3] * qd[0] + Rm[4] * qd[1] + Rm[5] * qd[2];
+          const double vz = Rm[6] * qd[0] + Rm[7] * qd[1] + Rm[8] * qd[2];
+          const double rix = r * vx, riy = r * vy, riz = r * vz;  // eval_ecp.py:242
+          const double cosv = (dx * rix + dy * riy + dz * riz) / (r * sqrt(rix * rix + riy * riy + riz * riz));
+          double wsum = 0.0;
+          for (int c = 0; c < nch - 1; ++c) wsum += (v[c] / prob) * (2 * c + 1) * legendre_l(c, cosv);
+          const long slot = off + ip;
+          B.pts[s][3 * slot] = (x0 - dx) + rix;  // eval_ecp.py:110
+          B.pts[s][3 * slot + 1] = (y0 - dy) + riy;
+          B.pts[s][3 * slot + 2] = (z0 - dz) + riz;
+          B.wgt[s][slot] = wsum * B.quadw[qoff + ip];
+          B.pte[s][slot] = e;
+          B.ptw[s][slot] = (int)w;
+          B.u0[s][slot] = U0;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -66,7 +66,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       TRY(copy_in(h, h->b_eunif.p, unif, nrot * W * sizeof(double)));
       B.unif = (const double*)h->b_eunif.p;
     }
-    B.quad = h->d_quad; B.seed = seed; B.step = step; B.threshold = threshold;
+    B.quad = h->d_quad; B.quadw = h->d_quadw; B.seed = seed; B.step = step; B.threshold = threshold;
     TRY(ensure(h, h->b_elocal, W * sizeof(double)));
     // second-generation list passes (pqa_ecp.hpp): tables in LDS, four walkers per block, ATOM-major point lists
     const size_t tab_b = ecp_tab_bytes(h->necp, h->ecp_nchan, h->ecp_nterm);

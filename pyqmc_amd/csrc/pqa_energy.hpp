@@ -257,7 +257,8 @@ static __global__ __launch_bounds__(PQA_EWALD_T) void k_ewald(SysDev S, EwaldDev
 struct EcpBuf {
   const double* rot;     // [N][necp][3][3]
   const double* unif;    // [N][necp][W] or NULL -> Philox
-  const double* quad;    // [6+12][3] quadrature directions: rows 0-5 octahedral, 6-17 icosahedral
+  const double* quad;    // [144][3] quadrature directions: rows 0-5 octahedral OA, 6-17 icosahedral IAB, then OAB (18), OABC (26), IABC (32), OABCD (50)
+  const double* quadw;   // [144] their weights (eval_ecp.py:325-334)
   uint64_t seed;
   uint32_t step;
   double threshold;
@@ -371,7 +372,7 @@ static __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState 
           ecp_radial(S, k, r, B.threshold, v, nch, prob);
           loc += v[nch - 1];
           if (nch > 1 && ecp_pass(S, B, w, W, e, k, prob)) {
-            const int naip = (nch <= 2) ? 6 : 12;
+            const int naip = S.ecp_naip[k];
             if (e < S.nup) c_up += naip; else c_dn += naip;
             atomicOr(&pb[k], 1ull << lane);
           }
@@ -395,7 +396,7 @@ static __global__ __launch_bounds__(64) void k_ecp_count(SysDev S, JastrowState 
         loc += v[nch - 1];
         pass = nch > 1 && ecp_pass(S, B, w, W, e, k, prob);
         if (pass) {
-          const int naip = (nch <= 2) ? 6 : 12;
+          const int naip = S.ecp_naip[k];
           if (e < S.nup) c_up += naip; else c_dn += naip;
         }
       }
@@ -456,14 +457,14 @@ static __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState j
       double v[PQA_MAXCHAN], prob;
       int nch;
       ecp_radial(S, k, r, B.threshold, v, nch, prob);
-      const int naip = (nch <= 2) ? 6 : 12;
+      const int naip = S.ecp_naip[k], qoff = S.ecp_qoff[k];  // (at most 50 points: one lane each)
       double U0 = 0.0;
       if (B.has_j2) {  // once per (electron, atom) entry, by the whole wave, instead of once per point later
         double g_[3], lp_;
         jas_eval<0, PBC>(S, xw, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], U0, g_, lp_, 1);
       }
       if (lane < naip) {
-        const double* qd = B.quad + ((nch <= 2) ? 0 : 18) + 3 * lane;
+        const double* qd = B.quad + 3 * (qoff + lane);
         const double* R = B.rot + ((size_t)e * S.necp + k) * 9;
         const double vx = R[0] * qd[0] + R[1] * qd[1] + R[2] * qd[2];
         const double vy = R[3] * qd[0] + R[4] * qd[1] + R[5] * qd[2];
@@ -476,7 +477,7 @@ static __global__ __launch_bounds__(64) void k_ecp_fill(SysDev S, JastrowState j
         B.pts[s][3 * slot] = (xw[3 * e] - dx) + rix;  // eval_ecp.py:110
         B.pts[s][3 * slot + 1] = (xw[3 * e + 1] - dy) + riy;
         B.pts[s][3 * slot + 2] = (xw[3 * e + 2] - dz) + riz;
-        B.wgt[s][slot] = wsum * (1.0 / naip);
+        B.wgt[s][slot] = wsum * B.quadw[qoff + lane];
         B.pte[s][slot] = e;
         B.ptw[s][slot] = (int)w;
         B.u0[s][slot] = U0;

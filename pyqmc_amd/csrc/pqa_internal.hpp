@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -75,7 +76,10 @@ struct pqa_handle {
   long out_slot_stride = 0;
   double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
   double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
-  double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr;
+  double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr, *d_quadw = nullptr;
+  int *d_ecp_naip = nullptr, *d_ecp_qoff = nullptr;  // per-atom quadrature rule (pqa_set_ecp_naip)
+  int ecp_naip = 0;                                  // 0: the reference's default, 6 or 12 by channel count
+  std::vector<int> ecp_nch;                          // channels (incl. local) of every ECP atom
   double *d_aq = nullptr, *d_bq = nullptr;  // merged Pade numerators (jas_merge_tables); jas_merge: PQA_JAS_MERGE=0 keeps the function-by-function route (A/B)
   int jas_merge = 1;
   // walker state

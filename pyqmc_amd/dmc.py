@@ -54,8 +54,7 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     tmoves = acc.has_nonlocal_moves() and necp > 0
     if not state_current:  # the reference recomputes at the start of every block (dmc.py:155)
         wf.recompute(configs)
-    if dev.pbc:
-        dev.set_ewald(**acc._ewald_kws)
+    acc.bind(dev)
     tapes = None if rng is None else _record_tapes(rng, nsteps, N, necp, W, tmoves)
     w = np.ascontiguousarray(weights, dtype=np.float64)
     # like vmc_worker: the device Philox streams are keyed by a seed drawn from numpy's global generator, so
@@ -92,8 +91,7 @@ def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_
     W = configs.configs.shape[0]
     if not state_current:
         wf.recompute(configs)
-    if dev.pbc:
-        dev.set_ewald(**acc._ewald_kws)
+    acc.bind(dev)
     w = np.ascontiguousarray(weights, dtype=np.float64)
     df = []
     for _ in range(nsteps):

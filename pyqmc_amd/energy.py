@@ -10,11 +10,14 @@ The accumulator needs a wave function whose factors share one device handle
 import numpy as np
 
 KEYS = ("ke", "ee", "ei", "ecp", "grad2", "total")
+NAIP = (6, 12, 18, 26, 32, 50)  # the quadrature grids of eval_ecp.py:278-336
 
 
 class EnergyAccumulator:
     def __init__(self, mol, threshold=10, naip=None, seed=None, check_configs=True, **kwargs):
         """``kwargs``: ``ewald_gmax`` / ``nlatvec`` of the periodic Coulomb sum (accumulators.py:48-53, ewald.py:95).
+        ``naip``: number of quadrature points of the ECP integrator for every ECP atom (accumulators.py:48-51, eval_ecp.py:228-252);
+        None (default) is the reference's per-atom choice, 6 or 12 points by channel count (eval_ecp.py:239-240).
         ``seed``: key of the device's ECP rotation / mask streams; None (default) draws a fresh key from ``numpy.random``
         at every evaluation, so ``np.random.seed`` controls the run as it does in the reference (eval_ecp.py:255-275, :135-146)
         and accumulators on different ranks do not replay one another's rotations; an integer makes the sequence explicit."""
@@ -23,8 +26,9 @@ class EnergyAccumulator:
         if kwargs and not hasattr(mol, "a"):
             raise TypeError(f"unexpected arguments {sorted(kwargs)} for an open-boundary system")
         self.threshold = threshold
-        if naip is not None:
-            raise NotImplementedError("naip is chosen per atom as in eval_ecp.py:239-240 (6 or 12)")
+        if naip is not None and naip not in NAIP:  # eval_ecp.get_rot refuses anything else (eval_ecp.py:266-267)
+            raise ValueError(f"Possible AIPs are one of {NAIP}")
+        self.naip = naip
         self.seed = None if seed is None else int(seed)
         self._calls = 0
         self.check_configs = check_configs
@@ -36,6 +40,12 @@ class EnergyAccumulator:
             raise TypeError("pyqmc_amd.EnergyAccumulator needs a pyqmc_amd wave function living on one device handle")
         return dev
 
+    def bind(self, dev):
+        """Make the handle's energy pass the one this accumulator describes (quadrature rule, Ewald tables)."""
+        dev.set_ecp_naip(self.naip)
+        if dev.pbc:
+            dev.set_ewald(**self._ewald_kws)
+
     def __call__(self, configs, wf, rot=None, unif=None):
         dev = self._device(wf)
         if getattr(dev, "twisted", False):  # twisted handles hold unfolded coordinates (include/pyqmc_amd.h)
@@ -45,8 +55,7 @@ class EnergyAccumulator:
         if self.check_configs and not same:
             raise ValueError("walkers on the device differ from `configs`: call wf.recompute(configs) "
                              "(or keep wf.updateinternals in step with configs.move) first")
-        if dev.pbc:
-            dev.set_ewald(**self._ewald_kws)
+        self.bind(dev)
         self._calls += 1
         if rot is not None and unif is not None:
             key = 0  # every draw is replayed: the device streams are not used

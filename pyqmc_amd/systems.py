@@ -167,6 +167,19 @@ def water_cluster(nx=2, ny=2, nz=2, spacing=6.0):
     return Mol(sym, xyz)
 
 
+def water_multichannel():
+    """H2O whose oxygen carries s, p and d non-local channels (four channels with the local one: the reference's default rule
+    for it is the 12-point icosahedral grid, eval_ecp.py:239-240) and whose hydrogens keep the one-channel table (6 points):
+    the system of the quadrature-rule fixtures (naip = None, 18, 26, 32, 50)."""
+    ecp = dict(_ECP)
+    ecp["O"] = (2, [[-1, [[], [[12.30997, 6.0]], [[13.71419, -47.876]], [[14.76962, 73.85984]]]],
+                    [0, [[], [], [[13.65512, 85.86406]]]],
+                    [1, [[], [], [[9.21, -3.4], [2.87, 1.15]]]],
+                    [2, [[], [], [[6.4, -1.9]], [[3.1, 0.45]]]]])
+    sym, xyz = zip(*_WATER)
+    return Mol(sym, xyz, ecp=ecp)
+
+
 def helium():
     """C1 of BASELINE.json: He atom, 2 electrons, 5 AOs."""
     return Mol(["He"], [(0.0, 0.0, 0.0)])

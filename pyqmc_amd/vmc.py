@@ -95,8 +95,8 @@ def vmc_worker(wf, configs, tstep, nsteps, accumulators, tapes=None, seed=None, 
         wf.recompute(configs)
     block_avg = {}
     thr = next(iter(accumulators.values())).threshold if accumulators else 10.0
-    if dev.pbc and accumulators:
-        dev.set_ewald(**next(iter(accumulators.values()))._ewald_kws)
+    if accumulators:
+        next(iter(accumulators.values())).bind(dev)
     t0 = time.perf_counter()
     acc, en, rec = dev.vmc_sweeps(tstep, nsteps, gauss=tapes.get("gauss"), unif=tapes.get("unif"), threshold=thr,
                                   ecp_rot=tapes.get("ecp_rot"), ecp_unif=tapes.get("ecp_unif"), seed=seed,

@@ -382,6 +382,13 @@ class DeviceWF:
         self.call("pqa_profile_query_part", C.byref(n), C.byref(ms), C.byref(g))
         return n.value, ms.value, g.value
 
+    def set_ecp_naip(self, naip):
+        """Quadrature rule of the energy pass's ECP integrator (pqa_set_ecp_naip): 6/12/18/26/32/50, None = per-atom default."""
+        naip = 0 if naip is None else int(naip)
+        if getattr(self, "_naip", 0) != naip:
+            self.call("pqa_set_ecp_naip", naip)
+            self._naip = naip
+
     def last_ecp_points(self):
         n = C.c_int64()
         self.call("pqa_last_ecp_points", C.byref(n))

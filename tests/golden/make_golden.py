@@ -293,6 +293,36 @@ def g_energy():
     save("g10_energy", **out)
 
 
+# ------------------------------------------------------------------ G33 the ECP integrator's quadrature rules
+def g_ecp_naip():
+    """EnergyAccumulator(mol, naip=...) (accumulators.py:48-51 -> eval_ecp.ecp, eval_ecp.py:21-40, get_P_l :228-252) on a water
+    molecule whose oxygen has s, p, d non-local channels: naip = None (12 points at O, 6 at H), 18, 26, 32, 50 and 6;
+    deterministic mask (threshold -1) and the stochastic one (threshold 10)."""
+    mol = systems.water_multichannel()
+    mf = systems.random_mf(mol)
+    wf = make_wf(mol, mf)
+    W, N = 4, sum(mol.nelec)
+    configs = walkers(mol, W, 33)
+    rng = np.random.default_rng(5)
+    configs.configs[:, :3, :] = mol.atom_coords()[0] + 0.4 * rng.standard_normal((W, 3, 3))  # electrons inside the oxygen core
+    configs.configs[:, 5, :] = mol.atom_coords()[1] + 0.2 * rng.standard_normal((W, 3))     # and one at a hydrogen
+    out = {"configs": configs.configs.copy()}
+    wf.recompute(configs)
+    natm_ecp = sum(1 for a in mol._atom if a[0] in mol._ecp)
+    for naip in (None, 6, 18, 26, 32, 50):
+        for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+            with Tapes(3300 + len(out)) as t:
+                en = pyq.EnergyAccumulator(mol, threshold=thr, naip=naip)(configs, wf)
+            tag = f"naip{naip}_{thr_tag}"
+            out[tag + "_ecp"], out[tag + "_total"] = np.asarray(en["ecp"]), np.asarray(en["total"])
+            out[tag + "_rot"] = np.asarray(t.log["rot"]).reshape(N, natm_ecp, 3, 3)
+            out[tag + "_unif"] = np.asarray(t.log["random"]).reshape(N, natm_ecp, W)
+    for naip in (6, 12, 18, 26, 32, 50):  # the grids themselves (eval_ecp.py:278-336)
+        pts, wts = eval_ecp.generate_quadrature_grids()[naip]
+        out[f"grid{naip}_points"], out[f"grid{naip}_weights"] = pts, wts
+    save("g33_ecp_naip", **out)
+
+
 # ------------------------------------------------------------------ G11 VMC trajectory
 def g_vmc():
     out = {}
@@ -1594,3 +1624,4 @@ if __name__ == "__main__":
     g_pbc_complex_dmc()
     g_complex_pgrad()
     g_pbc_high_l()
+    g_ecp_naip()

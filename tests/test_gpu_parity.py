@@ -151,6 +151,34 @@ def test_energy_golden(tag, mol, W):
     assert wf.fused_device().last_ecp_points() > 0
 
 
+@pytest.mark.parametrize("ecp_lds", ["1", "0"])
+def test_ecp_quadrature_rules_golden(ecp_lds, monkeypatch):
+    """EnergyAccumulator(mol, naip=...) (accumulators.py:48-51 -> eval_ecp.py:21-40, get_P_l :228-252) against the reference for
+    every grid it tabulates (:278-336) on an oxygen with s, p, d non-local channels (default rule: 12 points there, 6 at the
+    hydrogens), deterministic and stochastic mask; both generations of the list-building passes (PQA_ECP_LDS)."""
+    import pyqmc_amd as pa
+
+    monkeypatch.setenv("PQA_ECP_LDS", ecp_lds)
+    g = golden("g33_ecp_naip")
+    mol = systems.water_multichannel()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["configs"].copy())
+    wf.recompute(configs)
+    npts = {}
+    for naip in (None, 6, 18, 26, 32, 50, None):  # (and back to the default rule)
+        for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+            tag = f"naip{naip}_{thr_tag}"
+            en = pa.EnergyAccumulator(mol, threshold=thr, naip=naip)(configs, wf, rot=g[tag + "_rot"], unif=g[tag + "_unif"])
+            assert note(f"ecp_{tag}", relerr(en["ecp"], g[tag + "_ecp"])) < 1e-9, tag
+            assert relerr(en["total"], g[tag + "_total"]) < 1e-9, tag
+            npts[tag] = wf.fused_device().last_ecp_points()
+    # the same (electron, atom) entries under every rule (entries beyond an atom's range are skipped: their terms are < 1e-22)
+    assert npts["naip50_det"] * 18 == npts["naip18_det"] * 50 and npts["naip6_det"] * 3 == npts["naip18_det"] > 0
+    assert npts["naip6_det"] < npts["naipNone_det"] < 2 * npts["naip6_det"]  # 12 points at the oxygen, 6 at the hydrogens
+    with pytest.raises(ValueError):
+        pa.EnergyAccumulator(mol, naip=14)
+
+
 @pytest.mark.parametrize("tag,mol", [("h2o", systems.water()), ("he", systems.helium())])
 @pytest.mark.parametrize("fused", [True, False])
 def test_vmc_trajectory_golden(tag, mol, fused, monkeypatch):

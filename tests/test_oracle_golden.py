@@ -111,6 +111,27 @@ def test_g10_energy(tag, mol, W):
     assert abs(oenergy.coulomb(mol, configs)[2] - float(np.ravel(g[tag + "_ii"])[0])) < 1e-10
 
 
+def test_g33_ecp_quadrature_rules():
+    """eval_ecp.ecp(..., naip) (eval_ecp.py:21-40, :228-252) for every grid the reference tabulates (:278-336), on an oxygen with
+    s, p, d non-local channels; the grids themselves bit for bit."""
+    g = golden("g33_ecp_naip")
+    for naip in (6, 12, 18, 26, 32, 50):
+        pts, wts = oenergy.quadrature(naip)
+        assert np.array_equal(pts, g[f"grid{naip}_points"]) and np.array_equal(wts, g[f"grid{naip}_weights"])
+    with pytest.raises(ValueError):
+        oenergy.quadrature(14)
+    mol = systems.water_multichannel()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["configs"].copy())
+    wf.recompute(configs)
+    for naip in (None, 6, 18, 26, 32, 50):
+        for thr_tag, thr in (("det", -1.0), ("thr10", 10.0)):
+            tag = f"naip{naip}_{thr_tag}"
+            en = oenergy.energy(mol, configs, wf, thr, g[tag + "_rot"], g[tag + "_unif"], naip=naip)
+            assert relerr(en["ecp"], g[tag + "_ecp"]) < 1e-10 and relerr(en["total"], g[tag + "_total"]) < 1e-10, tag
+    assert relerr(g["naip50_det_ecp"], g["naip18_det_ecp"]) > 1e-6  # the rules really differ on this system
+
+
 def test_g9_ecp_ea_detail():
     g = golden("g10_energy")
     mol = systems.water()
