@@ -260,6 +260,24 @@ int pqa_energy(pqa_handle_t* h, double threshold, const double* rot, const doubl
    (pqa_tmoves, pqa_dmc_steps) keep the default rule: the reference's nonlocal_tmoves does not pass naip (accumulators.py:82-84). */
 int pqa_set_ecp_naip(pqa_handle_t* h, int32_t naip);
 
+/* EnergyAccumulator(use_old_ecp=False) (accumulators.py:57-58) -> jax_ecp.ECPAccumulator (jax_ecp.py:22-142): the batched
+   formulation of the ECP integral.  For every electron ALL ECP atoms' quadrature points form one table (evaluate_vl,
+   jax_ecp.py:160-222: naip[k] points at ECP atom k, 0 or one of the six grids; no range cut-off, no stochastic mask), of which
+   nselect_deterministic points of largest sum_l v_l^2 are evaluated with weight 1 and nselect_random are sampled from the
+   rest with weight 1 / (nselect_random p) (downselect_move_info, jax_ecp.py:225-290); nothing is dropped when the two add up
+   to the table size.  enable = 1 switches the ECP part of pqa_energy and of the energy passes of pqa_vmc_sweeps /
+   pqa_dmc_steps to it, 0 back to the semi-local integrator (eval_ecp.py).  In this mode pqa_energy's `unif` is the
+   (N, W, nselect_random) table of selection uniforms (jax_ecp.py:255) and `rot` (N, necp, 3, 3) as before; pqa_vmc_sweeps /
+   pqa_dmc_steps draw both from the device streams (their tapes keep the semi-local layout and are refused).
+   pqa_ecp_batched_nselected: slots per electron (the P of the outputs below).
+   pqa_ecp_batched_moves: ECPAccumulator.nonlocal_tmoves (jax_ecp.py:110-135) for electron e — the selected points' positions
+   pos (W, P, 3) and T-move weights weight (W, P) = sum_l [P_l > 0] (exp(-tau v_l / P_l) - 1) P_l; rot (necp, 3, 3),
+   unif (W, nselect_random) or NULL -> device stream `seed`.  The ratios come from pqa_wf_testvalue at `pos`. */
+int pqa_set_ecp_batched(pqa_handle_t* h, int32_t enable, const int32_t* naip, int32_t nselect_deterministic, int32_t nselect_random);
+int pqa_ecp_batched_nselected(pqa_handle_t* h);
+int pqa_ecp_batched_moves(pqa_handle_t* h, int e, double tau, const double* rot, const double* unif, uint64_t seed,
+                          double* weight, double* pos);
+
 /* EnergyAccumulator.nonlocal_tmoves -> eval_ecp.compute_tmoves (eval_ecp.py:43-80) for electron e of the resident
    walkers: the candidate T-moves over every ECP atom's quadrature points (P = pqa_tmove_npoints() per walker).
    rot (necp,3,3), unif (necp,W): the reference's per-atom random rotation / mask uniforms.  Outputs: ratio (W,P)

@@ -9,6 +9,7 @@ from . import systems  # noqa: F401
 from .configs import OpenConfigs, OpenElectron  # noqa: F401
 from .dmc import branch, dmc_propagate, rundmc  # noqa: F401
 from .energy import EnergyAccumulator  # noqa: F401
+from .ecp_batched import ECPAccumulator  # noqa: F401
 from .func3d import CutoffCuspFunction, PolyPadeFunction, default_jastrow_basis  # noqa: F401
 from .systems import initial_guess  # noqa: F401
 from .vmc import vmc, vmc_worker  # noqa: F401

@@ -26,6 +26,7 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   const int N = h->N, necp = h->necp, P = h->tm_P;
   const bool tmoves = necp > 0 && P > 0;
   if (tp && (!tp->gauss || !tp->unif)) FAIL("pqa_dmc_steps: a tape set needs gauss and unif");
+  if (tp && h->ecpb_on) FAIL("pqa_dmc_steps: the tapes have the semi-local ECP integrator's layout (pqa_set_ecp_batched is on)");
   if (tp && necp > 0 && (!tp->ecp_rot || !tp->ecp_unif)) FAIL("pqa_dmc_steps: a tape set needs ecp_rot and ecp_unif for ECP systems");
   if (tp && tmoves && (!tp->tm_rot || !tp->tm_unif || !tp->tm_u1 || !tp->tm_u2)) FAIL("pqa_dmc_steps: a tape set needs the four T-move tapes");
   h->saved_valid = false;

@@ -61,7 +61,8 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     }
     EcpBuf B{};
     B.rot = (const double*)h->b_rot.p;
-    if (unif) {
+    const bool batched = h->ecpb_on != 0;
+    if (unif && !batched) {
       TRY(ensure(h, h->b_eunif, nrot * W * sizeof(double)));
       TRY(copy_in(h, h->b_eunif.p, unif, nrot * W * sizeof(double)));
       B.unif = (const double*)h->b_eunif.p;
@@ -73,7 +74,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     const bool ecp_t = h->ecp_lds && h->necp <= 64 && (long)h->necp * ((h->N + 63) / 64) <= 64 && tab_b <= 32768;
     // (atom-major lists where the orbital kernel gains from them: periodic cells, whose per-lane image walks then have similar
     // lengths within a tile — 2x2x2 diamond VMC +3 % at 32768 walkers; open systems gain nothing and pay a longer scan and sum)
-    const long nseg = (ecp_t && h->ecp_atom_major && h->S.pbc) ? h->necp : 1, nsw = nseg * W;
+    const long nseg = (!batched && ecp_t && h->ecp_atom_major && h->S.pbc) ? h->necp : 1, nsw = nseg * W;
     B.nseg = (int)nseg;
     TRY(ensure(h, h->b_ecnt, 2 * nsw * sizeof(int)));
     TRY(ensure(h, h->b_eoff, 2 * (nsw + 1) * sizeof(long)));
@@ -84,6 +85,20 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     B.has_j2 = h->has_j2 ? 1 : 0;
     B.ue = (soa_current && h->has_j2) ? (const double*)h->b_kpart.p + (size_t)4 * h->N * W : nullptr;  // k_kinetic_lw left U_e there
     const dim3 g_t((unsigned)((W + PQA_ECP_WB - 1) / PQA_ECP_WB)), b_t(64 * PQA_ECP_WB);
+    long tot[2];
+    EcpbArgs A{};
+    if (batched) {  // every (walker, electron) has ecpb_nsel slots: no counting pass, no scan (pqa_ecpb.hpp)
+      A.naip = h->d_ecpb_naip; A.qoff = h->d_ecpb_qoff; A.pstart = h->d_ecpb_pstart;
+      A.npoints = h->ecpb_npoints; A.nsd = h->ecpb_nsd; A.nsr = h->ecpb_nsr; A.nsel = h->ecpb_nsel;
+      A.e0 = 0; A.e1 = h->N; A.tau = 0.0;
+      if (unif && A.nsel < A.npoints) {  // here: the (N, W, nselect_random) selection uniforms
+        const size_t nb = (size_t)h->N * W * A.nsr * sizeof(double);
+        TRY(ensure(h, h->b_eunif, nb));
+        TRY(copy_in(h, h->b_eunif.p, unif, nb));
+        A.selu = (const double*)h->b_eunif.p;
+      }
+      tot[0] = W * (long)h->nup * A.nsel; tot[1] = W * (long)h->ndn * A.nsel;
+    } else {
     if (ecp_t) {
       if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count_t<true>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
       else hipLaunchKernelGGL(k_ecp_count_t<false>, g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
@@ -95,9 +110,9 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
     TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
     TRY(check_launch(h, "k_ecp_count/k_scan2"));
-    long tot[2];
     TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
     TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
+    }
     h->last_ecp_points = tot[0] + tot[1];
     for (int s = 0; s < 2; ++s) {
       const size_t n = (size_t)std::max<long>(tot[s], 1);
@@ -112,7 +127,15 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       TRY(ensure(h, h->b_emo[s], n * std::max(h->nmo[s], 1) * sizeof(double)));
       B.pts[s] = (double*)h->b_epts[s].p; B.wgt[s] = (double*)h->b_ewgt[s].p; B.pte[s] = (int*)h->b_epte[s].p;
     }
+    if (batched) {  // (also with no point at all: the local channels and the list offsets come from this launch)
+      const dim3 g_b((unsigned)((W + PQA_ECPB_WB - 1) / PQA_ECPB_WB)), b_b(64 * PQA_ECPB_WB);
+      if (h->S.pbc) hipLaunchKernelGGL(k_ecpb_fill<true>, g_b, b_b, 0, h->stream, h->S, h->js, B, A, W);
+      else hipLaunchKernelGGL(k_ecpb_fill<false>, g_b, b_b, 0, h->stream, h->S, h->js, B, A, W);
+      TRY(check_launch(h, "k_ecpb_fill"));
+    }
     if (tot[0] + tot[1] > 0) {
+      if (batched) {
+      } else
       if (ecp_t) {
         if (B.ue) {
           if (h->S.pbc) hipLaunchKernelGGL((k_ecp_fill_t<true, true>), g_t, b_t, tab_b, h->stream, h->S, h->js, B, h->ecp_nchan, h->ecp_nterm, W);
@@ -187,6 +210,79 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
   hipLaunchKernelGGL((k_energy_assemble<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
                      h->ii_energy, W, (double*)h->b_en.p, (int)h->cplx);
   return check_launch(h, "k_energy_assemble");
+}
+
+// ---------------------------------------------------------------- batched ECP integrator (jax_ecp.py)
+extern "C" int pqa_set_ecp_batched(pqa_handle_t* h, int32_t enable, const int32_t* naip, int32_t nsd, int32_t nsr) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!enable) { h->ecpb_on = 0; return 0; }
+  if (h->necp == 0) { h->ecpb_on = 0; return 0; }  // nothing to integrate
+  if (h->necp > 64) FAIL("the batched ECP integrator holds one ECP atom per lane: at most 64 ECP atoms");
+  if (!naip || nsd < 0 || nsr < 0) FAIL("bad arguments");
+  std::vector<int> na((size_t)h->necp), qo((size_t)h->necp), ps((size_t)h->necp);
+  int np = 0;
+  for (int k = 0; k < h->necp; ++k) {
+    static const int offs[][2] = {{6, 0}, {12, 6}, {18, 18}, {26, 36}, {32, 62}, {50, 94}};
+    int off = naip[k] == 0 ? 0 : -1;
+    for (auto& o : offs) if (o[0] == naip[k]) off = o[1];
+    if (off < 0) FAIL("naip must be 0 or one of 6, 12, 18, 26, 32, 50 for every atom (eval_ecp.py:266-267)");
+    if (naip[k] > 0 && h->ecp_nch[k] < 2) FAIL("quadrature points on an atom without a non-local channel");
+    na[k] = naip[k]; qo[k] = off; ps[k] = np; np += naip[k];
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!h->d_ecpb_naip) {
+    TRY(upload_table(h, na.data(), na.size(), &h->d_ecpb_naip));
+    TRY(upload_table(h, qo.data(), qo.size(), &h->d_ecpb_qoff));
+    TRY(upload_table(h, ps.data(), ps.size(), &h->d_ecpb_pstart));
+  } else {
+    HIPCHK(hipMemcpy(h->d_ecpb_naip, na.data(), na.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ecpb_qoff, qo.data(), qo.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ecpb_pstart, ps.data(), ps.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  h->ecpb_npoints = np; h->ecpb_nsd = nsd; h->ecpb_nsr = nsr;
+  h->ecpb_nsel = (nsd + nsr >= np) ? np : nsd + nsr;  // jax_ecp.py:236-237: nothing is dropped
+  if (h->ecpb_nsel < np && nsd + nsr > PQA_ECPB_MAXSEL) FAIL("more than 256 selected points per electron");
+  h->ecpb_on = 1;
+  return 0;
+}
+
+extern "C" int pqa_ecp_batched_nselected(pqa_handle_t* h) { return h->ecpb_on ? h->ecpb_nsel : 0; }
+
+extern "C" int pqa_ecp_batched_moves(pqa_handle_t* h, int e, double tau, const double* rot, const double* unif, uint64_t seed,
+                                     double* weight, double* pos) {
+  TRY(sync_aos(h));
+  HIPCHK(hipSetDevice(h->device));
+  if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
+  if (!h->ecpb_on) FAIL("pqa_set_ecp_batched first");
+  if (e < 0 || e >= h->N || !(tau > 0.0) || !rot) FAIL("bad arguments");
+  const long W = h->W;
+  const int nsel = h->ecpb_nsel;
+  if (nsel == 0) return 0;
+  // the kernel indexes the rotations by (electron, atom): place this electron's necp matrices at its row
+  const size_t nrot = (size_t)h->N * h->necp;
+  TRY(ensure(h, h->b_rot, nrot * 9 * sizeof(double)));
+  TRY(copy_in(h, (double*)h->b_rot.p + (size_t)e * h->necp * 9, rot, (size_t)h->necp * 9 * sizeof(double)));
+  EcpBuf B{};
+  B.rot = (const double*)h->b_rot.p; B.quad = h->d_quad; B.quadw = h->d_quadw; B.seed = seed; B.step = 0x7d0u;
+  EcpbArgs A{};
+  A.naip = h->d_ecpb_naip; A.qoff = h->d_ecpb_qoff; A.pstart = h->d_ecpb_pstart;
+  A.npoints = h->ecpb_npoints; A.nsd = h->ecpb_nsd; A.nsr = h->ecpb_nsr; A.nsel = nsel;
+  A.e0 = e; A.e1 = e + 1; A.tau = tau;
+  if (unif && nsel < A.npoints) {
+    const size_t nb = (size_t)h->N * W * A.nsr * sizeof(double);  // (indexed by (electron, walker, draw) like the energy pass)
+    TRY(ensure(h, h->b_eunif, nb));
+    TRY(copy_in(h, (double*)h->b_eunif.p + (size_t)e * W * A.nsr, unif, (size_t)W * A.nsr * sizeof(double)));
+    A.selu = (const double*)h->b_eunif.p;
+  }
+  TRY(ensure(h, h->b_epts[0], (size_t)W * nsel * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_ewgt[0], (size_t)W * nsel * sizeof(double)));
+  A.out_pos = (double*)h->b_epts[0].p; A.out_w = (double*)h->b_ewgt[0].p;
+  const dim3 g_b((unsigned)((W + PQA_ECPB_WB - 1) / PQA_ECPB_WB)), b_b(64 * PQA_ECPB_WB);
+  if (h->S.pbc) hipLaunchKernelGGL(k_ecpb_fill<true>, g_b, b_b, 0, h->stream, h->S, h->js, B, A, W);
+  else hipLaunchKernelGGL(k_ecpb_fill<false>, g_b, b_b, 0, h->stream, h->S, h->js, B, A, W);
+  TRY(check_launch(h, "k_ecpb_fill"));
+  TRY(copy_in(h, weight, A.out_w, (size_t)W * nsel * sizeof(double)));
+  return copy_out(h, pos, A.out_pos, (size_t)W * nsel * 3 * sizeof(double));
 }
 
 extern "C" int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoints, const double* gweight,

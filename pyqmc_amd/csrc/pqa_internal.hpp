@@ -20,6 +20,7 @@
 #include "pqa_dmc.hpp"
 #include "pqa_energy.hpp"
 #include "pqa_ecp.hpp"
+#include "pqa_ecpb.hpp"
 #include "pqa_jastrow.hpp"
 #include "pqa_lw.hpp"
 #include "pqa_slater.hpp"
@@ -80,6 +81,9 @@ struct pqa_handle {
   int *d_ecp_naip = nullptr, *d_ecp_qoff = nullptr;  // per-atom quadrature rule (pqa_set_ecp_naip)
   int ecp_naip = 0;                                  // 0: the reference's default, 6 or 12 by channel count
   std::vector<int> ecp_nch;                          // channels (incl. local) of every ECP atom
+  // batched ECP integrator (pqa_set_ecp_batched, pqa_ecpb.hpp): per-atom point counts, table size, selections, slots per electron
+  int ecpb_on = 0, ecpb_npoints = 0, ecpb_nsd = 0, ecpb_nsr = 0, ecpb_nsel = 0;
+  int *d_ecpb_naip = nullptr, *d_ecpb_qoff = nullptr, *d_ecpb_pstart = nullptr;
   double *d_aq = nullptr, *d_bq = nullptr;  // merged Pade numerators (jas_merge_tables); jas_merge: PQA_JAS_MERGE=0 keeps the function-by-function route (A/B)
   int jas_merge = 1;
   // walker state

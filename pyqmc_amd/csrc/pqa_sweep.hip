@@ -357,6 +357,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   if (nsteps <= 0) return 0;
+  if (h->ecpb_on && (ecp_rot || ecp_unif)) FAIL("the ECP tapes of pqa_vmc_sweeps have the semi-local integrator's layout: with pqa_set_ecp_batched the draws come from the device streams (replay through pqa_energy)");
   const long W = h->W;
   const int N = h->N;
   h->saved_valid = false;

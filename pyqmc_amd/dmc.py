@@ -52,6 +52,10 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     W, N = configs.configs.shape[:2]
     necp = getattr(dev, "necp", 0)
     tmoves = acc.has_nonlocal_moves() and necp > 0
+    if tmoves and not getattr(acc, "use_old_ecp", True):
+        raise NotImplementedError("the device DMC driver draws its T-move candidates from the semi-local integrator's table (eval_ecp.compute_tmoves); "
+                                  "with use_old_ecp=False run the reference's pyqmc.method.dmc over the protocol objects: "
+                                  "EnergyAccumulator.nonlocal_tmoves then serves the batched candidates (INTEGRATION.md)")
     if not state_current:  # the reference recomputes at the start of every block (dmc.py:155)
         wf.recompute(configs)
     acc.bind(dev)

@@ -14,10 +14,12 @@ NAIP = (6, 12, 18, 26, 32, 50)  # the quadrature grids of eval_ecp.py:278-336
 
 
 class EnergyAccumulator:
-    def __init__(self, mol, threshold=10, naip=None, seed=None, check_configs=True, **kwargs):
+    def __init__(self, mol, threshold=10, naip=None, use_old_ecp=True, seed=None, check_configs=True, **kwargs):
         """``kwargs``: ``ewald_gmax`` / ``nlatvec`` of the periodic Coulomb sum (accumulators.py:48-53, ewald.py:95).
         ``naip``: number of quadrature points of the ECP integrator for every ECP atom (accumulators.py:48-51, eval_ecp.py:228-252);
         None (default) is the reference's per-atom choice, 6 or 12 points by channel count (eval_ecp.py:239-240).
+        ``use_old_ecp=False``: the batched ECP integrator (jax_ecp.ECPAccumulator, accumulators.py:57-58; ``pyqmc_amd.ECPAccumulator``);
+        ``threshold`` plays no part there, ``rot`` / ``unif`` of ``__call__`` then have that integrator's layout.
         ``seed``: key of the device's ECP rotation / mask streams; None (default) draws a fresh key from ``numpy.random``
         at every evaluation, so ``np.random.seed`` controls the run as it does in the reference (eval_ecp.py:255-275, :135-146)
         and accumulators on different ranks do not replay one another's rotations; an integer makes the sequence explicit."""
@@ -29,6 +31,11 @@ class EnergyAccumulator:
         if naip is not None and naip not in NAIP:  # eval_ecp.get_rot refuses anything else (eval_ecp.py:266-267)
             raise ValueError(f"Possible AIPs are one of {NAIP}")
         self.naip = naip
+        self.use_old_ecp = use_old_ecp
+        if not use_old_ecp:  # accumulators.py:57-58
+            from .ecp_batched import ECPAccumulator
+
+            self.ecp = ECPAccumulator(mol, naip=naip)
         self.seed = None if seed is None else int(seed)
         self._calls = 0
         self.check_configs = check_configs
@@ -42,7 +49,11 @@ class EnergyAccumulator:
 
     def bind(self, dev):
         """Make the handle's energy pass the one this accumulator describes (quadrature rule, Ewald tables)."""
-        dev.set_ecp_naip(self.naip)
+        if self.use_old_ecp:
+            dev.set_ecp_batched(None)
+            dev.set_ecp_naip(self.naip)
+        else:
+            self.ecp.bind(dev)
         if dev.pbc:
             dev.set_ewald(**self._ewald_kws)
 
@@ -76,6 +87,8 @@ class EnergyAccumulator:
         replay the reference's draws; by default they are drawn from ``numpy.random`` like the reference does."""
         from . import _ffi
 
+        if not self.use_old_ecp:  # accumulators.py:84-86
+            return self.ecp.nonlocal_tmoves(configs, wf, e, tau, rot=rot, unif=unif)
         dev = self._device(wf)
         W, P = dev.W, dev.call_int("pqa_tmove_npoints")
         if P == 0:  # no ECP atom: empty candidate lists (the callers index all three keys, dmc.py:96-101)

@@ -389,6 +389,25 @@ class DeviceWF:
             self.call("pqa_set_ecp_naip", naip)
             self._naip = naip
 
+    def set_ecp_batched(self, naip, nsd=0, nsr=0):
+        """Switch the energy pass's ECP part to the batched integrator (pqa_set_ecp_batched; naip per ECP atom) or, with None, back."""
+        if naip is None:
+            self.call("pqa_set_ecp_batched", 0, None, 0, 0)
+            return
+        a = np.ascontiguousarray(naip, dtype=np.int32)
+        if a.shape != (self.necp,):
+            raise ValueError(f"naip: one entry per ECP atom ({self.necp})")
+        self.call("pqa_set_ecp_batched", 1, _ffi.ptr(a), int(nsd), int(nsr))
+
+    def ecp_batched_moves(self, e, tau, rot, unif=None, seed=0):
+        """(weight (W, P), pos (W, P, 3)) of pqa_ecp_batched_moves for electron e."""
+        P = self.call_int("pqa_ecp_batched_nselected")
+        weight, pos = np.empty((self.W, P)), np.empty((self.W, P, 3))
+        rot = _ffi.f64(rot)
+        unif = None if unif is None or unif.size == 0 else _ffi.f64(unif)
+        self.call("pqa_ecp_batched_moves", int(e), float(tau), _ffi.ptr(rot), _ffi.ptr(unif), int(seed), _ffi.ptr(weight), _ffi.ptr(pos))
+        return weight, pos
+
     def last_ecp_points(self):
         n = C.c_int64()
         self.call("pqa_last_ecp_points", C.byref(n))

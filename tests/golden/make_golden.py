@@ -323,6 +323,75 @@ def g_ecp_naip():
     save("g33_ecp_naip", **out)
 
 
+# ------------------------------------------------------------------ G34 the batched ECP integrator (jax_ecp.py)
+def g_ecp_batched():
+    """jax_ecp.ECPAccumulator (jax_ecp.py:22-142) — what EnergyAccumulator(use_old_ecp=False) evaluates — on the water molecule
+    with s, p, d channels at the oxygen (12 + 6 + 6 points per electron): the default selection (12 deterministic + 1 random),
+    6 + 3, and everything (24 + 0); its nonlocal_tmoves for two electrons; the EnergyAccumulator dict with use_old_ecp=False.
+    numpy's argsort is made stable while the reference runs: the points of one atom share their probability, and which of
+    them an unstable sort keeps where the cut falls inside an atom is an implementation detail of the sort (the fixture
+    records how many walkers that concerns)."""
+    import pyqmc.observables.jax_ecp as jax_ecp
+
+    mol = systems.water_multichannel()
+    mf = systems.random_mf(mol)
+    wf = make_wf(mol, mf)
+    W, N = 6, sum(mol.nelec)
+    configs = walkers(mol, W, 34)
+    rng = np.random.default_rng(6)
+    configs.configs[:, :2, :] = mol.atom_coords()[0] + 0.4 * rng.standard_normal((W, 2, 3))
+    configs.configs[:, 5, :] = mol.atom_coords()[1] + 0.15 * rng.standard_normal((W, 3))  # closer to a hydrogen than to the oxygen
+    out = {"configs": configs.configs.copy()}
+    wf.recompute(configs)
+    real_argsort = np.argsort
+
+    def stable_argsort(a, axis=-1, kind=None, order=None):
+        return real_argsort(a, axis=axis, kind="stable", order=order)
+
+    natom = mol.natm
+    for tag, kws in (("default", {}), ("sel6_3", dict(nselect_deterministic=6, nselect_random=3)),
+                     ("all", dict(nselect_deterministic=24, nselect_random=0)), ("fixedgrid", dict(stochastic_rotation=False))):
+        acc = jax_ecp.ECPAccumulator(mol, **kws)
+        nsr = acc.nselect_random
+        out[tag + "_naip"], out[tag + "_nsd"], out[tag + "_nsr"] = np.asarray(acc.naip), acc.nselect_deterministic, nsr
+        np.argsort = stable_argsort
+        try:
+            with Tapes(3400 + len(out)) as t:
+                out[tag + "_ecp"] = np.asarray(acc(configs, wf))
+            out[tag + "_rot"] = np.asarray(t.log["rot"]).reshape(N, natom, 3, 3)
+            out[tag + "_unif"] = np.asarray(t.log["random"]).reshape(N, W, nsr) if t.log["random"] else np.zeros((N, W, 0))
+            for e in (1, 5):
+                with Tapes(3450 + e) as t:
+                    d = acc.nonlocal_tmoves(configs, wf, e, 0.02)
+                out[f"{tag}_tm{e}_rot"] = np.asarray(t.log["rot"]).reshape(natom, 3, 3)
+                out[f"{tag}_tm{e}_unif"] = np.asarray(t.log["random"]).reshape(W, nsr) if t.log["random"] else np.zeros((W, 0))
+                out[f"{tag}_tm{e}_ratio"], out[f"{tag}_tm{e}_weight"] = np.asarray(d["ratio"]), np.asarray(d["weight"])
+                out[f"{tag}_tm{e}_epos"] = d["configs"].configs
+        finally:
+            np.argsort = real_argsort
+        # the same draws under numpy's default sort: how far the reference's own answer depends on the tie order
+        rots, unis = iter(out[tag + "_rot"].reshape(-1, 3, 3)), iter(out[tag + "_unif"])
+        saved = (eval_ecp.scipy, np.random.random)
+        ns = types.SimpleNamespace
+        eval_ecp.scipy = ns(spatial=ns(transform=ns(Rotation=ns(random=lambda: ns(as_matrix=lambda R=None: next(rots))))))
+        np.random.random = lambda size=None: next(unis)
+        try:
+            out[tag + "_ecp_default_sort"] = np.asarray(acc(configs, wf))
+        finally:
+            eval_ecp.scipy, np.random.random = saved
+    np.argsort = stable_argsort
+    try:
+        with Tapes(3499) as t:
+            en = pyq.EnergyAccumulator(mol, use_old_ecp=False)(configs, wf)
+    finally:
+        np.argsort = real_argsort
+    for k, v in en.items():
+        out["energy_" + k] = np.asarray(v)
+    out["energy_rot"] = np.asarray(t.log["rot"]).reshape(N, natom, 3, 3)
+    out["energy_unif"] = np.asarray(t.log["random"]).reshape(N, W, 1)
+    save("g34_ecp_batched", **out)
+
+
 # ------------------------------------------------------------------ G11 VMC trajectory
 def g_vmc():
     out = {}
@@ -1625,3 +1694,4 @@ if __name__ == "__main__":
     g_complex_pgrad()
     g_pbc_high_l()
     g_ecp_naip()
+    g_ecp_batched()

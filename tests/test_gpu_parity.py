@@ -179,6 +179,48 @@ def test_ecp_quadrature_rules_golden(ecp_lds, monkeypatch):
         pa.EnergyAccumulator(mol, naip=14)
 
 
+def test_batched_ecp_golden():
+    """pyqmc_amd.ECPAccumulator / EnergyAccumulator(use_old_ecp=False) against the reference's jax_ecp.ECPAccumulator
+    (jax_ecp.py:72-135, accumulators.py:57-64): energies and T-move tables with the reference's rotations and selection
+    uniforms replayed — default selection (12 + 1 of 24 points), a cut inside the oxygen's 12 points (6 + 3), no
+    down-selection, the unrotated grid; then the device's own draws against the no-selection value (an unbiased estimator)."""
+    import pyqmc_amd as pa
+
+    g = golden("g34_ecp_batched")
+    mol = systems.water_multichannel()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["configs"].copy())
+    wf.recompute(configs)
+    for tag, kws in (("default", {}), ("sel6_3", dict(nselect_deterministic=6, nselect_random=3)),
+                     ("all", dict(nselect_deterministic=24, nselect_random=0)), ("fixedgrid", dict(stochastic_rotation=False))):
+        acc = pa.ECPAccumulator(mol, **kws)
+        assert np.array_equal(acc.naip, g[tag + "_naip"]) and acc.nselect_deterministic == int(g[tag + "_nsd"]) and acc.nselect_random == int(g[tag + "_nsr"])
+        fixed = tag == "fixedgrid"
+        val = acc(configs, wf, rot=None if fixed else g[tag + "_rot"], unif=g[tag + "_unif"])
+        assert note(f"ecpb_{tag}", relerr(val, g[tag + "_ecp"])) < 1e-9, tag
+        for e in (1, 5):
+            d = acc.nonlocal_tmoves(configs, wf, e, 0.02, rot=None if fixed else g[f"{tag}_tm{e}_rot"], unif=g[f"{tag}_tm{e}_unif"])
+            assert relerr(d["configs"].configs, g[f"{tag}_tm{e}_epos"]) < 1e-12, (tag, e)
+            assert note(f"ecpb_{tag}_tm{e}_weight", relerr(d["weight"], g[f"{tag}_tm{e}_weight"])) < 1e-9, (tag, e)
+            assert note(f"ecpb_{tag}_tm{e}_ratio", relerr(d["ratio"], g[f"{tag}_tm{e}_ratio"])) < 1e-9, (tag, e)
+    en = pa.EnergyAccumulator(mol, use_old_ecp=False)(configs, wf, rot=g["energy_rot"], unif=g["energy_unif"])
+    for k in ("ke", "ee", "ei", "ecp", "grad2", "total"):
+        assert note(f"ecpb_energy_{k}", relerr(en[k], g["energy_" + k])) < 1e-8, k
+    # the semi-local integrator is untouched by the excursion (g33's default rule)
+    g33 = golden("g33_ecp_naip")
+    wf.recompute(OpenConfigs(g33["configs"].copy()))
+    en = pa.EnergyAccumulator(mol, threshold=-1.0)(OpenConfigs(g33["configs"].copy()), wf, rot=g33["naipNone_det_rot"], unif=g33["naipNone_det_unif"])
+    assert relerr(en["ecp"], g33["naipNone_det_ecp"]) < 1e-9
+    # device streams: many independent draws of the sampled estimator average to the full table's value
+    wf.recompute(configs)
+    np.random.seed(7)
+    full = pa.ECPAccumulator(mol, nselect_deterministic=24, nselect_random=0, stochastic_rotation=False)(configs, wf)
+    acc = pa.ECPAccumulator(mol, nselect_deterministic=6, nselect_random=3, stochastic_rotation=False)
+    draws = np.array([acc(configs, wf) for _ in range(400)])
+    err = draws.std(axis=0) / np.sqrt(len(draws))
+    assert np.all(np.abs(draws.mean(axis=0) - full) < 5 * err + 1e-12), (draws.mean(axis=0) - full, err)
+
+
 @pytest.mark.parametrize("tag,mol", [("h2o", systems.water()), ("he", systems.helium())])
 @pytest.mark.parametrize("fused", [True, False])
 def test_vmc_trajectory_golden(tag, mol, fused, monkeypatch):

@@ -110,6 +110,39 @@ def test_periodic_energy_matches_reference(tag):
     assert helpers.relerr(en["ee"], g[f"{tag}_ewald_ee"]) < 1e-12 and helpers.relerr(en["ei"], g[f"{tag}_ewald_ei"]) < 1e-12
 
 
+@pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
+def test_periodic_batched_ecp_matches_oracle(tag):
+    """The batched ECP integrator (jax_ecp.py:72-135; oracle/ecp_batched.py is pinned to the reference by g34) in a periodic cell:
+    minimal-image electron-ion vectors, every carbon's 6 points in one table per electron, 6 kept + 1 sampled; energies and the
+    T-move table of one electron against the oracle with the same rotations and selection uniforms."""
+    import pyqmc_amd as pa
+    from oracle import ecp_batched as ob
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    g = golden("g16_pbc_energy")
+    sup, wf = helpers.gpu_pbc_wf(tag)
+    _, owf = helpers.oracle_pbc_wf(tag)
+    x = g[f"{tag}_configs"].copy()
+    cfg, ocfg = PeriodicConfigs(x.copy(), sup.lattice_vectors()), PeriodicConfigs(x.copy(), sup.lattice_vectors())
+    wf.recompute(cfg)
+    owf.recompute(ocfg)
+    W, N = x.shape[:2]
+    acc = pa.ECPAccumulator(sup)
+    necp = len(acc.naip)
+    assert acc.nselect_deterministic == 6 and acc.nselect_random == 1 and acc.naip.sum() == 6 * necp
+    rng = np.random.default_rng(16)
+    rot = pa.ecp_batched.random_rotations(N * necp).reshape(N, necp, 3, 3)
+    unif = rng.random((N, W, 1))
+    val = acc(cfg, wf, rot=rot, unif=unif)
+    ref = ob.ecp(sup, ocfg, owf, acc.naip, 6, 1, rot, unif)
+    assert helpers.relerr(val, ref) < 2e-9
+    d = acc.nonlocal_tmoves(cfg, wf, 2, 0.01, rot=rot[2], unif=unif[2])
+    o = ob.tmoves(sup, ocfg, owf, 2, 0.01, acc.naip, 6, 1, rot[2], unif[2])
+    assert helpers.relerr(d["weight"], o["weight"]) < 1e-9 and helpers.relerr(d["ratio"], o["ratio"]) < 2e-9
+    wrapped = PeriodicConfigs(x.copy(), sup.lattice_vectors()).make_irreducible(2, o["epos"])
+    assert np.max(np.abs(d["configs"].configs - wrapped.configs)) < 1e-10
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_periodic_vmc_trajectory_matches_reference(fused, monkeypatch):
     """vmc_worker on PeriodicConfigs replayed with the reference's random draws: identical accept decisions, final

@@ -132,6 +132,35 @@ def test_g33_ecp_quadrature_rules():
     assert relerr(g["naip50_det_ecp"], g["naip18_det_ecp"]) > 1e-6  # the rules really differ on this system
 
 
+def test_g34_batched_ecp():
+    """jax_ecp.ECPAccumulator (jax_ecp.py:72-135) and EnergyAccumulator(use_old_ecp=False): energies and T-move tables for
+    the default selection, a cut inside one atom's points, no down-selection, and the unrotated grid."""
+    from oracle import ecp_batched as ob
+
+    g = golden("g34_ecp_batched")
+    mol = systems.water_multichannel()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["configs"].copy())
+    wf.recompute(configs)
+    assert np.array_equal(ob.default_naip(mol), g["default_naip"])
+    for tag in ("default", "sel6_3", "all", "fixedgrid"):
+        naip, nsd, nsr = g[tag + "_naip"], int(g[tag + "_nsd"]), int(g[tag + "_nsr"])
+        rot = g[tag + "_rot"] if tag != "fixedgrid" else np.broadcast_to(np.eye(3), g[tag + "_rot"].shape)
+        val = ob.ecp(mol, configs, wf, naip, nsd, nsr, rot, g[tag + "_unif"])
+        assert relerr(val, g[tag + "_ecp"]) < 1e-10, tag
+        for e in (1, 5):
+            r = g[f"{tag}_tm{e}_rot"] if tag != "fixedgrid" else np.broadcast_to(np.eye(3), (3, 3, 3))
+            d = ob.tmoves(mol, configs, wf, e, 0.02, naip, nsd, nsr, r, g[f"{tag}_tm{e}_unif"])
+            for k in ("ratio", "weight", "epos"):
+                assert relerr(d[k], g[f"{tag}_tm{e}_{k}"]) < 1e-10, (tag, e, k)
+    # where the cut does not split an atom's points the unstable sort the reference calls gives the same energies
+    assert relerr(g["default_ecp_default_sort"], g["default_ecp"]) < 1e-13
+    val = ob.ecp(mol, configs, wf, g["default_naip"], 12, 1, g["energy_rot"], g["energy_unif"])
+    assert relerr(val, g["energy_ecp"]) < 1e-10
+    en = oenergy.energy(mol, configs, wf, 10.0, np.zeros((8, 3, 3, 3)), np.ones((8, 3, len(val))))  # (ECP part masked out)
+    assert relerr(en["ke"] + en["ee"] + en["ei"] + val + oenergy.coulomb(mol, configs)[2], g["energy_total"]) < 1e-9
+
+
 def test_g9_ecp_ea_detail():
     g = golden("g10_energy")
     mol = systems.water()
