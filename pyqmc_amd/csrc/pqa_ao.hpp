@@ -679,6 +679,8 @@ struct ChunkTab {
   const int* cw_shell[3]; // shells for (chunk, group)
   const double* cpad[2];  // per spin [rows_pad][ldc[s]], rows padded to x4 per chunk, cols to x16
   int ldc[2];
+  int col0;               // first orbital column of THIS launch (k_orb): handles with more than 64 orbitals of a spin contract them in
+                          // windows of 64 = four 16-column MFMA tiles, one launch per window (0 everywhere else)
   // periodic launches only: per (atom, point) folded displacement [natom][3][P] and sorted image list [natom][pbc_nw][P],
   // written by k_pbc_prepass for the points of THIS launch
   const double* pbc_d0;
@@ -756,7 +758,7 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) acc[u][c] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  const double* __restrict__ C = T.cpad[spin];
+  const double* __restrict__ C = T.cpad[spin] + T.col0;
   const int ldc = T.ldc[spin];
   const int i16 = lane & 15, kq = lane >> 4;
   const int ptile = (TP == 64) ? wv : ((TP == 32) ? (wv & 1) : 0);
@@ -886,7 +888,7 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int ut = u0 + u * ustep;
-    const int j = 16 * ut + i16;
+    const int j = T.col0 + 16 * ut + i16;
     if (ut >= NT || j >= nmo) continue;
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c)

@@ -447,7 +447,14 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   h->na = sys->na; h->nb = sys->nb; h->necp = sys->necp; h->na3 = h->has_j3 ? sys->na3 : 0; h->nb3 = h->has_j3 ? sys->nb3 : 0;
   if (h->na > PQA_MAXBAS || h->nb > PQA_MAXBAS) FAIL("more than 16 two-body Jastrow basis functions per kind");
   if (h->na3 > PQA_MAXBAS3 || h->nb3 > PQA_MAXBAS3) FAIL("more than 8 three-body Jastrow basis functions per kind");
-  if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 64 electrons per spin channel is not supported by the one-wave determinant tile");
+  if (h->nup > PQA_MAXN || h->ndn > PQA_MAXN) FAIL("more than 128 electrons per spin channel are not supported");
+  // More than 64 electrons or orbitals of a spin (slater.py:155-260 takes any number): the handle runs on the kernels that are
+  // general in n — orbitals by the thread-per-point evaluator + k_mo_rows, determinants by the wave-per-walker kernels with two
+  // columns per lane (k_build_invert, slater_ratios, sm_update_wave on the inverse in place), no lane-per-walker planes.
+  h->big = h->nup > PQA_MAXN_FAST || h->ndn > PQA_MAXN_FAST || (sys->has_slater && (sys->nmo_up > PQA_MAXN_FAST || sys->nmo_dn > PQA_MAXN_FAST));
+  if (h->big && h->cplx) FAIL("complex orbitals: at most 64 electrons and 64 orbitals (32 complex) per spin channel");
+  if (h->big) h->lw_mode = 0;
+  if (const char* e = getenv("PQA_ORB_GENERAL")) h->orb_general = atoi(e) != 0;
   SysDev& S = h->S;
   S.natom = h->natom; S.nup = h->nup; S.ndn = h->ndn; S.nelec = h->N;
   S.pbc = sys->pbc;
@@ -594,9 +601,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     build_chunks(h, 16, h->chunks[0]);
     build_chunks(h, 32, h->chunks[1]);
     for (int s = 0; s < 2; ++s) {
-      if (h->nmo[s] > 64) FAIL("more than 64 orbitals per spin are not supported by the contraction tiles");
+      if (h->nmo[s] > PQA_MAXN) FAIL("more than 128 orbitals per spin are not supported");
       const int nt = (h->nmo[s] + 15) / 16;
-      h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+      h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt <= 4 ? 4 : 8));  // (8: padded coefficient rows of 128 columns, contracted in two windows of four tiles; periodic big handles through k_mo_rows)
       S.nmo[s] = h->nmo[s]; S.ndet_s[s] = h->ndet_s[s];
       TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
       {
@@ -682,7 +689,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (h->has_j3 && sys->ccoeff) TRY(set_c3(h, sys->ccoeff));
   {  // the three-body scratch sits behind whatever else a kernel keeps in dynamic LDS
     const size_t n = std::max(sys->nelec_up, sys->nelec_dn);
-    const size_t other = std::max((n * (n + 1) + 3 * n + 64) * sizeof(double),
+    const size_t other = std::max((n > PQA_MAXN_FAST ? 3 * n + 64 : n * (n + 1) + 3 * n + 64) * sizeof(double),
                                   (size_t)std::max(sys->has_slater ? std::max(sys->ndet_up, sys->ndet_dn) : 1, 1) * 5 * sizeof(double));
     S.j3_off = (int)((other + 7) / 8);
   }
@@ -1045,6 +1052,10 @@ static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants fr
     pa.group_stride = (long)h->N * 3;
     TRY(launch_orb(h, s, pa, h->W * nel[s], 5, h->st.cache[s]));
     const size_t lds = (h->cplx ? 2 : 1) * ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
+    if (lds > 64 * 1024 && !h->invert_attr) {  // (91 electrons of a spin and more: past the default dynamic-LDS limit)
+      HIPCHK(hipFuncSetAttribute((const void*)k_build_invert<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      h->invert_attr = true;
+    }
     if (h->cplx) hipLaunchKernelGGL((k_build_invert_c<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     else hipLaunchKernelGGL((k_build_invert<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     TRY(check_launch(h, "k_build_invert"));

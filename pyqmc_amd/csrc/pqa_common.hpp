@@ -9,7 +9,8 @@
 #define PQA_MAXBAS3 8     // max three-body basis functions per kind (fully unrolled register arrays in jas3_eval)
 #endif
 #define PQA_JQ 24         // doubles per merged-numerator record (N1[4], N2[7], N3[10], padding)
-#define PQA_MAXN 64       // max electrons per spin handled by one wave (LU / Sherman-Morrison tile)
+#define PQA_MAXN 128      // max electrons / orbitals per spin (real orbitals; up to 64 on every fast path, above: the two-slot wave kernels)
+#define PQA_MAXN_FAST 64  // one lane per column: LDS-staged determinant tile, lane-per-walker planes, four 16-column MFMA tiles
 #define PQA_MAXCHAN 5     // ECP channels per atom incl. local
 #define PQA_MAXAIP 12
 

@@ -57,6 +57,9 @@ struct pqa_handle {
   int wide_nth = 1024;  // threads per block of k_orb_wide (PQA_WIDE_NTH; periodic default 512)
   int pbc_maxcls = PQA_PRE_NCUT;  // most distinct shell cut-offs any atom has (picks the pre-pass instantiation)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
+  bool orb_general = false;  // PQA_ORB_GENERAL=1: big open handles evaluate orbitals by k_ao + k_mo_rows instead of the windowed k_orb (A/B, tests)
+  bool invert_attr = false;  // k_build_invert's dynamic-LDS limit raised (n > 90)
+  bool big = false;         // more than 64 electrons or orbitals of a spin: general orbital path, wave-per-walker kernels (pqa_create)
   bool pbc_high_l = false;  // a periodic cell with g / h shells: orbitals through k_ao<.., 5> + k_mo_rows (pqa_orb_pbc.hip)
   bool twist = false;  // twisted boundary conditions: complex lattice-summed AOs, unfolded positions (include/pyqmc_amd.h)
   bool cplx = false;  // complex orbitals: mo_* hold [Re C | Im C], see pqa_cslater.hpp
@@ -75,6 +78,7 @@ struct pqa_handle {
   ChunkTab tab[2]{};
   const unsigned char* out_sel = nullptr;  // two-slot output of the NEXT orbital launch (ChunkTab::out_sel; set by launch_orb)
   long out_slot_stride = 0;
+  int orb_col0 = 0;  // first orbital column of the NEXT k_orb launch (ChunkTab::col0; set by launch_orb for handles with > 64 orbitals)
   double* d_mo[2] = {nullptr, nullptr};       // [nao][nmo]
   double* d_cpad[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [tab][spin]
   double *d_acoeff = nullptr, *d_bcoeff = nullptr, *d_detcoeff = nullptr, *d_quad = nullptr, *d_quadw = nullptr;
@@ -271,6 +275,7 @@ static inline size_t lds_j3(const pqa_handle* h) {  // bytes needed by kernels t
 }
 static inline size_t lds_sm(const pqa_handle* h) {
   const size_t n = std::max(h->nup, h->ndn);
+  if (n > PQA_MAXN_FAST) return std::max((3 * n + 64) * sizeof(double), lds_j3(h));  // sm_update_wave works on the inverse in place there
   return std::max((n * (n + 1) + 2 * n + 64 + n) * sizeof(double), lds_j3(h));
 }
 static inline size_t lds_det(const pqa_handle* h, int ncomp) {

@@ -3,6 +3,7 @@
 #include "pqa_orb_common.hpp"
 // ---------------------------------------------------------------- orbital kernel launch
 int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out);  // pqa_orb_pbc.hip
+int launch_orb_general(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out);  // pqa_orb_pbc.hip
 
 template <int NCOMP, int KC>
 static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
@@ -17,7 +18,8 @@ static void launch_orb_ws(pqa_handle* h, int tabi, int spin, PointAddr pa, long 
 template <int NCOMP, int KC, int TP, bool LT>
 static void launch_orb_t2(pqa_handle* h, int tabi, int spin, PointAddr pa, long P, double* out) {
   const dim3 grid((unsigned)((P + TP - 1) / TP)), block(256);
-  switch (h->nt[spin]) {
+  const int left = (h->nmo[spin] - h->orb_col0 + 15) / 16;  // 16-column tiles from this launch's first column on (at most four per launch)
+  switch (left) {
     case 1: hipLaunchKernelGGL((k_orb<NCOMP, 1, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
     case 2: hipLaunchKernelGGL((k_orb<NCOMP, 2, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
     default: hipLaunchKernelGGL((k_orb<NCOMP, 4, KC, TP, LT>), grid, block, 0, h->stream, h->S, tabx(h, tabi), spin, pa, P, out); break;
@@ -66,7 +68,16 @@ static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int nc
   // walkers, 12.9 -> 11.3 at 22528, measured at the end of round 4; at 16384 the two are level)
   const bool want_ws = h->orb_ws < 0 ? (P <= (long)64 * 256) : (h->orb_ws != 0);
   if (h->S.nL > 0) TRY(launch_orb_pbc_any(h, ncomp, spin, pa, P, out));
-  else
+  else if (h->big && h->orb_general) TRY(launch_orb_general(h, ncomp, spin, pa, P, out));
+  else if (h->big) {  // more than 64 orbitals of a spin: windows of 64 columns, one k_orb launch each (the AO phase runs once per window)
+    for (int col0 = 0; col0 < 16 * h->nt[spin] && col0 < h->nmo[spin]; col0 += 64) {
+      h->orb_col0 = col0;
+      if (ncomp == 5) { if (tp == 64) launch_orb_t<5, 16, 64>(h, 0, spin, pa, P, out); else launch_orb_t<5, 16, 32>(h, 0, spin, pa, P, out); }
+      else if (ncomp == 1) { if (tp == 64) launch_orb_t<1, 32, 64>(h, 1, spin, pa, P, out); else launch_orb_t<1, 32, 32>(h, 1, spin, pa, P, out); }
+      else { h->orb_col0 = 0; FAIL("orbital kernel supports ncomp 1 or 5"); }
+    }
+    h->orb_col0 = 0;
+  } else
   if (wide_wanted(h, 0, P, ncomp)) {
     TRY((launch_orb_wide<0, 1024>(h, tabx(h, 0), 0, spin, pa, P, out)));
   } else

@@ -7,6 +7,7 @@ static inline ChunkTab tabx(const pqa_handle* h, int tabi) {  // the chunk table
   ChunkTab T = h->tab[tabi];
   T.out_sel = h->out_sel;
   T.out_slot_stride = h->out_slot_stride;
+  T.col0 = h->orb_col0;
   return T;
 }
 // whole-K kernel for small 5-component launches (k_orb_wide, pqa_ao.hpp)

@@ -107,15 +107,18 @@ int launch_ao(pqa_handle* h, PointAddr pa, long P, int ncomp, double* out) {
 }
 // periodic cells with g / h shells: AO planes by the thread-per-point evaluator (direct image tests, the reference's cut-offs and
 // membership rule like every other path), contracted by k_mo_rows into the row layout the callers expect
-static int launch_orb_pbc_general(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
-  const long chunk = std::max<long>(1, ((long)1 << 28) / ((long)ncomp * h->nao));  // <= 2 GiB of AO planes per pass
-  if (pa.group_stride != 0 && P > chunk) FAIL("general periodic orbital path: grouped point lists longer than one pass are not supported");
+int launch_orb_general(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
+  long chunk = std::max<long>(1, ((long)1 << 28) / ((long)ncomp * h->nao));  // <= 2 GiB of AO planes per pass
+  if (pa.group_stride != 0 && P > chunk) {  // grouped lists (an electron block per walker): whole groups per pass
+    if (pa.group > chunk) FAIL("general orbital path: a point group longer than one pass");
+    chunk -= chunk % pa.group;
+  }
   for (long p0 = 0; p0 < P; p0 += chunk) {
     const long n = std::min(chunk, P - p0);
     TRY(ensure(h, h->b_ao, (size_t)n * ncomp * h->nao * sizeof(double)));
     PointAddr pp = pa;
-    if (p0) pp.base = pa.base + 3 * p0;  // (plain lists: group = P, stride 0)
-    if (p0) pp.group = (int)n;
+    if (pa.group_stride != 0) pp.base = pa.base + (p0 / pa.group) * pa.group_stride;
+    else if (p0) { pp.base = pa.base + 3 * p0; pp.group = (int)n; }  // (plain lists: group = P, stride 0)
     TRY(launch_ao(h, pp, n, ncomp, (double*)h->b_ao.p));
     const long tot = n * ncomp * h->nmo[spin];
     hipLaunchKernelGGL((k_mo_rows<>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_ao.p, (const double*)h->d_mo[spin], n,
@@ -125,7 +128,7 @@ static int launch_orb_pbc_general(pqa_handle* h, int ncomp, int spin, PointAddr 
   return 0;
 }
 int launch_orb_pbc_any(pqa_handle* h, int ncomp, int spin, PointAddr pa, long P, double* out) {
-  if (h->pbc_high_l) return launch_orb_pbc_general(h, ncomp, spin, pa, P, out);
+  if (h->pbc_high_l || h->big) return launch_orb_general(h, ncomp, spin, pa, P, out);
   if (ncomp == 5) {
     // AO rows per chunk of the 5-component launch.  Automatic (PQA_ORB_KC5 unset): 16 for launches of at least 16384 points, 32 below —
     // measured at the end of round 4: whole-ensemble launches (recompute, the DMC step's refresh of accepted T-moves: 131 k points per

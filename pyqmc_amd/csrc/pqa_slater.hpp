@@ -49,9 +49,14 @@ static __global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterStat
   __syncthreads();
   double sign = 1.0, logd = 0.0;
   bool singular = false;
+  // (a lane owns the rows / columns lane, lane + 64, ...: one each up to 64 electrons, two up to 128)
   for (int k = 0; k < n; ++k) {
-    double v = (lane >= k && lane < n) ? fabs(M[lane * ld + k]) : -1.0;
+    double v = -1.0;
     int idx = lane;
+    for (int r = lane; r < n; r += 64) {
+      const double c = (r >= k) ? fabs(M[r * ld + k]) : -1.0;
+      if (c > v) { v = c; idx = r; }  // (ascending r: the lowest index among equals, like the butterfly below)
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const double ov = __shfl_xor(v, off, 64);
@@ -60,11 +65,12 @@ static __global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterStat
     }
     const int p = idx;
     if (!(v > 0.0) || !(v <= DBL_MAX)) { singular = true; break; }
-    if (p != k && lane < n) {
-      const double t = M[k * ld + lane];
-      M[k * ld + lane] = M[p * ld + lane];
-      M[p * ld + lane] = t;
-    }
+    if (p != k)
+      for (int c = lane; c < n; c += 64) {
+        const double t = M[k * ld + c];
+        M[k * ld + c] = M[p * ld + c];
+        M[p * ld + c] = t;
+      }
     if (p != k) sign = -sign;
     if (lane == 0) perm[k] = p;
     __syncthreads();
@@ -72,17 +78,27 @@ static __global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterStat
     logd += log(fabs(piv));
     if (piv < 0.0) sign = -sign;
     __syncthreads();
-    double rk = 0.0;
-    if (lane < n) {
-      rk = (lane == k) ? 1.0 / piv : M[k * ld + lane] / piv;
-      M[k * ld + lane] = rk;
+    double rk[PQA_MAXN / 64];
+#pragma unroll
+    for (int q = 0; q < PQA_MAXN / 64; ++q) {
+      const int c = lane + 64 * q;
+      rk[q] = 0.0;
+      if (c < n) {
+        rk[q] = (c == k) ? 1.0 / piv : M[k * ld + c] / piv;
+        M[k * ld + c] = rk[q];
+      }
     }
     for (int r = 0; r < n; ++r) {
       if (r == k) continue;
       const double f = M[r * ld + k];
-      if (lane < n) {
-        const double cur = (lane == k) ? 0.0 : M[r * ld + lane];
-        M[r * ld + lane] = cur - f * rk;
+      __builtin_amdgcn_wave_barrier();  // (n > 64: column k belongs to one lane, read by all before that lane rewrites it)
+#pragma unroll
+      for (int q = 0; q < PQA_MAXN / 64; ++q) {
+        const int c = lane + 64 * q;
+        if (c < n) {
+          const double cur = (c == k) ? 0.0 : M[r * ld + c];
+          M[r * ld + c] = cur - f * rk[q];
+        }
       }
     }
     __syncthreads();
@@ -95,11 +111,12 @@ static __global__ __launch_bounds__(64) void k_build_invert(SysDev S, SlaterStat
   }
   for (int k = n - 1; k >= 0; --k) {  // undo the row pivoting: column swaps in reverse order
     const int p = perm[k];
-    if (p != k && lane < n) {
-      const double t = M[lane * ld + k];
-      M[lane * ld + k] = M[lane * ld + p];
-      M[lane * ld + p] = t;
-    }
+    if (p != k)
+      for (int r = lane; r < n; r += 64) {
+        const double t = M[r * ld + k];
+        M[r * ld + k] = M[r * ld + p];
+        M[r * ld + p] = t;
+      }
     __syncthreads();
   }
   for (int idx = lane; idx < n * n; idx += 64) Tw[idx] = M[(idx / n) * ld + idx % n];
@@ -290,6 +307,42 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
         st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)
         st.dlog[s][o] += log(fabs(ratio));
       }
+    }
+    return;
+  }
+  if (n > PQA_MAXN_FAST) {
+    // More than 64 electrons of this spin: the tile does not fit the staging scheme below (one lane per row, n (n + 1) doubles of
+    // LDS), so the update runs on the inverse where it lies: one wave sum per row for tmp, then the rank-1 update row by row.
+    // LDS: 3 n doubles.  Same formulas (slater.py:88-94); the row dot is a wave sum over lanes that hold columns lane, lane + 64.
+    double* V = lds;
+    double* TMP = lds + n;
+    double* Rr = TMP + n;
+    for (int d = 0; d < D; ++d) {
+      double* Tw = st.T[s] + ((size_t)w * D + d) * n * n;
+      const int* occ = S.det_occ[s] + (size_t)d * n;
+      for (int k = lane; k < n; k += 64) V[k] = morow[occ[k]];
+      __syncthreads();
+      for (int j = 0; j < n; ++j) {
+        double p = 0.0;
+        for (int k = lane; k < n; k += 64) p += V[k] * Tw[(size_t)j * n + k];
+        p = wave_sum(p);
+        if (lane == 0) TMP[j] = p;
+      }
+      __syncthreads();
+      const double ratio = TMP[i];
+      for (int k = lane; k < n; k += 64) Rr[k] = Tw[(size_t)i * n + k] / ratio;
+      __syncthreads();
+      for (int j = 0; j < n; ++j) {
+        const double tj = TMP[j];
+        if (j == i) { for (int k = lane; k < n; k += 64) Tw[(size_t)j * n + k] = Rr[k]; }
+        else { for (int k = lane; k < n; k += 64) Tw[(size_t)j * n + k] -= Rr[k] * tj; }
+      }
+      if (lane == 0) {
+        const size_t o = (size_t)w * D + d;
+        st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);
+        st.dlog[s][o] += log(fabs(ratio));
+      }
+      __syncthreads();
     }
     return;
   }

@@ -392,6 +392,47 @@ def g_ecp_batched():
     save("g34_ecp_batched", **out)
 
 
+# ------------------------------------------------------------------ G35 more than 64 electrons per spin
+def g_big():
+    """(H2O)18: 72 + 72 electrons, 414 AOs, 72 orbitals per spin (slater.py:155-260 takes any number of electrons) — the
+    update / testvalue / recompute triangle for the first, the last and the two middle electrons (2 walkers), and one
+    vmc_worker sweep with the energy (mc.py:102-153) of 2 walkers with every draw recorded."""
+    mol = systems.water_cluster(3, 3, 2)
+    mf = systems.random_mf(mol)
+    wf = make_wf(mol, mf)
+    out = {}
+    protocol_dump("", mol, mf, wf, W=2, seed=35, electrons=[0, 71, 72, 143], out=out)
+    for k in ("mo_coeff_alpha", "mo_coeff_beta", "acoeff"):  # (regenerated from the seeds by the tests; 0.5 MB each)
+        out.pop(k)
+    W, N, nsteps, tstep = 2, sum(mol.nelec), 1, 0.3
+    natm_ecp = sum(1 for a in mol._atom if a[0] in mol._ecp)
+    configs = walkers(mol, W, 135)
+    out["vmc_start"] = configs.configs.copy()
+    accepts = []
+    orig_update = wf.updateinternals
+
+    def spy(e, epos, cfg, mask=None, saved_values=None, _o=orig_update):
+        accepts.append(np.asarray(mask).copy())
+        return _o(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(3500) as t:
+        blk, configs = vmc_worker(wf, configs, tstep, nsteps, {"energy": pyq.EnergyAccumulator(mol)})
+    wf.updateinternals = orig_update
+    out["vmc_tstep"], out["vmc_nsteps"] = tstep, nsteps
+    out["vmc_gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+    out["vmc_unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+    out["vmc_ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm_ecp, 3, 3)
+    out["vmc_ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm_ecp, W)
+    out["vmc_accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+    out["vmc_final"] = configs.configs.copy()
+    out["vmc_final_log"] = wf.value()[1]
+    for k, v in blk.items():
+        if "time" not in k:
+            out[f"vmc_blk_{k}"] = np.asarray(v)
+    save("g35_big", **out)
+
+
 # ------------------------------------------------------------------ G11 VMC trajectory
 def g_vmc():
     out = {}
@@ -1695,3 +1736,4 @@ if __name__ == "__main__":
     g_pbc_high_l()
     g_ecp_naip()
     g_ecp_batched()
+    g_big()

@@ -61,6 +61,9 @@ def case(name):
     if name == "g5_protocol_cluster":
         mol = systems.water_cluster()
         return mol, systems.random_mf(mol), None, g
+    if name == "g35_big":
+        mol = systems.water_cluster(3, 3, 2)
+        return mol, systems.random_mf(mol), None, g
     raise KeyError(name)
 
 
@@ -326,6 +329,14 @@ PBC_SLATER_CASES = {
 }
 
 
+def big_cell_case():
+    """Diamond, 2 x 2 x 2 conventional cells as ONE cell at Gamma: 64 atoms, 128 + 128 electrons, 832 AOs, real orbitals."""
+    from pyqmc_amd import pbc
+
+    sup = pbc.get_supercell(systems.diamond_cubic(2), np.eye(3))
+    return sup, pbc.random_kmf(sup)
+
+
 def pbc_slater_case(tag):
     """(supercell, k-point mean field) exactly as make_golden.g_pbc_slater built them."""
     from pyqmc_amd import pbc
@@ -358,7 +369,7 @@ def oracle_pbc_wf(tag, Ls=None):
     from oracle import jastrow_basis, wf as owf
     from pyqmc_amd import pbc
 
-    sup, mf = pbc_slater_case(tag)
+    sup, mf = big_cell_case() if tag == "big" else pbc_slater_case(tag)
     if Ls is None:
         Ls = pbc.lattice_points_within(sup.original_cell.lattice_vectors(), 30.0)
     sl = owf.Slater.periodic(sup, mf.kpts, mf.mo_coeff, Ls)
@@ -372,7 +383,7 @@ def oracle_pbc_wf(tag, Ls=None):
 def gpu_pbc_wf(tag, **kw):
     import pyqmc_amd as pa
 
-    sup, mf = pbc_slater_case(tag)
+    sup, mf = big_cell_case() if tag == "big" else pbc_slater_case(tag)
     wf = pa.generate_wf(sup, mf, **kw)
     a, b = pbc_jastrow_coeffs(sup)
     wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = a, b

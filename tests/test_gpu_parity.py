@@ -179,6 +179,40 @@ def test_ecp_quadrature_rules_golden(ecp_lds, monkeypatch):
         pa.EnergyAccumulator(mol, naip=14)
 
 
+@pytest.mark.parametrize("orb_general", ["0", "1"])
+def test_more_than_64_electrons_per_spin_golden(orb_general, monkeypatch):
+    """(H2O)18: 72 + 72 electrons, 414 AOs, 72 orbitals per spin (slater.py:155-260 takes any number; every fast path here holds one
+    column per lane): the reference's update / testvalue / recompute triangle, its inverse, and its recorded VMC sweep + energy
+    on the general-n kernels (orbitals by k_orb in windows of 64 columns or by the thread-per-point evaluator + k_mo_rows, two
+    columns per lane in k_build_invert / slater_ratios, Sherman-Morrison on the inverse in place)."""
+    import pyqmc_amd as pa
+
+    monkeypatch.setenv("PQA_ORB_GENERAL", orb_general)  # 0: k_orb in windows of 64 orbital columns (default); 1: k_ao + k_mo_rows
+    mol, mf, dets, g = helpers.case("g35_big")
+    wf = helpers.gpu_wf(mol, mf, dets)
+    err = helpers.run_protocol(wf, g, relerr=helpers.relerr_elem)
+    for k, v in err.items():
+        note(f"g35_big:{k}", v)
+    bad = {k: v for k, v in err.items() if not v < helpers.g5_tolerance(k, 1e2)}
+    assert not bad, bad
+    configs = OpenConfigs(g["configs"].copy())
+    wf.recompute(configs)
+    for s in (0, 1):
+        inv, dets_ = wf.wf_factors[0]._get_state(s)
+        assert note(f"g35_big:inverse{s}", helpers.relerr_elem(inv, g[f"slater_inverse{s}"])) < 1e-8
+        assert note(f"g35_big:dets{s}", helpers.relerr_elem(dets_, g[f"slater_dets{s}"])) < 1e-10
+    tapes = dict(gauss=g["vmc_gauss"], unif=g["vmc_unif"], ecp_rot=g["vmc_ecp_rot"], ecp_unif=g["vmc_ecp_unif"], record=[])
+    blk, cfg = pa.vmc_worker(wf, OpenConfigs(g["vmc_start"].copy()), float(g["vmc_tstep"]), int(g["vmc_nsteps"]), {"energy": pa.EnergyAccumulator(mol)}, tapes=tapes)
+    assert np.array_equal(np.asarray(tapes["record"][0]).reshape(g["vmc_accepts"].shape).astype(bool), g["vmc_accepts"].astype(bool))
+    assert note("g35_big:vmc_final", float(np.max(np.abs(cfg.configs - g["vmc_final"])))) < 1e-10
+    for k in ("energytotal", "energyke", "energyecp", "energyee", "energyei", "acceptance"):
+        assert note(f"g35_big:{k}", abs(blk[k] - g["vmc_blk_" + k]) / max(1.0, abs(g["vmc_blk_" + k]))) < 1e-8, k
+    # update vs recompute after the sweep (update-vs-recompute drift of 144 rank-1 updates)
+    s1, l1 = wf.value()
+    s2, l2 = wf.recompute(cfg)
+    assert np.array_equal(s1, s2) and note("g35_big:update_vs_recompute", float(np.max(np.abs(l1 - l2)))) < 1e-9
+
+
 def test_batched_ecp_golden():
     """pyqmc_amd.ECPAccumulator / EnergyAccumulator(use_old_ecp=False) against the reference's jax_ecp.ECPAccumulator
     (jax_ecp.py:72-135, accumulators.py:57-64): energies and T-move tables with the reference's rotations and selection

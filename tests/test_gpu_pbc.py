@@ -110,6 +110,45 @@ def test_periodic_energy_matches_reference(tag):
     assert helpers.relerr(en["ee"], g[f"{tag}_ewald_ee"]) < 1e-12 and helpers.relerr(en["ei"], g[f"{tag}_ewald_ei"]) < 1e-12
 
 
+def test_periodic_cell_with_128_electrons_per_spin_matches_oracle():
+    """64-atom diamond cell at Gamma: 128 + 128 electrons, 832 AOs (slater.py:155-260, orbitals.py:192-239 take any size; here the
+    general-n kernels: lattice-summed AOs by the thread-per-point evaluator, k_mo_rows, two columns per lane in the determinant
+    kernels).  Recompute, derivatives of the first / a middle / the last electron, an accepted update and the local energy of 2
+    walkers against the oracle."""
+    import pyqmc_amd as pa
+    from oracle import energy as oenergy
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    sup, wf = helpers.gpu_pbc_wf("big")
+    _, owf = helpers.oracle_pbc_wf("big")
+    assert sup.nelec == (128, 128)
+    x = pa.initial_guess(sup, 2, rng=np.random.default_rng(128)).configs
+    cfg, ocfg = PeriodicConfigs(x.copy(), sup.lattice_vectors()), PeriodicConfigs(x.copy(), sup.lattice_vectors())
+    (s1, l1), (s2, l2) = wf.recompute(cfg), owf.recompute(ocfg)
+    assert np.array_equal(s1, s2) and note("big_pbc:recompute_log", float(np.max(np.abs(l1 - l2)))) < 1e-8
+    rng = np.random.default_rng(3)
+    for e in (0, 127, 128, 255):
+        new = x[:, e, :] + 0.2 * rng.standard_normal((2, 3))
+        ep, oep = cfg.make_irreducible(e, new), ocfg.make_irreducible(e, new)
+        (g1, v1, sv), (g2, v2, osv) = wf.gradient_value(e, ep), owf.gradient_value(e, oep)
+        assert note(f"big_pbc:e{e}_val", helpers.relerr(v1, v2)) < 1e-8 and note(f"big_pbc:e{e}_grad", helpers.relerr(g1, g2)) < 1e-7
+        (g1, p1), (g2, p2) = wf.gradient_laplacian(e, ep), owf.gradient_laplacian(e, oep)
+        assert note(f"big_pbc:e{e}_lap", helpers.relerr(p1, p2)) < 1e-7
+        acc = np.array([True, e % 2 == 0])
+        cfg.move(e, ep, acc)
+        ocfg.move(e, oep, acc)
+        wf.updateinternals(e, ep, cfg, mask=acc, saved_values=sv)
+        owf.updateinternals(e, oep, ocfg, mask=acc, saved_values=osv)
+    assert note("big_pbc:value_after_updates", float(np.max(np.abs(wf.value()[1] - owf.value()[1])))) < 1e-8
+    N, necp = 256, 64
+    rot = pa.ecp_batched.random_rotations(N * necp).reshape(N, necp, 3, 3)
+    unif = rng.random((N, necp, 2))
+    en = pa.EnergyAccumulator(sup, ewald_gmax=6)(cfg, wf, rot=rot, unif=unif)
+    oen = oenergy.energy(sup, ocfg, owf, 10.0, rot, unif, ewald_kws=dict(ewald_gmax=6))
+    for k in ("ke", "ee", "ei", "ecp", "total"):
+        assert note(f"big_pbc:energy_{k}", helpers.relerr(en[k], oen[k])) < 1e-7, k
+
+
 @pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
 def test_periodic_batched_ecp_matches_oracle(tag):
     """The batched ECP integrator (jax_ecp.py:72-135; oracle/ecp_batched.py is pinned to the reference by g34) in a periodic cell:

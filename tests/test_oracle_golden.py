@@ -161,6 +161,24 @@ def test_g34_batched_ecp():
     assert relerr(en["ke"] + en["ee"] + en["ei"] + val + oenergy.coulomb(mol, configs)[2], g["energy_total"]) < 1e-9
 
 
+def test_g35_more_than_64_electrons_per_spin():
+    """(H2O)18, 72 + 72 electrons (slater.py:155-260 takes any number): the oracle on the reference's protocol triangle and on its
+    recorded VMC sweep."""
+    mol, mf, _, g = helpers.case("g35_big")
+    wf = helpers.oracle_wf(mol, mf)
+    err = helpers.run_protocol(wf, g, relerr=helpers.relerr_elem)
+    bad = {k: v for k, v in err.items() if not v < helpers.g5_tolerance(k, 1e2)}
+    assert not bad, bad
+    wf = helpers.oracle_wf(mol, mf)
+    rec = []
+    blk, configs = ovmc.vmc_worker(mol, wf, OpenConfigs(g["vmc_start"].copy()), float(g["vmc_tstep"]), g["vmc_gauss"], g["vmc_unif"],
+                                   g["vmc_ecp_rot"], g["vmc_ecp_unif"], record=rec)
+    assert np.array_equal(np.asarray(rec).reshape(g["vmc_accepts"].shape), g["vmc_accepts"])
+    assert np.max(np.abs(configs.configs - g["vmc_final"])) < 1e-10  # (drift through 72 x 72 inverses after up to 143 rank-1 updates)
+    for k in ("energytotal", "energyke", "energyecp", "acceptance"):
+        assert abs(blk[k] - g["vmc_blk_" + k]) < 1e-8 * max(1.0, abs(g["vmc_blk_" + k])), k
+
+
 def test_g9_ecp_ea_detail():
     g = golden("g10_energy")
     mol = systems.water()

@@ -1,6 +1,6 @@
 """Throughput of the BASELINE.json configurations other than the headline one (synthetic tables, see pyqmc_amd.systems).
 
-    python tools/config_bench.py c2|c3|c4|c5 [--walkers W] [--steps K]
+    python tools/config_bench.py c2|c3|c4|c5|big|big_pbc [--walkers W] [--steps K]
 
 c2: H2O single-determinant Slater-Jastrow VMC, 4096 walkers (lane-per-walker sweep; launch-latency bound at this size)
 
@@ -55,8 +55,18 @@ elif a.config == "c5":
     sup = pbc.get_supercell(prim, 2.0 * np.eye(3))
     wf = pa.generate_wf(sup, pbc.random_kmf(sup))
     cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
+elif a.config == "big":  # (H2O)18: 72 + 72 electrons, 414 AOs — beyond 64 per spin (general-n kernels)
+    W = a.walkers or 1024
+    sup = mol = pa.systems.water_cluster(3, 3, 2)
+    wf = pa.generate_wf(mol, pa.systems.random_mf(mol))
+    cfg = pa.initial_guess(mol, W, rng=np.random.default_rng(1))
+elif a.config == "big_pbc":  # diamond, 2x2x2 conventional cells as one cell at Gamma: 64 atoms, 128 + 128 electrons, 832 AOs, real orbitals
+    W = a.walkers or 256
+    sup = pbc.get_supercell(pa.systems.diamond_cubic(2), np.eye(3))
+    wf = pa.generate_wf(sup, pbc.random_kmf(sup))
+    cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
 else:
-    raise SystemExit("config must be c2, c3, c4 or c5")
+    raise SystemExit("config must be c2, c3, c4, c5, big or big_pbc")
 dev = wf.fused_device()
 wf.recompute(cfg)
 if a.config == "c5" and a.rundmc:
