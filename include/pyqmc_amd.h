@@ -246,6 +246,16 @@ int pqa_set_ewald(pqa_handle_t* h, double alpha, int32_t ng, const double* gpoin
    cell (make_irreducible, mc.py:121). */
 int pqa_get_wrap(pqa_handle_t* h, int32_t* wrap);
 
+/* MultiplyWF.gradient / gradient_value / gradient_laplacian (multiplywf.py:116-129) of a real Slater x two-body-Jastrow product
+   living on this handle, electron e moved to pts (W, 3), in ONE call: out (9, W) = the five Slater ratio rows of pqa_slater_eval
+   (value, d/dx, d/dy, d/dz, laplacian, all relative to the current determinant) followed by the four Jastrow rows of
+   pqa_jastrow_eval in mode jmode (1: grad U (3), value ratio; 2: grad U (3), laplacian).  keep_saved as pqa_slater_eval.
+   pqa_wf_update: MultiplyWF.updateinternals (multiplywf.py:102-106) — Sherman-Morrison + Jastrow sums for the walkers of `mask`
+   (NULL: all), and *has_zero = 1 if a determinant of e's spin is zero / not finite AFTER the update: what slater.py:269-275 tests
+   before the NEXT update of that spin (the caller carries the flag; pqa_slater_has_zero is the stand-alone test). */
+int pqa_wf_eval(pqa_handle_t* h, int e, const double* pts, int jmode, int keep_saved, double* out);
+int pqa_wf_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved, int* has_zero);
+
 /* EnergyAccumulator.__call__ (accumulators.py:60-75) on the device-resident walkers:
    out (6, W) rows ke, ee, ei, ecp, grad2, total (kinetic energy.py:57-65, Coulomb :28-54, ECP
    eval_ecp.py:21-146).  threshold as eval_ecp.ecp_mask (:135-146).  rot (N, necp, 3, 3) and

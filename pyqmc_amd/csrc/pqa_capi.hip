@@ -1445,6 +1445,67 @@ extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, co
   return 0;
 }
 
+// ---------------------------------------------------------------- product wave function: one call per protocol method
+// MultiplyWF.gradient / gradient_value / gradient_laplacian and updateinternals (multiplywf.py:102-129) of a Slater x two-body-Jastrow
+// product living on this handle.  The per-factor entries above cost a copy-in, a launch chain, a copy-out and a synchronisation EACH
+// (tools/protocol_profile.py: ~60 us per call at 4096 walkers, seven calls per electron move of pyqmc.method.mc.vmc_worker); here
+// the proposal goes in once and both factors' rows come back in one transfer.
+extern "C" int pqa_wf_eval(pqa_handle_t* h, int e, const double* pts, int jmode, int keep_saved, double* out) {
+  TRY(sync_aos(h));
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || !h->has_j2 || h->has_j3 || h->cplx || h->W == 0) FAIL("pqa_wf_eval: a real Slater x two-body-Jastrow product with resident walkers");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  if (jmode != 1 && jmode != 2) FAIL("jmode: 1 (Jastrow gradient + value) or 2 (gradient + laplacian)");
+  const int s = e >= h->nup, nmo = h->nmo[s];
+  const long W = h->W;
+  h->saved_valid = false;
+  TRY(ensure(h, h->b_pts, (size_t)W * 3 * sizeof(double)));
+  TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo * sizeof(double)));
+  TRY(ensure(h, h->b_out, (size_t)9 * W * sizeof(double)));
+  TRY(copy_in(h, h->b_pts.p, pts, (size_t)W * 3 * sizeof(double)));
+  TRY(launch_orb(h, s, plain_points((const double*)h->b_pts.p, W), W, 5, (double*)h->b_motmp.p));
+  hipLaunchKernelGGL(k_slater_eval<5>, dim3((unsigned)W), dim3(64), lds_det(h, 5), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p, W, 1,
+                     (const int*)nullptr, (double*)h->b_out.p);
+  hipLaunchKernelGGL((k_jastrow_eval<>), dim3((unsigned)W), dim3(64), lds_j3(h), h->stream, h->S, h->js, e, (const double*)h->b_pts.p, W, 1,
+                     (const int*)nullptr, jmode, 1, (double*)h->b_out.p + (size_t)5 * W);
+  TRY(check_launch(h, "k_slater_eval / k_jastrow_eval"));
+  TRY(copy_out(h, out, h->b_out.p, (size_t)9 * W * sizeof(double)));
+  if (keep_saved) { h->saved_valid = true; h->saved_e = e; }
+  return 0;
+}
+
+extern "C" int pqa_wf_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved, int* has_zero) {
+  TRY(sync_aos(h));
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->has_slater || !h->has_j2 || h->has_j3 || h->cplx || h->W == 0) FAIL("pqa_wf_update: a real Slater x two-body-Jastrow product with resident walkers");
+  if (e < 0 || e >= h->N) FAIL("electron index out of range");
+  const int s = e >= h->nup, nmo = h->nmo[s];
+  const long W = h->W;
+  TRY(jas_refresh(h));
+  TRY(ensure(h, h->b_newpos, (size_t)W * 3 * sizeof(double)));
+  TRY(copy_in(h, h->b_newpos.p, epos, (size_t)W * 3 * sizeof(double)));
+  if (!(use_saved && h->saved_valid && h->saved_e == e)) {
+    TRY(ensure(h, h->b_motmp, (size_t)W * 5 * nmo * sizeof(double)));
+    TRY(launch_orb(h, s, plain_points((const double*)h->b_newpos.p, W), W, 5, (double*)h->b_motmp.p));
+  }
+  h->saved_valid = false;
+  const uint8_t* dm = nullptr;
+  if (mask) {
+    TRY(copy_in(h, h->b_mask.p, mask, (size_t)W));
+    dm = (const uint8_t*)h->b_mask.p;
+  }
+  hipLaunchKernelGGL((k_sm_update<>), dim3((unsigned)W), dim3(64), lds_sm(h), h->stream, h->S, h->st, e, (const double*)h->b_motmp.p, 5 * nmo, dm, 1);
+  hipLaunchKernelGGL((k_jastrow_update<>), dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, e, (const double*)h->b_newpos.p, dm);
+  // slater.py:269-275 looks for a vanished determinant BEFORE an update; the flag of the state this call leaves is what the next
+  // update of this spin needs (the caller keeps it), and it travels with the synchronisation the call ends with anyway
+  TRY(ensure(h, h->b_flag, sizeof(int)));
+  HIPCHK(hipMemsetAsync(h->b_flag.p, 0, sizeof(int), h->stream));
+  const long count = W * h->ndet_s[s];
+  hipLaunchKernelGGL((k_has_zero<>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->st.dlog[s], count, (int*)h->b_flag.p);
+  TRY(check_launch(h, "k_sm_update / k_jastrow_update"));
+  return copy_out(h, has_zero, h->b_flag.p, sizeof(int));
+}
+
 extern "C" int pqa_jastrow_get_state(pqa_handle_t* h, double* avalues, double* bvalues, double* configs) {
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));

@@ -152,6 +152,7 @@ class DeviceWF:
                     s.member_M, s.n_member_class = int(pt["member_M"]), int(pt["member"].shape[0])
         self._struct = s
         self._h = C.c_void_p()
+        self._zero = [None, None]  # per spin: did the last pqa_wf_update leave a vanished determinant (None: unknown)
         lib = _ffi.lib()
         rc = lib.pqa_create(C.byref(s), int(device), C.byref(self._h))
         if rc != 0:
@@ -174,6 +175,8 @@ class DeviceWF:
 
     # ------------------------------------------------------------------
     def call(self, name, *args):
+        if name != "pqa_wf_eval":  # (anything else may change the determinants: the flag pqa_wf_update returned no longer describes them)
+            self._zero = [None, None]
         _ffi.check(self._h, getattr(_ffi.lib(), name)(self._h, *args))
 
     def call_int(self, name, *args):
@@ -407,6 +410,18 @@ class DeviceWF:
         unif = None if unif is None or unif.size == 0 else _ffi.f64(unif)
         self.call("pqa_ecp_batched_moves", int(e), float(tau), _ffi.ptr(rot), _ffi.ptr(unif), int(seed), _ffi.ptr(weight), _ffi.ptr(pos))
         return weight, pos
+
+    # product wave function in one call per protocol method (pqa_wf_eval / pqa_wf_update) -------------------------
+    def wf_eval(self, e, pts, jmode, keep):
+        """(9, W): Slater ratio rows (value, gradient, laplacian) + Jastrow rows (gradient, value | laplacian) at pts (W, 3)."""
+        out = np.empty((9, self.W))
+        self.call("pqa_wf_eval", int(e), _ffi.ptr(pts), int(jmode), int(keep), _ffi.ptr(out))
+        return out
+
+    def wf_update(self, e, x, m8, use_saved, spin):
+        flag = C.c_int()
+        self.call("pqa_wf_update", int(e), _ffi.ptr(x), _ffi.ptr(m8), int(use_saved), C.byref(flag))
+        self._zero[spin] = bool(flag.value)
 
     def last_ecp_points(self):
         n = C.c_int64()
@@ -948,12 +963,44 @@ class MultiplyWF:
         res = [w.value() for w in self.wf_factors]
         return np.prod([r[0] for r in res], axis=0), np.sum([r[1] for r in res], axis=0)
 
+    def _product_device(self, epos=None):
+        """The shared handle when this is a real Slater x two-body-Jastrow product on one device (generate_wf's default): its
+        protocol methods then take ONE C call each (pqa_wf_eval / pqa_wf_update) instead of one per factor."""
+        f = self.wf_factors
+        if len(f) != 2 or type(f[0]) is not Slater or type(f[1]) is not JastrowSpin:
+            return None
+        d = self.fused_device()
+        if d is None or d.cplx or (epos is not None and np.ndim(epos.configs) != 2):
+            return None
+        return d
+
     def updateinternals(self, e, epos, configs, mask=None, saved_values=None):
+        d = self._product_device(epos)
+        if d is not None:
+            sl = self.wf_factors[0]
+            s = sl._spin(e)
+            zero = d._zero[s]
+            if zero is None:
+                flag = C.c_int()
+                d.call("pqa_slater_has_zero", s, C.byref(flag))
+                zero = bool(flag.value)
+            if not zero:
+                _, m8 = _mask_args(mask, d.W)
+                sv = None if saved_values is None else saved_values[0]
+                use_saved = sv is not None and sv is sl._saved and sv[1] == int(e)
+                d.wf_update(e, _ffi.f64(_xyz(d, epos)), m8, use_saved, s)
+                sl._saved = None
+                return
         saved_values = [None] * len(self.wf_factors) if saved_values is None else saved_values
         for w, sv in zip(self.wf_factors, saved_values):
             w.updateinternals(e, epos, configs, mask=mask, saved_values=sv)
 
     def gradient(self, e, epos):
+        d = self._product_device(epos)
+        if d is not None:
+            r = d.wf_eval(e, _ffi.f64(_xyz(d, epos)), 1, False)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return r[1:4] / r[0] + r[5:8]
         return np.sum([w.gradient(e, epos) for w in self.wf_factors], axis=0)
 
     def testvalue(self, e, epos, mask=None):
@@ -975,10 +1022,27 @@ class MultiplyWF:
         return np.prod([w.testvalue_many(e, epos, mask=mask) for w in self.wf_factors], axis=0)
 
     def gradient_value(self, e, epos):
+        d = self._product_device(epos)
+        if d is not None:
+            r = d.wf_eval(e, _ffi.f64(_xyz(d, epos)), 1, True)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                deriv = r[1:4] / r[0]
+            deriv[~np.isfinite(deriv)] = 0.0  # (as Slater.gradient_value, slater.py:403-418)
+            val = r[0].copy()
+            val[~np.isfinite(val)] = 1.0
+            sl = self.wf_factors[0]
+            sl._saved = ("pqa-slater-saved", int(e), next(_serial))
+            return deriv + r[5:8], val * r[8], (sl._saved, None)
         g, v, s = zip(*[w.gradient_value(e, epos) for w in self.wf_factors])
         return np.sum(g, axis=0), np.prod(v, axis=0), s
 
     def gradient_laplacian(self, e, epos):
+        d = self._product_device(epos)
+        if d is not None:
+            r = d.wf_eval(e, _ffi.f64(_xyz(d, epos)), 2, False)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                gs, ls = r[1:4] / r[0], r[4] / r[0]
+            return gs + r[5:8], ls + r[8] + 2 * np.sum(gs * r[5:8], axis=0)
         g, l = zip(*[w.gradient_laplacian(e, epos) for w in self.wf_factors])
         cross = np.zeros(l[0].shape, dtype=self.dtype)
         for i in range(len(g)):

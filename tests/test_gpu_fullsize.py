@@ -172,27 +172,24 @@ def test_dmc_steps_at_baseline_size():
     frac = x @ np.linalg.inv(sup.lattice_vectors())
     assert frac.min() >= -1e-12 and frac.max() < 1 + 1e-12
     assert note("C5_dmc_update_vs_recompute", np.max(np.abs(dev.recompute(x)[1] - logv))) < 1e-9
-    # the first walkers of the 4096, replayed by the oracle's dmc_propagate (dmc.py:123-221) on the device's own draws
-    # (pqa_philox_dmc_tapes): every T-move and drift-diffusion decision, the walkers, and the weights
-    from oracle import dmc as odmc
-
-    nchk, nst = 4, 2
+    # The first 32 walkers of the 4096 over 5 steps, replayed by the oracle's dmc_propagate (dmc.py:123-221) on the device's own
+    # draws (pqa_philox_dmc_tapes): every T-move and drift-diffusion decision, the walkers, and the weights.  The oracle side (88 s
+    # of host time) is the committed fixture g36 (tools/make_dmc_replay.py: starting coordinates, trial energy, branch cut, the
+    # oracle's final state and its decisions); the device side runs here, from the fixture's inputs.
+    g = helpers.golden("g36_dmc_replay")
+    nchk, nst = g["x0"].shape[0], int(g["nsteps"])
+    n_t, n_d = int(g["n_tmoves_accepted"]), int(g["n_diffusion_rejected"])
+    assert n_t == int(g["tmove_accepted"].sum()) >= 20 and n_d == int((~g["diffusion_accepted"]).sum()) >= 50  # (verdict r4 item 6: were 2 and 7)
+    note("C5_dmc_oracle_tmoves_accepted", n_t); note("C5_dmc_oracle_diffusion_rejected", n_d)
+    assert np.array_equal(x0[:nchk], g["x0"]), "the device's starting walkers changed: regenerate g36 (tools/make_dmc_replay.py)"
     wf.recompute(_container(sup, x0))
     w = np.ones(W)
-    bc = 10.0 * float(np.std(en0[5]))
-    dev.dmc_steps(0.02, nst, w, bc, etrial, etrial, seed=77)
+    dev.dmc_steps(float(g["tstep"]), nst, w, float(g["branchcut"]), float(g["etrial"]), float(g["etrial"]), seed=int(g["seed"]))
     xd = dev.configs()
-    tape = dev.philox_dmc_tapes(77, nst, nchk)
-    owf = build("C5")[2]()
-    ocfg = _container(sup, x0[:nchk].copy(), np.zeros((nchk, 64, 3)))
-    record = []
-    _, ocfg, ow = odmc.dmc_propagate(sup, owf, ocfg, np.ones(nchk), 0.02, bc, etrial, etrial, nst, helpers.DeviceDmcTape(tape, 64, dev.necp, True),
-                                     record=record)
-    n_t = sum(int(r[2].sum()) for r in record if r[0] == "t")
-    n_d = sum(int((~r[2]).sum()) for r in record if r[0] == "d")
-    note("C5_dmc_oracle_tmoves_accepted", n_t); note("C5_dmc_oracle_diffusion_rejected", n_d)
-    assert note("C5_dmc_vs_oracle_configs", np.max(np.abs(xd[:nchk] - ocfg.configs))) < 1e-9
-    assert note("C5_dmc_vs_oracle_weights", np.max(np.abs(w[:nchk] - ow) / ow)) < 1e-8
+    assert note("C5_dmc_vs_oracle_configs", np.max(np.abs(xd[:nchk] - g["oracle_configs"]))) < 1e-9
+    assert note("C5_dmc_vs_oracle_weights", np.max(np.abs(w[:nchk] - g["oracle_weights"]) / g["oracle_weights"])) < 1e-8
+    # an accepted move displaces its electron by ~sqrt(3 tstep) ~ 0.2 bohr, a wrong decision anywhere shows up above: the 10 240
+    # drift-diffusion and 10 240 T-move decisions of these walkers are the oracle's
 
 
 def test_vmc_philox_energy_statistics():
@@ -430,7 +427,7 @@ def test_energy_statistics_against_the_oracle():
     wf = helpers.gpu_wf(mol, systems.MeanField(mo, np.ones((2, mo.shape[2]))))
     wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = g["acoeff"].copy(), g["bcoeff"].copy()
     dev = wf.fused_device()
-    W, nsamp = 65536, 120
+    W, nsamp = 262144, 120
     tstep, equil, stride = float(g["tstep"]), int(g["equil"]), int(g["stride"])
     wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(2029)))
     dev.vmc_sweeps(tstep, equil, seed=41, energy=False)
@@ -445,8 +442,8 @@ def test_energy_statistics_against_the_oracle():
     note("energy_stat_device_mean", e_dev), note("energy_stat_device_stderr", s_dev)
     note("energy_stat_oracle_mean", e_orc), note("energy_stat_oracle_stderr", s_orc)
     note("energy_stat_difference_mHa", 1e3 * (e_dev - e_orc)), note("energy_stat_combined_stderr_mHa", 1e3 * comb)
-    assert comb <= 1e-3, (s_dev, s_orc)
-    assert abs(e_dev - e_orc) < 3.0 * comb, (e_dev, e_orc, comb)
+    assert comb <= 0.5e-3, (s_dev, s_orc)  # so that |dE| < 1 mHa is itself a >= 2 sigma statement (verdict r4 item 6)
+    assert abs(e_dev - e_orc) < 3.0 * comb and abs(e_dev - e_orc) < 1e-3, (e_dev, e_orc, comb)
 
 
 @pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C5", 4096)])
