@@ -452,7 +452,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   // general in n — orbitals by the thread-per-point evaluator + k_mo_rows, determinants by the wave-per-walker kernels with two
   // columns per lane (k_build_invert, slater_ratios, sm_update_wave on the inverse in place), no lane-per-walker planes.
   h->big = h->nup > PQA_MAXN_FAST || h->ndn > PQA_MAXN_FAST || (sys->has_slater && (sys->nmo_up > PQA_MAXN_FAST || sys->nmo_dn > PQA_MAXN_FAST));
-  if (h->big && h->cplx) FAIL("complex orbitals: at most 64 electrons and 64 orbitals (32 complex) per spin channel");
+  if (h->big && h->twist) FAIL("twisted cells: at most 64 electrons and 64 orbitals per spin channel (the general orbital path evaluates real AOs)");
+  if (h->big && h->cplx && !(sys->pbc && sys->nL > 0)) FAIL("complex orbitals beyond 64 per spin: periodic handles only");
   if (h->big) h->lw_mode = 0;
   if (const char* e = getenv("PQA_ORB_GENERAL")) h->orb_general = atoi(e) != 0;
   SysDev& S = h->S;
@@ -601,9 +602,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     build_chunks(h, 16, h->chunks[0]);
     build_chunks(h, 32, h->chunks[1]);
     for (int s = 0; s < 2; ++s) {
-      if (h->nmo[s] > PQA_MAXN) FAIL("more than 128 orbitals per spin are not supported");
+      if (h->nmo[s] > (h->cplx ? 2 : 1) * PQA_MAXN) FAIL("more than 128 orbitals per spin are not supported");
       const int nt = (h->nmo[s] + 15) / 16;
-      h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt <= 4 ? 4 : 8));  // (8: padded coefficient rows of 128 columns, contracted in two windows of four tiles; periodic big handles through k_mo_rows)
+      h->nt[s] = nt <= 1 ? 1 : (nt == 2 ? 2 : (nt <= 4 ? 4 : (nt <= 8 ? 8 : 16)));  // (8: padded coefficient rows of 128 columns, contracted in two windows of four tiles; periodic big handles through k_mo_rows)
       S.nmo[s] = h->nmo[s]; S.ndet_s[s] = h->ndet_s[s];
       TRY(upload_table(h, occ_src[s], (size_t)h->ndet_s[s] * nel[s], &tmp_i)); S.det_occ[s] = tmp_i;
       {
@@ -1052,10 +1053,20 @@ static int slater_rebuild(pqa_handle* h) {  // cache + inverse + determinants fr
     pa.group_stride = (long)h->N * 3;
     TRY(launch_orb(h, s, pa, h->W * nel[s], 5, h->st.cache[s]));
     const size_t lds = (h->cplx ? 2 : 1) * ((size_t)nel[s] * (nel[s] + 1)) * sizeof(double) + (size_t)nel[s] * sizeof(int) + 16;
-    if (lds > 64 * 1024 && !h->invert_attr) {  // (91 electrons of a spin and more: past the default dynamic-LDS limit)
+    if (!h->cplx && lds > 64 * 1024 && !h->invert_attr) {  // (91 electrons of a spin and more: past the default dynamic-LDS limit)
       HIPCHK(hipFuncSetAttribute((const void*)k_build_invert<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       h->invert_attr = true;
     }
+    if (h->cplx && nel[s] > PQA_MAXN_FAST) {  // the complex tile does not fit LDS: scratch matrices in global memory, <= 512 MB per pass
+      const size_t per = (size_t)2 * nel[s] * (nel[s] + 1) * sizeof(double) * h->ndet_s[s];
+      const long wchunk = std::max<long>(1, std::min<long>(h->W, (long)(((size_t)512 << 20) / per)));
+      TRY(ensure(h, h->b_ao, (size_t)wchunk * per));
+      for (long w0 = 0; w0 < h->W; w0 += wchunk) {
+        const long nw = std::min(wchunk, h->W - w0);
+        hipLaunchKernelGGL((k_build_invert_cg<>), dim3((unsigned)(nw * h->ndet_s[s])), dim3(64), (size_t)nel[s] * sizeof(int) + 16, h->stream, h->S, h->st, s, w0,
+                           (double*)h->b_ao.p);
+      }
+    } else
     if (h->cplx) hipLaunchKernelGGL((k_build_invert_c<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     else hipLaunchKernelGGL((k_build_invert<>), dim3((unsigned)(h->W * h->ndet_s[s])), dim3(64), lds, h->stream, h->S, h->st, s, h->W);
     TRY(check_launch(h, "k_build_invert"));

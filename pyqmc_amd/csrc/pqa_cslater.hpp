@@ -114,6 +114,111 @@ static __global__ __launch_bounds__(64) void k_build_invert_c(SysDev S, SlaterSt
   if (lane == 0) { ph[0] = phase.r; ph[1] = phase.i; st.dlog[s][w * D + d] = logd; }
 }
 
+// More than 64 electrons of a spin: the complex tile (2 n (n + 1) doubles: 188 KB at n = 108) does not fit LDS, so the elimination runs
+// on a scratch matrix in global memory (M: [block][2][n][n + 1], volatile accesses: every element is written by one lane and read by
+// others of the same wave between block barriers), lanes owning columns lane, lane + 64.  Same pivoting rule and arithmetic as above.
+// grid = nw * ndet_s blocks of 64 threads for walkers [w0, w0 + nw); dynamic LDS: n ints.
+template <int PQA_UNIT = 0>
+static __global__ __launch_bounds__(64) void k_build_invert_cg(SysDev S, SlaterState st, int s, long w0, double* __restrict__ scratch) {
+  extern __shared__ double lds[];
+  const int n = s ? S.ndn : S.nup, nmo2 = S.nmo[s], nmo = nmo2 / 2, D = S.ndet_s[s];
+  if (n == 0) return;
+  const long w = w0 + blockIdx.x / D;
+  const int d = blockIdx.x % D;
+  const int lane = threadIdx.x, ld = n + 1;
+  volatile double* Mr = scratch + (size_t)blockIdx.x * 2 * n * ld;
+  volatile double* Mi = Mr + (size_t)n * ld;
+  int* perm = (int*)lds;
+  const int* occ = S.det_occ[s] + (size_t)d * n;
+  const double* cw = st.cache[s] + (size_t)w * n * 5 * nmo2;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx % n;
+    Mr[j * ld + i] = cw[(size_t)i * 5 * nmo2 + occ[j]];
+    Mi[j * ld + i] = cw[(size_t)i * 5 * nmo2 + nmo + occ[j]];
+  }
+  __syncthreads();
+  cx phase = {1.0, 0.0};
+  double logd = 0.0;
+  bool singular = false;
+  for (int k = 0; k < n; ++k) {
+    double v = -1.0;
+    int idx = lane;
+    for (int r = lane; r < n; r += 64) {
+      const double a = Mr[r * ld + k], b = Mi[r * ld + k];
+      const double c = (r >= k) ? a * a + b * b : -1.0;
+      if (c > v) { v = c; idx = r; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(v, off, 64);
+      const int oi = __shfl_xor(idx, off, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int p = idx;
+    if (!(v > 0.0) || !(v <= DBL_MAX)) { singular = true; break; }
+    if (p != k)
+      for (int c = lane; c < n; c += 64) {
+        double t = Mr[k * ld + c]; Mr[k * ld + c] = Mr[p * ld + c]; Mr[p * ld + c] = t;
+        t = Mi[k * ld + c]; Mi[k * ld + c] = Mi[p * ld + c]; Mi[p * ld + c] = t;
+      }
+    if (p != k) phase = cscale(phase, -1.0);
+    if (lane == 0) perm[k] = p;
+    __syncthreads();
+    const cx piv = {Mr[k * ld + k], Mi[k * ld + k]};
+    logd += 0.5 * log(cabs2(piv));
+    phase = cmul(phase, cphase(piv));
+    __syncthreads();
+    cx rk[PQA_MAXN / 64];
+#pragma unroll
+    for (int q = 0; q < PQA_MAXN / 64; ++q) {
+      const int c = lane + 64 * q;
+      rk[q] = {0.0, 0.0};
+      if (c < n) {
+        const cx one = {1.0, 0.0};
+        rk[q] = (c == k) ? cdiv(one, piv) : cdiv(cx{Mr[k * ld + c], Mi[k * ld + c]}, piv);
+        Mr[k * ld + c] = rk[q].r; Mi[k * ld + c] = rk[q].i;
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < n; ++r) {
+      if (r == k) continue;
+      const cx f = {Mr[r * ld + k], Mi[r * ld + k]};
+      __syncthreads();  // (every lane has column k's entry of row r before its owner overwrites it)
+#pragma unroll
+      for (int q = 0; q < PQA_MAXN / 64; ++q) {
+        const int c = lane + 64 * q;
+        if (c < n) {
+          const cx cur = (c == k) ? cx{0.0, 0.0} : cx{Mr[r * ld + c], Mi[r * ld + c]};
+          const cx nv = csub(cur, cmul(f, rk[q]));
+          Mr[r * ld + c] = nv.r; Mi[r * ld + c] = nv.i;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double* Tw = st.T[s] + ((size_t)w * D + d) * n * n * 2;
+  double* ph = st.dsign[s] + ((size_t)w * D + d) * 2;
+  if (singular) {
+    for (int idx = lane; idx < 2 * n * n; idx += 64) Tw[idx] = 0.0;
+    if (lane == 0) { ph[0] = 0.0; ph[1] = 0.0; st.dlog[s][w * D + d] = -INFINITY; }
+    return;
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = perm[k];
+    if (p != k)
+      for (int r = lane; r < n; r += 64) {
+        double t = Mr[r * ld + k]; Mr[r * ld + k] = Mr[r * ld + p]; Mr[r * ld + p] = t;
+        t = Mi[r * ld + k]; Mi[r * ld + k] = Mi[r * ld + p]; Mi[r * ld + p] = t;
+      }
+    __syncthreads();
+  }
+  for (int idx = lane; idx < n * n; idx += 64) {
+    Tw[2 * idx] = Mr[(idx / n) * ld + idx % n];
+    Tw[2 * idx + 1] = Mi[(idx / n) * ld + idx % n];
+  }
+  if (lane == 0) { ph[0] = phase.r; ph[1] = phase.i; st.dlog[s][w * D + d] = logd; }
+}
+
 // ---------------------------------------------------------------- multi-determinant bookkeeping
 __device__ __forceinline__ cx det_weight_c(const SysDev& S, const SlaterState& st, long w, int Dd, double ref) {
   cx ph = {1.0, 0.0};
@@ -220,6 +325,47 @@ __device__ __forceinline__ void sm_update_wave_c(const SysDev& S, const SlaterSt
                                                  const double* __restrict__ morow, double* lds) {
   const int lane = threadIdx.x & 63;
   const int n = s ? S.ndn : S.nup, nmo = S.nmo[s] / 2, D = S.ndet_s[s], ld = n + 1;
+  if (n > PQA_MAXN_FAST) {  // on the inverse in place (see sm_update_wave): LDS 6 n doubles
+    double* V = lds;       // [n][2]
+    double* TMP = V + 2 * n;
+    double* R = TMP + 2 * n;
+    for (int d = 0; d < D; ++d) {
+      double* Tw = st.T[s] + ((size_t)w * D + d) * n * n * 2;
+      const int* occ = S.det_occ[s] + (size_t)d * n;
+      for (int k = lane; k < n; k += 64) { V[2 * k] = morow[occ[k]]; V[2 * k + 1] = morow[nmo + occ[k]]; }
+      __syncthreads();
+      for (int j = 0; j < n; ++j) {
+        cx p = {0.0, 0.0};
+        for (int k = lane; k < n; k += 64) p = cadd(p, cmul(cx{V[2 * k], V[2 * k + 1]}, cx{Tw[2 * ((size_t)j * n + k)], Tw[2 * ((size_t)j * n + k) + 1]}));
+        p = wave_sum_cx(p);
+        if (lane == 0) { TMP[2 * j] = p.r; TMP[2 * j + 1] = p.i; }
+      }
+      __syncthreads();
+      const cx ratio = {TMP[2 * i], TMP[2 * i + 1]};
+      for (int k = lane; k < n; k += 64) {
+        const cx q = cdiv(cx{Tw[2 * ((size_t)i * n + k)], Tw[2 * ((size_t)i * n + k) + 1]}, ratio);
+        R[2 * k] = q.r; R[2 * k + 1] = q.i;
+      }
+      __syncthreads();
+      for (int j = 0; j < n; ++j) {
+        const cx tj = {TMP[2 * j], TMP[2 * j + 1]};
+        for (int k = lane; k < n; k += 64) {
+          const cx rk = {R[2 * k], R[2 * k + 1]};
+          double* t = Tw + 2 * ((size_t)j * n + k);
+          const cx nv = (j == i) ? rk : csub(cx{t[0], t[1]}, cmul(rk, tj));
+          t[0] = nv.r; t[1] = nv.i;
+        }
+      }
+      if (lane == 0) {
+        double* ph = st.dsign[s] + ((size_t)w * D + d) * 2;
+        const cx np_ = cmul(cx{ph[0], ph[1]}, cphase(ratio));
+        ph[0] = np_.r; ph[1] = np_.i;
+        st.dlog[s][(size_t)w * D + d] += 0.5 * log(cabs2(ratio));
+      }
+      __syncthreads();
+    }
+    return;
+  }
   double* Lr = lds;
   double* Li = Lr + (size_t)n * ld;
   double* Vr = Li + (size_t)n * ld;

@@ -149,6 +149,52 @@ def test_periodic_cell_with_128_electrons_per_spin_matches_oracle():
         assert note(f"big_pbc:energy_{k}", helpers.relerr(en[k], oen[k])) < 1e-7, k
 
 
+def test_periodic_cell_with_108_complex_orbitals_per_spin_matches_oracle():
+    """Diamond, 3 x 3 x 3 primitive cells (54 atoms, 108 + 108 electrons, complex Bloch orbitals at 27 k-points): complex determinants
+    beyond one column per lane — k_build_invert_cg (elimination on a scratch matrix in global memory: the complex tile is 188 KB),
+    slater_ratios_c, Sherman-Morrison on the inverse in place — with the thread-per-point lattice sums + k_mo_rows.  Recompute,
+    derivatives of the first / a middle / the last electron, accepted updates, kinetic + ECP energy of 2 walkers against the oracle."""
+    import pyqmc_amd as pa
+    from oracle import energy as oenergy
+    from pyqmc_amd.configs import PeriodicConfigs
+
+    sup, wf = helpers.gpu_pbc_wf("big_complex")
+    _, owf = helpers.oracle_pbc_wf("big_complex")
+    assert sup.nelec == (108, 108) and wf.dtype == complex
+    x = pa.initial_guess(sup, 2, rng=np.random.default_rng(108)).configs
+    cfg, ocfg = PeriodicConfigs(x.copy(), sup.lattice_vectors()), PeriodicConfigs(x.copy(), sup.lattice_vectors())
+    (s1, l1), (s2, l2) = wf.recompute(cfg), owf.recompute(ocfg)
+    assert note("big_complex:recompute_phase", float(np.max(np.abs(s1 - s2)))) < 1e-8 and note("big_complex:recompute_log", float(np.max(np.abs(l1 - l2)))) < 1e-8
+    rng = np.random.default_rng(4)
+    for e in (0, 107, 108, 215):
+        new = x[:, e, :] + 0.2 * rng.standard_normal((2, 3))
+        ep, oep = cfg.make_irreducible(e, new), ocfg.make_irreducible(e, new)
+        (g1, v1, sv), (g2, v2, osv) = wf.gradient_value(e, ep), owf.gradient_value(e, oep)
+        assert note(f"big_complex:e{e}_val", helpers.relerr(v1, v2)) < 1e-8 and note(f"big_complex:e{e}_grad", helpers.relerr(g1, g2)) < 1e-7
+        (g1, p1), (g2, p2) = wf.gradient_laplacian(e, ep), owf.gradient_laplacian(e, oep)
+        assert note(f"big_complex:e{e}_lap", helpers.relerr(p1, p2)) < 1e-7
+        acc = np.array([True, e % 2 == 0])
+        cfg.move(e, ep, acc)
+        ocfg.move(e, oep, acc)
+        wf.updateinternals(e, ep, cfg, mask=acc, saved_values=sv)
+        owf.updateinternals(e, oep, ocfg, mask=acc, saved_values=osv)
+    (s1, l1), (s2, l2) = wf.value(), owf.value()
+    assert note("big_complex:value_after_updates", float(max(np.max(np.abs(l1 - l2)), np.max(np.abs(s1 - s2))))) < 1e-8
+    N, necp = 216, 54
+    rot = pa.ecp_batched.random_rotations(N * necp).reshape(N, necp, 3, 3)
+    unif = rng.random((N, necp, 2))
+    en = pa.EnergyAccumulator(sup, ewald_gmax=6)(cfg, wf, rot=rot, unif=unif)
+    oen = oenergy.energy(sup, ocfg, owf, 10.0, rot, unif, ewald_kws=dict(ewald_gmax=6))
+    for k in ("ke", "ee", "ei", "ecp", "total"):
+        assert note(f"big_complex:energy_{k}", helpers.relerr(en[k], oen[k])) < 1e-7, k
+    # one fused VMC sweep leaves a state that equals a fresh recompute
+    dev = wf.fused_device()
+    dev.vmc_sweeps(0.3, 1, seed=3, energy=False)
+    xs = dev.configs()
+    l_upd = dev.value()[1]
+    assert note("big_complex:sweep_update_vs_recompute", float(np.max(np.abs(dev.recompute(xs)[1] - l_upd)))) < 1e-8
+
+
 @pytest.mark.parametrize("tag", ["gamma", "fcc2cubic"])
 def test_periodic_batched_ecp_matches_oracle(tag):
     """The batched ECP integrator (jax_ecp.py:72-135; oracle/ecp_batched.py is pinned to the reference by g34) in a periodic cell:

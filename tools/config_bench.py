@@ -65,8 +65,13 @@ elif a.config == "big_pbc":  # diamond, 2x2x2 conventional cells as one cell at 
     sup = pbc.get_supercell(pa.systems.diamond_cubic(2), np.eye(3))
     wf = pa.generate_wf(sup, pbc.random_kmf(sup))
     cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
+elif a.config == "big_complex":  # diamond 3x3x3 primitive cells: 54 atoms, 108 + 108 electrons, complex Bloch orbitals (27 k-points)
+    W = a.walkers or 128
+    sup = pbc.get_supercell(prim, 3.0 * np.eye(3))
+    wf = pa.generate_wf(sup, pbc.random_kmf(sup))
+    cfg = pa.initial_guess(sup, W, rng=np.random.default_rng(1))
 else:
-    raise SystemExit("config must be c2, c3, c4, c5, big or big_pbc")
+    raise SystemExit("config must be c2, c3, c4, c5, big, big_pbc or big_complex")
 dev = wf.fused_device()
 wf.recompute(cfg)
 if a.config == "c5" and a.rundmc:
