@@ -700,7 +700,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     const int nterm = sys->ecp_term_off[nchan];
     h->ecp_nchan = nchan; h->ecp_nterm = nterm;
     for (int k = 0; k < h->necp; ++k)
-      if (sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k] > PQA_MAXCHAN) FAIL("ECP with more than 4 non-local channels");
+      if (sys->ecp_chan_off[k + 1] - sys->ecp_chan_off[k] > PQA_MAXCHAN) FAIL("ECP with more than 5 non-local channels (the reference's Legendre functions end at l = 4, eval_ecp.py:203-225)");
     TRY(upload_table(h, sys->ecp_atom, (size_t)h->necp, &tmp_i)); S.ecp_atom = tmp_i;
     TRY(upload_table(h, sys->ecp_chan_off, (size_t)h->necp + 1, &tmp_i)); S.ecp_chan_off = tmp_i;
     TRY(upload_table(h, sys->ecp_term_off, (size_t)nchan + 1, &tmp_i)); S.ecp_term_off = tmp_i;

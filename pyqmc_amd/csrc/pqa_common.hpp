@@ -11,7 +11,7 @@
 #define PQA_JQ 24         // doubles per merged-numerator record (N1[4], N2[7], N3[10], padding)
 #define PQA_MAXN 128      // max electrons / orbitals per spin (real orbitals; up to 64 on every fast path, above: the two-slot wave kernels)
 #define PQA_MAXN_FAST 64  // one lane per column: LDS-staged determinant tile, lane-per-walker planes, four 16-column MFMA tiles
-#define PQA_MAXCHAN 5     // ECP channels per atom incl. local
+#define PQA_MAXCHAN 6     // ECP channels per atom incl. local: s, p, d, f, g non-local channels — the reference's Legendre table ends at l = 4 (eval_ecp.py:203-225)
 #define PQA_MAXAIP 12
 
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -63,7 +63,7 @@ static __global__ __launch_bounds__(64 * PQA_ECPB_WB) void k_ecpb_fill(SysDev S,
     double dx = x0 - ax, dy = y0 - ay, dz = z0 - az;
     if (PBC) min_image(S, dx, dy, dz);  // configs.dist.dist_i (jax_ecp.py:170-172)
     const double r = sqrt(dx * dx + dy * dy + dz * dz);
-    double v[PQA_MAXCHAN] = {0.0, 0.0, 0.0, 0.0, 0.0}, pr_;
+    double v[PQA_MAXCHAN] = {}, pr_;
     int nch = 1;
     if (atom) ecp_radial(S, kk, r, 0.0, v, nch, pr_);
     double vloc = atom ? v[nch - 1] : 0.0, prob = 0.0;

@@ -167,8 +167,9 @@ def water_cluster(nx=2, ny=2, nz=2, spacing=6.0):
     return Mol(sym, xyz)
 
 
-def water_multichannel():
-    """H2O whose oxygen carries s, p and d non-local channels (four channels with the local one: the reference's default rule
+def water_multichannel(lmax=2):
+    """H2O whose oxygen carries s, p and d non-local channels (``lmax=4``: also f and g, the last Legendre function the reference
+    tabulates, eval_ecp.py:203-225) (four channels with the local one: the reference's default rule
     for it is the 12-point icosahedral grid, eval_ecp.py:239-240) and whose hydrogens keep the one-channel table (6 points):
     the system of the quadrature-rule fixtures (naip = None, 18, 26, 32, 50)."""
     ecp = dict(_ECP)
@@ -176,6 +177,10 @@ def water_multichannel():
                     [0, [[], [], [[13.65512, 85.86406]]]],
                     [1, [[], [], [[9.21, -3.4], [2.87, 1.15]]]],
                     [2, [[], [], [[6.4, -1.9]], [[3.1, 0.45]]]]])
+    if lmax >= 3:
+        ecp["O"][1].append([3, [[], [], [[4.7, 1.3]]]])
+    if lmax >= 4:
+        ecp["O"][1].append([4, [[], [], [[3.9, -0.8], [1.7, 0.12]]]])
     sym, xyz = zip(*_WATER)
     return Mol(sym, xyz, ecp=ecp)
 

@@ -317,6 +317,17 @@ def g_ecp_naip():
             out[tag + "_ecp"], out[tag + "_total"] = np.asarray(en["ecp"]), np.asarray(en["total"])
             out[tag + "_rot"] = np.asarray(t.log["rot"]).reshape(N, natm_ecp, 3, 3)
             out[tag + "_unif"] = np.asarray(t.log["random"]).reshape(N, natm_ecp, W)
+    # s .. g non-local channels (the reference's Legendre table ends at l = 4, eval_ecp.py:203-225): six channels with the local one
+    mol4 = systems.water_multichannel(lmax=4)
+    wf4 = make_wf(mol4, systems.random_mf(mol4))
+    wf4.recompute(configs)
+    for naip in (None, 26, 50):
+        with Tapes(3390 + len(out)) as t:
+            en = pyq.EnergyAccumulator(mol4, threshold=10.0, naip=naip)(configs, wf4)
+        tag = f"l4_naip{naip}"
+        out[tag + "_ecp"], out[tag + "_total"] = np.asarray(en["ecp"]), np.asarray(en["total"])
+        out[tag + "_rot"] = np.asarray(t.log["rot"]).reshape(N, natm_ecp, 3, 3)
+        out[tag + "_unif"] = np.asarray(t.log["random"]).reshape(N, natm_ecp, W)
     for naip in (6, 12, 18, 26, 32, 50):  # the grids themselves (eval_ecp.py:278-336)
         pts, wts = eval_ecp.generate_quadrature_grids()[naip]
         out[f"grid{naip}_points"], out[f"grid{naip}_weights"] = pts, wts

@@ -177,6 +177,14 @@ def test_ecp_quadrature_rules_golden(ecp_lds, monkeypatch):
     assert npts["naip6_det"] < npts["naipNone_det"] < 2 * npts["naip6_det"]  # 12 points at the oxygen, 6 at the hydrogens
     with pytest.raises(ValueError):
         pa.EnergyAccumulator(mol, naip=14)
+    # s .. g non-local channels at the oxygen (six channels with the local one: the reference's Legendre table ends at l = 4)
+    mol4 = systems.water_multichannel(lmax=4)
+    wf4 = helpers.gpu_wf(mol4, systems.random_mf(mol4))
+    wf4.recompute(configs)
+    for naip in (None, 26, 50):
+        tag = f"l4_naip{naip}"
+        en = pa.EnergyAccumulator(mol4, threshold=10.0, naip=naip)(configs, wf4, rot=g[tag + "_rot"], unif=g[tag + "_unif"])
+        assert note(f"ecp_{tag}", relerr(en["ecp"], g[tag + "_ecp"])) < 1e-9 and relerr(en["total"], g[tag + "_total"]) < 1e-9, tag
 
 
 @pytest.mark.parametrize("orb_general", ["0", "1"])

@@ -130,6 +130,14 @@ def test_g33_ecp_quadrature_rules():
             en = oenergy.energy(mol, configs, wf, thr, g[tag + "_rot"], g[tag + "_unif"], naip=naip)
             assert relerr(en["ecp"], g[tag + "_ecp"]) < 1e-10 and relerr(en["total"], g[tag + "_total"]) < 1e-10, tag
     assert relerr(g["naip50_det_ecp"], g["naip18_det_ecp"]) > 1e-6  # the rules really differ on this system
+    mol4 = systems.water_multichannel(lmax=4)  # s .. g channels: the Legendre table's last entry (eval_ecp.py:203-225)
+    wf4 = helpers.oracle_wf(mol4, systems.random_mf(mol4))
+    wf4.recompute(configs)
+    for naip in (None, 26, 50):
+        tag = f"l4_naip{naip}"
+        en = oenergy.energy(mol4, configs, wf4, 10.0, g[tag + "_rot"], g[tag + "_unif"], naip=naip)
+        assert relerr(en["ecp"], g[tag + "_ecp"]) < 1e-10, tag
+    assert relerr(g["l4_naip50_ecp"], g["naip50_thr10_ecp"]) > 1e-6  # the f and g channels contribute
 
 
 def test_g34_batched_ecp():
