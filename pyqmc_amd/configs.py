@@ -33,6 +33,53 @@ class RawDistance:
         return config2[:, np.newaxis, :] - config1[:, :, np.newaxis]
 
 
+class _WalkerArrays:
+    """What the two containers share: every per-walker array named in ``_arrays`` (``configs``, for periodic cells also the
+    ``wrap`` counters) is moved, resampled, split, joined and reshaped in step.  Constructor arguments other than the arrays
+    come from ``_like()``."""
+
+    _arrays = ("configs",)
+
+    def _like(self, **arrays):
+        raise NotImplementedError
+
+    def _get(self):
+        return {k: getattr(self, k) for k in self._arrays}
+
+    def _view(self, index):
+        return self._like(**{k: v[index] for k, v in self._get().items()})
+
+    def select_electrons(self, es):
+        return self._view((slice(None), es))
+
+    def mask(self, mask):
+        return self._view(mask)
+
+    def move(self, e, new, accept):
+        """Electron e of the walkers flagged in ``accept`` takes the position (and counters) of the electron object ``new``."""
+        for k, v in self._get().items():
+            v[accept, e, :] = getattr(new, k)[accept, :]
+
+    def resample(self, newinds):
+        for k, v in self._get().items():
+            setattr(self, k, v[newinds])
+
+    def split(self, npartitions):
+        parts = {k: np.array_split(v, npartitions) for k, v in self._get().items()}
+        return [self._like(**{k: parts[k][i] for k in parts}) for i in range(npartitions)]
+
+    def join(self, configslist, axis=0):
+        for k in self._arrays:
+            setattr(self, k, np.concatenate([getattr(c, k) for c in configslist], axis=axis))
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def reshape(self, shape):
+        for k, v in self._get().items():
+            setattr(self, k, v.reshape(shape))
+
+
 class OpenElectron:
     """(nconf,3) or (nconf,naip,3) positions for one electron (``coord.py:21-28``)."""
 
@@ -44,42 +91,24 @@ class OpenElectron:
         return OpenElectron(self.configs[mask], dist=self.dist)
 
 
-class OpenConfigs:
-    """(nconf,nelec,3) walker positions (``coord.py:31-112``)."""
+class OpenConfigs(_WalkerArrays):
+    """(nconf,nelec,3) walker positions (interface of ``coord.py:31-112``)."""
 
     def __init__(self, configs, dist=None):
         self.configs = np.ascontiguousarray(configs, dtype=float)
         self.dist = dist if dist is not None else RawDistance()
 
+    def _like(self, configs):
+        return OpenConfigs(configs, dist=self.dist)
+
     def electron(self, e):
         return OpenElectron(self.configs[:, e], self.dist)
-
-    def select_electrons(self, es):
-        return OpenConfigs(self.configs[:, es], self.dist)
-
-    def mask(self, mask):
-        return OpenConfigs(self.configs[mask], dist=self.dist)
 
     def make_irreducible(self, e, vec, mask=True):
         return OpenElectron(vec, self.dist)
 
-    def move(self, e, new, accept):
-        self.configs[accept, e, :] = new.configs[accept, :]
-
-    def resample(self, newinds):
-        self.configs = self.configs[newinds]
-
-    def split(self, npartitions):
+    def split(self, npartitions):  # (the pieces get distance objects of their own, as coord.py:64-66 builds them)
         return [OpenConfigs(c) for c in np.array_split(self.configs, npartitions)]
-
-    def join(self, configslist, axis=0):
-        self.configs = np.concatenate([c.configs for c in configslist], axis=axis)
-
-    def copy(self):
-        return copy.deepcopy(self)
-
-    def reshape(self, shape):
-        self.configs = self.configs.reshape(shape)
 
 
 # ------------------------------------------------------------------------------------ periodic
@@ -161,60 +190,34 @@ class PeriodicElectron:
         return PeriodicElectron(self.configs[mask], self.lvecs, self.dist, wrap=self.wrap[mask])
 
 
-class PeriodicConfigs:
+class PeriodicConfigs(_WalkerArrays):
     """(nconf,nelec,3) walker positions folded into the simulation cell, with per-electron ``wrap`` counters
-    (``coord.py:137-252``)."""
+    (interface of ``coord.py:137-252``)."""
+
+    _arrays = ("configs", "wrap")
 
     def __init__(self, configs, lattice_vectors, wrap=None, dist=None):
-        lattice_vectors = np.asarray(lattice_vectors, dtype=float)
-        folded, w = enforce_pbc(lattice_vectors, np.asarray(configs, dtype=float))
+        self.lvecs = np.asarray(lattice_vectors, dtype=float)
+        folded, crossed = enforce_pbc(self.lvecs, np.asarray(configs, dtype=float))
         self.configs = np.ascontiguousarray(folded)
-        self.wrap = w if wrap is None else w + wrap
-        self.lvecs = lattice_vectors
-        self.dist = dist if dist is not None else MinimalImageDistance(lattice_vectors)
+        self.wrap = crossed if wrap is None else crossed + wrap
+        self.dist = dist if dist is not None else MinimalImageDistance(self.lvecs)
+
+    def _like(self, configs, wrap):
+        return PeriodicConfigs(configs, self.lvecs, wrap=wrap, dist=self.dist)
 
     def electron(self, e):
         return PeriodicElectron(self.configs[:, e], self.lvecs, self.dist, wrap=self.wrap[:, e])
 
-    def select_electrons(self, es):
-        return PeriodicConfigs(self.configs[:, es], self.lvecs, wrap=self.wrap[:, es], dist=self.dist)
-
-    def mask(self, mask):
-        return PeriodicConfigs(self.configs[mask], self.lvecs, wrap=self.wrap[mask], dist=self.dist)
-
     def make_irreducible(self, e, vec, mask=None):
-        """Fold proposed positions ``vec`` ((nconf,3) or (nconf,naip,3)) for electron ``e`` into the cell and
-        carry the electron's wrap counters along (``coord.py:164-178``)."""
-        if mask is None:
-            mask = np.ones(vec.shape[:-1], dtype=bool)
-        folded, dw = enforce_pbc(self.lvecs, vec[mask])
+        """Electron object for proposed positions ``vec`` of electron ``e`` — (nconf,3), or (nconf,naip,3) for auxiliary points —
+        folded into the cell where ``mask`` (default: everywhere) selects them; its counters are the electron's own plus the cells
+        crossed by the fold (semantics of ``coord.py:164-178``)."""
+        vec = np.asarray(vec)
+        own = self.wrap[:, e, :]
+        wrap = np.array(np.broadcast_to(own[:, np.newaxis, :] if vec.ndim == 3 else own, vec.shape))
         epos = vec.copy()
-        epos[mask] = folded
-        wrap = self.wrap[:, e, :].copy()
-        if vec.ndim == 3:
-            wrap = np.repeat(self.wrap[:, e][:, np.newaxis], vec.shape[1], axis=1)
-        wrap[mask] += dw
+        where = np.ones(vec.shape[:-1], dtype=bool) if mask is None else mask
+        epos[where], crossed = enforce_pbc(self.lvecs, vec[where])
+        wrap[where] += crossed
         return PeriodicElectron(epos, self.lvecs, self.dist, wrap=wrap)
-
-    def move(self, e, new, accept):
-        self.configs[accept, e, :] = new.configs[accept, :]
-        self.wrap[accept, e, :] = new.wrap[accept, :]
-
-    def resample(self, newinds):
-        self.configs = self.configs[newinds]
-        self.wrap = self.wrap[newinds]
-
-    def split(self, npartitions):
-        return [PeriodicConfigs(c, self.lvecs, w, dist=self.dist)
-                for c, w in zip(np.array_split(self.configs, npartitions), np.array_split(self.wrap, npartitions))]
-
-    def join(self, configslist, axis=0):
-        self.configs = np.concatenate([c.configs for c in configslist], axis=axis)
-        self.wrap = np.concatenate([c.wrap for c in configslist], axis=axis)
-
-    def copy(self):
-        return copy.deepcopy(self)
-
-    def reshape(self, shape):
-        self.configs = self.configs.reshape(shape)
-        self.wrap = self.wrap.reshape(shape)

@@ -47,6 +47,27 @@ def pmc_traffic(case, walkers):
             "fetch_calibration": d["calibration"]["applied_fetch_factor"], "source": "profiles/" + os.path.basename(path)}
 
 
+def ao_valu_flops(nsample=400):
+    """SURVEY 8(d).2's vector-pipe work of the lattice-summed AO phase per point of a 5-component launch: F_ao = 30 P + 4 ncomp M
+    with P = the (image, primitive) pairs the cut-offs admit at the point — counted here for random points of the cell with the
+    tables' own rule (an image L_j, j < num_Ls[atom], contributes to a shell when |r - R_atom - L_j|^2 < shell_cut[shell]; the
+    reference's cut-offs, pbcgto.py:565-604) — and M = AOs.  Returns (flops per point, admitted pairs per point)."""
+    from pyqmc_amd import tables
+
+    pt, bt = pbc.periodic_tables(sup), tables.basis_tables(sup)
+    rng = np.random.default_rng(7)
+    pts = rng.random((nsample, 3)) @ sup.lattice_vectors()
+    R = np.asarray(sup.atom_coords())
+    nprim = np.diff(bt["shell_prim_off"])
+    pairs = 0.0
+    for A in range(sup.natm):
+        d = pts[:, None, :] - R[A][None, None, :] - pt["Ls"][None, : pt["num_Ls"][A], :]
+        r2 = np.sum(d * d, axis=-1)  # (nsample, images)
+        for sh in np.nonzero(bt["shell_atom"] == A)[0]:
+            pairs += nprim[sh] * np.count_nonzero(r2 < min(pt["shell_cut"][sh], pt["atom_cut"][A])) / nsample
+    return 30.0 * pairs + 4.0 * 5 * int(bt["nao"]), pairs
+
+
 wf = pa.generate_wf(sup, mf, image_rule=a.rule)
 dev = wf.fused_device()
 cfg = pa.initial_guess(sup, a.walkers, rng=np.random.default_rng(1))
@@ -54,7 +75,7 @@ wf.recompute(cfg)
 dev.profile_enable(True)  # event pairs are created during the warm-up
 dev.vmc_sweeps(0.3, a.warmup, seed=1, energy=not a.no_energy)
 dev.sync()
-dt, roof = float("inf"), None
+dt, roof, roof_valu = float("inf"), None, None
 for rep in range(2):  # best of two timed passes: about one process in eight sees a 1.5-2x slow pass on these boxes
     dev.profile_enable(True)
     t0 = time.perf_counter()
@@ -70,8 +91,15 @@ for rep in range(2):  # best of two timed passes: about one process in eight see
         roof = {"bound": "mfma", "kernel": "k_pbc_prepass + k_orb<5, PBC> / k_orb_wide<5, PBC> (move launches)", "achieved": flops / (orb_ms * 1e-3) / 1e12,
                 "peak": 78.6, "unit": "TFLOP/s", "frac": flops / (orb_ms * 1e-3) / 1e12 / 78.6, "launches": launches,
                 "avg_launch_ms": orb_ms / launches, "flops_per_point_component": 2 * nao * nmo, "traffic": pmc_traffic(a.case, a.walkers)}
+        f_ao, pairs = ao_valu_flops()
+        points = point_comps / 5.0
+        roof_valu = {"bound": "valu", "kernel": "lattice-summed AO phase of the move launches (k_pbc_prepass + phase 1 of k_orb<5, PBC> / k_orb_wide<5, PBC>)",
+                     "achieved": f_ao * points / (orb_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                     "frac": f_ao * points / (orb_ms * 1e-3) / 1e12 / 78.6, "flops_per_point": f_ao, "admitted_image_primitive_pairs_per_point": pairs,
+                     "pipe_frac_mfma_plus_valu": (f_ao * points + flops) / (orb_ms * 1e-3) / 1e12 / 78.6,
+                     "note": "same launches and event times as `roofline`; SURVEY 8(d).2: F_ao = 30 P + 4 ncomp M, P counted with the tables' cut-offs on random points of the cell"}
     dt = min(dt, t)
 dev.profile_enable(False)
 print(json.dumps({"case": a.case, "nelec": int(sum(sup.nelec)), "natom": sup.natm, "walkers": a.walkers, "ms_per_step": 1e3 * dt / a.steps,
                   "walker_steps_per_s": a.walkers * a.steps / dt, "acceptance": float(acc[-1]),
-                  "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule, "roofline": roof}))
+                  "energy": None if a.no_energy else float(en[-1, -1]), "rule": a.rule, "roofline": roof, "roofline_valu": roof_valu}))
