@@ -294,6 +294,12 @@ int pqa_ecp_batched_moves(pqa_handle_t* h, int e, double tau, const double* rot,
    Psi(candidate)/Psi (1 where the walker fails the ECP mask for that atom), weight (W,P) = sum_l (exp(-tau v_l)-1)
    (2l+1)P_l w_i (0 there), pos (W,P,3) candidate positions (current position there).  ratio = NULL: positions and weights
    only — complex handles take their (complex) ratios from pqa_wf_testvalue at those positions. */
+/* The next pqa_dmc_steps call starts from the energies (E_L, |grad|^2) its predecessor's last step left on the device instead of
+   evaluating the starting configuration again — what dmc_propagate carries from step to step (dmc.py:148-149, :199-200); for callers
+   that make one call per step to run host accumulators in between (pyqmc_amd.dmc with OBDM / TBDM accumulators).  One-shot; refused
+   when the wave-function state changed since that call (recompute, update, resample, sweep, parameter change).  With tapes the
+   index-0 energy draws of the call are unused. */
+int pqa_dmc_continue(pqa_handle_t* h, int on);
 int pqa_tmove_npoints(pqa_handle_t* h);
 int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif, double* ratio,
                double* weight, double* pos);

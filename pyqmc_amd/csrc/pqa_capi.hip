@@ -888,6 +888,7 @@ static int jas_merge_tables(pqa_handle* h) {
 
 // ---------------------------------------------------------------- parameters
 extern "C" int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize(h->stream));
   const std::string k(name);
@@ -1081,6 +1082,7 @@ static int slater_value_dev(pqa_handle* h) {
 }
 
 extern "C" int pqa_slater_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater) FAIL("handle has no Slater factor");
@@ -1257,6 +1259,7 @@ extern "C" int pqa_slater_has_zero(pqa_handle_t* h, int spin, int* flag) {
 }
 
 extern "C" int pqa_slater_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || h->W == 0) FAIL("Slater state not initialised (call recompute)");
@@ -1311,6 +1314,7 @@ extern "C" int pqa_slater_get_state(pqa_handle_t* h, int spin, double* inverse, 
 
 // ---------------------------------------------------------------- Jastrow
 extern "C" int pqa_jastrow_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2) FAIL("handle has no two-body Jastrow factor");
@@ -1398,6 +1402,7 @@ extern "C" int pqa_j3_pgradient(pqa_handle_t* h, double* d_ccoeff) {
 }
 
 extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* logval) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3) FAIL("handle has no three-body Jastrow factor");
@@ -1417,6 +1422,7 @@ extern "C" int pqa_j3_recompute(pqa_handle_t* h, const double* configs, int64_t 
 }
 
 extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j3 || h->W == 0) FAIL("three-body Jastrow state not initialised (call recompute)");
@@ -1437,6 +1443,7 @@ extern "C" int pqa_j3_update(pqa_handle_t* h, int e, const double* epos, const u
 }
 
 extern "C" int pqa_jastrow_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_j2 || h->W == 0) FAIL("Jastrow state not initialised (call recompute)");
@@ -1486,6 +1493,7 @@ extern "C" int pqa_wf_eval(pqa_handle_t* h, int e, const double* pts, int jmode,
 }
 
 extern "C" int pqa_wf_update(pqa_handle_t* h, int e, const double* epos, const uint8_t* mask, int use_saved, int* has_zero) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (!h->has_slater || !h->has_j2 || h->has_j3 || h->cplx || h->W == 0) FAIL("pqa_wf_update: a real Slater x two-body-Jastrow product with resident walkers");
@@ -1558,6 +1566,7 @@ static int wf_value_host(pqa_handle* h, double* sign, double* logabs) {
 }
 
 extern "C" int pqa_wf_recompute(pqa_handle_t* h, const double* configs, int64_t W, double* sign, double* logabs) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   TRY(ensure_walkers(h, W));
@@ -1599,6 +1608,7 @@ static int gather_swap(pqa_handle* h, DevBuf& cur, DevBuf& alt, const int* d_idx
   return 0;
 }
 extern "C" int pqa_resample(pqa_handle_t* h, const int32_t* newinds) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");
@@ -1692,6 +1702,7 @@ static int recompute_range(pqa_handle* h, long w0, long n) {
 }
 
 extern "C" int pqa_branch_exchange(pqa_handle_t* h, const int32_t* keep_src, int64_t nkeep, const double* recv_x, int64_t nrecv) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   TRY(sync_aos(h));
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call recompute)");

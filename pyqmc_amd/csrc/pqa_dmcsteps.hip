@@ -77,9 +77,15 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
   double* eold = (double*)h->b_dmcold.p;
   double* r2 = (double*)h->b_dmcr2.p;
   std::vector<long> tm_accepted((size_t)nsteps, 0);
-  // energy of the starting configuration (dmc.py:146-149)
-  TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
-  hipLaunchKernelGGL((k_dmc_keep<>), gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
+  // energy of the starting configuration (dmc.py:146-149) — or, after pqa_dmc_continue, the energies the previous call's last step
+  // left in eold / v2old: what the reference itself carries from step to step (dmc.py:148-149, :199-200)
+  const bool cont = h->dmc_continue;
+  h->dmc_continue = false;
+  if (cont && !(h->dmc_old_valid && h->dmc_old_W == W)) FAIL("pqa_dmc_continue: no previous pqa_dmc_steps call on the resident walkers' state");
+  if (!cont) {
+    TRY(energy_dev(h, threshold, (tp && necp) ? tp->ecp_rot : nullptr, (tp && necp) ? tp->ecp_unif : nullptr, seed, 0u, false));
+    hipLaunchKernelGGL((k_dmc_keep<>), gw256, dim3(256), 0, h->stream, (const double*)h->b_en.p, eold, eold + W, W);
+  }
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
@@ -202,6 +208,12 @@ extern "C" int pqa_dmc_steps(pqa_handle_t* h, double tstep, int nsteps, double b
     step_acc[2 * i] = (double)cnt[2 * i] / ((double)W * N);
     step_acc[2 * i + 1] = (double)tm_accepted[i] / ((double)W * N);
   }
+  h->dmc_old_valid = true; h->dmc_old_W = W;
+  return 0;
+}
+
+extern "C" int pqa_dmc_continue(pqa_handle_t* h, int on) {
+  h->dmc_continue = on != 0;
   return 0;
 }
 

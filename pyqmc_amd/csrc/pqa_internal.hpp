@@ -58,6 +58,9 @@ struct pqa_handle {
   int pbc_maxcls = PQA_PRE_NCUT;  // most distinct shell cut-offs any atom has (picks the pre-pass instantiation)
   int pbc_nw = 2;  // words per (atom, point) of the sorted image lists k_pbc_prepass writes (4 entries each)
   bool orb_general = false;  // PQA_ORB_GENERAL=1: big open handles evaluate orbitals by k_ao + k_mo_rows instead of the windowed k_orb (A/B, tests)
+  // pqa_dmc_continue: the next pqa_dmc_steps call takes the energies its predecessor ended with as its starting energies
+  bool dmc_continue = false, dmc_old_valid = false;
+  long dmc_old_W = 0;
   bool invert_attr = false;  // k_build_invert's dynamic-LDS limit raised (n > 90)
   bool big = false;         // more than 64 electrons or orbitals of a spin: general orbital path, wave-per-walker kernels (pqa_create)
   bool pbc_high_l = false;  // a periodic cell with g / h shells: orbitals through k_ao<.., 5> + k_mo_rows (pqa_orb_pbc.hip)

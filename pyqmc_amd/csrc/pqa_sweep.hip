@@ -354,6 +354,7 @@ int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) 
 extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const double* gauss, const double* unif, double threshold,
                               const double* ecp_rot, const double* ecp_unif, uint64_t seed, double* acceptance,
                               double* energy_mean, uint8_t* accept_rec) {
+  h->dmc_old_valid = false;  // (the state pqa_dmc_continue refers to is gone)
   HIPCHK(hipSetDevice(h->device));
   if (h->W == 0) FAIL("state not initialised (call pqa_wf_recompute)");
   if (nsteps <= 0) return 0;

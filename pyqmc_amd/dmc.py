@@ -82,12 +82,14 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     return out, configs, weights
 
 
-def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, accumulators, ekey, state_current=False):
+def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, accumulators, ekey, state_current=False,
+                                 rng=None):
     """``dmc_propagate`` with further accumulators (density matrices, ...) next to the energy: every step is one device call
     (``pqa_dmc_steps`` with ``nsteps = 1``), after which the walkers come back and the other accumulators run on the host over
-    the protocol entry points, weight-averaged as in dmc.py:205-221.  The device evaluates the energy of the step's starting
-    configuration itself, where the reference carries the previous step's: the same numbers unless the ECP evaluation is
-    stochastic (then an independent unbiased sample of the same energy)."""
+    the protocol entry points, weight-averaged as in dmc.py:205-221.  From the second step on the device starts from the
+    energies its previous step ended with (``pqa_dmc_continue``), as the reference carries ``eloc`` / ``v2`` from step to step
+    (dmc.py:148-149, :199-200): same trajectory as the all-device loop, one energy evaluation per step.  ``rng`` replays the
+    reference's draws (tests)."""
     from .energy import KEYS
     from .vmc import _fetch
 
@@ -98,8 +100,16 @@ def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_
     acc.bind(dev)
     w = np.ascontiguousarray(weights, dtype=np.float64)
     df = []
-    for _ in range(nsteps):
-        avg, stat = dev.dmc_steps(tstep, 1, w, branchcut, e_trial, e_est, threshold=acc.threshold, seed=int(np.random.randint(0, 2**31 - 1)))
+    tapes = None
+    if rng is not None:
+        N, necp = configs.configs.shape[1], getattr(dev, "necp", 0)
+        tapes = _record_tapes(rng, nsteps, N, necp, W, acc.has_nonlocal_moves() and necp > 0)
+    for i in range(nsteps):
+        step_tapes = None
+        if tapes is not None:  # this step's slice; the energy draws: [starting configuration (used by the first call only), this step]
+            step_tapes = {k: (np.stack([v[0 if i == 0 else i], v[i + 1]]) if k.startswith("ecp_") else v[i:i + 1]) for k, v in tapes.items()}
+        avg, stat = dev.dmc_steps(tstep, 1, w, branchcut, e_trial, e_est, threshold=acc.threshold, tapes=step_tapes,
+                                  seed=int(np.random.randint(0, 2**31 - 1)), cont=i > 0)
         _fetch(dev, configs)
         wavg = float(avg[0, 6])
         d = {name + k: avg[0, i] for i, k in enumerate(KEYS[:6])}
@@ -141,7 +151,7 @@ def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, 
     The whole step loop of dmc.py:123-221 runs on the device (``pqa_dmc_steps``): wave functions on one handle — real, or
     complex (no node constraint, weights from Re E_L, T-move amplitudes from Re[Psi(R')/Psi(R)]: golden g30) — with the
     energy accumulator; further accumulators (OBDM, TBDM, ...) are evaluated on the host between device steps and
-    weight-averaged as dmc.py:205-212 does.  ``rng`` replays the reference's draws (tests, energy only); ``state_current=True``
+    weight-averaged as dmc.py:205-212 does.  ``rng`` replays the reference's draws (tests); ``state_current=True``
     promises that the device already holds the wave-function state of ``configs`` — ``rundmc`` passes it after branching on
     the device (``DeviceWF.resample``) — and skips the initial recompute.  (``tests/helpers.protocol_dmc_propagate`` is the
     protocol-route harness the parity tests use.)"""
@@ -151,10 +161,8 @@ def dmc_propagate(wf, configs, weights, tstep, branchcut_start, e_trial, e_est, 
         raise NotImplementedError("pyqmc_amd.dmc_propagate runs wave functions on one device handle whose energy comes from "
                                   "pyqmc_amd.EnergyAccumulator; drive pyqmc.method.dmc.dmc_propagate over the protocol objects for anything else")
     if set(accumulators) != {ekey[0]}:
-        if rng is not None:
-            raise NotImplementedError("replayed draws (rng=) cover the energy-only step loop")
         return _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators, ekey,
-                                            state_current=state_current)
+                                            state_current=state_current, rng=rng)
     return _propagate_fused(dev, wf, configs, weights, tstep, branchcut_start, e_trial, e_est, nsteps, accumulators[ekey[0]], ekey[0], rng,
                             state_current=state_current)
 

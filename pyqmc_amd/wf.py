@@ -334,7 +334,7 @@ class DeviceWF:
         ptr = C.c_void_p(recv_x) if isinstance(recv_x, int) else _ffi.ptr(None if recv_x is None else _ffi.f64(recv_x))
         self.call("pqa_branch_exchange", _ffi.ptr(keep), len(keep), ptr, int(nrecv))
 
-    def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0):
+    def dmc_steps(self, tstep, nsteps, weights, branchcut, e_trial, e_est, threshold=10.0, tapes=None, seed=0, cont=False):
         """``pqa_dmc_steps``: ``nsteps`` DMC steps on the resident walkers.  ``weights`` (W) is updated in place.
         ``tapes``: dict of the replay arrays of ``pqa_dmc_tapes_t`` or None (device Philox streams).
         Returns (step_avg (nsteps,7) — (nsteps,8) for complex wave functions —, step_acc (nsteps,2))."""
@@ -349,6 +349,8 @@ class DeviceWF:
                     a = _ffi.f64(a)
                     keep.append(a)
                     setattr(tp, name, a.ctypes.data)
+        if cont:  # start from the energies the previous call ended with (pqa_dmc_continue)
+            self.call("pqa_dmc_continue", 1)
         self.call("pqa_dmc_steps", float(tstep), int(nsteps), float(branchcut), float(e_trial), float(e_est), float(threshold),
                   _ffi.ptr(weights), None if tp is None else C.addressof(tp), int(seed), _ffi.ptr(avg), _ffi.ptr(acc))
         return avg, acc

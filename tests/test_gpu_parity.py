@@ -432,6 +432,42 @@ def test_fused_dmc_steps_golden():
     assert np.array_equal(ph0, ph1) and relerr(v0, v1) < 1e-10
 
 
+def test_dmc_with_a_host_accumulator_replays_the_reference():
+    """dmc_propagate with an accumulator next to the energy makes one device call per step; from the second step
+    on the call starts from the energies its predecessor ended with (pqa_dmc_continue) — the reference carries eloc / v2 from
+    step to step (dmc.py:148-149, :199-200).  With the reference's draws replayed the route reproduces golden g12 exactly
+    like the all-device loop does: final walkers, weights, every block average; a continuation after a state change is refused."""
+    import pyqmc_amd as pa
+
+    g = golden("g12_dmc")
+    mol = systems.water()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    tstep, branchcut, e_trial, e_est, nsteps = g["params"]
+
+    class Count:  # a host-side accumulator: forces the per-step route, reads the walkers it is handed
+        def __call__(self, configs, wf):
+            return {"r2": np.sum(configs.configs ** 2, axis=(1, 2))}
+
+        def keys(self):
+            return {"r2"}
+
+        def shapes(self):
+            return {"r2": ()}
+
+    accs = {"energy": pa.EnergyAccumulator(mol), "probe": Count()}
+    df, configs, weights = pa.dmc_propagate(wf, OpenConfigs(g["start"].copy()), g["weights0"].copy(), float(tstep), float(branchcut),
+                                            float(e_trial), float(e_est), nsteps=int(nsteps), accumulators=accs, rng=helpers.ReplayTape(g))
+    assert note("hdmc_final", relerr(configs.configs, g["final"])) < 1e-9
+    assert note("hdmc_weights", relerr(weights, g["weights"])) < 1e-8
+    for k in g["df_keys"].tolist():
+        assert note("hdmc_" + k, relerr(df[k], g["df_" + k])) < 1e-8, k
+    assert np.isfinite(df["prober2"]) and df["prober2"] > 0
+    dev = wf.fused_device()
+    wf.recompute(configs)
+    with pytest.raises(pa._ffi.PqaError):
+        dev.dmc_steps(float(tstep), 1, np.ones(dev.W), float(branchcut), float(e_trial), float(e_est), cont=True)
+
+
 def test_fused_dmc_philox_statistics():
     """Device-RNG mode of pqa_dmc_steps against the host-driven loop on independent draws: same population, same
     trial function, so block energies, acceptance and T-move acceptance agree within the statistical error."""

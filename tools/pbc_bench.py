@@ -32,9 +32,9 @@ mf = pbc.random_kmf(sup)
 
 def pmc_traffic(case, walkers):
     """Counter-measured HBM bytes of one move's orbital evaluation (image-list pre-pass + orbital kernel), per launch, scaled
-    from the walker count the counters were collected at: profiles/r04_pbc_<case>_pmc_summary.json (tools/refresh_evidence.sh:
+    from the walker count the counters were collected at: profiles/r05_pbc_<case>_pmc_summary.json (tools/refresh_evidence.sh:
     separate FETCH_SIZE / WRITE_SIZE passes, calibrated by tools/pmc_calib).  None when no summary exists for the case."""
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r04_pbc_{case}_pmc_summary.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", next((f for f in (f"r05_pbc_{case}_pmc_summary.json", f"r04_pbc_{case}_pmc_summary.json") if os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f))), f"r05_pbc_{case}_pmc_summary.json"))
     if not os.path.exists(path):
         return None
     d = json.load(open(path))

@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d /tmp/pc_$c -o t -- $R/tools/pmc_calib > $O/pmc_calib_$c.txt 2>&1 < /dev/null
 done
 python $R/tools/pmc_summary.py /tmp/pm_FETCH_SIZE/t_results.db /tmp/pm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db $W $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
-cp $O/pmc_summary.json $R/profiles/r04_pmc_summary.json  # (this box's copy: bench.py reads its `traffic` fields from it)
+cp $O/pmc_summary.json $R/profiles/r05_pmc_summary.json  # (this box's copy: bench.py reads its `traffic` fields from it)
 python $R/bench.py --walkers $W > $O/bench.json 2> $O/bench.err < /dev/null
 python $R/bench.py --mode dmc --steps 20 --warmup 2 > $O/bench_dmc.json 2>> $O/bench.err < /dev/null
 python $R/bench.py --mode c4 --steps 20 --warmup 2 > $O/bench_c4.json 2>> $O/bench.err < /dev/null
@@ -26,7 +26,7 @@ for case in k222 cubic; do  # counter passes of the periodic cases (separate run
     python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_${case}_pmc_$c.csv
   done
   python $R/tools/pmc_summary.py /tmp/pkm_FETCH_SIZE/t_results.db /tmp/pkm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db 32768 $O/pbc_${case}_pmc_summary.json > /dev/null 2>&1
-  cp $O/pbc_${case}_pmc_summary.json $R/profiles/r04_pbc_${case}_pmc_summary.json
+  cp $O/pbc_${case}_pmc_summary.json $R/profiles/r05_pbc_${case}_pmc_summary.json
 done
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
@@ -55,5 +55,13 @@ python $R/tools/split_ab.py --walkers $W --steps 10 1 2 3 > $O/split_ab.jsonl 2>
 for m in 0 1 2; do rm -rf /tmp/tr$m; rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$m -o t -- python $R/tools/split_ab.py --walkers $W --steps 3 $m > /dev/null 2>&1 < /dev/null; echo "== PQA_SPLIT=$m (first block: mode 0 reference run, second: the mode)"; python $R/tools/trace_overlap.py $(find /tmp/tr$m -name "*kernel_trace.csv" | head -1) 0.25; done > $O/split_overlap.txt 2>&1
 (cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --mode dmc --backend gloo --same-gpu --device-buffers --unbalance 0.5 --steps 20 --warmup 1 > $O/bench_dmc_2rank_same_gpu.json 2>> $O/bench.err < /dev/null)
 python $R/tools/cpu_config_baseline.py c2 c3 c4 c5 > $O/cpu_config_baseline.jsonl 2>> $O/bench.err
+# round 5: handles beyond 64 electrons per spin, the protocol route, the resident sweep against the launch-per-move sweep, the LDS-DMA probe
+for c in "big --walkers 1024" "big --walkers 8192" "big_pbc --walkers 256" "big_complex --walkers 128"; do python $R/tools/config_bench.py $c --steps 1 2>/dev/null | tail -1 >> $O/config_bench.jsonl; done
+for w in 4096 65536; do python $R/tools/protocol_profile.py $w --json $O/protocol_$w.json > /dev/null 2>> $O/bench.err; done
+for w in 1024 4096 16384 65536; do for r in 1 0; do echo -n "{\"walkers\": $w, \"PQA_RES\": $r, \"line\": \"" >> $O/resident_ab.txt; PQA_RES=$r python $R/tools/scratch/lib_bench.py $R/pyqmc_amd/lib/libpyqmc_amd.so $w 2>/dev/null | tr -d '\n' >> $O/resident_ab.txt; echo "\"}" >> $O/resident_ab.txt; done; done
+rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/tools/scratch/lib_bench.py $R/pyqmc_amd/lib/libpyqmc_amd.so 4096 > /dev/null 2>&1 < /dev/null
+python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/m_4096_kernel_stats.csv
+[ -x $R/tools/scratch/bin/dma_probe ] || (mkdir -p $R/tools/scratch/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 $R/tools/scratch/dma_probe.hip -o $R/tools/scratch/bin/dma_probe 2>/dev/null)
+timeout 120 $R/tools/scratch/bin/dma_probe > $O/dma_probe.txt 2>&1
 cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
