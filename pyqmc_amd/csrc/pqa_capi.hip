@@ -288,6 +288,7 @@ static int set_mo(pqa_handle* h, int s, const double* mo_host) {
   if (h->nmo[s] == 0 || !mo_host) return 0;  // an empty spin channel (fully polarised systems): nothing to upload
   HIPCHK(hipMemcpy(h->d_mo[s], mo_host, (size_t)h->nao * std::max(h->nmo[s], 1) * sizeof(double), hipMemcpyHostToDevice));
   for (int t = 0; t < 2; ++t) TRY(upload_cpad(h, t, s, mo_host));
+  TRY(res_refresh_coeff(h, s, mo_host));  // (the resident sweep's dense coefficient copy, if it keeps one)
   return 0;
 }
 
@@ -398,6 +399,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
+  if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_MIN")) h->res_min = atol(rs);
   if (const char* rs = getenv("PQA_RES_MAX")) h->res_max = atol(rs);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);

@@ -168,9 +168,15 @@ struct pqa_handle {
   int res_mode = -1;
   long res_min = 1, res_max = 1L << 40;
   bool res_ready = false, res_ok = false;
+  // dense mode: the tile holds the AOs in their own order (rows padded to x4 only) with its own coefficient copy d_cres[s] [rows4][ldc] —
+  // for bases whose chunk-padded rows do not fit one LDS tile (the 2x2x2 diamond cell: 208 AOs, 224 padded rows)
+  bool res_dense = false;
+  int res_rows4 = 0;
+  double* d_cres[2] = {nullptr, nullptr};
   ResTab res_tab{};
   size_t res_lds = 0;
   int res_lmax = 0;
+  int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
   // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
   // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
@@ -313,6 +319,7 @@ void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, lo
 // pqa_res.hip
 bool res_eligible(pqa_handle* h, long W);
 int sweep_res(pqa_handle* h, const MoveBuf& mb);
+int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host);  // (pqa_res.hip: dense coefficient copy follows set_mo)
 // pqa_tile.hip
 bool tile_eligible(const pqa_handle* h);
 int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);

@@ -5,11 +5,24 @@
 // Passes over the padded coefficient rows of the 16-row chunk table (h->chunks[0]: the coefficient matrices cpad[0] are shared
 // with k_orb), shell lists per (pass, lane group), LDS budget.  Once per handle; leaves res_ok = false when the system is outside
 // the kernel's scope.
+// dense coefficient copy [rows4][ldc] of spin s in AO order (rows beyond nao and columns beyond nmo zero)
+int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host) {
+  if (!h->d_cres[s] || h->nmo[s] == 0) return 0;
+  const int ldc = 16 * h->nt[s], nmo = h->nmo[s];
+  std::vector<double> pad((size_t)h->res_rows4 * ldc, 0.0);
+  for (int a = 0; a < h->nao; ++a)
+    for (int j = 0; j < nmo; ++j) pad[(size_t)a * ldc + j] = mo_host[(size_t)a * nmo + j];
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->d_cres[s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 static int res_setup(pqa_handle* h) {
   h->res_ready = true;
   h->res_ok = false;
   if (h->res_mode == 0) return 0;
-  if (!h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->S.pbc || h->twist) return 0;
+  if (!h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->twist) return 0;
+  if (h->S.pbc && (h->S.nL <= 0 || h->pbc_high_l || h->res_pbc == 0)) return 0;  // periodic: lattice-summed orbitals, l <= 3 (PQA_RES_PBC=0 keeps the launches)
   if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32 || h->N > 64 || h->N < 1 || h->natom > 64) return 0;
   int lmax = 0;
   for (int l : h->shell_l) lmax = std::max(lmax, l);
@@ -27,18 +40,55 @@ static int res_setup(pqa_handle* h) {
     rows_cap = std::min(rows_cap, 4 * PQA_RES_MAXKS * (8 / nt));
     part_rn = std::max(part_rn, (size_t)(8 / nt) * 16 * res_ps(nt) + (size_t)16 * PQA_RES_RS);
   }
-  const size_t fixed = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS);
+  // periodic: the image lists take what is left beside a one-pass tile — 32, 24, 16 or 12 entries per (point, atom)
+  int icap = 0;
+  size_t pbc_b = 0;
+  if (h->S.pbc) {
+    const size_t f0 = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS);
+    for (int cand : {32, 24, 16, 12}) {
+      icap = cand;
+      pbc_b = res_lds_pbc(h->natom, h->S.nL, icap) + 8;
+      if (f0 + pbc_b + (size_t)80 * c.rows_pad * sizeof(double) <= (size_t)160 * 1024 - 256) break;
+    }
+  }
+  const size_t fixed = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS) + pbc_b;
   const size_t budget = 160 * 1024 - 256;
   if (fixed + part_rn * sizeof(double) > budget) return 0;
   const size_t avail = (budget - fixed) / sizeof(double);
   // one pass if the whole basis fits (the partials then reuse the tile's memory); otherwise the tile shares the region with them
   const int rows_all = c.rows_pad;
   const bool one = rows_all <= rows_cap && (size_t)80 * rows_all <= avail;
-  const int kt_cap = one ? rows_all : std::min(rows_cap, (int)(((avail - part_rn) / 80) & ~(size_t)3));
+  // dense mode: the chunk padding (16-row chunks: 224 rows for the 208 AOs of the 2x2x2 diamond cell) is what keeps the basis out of one
+  // tile, and the AOs in their own order (padded to x4) fit
+  const int rows4 = (h->nao + 3) & ~3;
+  const size_t fixed1 = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, 1);
+  bool dense = false;
+  if (!one && rows4 <= rows_cap) {
+    for (int cand : {32, 24, 16, 12}) {
+      const size_t pb = h->S.pbc ? res_lds_pbc(h->natom, h->S.nL, cand) + 8 : 0;
+      if (fixed1 + pb + std::max((size_t)80 * rows4, part_rn) * sizeof(double) + 8 <= budget) { dense = true; icap = cand; pbc_b = pb; break; }
+      if (!h->S.pbc) break;
+    }
+  }
+  const int kt_cap = (one || dense) ? (dense ? rows4 : rows_all) : std::min(rows_cap, (int)(((avail - part_rn) / 80) & ~(size_t)3));
   if (kt_cap < 20) return 0;
   ResTab RT{};
+  h->res_dense = dense;
+  h->res_rows4 = rows4;
+  if (dense) {
+    for (int s = 0; s < 2; ++s) {
+      if (h->nmo[s] == 0) continue;
+      std::vector<double> mo((size_t)h->nao * h->nmo[s]);
+      HIPCHK(hipMemcpy(mo.data(), h->d_mo[s], mo.size() * sizeof(double), hipMemcpyDeviceToHost));
+      if (!h->d_cres[s]) TRY(upload_table<double>(h, nullptr, (size_t)rows4 * 16 * h->nt[s], &h->d_cres[s]));
+      TRY(res_refresh_coeff(h, s, mo.data()));
+    }
+  }
   int ch = 0, kt = 0;
   std::vector<int> pass_of_chunk((size_t)nch, 0);
+  if (dense) {
+    RT.npass = 1; RT.pass_row0[0] = 0; kt = rows4; ch = nch;
+  }
   while (ch < nch) {  // greedy: consecutive chunks while their padded rows fit the tile
     if (RT.npass == PQA_RES_MAXPASS) return 0;
     const int base = c.row0[ch];
@@ -51,14 +101,14 @@ static int res_setup(pqa_handle* h) {
     ch = end;
     ++RT.npass;
   }
-  RT.pass_row0[RT.npass] = c.rows_pad;
+  RT.pass_row0[RT.npass] = dense ? rows4 : c.rows_pad;
   RT.kt = kt;
   RT.part_off = (RT.npass == 1) ? 0 : 80 * kt;
   RT.region = (RT.npass == 1) ? (int)std::max((size_t)80 * kt, part_rn) : (int)((size_t)80 * kt + part_rn);
   // shell lists: per pass the shells by descending phase-1 cost, dealt to the 32 lane groups in snake order — neighbours in cost
   // (the same kind of shell) land in neighbouring groups, i.e. in one wave, and the groups' totals stay balanced
   std::vector<int> off(1, 0), list, srow((size_t)h->nshell, 0);
-  for (int sh = 0; sh < h->nshell; ++sh) srow[sh] = c.row0[c.shell_chunk[sh]] + c.shell_kb[sh];
+  for (int sh = 0; sh < h->nshell; ++sh) srow[sh] = dense ? h->shell_ao[sh] : c.row0[c.shell_chunk[sh]] + c.shell_kb[sh];
   for (int p = 0; p < RT.npass; ++p) {
     std::vector<int> mem;
     for (int sh = 0; sh < h->nshell; ++sh)
@@ -83,11 +133,17 @@ static int res_setup(pqa_handle* h) {
   TRY(upload_table(h, list.data(), list.size(), &tmp_i)); RT.grp_shell = tmp_i;
   TRY(upload_table(h, srow.data(), srow.size(), &tmp_i)); RT.shell_row = tmp_i;
   h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, RT.nlist, RT.npass);
+  h->res_lds = (h->res_lds + 7) & ~(size_t)7;
+  RT.pbc_off = (int)h->res_lds; RT.icap = icap;
+  h->res_lds += pbc_b;
   if (h->res_lds > 160 * 1024) return 0;
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa_res] passes %d, tile rows %d (padded basis %d), LDS %zu B, image-list capacity %d\n", RT.npass, RT.kt, c.rows_pad, h->res_lds, RT.icap);
   h->res_tab = RT;
   h->res_ok = true;
   return 0;
@@ -103,6 +159,9 @@ bool res_eligible(pqa_handle* h, long W) {
   // walkers, 1.88x at 4096, 1.38x at 16384, 1.06x at 32768, 1.02x at 49152, 0.97x at 65536; H2O (8 electrons: a walker's 32 lanes
   // are mostly idle) 1.2x up to 4096 walkers, 0.49x at 16384.  One round of blocks (16 walkers per CU) always wins.
   if (W < h->res_min || W > h->res_max) return false;
+  // periodic cells (lattice-summed AO phase in the block, round 5): 2x2x2 diamond DMC step 6.59 -> 6.00 ms at 1024 walkers, 9.88 -> 8.89 at
+  // 4096, 17.3 -> 16.4 at 8192; sweep alone 12.5 -> 13.1 ms at 16384 (loses)
+  if (h->S.pbc) return W <= 8192;
   return W <= 4096 || (std::max(h->nup, h->ndn) >= 16 && W <= 49152);
 }
 
@@ -111,6 +170,8 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
   if (!mb.gauss || !mb.unif) FAIL("resident sweep: the random-number tapes are missing");
   const long W = h->W;
   const LwState L = lw_state(h);
+  ChunkTab Tc = h->tab[0];
+  if (h->res_dense) { Tc.cpad[0] = h->d_cres[0]; Tc.cpad[1] = h->d_cres[1]; }
   const dim3 grid((unsigned)((W + PQA_RES_NW - 1) / PQA_RES_NW)), block(PQA_RES_NT);
   hipEvent_t e1 = nullptr;
   if (h->profile) {  // every launch is bracketed (one launch per sweep)
@@ -126,7 +187,11 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
     h->prof_launches += 1;
     h->prof_pc += (double)W * h->N * 5;  // point-components of this launch (as launch_orb counts them)
   }
-#define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, h->tab[0], h->res_tab, (int)h->has_jastrow, W, 0L, W)
+#define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
+  if (h->S.pbc) {
+    if (mb.dmc) hipLaunchKernelGGL((k_sweep_res<true, 3, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+    else hipLaunchKernelGGL((k_sweep_res<false, 3, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+  } else
   if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH(true, 2); else PQA_RES_LAUNCH(true, 3); }
   else { if (h->res_lmax <= 2) PQA_RES_LAUNCH(false, 2); else PQA_RES_LAUNCH(false, 3); }
 #undef PQA_RES_LAUNCH

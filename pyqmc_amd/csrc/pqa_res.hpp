@@ -23,8 +23,9 @@
 // measure-zero ties; the random numbers are the same Philox streams (drawn ahead by k_tile_draws), so the oracle replays apply.
 // State in and out: the lane-per-walker SoA planes (xt, Tt, two-slot row cache + selectors, dsign / dlog) — the energy kernels
 // run on them unchanged.
-// Scope: open boundary conditions, real single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin,
-// optional two-body Jastrow factor, l <= 3.  Everything else keeps the lane-per-walker sweep.
+// Scope: real single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin, optional two-body Jastrow factor,
+// l <= 3; open boundary conditions or (PBC) an untwisted periodic cell with real orbitals — lattice-summed AOs by direct image tests
+// inside the AO phase, minimal-image Jastrow pairs, proposals folded into the cell.  Everything else keeps the lane-per-walker sweep.
 #pragma once
 #include "pqa_ao.hpp"
 #include "pqa_jastrow.hpp"
@@ -36,6 +37,7 @@
 #define PQA_RES_G 32       // lane groups of the AO phase
 #define PQA_RES_MAXKS 16   // k-steps (4 AO rows each) of one pass a wave contracts at most
 #define PQA_RES_MAXPASS 8
+#define PQA_RES_WS 20     // doubles per walker of the per-walker scalars (wsc): 16 of the move + the cell wraps of a folded proposal
 #define PQA_RES_RS 176     // doubles per walker of the combined orbital rows [5][32] (+16: walkers of a wave on disjoint LDS banks)
 
 struct ResTab {
@@ -48,13 +50,20 @@ struct ResTab {
   int nlist;                               // entries of grp_shell
   int region;                              // doubles of the tile / partial-sum / orbital-row region
   int part_off;                            // offset of the K-partials in the region: 0 (one pass: they reuse the tile) or 80 kt
+  int pbc_off, icap;                       // periodic: byte offset of the lattice vectors / image lists in the dynamic LDS, list capacity
 };
 // doubles per point of a K-partial [5][16 nt] (+ padding: the four point quartets of a wave on different banks)
 __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
+// (ResTab::icap: admitted images per (point, atom) the block's image lists hold — 32, 24, 16 or 12, the most the LDS budget allows with the
+// whole basis in one tile; a pair with more takes the direct tests)
+// periodic instantiation: candidate lattice vectors [nL][3], image lists [natom][16][icap] and their lengths [natom][16]
+__host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap) {
+  return ((size_t)3 * nL) * sizeof(double) + (((size_t)natom * 16 * (icap + 1) + 7) & ~(size_t)7);
+}
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
-  const size_t d = 16 * 32 + 16 * 16 + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
+  const size_t d = 16 * 32 + 16 * PQA_RES_WS + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
                    2 * (size_t)natom * PQA_JQ + (3 * PQA_JQ + 24);
-  const size_t i = 4 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
+  const size_t i = 5 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
   return d * sizeof(double) + i * sizeof(int);
 }
 
@@ -92,6 +101,7 @@ __device__ __forceinline__ void res_wave_sync() {
 // (coordinates in registers) and the ions r, r + 32 — so the partner's spin, and with it the coefficient set, is wave-uniform.
 // Merged route (S.jq_on, pqa_jastrow.hpp: the Pade functions of a basis as one rational function per pair; electron-electron
 // numerators through scalar registers, the per-ion numerators from the block's LDS copy) or function by function (any basis).
+template <bool PBC>
 __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, double rx, double ry, double rz, const double (&cx)[2],
                                              const double (&cy)[2], const double (&cz)[2], const double* __restrict__ at_xyz,
                                              const double* __restrict__ acoef, const double* __restrict__ aq, double& U, double (&g)[3], int excl = -1) {
@@ -108,7 +118,8 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
     for (int q = 0; q < 2; ++q) {
       const int j = (q ? S.nup : 0) + r;
       if (S.nb > 0 && r < (q ? S.ndn : S.nup) && j != e && j != excl) {
-        const double dx = rx - cx[q], dy = ry - cy[q], dz = rz - cz[q];
+        double dx = rx - cx[q], dy = ry - cy[q], dz = rz - cz[q];
+        if (PBC) min_image_j(S, dx, dy, dz);
         double rr, ri;
         sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
         if (rr < S.rcut_b) {
@@ -133,7 +144,8 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
       const int I = r + 32 * q;
       if (q == 1 && S.natom <= 32) break;
       if (S.na > 0 && I < S.natom) {
-        const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        if (PBC) min_image_j(S, dx, dy, dz);
         double rr, ri;
         sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
         if (rr < S.rcut_a) {
@@ -158,7 +170,8 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
     for (int q = 0; q < 2; ++q) {
       const int j = (q ? S.nup : 0) + r;
       if (S.nb > 0 && r < (q ? S.ndn : S.nup) && j != e && j != excl) {
-        const double dx = rx - (q ? cx[1] : cx[0]), dy = ry - (q ? cy[1] : cy[0]), dz = rz - (q ? cz[1] : cz[0]);
+        double dx = rx - (q ? cx[1] : cx[0]), dy = ry - (q ? cy[1] : cy[0]), dz = rz - (q ? cz[1] : cz[0]);
+        if (PBC) min_image_j(S, dx, dy, dz);
         const double rr = sqrt(dx * dx + dy * dy + dz * dz);
         if (rr < S.rcut_b) {
           const RadShared sh = rad_shared<1>(rr, irb);
@@ -179,7 +192,8 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
     for (int q = 0; q < 2; ++q) {
       const int I = r + 32 * q;
       if (S.na > 0 && I < S.natom) {
-        const double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        double dx = rx - at_xyz[3 * I], dy = ry - at_xyz[3 * I + 1], dz = rz - at_xyz[3 * I + 2];
+        if (PBC) min_image_j(S, dx, dy, dz);
         const double rr = sqrt(dx * dx + dy * dy + dz * dz);
         if (rr < S.rcut_a) {
           const RadShared sh = rad_shared<1>(rr, ira);
@@ -233,6 +247,7 @@ __device__ __forceinline__ void res_pair_m(bool valid, double dx, double dy, dou
 // bcoeff[0][0..2]) and aq: a vector load from global memory in here makes the compiler wait for vmcnt(0), i.e. for the row / tape
 // prefetches and the cache-row stores still in flight (3.7 us per evaluation instead of ~1).
 #define PQA_RES_JT (3 * PQA_JQ + 24)
+template <bool PBC>
 __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (&cx)[2], const double (&cy)[2], const double (&cz)[2],
                                           const double* __restrict__ at_xyz, const double* __restrict__ acoef, const double* __restrict__ aq,
                                           const double* __restrict__ jt, int e, double px, double py, double pz, ResJ& j) {
@@ -247,7 +262,9 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
 #pragma unroll
     for (int q = 0; q < 2; ++q) {  // partner slot q: spin q
       const int jj = (q ? S.nup : 0) + r;
-      res_pair_m<false>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, px - cx[q], py - cy[q], pz - cz[q], S.rcut_b, irb, Db,
+      double dx = px - cx[q], dy = py - cy[q], dz = pz - cz[q];
+      if (PBC) min_image_j(S, dx, dy, dz);  // (distance.py:83-159; inside the cut-off the folded vector where the cell allows)
+      res_pair_m<false>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, dx, dy, dz, S.rcut_b, irb, Db,
                         jt + (se + q) * PQA_JQ, bcp, bca, jt[3 * PQA_JQ + 10 + se + q], j);
     }
   }
@@ -260,7 +277,9 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
     for (int i = 0; i < 5; ++i) Da[i] = jt[3 * PQA_JQ + 5 + i];
     for (int q = 0; q < (S.natom > 32 ? 2 : 1); ++q) {
       const int I = r + 32 * q, Ic = I < S.natom ? I : 0;
-      res_pair_m<false>(S.na > 0 && I < S.natom, px - at_xyz[3 * Ic], py - at_xyz[3 * Ic + 1], pz - at_xyz[3 * Ic + 2], S.rcut_a, ira, Da,
+      double dx = px - at_xyz[3 * Ic], dy = py - at_xyz[3 * Ic + 1], dz = pz - at_xyz[3 * Ic + 2];
+      if (PBC) min_image_j(S, dx, dy, dz);
+      res_pair_m<false>(S.na > 0 && I < S.natom, dx, dy, dz, S.rcut_a, ira, Da,
                         aq + (size_t)(Ic * 2 + se) * PQA_JQ, acp, aca, acusp ? acoef[(Ic * S.na) * 2 + se] : 0.0, j);
     }
   }
@@ -281,6 +300,36 @@ __device__ __forceinline__ void res_combine(const double* __restrict__ pb, int P
   }
 }
 
+// Candidate images of a (point, atom) pair that are worth a distance test (k_pbc_prepass, step 1): the candidates near the sub-cell of
+// the folded displacement (near_masks) that the reference's membership rule admits (member_masks).  false: no mask table for this
+// handle / atom — test every candidate directly (shell_eval_pbc's list-less path).
+__device__ __forceinline__ bool res_image_masks(const SysDev& S, const PbcCtx& c, int a, unsigned long long& m0, unsigned long long& m1) {
+  const int nimg = S.pb->num_Ls[a];
+  const bool has_member = S.pb->member != nullptr;
+  if (nimg > 128 || (has_member && !S.pb->memb_mask)) return false;
+  m0 = nimg >= 64 ? ~0ull : (1ull << nimg) - 1ull;
+  m1 = nimg <= 64 ? 0ull : (nimg >= 128 ? ~0ull : (1ull << (nimg - 64)) - 1ull);
+  if (S.pb->near_mask) {
+    const int G = S.pb->near_G;
+    const double u0 = c.x0 * S.pb->linv[0] + c.y0 * S.pb->linv[3] + c.z0 * S.pb->linv[6];
+    const double u1 = c.x0 * S.pb->linv[1] + c.y0 * S.pb->linv[4] + c.z0 * S.pb->linv[7];
+    const double u2 = c.x0 * S.pb->linv[2] + c.y0 * S.pb->linv[5] + c.z0 * S.pb->linv[8];
+    const int g0 = min(G - 1, max(0, (int)((u0 + 0.5) * G))), g1 = min(G - 1, max(0, (int)((u1 + 0.5) * G))),
+              g2 = min(G - 1, max(0, (int)((u2 + 0.5) * G)));
+    const unsigned long long* nm = S.pb->near_mask + 2 * ((((size_t)a * G + g0) * G + g1) * G + g2);
+    m0 &= nm[0]; m1 &= nm[1];
+  }
+  if (has_member) {
+    const int side = 2 * S.pb->member_M + 1, E = S.pb->memb_E, Tm = side + 2 * E;
+    const int i0 = c.b0 + E, i1 = c.b1 + E, i2 = c.b2 + E;
+    if ((unsigned)i0 < (unsigned)Tm && (unsigned)i1 < (unsigned)Tm && (unsigned)i2 < (unsigned)Tm) {
+      const unsigned long long* mm = S.pb->memb_mask + 2 * ((((size_t)S.pb->member_class[a] * Tm + i0) * Tm + i1) * Tm + i2);
+      m0 &= mm[0]; m1 &= mm[1];
+    } else { m0 = 0ull; m1 = 0ull; }
+  }
+  return true;
+}
+
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
 static __device__ unsigned long long pqa_res_clk[64 * 16];
 #define PQA_RCLK(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -296,7 +345,7 @@ static __device__ unsigned long long pqa_res_clk[64 * 16];
 #ifndef PQA_RES_LB
 #define PQA_RES_LB PQA_RES_NT
 #endif
-template <bool DMC, int LMAX>
+template <bool DMC, int LMAX, bool PBC = false>
 static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwState L, MoveBuf mb, ChunkTab T, ResTab RT, int has_jastrow,
                                                                   long W, long w_lo, long w_hi) {
   extern __shared__ double lds[];
@@ -308,19 +357,24 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   double* region = lds;
   double* rowE = region + RT.region;           // [16][32] inverse row of the electron being moved
   double* wsc = rowE + 16 * 32;                // [16][16] per walker: 0..2 proposal, 3..5 scaled gaussians, 6..8 drift, 9 U at the old position,
-                                               // 10..12 determinant sign / log / running |ratio| product, 13..14 r^2 sums (DMC), 15 accepted moves
-  double* sh_xyz = wsc + 16 * 16;
+                                               // 10..12 determinant sign / log / running |ratio| product, 13..14 r^2 sums (DMC), 15 accepted moves, 16..18 cells the
+                                               // folded proposal crossed (periodic)
+  double* sh_xyz = wsc + 16 * PQA_RES_WS;
   double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
   double* pr_coef = pr_exp + S.nprim;
   double* at_xyz = pr_coef + S.nprim;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
   double* aql = acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1);          // merged Pade numerators per (ion, spin)
   double* jt = aql + 2 * (size_t)S.natom * PQA_JQ;                             // electron-electron Jastrow tables (res_jas_m)
-  int* sh_meta = (int*)(jt + PQA_RES_JT);  // l, primitives, first primitive, padded row
-  int* glist = sh_meta + 4 * (size_t)S.nshell;
+  int* sh_meta = (int*)(jt + PQA_RES_JT);  // l, primitives, first primitive, padded row, atom
+  int* glist = sh_meta + 5 * (size_t)S.nshell;
   int* goff = glist + RT.nlist;
   int* occ = goff + RT.npass * 32 + 1;
-  double* ws = wsc + wl * 16;
+  // periodic: behind everything else (res_lds_pbc; 8-byte aligned: the int block above holds an even number of entries or is padded by the host)
+  double* LsL = lds + (RT.pbc_off >> 3);
+  unsigned char* imgl = reinterpret_cast<unsigned char*>(LsL + 3 * (PBC ? S.nL : 0));
+  unsigned char* imgn = imgl + (size_t)S.natom * 16 * RT.icap;
+  double* ws = wsc + wl * PQA_RES_WS;
 
   const long wraw = w_lo + (long)blockIdx.x * PQA_RES_NW + wl;
   const bool live = wraw < w_hi;
@@ -330,10 +384,11 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   for (int sh = tid; sh < S.nshell; sh += PQA_RES_NT) {
     const int ia = S.shell_atom[sh];
     sh_xyz[3 * sh] = S.atom_xyz[3 * ia]; sh_xyz[3 * sh + 1] = S.atom_xyz[3 * ia + 1]; sh_xyz[3 * sh + 2] = S.atom_xyz[3 * ia + 2];
-    sh_meta[4 * sh] = S.shell_l[sh];
-    sh_meta[4 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
-    sh_meta[4 * sh + 2] = S.shell_prim_off[sh];
-    sh_meta[4 * sh + 3] = RT.shell_row[sh];
+    sh_meta[5 * sh] = S.shell_l[sh];
+    sh_meta[5 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
+    sh_meta[5 * sh + 2] = S.shell_prim_off[sh];
+    sh_meta[5 * sh + 3] = RT.shell_row[sh];
+    sh_meta[5 * sh + 4] = ia;
   }
   for (int p = tid; p < S.nprim; p += PQA_RES_NT) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
@@ -359,6 +414,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     const int s = k >> 5, q = k & 31, n = s ? S.ndn : S.nup;
     occ[k] = q < n ? (s ? S.det_occ[1][q] : S.det_occ[0][q]) : 0;
   }
+  if (PBC) for (int k = tid; k < 3 * S.nL; k += PQA_RES_NT) LsL[k] = S.pb->Ls[k];
   for (int k = tid; k < RT.region; k += PQA_RES_NT) region[k] = 0.0;  // (K-padding rows of the tile stay finite)
   double cx[2], cy[2], cz[2];
 #pragma unroll
@@ -416,7 +472,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       const long wraw = w_lo + (long)blockIdx.x * PQA_RES_NW + wl;
       const bool live = wraw < w_hi;
       const long wg = live ? wraw : w_hi - 1;
-      double* ws = wsc + wl * 16;
+      double* ws = wsc + wl * PQA_RES_WS;
       double* rn = part + (size_t)KW * 16 * PS + (size_t)wl * PQA_RES_RS;
       const int oc = occs[r];
       double ro[4] = {0.0, 0.0, 0.0, 0.0}, uacc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
@@ -442,15 +498,170 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         // loop-invariant address values out of the electron loop — it did, and spilled them and a third of the inverse row)
         int kwv = kw, ktv = KT;
         asm volatile("" : "+s"(kwv), "+s"(ktv));
+        if (PBC) {
+          // ---- images of every (point, atom) pair the reference's rule admits inside the atom's cut-off (numba/pbcgto.py:565-604; the
+          // work of k_pbc_prepass, in the block): candidates from the pre-tabulated near / membership masks, a distance test each,
+          // indices into the pair's LDS list.  Pairs the lists cannot hold (no mask table, more images than a list holds) are flagged 255 and
+          // take the direct tests of shell_eval_pbc; 254: the list is too short, the pair's shells walk the candidate masks themselves.
+          const double ppx = wsc[pl * PQA_RES_WS], ppy = wsc[pl * PQA_RES_WS + 1], ppz = wsc[pl * PQA_RES_WS + 2];
+          const PrimWrap pw0 = prim_wrap(S, ppx, ppy, ppz);
+          for (int a = grp; a < S.natom; a += 32) {
+            PbcCtx c;
+            pbc_ctx_base(S, c, a, ppx - at_xyz[3 * a], ppy - at_xyz[3 * a + 1], ppz - at_xyz[3 * a + 2], pw0);
+            int n = 0;
+            unsigned long long m0 = 0ull, m1 = 0ull;
+            const int ncl = S.pb->ncls[a];
+            bool over = !res_image_masks(S, c, a, m0, m1) || ncl <= 0 || ncl > 8;
+            if (!over) {
+              // Every admitted image gets the class of the smallest shell cut-off of this atom that contains it (at most 8 distinct
+              // cut-offs here) and the list is written class by class — a counting sort in two walks over the candidate bits — so that a
+              // shell's walk ends at the first image outside ITS cut-off: the lanes of a wave run the union of their walks, and unsorted
+              // lists made every shell walk every image of the atom (158 us per move instead of ~15).
+              double cut_r[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) cut_r[q] = q < ncl ? S.pb->cls_cut[a * PQA_MAXCLS + q] : INFINITY;
+              const double acut = S.pb->atom_cut[a];
+              unsigned long long cnt = 0ull;  // eight 6-bit class populations
+#pragma unroll 1
+              for (int half = 0; half < 2; ++half) {
+                unsigned long long m = half ? m1 : m0, keep = 0ull;
+                while (m) {
+                  const int b = __ffsll((long long)m) - 1, j = 64 * half + b;
+                  m &= m - 1;
+                  const double xj = c.x0 - LsL[3 * j], yj = c.y0 - LsL[3 * j + 1], zj = c.z0 - LsL[3 * j + 2];
+                  const double r2 = xj * xj + yj * yj + zj * zj;
+                  int cls = 0;
+#pragma unroll
+                  for (int q = 0; q < 8; ++q) cls += r2 > cut_r[q] ? 1 : 0;
+                  if (r2 > acut || cls >= ncl) continue;
+                  cnt += 1ull << (6 * cls);
+                  keep |= 1ull << b;
+                  ++n;
+                }
+                if (half) m1 = keep; else m0 = keep;  // (the second walk visits the admitted ones only)
+              }
+              if (n > RT.icap) n = 254;  // more than the list holds: the shells of this pair walk the candidate masks themselves
+              else {
+                unsigned long long off = 0ull;
+                int run = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { off |= (unsigned long long)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63); }
+                unsigned char* lst = imgl + ((size_t)a * 16 + pl) * RT.icap;
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                  unsigned long long m = half ? m1 : m0;
+                  while (m) {
+                    const int j = 64 * half + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double xj = c.x0 - LsL[3 * j], yj = c.y0 - LsL[3 * j + 1], zj = c.z0 - LsL[3 * j + 2];
+                    const double r2 = xj * xj + yj * yj + zj * zj;
+                    int cls = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) cls += r2 > cut_r[q] ? 1 : 0;
+                    const int pos = (int)((off >> (6 * cls)) & 63);
+                    off += 1ull << (6 * cls);
+                    lst[pos] = (unsigned char)j;
+                  }
+                }
+              }
+            }
+            imgn[a * 16 + pl] = over ? (unsigned char)255 : (unsigned char)n;
+          }
+          res_block_sync();
+          PQA_RCLK(14);
+#ifdef PQA_RES_CLK
+          if (blockIdx.x < 64 && threadIdx.x == 0) { int c255 = 0, tot = 0; for (int q = 0; q < S.natom * 16; ++q) { c255 += imgn[q] == 255; tot += imgn[q] == 255 ? 0 : imgn[q]; } pqa_res_clk[blockIdx.x * 16 + 15] = ((unsigned long long)c255 << 32) | (unsigned)tot; }
+#endif
+        }
         for (int ps = 0; ps < RT.npass; ++ps) {
           const int row_base = RT.pass_row0[ps], nks = (RT.pass_row0[ps + 1] - row_base) >> 2;
           if (ps > 0) res_block_sync();  // the previous pass's MFMA reads of the tile are done
           {
-            const double px = wsc[pl * 16], py = wsc[pl * 16 + 1], pz = wsc[pl * 16 + 2];
+            const double px = wsc[pl * PQA_RES_WS], py = wsc[pl * PQA_RES_WS + 1], pz = wsc[pl * PQA_RES_WS + 2];
 #ifndef PQA_RES_ABL_NOAO
+            PbcCtx ctx;
+            const PrimWrap pw = PBC ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};  // (the proposals in wsc are inside the cell)
             for (int it = goff[ps * 32 + grp]; it < goff[ps * 32 + grp + 1]; ++it) {
               const int sh = glist[it];
-              const int l_ = sh_meta[4 * sh], np_ = sh_meta[4 * sh + 1], q0 = sh_meta[4 * sh + 2], krow = sh_meta[4 * sh + 3] - row_base;
+              const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], krow = sh_meta[5 * sh + 3] - row_base;
+              if (PBC) {
+                // lattice sum over the admitted images inside this shell's cut-off (numba/pbcgto.py:99-506): the tile element belongs
+                // to this thread, the sum accumulates in place
+                const int a_ = sh_meta[5 * sh + 4], nim = imgn[a_ * 16 + pl];
+                if (nim != 255) {
+                  double* tl = region + (size_t)krow * 16 + pl;
+                  auto add_image = [&](double xj, double yj, double zj) {
+#if defined(PQA_RES_ABL_PBC) && PQA_RES_ABL_PBC == 1
+                    if (xj != 1.2345e300) return;
+#endif
+                    shell_eval<5, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
+                                              [&](int m, double v, double ax, double ay, double az, double lp) {
+                                                double* t_ = tl + (size_t)m * 16;
+                                                t_[0] += v; t_[(size_t)KT * 16] += ax; t_[(size_t)2 * KT * 16] += ay; t_[(size_t)3 * KT * 16] += az;
+                                                t_[(size_t)4 * KT * 16] += lp;
+                                              });
+                  };
+#pragma unroll
+                  for (int m = 0; m < 2 * LMAX + 1; ++m)
+                    if (m < 2 * l_ + 1) {
+                      tl[(size_t)m * 16] = 0.0; tl[((size_t)KT + m) * 16] = 0.0; tl[((size_t)2 * KT + m) * 16] = 0.0; tl[((size_t)3 * KT + m) * 16] = 0.0;
+                      tl[((size_t)4 * KT + m) * 16] = 0.0;
+                    }
+                  // point - atom folded into the cell-centred parallelepiped (pbc_ctx_base)
+                  const double x = px - sh_xyz[3 * sh], y = py - sh_xyz[3 * sh + 1], z = pz - sh_xyz[3 * sh + 2];
+                  const double f0 = floor(x * S.pb->linv[0] + y * S.pb->linv[3] + z * S.pb->linv[6] + 0.5);
+                  const double f1 = floor(x * S.pb->linv[1] + y * S.pb->linv[4] + z * S.pb->linv[7] + 0.5);
+                  const double f2 = floor(x * S.pb->linv[2] + y * S.pb->linv[5] + z * S.pb->linv[8] + 0.5);
+                  const double x0 = x - (f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6]);
+                  const double y0 = y - (f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7]);
+                  const double z0 = z - (f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8]);
+                  const double scut = S.pb->shell_cut[sh];
+                  const unsigned char* lst = imgl + ((size_t)a_ * 16 + pl) * RT.icap;
+                  if (nim == 254) {  // (rare: same images in index order, found again from the masks)
+                    PbcCtx c2;
+                    pbc_ctx_base(S, c2, a_, x, y, z, pw);
+                    unsigned long long m0 = 0ull, m1 = 0ull;
+                    res_image_masks(S, c2, a_, m0, m1);
+                    const double cut2 = fmin(scut, S.pb->atom_cut[a_]);
+#pragma unroll 1
+                    for (int half = 0; half < 2; ++half) {
+                      unsigned long long m = half ? m1 : m0;
+                      while (m) {
+                        const int j = 64 * half + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
+                        if (xj * xj + yj * yj + zj * zj <= cut2) add_image(xj, yj, zj);
+                      }
+                    }
+                    continue;
+                  }
+#if defined(PQA_RES_ABL_PBC) && PQA_RES_ABL_PBC == 2
+                  if (x0 != 1.2345e300) continue;
+#endif
+#pragma unroll 1
+                  for (int k = 0; k < nim; ++k) {
+                    const int j = lst[k];
+                    const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
+                    if (xj * xj + yj * yj + zj * zj > scut) break;  // (class-ordered list: nothing further is inside this shell's cut-off)
+                    add_image(xj, yj, zj);
+                  }
+                  continue;
+                }
+                bool accum = false;
+                ctx.ia = -1;
+                pbc_ctx_update(S, ctx, a_, px - sh_xyz[3 * sh], py - sh_xyz[3 * sh + 1], pz - sh_xyz[3 * sh + 2], pw);
+                shell_eval_pbc<5, LMAX>(S, ctx, sh, l_, pr_exp + q0, pr_coef + q0, np_,
+                                        [&](int m, double v, double ax, double ay, double az, double lp) {
+                                          double* tl = region + (size_t)(krow + m) * 16 + pl;
+                                          if (accum) {
+                                            tl[0] += v; tl[(size_t)KT * 16] += ax; tl[(size_t)2 * KT * 16] += ay; tl[(size_t)3 * KT * 16] += az;
+                                            tl[(size_t)4 * KT * 16] += lp;
+                                          } else {
+                                            tl[0] = v; tl[(size_t)KT * 16] = ax; tl[(size_t)2 * KT * 16] = ay; tl[(size_t)3 * KT * 16] = az;
+                                            tl[(size_t)4 * KT * 16] = lp;
+                                          }
+                                        }, accum);
+              } else
               shell_eval<5, LMAX>(l_, px - sh_xyz[3 * sh], py - sh_xyz[3 * sh + 1], pz - sh_xyz[3 * sh + 2], pr_exp + q0, pr_coef + q0, np_,
                                   [&](int m, double v, double ax, double ay, double az, double lp) {
                                     double* tl = region + (size_t)(krow + m) * 16 + pl;
@@ -543,10 +754,10 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jn{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, e, npx, npy, npz, jn);
+          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, e, npx, npy, npz, jn);
           else {
             double g3[3];
-            res_jas_part(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, aql, jn.u, g3);
+            res_jas_part<PBC>(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, aql, jn.u, g3);
             jn.x = g3[0]; jn.y = g3[1]; jn.z = g3[2];
           }
           jn.u = res_sum32(jn.u); jn.x = res_sum32(jn.x); jn.y = res_sum32(jn.y); jn.z = res_sum32(jn.z);
@@ -628,6 +839,10 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           }
           if (r == i) {
             if (s) { cx[1] = npx; cy[1] = npy; cz[1] = npz; } else { cx[0] = npx; cy[0] = npy; cz[0] = npz; }
+            if (PBC && live && mb.wrap) {  // PeriodicConfigs.move: the electron's wrap counters follow (coord.py:180-189)
+              int* wp = mb.wrap + ((size_t)wg * S.nelec + e) * 3;
+              wp[0] += (int)ws[16]; wp[1] += (int)ws[17]; wp[2] += (int)ws[18];
+            }
           }
           // the proposal's rows become the cached rows of electron i: into the walker's other slot, selector flipped
           const int cur = __shfl(selr, (lane & 32) | i, 64);
@@ -664,10 +879,10 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jo{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, ep, pox, poy, poz, jo);
+          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, ep, pox, poy, poz, jo);
           else {
             double g3[3];
-            res_jas_part(S, ep, r, pox, poy, poz, cx, cy, cz, at_xyz, acoef, aql, jo.u, g3);
+            res_jas_part<PBC>(S, ep, r, pox, poy, poz, cx, cy, cz, at_xyz, acoef, aql, jo.u, g3);
             jo.x = g3[0]; jo.y = g3[1]; jo.z = g3[2];
           }
           jo.u = res_sum32(jo.u); jo.x = res_sum32(jo.x); jo.y = res_sum32(jo.y); jo.z = res_sum32(jo.z);
@@ -679,7 +894,13 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         const double sq = jt[3 * PQA_JQ + 15], df = DMC ? 1.0 : mb.tstep;
         const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
         if (r == 0) {
-          ws[0] = pox + z0 + gx * df; ws[1] = poy + z1 + gy * df; ws[2] = poz + z2 + gz * df;
+          double nx = pox + z0 + gx * df, ny = poy + z1 + gy * df, nz = poz + z2 + gz * df;
+          if (PBC) {  // make_irreducible (mc.py:121, coord.py:164-178): the proposal inside the cell, the cells it crossed kept for the accept
+            int dw[3];
+            fold_cell(S, nx, ny, nz, dw);
+            ws[16] = dw[0]; ws[17] = dw[1]; ws[18] = dw[2];
+          }
+          ws[0] = nx; ws[1] = ny; ws[2] = nz;
           ws[3] = z0; ws[4] = z1; ws[5] = z2; ws[6] = gx; ws[7] = gy; ws[8] = gz; ws[9] = U0;
         }
         res_wave_sync();

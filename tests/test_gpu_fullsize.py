@@ -477,14 +477,16 @@ def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
             assert note(f"{cfg}_{W}_pre_vs_general_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-11
 
 
-@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C2", 530)])
+@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C2", 530), ("C5", 1000)])
 def test_resident_sweep_against_the_launch_per_move_sweep(cfg, W, monkeypatch):
     """The resident sweep (k_sweep_res: the whole electron sweep of 16 walkers in one block — inverse rows in registers, AO tile +
     MFMA contraction + decision + Sherman-Morrison on chip, one launch per sweep) against the launch-per-move sweep (k_orb +
     k_step_lw / k_step_pre per move): the same Philox streams, sums in a different order.  Every Metropolis decision equal, walkers,
     log-values and energies equal to rounding, the updated state equal to a fresh recompute; W = 1000 leaves a partly filled block
     and 530 walkers of the 8-electron molecule exercise one orbital tile per spin (8-way K split) and idle lanes.  Open-system DMC
-    steps (drift limiter, fixed-node rejection, r^2 sums, T-moves between the sweeps) go through the same kernel in DMC mode."""
+    steps (drift limiter, fixed-node rejection, r^2 sums, T-moves between the sweeps) go through the same kernel in DMC mode.
+    C5: the periodic instantiation (lattice-summed AOs by direct image tests, minimal-image Jastrow pairs, folded proposals and the
+    wrap counters) on the 2x2x2 diamond cell."""
     import pyqmc_amd as pa
 
     outs = []
