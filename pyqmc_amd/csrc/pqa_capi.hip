@@ -540,6 +540,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
         TRY(upload_table(h, cc.data(), cc.size(), &tmp_d)); P.cls_cut = tmp_d;
         TRY(upload_table(h, nc.data(), nc.size(), &tmp_i)); P.ncls = tmp_i;
         h->pbc_maxcls = *std::max_element(nc.begin(), nc.end());
+        h->pbc_mincls = *std::min_element(nc.begin(), nc.end());
         if (const char* e = getenv("PQA_PRE_NCUT")) h->pbc_maxcls = std::max(h->pbc_maxcls, atoi(e));  // (tests: the ten-class instantiation)
       }
       {  // capacity of the per-(atom, point) image lists: the lattice points inside a sphere of the largest atom cut-off number
@@ -678,6 +679,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   for (int k = 0; k < h->na; ++k) { S.a_kind[k] = sys->a_kind[k]; S.a_param[k] = sys->a_param[k]; S.a_aux[k] = 1.0 / (3.0 + sys->a_param[k]); }
   for (int k = 0; k < h->nb; ++k) { S.b_kind[k] = sys->b_kind[k]; S.b_param[k] = sys->b_param[k]; S.b_aux[k] = 1.0 / (3.0 + sys->b_param[k]); }
   if (S.pbc) {  // all periodic tables sit behind one pointer (see SysDev)
+    // (the resident sweep's in-block image lists need the mask tables, at most 128 candidates and a handful of shell cut-offs per atom)
+    h->pbc_lists_ok = sys->nL > 0 && sys->nL <= 128 && (P.member == nullptr || P.memb_mask != nullptr) && h->pbc_mincls >= 1 && h->pbc_maxcls <= PQA_RES_NCUT;
     PbcDev* dp;
     TRY(upload_table(h, &P, (size_t)1, &dp));
     S.pb = dp;

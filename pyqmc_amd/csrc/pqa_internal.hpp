@@ -176,6 +176,8 @@ struct pqa_handle {
   ResTab res_tab{};
   size_t res_lds = 0;
   int res_lmax = 0;
+  int pbc_mincls = 0;
+  bool pbc_lists_ok = false;
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
   // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples

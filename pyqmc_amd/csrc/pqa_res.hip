@@ -22,7 +22,7 @@ static int res_setup(pqa_handle* h) {
   h->res_ok = false;
   if (h->res_mode == 0) return 0;
   if (!h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->twist) return 0;
-  if (h->S.pbc && (h->S.nL <= 0 || h->pbc_high_l || h->res_pbc == 0)) return 0;  // periodic: lattice-summed orbitals, l <= 3 (PQA_RES_PBC=0 keeps the launches)
+  if (h->S.pbc && (h->S.nL <= 0 || h->pbc_high_l || h->res_pbc == 0 || !h->pbc_lists_ok)) return 0;  // periodic: lattice-summed orbitals, l <= 3 (PQA_RES_PBC=0 keeps the launches)
   if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32 || h->N > 64 || h->N < 1 || h->natom > 64) return 0;
   int lmax = 0;
   for (int l : h->shell_l) lmax = std::max(lmax, l);
@@ -31,6 +31,26 @@ static int res_setup(pqa_handle* h) {
   const ChunkHost& c = h->chunks[0];
   const int nch = (int)c.nk.size();
   if (nch == 0) return 0;
+  // primitives: shells with the same (exponent, coefficient) sequence — the same shell of every atom of a species — share one LDS copy
+  std::vector<double> pe_u, pc_u;
+  std::vector<int> q0_u((size_t)h->nshell, 0);
+  {
+    std::vector<double> pe((size_t)h->S.nprim), pc((size_t)h->S.nprim);
+    std::vector<int> po((size_t)h->nshell + 1);
+    HIPCHK(hipMemcpy(pe.data(), h->S.prim_exp, pe.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pc.data(), h->S.prim_coef, pc.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(po.data(), h->S.shell_prim_off, po.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int sh = 0; sh < h->nshell; ++sh) {
+      const int n = po[sh + 1] - po[sh];
+      int found = -1;
+      for (int prev = 0; prev < sh && found < 0; ++prev)
+        if (po[prev + 1] - po[prev] == n && std::equal(pe.begin() + po[sh], pe.begin() + po[sh + 1], pe.begin() + po[prev]) &&
+            std::equal(pc.begin() + po[sh], pc.begin() + po[sh + 1], pc.begin() + po[prev])) found = q0_u[prev];
+      if (found < 0) { found = (int)pe_u.size(); pe_u.insert(pe_u.end(), pe.begin() + po[sh], pe.begin() + po[sh + 1]); pc_u.insert(pc_u.end(), pc.begin() + po[sh], pc.begin() + po[sh + 1]); }
+      q0_u[sh] = found;
+    }
+  }
+  const int nprim_u = (int)pe_u.size();
   int rows_cap = 1 << 30;
   size_t part_rn = 0;
   for (int s = 0; s < 2; ++s) {
@@ -40,18 +60,22 @@ static int res_setup(pqa_handle* h) {
     rows_cap = std::min(rows_cap, 4 * PQA_RES_MAXKS * (8 / nt));
     part_rn = std::max(part_rn, (size_t)(8 / nt) * 16 * res_ps(nt) + (size_t)16 * PQA_RES_RS);
   }
-  // periodic: the image lists take what is left beside a one-pass tile — 32, 24, 16 or 12 entries per (point, atom)
+  // periodic: the image lists take what is left beside a one-pass tile — up to 32 entries per (point, atom), at least 10
   int icap = 0;
   size_t pbc_b = 0;
+  auto pick_icap = [&](size_t rest) {  // largest capacity whose lists fit `rest` bytes (0: none)
+    for (int cand = 32; cand >= 10; --cand)
+      if (res_lds_pbc(h->natom, h->S.nL, cand, h->nshell) + 8 <= rest) return cand;
+    return 0;
+  };
   if (h->S.pbc) {
-    const size_t f0 = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS);
-    for (int cand : {32, 24, 16, 12}) {
-      icap = cand;
-      pbc_b = res_lds_pbc(h->natom, h->S.nL, icap) + 8;
-      if (f0 + pbc_b + (size_t)80 * c.rows_pad * sizeof(double) <= (size_t)160 * 1024 - 256) break;
-    }
+    const size_t f0 = res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, h->nshell, PQA_RES_MAXPASS);
+    const size_t tile = (size_t)80 * c.rows_pad * sizeof(double), budget0 = (size_t)160 * 1024 - 256;
+    icap = f0 + tile < budget0 ? pick_icap(budget0 - f0 - tile) : 0;
+    if (icap == 0) icap = 10;
+    pbc_b = res_lds_pbc(h->natom, h->S.nL, icap, h->nshell) + 8;
   }
-  const size_t fixed = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, PQA_RES_MAXPASS) + pbc_b;
+  const size_t fixed = res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, h->nshell, PQA_RES_MAXPASS) + pbc_b;
   const size_t budget = 160 * 1024 - 256;
   if (fixed + part_rn * sizeof(double) > budget) return 0;
   const size_t avail = (budget - fixed) / sizeof(double);
@@ -61,13 +85,14 @@ static int res_setup(pqa_handle* h) {
   // dense mode: the chunk padding (16-row chunks: 224 rows for the 208 AOs of the 2x2x2 diamond cell) is what keeps the basis out of one
   // tile, and the AOs in their own order (padded to x4) fit
   const int rows4 = (h->nao + 3) & ~3;
-  const size_t fixed1 = res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, h->nshell, 1);
+  const size_t fixed1 = res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, h->nshell, 1);
   bool dense = false;
   if (!one && rows4 <= rows_cap) {
-    for (int cand : {32, 24, 16, 12}) {
-      const size_t pb = h->S.pbc ? res_lds_pbc(h->natom, h->S.nL, cand) + 8 : 0;
-      if (fixed1 + pb + std::max((size_t)80 * rows4, part_rn) * sizeof(double) + 8 <= budget) { dense = true; icap = cand; pbc_b = pb; break; }
-      if (!h->S.pbc) break;
+    const size_t tile = std::max((size_t)80 * rows4, part_rn) * sizeof(double) + 8;
+    if (!h->S.pbc) dense = fixed1 + tile <= budget;
+    else if (fixed1 + tile < budget) {
+      const int cand = pick_icap(budget - fixed1 - tile);
+      if (cand > 0) { dense = true; icap = cand; pbc_b = res_lds_pbc(h->natom, h->S.nL, cand, h->nshell) + 8; }
     }
   }
   const int kt_cap = (one || dense) ? (dense ? rows4 : rows_all) : std::min(rows_cap, (int)(((avail - part_rn) / 80) & ~(size_t)3));
@@ -132,7 +157,12 @@ static int res_setup(pqa_handle* h) {
   TRY(upload_table(h, off.data(), off.size(), &tmp_i)); RT.grp_off = tmp_i;
   TRY(upload_table(h, list.data(), list.size(), &tmp_i)); RT.grp_shell = tmp_i;
   TRY(upload_table(h, srow.data(), srow.size(), &tmp_i)); RT.shell_row = tmp_i;
-  h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, (int)h->S.nprim, h->natom, h->na, RT.nlist, RT.npass);
+  TRY(upload_table(h, q0_u.data(), q0_u.size(), &tmp_i)); RT.shell_q0 = tmp_i;
+  double* tmp_d = nullptr;
+  TRY(upload_table(h, pe_u.data(), pe_u.size(), &tmp_d)); RT.prim_exp_u = tmp_d;
+  TRY(upload_table(h, pc_u.data(), pc_u.size(), &tmp_d)); RT.prim_coef_u = tmp_d;
+  RT.nprim_u = nprim_u;
+  h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, RT.nlist, RT.npass);
   h->res_lds = (h->res_lds + 7) & ~(size_t)7;
   RT.pbc_off = (int)h->res_lds; RT.icap = icap;
   h->res_lds += pbc_b;

@@ -50,6 +50,10 @@ struct ResTab {
   int nlist;                               // entries of grp_shell
   int region;                              // doubles of the tile / partial-sum / orbital-row region
   int part_off;                            // offset of the K-partials in the region: 0 (one pass: they reuse the tile) or 80 kt
+  int nprim_u;                             // distinct primitives: shells with the same (exponent, coefficient) sequence share one copy in LDS
+  const double* prim_exp_u;                // [nprim_u]
+  const double* prim_coef_u;
+  const int* shell_q0;                     // [nshell] first primitive of the shell in those tables
   int pbc_off, icap;                       // periodic: byte offset of the lattice vectors / image lists in the dynamic LDS, list capacity
 };
 // doubles per point of a K-partial [5][16 nt] (+ padding: the four point quartets of a wave on different banks)
@@ -57,11 +61,16 @@ __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
 // (ResTab::icap: admitted images per (point, atom) the block's image lists hold — 32, 24, 16 or 12, the most the LDS budget allows with the
 // whole basis in one tile; a pair with more takes the direct tests)
 // periodic instantiation: candidate lattice vectors [nL][3], image lists [natom][16][icap] and their lengths [natom][16]
-__host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap) {
-  return ((size_t)3 * nL) * sizeof(double) + (((size_t)natom * 16 * (icap + 1) + 7) & ~(size_t)7);
+#define PQA_RES_NCUT 6   // distinct shell cut-offs per atom the block's image lists sort by (more: the pair walks the candidate masks)
+// + shell cut-offs [nshell], per atom: cut-off + PQA_RES_NCUT class cut-offs (doubles), candidates / classes / membership class (ints),
+// + the cell (inverse lattice, lattice, inverse primitive lattice: 27 doubles, the two mask-table addresses) and the membership rule's
+// integers (supercell matrix, M, E, G, flags, atom_n[natom][3])
+__host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap, int nshell) {
+  return ((size_t)3 * nL + nshell + (size_t)natom * (1 + PQA_RES_NCUT) + 30) * sizeof(double) + (((size_t)(natom * 6 + 16) * sizeof(int) + 7) & ~(size_t)7) +
+         (((size_t)natom * 16 * (icap + 1) + 7) & ~(size_t)7);
 }
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
-  const size_t d = 16 * 32 + 16 * PQA_RES_WS + 3 * (size_t)nshell + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
+  const size_t d = 16 * 32 + 16 * PQA_RES_WS + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
                    2 * (size_t)natom * PQA_JQ + (3 * PQA_JQ + 24);
   const size_t i = 5 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
   return d * sizeof(double) + i * sizeof(int);
@@ -222,6 +231,18 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
 #ifndef PQA_RES_JCHAIN
 #define PQA_RES_JCHAIN 2
 #endif
+// Minimal image of a Jastrow pair from the block's LDS copy of the cell: where every Jastrow cut-off is at most the inradius of the
+// cell-centred parallelepiped (PbcDev::jas_fold, flag at pbt[29]) the fold IS the minimal image inside the cut-off (min_image_j);
+// otherwise the general reduction on the global tables.
+__device__ __forceinline__ void res_min_image(const SysDev& S, const double* __restrict__ pbt, double& dx, double& dy, double& dz) {
+  if (pbt[29] != 0.0) {
+    double f0 = dx * pbt[0] + dy * pbt[3] + dz * pbt[6], f1 = dx * pbt[1] + dy * pbt[4] + dz * pbt[7], f2 = dx * pbt[2] + dy * pbt[5] + dz * pbt[8];
+    f0 -= floor(f0 + 0.5); f1 -= floor(f1 + 0.5); f2 -= floor(f2 + 0.5);
+    dx = f0 * pbt[9] + f1 * pbt[12] + f2 * pbt[15];
+    dy = f0 * pbt[10] + f1 * pbt[13] + f2 * pbt[16];
+    dz = f0 * pbt[11] + f1 * pbt[14] + f2 * pbt[17];
+  } else min_image_j(S, dx, dy, dz);
+}
 struct ResJ { double u, x, y, z; };
 template <bool UNI>
 __device__ __forceinline__ void res_pair_m(bool valid, double dx, double dy, double dz, double rcut, double ircut, const double (&D)[5],
@@ -250,7 +271,8 @@ __device__ __forceinline__ void res_pair_m(bool valid, double dx, double dy, dou
 template <bool PBC>
 __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (&cx)[2], const double (&cy)[2], const double (&cz)[2],
                                           const double* __restrict__ at_xyz, const double* __restrict__ acoef, const double* __restrict__ aq,
-                                          const double* __restrict__ jt, int e, double px, double py, double pz, ResJ& j) {
+                                          const double* __restrict__ jt, int e, double px, double py, double pz, ResJ& j,
+                                          const double* __restrict__ pbt = nullptr) {
   const int se = e >= S.nup;
   const double irb = jt[3 * PQA_JQ + 13], ira = jt[3 * PQA_JQ + 14];  // (loop-invariant VALU results would be hoisted and spilled)
   const bool bcusp = S.nb > 0 && S.b_kind[0] == 1, acusp = S.na > 0 && S.a_kind[0] == 1;
@@ -263,7 +285,7 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
     for (int q = 0; q < 2; ++q) {  // partner slot q: spin q
       const int jj = (q ? S.nup : 0) + r;
       double dx = px - cx[q], dy = py - cy[q], dz = pz - cz[q];
-      if (PBC) min_image_j(S, dx, dy, dz);  // (distance.py:83-159; inside the cut-off the folded vector where the cell allows)
+      if (PBC) res_min_image(S, pbt, dx, dy, dz);  // (distance.py:83-159; inside the cut-off the folded vector where the cell allows)
       res_pair_m<false>(S.nb > 0 && r < (q ? S.ndn : S.nup) && jj != e, dx, dy, dz, S.rcut_b, irb, Db,
                         jt + (se + q) * PQA_JQ, bcp, bca, jt[3 * PQA_JQ + 10 + se + q], j);
     }
@@ -278,7 +300,7 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
     for (int q = 0; q < (S.natom > 32 ? 2 : 1); ++q) {
       const int I = r + 32 * q, Ic = I < S.natom ? I : 0;
       double dx = px - at_xyz[3 * Ic], dy = py - at_xyz[3 * Ic + 1], dz = pz - at_xyz[3 * Ic + 2];
-      if (PBC) min_image_j(S, dx, dy, dz);
+      if (PBC) res_min_image(S, pbt, dx, dy, dz);
       res_pair_m<false>(S.na > 0 && I < S.natom, dx, dy, dz, S.rcut_a, ira, Da,
                         aq + (size_t)(Ic * 2 + se) * PQA_JQ, acp, aca, acusp ? acoef[(Ic * S.na) * 2 + se] : 0.0, j);
     }
@@ -300,34 +322,61 @@ __device__ __forceinline__ void res_combine(const double* __restrict__ pb, int P
   }
 }
 
-// Candidate images of a (point, atom) pair that are worth a distance test (k_pbc_prepass, step 1): the candidates near the sub-cell of
-// the folded displacement (near_masks) that the reference's membership rule admits (member_masks).  false: no mask table for this
-// handle / atom — test every candidate directly (shell_eval_pbc's list-less path).
-__device__ __forceinline__ bool res_image_masks(const SysDev& S, const PbcCtx& c, int a, unsigned long long& m0, unsigned long long& m1) {
-  const int nimg = S.pb->num_Ls[a];
-  const bool has_member = S.pb->member != nullptr;
-  if (nimg > 128 || (has_member && !S.pb->memb_mask)) return false;
+// The periodic instantiation's view of the cell, from the block's LDS copy (pbt / pbi, see the kernel): fold of point - atom into the
+// cell-centred parallelepiped with the membership base of the pair (pbc_ctx_base + prim_wrap, pqa_ao.hpp), the fold alone, and the
+// candidate images of a (point, atom) pair that are worth a distance test (k_pbc_prepass, step 1: the candidates near the sub-cell of
+// the folded displacement, near_masks, that the reference's membership rule admits, member_masks).  Handles without the mask tables,
+// with more than 128 candidates or more than PQA_RES_NCUT shell cut-offs per atom keep the launch-per-move sweep (pbc_lists_ok).
+__device__ __forceinline__ void res_fold(const double* __restrict__ pbt, double x, double y, double z, double& x0, double& y0, double& z0,
+                                         double& f0, double& f1, double& f2) {
+  f0 = floor(x * pbt[0] + y * pbt[3] + z * pbt[6] + 0.5);
+  f1 = floor(x * pbt[1] + y * pbt[4] + z * pbt[7] + 0.5);
+  f2 = floor(x * pbt[2] + y * pbt[5] + z * pbt[8] + 0.5);
+  x0 = x - (f0 * pbt[9] + f1 * pbt[12] + f2 * pbt[15]);
+  y0 = y - (f0 * pbt[10] + f1 * pbt[13] + f2 * pbt[16]);
+  z0 = z - (f0 * pbt[11] + f1 * pbt[14] + f2 * pbt[17]);
+}
+struct ResPair { double x0, y0, z0; int b0, b1, b2; };
+__device__ __forceinline__ ResPair res_pair_base(const double* __restrict__ pbt, const int* __restrict__ pbi, int a, double px, double py, double pz,
+                                                 double ax, double ay, double az) {
+  ResPair c;
+  double f0, f1, f2;
+  res_fold(pbt, px - ax, py - ay, pz - az, c.x0, c.y0, c.z0, f0, f1, f2);
+  c.b0 = c.b1 = c.b2 = 0;
+  if (pbi[12]) {
+    const int w0 = (int)floor(px * pbt[18] + py * pbt[21] + pz * pbt[24]), w1 = (int)floor(px * pbt[19] + py * pbt[22] + pz * pbt[25]),
+              w2 = (int)floor(px * pbt[20] + py * pbt[23] + pz * pbt[26]);
+    const int i0 = (int)f0, i1 = (int)f1, i2 = (int)f2, M = pbi[9];
+    c.b0 = pbi[14 + 3 * a] + i0 * pbi[0] + i1 * pbi[3] + i2 * pbi[6] - w0 + M;
+    c.b1 = pbi[14 + 3 * a + 1] + i0 * pbi[1] + i1 * pbi[4] + i2 * pbi[7] - w1 + M;
+    c.b2 = pbi[14 + 3 * a + 2] + i0 * pbi[2] + i1 * pbi[5] + i2 * pbi[8] - w2 + M;
+  }
+  return c;
+}
+__device__ __forceinline__ void res_image_masks(const double* __restrict__ pbt, const int* __restrict__ pbi, const ResPair& c, int a, int nimg,
+                                                int mclass, unsigned long long& m0, unsigned long long& m1) {
   m0 = nimg >= 64 ? ~0ull : (1ull << nimg) - 1ull;
   m1 = nimg <= 64 ? 0ull : (nimg >= 128 ? ~0ull : (1ull << (nimg - 64)) - 1ull);
-  if (S.pb->near_mask) {
-    const int G = S.pb->near_G;
-    const double u0 = c.x0 * S.pb->linv[0] + c.y0 * S.pb->linv[3] + c.z0 * S.pb->linv[6];
-    const double u1 = c.x0 * S.pb->linv[1] + c.y0 * S.pb->linv[4] + c.z0 * S.pb->linv[7];
-    const double u2 = c.x0 * S.pb->linv[2] + c.y0 * S.pb->linv[5] + c.z0 * S.pb->linv[8];
+  const unsigned long long* near_mask = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned long long*>(pbt + 27)[0]);
+  const unsigned long long* memb_mask = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned long long*>(pbt + 27)[1]);
+  if (near_mask) {
+    const int G = pbi[11];
+    const double u0 = c.x0 * pbt[0] + c.y0 * pbt[3] + c.z0 * pbt[6];
+    const double u1 = c.x0 * pbt[1] + c.y0 * pbt[4] + c.z0 * pbt[7];
+    const double u2 = c.x0 * pbt[2] + c.y0 * pbt[5] + c.z0 * pbt[8];
     const int g0 = min(G - 1, max(0, (int)((u0 + 0.5) * G))), g1 = min(G - 1, max(0, (int)((u1 + 0.5) * G))),
               g2 = min(G - 1, max(0, (int)((u2 + 0.5) * G)));
-    const unsigned long long* nm = S.pb->near_mask + 2 * ((((size_t)a * G + g0) * G + g1) * G + g2);
+    const unsigned long long* nm = near_mask + 2 * ((((size_t)a * G + g0) * G + g1) * G + g2);
     m0 &= nm[0]; m1 &= nm[1];
   }
-  if (has_member) {
-    const int side = 2 * S.pb->member_M + 1, E = S.pb->memb_E, Tm = side + 2 * E;
+  if (pbi[12]) {
+    const int side = 2 * pbi[9] + 1, E = pbi[10], Tm = side + 2 * E;
     const int i0 = c.b0 + E, i1 = c.b1 + E, i2 = c.b2 + E;
     if ((unsigned)i0 < (unsigned)Tm && (unsigned)i1 < (unsigned)Tm && (unsigned)i2 < (unsigned)Tm) {
-      const unsigned long long* mm = S.pb->memb_mask + 2 * ((((size_t)S.pb->member_class[a] * Tm + i0) * Tm + i1) * Tm + i2);
+      const unsigned long long* mm = memb_mask + 2 * ((((size_t)mclass * Tm + i0) * Tm + i1) * Tm + i2);
       m0 &= mm[0]; m1 &= mm[1];
     } else { m0 = 0ull; m1 = 0ull; }
   }
-  return true;
 }
 
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
@@ -359,10 +408,9 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   double* wsc = rowE + 16 * 32;                // [16][16] per walker: 0..2 proposal, 3..5 scaled gaussians, 6..8 drift, 9 U at the old position,
                                                // 10..12 determinant sign / log / running |ratio| product, 13..14 r^2 sums (DMC), 15 accepted moves, 16..18 cells the
                                                // folded proposal crossed (periodic)
-  double* sh_xyz = wsc + 16 * PQA_RES_WS;
-  double* pr_exp = sh_xyz + 3 * (size_t)S.nshell;
-  double* pr_coef = pr_exp + S.nprim;
-  double* at_xyz = pr_coef + S.nprim;
+  double* pr_exp = wsc + 16 * PQA_RES_WS;      // [RT.nprim_u] distinct primitives (the 16 carbon atoms of a cell share 14, not 224)
+  double* pr_coef = pr_exp + RT.nprim_u;
+  double* at_xyz = pr_coef + RT.nprim_u;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
   double* aql = acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1);          // merged Pade numerators per (ion, spin)
   double* jt = aql + 2 * (size_t)S.natom * PQA_JQ;                             // electron-electron Jastrow tables (res_jas_m)
@@ -372,7 +420,12 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   int* occ = goff + RT.npass * 32 + 1;
   // periodic: behind everything else (res_lds_pbc; 8-byte aligned: the int block above holds an even number of entries or is padded by the host)
   double* LsL = lds + (RT.pbc_off >> 3);
-  unsigned char* imgl = reinterpret_cast<unsigned char*>(LsL + 3 * (PBC ? S.nL : 0));
+  double* sh_cut = LsL + 3 * (PBC ? S.nL : 0);                     // [nshell] shell cut-offs
+  double* at_cut = sh_cut + (PBC ? S.nshell : 0);                  // [natom][1 + PQA_RES_NCUT]: atom cut-off, class cut-offs (ascending)
+  double* pbt = at_cut + (PBC ? S.natom * (1 + PQA_RES_NCUT) : 0);   // [30]: linv, lat, lprim_inv, then the addresses of near_mask / memb_mask
+  int* at_int = reinterpret_cast<int*>(pbt + (PBC ? 30 : 0));        // [natom][3]: candidates, classes, membership class
+  int* pbi = at_int + (PBC ? 3 * S.natom : 0);                       // [14 + 3 natom]: supercell[9], M, E, G, has_member, jas_fold, atom_n
+  unsigned char* imgl = reinterpret_cast<unsigned char*>(pbi + ((PBC ? 3 * S.natom + 16 : 0) & ~1));
   unsigned char* imgn = imgl + (size_t)S.natom * 16 * RT.icap;
   double* ws = wsc + wl * PQA_RES_WS;
 
@@ -383,14 +436,13 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   // ---- tables and the walker's coordinates
   for (int sh = tid; sh < S.nshell; sh += PQA_RES_NT) {
     const int ia = S.shell_atom[sh];
-    sh_xyz[3 * sh] = S.atom_xyz[3 * ia]; sh_xyz[3 * sh + 1] = S.atom_xyz[3 * ia + 1]; sh_xyz[3 * sh + 2] = S.atom_xyz[3 * ia + 2];
     sh_meta[5 * sh] = S.shell_l[sh];
     sh_meta[5 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
-    sh_meta[5 * sh + 2] = S.shell_prim_off[sh];
+    sh_meta[5 * sh + 2] = RT.shell_q0[sh];
     sh_meta[5 * sh + 3] = RT.shell_row[sh];
     sh_meta[5 * sh + 4] = ia;
   }
-  for (int p = tid; p < S.nprim; p += PQA_RES_NT) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
+  for (int p = tid; p < RT.nprim_u; p += PQA_RES_NT) { pr_exp[p] = RT.prim_exp_u[p]; pr_coef[p] = RT.prim_coef_u[p]; }
   for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
   for (int k = tid; k < 2 * S.natom * S.na; k += PQA_RES_NT) acoef[k] = has_jastrow ? S.acoeff[k] : 0.0;
   for (int k = tid; k < 2 * S.natom * PQA_JQ; k += PQA_RES_NT) aql[k] = (has_jastrow && S.jq_on && S.na > 0) ? S.aq[k] : 0.0;
@@ -414,7 +466,27 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     const int s = k >> 5, q = k & 31, n = s ? S.ndn : S.nup;
     occ[k] = q < n ? (s ? S.det_occ[1][q] : S.det_occ[0][q]) : 0;
   }
-  if (PBC) for (int k = tid; k < 3 * S.nL; k += PQA_RES_NT) LsL[k] = S.pb->Ls[k];
+  if (PBC) {  // (no vector load from global memory inside the AO phase: each one waits for everything in flight, and the per-atom /
+              // per-shell table look-ups were dependent round trips — 12 of the phase's 38 us)
+    for (int k = tid; k < 3 * S.nL; k += PQA_RES_NT) LsL[k] = S.pb->Ls[k];
+    for (int k = tid; k < S.nshell; k += PQA_RES_NT) sh_cut[k] = S.pb->shell_cut[k];
+    for (int k = tid; k < S.natom; k += PQA_RES_NT) {
+      const int ncl = S.pb->ncls[k];
+      at_cut[k * (1 + PQA_RES_NCUT)] = S.pb->atom_cut[k];
+      for (int q = 0; q < PQA_RES_NCUT; ++q) at_cut[k * (1 + PQA_RES_NCUT) + 1 + q] = q < ncl ? S.pb->cls_cut[k * PQA_MAXCLS + q] : INFINITY;
+      at_int[3 * k] = S.pb->num_Ls[k]; at_int[3 * k + 1] = ncl; at_int[3 * k + 2] = S.pb->member ? S.pb->member_class[k] : 0;
+      for (int q = 0; q < 3; ++q) pbi[14 + 3 * k + q] = S.pb->member ? S.pb->atom_n[3 * k + q] : 0;
+    }
+    // (a load from S.pb inside the electron loop is a VECTOR load — after the loop's stores the compiler cannot keep it scalar — and
+    // waits for everything in flight: the cell and the membership rule's scalars from LDS instead)
+    if (tid < 9) { pbt[tid] = S.pb->linv[tid]; pbt[9 + tid] = S.pb->lat[tid]; pbt[18 + tid] = S.pb->lprim_inv[tid]; pbi[tid] = S.pb->supercell[tid]; }
+    if (tid == 9) {
+      pbi[9] = S.pb->member_M; pbi[10] = S.pb->memb_E; pbi[11] = S.pb->near_G; pbi[12] = S.pb->member != nullptr; pbi[13] = S.pb->jas_fold;
+      reinterpret_cast<unsigned long long*>(pbt + 27)[0] = (unsigned long long)S.pb->near_mask;
+      reinterpret_cast<unsigned long long*>(pbt + 27)[1] = (unsigned long long)S.pb->memb_mask;
+      pbt[29] = (S.pbc == 1 || S.pb->jas_fold) ? 1.0 : 0.0;  // (pbc 1: orthogonal cell, the fold is the minimal image)
+    }
+  }
   for (int k = tid; k < RT.region; k += PQA_RES_NT) region[k] = 0.0;  // (K-padding rows of the tile stay finite)
   double cx[2], cy[2], cz[2];
 #pragma unroll
@@ -504,24 +576,22 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           // indices into the pair's LDS list.  Pairs the lists cannot hold (no mask table, more images than a list holds) are flagged 255 and
           // take the direct tests of shell_eval_pbc; 254: the list is too short, the pair's shells walk the candidate masks themselves.
           const double ppx = wsc[pl * PQA_RES_WS], ppy = wsc[pl * PQA_RES_WS + 1], ppz = wsc[pl * PQA_RES_WS + 2];
-          const PrimWrap pw0 = prim_wrap(S, ppx, ppy, ppz);
           for (int a = grp; a < S.natom; a += 32) {
-            PbcCtx c;
-            pbc_ctx_base(S, c, a, ppx - at_xyz[3 * a], ppy - at_xyz[3 * a + 1], ppz - at_xyz[3 * a + 2], pw0);
+            const ResPair c = res_pair_base(pbt, pbi, a, ppx, ppy, ppz, at_xyz[3 * a], at_xyz[3 * a + 1], at_xyz[3 * a + 2]);
             int n = 0;
             unsigned long long m0 = 0ull, m1 = 0ull;
-            const int ncl = S.pb->ncls[a];
-            bool over = !res_image_masks(S, c, a, m0, m1) || ncl <= 0 || ncl > 8;
-            if (!over) {
-              // Every admitted image gets the class of the smallest shell cut-off of this atom that contains it (at most 8 distinct
-              // cut-offs here) and the list is written class by class — a counting sort in two walks over the candidate bits — so that a
+            const int ncl = at_int[3 * a + 1];
+            res_image_masks(pbt, pbi, c, a, at_int[3 * a], at_int[3 * a + 2], m0, m1);
+            {
+              // Every admitted image gets the class of the smallest shell cut-off of this atom that contains it (at most PQA_RES_NCUT
+              // distinct cut-offs here) and the list is written class by class — a counting sort in two walks over the candidate bits — so that a
               // shell's walk ends at the first image outside ITS cut-off: the lanes of a wave run the union of their walks, and unsorted
               // lists made every shell walk every image of the atom (158 us per move instead of ~15).
-              double cut_r[8];
+              double cut_r[PQA_RES_NCUT];
 #pragma unroll
-              for (int q = 0; q < 8; ++q) cut_r[q] = q < ncl ? S.pb->cls_cut[a * PQA_MAXCLS + q] : INFINITY;
-              const double acut = S.pb->atom_cut[a];
-              unsigned long long cnt = 0ull;  // eight 6-bit class populations
+              for (int q = 0; q < PQA_RES_NCUT; ++q) cut_r[q] = at_cut[a * (1 + PQA_RES_NCUT) + 1 + q];
+              const double acut = at_cut[a * (1 + PQA_RES_NCUT)];
+              unsigned long long cnt = 0ull;  // 6-bit class populations
 #pragma unroll 1
               for (int half = 0; half < 2; ++half) {
                 unsigned long long m = half ? m1 : m0, keep = 0ull;
@@ -532,7 +602,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                   const double r2 = xj * xj + yj * yj + zj * zj;
                   int cls = 0;
 #pragma unroll
-                  for (int q = 0; q < 8; ++q) cls += r2 > cut_r[q] ? 1 : 0;
+                  for (int q = 0; q < PQA_RES_NCUT; ++q) cls += r2 > cut_r[q] ? 1 : 0;
                   if (r2 > acut || cls >= ncl) continue;
                   cnt += 1ull << (6 * cls);
                   keep |= 1ull << b;
@@ -545,7 +615,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                 unsigned long long off = 0ull;
                 int run = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { off |= (unsigned long long)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63); }
+                for (int q = 0; q < PQA_RES_NCUT; ++q) { off |= (unsigned long long)run << (6 * q); run += (int)((cnt >> (6 * q)) & 63); }
                 unsigned char* lst = imgl + ((size_t)a * 16 + pl) * RT.icap;
 #pragma unroll 1
                 for (int half = 0; half < 2; ++half) {
@@ -557,7 +627,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                     const double r2 = xj * xj + yj * yj + zj * zj;
                     int cls = 0;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) cls += r2 > cut_r[q] ? 1 : 0;
+                    for (int q = 0; q < PQA_RES_NCUT; ++q) cls += r2 > cut_r[q] ? 1 : 0;
                     const int pos = (int)((off >> (6 * cls)) & 63);
                     off += 1ull << (6 * cls);
                     lst[pos] = (unsigned char)j;
@@ -565,7 +635,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                 }
               }
             }
-            imgn[a * 16 + pl] = over ? (unsigned char)255 : (unsigned char)n;
+            imgn[a * 16 + pl] = (unsigned char)n;
           }
           res_block_sync();
           PQA_RCLK(14);
@@ -579,8 +649,6 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           {
             const double px = wsc[pl * PQA_RES_WS], py = wsc[pl * PQA_RES_WS + 1], pz = wsc[pl * PQA_RES_WS + 2];
 #ifndef PQA_RES_ABL_NOAO
-            PbcCtx ctx;
-            const PrimWrap pw = PBC ? prim_wrap(S, px, py, pz) : PrimWrap{0, 0, 0};  // (the proposals in wsc are inside the cell)
             for (int it = goff[ps * 32 + grp]; it < goff[ps * 32 + grp + 1]; ++it) {
               const int sh = glist[it];
               const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], krow = sh_meta[5 * sh + 3] - row_base;
@@ -588,7 +656,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                 // lattice sum over the admitted images inside this shell's cut-off (numba/pbcgto.py:99-506): the tile element belongs
                 // to this thread, the sum accumulates in place
                 const int a_ = sh_meta[5 * sh + 4], nim = imgn[a_ * 16 + pl];
-                if (nim != 255) {
+                {
                   double* tl = region + (size_t)krow * 16 + pl;
                   auto add_image = [&](double xj, double yj, double zj) {
 #if defined(PQA_RES_ABL_PBC) && PQA_RES_ABL_PBC == 1
@@ -608,21 +676,15 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                       tl[((size_t)4 * KT + m) * 16] = 0.0;
                     }
                   // point - atom folded into the cell-centred parallelepiped (pbc_ctx_base)
-                  const double x = px - sh_xyz[3 * sh], y = py - sh_xyz[3 * sh + 1], z = pz - sh_xyz[3 * sh + 2];
-                  const double f0 = floor(x * S.pb->linv[0] + y * S.pb->linv[3] + z * S.pb->linv[6] + 0.5);
-                  const double f1 = floor(x * S.pb->linv[1] + y * S.pb->linv[4] + z * S.pb->linv[7] + 0.5);
-                  const double f2 = floor(x * S.pb->linv[2] + y * S.pb->linv[5] + z * S.pb->linv[8] + 0.5);
-                  const double x0 = x - (f0 * S.pb->lat[0] + f1 * S.pb->lat[3] + f2 * S.pb->lat[6]);
-                  const double y0 = y - (f0 * S.pb->lat[1] + f1 * S.pb->lat[4] + f2 * S.pb->lat[7]);
-                  const double z0 = z - (f0 * S.pb->lat[2] + f1 * S.pb->lat[5] + f2 * S.pb->lat[8]);
-                  const double scut = S.pb->shell_cut[sh];
+                  double x0, y0, z0, f0_, f1_, f2_;
+                  res_fold(pbt, px - at_xyz[3 * a_], py - at_xyz[3 * a_ + 1], pz - at_xyz[3 * a_ + 2], x0, y0, z0, f0_, f1_, f2_);
+                  const double scut = sh_cut[sh];
                   const unsigned char* lst = imgl + ((size_t)a_ * 16 + pl) * RT.icap;
                   if (nim == 254) {  // (rare: same images in index order, found again from the masks)
-                    PbcCtx c2;
-                    pbc_ctx_base(S, c2, a_, x, y, z, pw);
+                    const ResPair c2 = res_pair_base(pbt, pbi, a_, px, py, pz, at_xyz[3 * a_], at_xyz[3 * a_ + 1], at_xyz[3 * a_ + 2]);
                     unsigned long long m0 = 0ull, m1 = 0ull;
-                    res_image_masks(S, c2, a_, m0, m1);
-                    const double cut2 = fmin(scut, S.pb->atom_cut[a_]);
+                    res_image_masks(pbt, pbi, c2, a_, at_int[3 * a_], at_int[3 * a_ + 2], m0, m1);
+                    const double cut2 = fmin(scut, at_cut[a_ * (1 + PQA_RES_NCUT)]);
 #pragma unroll 1
                     for (int half = 0; half < 2; ++half) {
                       unsigned long long m = half ? m1 : m0;
@@ -647,22 +709,8 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                   }
                   continue;
                 }
-                bool accum = false;
-                ctx.ia = -1;
-                pbc_ctx_update(S, ctx, a_, px - sh_xyz[3 * sh], py - sh_xyz[3 * sh + 1], pz - sh_xyz[3 * sh + 2], pw);
-                shell_eval_pbc<5, LMAX>(S, ctx, sh, l_, pr_exp + q0, pr_coef + q0, np_,
-                                        [&](int m, double v, double ax, double ay, double az, double lp) {
-                                          double* tl = region + (size_t)(krow + m) * 16 + pl;
-                                          if (accum) {
-                                            tl[0] += v; tl[(size_t)KT * 16] += ax; tl[(size_t)2 * KT * 16] += ay; tl[(size_t)3 * KT * 16] += az;
-                                            tl[(size_t)4 * KT * 16] += lp;
-                                          } else {
-                                            tl[0] = v; tl[(size_t)KT * 16] = ax; tl[(size_t)2 * KT * 16] = ay; tl[(size_t)3 * KT * 16] = az;
-                                            tl[(size_t)4 * KT * 16] = lp;
-                                          }
-                                        }, accum);
               } else
-              shell_eval<5, LMAX>(l_, px - sh_xyz[3 * sh], py - sh_xyz[3 * sh + 1], pz - sh_xyz[3 * sh + 2], pr_exp + q0, pr_coef + q0, np_,
+              shell_eval<5, LMAX>(l_, px - at_xyz[3 * sh_meta[5 * sh + 4]], py - at_xyz[3 * sh_meta[5 * sh + 4] + 1], pz - at_xyz[3 * sh_meta[5 * sh + 4] + 2], pr_exp + q0, pr_coef + q0, np_,
                                   [&](int m, double v, double ax, double ay, double az, double lp) {
                                     double* tl = region + (size_t)(krow + m) * 16 + pl;
                                     tl[0] = v; tl[(size_t)KT * 16] = ax; tl[(size_t)2 * KT * 16] = ay; tl[(size_t)3 * KT * 16] = az;
@@ -754,7 +802,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jn{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, e, npx, npy, npz, jn);
+          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, e, npx, npy, npz, jn, pbt);
           else {
             double g3[3];
             res_jas_part<PBC>(S, e, r, npx, npy, npz, cx, cy, cz, at_xyz, acoef, aql, jn.u, g3);
@@ -879,7 +927,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jo{0.0, 0.0, 0.0, 0.0};
-          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, ep, pox, poy, poz, jo);
+          if (S.jq_on) res_jas_m<PBC>(S, r, cx, cy, cz, at_xyz, acoef, aql, jt, ep, pox, poy, poz, jo, pbt);
           else {
             double g3[3];
             res_jas_part<PBC>(S, ep, r, pox, poy, poz, cx, cy, cz, at_xyz, acoef, aql, jo.u, g3);
@@ -896,9 +944,13 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         if (r == 0) {
           double nx = pox + z0 + gx * df, ny = poy + z1 + gy * df, nz = poz + z2 + gz * df;
           if (PBC) {  // make_irreducible (mc.py:121, coord.py:164-178): the proposal inside the cell, the cells it crossed kept for the accept
-            int dw[3];
-            fold_cell(S, nx, ny, nz, dw);
-            ws[16] = dw[0]; ws[17] = dw[1]; ws[18] = dw[2];
+            double f0 = nx * pbt[0] + ny * pbt[3] + nz * pbt[6], f1 = nx * pbt[1] + ny * pbt[4] + nz * pbt[7], f2 = nx * pbt[2] + ny * pbt[5] + nz * pbt[8];
+            const double w0 = floor(f0), w1 = floor(f1), w2 = floor(f2);  // (fold_cell, pqa_common.hpp, on the block's copy of the cell)
+            f0 -= w0; f1 -= w1; f2 -= w2;
+            nx = f0 * pbt[9] + f1 * pbt[12] + f2 * pbt[15];
+            ny = f0 * pbt[10] + f1 * pbt[13] + f2 * pbt[16];
+            nz = f0 * pbt[11] + f1 * pbt[14] + f2 * pbt[17];
+            ws[16] = w0; ws[17] = w1; ws[18] = w2;
           }
           ws[0] = nx; ws[1] = ny; ws[2] = nz;
           ws[3] = z0; ws[4] = z1; ws[5] = z2; ws[6] = gx; ws[7] = gy; ws[8] = gz; ws[9] = U0;
