@@ -171,6 +171,8 @@ static int res_setup(pqa_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa_res] passes %d, tile rows %d (padded basis %d), LDS %zu B, image-list capacity %d\n", RT.npass, RT.kt, c.rows_pad, h->res_lds, RT.icap);
@@ -218,10 +220,12 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
     h->prof_pc += (double)W * h->N * 5;  // point-components of this launch (as launch_orb counts them)
   }
 #define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
-  if (h->S.pbc) {
-    if (mb.dmc) hipLaunchKernelGGL((k_sweep_res<true, 3, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
-    else hipLaunchKernelGGL((k_sweep_res<false, 3, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+#define PQA_RES_LAUNCH_P(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
+  if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
+    if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(true, 2); else PQA_RES_LAUNCH_P(true, 3); }
+    else { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(false, 2); else PQA_RES_LAUNCH_P(false, 3); }
   } else
+#undef PQA_RES_LAUNCH_P
   if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH(true, 2); else PQA_RES_LAUNCH(true, 3); }
   else { if (h->res_lmax <= 2) PQA_RES_LAUNCH(false, 2); else PQA_RES_LAUNCH(false, 3); }
 #undef PQA_RES_LAUNCH
@@ -230,6 +234,9 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
 }
 
 #ifdef PQA_RES_CLK  // timing build only
+extern "C" int pqa_debug_res_clk2(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk2), (size_t)n * sizeof(unsigned long long));
+}
 extern "C" int pqa_debug_res_clk(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk), (size_t)n * sizeof(unsigned long long));
 }

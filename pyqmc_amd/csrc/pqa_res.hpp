@@ -381,9 +381,12 @@ __device__ __forceinline__ void res_image_masks(const double* __restrict__ pbt, 
 
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
 static __device__ unsigned long long pqa_res_clk[64 * 16];
+static __device__ unsigned long long pqa_res_clk2[64 * 8];  // thread 0's AO phase: cycles in [0] list header + zeroing, [1] fold, [2] walk + evaluation, [3] shells, [4] images evaluated
+#define PQA_RCLK2(k, v) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk2[blockIdx.x * 8 + (k)] = (v); } while (0)
 #define PQA_RCLK(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PQA_RCLK(k) do { } while (0)
+#define PQA_RCLK2(k, v) do { } while (0)
 #endif
 
 // grid = ceil((w_hi - w_lo) / 16) blocks of 512 threads; dynamic LDS = RT.region doubles + res_lds_fixed(...).
@@ -649,7 +652,13 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           {
             const double px = wsc[pl * PQA_RES_WS], py = wsc[pl * PQA_RES_WS + 1], pz = wsc[pl * PQA_RES_WS + 2];
 #ifndef PQA_RES_ABL_NOAO
+#ifdef PQA_RES_CLK
+            unsigned long long c_a = 0, c_b = 0, c_c = 0, n_sh = 0, n_im = 0;
+#endif
             for (int it = goff[ps * 32 + grp]; it < goff[ps * 32 + grp + 1]; ++it) {
+#ifdef PQA_RES_CLK
+              const unsigned long long t_0 = clock64();
+#endif
               const int sh = glist[it];
               const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], krow = sh_meta[5 * sh + 3] - row_base;
               if (PBC) {
@@ -658,27 +667,37 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                 const int a_ = sh_meta[5 * sh + 4], nim = imgn[a_ * 16 + pl];
                 {
                   double* tl = region + (size_t)krow * 16 + pl;
-                  auto add_image = [&](double xj, double yj, double zj) {
-#if defined(PQA_RES_ABL_PBC) && PQA_RES_ABL_PBC == 1
-                    if (xj != 1.2345e300) return;
-#endif
-                    shell_eval<5, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
-                                              [&](int m, double v, double ax, double ay, double az, double lp) {
-                                                double* t_ = tl + (size_t)m * 16;
-                                                t_[0] += v; t_[(size_t)KT * 16] += ax; t_[(size_t)2 * KT * 16] += ay; t_[(size_t)3 * KT * 16] += az;
-                                                t_[(size_t)4 * KT * 16] += lp;
-                                              });
-                  };
+                  // (the lattice sum accumulates in the tile: 15-25 running sums in registers beside the inverse row end up in scratch —
+                  // tried, 39 k -> 62 k cycles for thread 0's three shells)
 #pragma unroll
                   for (int m = 0; m < 2 * LMAX + 1; ++m)
                     if (m < 2 * l_ + 1) {
                       tl[(size_t)m * 16] = 0.0; tl[((size_t)KT + m) * 16] = 0.0; tl[((size_t)2 * KT + m) * 16] = 0.0; tl[((size_t)3 * KT + m) * 16] = 0.0;
                       tl[((size_t)4 * KT + m) * 16] = 0.0;
                     }
-                  // point - atom folded into the cell-centred parallelepiped (pbc_ctx_base)
+                  // (the five component planes as restrict pointers: the compiler could not tell that tl + c KT 16 are different addresses and
+                  // ran the 5 (2 l + 1) read-add-write sequences of an image one after the other)
+                  double* __restrict__ pl0 = tl;
+                  double* __restrict__ pl1 = tl + (size_t)KT * 16;
+                  double* __restrict__ pl2 = tl + (size_t)2 * KT * 16;
+                  double* __restrict__ pl3 = tl + (size_t)3 * KT * 16;
+                  double* __restrict__ pl4 = tl + (size_t)4 * KT * 16;
+                  auto add_image = [&](double xj, double yj, double zj) __attribute__((always_inline)) {
+                    shell_eval<5, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
+                                              [&](int m, double v, double ax, double ay, double az, double lp) __attribute__((always_inline)) {
+                                                const double o0 = pl0[m * 16], o1 = pl1[m * 16], o2 = pl2[m * 16], o3 = pl3[m * 16], o4 = pl4[m * 16];
+                                                pl0[m * 16] = o0 + v; pl1[m * 16] = o1 + ax; pl2[m * 16] = o2 + ay; pl3[m * 16] = o3 + az; pl4[m * 16] = o4 + lp;
+                                              });
+                  };
+#ifdef PQA_RES_CLK
+                  const unsigned long long t_1 = clock64();
+#endif
                   double x0, y0, z0, f0_, f1_, f2_;
                   res_fold(pbt, px - at_xyz[3 * a_], py - at_xyz[3 * a_ + 1], pz - at_xyz[3 * a_ + 2], x0, y0, z0, f0_, f1_, f2_);
                   const double scut = sh_cut[sh];
+#ifdef PQA_RES_CLK
+                  const unsigned long long t_2 = clock64();
+#endif
                   const unsigned char* lst = imgl + ((size_t)a_ * 16 + pl) * RT.icap;
                   if (nim == 254) {  // (rare: same images in index order, found again from the masks)
                     const ResPair c2 = res_pair_base(pbt, pbi, a_, px, py, pz, at_xyz[3 * a_], at_xyz[3 * a_ + 1], at_xyz[3 * a_ + 2]);
@@ -697,16 +716,19 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                     }
                     continue;
                   }
-#if defined(PQA_RES_ABL_PBC) && PQA_RES_ABL_PBC == 2
-                  if (x0 != 1.2345e300) continue;
-#endif
 #pragma unroll 1
                   for (int k = 0; k < nim; ++k) {
                     const int j = lst[k];
                     const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
                     if (xj * xj + yj * yj + zj * zj > scut) break;  // (class-ordered list: nothing further is inside this shell's cut-off)
                     add_image(xj, yj, zj);
+#ifdef PQA_RES_CLK
+                    ++n_im;
+#endif
                   }
+#ifdef PQA_RES_CLK
+                  { const unsigned long long t_3 = clock64(); c_a += t_1 - t_0; c_b += t_2 - t_1; c_c += t_3 - t_2; ++n_sh; }
+#endif
                   continue;
                 }
               } else
@@ -717,6 +739,9 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                                     tl[(size_t)4 * KT * 16] = lp;
                                   });
             }
+#endif
+#ifdef PQA_RES_CLK
+            if (PBC) { PQA_RCLK2(0, c_a); PQA_RCLK2(1, c_b); PQA_RCLK2(2, c_c); PQA_RCLK2(3, n_sh); PQA_RCLK2(4, n_im); }
 #endif
           }
           // B operand of this wave's k-steps (L2-resident coefficient rows): a ring of four, the first three requested behind the AO

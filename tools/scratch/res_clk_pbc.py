@@ -39,3 +39,9 @@ prev = 5
 for k, name in [(10, "rowE handed over"), (11, "Slater sums"), (12, "Jastrow at the current position"), (6, "drift, proposal")]:
     d = (c[:, k] - c[:, 10 if k != 10 else k]) / 100.0
     print("%-36s at %6.2f us after the hand-over" % (name, d.mean()))
+
+b2 = (ctypes.c_ulonglong * (64 * 8))()
+lib.pqa_debug_res_clk2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+if lib.pqa_debug_res_clk2(b2, 64 * 8) == 0:
+    q = np.array(b2[:], dtype=np.float64).reshape(64, 8)[: len(c)]
+    print("thread 0's phase 1, shader cycles (mean over blocks): header+zeroing %.0f, fold %.0f, walk+evaluation %.0f; shells %.1f, images evaluated %.1f" % tuple(q[:, k].mean() for k in range(5)))
