@@ -191,9 +191,9 @@ bool res_eligible(pqa_handle* h, long W) {
   // walkers, 1.88x at 4096, 1.38x at 16384, 1.06x at 32768, 1.02x at 49152, 0.97x at 65536; H2O (8 electrons: a walker's 32 lanes
   // are mostly idle) 1.2x up to 4096 walkers, 0.49x at 16384.  One round of blocks (16 walkers per CU) always wins.
   if (W < h->res_min || W > h->res_max) return false;
-  // periodic cells (lattice-summed AO phase in the block, round 5): 2x2x2 diamond DMC step 6.59 -> 6.00 ms at 1024 walkers, 9.88 -> 8.89 at
-  // 4096, 17.3 -> 16.4 at 8192; sweep alone 12.5 -> 13.1 ms at 16384 (loses)
-  if (h->S.pbc) return W <= 8192;
+  // periodic cells (lattice-summed AO phase in the block, round 5; 2x2x2 diamond cell, sweep alone, launches -> resident): 4.10 -> 2.71 ms at
+  // 2048 walkers, 4.43 -> 2.74 at 4096, 7.56 -> 5.48 at 8192, 12.5 -> 10.9 at 16384, 17.2 -> 16.4 at 24576, even at 32768
+  if (h->S.pbc) return W <= 24576;
   return W <= 4096 || (std::max(h->nup, h->ndn) >= 16 && W <= 49152);
 }
 

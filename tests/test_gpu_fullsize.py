@@ -181,7 +181,11 @@ def test_dmc_steps_at_baseline_size():
     n_t, n_d = int(g["n_tmoves_accepted"]), int(g["n_diffusion_rejected"])
     assert n_t == int(g["tmove_accepted"].sum()) >= 20 and n_d == int((~g["diffusion_accepted"]).sum()) >= 50  # (verdict r4 item 6: were 2 and 7)
     note("C5_dmc_oracle_tmoves_accepted", n_t); note("C5_dmc_oracle_diffusion_rejected", n_d)
-    assert np.array_equal(x0[:nchk], g["x0"]), "the device's starting walkers changed: regenerate g36 (tools/make_dmc_replay.py)"
+    # (the fixture's own starting coordinates for these walkers: the warm-up sweeps above reproduce them to rounding only — sums run in a
+    # different order in the resident and the launch-per-move sweep — and the oracle's trajectory belongs to exactly these numbers)
+    assert np.max(np.abs(x0[:nchk] - g["x0"])) < 1e-7, "the device's starting walkers changed: regenerate g36 (tools/make_dmc_replay.py)"
+    x0 = x0.copy()
+    x0[:nchk] = g["x0"]
     wf.recompute(_container(sup, x0))
     w = np.ones(W)
     dev.dmc_steps(float(g["tstep"]), nst, w, float(g["branchcut"]), float(g["etrial"]), float(g["etrial"]), seed=int(g["seed"]))
