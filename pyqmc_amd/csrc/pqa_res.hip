@@ -165,6 +165,7 @@ static int res_setup(pqa_handle* h) {
   h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, RT.nlist, RT.npass);
   h->res_lds = (h->res_lds + 7) & ~(size_t)7;
   RT.pbc_off = (int)h->res_lds; RT.icap = icap;
+  if (const char* e = getenv("PQA_RES_ICAP")) RT.icap = std::max(1, std::min(icap, atoi(e)));  // (tests: short lists, the pairs that overflow walk the masks)
   h->res_lds += pbc_b;
   if (h->res_lds > 160 * 1024) return 0;
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

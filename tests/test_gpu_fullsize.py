@@ -516,6 +516,26 @@ def test_resident_sweep_against_the_launch_per_move_sweep(cfg, W, monkeypatch):
             assert note(f"{cfg}_{W}_resident_vs_launches_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-10
 
 
+def test_periodic_resident_sweep_with_short_image_lists(monkeypatch):
+    """The periodic resident sweep keeps the admitted images of a (point, atom) pair in an LDS list (32 entries in the 2x2x2 diamond cell,
+    where a pair has 13 at most); a pair with more walks the candidate masks itself.  With the lists cut to 6 entries most diffuse pairs
+    take that route: same decisions and walkers as with full lists."""
+    import pyqmc_amd as pa
+
+    outs = []
+    for icap in ("32", "6"):
+        monkeypatch.setenv("PQA_RES", "1")
+        monkeypatch.setenv("PQA_RES_ICAP", icap)
+        sup, wf, _, _ = build("C5")
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(sup, 200, rng=np.random.default_rng(12)))
+        acc, en, rec = dev.vmc_sweeps(0.3, 2, seed=8, energy=True, record=True)
+        outs.append((rec, dev.configs(), dev.value()[1]))
+    a, b = outs
+    assert np.array_equal(a[0], b[0])
+    assert note("C5_short_lists_x", np.max(np.abs(a[1] - b[1]))) < 1e-10 and note("C5_short_lists_logv", np.max(np.abs(a[2] - b[2]))) < 1e-9
+
+
 def _scf_kinetic_energy(cell, mf, n=20):
     """2 sum_k sum_occ 1/2 int_cell |grad psi_kn|^2 — the supercell's kinetic energy of the SCF determinant — by midpoint quadrature
     of the oracle's lattice-summed AOs over the primitive cell (periodic integrands: spectrally accurate; the role of
