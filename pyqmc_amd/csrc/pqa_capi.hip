@@ -391,6 +391,10 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   PQA_SPLIT 0..3 / PQA_SPLIT_MIN / PQA_SPLIT_CUS pipelined half-ensembles, PQA_JPRE 1 Jastrow sums ahead on a side stream,
   //   PQA_JAS_MERGE 0 Pade functions one by one instead of the merged rational function (jas_merge_tables),
   //   PQA_ORB_KC5 / PQA_ORB_KC1 16|32 AO rows per chunk of the periodic 5-component / value-only orbital launches.
+  //   round 5: PQA_RES 0|1 resident sweep off / forced (default: by shard size, pqa_res.hip res_eligible), PQA_RES_MIN / PQA_RES_MAX walker
+  //   window of the automatic choice, PQA_RES_PBC 0 periodic handles keep the launch-per-move sweep, PQA_RES_ICAP n shorter image lists in
+  //   the periodic resident sweep (tests), PQA_RES_DEBUG 1 prints the tile / LDS plan, PQA_ORB_GENERAL 1 orbitals of handles beyond 64 per
+  //   spin by k_ao + k_mo_rows instead of the windowed k_orb.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);

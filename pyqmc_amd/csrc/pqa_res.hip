@@ -235,6 +235,9 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
 }
 
 #ifdef PQA_RES_CLK  // timing build only
+extern "C" int pqa_debug_res_clk3(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk3), (size_t)n * sizeof(unsigned long long));
+}
 extern "C" int pqa_debug_res_clk2(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk2), (size_t)n * sizeof(unsigned long long));
 }

@@ -381,6 +381,7 @@ __device__ __forceinline__ void res_image_masks(const double* __restrict__ pbt, 
 
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
 static __device__ unsigned long long pqa_res_clk[64 * 16];
+static __device__ unsigned long long pqa_res_clk3[64 * 8];
 static __device__ unsigned long long pqa_res_clk2[64 * 8];  // thread 0's AO phase: cycles in [0] list header + zeroing, [1] fold, [2] walk + evaluation, [3] shells, [4] images evaluated
 #define PQA_RCLK2(k, v) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk2[blockIdx.x * 8 + (k)] = (v); } while (0)
 #define PQA_RCLK(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
@@ -742,6 +743,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
 #endif
 #ifdef PQA_RES_CLK
             if (PBC) { PQA_RCLK2(0, c_a); PQA_RCLK2(1, c_b); PQA_RCLK2(2, c_c); PQA_RCLK2(3, n_sh); PQA_RCLK2(4, n_im); }
+            if (PBC && blockIdx.x < 64 && (threadIdx.x & 63) == 0) pqa_res_clk3[blockIdx.x * 8 + (threadIdx.x >> 6)] = c_a + c_b + c_c;  // per wave: its phase 1
 #endif
           }
           // B operand of this wave's k-steps (L2-resident coefficient rows): a ring of four, the first three requested behind the AO

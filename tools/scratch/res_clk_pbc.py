@@ -45,3 +45,9 @@ lib.pqa_debug_res_clk2.argtypes = [ctypes.c_void_p, ctypes.c_int]
 if lib.pqa_debug_res_clk2(b2, 64 * 8) == 0:
     q = np.array(b2[:], dtype=np.float64).reshape(64, 8)[: len(c)]
     print("thread 0's phase 1, shader cycles (mean over blocks): header+zeroing %.0f, fold %.0f, walk+evaluation %.0f; shells %.1f, images evaluated %.1f" % tuple(q[:, k].mean() for k in range(5)))
+
+b3 = (ctypes.c_ulonglong * (64 * 8))()
+lib.pqa_debug_res_clk3.argtypes = [ctypes.c_void_p, ctypes.c_int]
+if lib.pqa_debug_res_clk3(b3, 64 * 8) == 0:
+    q = np.array(b3[:], dtype=np.float64).reshape(64, 8)[: len(c)]
+    print("phase 1 per wave (lane 0 of waves 0..7), k cycles:", (q.mean(axis=0) / 1e3).round(1))
