@@ -179,6 +179,7 @@ struct pqa_handle {
   int pbc_mincls = 0;
   bool pbc_lists_ok = false;
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
+  int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
   // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
   // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm

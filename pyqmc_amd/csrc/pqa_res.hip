@@ -12,6 +12,14 @@ int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host) {
   std::vector<double> pad((size_t)h->res_rows4 * ldc, 0.0);
   for (int a = 0; a < h->nao; ++a)
     for (int j = 0; j < nmo; ++j) pad[(size_t)a * ldc + j] = mo_host[(size_t)a * nmo + j];
+  if (h->twist) {  // rows nao .. 2 nao: the imaginary AO parts, (i AO_im)(C_re + i C_im) = AO_im (-C_im + i C_re), columns [re | im] (upload_cpad)
+    const int nr = nmo / 2;
+    for (int a = 0; a < h->nao; ++a)
+      for (int j = 0; j < nr; ++j) {
+        pad[(size_t)(h->nao + a) * ldc + j] = -mo_host[(size_t)a * nmo + nr + j];
+        pad[(size_t)(h->nao + a) * ldc + nr + j] = mo_host[(size_t)a * nmo + j];
+      }
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy(h->d_cres[s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
@@ -21,7 +29,10 @@ static int res_setup(pqa_handle* h) {
   h->res_ready = true;
   h->res_ok = false;
   if (h->res_mode == 0) return 0;
-  if (!h->has_slater || h->ndet != 1 || h->has_j3 || h->cplx || h->twist) return 0;
+  if (!h->has_slater || h->ndet != 1 || h->has_j3) return 0;
+  // complex determinants: periodic cells (twisted or not), 16 electrons and 16 orbitals per spin — a row of the inverse is 32 doubles
+  if (h->cplx && (!h->S.pbc || h->nup > 16 || h->ndn > 16 || h->res_cx == 0)) return 0;
+  if (h->twist && !h->cplx) return 0;
   if (h->S.pbc && (h->S.nL <= 0 || h->pbc_high_l || h->res_pbc == 0 || !h->pbc_lists_ok)) return 0;  // periodic: lattice-summed orbitals, l <= 3 (PQA_RES_PBC=0 keeps the launches)
   if (h->nup > 32 || h->ndn > 32 || h->nmo[0] > 32 || h->nmo[1] > 32 || h->N > 64 || h->N < 1 || h->natom > 64) return 0;
   int lmax = 0;
@@ -65,7 +76,7 @@ static int res_setup(pqa_handle* h) {
   size_t pbc_b = 0;
   auto pick_icap = [&](size_t rest) {  // largest capacity whose lists fit `rest` bytes (0: none)
     for (int cand = 32; cand >= 10; --cand)
-      if (res_lds_pbc(h->natom, h->S.nL, cand, h->nshell) + 8 <= rest) return cand;
+      if (res_lds_pbc(h->natom, h->S.nL, cand, h->nshell, h->twist) + 8 <= rest) return cand;
     return 0;
   };
   if (h->S.pbc) {
@@ -73,7 +84,7 @@ static int res_setup(pqa_handle* h) {
     const size_t tile = (size_t)80 * c.rows_pad * sizeof(double), budget0 = (size_t)160 * 1024 - 256;
     icap = f0 + tile < budget0 ? pick_icap(budget0 - f0 - tile) : 0;
     if (icap == 0) icap = 10;
-    pbc_b = res_lds_pbc(h->natom, h->S.nL, icap, h->nshell) + 8;
+    pbc_b = res_lds_pbc(h->natom, h->S.nL, icap, h->nshell, h->twist) + 8;
   }
   const size_t fixed = res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, h->nshell, PQA_RES_MAXPASS) + pbc_b;
   const size_t budget = 160 * 1024 - 256;
@@ -81,10 +92,11 @@ static int res_setup(pqa_handle* h) {
   const size_t avail = (budget - fixed) / sizeof(double);
   // one pass if the whole basis fits (the partials then reuse the tile's memory); otherwise the tile shares the region with them
   const int rows_all = c.rows_pad;
-  const bool one = rows_all <= rows_cap && (size_t)80 * rows_all <= avail;
+  // (twisted cells: dense rows only — the real rows of the whole basis, then the imaginary rows)
+  const bool one = !h->twist && rows_all <= rows_cap && (size_t)80 * rows_all <= avail;
   // dense mode: the chunk padding (16-row chunks: 224 rows for the 208 AOs of the 2x2x2 diamond cell) is what keeps the basis out of one
   // tile, and the AOs in their own order (padded to x4) fit
-  const int rows4 = (h->nao + 3) & ~3;
+  const int rows4 = ((h->twist ? 2 : 1) * h->nao + 3) & ~3;
   const size_t fixed1 = res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, h->nshell, 1);
   bool dense = false;
   if (!one && rows4 <= rows_cap) {
@@ -92,9 +104,10 @@ static int res_setup(pqa_handle* h) {
     if (!h->S.pbc) dense = fixed1 + tile <= budget;
     else if (fixed1 + tile < budget) {
       const int cand = pick_icap(budget - fixed1 - tile);
-      if (cand > 0) { dense = true; icap = cand; pbc_b = res_lds_pbc(h->natom, h->S.nL, cand, h->nshell) + 8; }
+      if (cand > 0) { dense = true; icap = cand; pbc_b = res_lds_pbc(h->natom, h->S.nL, cand, h->nshell, h->twist) + 8; }
     }
   }
+  if (h->twist && !dense) return 0;
   const int kt_cap = (one || dense) ? (dense ? rows4 : rows_all) : std::min(rows_cap, (int)(((avail - part_rn) / 80) & ~(size_t)3));
   if (kt_cap < 20) return 0;
   ResTab RT{};
@@ -165,6 +178,7 @@ static int res_setup(pqa_handle* h) {
   h->res_lds = (size_t)RT.region * sizeof(double) + res_lds_fixed(h->nshell, nprim_u, h->natom, h->na, RT.nlist, RT.npass);
   h->res_lds = (h->res_lds + 7) & ~(size_t)7;
   RT.pbc_off = (int)h->res_lds; RT.icap = icap;
+  RT.twist = h->twist ? 1 : 0; RT.im_off = h->nao;
   if (const char* e = getenv("PQA_RES_ICAP")) RT.icap = std::max(1, std::min(icap, atoi(e)));  // (tests: short lists, the pairs that overflow walk the masks)
   h->res_lds += pbc_b;
   if (h->res_lds > 160 * 1024) return 0;
@@ -176,6 +190,7 @@ static int res_setup(pqa_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa_res] passes %d, tile rows %d (padded basis %d), LDS %zu B, image-list capacity %d\n", RT.npass, RT.kt, c.rows_pad, h->res_lds, RT.icap);
   h->res_tab = RT;
   h->res_ok = true;
@@ -222,7 +237,8 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
   }
 #define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
 #define PQA_RES_LAUNCH_P(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
-  if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
+  if (h->cplx) hipLaunchKernelGGL((k_sweep_res<false, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+  else if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
     if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(true, 2); else PQA_RES_LAUNCH_P(true, 3); }
     else { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(false, 2); else PQA_RES_LAUNCH_P(false, 3); }
   } else

@@ -37,7 +37,8 @@
 #define PQA_RES_G 32       // lane groups of the AO phase
 #define PQA_RES_MAXKS 16   // k-steps (4 AO rows each) of one pass a wave contracts at most
 #define PQA_RES_MAXPASS 8
-#define PQA_RES_WS 20     // doubles per walker of the per-walker scalars (wsc): 16 of the move + the cell wraps of a folded proposal
+#define PQA_RES_WS 24     // doubles per walker of the per-walker scalars (wsc): 16 of the move + the cell wraps of a folded proposal (or, in a
+                          // twisted cell, the folded proposal) + the imaginary part of the determinant phase + the wrap phase of the proposal
 #define PQA_RES_RS 176     // doubles per walker of the combined orbital rows [5][32] (+16: walkers of a wave on disjoint LDS banks)
 
 struct ResTab {
@@ -54,7 +55,8 @@ struct ResTab {
   const double* prim_exp_u;                // [nprim_u]
   const double* prim_coef_u;
   const int* shell_q0;                     // [nshell] first primitive of the shell in those tables
-  int pbc_off, icap;                       // periodic: byte offset of the lattice vectors / image lists in the dynamic LDS, list capacity
+  int pbc_off, icap, twist;                // (twist: complex AOs — the tile holds the real rows, then from row im_off on the imaginary rows)
+  int im_off;                       // periodic: byte offset of the lattice vectors / image lists in the dynamic LDS, list capacity
 };
 // doubles per point of a K-partial [5][16 nt] (+ padding: the four point quartets of a wave on different banks)
 __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
@@ -65,8 +67,9 @@ __host__ __device__ inline int res_ps(int nt) { return 80 * nt + 16; }
 // + shell cut-offs [nshell], per atom: cut-off + PQA_RES_NCUT class cut-offs (doubles), candidates / classes / membership class (ints),
 // + the cell (inverse lattice, lattice, inverse primitive lattice: 27 doubles, the two mask-table addresses) and the membership rule's
 // integers (supercell matrix, M, E, G, flags, atom_n[natom][3])
-__host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap, int nshell) {
-  return ((size_t)3 * nL + nshell + (size_t)natom * (1 + PQA_RES_NCUT) + 30) * sizeof(double) + (((size_t)(natom * 6 + 16) * sizeof(int) + 7) & ~(size_t)7) +
+// twisted cells: + image phases [nL][2], the fold phase of every (point, atom) pair [natom][16][2]
+__host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap, int nshell, int twist = 0) {
+  return ((size_t)3 * nL + nshell + (size_t)natom * (1 + PQA_RES_NCUT) + 36 + (twist ? 2 * (size_t)nL + 32 * (size_t)natom : 0)) * sizeof(double) + (((size_t)(natom * 6 + 16) * sizeof(int) + 7) & ~(size_t)7) +
          (((size_t)natom * 16 * (icap + 1) + 7) & ~(size_t)7);
 }
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
@@ -336,12 +339,13 @@ __device__ __forceinline__ void res_fold(const double* __restrict__ pbt, double 
   y0 = y - (f0 * pbt[10] + f1 * pbt[13] + f2 * pbt[16]);
   z0 = z - (f0 * pbt[11] + f1 * pbt[14] + f2 * pbt[17]);
 }
-struct ResPair { double x0, y0, z0; int b0, b1, b2; };
+struct ResPair { double x0, y0, z0; int b0, b1, b2; double f0, f1, f2; };
 __device__ __forceinline__ ResPair res_pair_base(const double* __restrict__ pbt, const int* __restrict__ pbi, int a, double px, double py, double pz,
                                                  double ax, double ay, double az) {
   ResPair c;
   double f0, f1, f2;
   res_fold(pbt, px - ax, py - ay, pz - az, c.x0, c.y0, c.z0, f0, f1, f2);
+  c.f0 = f0; c.f1 = f1; c.f2 = f2;
   c.b0 = c.b1 = c.b2 = 0;
   if (pbi[12]) {
     const int w0 = (int)floor(px * pbt[18] + py * pbt[21] + pz * pbt[24]), w1 = (int)floor(px * pbt[19] + py * pbt[22] + pz * pbt[25]),
@@ -398,7 +402,7 @@ static __device__ unsigned long long pqa_res_clk2[64 * 8];  // thread 0's AO pha
 #ifndef PQA_RES_LB
 #define PQA_RES_LB PQA_RES_NT
 #endif
-template <bool DMC, int LMAX, bool PBC = false>
+template <bool DMC, int LMAX, bool PBC = false, bool CX = false>
 static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwState L, MoveBuf mb, ChunkTab T, ResTab RT, int has_jastrow,
                                                                   long W, long w_lo, long w_hi) {
   extern __shared__ double lds[];
@@ -426,8 +430,10 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   double* LsL = lds + (RT.pbc_off >> 3);
   double* sh_cut = LsL + 3 * (PBC ? S.nL : 0);                     // [nshell] shell cut-offs
   double* at_cut = sh_cut + (PBC ? S.nshell : 0);                  // [natom][1 + PQA_RES_NCUT]: atom cut-off, class cut-offs (ascending)
-  double* pbt = at_cut + (PBC ? S.natom * (1 + PQA_RES_NCUT) : 0);   // [30]: linv, lat, lprim_inv, then the addresses of near_mask / memb_mask
-  int* at_int = reinterpret_cast<int*>(pbt + (PBC ? 30 : 0));        // [natom][3]: candidates, classes, membership class
+  double* pbt = at_cut + (PBC ? S.natom * (1 + PQA_RES_NCUT) : 0);   // [36]: linv, lat, lprim_inv, the addresses of near_mask / memb_mask, jas_fold, ktl, twist
+  double* phL = pbt + (PBC ? 36 : 0);                                // twisted: [nL][2] (cos, sin)(k_t . Ls[j])
+  double* pcs = phL + ((PBC && CX && RT.twist) ? 2 * S.nL : 0);      // twisted: [natom][16][2] fold phase of (point, atom)
+  int* at_int = reinterpret_cast<int*>(pcs + ((PBC && CX && RT.twist) ? 32 * S.natom : 0));  // [natom][3]: candidates, classes, membership class
   int* pbi = at_int + (PBC ? 3 * S.natom : 0);                       // [14 + 3 natom]: supercell[9], M, E, G, has_member, jas_fold, atom_n
   unsigned char* imgl = reinterpret_cast<unsigned char*>(pbi + ((PBC ? 3 * S.natom + 16 : 0) & ~1));
   unsigned char* imgn = imgl + (size_t)S.natom * 16 * RT.icap;
@@ -474,6 +480,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
               // per-shell table look-ups were dependent round trips — 12 of the phase's 38 us)
     for (int k = tid; k < 3 * S.nL; k += PQA_RES_NT) LsL[k] = S.pb->Ls[k];
     for (int k = tid; k < S.nshell; k += PQA_RES_NT) sh_cut[k] = S.pb->shell_cut[k];
+    if (CX && RT.twist) for (int k = tid; k < 2 * S.nL; k += PQA_RES_NT) phL[k] = S.pb->img_phase[k];
     for (int k = tid; k < S.natom; k += PQA_RES_NT) {
       const int ncl = S.pb->ncls[k];
       at_cut[k * (1 + PQA_RES_NCUT)] = S.pb->atom_cut[k];
@@ -489,6 +496,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       reinterpret_cast<unsigned long long*>(pbt + 27)[0] = (unsigned long long)S.pb->near_mask;
       reinterpret_cast<unsigned long long*>(pbt + 27)[1] = (unsigned long long)S.pb->memb_mask;
       pbt[29] = (S.pbc == 1 || S.pb->jas_fold) ? 1.0 : 0.0;  // (pbc 1: orthogonal cell, the fold is the minimal image)
+      pbt[30] = S.pb->ktl[0]; pbt[31] = S.pb->ktl[1]; pbt[32] = S.pb->ktl[2]; pbt[33] = S.pb->twist ? 1.0 : 0.0;
     }
   }
   for (int k = tid; k < RT.region; k += PQA_RES_NT) region[k] = 0.0;  // (K-padding rows of the tile stay finite)
@@ -518,22 +526,26 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     const int* occs = occ + 32 * s;
     const bool ident = (s ? S.occ_ident[1] : S.occ_ident[0]) != 0;
     const int oc = occs[r];
+    const int ncol = CX ? 2 * n : n;  // doubles per inverse row (complex: (re, im) pairs — 16 electrons of a spin at most)
+    const int nh = CX ? nmo / 2 : nmo;  // orbitals (complex: the rows are [re block | im block])
     // ---- the transposed inverse of this spin: row r of walker wl
     double t[32];
 #pragma unroll
     for (int k8 = 0; k8 < 4; ++k8) {
 #pragma unroll
       for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {  // (unconditional loads of clamped addresses: a branch per element otherwise)
-        double v = Tg[((size_t)(r < n ? r : 0) * n + (k < n ? k : 0)) * W];
+        double v = Tg[((size_t)(r < n ? r : 0) * ncol + (k < ncol ? k : 0)) * W];
         asm volatile("" : "+v"(v));
-        t[k] = (r < n && k < n) ? v : 0.0;
+        t[k] = (r < n && k < ncol) ? v : 0.0;
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     int selr = (r < n) ? (int)sels[(size_t)r * W + wg] : 0;  // slot of electron r's cached row
     if (r == 0) {  // per-walker scalars of this spin's sweep live in LDS (wsc 10..12: sign, log, running product of |ratio|)
-      ws[10] = (s ? L.dsign[1] : L.dsign[0])[wg]; ws[11] = (s ? L.dlog[1] : L.dlog[0])[wg]; ws[12] = 1.0;
+      const double* dsg = s ? L.dsign[1] : L.dsign[0];
+      if (CX) { ws[10] = dsg[2 * wg]; ws[19] = dsg[2 * wg + 1]; } else ws[10] = dsg[wg];  // (complex: the determinant's phase)
+      ws[11] = (s ? L.dlog[1] : L.dlog[0])[wg]; ws[12] = 1.0;
     }
 
 #pragma unroll 1
@@ -551,15 +563,21 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       double* ws = wsc + wl * PQA_RES_WS;
       double* rn = part + (size_t)KW * 16 * PS + (size_t)wl * PQA_RES_RS;
       const int oc = occs[r];
-      double ro[4] = {0.0, 0.0, 0.0, 0.0}, uacc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+      double ro[CX ? 8 : 4], uacc = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < (CX ? 8 : 4); ++q) ro[q] = 0.0;
       double p0 = 1.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;  // Slater sums at the proposal of electron i
+      double q0i = 0.0, q1i = 0.0, q2i = 0.0, q3i = 0.0;  // (complex: their imaginary parts)
       // loads the decision / the next proposal need (cached row of electron i + 1, tape entries): issued behind the AO phase, used
       // after the contraction
       auto prefetch = [&]() {
         if (i + 1 < n) {
           const int slot = __shfl(selr, (lane & 32) | (i + 1), 64);
           const double* row = rcs + (((size_t)(i + 1) * 2 + slot) * W + wg) * 5 * nmo;
-          if (r < n) { ro[0] = row[oc]; ro[1] = row[nmo + oc]; ro[2] = row[2 * nmo + oc]; ro[3] = row[3 * nmo + oc]; }
+          if (r < n) {
+            ro[0] = row[oc]; ro[1] = row[nmo + oc]; ro[2] = row[2 * nmo + oc]; ro[3] = row[3 * nmo + oc];
+            if (CX) { ro[4] = row[nh + oc]; ro[5] = row[nmo + nh + oc]; ro[6] = row[2 * nmo + nh + oc]; ro[7] = row[3 * nmo + nh + oc]; }
+          }
           const double* zt = mb.gauss + ((size_t)(e + 1) * W + wg) * 3;
           g0 = zt[0]; g1 = zt[1]; g2 = zt[2];
         }
@@ -579,9 +597,15 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           // work of k_pbc_prepass, in the block): candidates from the pre-tabulated near / membership masks, a distance test each,
           // indices into the pair's LDS list.  Pairs the lists cannot hold (no mask table, more images than a list holds) are flagged 255 and
           // take the direct tests of shell_eval_pbc; 254: the list is too short, the pair's shells walk the candidate masks themselves.
-          const double ppx = wsc[pl * PQA_RES_WS], ppy = wsc[pl * PQA_RES_WS + 1], ppz = wsc[pl * PQA_RES_WS + 2];
+          const int po = (CX && RT.twist) ? 16 : 0;  // (twisted: the folded copy of the proposal)
+          const double ppx = wsc[pl * PQA_RES_WS + po], ppy = wsc[pl * PQA_RES_WS + po + 1], ppz = wsc[pl * PQA_RES_WS + po + 2];
           for (int a = grp; a < S.natom; a += 32) {
             const ResPair c = res_pair_base(pbt, pbi, a, ppx, ppy, ppz, at_xyz[3 * a], at_xyz[3 * a + 1], at_xyz[3 * a + 2]);
+            if (CX && RT.twist) {  // exp(i k_t . f . lattice) of the fold of point - atom (pbc_ctx_base)
+              double sf_, cf_;
+              sincos(c.f0 * pbt[30] + c.f1 * pbt[31] + c.f2 * pbt[32], &sf_, &cf_);
+              pcs[(a * 16 + pl) * 2] = cf_; pcs[(a * 16 + pl) * 2 + 1] = sf_;
+            }
             int n = 0;
             unsigned long long m0 = 0ull, m1 = 0ull;
             const int ncl = at_int[3 * a + 1];
@@ -651,7 +675,8 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           const int row_base = RT.pass_row0[ps], nks = (RT.pass_row0[ps + 1] - row_base) >> 2;
           if (ps > 0) res_block_sync();  // the previous pass's MFMA reads of the tile are done
           {
-            const double px = wsc[pl * PQA_RES_WS], py = wsc[pl * PQA_RES_WS + 1], pz = wsc[pl * PQA_RES_WS + 2];
+            const int po1 = (PBC && CX && RT.twist) ? 16 : 0;
+            const double px = wsc[pl * PQA_RES_WS + po1], py = wsc[pl * PQA_RES_WS + po1 + 1], pz = wsc[pl * PQA_RES_WS + po1 + 2];
 #ifndef PQA_RES_ABL_NOAO
 #ifdef PQA_RES_CLK
             unsigned long long c_a = 0, c_b = 0, c_c = 0, n_sh = 0, n_im = 0;
@@ -670,11 +695,17 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                   double* tl = region + (size_t)krow * 16 + pl;
                   // (the lattice sum accumulates in the tile: 15-25 running sums in registers beside the inverse row end up in scratch —
                   // tried, 39 k -> 62 k cycles for thread 0's three shells)
+                  const bool tw = CX && RT.twist;
+                  double* tli = tl + (size_t)RT.im_off * 16;  // twisted: the imaginary rows of the shell
 #pragma unroll
                   for (int m = 0; m < 2 * LMAX + 1; ++m)
                     if (m < 2 * l_ + 1) {
                       tl[(size_t)m * 16] = 0.0; tl[((size_t)KT + m) * 16] = 0.0; tl[((size_t)2 * KT + m) * 16] = 0.0; tl[((size_t)3 * KT + m) * 16] = 0.0;
                       tl[((size_t)4 * KT + m) * 16] = 0.0;
+                      if (tw) {
+                        tli[(size_t)m * 16] = 0.0; tli[((size_t)KT + m) * 16] = 0.0; tli[((size_t)2 * KT + m) * 16] = 0.0; tli[((size_t)3 * KT + m) * 16] = 0.0;
+                        tli[((size_t)4 * KT + m) * 16] = 0.0;
+                      }
                     }
                   // (the five component planes as restrict pointers: the compiler could not tell that tl + c KT 16 are different addresses and
                   // ran the 5 (2 l + 1) read-add-write sequences of an image one after the other)
@@ -683,11 +714,26 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                   double* __restrict__ pl2 = tl + (size_t)2 * KT * 16;
                   double* __restrict__ pl3 = tl + (size_t)3 * KT * 16;
                   double* __restrict__ pl4 = tl + (size_t)4 * KT * 16;
-                  auto add_image = [&](double xj, double yj, double zj) __attribute__((always_inline)) {
+                  double* __restrict__ qi0 = tli;
+                  double* __restrict__ qi1 = tli + (size_t)KT * 16;
+                  double* __restrict__ qi2 = tli + (size_t)2 * KT * 16;
+                  double* __restrict__ qi3 = tli + (size_t)3 * KT * 16;
+                  double* __restrict__ qi4 = tli + (size_t)4 * KT * 16;
+                  const double cf_ = tw ? pcs[(a_ * 16 + pl) * 2] : 1.0, sf_ = tw ? pcs[(a_ * 16 + pl) * 2 + 1] : 0.0;
+                  auto add_image = [&](double xj, double yj, double zj, int j) __attribute__((always_inline)) {
+                    // twisted: exp(i k_t . (f . lattice + Ls[j])) weights the image (shell_eval_pbc, TW)
+                    const double cj = tw ? phL[2 * j] : 1.0, sj = tw ? phL[2 * j + 1] : 0.0;
+                    const double wr = cf_ * cj - sf_ * sj, wi = sf_ * cj + cf_ * sj;
                     shell_eval<5, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
                                               [&](int m, double v, double ax, double ay, double az, double lp) __attribute__((always_inline)) {
                                                 const double o0 = pl0[m * 16], o1 = pl1[m * 16], o2 = pl2[m * 16], o3 = pl3[m * 16], o4 = pl4[m * 16];
-                                                pl0[m * 16] = o0 + v; pl1[m * 16] = o1 + ax; pl2[m * 16] = o2 + ay; pl3[m * 16] = o3 + az; pl4[m * 16] = o4 + lp;
+                                                if (tw) {
+                                                  const double i0 = qi0[m * 16], i1 = qi1[m * 16], i2 = qi2[m * 16], i3 = qi3[m * 16], i4 = qi4[m * 16];
+                                                  qi0[m * 16] = i0 + wi * v; qi1[m * 16] = i1 + wi * ax; qi2[m * 16] = i2 + wi * ay; qi3[m * 16] = i3 + wi * az; qi4[m * 16] = i4 + wi * lp;
+                                                  pl0[m * 16] = o0 + wr * v; pl1[m * 16] = o1 + wr * ax; pl2[m * 16] = o2 + wr * ay; pl3[m * 16] = o3 + wr * az; pl4[m * 16] = o4 + wr * lp;
+                                                } else {
+                                                  pl0[m * 16] = o0 + v; pl1[m * 16] = o1 + ax; pl2[m * 16] = o2 + ay; pl3[m * 16] = o3 + az; pl4[m * 16] = o4 + lp;
+                                                }
                                               });
                   };
 #ifdef PQA_RES_CLK
@@ -712,7 +758,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                         const int j = 64 * half + __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
-                        if (xj * xj + yj * yj + zj * zj <= cut2) add_image(xj, yj, zj);
+                        if (xj * xj + yj * yj + zj * zj <= cut2) add_image(xj, yj, zj, j);
                       }
                     }
                     continue;
@@ -722,7 +768,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                     const int j = lst[k];
                     const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
                     if (xj * xj + yj * yj + zj * zj > scut) break;  // (class-ordered list: nothing further is inside this shell's cut-off)
-                    add_image(xj, yj, zj);
+                    add_image(xj, yj, zj, j);
 #ifdef PQA_RES_CLK
                     ++n_im;
 #endif
@@ -812,9 +858,31 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         res_wave_sync();
         PQA_RCLK(7);
         // Slater sums at the proposal: ratio and gradient rows against T[i] (zero beyond n)
+        if (CX) {
+          if (RT.twist) {  // wrap phase of the folded proposal (orbitals.py:203-213; k_row_phase): every orbital row times exp(i theta)
+            const double cs = ws[20], sn = ws[21];
+            if (r < nh) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c) {
+                const double re = rn[c * 32 + r], im = rn[c * 32 + nh + r];
+                rn[c * 32 + r] = re * cs - im * sn; rn[c * 32 + nh + r] = re * sn + im * cs;
+              }
+            }
+            res_wave_sync();
+          }
+          // complex row sums: lane r < n holds T[i][r] = (rowE[2 r], rowE[2 r + 1]) and the row's entries of ITS orbital
+          const double tr = r < n ? rowE[wl * 32 + 2 * r] : 0.0, ti = r < n ? rowE[wl * 32 + 2 * r + 1] : 0.0;
+          const double a0 = rn[oc], b0 = rn[nh + oc], a1 = rn[32 + oc], b1 = rn[32 + nh + oc];
+          const double a2 = rn[64 + oc], b2 = rn[64 + nh + oc], a3 = rn[96 + oc], b3 = rn[96 + nh + oc];
+          p0 = a0 * tr - b0 * ti; q0i = a0 * ti + b0 * tr; p1 = a1 * tr - b1 * ti; q1i = a1 * ti + b1 * tr;
+          p2 = a2 * tr - b2 * ti; q2i = a2 * ti + b2 * tr; p3 = a3 * tr - b3 * ti; q3i = a3 * ti + b3 * tr;
+          p0 = res_sum32(p0); p1 = res_sum32(p1); p2 = res_sum32(p2); p3 = res_sum32(p3);
+          q0i = res_sum32(q0i); q1i = res_sum32(q1i); q2i = res_sum32(q2i); q3i = res_sum32(q3i);
+        } else {
         const double te = rowE[wl * 32 + r];
         p0 = rn[oc] * te; p1 = rn[32 + oc] * te; p2 = rn[64 + oc] * te; p3 = rn[96 + oc] * te;
         p0 = res_sum32(p0); p1 = res_sum32(p1); p2 = res_sum32(p2); p3 = res_sum32(p3);
+        }
         PQA_RCLK(8);
       }
       const bool have_dec = i >= 0, have_prop = i + 1 < n;
@@ -822,10 +890,14 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       if (have_dec) {
         // ================= decide electron i (mc.py:124-132; dmc.py:57-70): the same numbers in all lanes of the walker
         const double npx = ws[0], npy = ws[1], npz = ws[2];
-        double hx = finite_or(p1 / p0, 0.0), hy = finite_or(p2 / p0, 0.0), hz = finite_or(p3 / p0, 0.0);
-        const double dr = p0;
+        const double dr = p0, di = q0i, m2 = CX ? dr * dr + di * di : dr * dr;
+        double hx, hy, hz;
+        if (CX) {  // Re(grad / value) = Re(grad conj(value)) / |value|^2 (lw_slater_terms)
+          const double d_ = 1.0 / m2;
+          hx = finite_or((p1 * dr + q1i * di) * d_, 0.0); hy = finite_or((p2 * dr + q2i * di) * d_, 0.0); hz = finite_or((p3 * dr + q3i * di) * d_, 0.0);
+        } else { hx = finite_or(p1 / p0, 0.0); hy = finite_or(p2 / p0, 0.0); hz = finite_or(p3 / p0, 0.0); }
         const double val = finite_or(dr, 1.0);
-        double val2 = val * val;
+        double val2 = CX ? finite_or(m2, 1.0) : val * val;
 #ifndef PQA_RES_ABL_NOJAS
         if (has_jastrow) {
           ResJ jn{0.0, 0.0, 0.0, 0.0};
@@ -855,7 +927,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           }
           const double bwd = bx * bx + by * by + bz * bz;
           double ratio = val2 * exp(jt[3 * PQA_JQ + 16] * (fwd - bwd));
-          if (DMC) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
+          if (DMC && !CX) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
           accd = ratio > uacc;
           if (DMC && r == 0) {
             const double rx = z0 + d0, ry = z1 + d1, rz = z2 + d2, r2 = rx * rx + ry * ry + rz * rz;
@@ -870,6 +942,36 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           // the row's dot product in the PQA_ROWDOT order of the lane-per-walker kernels.  Eight columns at a time (the
           // scheduling fences keep the compiler from requesting all 64 LDS operands at once)
 #ifndef PQA_RES_ABL_NOSM
+          if (CX) {
+            // complex rows: 16 (re, im) columns; the row's dot product V . T[r] in the PQA_ROWDOT order of the complex lane-per-walker
+            // kernels (quarters of the complex columns), R = T_old[i] / ratio
+            const double ir = dr / m2, ii = -di / m2;
+            double pr4[4] = {0.0, 0.0, 0.0, 0.0}, pi4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+              for (int kc = 4 * k4; kc < 4 * k4 + 4; ++kc) {
+                const int o = occs[kc];
+                const double vr = rn[o], vi = rn[nh + o];
+                pr4[k4] += vr * t[2 * kc] - vi * t[2 * kc + 1];
+                pi4[k4] += vr * t[2 * kc + 1] + vi * t[2 * kc];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            const double tmp = ((pr4[0] + pr4[1]) + pr4[2]) + pr4[3], tmi = ((pi4[0] + pi4[1]) + pi4[2]) + pi4[3];
+            const double* Re = rowE + wl * 32;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+#pragma unroll
+              for (int kc = 4 * k4; kc < 4 * k4 + 4; ++kc) {
+                const double2 e2 = *reinterpret_cast<const double2*>(Re + 2 * kc);
+                const double rr = e2.x * ir - e2.y * ii, ri = e2.x * ii + e2.y * ir;
+                t[2 * kc] = (r == i) ? rr : t[2 * kc] - (rr * tmp - ri * tmi);
+                t[2 * kc + 1] = (r == i) ? ri : t[2 * kc + 1] - (rr * tmi + ri * tmp);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
           const double inv = 1.0 / dr;
           double p4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -900,14 +1002,19 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+          }
 #endif
           PQA_RCLK(13);
           // sign and log of the determinant (per walker, in LDS; lane 0): the ratios' magnitudes as a running product, its
           // logarithm taken when it leaves [1e-60, 1e60] and at the end of the spin's sweep (log of a product = sum of logs to
           // rounding; one log per move was ~1 us)
           if (r == 0) {
-            ws[10] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
-            double lpr = ws[12] * fabs(dr);
+            const double mag = CX ? sqrt(m2) : fabs(dr);
+            if (CX) {  // phase *= ratio / |ratio|
+              const double ur = dr / mag, ui = di / mag, sr = ws[10], si = ws[19];
+              ws[10] = sr * ur - si * ui; ws[19] = sr * ui + si * ur;
+            } else ws[10] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
+            double lpr = ws[12] * mag;
             if (!(lpr > 1e-60 && lpr < 1e60)) { ws[11] += log(lpr); lpr = 1.0; }
             ws[12] = lpr;
             ws[15] += 1.0;
@@ -943,10 +1050,21 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         }
         res_wave_sync();
         PQA_RCLK(10);
-        const double te = rowE[wl * 32 + r];
-        double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
-        q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
-        double gx = finite_or(q1 / q0, 0.0), gy = finite_or(q2 / q0, 0.0), gz = finite_or(q3 / q0, 0.0);
+        double gx, gy, gz;
+        if (CX) {
+          const double tr = r < n ? rowE[wl * 32 + 2 * r] : 0.0, ti = r < n ? rowE[wl * 32 + 2 * r + 1] : 0.0;
+          double q0 = ro[0] * tr - ro[4] * ti, s0 = ro[0] * ti + ro[4] * tr, q1 = ro[1] * tr - ro[5] * ti, s1 = ro[1] * ti + ro[5] * tr;
+          double q2 = ro[2] * tr - ro[6] * ti, s2 = ro[2] * ti + ro[6] * tr, q3 = ro[3] * tr - ro[7] * ti, s3 = ro[3] * ti + ro[7] * tr;
+          q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
+          s0 = res_sum32(s0); s1 = res_sum32(s1); s2 = res_sum32(s2); s3 = res_sum32(s3);
+          const double d_ = 1.0 / (q0 * q0 + s0 * s0);
+          gx = finite_or((q1 * q0 + s1 * s0) * d_, 0.0); gy = finite_or((q2 * q0 + s2 * s0) * d_, 0.0); gz = finite_or((q3 * q0 + s3 * s0) * d_, 0.0);
+        } else {
+          const double te = rowE[wl * 32 + r];
+          double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
+          q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
+          gx = finite_or(q1 / q0, 0.0); gy = finite_or(q2 / q0, 0.0); gz = finite_or(q3 / q0, 0.0);
+        }
         const int src = (lane & 32) | ip;
         const double pox = __shfl(s ? cx[1] : cx[0], src, 64), poy = __shfl(s ? cy[1] : cy[0], src, 64), poz = __shfl(s ? cz[1] : cz[0], src, 64);
         double U0 = 0.0;
@@ -970,6 +1088,19 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
         const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
         if (r == 0) {
           double nx = pox + z0 + gx * df, ny = poy + z1 + gy * df, nz = poz + z2 + gz * df;
+          if (PBC && CX && RT.twist) {
+            // twisted cell: the walker stays unfolded (include/pyqmc_amd.h); the orbitals are tabulated inside the cell — the folded copy
+            // for the AO phase and the wrap phase exp(i k_t . wrap . lattice) of that fold (orbitals.py:203-213) beside it
+            double f0 = nx * pbt[0] + ny * pbt[3] + nz * pbt[6], f1 = nx * pbt[1] + ny * pbt[4] + nz * pbt[7], f2 = nx * pbt[2] + ny * pbt[5] + nz * pbt[8];
+            const double w0 = floor(f0), w1 = floor(f1), w2 = floor(f2);
+            f0 -= w0; f1 -= w1; f2 -= w2;
+            ws[16] = f0 * pbt[9] + f1 * pbt[12] + f2 * pbt[15];
+            ws[17] = f0 * pbt[10] + f1 * pbt[13] + f2 * pbt[16];
+            ws[18] = f0 * pbt[11] + f1 * pbt[14] + f2 * pbt[17];
+            double sn_, cs_;
+            sincos(w0 * pbt[30] + w1 * pbt[31] + w2 * pbt[32], &sn_, &cs_);
+            ws[20] = cs_; ws[21] = sn_;
+          } else
           if (PBC) {  // make_irreducible (mc.py:121, coord.py:164-178): the proposal inside the cell, the cells it crossed kept for the accept
             double f0 = nx * pbt[0] + ny * pbt[3] + nz * pbt[6], f1 = nx * pbt[1] + ny * pbt[4] + nz * pbt[7], f2 = nx * pbt[2] + ny * pbt[5] + nz * pbt[8];
             const double w0 = floor(f0), w1 = floor(f1), w2 = floor(f2);  // (fold_cell, pqa_common.hpp, on the block's copy of the cell)
@@ -992,11 +1123,15 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
       for (int k8 = 0; k8 < 4; ++k8) {
 #pragma unroll
         for (int k = 8 * k8; k < 8 * k8 + 8; ++k)
-          if (k < n) Tg[((size_t)r * n + k) * W] = t[k];
+          if (k < ncol) Tg[((size_t)r * ncol + k) * W] = t[k];
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (live && r == 0) { (s ? L.dsign[1] : L.dsign[0])[wg] = ws[10]; (s ? L.dlog[1] : L.dlog[0])[wg] = ws[11] + log(ws[12]); }
+    if (live && r == 0) {
+      double* dsg = s ? L.dsign[1] : L.dsign[0];
+      if (CX) { dsg[2 * wg] = ws[10]; dsg[2 * wg + 1] = ws[19]; } else dsg[wg] = ws[10];
+      (s ? L.dlog[1] : L.dlog[0])[wg] = ws[11] + log(ws[12]);
+    }
     __syncthreads();  // (rowE / region reads of this spin's last decision before the next spin's first proposal)
   }
   if (live) {

@@ -481,7 +481,7 @@ def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
             assert note(f"{cfg}_{W}_pre_vs_general_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-11
 
 
-@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C2", 530), ("C5", 1000)])
+@pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C2", 530), ("C5", 1000), ("C3", 1000)])
 def test_resident_sweep_against_the_launch_per_move_sweep(cfg, W, monkeypatch):
     """The resident sweep (k_sweep_res: the whole electron sweep of 16 walkers in one block — inverse rows in registers, AO tile +
     MFMA contraction + decision + Sherman-Morrison on chip, one launch per sweep) against the launch-per-move sweep (k_orb +
