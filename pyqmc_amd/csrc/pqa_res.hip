@@ -209,7 +209,12 @@ bool res_eligible(pqa_handle* h, long W) {
   if (W < h->res_min || W > h->res_max) return false;
   // periodic cells (lattice-summed AO phase in the block, round 5; 2x2x2 diamond cell, sweep alone, launches -> resident): 4.10 -> 2.71 ms at
   // 2048 walkers, 4.43 -> 2.74 at 4096, 7.56 -> 5.48 at 8192, 12.5 -> 10.9 at 16384, 17.2 -> 16.4 at 24576, even at 32768
-  if (h->S.pbc) return W <= 24576;
+  // (after the image lists were dealt to several threads per pair and the lattice sums went to ds_add_f64: DMC step 13.6 -> 12.1 ms at 4096,
+  // 43.3 -> 41.4 at 16384, 82.8 -> 82.1 at 32768)
+  // complex determinants (twisted 8-atom cell, VMC step with energy, launches -> resident): 4.29 -> 2.90 ms at 4096 walkers, 6.69 -> 5.33 at 8192,
+  // 8.57 -> 7.76 at 12288, 10.8 -> 10.2 at 16384
+  if (h->cplx) return W <= 16384;
+  if (h->S.pbc) return W <= 32768;
   return W <= 4096 || (std::max(h->nup, h->ndn) >= 16 && W <= 49152);
 }
 

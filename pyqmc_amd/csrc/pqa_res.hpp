@@ -23,9 +23,13 @@
 // measure-zero ties; the random numbers are the same Philox streams (drawn ahead by k_tile_draws), so the oracle replays apply.
 // State in and out: the lane-per-walker SoA planes (xt, Tt, two-slot row cache + selectors, dsign / dlog) — the energy kernels
 // run on them unchanged.
-// Scope: real single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin, optional two-body Jastrow factor,
-// l <= 3; open boundary conditions or (PBC) an untwisted periodic cell with real orbitals — lattice-summed AOs by direct image tests
-// inside the AO phase, minimal-image Jastrow pairs, proposals folded into the cell.  Everything else keeps the lane-per-walker sweep.
+// Scope: single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin, optional two-body Jastrow factor, l <= 3; open
+// boundary conditions or (PBC) a periodic cell — lattice-summed AOs from per-(point, atom) image lists built in the block (phase 0) and
+// accumulated in the tile with ds_add_f64 (phase 1), minimal-image Jastrow pairs, proposals folded into the cell.  CX: complex determinants
+// in periodic cells (<= 16 electrons and orbitals per spin: a row of the inverse is 16 (re, im) pairs in the same 32 registers; VMC), with or
+// without a twist — a twisted cell's tile holds the real AO rows and behind them the imaginary ones (coefficient rows [-C_im | C_re]), every
+// image weighted by exp(i k_t . (fold + L_j)), the orbital rows by the wrap phase of the folded proposal; the walkers stay unfolded.
+// Everything else keeps the lane-per-walker sweep.
 #pragma once
 #include "pqa_ao.hpp"
 #include "pqa_jastrow.hpp"
@@ -102,6 +106,7 @@ __device__ __forceinline__ double res_sum32(double v) {
 // orders goes through global memory (a thread only re-reads global data written by earlier launches), so: this wave's LDS
 // operations done, then the barrier.
 __device__ __forceinline__ void res_block_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void res_lds_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // LDS written by other lanes of the SAME wave: the hardware executes a wave's DS instructions in order; this keeps the compiler
 // from moving accesses across the point.
 __device__ __forceinline__ void res_wave_sync() {
@@ -363,6 +368,10 @@ __device__ __forceinline__ void res_image_masks(const double* __restrict__ pbt, 
   m1 = nimg <= 64 ? 0ull : (nimg >= 128 ? ~0ull : (1ull << (nimg - 64)) - 1ull);
   const unsigned long long* near_mask = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned long long*>(pbt + 27)[0]);
   const unsigned long long* memb_mask = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const unsigned long long*>(pbt + 27)[1]);
+  // (both table entries requested before either is used: two dependent round trips to L2 otherwise)
+  const unsigned long long* nm = nullptr;
+  const unsigned long long* mm = nullptr;
+  bool outside = false;
   if (near_mask) {
     const int G = pbi[11];
     const double u0 = c.x0 * pbt[0] + c.y0 * pbt[3] + c.z0 * pbt[6];
@@ -370,24 +379,26 @@ __device__ __forceinline__ void res_image_masks(const double* __restrict__ pbt, 
     const double u2 = c.x0 * pbt[2] + c.y0 * pbt[5] + c.z0 * pbt[8];
     const int g0 = min(G - 1, max(0, (int)((u0 + 0.5) * G))), g1 = min(G - 1, max(0, (int)((u1 + 0.5) * G))),
               g2 = min(G - 1, max(0, (int)((u2 + 0.5) * G)));
-    const unsigned long long* nm = near_mask + 2 * ((((size_t)a * G + g0) * G + g1) * G + g2);
-    m0 &= nm[0]; m1 &= nm[1];
+    nm = near_mask + 2 * ((((size_t)a * G + g0) * G + g1) * G + g2);
   }
   if (pbi[12]) {
     const int side = 2 * pbi[9] + 1, E = pbi[10], Tm = side + 2 * E;
     const int i0 = c.b0 + E, i1 = c.b1 + E, i2 = c.b2 + E;
-    if ((unsigned)i0 < (unsigned)Tm && (unsigned)i1 < (unsigned)Tm && (unsigned)i2 < (unsigned)Tm) {
-      const unsigned long long* mm = memb_mask + 2 * ((((size_t)mclass * Tm + i0) * Tm + i1) * Tm + i2);
-      m0 &= mm[0]; m1 &= mm[1];
-    } else { m0 = 0ull; m1 = 0ull; }
+    if ((unsigned)i0 < (unsigned)Tm && (unsigned)i1 < (unsigned)Tm && (unsigned)i2 < (unsigned)Tm)
+      mm = memb_mask + 2 * ((((size_t)mclass * Tm + i0) * Tm + i1) * Tm + i2);
+    else outside = true;
   }
+  const ulonglong2 vn = nm ? *reinterpret_cast<const ulonglong2*>(nm) : make_ulonglong2(~0ull, ~0ull);
+  const ulonglong2 vm = mm ? *reinterpret_cast<const ulonglong2*>(mm) : make_ulonglong2(~0ull, ~0ull);
+  m0 &= vn.x & vm.x; m1 &= vn.y & vm.y;
+  if (outside) { m0 = 0ull; m1 = 0ull; }
 }
 
 #ifdef PQA_RES_CLK  // timing build only: 100 MHz stamps of thread 0 of the first blocks, last move of the sweep
 static __device__ unsigned long long pqa_res_clk[64 * 16];
 static __device__ unsigned long long pqa_res_clk3[64 * 8];
-static __device__ unsigned long long pqa_res_clk2[64 * 8];  // thread 0's AO phase: cycles in [0] list header + zeroing, [1] fold, [2] walk + evaluation, [3] shells, [4] images evaluated
-#define PQA_RCLK2(k, v) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk2[blockIdx.x * 8 + (k)] = (v); } while (0)
+static __device__ unsigned long long pqa_res_clk2[64 * 16];  // thread 0's AO phase: cycles in [0] list header + zeroing, [1] fold, [2] walk + evaluation, [3] shells, [4] images evaluated
+#define PQA_RCLK2(k, v) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk2[blockIdx.x * 16 + (k)] = (v); } while (0)
 #define PQA_RCLK(k) do { if (blockIdx.x < 64 && threadIdx.x == 0) pqa_res_clk[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #else
 #define PQA_RCLK(k) do { } while (0)
@@ -599,6 +610,124 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
           // take the direct tests of shell_eval_pbc; 254: the list is too short, the pair's shells walk the candidate masks themselves.
           const int po = (CX && RT.twist) ? 16 : 0;  // (twisted: the folded copy of the proposal)
           const double ppx = wsc[pl * PQA_RES_WS + po], ppy = wsc[pl * PQA_RES_WS + po + 1], ppz = wsc[pl * PQA_RES_WS + po + 2];
+          int NS = 1;  // threads per (point, atom) pair: the largest power of two with natom NS <= 32
+          while (2 * NS * S.natom <= 32) NS *= 2;
+          if (NS > 1) {
+            // Few atoms: the pair's candidates dealt to NS threads (image j to thread j mod NS), each with its own class populations;
+            // the populations meet in LDS (the tile region is free until phase 1 zeroes its rows; the values are finite as doubles, so rows of
+            // K padding they land on still contract to zero) and every thread writes its entries at its own offsets — class by class, inside a
+            // class slice by slice.  One thread per pair was 11 of the move's 50 us in the 8-atom cell (8 of 32 lane groups busy).
+            unsigned long long* pcnt = reinterpret_cast<unsigned long long*>(region);  // [natom][16][NS], 8-bit fields
+#ifdef PQA_RES_CLK
+            const unsigned long long tA = clock64(); unsigned long long tB = tA, tC = tA, tD = tA, tE = tA;
+#endif
+            const int a = grp % S.natom, q = grp / S.natom;
+            const bool on = q < NS;
+            unsigned long long k0 = 0ull, k1 = 0ull;
+            double cx0 = 0.0, cy0 = 0.0, cz0 = 0.0;
+            if (on) {
+              const ResPair c = res_pair_base(pbt, pbi, a, ppx, ppy, ppz, at_xyz[3 * a], at_xyz[3 * a + 1], at_xyz[3 * a + 2]);
+              cx0 = c.x0; cy0 = c.y0; cz0 = c.z0;
+              if (CX && RT.twist && q == 0) {
+                double sf_, cf_;
+                sincos(c.f0 * pbt[30] + c.f1 * pbt[31] + c.f2 * pbt[32], &sf_, &cf_);
+                pcs[(a * 16 + pl) * 2] = cf_; pcs[(a * 16 + pl) * 2 + 1] = sf_;
+              }
+              unsigned long long m0 = 0ull, m1 = 0ull;
+              const int ncl = at_int[3 * a + 1];
+              res_image_masks(pbt, pbi, c, a, at_int[3 * a], at_int[3 * a + 2], m0, m1);
+#ifdef PQA_RES_CLK
+              asm volatile("" : "+v"(m0), "+v"(m1)); tB = clock64();
+#endif
+              double cut_r[PQA_RES_NCUT];
+#pragma unroll
+              for (int k = 0; k < PQA_RES_NCUT; ++k) cut_r[k] = at_cut[a * (1 + PQA_RES_NCUT) + 1 + k];
+              const double acut = at_cut[a * (1 + PQA_RES_NCUT)];
+              unsigned long long cnt = 0ull;
+              // bits j = q mod NS (NS divides 64: the same stripe in both words)
+              const unsigned long long stripe = (NS == 2 ? 0x5555555555555555ull : NS == 4 ? 0x1111111111111111ull : NS == 8 ? 0x0101010101010101ull
+                                                 : NS == 16 ? 0x0001000100010001ull : 0x0000000100000001ull) << q;
+#pragma unroll 1
+              for (int half = 0; half < 2; ++half) {
+                unsigned long long m = (half ? m1 : m0) & stripe, keep = 0ull;
+                while (m) {
+                  const int b = __ffsll((long long)m) - 1, j = 64 * half + b;
+                  m &= m - 1;
+                  const double xj = c.x0 - LsL[3 * j], yj = c.y0 - LsL[3 * j + 1], zj = c.z0 - LsL[3 * j + 2];
+                  const double r2 = xj * xj + yj * yj + zj * zj;
+                  int cls = 0;
+#pragma unroll
+                  for (int k = 0; k < PQA_RES_NCUT; ++k) cls += r2 > cut_r[k] ? 1 : 0;
+                  if (r2 > acut || cls >= ncl) continue;
+                  cnt += 1ull << (8 * cls);
+                  keep |= 1ull << b;
+                }
+                if (half) k1 = keep; else k0 = keep;
+              }
+              pcnt[((size_t)a * 16 + pl) * NS + q] = cnt;
+            }
+#ifdef PQA_RES_CLK
+            tC = clock64();
+#endif
+            res_block_sync();
+#ifdef PQA_RES_CLK
+            tD = clock64();
+#endif
+            if (on) {
+              const unsigned long long* pc = pcnt + ((size_t)a * 16 + pl) * NS;
+              int n = 0;
+              unsigned long long off = 0ull;
+              {
+                int tc[PQA_RES_NCUT], bq[PQA_RES_NCUT];
+#pragma unroll
+                for (int k = 0; k < PQA_RES_NCUT; ++k) { tc[k] = 0; bq[k] = 0; }
+                for (int q2 = 0; q2 < NS; ++q2) {  // (one LDS read per thread of the pair)
+                  const unsigned long long v = pc[q2];
+#pragma unroll
+                  for (int k = 0; k < PQA_RES_NCUT; ++k) {
+                    const int f = (int)((v >> (8 * k)) & 255);
+                    bq[k] += q2 < q ? f : 0;
+                    tc[k] += f;
+                  }
+                }
+                int run = 0;
+#pragma unroll
+                for (int k = 0; k < PQA_RES_NCUT; ++k) {
+                  off |= (unsigned long long)((run + bq[k]) & 255) << (8 * k);
+                  run += tc[k];
+                }
+                n = run;
+              }
+              if (n > RT.icap) n = 254;
+              else {
+                double cut_r[PQA_RES_NCUT];
+#pragma unroll
+                for (int k = 0; k < PQA_RES_NCUT; ++k) cut_r[k] = at_cut[a * (1 + PQA_RES_NCUT) + 1 + k];
+                unsigned char* lst = imgl + ((size_t)a * 16 + pl) * RT.icap;
+#pragma unroll 1
+                for (int half = 0; half < 2; ++half) {
+                  unsigned long long m = half ? k1 : k0;
+                  while (m) {
+                    const int j = 64 * half + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double xj = cx0 - LsL[3 * j], yj = cy0 - LsL[3 * j + 1], zj = cz0 - LsL[3 * j + 2];
+                    const double r2 = xj * xj + yj * yj + zj * zj;
+                    int cls = 0;
+#pragma unroll
+                    for (int k = 0; k < PQA_RES_NCUT; ++k) cls += r2 > cut_r[k] ? 1 : 0;
+                    const int pos = (int)((off >> (8 * cls)) & 255);
+                    off += 1ull << (8 * cls);
+                    lst[pos] = (unsigned char)j;
+                  }
+                }
+              }
+              if (q == 0) imgn[a * 16 + pl] = (unsigned char)n;
+            }
+#ifdef PQA_RES_CLK
+            tE = clock64();
+            PQA_RCLK2(5, tB - tA); PQA_RCLK2(6, tC - tB); PQA_RCLK2(7, tD - tC); PQA_RCLK2(8, tE - tD);
+#endif
+          } else
           for (int a = grp; a < S.natom; a += 32) {
             const ResPair c = res_pair_base(pbt, pbi, a, ppx, ppy, ppz, at_xyz[3 * a], at_xyz[3 * a + 1], at_xyz[3 * a + 2]);
             if (CX && RT.twist) {  // exp(i k_t . f . lattice) of the fold of point - atom (pbc_ctx_base)
@@ -726,13 +855,16 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
                     const double wr = cf_ * cj - sf_ * sj, wi = sf_ * cj + cf_ * sj;
                     shell_eval<5, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
                                               [&](int m, double v, double ax, double ay, double az, double lp) __attribute__((always_inline)) {
-                                                const double o0 = pl0[m * 16], o1 = pl1[m * 16], o2 = pl2[m * 16], o3 = pl3[m * 16], o4 = pl4[m * 16];
+                                                // ds_add_f64 without return value: one LDS operation per element instead of a dependent read / add / write; every
+                                                // address has ONE owner thread, so the order of the sum stays the program's
                                                 if (tw) {
-                                                  const double i0 = qi0[m * 16], i1 = qi1[m * 16], i2 = qi2[m * 16], i3 = qi3[m * 16], i4 = qi4[m * 16];
-                                                  qi0[m * 16] = i0 + wi * v; qi1[m * 16] = i1 + wi * ax; qi2[m * 16] = i2 + wi * ay; qi3[m * 16] = i3 + wi * az; qi4[m * 16] = i4 + wi * lp;
-                                                  pl0[m * 16] = o0 + wr * v; pl1[m * 16] = o1 + wr * ax; pl2[m * 16] = o2 + wr * ay; pl3[m * 16] = o3 + wr * az; pl4[m * 16] = o4 + wr * lp;
+                                                  res_lds_add(qi0 + m * 16, wi * v); res_lds_add(qi1 + m * 16, wi * ax); res_lds_add(qi2 + m * 16, wi * ay);
+                                                  res_lds_add(qi3 + m * 16, wi * az); res_lds_add(qi4 + m * 16, wi * lp);
+                                                  res_lds_add(pl0 + m * 16, wr * v); res_lds_add(pl1 + m * 16, wr * ax); res_lds_add(pl2 + m * 16, wr * ay);
+                                                  res_lds_add(pl3 + m * 16, wr * az); res_lds_add(pl4 + m * 16, wr * lp);
                                                 } else {
-                                                  pl0[m * 16] = o0 + v; pl1[m * 16] = o1 + ax; pl2[m * 16] = o2 + ay; pl3[m * 16] = o3 + az; pl4[m * 16] = o4 + lp;
+                                                  res_lds_add(pl0 + m * 16, v); res_lds_add(pl1 + m * 16, ax); res_lds_add(pl2 + m * 16, ay);
+                                                  res_lds_add(pl3 + m * 16, az); res_lds_add(pl4 + m * 16, lp);
                                                 }
                                               });
                   };

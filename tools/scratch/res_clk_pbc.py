@@ -12,8 +12,12 @@ from tests import helpers
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 from pyqmc_amd import pbc as _pbc
-mol = _pbc.get_supercell(systems.diamond_primitive(), 2.0 * np.eye(3))
-wf = pa.generate_wf(mol, _pbc.random_kmf(mol))
+if len(sys.argv) > 2 and sys.argv[2] == "c3":  # twisted conventional cell, complex orbitals
+    mol = _pbc.get_supercell(systems.diamond_primitive(), np.array([[-1.0, 1, 1], [1, -1, 1], [1, 1, -1]]))
+    wf = pa.generate_wf(mol, _pbc.random_kmf(mol, complex_coeff=True, twist=(0.25, 0.1, -0.3)))
+else:
+    mol = _pbc.get_supercell(systems.diamond_primitive(), 2.0 * np.eye(3))
+    wf = pa.generate_wf(mol, _pbc.random_kmf(mol))
 dev = wf.fused_device()
 wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(1)))
 dev.vmc_sweeps(0.3, 3, seed=5, energy=False)
@@ -40,10 +44,11 @@ for k, name in [(10, "rowE handed over"), (11, "Slater sums"), (12, "Jastrow at 
     d = (c[:, k] - c[:, 10 if k != 10 else k]) / 100.0
     print("%-36s at %6.2f us after the hand-over" % (name, d.mean()))
 
-b2 = (ctypes.c_ulonglong * (64 * 8))()
+b2 = (ctypes.c_ulonglong * (64 * 16))()
 lib.pqa_debug_res_clk2.argtypes = [ctypes.c_void_p, ctypes.c_int]
-if lib.pqa_debug_res_clk2(b2, 64 * 8) == 0:
-    q = np.array(b2[:], dtype=np.float64).reshape(64, 8)[: len(c)]
+if lib.pqa_debug_res_clk2(b2, 64 * 16) == 0:
+    q = np.array(b2[:], dtype=np.float64).reshape(64, 16)[: len(c)]
+    print("thread 0's phase 0 (pairs dealt to several threads), shader cycles: fold + masks %.0f, first walk %.0f, barrier %.0f, offsets + second walk %.0f" % tuple(q[:, k].mean() for k in range(5, 9)))
     print("thread 0's phase 1, shader cycles (mean over blocks): header+zeroing %.0f, fold %.0f, walk+evaluation %.0f; shells %.1f, images evaluated %.1f" % tuple(q[:, k].mean() for k in range(5)))
 
 b3 = (ctypes.c_ulonglong * (64 * 8))()
