@@ -405,6 +405,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
   if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_CX")) h->res_cx = atoi(rs);
+  if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);
   if (const char* rs = getenv("PQA_RES_MIN")) h->res_min = atol(rs);
   if (const char* rs = getenv("PQA_RES_MAX")) h->res_max = atol(rs);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);

@@ -218,6 +218,12 @@ __device__ __forceinline__ double dpp_add(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
   return v + __hiloint2double(hi, lo);  // lanes whose source is out of range / row-masked add +0.0
 }
+// Synchronisation inside the wave-per-walker device functions (slater_ratios, sm_update_wave, jas3_eval: one wave works on one walker
+// through its own LDS scratch).  In blocks whose waves all run the same function it is the block barrier; pqa_sweep_ww.hip — three
+// waves of a block running DIFFERENT functions of one move — defines it as a wave-level fence before including the headers.
+#ifndef PQA_WSYNC
+#define PQA_WSYNC() __syncthreads()
+#endif
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add<0x111, 0xf>(v);  // row_shr:1   inclusive scan inside each row of 16 lanes
   v = dpp_add<0x112, 0xf>(v);  // row_shr:2

@@ -180,6 +180,11 @@ struct pqa_handle {
   bool pbc_lists_ok = false;
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
+  // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
+  // 3 always with three waves per walker (measured slower).  50-determinant water molecule, VMC step with energy, launches -> one
+  // launch: 0.722 -> 0.663 ms at 1 024 walkers, 0.884 -> 0.801 at 2 048, 1.428 -> 1.382 at 4 096, 2.25 -> 2.38 at 8 192
+  int ww_mode = -1;
+  long ww_max = 4096;
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
   // density-matrix sampling (pqa_dm.hpp): per slot the auxiliary walkers (position, orbital row, density), the kept samples
   // and the orbitals at the configurations' electrons; accumulators of the estimator in dm_val / dm_norm
@@ -323,6 +328,9 @@ void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, lo
 bool res_eligible(pqa_handle* h, long W);
 int sweep_res(pqa_handle* h, const MoveBuf& mb);
 int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host);  // (pqa_res.hip: dense coefficient copy follows set_mo)
+// pqa_sweep_ww.hip
+bool ww_eligible(pqa_handle* h, long W);
+int sweep_ww(pqa_handle* h, const MoveBuf& mb);
 // pqa_tile.hip
 bool tile_eligible(const pqa_handle* h);
 int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);

@@ -268,7 +268,7 @@ __device__ __forceinline__ void jas3_eval_n(const SysDev& S, const double* __res
           row[o] = e0; row[o + nlm] = eg; row[o + 2 * nlm] = el;
         }
   }
-  __syncthreads();
+  PQA_WSYNC();
   double u = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0;
   // Phase 2, one (partner electron j, ion I) term: a_l(r_jI) against the contracted tables of ion I and the b-functions of the pair
   auto pair_ion = [&](int I, int sp, double jx, double jy, double jz, double dx, double dy, double dz, const double (&bv)[NB3],
@@ -325,7 +325,7 @@ __device__ __forceinline__ void jas3_eval_n(const SysDev& S, const double* __res
   if (MODE <= 1) U += wave_sum(u);
   if (MODE >= 1) { g[0] += wave_sum(gx); g[1] += wave_sum(gy); g[2] += wave_sum(gz); }
   if (MODE == 2) lapU += wave_sum(lp);
-  __syncthreads();
+  PQA_WSYNC();
 }
 
 // The usual three-body expansions have at most four functions per kind: the arrays and unrolled loops of that instantiation are

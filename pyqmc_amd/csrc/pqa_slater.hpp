@@ -231,7 +231,7 @@ __device__ __forceinline__ void slater_ratios(const SysDev& S, const SlaterState
       if (lane == 0) scratch[d * NCOMP + c] = r;
     }
   }
-  __syncthreads();
+  PQA_WSYNC();
   const double ref = det_ref(S, st, w);
   double num[NCOMP], den = 0.0;
 #pragma unroll
@@ -246,7 +246,7 @@ __device__ __forceinline__ void slater_ratios(const SysDev& S, const SlaterState
   den = wave_sum(den);
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) out[c] = wave_sum(num[c]) / den;
-  __syncthreads();
+  PQA_WSYNC();
 }
 
 // out (NCOMP, nrow*npt); mo rows [(r*npt+q)][NCOMP][nmo]; dynamic LDS: max(ndet_s)*NCOMP doubles
@@ -276,8 +276,10 @@ static __global__ __launch_bounds__(64) void k_slater_eval(SysDev S, SlaterState
 // The n x n tile is staged global -> LDS with coalesced 512-B wave accesses (row stride n+1, odd, so
 // the row-per-lane accesses below are bank-conflict free); every row is split over R = 64/n lane
 // groups so all 64 lanes work for n <= 32.  LDS: n(n+1) + 2n + 64 doubles.
+// dpart / dparts: this wave updates the passes dpart, dpart + dparts, ... of the small-determinant branch (n <= 8; the fused
+// wave-per-walker sweep deals a walker's determinants to its three waves); elsewhere every determinant (dparts 1).
 __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterState& st, int s, int i, long w,
-                                               const double* __restrict__ morow, double* lds) {
+                                               const double* __restrict__ morow, double* lds, int dpart = 0, int dparts = 1) {
   const int lane = threadIdx.x & 63;
   const int n = s ? S.ndn : S.nup, D = S.ndet_s[s], ld = n + 1;
   if (n <= 8) {
@@ -288,7 +290,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
     // sequential sum of the n rounded products).
     const int GS = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)), E = GS * GS, DP = 64 / E;
     const int g = lane / E, r = (lane & (E - 1)) / GS, c = lane & (GS - 1);
-    for (int d0 = 0; d0 < D; d0 += DP) {
+    for (int d0 = dpart * DP; d0 < D; d0 += DP * dparts) {
       const int d = d0 + g;
       const bool act = d < D && r < n && c < n;
       double* Tw = st.T[s] + ((size_t)w * D + (d < D ? d : 0)) * n * n;
@@ -310,6 +312,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
     }
     return;
   }
+  if (dpart != 0) return;  // (the branches below work on one determinant at a time through the wave's LDS tile: one wave does them all)
   if (n > PQA_MAXN_FAST) {
     // More than 64 electrons of this spin: the tile does not fit the staging scheme below (one lane per row, n (n + 1) doubles of
     // LDS), so the update runs on the inverse where it lies: one wave sum per row for tmp, then the rank-1 update row by row.
@@ -321,17 +324,17 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
       double* Tw = st.T[s] + ((size_t)w * D + d) * n * n;
       const int* occ = S.det_occ[s] + (size_t)d * n;
       for (int k = lane; k < n; k += 64) V[k] = morow[occ[k]];
-      __syncthreads();
+      PQA_WSYNC();
       for (int j = 0; j < n; ++j) {
         double p = 0.0;
         for (int k = lane; k < n; k += 64) p += V[k] * Tw[(size_t)j * n + k];
         p = wave_sum(p);
         if (lane == 0) TMP[j] = p;
       }
-      __syncthreads();
+      PQA_WSYNC();
       const double ratio = TMP[i];
       for (int k = lane; k < n; k += 64) Rr[k] = Tw[(size_t)i * n + k] / ratio;
-      __syncthreads();
+      PQA_WSYNC();
       for (int j = 0; j < n; ++j) {
         const double tj = TMP[j];
         if (j == i) { for (int k = lane; k < n; k += 64) Tw[(size_t)j * n + k] = Rr[k]; }
@@ -342,7 +345,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
         st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);
         st.dlog[s][o] += log(fabs(ratio));
       }
-      __syncthreads();
+      PQA_WSYNC();
     }
     return;
   }
@@ -368,20 +371,20 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
       }
     }
     for (int k = lane; k < n; k += 64) V[k] = morow[occ[k]];
-    __syncthreads();
+    PQA_WSYNC();
     double tmp = 0.0;
     if (active) {
       const double* Lr = L + row * ld;
       for (int k = kb; k < ke; ++k) tmp += V[k] * Lr[k];
       Pt[part * n + row] = tmp;
     }
-    __syncthreads();
+    PQA_WSYNC();
     tmp = 0.0;
     if (active)
       for (int q = 0; q < R; ++q) tmp += Pt[q * n + row];  // same order in every lane group: bitwise equal
     const double ratio = __shfl(tmp, i, 64);               // lane i is (part 0, row i)
     if (lane < n) Rr[lane] = L[i * ld + lane] / ratio;     // inv_ratio[k] = inv[k][i] / ratio
-    __syncthreads();
+    PQA_WSYNC();
     if (active) {
       double* Lr = L + row * ld;
       if (row == i) {
@@ -390,7 +393,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
         for (int k = kb; k < ke; ++k) Lr[k] -= Rr[k] * tmp;
       }
     }
-    __syncthreads();
+    PQA_WSYNC();
     {
       int r = part, c = row;
       for (int idx = lane; idx < n * n; idx += 64) {
@@ -404,7 +407,7 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
       st.dsign[s][o] *= (ratio > 0.0) ? 1.0 : ((ratio < 0.0) ? -1.0 : ratio);  // np.sign (0 and nan propagate)
       st.dlog[s][o] += log(fabs(ratio));
     }
-    __syncthreads();
+    PQA_WSYNC();
   }
 }
 

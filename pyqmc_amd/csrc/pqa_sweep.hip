@@ -330,6 +330,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
 int sweep_electrons(pqa_handle* h, const MoveBuf& mb, bool lw, const LwCtx& lc) {
   if (lw) return sweep_electrons_fused(h, mb, lc);
   const long W = h->W;
+  if (ww_eligible(h, W)) return sweep_ww(h, mb);  // small shards: the whole sweep of a walker in one launch, three waves per walker (pqa_ww.hpp)
   const size_t lds_acc = std::max(lds_sm(h), lds_det(h, 5));
   for (int e = 0; e < h->N; ++e) {
     const int s = e >= h->nup;

@@ -516,6 +516,39 @@ def test_resident_sweep_against_the_launch_per_move_sweep(cfg, W, monkeypatch):
             assert note(f"{cfg}_{W}_resident_vs_launches_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-10
 
 
+@pytest.mark.parametrize("cfg,W,ww_mode", [("C4", 2048, "1"), ("C4", 77, "1"), ("C4", 300, "3")])
+def test_one_launch_wave_per_walker_sweep_against_the_launches(cfg, W, ww_mode, monkeypatch):
+    """The wave-per-walker sweep in one launch (k_sweep_ww; PQA_WW=1: one wave per walker, =3: three waves per walker — Slater terms, two-body
+    Jastrow, three-body Jastrow side by side, the determinants' Sherman-Morrison updates dealt to the waves; the proposal's orbital row
+    evaluated by the block itself)
+    against k_propose -> orbital kernel -> k_accept per move, on the 50-determinant water molecule with a three-body Jastrow factor: the
+    same Philox streams and the same device functions, only the orbital row's contraction sums in another order.  Every Metropolis decision
+    equal; walkers, log-values, energies and the DMC step's statistics equal to rounding; the updated state equal to a fresh recompute."""
+    import pyqmc_amd as pa
+
+    outs = []
+    for ww in ("0", ww_mode):
+        monkeypatch.setenv("PQA_WW", ww)  # read when the handle is created
+        mol, wf, _, _ = build(cfg)
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(11)))
+        acc, en, rec = dev.vmc_sweeps(0.3, 3, seed=21, energy=True, record=True)
+        x = dev.configs()
+        out = {"rec": rec, "x": x, "logv": dev.value()[1], "en": np.asarray(en), "acc": np.asarray(acc)}
+        out["upd"] = float(np.max(np.abs(dev.recompute(x)[1] - out["logv"])))
+        w = np.ones(W)
+        et = float(np.real(en[-1][5]))
+        avg, dacc = dev.dmc_steps(0.02, 2, w, 10.0, et, et, seed=5)
+        out.update(x2=dev.configs(), avg=avg.copy(), dacc=dacc.copy(), w=w.copy())
+        outs.append(out)
+    a, b = outs
+    assert np.array_equal(a["rec"], b["rec"]) and np.array_equal(a["acc"], b["acc"]) and np.array_equal(a["dacc"], b["dacc"])
+    assert note(f"{cfg}_{W}_one_launch{ww_mode}_update_vs_recompute", b["upd"]) < 1e-9
+    for k in a:
+        if k not in ("rec", "acc", "dacc", "upd"):
+            assert note(f"{cfg}_{W}_one_launch{ww_mode}_vs_launches_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-10
+
+
 def test_periodic_resident_sweep_with_short_image_lists(monkeypatch):
     """The periodic resident sweep keeps the admitted images of a (point, atom) pair in an LDS list (32 entries in the 2x2x2 diamond cell,
     where a pair has 13 at most); a pair with more walks the candidate masks itself.  With the lists cut to 6 entries most diffuse pairs
