@@ -66,11 +66,19 @@ __device__ __forceinline__ double exp_neg(double x) {
 #define PQA_PRIM_CUT 50.0
 
 // p-th point lives at base + (p / group) * group_stride + (p % group) * 3
+// count (optional): the number of points lives on the device — the launch covers an upper bound P and the blocks beyond *count leave at
+// once (the ECP point lists of small shards: sizing the launch from the host costs a device -> host round trip per energy evaluation)
 struct PointAddr {
   const double* base;
   int group;
   long group_stride;
+  const long* count = nullptr;
 };
+__device__ __forceinline__ long point_count(const PointAddr& a, long P) {
+  if (!a.count) return P;
+  const long c = *a.count;
+  return c < P ? c : P;
+}
 __device__ __forceinline__ void load_point(const PointAddr& a, long p, double& x, double& y, double& z) {
   const double* q = a.base + (p / a.group) * a.group_stride + (p % a.group) * 3;
   x = q[0]; y = q[1]; z = q[2];
@@ -710,6 +718,8 @@ __device__ __forceinline__ double* orb_out(const ChunkTab& T, double* out, long 
 template <int NCOMP, int NT, int KC, int TP, bool LDSTAB, int PBC = 0>
 static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                              double* __restrict__ out) {
+  P = point_count(pa, P);
+  if ((long)blockIdx.x * TP >= P) return;
   constexpr int G = 256 / TP;                         // lane groups in phase 1
   constexpr int NU = (TP == 64) ? NT : ((TP == 32) ? (NT + 1) / 2 : (NT + 3) / 4);  // orbital tiles per wave in phase 2
   constexpr int KS = KC / 4;
@@ -913,6 +923,8 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
 template <int NCOMP, int NT, int KC>
 static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int spin, PointAddr pa, long P,
                                                 double* __restrict__ out) {
+  P = point_count(pa, P);
+  if ((long)blockIdx.x * 64 >= P) return;
   constexpr int KS = KC / 4;
   __shared__ double tile[2][NCOMP][KC][64];
   // basis tables staged once per block: the producer loop then never waits on dependent global/scalar

@@ -406,6 +406,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_CX")) h->res_cx = atoi(rs);
   if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);
+  if (const char* rs = getenv("PQA_ECP_DEFER")) h->ecp_defer = atoi(rs);
+  if (const char* rs = getenv("PQA_EN_OVERLAP")) h->en_overlap = atoi(rs);
   if (const char* rs = getenv("PQA_RES_MIN")) h->res_min = atol(rs);
   if (const char* rs = getenv("PQA_RES_MAX")) h->res_max = atol(rs);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
@@ -760,6 +762,8 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     TRY(upload_table(h, na.data(), na.size(), &h->d_ecp_naip));
     TRY(upload_table(h, qo.data(), qo.size(), &h->d_ecp_qoff));
     S.ecp_naip = h->d_ecp_naip; S.ecp_qoff = h->d_ecp_qoff;
+    S.ecp_naip_max = 0;
+    for (int k = 0; k < h->necp; ++k) S.ecp_naip_max = std::max(S.ecp_naip_max, na[k]);
   }
   {  // flat (atom, quadrature index) list of the T-move candidates of one electron
     std::vector<int> ptk, pti;
@@ -818,6 +822,9 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (hipStream_t s : h->jas_stream)
     if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   if (h->b_jpre.p) (void)hipFree(h->b_jpre.p);
+  if (h->en_stream) { (void)hipStreamSynchronize(h->en_stream); (void)hipStreamDestroy(h->en_stream); }
+  for (hipEvent_t e : h->en_ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -2050,12 +2057,21 @@ extern "C" int pqa_set_ecp_naip(pqa_handle_t* h, int32_t naip) {
     qo[k] = ecp_quadrature_offset(na[k]);
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->S.ecp_naip_max = 0;
+  for (int k = 0; k < h->necp; ++k) h->S.ecp_naip_max = std::max(h->S.ecp_naip_max, na[k]);
   HIPCHK(hipMemcpy(h->d_ecp_naip, na.data(), na.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(h->d_ecp_qoff, qo.data(), qo.size() * sizeof(int), hipMemcpyHostToDevice));
   h->ecp_naip = naip;
   return 0;
 }
 extern "C" int pqa_last_ecp_points(pqa_handle_t* h, int64_t* npoints) {
+  if (h->last_ecp_points < 0 && h->last_ecp_dev[0]) {  // the last evaluation left its totals on the device (pqa_energy.hip)
+    HIPCHK(hipSetDevice(h->device));
+    long t[2];
+    TRY(copy_in(h, &t[0], h->last_ecp_dev[0], sizeof(long)));
+    TRY(copy_out(h, &t[1], h->last_ecp_dev[1], sizeof(long)));
+    h->last_ecp_points = t[0] + t[1];
+  }
   *npoints = h->last_ecp_points;
   return 0;
 }

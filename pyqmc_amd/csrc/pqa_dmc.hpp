@@ -139,6 +139,29 @@ static __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, 
   if (i == 0) { o[n] = tile_off[nt]; marks[n / W] = tile_off[nt]; }
 }
 
+// The same scans for small inputs in ONE launch: two count arrays of n <= 16384 entries each (the ECP point counts of the two spin channels of
+// a small shard), one block; o0 / o1 get n + 1 entries (exclusive prefix, total last).  Three launches per array were 45 us of a 0.8 ms step.
+template <int PQA_UNIT = 0>
+static __global__ __launch_bounds__(1024) void k_scan_small2(const int* __restrict__ c0, long* __restrict__ o0, const int* __restrict__ c1,
+                                                             long* __restrict__ o1, long n) {
+  __shared__ long part[2][1024];
+  const long per = (n + 1023) / 1024;
+  const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
+  long s0 = 0, s1 = 0;
+  for (long i = b; i < e; ++i) { s0 += c0[i]; s1 += c1[i]; }
+  part[0][threadIdx.x] = s0; part[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the per-thread sums (integers: any order is exact)
+    const long a0 = (int)threadIdx.x >= d ? part[0][threadIdx.x - d] : 0, a1 = (int)threadIdx.x >= d ? part[1][threadIdx.x - d] : 0;
+    __syncthreads();
+    part[0][threadIdx.x] += a0; part[1][threadIdx.x] += a1;
+    __syncthreads();
+  }
+  long r0 = part[0][threadIdx.x] - s0, r1 = part[1][threadIdx.x] - s1;
+  for (long i = b; i < e; ++i) { o0[i] = r0; r0 += c0[i]; o1[i] = r1; r1 += c1[i]; }
+  if (threadIdx.x == 1023) { o0[n] = part[0][1023]; o1[n] = part[1][1023]; }
+}
+
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).
 // grid = (W, N), block = 64.
 template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)

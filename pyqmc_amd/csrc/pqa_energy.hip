@@ -3,9 +3,11 @@
 #include "pqa_internal.hpp"
 
 int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-               bool soa_current, bool aos_T_needed) {
+               bool soa_current, bool aos_T_needed, bool assemble) {
   const long W = h->W;
   bool soa_T = false;
+  struct Side { pqa_handle* h = nullptr; hipStream_t main = nullptr; ~Side() { if (h) h->stream = main; } } side;  // (launches go to h->stream: restored on every exit)
+  bool side_join = false;
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
   if (soa_current) {
@@ -28,6 +30,19 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       else TRY(lw_to_aos(h, false));
     }
   } else {
+    // small shards with ECPs: the kinetic / Coulomb pass on a side stream beside the ECP passes — both are a few thousand latency-bound waves
+    // (50-determinant water molecule, 2 048 walkers: 125 us and 245 us one after the other)
+    if (h->necp > 0 && h->en_overlap && W * h->N <= 32768) {
+      if (!h->en_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->en_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->en_ev[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->en_ev[1], hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(h->en_ev[0], h->stream));
+      HIPCHK(hipStreamWaitEvent(h->en_stream, h->en_ev[0], 0));
+      side.main = h->stream; side.h = h;
+      h->stream = h->en_stream;
+    }
     {  // four waves per walker while the launch is too small to fill the chip with one
       const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
       const size_t st_ = (size_t)(h->cplx ? 2 : 1) * lds_det(h, 5);
@@ -48,6 +63,12 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     hipLaunchKernelGGL((k_ewald<>), dim3((unsigned)W), dim3(PQA_EWALD_T), lds_ew, h->stream, h->S, h->ew, x,
                        soa ? 1L : (long)h->N * 3, soa ? 3 * W : 3L, soa ? W : 1L, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_ewald"));
+  }
+  if (side.h) {  // the ECP passes go on in the caller's stream; k_energy_assemble waits for the side stream
+    HIPCHK(hipEventRecord(h->en_ev[1], h->stream));
+    h->stream = side.main;
+    side.h = nullptr;
+    side_join = true;
   }
   const double* d_ecp = nullptr;
   h->last_ecp_points = 0;
@@ -86,6 +107,8 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     B.ue = (soa_current && h->has_j2) ? (const double*)h->b_kpart.p + (size_t)4 * h->N * W : nullptr;  // k_kinetic_lw left U_e there
     const dim3 g_t((unsigned)((W + PQA_ECP_WB - 1) / PQA_ECP_WB)), b_t(64 * PQA_ECP_WB);
     long tot[2];
+    bool defer = false;  // totals stay on the device (below)
+    const long* cnt_dev[2] = {nullptr, nullptr};
     EcpbArgs A{};
     if (batched) {  // every (walker, electron) has ecpb_nsel slots: no counting pass, no scan (pqa_ecpb.hpp)
       A.naip = h->d_ecpb_naip; A.qoff = h->d_ecpb_qoff; A.pstart = h->d_ecpb_pstart;
@@ -105,15 +128,37 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     } else
     if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
-    // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers)
-    TRY(ensure(h, h->b_tmmarks, 4 * sizeof(long)));
-    TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
-    TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
-    TRY(check_launch(h, "k_ecp_count/k_scan2"));
-    TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
-    TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
+    // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers; small shards: one launch)
+    if (nsw <= 16384) hipLaunchKernelGGL((k_scan_small2<>), dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw);
+    else {
+      TRY(ensure(h, h->b_tmmarks, 4 * sizeof(long)));
+      TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
+      TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
     }
-    h->last_ecp_points = tot[0] + tot[1];
+    TRY(check_launch(h, "k_ecp_count/k_scan2"));
+    // Small shards whose accumulation pass reads the list offsets from the device anyway (k_ecp_accum): no device -> host round trip for the
+    // totals (two copies and the host's wake-up: ~80 us of a 0.8 ms step).  The lists are sized for every point of every ECP atom, the orbital
+    // launch covers that bound and its blocks beyond the device-side count leave at once (PointAddr::count); the kernel choice follows the totals
+    // of the last evaluation that did read them (every 16th does).
+    {
+      const bool accum_path = h->cplx ? !(soa_current && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_point_lw)
+                                      : !(h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0);
+      const long pmax = (long)h->necp * std::max(h->S.ecp_naip_max, 1);  // quadrature points of one electron over all ECP atoms, at most
+      const long ub0 = W * (long)h->nup * pmax, ub1 = W * (long)h->ndn * pmax;
+      defer = h->ecp_defer != 0 && accum_path && !h->S.pbc && h->ecp_hint_valid && (h->ecp_evals % 16) != 0 &&
+              (ub0 + ub1) * (long)(64 + 8 * std::max(h->nmo[0], h->nmo[1])) <= (long)256 << 20;
+      if (defer) { tot[0] = ub0; tot[1] = ub1; }
+      else {
+        TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
+        TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
+        h->ecp_hint[0] = tot[0]; h->ecp_hint[1] = tot[1]; h->ecp_hint_valid = true;
+      }
+      ++h->ecp_evals;
+      cnt_dev[0] = B.off + nsw; cnt_dev[1] = B.off + (nsw + 1) + nsw;
+    }
+    }
+    h->last_ecp_points = defer ? -1 : tot[0] + tot[1];
+    h->last_ecp_dev[0] = defer ? cnt_dev[0] : nullptr; h->last_ecp_dev[1] = defer ? cnt_dev[1] : nullptr;
     for (int s = 0; s < 2; ++s) {
       const size_t n = (size_t)std::max<long>(tot[s], 1);
       TRY(ensure(h, h->b_epts[s], n * 3 * sizeof(double)));
@@ -149,8 +194,13 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       else hipLaunchKernelGGL(k_ecp_fill<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
       TRY(check_launch(h, "k_ecp_fill"));
       if (h->has_slater)
-        for (int s = 0; s < 2; ++s)
-          TRY(launch_orb(h, s, plain_points(B.pts[s], tot[s]), tot[s], 1, (double*)h->b_emo[s].p));
+        for (int s = 0; s < 2; ++s) {
+          PointAddr pa = plain_points(B.pts[s], tot[s]);
+          if (defer) { pa.count = cnt_dev[s]; h->orb_p_hint = std::max<long>(h->ecp_hint[s], 1); }
+          const int rc = launch_orb(h, s, pa, tot[s], 1, (double*)h->b_emo[s].p);
+          h->orb_p_hint = 0;
+          if (rc != 0) return rc;
+        }
     }
     // wave-per-walker accumulation (complex determinants, several determinants, three-body factor): four waves share a walker's
     // points while the launch is too small to fill the chip with one (measured after the three-body / determinant-pass fixes: C4
@@ -207,6 +257,9 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     TRY(check_launch(h, "k_ecp_accum"));
     d_ecp = (const double*)h->b_ecp.p;
   }
+  if (side_join) HIPCHK(hipStreamWaitEvent(h->stream, h->en_ev[1], 0));
+  h->en_d_ecp = d_ecp;
+  if (!assemble) return 0;  // (the caller finishes: k_energy_finish)
   hipLaunchKernelGGL((k_energy_assemble<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kc.p, d_ecp,
                      h->ii_energy, W, (double*)h->b_en.p, (int)h->cplx);
   return check_launch(h, "k_energy_assemble");

@@ -606,6 +606,49 @@ static __global__ __launch_bounds__(256) void k_row_means(const double* __restri
   if (threadIdx.x == 0) out[blockIdx.x] = part[0] / (double)W;
 }
 
+// k_energy_assemble + k_row_means (+ k_sum_reset_int of the sweep before) in one launch for small shards: block r < nen assembles row r of out
+// and sums it the way k_row_means does (the same values in the same order: the same means); block nen adds the walkers' accepted moves.
+template <int PQA_UNIT = 0>
+static __global__ __launch_bounds__(256) void k_energy_finish(const double* __restrict__ kc, const double* __restrict__ ecp, double ii, long W,
+                                                               double* __restrict__ out, double* __restrict__ means, int nen,
+                                                               int* __restrict__ acc_w, int* __restrict__ acc_out) {
+  const int r = blockIdx.x;
+  if (r == nen) {
+    __shared__ int ipart[256];
+    int s = 0;
+    for (long i = threadIdx.x; i < W; i += 256) { s += acc_w[i]; acc_w[i] = 0; }
+    ipart[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) ipart[threadIdx.x] += ipart[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *acc_out = ipart[0];
+    return;
+  }
+  __shared__ double part[256];
+  double s = 0.0;
+  for (long w = threadIdx.x; w < W; w += 256) {
+    double v;
+    if (r == 0) v = kc[w];
+    else if (r == 1) v = kc[W + w];
+    else if (r == 2) v = kc[2 * W + w];
+    else if (r == 3) v = ecp ? ecp[w] : 0.0;
+    else if (r == 4) v = kc[3 * W + w];
+    else if (r == 5) { const double ke = kc[w], ee = kc[W + w], ei = kc[2 * W + w], ec = ecp ? ecp[w] : 0.0; v = ke + ee + ei + ec + ii; }
+    else v = ecp ? ecp[W + w] : 0.0;
+    out[(size_t)r * W + w] = v;
+    s += v;
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) means[r] = part[0] / (double)W;
+}
+
 // pass C, thread-per-point variant (single determinant, no three-body factor): contrib[p] = weight_p * Psi(aux_p)/Psi.
 // One wave per walker (k_ecp_accum) walks ~38 points one after another with every load and reduction latency
 // exposed; here each point is one thread: a 32-term dot with the walker's inverse row for the determinant ratio and

@@ -183,6 +183,16 @@ struct pqa_handle {
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
   // 3 always with three waves per walker (measured slower).  50-determinant water molecule, VMC step with energy, launches -> one
   // launch: 0.722 -> 0.663 ms at 1 024 walkers, 0.884 -> 0.801 at 2 048, 1.428 -> 1.382 at 4 096, 2.25 -> 2.38 at 8 192
+  // ECP point totals left on the device (pqa_energy.hip: small shards on the k_ecp_accum path; PQA_ECP_DEFER=0 reads them every time)
+  const double* en_d_ecp = nullptr;  // energy_dev: the ECP row(s) of its last evaluation (nullptr: no ECP)
+  int ecp_defer = 1;
+  int en_overlap = 1;  // kinetic / Coulomb pass of small wave-per-walker shards on a side stream beside the ECP passes (PQA_EN_OVERLAP=0: in line)
+  hipStream_t en_stream = nullptr;
+  hipEvent_t en_ev[2] = {nullptr, nullptr};
+  bool ecp_hint_valid = false;
+  long ecp_hint[2] = {0, 0}, ecp_evals = 0;
+  const long* last_ecp_dev[2] = {nullptr, nullptr};
+  long orb_p_hint = 0;  // launch_orb: points the next launch is expected to work on when its P is an upper bound (0: P)
   int ww_mode = -1;
   long ww_max = 4096;
   int lw_mode = 1;  // 1: lane-per-walker fused sweep (single determinant); 0: wave-per-walker kernels; 2: walker-tile sweep (PQA_LW)
@@ -335,7 +345,8 @@ int sweep_ww(pqa_handle* h, const MoveBuf& mb);
 bool tile_eligible(const pqa_handle* h);
 int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);
 // pqa_energy.hip
+// assemble = false: the rows of b_en are left to the caller (k_energy_finish, from b_kc and en_d_ecp)
 int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-               bool soa_current = false, bool aos_T_needed = true);
+               bool soa_current = false, bool aos_T_needed = true, bool assemble = true);
 // pqa_dmcsteps.hip
 int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks);

@@ -60,13 +60,14 @@ static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int nc
   }
   // 64-point tiles need >= ~4 blocks per CU to overlap their exp and MFMA phases across blocks; below
   // that, 32-point tiles double the number of resident blocks (PQA_ORB_TP overrides for A/B runs)
-  int tp = (P >= (long)64 * 448) ? 64 : 32;  // (28672 points: 15.4 -> 14.5 ms per (H2O)8 step with 64-point tiles; 24576: 11.7 vs 12.2 for 32)
+  const long Ps = h->orb_p_hint > 0 ? std::min(h->orb_p_hint, P) : P;  // points the launch is expected to work on (PointAddr::count: P is a bound)
+  int tp = (Ps >= (long)64 * 448) ? 64 : 32;  // (28672 points: 15.4 -> 14.5 ms per (H2O)8 step with 64-point tiles; 24576: 11.7 vs 12.2 for 32)
   if (h->orb_tp == 32 || h->orb_tp == 64) tp = h->orb_tp;
   // measured on MI355X: below ~2 blocks per CU the wave-specialised schedule wins (its
   // producer and consumer waves overlap inside one block); with >= 4 resident blocks per CU the plain kernel does
   // (one 64-point block per CU at most: with a second round of blocks the plain kernel wins — (H2O)8 step 12.3 -> 10.6 ms at 18432
   // walkers, 12.9 -> 11.3 at 22528, measured at the end of round 4; at 16384 the two are level)
-  const bool want_ws = h->orb_ws < 0 ? (P <= (long)64 * 256) : (h->orb_ws != 0);
+  const bool want_ws = h->orb_ws < 0 ? (Ps <= (long)64 * 256) : (h->orb_ws != 0);
   if (h->S.nL > 0) TRY(launch_orb_pbc_any(h, ncomp, spin, pa, P, out));
   else if (h->big && h->orb_general) TRY(launch_orb_general(h, ncomp, spin, pa, P, out));
   else if (h->big) {  // more than 64 orbitals of a spin: windows of 64 columns, one k_orb launch each (the AO phase runs once per window)

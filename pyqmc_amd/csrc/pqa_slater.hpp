@@ -191,7 +191,8 @@ __device__ __forceinline__ void slater_ratios(const SysDev& S, const SlaterState
     // 0 .. n-1 (adjacent pairs, then pairs of pairs; the other lanes hold zeros there): the ratios are bitwise the same.
     const int GS = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16)));
     const int DP = 64 / GS, g = lane / GS, j = lane & (GS - 1);
-    for (int d0 = 0; d0 < D; d0 += DP) {
+#pragma unroll 2
+    for (int d0 = 0; d0 < D; d0 += DP) {  // (passes are independent: two in flight)
       const int d = d0 + g;
       const bool act = d < D && j < n;
       double part[NCOMP];
@@ -290,7 +291,8 @@ __device__ __forceinline__ void sm_update_wave(const SysDev& S, const SlaterStat
     // sequential sum of the n rounded products).
     const int GS = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)), E = GS * GS, DP = 64 / E;
     const int g = lane / E, r = (lane & (E - 1)) / GS, c = lane & (GS - 1);
-    for (int d0 = dpart * DP; d0 < D; d0 += DP * dparts) {
+#pragma unroll 2
+    for (int d0 = dpart * DP; d0 < D; d0 += DP * dparts) {  // (passes are independent: two in flight)
       const int d = d0 + g;
       const bool act = d < D && r < n && c < n;
       double* Tw = st.T[s] + ((size_t)w * D + (d < D ? d : 0)) * n * n;

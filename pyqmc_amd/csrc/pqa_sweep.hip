@@ -404,13 +404,20 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
     if (tile) TRY(sweep_tile(h, mb));
     else TRY(sweep_electrons(h, mb, lw, lc));
-    hipLaunchKernelGGL((k_sum_reset_int<>), dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
+    // small shards: the accepted-move count, the energy rows and their means in one launch at the end of the step (three launches of ~5 us
+    // otherwise — 2 % of the 50-determinant molecule's step at 2 048 walkers)
+    const bool finish1 = energy_mean && W <= 16384;
+    if (!finish1) hipLaunchKernelGGL((k_sum_reset_int<>), dim3(1), dim3(1024), 0, h->stream, (int*)h->b_accw.p, W, (int*)h->b_acccnt.p + step);
     TRY(check_launch(h, "k_propose/k_accept"));
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
-                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false));
-      hipLaunchKernelGGL((k_row_means<>), dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
+                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false, /*assemble=*/!finish1));
+      if (finish1)
+        hipLaunchKernelGGL((k_energy_finish<>), dim3(nen + 1), dim3(256), 0, h->stream, (const double*)h->b_kc.p, h->en_d_ecp, h->ii_energy, W,
+                           (double*)h->b_en.p, (double*)h->b_means.p + (size_t)step * nen, nen, (int*)h->b_accw.p, (int*)h->b_acccnt.p + step);
+      else
+        hipLaunchKernelGGL((k_row_means<>), dim3(nen), dim3(256), 0, h->stream, (const double*)h->b_en.p, W, (double*)h->b_means.p + (size_t)step * nen);
       TRY(check_launch(h, "k_row_means"));
     }
   }
