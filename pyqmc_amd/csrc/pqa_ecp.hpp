@@ -299,7 +299,7 @@ template <bool PBC, bool CX = false>
 static __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBuf B, int s, int has_slater, int has_jastrow,
                                                       const double* __restrict__ mo, long npts, long W, double* __restrict__ contrib) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npts) return;
+  if (p >= npts || (B.ptot[s] && p >= *B.ptot[s])) return;
   const int e = B.pte[s][p];
   const long w = B.ptw[s][p];
   const int n = s ? S.ndn : S.nup, i = e - s * S.nup, nmo = S.nmo[s];

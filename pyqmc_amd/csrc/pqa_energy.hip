@@ -136,16 +136,14 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       TRY(scan_ints(h, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, nsw, (long*)h->b_tmmarks.p + 2));
     }
     TRY(check_launch(h, "k_ecp_count/k_scan2"));
-    // Small shards whose accumulation pass reads the list offsets from the device anyway (k_ecp_accum): no device -> host round trip for the
-    // totals (two copies and the host's wake-up: ~80 us of a 0.8 ms step).  The lists are sized for every point of every ECP atom, the orbital
-    // launch covers that bound and its blocks beyond the device-side count leave at once (PointAddr::count); the kernel choice follows the totals
-    // of the last evaluation that did read them (every 16th does).
+    // Small shards: no device -> host round trip for the totals (two copies and the host's wake-up: ~80 us of a 0.3 - 0.8 ms step).  The
+    // lists are sized for every point of every ECP atom, the orbital launch and the per-point pass cover that bound and their blocks beyond
+    // the device-side count leave at once (PointAddr::count, EcpBuf::ptot; k_ecp_accum / k_ecp_sum read the list offsets from the device
+    // anyway); the kernel choice follows the totals of the last evaluation that did read them (every 16th does).
     {
-      const bool accum_path = h->cplx ? !(soa_current && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_point_lw)
-                                      : !(h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0);
       const long pmax = (long)h->necp * std::max(h->S.ecp_naip_max, 1);  // quadrature points of one electron over all ECP atoms, at most
       const long ub0 = W * (long)h->nup * pmax, ub1 = W * (long)h->ndn * pmax;
-      defer = h->ecp_defer != 0 && accum_path && !h->S.pbc && h->ecp_hint_valid && (h->ecp_evals % 16) != 0 &&
+      defer = h->ecp_defer != 0 && !h->S.pbc && h->ecp_hint_valid && (h->ecp_evals % 16) != 0 &&
               (ub0 + ub1) * (long)(64 + 8 * std::max(h->nmo[0], h->nmo[1])) <= (long)256 << 20;
       if (defer) { tot[0] = ub0; tot[1] = ub1; }
       else {
@@ -155,6 +153,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       }
       ++h->ecp_evals;
       cnt_dev[0] = B.off + nsw; cnt_dev[1] = B.off + (nsw + 1) + nsw;
+      B.ptot[0] = defer ? cnt_dev[0] : nullptr; B.ptot[1] = defer ? cnt_dev[1] : nullptr;
     }
     }
     h->last_ecp_points = defer ? -1 : tot[0] + tot[1];

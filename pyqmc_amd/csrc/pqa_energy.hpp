@@ -273,6 +273,7 @@ struct EcpBuf {
   double* wgt[2];        // [npts_s]  sum_l (v_l/prob)(2l+1)P_l(cos) w_i
   int* pte[2];           // [npts_s]  electron index of the point
   int* ptw[2];           // [npts_s]  walker index of the point (thread-per-point accumulation)
+  const long* ptot[2];   // device-side totals of the two lists where the host launched over an upper bound (pqa_energy.hip: defer), else nullptr
   double* u0[2];         // [npts_s]  two-body Jastrow exponent U_e at the electron's CURRENT position (same for the 6/12 points of an entry)
   int has_j2;            // fill u0
   const double* ue;      // [N][W] U_e of every electron at its own position (k_kinetic_lw), or NULL: the fill pass sums it itself
@@ -662,7 +663,7 @@ static __global__ __launch_bounds__(256) void k_ecp_point(SysDev S, SlaterState 
   // walker-major array (sw = n^2, si = n, sk = 1) or the lane-per-walker planes (sw = 1, si = n W, sk = W), which spares the
   // fused sweep a transpose of every walker's inverse per energy evaluation (35 KB per walker moved for ~2 KB read here)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= npts) return;
+  if (p >= npts || (B.ptot[s] && p >= *B.ptot[s])) return;
   const int e = B.pte[s][p];
   const long w = B.ptw[s][p];
   const int n = s ? S.ndn : S.nup, i = e - s * S.nup, nmo = S.nmo[s];
