@@ -297,7 +297,9 @@ static __global__ __launch_bounds__(64 * PQA_ECP_WB) void k_ecp_fill_t(SysDev S,
 // busy in the 16-electron dots: 0.99 ms per evaluation of the twisted 32-electron cell at 8 192 walkers, 11 % of its step.)
 template <bool PBC, bool CX = false>
 static __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L, EcpBuf B, int s, int has_slater, int has_jastrow,
-                                                      const double* __restrict__ mo, long npts, long W, double* __restrict__ contrib) {
+                                                      const double* __restrict__ mo, long npts, long W, double* __restrict__ contrib,
+                                                      const double* __restrict__ mo1 = nullptr, long npts1 = 0, double* __restrict__ contrib1 = nullptr) {
+  if (blockIdx.y) { s = 1; mo = mo1; npts = npts1; contrib = contrib1; }  // (small shards: both spin channels in one launch, grid rows 0 / 1)
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   if (p >= npts || (B.ptot[s] && p >= *B.ptot[s])) return;
   const int e = B.pte[s][p];

@@ -215,6 +215,17 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       if (h->S.pbc) PQA_ECP_ACC(true, true, 2); else PQA_ECP_ACC(false, true, 2);
     } else
     if (h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0) {  // thread per point, then an ordered per-walker sum
+      // small shards: the two spin channels of the per-point pass in one launch (two launches of ~11 us for a few thousand points each)
+      const bool both = (cx_points || (soa_current && !h->cplx && h->ecp_point_lw)) && tot[0] > 0 && tot[1] > 0 &&
+                        std::max(h->ecp_hint[0], h->ecp_hint[1]) <= 262144 && h->ecp_hint_valid;
+      if (both) {
+        const dim3 g2((unsigned)((std::max(tot[0], tot[1]) + 255) / 256), 2);
+#define PQA_PT2(PB, CXF) hipLaunchKernelGGL((k_ecp_point_lw<PB, CXF>), g2, dim3(256), 0, h->stream, h->S, lw_state(h), B, 0, (int)h->has_slater, (int)h->has_jastrow, \
+                                            (const double*)h->b_emo[0].p, tot[0], W, (double*)h->b_econ[0].p, (const double*)h->b_emo[1].p, tot[1], (double*)h->b_econ[1].p)
+        if (cx_points) { if (h->S.pbc) PQA_PT2(true, true); else PQA_PT2(false, true); }
+        else { if (h->S.pbc) PQA_PT2(true, false); else PQA_PT2(false, false); }
+#undef PQA_PT2
+      } else
       for (int s = 0; s < 2; ++s) {
         if (tot[s] <= 0) continue;
         const dim3 g((unsigned)((tot[s] + 255) / 256));
