@@ -394,7 +394,9 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   //   round 5: PQA_RES 0|1 resident sweep off / forced (default: by shard size, pqa_res.hip res_eligible), PQA_RES_MIN / PQA_RES_MAX walker
   //   window of the automatic choice, PQA_RES_PBC 0 periodic handles keep the launch-per-move sweep, PQA_RES_ICAP n shorter image lists in
   //   the periodic resident sweep (tests), PQA_RES_DEBUG 1 prints the tile / LDS plan, PQA_ORB_GENERAL 1 orbitals of handles beyond 64 per
-  //   spin by k_ao + k_mo_rows instead of the windowed k_orb.
+  //   spin by k_ao + k_mo_rows instead of the windowed k_orb, PQA_RES_CX 0 complex determinants keep the launch-per-move sweep, PQA_WW 0|1|3
+  //   wave-per-walker sweep in one launch off / forced with one / three waves per walker (default: one wave up to 4096 walkers), PQA_ECP_DEFER 0
+  //   the ECP point totals are read back at every evaluation, PQA_EN_OVERLAP 0 the kinetic pass of small shards stays in line.
   if (const char* tp = getenv("PQA_ORB_TP")) h->orb_tp = atoi(tp);
   if (const char* ns = getenv("PQA_ORB_NOSPLIT")) h->orb_nosplit = atoi(ns);
   if (const char* sm = getenv("PQA_ORB_SPLIT_MAX")) h->orb_split_max = atol(sm);
@@ -405,6 +407,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
   if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_CX")) h->res_cx = atoi(rs);
+  if (const char* rs = getenv("PQA_ORB_PTS")) h->orb_pts = atoi(rs);
   if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);
   if (const char* rs = getenv("PQA_ECP_DEFER")) h->ecp_defer = atoi(rs);
   if (const char* rs = getenv("PQA_EN_OVERLAP")) h->en_overlap = atoi(rs);

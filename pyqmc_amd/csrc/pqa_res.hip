@@ -255,6 +255,33 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
   return check_launch(h, "k_sweep_res");
 }
 
+// Value-only orbitals at arbitrary points of an untwisted periodic cell through k_orb_pts (pqa_res.hpp) where the handle's resident tables
+// allow it: false -> the caller takes the pre-pass + k_orb route.
+bool orb_pts_ok(pqa_handle* h, int spin) {
+  if (h->orb_pts == 0 || !h->S.pbc || h->cplx || h->twist || h->out_sel) return false;
+  if (!h->res_ready) {
+    if (res_setup(h) != 0) { h->res_ok = false; h->err.clear(); }
+  }
+  if (!h->res_ok || h->res_tab.npass != 1 || h->nmo[spin] > 32 || h->nmo[spin] < 1 || h->nt[spin] > 2) return false;
+  return orbpts_lds(h->res_tab.kt, h->nt[spin], h->res_tab.nprim_u, h->natom, h->S.nL, h->nshell, h->res_tab.nlist, h->res_tab.icap) <= 80 * 1024;
+}
+int launch_orb_pts(pqa_handle* h, int spin, PointAddr pa, long P, double* out) {
+  ChunkTab Tc = h->tab[0];
+  if (h->res_dense) { Tc.cpad[0] = h->d_cres[0]; Tc.cpad[1] = h->d_cres[1]; }
+  const size_t lds = orbpts_lds(h->res_tab.kt, h->nt[spin], h->res_tab.nprim_u, h->natom, h->S.nL, h->nshell, h->res_tab.nlist, h->res_tab.icap);
+  static bool attr = false;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_orb_pts<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)k_orb_pts<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr = true;
+  }
+  const long ntile = (P + 15) / 16;
+  const dim3 grid((unsigned)std::min<long>(ntile, (long)2 * 256 * 4)), block(PQA_RES_NT);  // persistent blocks: tables staged once, several tiles each
+  if (h->res_lmax <= 2) hipLaunchKernelGGL((k_orb_pts<2>), grid, block, lds, h->stream, h->S, Tc, h->res_tab, spin, pa, P, out);
+  else hipLaunchKernelGGL((k_orb_pts<3>), grid, block, lds, h->stream, h->S, Tc, h->res_tab, spin, pa, P, out);
+  return check_launch(h, "k_orb_pts");
+}
+
 #ifdef PQA_RES_CLK  // timing build only
 extern "C" int pqa_debug_res_clk3(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk3), (size_t)n * sizeof(unsigned long long));

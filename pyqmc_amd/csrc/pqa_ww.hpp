@@ -27,7 +27,6 @@
 #include "pqa_ao.hpp"
 #include "pqa_vmc.hpp"
 
-#define PQA_WW_NT 192
 #ifdef PQA_WW_CLK  // timing build only (tools/scratch/ww1_clk.py): 100 MHz stamps of lane 0 of each wave of the first 256 blocks, last move
 static __device__ unsigned long long pqa_ww1_clk[256 * 3 * 8];
 #define PQA_W1CLK(k) do { if (blockIdx.x < 256 && (threadIdx.x & 63) == 0) pqa_ww1_clk[(blockIdx.x * 3 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); } while (0)

@@ -151,6 +151,31 @@ def test_energy_golden(tag, mol, W):
     assert wf.fused_device().last_ecp_points() > 0
 
 
+@pytest.mark.parametrize("kind", ["single", "multi"])
+def test_ecp_point_totals_left_on_the_device(kind, monkeypatch):
+    """Small shards keep the ECP point totals on the device (PointAddr::count / EcpBuf::ptot: the orbital launch and the per-point pass cover
+    an upper bound, blocks beyond the device-side count leave; every 16th evaluation reads the totals back for the kernel choice) — against
+    the read-back at every evaluation: the same energies bit for bit over 20 sweeps, the same point count on demand.  `single`: thread-per-point
+    pass; `multi`: 50 determinants + three-body factor, wave-per-walker accumulation."""
+    import pyqmc_amd as pa
+
+    mol = systems.water()
+    outs = []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("PQA_ECP_DEFER", defer)
+        if kind == "single":
+            wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+        else:
+            mf = systems.random_mf(mol, nvirt=8)
+            wf = helpers.gpu_wf3(mol, mf, systems.random_determinants(mol, mf, 50))
+        dev = wf.fused_device()
+        wf.recompute(pa.initial_guess(mol, 300, rng=np.random.default_rng(3)))
+        acc, en, _ = dev.vmc_sweeps(0.3, 20, seed=9, energy=True, record=True)
+        outs.append((np.asarray(en), dev.last_ecp_points(), dev.configs()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][1] == outs[1][1] > 0
+
+
 @pytest.mark.parametrize("ecp_lds", ["1", "0"])
 def test_ecp_quadrature_rules_golden(ecp_lds, monkeypatch):
     """EnergyAccumulator(mol, naip=...) (accumulators.py:48-51 -> eval_ecp.py:21-40, get_P_l :228-252) against the reference for

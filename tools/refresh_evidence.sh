@@ -63,5 +63,10 @@ rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats -d /tmp/pd -o d -- python $R/to
 python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/m_4096_kernel_stats.csv
 [ -x $R/tools/scratch/bin/dma_probe ] || (mkdir -p $R/tools/scratch/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 $R/tools/scratch/dma_probe.hip -o $R/tools/scratch/bin/dma_probe 2>/dev/null)
 timeout 120 $R/tools/scratch/bin/dma_probe > $O/dma_probe.txt 2>&1
+# round 5, later sessions: the periodic / complex resident sweep and the one-launch wave-per-walker sweep against the launches they replace, the
+# ECP point totals left on the device against the read-back
+for c in c3 c5; do for w in 4096 8192 16384; do for r in 1 0; do echo -n "{\"PQA_RES\": $r, \"line\": " >> $O/resident_pbc_ab.txt; PQA_RES=$r python $R/tools/config_bench.py $c --walkers $w --steps 8 2>/dev/null | tail -1 | tr -d '\n' >> $O/resident_pbc_ab.txt; echo "}" >> $O/resident_pbc_ab.txt; done; done; done
+for w in 1024 2048 4096; do for m in "PQA_WW=0 PQA_ECP_DEFER=0 PQA_EN_OVERLAP=0" "PQA_WW=0" "PQA_WW=3" "PQA_WW=1 PQA_ECP_DEFER=0" "PQA_WW=1"; do echo -n "{\"env\": \"$m\", \"line\": " >> $O/c4_one_launch_ab.txt; env $m python $R/tools/config_bench.py c4 --walkers $w --steps 20 2>/dev/null | tail -1 | tr -d '\n' >> $O/c4_one_launch_ab.txt; echo "}" >> $O/c4_one_launch_ab.txt; done; done
+for d in 0 1; do echo -n "{\"PQA_ECP_DEFER\": $d, \"line\": " >> $O/c4_one_launch_ab.txt; PQA_ECP_DEFER=$d python $R/tools/config_bench.py c2 --walkers 4096 --steps 40 2>/dev/null | tail -1 | tr -d '\n' >> $O/c4_one_launch_ab.txt; echo "}" >> $O/c4_one_launch_ab.txt; done
 cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
