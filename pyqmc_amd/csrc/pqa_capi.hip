@@ -407,7 +407,6 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
   if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_CX")) h->res_cx = atoi(rs);
-  if (const char* rs = getenv("PQA_ORB_PTS")) h->orb_pts = atoi(rs);
   if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);
   if (const char* rs = getenv("PQA_ECP_DEFER")) h->ecp_defer = atoi(rs);
   if (const char* rs = getenv("PQA_EN_OVERLAP")) h->en_overlap = atoi(rs);

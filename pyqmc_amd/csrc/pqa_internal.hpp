@@ -179,7 +179,6 @@ struct pqa_handle {
   int pbc_mincls = 0;
   bool pbc_lists_ok = false;
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
-  int orb_pts = 1;  // PQA_ORB_PTS=0: value-only periodic orbitals keep the pre-pass + k_orb route (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
   // 3 always with three waves per walker (measured slower).  50-determinant water molecule, VMC step with energy, launches -> one
@@ -338,8 +337,6 @@ void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, lo
 // pqa_res.hip
 bool res_eligible(pqa_handle* h, long W);
 int sweep_res(pqa_handle* h, const MoveBuf& mb);
-bool orb_pts_ok(pqa_handle* h, int spin);  // value-only orbitals of an untwisted periodic cell through k_orb_pts
-int launch_orb_pts(pqa_handle* h, int spin, PointAddr pa, long P, double* out);
 int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host);  // (pqa_res.hip: dense coefficient copy follows set_mo)
 // pqa_sweep_ww.hip
 bool ww_eligible(pqa_handle* h, long W);

@@ -68,8 +68,7 @@ static int launch_orb_impl(pqa_handle* h, int spin, PointAddr pa, long P, int nc
   // (one 64-point block per CU at most: with a second round of blocks the plain kernel wins — (H2O)8 step 12.3 -> 10.6 ms at 18432
   // walkers, 12.9 -> 11.3 at 22528, measured at the end of round 4; at 16384 the two are level)
   const bool want_ws = h->orb_ws < 0 ? (Ps <= (long)64 * 256) : (h->orb_ws != 0);
-  if (h->S.nL > 0 && ncomp == 1 && orb_pts_ok(h, spin)) TRY(launch_orb_pts(h, spin, pa, P, out));
-  else if (h->S.nL > 0) TRY(launch_orb_pbc_any(h, ncomp, spin, pa, P, out));
+  if (h->S.nL > 0) TRY(launch_orb_pbc_any(h, ncomp, spin, pa, P, out));
   else if (h->big && h->orb_general) TRY(launch_orb_general(h, ncomp, spin, pa, P, out));
   else if (h->big) {  // more than 64 orbitals of a spin: windows of 64 columns, one k_orb launch each (the AO phase runs once per window)
     for (int col0 = 0; col0 < 16 * h->nt[spin] && col0 < h->nmo[spin]; col0 += 64) {

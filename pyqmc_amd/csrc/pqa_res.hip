@@ -191,6 +191,7 @@ static int res_setup(pqa_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa_res] passes %d, tile rows %d (padded basis %d), LDS %zu B, image-list capacity %d\n", RT.npass, RT.kt, c.rows_pad, h->res_lds, RT.icap);
   h->res_tab = RT;
   h->res_ok = true;
@@ -242,7 +243,8 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
   }
 #define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
 #define PQA_RES_LAUNCH_P(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
-  if (h->cplx) hipLaunchKernelGGL((k_sweep_res<false, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+  if (h->cplx && mb.dmc) hipLaunchKernelGGL((k_sweep_res<true, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
+  else if (h->cplx) hipLaunchKernelGGL((k_sweep_res<false, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
   else if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
     if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(true, 2); else PQA_RES_LAUNCH_P(true, 3); }
     else { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(false, 2); else PQA_RES_LAUNCH_P(false, 3); }
@@ -253,33 +255,6 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
 #undef PQA_RES_LAUNCH
   if (e1) HIPCHK(hipEventRecord(e1, h->stream));
   return check_launch(h, "k_sweep_res");
-}
-
-// Value-only orbitals at arbitrary points of an untwisted periodic cell through k_orb_pts (pqa_res.hpp) where the handle's resident tables
-// allow it: false -> the caller takes the pre-pass + k_orb route.
-bool orb_pts_ok(pqa_handle* h, int spin) {
-  if (h->orb_pts == 0 || !h->S.pbc || h->cplx || h->twist || h->out_sel) return false;
-  if (!h->res_ready) {
-    if (res_setup(h) != 0) { h->res_ok = false; h->err.clear(); }
-  }
-  if (!h->res_ok || h->res_tab.npass != 1 || h->nmo[spin] > 32 || h->nmo[spin] < 1 || h->nt[spin] > 2) return false;
-  return orbpts_lds(h->res_tab.kt, h->nt[spin], h->res_tab.nprim_u, h->natom, h->S.nL, h->nshell, h->res_tab.nlist, h->res_tab.icap) <= 80 * 1024;
-}
-int launch_orb_pts(pqa_handle* h, int spin, PointAddr pa, long P, double* out) {
-  ChunkTab Tc = h->tab[0];
-  if (h->res_dense) { Tc.cpad[0] = h->d_cres[0]; Tc.cpad[1] = h->d_cres[1]; }
-  const size_t lds = orbpts_lds(h->res_tab.kt, h->nt[spin], h->res_tab.nprim_u, h->natom, h->S.nL, h->nshell, h->res_tab.nlist, h->res_tab.icap);
-  static bool attr = false;
-  if (!attr) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_orb_pts<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)k_orb_pts<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr = true;
-  }
-  const long ntile = (P + 15) / 16;
-  const dim3 grid((unsigned)std::min<long>(ntile, (long)2 * 256 * 4)), block(PQA_RES_NT);  // persistent blocks: tables staged once, several tiles each
-  if (h->res_lmax <= 2) hipLaunchKernelGGL((k_orb_pts<2>), grid, block, lds, h->stream, h->S, Tc, h->res_tab, spin, pa, P, out);
-  else hipLaunchKernelGGL((k_orb_pts<3>), grid, block, lds, h->stream, h->S, Tc, h->res_tab, spin, pa, P, out);
-  return check_launch(h, "k_orb_pts");
 }
 
 #ifdef PQA_RES_CLK  // timing build only

@@ -26,7 +26,7 @@
 // Scope: single-determinant Slater factor with <= 32 electrons and <= 32 orbitals per spin, optional two-body Jastrow factor, l <= 3; open
 // boundary conditions or (PBC) a periodic cell — lattice-summed AOs from per-(point, atom) image lists built in the block (phase 0) and
 // accumulated in the tile with ds_add_f64 (phase 1), minimal-image Jastrow pairs, proposals folded into the cell.  CX: complex determinants
-// in periodic cells (<= 16 electrons and orbitals per spin: a row of the inverse is 16 (re, im) pairs in the same 32 registers; VMC), with or
+// in periodic cells (<= 16 electrons and orbitals per spin: a row of the inverse is 16 (re, im) pairs in the same 32 registers), with or
 // without a twist — a twisted cell's tile holds the real AO rows and behind them the imaginary ones (coefficient rows [-C_im | C_re]), every
 // image weighted by exp(i k_t . (fold + L_j)), the orbital rows by the wrap phase of the folded proposal; the walkers stay unfolded.
 // Everything else keeps the lane-per-walker sweep.
@@ -1278,253 +1278,6 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     if (r == 0) {
       mb.acc_w[wg] += (int)ws[15];
       if (DMC) { mb.r2_prop[wg] += ws[13]; mb.r2_acc[wg] += ws[14]; }
-    }
-  }
-}
-
-// ---------------------------------------------------------------- k_orb_pts: lattice-summed orbital VALUES at arbitrary points
-// The periodic AO phase of the resident sweep as an orbital kernel of its own: the ECP quadrature points and T-move candidates of a periodic
-// cell (value-only launches) went through k_pbc_prepass (image lists in global memory) + k_orb<1, .., PBC> — 25 % of BASELINE config C5's DMC
-// step.  Here a 512-thread block takes 16 points at a time: the images of every (point, atom) pair into LDS lists (phase 0 of k_sweep_res),
-// the lattice sums of the shells into a dense value tile [K][16] (27 KB for the 208 AOs of the 2x2x2 diamond cell: several blocks per CU,
-// which is what hides the image walks' latency), the contraction on v_mfma_f64_16x16x4_f64 with K split over the waves.
-// Scope: untwisted periodic cells with real orbitals, <= 32 orbitals of the spin, the handle's resident tables in dense or one-pass form.
-// LDS (doubles): tile [kt][16], partials [KW][16][PS1], points [16][3], primitives, atoms, lattice vectors, cut-offs, cell; ints: shell
-// table, group lists, per-atom integers, membership rule; bytes: image lists
-#define PQA_OP_PS(nt) (16 * (nt) + 4)
-__host__ __device__ inline size_t orbpts_lds(int kt, int nt, int nprim_u, int natom, int nL, int nshell, int nlist, int icap) {
-  const size_t d = (size_t)16 * kt + (size_t)(8 / nt) * 16 * PQA_OP_PS(nt) + 48 + 2 * (size_t)nprim_u + 3 * (size_t)natom + 3 * (size_t)nL + nshell +
-                   (size_t)natom * (1 + PQA_RES_NCUT) + 36;
-  const size_t i = 5 * (size_t)nshell + nlist + 34 + 3 * (size_t)natom + ((3 * (size_t)natom + 16) & ~(size_t)1);
-  return d * sizeof(double) + ((i * sizeof(int) + 7) & ~(size_t)7) + (((size_t)natom * 16 * (icap + 1) + 7) & ~(size_t)7);
-}
-template <int LMAX>
-static __global__ __launch_bounds__(PQA_RES_NT, 2) void k_orb_pts(SysDev S, ChunkTab T, ResTab RT, int spin, PointAddr pa, long P, double* __restrict__ out) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pl = tid & 15, grp = tid >> 4, i16 = lane & 15, kq = lane >> 4;
-  const int KT = RT.kt, nmo = spin ? S.nmo[1] : S.nmo[0], ldc = spin ? T.ldc[1] : T.ldc[0], nt = ldc >> 4;
-  const double* __restrict__ cpad = spin ? T.cpad[1] : T.cpad[0];
-  const int KW = 8 / nt, u = wv % nt, kw = wv / nt, PS = PQA_OP_PS(nt);
-  double* tile = lds;
-  double* part = tile + (size_t)16 * KT;
-  double* pts = part + (size_t)KW * 16 * PS;
-  double* pr_exp = pts + 48;
-  double* pr_coef = pr_exp + RT.nprim_u;
-  double* at_xyz = pr_coef + RT.nprim_u;
-  double* LsL = at_xyz + 3 * (size_t)S.natom;
-  double* sh_cut = LsL + 3 * (size_t)S.nL;
-  double* at_cut = sh_cut + S.nshell;
-  double* pbt = at_cut + (size_t)S.natom * (1 + PQA_RES_NCUT);
-  int* sh_meta = reinterpret_cast<int*>(pbt + 36);
-  int* glist = sh_meta + 5 * (size_t)S.nshell;
-  int* goff = glist + RT.nlist;
-  int* at_int = goff + 34;
-  int* pbi = at_int + 3 * (size_t)S.natom;
-  unsigned char* imgl = reinterpret_cast<unsigned char*>(lds) +
-                        ((((size_t)16 * KT + (size_t)KW * 16 * PS + 48 + 2 * (size_t)RT.nprim_u + 3 * (size_t)S.natom + 3 * (size_t)S.nL + S.nshell +
-                           (size_t)S.natom * (1 + PQA_RES_NCUT) + 36) * sizeof(double)) +
-                         (((5 * (size_t)S.nshell + RT.nlist + 34 + 3 * (size_t)S.natom + ((3 * (size_t)S.natom + 16) & ~(size_t)1)) * sizeof(int) + 7) & ~(size_t)7));
-  unsigned char* imgn = imgl + (size_t)S.natom * 16 * RT.icap;
-  // ---- tables (once per block)
-  for (int sh = tid; sh < S.nshell; sh += PQA_RES_NT) {
-    sh_meta[5 * sh] = S.shell_l[sh];
-    sh_meta[5 * sh + 1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
-    sh_meta[5 * sh + 2] = RT.shell_q0[sh];
-    sh_meta[5 * sh + 3] = RT.shell_row[sh];
-    sh_meta[5 * sh + 4] = S.shell_atom[sh];
-  }
-  for (int p = tid; p < RT.nprim_u; p += PQA_RES_NT) { pr_exp[p] = RT.prim_exp_u[p]; pr_coef[p] = RT.prim_coef_u[p]; }
-  for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
-  for (int k = tid; k < RT.nlist; k += PQA_RES_NT) glist[k] = RT.grp_shell[k];
-  for (int k = tid; k < 33; k += PQA_RES_NT) goff[k] = RT.grp_off[k];
-  for (int k = tid; k < 3 * S.nL; k += PQA_RES_NT) LsL[k] = S.pb->Ls[k];
-  for (int k = tid; k < S.nshell; k += PQA_RES_NT) sh_cut[k] = S.pb->shell_cut[k];
-  for (int k = tid; k < S.natom; k += PQA_RES_NT) {
-    const int ncl = S.pb->ncls[k];
-    at_cut[k * (1 + PQA_RES_NCUT)] = S.pb->atom_cut[k];
-    for (int q = 0; q < PQA_RES_NCUT; ++q) at_cut[k * (1 + PQA_RES_NCUT) + 1 + q] = q < ncl ? S.pb->cls_cut[k * PQA_MAXCLS + q] : INFINITY;
-    at_int[3 * k] = S.pb->num_Ls[k]; at_int[3 * k + 1] = ncl; at_int[3 * k + 2] = S.pb->member ? S.pb->member_class[k] : 0;
-    for (int q = 0; q < 3; ++q) pbi[14 + 3 * k + q] = S.pb->member ? S.pb->atom_n[3 * k + q] : 0;
-  }
-  if (tid < 9) { pbt[tid] = S.pb->linv[tid]; pbt[9 + tid] = S.pb->lat[tid]; pbt[18 + tid] = S.pb->lprim_inv[tid]; pbi[tid] = S.pb->supercell[tid]; }
-  if (tid == 9) {
-    pbi[9] = S.pb->member_M; pbi[10] = S.pb->memb_E; pbi[11] = S.pb->near_G; pbi[12] = S.pb->member != nullptr; pbi[13] = S.pb->jas_fold;
-    reinterpret_cast<unsigned long long*>(pbt + 27)[0] = (unsigned long long)S.pb->near_mask;
-    reinterpret_cast<unsigned long long*>(pbt + 27)[1] = (unsigned long long)S.pb->memb_mask;
-  }
-  for (int k = tid; k < 16 * KT; k += PQA_RES_NT) tile[k] = 0.0;  // (K-padding rows stay finite)
-  int NS = 1;
-  while (2 * NS * S.natom <= 32) NS *= 2;
-  const long ntile = (P + 15) / 16;
-#pragma unroll 1
-  for (long tl_ = blockIdx.x; tl_ < ntile; tl_ += gridDim.x) {
-    __syncthreads();  // (tables; the previous tile's combine has read the partials, its contraction the tile)
-    if (tid < 16) {
-      const long p = tl_ * 16 + tid < P ? tl_ * 16 + tid : P - 1;
-      double x, y, z;
-      load_point(pa, p, x, y, z);
-      pts[3 * tid] = x; pts[3 * tid + 1] = y; pts[3 * tid + 2] = z;
-    }
-    __syncthreads();
-    const double ppx = pts[3 * pl], ppy = pts[3 * pl + 1], ppz = pts[3 * pl + 2];
-    // ---- phase 0: image lists (see k_sweep_res)
-    {
-      unsigned long long* pcnt = reinterpret_cast<unsigned long long*>(tile);
-      const int a0 = NS > 1 ? grp % S.natom : grp, q = NS > 1 ? grp / S.natom : 0;
-      for (int a = a0; a < S.natom; a += (NS > 1 ? S.natom : 32)) {  // (NS > 1: one trip)
-        const bool on = q < NS;
-        unsigned long long k0 = 0ull, k1 = 0ull;
-        double cx0 = 0.0, cy0 = 0.0, cz0 = 0.0;
-        double cut_r[PQA_RES_NCUT];
-#pragma unroll
-        for (int k = 0; k < PQA_RES_NCUT; ++k) cut_r[k] = at_cut[a * (1 + PQA_RES_NCUT) + 1 + k];
-        unsigned long long cnt = 0ull;
-        if (on) {
-          const ResPair c = res_pair_base(pbt, pbi, a, ppx, ppy, ppz, at_xyz[3 * a], at_xyz[3 * a + 1], at_xyz[3 * a + 2]);
-          cx0 = c.x0; cy0 = c.y0; cz0 = c.z0;
-          unsigned long long m0 = 0ull, m1 = 0ull;
-          const int ncl = at_int[3 * a + 1];
-          res_image_masks(pbt, pbi, c, a, at_int[3 * a], at_int[3 * a + 2], m0, m1);
-          const double acut = at_cut[a * (1 + PQA_RES_NCUT)];
-          const unsigned long long stripe = NS == 1 ? ~0ull : ((NS == 2 ? 0x5555555555555555ull : NS == 4 ? 0x1111111111111111ull : NS == 8 ? 0x0101010101010101ull
-                                                                : NS == 16 ? 0x0001000100010001ull : 0x0000000100000001ull) << q);
-#pragma unroll 1
-          for (int half = 0; half < 2; ++half) {
-            unsigned long long m = (half ? m1 : m0) & stripe, keep = 0ull;
-            while (m) {
-              const int b = __ffsll((long long)m) - 1, j = 64 * half + b;
-              m &= m - 1;
-              const double xj = c.x0 - LsL[3 * j], yj = c.y0 - LsL[3 * j + 1], zj = c.z0 - LsL[3 * j + 2];
-              const double r2 = xj * xj + yj * yj + zj * zj;
-              int cls = 0;
-#pragma unroll
-              for (int k = 0; k < PQA_RES_NCUT; ++k) cls += r2 > cut_r[k] ? 1 : 0;
-              if (r2 > acut || cls >= ncl) continue;
-              cnt += 1ull << (8 * cls);
-              keep |= 1ull << b;
-            }
-            if (half) k1 = keep; else k0 = keep;
-          }
-          if (NS > 1) pcnt[((size_t)a * 16 + pl) * NS + q] = cnt;
-        }
-        if (NS > 1) res_block_sync();
-        if (on) {
-          int n = 0;
-          unsigned long long off = 0ull;
-          {
-            int tc[PQA_RES_NCUT], bq[PQA_RES_NCUT];
-#pragma unroll
-            for (int k = 0; k < PQA_RES_NCUT; ++k) { tc[k] = 0; bq[k] = 0; }
-            for (int q2 = 0; q2 < NS; ++q2) {
-              const unsigned long long v = NS > 1 ? pcnt[((size_t)a * 16 + pl) * NS + q2] : cnt;
-#pragma unroll
-              for (int k = 0; k < PQA_RES_NCUT; ++k) {
-                const int f = (int)((v >> (8 * k)) & 255);
-                bq[k] += q2 < q ? f : 0;
-                tc[k] += f;
-              }
-            }
-            int run = 0;
-#pragma unroll
-            for (int k = 0; k < PQA_RES_NCUT; ++k) { off |= (unsigned long long)((run + bq[k]) & 255) << (8 * k); run += tc[k]; }
-            n = run;
-          }
-          if (n > RT.icap) n = 254;
-          else {
-            unsigned char* lst = imgl + ((size_t)a * 16 + pl) * RT.icap;
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-              unsigned long long m = half ? k1 : k0;
-              while (m) {
-                const int j = 64 * half + __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const double xj = cx0 - LsL[3 * j], yj = cy0 - LsL[3 * j + 1], zj = cz0 - LsL[3 * j + 2];
-                const double r2 = xj * xj + yj * yj + zj * zj;
-                int cls = 0;
-#pragma unroll
-                for (int k = 0; k < PQA_RES_NCUT; ++k) cls += r2 > cut_r[k] ? 1 : 0;
-                const int pos = (int)((off >> (8 * cls)) & 255);
-                off += 1ull << (8 * cls);
-                lst[pos] = (unsigned char)j;
-              }
-            }
-          }
-          if (q == 0) imgn[a * 16 + pl] = (unsigned char)n;
-        }
-      }
-    }
-    res_block_sync();
-    // ---- phase 1: lattice-summed values of this thread's shells into the tile
-    for (int it = goff[grp]; it < goff[grp + 1]; ++it) {
-      const int sh = glist[it];
-      const int l_ = sh_meta[5 * sh], np_ = sh_meta[5 * sh + 1], q0 = sh_meta[5 * sh + 2], krow = sh_meta[5 * sh + 3], a_ = sh_meta[5 * sh + 4];
-      const int nim = imgn[a_ * 16 + pl];
-      double* __restrict__ tl = tile + (size_t)krow * 16 + pl;
-#pragma unroll
-      for (int m = 0; m < 2 * LMAX + 1; ++m)
-        if (m < 2 * l_ + 1) tl[(size_t)m * 16] = 0.0;
-      auto add_image = [&](double xj, double yj, double zj) __attribute__((always_inline)) {
-        shell_eval<1, LMAX, true>(l_, xj, yj, zj, pr_exp + q0, pr_coef + q0, np_,
-                                  [&](int m, double v, double, double, double, double) __attribute__((always_inline)) { res_lds_add(tl + m * 16, v); });
-      };
-      double x0, y0, z0, f0_, f1_, f2_;
-      res_fold(pbt, ppx - at_xyz[3 * a_], ppy - at_xyz[3 * a_ + 1], ppz - at_xyz[3 * a_ + 2], x0, y0, z0, f0_, f1_, f2_);
-      const double scut = sh_cut[sh];
-      if (nim == 254) {
-        const ResPair c2 = res_pair_base(pbt, pbi, a_, ppx, ppy, ppz, at_xyz[3 * a_], at_xyz[3 * a_ + 1], at_xyz[3 * a_ + 2]);
-        unsigned long long m0 = 0ull, m1 = 0ull;
-        res_image_masks(pbt, pbi, c2, a_, at_int[3 * a_], at_int[3 * a_ + 2], m0, m1);
-        const double cut2 = fmin(scut, at_cut[a_ * (1 + PQA_RES_NCUT)]);
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-          unsigned long long m = half ? m1 : m0;
-          while (m) {
-            const int j = 64 * half + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
-            if (xj * xj + yj * yj + zj * zj <= cut2) add_image(xj, yj, zj);
-          }
-        }
-        continue;
-      }
-      const unsigned char* lst = imgl + ((size_t)a_ * 16 + pl) * RT.icap;
-#pragma unroll 1
-      for (int k = 0; k < nim; ++k) {
-        const int j = lst[k];
-        const double xj = x0 - LsL[3 * j], yj = y0 - LsL[3 * j + 1], zj = z0 - LsL[3 * j + 2];
-        if (xj * xj + yj * yj + zj * zj > scut) break;
-        add_image(xj, yj, zj);
-      }
-    }
-    // ---- contraction: wave (u, kw) takes the k-steps kw, kw + KW, ... of orbital tile u
-    const int nks = KT >> 2;
-    const double* cb = cpad + (size_t)kq * ldc + 16 * u + i16;
-    res_block_sync();
-    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    {
-      const double* a_ = tile + (size_t)kq * 16 + i16;
-#pragma unroll 2
-      for (int ks = kw; ks < nks; ks += KW) {
-        const double b = cb[(size_t)ks * 4 * ldc];
-        const double av = a_[(size_t)(4 * ks) * 16];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc, 0, 0, 0);
-      }
-    }
-    {
-      double* pw = part + ((size_t)kw * 16 + kq) * PS + 16 * u + i16;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) pw[(size_t)4 * rr * PS] = acc[rr];
-    }
-    res_block_sync();
-    {  // combine: thread (point = tid / 32, orbital = tid % 32), the KW partials in a fixed order
-      const int pt = tid >> 5, r = tid & 31;
-      const long p = tl_ * 16 + pt;
-      if (r < nmo && p < P) {
-        double sum = part[(size_t)pt * PS + r];
-        for (int k = 1; k < KW; ++k) sum += part[((size_t)k * 16 + pt) * PS + r];
-        out[(size_t)p * nmo + r] = sum;
-      }
     }
   }
 }

@@ -159,7 +159,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
   const long W = h->W;
   MoveBuf mb = mb_in;
   // the resident sweep (pqa_res.hpp: one launch per sweep, state on chip) where the system is in its scope; it reads both tapes
-  const bool res = ((mb.gauss != nullptr) == (mb.unif != nullptr)) && !(h->cplx && mb.dmc) && res_eligible(h, W);
+  const bool res = ((mb.gauss != nullptr) == (mb.unif != nullptr)) && res_eligible(h, W);
   if (!mb.gauss && !mb.unif && (res || W <= h->draws_max)) {
     // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
     // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD

@@ -549,24 +549,25 @@ def test_one_launch_wave_per_walker_sweep_against_the_launches(cfg, W, ww_mode, 
             assert note(f"{cfg}_{W}_one_launch{ww_mode}_vs_launches_{k}", np.max(np.abs(a[k] - b[k]) / np.maximum(1.0, np.abs(b[k])))) < 1e-10
 
 
-def test_periodic_resident_sweep_with_short_image_lists(monkeypatch):
+@pytest.mark.parametrize("cfg", ["C5", "C3"])
+def test_periodic_resident_sweep_with_short_image_lists(cfg, monkeypatch):
     """The periodic resident sweep keeps the admitted images of a (point, atom) pair in an LDS list (32 entries in the 2x2x2 diamond cell,
     where a pair has 13 at most); a pair with more walks the candidate masks itself.  With the lists cut to 6 entries most diffuse pairs
-    take that route: same decisions and walkers as with full lists."""
+    take that route: same decisions and walkers as with full lists.  C3: the twisted cell (image and fold phases on both routes)."""
     import pyqmc_amd as pa
 
     outs = []
     for icap in ("32", "6"):
         monkeypatch.setenv("PQA_RES", "1")
         monkeypatch.setenv("PQA_RES_ICAP", icap)
-        sup, wf, _, _ = build("C5")
+        sup, wf, _, _ = build(cfg)
         dev = wf.fused_device()
         wf.recompute(pa.initial_guess(sup, 200, rng=np.random.default_rng(12)))
         acc, en, rec = dev.vmc_sweeps(0.3, 2, seed=8, energy=True, record=True)
         outs.append((rec, dev.configs(), dev.value()[1]))
     a, b = outs
     assert np.array_equal(a[0], b[0])
-    assert note("C5_short_lists_x", np.max(np.abs(a[1] - b[1]))) < 1e-10 and note("C5_short_lists_logv", np.max(np.abs(a[2] - b[2]))) < 1e-9
+    assert note(f"{cfg}_short_lists_x", np.max(np.abs(a[1] - b[1]))) < 1e-10 and note(f"{cfg}_short_lists_logv", np.max(np.abs(a[2] - b[2]))) < 1e-9
 
 
 def _scf_kinetic_energy(cell, mf, n=20):
