@@ -824,6 +824,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   for (hipStream_t s : h->jas_stream)
     if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
   if (h->b_jpre.p) (void)hipFree(h->b_jpre.p);
+  if (h->pin_tot) (void)hipHostFree(h->pin_tot);
   if (h->en_stream) { (void)hipStreamSynchronize(h->en_stream); (void)hipStreamDestroy(h->en_stream); }
   for (hipEvent_t e : h->en_ev)
     if (e) (void)hipEventDestroy(e);

@@ -143,7 +143,7 @@ static __global__ __launch_bounds__(1024) void k_scan_add(long* __restrict__ o, 
 // a small shard), one block; o0 / o1 get n + 1 entries (exclusive prefix, total last).  Three launches per array were 45 us of a 0.8 ms step.
 template <int PQA_UNIT = 0>
 static __global__ __launch_bounds__(1024) void k_scan_small2(const int* __restrict__ c0, long* __restrict__ o0, const int* __restrict__ c1,
-                                                             long* __restrict__ o1, long n) {
+                                                             long* __restrict__ o1, long n, long* __restrict__ totals) {
   __shared__ long part[2][1024];
   const long per = (n + 1023) / 1024;
   const long b = (long)threadIdx.x * per, e = (b + per < n) ? b + per : n;
@@ -159,7 +159,7 @@ static __global__ __launch_bounds__(1024) void k_scan_small2(const int* __restri
   }
   long r0 = part[0][threadIdx.x] - s0, r1 = part[1][threadIdx.x] - s1;
   for (long i = b; i < e; ++i) { o0[i] = r0; r0 += c0[i]; o1[i] = r1; r1 += c1[i]; }
-  if (threadIdx.x == 1023) { o0[n] = part[0][1023]; o1[n] = part[1][1023]; }
+  if (threadIdx.x == 1023) { o0[n] = part[0][1023]; o1[n] = part[1][1023]; totals[0] = part[0][1023]; totals[1] = part[1][1023]; }
 }
 
 // pass B: candidate positions and T-move weights, atom-major in quadrature order (the order of the dense table).

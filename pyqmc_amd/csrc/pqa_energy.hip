@@ -129,7 +129,9 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     if (h->S.pbc) hipLaunchKernelGGL(k_ecp_count<true>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     else hipLaunchKernelGGL(k_ecp_count<false>, dim3((unsigned)W), dim3(64), 0, h->stream, h->S, h->js, B, W);
     // device-wide scans of the two spins' point counts (the one-block k_scan2 took 0.26 ms at 65536 walkers; small shards: one launch)
-    if (nsw <= 16384) hipLaunchKernelGGL((k_scan_small2<>), dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw);
+    // (both totals land in the handle's pinned, device-visible host words: one stream synchronisation is the whole read-back)
+    if (!h->pin_tot) HIPCHK(hipHostMalloc((void**)&h->pin_tot, 4 * sizeof(long), hipHostMallocMapped));
+    if (nsw <= 16384) hipLaunchKernelGGL((k_scan_small2<>), dim3(1), dim3(1024), 0, h->stream, (const int*)B.cnt, B.off, (const int*)B.cnt + nsw, B.off + (nsw + 1), nsw, h->pin_tot);
     else {
       TRY(ensure(h, h->b_tmmarks, 4 * sizeof(long)));
       TRY(scan_ints(h, (const int*)B.cnt, B.off, nsw, nsw, (long*)h->b_tmmarks.p));
@@ -147,8 +149,14 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
               (ub0 + ub1) * (long)(64 + 8 * std::max(h->nmo[0], h->nmo[1])) <= (long)256 << 20;
       if (defer) { tot[0] = ub0; tot[1] = ub1; }
       else {
-        TRY(copy_in(h, &tot[0], B.off + nsw, sizeof(long)));
-        TRY(copy_out(h, &tot[1], B.off + (nsw + 1) + nsw, sizeof(long)));
+        if (nsw <= 16384) {
+          HIPCHK(hipStreamSynchronize(h->stream));
+          tot[0] = h->pin_tot[0]; tot[1] = h->pin_tot[1];
+        } else {  // (marks[1], marks[3] of the two scans: one copy)
+          long mk[4];
+          TRY(copy_out(h, mk, h->b_tmmarks.p, 4 * sizeof(long)));
+          tot[0] = mk[1]; tot[1] = mk[3];
+        }
         h->ecp_hint[0] = tot[0]; h->ecp_hint[1] = tot[1]; h->ecp_hint_valid = true;
       }
       ++h->ecp_evals;

@@ -185,6 +185,7 @@ struct pqa_handle {
   // launch: 0.722 -> 0.663 ms at 1 024 walkers, 0.884 -> 0.801 at 2 048, 1.428 -> 1.382 at 4 096, 2.25 -> 2.38 at 8 192
   // ECP point totals left on the device (pqa_energy.hip: small shards on the k_ecp_accum path; PQA_ECP_DEFER=0 reads them every time)
   const double* en_d_ecp = nullptr;  // energy_dev: the ECP row(s) of its last evaluation (nullptr: no ECP)
+  long* pin_tot = nullptr;  // pinned host words the scan kernels write the ECP point totals to (device-visible: hipHostMallocMapped)
   int ecp_defer = 1;
   int en_overlap = 1;  // kinetic / Coulomb pass of small wave-per-walker shards on a side stream beside the ECP passes (PQA_EN_OVERLAP=0: in line)
   hipStream_t en_stream = nullptr;
