@@ -262,7 +262,8 @@ def c4_bench(args, torch, dist, rank, local_rank, world, red_dev, fence):
     dev = wf.fused_device()
     wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(1234 + rank)))
     seed = 20260928 + 7919 * rank
-    dev.vmc_sweeps(args.tstep, max(args.warmup, 1), seed=seed, energy=True)
+    _, en_w, _ = dev.vmc_sweeps(args.tstep, max(args.warmup, 1), seed=seed, energy=True)
+    allreduce_block(en_w.sum(axis=0) * W, en_w.shape[0] * W, device=red_dev)  # (warm-up of the reduction path too: its first call initialises the device-side ops)
     fence()
     t0 = time.perf_counter()
     acc, en, _ = dev.vmc_sweeps(args.tstep, args.steps, seed=seed + 1, energy=True)
