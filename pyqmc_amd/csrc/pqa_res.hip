@@ -192,6 +192,13 @@ static int res_setup(pqa_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (const char* dbg = getenv("PQA_RES_DEBUG"); dbg && atoi(dbg) > 1) {  // the lane groups' shell lists with the cost model's figures
+    for (int g = 0; g < PQA_RES_G * RT.npass; ++g) {
+      fprintf(stderr, "[pqa_res] group %2d:", g);
+      for (int k = off[g]; k < off[g + 1]; ++k) fprintf(stderr, " sh %d (l %d, np %d, cost %d)", list[k], h->shell_l[list[k]], h->shell_np[list[k]], h->shell_cost[list[k]]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa_res] passes %d, tile rows %d (padded basis %d), LDS %zu B, image-list capacity %d\n", RT.npass, RT.kt, c.rows_pad, h->res_lds, RT.icap);
   h->res_tab = RT;
   h->res_ok = true;
