@@ -36,8 +36,8 @@ python $R/tools/config_bench.py c2 --walkers 65536 --steps 20 2>/dev/null | tail
 python $R/tools/config_bench.py c3 --walkers 4096 --steps 8 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 8192 --steps 8 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c3 --walkers 32768 --steps 8 2>/dev/null | tail -1 >> $O/config_bench.jsonl
-python $R/tools/config_bench.py c4 --walkers 2048 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
-python $R/tools/config_bench.py c4 --walkers 16384 --steps 4 2>/dev/null | tail -1 >> $O/config_bench.jsonl
+python $R/tools/config_bench.py c4 --walkers 2048 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
+python $R/tools/config_bench.py c4 --walkers 16384 --steps 20 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c5 --walkers 4096 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c5 --walkers 16384 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
 python $R/tools/config_bench.py c5 --walkers 32768 --steps 10 2>/dev/null | tail -1 >> $O/config_bench.jsonl
