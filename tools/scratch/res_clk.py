@@ -11,7 +11,7 @@ from pyqmc_amd import _ffi, systems
 from tests import helpers
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-mol = systems.water_cluster()
+mol = systems.water() if len(sys.argv) > 2 and sys.argv[2] == "c2" else systems.water_cluster()
 wf = helpers.gpu_wf(mol, systems.random_mf(mol))
 dev = wf.fused_device()
 wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(1)))
