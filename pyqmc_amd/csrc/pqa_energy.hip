@@ -10,7 +10,24 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
   bool side_join = false;
   TRY(ensure(h, h->b_kc, (size_t)4 * W * sizeof(double)));
   TRY(ensure(h, h->b_en, (size_t)(h->cplx ? 7 : 6) * W * sizeof(double)));
+  // will the ECP passes below leave their point totals on the device (no host synchronisation inside this evaluation)?
+  const bool will_defer = h->necp > 0 && h->ecpb_on == 0 && h->ecp_defer != 0 && !h->S.pbc && h->ecp_hint_valid && (h->ecp_evals % 16) != 0 &&
+                          (W * (long)h->N * h->necp * std::max(h->S.ecp_naip_max, 1)) * (long)(64 + 8 * std::max(h->nmo[0], h->nmo[1])) <= (long)256 << 20;
+  auto side_begin = [&]() -> int {  // the kinetic / Coulomb pass goes to the side stream; the caller's stream carries on with the ECP passes
+    if (!h->en_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&h->en_stream, hipStreamNonBlocking));
+      for (hipEvent_t& e : h->en_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(h->en_ev[0], h->stream));
+    HIPCHK(hipStreamWaitEvent(h->en_stream, h->en_ev[0], 0));
+    side.main = h->stream; side.h = h;
+    h->stream = h->en_stream;
+    return 0;
+  };
   if (soa_current) {
+    // shards whose ECP passes read their point totals back: the host waits for the counting passes while the kinetic pass runs beside them on
+    // the side stream, and has the rest of the evaluation enqueued before the device gets there (the read-back was an idle gap of ~50 us)
+    if (h->necp > 0 && h->ecpb_on == 0 && h->en_overlap && W <= 16384 && !will_defer) TRY(side_begin());
     const dim3 gk((unsigned)((((W + 63) / 64 + 7) / 8) * 8 * ((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB))), bk(64, PQA_KIN_EB);  // see k_kinetic_lw
     if (h->cplx) {
       if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
@@ -26,23 +43,20 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     // caller works on the walker-major state next: the DMC step's T-moves) — the thread-per-point kernel takes the planes
     soa_T = !aos_T_needed && (!h->cplx || h->ecp_point_lw) && h->ndet == 1 && !h->has_j3 && h->ecp_wave == 0 && h->ecp_soa_t;
     if (h->necp > 0) {
+      hipStream_t cur = h->stream;
+      if (side.h) h->stream = side.main;  // (the ECP passes' input: in their stream)
       if (soa_T) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }
       else TRY(lw_to_aos(h, false));
+      if (side.h) {  // the Ewald pass (side stream) reads the walker-major coordinates too
+        HIPCHK(hipEventRecord(h->en_ev[2], h->stream));
+        HIPCHK(hipStreamWaitEvent(cur, h->en_ev[2], 0));
+      }
+      h->stream = cur;
     }
   } else {
     // small shards with ECPs: the kinetic / Coulomb pass on a side stream beside the ECP passes — both are a few thousand latency-bound waves
     // (50-determinant water molecule, 2 048 walkers: 125 us and 245 us one after the other)
-    if (h->necp > 0 && h->en_overlap && W * h->N <= 32768) {
-      if (!h->en_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&h->en_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->en_ev[0], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->en_ev[1], hipEventDisableTiming));
-      }
-      HIPCHK(hipEventRecord(h->en_ev[0], h->stream));
-      HIPCHK(hipStreamWaitEvent(h->en_stream, h->en_ev[0], 0));
-      side.main = h->stream; side.h = h;
-      h->stream = h->en_stream;
-    }
+    if (h->necp > 0 && h->en_overlap && W * h->N <= 32768) TRY(side_begin());
     {  // four waves per walker while the launch is too small to fill the chip with one
       const bool kc4 = h->ecp_acc_waves == 4 || (h->ecp_acc_waves == 0 && W * h->N <= 32768);
       const size_t st_ = (size_t)(h->cplx ? 2 : 1) * lds_det(h, 5);
@@ -185,6 +199,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
       else hipLaunchKernelGGL(k_ecpb_fill<false>, g_b, b_b, 0, h->stream, h->S, h->js, B, A, W);
       TRY(check_launch(h, "k_ecpb_fill"));
     }
+    if (side_join && soa_current) HIPCHK(hipStreamWaitEvent(h->stream, h->en_ev[1], 0));  // (the fill pass reads U_e from the kinetic pass's output)
     if (tot[0] + tot[1] > 0) {
       if (batched) {
       } else

@@ -189,7 +189,7 @@ struct pqa_handle {
   int ecp_defer = 1;
   int en_overlap = 1;  // kinetic / Coulomb pass of small wave-per-walker shards on a side stream beside the ECP passes (PQA_EN_OVERLAP=0: in line)
   hipStream_t en_stream = nullptr;
-  hipEvent_t en_ev[2] = {nullptr, nullptr};
+  hipEvent_t en_ev[3] = {nullptr, nullptr, nullptr};
   bool ecp_hint_valid = false;
   long ecp_hint[2] = {0, 0}, ecp_evals = 0;
   const long* last_ecp_dev[2] = {nullptr, nullptr};
