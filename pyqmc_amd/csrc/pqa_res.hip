@@ -192,6 +192,8 @@ static int res_setup(pqa_handle* h) {
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<false, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)k_sweep_res<true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (const char* dbg = getenv("PQA_RES_DEBUG"); dbg && atoi(dbg) > 1) {  // the lane groups' shell lists with the cost model's figures
     for (int g = 0; g < PQA_RES_G * RT.npass; ++g) {
       fprintf(stderr, "[pqa_res] group %2d:", g);
@@ -250,9 +252,13 @@ int sweep_res(pqa_handle* h, const MoveBuf& mb) {
   }
 #define PQA_RES_LAUNCH(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
 #define PQA_RES_LAUNCH_P(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
-  if (h->cplx && mb.dmc) hipLaunchKernelGGL((k_sweep_res<true, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
-  else if (h->cplx) hipLaunchKernelGGL((k_sweep_res<false, 3, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W);
-  else if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
+#define PQA_RES_LAUNCH_C(D, LM) hipLaunchKernelGGL((k_sweep_res<D, LM, true, true>), grid, block, h->res_lds, h->stream, h->S, L, mb, Tc, h->res_tab, (int)h->has_jastrow, W, 0L, W)
+  if (h->cplx) {
+    if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH_C(true, 2); else PQA_RES_LAUNCH_C(true, 3); }
+    else { if (h->res_lmax <= 2) PQA_RES_LAUNCH_C(false, 2); else PQA_RES_LAUNCH_C(false, 3); }
+  } else
+#undef PQA_RES_LAUNCH_C
+  if (h->S.pbc) {  // (s, p, d shells: 25 running sums of a shell's lattice sum in registers; with f shells 35)
     if (mb.dmc) { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(true, 2); else PQA_RES_LAUNCH_P(true, 3); }
     else { if (h->res_lmax <= 2) PQA_RES_LAUNCH_P(false, 2); else PQA_RES_LAUNCH_P(false, 3); }
   } else
