@@ -223,7 +223,8 @@ bool res_eligible(pqa_handle* h, long W) {
   // 43.3 -> 41.4 at 16384, 82.8 -> 82.1 at 32768)
   // complex determinants (twisted 8-atom cell, VMC step with energy, launches -> resident): 4.29 -> 2.90 ms at 4096 walkers, 6.69 -> 5.33 at 8192,
   // 8.57 -> 7.76 at 12288, 10.8 -> 10.2 at 16384
-  if (h->cplx) return W <= 16384;
+  // (with the instantiation for bases without f shells: 15.3 -> 14.5 ms at 24 576 walkers, 19.7 -> 19.3 at 32 768)
+  if (h->cplx) return W <= 32768;
   if (h->S.pbc) return W <= 32768;
   return W <= 4096 || (std::max(h->nup, h->ndn) >= 16 && W <= 49152);
 }
