@@ -41,6 +41,23 @@ __device__ __forceinline__ double exp_neg(double x) {
   p = fma(p, r, 1.0);
   return ldexp(p, (int)k);
 }
+// Three exponentials side by side, every step of exp_neg for the three arguments in turn: a kernel with one or two waves per SIMD hides
+// the latency of the dependent fma chain only with independent chains in the SAME thread, and the compiler does not interleave the
+// unrolled calls by itself (pqa_res8.hpp).  Bit for bit exp_neg of each argument.
+__device__ __forceinline__ void exp_neg3(double x0, double x1, double x2, double& e0, double& e1, double& e2) {
+  x0 = fmax(x0, -800.0); x1 = fmax(x1, -800.0); x2 = fmax(x2, -800.0);
+  const double k0 = __builtin_rint(x0 * 1.4426950408889634074), k1 = __builtin_rint(x1 * 1.4426950408889634074),
+               k2 = __builtin_rint(x2 * 1.4426950408889634074);
+  double r0 = fma(-k0, 6.93147180369123816490e-01, x0), r1 = fma(-k1, 6.93147180369123816490e-01, x1), r2 = fma(-k2, 6.93147180369123816490e-01, x2);
+  r0 = fma(-k0, 1.90821492927058770002e-10, r0); r1 = fma(-k1, 1.90821492927058770002e-10, r1); r2 = fma(-k2, 1.90821492927058770002e-10, r2);
+  double p0 = 2.519062899249436e-08, p1 = 2.519062899249436e-08, p2 = 2.519062899249436e-08;
+#define PQA_E3(c) p0 = fma(p0, r0, c); p1 = fma(p1, r1, c); p2 = fma(p2, r2, c);
+  PQA_E3(2.761249479944321e-07) PQA_E3(2.7557019442003614e-06) PQA_E3(2.480153911822949e-05) PQA_E3(0.0001984127010654779)
+  PQA_E3(0.0013888888904182626) PQA_E3(0.008333333333235474) PQA_E3(0.04166666666665442) PQA_E3(0.1666666666666677)
+  PQA_E3(0.5) PQA_E3(1.0) PQA_E3(1.0)
+#undef PQA_E3
+  e0 = ldexp(p0, (int)k0); e1 = ldexp(p1, (int)k1); e2 = ldexp(p2, (int)k2);
+}
 #ifndef PQA_EXP_NEG
 #define PQA_EXP_NEG 1  // 0: library exp (A/B: k_orb<5> 129.2 -> 127.3 us, k_orb<1> 821 -> 790, periodic k_orb_wide 193 -> 187)
 #endif
@@ -127,6 +144,9 @@ __device__ __forceinline__ void sph_high(int l, int m, double x, double y, doubl
 // LMAX < 3 compiles the f-shell branch out (callers that know the basis has none: its seven functions set the register
 // high-water mark of the routine); LMAX < 5 the g/h branch (the periodic kernels: their register budget is exhausted — with it
 // k_orb<5,..,PBC=1> went from 213 to 228 VGPRs, 2 to 1 waves per SIMD and +70 % time; periodic cells take l <= 3).
+// The angular half: the shell's 2l+1 functions from its radial sums R = sum c e^{-a r^2}, dRs = sum a c e^{-a r^2}, lapR = sum 2a (2a r^2 - 3) c e^{-a r^2}.
+template <int NCOMP, int LMAX = 5, class Sink>
+__device__ __forceinline__ void shell_angular(int l, double x, double y, double z, double R, double dRs, double lapR, Sink&& sink);
 template <int NCOMP, int LMAX = 5, bool SCREEN = false, class Sink>
 __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, const double* __restrict__ pexp,
                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
@@ -145,6 +165,39 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
     if (NCOMP > 1) dRs += a * t;
     if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
   }
+  shell_angular<NCOMP, LMAX>(l, x, y, z, R, dRs, lapR, sink);
+}
+// The same sums with the primitives three at a time (exp_neg3: independent chains for kernels with one or two waves per SIMD); the
+// primitives are added in the same order as in shell_eval.
+template <int NCOMP, int LMAX = 5, class Sink>
+__device__ __forceinline__ void shell_eval3(int l, double x, double y, double z, const double* __restrict__ pexp,
+                                            const double* __restrict__ pcoef, int np, Sink&& sink) {
+  const double r2 = x * x + y * y + z * z;
+  double R = 0.0, dRs = 0.0, lapR = 0.0;
+  auto add = [&](double a, double c, double e) __attribute__((always_inline)) {
+    const double t = c * e;
+    R += t;
+    if (NCOMP > 1) dRs += a * t;
+    if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
+  };
+  int p = 0;
+#pragma unroll 1
+  for (; p + 3 <= np; p += 3) {
+    const double a0 = pexp[p], a1 = pexp[p + 1], a2 = pexp[p + 2], c0 = pcoef[p], c1 = pcoef[p + 1], c2 = pcoef[p + 2];
+    double e0, e1, e2;
+    exp_neg3(-a0 * r2, -a1 * r2, -a2 * r2, e0, e1, e2);
+    add(a0, c0, e0); add(a1, c1, e1); add(a2, c2, e2);
+  }
+  if (p + 2 == np) {  // two left: the three-way routine with the spare argument at zero (e^0 discarded)
+    const double a0 = pexp[p], c0 = pcoef[p], a1 = pexp[p + 1], c1 = pcoef[p + 1];
+    double e0, e1, e2;
+    exp_neg3(-a0 * r2, -a1 * r2, 0.0, e0, e1, e2);
+    add(a0, c0, e0); add(a1, c1, e1);
+  } else if (p < np) add(pexp[p], pcoef[p], exp_neg(-pexp[p] * r2));
+  shell_angular<NCOMP, LMAX>(l, x, y, z, R, dRs, lapR, sink);
+}
+template <int NCOMP, int LMAX, class Sink>
+__device__ __forceinline__ void shell_angular(int l, double x, double y, double z, double R, double dRs, double lapR, Sink&& sink) {
   dRs *= -2.0;  // grad R = dRs * (x,y,z)
   const double Rx = dRs * x, Ry = dRs * y, Rz = dRs * z;
 #define EMIT(m, S, Sx, Sy, Sz)                                                                             \

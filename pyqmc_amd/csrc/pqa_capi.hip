@@ -405,6 +405,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* ps = getenv("PQA_PROF_STRIDE")) h->prof_stride = (unsigned)std::max(1, atoi(ps));
   if (const char* lw = getenv("PQA_LW")) h->lw_mode = atoi(lw);
   if (const char* rs = getenv("PQA_RES")) h->res_mode = atoi(rs);
+  if (const char* rs = getenv("PQA_R8")) h->r8_mode = atoi(rs);
   if (const char* rs = getenv("PQA_RES_PBC")) h->res_pbc = atoi(rs);
   if (const char* rs = getenv("PQA_RES_CX")) h->res_cx = atoi(rs);
   if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);

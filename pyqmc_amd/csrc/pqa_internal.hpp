@@ -26,6 +26,7 @@
 #include "pqa_slater.hpp"
 #include "pqa_tile.hpp"
 #include "pqa_res.hpp"
+#include "pqa_res8.hpp"
 #include "pqa_dm.hpp"
 #include "pqa_vmc.hpp"
 
@@ -178,6 +179,13 @@ struct pqa_handle {
   int res_lmax = 0;
   int pbc_mincls = 0;
   bool pbc_lists_ok = false;
+  // second generation of the resident sweep for open-boundary real handles (pqa_res8.hpp / pqa_res8.hip): 8 walkers per 256-thread block, two
+  // blocks per CU, wave-uniform AO phase.  PQA_R8: -1 automatic (r8_eligible), 0 never (k_sweep_res / the launches), 1 whenever in scope
+  int r8_mode = -1;
+  bool r8_ready = false, r8_ok = false;
+  R8Tab r8_tab{};
+  size_t r8_lds = 0;
+  double r8_util = 0.0;  // mean fraction of a work item's eight atom slots in use
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
@@ -339,6 +347,10 @@ void launch_flush_cx(pqa_handle* h, const LwState& L, int s, long W, long w0, lo
 bool res_eligible(pqa_handle* h, long W);
 int sweep_res(pqa_handle* h, const MoveBuf& mb);
 int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host);  // (pqa_res.hip: dense coefficient copy follows set_mo)
+// pqa_res8.hip
+static inline int res_rows_alloc(int rows4) { return rows4 + 96; }  // rows of the dense coefficient copies d_cres: zero beyond the basis (k_sweep_r8 contracts six k-steps per trip in every wave)
+bool r8_eligible(pqa_handle* h, long W);
+int sweep_r8(pqa_handle* h, const MoveBuf& mb);
 // pqa_sweep_ww.hip
 bool ww_eligible(pqa_handle* h, long W);
 int sweep_ww(pqa_handle* h, const MoveBuf& mb);

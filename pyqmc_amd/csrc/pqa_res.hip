@@ -9,7 +9,7 @@
 int res_refresh_coeff(pqa_handle* h, int s, const double* mo_host) {
   if (!h->d_cres[s] || h->nmo[s] == 0) return 0;
   const int ldc = 16 * h->nt[s], nmo = h->nmo[s];
-  std::vector<double> pad((size_t)h->res_rows4 * ldc, 0.0);
+  std::vector<double> pad((size_t)res_rows_alloc(h->res_rows4) * ldc, 0.0);  // (zero rows behind the basis: k_sweep_r8's K split)
   for (int a = 0; a < h->nao; ++a)
     for (int j = 0; j < nmo; ++j) pad[(size_t)a * ldc + j] = mo_host[(size_t)a * nmo + j];
   if (h->twist) {  // rows nao .. 2 nao: the imaginary AO parts, (i AO_im)(C_re + i C_im) = AO_im (-C_im + i C_re), columns [re | im] (upload_cpad)
@@ -118,7 +118,7 @@ static int res_setup(pqa_handle* h) {
       if (h->nmo[s] == 0) continue;
       std::vector<double> mo((size_t)h->nao * h->nmo[s]);
       HIPCHK(hipMemcpy(mo.data(), h->d_mo[s], mo.size() * sizeof(double), hipMemcpyDeviceToHost));
-      if (!h->d_cres[s]) TRY(upload_table<double>(h, nullptr, (size_t)rows4 * 16 * h->nt[s], &h->d_cres[s]));
+      if (!h->d_cres[s]) TRY(upload_table<double>(h, nullptr, (size_t)res_rows_alloc(rows4) * 16 * h->nt[s], &h->d_cres[s]));
       TRY(res_refresh_coeff(h, s, mo.data()));
     }
   }

@@ -43,6 +43,9 @@
 #define PQA_RES_MAXPASS 8
 #define PQA_RES_WS 24     // doubles per walker of the per-walker scalars (wsc): 16 of the move + the cell wraps of a folded proposal (or, in a
                           // twisted cell, the folded proposal) + the imaginary part of the determinant phase + the wrap phase of the proposal
+#define PQA_JQP (PQA_JQ + 1)  // doubles per (spin, ion) record of the block's LDS copy of the merged electron-ion numerators: [spin][ion][25] — the
+                            // lanes of a wave read THEIR ion's record, and an odd stride spreads them over the banks (the global layout [ion][spin][24]
+                            // put all 64 lanes on one bank pair: 11 reads of ~64 cycles per pair); slot 24: the ion's cusp coefficient of that spin
 #define PQA_RES_RS 176     // doubles per walker of the combined orbital rows [5][32] (+16: walkers of a wave on disjoint LDS banks)
 
 struct ResTab {
@@ -78,7 +81,7 @@ __host__ __device__ inline size_t res_lds_pbc(int natom, int nL, int icap, int n
 }
 __host__ __device__ inline size_t res_lds_fixed(int nshell, int nprim, int natom, int na, int nlist, int npass) {
   const size_t d = 16 * 32 + 16 * PQA_RES_WS + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
-                   2 * (size_t)natom * PQA_JQ + (3 * PQA_JQ + 24);
+                   2 * (size_t)natom * PQA_JQP + (3 * PQA_JQ + 24);
   const size_t i = 5 * (size_t)nshell + (size_t)nlist + (size_t)npass * 32 + 1 + 64;
   return d * sizeof(double) + i * sizeof(int);
 }
@@ -167,7 +170,7 @@ __device__ __forceinline__ void res_jas_part(const SysDev& S, int e, int r, doub
         sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
         if (rr < S.rcut_a) {
           const RadShared sh = rad_shared_ri<1>(rr, ri, ira);
-          const double* qq = aq + (size_t)(I * 2 + edown) * PQA_JQ;
+          const double* qq = aq + ((size_t)edown * S.natom + I) * PQA_JQP;
           const MergedSums m = ka4 ? pade_merged<1, 4, false>(Da, qq, sh.p) : pade_merged<1, 3, false>(Da, qq, sh.p);
           u_ += sh.omp * m.S1;
           double sg = sh.c0 * m.S2;
@@ -309,8 +312,8 @@ __device__ __forceinline__ void res_jas_m(const SysDev& S, int r, const double (
       const int I = r + 32 * q, Ic = I < S.natom ? I : 0;
       double dx = px - at_xyz[3 * Ic], dy = py - at_xyz[3 * Ic + 1], dz = pz - at_xyz[3 * Ic + 2];
       if (PBC) res_min_image(S, pbt, dx, dy, dz);
-      res_pair_m<false>(S.na > 0 && I < S.natom, dx, dy, dz, S.rcut_a, ira, Da,
-                        aq + (size_t)(Ic * 2 + se) * PQA_JQ, acp, aca, acusp ? acoef[(Ic * S.na) * 2 + se] : 0.0, j);
+      const double* qrec = aq + ((size_t)se * S.natom + Ic) * PQA_JQP;
+      res_pair_m<false>(S.na > 0 && I < S.natom, dx, dy, dz, S.rcut_a, ira, Da, qrec, acp, aca, qrec[PQA_JQ], j);
     }
   }
 }
@@ -432,7 +435,7 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   double* at_xyz = pr_coef + RT.nprim_u;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
   double* aql = acoef + 2 * (size_t)S.natom * (S.na > 0 ? S.na : 1);          // merged Pade numerators per (ion, spin)
-  double* jt = aql + 2 * (size_t)S.natom * PQA_JQ;                             // electron-electron Jastrow tables (res_jas_m)
+  double* jt = aql + 2 * (size_t)S.natom * PQA_JQP;                            // electron-electron Jastrow tables (res_jas_m)
   int* sh_meta = (int*)(jt + PQA_RES_JT);  // l, primitives, first primitive, padded row, atom
   int* glist = sh_meta + 5 * (size_t)S.nshell;
   int* goff = glist + RT.nlist;
@@ -466,7 +469,12 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
   for (int p = tid; p < RT.nprim_u; p += PQA_RES_NT) { pr_exp[p] = RT.prim_exp_u[p]; pr_coef[p] = RT.prim_coef_u[p]; }
   for (int k = tid; k < 3 * S.natom; k += PQA_RES_NT) at_xyz[k] = S.atom_xyz[k];
   for (int k = tid; k < 2 * S.natom * S.na; k += PQA_RES_NT) acoef[k] = has_jastrow ? S.acoeff[k] : 0.0;
-  for (int k = tid; k < 2 * S.natom * PQA_JQ; k += PQA_RES_NT) aql[k] = (has_jastrow && S.jq_on && S.na > 0) ? S.aq[k] : 0.0;
+  for (int k = tid; k < 2 * S.natom * PQA_JQP; k += PQA_RES_NT) {  // [spin][ion][PQA_JQP] from the global [ion][spin][PQA_JQ]; slot 24: cusp coefficient
+    const int j = k % PQA_JQP, I = (k / PQA_JQP) % S.natom, sp = k / (PQA_JQP * S.natom);
+    double v = 0.0;
+    if (has_jastrow && S.jq_on && S.na > 0) v = j < PQA_JQ ? S.aq[(size_t)(I * 2 + sp) * PQA_JQ + j] : (S.a_kind[0] == 1 ? S.acoeff[(I * S.na) * 2 + sp] : 0.0);
+    aql[k] = v;
+  }
   for (int k = tid; k < PQA_RES_JT; k += PQA_RES_NT) {
     double v = 0.0;
     if (has_jastrow && S.jq_on) {

@@ -159,7 +159,9 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
   const long W = h->W;
   MoveBuf mb = mb_in;
   // the resident sweep (pqa_res.hpp: one launch per sweep, state on chip) where the system is in its scope; it reads both tapes
-  const bool res = ((mb.gauss != nullptr) == (mb.unif != nullptr)) && res_eligible(h, W);
+  const bool tapes_ok = (mb.gauss != nullptr) == (mb.unif != nullptr);
+  const bool r8 = tapes_ok && r8_eligible(h, W);  // (second generation, open-boundary real handles: pqa_res8.hpp)
+  const bool res = r8 || (tapes_ok && res_eligible(h, W));
   if (!mb.gauss && !mb.unif && (res || W <= h->draws_max)) {
     // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
     // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD
@@ -170,6 +172,7 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
                        (double*)h->b_gauss.p, (double*)h->b_unif.p);
     mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
   }
+  if (r8) return sweep_r8(h, mb);
   if (res) return sweep_res(h, mb);
   const int N = h->N, KB = lc.KB, nmax = lc.nmax;
   const LwState L = lw_state(h);

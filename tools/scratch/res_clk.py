@@ -18,17 +18,23 @@ wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(1)))
 dev.vmc_sweeps(0.3, 3, seed=5, energy=False)
 lib = _ffi.lib()
 buf = (ctypes.c_ulonglong * (64 * 16))()
-lib.pqa_debug_res_clk.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert lib.pqa_debug_res_clk(buf, 64 * 16) == 0
+r8 = os.environ.get("PQA_R8", "-1") != "0" and len(sys.argv) <= 2  # (the 64-electron cluster runs k_sweep_r8 unless PQA_R8=0)
+fn = lib.pqa_debug_r8_clk if r8 else lib.pqa_debug_res_clk
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert fn(buf, 64 * 16) == 0
 c = np.array(buf[:], dtype=np.float64).reshape(64, 16)[: min(64, (W + 15) // 16)]
+print("kernel", "k_sweep_r8" if r8 else "k_sweep_res")
 seq = [(0, "move entry"), (1, "AO phase (+ barrier wait before)"), (2, "contraction (+ barrier)"), (3, "partials + 2 barriers"), (7, "rows combined"),
        (8, "Slater sums (4 x sum32)"), (9, "Jastrow at the proposal (+ 4 x sum32)"), (4, "Metropolis"), (13, "Sherman-Morrison (accepted)"), (5, "cache row, selector")]
+if r8:  # k_sweep_r8: both Jastrow evaluations run ahead of the orbitals (stamp 9 before the AO phase's barrier)
+    seq = [(0, "move entry"), (9, "Jastrow, both evaluations (+ 12 x sum32)"), (1, "barrier + AO phase"), (2, "contraction (+ barrier)"), (3, "partials + 2 barriers"),
+           (7, "rows combined"), (8, "Slater sums (4 x sum32)"), (4, "Metropolis"), (13, "Sherman-Morrison (accepted)"), (5, "cache row, selector")]
 print("walkers", W, "blocks sampled", len(c))
 prev = 0
 for k, name in seq[1:]:
     ok = c[:, k] >= c[:, prev]
     d = (c[ok, k] - c[ok, prev]) / 100.0
-    print("%-36s %6.2f us  (min %5.2f max %5.2f, n %d)" % (name, d.mean(), d.min(), d.max(), ok.sum()))
+    if len(d): print("%-36s %6.2f us  (min %5.2f max %5.2f, n %d)" % (name, d.mean(), d.min(), d.max(), ok.sum()))
     prev = k
 print("%-36s %6.2f us" % ("entry -> committed", ((c[:, 5] - c[:, 0]) / 100.0).mean()))
 print("previous move's proposal:")
@@ -36,3 +42,7 @@ prev = 5
 for k, name in [(10, "rowE handed over"), (11, "Slater sums"), (12, "Jastrow at the current position"), (6, "drift, proposal")]:
     d = (c[:, k] - c[:, 10 if k != 10 else k]) / 100.0
     print("%-36s at %6.2f us after the hand-over" % (name, d.mean()))
+
+if r8:
+    d = (c[:, 15] - c[:, 14]) / 100.0
+    print("block lifetime (entry -> end of the sweep): mean %.1f us, min %.1f, max %.1f; per move %.2f us" % (d.mean(), d.min(), d.max(), d.mean() / 64))
