@@ -26,7 +26,7 @@
 #include "pqa_slater.hpp"
 #include "pqa_tile.hpp"
 #include "pqa_res.hpp"
-#include "pqa_res8.hpp"
+#include "pqa_res8_tab.hpp"
 #include "pqa_dm.hpp"
 #include "pqa_vmc.hpp"
 

@@ -1,6 +1,7 @@
 // pyqmc_amd C ABI implementation (host side): the second-generation resident sweep (pqa_res8.hpp) — work items of the wave-uniform AO
 // phase, eligibility, launch.  Called by sweep_electrons_fused (pqa_sweep.hip) ahead of k_sweep_res and the launch-per-move sweep.
 #include "pqa_internal.hpp"
+#include "pqa_res8.hpp"
 
 // Once per handle.  Work item = one shell type (same l and the same exponent / coefficient sequence: the same shell of every atom of a
 // species) on up to eight atoms; items go to the four waves by descending cost (longest processing time first).  The tile holds the AOs in
