@@ -24,45 +24,9 @@
 // jastrowspin.py:296-385, numba/gto.py:89-254.
 #pragma once
 #include "pqa_res.hpp"
-
-#define PQA_R8_NT 256
-#define PQA_R8_NW 8
-#define PQA_R8_MAXQ 32   // k-steps one wave contracts at most (kt <= 4 * 32 * KW)
-#define PQA_R8_WS 32      // doubles per walker of the per-walker scalars: 0..15 as k_sweep_res; 16..19 U, grad U of the decided electron at its
-                          // proposal; 20..23 the same of the NEXT electron at its current position if the move is rejected, 24..27 if it is accepted
-
-struct R8Tab {
-  int kt;                   // tile rows: the AOs in their own order, padded to x4 (coefficient copy d_cres[s] [kt][ldc])
-  int cstride;              // doubles between the five component planes of the tile (8 kt, padded so that planes c and c + 1 start 128 B apart mod 256)
-  int nitem;                // AO work items
-  int wave_off[5];          // items of wave w: [wave_off[w], wave_off[w + 1])
-  const int* item_hdr;      // [nitem][4]: l, primitives, first primitive in the deduplicated tables, 0
-  const int* item_lane;     // [nitem][8][2]: atom of the slot (-1: idle), tile row of the shell's first function
-  int nprim_u;
-  const double* prim_exp_u;
-  const double* prim_coef_u;
-  int region;               // doubles of the tile / partial-sum / orbital-row region
-  int stagger;              // the block that shares its CU with an earlier one (LDS base > 0) starts this many x 3 us late: the two blocks' phases
-                            // (AO / contraction / sums) then interleave instead of running in lock step (PQA_R8_STAGGER)
-  int abl;                  // timing builds (-DPQA_RES_CLK) only: phases left out, PQA_R8_ABL bit mask (1 AO, 2 contraction, 4 Jastrow, 8 row / tape prefetch, 16 cache-row stores)
-};
-#ifdef PQA_RES_CLK
-#define PQA_R8_ON(bit) (!(RT.abl & (bit)))
-#else
-#define PQA_R8_ON(bit) true
-#endif
-__host__ __device__ inline size_t r8_lds_fixed(int nprim, int natom, int na, int nitem) {
-  const size_t d = PQA_R8_NW * 32 + PQA_R8_NW * PQA_R8_WS + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
-                   2 * (size_t)natom * PQA_JQP + PQA_RES_JT;
-  const size_t i = 20 * (size_t)nitem + 64 + 8;
-  return d * sizeof(double) + i * sizeof(int);
-}
-
+#include "pqa_res8_tab.hpp"
 
 // One Jastrow pair of the merged route, branch-free (res_pair_m), handed back instead of accumulated: the terms u and g = sg (dx, dy, dz).
-#ifndef PQA_R8_JSERIAL
-#define PQA_R8_JSERIAL 1  // 1: one Jastrow pair at a time (a pair's own polynomial chains run side by side); 0: two
-#endif
 struct R8Pair { double du, sg, dx, dy, dz; };
 __device__ __forceinline__ R8Pair r8_pair(bool valid, double dx, double dy, double dz, double rcut, double ircut, const double (&D)[5],
                                           const double* __restrict__ q, double cpar, double caux, double ccoef) {
@@ -120,21 +84,20 @@ __device__ __forceinline__ void r8_jas_dual(const SysDev& S, int r, const double
   // The seven pairs of the move (three of the decided electron, four of the next one) as independent chains, two side by side: with one
   // wave per SIMD and block a dependent fp64 instruction issues every 10 cycles, two chains every 5.75, the pipe's limit is 4 — and a third
   // chain makes the compiler spill a third of the inverse row across this block (measured: 16.2 against 15.4 us per move).
-#if PQA_R8_JSERIAL
-#define PQA_R8_JSB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PQA_R8_JSB() do { } while (0)
-#endif
+  // The seven pairs of the move (three of the decided electron, four of the next one), ONE AT A TIME, the ion pairs inside (one-trip) loops:
+  // a pair's own chains (denominator and two numerator polynomials, the cusp function) already run side by side, and every attempt to run
+  // pairs side by side — two, three or all seven in one basic block — made the compiler hold their LDS operands early and spill a quarter of
+  // the inverse row across this block (17-22 scratch stores and reloads per move: 19-21 us per move of two resident blocks against 17.2).
+  const int nion = S.natom > 32 ? 2 : 1;
   const R8Pair na_ = r8_pair(v0 && j0 != e, nx - cx[0], ny - cy[0], nz - cz[0], S.rcut_b, irb, Db, q0, bcp, bca, c0);
   r8_acc(jn, na_);
-  PQA_R8_JSB();
+  __builtin_amdgcn_sched_barrier(0);
   const R8Pair nb_ = r8_pair(v1 && j1 != e, nx - cx[1], ny - cy[1], nz - cz[1], S.rcut_b, irb, Db, q0 + PQA_JQ, bcp, bca, c1);
   r8_acc(jn, nb_);
   __builtin_amdgcn_sched_barrier(0);
-  const R8Pair nc_ = ion(r, nx, ny, nz);
-  r8_acc(jn, nc_);
+  for (int q = 0; q < nion; ++q) { const R8Pair nc_ = ion(r + 32 * q, nx, ny, nz); r8_acc(jn, nc_); }
   if (NEXT) {  // ---- the next electron at its current position: partner e at its old place (R) or at its proposal (A)
-    PQA_R8_JSB();
+    __builtin_amdgcn_sched_barrier(0);
     // the partner slot of e's spin twice: e where it is (R) and at its proposal (A; the same pair again in every lane but e's own)
     const bool mine = (se ? j1 : j0) == e;
     const double px_ = mine ? nx : (se ? cx[1] : cx[0]), py_ = mine ? ny : (se ? cy[1] : cy[0]), pz_ = mine ? nz : (se ? cz[1] : cz[0]);
@@ -142,16 +105,11 @@ __device__ __forceinline__ void r8_jas_dual(const SysDev& S, int r, const double
     __builtin_amdgcn_sched_barrier(0);
     const R8Pair a = r8_pair(v0 && j0 != ep, ox - cx[0], oy - cy[0], oz - cz[0], S.rcut_b, irb, Db, q0, bcp, bca, c0);
     r8_acc(joR, a); r8_acc(joA, r8_sel(se == 0, y, a));
-    PQA_R8_JSB();
+    __builtin_amdgcn_sched_barrier(0);
     const R8Pair b = r8_pair(v1 && j1 != ep, ox - cx[1], oy - cy[1], oz - cz[1], S.rcut_b, irb, Db, q0 + PQA_JQ, bcp, bca, c1);
     r8_acc(joR, b); r8_acc(joA, r8_sel(se == 1, y, b));
     __builtin_amdgcn_sched_barrier(0);
-    const R8Pair c = ion(r, ox, oy, oz);
-    r8_acc(joR, c); r8_acc(joA, c);
-  }
-  if (S.natom > 32) {
-    r8_acc(jn, ion(r + 32, nx, ny, nz));
-    if (NEXT) { const R8Pair c = ion(r + 32, ox, oy, oz); r8_acc(joR, c); r8_acc(joA, c); }
+    for (int q = 0; q < nion; ++q) { const R8Pair c = ion(r + 32 * q, ox, oy, oz); r8_acc(joR, c); r8_acc(joA, c); }
   }
 }
 
