@@ -181,12 +181,17 @@ __device__ __forceinline__ void shell_eval3(int l, double x, double y, double z,
     if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
   };
   int p = 0;
+  if (np >= 3) {  // (the next triple's exponents and coefficients are requested before this one's exponentials: their LDS round trip runs under the chains)
+    double a0 = pexp[0], a1 = pexp[1], a2 = pexp[2], c0 = pcoef[0], c1 = pcoef[1], c2 = pcoef[2];
 #pragma unroll 1
-  for (; p + 3 <= np; p += 3) {
-    const double a0 = pexp[p], a1 = pexp[p + 1], a2 = pexp[p + 2], c0 = pcoef[p], c1 = pcoef[p + 1], c2 = pcoef[p + 2];
-    double e0, e1, e2;
-    exp_neg3(-a0 * r2, -a1 * r2, -a2 * r2, e0, e1, e2);
-    add(a0, c0, e0); add(a1, c1, e1); add(a2, c2, e2);
+    for (; p + 3 <= np; p += 3) {
+      const int pn = min(p + 3, np - 3);
+      const double na0 = pexp[pn], na1 = pexp[pn + 1], na2 = pexp[pn + 2], nc0 = pcoef[pn], nc1 = pcoef[pn + 1], nc2 = pcoef[pn + 2];
+      double e0, e1, e2;
+      exp_neg3(-a0 * r2, -a1 * r2, -a2 * r2, e0, e1, e2);
+      add(a0, c0, e0); add(a1, c1, e1); add(a2, c2, e2);
+      a0 = na0; a1 = na1; a2 = na2; c0 = nc0; c1 = nc1; c2 = nc2;
+    }
   }
   if (p + 2 == np) {  // two left: the three-way routine with the spare argument at zero (e^0 discarded)
     const double a0 = pexp[p], c0 = pcoef[p], a1 = pexp[p + 1], c1 = pcoef[p + 1];

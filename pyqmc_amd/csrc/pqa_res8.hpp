@@ -28,12 +28,25 @@
 
 // One Jastrow pair of the merged route, branch-free (res_pair_m), handed back instead of accumulated: the terms u and g = sg (dx, dy, dz).
 struct R8Pair { double du, sg, dx, dy, dz; };
+// (no fix-up of r = 0 and no early replacement of out-of-range distances: whatever an excluded pair produces — the self pair sits at r = 0
+// exactly, 1 / r = inf, NaN products — is discarded by the final select, which is all the branch-free evaluation needs)
 __device__ __forceinline__ R8Pair r8_pair(bool valid, double dx, double dy, double dz, double rcut, double ircut, const double (&D)[5],
                                           const double* __restrict__ q, double cpar, double caux, double ccoef) {
+  const double x = dx * dx + dy * dy + dz * dz;
   double rr, ri;
-  sqrt_rinv(dx * dx + dy * dy + dz * dz, rr, ri);
+  {  // sqrt_rinv without its x == 0 branch
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    const double t = h + h;
+    rr = g; ri = fma(t, fma(-g, t, 1.0), t);
+  }
   const bool in = valid && rr < rcut;
-  rr = in ? rr : 0.5 * rcut; ri = in ? ri : 2.0 * ircut;
   const RadShared sh = rad_shared_ri<1>(rr, ri, ircut);
   const MergedSums m = pade_merged<1, 4, false>(D, q, sh.p);
   double du = sh.omp * m.S1, sg = sh.c0 * m.S2;
@@ -104,15 +117,22 @@ __device__ __forceinline__ void r8_jas_dual(const SysDev& S, int r, const double
     const R8Pair y = r8_pair((se ? v1 : v0) && (se ? j1 : j0) != ep, ox - px_, oy - py_, oz - pz_, S.rcut_b, irb, Db, q0 + se * PQA_JQ, bcp, bca, se ? c1 : c0);
     __builtin_amdgcn_sched_barrier(0);
     const R8Pair a = r8_pair(v0 && j0 != ep, ox - cx[0], oy - cy[0], oz - cz[0], S.rcut_b, irb, Db, q0, bcp, bca, c0);
-    r8_acc(joR, a); r8_acc(joA, r8_sel(se == 0, y, a));
+    r8_acc(joR, a);
+    if (se == 0) r8_acc(joA, y); else r8_acc(joA, a);  // (wave-uniform)
     __builtin_amdgcn_sched_barrier(0);
     const R8Pair b = r8_pair(v1 && j1 != ep, ox - cx[1], oy - cy[1], oz - cz[1], S.rcut_b, irb, Db, q0 + PQA_JQ, bcp, bca, c1);
-    r8_acc(joR, b); r8_acc(joA, r8_sel(se == 1, y, b));
+    r8_acc(joR, b);
+    if (se == 1) r8_acc(joA, y); else r8_acc(joA, b);
     __builtin_amdgcn_sched_barrier(0);
     for (int q = 0; q < nion; ++q) { const R8Pair c = ion(r + 32 * q, ox, oy, oz); r8_acc(joR, c); r8_acc(joA, c); }
   }
 }
 
+// limdrift3 (mc.py:76-89) with one division
+__device__ __forceinline__ void r8_limdrift3(double& gx, double& gy, double& gz) {
+  const double tot = sqrt(gx * gx + gy * gy + gz * gz);
+  if (tot > 1.0) { const double it = 1.0 / tot; gx *= it; gy *= it; gz *= it; }
+}
 template <int KWC>
 __device__ __forceinline__ void r8_combine(const double* __restrict__ pb, int PS, int cstride, double* __restrict__ rn_r) {
   double v[5][KWC];
@@ -130,6 +150,9 @@ __device__ __forceinline__ void r8_combine(const double* __restrict__ pb, int PS
 }
 
 // grid = ceil((w_hi - w_lo) / 8) blocks of 256 threads, two per CU (256 registers per thread, dynamic LDS <= 80 KB).
+// timing builds: the phase stamps of a move in the MIDDLE of the second spin's sweep (the last move has no next electron: half the Jastrow
+// work, no prefetch)
+#define PQA_R8CLK(k) do { if (s == 1 && i == 16) PQA_RCLK(k); } while (0)
 template <bool DMC, int LMAX>
 static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwState L, MoveBuf mb, ChunkTab T, R8Tab RT, int has_jastrow,
                                                                   long W, long w_lo, long w_hi) {
@@ -267,7 +290,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
       };
       if (i < 0) prefetch();
       if (i >= 0) {
-        PQA_RCLK(0);
+        PQA_R8CLK(0);
         if (has_jastrow && PQA_R8_ON(4)) {
           // ---- both Jastrow evaluations of this move, ahead of the orbitals (r8_jas_dual): totals to wsc 16..27
           const bool nxt = i + 1 < n;
@@ -301,7 +324,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             if (nxt) { ws[20] = jr.u; ws[21] = jr.x; ws[22] = jr.y; ws[23] = jr.z; ws[24] = ja.u; ws[25] = ja.x; ws[26] = ja.y; ws[27] = ja.z; }
           }
         }
-        PQA_RCLK(9);
+        PQA_R8CLK(9);
         res_block_sync();  // proposals of all 8 walkers are in wsc; the previous move's reads of the region are done
         int kwv = kw, csv = CS;
         asm volatile("" : "+s"(kwv), "+s"(csv));
@@ -331,14 +354,14 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         // ks = kw + q KW for q < nq = ceil(nks / KW) in EVERY wave — a wave whose last step lies behind the tile contracts the tile's last
         // rows against zeros.  Every load of the loop is unconditional: with a load inside a branch the compiler cannot count what is in
         // flight and waits for vmcnt(0), i.e. for the load it has just issued (k_sweep_res: 4.9 us per contraction against 2 of MFMA time).
-        const int nq = (nks + KW - 1) / KW, nq6 = ((nq + 5) / 6) * 6;  // (six k-steps per trip: the operand rings' static indices; the steps behind nq meet zero rows)
+        const int nq = (nks + KW - 1) / KW;  // k-steps of a wave (six per trip: the operand rings' static indices; a wave's last one may lie behind the tile)
         const size_t bstep = (size_t)4 * KW * ldc;
         const double* cb = cpad + (size_t)(4 * kwv + kq) * ldc + 16 * u + i16;
         double bq[6];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) bq[q] = cb[(size_t)q * bstep];
+        for (int q = 0; q < 5; ++q) bq[q] = cb[(size_t)min(q, nq - 1) * bstep];
         bq[5] = 0.0;
-        PQA_RCLK(1);
+        PQA_R8CLK(1);
         res_block_sync();
         d4 acc[3];
 #pragma unroll
@@ -356,21 +379,23 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             xa[0][0] = a0[ka]; xa[0][1] = a1[ka]; xa[0][2] = a2[ka];
           }
 #pragma unroll 1
-          for (int q6 = 0; q6 < nq6 && PQA_R8_ON(2); q6 += 6) {
+          for (int q6 = 0; q6 < nq && PQA_R8_ON(2); q6 += 6) {
 #pragma unroll
             for (int qq = 0; qq < 6; ++qq) {
               const int q = q6 + qq;
-              bq[(qq + 5) % 6] = cb[(size_t)min(q + 5, nq6 - 1) * bstep];
+              bq[(qq + 5) % 6] = cb[(size_t)min(q + 5, nq - 1) * bstep];
               const int ka = min(kwv + (q + 1) * KW, nks - 1) * 32;
               xa[(qq + 1) & 1][0] = a0[ka]; xa[(qq + 1) & 1][1] = a1[ka]; xa[(qq + 1) & 1][2] = a2[ka];
-              acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][0], bq[qq], acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][1], bq[qq], acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][2], bq[qq], acc[2], 0, 0, 0);
+              if (q < nq) {  // (wave-uniform; the loads above stay unconditional so that the compiler can count them)
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][0], bq[qq], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][1], bq[qq], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[qq & 1][2], bq[qq], acc[2], 0, 0, 0);
+              }
             }
           }
         }
         prefetch();
-        PQA_RCLK(2);
+        PQA_R8CLK(2);
         res_block_sync();  // every wave is done reading the tile: the K-partials take its place
         {
           // lane holds D[m = kq + 4 rr][orbital = 16 u + i16]: rr 0, 1 -> component 2 j of points kq, kq + 4; rr 2, 3 -> component 2 j + 1
@@ -384,18 +409,18 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             }
         }
         res_block_sync();
-        PQA_RCLK(3);
+        PQA_R8CLK(3);
         // ---- this walker's rows: the KW partials added in a fixed order (thread r: orbital r, five components)
         if (r < 16 * nt) {
           if (KW == 2) r8_combine<2>(part + (size_t)wl * PS + r, PS, 16 * nt, rn + r);
           else r8_combine<4>(part + (size_t)wl * PS + r, PS, 16 * nt, rn + r);
         }
         res_wave_sync();
-        PQA_RCLK(7);
+        PQA_R8CLK(7);
         const double te = rowE[wl * 32 + r];
         p0 = rn[oc] * te; p1 = rn[32 + oc] * te; p2 = rn[64 + oc] * te; p3 = rn[96 + oc] * te;
         p0 = res_sum32(p0); p1 = res_sum32(p1); p2 = res_sum32(p2); p3 = res_sum32(p3);
-        PQA_RCLK(8);
+        PQA_R8CLK(8);
       }
       const bool have_dec = i >= 0, have_prop = i + 1 < n;
       bool accd = false;
@@ -403,13 +428,14 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         // ================= decide electron i (mc.py:124-132; dmc.py:57-70): the same numbers in all lanes of the walker
         const double npx = ws[0], npy = ws[1], npz = ws[2];
         const double dr = p0;
-        double hx = finite_or(p1 / p0, 0.0), hy = finite_or(p2 / p0, 0.0), hz = finite_or(p3 / p0, 0.0);
+        const double ip0 = 1.0 / p0;  // (one division for the three drift components)
+        double hx = finite_or(p1 * ip0, 0.0), hy = finite_or(p2 * ip0, 0.0), hz = finite_or(p3 * ip0, 0.0);
         const double val = finite_or(dr, 1.0);
         double val2 = val * val;
+        double jexp = 0.0;  // exponent of the Jastrow factor's part of the acceptance ratio: |Psi_new / Psi_old|^2 = val^2 exp(2 (U_new - U_old))
         if (has_jastrow) {  // (summed ahead of the orbitals: wsc 16..19)
           hx += ws[17]; hy += ws[18]; hz += ws[19];
-          const double ej = exp(ws[16] - ws[9]);
-          val2 *= ej * ej;
+          jexp = 2.0 * (ws[16] - ws[9]);
         }
         {
           const double z0 = ws[3], z1 = ws[4], z2 = ws[5], d0 = ws[6], d1 = ws[7], d2 = ws[8];
@@ -419,11 +445,11 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             limdrift_dmc(hx, hy, hz, mb.tstep);
             bx = z0 + d0 + hx; by = z1 + d1 + hy; bz = z2 + d2 + hz;
           } else {
-            limdrift3(hx, hy, hz);
+            r8_limdrift3(hx, hy, hz);
             bx = z0 + mb.tstep * (d0 + hx); by = z1 + mb.tstep * (d1 + hy); bz = z2 + mb.tstep * (d2 + hz);
           }
           const double bwd = bx * bx + by * by + bz * bz;
-          double ratio = val2 * exp(jt[3 * PQA_JQ + 16] * (fwd - bwd));
+          double ratio = val2 * exp(jexp + jt[3 * PQA_JQ + 16] * (fwd - bwd));  // (one exponential for the Jastrow ratio and the Green's function ratio)
           if (DMC) ratio *= (val > 0.0) ? 1.0 : ((val < 0.0) ? -1.0 : 0.0);  // fixed node (dmc.py:64-66)
           accd = ratio > uacc;
           if (DMC && r == 0) {
@@ -433,7 +459,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
           }
         }
         if (live && r == 0 && mb.accept_rec) mb.accept_rec[(size_t)e * W + wg] = accd;
-        PQA_RCLK(4);
+        PQA_R8CLK(4);
         if (accd) {
           // Sherman-Morrison on the register rows (slater.py:88-94): R = T_old[i] / ratio, T[j] -= R (V . T[j]), T[i] = R;
           // the row's dot product in the PQA_ROWDOT order of the lane-per-walker kernels
@@ -467,7 +493,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          PQA_RCLK(13);
+          PQA_R8CLK(13);
           if (r == 0) {  // sign and log of the determinant: running product of |ratio|, its logarithm taken when it leaves [1e-60, 1e60]
             const double mag = fabs(dr);
             ws[10] *= (dr > 0.0) ? 1.0 : ((dr < 0.0) ? -1.0 : dr);
@@ -491,7 +517,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
             if (live) sels[(size_t)i * W + wg] = (uint8_t)selr;
           }
         }
-        PQA_RCLK(5);
+        PQA_R8CLK(5);
       }
       // ================= propose electron i + 1 (mc.py:117-121): drift at its current position
       if (have_prop) {
@@ -502,18 +528,19 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
           for (int k = 0; k < 32; ++k) rowE[wl * 32 + k] = t[k];
         }
         res_wave_sync();
-        PQA_RCLK(10);
+        PQA_R8CLK(10);
         double gx, gy, gz;
         {
           const double te = rowE[wl * 32 + r];
           double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
           q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
-          gx = finite_or(q1 / q0, 0.0); gy = finite_or(q2 / q0, 0.0); gz = finite_or(q3 / q0, 0.0);
+          const double iq0 = 1.0 / q0;
+          gx = finite_or(q1 * iq0, 0.0); gy = finite_or(q2 * iq0, 0.0); gz = finite_or(q3 * iq0, 0.0);
         }
         const int src = (lane & 32) | ip;
         const double pox = __shfl(s ? cx[1] : cx[0], src, 64), poy = __shfl(s ? cy[1] : cy[0], src, 64), poz = __shfl(s ? cz[1] : cz[0], src, 64);
         double U0 = 0.0;
-        PQA_RCLK(11);
+        PQA_R8CLK(11);
         if (has_jastrow && i >= 0) {  // (summed ahead for both outcomes of the decision: wsc 20..23 rejected, 24..27 accepted)
           const double* jq = ws + (accd ? 24 : 20);
           U0 = jq[0]; gx += jq[1]; gy += jq[2]; gz += jq[3];
@@ -528,8 +555,8 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
           jo.u = res_sum32(jo.u); jo.x = res_sum32(jo.x); jo.y = res_sum32(jo.y); jo.z = res_sum32(jo.z);
           U0 = jo.u; gx += jo.x; gy += jo.y; gz += jo.z;
         }
-        PQA_RCLK(12);
-        if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else limdrift3(gx, gy, gz);
+        PQA_R8CLK(12);
+        if (DMC) limdrift_dmc(gx, gy, gz, mb.tstep); else r8_limdrift3(gx, gy, gz);
         const double sq = jt[3 * PQA_JQ + 15], df = DMC ? 1.0 : mb.tstep;
         const double z0 = g0 * sq, z1 = g1 * sq, z2 = g2 * sq;
         if (r == 0) {
@@ -537,7 +564,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
           ws[3] = z0; ws[4] = z1; ws[5] = z2; ws[6] = gx; ws[7] = gy; ws[8] = gz; ws[9] = U0;
         }
         res_wave_sync();
-        PQA_RCLK(6);
+        PQA_R8CLK(6);
       }
     }
     // ---- this spin's state back to the planes
