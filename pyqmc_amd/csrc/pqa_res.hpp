@@ -548,17 +548,17 @@ static __global__ __launch_bounds__(PQA_RES_LB) void k_sweep_res(SysDev S, LwSta
     const int ncol = CX ? 2 * n : n;  // doubles per inverse row (complex: (re, im) pairs — 16 electrons of a spin at most)
     const int nh = CX ? nmo / 2 : nmo;  // orbitals (complex: the rows are [re block | im block])
     // ---- the transposed inverse of this spin: row r of walker wl
+    // (all 32 loads in flight at once — clamped addresses, the entries outside the block multiplied by zero: with a select per element the
+    // compiler branches around each load, and the opaque copy used against that until round 6 made it wait for every load before it issued
+    // the next: 32 dependent HBM round trips per spin)
     double t[32];
+    {
+      const double* trow = Tg + (size_t)(r < n ? r : 0) * ncol * W;
+      const double rm = r < n ? 1.0 : 0.0;
 #pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8) {
+      for (int k = 0; k < 32; ++k) t[k] = trow[(size_t)(k < ncol ? k : 0) * W];
 #pragma unroll
-      for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {  // (unconditional loads of clamped addresses: a branch per element otherwise)
-        double v = Tg[((size_t)(r < n ? r : 0) * ncol + (k < ncol ? k : 0)) * W];
-        asm volatile("" : "+v"(v));
-        t[k] = (r < n && k < ncol) ? v : 0.0;
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < 32; ++k) t[k] *= (k < ncol) ? rm : 0.0;
     }
     int selr = (r < n) ? (int)sels[(size_t)r * W + wg] : 0;  // slot of electron r's cached row
     if (r == 0) {  // per-walker scalars of this spin's sweep live in LDS (wsc 10..12: sign, log, running product of |ratio|)

@@ -100,7 +100,8 @@ static int r8_setup(pqa_handle* h) {
     if (rows4 / 4 > PQA_R8_MAXQ * KW) return 0;
     part_rn = std::max(part_rn, (size_t)KW * PQA_R8_NW * res_ps(nt) + (size_t)PQA_R8_NW * PQA_RES_RS);
   }
-  RT.region = (int)std::max((size_t)5 * RT.cstride, part_rn);
+  RT.jstage = (int)part_rn;
+  RT.region = (int)std::max((size_t)5 * RT.cstride, part_rn + (size_t)PQA_R8_NW * 12 * 33);
   RT.nprim_u = (int)pe_u.size();
   h->r8_lds = (size_t)RT.region * sizeof(double) + r8_lds_fixed(RT.nprim_u, h->natom, h->na, nitem);
   h->r8_lds = (h->r8_lds + 15) & ~(size_t)15;
@@ -179,6 +180,7 @@ int sweep_r8(pqa_handle* h, const MoveBuf& mb) {
   else { if (h->res_lmax <= 2) PQA_R8_LAUNCH(false, 2); else PQA_R8_LAUNCH(false, 3); }
 #undef PQA_R8_LAUNCH
   if (e1) HIPCHK(hipEventRecord(e1, h->stream));
+  h->slk_fresh = mb.slk != nullptr;
   return check_launch(h, "k_sweep_r8");
 }
 

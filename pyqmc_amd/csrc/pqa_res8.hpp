@@ -241,17 +241,17 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
     const int* occs = occ + 32 * s;
     const bool ident = (s ? S.occ_ident[1] : S.occ_ident[0]) != 0;
     // ---- the transposed inverse of this spin: row r of walker wl
+    // (all 32 loads in flight at once — clamped addresses, the entries outside the n x n block multiplied by zero: with a select per element
+    // the compiler branches around each load, and the opaque copy k_sweep_res used against that made it wait for every load before it issued
+    // the next: 32 dependent HBM round trips per spin, ~40 us of a block's 1.07 ms)
     double t[32];
+    {
+      const double* trow = Tg + (size_t)(r < n ? r : 0) * n * W;
+      const double rm = r < n ? 1.0 : 0.0;
 #pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8) {
+      for (int k = 0; k < 32; ++k) t[k] = trow[(size_t)(k < n ? k : 0) * W];
 #pragma unroll
-      for (int k = 8 * k8; k < 8 * k8 + 8; ++k) {
-        double v = Tg[((size_t)(r < n ? r : 0) * n + (k < n ? k : 0)) * W];
-        asm volatile("" : "+v"(v));
-        t[k] = (r < n && k < n) ? v : 0.0;
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      for (int k = 0; k < 32; ++k) t[k] *= (k < n) ? rm : 0.0;
     }
     int selr = (r < n) ? (int)sels[(size_t)r * W + wg] : 0;
     if (r == 0) {
@@ -314,14 +314,27 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
               ja.x = g3[0]; ja.y = g3[1]; ja.z = g3[2];
             }
           }
-          jn.u = res_sum32(jn.u); jn.x = res_sum32(jn.x); jn.y = res_sum32(jn.y); jn.z = res_sum32(jn.z);
-          if (nxt) {
-            jr.u = res_sum32(jr.u); jr.x = res_sum32(jr.x); jr.y = res_sum32(jr.y); jr.z = res_sum32(jr.z);
-            ja.u = res_sum32(ja.u); ja.x = res_sum32(ja.x); ja.y = res_sum32(ja.y); ja.z = res_sum32(ja.z);
-          }
-          if (r == 0) {
-            ws[16] = jn.u; ws[17] = jn.x; ws[18] = jn.y; ws[19] = jn.z;
-            if (nxt) { ws[20] = jr.u; ws[21] = jr.x; ws[22] = jr.y; ws[23] = jr.z; ws[24] = ja.u; ws[25] = ja.x; ws[26] = ja.y; ws[27] = ja.z; }
+          // The walker's totals of the twelve (four) sums through LDS instead of twelve 32-lane butterflies (13 vector instructions each, 160 of
+          // the move's ~1300 Jastrow instructions): every lane writes its terms, lane v adds the 32 terms of sum v in a fixed order and leaves
+          // the total in wsc 16 + v.  The staging area is the part of the region behind the partials and orbital rows, which nothing uses
+          // between the combination of the previous move and this move's AO phase; only this walker's lanes touch its slice (wave-local order).
+          {
+            double* st = region + RT.jstage + (size_t)wl * (12 * 33);
+            const int nv = nxt ? 12 : 4;
+            st[r] = jn.u; st[33 + r] = jn.x; st[66 + r] = jn.y; st[99 + r] = jn.z;
+            if (nxt) {
+              st[132 + r] = jr.u; st[165 + r] = jr.x; st[198 + r] = jr.y; st[231 + r] = jr.z;
+              st[264 + r] = ja.u; st[297 + r] = ja.x; st[330 + r] = ja.y; st[363 + r] = ja.z;
+            }
+            res_wave_sync();
+            if (r < nv) {
+              const double* sv = st + 33 * r;
+              double a0 = sv[0], a1 = sv[1], a2 = sv[2], a3 = sv[3];
+#pragma unroll
+              for (int j = 4; j < 32; j += 4) { a0 += sv[j]; a1 += sv[j + 1]; a2 += sv[j + 2]; a3 += sv[j + 3]; }
+              ws[16 + r] = (a0 + a1) + (a2 + a3);
+            }
+            res_wave_sync();
           }
         }
         PQA_R8CLK(9);
@@ -565,6 +578,39 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         }
         res_wave_sync();
         PQA_R8CLK(6);
+      }
+    }
+    // ---- Slater parts of the kinetic energy at the sweep's final configuration (mb.slk; energy.py:57-65, slater.py:403-446): electron r's
+    // inverse row is in this thread's registers, its cached orbital row [5][nmo] in the slot the selector names — the accepted moves' rows
+    // were stored by the other lanes of this walker, hence the workgroup fence (one CU, one L1: a wait for the stores).  The energy pass's
+    // own pass over the inverse and the row cache (96 KB per walker at 3.5 TB/s, half of k_kinetic_lw) is skipped in exchange; here the
+    // loads run under the other resident block's arithmetic.
+    if (mb.slk) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (live && r < n) {
+        const double* row = rcs + (((size_t)r * 2 + selr) * W + wg) * 5 * nmo;
+        double rc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (ident && (nmo & 7) == 0) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int j = 0; j < 32; j += 8)
+              if (j < n) {
+                const double4 lo = *reinterpret_cast<const double4*>(row + c * nmo + j), hi = *reinterpret_cast<const double4*>(row + c * nmo + j + 4);
+                rc[c] += lo.x * t[j]; rc[c] += lo.y * t[j + 1]; rc[c] += lo.z * t[j + 2]; rc[c] += lo.w * t[j + 3];
+                rc[c] += hi.x * t[j + 4]; rc[c] += hi.y * t[j + 5]; rc[c] += hi.z * t[j + 6]; rc[c] += hi.w * t[j + 7];
+              }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 32; ++k)
+            if (k < n) {
+              const int o = occs[k];
+#pragma unroll
+              for (int c = 0; c < 5; ++c) rc[c] += row[c * nmo + o] * t[k];
+            }
+        }
+        const size_t o_ = (size_t)(e0 + r) * W + wg, NW_ = (size_t)S.nelec * W;
+        mb.slk[o_] = rc[1] / rc[0]; mb.slk[NW_ + o_] = rc[2] / rc[0]; mb.slk[2 * NW_ + o_] = rc[3] / rc[0]; mb.slk[3 * NW_ + o_] = rc[4] / rc[0];
       }
     }
     // ---- this spin's state back to the planes

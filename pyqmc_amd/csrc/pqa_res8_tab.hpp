@@ -20,6 +20,7 @@ struct R8Tab {
   const double* prim_exp_u;
   const double* prim_coef_u;
   int region;               // doubles of the tile / partial-sum / orbital-row region
+  int jstage;               // offset (doubles) of the Jastrow sums' staging area [8][12][33] in the region, behind the partials and orbital rows
   int stagger;              // the block that shares its CU with an earlier one (LDS base > 0) starts this many x 3 us late: the two blocks' phases
                             // (AO / contraction / sums) then interleave instead of running in lock step (PQA_R8_STAGGER)
   int abl;                  // timing builds (-DPQA_RES_CLK) only: phases left out, PQA_R8_ABL bit mask (1 AO, 2 contraction, 4 Jastrow, 8 row / tape prefetch, 16 cache-row stores)
