@@ -27,7 +27,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
   if (soa_current) {
     // shards whose ECP passes read their point totals back: the host waits for the counting passes while the kinetic pass runs beside them on
     // the side stream, and has the rest of the evaluation enqueued before the device gets there (the read-back was an idle gap of ~50 us)
-    if (h->necp > 0 && h->ecpb_on == 0 && h->en_overlap && W <= 16384 && !will_defer) TRY(side_begin());
+    if (h->necp > 0 && h->ecpb_on == 0 && h->en_overlap && (W <= 16384 || h->en_overlap > 1) && !will_defer) TRY(side_begin());  // (PQA_EN_OVERLAP=2: at every size, A/B)
     const dim3 gk((unsigned)((((W + 63) / 64 + 7) / 8) * 8 * ((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB))), bk(64, PQA_KIN_EB);  // see k_kinetic_lw
     if (h->cplx) {
       if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);

@@ -188,7 +188,7 @@ struct pqa_handle {
   double r8_util = 0.0;
   DevBuf b_slk;            // [4][N][W] Slater kinetic terms left by k_sweep_r8 for the energy pass of the same step (MoveBuf::slk)
   bool slk_fresh = false;  // set by sweep_r8 when it wrote them; the step loop hands them to energy_dev and clears the flag
-  int r8_slk = 1;          // PQA_R8_SLK=0: the kinetic pass forms them itself (A/B)  // mean fraction of a work item's eight atom slots in use
+  int r8_slk = 0;          // PQA_R8_SLK=1: on (measured: the sweep's epilogue +3.0 ms at 65 536 walkers — every lane streams its own 1 280-B row — for -0.7 ms of the kinetic pass)  // mean fraction of a work item's eight atom slots in use
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
