@@ -300,6 +300,9 @@ int pqa_ecp_batched_moves(pqa_handle_t* h, int e, double tau, const double* rot,
    when the wave-function state changed since that call (recompute, update, resample, sweep, parameter change).  With tapes the
    index-0 energy draws of the call are unused. */
 int pqa_dmc_continue(pqa_handle_t* h, int on);
+/* 1 while the energies of the last pqa_dmc_steps call still describe the resident walkers' state (pqa_dmc_continue would be honoured), else 0:
+   a per-step caller whose host accumulators may have touched the state asks before it continues (pyqmc_amd.dmc; dmc.py:196-212). */
+int pqa_dmc_can_continue(pqa_handle_t* h);
 int pqa_tmove_npoints(pqa_handle_t* h);
 int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif, double* ratio,
                double* weight, double* pos);

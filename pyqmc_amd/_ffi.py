@@ -118,6 +118,7 @@ _PROTOTYPES = {
     "pqa_last_ecp_points": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "pqa_set_ecp_naip": (C.c_int, [_H, C.c_int32]),
     "pqa_dmc_continue": (C.c_int, [_H, C.c_int]),
+    "pqa_dmc_can_continue": (C.c_int, [_H]),
     "pqa_wf_eval": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pqa_wf_update": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "pqa_set_ecp_batched": (C.c_int, [_H, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),

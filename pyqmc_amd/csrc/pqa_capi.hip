@@ -1016,6 +1016,10 @@ extern "C" int pqa_eval_mo(pqa_handle_t* h, int spin, const double* pts, int64_t
 // ---------------------------------------------------------------- walker state allocation
 static int ensure_walkers(pqa_handle* h, long W) {
   if (W <= 0) FAIL("number of walkers must be positive");
+  if (W != h->W) {  // (the deferred ECP point totals and the kernel-choice hints describe the shard they were measured on: ADVICE r5)
+    h->ecp_hint_valid = false; h->last_ecp_dev[0] = h->last_ecp_dev[1] = nullptr;
+    if (h->last_ecp_points < 0) h->last_ecp_points = 0;
+  }
   h->W = W;
   h->saved_valid = false;
   TRY(ensure(h, h->b_x, (size_t)W * h->N * 3 * sizeof(double)));
@@ -2062,6 +2066,8 @@ extern "C" int pqa_set_ecp_naip(pqa_handle_t* h, int32_t naip) {
     qo[k] = ecp_quadrature_offset(na[k]);
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->ecp_hint_valid = false; h->last_ecp_dev[0] = h->last_ecp_dev[1] = nullptr;  // (another rule: other point totals)
+  if (h->last_ecp_points < 0) h->last_ecp_points = 0;
   h->S.ecp_naip_max = 0;
   for (int k = 0; k < h->necp; ++k) h->S.ecp_naip_max = std::max(h->S.ecp_naip_max, na[k]);
   HIPCHK(hipMemcpy(h->d_ecp_naip, na.data(), na.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -217,6 +217,8 @@ extern "C" int pqa_dmc_continue(pqa_handle_t* h, int on) {
   return 0;
 }
 
+extern "C" int pqa_dmc_can_continue(pqa_handle_t* h) { return (h->dmc_old_valid && h->dmc_old_W == h->W) ? 1 : 0; }
+
 extern "C" int pqa_tmove_npoints(pqa_handle_t* h) { return h->tm_P; }
 
 extern "C" int pqa_tmoves(pqa_handle_t* h, int e, double tau, double threshold, const double* rot, const double* unif,

@@ -45,6 +45,16 @@ def _record_tapes(rng, nsteps, N, necp, W, tmoves):
     return t
 
 
+def _refuse_batched_tmoves(acc, necp):
+    """Both device step loops (all-device and one step per call) draw their T-move candidates inside ``pqa_dmc_steps`` from the semi-local
+    integrator's table (eval_ecp.compute_tmoves); an accumulator bound with ``use_old_ecp=False`` would have its ENERGY from the batched
+    integrator and its T-MOVES from the other one — refused in both, not mixed silently."""
+    if acc.has_nonlocal_moves() and necp > 0 and not getattr(acc, "use_old_ecp", True):
+        raise NotImplementedError("the device DMC driver draws its T-move candidates from the semi-local integrator's table (eval_ecp.compute_tmoves); "
+                                  "with use_old_ecp=False run the reference's pyqmc.method.dmc over the protocol objects: "
+                                  "EnergyAccumulator.nonlocal_tmoves then serves the batched candidates (INTEGRATION.md)")
+
+
 def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est, nsteps, acc, name, rng, state_current=False):
     """``dmc_propagate`` through ``pqa_dmc_steps``: the whole step loop stays on the device."""
     from .energy import KEYS
@@ -52,10 +62,7 @@ def _propagate_fused(dev, wf, configs, weights, tstep, branchcut, e_trial, e_est
     W, N = configs.configs.shape[:2]
     necp = getattr(dev, "necp", 0)
     tmoves = acc.has_nonlocal_moves() and necp > 0
-    if tmoves and not getattr(acc, "use_old_ecp", True):
-        raise NotImplementedError("the device DMC driver draws its T-move candidates from the semi-local integrator's table (eval_ecp.compute_tmoves); "
-                                  "with use_old_ecp=False run the reference's pyqmc.method.dmc over the protocol objects: "
-                                  "EnergyAccumulator.nonlocal_tmoves then serves the batched candidates (INTEGRATION.md)")
+    _refuse_batched_tmoves(acc, necp)
     if not state_current:  # the reference recomputes at the start of every block (dmc.py:155)
         wf.recompute(configs)
     acc.bind(dev)
@@ -95,6 +102,7 @@ def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_
 
     acc, name = accumulators[ekey[0]], ekey[0]
     W = configs.configs.shape[0]
+    _refuse_batched_tmoves(acc, getattr(dev, "necp", 0))
     if not state_current:
         wf.recompute(configs)
     acc.bind(dev)
@@ -108,8 +116,10 @@ def _propagate_host_accumulators(dev, wf, configs, weights, tstep, branchcut, e_
         step_tapes = None
         if tapes is not None:  # this step's slice; the energy draws: [starting configuration (used by the first call only), this step]
             step_tapes = {k: (np.stack([v[0 if i == 0 else i], v[i + 1]]) if k.startswith("ecp_") else v[i:i + 1]) for k, v in tapes.items()}
+        # a host accumulator of the previous step may have touched the device state (wf.recompute, parameter setters): the energies the
+        # device kept are then gone and the step starts from a fresh evaluation, as the first one does
         avg, stat = dev.dmc_steps(tstep, 1, w, branchcut, e_trial, e_est, threshold=acc.threshold, tapes=step_tapes,
-                                  seed=int(np.random.randint(0, 2**31 - 1)), cont=i > 0)
+                                  seed=int(np.random.randint(0, 2**31 - 1)), cont=i > 0 and dev.dmc_can_continue())
         _fetch(dev, configs)
         wavg = float(avg[0, 6])
         d = {name + k: avg[0, i] for i, k in enumerate(KEYS[:6])}

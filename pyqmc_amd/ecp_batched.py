@@ -75,6 +75,10 @@ class ECPAccumulator:
 
     def bind(self, dev):
         dev.set_ecp_batched(self.naip, self.nselect_deterministic, self.nselect_random)
+        # the ECP row comes out of the handle's whole energy pass (kinetic, Coulomb, ECP), and on a periodic handle that pass refuses to run
+        # without the Ewald tables — which only an EnergyAccumulator would have set: a standalone ECPAccumulator sets the defaults itself
+        if getattr(dev, "pbc", False) and getattr(dev, "_ewald_key", None) is None:
+            dev.set_ewald()
 
     def _rotations(self, dev, n, rot):
         if rot is not None:

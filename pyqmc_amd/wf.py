@@ -355,6 +355,10 @@ class DeviceWF:
                   _ffi.ptr(weights), None if tp is None else C.addressof(tp), int(seed), _ffi.ptr(avg), _ffi.ptr(acc))
         return avg, acc
 
+    def dmc_can_continue(self):
+        """True while the device still holds the energies its last ``dmc_steps`` call ended with for the resident state (``pqa_dmc_can_continue``)."""
+        return bool(self.call_int("pqa_dmc_can_continue"))
+
     # measurement ----------------------------------------------------------
     def sync(self):
         self.call("pqa_sync")

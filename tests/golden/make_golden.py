@@ -444,6 +444,46 @@ def g_big():
     save("g35_big", **out)
 
 
+# ------------------------------------------------------------------ G37 VMC trajectory of the headline system
+def g_vmc_cluster():
+    """(H2O)8, the 64-electron system of BASELINE.json's metric: one vmc_worker sweep (mc.py:102-153) of 4 walkers with the energy, every
+    draw recorded — the reference-generated trajectory the resident sweep (k_sweep_r8: 32 electrons per spin, both orbital tiles, the
+    K-split contraction) is held to directly (round-5 verdict, item 2)."""
+    mol = systems.water_cluster()
+    mf = systems.random_mf(mol)
+    wf = make_wf(mol, mf)
+    W, N, nsteps, tstep = 4, sum(mol.nelec), 1, 0.3
+    natm_ecp = sum(1 for a in mol._atom if a[0] in mol._ecp)
+    configs = walkers(mol, W, 137)
+    out = {"start": configs.configs.copy()}
+    accepts = []
+    orig_update = wf.updateinternals
+
+    def spy(e, epos, cfg, mask=None, saved_values=None, _o=orig_update):
+        accepts.append(np.asarray(mask).copy())
+        return _o(e, epos, cfg, mask=mask, saved_values=saved_values)
+
+    wf.updateinternals = spy
+    with Tapes(3700) as t:
+        blk, configs = vmc_worker(wf, configs, tstep, nsteps, {"energy": pyq.EnergyAccumulator(mol)})
+    wf.updateinternals = orig_update
+    out["tstep"], out["nsteps"] = tstep, nsteps
+    out["gauss"] = np.asarray(t.log["normal"]).reshape(nsteps, N, W, 3)
+    out["unif"] = np.asarray(t.log["rand"]).reshape(nsteps, N, W)
+    out["ecp_rot"] = np.asarray(t.log["rot"]).reshape(nsteps, N, natm_ecp, 3, 3)
+    out["ecp_unif"] = np.asarray(t.log["random"]).reshape(nsteps, N, natm_ecp, W)
+    out["accepts"] = np.asarray(accepts).reshape(nsteps, N, W)
+    out["final"] = configs.configs.copy()
+    out["final_log"] = wf.value()[1]
+    for k, v in blk.items():
+        if "time" not in k:
+            out[f"blk_{k}"] = np.asarray(v)
+    for k in ("acoeff", "bcoeff"):
+        out[k] = wf.wf_factors[1].parameters[k]
+    print("cluster vmc: acceptance", blk["acceptance"], "E", blk["energytotal"])
+    save("g37_vmc_cluster", **out)
+
+
 # ------------------------------------------------------------------ G11 VMC trajectory
 def g_vmc():
     out = {}
@@ -1748,3 +1788,4 @@ if __name__ == "__main__":
     g_ecp_naip()
     g_ecp_batched()
     g_big()
+    g_vmc_cluster()

@@ -95,12 +95,26 @@ def _container(mol, x, wrap=None):
     return PeriodicConfigs(x, mol.lattice_vectors(), wrap=wrap) if hasattr(mol, "a") else OpenConfigs(x)
 
 
-@pytest.mark.parametrize("cfg", ["M", "C2", "C3", "C4", "C5"])
-def test_vmc_sweep_at_baseline_size(cfg):
+@pytest.mark.parametrize("cfg", ["M", "M@launches", "M@res16", "M@4096", "M@16384", "C2", "C3", "C4", "C5"])
+def test_vmc_sweep_at_baseline_size(cfg, monkeypatch):
+    """Every BASELINE configuration at its walker count: bit-reproducible from the seed, updated state = fresh recompute, and the first
+    walkers replayed by the CPU oracle on the device's own Philox draws (decisions equal, coordinates to rounding).  The headline system M
+    runs through each of its three sweeps against the oracle: 'M' = what the library selects at 65 536 walkers (the resident sweep
+    k_sweep_r8 since round 6), 'M@launches' the launch-per-move sweep (PQA_RES=0), 'M@res16' k_sweep_res (PQA_R8=0), and the resident
+    sweep at 4 096 and 16 384 walkers (round-5 verdict, item 2: direct oracle parity of the resident sweep on the headline system)."""
     import pyqmc_amd as pa
     from oracle import vmc as ovmc
 
+    cfg, _, variant = cfg.partition("@")
+    if variant == "launches":
+        monkeypatch.setenv("PQA_RES", "0")  # read when the handle is created
+    elif variant == "res16":
+        monkeypatch.setenv("PQA_RES", "1"), monkeypatch.setenv("PQA_R8", "0")
+    elif variant:
+        monkeypatch.setenv("PQA_RES", "1")
     mol, wf, make_oracle, W = build(cfg)
+    if variant.isdigit():
+        W = int(variant)
     dev = wf.fused_device()
     if cfg == "C4":
         assert dev.ndet == 50
@@ -121,7 +135,8 @@ def test_vmc_sweep_at_baseline_size(cfg):
     fresh = dev.recompute(x)[1]
     ok = np.isfinite(fresh)
     assert ok.mean() > 0.999
-    assert note(f"{cfg}_update_vs_recompute", np.max(np.abs(fresh[ok] - logv[ok]))) < (1e-9 if cfg in ("M", "C5") else 1e-11)
+    tag = cfg + ("_" + variant if variant else "")
+    assert note(f"{tag}_update_vs_recompute", np.max(np.abs(fresh[ok] - logv[ok]))) < (1e-9 if cfg in ("M", "C5") else 1e-11)
     # (3) the first walkers, replayed by the oracle on the device's own draws: same decisions, same coordinates
     gauss, unif = dev.philox_tapes(seed, nsteps, NCHECK)
     owf = make_oracle()
@@ -131,7 +146,7 @@ def test_vmc_sweep_at_baseline_size(cfg):
     _, ocfg = ovmc.vmc_worker(mol, owf, ocfg, tstep, gauss, unif, with_energy=False, record=record, margins=margins)
     odec = np.asarray(record).reshape(nsteps, -1, NCHECK)
     same = odec == rec[:, :, :NCHECK]
-    note(f"{cfg}_decisions_equal", same.mean())
+    note(f"{tag}_decisions_equal", same.mean())
     # every decision is the oracle's — except where the oracle's own Metropolis test was a near-tie (|ratio - u| < 1e-9, which
     # round-off may legitimately flip); a walker is only excused from the comparisons below by such a near-tie (none occurs
     # with these seeds: measured 1.0 for every configuration)
@@ -139,12 +154,13 @@ def test_vmc_sweep_at_baseline_size(cfg):
     assert np.all(same | near_tie), (int((~same).sum()), float(np.abs(np.asarray(margins)).min()))
     good = same.all(axis=(0, 1))
     ox = ocfg.configs + (ocfg.wrap @ mol.lattice_vectors() if (cfg == "C3") else 0.0)  # twisted handles keep true coordinates
-    assert note(f"{cfg}_vs_oracle_configs", relerr(x[:NCHECK][good], ox[good])) < 1e-11
-    assert note(f"{cfg}_vs_oracle_log", np.max(np.abs(owf.recompute(ocfg)[1][good] - logv[:NCHECK][good]))) < 1e-9
+    assert note(f"{tag}_vs_oracle_configs", relerr(x[:NCHECK][good], ox[good])) < 1e-11
+    assert note(f"{tag}_vs_oracle_log", np.max(np.abs(owf.recompute(ocfg)[1][good] - logv[:NCHECK][good]))) < 1e-9
 
 
 def test_dmc_steps_at_baseline_size():
-    """C5 at 4096 walkers: the fused DMC step (T-moves, drift-diffusion, weights) is reproducible bit for bit from its
+    """(Its replay part uses the oracle-generated fixture g36: the pinned CPU oracle's dmc_propagate on the device's draws, not the reference itself.)
+    C5 at 4096 walkers: the fused DMC step (T-moves, drift-diffusion, weights) is reproducible bit for bit from its
     seed, leaves a state that equals a fresh recompute, keeps the walkers in the cell and the weights finite and close to 1
     at tstep 0.02 around the trial energy."""
     import pyqmc_amd as pa
@@ -415,7 +431,8 @@ def test_two_gpu_dmc_bench_over_rccl():
 
 
 def test_energy_statistics_against_the_oracle():
-    """north_star: "energies within 1 mHa statistical error of reference" — as a test that can fail.  Trial function: H2O with
+    """(Oracle-generated fixture g29: the expected mean and error bar come from the pinned CPU oracle, not from the reference itself.)
+    north_star: "energies within 1 mHa statistical error of reference" — as a test that can fail.  Trial function: H2O with
     the orbitals of a model one-electron Hamiltonian (systems.model_mf) and the cusp-only default Jastrow, sigma(E_L) ~ 1.6 Ha
     (random orbitals: ~5 Ha).  Reference side: the CPU oracle, 8000 independent chains x 1100 samples, stored by
     tools/make_energy_stats.py in tests/golden/g29_energy_stats.npz together with the wave-function parameters

@@ -323,6 +323,29 @@ def test_vmc_trajectory_golden(tag, mol, fused, monkeypatch):
     assert set(g[tag + "_blk_keys"].tolist()) == set(blk.keys())
 
 
+@pytest.mark.parametrize("sweep", ["r8", "res16", "launches"])
+def test_vmc_trajectory_golden_of_the_headline_system(sweep, monkeypatch):
+    """g37 (reference-generated, make_golden.g_vmc_cluster): one vmc_worker sweep + energy of 4 walkers of the 64-electron (H2O)8 cluster
+    replayed with the reference's own draws through each of the three single-determinant sweeps — the resident sweep of round 6
+    (k_sweep_r8: 8 walkers per block, wave-uniform AO phase, both Jastrow evaluations ahead of the orbitals), k_sweep_res and the
+    launch-per-move sweep: identical accept / reject decisions, final coordinates, log|Psi| and block averages (mc.py:102-153)."""
+    import pyqmc_amd as pa
+
+    monkeypatch.setenv("PQA_RES", "0" if sweep == "launches" else "1")  # read when the handle is created
+    monkeypatch.setenv("PQA_R8", "1" if sweep == "r8" else "0")
+    g = golden("g37_vmc_cluster")
+    mol = systems.water_cluster()
+    wf = helpers.gpu_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["start"].copy())
+    tapes = dict(gauss=g["gauss"], unif=g["unif"], ecp_rot=g["ecp_rot"], ecp_unif=g["ecp_unif"], record=[])
+    blk, configs = pa.vmc_worker(wf, configs, float(g["tstep"]), int(g["nsteps"]), {"energy": pa.EnergyAccumulator(mol)}, tapes=tapes)
+    assert np.array_equal(np.asarray(tapes["record"][0], dtype=bool), g["accepts"])
+    assert note(f"vmc_cluster_{sweep}_final", relerr(configs.configs, g["final"])) < 1e-9
+    assert note(f"vmc_cluster_{sweep}_log", np.max(np.abs(wf.value()[1] - g["final_log"]))) < 1e-8
+    for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
+        assert note(f"vmc_cluster_{sweep}_{k}", relerr(blk[k], g[f"blk_{k}"])) < 1e-8, k
+
+
 def test_masks_and_ragged_sizes():
     """Edge cases the reference tests (testwf.py:20-31 masked = full[mask]; empty mask; W not a
     multiple of the wavefront/tile sizes; single walker)."""

@@ -218,6 +218,23 @@ def test_g11_vmc_trajectory(tag, mol):
     assert set(g[tag + "_blk_keys"].tolist()) == set(blk.keys())
 
 
+def test_g37_vmc_trajectory_of_the_headline_system():
+    """(H2O)8 — 64 electrons, the system of BASELINE.json's metric: one vmc_worker sweep of 4 walkers with the energy, generated by the
+    reference (make_golden.g_vmc_cluster); the oracle replays it on the recorded draws."""
+    g = golden("g37_vmc_cluster")
+    mol = systems.water_cluster()
+    wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    configs = OpenConfigs(g["start"].copy())
+    rec = []
+    blk, configs = ovmc.vmc_worker(mol, wf, configs, float(g["tstep"]), g["gauss"], g["unif"], g["ecp_rot"], g["ecp_unif"], record=rec)
+    acc = np.asarray(rec).reshape(g["accepts"].shape)
+    assert np.array_equal(acc, g["accepts"]) and 0.05 < acc.mean() < 0.999
+    assert relerr(configs.configs, g["final"]) < 1e-9
+    assert np.max(np.abs(wf.value()[1] - g["final_log"])) < 1e-8
+    for k in ("energyke", "energyee", "energyei", "energyecp", "energygrad2", "energytotal", "acceptance"):
+        assert relerr(blk[k], g[f"blk_{k}"]) < 1e-8, k
+
+
 def test_g12_dmc_propagate_and_branch():
     """dmc_propagate (dmc.py:123-221: T-moves, drift-diffusion with fixed-node rejection, weights) and branch
     (:342-376) replayed with the reference's own random draws."""
