@@ -88,13 +88,8 @@ def mol_from_json(d):
     symbols = [a[0] for a in d["_atom"]]
     coords = np.array([a[1] for a in d["_atom"]], dtype=float)  # bohr (Mole.build converts; format_atom, pyscf/gto/mole.py)
     pure = ["".join(ch for ch in s if ch.isalpha()) for s in symbols]  # atom_pure_symbol: 'C1' -> 'C'
-    for sym, shells in d["_basis"].items():
-        for sh in shells:
-            if len(sh) > 1 and not hasattr(sh[1], "__len__"):  # [l, kappa, [exp, c], ...]
-                raise NotImplementedError(f"{sym}: shells with a kappa entry (spinor basis) are not supported")
-            if not all(len(p) == 2 for p in sh[1:]):
-                raise NotImplementedError(f"{sym}: general contractions (several coefficient columns) are not supported")
-    basis = {k: [[int(sh[0])] + [[float(x) for x in p] for p in sh[1:]] for sh in v] for k, v in d["_basis"].items()}
+    # (generally contracted shells and kappa = 0 entries are taken apart by systems.Mol: tables.split_general_contractions)
+    basis = {k: [[int(sh[0])] + [(int(p) if not hasattr(p, "__len__") else [float(x) for x in p]) for p in sh[1:]] for sh in v] for k, v in d["_basis"].items()}
     ecp = {k: (int(v[0]), [[int(ch[0]), [[[float(t[0]), float(t[1])] for t in terms] for terms in ch[1]]] for ch in v[1]]) for k, v in (d.get("_ecp") or {}).items()}
     # effective nuclear charges: _atm[:, 0] (CHARGE_OF) already has the ECP core removed
     if d.get("_atm"):

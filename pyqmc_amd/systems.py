@@ -78,7 +78,10 @@ class Mol:
     def __init__(self, symbols, coords_bohr, nelec=None, basis=None, ecp=None, charges=None):
         self._names = list(symbols)
         self._coords = np.asarray(coords_bohr, dtype=float).reshape(-1, 3)
-        self._basis = {k: (basis or _BASIS)[k] for k in dict.fromkeys(self._names)}
+        from .tables import split_general_contractions
+
+        # (general contractions — several coefficient columns over one set of exponents — become single-column shells in PySCF's AO order)
+        self._basis = {k: split_general_contractions((basis or _BASIS)[k]) for k in dict.fromkeys(self._names)}
         src_ecp = _ECP if ecp is None else ecp
         self._ecp = {k: src_ecp[k] for k in dict.fromkeys(self._names) if k in src_ecp}
         self._atom = [(n, [float(x) for x in c]) for n, c in zip(self._names, self._coords)]
@@ -152,6 +155,27 @@ def water():
     """C2 of BASELINE.json: H2O, 8 valence electrons, 23 AOs."""
     sym, xyz = zip(*_WATER)
     return Mol(sym, xyz)
+
+
+# generally contracted all-electron tables in cc-pVDZ's shape (two s contractions over eight primitives, the p contraction sharing its
+# exponents with an uncontracted function written as a second column with zeros): what every all-electron PySCF checkpoint holds
+_O_GENERAL = [
+    [0, [11720.0, 0.000710, -0.000160], [1759.0, 0.005470, -0.001263], [400.8, 0.027837, -0.006267], [113.7, 0.104800, -0.025716],
+        [37.03, 0.283062, -0.070924], [13.27, 0.448719, -0.165411], [5.025, 0.270952, -0.116955], [1.013, 0.015458, 0.557368]],
+    [0, [0.3023, 1.0]],
+    [1, [17.70, 0.043018, 0.0], [3.854, 0.228913, 0.0], [1.046, 0.508728, 0.0], [0.2753, 0.460531, 1.0]],
+    [2, [1.185, 1.0]],
+]
+_H_GENERAL = [
+    [0, [13.01, 0.019685, 0.0], [1.962, 0.137977, 0.0], [0.4446, 0.478148, 0.0], [0.1220, 0.501240, 1.0]],
+    [1, [0.727, 1.0]],
+]
+
+
+def water_general():
+    """All-electron H2O (5 + 5 electrons, no ECP) in a generally contracted basis: 24 AOs from 6 PySCF shells = 9 single-column shells."""
+    sym, xyz = zip(*_WATER)
+    return Mol(sym, xyz, basis={"O": _O_GENERAL, "H": _H_GENERAL}, ecp={}, charges=[8.0, 1.0, 1.0])
 
 
 def water_cluster(nx=2, ny=2, nz=2, spacing=6.0):

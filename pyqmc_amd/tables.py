@@ -26,14 +26,42 @@ def _shell_norm(l, exps, coefs):
     return [c * inv for c in scaled]
 
 
+def split_general_contractions(shells):
+    """PySCF ``_basis`` entries of one species, ``[l, (kappa,) [exp, c_1, ..., c_n], ...]``, as single-column shells
+    ``[l, [exp, c], ...]`` in PySCF's AO order: a generally contracted shell (n coefficient columns over one set of exponents — every
+    all-electron cc-pVXZ set) is n contracted shells that share their exponents, and its AOs are numbered contraction by contraction
+    (libcint: index = contraction * (2l+1) + m), each column normalised on its own (``gto_norm`` + ``_nomalize_contracted_ao``: what
+    ``_shell_norm`` does).  Primitives whose coefficient in a column is exactly zero are left out of that column: they contribute nothing
+    to its value or its norm.  The reference's default AO path (orbitals.py:46-51, ``mol.eval_gto``) takes any such basis; its in-repo
+    evaluator (numba/gto.py:443-455), the oracle and the device take the split shells."""
+    out = []
+    for sh in shells:
+        l, rows = int(sh[0]), list(sh[1:])
+        if rows and not hasattr(rows[0], "__len__"):  # [l, kappa, [exp, c], ...]
+            if int(rows[0]) != 0:
+                raise NotImplementedError("shells with kappa != 0 (spinor basis sets) are not supported")
+            rows = rows[1:]
+        if not rows:
+            raise ValueError("shell without primitives")
+        ncol = len(rows[0]) - 1
+        if ncol < 1 or any(len(p) != ncol + 1 for p in rows):
+            raise ValueError("every primitive of a shell needs one exponent and the same number of coefficients")
+        for k in range(ncol):
+            prims = [[float(p[0]), float(p[1 + k])] for p in rows if float(p[1 + k]) != 0.0]
+            if not prims:
+                raise ValueError("contraction column without a non-zero coefficient")
+            out.append([l] + prims)
+    return out
+
+
 def basis_tables(mol):
     shell_atom, shell_l, prim_off, ao_off, pexp, pcoef = [], [], [0], [], [], []
     nao = 0
     for ia in range(mol.natm):
         for sh in mol._basis[mol.atom_pure_symbol(ia)]:
             l = int(sh[0])
-            if len(sh[1]) != 2:
-                raise NotImplementedError("general contractions (several coefficient columns) are not supported")
+            if len(sh[1]) != 2:  # (systems.Mol splits general contractions when it is built: split_general_contractions)
+                raise ValueError("mol._basis holds a generally contracted shell: pass it through tables.split_general_contractions")
             exps = [float(p[0]) for p in sh[1:]]
             coefs = _shell_norm(l, exps, [float(p[1]) for p in sh[1:]])
             shell_atom.append(ia)

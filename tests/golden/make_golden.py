@@ -146,6 +146,20 @@ def g_ao():
     save("g2_ao", **out)
 
 
+def g_ao_general():
+    """G38: a generally contracted all-electron basis (systems.water_general: two s contractions over eight primitives, a p contraction
+    sharing its exponents with an uncontracted function) — the reference's in-repo evaluator (numba/gto.py:435-470) takes one coefficient
+    column per shell, so it is fed the single-column shells tables.split_general_contractions makes of the PySCF ``_basis`` entries (which
+    is what ``mol._basis`` of a systems.Mol holds); the oracle and the device do their own split of the generally contracted tables."""
+    rng = np.random.default_rng(38)
+    mol = systems.water_general()
+    ev = refgto.AtomicOrbitalEvaluator(mol)
+    pts = np.concatenate([rng.standard_normal((30, 3)) * 1.2 + mol.atom_coords()[rng.integers(mol.natm, size=30)],
+                          np.linspace(0.0, 5, 9)[:, None] * np.array([0.5, 0.4, -0.7])[None]])
+    save("g38_ao_general", pts=pts, val=ev.eval_gto("GTOval_sph", pts), deriv1=ev.eval_gto("GTOval_sph_deriv1", pts),
+         deriv2=ev.eval_gto("GTOval_sph_deriv2", pts))
+
+
 def g_ao_high_l():
     """f, g and h shells (l = 3..5): the reference's AO evaluator (numba/gto.py:89-254 with the sphericart harmonics
     numba/spherical_harmonics.py:636-739) on a carbon dimer with added high-l shells."""
@@ -1789,3 +1803,4 @@ if __name__ == "__main__":
     g_ecp_batched()
     g_big()
     g_vmc_cluster()
+    g_ao_general()

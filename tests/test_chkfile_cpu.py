@@ -138,6 +138,15 @@ def test_chkfile_reader_handles_labelled_atoms_kappa_and_stale_json():
     kap["_basis"]["C"][0] = [0, -1] + kap["_basis"]["C"][0][1:]
     with pytest.raises(NotImplementedError, match="kappa"):
         chkfile.mol_from_json(kap)
+    # round 6: a generally contracted shell (two coefficient columns) and a kappa = 0 entry are ingested — the shell becomes two
+    # single-column shells in PySCF's AO order, zero coefficients dropped (tables.split_general_contractions)
+    gen = json.loads(json.dumps(d))
+    first = gen["_basis"]["C"][0]
+    gen["_basis"]["C"][0] = [first[0], 0] + [[p[0], p[1], (1.0 if i == len(first) - 2 else 0.0)] for i, p in enumerate(first[1:])]
+    mg = chkfile.mol_from_json(gen)
+    m0 = chkfile.mol_from_json(d)
+    assert len(mg._basis["C"]) == len(m0._basis["C"]) + 1 and mg._basis["C"][0] == m0._basis["C"][0]
+    assert mg._basis["C"][1] == [first[0], [float(first[-1][0]), 1.0]] and mg.nao() == m0.nao() + m0.natm * (2 * first[0] + 1)
     raw = open(os.path.join(FILES, "diamond_primitive.hdf5"), "rb").read()
     other = json.dumps({"atom": "x", "_atom": []}).encode()
     assert chkfile._scan_json(raw + b"\0" + raw) == d

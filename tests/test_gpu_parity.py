@@ -50,6 +50,38 @@ def test_ao_golden(tag, mol):
     assert note(f"ao_{tag}_d2", relerr(dev.eval_ao(pts, 5), g[tag + "_deriv2"])) < 1e-12
 
 
+def test_general_contractions_golden():
+    """g38: an all-electron water molecule in a generally contracted basis (tables.split_general_contractions) — device AOs and MOs against
+    the reference's evaluator on the split shells, and one fused VMC sweep + energy against the oracle (no ECP: 5 + 5 electrons)."""
+    import pyqmc_amd as pa
+    from oracle import vmc as ovmc
+
+    g = golden("g38_ao_general")
+    mol = systems.water_general()
+    mf = systems.random_mf(mol)
+    dev = pa.DeviceWF(mol, mo_coeff=mf.mo_coeff)
+    pts = g["pts"]
+    assert note("ao_general_val", relerr(dev.eval_ao(pts, 1)[0], g["val"])) < 1e-12
+    assert note("ao_general_d1", relerr(dev.eval_ao(pts, 4), g["deriv1"])) < 1e-12
+    assert note("ao_general_d2", relerr(dev.eval_ao(pts, 5), g["deriv2"])) < 1e-12
+    for s in (0, 1):
+        c = np.asarray(mf.mo_coeff[s])[:, : dev.nmo[s]]
+        assert note(f"mo_general_{s}", relerr(dev.eval_mo(s, pts, 5), g["deriv2"] @ c)) < 1e-12
+    W, N, tstep = 40, sum(mol.nelec), 0.3
+    rng = np.random.default_rng(38)
+    start = pa.initial_guess(mol, W, rng=rng).configs
+    gauss, unif = rng.standard_normal((1, N, W, 3)), rng.random((1, N, W))
+    wf = helpers.gpu_wf(mol, mf)
+    tapes = dict(gauss=gauss, unif=unif, ecp_rot=np.zeros((1, N, 0, 3, 3)), ecp_unif=np.zeros((1, N, 0, W)), record=[])
+    blk, cfg = pa.vmc_worker(wf, OpenConfigs(start.copy()), tstep, 1, {"energy": pa.EnergyAccumulator(mol)}, tapes=tapes)
+    owf = helpers.oracle_wf(mol, mf)
+    rec = []
+    oblk, ocfg = ovmc.vmc_worker(mol, owf, OpenConfigs(start.copy()), tstep, gauss, unif, np.zeros((1, N, 0, 3, 3)), np.zeros((1, N, 0, W)), record=rec)
+    assert np.array_equal(np.asarray(tapes["record"][0], dtype=bool), np.asarray(rec).reshape(1, N, W))
+    assert note("general_vmc_configs", relerr(cfg.configs, ocfg.configs)) < 1e-10
+    assert note("general_vmc_energy", relerr(blk["energytotal"], oblk["energytotal"])) < 1e-8
+
+
 def test_ao_high_l_golden():
     """f, g and h shells (l <= 5 as numba/gto.py:107-118; golden g26 from the reference): the AO-only kernel and the
     fused AO->MO MFMA kernel (whose g/h branch is the compact table loop of pqa_ao.hpp:sph_high)."""

@@ -36,6 +36,52 @@ def test_g2_ao(tag, mol):
     assert relerr(gto.eval_ao(table, pts, 5), g[tag + "_deriv2"]) < 1e-12
 
 
+def test_g38_general_contractions():
+    """A generally contracted basis (several coefficient columns over one set of exponents: every all-electron cc-pVXZ set, and what the
+    reference's default AO path ``mol.eval_gto`` takes, orbitals.py:46-51) is split into single-column shells in PySCF's AO order
+    (tables.split_general_contractions).  (a) The oracle on the split shells against the reference's in-repo evaluator fed the same
+    shells (golden g38).  (b) libcgto-free check that the split is exact: the s and p functions evaluated straight from the generally
+    contracted tables — one exponential per primitive, the columns of the coefficient matrix normalised as PySCF does — equal them."""
+    from pyqmc_amd import tables
+
+    g = golden("g38_ao_general")
+    mol = systems.water_general()
+    table = gto.AOTable(mol)
+    for nc, key in ((1, "val"), (4, "deriv1"), (5, "deriv2")):
+        out = gto.eval_ao(table, g["pts"], nc)
+        assert relerr(out[0] if nc == 1 else out, g[key]) < 1e-13, key
+    # (b)
+    import math
+
+    val = gto.eval_ao(table, g["pts"], 1)[0]
+    col = 0
+    for ia in range(mol.natm):
+        raw = {"O": systems._O_GENERAL, "H": systems._H_GENERAL}[mol.atom_pure_symbol(ia)]
+        d = g["pts"] - mol.atom_coords()[ia]
+        r2 = np.sum(d * d, axis=1)
+        for sh in raw:
+            l, rows = sh[0], np.asarray(sh[1:], dtype=float)
+            e, C = rows[:, 0], rows[:, 1:]
+            m = l + 1.5
+            C = C * np.sqrt(2.0 * (2.0 * e) ** m / math.gamma(m))[:, None]  # gto_norm of every primitive
+            S = math.gamma(m) / (2.0 * (e[:, None] + e[None, :]) ** m)
+            C = C / np.sqrt(np.einsum("pi,pq,qi->i", C, S, C))[None, :]  # every column normalised on its own
+            R = np.exp(-np.outer(r2, e)) @ C  # (points, columns)
+            for k in range(C.shape[1]):
+                if l == 0:
+                    assert relerr(val[:, col], 0.28209479177387814 * R[:, k]) < 1e-13
+                elif l == 1:
+                    assert relerr(val[:, col:col + 3], 0.4886025119029199 * d * R[:, k, None]) < 1e-13
+                col += 2 * l + 1
+    assert col == mol.nao() == 24
+    # the splitter itself: kappa = 0 entries are accepted, other kappas and ragged rows refused
+    assert tables.split_general_contractions([[1, 0, [2.0, 1.0, 0.0], [0.5, 0.3, 1.0]]]) == [[1, [2.0, 1.0], [0.5, 0.3]], [1, [0.5, 1.0]]]
+    with pytest.raises(NotImplementedError):
+        tables.split_general_contractions([[1, -2, [2.0, 1.0]]])
+    with pytest.raises(ValueError):
+        tables.split_general_contractions([[0, [2.0, 1.0, 0.5], [1.0, 1.0]]])
+
+
 def test_g26_ao_high_l():
     """f, g, h shells (numba/gto.py:107-118 supports l <= 5): oracle (l <= 3 written out, l = 4, 5 from the generated
     monomial tables) against the reference's evaluator."""
