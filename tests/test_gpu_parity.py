@@ -71,7 +71,8 @@ def test_general_contractions_golden():
     rng = np.random.default_rng(38)
     start = pa.initial_guess(mol, W, rng=rng).configs
     gauss, unif = rng.standard_normal((1, N, W, 3)), rng.random((1, N, W))
-    wf = helpers.gpu_wf(mol, mf)
+    wf = pa.generate_wf(mol, mf, jastrow_kws=dict(ion_cusp=False))  # (the oracle helper's basis: no electron-ion cusp function)
+    wf.parameters["wf2acoeff"], wf.parameters["wf2bcoeff"] = helpers.jastrow_params(mol, 11)
     tapes = dict(gauss=gauss, unif=unif, ecp_rot=np.zeros((1, N, 0, 3, 3)), ecp_unif=np.zeros((1, N, 0, W)), record=[])
     blk, cfg = pa.vmc_worker(wf, OpenConfigs(start.copy()), tstep, 1, {"energy": pa.EnergyAccumulator(mol)}, tapes=tapes)
     owf = helpers.oracle_wf(mol, mf)
