@@ -66,7 +66,7 @@ def kernel_stats():
 
     for row in csv.DictReader(open(KERNEL_STATS)):
         name = row.get("kernel", "")
-        for key, pat in (("k_orb1", "k_orb<1,"), ("k_orb5", "k_orb<5,"), ("k_step_lw", "k_step_lw<"), ("k_flush_lw", "k_flush_lw<"), ("k_sweep_res", "k_sweep_res<")):
+        for key, pat in (("k_orb1", "k_orb<1,"), ("k_orb5", "k_orb<5,"), ("k_step_lw", "k_step_lw<"), ("k_flush_lw", "k_flush_lw<"), ("k_sweep_res", "k_sweep_res<"), ("k_sweep_r8", "k_sweep_r8<"), ("k_kinetic_lw", "k_kinetic_lw<")):
             if pat in name and key not in out:
                 out[key] = float(row["avg_us"])
     return out
@@ -200,7 +200,7 @@ def extra_measurements(pa, wf, dev, mol, W, args):
                 # AO-phase flops over the kernel's own duration, against the fp64 pipe both share
                 tf = pc * 2.0 * 184 * 32 / (ms * 1e-3) / 1e12
                 tv = (pc / 5.0) * (30 * 328 + 4 * 5 * 184) / (ms * 1e-3) / 1e12
-                res.update(sweep="resident (k_sweep_res, one launch per sweep)", sweep_kernel_ms=ms / launches,
+                res.update(sweep="resident (k_sweep_r8 / k_sweep_res, one launch per sweep)", sweep_kernel_ms=ms / launches,
                            sweep_kernel_mfma_tflops=tf, sweep_kernel_mfma_frac=tf / FP64_MFMA_PEAK_TFLOPS,
                            sweep_kernel_ao_valu_frac=tv / FP64_MFMA_PEAK_TFLOPS, us_per_move_of_a_16_walker_block=1e3 * ms / launches / dev.N / max(1.0, walkers / 4096.0))
             else:
@@ -514,7 +514,32 @@ def main():
             "acceptance": float(np.mean(acc)), "energy_total_mean": float(e_mean[5]),
             "ecp_points_per_walker_step": ecp_pts / W, "stream_event_ms": ev_ms, **info,
         }
-        if not args.no_profile and launches:
+        resident = (not args.no_profile) and launches == args.steps and point_comps == launches * W * 64 * 5  # one bracketed launch per sweep
+        if resident:
+            # The dominant kernel since round 6 is the resident sweep k_sweep_r8 (one launch per sweep: AO evaluation, contraction, both
+            # Jastrow evaluations, Metropolis test and Sherman-Morrison of all 64 moves on chip).  Its bound is the fp64 pipe, which the
+            # matrix and the vector path share on this part: `achieved` = the USEFUL fp64 flops of a sweep (SURVEY 8(d) formula sheet:
+            # per move F_ao(5) + 2*5*M*n contraction + 16 n ratio sums + 2 F_j2 + acc * 4 n^2 Sherman-Morrison) over the kernel's own
+            # duration (HIP events around every launch on the library's stream); the matrix part alone is `mfma_frac`.
+            n_s_, acc_ = 32, float(np.mean(acc))
+            f_ao5_ = 30 * 328 + 4 * 5 * nao
+            f_move_ = f_ao5_ + 2 * 5 * nao * n_s_ + 2 * (2 * 4 * n_s_) + 2 * 9500.0 + acc_ * 4 * n_s_ * n_s_
+            moves = point_comps / 5.0
+            achieved = moves * f_move_ / (orb_ms * 1e-3) / 1e12
+            mf_ = point_comps * 2.0 * nao * nmo / (orb_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_sweep_r8 (resident sweep: GTO AO evaluation + AO->MO fp64 MFMA contraction + Jastrow pair sums + Metropolis "
+                                                          "+ Sherman-Morrison of all 64 moves of 8 walkers per block, two blocks per CU, one launch per sweep)",
+                               "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                               "peak_note": "fp64 matrix peak = fp64 vector peak on MI355X, one shared pipe (tools/ubench.hip, tools/scratch/mfma_probe.hip)",
+                               "mfma_tflops": mf_, "mfma_frac": mf_ / FP64_MFMA_PEAK_TFLOPS,
+                               "ao_valu_frac": moves * f_ao5_ / (orb_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                               "jastrow_valu_frac": moves * 2 * 9500.0 / (orb_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                               "useful_flop_per_move": f_move_, "traffic": pmc_kernel("k_sweep_r8", W),
+                               "algorithmic_bytes_per_launch": W * (2 * 8 * (3 * 64 + 2 * n_s_ * n_s_) + 64 * (8 * (4 * n_s_ + 4) + acc_ * (5 * nmo * 8 + 1))),
+                               "launches": launches, "avg_launch_ms": orb_ms / launches, "launches_timed": "every launch (one per sweep)",
+                               "us_per_move_of_a_16_walker_pair_of_blocks": 1e3 * (orb_ms / launches) / 64 / (W / 4096.0),
+                               "kernel_share_of_step": (orb_ms / launches) * args.steps / (1e3 * elapsed)}
+        elif not args.no_profile and launches:
             flops = point_comps * 2.0 * nao * nmo  # AO->MO contraction only: the MFMA-eligible work of the kernel
             achieved = flops / (orb_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_orb (fused GTO AO evaluation + AO->MO fp64 MFMA contraction)",
@@ -564,7 +589,7 @@ def main():
         # with P = 328 primitives (one exp each), M = 184 functions, ncomp = 5.
         nprim = 328
         f_ao5, f_ao1 = 30 * nprim + 4 * 5 * nao, 30 * nprim + 4 * 1 * nao
-        if not args.no_profile and launches and "roofline" in out:
+        if not args.no_profile and launches and "roofline" in out and not resident:
             pts = point_comps / 5.0
             ach = pts * f_ao5 / (orb_ms * 1e-3) / 1e12
             out["roofline_valu"] = {"bound": "valu", "kernel": "k_orb, AO phase (GTO value / gradient / Laplacian of 184 functions, 328 exp per point)",
@@ -591,6 +616,8 @@ def main():
         f_ecp = (ecp_pts / W) * (f_ao1 + 2 * nao * n_s + 2 * n_s + 0.5 * f_j2)
         f_step = N * f_move + f_kin + f_ecp
         per_step = {"k_step_lw": 77, "k_flush_lw": 14, "k_kinetic_lw": 1, "k_orb5": 64, "k_orb1": 2, "k_ecp_point": 2, "k_ecp_count": 1, "k_ecp_fill": 1}
+        if resident:
+            per_step = {"k_sweep_r8": 1, "k_tile_draws": 1, "k_kinetic_lw": 1, "k_orb1": 2, "k_ecp_point": 2, "k_ecp_count": 1, "k_ecp_fill": 1}
         b_step = None
         if os.path.exists(PMC_SUMMARY):
             dpm = json.load(open(PMC_SUMMARY))
@@ -604,7 +631,8 @@ def main():
                                 "frac_of_hbm_peak": None if b_step is None else b_step * W / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "survey_B_sweep_bytes": 2 * 8 * (3 * N + 2 * n_s * n_s) + N * 2 * 8 * (24 * 4 + 2 * 4),
                                 "formula": "N (F_ao(5) + 2*5*M*n + 16 n + 2 F_j2 + acc*4 n^2) + N (10 n + 1.3 F_j2) + ecp_points (F_ao(1) + 2 M n + 2 n + F_j2/2); "
-                                           "bytes: launches per step x calibrated counter bytes per launch (k_step_lw 77, k_flush_lw 14, k_orb 64 + 2, kinetic, ECP passes)"}
+                                           "bytes: launches per step x calibrated counter bytes per launch (resident sweep: k_sweep_r8 1, k_tile_draws 1, k_orb<1> 2, kinetic, ECP passes; "
+                                           "launch-per-move sweep: k_step_lw 77, k_flush_lw 14, k_orb 64 + 2, kinetic, ECP passes)"}
         if world == 1 and not args.no_extra:
             out["extra"] = extra_measurements(pa, wf, dev, mol, W, args)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would just wait)

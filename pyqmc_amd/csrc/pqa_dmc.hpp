@@ -111,20 +111,29 @@ static __global__ __launch_bounds__(1024) void k_scan_local(const int* __restric
 }
 template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
 static __global__ __launch_bounds__(1024) void k_scan_tiles(long* __restrict__ t, long nt) {  // in place, t[nt] = total
-  __shared__ long part[1024];
+  // (the 1 024 per-thread sums are scanned by the waves — shuffle scan inside a wave, the 16 wave totals by one thread; until round 6 thread 0
+  // walked all 1 024 through LDS: 110 us per call, 5 % of the C5 DMC step at 4 096 walkers)
+  __shared__ long wsum[16];
   const long per = (nt + 1023) / 1024;
   const long b = (long)threadIdx.x * per, e = (b + per < nt) ? b + per : nt;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   long sum = 0;
   for (long i = b; i < e; ++i) sum += t[i];
-  part[threadIdx.x] = sum;
+  long x = sum;  // inclusive scan within the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wv] = x;
   __syncthreads();
   if (threadIdx.x == 0) {
     long run = 0;
-    for (int k = 0; k < 1024; ++k) { const long v = part[k]; part[k] = run; run += v; }
+    for (int k = 0; k < 16; ++k) { const long v = wsum[k]; wsum[k] = run; run += v; }
     t[nt] = run;
   }
   __syncthreads();
-  long run = part[threadIdx.x];
+  long run = wsum[wv] + x - sum;
   for (long i = b; i < e; ++i) { const long v = t[i]; t[i] = run; run += v; }
 }
 template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)

@@ -3,7 +3,7 @@
 #include "pqa_internal.hpp"
 
 int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-               bool soa_current, bool aos_T_needed, bool assemble, const double* slk) {
+               bool soa_current, bool aos_T_needed, bool assemble) {
   const long W = h->W;
   bool soa_T = false;
   struct Side { pqa_handle* h = nullptr; hipStream_t main = nullptr; ~Side() { if (h) h->stream = main; } } side;  // (launches go to h->stream: restored on every exit)
@@ -35,7 +35,7 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     } else if (h->S.pbc)
       hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     else
-      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p, slk);
+      hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL((k_kinetic_reduce<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,
                        h->N, W, (double*)h->b_kc.p);
     TRY(check_launch(h, "k_kinetic_lw"));

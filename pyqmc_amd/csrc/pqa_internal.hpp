@@ -186,9 +186,6 @@ struct pqa_handle {
   R8Tab r8_tab{};
   size_t r8_lds = 0;
   double r8_util = 0.0;
-  DevBuf b_slk;            // [4][N][W] Slater kinetic terms left by k_sweep_r8 for the energy pass of the same step (MoveBuf::slk)
-  bool slk_fresh = false;  // set by sweep_r8 when it wrote them; the step loop hands them to energy_dev and clears the flag
-  int r8_slk = 0;          // PQA_R8_SLK=1: on (measured: the sweep's epilogue +3.0 ms at 65 536 walkers — every lane streams its own 1 280-B row — for -0.7 ms of the kinetic pass)  // mean fraction of a work item's eight atom slots in use
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,
@@ -363,6 +360,6 @@ int sweep_tile(pqa_handle* h, const MoveBuf& mb_in);
 // pqa_energy.hip
 // assemble = false: the rows of b_en are left to the caller (k_energy_finish, from b_kc and en_d_ecp)
 int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
-               bool soa_current = false, bool aos_T_needed = true, bool assemble = true, const double* slk = nullptr);
+               bool soa_current = false, bool aos_T_needed = true, bool assemble = true);
 // pqa_dmcsteps.hip
 int scan_ints(pqa_handle* h, const int* c, long* o, long n, long Wm, long* marks);

@@ -1364,10 +1364,7 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 #define PQA_KIN_V 1
 #endif
 template <bool PBC, bool CX = false>
-// slk (open-boundary real handles after a resident sweep, MoveBuf::slk): [4][N][W] grad log D and lap D / D of every electron, already formed
-// by the sweep from its register-resident inverse — the pass over the inverse and the row cache below is skipped.
-static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part,
-                                                                        const double* __restrict__ slk = nullptr) {
+static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   // Block b -> (walker group, electron block): the electron blocks of ONE walker group sit 8 apart in the linear block order, so
   // they land on the same XCD (blocks go to the XCDs round-robin) and run at about the same time: the group's coordinates, which
   // every one of them walks, come out of that XCD's L2 after the first.  (With the electron on grid.y the 64 blocks of a group were
@@ -1382,10 +1379,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
   const int s = e >= S.nup, i = e - s * S.nup, n = s ? S.ndn : S.nup, nmo = S.nmo[s];
   constexpr int CF = CX ? 2 : 1;
   double r[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if (!CX && slk) {
-    const size_t o_ = (size_t)e * W + w, NW_ = (size_t)S.nelec * W;
-    r[0] = 1.0; r[1] = slk[o_]; r[2] = slk[NW_ + o_]; r[3] = slk[2 * NW_ + o_]; r[4] = slk[3 * NW_ + o_];
-  } else {
+  {
     const double* Ti = L.Tt[s] + (size_t)i * n * CF * W + w;
     const double* row = lw_row(L, s, i, L.sel[s][(size_t)i * W + w], w, W, nmo);  // [5][nmo], this lane's own 1280-B row
     const int* occ = S.det_occ[s];

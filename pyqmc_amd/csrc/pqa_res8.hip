@@ -73,6 +73,8 @@ static int r8_setup(pqa_handle* h) {
   }
   R8Tab RT{};
   std::vector<int> hdr, lane;
+  std::vector<double> axyz((size_t)3 * h->natom), ixyz;
+  HIPCHK(hipMemcpy(axyz.data(), h->S.atom_xyz, axyz.size() * sizeof(double), hipMemcpyDeviceToHost));
   int pos = 0;
   for (int w = 0; w < 4; ++w) {
     RT.wave_off[w] = pos;
@@ -83,6 +85,7 @@ static int r8_setup(pqa_handle* h) {
         const bool on = q < (int)it.shells.size();
         lane.push_back(on ? sat[it.shells[q]] : -1);
         lane.push_back(on ? h->shell_ao[it.shells[q]] : 0);
+        for (int d = 0; d < 3; ++d) ixyz.push_back(on ? axyz[3 * sat[it.shells[q]] + d] : 0.0);
       }
       ++pos;
     }
@@ -119,6 +122,7 @@ static int r8_setup(pqa_handle* h) {
   TRY(upload_table(h, hdr.data(), hdr.size(), &tmp_i)); RT.item_hdr = tmp_i;
   TRY(upload_table(h, lane.data(), lane.size(), &tmp_i)); RT.item_lane = tmp_i;
   double* tmp_d = nullptr;
+  TRY(upload_table(h, ixyz.data(), ixyz.size(), &tmp_d)); RT.item_xyz = tmp_d;
   TRY(upload_table(h, pe_u.data(), pe_u.size(), &tmp_d)); RT.prim_exp_u = tmp_d;
   TRY(upload_table(h, pc_u.data(), pc_u.size(), &tmp_d)); RT.prim_coef_u = tmp_d;
   HIPCHK(hipFuncSetAttribute((const void*)k_sweep_r8<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -180,7 +184,6 @@ int sweep_r8(pqa_handle* h, const MoveBuf& mb) {
   else { if (h->res_lmax <= 2) PQA_R8_LAUNCH(false, 2); else PQA_R8_LAUNCH(false, 3); }
 #undef PQA_R8_LAUNCH
   if (e1) HIPCHK(hipEventRecord(e1, h->stream));
-  h->slk_fresh = mb.slk != nullptr;
   return check_launch(h, "k_sweep_r8");
 }
 

@@ -164,7 +164,8 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
   double* region = lds;
   double* rowE = region + RT.region;           // [8][32] inverse row of the electron being moved
   double* wsc = rowE + PQA_R8_NW * 32;         // [8][PQA_RES_WS] per-walker scalars (layout of k_sweep_res)
-  double* pr_exp = wsc + PQA_R8_NW * PQA_R8_WS;
+  double* ixyz = wsc + PQA_R8_NW * PQA_R8_WS;  // [nitem][8][3] atom position of every (item, slot)
+  double* pr_exp = ixyz + 24 * (size_t)RT.nitem;
   double* pr_coef = pr_exp + RT.nprim_u;
   double* at_xyz = pr_coef + RT.nprim_u;
   double* acoef = at_xyz + 3 * (size_t)S.natom;
@@ -206,6 +207,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
   }
   for (int k = tid; k < 4 * RT.nitem; k += PQA_R8_NT) ihdr[k] = RT.item_hdr[k];
   for (int k = tid; k < 16 * RT.nitem; k += PQA_R8_NT) ilane[k] = RT.item_lane[k];
+  for (int k = tid; k < 24 * RT.nitem; k += PQA_R8_NT) ixyz[k] = RT.item_xyz[k];
   for (int k = tid; k < 64; k += PQA_R8_NT) {
     const int s = k >> 5, q = k & 31, n = s ? S.ndn : S.nup;
     occ[k] = q < n ? (s ? S.det_occ[1][q] : S.det_occ[0][q]) : 0;
@@ -345,22 +347,33 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         {
           const int pt = lane & 7, slot = lane >> 3;
           const double px = wsc[pt * PQA_R8_WS], py = wsc[pt * PQA_R8_WS + 1], pz = wsc[pt * PQA_R8_WS + 2];
-          const int it1 = __builtin_amdgcn_readfirstlane(woff[wv + 1]);
+          const int it1 = __builtin_amdgcn_readfirstlane(woff[wv + 1]), it0 = __builtin_amdgcn_readfirstlane(woff[wv]);
+          // (an item's header — shell type, the slot's tile row and atom position — is requested while the previous item is evaluated: two
+          // dependent LDS round trips in front of every item otherwise, three items per wave)
+          auto hdr = [&](int it, int& h0, int& h1, int& h2, int& at, int& krow, double& ax, double& ay, double& az) __attribute__((always_inline)) {
+            h0 = ihdr[4 * it]; h1 = ihdr[4 * it + 1]; h2 = ihdr[4 * it + 2];
+            at = ilane[(it * 8 + slot) * 2]; krow = ilane[(it * 8 + slot) * 2 + 1];
+            ax = ixyz[(it * 8 + slot) * 3]; ay = ixyz[(it * 8 + slot) * 3 + 1]; az = ixyz[(it * 8 + slot) * 3 + 2];
+          };
+          int h0 = 0, h1 = 0, h2 = 0, at = -1, krow = 0;
+          double ax_ = 0.0, ay_ = 0.0, az_ = 0.0;
+          if (it0 < it1) hdr(it0, h0, h1, h2, at, krow, ax_, ay_, az_);
 #pragma unroll 1
-          for (int it = __builtin_amdgcn_readfirstlane(woff[wv]); it < it1 && PQA_R8_ON(1); ++it) {
-            const int l_ = __builtin_amdgcn_readfirstlane(ihdr[4 * it]), np_ = __builtin_amdgcn_readfirstlane(ihdr[4 * it + 1]),
-                      q0 = __builtin_amdgcn_readfirstlane(ihdr[4 * it + 2]);
-            const int at = ilane[(it * 8 + slot) * 2], krow = ilane[(it * 8 + slot) * 2 + 1];
+          for (int it = it0; it < it1 && PQA_R8_ON(1); ++it) {
+            int n0, n1, n2, nat, nkrow;
+            double nax, nay, naz;
+            hdr(min(it + 1, it1 - 1), n0, n1, n2, nat, nkrow, nax, nay, naz);
+            const int l_ = __builtin_amdgcn_readfirstlane(h0), np_ = __builtin_amdgcn_readfirstlane(h1), q0 = __builtin_amdgcn_readfirstlane(h2);
             const bool on = at >= 0;
-            const int ac = on ? at : 0;
             double* tl = region + (size_t)krow * 8 + pt;
-            shell_eval3<5, LMAX>(l_, px - at_xyz[3 * ac], py - at_xyz[3 * ac + 1], pz - at_xyz[3 * ac + 2], pr_exp + q0, pr_coef + q0, np_,
+            shell_eval3<5, LMAX>(l_, px - ax_, py - ay_, pz - az_, pr_exp + q0, pr_coef + q0, np_,
                                           [&](int m, double v, double ax, double ay, double az, double lp) __attribute__((always_inline)) {
                                             if (on) {
                                               double* q = tl + m * 8;
                                               q[0] = v; q[csv] = ax; q[2 * csv] = ay; q[3 * csv] = az; q[4 * csv] = lp;
                                             }
                                           });
+            h0 = n0; h1 = n1; h2 = n2; at = nat; krow = nkrow; ax_ = nax; ay_ = nay; az_ = naz;
           }
         }
         // B operand of this wave's k-steps (L2-resident coefficient rows, zero rows behind the basis: d_cres is padded to x16): k-step
@@ -578,39 +591,6 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         }
         res_wave_sync();
         PQA_R8CLK(6);
-      }
-    }
-    // ---- Slater parts of the kinetic energy at the sweep's final configuration (mb.slk; energy.py:57-65, slater.py:403-446): electron r's
-    // inverse row is in this thread's registers, its cached orbital row [5][nmo] in the slot the selector names — the accepted moves' rows
-    // were stored by the other lanes of this walker, hence the workgroup fence (one CU, one L1: a wait for the stores).  The energy pass's
-    // own pass over the inverse and the row cache (96 KB per walker at 3.5 TB/s, half of k_kinetic_lw) is skipped in exchange; here the
-    // loads run under the other resident block's arithmetic.
-    if (mb.slk) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if (live && r < n) {
-        const double* row = rcs + (((size_t)r * 2 + selr) * W + wg) * 5 * nmo;
-        double rc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (ident && (nmo & 7) == 0) {
-#pragma unroll
-          for (int c = 0; c < 5; ++c)
-#pragma unroll
-            for (int j = 0; j < 32; j += 8)
-              if (j < n) {
-                const double4 lo = *reinterpret_cast<const double4*>(row + c * nmo + j), hi = *reinterpret_cast<const double4*>(row + c * nmo + j + 4);
-                rc[c] += lo.x * t[j]; rc[c] += lo.y * t[j + 1]; rc[c] += lo.z * t[j + 2]; rc[c] += lo.w * t[j + 3];
-                rc[c] += hi.x * t[j + 4]; rc[c] += hi.y * t[j + 5]; rc[c] += hi.z * t[j + 6]; rc[c] += hi.w * t[j + 7];
-              }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 32; ++k)
-            if (k < n) {
-              const int o = occs[k];
-#pragma unroll
-              for (int c = 0; c < 5; ++c) rc[c] += row[c * nmo + o] * t[k];
-            }
-        }
-        const size_t o_ = (size_t)(e0 + r) * W + wg, NW_ = (size_t)S.nelec * W;
-        mb.slk[o_] = rc[1] / rc[0]; mb.slk[NW_ + o_] = rc[2] / rc[0]; mb.slk[2 * NW_ + o_] = rc[3] / rc[0]; mb.slk[3 * NW_ + o_] = rc[4] / rc[0];
       }
     }
     // ---- this spin's state back to the planes

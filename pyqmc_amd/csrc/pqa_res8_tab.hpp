@@ -16,6 +16,7 @@ struct R8Tab {
   int wave_off[5];          // items of wave w: [wave_off[w], wave_off[w + 1])
   const int* item_hdr;      // [nitem][4]: l, primitives, first primitive in the deduplicated tables, 0
   const int* item_lane;     // [nitem][8][2]: atom of the slot (-1: idle), tile row of the shell's first function
+  const double* item_xyz;   // [nitem][8][3]: the slot's atom position (one LDS round trip per item instead of atom index -> position)
   int nprim_u;
   const double* prim_exp_u;
   const double* prim_coef_u;
@@ -31,7 +32,7 @@ struct R8Tab {
 #define PQA_R8_ON(bit) true
 #endif
 __host__ __device__ inline size_t r8_lds_fixed(int nprim, int natom, int na, int nitem) {
-  const size_t d = PQA_R8_NW * 32 + PQA_R8_NW * PQA_R8_WS + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
+  const size_t d = PQA_R8_NW * 32 + PQA_R8_NW * PQA_R8_WS + 24 * (size_t)nitem + 2 * (size_t)nprim + 3 * (size_t)natom + 2 * (size_t)natom * (na > 0 ? na : 1) +
                    2 * (size_t)natom * PQA_JQP + PQA_RES_JT;
   const size_t i = 20 * (size_t)nitem + 64 + 8;
   return d * sizeof(double) + i * sizeof(int);

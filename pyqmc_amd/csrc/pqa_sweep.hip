@@ -405,11 +405,6 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       mb.unif = (const double*)h->b_unif.p;
     }
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
-    h->slk_fresh = false;
-    if (energy_mean && lw && h->r8_slk && !h->cplx && !h->S.pbc) {  // (only the resident sweep k_sweep_r8 fills it, and says so: slk_fresh)
-      TRY(ensure(h, h->b_slk, (size_t)4 * N * W * sizeof(double)));
-      mb.slk = (double*)h->b_slk.p;
-    }
     if (tile) TRY(sweep_tile(h, mb));
     else TRY(sweep_electrons(h, mb, lw, lc));
     // small shards: the accepted-move count, the energy rows and their means in one launch at the end of the step (three launches of ~5 us
@@ -420,9 +415,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) TRY(copy_in(h, accept_rec + (size_t)step * N * W, h->b_accrec.p, (size_t)N * W));
     if (energy_mean) {
       TRY(energy_dev(h, threshold, ecp_rot ? ecp_rot + (size_t)step * nrot * 9 : nullptr,
-                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false, /*assemble=*/!finish1,
-                     h->slk_fresh ? (const double*)h->b_slk.p : nullptr));
-      h->slk_fresh = false;
+                     ecp_unif ? ecp_unif + (size_t)step * nrot * W : nullptr, seed, (uint32_t)step, lw, /*aos_T_needed=*/false, /*assemble=*/!finish1));
       if (finish1)
         hipLaunchKernelGGL((k_energy_finish<>), dim3(nen + 1), dim3(256), 0, h->stream, (const double*)h->b_kc.p, h->en_d_ecp, h->ii_energy, W,
                            (double*)h->b_en.p, (double*)h->b_means.p + (size_t)step * nen, nen, (int*)h->b_accw.p, (int*)h->b_acccnt.p + step);

@@ -33,10 +33,6 @@ struct MoveBuf {
   int dmc;
   double* r2_prop;  // [W] sum over electrons of |gauss + drift|^2 of every proposal
   double* r2_acc;   // [W] the same for accepted proposals
-  // resident sweep (k_sweep_r8) only: [4][N][W] Slater parts of the kinetic energy at the sweep's final configuration — grad log D (3) and
-  // lap D / D of every electron, from the inverse rows the block still holds and the cached orbital rows — or NULL.  The energy pass that
-  // follows the sweep then skips its own pass over the inverse and the row cache (96 KB per walker).
-  double* slk;
 };
 
 __device__ __forceinline__ void limdrift3(double& gx, double& gy, double& gz) {  // mc.py:76-89, cutoff 1

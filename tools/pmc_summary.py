@@ -15,7 +15,7 @@ import sqlite3
 import sys
 
 CLASSES = {  # substring of the demangled kernel name -> key
-    "k_orb<5": "k_orb5", "k_orb<1": "k_orb1", "k_orb_wide": "k_orb_wide", "k_step_lw": "k_step_lw", "k_flush_lw": "k_flush_lw",
+    "k_sweep_r8": "k_sweep_r8", "k_sweep_res": "k_sweep_res", "k_tile_draws": "k_tile_draws", "k_orb<5": "k_orb5", "k_orb<1": "k_orb1", "k_orb_wide": "k_orb_wide", "k_step_lw": "k_step_lw", "k_flush_lw": "k_flush_lw",
     "k_kinetic_lw": "k_kinetic_lw", "k_transpose": "k_transpose", "k_cache_to_rc": "k_cache_to_rc", "k_cache_from_rc": "k_cache_from_rc",
     "k_ecp_point": "k_ecp_point", "k_ecp_count": "k_ecp_count", "k_ecp_fill": "k_ecp_fill", "k_pbc_prepass": "k_pbc_prepass", "k_ewald": "k_ewald",
 }
