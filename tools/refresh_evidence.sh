@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d /tmp/pc_$c -o t -- $R/tools/pmc_calib > $O/pmc_calib_$c.txt 2>&1 < /dev/null
 done
 python $R/tools/pmc_summary.py /tmp/pm_FETCH_SIZE/t_results.db /tmp/pm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db $W $O/pmc_summary.json > $O/pmc_summary.txt 2>&1
-cp $O/pmc_summary.json $R/profiles/r05_pmc_summary.json  # (this box's copy: bench.py reads its `traffic` fields from it)
+cp $O/pmc_summary.json $R/profiles/r06_pmc_summary.json  # (this box's copy: bench.py reads its `traffic` fields from it)
 python $R/bench.py --walkers $W > $O/bench.json 2> $O/bench.err < /dev/null
 python $R/bench.py --mode dmc --steps 20 --warmup 2 > $O/bench_dmc.json 2>> $O/bench.err < /dev/null
 python $R/bench.py --mode c4 --steps 20 --warmup 2 > $O/bench_c4.json 2>> $O/bench.err < /dev/null
@@ -26,7 +26,7 @@ for case in k222 cubic; do  # counter passes of the periodic cases (separate run
     python $R/tools/pmc_counters.py /tmp/pkm_$c/t_results.db $O/pbc_${case}_pmc_$c.csv
   done
   python $R/tools/pmc_summary.py /tmp/pkm_FETCH_SIZE/t_results.db /tmp/pkm_WRITE_SIZE/t_results.db /tmp/pc_FETCH_SIZE/t_results.db /tmp/pc_WRITE_SIZE/t_results.db 32768 $O/pbc_${case}_pmc_summary.json > /dev/null 2>&1
-  cp $O/pbc_${case}_pmc_summary.json $R/profiles/r05_pbc_${case}_pmc_summary.json
+  cp $O/pbc_${case}_pmc_summary.json $R/profiles/r06_pbc_${case}_pmc_summary.json
 done
 for c in k222 cubic; do for w in 8192 32768; do python $R/tools/pbc_bench.py --case $c --walkers $w --steps 4 2>/dev/null | tail -1 >> $O/pbc_bench.jsonl; done; done
 rocprofv3 --kernel-trace --stats -d /tmp/pk -o k -- python $R/tools/pbc_bench.py --case k222 --walkers 32768 --steps 3 > /dev/null 2>&1 < /dev/null
@@ -68,5 +68,14 @@ timeout 120 $R/tools/scratch/bin/dma_probe > $O/dma_probe.txt 2>&1
 for c in c3 c5; do for w in 4096 8192 16384; do for r in 1 0; do echo -n "{\"PQA_RES\": $r, \"line\": " >> $O/resident_pbc_ab.txt; PQA_RES=$r python $R/tools/config_bench.py $c --walkers $w --steps 8 2>/dev/null | tail -1 | tr -d '\n' >> $O/resident_pbc_ab.txt; echo "}" >> $O/resident_pbc_ab.txt; done; done; done
 for w in 1024 2048 4096; do for m in "PQA_WW=0 PQA_ECP_DEFER=0 PQA_EN_OVERLAP=0" "PQA_WW=0" "PQA_WW=3" "PQA_WW=1 PQA_ECP_DEFER=0" "PQA_WW=1"; do echo -n "{\"env\": \"$m\", \"line\": " >> $O/c4_one_launch_ab.txt; env $m python $R/tools/config_bench.py c4 --walkers $w --steps 20 2>/dev/null | tail -1 | tr -d '\n' >> $O/c4_one_launch_ab.txt; echo "}" >> $O/c4_one_launch_ab.txt; done; done
 for d in 0 1; do echo -n "{\"PQA_ECP_DEFER\": $d, \"line\": " >> $O/c4_one_launch_ab.txt; PQA_ECP_DEFER=$d python $R/tools/config_bench.py c2 --walkers 4096 --steps 40 2>/dev/null | tail -1 | tr -d '\n' >> $O/c4_one_launch_ab.txt; echo "}" >> $O/c4_one_launch_ab.txt; done
+# round 6: the second-generation resident sweep (k_sweep_r8) against k_sweep_res and the launch-per-move sweep, its phase stamps (timing build
+# libpqa_RCLK.so, in-tree: python -c "import __graft_entry__ as g, os; g.build(extra_flags=['-DPQA_RES_CLK'], lib=os.path.join(g.LIBDIR, 'libpqa_RCLK.so'))"),
+# the MFMA / FMA issue-rate probe behind its schedule, and the N = 1 point of the strong-scaling curve (65 536 walkers in all)
+python $R/tools/scratch/r8_scan.py M 2048 4096 8192 16384 32768 65536 > $O/resident_r8_ab.jsonl 2>> $O/bench.err < /dev/null
+python $R/tools/scratch/r8_scan.py C2 1024 4096 16384 >> $O/resident_r8_ab.jsonl 2>> $O/bench.err < /dev/null
+if [ -f $R/pyqmc_amd/lib/libpqa_RCLK.so ]; then for w in 2048 4096 16384; do PQA_LIB=$R/pyqmc_amd/lib/libpqa_RCLK.so PQA_RES=1 python $R/tools/scratch/res_clk.py $w; done > $O/r8_phase_stamps.txt 2>&1; fi
+[ -x $R/tools/scratch/bin/mfma_probe ] || (mkdir -p $R/tools/scratch/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/scratch/mfma_probe.hip -o $R/tools/scratch/bin/mfma_probe 2>/dev/null)
+timeout 120 $R/tools/scratch/bin/mfma_probe > $O/mfma_probe.txt 2>&1
+python $R/bench.py --scaling strong --walkers $W --no-cpu-baseline --no-extra > $O/bench_strong_n1.json 2>> $O/bench.err < /dev/null
 cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
