@@ -107,5 +107,19 @@ else:
         dt = min(dt, time.perf_counter() - t0)
     kind = "VMC fused sweep + energy"
     extra = {}
+if a.config == "big":
+    # Roofline of the step for the open-boundary single-determinant handle beyond 64 electrons per spin (round-5 verdict item 6 iii): useful fp64 flops of
+    # a walker-step by SURVEY 8(d)'s formula sheet — per move F_ao(5) = 30 P + 20 M, the contraction 2*5*M*n, the ratio sums 16 n, two Jastrow evaluations of
+    # ~110 flops per pair, Sherman-Morrison 4 n^2 per accepted move (acceptance taken as 0.5); per electron of the energy 10 n + 1.3 Jastrow evaluations; the ECP
+    # points are left out (a lower bound of the work) — against the 78.6 TFLOP/s fp64 pipe.
+    from pyqmc_amd import tables
+
+    t = tables.basis_tables(sup)
+    N, n, M, P = int(sum(sup.nelec)), int(max(sup.nelec)), int(t["nao"]), int(len(t["prim_exp"]))
+    fj = 110.0 * (N - 1 + sup.natm)
+    f_step = N * (30 * P + 20 * M + 2 * 5 * M * n + 16 * n + 2 * fj + 0.5 * 4 * n * n) + N * (10 * n + 1.3 * fj)
+    ach = f_step * W * a.steps / dt / 1e12
+    extra["roofline"] = {"bound": "mfma", "useful_flop_per_walker_step": f_step, "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                         "note": "wave-per-walker kernels (k_propose / k_accept per move, DESIGN 16.2): a correctness path, this is how far from the pipe it runs"}
 print(json.dumps({"config": a.config, "kind": kind, "nelec": int(sum(sup.nelec)), "walkers": W, "steps": a.steps,
                   "ms_per_step": 1e3 * dt / a.steps, "walker_steps_per_s": W * a.steps / dt, **extra}))

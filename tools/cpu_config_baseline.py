@@ -1,6 +1,6 @@
 """CPU baselines of the BASELINE.json configurations other than the headline one.
 
-    python tools/cpu_config_baseline.py [c2 c3 c4 c5] [--procs P]
+    python tools/cpu_config_baseline.py [c2 c3 c4 c5 big] [--procs P]
 
 Same model as bench.py's `cpu_baseline`: P concurrent single-thread processes (P = the CPUs the container may use, at most the
 physical cores of one socket), each running the NumPy ORACLE — reference algorithm and structure — on its own walkers; all start
@@ -18,7 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SIZES = {"c2": (2048, 4), "c3": (256, 2), "c4": (256, 4), "c5": (64, 1)}  # (walkers per process, steps): a few seconds of work each
+SIZES = {"c2": (2048, 4), "c3": (256, 2), "c4": (256, 4), "c5": (64, 1), "big": (8, 1)}  # (walkers per process, steps): a few seconds of work each
 
 
 def worker(args):
@@ -45,7 +45,10 @@ def worker(args):
     W, nsteps = SIZES[name]
     rng = np.random.default_rng(5 + idx)
     np.random.seed(5 + idx)
-    if name in ("c2", "c4"):
+    if name == "big":  # (H2O)18: 72 + 72 electrons, 414 AOs (tools/config_bench.py big)
+        mol = systems.water_cluster(3, 3, 2)
+        wf = helpers.oracle_wf(mol, systems.random_mf(mol))
+    elif name in ("c2", "c4"):
         mol = systems.water()
         if name == "c2":
             wf = helpers.oracle_wf(mol, systems.random_mf(mol))

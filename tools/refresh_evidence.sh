@@ -54,7 +54,7 @@ python $R/tools/prof_stats.py /tmp/pd/d_results.db $O/m_4096_kernel_stats.csv
 python $R/tools/split_ab.py --walkers $W --steps 10 1 2 3 > $O/split_ab.jsonl 2>> $O/bench.err < /dev/null
 for m in 0 1 2; do rm -rf /tmp/tr$m; rocprofv3 --kernel-trace --output-format csv -d /tmp/tr$m -o t -- python $R/tools/split_ab.py --walkers $W --steps 3 $m > /dev/null 2>&1 < /dev/null; echo "== PQA_SPLIT=$m (first block: mode 0 reference run, second: the mode)"; python $R/tools/trace_overlap.py $(find /tmp/tr$m -name "*kernel_trace.csv" | head -1) 0.25; done > $O/split_overlap.txt 2>&1
 (cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --mode dmc --backend gloo --same-gpu --device-buffers --unbalance 0.5 --steps 20 --warmup 1 > $O/bench_dmc_2rank_same_gpu.json 2>> $O/bench.err < /dev/null)
-python $R/tools/cpu_config_baseline.py c2 c3 c4 c5 > $O/cpu_config_baseline.jsonl 2>> $O/bench.err
+python $R/tools/cpu_config_baseline.py c2 c3 c4 c5 big > $O/cpu_config_baseline.jsonl 2>> $O/bench.err
 # round 5: handles beyond 64 electrons per spin, the protocol route, the resident sweep against the launch-per-move sweep, the LDS-DMA probe
 for c in "big --walkers 1024" "big --walkers 8192" "big_pbc --walkers 256" "big_complex --walkers 128"; do python $R/tools/config_bench.py $c --steps 1 2>/dev/null | tail -1 >> $O/config_bench.jsonl; done
 for w in 4096 65536; do python $R/tools/protocol_profile.py $w --json $O/protocol_$w.json > /dev/null 2>> $O/bench.err; done
