@@ -94,9 +94,6 @@ __device__ __forceinline__ void r8_jas_dual(const SysDev& S, int r, const double
     const double* qrec = aq + ((size_t)se * S.natom + Ic) * PQA_JQP;  // (conflict-free record layout of the LDS copy, pqa_res.hpp)
     return r8_pair(S.na > 0 && I < S.natom, x - at_xyz[3 * Ic], y - at_xyz[3 * Ic + 1], z - at_xyz[3 * Ic + 2], S.rcut_a, ira, Da, qrec, acp, aca, qrec[PQA_JQ]);
   };
-  // The seven pairs of the move (three of the decided electron, four of the next one) as independent chains, two side by side: with one
-  // wave per SIMD and block a dependent fp64 instruction issues every 10 cycles, two chains every 5.75, the pipe's limit is 4 — and a third
-  // chain makes the compiler spill a third of the inverse row across this block (measured: 16.2 against 15.4 us per move).
   // The seven pairs of the move (three of the decided electron, four of the next one), ONE AT A TIME, the ion pairs inside (one-trip) loops:
   // a pair's own chains (denominator and two numerator polynomials, the cusp function) already run side by side, and every attempt to run
   // pairs side by side — two, three or all seven in one basic block — made the compiler hold their LDS operands early and spill a quarter of
