@@ -46,3 +46,17 @@ for k, name in [(10, "rowE handed over"), (11, "Slater sums"), (12, "Jastrow at 
 if r8:
     d = (c[:, 15] - c[:, 14]) / 100.0
     print("block lifetime (entry -> end of the sweep): mean %.1f us, min %.1f, max %.1f; per move %.2f us" % (d.mean(), d.min(), d.max(), d.mean() / 64))
+    fn2 = lib.pqa_debug_r8_clk2
+    fn2.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf2 = (ctypes.c_ulonglong * (64 * 16))()
+    assert fn2(buf2, 64 * 16) == 0
+    c2 = np.array(buf2[:], dtype=np.float64).reshape(64, 16)[: len(c)]
+    t0 = c[:, 14]
+    names = ["tables in LDS", "spin 0: rows loaded", "spin 0: moves done", "spin 0: state stored", "spin 0: closing barrier",
+             "spin 1: rows loaded", "spin 1: moves done", "spin 1: state stored", "spin 1: closing barrier"]
+    prev = t0
+    for k, nm in enumerate(names):
+        d = (c2[:, k] - prev) / 100.0
+        print("  %-26s +%7.2f us (min %6.2f max %7.2f)" % (nm, d.mean(), d.min(), d.max()))
+        prev = c2[:, k]
+    print("  %-26s +%7.2f us" % ("end of the sweep", ((c[:, 15] - prev) / 100.0).mean()))
