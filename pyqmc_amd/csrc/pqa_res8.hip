@@ -191,4 +191,7 @@ int sweep_r8(pqa_handle* h, const MoveBuf& mb) {
 extern "C" int pqa_debug_r8_clk(unsigned long long* dst, int n) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk), (size_t)n * sizeof(unsigned long long));
 }
+extern "C" int pqa_debug_r8_clk2(unsigned long long* dst, int n) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(pqa_res_clk2), (size_t)n * sizeof(unsigned long long));
+}
 #endif

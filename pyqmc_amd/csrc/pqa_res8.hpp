@@ -150,6 +150,13 @@ __device__ __forceinline__ void r8_combine(const double* __restrict__ pb, int PS
 // timing builds: the phase stamps of a move in the MIDDLE of the second spin's sweep (the last move has no next electron: half the Jastrow
 // work, no prefetch)
 #define PQA_R8CLK(k) do { if (s == 1 && i == 16) PQA_RCLK(k); } while (0)
+// (timing builds) wall-clock stamps of a block's prologue / epilogue: 0 tables in LDS, 1 + 4 s: spin s rows loaded, 2 + 4 s: its moves done,
+// 3 + 4 s: its state stored, 4 + 4 s: past the spin's closing barrier
+#ifdef PQA_RES_CLK
+#define PQA_R8T(k) PQA_RCLK2(k, wall_clock64())
+#else
+#define PQA_R8T(k) do { } while (0)
+#endif
 template <bool DMC, int LMAX>
 static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwState L, MoveBuf mb, ChunkTab T, R8Tab RT, int has_jastrow,
                                                                   long W, long w_lo, long w_hi) {
@@ -220,6 +227,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
   }
   if (r == 0) { ws[13] = 0.0; ws[14] = 0.0; ws[15] = 0.0; }
   __syncthreads();
+  PQA_R8T(0);
   if (RT.stagger > 0 && (__builtin_amdgcn_s_getreg(0x3806) & 0xff) != 0) {  // HW_REG_LDS_ALLOC.LDS_BASE: not the first workgroup on this CU
     for (int k = 0; k < RT.stagger; ++k) { __builtin_amdgcn_s_sleep(100); }  // (64 x 100 cycles each)
   }
@@ -258,6 +266,10 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
       ws[11] = (s ? L.dlog[1] : L.dlog[0])[wg]; ws[12] = 1.0;
     }
 
+#ifdef PQA_RES_CLK
+    { double chk = t[0] + t[31]; asm volatile("" :: "v"(chk)); }  // (the rows have arrived)
+#endif
+    PQA_R8T(1 + 4 * s);
 #pragma unroll 1
     for (int i = -1; i < n; ++i) {  // iteration i: [orbitals at the proposals of electron i, decide i], then propose i + 1
       const int e = e0 + i;
@@ -590,6 +602,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         PQA_R8CLK(6);
       }
     }
+    PQA_R8T(2 + 4 * s);
     // ---- this spin's state back to the planes
     if (live && r < n) {
 #pragma unroll
@@ -604,7 +617,9 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
       (s ? L.dsign[1] : L.dsign[0])[wg] = ws[10];
       (s ? L.dlog[1] : L.dlog[0])[wg] = ws[11] + log(ws[12]);
     }
+    PQA_R8T(3 + 4 * s);
     __syncthreads();  // (rowE / region reads of this spin's last decision before the next spin's first proposal)
+    PQA_R8T(4 + 4 * s);
   }
   PQA_RCLK(15);
   if (live) {
