@@ -146,6 +146,9 @@ int pqa_device_count(void);
    evaluations; cached walker state is refreshed by the next recompute, as in the reference. */
 int pqa_set_param(pqa_handle_t* h, const char* name, const double* data, int64_t n);
 int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int64_t n);
+/* pqa_get_param also answers "radial_table_info" (n = 2): the size in doubles of the radial tables the value-only
+   orbital kernel reads for contracted shells of open systems and the largest fit error found when they were built,
+   relative to sum |c| of the contraction (0, 0 with PQA_RADTAB=0 or a periodic system). */
 
 /* ---- orbital evaluation (orbitals.py:85-96; numba/gto.py:89-254) --------------------- */
 /* out (ncomp, npts, nao); ncomp 1 = value, 4 = +gradient, 5 = +laplacian */

@@ -144,6 +144,38 @@ __device__ __forceinline__ void sph_high(int l, int m, double x, double y, doubl
 // LMAX < 3 compiles the f-shell branch out (callers that know the basis has none: its seven functions set the register
 // high-water mark of the routine); LMAX < 5 the g/h branch (the periodic kernels: their register budget is exhausted — with it
 // k_orb<5,..,PBC=1> went from 213 to 228 VGPRs, 2 to 1 waves per SIMD and +70 % time; periodic cells take l <= 3).
+// Radial value of a contracted shell from its table (SysDev::rtab): x = r^2 is located by the binary exponent and the top three mantissa bits
+// of y = x + 2^-7 — interval (octave, eighth), local variable u in [-1, 1) — and R(x) = sum c e^{-a x} is a degree-9 polynomial in u (Horner).
+// One exponential per primitive (20 instructions each, 9 primitives in a cc-pVDZ s or p contraction) becomes ~12 instructions of indexing, five
+// 16-byte gathers from an L2-resident table and 9 fused multiply-adds.  Beyond the last interval every primitive is below 1e-20 of its
+// coefficient: zero.  Values only — the value-only orbital kernel of the ECP quadrature (k_orb<1>) is where the exponentials were 40 % of the
+// instructions.  With the derivative sums as well (30 coefficients, 15 gathers per lane and shell) the texture path takes as long as the
+// exponentials did: k_orb<5> 3.83 -> 3.9 ms, the resident sweep unchanged, so those keep the primitive sums.  (With every
+// lane on ONE record k_orb<1> is only 5 % faster still: the gathers are not what bounds it now.)
+#define PQA_RT_X0 0.0078125  // 2^-7
+#define PQA_RT_NSUB 8
+#define PQA_RT_DEG 9
+#define PQA_RT_REC (PQA_RT_DEG + 1)  // doubles per interval
+#define PQA_RT_MINP 3        // shells with fewer primitives keep their exponentials
+__device__ __forceinline__ double radial_tab(const double* __restrict__ tab, int nint, double r2) {
+  const double y = r2 + PQA_RT_X0;
+  const int E = __builtin_amdgcn_frexp_exp(y);       // y = m 2^E, m in [0.5, 1)
+  const double m = __builtin_amdgcn_frexp_mant(y);
+  const double t = fma(m, 2.0 * PQA_RT_NSUB, -(double)PQA_RT_NSUB);  // (2 m - 1) NSUB in [0, NSUB)
+  const double tj = floor(t);
+  const double u = fma(t - tj, 2.0, -1.0);
+  int idx = (E + 6) * PQA_RT_NSUB + (int)tj;
+  const bool in = idx < nint;
+  idx = in ? idx : nint - 1;
+  const double2* rec = reinterpret_cast<const double2*>(tab + (size_t)idx * PQA_RT_REC);
+  double c[PQA_RT_REC];
+#pragma unroll
+  for (int q = 0; q < PQA_RT_REC / 2; ++q) { const double2 v = rec[q]; c[2 * q] = v.x; c[2 * q + 1] = v.y; }
+  double f0 = c[PQA_RT_DEG];
+#pragma unroll
+  for (int q = PQA_RT_DEG - 1; q >= 0; --q) f0 = fma(f0, u, c[q]);
+  return in ? f0 : 0.0;
+}
 // The angular half: the shell's 2l+1 functions from its radial sums R = sum c e^{-a r^2}, dRs = sum a c e^{-a r^2}, lapR = sum 2a (2a r^2 - 3) c e^{-a r^2}.
 template <int NCOMP, int LMAX = 5, class Sink>
 __device__ __forceinline__ void shell_angular(int l, double x, double y, double z, double R, double dRs, double lapR, Sink&& sink);
@@ -166,6 +198,11 @@ __device__ __forceinline__ void shell_eval(int l, double x, double y, double z, 
     if (NCOMP == 5) lapR += t * (2.0 * a) * (2.0 * a * r2 - 3.0);
   }
   shell_angular<NCOMP, LMAX>(l, x, y, z, R, dRs, lapR, sink);
+}
+// The values of a contracted shell through its radial table (open systems; callers check SysDev::shell_rt)
+template <int LMAX = 5, class Sink>
+__device__ __forceinline__ void shell_eval_tab(int l, double x, double y, double z, const double* __restrict__ tab, int nint, Sink&& sink) {
+  shell_angular<1, LMAX>(l, x, y, z, radial_tab(tab, nint, x * x + y * y + z * z), 0.0, 0.0, sink);
 }
 // The same sums with the primitives three at a time (exp_neg3: independent chains for kernels with one or two waves per SIMD); the
 // primitives are added in the same order as in shell_eval.
@@ -784,7 +821,7 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
   __shared__ double tile[NCOMP][KC][TP];
   // LDSTAB: basis tables staged once per block so phase 1 never waits on chains of dependent scalar loads
   __shared__ double sh_xyz[LDSTAB ? PQA_WS_MAXSH : 1][3];
-  __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][5];  // l, nprim, first primitive, tile row in chunk, atom
+  __shared__ int sh_meta[LDSTAB ? PQA_WS_MAXSH : 1][7];  // l, nprim, first primitive, tile row in chunk, atom, radial table offset (-1: none) and intervals
   __shared__ double pr_exp[LDSTAB ? PQA_WS_MAXP : 1], pr_coef[LDSTAB ? PQA_WS_MAXP : 1];
   __shared__ double sh_Ls[PBC ? PQA_LS_MAX : 1][3], sh_ph[PBC == 2 ? PQA_LS_MAX : 1][2];  // lattice vectors (phases) of the candidate images
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -803,6 +840,7 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
       sh_meta[sh][2] = S.shell_prim_off[sh];
       sh_meta[sh][3] = T.shell_kb[sh];
       sh_meta[sh][4] = ia;
+      sh_meta[sh][5] = (PBC || NCOMP > 1) ? -1 : S.shell_rt[2 * sh]; sh_meta[sh][6] = (PBC || NCOMP > 1) ? 0 : S.shell_rt[2 * sh + 1];
     }
     for (int p = tid; p < S.nprim; p += 256) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
     __syncthreads();
@@ -869,11 +907,12 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
 #endif
     for (int si = cw_off[ch * G + grp]; si < s_end; ++si) {
       const int sh = cw_shell[si];
-      int l_, np_, q0, kb, ia_ = 0;
+      int l_, np_, q0, kb, ia_ = 0, rt_ = -1, rn_ = 0;
       double x, y, z;
       const double *pe, *pc;
       if (LDSTAB) {
         l_ = sh_meta[sh][0]; np_ = sh_meta[sh][1]; q0 = sh_meta[sh][2]; kb = sh_meta[sh][3]; ia_ = sh_meta[sh][4];
+        if (!PBC && NCOMP == 1) { rt_ = sh_meta[sh][5]; rn_ = sh_meta[sh][6]; }
         x = px - sh_xyz[sh][0]; y = py - sh_xyz[sh][1]; z = pz - sh_xyz[sh][2];
         pe = pr_exp + q0; pc = pr_coef + q0;
       } else {
@@ -882,6 +921,7 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
         q0 = S.shell_prim_off[sh]; kb = T.shell_kb[sh]; l_ = S.shell_l[sh]; np_ = S.shell_prim_off[sh + 1] - q0;
         x = px - S.atom_xyz[3 * ia]; y = py - S.atom_xyz[3 * ia + 1]; z = pz - S.atom_xyz[3 * ia + 2];
         pe = S.prim_exp + q0; pc = S.prim_coef + q0;
+        if (!PBC && NCOMP == 1) { rt_ = S.shell_rt[2 * sh]; rn_ = S.shell_rt[2 * sh + 1]; }
       }
       bool accum = false;  // periodic: the lattice sum accumulates in the tile (shell_eval_pbc)
       auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
@@ -918,7 +958,8 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
           else shell_eval_pbc<NCOMP, true>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile_im, accum, ls_from_global);
         } else if (ls_lds) shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_from_lds);
         else shell_eval_pbc<NCOMP, false>(S, ctx, sh, l_, pe, pc, np_, to_tile, to_tile, accum, ls_from_global);
-      } else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
+      } else if (NCOMP == 1 && rt_ >= 0) shell_eval_tab(l_, x, y, z, S.rtab + rt_, rn_, to_tile);  // contracted shell, values: the radial sum from its table
+      else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
     for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
       const int rc = idx / TP;
@@ -988,7 +1029,7 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
   // basis tables staged once per block: the producer loop then never waits on dependent global/scalar
   // loads (shell -> atom -> coordinates -> primitives), which is what bounded it before
   __shared__ double sh_xyz[PQA_WS_MAXSH][3];
-  __shared__ int sh_meta[PQA_WS_MAXSH][4];  // l, nprim, first primitive, first AO
+  __shared__ int sh_meta[PQA_WS_MAXSH][NCOMP == 1 ? 6 : 4];  // l, nprim, first primitive, first AO; values only: radial table offset (-1: none), intervals
   __shared__ double pr_exp[PQA_WS_MAXP], pr_coef[PQA_WS_MAXP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int sh = tid; sh < S.nshell; sh += 512) {
@@ -998,6 +1039,7 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
     sh_meta[sh][1] = S.shell_prim_off[sh + 1] - S.shell_prim_off[sh];
     sh_meta[sh][2] = S.shell_prim_off[sh];
     sh_meta[sh][3] = T.shell_kb[sh];
+    if (NCOMP == 1) { sh_meta[sh][4 % (NCOMP == 1 ? 6 : 4)] = S.shell_rt[2 * sh]; sh_meta[sh][5 % (NCOMP == 1 ? 6 : 4)] = S.shell_rt[2 * sh + 1]; }
   }
   for (int p = tid; p < S.nprim; p += 512) { pr_exp[p] = S.prim_exp[p]; pr_coef[p] = S.prim_coef[p]; }
   __syncthreads();
@@ -1036,14 +1078,16 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
           const int sh = cw_shell[si];
           const int q0 = sh_meta[sh][2], kb = sh_meta[sh][3];
           const double x = px - sh_xyz[sh][0], y = py - sh_xyz[sh][1], z = pz - sh_xyz[sh][2];
-          shell_eval<NCOMP>(sh_meta[sh][0], x, y, z, pr_exp + q0, pr_coef + q0, sh_meta[sh][1],
-                            [&](int m, double v, double gx, double gy, double gz, double lp) {
-                              const int k = kb + m;
-                              const int col = lane ^ ((k & 1) << 4);
-                              tb[0][k][col] = v;
-                              if (NCOMP > 1) { tb[1 % NCOMP][k][col] = gx; tb[2 % NCOMP][k][col] = gy; tb[3 % NCOMP][k][col] = gz; }
-                              if (NCOMP == 5) tb[4 % NCOMP][k][col] = lp;
-                            });
+          auto to_tile = [&](int m, double v, double gx, double gy, double gz, double lp) {
+            const int k = kb + m;
+            const int col = lane ^ ((k & 1) << 4);
+            tb[0][k][col] = v;
+            if (NCOMP > 1) { tb[1 % NCOMP][k][col] = gx; tb[2 % NCOMP][k][col] = gy; tb[3 % NCOMP][k][col] = gz; }
+            if (NCOMP == 5) tb[4 % NCOMP][k][col] = lp;
+          };
+          const int rt_ = NCOMP == 1 ? sh_meta[sh][4 % (NCOMP == 1 ? 6 : 4)] : -1;
+          if (NCOMP == 1 && rt_ >= 0) shell_eval_tab(sh_meta[sh][0], x, y, z, S.rtab + rt_, sh_meta[sh][5 % (NCOMP == 1 ? 6 : 4)], to_tile);  // radial_tab
+          else shell_eval<NCOMP>(sh_meta[sh][0], x, y, z, pr_exp + q0, pr_coef + q0, sh_meta[sh][1], to_tile);
         }
         for (int idx = tid; idx < (nk4 - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows (256 producer threads)
           const int rc = idx >> 6;

@@ -134,6 +134,96 @@ static int voronoi_vectors(const double* a, PbcDev& P) {
 // (farther) image on only the primitives that survive the screening at half the shortest lattice vector are evaluated.
 // Packing the lane groups with the per-evaluation cost alone gave a group holding two diffuse p shells (13 images each in
 // the 2x2x2 diamond cell) 2.3 x the average load, and a barrier ends every chunk.
+// Radial tables of the contracted shells (SysDev::rtab, radial_tab in pqa_ao.hpp): per distinct (exponent, coefficient) sequence of at least
+// PQA_RT_MINP primitives the sum R(x) = sum_p c_p exp(-a_p x) as degree-9 polynomials on the intervals y = x + 2^-7 in
+// 2^(o-7) [1 + j/8, 1 + (j+1)/8), o = 0 .. until every primitive is below exp(-46).  Chebyshev interpolation at the 10 nodes of every interval
+// in long double, converted to powers of the local variable u in [-1, 1]; the largest error found at 33 points per interval (in the device's
+// arithmetic: double Horner) is kept in h->rt_err, relative to sum_p |c_p| (1e-15 for cc-pVDZ-shaped contractions; pqa_debug_radtab_err, and
+// the device tests compare the orbitals with the primitive sums).  Open systems only (the lattice sums keep their exponentials), value-only
+// orbital kernel only; PQA_RADTAB=0 turns it off.
+static int build_radial_tables(pqa_handle* h, const pqa_system_t* sys, SysDev& S) {
+  std::vector<int> rt((size_t)2 * sys->nshell, -1);
+  std::vector<double> tab;
+  h->rt_err = 0.0;
+  const char* env = getenv("PQA_RADTAB");
+  const bool on = !(env && atoi(env) == 0) && sys->pbc == 0;
+  std::vector<double> pe_((size_t)std::max(sys->nprim, 1)), pc_((size_t)std::max(sys->nprim, 1));
+  std::vector<int> po_((size_t)sys->nshell + 1);
+  HIPCHK(hipMemcpy(pe_.data(), sys->prim_exp, (size_t)sys->nprim * sizeof(double), hipMemcpyDefault));
+  HIPCHK(hipMemcpy(pc_.data(), sys->prim_coef, (size_t)sys->nprim * sizeof(double), hipMemcpyDefault));
+  HIPCHK(hipMemcpy(po_.data(), sys->shell_prim_off, po_.size() * sizeof(int), hipMemcpyDefault));
+  const double* prim_exp = pe_.data();
+  const double* prim_coef = pc_.data();
+  const int* shell_prim_off = po_.data();
+  if (on) {
+    constexpr int n = PQA_RT_DEG + 1;
+    long double nodes[n], Tm[n][n];  // Chebyshev nodes; T_q(u) in powers of u
+    const long double pi = acosl(-1.0L);
+    for (int k = 0; k < n; ++k) nodes[k] = cosl(pi * (k + 0.5L) / n);
+    for (int q = 0; q < n; ++q)
+      for (int d = 0; d < n; ++d) Tm[q][d] = 0.0L;
+    Tm[0][0] = 1.0L; Tm[1][1] = 1.0L;
+    for (int q = 2; q < n; ++q)
+      for (int d = 0; d < n; ++d) Tm[q][d] = (d > 0 ? 2.0L * Tm[q - 1][d - 1] : 0.0L) - Tm[q - 2][d];
+    for (int sh = 0; sh < sys->nshell; ++sh) {
+      const int p0 = shell_prim_off[sh], np = shell_prim_off[sh + 1] - p0;
+      if (np < PQA_RT_MINP) continue;
+      int same = -1;
+      for (int prev = 0; prev < sh && same < 0; ++prev) {
+        const int q0 = shell_prim_off[prev];
+        if (shell_prim_off[prev + 1] - q0 == np && rt[2 * prev] >= 0 && std::equal(prim_exp + p0, prim_exp + p0 + np, prim_exp + q0) &&
+            std::equal(prim_coef + p0, prim_coef + p0 + np, prim_coef + q0)) same = prev;
+      }
+      if (same >= 0) { rt[2 * sh] = rt[2 * same]; rt[2 * sh + 1] = rt[2 * same + 1]; continue; }
+      double amin = prim_exp[p0];
+      for (int p = 0; p < np; ++p) amin = std::min(amin, prim_exp[p0 + p]);
+      if (!(amin > 0.0)) continue;
+      const int noct = std::max(1, (int)std::ceil(std::log2((46.0 / amin + PQA_RT_X0) / PQA_RT_X0)));
+      if (noct > 40) continue;
+      const int nint = noct * PQA_RT_NSUB;
+      rt[2 * sh] = (int)tab.size(); rt[2 * sh + 1] = nint;
+      long double scale = 0.0L;
+      for (int p = 0; p < np; ++p) scale += fabsl((long double)prim_coef[p0 + p]);
+      auto F = [&](long double x) {
+        long double f = 0.0L;
+        for (int p = 0; p < np; ++p) f += (long double)prim_coef[p0 + p] * expl(-(long double)prim_exp[p0 + p] * x);
+        return f;
+      };
+      for (int o = 0; o < noct; ++o)
+        for (int j = 0; j < PQA_RT_NSUB; ++j) {
+          const long double ylo = (long double)PQA_RT_X0 * ldexpl(1.0L, o) * (1.0L + (long double)j / PQA_RT_NSUB);
+          const long double yhi = (long double)PQA_RT_X0 * ldexpl(1.0L, o) * (1.0L + (long double)(j + 1) / PQA_RT_NSUB);
+          const long double xc = 0.5L * (ylo + yhi) - (long double)PQA_RT_X0, hw = 0.5L * (yhi - ylo);
+          {
+            long double fv[n], cc[n], mono[n];
+            for (int q = 0; q < n; ++q) fv[q] = F(xc + hw * nodes[q]);
+            for (int q = 0; q < n; ++q) {
+              long double sum = 0.0L;
+              for (int m = 0; m < n; ++m) sum += fv[m] * cosl(q * pi * (m + 0.5L) / n);
+              cc[q] = (q == 0 ? 1.0L : 2.0L) * sum / n;
+            }
+            for (int d = 0; d < n; ++d) { mono[d] = 0.0L; for (int q = 0; q < n; ++q) mono[d] += cc[q] * Tm[q][d]; }
+            double m64[n];
+            for (int d = 0; d < n; ++d) { m64[d] = (double)mono[d]; tab.push_back(m64[d]); }
+            for (int t = 0; t <= 32; ++t) {  // the table against the sums, in the arithmetic the device uses (double Horner)
+              const double u = -1.0 + t / 16.0;
+              double pv = m64[n - 1];
+              for (int d = n - 2; d >= 0; --d) pv = std::fma(pv, u, m64[d]);
+              const long double ex = F(xc + hw * (long double)u);
+              h->rt_err = std::max(h->rt_err, (double)(fabsl((long double)pv - ex) / scale));
+            }
+          }
+        }
+    }
+  }
+  double* td = nullptr; int* ti = nullptr;
+  TRY(upload_table(h, tab.data(), tab.size(), &td)); S.rtab = td;
+  TRY(upload_table(h, rt.data(), rt.size(), &ti)); S.shell_rt = ti;
+  h->rt_shells.assign(rt.begin(), rt.end());
+  if (getenv("PQA_RES_DEBUG")) fprintf(stderr, "[pqa] radial tables: %zu doubles, largest error %.2e of sum |c|\n", tab.size(), h->rt_err);
+  return 0;
+}
+
 static void shell_costs(pqa_handle* h, const pqa_system_t* sys) {
   const int tw = h->twist ? 2 : 1;
   h->shell_cost.assign((size_t)h->nshell, 0);
@@ -521,6 +611,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
     TRY(upload_table(h, sys->shell_ao_off, (size_t)sys->nshell, &tmp_i)); S.shell_ao_off = tmp_i;
     TRY(upload_table(h, sys->prim_exp, (size_t)sys->nprim, &tmp_d)); S.prim_exp = tmp_d;
     TRY(upload_table(h, sys->prim_coef, (size_t)sys->nprim, &tmp_d)); S.prim_coef = tmp_d;
+    TRY(build_radial_tables(h, sys, S));
     S.nL = 0;
     if (S.pbc) {
       if (sys->nL <= 0 || !sys->Ls || !sys->num_Ls || !sys->atom_cut || !sys->shell_cut) FAIL("periodic orbitals need the lattice-sum tables (Ls, num_Ls, atom_cut, shell_cut)");
@@ -954,6 +1045,14 @@ extern "C" int pqa_get_param(pqa_handle_t* h, const char* name, double* out, int
   else if (k == "det_coeff") { src = h->d_detcoeff; want = h->ndet; }
   else if (k == "mo_coeff_alpha") { src = h->d_mo[0]; want = (int64_t)h->nao * h->nmo[0]; }
   else if (k == "mo_coeff_beta") { src = h->d_mo[1]; want = (int64_t)h->nao * h->nmo[1]; }
+  else if (k == "radial_table_info") {  // [number of table doubles, largest fit error relative to sum |c|] (build_radial_tables)
+    if (n != 2) FAIL("parameter size mismatch");
+    long used = 0;
+    for (size_t q = 0; q + 1 < h->rt_shells.size(); q += 2)
+      if (h->rt_shells[q] >= 0) used = std::max(used, (long)h->rt_shells[q] + (long)h->rt_shells[q + 1] * PQA_RT_REC);
+    out[0] = (double)used; out[1] = h->rt_err;
+    return 0;
+  }
   else FAIL("unknown parameter name");
   if (n != want) FAIL("parameter size mismatch");
   HIPCHK(hipMemcpy(out, src, n * sizeof(double), hipMemcpyDefault));

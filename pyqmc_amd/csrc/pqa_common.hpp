@@ -69,6 +69,12 @@ struct SysDev {
   const int* shell_ao_off;
   const double* prim_exp;
   const double* prim_coef;
+  // Tabulated radial functions of contracted shells (round 6; open systems, the MFMA orbital kernels and the resident sweep): for a shell with
+  // shell_rt[2 sh] >= 0 the three radial sums F_k(x) = sum_p a_p^k c_p exp(-a_p x), k = 0, 1, 2, x = r^2 (numba/gto.py:89-254: R, dR, lap R) are
+  // piecewise degree-9 polynomials at rtab + shell_rt[2 sh], shell_rt[2 sh + 1] intervals of [interval][3][10] doubles (radial_tab, pqa_ao.hpp;
+  // host: build_radial_tables, pqa_capi.hip: |error| <= 1e-15 sum_p |c_p| a_p^k).  -1: the primitives are summed (exp per primitive).
+  const double* rtab;
+  const int* shell_rt;
   int nmo[2];
   const double* mo[2];  // [ao][nmo]
   int ndet, ndet_s[2];

@@ -76,6 +76,8 @@ struct pqa_handle {
   EwaldDev ew{};  // periodic Coulomb tables (pqa_set_ewald)
   bool ew_set = false;
   std::vector<int> shell_l, shell_np, shell_ao;
+  std::vector<int> rt_shells;  // [nshell][2] host copy of SysDev::shell_rt (radial tables of the contracted shells)
+  double rt_err = 0.0;         // largest table error found at create, relative to sum |c| a^k
   std::vector<int> shell_cost;  // phase-1 cost model of a shell (shell_costs): balances the lane groups of the orbital kernels
   SysDev S{};
   ChunkHost chunks[2];  // [0]: KC=16 (5 components), [1]: KC=32 (value only)

@@ -124,6 +124,46 @@ def test_mo_mfma_vs_valu_vs_oracle(mol, npts):
             assert note(f"mo_valu_{mol.natm}_{spin}_{ncomp}", relerr(b, ref)) < 1e-12
 
 
+@pytest.mark.parametrize("mol", [systems.water(), systems.water_cluster()])
+def test_radial_tables_against_primitive_sums(mol, monkeypatch):
+    """Values of contracted shells come from tabulated radial sums in the value-only orbital kernel (radial_tab,
+    pqa_ao.hpp): the same orbitals as with the primitive sums (PQA_RADTAB=0) and as the oracle, from the nuclei out to where
+    every primitive has died, and the fit error the library reports is at rounding level."""
+    import ctypes as C
+
+    import pyqmc_amd as pa
+    from oracle import gto
+    from pyqmc_amd import _ffi
+
+    mf = systems.random_mf(mol)
+    rng = np.random.default_rng(11)
+    at = mol.atom_coords()
+    dirs = rng.standard_normal((400, 3))
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    radii = np.concatenate([np.zeros(8), 10.0 ** rng.uniform(-4, 1.2, size=392)])  # on a nucleus ... 16 bohr
+    pts = at[rng.integers(mol.natm, size=400)] + radii[:, None] * dirs
+    info = np.zeros(2)
+    table = gto.AOTable(mol)
+    for ws in ("1", "0"):  # the wave-specialised kernel (small launches) and the plain one
+        monkeypatch.setenv("PQA_ORB_WS", ws)
+        monkeypatch.delenv("PQA_RADTAB", raising=False)
+        dev = pa.DeviceWF(mol, mo_coeff=mf.mo_coeff)
+        assert _ffi.lib().pqa_get_param(dev._h, b"radial_table_info", info.ctypes.data_as(C.c_void_p), 2) == 0
+        assert info[0] > 0 and note(f"radial_table_fit_{mol.natm}", info[1]) < 5e-15
+        monkeypatch.setenv("PQA_RADTAB", "0")
+        plain = pa.DeviceWF(mol, mo_coeff=mf.mo_coeff)
+        assert _ffi.lib().pqa_get_param(plain._h, b"radial_table_info", info.ctypes.data_as(C.c_void_p), 2) == 0
+        assert info[0] == 0
+        for spin in (0, 1):
+            ref = gto.eval_mo(gto.eval_ao(table, pts, 1), mf.mo_coeff[spin][:, : dev.nmo[spin]])
+            a = dev.eval_mo(spin, pts, 1, use_mfma=True)
+            b = plain.eval_mo(spin, pts, 1, use_mfma=True)
+            scale = np.abs(ref).max()
+            d = np.abs(a - b).max() / scale
+            assert 0 < note(f"radial_table_vs_sums_{mol.natm}_{spin}_ws{ws}", d) < 2e-14  # 0: the table was not read
+            assert note(f"radial_table_vs_oracle_{mol.natm}_{spin}_ws{ws}", np.abs(a - ref).max() / scale) < 2e-14
+
+
 @pytest.mark.parametrize("name", ["g5_protocol_h2o", "g8_protocol_h2o_multidet", "g5_protocol_cluster"])
 def test_protocol_golden(name):
     """update / testvalue / recompute triangle of the reference's run_tests
