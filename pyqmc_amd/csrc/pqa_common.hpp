@@ -224,6 +224,13 @@ __device__ __forceinline__ double dpp_add(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
   return v + __hiloint2double(hi, lo);  // lanes whose source is out of range / row-masked add +0.0
 }
+// v of the lane quad_perm CTRL names, inside each quad of four lanes
+template <int CTRL>
+__device__ __forceinline__ double quad_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 // Synchronisation inside the wave-per-walker device functions (slater_ratios, sm_update_wave, jas3_eval: one wave works on one walker
 // through its own LDS scratch).  In blocks whose waves all run the same function it is the block barrier; pqa_sweep_ww.hip — three
 // waves of a block running DIFFERENT functions of one move — defines it as a wave-level fence before including the headers.

@@ -597,7 +597,17 @@ static __global__ __launch_bounds__(256) void k_row_means(const double* __restri
   __shared__ double part[256];
   const double* row = a + (size_t)blockIdx.x * W;
   double s = 0.0;
-  for (long i = threadIdx.x; i < W; i += 256) s += row[i];
+  // eight loads in flight per thread (one at a time the 256 dependent round trips of a 65 536-walker row took 64 us); the thread's sum keeps
+  // its order: element i, i + 256, ...
+  long i = threadIdx.x;
+  for (; i + 7 * 256 < W; i += 8 * 256) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = row[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < W; i += 256) s += row[i];
   part[threadIdx.x] = s;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) {

@@ -1357,11 +1357,16 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 // 2.0 -> 3.3 ms per evaluation.)  Every electron's thread walks ALL coordinates of its walker for the Jastrow and Coulomb sums,
 // so the 64 electron-waves of a walker group pull the group's coordinates through the fabric 64 times (the counters show
 // 195 KB per walker against 96 KB of inverse + cache rows; the re-reads hit the Infinity Cache).
+// Where the time goes at 65 536 walkers (round 6, tools/scratch/row_probe.hip + kernel variants): the row cache alone streams at 5.0 (a lane per
+// row) to 5.8 TB/s (a quad per line), the inverse planes alone at 5.8 TB/s — 1.1 ms for both — but read in the same kernel, even by different
+// blocks, the two streams take 1.5-1.9 ms (tile-blocked inverse: 1.55): the mix, not either pattern, costs the bandwidth.  The coordinate walk
+// of the Jastrow / Coulomb sums (96 KB per wave out of L2) adds 0.28 ms on top although its arithmetic is 0.07 ms.  PQA_KIN_V: 1 = a lane
+// streams its own row (1.86 ms), 3 = quad-cooperative lines (1.79 ms, default), 4 = V1 with half a component requested ahead (1.84 ms).
 #ifndef PQA_KIN_EB
 #define PQA_KIN_EB 1
 #endif
 #ifndef PQA_KIN_V
-#define PQA_KIN_V 1
+#define PQA_KIN_V 3
 #endif
 template <bool PBC, bool CX = false>
 static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
@@ -1388,7 +1393,88 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
       // ground-state occupation: whole 64-byte lines of the lane's own row, two adjacent 32-byte loads each, used up at once
       // (walking 4 slots of all five components first left every line half used until the next round: 320 lines per wave in
       // flight, more than L1 keeps with 16 waves per CU — the kernel took 3.5 ms instead of 1.9)
-#if PQA_KIN_V == 1  // component-major: the lane streams its row front to back (adjacent lines back to back), inverse row in registers
+#if PQA_KIN_V == 3
+      // Quad-cooperative rows: the four lanes of a quad (walkers wq .. wq + 3) read the row of each of the four walkers together, 16 bytes per
+      // lane = one whole 64-byte line per quad and instruction, 16 lines per wave-instruction.  (A lane streaming its own row touches a line of
+      // its own per load: 64 lines per instruction, and the address path — one line per cycle and CU — not HBM set the kernel's time: 3.7 TB/s.)
+      // Lane q of the quad holds orbital slots j + 2q, j + 2q + 1 of each 8-slot line, so it takes those two slots of the inverse row of ALL four
+      // walkers (two 32-byte loads of T[slot][wq .. wq + 3]) and accumulates its share of all four walkers' sums; the quad adds the shares at the
+      // end (DPP) and lane q keeps walker wq + q's.
+      if (n <= 32 && (W & 3) == 0) {
+        const int q = (int)threadIdx.x & 3;
+        const long wq = w - q;
+        const uint32_t s4 = *reinterpret_cast<const uint32_t*>(L.sel[s] + (size_t)i * W + wq);
+        const double* rq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rq[t] = lw_row(L, s, i, (int)((s4 >> (8 * t)) & 0xffu), wq + t, W, nmo) + 2 * q;
+        const double* Tq = L.Tt[s] + ((size_t)i * n + 2 * q) * W + wq;
+        double p[4][5];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < 5; ++c) p[t][c] = 0.0;
+        for (int j = 0; j < n; j += 8) {  // one line of every component of the four rows (20 loads) + the quad's share of the inverse in flight
+          const double4 ta = *reinterpret_cast<const double4*>(Tq + (size_t)j * W), tb = *reinterpret_cast<const double4*>(Tq + (size_t)(j + 1) * W);
+          double2 v[20];
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[c * 4 + t] = *reinterpret_cast<const double2*>(rq[t] + c * nmo + j);
+          __builtin_amdgcn_sched_barrier(0);
+          const double t0[4] = {ta.x, ta.y, ta.z, ta.w}, t1[4] = {tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { p[t][c] += v[c * 4 + t].x * t0[t]; p[t][c] += v[c * 4 + t].y * t1[t]; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          double mine = 0.0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            double x = p[t][c];
+            x += quad_dpp<0xb1>(x);  // quad_perm [1, 0, 3, 2]
+            x += quad_dpp<0x4e>(x);  // quad_perm [2, 3, 0, 1]: the quad's total in every lane
+            mine = (q == t) ? x : mine;
+          }
+          r[c] = mine;
+        }
+      } else
+#elif PQA_KIN_V == 4
+      // component-major, a whole component (n doubles = n / 8 lines of the lane's own row) requested before the previous component's products:
+      // 256 bytes per lane in flight all the time (the compiler's own schedule of V == 1 waits for every line before it asks for the next:
+      // one 64-byte line per lane in flight, 3.7 TB/s)
+      if (n <= 32) {
+        double t[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t[u] = (u < n) ? Ti[(size_t)u * W] : 0.0;
+        // half a component (16 slots = 128 bytes) per buffer: request the next half, then use the previous one
+        double4 A[4], B[4];
+#define PQA_KIN_SB __builtin_amdgcn_sched_barrier(0);
+#define PQA_KIN_LOAD(BUF, H) _Pragma("unroll") for (int k = 0; k < 4; ++k) BUF[k] = *reinterpret_cast<const double4*>(row + ((H) >> 1) * nmo + ((((H) & 1) * 16 + 4 * k) < n ? ((H) & 1) * 16 + 4 * k : 0));  /* (slots >= n: t = 0) */
+#define PQA_KIN_DOT(BUF, H)                                                                                       \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                 \
+    const int j_ = ((H) & 1) * 16 + 4 * k;                                                                        \
+    r[(H) >> 1] += BUF[k].x * t[j_]; r[(H) >> 1] += BUF[k].y * t[j_ + 1]; r[(H) >> 1] += BUF[k].z * t[j_ + 2]; r[(H) >> 1] += BUF[k].w * t[j_ + 3]; \
+  }
+        PQA_KIN_LOAD(A, 0)
+        PQA_KIN_LOAD(B, 1)
+        PQA_KIN_SB PQA_KIN_DOT(A, 0) PQA_KIN_SB PQA_KIN_LOAD(A, 2)
+        PQA_KIN_SB PQA_KIN_DOT(B, 1) PQA_KIN_SB PQA_KIN_LOAD(B, 3)
+        PQA_KIN_SB PQA_KIN_DOT(A, 2) PQA_KIN_SB PQA_KIN_LOAD(A, 4)
+        PQA_KIN_SB PQA_KIN_DOT(B, 3) PQA_KIN_SB PQA_KIN_LOAD(B, 5)
+        PQA_KIN_SB PQA_KIN_DOT(A, 4) PQA_KIN_SB PQA_KIN_LOAD(A, 6)
+        PQA_KIN_SB PQA_KIN_DOT(B, 5) PQA_KIN_SB PQA_KIN_LOAD(B, 7)
+        PQA_KIN_SB PQA_KIN_DOT(A, 6) PQA_KIN_SB PQA_KIN_LOAD(A, 8)
+        PQA_KIN_SB PQA_KIN_DOT(B, 7) PQA_KIN_SB PQA_KIN_LOAD(B, 9)
+        PQA_KIN_SB PQA_KIN_DOT(A, 8)
+        PQA_KIN_DOT(B, 9)
+#undef PQA_KIN_LOAD
+#undef PQA_KIN_DOT
+#undef PQA_KIN_SB
+      } else
+#elif PQA_KIN_V == 1  // component-major: the lane streams its row front to back (adjacent lines back to back), inverse row in registers
       if (n <= 32) {
         double t[32];
 #pragma unroll

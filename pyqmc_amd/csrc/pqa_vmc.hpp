@@ -208,7 +208,15 @@ template <int PQA_UNIT = 0>  // (a template so that only the units that launch i
 static __global__ __launch_bounds__(1024) void k_sum_reset_int(int* __restrict__ acc_w, long W, int* __restrict__ out) {
   __shared__ int part[1024];
   int s = 0;
-  for (long i = threadIdx.x; i < W; i += 1024) { s += acc_w[i]; acc_w[i] = 0; }
+  long i = threadIdx.x;
+  for (; i + 7 * 1024 < W; i += 8 * 1024) {  // eight loads in flight per thread
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = acc_w[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += v[u]; acc_w[i + u * 1024] = 0; }
+  }
+  for (; i < W; i += 1024) { s += acc_w[i]; acc_w[i] = 0; }
   part[threadIdx.x] = s;
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
