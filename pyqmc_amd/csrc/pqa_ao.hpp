@@ -961,14 +961,20 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
       } else if (NCOMP == 1 && rt_ >= 0) shell_eval_tab(l_, x, y, z, S.rtab + rt_, rn_, to_tile);  // contracted shell, values: the radial sum from its table
       else shell_eval<NCOMP>(l_, x, y, z, pe, pc, np_, to_tile);
     }
-    for (int idx = tid; idx < (nk4 - nk) * NCOMP * TP; idx += 256) {  // zero the K padding rows
+    // zero the rows behind the chunk's last function up to KC: every chunk then takes all KS k-steps, without a branch.  (Guarded by
+    // `ks * 4 < nk4` every k-step was a basic block of its own and the accumulators changed register class at each of them: 16 v_accvgpr_write,
+    // the MFMAs, s_nop 15, 16 v_accvgpr_read per step — half the vector instructions of the value-only kernel.  The rows' B operands are the next
+    // chunk's coefficients or the zero rows behind the table: finite, times zero.)
+    // (Five components keep the guard: their 80 accumulator registers live in AGPRs throughout, and one basic block of 40 MFMAs lets the scheduler
+    // hoist all their LDS operands: 204 -> 260 registers.)
+    for (int idx = tid; idx < ((NCOMP == 1 ? KC : nk4) - nk) * NCOMP * TP; idx += 256) {
       const int rc = idx / TP;
       tile[rc % NCOMP][nk + rc / NCOMP][idx & (TP - 1)] = 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks * 4 < nk4) {
+      if (NCOMP == 1 || ks * 4 < nk4) {
         const int k = ks * 4 + kq;
         const int col = (TP >= 32) ? ((16 * ptile + i16) ^ ((k & 1) << 4)) : i16;
 #pragma unroll
@@ -1089,7 +1095,7 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
           if (NCOMP == 1 && rt_ >= 0) shell_eval_tab(sh_meta[sh][0], x, y, z, S.rtab + rt_, sh_meta[sh][5 % (NCOMP == 1 ? 6 : 4)], to_tile);  // radial_tab
           else shell_eval<NCOMP>(sh_meta[sh][0], x, y, z, pr_exp + q0, pr_coef + q0, sh_meta[sh][1], to_tile);
         }
-        for (int idx = tid; idx < (nk4 - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows (256 producer threads)
+        for (int idx = tid; idx < ((NCOMP == 1 ? KC : nk4) - nk) * NCOMP * 64; idx += 256) {  // zero the K padding rows; values only: up to KC (k_orb: branch-free k-steps); 256 producer threads
           const int rc = idx >> 6;
           tb[rc % NCOMP][nk + rc / NCOMP][idx & 63] = 0.0;
         }
@@ -1114,7 +1120,7 @@ static __global__ __launch_bounds__(512) void k_orb_ws(SysDev S, ChunkTab T, int
         const int nk4 = (T.chunk_nk[ch - 1] + 3) & ~3;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          if (ks * 4 < nk4) {
+          if (NCOMP == 1 || ks * 4 < nk4) {
             const int k = ks * 4 + kq;
             const int col = (16 * grp + i16) ^ ((k & 1) << 4);
 #pragma unroll
