@@ -965,16 +965,17 @@ static __global__ __launch_bounds__(256) void k_orb(SysDev S, ChunkTab T, int sp
     // `ks * 4 < nk4` every k-step was a basic block of its own and the accumulators changed register class at each of them: 16 v_accvgpr_write,
     // the MFMAs, s_nop 15, 16 v_accvgpr_read per step — half the vector instructions of the value-only kernel.  The rows' B operands are the next
     // chunk's coefficients or the zero rows behind the table: finite, times zero.)
-    // (Five components keep the guard: their 80 accumulator registers live in AGPRs throughout, and one basic block of 40 MFMAs lets the scheduler
+    // (The periodic value-only kernels keep the guard — with it removed k_orb<1, 2, 16, 64, true, 1> went from 399 to 480 us per launch of C5's
+    // T-move candidates — and so do five components: their 80 accumulator registers live in AGPRs throughout, and one basic block of 40 MFMAs lets the scheduler
     // hoist all their LDS operands: 204 -> 260 registers.)
-    for (int idx = tid; idx < ((NCOMP == 1 ? KC : nk4) - nk) * NCOMP * TP; idx += 256) {
+    for (int idx = tid; idx < (((NCOMP == 1 && PBC == 0) ? KC : nk4) - nk) * NCOMP * TP; idx += 256) {
       const int rc = idx / TP;
       tile[rc % NCOMP][nk + rc / NCOMP][idx & (TP - 1)] = 0.0;
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (NCOMP == 1 || ks * 4 < nk4) {
+      if ((NCOMP == 1 && PBC == 0) || ks * 4 < nk4) {
         const int k = ks * 4 + kq;
         const int col = (TP >= 32) ? ((16 * ptile + i16) ^ ((k & 1) << 4)) : i16;
 #pragma unroll

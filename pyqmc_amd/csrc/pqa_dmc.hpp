@@ -14,6 +14,7 @@
 #pragma once
 #include "pqa_energy.hpp"
 #include "pqa_vmc.hpp"
+#include "pqa_lw.hpp"  // jas_eval_lane (tm_ratio_part)
 
 #define PQA_STREAM_TMMASK 6u
 #define PQA_STREAM_TM_U1 7u
@@ -295,6 +296,27 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
   return ratio;
 }
 
+// Share c of ngrp of a candidate's sums (k_tm_walker after a walker's first accepted T-move: lanes = (candidate, share), the shares added by
+// shuffles): orbital slots k = c, c + ngrp, ... of the determinant dot, partners j and ions I = c, c + ngrp, ... of the Jastrow exponent at the
+// candidate (jas_eval_lane on the walker-major coordinates: function tables in registers, coordinates four partners ahead).
+__device__ __forceinline__ void tm_ratio_part(const SysDev& S, const SlaterState& st, const JastrowState& js, const TmBuf& B, int s, int e, long w, long p,
+                                              const double* __restrict__ row, int c, int ngrp, int has_slater, int has_jastrow, double& rpart,
+                                              double& upart) {
+  const int n = s ? S.ndn : S.nup, i = e - s * S.nup;
+  rpart = 0.0; upart = 0.0;
+  if (has_slater) {
+    const double* Ti = st.T[s] + ((size_t)w * n + i) * n;
+    const int* occ = S.det_occ[s];
+    double r = 0.0;
+    for (int k = c; k < n; k += ngrp) r += row[occ[k]] * Ti[k];
+    rpart = r;
+  }
+  if (has_jastrow) {
+    double g_[3], lp_, ee_, ei_;
+    jas_eval_lane<0, true>(S, js.x + (size_t)w * S.nelec * 3, 1L, 0L, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], 1, c, ngrp, upart, g_, lp_, ee_, ei_);
+  }
+}
+
 // U_e at the CURRENT position of every (electron, walker) that has candidates: -log of the denominator all of its candidates
 // share (computed once here instead of once per candidate).  uold: [N][W].  grid = (ceil(W/256), N), block = 256.
 template <int PQA_UNIT = 0>  // (a template so that only the units that launch it compile it)
@@ -410,6 +432,24 @@ static __global__ __launch_bounds__(64) void k_tm_walker(SysDev S, SlaterState s
     double my_rat = 1.0, my_amp = 0.0, my_wgt = 0.0;
     if (fast) {
       if (lane < n) { my_rat = B.rat[p0 + lane]; my_amp = B.amp[p0 + lane]; my_wgt = B.wgt[p0 + lane]; }
+    } else if (!CX && precomputed && n <= 64) {
+      // the walker has accepted a T-move: the ratios of k_tm_ratio are stale.  All of this electron's candidates at once, lanes = (candidate,
+      // share of its sums) — one candidate after the other on the whole wave (the loop below: two wave reductions and a dependent chain per
+      // candidate) made the walkers with accepted T-moves the tail of the launch, 710 us against 114 for the others
+      int ngrp = 1, lg = 0;
+      while (ngrp * 2 * n <= 64) { ngrp *= 2; ++lg; }
+      const int q = lane >> lg, c = lane & (ngrp - 1);
+      const long p = p0 + (q < n ? q : 0);
+      double rpart, upart;
+      tm_ratio_part(S, st, js, B, s, e, w, p, mo + (size_t)(p - p_base) * nmo, c, ngrp, has_slater, has_jastrow, rpart, upart);
+      for (int o = 1; o < ngrp; o <<= 1) { rpart += __shfl_xor(rpart, o, 64); upart += __shfl_xor(upart, o, 64); }
+      double rat = has_slater ? rpart : 1.0;
+      if (has_jastrow) rat *= exp(upart - U0);
+      const double ratq = __shfl(rat, (lane < n ? lane : 0) << lg, 64);  // candidate q's ratio to lane q
+      if (lane < n) {
+        my_rat = ratq; my_wgt = B.wgt[p0 + lane]; my_amp = ratq * my_wgt;
+        B.rat[p0 + lane] = ratq; B.amp[p0 + lane] = my_amp;
+      }
     } else
     for (long p = p0; p < p1; ++p) {
       double rat = 1.0;

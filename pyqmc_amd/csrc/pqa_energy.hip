@@ -29,11 +29,15 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     // the side stream, and has the rest of the evaluation enqueued before the device gets there (the read-back was an idle gap of ~50 us)
     if (h->necp > 0 && h->ecpb_on == 0 && h->en_overlap && (W <= 16384 || h->en_overlap > 1) && !will_defer) TRY(side_begin());  // (PQA_EN_OVERLAP=2: at every size, A/B)
     const dim3 gk((unsigned)((((W + 63) / 64 + 7) / 8) * 8 * ((h->N + PQA_KIN_EB - 1) / PQA_KIN_EB))), bk(64, PQA_KIN_EB);  // see k_kinetic_lw
+    const bool kin_quad = W >= 16384 && (W & 3) == 0;  // quad-cooperative row reads (k_kinetic_lw): large shards
     if (h->cplx) {
       if (h->S.pbc) hipLaunchKernelGGL((k_kinetic_lw<true, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
       else hipLaunchKernelGGL((k_kinetic_lw<false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     } else if (h->S.pbc)
-      hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+      { if (kin_quad) hipLaunchKernelGGL((k_kinetic_lw<true, false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
+        else hipLaunchKernelGGL(k_kinetic_lw<true>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p); }
+    else if (kin_quad)
+      hipLaunchKernelGGL((k_kinetic_lw<false, false, true>), gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     else
       hipLaunchKernelGGL(k_kinetic_lw<false>, gk, bk, 0, h->stream, h->S, lw_state(h), (int)h->has_jastrow, W, (double*)h->b_kpart.p);
     hipLaunchKernelGGL((k_kinetic_reduce<>), dim3((unsigned)((W + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->b_kpart.p,

@@ -1361,14 +1361,16 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 // row) to 5.8 TB/s (a quad per line), the inverse planes alone at 5.8 TB/s — 1.1 ms for both — but read in the same kernel, even by different
 // blocks, the two streams take 1.5-1.9 ms (tile-blocked inverse: 1.55): the mix, not either pattern, costs the bandwidth.  The coordinate walk
 // of the Jastrow / Coulomb sums (96 KB per wave out of L2) adds 0.28 ms on top although its arithmetic is 0.07 ms.  PQA_KIN_V: 1 = a lane
-// streams its own row (1.86 ms), 3 = quad-cooperative lines (1.79 ms, default), 4 = V1 with half a component requested ahead (1.84 ms).
+// streams its own row (1.86 ms), 3 = quad-cooperative lines in the QUAD instantiation (1.79 ms, default; shards below 16 384 walkers take the
+// other one: 163 against 121 registers, and 4 096 walkers are one round of waves only at four per SIMD — 195 vs 231 us for C5), 4 = V1 with
+// half a component requested ahead (1.84 ms).
 #ifndef PQA_KIN_EB
 #define PQA_KIN_EB 1
 #endif
 #ifndef PQA_KIN_V
 #define PQA_KIN_V 3
 #endif
-template <bool PBC, bool CX = false>
+template <bool PBC, bool CX = false, bool QUAD = false>  // QUAD: quad-cooperative row reads (large shards; real determinants, W % 4 == 0)
 static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   // Block b -> (walker group, electron block): the electron blocks of ONE walker group sit 8 apart in the linear block order, so
   // they land on the same XCD (blocks go to the XCDs round-robin) and run at about the same time: the group's coordinates, which
@@ -1393,14 +1395,14 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
       // ground-state occupation: whole 64-byte lines of the lane's own row, two adjacent 32-byte loads each, used up at once
       // (walking 4 slots of all five components first left every line half used until the next round: 320 lines per wave in
       // flight, more than L1 keeps with 16 waves per CU — the kernel took 3.5 ms instead of 1.9)
-#if PQA_KIN_V == 3
+#if PQA_KIN_V == 3 || PQA_KIN_V == 1
       // Quad-cooperative rows: the four lanes of a quad (walkers wq .. wq + 3) read the row of each of the four walkers together, 16 bytes per
       // lane = one whole 64-byte line per quad and instruction, 16 lines per wave-instruction.  (A lane streaming its own row touches a line of
       // its own per load: 64 lines per instruction, and the address path — one line per cycle and CU — not HBM set the kernel's time: 3.7 TB/s.)
       // Lane q of the quad holds orbital slots j + 2q, j + 2q + 1 of each 8-slot line, so it takes those two slots of the inverse row of ALL four
       // walkers (two 32-byte loads of T[slot][wq .. wq + 3]) and accumulates its share of all four walkers' sums; the quad adds the shares at the
       // end (DPP) and lane q keeps walker wq + q's.
-      if (n <= 32 && (W & 3) == 0) {
+      if (QUAD && PQA_KIN_V == 3 && n <= 32 && (W & 3) == 0) {
         const int q = (int)threadIdx.x & 3;
         const long wq = w - q;
         const uint32_t s4 = *reinterpret_cast<const uint32_t*>(L.sel[s] + (size_t)i * W + wq);
@@ -1441,7 +1443,8 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
           r[c] = mine;
         }
       } else
-#elif PQA_KIN_V == 4
+#endif
+#if PQA_KIN_V == 4
       // component-major, a whole component (n doubles = n / 8 lines of the lane's own row) requested before the previous component's products:
       // 256 bytes per lane in flight all the time (the compiler's own schedule of V == 1 waits for every line before it asks for the next:
       // one 64-byte line per lane in flight, 3.7 TB/s)
@@ -1474,7 +1477,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
 #undef PQA_KIN_DOT
 #undef PQA_KIN_SB
       } else
-#elif PQA_KIN_V == 1  // component-major: the lane streams its row front to back (adjacent lines back to back), inverse row in registers
+#elif PQA_KIN_V == 1 || PQA_KIN_V == 3  // component-major: the lane streams its row front to back (adjacent lines back to back), inverse row in registers
       if (n <= 32) {
         double t[32];
 #pragma unroll
