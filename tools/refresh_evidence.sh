@@ -77,5 +77,11 @@ if [ -f $R/pyqmc_amd/lib/libpqa_RCLK.so ]; then for w in 2048 4096 16384; do PQA
 [ -x $R/tools/scratch/bin/mfma_probe ] || (mkdir -p $R/tools/scratch/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/scratch/mfma_probe.hip -o $R/tools/scratch/bin/mfma_probe 2>/dev/null)
 timeout 120 $R/tools/scratch/bin/mfma_probe > $O/mfma_probe.txt 2>&1
 python $R/bench.py --scaling strong --walkers $W --no-cpu-baseline --no-extra > $O/bench_strong_n1.json 2>> $O/bench.err < /dev/null
+# round 6, energy pass: what the row cache and the inverse planes stream at alone and mixed (k_kinetic_lw's bound); SQ counters of the headline step
+# and of the C5 DMC step (instruction counts, pipe busy, where the waves wait)
+[ -x $R/tools/scratch/bin/row_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/scratch/row_probe.hip -o $R/tools/scratch/bin/row_probe 2>/dev/null
+timeout 120 $R/tools/scratch/bin/row_probe > $O/row_probe.txt 2>&1
+timeout 600 bash $R/tools/scratch/r6_sq.sh > /dev/null 2>&1; cp $R/gpurun_out/r6_sq/sq.txt $O/sq_counters.txt 2>/dev/null
+timeout 600 bash $R/tools/scratch/r6_sq_dmc.sh > /dev/null 2>&1; cp $R/gpurun_out/r6_sq_dmc/sq.txt $O/sq_counters_dmc.txt 2>/dev/null
 cp $R/gpurun_out/parity_report.json $R/gpurun_out/parity_report_fullsize.json $O/ 2>/dev/null
 ls -la $O
