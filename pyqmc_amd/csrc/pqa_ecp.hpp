@@ -363,7 +363,10 @@ static __global__ __launch_bounds__(256) void k_ecp_point_lw(SysDev S, LwState L
   }
   if (has_jastrow) {
     double U, g[3], lp, ee, ei;
-    jas_eval_lane<0, PBC>(S, L.xt, W, w, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], 1, 0, 1, U, g, lp, ee, ei);
+    // every point of this launch (grid row) belongs to an electron of spin s: the merged Pade records are picked by scalar selects although the
+    // electron differs between lanes (jas_eval_lane_m ELANE: a third fewer instructions per pair than the function-by-function route)
+    if (S.jq_on) jas_eval_lane_m<0, PBC, true, true>(S, L.xt, W, w, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], 1, 0, 1, U, g, lp, ee, ei, -1, true);
+    else jas_eval_lane<0, PBC>(S, L.xt, W, w, e, B.pts[s][3 * p], B.pts[s][3 * p + 1], B.pts[s][3 * p + 2], 1, 0, 1, U, g, lp, ee, ei);
     const double ej = exp(U - B.u0[s][p]);  // U_e(new) - U_e(old); the old-position sum comes from the fill pass
     ratio *= ej; ratio_im *= ej;
   }

@@ -204,15 +204,17 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 // UNI = false: electron and partner index may differ between lanes (the narrow step kernel, the ECP passes): the same code with
 // per-lane table reads — taken only where the FAST route does not apply (more than PQA_JAS_NF functions in a basis, i.e. the
 // ion-cusp function of all-electron atoms next to four Pade functions), instead of the table walk in the innermost loop.
-template <int MODE, bool PBC, bool UNI = true>
+// ELANE (with UNI): the electron differs between the lanes of a wave but its SPIN does not (the thread-per-point ECP kernel: one launch, or one
+// grid row, per spin channel) — the records are still picked with scalar selects, only the j == e test is per lane.
+template <int MODE, bool PBC, bool UNI = true, bool ELANE = false>
 __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                                 double (&g)[3], double& lapU, double& ee, double& ei, int skip, bool ions) {
   if (UNI) {
     j0 = __builtin_amdgcn_readfirstlane(j0); dj = __builtin_amdgcn_readfirstlane(dj); skip = __builtin_amdgcn_readfirstlane(skip);
-    e = __builtin_amdgcn_readfirstlane(e);  // UJ callers: the electron is wave-uniform too (kernel argument / block index)
+    if (!ELANE) e = __builtin_amdgcn_readfirstlane(e);  // UJ callers: the electron is wave-uniform too (kernel argument / block index)
   }
-  const int edown = e >= S.nup;
+  const int edown = (UNI && ELANE) ? __builtin_amdgcn_readfirstlane((int)(e >= S.nup)) : (int)(e >= S.nup);
   const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
   double u_ = 0.0, gx = 0.0, gy = 0.0, gz = 0.0, lp = 0.0, see = 0.0, sei = 0.0;
   const bool jb_on = has_jastrow && S.nb > 0, ja_on = has_jastrow && S.na > 0;
