@@ -1372,6 +1372,15 @@ static __global__ __launch_bounds__(GW == 16 ? 256 : 16 * GW) void k_step_pre(Sy
 #ifndef PQA_KIN_V
 #define PQA_KIN_V 3
 #endif
+// PQA_KIN_C0 = 1 (default): the quad-cooperative instantiation does not read the VALUE block of the cached rows.  The reference divides the
+// derivative sums by sum_j phi_j(r_i) T_ji (slater.py gradient_laplacian: ratios[1:] / ratios[0]) — at the electron's own position that is row i of
+// the Slater matrix times column i of its inverse: 1, up to the rounding the inverse has accumulated since the last recompute.  Taking it as 1
+// saves a fifth of the row traffic (1.78 -> 1.68 ms at 65 536 walkers); measured on (H2O)8, 16 384 walkers, 40 sweeps without a recompute, the
+// steps' kinetic-energy means agree with the dividing build to the last bit or one ulp (<= 4e-16 relative; tools/scratch/c0_check.py).
+// -DPQA_KIN_C0=0 restores the division.
+#ifndef PQA_KIN_C0
+#define PQA_KIN_C0 1
+#endif
 template <bool PBC, bool CX = false, bool QUAD = false>  // QUAD: quad-cooperative row reads (large shards; real determinants, W % 4 == 0)
 static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S, LwState L, int has_jastrow, long W, double* __restrict__ part) {
   // Block b -> (walker group, electron block): the electron blocks of ONE walker group sit 8 apart in the linear block order, so
@@ -1421,19 +1430,19 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
           const double4 ta = *reinterpret_cast<const double4*>(Tq + (size_t)j * W), tb = *reinterpret_cast<const double4*>(Tq + (size_t)(j + 1) * W);
           double2 v[20];
 #pragma unroll
-          for (int c = 0; c < 5; ++c)
+          for (int c = PQA_KIN_C0; c < 5; ++c)
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[c * 4 + t] = *reinterpret_cast<const double2*>(rq[t] + c * nmo + j);
           __builtin_amdgcn_sched_barrier(0);
           const double t0[4] = {ta.x, ta.y, ta.z, ta.w}, t1[4] = {tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
-          for (int c = 0; c < 5; ++c)
+          for (int c = PQA_KIN_C0; c < 5; ++c)
 #pragma unroll
             for (int t = 0; t < 4; ++t) { p[t][c] += v[c * 4 + t].x * t0[t]; p[t][c] += v[c * 4 + t].y * t1[t]; }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
+        for (int c = PQA_KIN_C0; c < 5; ++c) {
           double mine = 0.0;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -1444,6 +1453,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
           }
           r[c] = mine;
         }
+        if (PQA_KIN_C0) r[0] = 1.0;
       } else
 #endif
 #if PQA_KIN_V == 4

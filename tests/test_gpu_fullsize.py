@@ -467,6 +467,33 @@ def test_energy_statistics_against_the_oracle():
     assert abs(e_dev - e_orc) < 3.0 * comb and abs(e_dev - e_orc) < 1e-3, (e_dev, e_orc, comb)
 
 
+@pytest.mark.parametrize("W", [16384, 65536])
+def test_fused_energy_pass_of_large_shards(W):
+    """Shards of 16 384 walkers and more take k_kinetic_lw's quad-cooperative instantiation, which does not read the value block
+    of the cached rows (the determinant row times its own inverse column is 1; the reference divides by it, slater.py
+    gradient_laplacian).  After sweeps without a recompute: the fused pass's walker means of ke, ee, ei, |grad|^2 against the
+    standalone evaluation of the same ensemble (pqa_energy: the walker-major kernels, which do divide), and the standalone per-walker
+    rows of the first walkers against the oracle's energy accumulator on the same configurations."""
+    import pyqmc_amd as pa
+    from oracle import energy as oen
+
+    mol, wf, owf_builder, _ = build("M")
+    dev = wf.fused_device()
+    wf.recompute(pa.initial_guess(mol, W, rng=np.random.default_rng(77)))
+    acc, en, _ = dev.vmc_sweeps(0.3, 6, seed=5, energy=True)
+    rows = np.asarray(dev.energy(10.0, seed=9))  # [6][W]: ke, ee, ei, ecp, grad2, total
+    for name, r in (("ke", 0), ("ee", 1), ("ei", 2), ("grad2", 4)):
+        a, b = float(en[-1][r]), float(rows[r].mean())
+        assert note(f"M_{W}_fused_vs_standalone_{name}_mean", abs(a - b) / abs(b)) < 1e-12, (name, a, b)
+    x = dev.configs()[:NCHECK]
+    owf = owf_builder()
+    owf.recompute(OpenConfigs(x.copy()))
+    ref = oen.kinetic(OpenConfigs(x.copy()), owf)
+    ke_ref, g2_ref = np.asarray(ref[0]), np.asarray(ref[1])
+    assert note(f"M_{W}_standalone_vs_oracle_ke", float(np.max(np.abs(rows[0][:NCHECK] - ke_ref) / np.abs(ke_ref)))) < 1e-9
+    assert note(f"M_{W}_standalone_vs_oracle_grad2", float(np.max(np.abs(rows[4][:NCHECK] - g2_ref) / np.abs(g2_ref)))) < 1e-9
+
+
 @pytest.mark.parametrize("cfg,W", [("M", 4096), ("M", 1000), ("C5", 4096)])
 def test_prefetching_step_kernel_against_the_general_one(cfg, W, monkeypatch):
     """Shards of at most 4096 walkers run k_step_pre (all loads of a move's decide / propose launch issued at entry, the next
