@@ -146,6 +146,9 @@ __device__ __forceinline__ void r8_combine(const double* __restrict__ pb, int PS
   }
 }
 
+#ifndef PQA_R8_UNIT0
+#define PQA_R8_UNIT0 1  // the value sum at an electron's own position taken as 1 (see the next-proposal drift below)
+#endif
 // grid = ceil((w_hi - w_lo) / 8) blocks of 256 threads, two per CU (256 registers per thread, dynamic LDS <= 80 KB).
 // timing builds: the phase stamps of a move in the MIDDLE of the second spin's sweep (the last move has no next electron: half the Jastrow
 // work, no prefetch)
@@ -293,7 +296,7 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         if (i + 1 < n) {
           const int slot = __shfl(selr, (lane & 32) | (i + 1), 64);
           const double* row = rcs + (((size_t)(i + 1) * 2 + slot) * W + wg) * 5 * nmo;
-          if (r < n) { ro[0] = row[oc]; ro[1] = row[nmo + oc]; ro[2] = row[2 * nmo + oc]; ro[3] = row[3 * nmo + oc]; }
+          if (r < n) { if (!PQA_R8_UNIT0) ro[0] = row[oc]; ro[1] = row[nmo + oc]; ro[2] = row[2 * nmo + oc]; ro[3] = row[3 * nmo + oc]; }
           const double* zt = mb.gauss + ((size_t)(e + 1) * W + wg) * 3;
           g0 = zt[0]; g1 = zt[1]; g2 = zt[2];
         }
@@ -567,10 +570,19 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
         double gx, gy, gz;
         {
           const double te = rowE[wl * 32 + r];
-          double q0 = ro[0] * te, q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
-          q0 = res_sum32(q0); q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
-          const double iq0 = 1.0 / q0;
-          gx = finite_or(q1 * iq0, 0.0); gy = finite_or(q2 * iq0, 0.0); gz = finite_or(q3 * iq0, 0.0);
+          double q1 = ro[1] * te, q2 = ro[2] * te, q3 = ro[3] * te;
+          q1 = res_sum32(q1); q2 = res_sum32(q2); q3 = res_sum32(q3);
+          if (PQA_R8_UNIT0) {
+            // The reference divides the gradient sums by the value sum (slater.py gradient: ratios[1:] / ratios[0]), which at the electron's own
+            // position is row e of the Slater matrix times column e of its inverse: 1 up to the rounding of the inverse.  Taken as 1: one load,
+            // one 32-lane sum and a division less per move (-DPQA_R8_UNIT0=0 restores them; the drift changes by that rounding, ~1e-13 relative).
+            gx = finite_or(q1, 0.0); gy = finite_or(q2, 0.0); gz = finite_or(q3, 0.0);
+          } else {
+            double q0 = ro[0] * te;
+            q0 = res_sum32(q0);
+            const double iq0 = 1.0 / q0;
+            gx = finite_or(q1 * iq0, 0.0); gy = finite_or(q2 * iq0, 0.0); gz = finite_or(q3 * iq0, 0.0);
+          }
         }
         const int src = (lane & 32) | ip;
         const double pox = __shfl(s ? cx[1] : cx[0], src, 64), poy = __shfl(s ? cy[1] : cy[0], src, 64), poz = __shfl(s ? cz[1] : cz[0], src, 64);
