@@ -237,6 +237,12 @@ __device__ __forceinline__ double quad_dpp(double v) {
 #ifndef PQA_WSYNC
 #define PQA_WSYNC() __syncthreads()
 #endif
+// The headers whose device functions contain PQA_WSYNC (pqa_slater.hpp, pqa_jastrow.hpp) put them into an inline namespace named after the
+// flavour, so that the two bodies of e.g. sm_update_wave are two different entities (no one-definition-rule hazard if the units were ever
+// linked with relocatable device code): a unit that redefines PQA_WSYNC also defines PQA_SYNC_NS.
+#ifndef PQA_SYNC_NS
+#define PQA_SYNC_NS pqa_sync_block
+#endif
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add<0x111, 0xf>(v);  // row_shr:1   inclusive scan inside each row of 16 lanes
   v = dpp_add<0x112, 0xf>(v);  // row_shr:2

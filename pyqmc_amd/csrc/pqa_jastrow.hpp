@@ -13,6 +13,7 @@
 // state to stream), and only the reference's public sums _avalues/_bvalues are maintained.
 #pragma once
 #include "pqa_common.hpp"
+inline namespace PQA_SYNC_NS {  // (PQA_WSYNC flavour: pqa_common.hpp)
 
 struct JastrowState {
   double* x;        // [W][N][3] walker coordinates (the reference's _configscurrent)
@@ -636,3 +637,4 @@ static __global__ __launch_bounds__(64) void k_j3_pgrad(SysDev S, JastrowState j
     out[(size_t)w * E + idx] = acc;
   }
 }
+}  // inline namespace PQA_SYNC_NS

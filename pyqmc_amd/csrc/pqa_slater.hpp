@@ -12,6 +12,7 @@
 #pragma once
 #include <float.h>
 #include "pqa_common.hpp"
+inline namespace PQA_SYNC_NS {  // (PQA_WSYNC flavour: pqa_common.hpp)
 
 struct SlaterState {
   double* T[2];      // [W][ndet_s][n_s][n_s]
@@ -492,3 +493,4 @@ static __global__ __launch_bounds__(256) void k_pgrad_mo(SysDev S, SlaterState s
     out[((size_t)w * nao + a) * nmo + m] = acc;
   }
 }
+}  // inline namespace PQA_SYNC_NS

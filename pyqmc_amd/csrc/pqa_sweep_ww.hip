@@ -2,6 +2,7 @@
 // Its three waves run different device functions of one move side by side, so the synchronisation INSIDE those functions (PQA_WSYNC,
 // pqa_common.hpp) is the wave-level fence here: LDS operations of a wave execute in order, the fence keeps the compiler from moving them.
 #define PQA_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define PQA_SYNC_NS pqa_sync_wave
 #include "pqa_internal.hpp"
 #include "pqa_ww.hpp"
 
