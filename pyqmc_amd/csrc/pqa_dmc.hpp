@@ -245,52 +245,12 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
     ratio = r;
   }
   if (has_jastrow) {
+    // the partner / ion sums by jas_eval_lane on the walker-major coordinates (function tables in registers, coordinates several partners
+    // ahead; the same terms in the same order as the plain loops this replaced, which read every table entry inside the pair loop)
     const double* xw = js.x + (size_t)w * S.nelec * 3;
-    const double nx = B.pts[3 * p], ny = B.pts[3 * p + 1], nz = B.pts[3 * p + 2];
-    const double ox = xw[3 * e], oy = xw[3 * e + 1], oz = xw[3 * e + 2];
-    const int edown = e >= S.nup;
-    const double irb = 1.0 / S.rcut_b, ira = 1.0 / S.rcut_a;
-    auto norm = [&](double dx, double dy, double dz) {
-      min_image_j(S, dx, dy, dz);
-      return sqrt(dx * dx + dy * dy + dz * dz);
-    };
-    auto u_b = [&](double rn, int col) {
-      double u = 0.0;
-      if (rn < S.rcut_b) {
-        const RadShared sh = rad_shared<0>(rn, irb);
-        for (int l = 0; l < S.nb; ++l) {
-          double v, g, lp;
-          rad_fn<0>(S.b_kind[l], S.b_param[l], S.b_aux[l], S.rcut_b, sh, v, g, lp);
-          u += S.bcoeff[l * 3 + col] * v;
-        }
-      }
-      return u;
-    };
-    auto u_a = [&](double rn, int I) {
-      double u = 0.0;
-      if (rn < S.rcut_a) {
-        const RadShared sh = rad_shared<0>(rn, ira);
-        for (int k = 0; k < S.na; ++k) {
-          double v, g, lp;
-          rad_fn<0>(S.a_kind[k], S.a_param[k], S.a_aux[k], S.rcut_a, sh, v, g, lp);
-          u += S.acoeff[(I * S.na + k) * 2 + edown] * v;
-        }
-      }
-      return u;
-    };
-    double un = 0.0, uo = 0.0;
-    for (int j = 0; j < S.nelec; ++j) {
-      if (j == e) continue;
-      const double jx = xw[3 * j], jy = xw[3 * j + 1], jz = xw[3 * j + 2];
-      const int col = edown + (j >= S.nup);
-      un += u_b(norm(nx - jx, ny - jy, nz - jz), col);
-      if (!have_uold) uo += u_b(norm(ox - jx, oy - jy, oz - jz), col);
-    }
-    for (int I = 0; I < S.natom; ++I) {
-      const double ax = S.atom_xyz[3 * I], ay = S.atom_xyz[3 * I + 1], az = S.atom_xyz[3 * I + 2];
-      un += u_a(norm(nx - ax, ny - ay, nz - az), I);
-      if (!have_uold) uo += u_a(norm(ox - ax, oy - ay, oz - az), I);
-    }
+    double un = 0.0, uo = 0.0, g_[3], lp_, ee_, ei_;
+    jas_eval_lane<0, true>(S, xw, 1L, 0L, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], 1, 0, 1, un, g_, lp_, ee_, ei_);
+    if (!have_uold) jas_eval_lane<0, true>(S, xw, 1L, 0L, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], 1, 0, 1, uo, g_, lp_, ee_, ei_);
     ratio *= exp(un - (have_uold ? u_old : uo));
   }
   return ratio;

@@ -91,7 +91,7 @@ static __global__ __launch_bounds__(256) void k_cache_from_rc(const double* __re
 // the two coefficient columns electron e can meet) are read ONCE into scalar registers.  Indexed by the loop variable they
 // were scalar loads inside the innermost loop — two dependent load-and-wait pairs per function and pair, ~90 per thread —
 // and with four waves per SIMD those waits, not the arithmetic, set the kernel's time.  Same operations in the same order.
-template <int MODE, bool PBC, bool FAST>
+template <int MODE, bool PBC, bool FAST, int PF = PQA_JAS_PF>
 __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                                 double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
@@ -110,17 +110,17 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
       bc1[l] = (has_jastrow && l < S.nb) ? S.bcoeff[l * 3 + edown + 1] : 0.0;
     }
   }
-  // The partners' coordinates are fetched PQA_JAS_PF at a time before any of them is used.
-  for (int jb = j0; jb < S.nelec; jb += PQA_JAS_PF * dj) {
-    double cx[PQA_JAS_PF], cy[PQA_JAS_PF], cz[PQA_JAS_PF];
+  // The partners' coordinates are fetched PF at a time before any of them is used.
+  for (int jb = j0; jb < S.nelec; jb += PF * dj) {
+    double cx[PF], cy[PF], cz[PF];
 #pragma unroll
-    for (int u = 0; u < PQA_JAS_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int j = jb + u * dj;
       const double* xj = xt + (size_t)(j < S.nelec ? j : e) * 3 * W + w;  // past the end: any valid address, never used
       cx[u] = xj[0]; cy[u] = xj[W]; cz[u] = xj[2 * W];
     }
 #pragma unroll
-    for (int u = 0; u < PQA_JAS_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int j = jb + u * dj;
       if (j >= S.nelec || j == e || j == skip) continue;
       double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void jas_eval_lane_t(const SysDev& S, const double* x
 // ion-cusp function of all-electron atoms next to four Pade functions), instead of the table walk in the innermost loop.
 // ELANE (with UNI): the electron differs between the lanes of a wave but its SPIN does not (the thread-per-point ECP kernel: one launch, or one
 // grid row, per spin channel) — the records are still picked with scalar selects, only the j == e test is per lane.
-template <int MODE, bool PBC, bool UNI = true, bool ELANE = false>
+template <int MODE, bool PBC, bool UNI = true, bool ELANE = false, int PF = PQA_JAS_PF>
 __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* xt, long W, long w, int e,
                                                 double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                                 double (&g)[3], double& lapU, double& ee, double& ei, int skip, bool ions) {
@@ -226,16 +226,16 @@ __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* x
 #pragma unroll
   for (int i = 0; i < 5; ++i) { Db[i] = S.b_D[i]; Da[i] = S.a_D[i]; }
   const bool kb4 = S.jq_b > 3, ka4 = S.jq_a > 3;
-  for (int jb = j0; jb < S.nelec; jb += PQA_JAS_PF * dj) {
-    double cx[PQA_JAS_PF], cy[PQA_JAS_PF], cz[PQA_JAS_PF];
+  for (int jb = j0; jb < S.nelec; jb += PF * dj) {
+    double cx[PF], cy[PF], cz[PF];
 #pragma unroll
-    for (int u = 0; u < PQA_JAS_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int j = jb + u * dj;
       const double* xj = xt + (size_t)(j < S.nelec ? j : e) * 3 * W + w;
       cx[u] = xj[0]; cy[u] = xj[W]; cz[u] = xj[2 * W];
     }
 #pragma unroll
-    for (int u = 0; u < PQA_JAS_PF; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int j = jb + u * dj;
       if (j >= S.nelec || j == e || j == skip) continue;
       double dx = rx - cx[u], dy = ry - cy[u], dz = rz - cz[u];
@@ -289,15 +289,17 @@ __device__ __forceinline__ void jas_eval_lane_m(const SysDev& S, const double* x
   }
   U = u_; g[0] = gx; g[1] = gy; g[2] = gz; lapU = lp; ee = see; ei = sei;
 }
-template <int MODE, bool PBC, bool UJ = false>
+// PF: partners whose coordinates are requested ahead (4; the kinetic pass of large shards, whose walk comes out of L2, takes 8: 1.68 -> 1.60 ms at
+// 65 536 walkers — at the price of 17 registers, a resident wave the small shards need: 195 -> 211 us at 4 096 walkers of C5)
+template <int MODE, bool PBC, bool UJ = false, int PF = PQA_JAS_PF>
 __device__ __forceinline__ void jas_eval_lane(const SysDev& S, const double* xt, long W, long w, int e,
                                               double rx, double ry, double rz, int has_jastrow, int j0, int dj, double& U,
                                               double (&g)[3], double& lapU, double& ee, double& ei, int skip = -1, bool ions = true) {
   const bool fast = S.nb <= PQA_JAS_NF && S.na <= PQA_JAS_NF;
-  if (UJ && S.jq_on) jas_eval_lane_m<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
-  else if (!UJ && S.jq_on && !fast) jas_eval_lane_m<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
-  else if (fast) jas_eval_lane_t<MODE, PBC, true>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
-  else jas_eval_lane_t<MODE, PBC, false>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  if (UJ && S.jq_on) jas_eval_lane_m<MODE, PBC, true, false, PF>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else if (!UJ && S.jq_on && !fast) jas_eval_lane_m<MODE, PBC, false, false, PF>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else if (fast) jas_eval_lane_t<MODE, PBC, true, PF>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
+  else jas_eval_lane_t<MODE, PBC, false, PF>(S, xt, W, w, e, rx, ry, rz, has_jastrow, j0, dj, U, g, lapU, ee, ei, skip, ions);
 }
 // Jastrow part of group g's partial sums of electron e at (px, py, pz): value and gradient over the partners j = g, g + G, ...
 // and the ions I = g, g + G, ...  `skip` (>= 0): the pair with electron `skip` is left out of the strided sum and ADDED LAST by
@@ -1598,7 +1600,7 @@ static __global__ __launch_bounds__(64 * PQA_KIN_EB) void k_kinetic_lw(SysDev S,
   }
   const double* xe = L.xt + (size_t)e * 3 * W + w;
   double U, gj[3], lj, ee, ei;
-  jas_eval_lane<2, PBC, true>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
+  jas_eval_lane<2, PBC, true, QUAD ? 8 : PQA_JAS_PF>(S, L.xt, W, w, e, xe[0], xe[W], xe[2 * W], has_jastrow, 0, 1, U, gj, lj, ee, ei);
   lj += gj[0] * gj[0] + gj[1] * gj[1] + gj[2] * gj[2];
   const double gx = gs0 + gj[0], gy = gs1 + gj[1], gz = gs2 + gj[2];
   const double lap = ls + lj + 2.0 * (gs0 * gj[0] + gs1 * gj[1] + gs2 * gj[2]);
