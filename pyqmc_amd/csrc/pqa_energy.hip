@@ -5,6 +5,8 @@
 int energy_dev(pqa_handle* h, double threshold, const double* rot, const double* unif, uint64_t seed, uint32_t step,
                bool soa_current, bool aos_T_needed, bool assemble) {
   const long W = h->W;
+  struct JsxOnce { pqa_handle* h; ~JsxOnce() { h->jsx_current = false; } } jsx_once{h};  // (valid for the evaluation that follows the sweep only)
+  if (!soa_current) h->jsx_current = false;
   bool soa_T = false;
   struct Side { pqa_handle* h = nullptr; hipStream_t main = nullptr; ~Side() { if (h) h->stream = main; } } side;  // (launches go to h->stream: restored on every exit)
   bool side_join = false;
@@ -49,7 +51,9 @@ int energy_dev(pqa_handle* h, double threshold, const double* rot, const double*
     if (h->necp > 0) {
       hipStream_t cur = h->stream;
       if (side.h) h->stream = side.main;  // (the ECP passes' input: in their stream)
-      if (soa_T) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }
+      if (soa_T) {
+        if (!h->jsx_current) { transpose(h, (const double*)h->b_xt.p, h->js.x, (long)h->N * 3, W); TRY(check_launch(h, "k_transpose")); }  // (else: k_sweep_r8 wrote them)
+      }
       else TRY(lw_to_aos(h, false));
       if (side.h) {  // the Ewald pass (side stream) reads the walker-major coordinates too
         HIPCHK(hipEventRecord(h->en_ev[2], h->stream));

@@ -188,6 +188,8 @@ struct pqa_handle {
   R8Tab r8_tab{};
   size_t r8_lds = 0;
   double r8_util = 0.0;
+  bool r8_xaos_next = false;  // the next k_sweep_r8 launch also writes the walker-major coordinates (js.x)
+  bool jsx_current = false;   // ... and did: energy_dev skips its transpose of the coordinate planes
   int res_pbc = 1;  // PQA_RES_PBC=0: periodic handles keep the launch-per-move sweep (A/B)
   int res_cx = 1;   // PQA_RES_CX=0: complex determinants keep the launch-per-move sweep (A/B)
   // wave-per-walker sweep in one launch (pqa_ww.hpp; PQA_WW): -1 by shard size (one wave per walker up to ww_max walkers), 0 off, 1 always,

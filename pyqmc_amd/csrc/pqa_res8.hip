@@ -165,6 +165,9 @@ int sweep_r8(pqa_handle* h, const MoveBuf& mb) {
   ChunkTab Tc = h->tab[0];
   Tc.cpad[0] = h->d_cres[0]; Tc.cpad[1] = h->d_cres[1];
   const dim3 grid((unsigned)((W + PQA_R8_NW - 1) / PQA_R8_NW)), block(PQA_R8_NT);
+  h->r8_tab.xaos = h->r8_xaos_next ? h->js.x : nullptr;  // (pqa_vmc_sweeps: an energy evaluation with ECP passes follows)
+  h->jsx_current = h->r8_xaos_next;
+  h->r8_xaos_next = false;
   hipEvent_t e1 = nullptr;
   if (h->profile) {  // every launch is bracketed (one launch per sweep)
     if (h->prof_used == h->prof_events.size()) {

@@ -641,6 +641,10 @@ static __global__ __launch_bounds__(PQA_R8_NT, 2) void k_sweep_r8(SysDev S, LwSt
       if (r < (q ? S.ndn : S.nup)) {
         double* xj = L.xt + (size_t)j * 3 * W + wg;
         xj[0] = cx[q]; xj[W] = cy[q]; xj[2 * W] = cz[q];
+        if (RT.xaos) {
+          double* xa = RT.xaos + ((size_t)wg * S.nelec + j) * 3;
+          xa[0] = cx[q]; xa[1] = cy[q]; xa[2] = cz[q];
+        }
       }
     }
     if (r == 0) {

@@ -24,6 +24,8 @@ struct R8Tab {
   int jstage;               // offset (doubles) of the Jastrow sums' staging area [8][12][33] in the region, behind the partials and orbital rows
   int stagger;              // the block that shares its CU with an earlier one (LDS base > 0) starts this many x 3 us late: the two blocks' phases
                             // (AO / contraction / sums) then interleave instead of running in lock step (PQA_R8_STAGGER)
+  double* xaos;             // (per launch) the walker-major coordinates [W][N][3] the ECP passes read, written with the planes at the end of the sweep
+                            // when an energy evaluation follows (instead of a transpose launch), or nullptr
   int abl;                  // timing builds (-DPQA_RES_CLK) only: phases left out, PQA_R8_ABL bit mask (1 AO, 2 contraction, 4 Jastrow, 8 row / tape prefetch, 16 cache-row stores)
 };
 #ifdef PQA_RES_CLK

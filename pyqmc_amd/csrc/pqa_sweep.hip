@@ -405,8 +405,11 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
       mb.unif = (const double*)h->b_unif.p;
     }
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
+    h->jsx_current = false;
+    h->r8_xaos_next = energy_mean != nullptr && h->necp > 0;  // (consumed by sweep_r8 only)
     if (tile) TRY(sweep_tile(h, mb));
     else TRY(sweep_electrons(h, mb, lw, lc));
+    h->r8_xaos_next = false;
     // small shards: the accepted-move count, the energy rows and their means in one launch at the end of the step (three launches of ~5 us
     // otherwise — 2 % of the 50-determinant molecule's step at 2 048 walkers)
     const bool finish1 = energy_mean && W <= 16384;
