@@ -501,6 +501,7 @@ static int create_impl(pqa_handle* h, const pqa_system_t* sys) {
   if (const char* rs = getenv("PQA_WW")) h->ww_mode = atoi(rs);
   if (const char* rs = getenv("PQA_ECP_DEFER")) h->ecp_defer = atoi(rs);
   if (const char* rs = getenv("PQA_EN_OVERLAP")) h->en_overlap = atoi(rs);
+  if (const char* rs = getenv("PQA_DRAWS_AHEAD")) h->draws_ahead_on = atoi(rs) != 0;
   if (const char* rs = getenv("PQA_RES_MIN")) h->res_min = atol(rs);
   if (const char* rs = getenv("PQA_RES_MAX")) h->res_max = atol(rs);
   if (const char* ws = getenv("PQA_ORB_WS")) h->orb_ws = atoi(ws);
@@ -897,7 +898,7 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
                     &h->b_mask, &h->b_ao, &h->b_flag, &h->b_newpos, &h->b_aux, &h->b_accept, &h->b_accrec, &h->b_acccnt, &h->b_accw,
                     &h->b_gauss, &h->b_unif, &h->b_kc, &h->b_en, &h->b_means, &h->b_sign, &h->b_log, &h->b_ju, &h->b_rot,
                     &h->b_eunif, &h->b_elocal, &h->b_ecnt, &h->b_eoff, &h->b_epts[0], &h->b_epts[1], &h->b_ewgt[0],
-                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_rc[0], &h->b_rc[1], &h->b_sel[0], &h->b_sel[1], &h->b_auxt, &h->b_kpart, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth, &h->b_tmuold};
+                    &h->b_ewgt[1], &h->b_epte[0], &h->b_epte[1], &h->b_emo[0], &h->b_emo[1], &h->b_ecp, &h->b_xt, &h->b_Tt[0], &h->b_Tt[1], &h->b_rc[0], &h->b_rc[1], &h->b_sel[0], &h->b_sel[1], &h->b_auxt, &h->b_kpart, &h->b_rbuf, &h->b_vbuf, &h->b_act, &h->b_alt_x, &h->b_alt_T[0], &h->b_alt_T[1], &h->b_alt_dsign[0], &h->b_alt_dsign[1], &h->b_alt_dlog[0], &h->b_alt_dlog[1], &h->b_alt_cache[0], &h->b_alt_cache[1], &h->b_alt_aval, &h->b_alt_bval, &h->b_alt_j3u, &h->b_rsidx, &h->b_tpos, &h->b_twgt, &h->b_tlive, &h->b_trat, &h->b_tmcnt, &h->b_tmoff, &h->b_tmpass, &h->b_tmamp, &h->b_tmacc, &h->b_tmidx, &h->b_tmapos, &h->b_tmu, &h->b_tmtile, &h->b_tmaoff, &h->b_tmptw, &h->b_tmmarks, &h->b_dmcw, &h->b_dmcold, &h->b_dmcr2, &h->b_dmcout, &h->b_j3u, &h->b_dwrap, &h->b_wrap, &h->b_epass, &h->b_eptw[0], &h->b_eptw[1], &h->b_econ[0], &h->b_econ[1], &h->b_eu0[0], &h->b_eu0[1], &h->b_tves, &h->b_pgdet, &h->b_pbcd0, &h->b_pbcmask, &h->b_pbcth, &h->b_tmuold, &h->b_gauss_b, &h->b_unif_b};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (auto& d : h->dm)
@@ -918,6 +919,8 @@ extern "C" void pqa_destroy(pqa_handle_t* h) {
   if (h->b_jpre.p) (void)hipFree(h->b_jpre.p);
   if (h->pin_tot) (void)hipHostFree(h->pin_tot);
   if (h->en_stream) { (void)hipStreamSynchronize(h->en_stream); (void)hipStreamDestroy(h->en_stream); }
+  if (h->draw_stream) { (void)hipStreamSynchronize(h->draw_stream); (void)hipStreamDestroy(h->draw_stream); }
+  for (hipEvent_t e : h->draw_ev) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->en_ev)
     if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);

@@ -200,6 +200,14 @@ struct pqa_handle {
   long* pin_tot = nullptr;  // pinned host words the scan kernels write the ECP point totals to (device-visible: hipHostMallocMapped)
   int ecp_defer = 1;
   int en_overlap = 1;  // kinetic / Coulomb pass of small wave-per-walker shards on a side stream beside the ECP passes (PQA_EN_OVERLAP=0: in line)
+  // the NEXT step's sweep draws (k_tile_draws) generated beside the energy pass of the current step: second tape set, its stream and events
+  DevBuf b_gauss_b, b_unif_b;
+  hipStream_t draw_stream = nullptr;
+  hipEvent_t draw_ev[2] = {nullptr, nullptr};
+  bool draw_ahead_valid = false, draws_on_device = false, draws_ahead_on = true;  // (PQA_DRAWS_AHEAD=0: A/B)  // draws_on_device: the last sweep took its draws from k_tile_draws
+  uint32_t draw_ahead_step = 0;
+  uint64_t draw_ahead_seed = 0;
+  long draw_ahead_W = 0;
   hipStream_t en_stream = nullptr;
   hipEvent_t en_ev[3] = {nullptr, nullptr, nullptr};
   bool ecp_hint_valid = false;

@@ -154,6 +154,28 @@ static int pipe_streams(pqa_handle* h) {
   return 0;
 }
 
+// The next step's draws on the side stream, behind the sweep that has just been enqueued (the tape set of step + 1 was last read by the sweep
+// of step - 1): they run beside this step's energy pass (k_tile_draws: 64 us of Philox + Box-Muller arithmetic at 65 536 walkers, next to
+// memory- and latency-bound kernels) instead of in front of the next sweep.
+int draws_ahead(pqa_handle* h, uint64_t seed, uint32_t next_step) {
+  const long W = h->W;
+  const size_t NW = (size_t)h->N * W;
+  if (!h->draw_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->draw_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->draw_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  DevBuf& bg = (next_step & 1) ? h->b_gauss_b : h->b_gauss;
+  DevBuf& bu = (next_step & 1) ? h->b_unif_b : h->b_unif;
+  TRY(ensure(h, bg, NW * 3 * sizeof(double)));
+  TRY(ensure(h, bu, NW * sizeof(double)));
+  HIPCHK(hipEventRecord(h->draw_ev[0], h->stream));
+  HIPCHK(hipStreamWaitEvent(h->draw_stream, h->draw_ev[0], 0));
+  hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->draw_stream, seed, next_step, h->N, W, (double*)bg.p, (double*)bu.p);
+  HIPCHK(hipEventRecord(h->draw_ev[1], h->draw_stream));
+  h->draw_ahead_valid = true; h->draw_ahead_step = next_step; h->draw_ahead_seed = seed; h->draw_ahead_W = W;
+  return 0;
+}
+
 static bool N_ok(const pqa_handle* h) { return h->N <= 64 && h->natom <= 64 && std::max(h->nup, h->ndn) <= 64; }
 static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCtx& lc) {
   const long W = h->W;
@@ -166,11 +188,19 @@ static int sweep_electrons_fused(pqa_handle* h, const MoveBuf& mb_in, const LwCt
     // small shards: the sweep's normals and uniforms drawn ahead by one launch from the same Philox streams (k_tile_draws) — in
     // k_step_lw the lead group's Box-Muller pairs are ~600 dependent instructions of every move's chain with one wave per SIMD
     const size_t NW = (size_t)h->N * W;
-    TRY(ensure(h, h->b_gauss, NW * 3 * sizeof(double)));
-    TRY(ensure(h, h->b_unif, NW * sizeof(double)));
-    hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W,
-                       (double*)h->b_gauss.p, (double*)h->b_unif.p);
-    mb.gauss = (const double*)h->b_gauss.p; mb.unif = (const double*)h->b_unif.p;
+    // two tape sets, step s in set s & 1: pqa_vmc_sweeps draws step s + 1 on a side stream while step s's energy pass runs (draws_ahead)
+    DevBuf& bg = (mb.step & 1) ? h->b_gauss_b : h->b_gauss;
+    DevBuf& bu = (mb.step & 1) ? h->b_unif_b : h->b_unif;
+    if (h->draw_ahead_valid && h->draw_ahead_step == mb.step && h->draw_ahead_seed == mb.seed && h->draw_ahead_W == W) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->draw_ev[1], 0));
+    } else {
+      TRY(ensure(h, bg, NW * 3 * sizeof(double)));
+      TRY(ensure(h, bu, NW * sizeof(double)));
+      hipLaunchKernelGGL((k_tile_draws<>), dim3((unsigned)((NW + 255) / 256)), dim3(256), 0, h->stream, mb.seed, mb.step, h->N, W, (double*)bg.p, (double*)bu.p);
+    }
+    h->draw_ahead_valid = false;
+    h->draws_on_device = true;
+    mb.gauss = (const double*)bg.p; mb.unif = (const double*)bu.p;
   }
   if (r8) return sweep_r8(h, mb);
   if (res) return sweep_res(h, mb);
@@ -391,6 +421,7 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
   const bool lw = !tile && h->lw_mode != 0 && h->has_slater && h->ndet == 1 && !h->has_j3 && (!h->cplx || std::max(h->nup, h->ndn) <= 32);
   LwCtx lc;
   TRY(lw_setup(h, lw, lc));
+  h->draw_ahead_valid = false;
   for (int step = 0; step < nsteps; ++step) {
     MoveBuf mb{};
     mb.newpos = (double*)h->b_newpos.p; mb.aux = (double*)h->b_aux.p; mb.accept = (uint8_t*)h->b_accept.p;
@@ -407,9 +438,11 @@ extern "C" int pqa_vmc_sweeps(pqa_handle_t* h, double tstep, int nsteps, const d
     if (accept_rec) mb.accept_rec = (uint8_t*)h->b_accrec.p;
     h->jsx_current = false;
     h->r8_xaos_next = energy_mean != nullptr && h->necp > 0;  // (consumed by sweep_r8 only)
+    h->draws_on_device = false;
     if (tile) TRY(sweep_tile(h, mb));
     else TRY(sweep_electrons(h, mb, lw, lc));
     h->r8_xaos_next = false;
+    if (h->draws_on_device && energy_mean && step + 1 < nsteps && W >= 16384 && h->draws_ahead_on) TRY(draws_ahead(h, seed, (uint32_t)(step + 1)));
     // small shards: the accepted-move count, the energy rows and their means in one launch at the end of the step (three launches of ~5 us
     // otherwise — 2 % of the 50-determinant molecule's step at 2 048 walkers)
     const bool finish1 = energy_mean && W <= 16384;
