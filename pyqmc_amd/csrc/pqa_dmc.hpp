@@ -249,8 +249,15 @@ __device__ __forceinline__ double tm_candidate_ratio(const SysDev& S, const Slat
     // ahead; the same terms in the same order as the plain loops this replaced, which read every table entry inside the pair loop)
     const double* xw = js.x + (size_t)w * S.nelec * 3;
     double un = 0.0, uo = 0.0, g_[3], lp_, ee_, ei_;
-    jas_eval_lane<0, true>(S, xw, 1L, 0L, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], 1, 0, 1, un, g_, lp_, ee_, ei_);
-    if (!have_uold) jas_eval_lane<0, true>(S, xw, 1L, 0L, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], 1, 0, 1, uo, g_, lp_, ee_, ei_);
+    // (k_tm_ratio is launched per spin channel: with the merged Pade records the pair's record is a scalar select although the electron and the
+    // walker differ between lanes — jas_eval_lane_m ELANE, as in k_ecp_point_lw)
+    if (S.jq_on) {
+      jas_eval_lane_m<0, true, true, true>(S, xw, 1L, 0L, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], 1, 0, 1, un, g_, lp_, ee_, ei_, -1, true);
+      if (!have_uold) jas_eval_lane_m<0, true, true, true>(S, xw, 1L, 0L, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], 1, 0, 1, uo, g_, lp_, ee_, ei_, -1, true);
+    } else {
+      jas_eval_lane<0, true>(S, xw, 1L, 0L, e, B.pts[3 * p], B.pts[3 * p + 1], B.pts[3 * p + 2], 1, 0, 1, un, g_, lp_, ee_, ei_);
+      if (!have_uold) jas_eval_lane<0, true>(S, xw, 1L, 0L, e, xw[3 * e], xw[3 * e + 1], xw[3 * e + 2], 1, 0, 1, uo, g_, lp_, ee_, ei_);
+    }
     ratio *= exp(un - (have_uold ? u_old : uo));
   }
   return ratio;
