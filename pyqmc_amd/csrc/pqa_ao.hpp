@@ -157,6 +157,7 @@ __device__ __forceinline__ void sph_high(int l, int m, double x, double y, doubl
 #define PQA_RT_DEG 9
 #define PQA_RT_REC (PQA_RT_DEG + 1)  // doubles per interval
 #define PQA_RT_MINP 3        // shells with fewer primitives keep their exponentials
+#define PQA_RT_MAXERR 2e-15  // largest fit error (relative to sum |c|) a table may have (build_radial_tables)
 __device__ __forceinline__ double radial_tab(const double* __restrict__ tab, int nint, double r2) {
   const double y = r2 + PQA_RT_X0;
   const int E = __builtin_amdgcn_frexp_exp(y);       // y = m 2^E, m in [0.5, 1)

@@ -181,6 +181,8 @@ static int build_radial_tables(pqa_handle* h, const pqa_system_t* sys, SysDev& S
       const int noct = std::max(1, (int)std::ceil(std::log2((46.0 / amin + PQA_RT_X0) / PQA_RT_X0)));
       if (noct > 40) continue;
       const int nint = noct * PQA_RT_NSUB;
+      const size_t tab0 = tab.size();
+      double err_sh = 0.0;
       rt[2 * sh] = (int)tab.size(); rt[2 * sh + 1] = nint;
       long double scale = 0.0L;
       for (int p = 0; p < np; ++p) scale += fabsl((long double)prim_coef[p0 + p]);
@@ -210,10 +212,15 @@ static int build_radial_tables(pqa_handle* h, const pqa_system_t* sys, SysDev& S
               double pv = m64[n - 1];
               for (int d = n - 2; d >= 0; --d) pv = std::fma(pv, u, m64[d]);
               const long double ex = F(xc + hw * (long double)u);
-              h->rt_err = std::max(h->rt_err, (double)(fabsl((long double)pv - ex) / scale));
+              err_sh = std::max(err_sh, (double)(fabsl((long double)pv - ex) / scale));
             }
           }
         }
+      // A table is kept only if it reproduces the primitive sum to rounding everywhere: the tight primitives of all-electron sets (exponent
+      // 11 720 in cc-pVDZ oxygen: e^{-a x} falls by e^-11 across the first interval) are beyond a degree-9 fit — 1e-5 of sum |c| — and such
+      // shells keep their exponentials.
+      if (err_sh > PQA_RT_MAXERR) { tab.resize(tab0); rt[2 * sh] = -1; rt[2 * sh + 1] = 0; }
+      else h->rt_err = std::max(h->rt_err, err_sh);
     }
   }
   double* td = nullptr; int* ti = nullptr;
