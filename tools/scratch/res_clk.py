@@ -32,8 +32,11 @@ if r8:  # k_sweep_r8: both Jastrow evaluations run ahead of the orbitals (stamp 
 print("walkers", W, "blocks sampled", len(c))
 prev = 0
 for k, name in seq[1:]:
-    ok = c[:, k] >= c[:, prev]
-    d = (c[ok, k] - c[ok, prev]) / 100.0
+    ref = c[:, prev]
+    if k == 5:  # stamp 13 (Sherman-Morrison) is written by accepted moves only: a rejected move goes from the Metropolis stamp to stamp 5
+        ref = np.where(c[:, 13] >= c[:, 4], c[:, 13], c[:, 4])
+    ok = c[:, k] >= ref
+    d = (c[ok, k] - ref[ok]) / 100.0
     if len(d): print("%-36s %6.2f us  (min %5.2f max %5.2f, n %d)" % (name, d.mean(), d.min(), d.max(), ok.sum()))
     prev = k
 print("%-36s %6.2f us" % ("entry -> committed", ((c[:, 5] - c[:, 0]) / 100.0).mean()))
